@@ -1,0 +1,97 @@
+"""Pins oracle/learner.py against golden vectors produced by the reference itself (G1-G5)."""
+import os
+
+import numpy as np
+
+from oracle import learner as L
+
+ACTOR_KEYS = ["actor_layers.0.weight", "actor_layers.0.bias", "actor_layers.1.weight", "actor_layers.1.bias",
+              "means.weight", "means.bias"]
+CRITIC_KEYS = ["critic_layers.0.weight", "critic_layers.0.bias", "critic_layers.1.weight", "critic_layers.1.bias",
+               "network_out.weight", "network_out.bias"]
+
+
+def test_g1_finish_path(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_finish_path.npz"))
+    for c in range(int(g["n_cases"])):
+        ret = L.discounted_returns(g[f"c{c}_rewards"], g[f"c{c}_lens"], g[f"c{c}_last_vals"], float(g[f"c{c}_gamma"]))
+        np.testing.assert_allclose(ret, g[f"c{c}_returns"], rtol=1e-12, atol=1e-12)
+        assert list(np.cumsum(np.r_[0, g[f"c{c}_lens"]])) == list(g[f"c{c}_traj_idx"])   # bit-exact step indices
+
+
+def test_g1_grid_layout_equals_list_layout():
+    rng = np.random.RandomState(0)
+    T, N = 17, 5
+    rew = rng.randn(T, N); end = (rng.rand(T, N) < 0.2).astype(np.int32); boot = rng.randn(T, N) * (rng.rand(T, N) < 0.5)
+    last = rng.randn(N)
+    grid = L.returns_scan_grid_boot(rew, end, boot, last, 0.99)
+    for n in range(N):
+        lens, lv, t0 = [], [], 0
+        for t in range(T):
+            if end[t, n]:
+                lens.append(t + 1 - t0); lv.append(boot[t, n]); t0 = t + 1
+        if t0 < T:
+            lens.append(T - t0); lv.append(last[n])
+        ref = L.discounted_returns(rew[:, n], lens, lv, 0.99)
+        np.testing.assert_allclose(grid[:, n], ref, rtol=1e-13)
+
+
+def test_g2_adv_norm(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g2_adv_norm.npz"))
+    for c in range(int(g["n_cases"])):
+        adv = L.normalize_advantages(g[f"c{c}_returns"], g[f"c{c}_values"], 1e-5)
+        np.testing.assert_allclose(adv, g[f"c{c}_adv"], rtol=1e-5, atol=1e-6)
+
+
+def test_g3_forward(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g3_policy_forward.npz"))
+    assert list(g["actor_keys"]) == ACTOR_KEYS and list(g["critic_keys"]) == CRITIC_KEYS
+    A = [g["actor." + k] for k in ACTOR_KEYS]
+    C = [g["critic." + k] for k in CRITIC_KEYS]
+    mu = L.actor_mean(A, g["obs"], g["obs_mean"], g["obs_std"])
+    np.testing.assert_allclose(mu, g["mean"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(L.critic_value(C, g["obs"]), g["value_train"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(L.critic_value(C, g["obs"], g["obs_mean"], g["obs_std"], training=False),
+                               g["value_eval"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(L.gaussian_logp(mu, float(g["fixed_std"]), g["act"]), g["logp"], rtol=1e-5)
+    assert abs(L.gaussian_entropy(float(g["fixed_std"])) - float(g["entropy"])) < 1e-6
+    np.testing.assert_allclose(g["init_row_norm_l0"], 1.0, atol=1e-5)       # normc: unit rows (base.py:7-13)
+    np.testing.assert_allclose(g["init_row_norm_means"], 0.01, atol=1e-6)   # mean head * 0.01 (actor.py:178)
+    assert float(g["init_bias_abs_max"]) == 0.0
+
+
+def test_g5_mirror(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g5_mirror.npz"))
+    Mo = L.mirror_matrix(list(g["mirrored_obs"])); Ma = L.mirror_matrix(list(g["mirrored_acts"]))
+    np.testing.assert_array_equal(Mo, g["obs_mirror_matrix"]); np.testing.assert_array_equal(Ma, g["act_mirror_matrix"])
+    np.testing.assert_allclose(L.mirror_clock_observation(g["obs"].astype(np.float64), Mo, [46, 47]), g["mirror_obs"],
+                               atol=1e-6)
+    np.testing.assert_allclose(g["act"] @ Ma, g["mirror_act"], atol=1e-7)
+
+
+def test_g4_update_policy(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g4_update_policy.npz"))
+    g5 = np.load(os.path.join(golden_dir, "g5_mirror.npz"))
+    for c in range(int(g["n_cases"])):
+        p = f"c{c}_"
+        actor = [g[p + "actor0." + k] for k in ACTOR_KEYS]
+        old = [g[p + "old." + k] for k in ACTOR_KEYS]
+        critic = [g[p + "critic0." + k] for k in CRITIC_KEYS]
+        mirror = bool(g[p + "mirror"])
+        oa, oc = L.Adam(actor), L.Adam(critic)
+        scal_all = []
+        for s in range(int(g[p + "nsteps"])):
+            scal, actor, critic = L.ppo_update(
+                actor, old, critic, oa, oc, g[p + f"s{s}_obs"], g[p + f"s{s}_act"], g[p + f"s{s}_ret"], g[p + f"s{s}_adv"],
+                g[p + "obs_mean"], g[p + "obs_std"], np.exp(-1.5), entropy_coeff=float(g[p + "entropy_coeff"]),
+                M_obs=g5["obs_mirror_matrix"] if mirror else None, M_act=g5["act_mirror_matrix"] if mirror else None)
+            scal_all.append(scal)
+        np.testing.assert_allclose(np.array(scal_all), g[p + "scalars"], rtol=2e-5, atol=1e-7)
+        for k, w in zip(ACTOR_KEYS, actor):
+            ref = g[p + "actor1." + k]
+            # Adam's first steps move every weight by ~lr*sign(g); allow a vanishing fraction of sign flips at g~0
+            bad = np.abs(w - ref) > 2e-6
+            assert bad.mean() < 1e-3, (c, k, bad.mean())
+        for k, w in zip(CRITIC_KEYS, critic):
+            bad = np.abs(w - g[p + "critic1." + k]) > 2e-6
+            assert bad.mean() < 1e-3, (c, k, bad.mean())
