@@ -1,0 +1,522 @@
+// Learner half of the Cassie-v0 PPO hot path as HIP kernels for gfx950 (MI355X).
+//
+//   returns scan        <- PPOBuffer.finish_path             rl/algos/ppo.py:73-89
+//   advantage normalise <- PPO.train                         rl/algos/ppo.py:395-396
+//   MLP forward/backward (fp32 MFMA 32x32x2, LDS-tiled)      rl/policies/actor.py:142-215, critic.py:37-77
+//   PPO clipped-ratio / value / mirror losses                rl/algos/ppo.py:276-345
+//   global-norm clip + Adam                                  rl/algos/ppo.py:322-336, :355-356
+//
+// Wave = 64 lanes.  GEMMs use v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain) so that the parity mode
+// meets the 1e-5 bar; everything elementwise is fused into GEMM epilogues or the single loss kernel.
+#include "apx_common.h"
+#include <cmath>
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------ reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+template <int NV>
+__device__ __forceinline__ void block_atomic_add(double (&v)[NV], double* out) {
+    __shared__ double sm[NV][16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double s = wave_sum(v[i]);
+        if (lane == 0) sm[i][w] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0;
+        for (int k = 0; k < nw; ++k) s += sm[threadIdx.x][k];
+        atomicAdd(out + threadIdx.x, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ returns scan
+// One lane per env column; loads of rew/end/boot at a fixed t are contiguous across lanes (coalesced).
+// Algorithmic HBM bytes per (t, env): 4 (rew) + 1 (end) + 4 (boot) + 4 (ret) = 13 B.
+__global__ void returns_scan_kernel(const float* __restrict__ rew, const uint8_t* __restrict__ end,
+                                    const float* __restrict__ boot, const float* __restrict__ last_val, double gamma,
+                                    int T, int N, float* __restrict__ ret) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float g32 = (float)gamma;
+    double R = (double)last_val[n];
+    bool fresh = true;  // R holds an fp32 bootstrap: the reference's first gamma*R is an fp32 product (ppo.py:80-82)
+    for (int t = T - 1; t >= 0; --t) {
+        const size_t i = (size_t)t * N + n;
+        if (end[i]) { R = (double)boot[i]; fresh = true; }
+        const double prod = fresh ? (double)(g32 * (float)R) : gamma * R;
+        R = prod + (double)rew[i];
+        fresh = false;
+        ret[i] = (float)R;
+    }
+}
+
+extern "C" int apx_returns_scan(const float* rew, const uint8_t* end, const float* boot, const float* last_val,
+                                double gamma, int T, int N, float* ret, void* stream) {
+    APX_REQUIRE(T >= 0 && N >= 0, "T,N");
+    if (T == 0 || N == 0) return APX_OK;
+    APX_REQUIRE(rew && end && boot && last_val && ret, "null pointer");
+    hipLaunchKernelGGL(returns_scan_kernel, dim3(apx_cdiv(N, 64)), dim3(64), 0, (hipStream_t)stream, rew, end, boot,
+                       last_val, gamma, T, N, ret);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ advantages
+__global__ void adv_moments_kernel(const float* __restrict__ ret, const float* __restrict__ val, int64_t n,
+                                   double* __restrict__ mom) {
+    double acc[2] = {0, 0};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double a = (double)(ret[i] - val[i]);
+        acc[0] += a; acc[1] += a * a;
+    }
+    block_atomic_add<2>(acc, mom);
+    if (blockIdx.x == 0 && threadIdx.x == 0) mom[2] = (double)n;
+}
+
+__global__ void adv_apply_kernel(const float* __restrict__ ret, const float* __restrict__ val, int64_t n, float mean,
+                                 float denom, float* __restrict__ adv) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        adv[i] = ((ret[i] - val[i]) - mean) / denom;
+}
+
+extern "C" int apx_adv_moments(const float* ret, const float* val, int64_t n, double* moments, void* stream) {
+    APX_REQUIRE(ret && val && moments && n > 0, "args");
+    APX_HIP(hipMemsetAsync(moments, 0, 3 * sizeof(double), (hipStream_t)stream));
+    const int grid = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(adv_moments_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ret, val, n, moments);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+}
+
+extern "C" int apx_adv_apply(const float* ret, const float* val, int64_t n, double mean, double std_unbiased,
+                             double eps, float* adv, void* stream) {
+    APX_REQUIRE(ret && val && adv && n > 0, "args");
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(adv_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ret, val, n, (float)mean,
+                       (float)std_unbiased + (float)eps, adv);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ input prep
+// xn[b, c] = normalise( mirror( x[idx[b], :] ) )[c]; one thread per element, rows contiguous.
+__global__ void prep_obs_kernel(const float* __restrict__ x, int64_t B, int D, const int64_t* __restrict__ idx,
+                                const int32_t* __restrict__ sign_perm, uint64_t clock_mask,
+                                const float* __restrict__ mean, const float* __restrict__ stdv,
+                                float* __restrict__ out) {
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= B * D) return;
+    const int64_t b = e / D;
+    const int c = (int)(e - b * D);
+    const int64_t row = idx ? idx[b] : b;
+    float v;
+    if (sign_perm) {
+        const int32_t s = sign_perm[c];
+        v = s >= 0 ? x[row * D + s] : -x[row * D + (-s - 1)];
+        if (c < 64 && ((clock_mask >> c) & 1ull)) v = sinf(asinf(v) + 3.14159265358979323846f);  // wrappers.py:65-66
+    } else {
+        v = x[row * D + c];
+    }
+    if (mean) v = (v - mean[c]) / stdv[c];
+    out[e] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ fp32 MFMA GEMM
+// C[M,N] = epi( sum_k A(m,k) B(k,n) ),  A(m,k) = A[m*a_rs + k*a_cs],  B(k,n) = B[k*b_rs + n*b_cs].
+// Block tile 64x64x16, 4 waves, each wave one 32x32 v_mfma_f32_32x32x2_f32 accumulator.
+// LDS tiles are k-major ([k][m], [k][n]) so the MFMA operand fetch (lane l: k = l>>5, m|n = l&31) is a
+// conflict-free ds_read_b32 (two 32-lane halves, 32 consecutive dwords each).
+enum { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_MASK = 3, EPI_ATOMIC = 4 };
+
+struct GemmArgs {
+    const float* A; long a_rs, a_cs;
+    const float* B; long b_rs, b_cs;
+    float* C; long ldc;
+    const float* aux; long ld_aux;   // bias[N] or mask[M, ld_aux]
+    int M, N, K, kchunk;
+};
+
+#define GBM 64
+#define GBN 64
+#define GBK 16
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    __shared__ float As[GBK][GBM + 1];
+    __shared__ float Bs[GBK][GBN + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * GBN;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    floatx16 acc = {0};
+    const bool a_kmajor = (g.a_cs == 1);   // k contiguous in memory
+    const bool b_kmajor = (g.b_rs == 1);
+    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m, k;
+            if (a_kmajor) { k = tid & 15; m = (tid >> 4) + 16 * i; }
+            else          { m = tid & 63; k = (tid >> 6) + 4 * i; }
+            const int gm = m0 + m, gk = k0 + k;
+            As[k][m] = (gm < g.M && gk < kend) ? g.A[gm * g.a_rs + gk * g.a_cs] : 0.f;
+            int n, kk;
+            if (b_kmajor) { kk = tid & 15; n = (tid >> 4) + 16 * i; }
+            else          { n = tid & 63; kk = (tid >> 6) + 4 * i; }
+            const int gn = n0 + n, gkk = k0 + kk;
+            Bs[kk][n] = (gn < g.N && gkk < kend) ? g.B[gkk * g.b_rs + gn * g.b_cs] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GBK; kk += 2) {
+            const float a = As[kk + (lane >> 5)][wm + (lane & 31)];
+            const float b = Bs[kk + (lane >> 5)][wn + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = n0 + wn + (lane & 31);
+    if (col >= g.N) return;
+    float bias = 0.f;
+    if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) bias = g.aux[col];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= g.M) continue;
+        float v = acc[r];
+        float* c = g.C + (long)row * g.ldc + col;
+        if (EPI == EPI_BIAS) v += bias;
+        if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
+        if (EPI == EPI_MASK) v = g.aux[(long)row * g.ld_aux + col] > 0.f ? v : 0.f;
+        if (EPI == EPI_ATOMIC) atomicAdd(c, v);
+        else *c = v;
+    }
+}
+
+static int launch_gemm(int epi, const GemmArgs& g0, int ksplit, hipStream_t s) {
+    GemmArgs g = g0;
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return APX_OK;
+    if (epi != EPI_ATOMIC) ksplit = 1;
+    int kchunk = (g.K + ksplit - 1) / ksplit;
+    kchunk = ((kchunk + GBK - 1) / GBK) * GBK;
+    g.kchunk = kchunk;
+    const int nz = (g.K + kchunk - 1) / kchunk;
+    dim3 grid(apx_cdiv(g.M, GBM), apx_cdiv(g.N, GBN), nz), block(256);
+    switch (epi) {
+        case EPI_STORE: hipLaunchKernelGGL(gemm_f32_kernel<EPI_STORE>, grid, block, 0, s, g); break;
+        case EPI_BIAS: hipLaunchKernelGGL(gemm_f32_kernel<EPI_BIAS>, grid, block, 0, s, g); break;
+        case EPI_BIAS_RELU: hipLaunchKernelGGL(gemm_f32_kernel<EPI_BIAS_RELU>, grid, block, 0, s, g); break;
+        case EPI_MASK: hipLaunchKernelGGL(gemm_f32_kernel<EPI_MASK>, grid, block, 0, s, g); break;
+        case EPI_ATOMIC: hipLaunchKernelGGL(gemm_f32_kernel<EPI_ATOMIC>, grid, block, 0, s, g); break;
+        default: return APX_E_ARG;
+    }
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+}
+
+// Y[B,Dout] = act(X[B,Din] W^T + b), W torch layout [Dout, Din]
+static int linear_fwd(const float* X, const float* W, const float* b, float* Y, long B, int Din, int Dout, bool relu,
+                      hipStream_t s) {
+    GemmArgs g{X, Din, 1, W, 1, Din, Y, Dout, b, 0, (int)B, Dout, Din, 0};
+    return launch_gemm(relu ? EPI_BIAS_RELU : EPI_BIAS, g, 1, s);
+}
+// dX[B,Din] = (dY[B,Dout] W) * (mask > 0)   (mask = saved post-ReLU activation of the layer below, or NULL)
+static int linear_bwd_input(const float* dY, const float* W, const float* mask, float* dX, long B, int Din, int Dout,
+                            hipStream_t s) {
+    GemmArgs g{dY, Dout, 1, W, Din, 1, dX, Din, mask, Din, (int)B, Din, Dout, 0};
+    return launch_gemm(mask ? EPI_MASK : EPI_STORE, g, 1, s);
+}
+// dW[Dout,Din] += dY^T X  (split-K over the batch, fp32 atomics)
+static int linear_bwd_weight(const float* dY, const float* X, float* dW, long B, int Din, int Dout, hipStream_t s) {
+    GemmArgs g{dY, 1, Dout, X, Din, 1, dW, Din, nullptr, 0, Dout, Din, (int)B, 0};
+    int ksplit = (int)(B / 256);
+    if (ksplit < 1) ksplit = 1;
+    if (ksplit > 64) ksplit = 64;
+    return launch_gemm(EPI_ATOMIC, g, ksplit, s);
+}
+
+// db[n] += sum_m dY[m, n]
+__global__ void colsum_kernel(const float* __restrict__ dY, long B, int N, float* __restrict__ db) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const long rows_per = (B + gridDim.y - 1) / gridDim.y;
+    const long r0 = blockIdx.y * rows_per, r1 = min(B, r0 + rows_per);
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += dY[r * N + n];
+    atomicAdd(db + n, s);
+}
+static int colsum(const float* dY, long B, int N, float* db, hipStream_t s) {
+    int chunks = (int)(B / 64);
+    if (chunks < 1) chunks = 1;
+    if (chunks > 256) chunks = 256;
+    hipLaunchKernelGGL(colsum_kernel, dim3(apx_cdiv(N, 64), chunks), dim3(64), 0, s, dY, B, N, db);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+}
+
+extern "C" size_t apx_mlp_param_count(int D, int H, int O) {
+    return (size_t)H * D + H + (size_t)H * H + H + (size_t)O * H + O;
+}
+
+struct MlpView {
+    const float *W0, *b0, *W1, *b1, *W2, *b2;
+    MlpView(const float* p, int D, int H, int O) {
+        W0 = p; b0 = W0 + (size_t)H * D; W1 = b0 + H; b1 = W1 + (size_t)H * H; W2 = b1 + H; b2 = W2 + (size_t)O * H;
+    }
+};
+struct MlpGrad {
+    float *W0, *b0, *W1, *b1, *W2, *b2;
+    MlpGrad(float* p, int D, int H, int O) {
+        W0 = p; b0 = W0 + (size_t)H * D; W1 = b0 + H; b1 = W1 + (size_t)H * H; W2 = b1 + H; b2 = W2 + (size_t)O * H;
+    }
+};
+
+#define APX_TRY(x) do { int rc__ = (x); if (rc__ != APX_OK) return rc__; } while (0)
+
+static int mlp_forward_impl(const float* params, int D, int H, int O, const float* xn, long B, float* a1, float* a2,
+                            float* y, hipStream_t s) {
+    MlpView p(params, D, H, O);
+    APX_TRY(linear_fwd(xn, p.W0, p.b0, a1, B, D, H, true, s));
+    APX_TRY(linear_fwd(a1, p.W1, p.b1, a2, B, H, H, true, s));
+    APX_TRY(linear_fwd(a2, p.W2, p.b2, y, B, H, O, false, s));
+    return APX_OK;
+}
+
+// grads += d(loss)/d(params) given dy = d(loss)/d(y); dh1/dh2 are [B,H] scratch
+static int mlp_backward_impl(const float* params, float* grads, int D, int H, int O, const float* xn, const float* a1,
+                             const float* a2, const float* dy, long B, float* dh2, float* dh1, hipStream_t s) {
+    MlpView p(params, D, H, O);
+    MlpGrad g(grads, D, H, O);
+    APX_TRY(linear_bwd_weight(dy, a2, g.W2, B, H, O, s));
+    APX_TRY(colsum(dy, B, O, g.b2, s));
+    APX_TRY(linear_bwd_input(dy, p.W2, a2, dh2, B, H, O, s));
+    APX_TRY(linear_bwd_weight(dh2, a1, g.W1, B, H, H, s));
+    APX_TRY(colsum(dh2, B, H, g.b1, s));
+    APX_TRY(linear_bwd_input(dh2, p.W1, a1, dh1, B, H, H, s));
+    APX_TRY(linear_bwd_weight(dh1, xn, g.W0, B, D, H, s));
+    APX_TRY(colsum(dh1, B, H, g.b0, s));
+    return APX_OK;
+}
+
+static int prep_obs(const float* x, long B, int D, const int64_t* idx, const int32_t* sp, uint64_t cm, const float* mean,
+                    const float* stdv, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(prep_obs_kernel, dim3(apx_cdiv(B * D, 256)), dim3(256), 0, s, x, (int64_t)B, D, idx, sp, cm, mean,
+                       stdv, out);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+}
+
+extern "C" int apx_mlp_forward(const float* params, int D, int H, int O, const float* x, int64_t B, const int64_t* idx,
+                               const int32_t* sign_perm, uint64_t clock_mask, const float* obs_mean,
+                               const float* obs_std, float* xn_out, float* act1, float* act2, float* y, int precision,
+                               void* stream) {
+    APX_REQUIRE(params && x && y && xn_out && act1 && act2, "null pointer");
+    APX_REQUIRE(D > 0 && H > 0 && O > 0 && B >= 0, "dims");
+    APX_REQUIRE(precision == 0, "only precision 0 (fp32 MFMA) is built in this round");
+    APX_REQUIRE((obs_mean == nullptr) == (obs_std == nullptr), "obs_mean/obs_std");
+    if (B == 0) return APX_OK;
+    hipStream_t s = (hipStream_t)stream;
+    APX_TRY(prep_obs(x, B, D, idx, sign_perm, clock_mask, obs_mean, obs_std, xn_out, s));
+    return mlp_forward_impl(params, D, H, O, xn_out, B, act1, act2, y, s);
+}
+
+// ------------------------------------------------------------------------------------------------ PPO losses
+// One thread per sample.  Produces d(loss)/d(mu) for the policy branch and the mirrored branch, d(loss)/d(v), and
+// the six scalars of update_policy (sums; divided on the host side of the ABI by nothing: already means).
+struct LossArgs {
+    const float *mu, *mum, *v;            // [mb,A], [mb,A] or NULL, [mb]
+    const float *act, *ret, *adv, *old_mu; const int64_t* idx;
+    const int32_t* act_sp;                // mirror_action as signed permutation, or NULL
+    float *dmu, *dmum, *dv;
+    double* acc;                          // [8]: actor_loss, ratio, kl, mirror, critic_loss
+    long mb; int A;
+    float sd, clip, mirror_coeff;
+};
+
+__global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs L) {
+    const long b = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    double acc[5] = {0, 0, 0, 0, 0};
+    if (b < L.mb) {
+        const long row = L.idx ? L.idx[b] : b;
+        const int A = L.A;
+        const float inv_var = 1.f / (L.sd * L.sd);
+        const float inv_mb = 1.f / (float)L.mb;
+        float dlp = 0.f, klsum = 0.f;
+        for (int j = 0; j < A; ++j) {
+            const float a = L.act[row * A + j], m = L.mu[b * A + j], mo = L.old_mu[row * A + j];
+            // log N(a; m, sd) - log N(a; mo, sd): the -log(sd) - log(sqrt(2 pi)) terms cancel exactly
+            dlp += (-(a - m) * (a - m) + (a - mo) * (a - mo)) * (0.5f * inv_var);
+            const float z = (m - mo) / L.sd;
+            klsum += 0.5f * z * z;
+        }
+        const float ratio = expf(dlp);
+        const float adv = L.adv[row];
+        const float cpi = ratio * adv;
+        const float lo = 1.f - L.clip, hi = 1.f + L.clip;
+        const float rc = fminf(fmaxf(ratio, lo), hi);
+        const float clp = rc * adv;
+        acc[0] = -(double)fminf(cpi, clp) * inv_mb;
+        acc[1] = (double)ratio * inv_mb;
+        acc[2] = (double)klsum * inv_mb / A;
+        // torch.min backward: ties split 1/2 + 1/2 (both branches carry the same derivative inside the clip range)
+        const float w_cpi = cpi < clp ? 1.f : (cpi == clp ? 0.5f : 0.f);
+        const float inside = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+        const float dsur = w_cpi * adv + (1.f - w_cpi) * adv * inside;
+        const float dlogp = -(dsur * ratio) * inv_mb;
+        float msum = 0.f;
+        const float dscale = 2.f * L.mirror_coeff * inv_mb / A;
+        for (int j = 0; j < A; ++j) {
+            const float a = L.act[row * A + j], m = L.mu[b * A + j];
+            float d = dlogp * (a - m) * inv_var;
+            if (L.mum) {
+                const int32_t sp = L.act_sp[j];
+                const int src = sp >= 0 ? sp : -sp - 1;
+                const float sg = sp >= 0 ? 1.f : -1.f;
+                const float diff = m - sg * L.mum[b * A + src];
+                msum += diff * diff;
+                const float dd = dscale * diff;
+                d += dd;
+                L.dmum[b * A + src] = -sg * dd;
+            }
+            L.dmu[b * A + j] = d;
+        }
+        acc[3] = (double)L.mirror_coeff * msum * inv_mb / A;
+        const float v = L.v[b], r = L.ret[row];
+        acc[4] = 0.5 * (double)(r - v) * (double)(r - v) * inv_mb;
+        L.dv[b] = -(r - v) * inv_mb;
+    }
+    block_atomic_add<5>(acc, L.acc);
+}
+
+__global__ void finish_scalars_kernel(const double* acc, float sd, double* out) {
+    out[0] = acc[0];
+    out[1] = 0.5 + 0.5 * log(2.0 * 3.14159265358979323846) + log((double)sd);
+    out[2] = acc[4];
+    out[3] = acc[1];
+    out[4] = acc[2];
+    out[5] = acc[3];
+}
+
+// ------------------------------------------------------------------------------------------------ clip + Adam
+__global__ void sumsq_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ out) {
+    double acc[1] = {0};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        acc[0] += (double)g[i] * (double)g[i];
+    block_atomic_add<1>(acc, out);
+}
+
+__global__ void clip_adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                 const float* __restrict__ g, int64_t n, const double* __restrict__ sumsq,
+                                 float grad_scale, float grad_clip, float step_size, float inv_bc2_sqrt, float eps) {
+    // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), applied when < 1
+    const float total = (float)sqrt(*sumsq) * fabsf(grad_scale);
+    float coef = grad_clip / (total + 1e-6f);
+    coef = coef < 1.f ? coef : 1.f;
+    const float sc = coef * grad_scale;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * sc;
+        const float mi = 0.9f * m[i] + 0.1f * gi;
+        const float vi = 0.999f * v[i] + 0.001f * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+        p[i] -= step_size * (mi / denom);
+    }
+}
+
+extern "C" int apx_clip_adam(float* param, float* m, float* v, float* grad, int64_t n, float grad_scale,
+                             float grad_clip, float lr, float adam_eps, int adam_t, double* sumsq_scratch,
+                             void* stream) {
+    APX_REQUIRE(param && m && v && grad && sumsq_scratch && n > 0 && adam_t >= 1, "args");
+    hipStream_t s = (hipStream_t)stream;
+    APX_HIP(hipMemsetAsync(sumsq_scratch, 0, sizeof(double), s));
+    const int grid = (int)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, grad, n, sumsq_scratch);
+    APX_LAUNCH_CHECK();
+    const double bc1 = 1.0 - pow(0.9, adam_t), bc2 = 1.0 - pow(0.999, adam_t);
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(grid), dim3(256), 0, s, param, m, v, grad, n, sumsq_scratch, grad_scale,
+                       grad_clip, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), adam_eps);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ PPO minibatch
+static size_t align_up(size_t x) { return (x + 63) & ~(size_t)63; }
+
+struct PpoWs {
+    float *xn, *xm, *xr, *a1, *a2, *m1, *m2, *c1, *c2, *mu, *mum, *v, *dmu, *dmum, *dv, *dh2, *dh1;
+    double* acc;
+    size_t bytes;
+    PpoWs(void* base, long mb, int D, int H, int A) {
+        char* p = (char*)base;
+        size_t off = 0;
+        auto take = [&](size_t nfloat) { float* r = (float*)(p + off); off += align_up(nfloat * sizeof(float)); return r; };
+        xn = take(mb * D); xm = take(mb * D); xr = take(mb * D);
+        a1 = take(mb * H); a2 = take(mb * H); m1 = take(mb * H); m2 = take(mb * H); c1 = take(mb * H); c2 = take(mb * H);
+        mu = take(mb * A); mum = take(mb * A); v = take(mb);
+        dmu = take(mb * A); dmum = take(mb * A); dv = take(mb);
+        dh2 = take(mb * H); dh1 = take(mb * H);
+        acc = (double*)(p + off); off += align_up(16 * sizeof(double));
+        bytes = off;
+    }
+};
+
+extern "C" size_t apx_ppo_workspace_bytes(int64_t mb, int D, int H, int A) {
+    PpoWs w(nullptr, mb, D, H, A);
+    return w.bytes;
+}
+
+extern "C" int apx_ppo_minibatch(const apx_ppo_args* a, void* stream) {
+    APX_REQUIRE(a, "args");
+    APX_REQUIRE(a->actor && a->actor_grad && a->critic && a->critic_grad, "network pointers");
+    APX_REQUIRE(a->grad_only || (a->actor_m && a->actor_v && a->critic_m && a->critic_v), "Adam state");
+    APX_REQUIRE(a->obs && a->act && a->ret && a->adv && a->old_mu && a->obs_mean && a->obs_std, "batch pointers");
+    APX_REQUIRE(a->mb > 0 && a->D > 0 && a->H > 0 && a->A > 0 && a->A <= 64, "dims");
+    APX_REQUIRE(a->precision == 0, "only precision 0 (fp32 MFMA) is built in this round");
+    APX_REQUIRE(a->workspace && a->workspace_bytes >= apx_ppo_workspace_bytes(a->mb, a->D, a->H, a->A), "workspace");
+    APX_REQUIRE(a->scalars_out, "scalars_out");
+    APX_REQUIRE((a->obs_sign_perm == nullptr) == (a->act_sign_perm == nullptr), "mirror tables");
+    hipStream_t s = (hipStream_t)stream;
+    const long mb = a->mb;
+    const int D = a->D, H = a->H, A = a->A;
+    const bool mirror = a->obs_sign_perm != nullptr;
+    PpoWs w(a->workspace, mb, D, H, A);
+    const size_t na = apx_mlp_param_count(D, H, A), nc = apx_mlp_param_count(D, H, 1);
+    APX_HIP(hipMemsetAsync(w.acc, 0, 16 * sizeof(double), s));
+    APX_HIP(hipMemsetAsync(a->actor_grad, 0, na * sizeof(float), s));
+    APX_HIP(hipMemsetAsync(a->critic_grad, 0, nc * sizeof(float), s));
+    // forwards
+    APX_TRY(prep_obs(a->obs, mb, D, a->idx, nullptr, 0, a->obs_mean, a->obs_std, w.xn, s));
+    APX_TRY(mlp_forward_impl(a->actor, D, H, A, w.xn, mb, w.a1, w.a2, w.mu, s));
+    if (mirror) {
+        APX_TRY(prep_obs(a->obs, mb, D, a->idx, a->obs_sign_perm, a->clock_mask, a->obs_mean, a->obs_std, w.xm, s));
+        APX_TRY(mlp_forward_impl(a->actor, D, H, A, w.xm, mb, w.m1, w.m2, w.mum, s));
+    }
+    APX_TRY(prep_obs(a->obs, mb, D, a->idx, nullptr, 0, nullptr, nullptr, w.xr, s));   // critic: raw obs (critic.py:66)
+    APX_TRY(mlp_forward_impl(a->critic, D, H, 1, w.xr, mb, w.c1, w.c2, w.v, s));
+    // losses
+    LossArgs L{w.mu, mirror ? w.mum : nullptr, w.v, a->act, a->ret, a->adv, a->old_mu, a->idx, a->act_sign_perm,
+               w.dmu, w.dmum, w.dv, w.acc, mb, A, a->fixed_std, a->clip, a->mirror_coeff};
+    hipLaunchKernelGGL(ppo_loss_kernel, dim3(apx_cdiv(mb, 256)), dim3(256), 0, s, L);
+    APX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(finish_scalars_kernel, dim3(1), dim3(1), 0, s, w.acc, a->fixed_std, a->scalars_out);
+    APX_LAUNCH_CHECK();
+    // backwards
+    APX_TRY(mlp_backward_impl(a->actor, a->actor_grad, D, H, A, w.xn, w.a1, w.a2, w.dmu, mb, w.dh2, w.dh1, s));
+    if (mirror)
+        APX_TRY(mlp_backward_impl(a->actor, a->actor_grad, D, H, A, w.xm, w.m1, w.m2, w.dmum, mb, w.dh2, w.dh1, s));
+    APX_TRY(mlp_backward_impl(a->critic, a->critic_grad, D, H, 1, w.xr, w.c1, w.c2, w.dv, mb, w.dh2, w.dh1, s));
+    if (a->grad_only) return APX_OK;
+    APX_TRY(apx_clip_adam(a->actor, a->actor_m, a->actor_v, a->actor_grad, (int64_t)na, 1.f, a->grad_clip, a->lr,
+                          a->adam_eps, a->adam_t, w.acc + 8, s));
+    APX_TRY(apx_clip_adam(a->critic, a->critic_m, a->critic_v, a->critic_grad, (int64_t)nc, 1.f, a->grad_clip, a->lr,
+                          a->adam_eps, a->adam_t, w.acc + 9, s));
+    return APX_OK;
+}

@@ -1,0 +1,176 @@
+"""Tensor-level wrappers over the C ABI (include/apx.h).  PyTorch-ROCm is plumbing here: device memory, streams,
+torch.distributed.  Every function launches HIP kernels from libapx.so on the current torch stream."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.ApxError("apex_amd needs device tensors (no CPU path exists)")
+
+
+def signed_perm_from_mirror(mirrored):
+    """Turn apex's mirror index list (cassie/cassie.py:69,244; 0.1 = '+index 0') into the column-gather table the
+    kernels use: (x @ M)[c] = sign_i * x[i] for the i with |mirrored[i]| == c (rl/envs/wrappers.py:70-77).
+    Encoding: entry >= 0 takes +x[entry]; entry < 0 takes -x[-entry-1]."""
+    n = len(mirrored)
+    out = np.zeros(n, dtype=np.int32)
+    seen = set()
+    for i, m in enumerate(mirrored):
+        c = int(abs(int(m)))
+        assert c not in seen, "mirror list must be a permutation"
+        seen.add(c)
+        out[c] = i if np.sign(m) > 0 else -(i + 1)
+    return out
+
+
+def returns_scan(rew, end, boot, last_val, gamma):
+    """[T,N] backward discounted-return scan (PPOBuffer.finish_path, rl/algos/ppo.py:73-89)."""
+    _need_gpu(rew, end, boot, last_val)
+    T, N = rew.shape
+    assert rew.dtype == torch.float32 and end.dtype == torch.uint8 and boot.dtype == torch.float32
+    rew, end, boot, last_val = rew.contiguous(), end.contiguous(), boot.contiguous(), last_val.contiguous()
+    ret = torch.empty_like(rew)
+    check(_lib.load().apx_returns_scan(_p(rew), _p(end), _p(boot), _p(last_val), float(gamma), T, N, _p(ret), _stream()))
+    return ret
+
+
+def adv_moments(ret, val):
+    _need_gpu(ret, val)
+    mom = torch.empty(3, dtype=torch.float64, device=ret.device)
+    check(_lib.load().apx_adv_moments(_p(ret), _p(val), ret.numel(), _p(mom), _stream()))
+    return mom
+
+
+def normalize_advantages(ret, val, eps=1e-5, group=None):
+    """rl/algos/ppo.py:395-396.  With a process group the three moments are all-reduced (RCCL) first so that every
+    rank normalises with the statistics of the union batch."""
+    ret, val = ret.contiguous().view(-1), val.contiguous().view(-1)
+    mom = adv_moments(ret, val)
+    if group is not None:
+        torch.distributed.all_reduce(mom, group=group)
+    s, ss, n = mom.tolist()
+    mean = s / n
+    var = max(ss - n * mean * mean, 0.0) / max(n - 1.0, 1.0)
+    adv = torch.empty_like(ret)
+    check(_lib.load().apx_adv_apply(_p(ret), _p(val), ret.numel(), mean, var ** 0.5, eps, _p(adv), _stream()))
+    return adv
+
+
+class Mlp:
+    """Flat fp32 parameter block of a 3-layer ReLU MLP in state_dict order (W0,b0,W1,b1,W2,b2; torch [out,in])."""
+
+    def __init__(self, D, H, O, device):
+        self.D, self.H, self.O = D, H, O
+        self.n = int(_lib.load().apx_mlp_param_count(D, H, O))
+        self.params = torch.zeros(self.n, dtype=torch.float32, device=device)
+
+    def views(self, flat=None):
+        flat = self.params if flat is None else flat
+        D, H, O = self.D, self.H, self.O
+        shapes = [(H, D), (H,), (H, H), (H,), (O, H), (O,)]
+        out, off = [], 0
+        for s in shapes:
+            k = int(np.prod(s))
+            out.append(flat[off:off + k].view(*s))
+            off += k
+        return out
+
+    def load_list(self, tensors):
+        for v, t in zip(self.views(), tensors):
+            v.copy_(torch.as_tensor(np.asarray(t), dtype=torch.float32))
+
+    def forward(self, x, obs_mean=None, obs_std=None, idx=None, sign_perm=None, clock_mask=0, keep=False):
+        _need_gpu(x)
+        x = x.contiguous()
+        B = x.shape[0] if idx is None else idx.numel()
+        dev = x.device
+        xn = torch.empty(B, self.D, dtype=torch.float32, device=dev)
+        a1 = torch.empty(B, self.H, dtype=torch.float32, device=dev)
+        a2 = torch.empty(B, self.H, dtype=torch.float32, device=dev)
+        y = torch.empty(B, self.O, dtype=torch.float32, device=dev)
+        check(_lib.load().apx_mlp_forward(_p(self.params), self.D, self.H, self.O, _p(x), B, _p(idx), _p(sign_perm),
+                                          int(clock_mask), _p(obs_mean), _p(obs_std), _p(xn), _p(a1), _p(a2), _p(y), 0,
+                                          _stream()))
+        return (y, xn, a1, a2) if keep else y
+
+
+class PPOLearner:
+    """Device-resident actor/critic + Adam state; one call = one PPO.update_policy (rl/algos/ppo.py:276-345)."""
+
+    def __init__(self, obs_dim, act_dim, hidden, device, fixed_std, lr=1e-4, eps=1e-5, clip=0.2, entropy_coeff=0.0,
+                 grad_clip=0.05, mirrored_obs=None, mirrored_acts=None, clock_inds=(46, 47), mirror_coeff=0.4):
+        self.device = device
+        self.actor = Mlp(obs_dim, hidden, act_dim, device)
+        self.critic = Mlp(obs_dim, hidden, 1, device)
+        z = lambda m: torch.zeros(m.n, dtype=torch.float32, device=device)
+        self.actor_m, self.actor_v, self.actor_g = z(self.actor), z(self.actor), z(self.actor)
+        self.critic_m, self.critic_v, self.critic_g = z(self.critic), z(self.critic), z(self.critic)
+        self.obs_mean = torch.zeros(obs_dim, dtype=torch.float32, device=device)
+        self.obs_std = torch.ones(obs_dim, dtype=torch.float32, device=device)
+        self.fixed_std, self.lr, self.eps, self.clip = float(fixed_std), lr, eps, clip
+        self.entropy_coeff, self.grad_clip, self.mirror_coeff = entropy_coeff, grad_clip, mirror_coeff
+        self.t = 0
+        self.obs_sp = self.act_sp = None
+        self.clock_mask = 0
+        if mirrored_obs is not None:
+            self.obs_sp = torch.as_tensor(signed_perm_from_mirror(mirrored_obs), device=device)
+            self.act_sp = torch.as_tensor(signed_perm_from_mirror(mirrored_acts), device=device)
+            for c in clock_inds:
+                self.clock_mask |= 1 << int(c)
+        self._ws = None
+        self._scal = torch.zeros(6, dtype=torch.float64, device=device)
+
+    def old_means(self, obs):
+        """old_policy.distribution(obs) means for the whole buffer (ppo.py:284-285; old == current at iteration start)."""
+        return self.actor.forward(obs, self.obs_mean, self.obs_std)
+
+    def values(self, obs):
+        return self.critic.forward(obs)          # training mode: raw obs (critic.py:66-67)
+
+    def minibatch(self, obs, act, ret, adv, old_mu, idx=None, mirror=True, grad_only=False, sync=True):
+        lib = _lib.load()
+        mb = obs.shape[0] if idx is None else idx.numel()
+        D, H, A = self.actor.D, self.actor.H, self.actor.O
+        need = int(lib.apx_ppo_workspace_bytes(mb, D, H, A))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if not grad_only:
+            self.t += 1
+        use_mirror = mirror and self.obs_sp is not None
+        a = _lib.PpoArgs(
+            actor=_p(self.actor.params), actor_m=_p(self.actor_m), actor_v=_p(self.actor_v), actor_grad=_p(self.actor_g),
+            critic=_p(self.critic.params), critic_m=_p(self.critic_m), critic_v=_p(self.critic_v),
+            critic_grad=_p(self.critic_g), D=D, H=H, A=A, obs=_p(obs), act=_p(act), ret=_p(ret), adv=_p(adv),
+            old_mu=_p(old_mu), idx=_p(idx), mb=mb, obs_mean=_p(self.obs_mean), obs_std=_p(self.obs_std),
+            obs_sign_perm=_p(self.obs_sp) if use_mirror else None, clock_mask=self.clock_mask,
+            act_sign_perm=_p(self.act_sp) if use_mirror else None, fixed_std=self.fixed_std, clip=self.clip,
+            entropy_coeff=self.entropy_coeff, grad_clip=self.grad_clip, lr=self.lr, adam_eps=self.eps,
+            mirror_coeff=self.mirror_coeff, adam_t=max(self.t, 1), precision=0, grad_only=int(grad_only),
+            workspace=_p(self._ws), workspace_bytes=self._ws.numel(), scalars_out=_p(self._scal))
+        check(lib.apx_ppo_minibatch(C.byref(a), _stream()))
+        return self._scal.cpu().numpy().copy() if sync else self._scal
+
+    def apply_grads(self, scale=1.0):
+        """clip + Adam on (all-reduced) gradients after minibatch(grad_only=True)."""
+        lib = _lib.load()
+        self.t += 1
+        sc = torch.zeros(2, dtype=torch.float64, device=self.device)
+        check(lib.apx_clip_adam(_p(self.actor.params), _p(self.actor_m), _p(self.actor_v), _p(self.actor_g), self.actor.n,
+                                scale, self.grad_clip, self.lr, self.eps, self.t, _p(sc[0:1]), _stream()))
+        check(lib.apx_clip_adam(_p(self.critic.params), _p(self.critic_m), _p(self.critic_v), _p(self.critic_g),
+                                self.critic.n, scale, self.grad_clip, self.lr, self.eps, self.t, _p(sc[1:2]), _stream()))

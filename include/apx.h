@@ -1,0 +1,154 @@
+/*
+ * apx.h — C ABI of libapx.so, the MI355X-native engine behind osudrl/apex's Cassie-v0 PPO hot path.
+ *
+ * Boundary rules: extern "C", plain pointers and sizes, no torch / C++ types.  Every pointer
+ * marked [dev] is DEVICE memory owned by the caller (e.g. a PyTorch-ROCm tensor's data_ptr()); [host] is
+ * host memory.  `stream` is a hipStream_t passed as void* (NULL = the null stream).  Functions return
+ * APX_OK (0) or a negative error code; apx_last_error() gives the message for the calling thread.
+ * Nothing here ever falls back to a CPU path: without a GPU every compute entry point returns APX_E_HIP.
+ *
+ * Each entry point cites the reference interface (osudrl/apex, file:line) it replaces.
+ */
+#ifndef APX_H
+#define APX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APX_OK 0
+#define APX_E_ARG (-1)
+#define APX_E_HIP (-2)
+#define APX_E_STATE (-3)
+
+#define APX_OBS_DIM 50   /* cassie/cassie.py:236-265  (46 estimator + 2 clock + 2 speed) */
+#define APX_ACT_DIM 10   /* cassie/cassie.py:68 */
+#define APX_NQ 35        /* cassie/cassiemujoco/cassiemujoco.py:36-39 */
+#define APX_NV 32
+
+int apx_version(void);
+const char* apx_last_error(void);
+/* number of visible HIP devices (0 when there is no GPU); never fails */
+int apx_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Learner half
+ * ---------------------------------------------------------------------------------------------------------- */
+
+/* Discounted-return backward scan over a [T, N] rollout grid (env-per-column).
+ * Replaces PPOBuffer.finish_path, rl/algos/ppo.py:73-89 (+ the bootstrap rule at ppo.py:183-184).
+ *   rew[T*N] f32, end[T*N] u8 (non-zero = last step of an episode), boot[T*N] f32 (bootstrap value used at an
+ *   episode end: (not done)*V(s_{t+1})), last_val[N] f32 (V of the state after the grid, for running episodes),
+ *   ret[T*N] f32 out.  fp64 recurrence like the reference; lambda is not a parameter because the reference never
+ *   reads it (ppo.py:50,103,112).                                                         all pointers [dev] */
+int apx_returns_scan(const float* rew, const uint8_t* end, const float* boot, const float* last_val, double gamma,
+                     int T, int N, float* ret, void* stream);
+
+/* Advantage normalisation, rl/algos/ppo.py:395-396, split so that N>1 ranks can all-reduce the moments.
+ *   apx_adv_moments: moments[3] f64 [dev] <- (sum a, sum a^2, count) of a = ret - val over n elements.
+ *   apx_adv_apply:   adv[i] = (ret[i]-val[i] - mean) / (std + eps)                         all pointers [dev] */
+int apx_adv_moments(const float* ret, const float* val, int64_t n, double* moments, void* stream);
+int apx_adv_apply(const float* ret, const float* val, int64_t n, double mean, double std_unbiased, double eps,
+                  float* adv, void* stream);
+
+/* Parameter block of one 3-layer ReLU MLP (rl/policies/actor.py:142-215, critic.py:37-77), fp32, torch layout
+ * [out,in], packed in state_dict order: W0[H*D] b0[H] W1[H*H] b1[H] W2[O*H] b2[O]. */
+size_t apx_mlp_param_count(int D, int H, int O);
+
+/* y[B,O] = MLP(x) with optional input normalisation (obs_mean/obs_std may be NULL = none; FF_V in train mode,
+ * critic.py:66-67).  act1/act2 (may be NULL) receive the post-ReLU hidden activations [B,H] for a later backward.
+ * idx (may be NULL) gathers rows: x_row = x[idx[b]].  sign_perm (may be NULL) = int32[D] signed permutation
+ * applied BEFORE normalisation (SymmetricEnv.mirror_clock_observation, rl/envs/wrappers.py:59-67): entry j>=0 takes
+ * +x[j], entry -(j+1) takes -x[j]; clock_mask bit c set => column c additionally gets sin(asin(.)+pi).
+ * precision: 0 = fp32 MFMA (parity mode), 1 = bf16 MFMA inputs with fp32 accumulate.       all pointers [dev] */
+int apx_mlp_forward(const float* params, int D, int H, int O, const float* x, int64_t B, const int64_t* idx,
+                    const int32_t* sign_perm, uint64_t clock_mask, const float* obs_mean, const float* obs_std,
+                    float* xn_out, float* act1, float* act2, float* y, int precision, void* stream);
+
+/* One PPO minibatch step: rl/algos/ppo.py:276-345 PPO.update_policy (feed-forward branch).
+ * All device pointers; scalars_out[6] f64 [dev] receives (actor_loss, entropy, critic_loss, ratio.mean, kl.mean,
+ * mirror_loss) exactly as update_policy returns them. */
+typedef struct apx_ppo_args {
+    /* networks + Adam state (fp32, apx_mlp_param_count floats each) */
+    float* actor; float* actor_m; float* actor_v; float* actor_grad;
+    float* critic; float* critic_m; float* critic_v; float* critic_grad;
+    int D, H, A;
+    /* rollout buffer (whole iteration) and minibatch selection */
+    const float* obs;      /* [Btot, D] raw observations                    (ppo.py:393) */
+    const float* act;      /* [Btot, A]                                                   */
+    const float* ret;      /* [Btot]                                                      */
+    const float* adv;      /* [Btot] normalised advantages                  (ppo.py:396) */
+    const float* old_mu;   /* [Btot, A] old policy means                    (ppo.py:284-285) */
+    const int64_t* idx;    /* [mb] row indices of this minibatch (BatchSampler, ppo.py:416) or NULL = 0..mb-1 */
+    int64_t mb;
+    const float* obs_mean; const float* obs_std;   /* [D] shared normaliser (ppo.py:546-549) */
+    /* mirror loss (ppo.py:302-318): NULL sign_perm disables it */
+    const int32_t* obs_sign_perm; uint64_t clock_mask; const int32_t* act_sign_perm;
+    /* hyper-parameters */
+    float fixed_std, clip, entropy_coeff, grad_clip, lr, adam_eps, mirror_coeff;
+    int adam_t;            /* 1-based optimiser step count (bias correction) */
+    int precision;         /* 0 fp32 MFMA, 1 bf16 MFMA */
+    int grad_only;         /* 1 = stop after gradients (no clip/Adam): lets N>1 ranks all-reduce actor_grad/critic_grad */
+    /* scratch: apx_ppo_workspace_bytes(mb, D, H, A) bytes [dev] */
+    void* workspace; size_t workspace_bytes;
+    double* scalars_out;
+} apx_ppo_args;
+
+size_t apx_ppo_workspace_bytes(int64_t mb, int D, int H, int A);
+int apx_ppo_minibatch(const apx_ppo_args* args, void* stream);
+/* second half when grad_only=1 was used: global-norm clip (clip_grad_norm_, ppo.py:326,335) + Adam (ppo.py:355-356)
+ * on an (all-reduced) gradient; scale multiplies the gradient first (1/world_size for an averaged sum). */
+int apx_clip_adam(float* param, float* m, float* v, float* grad, int64_t n, float grad_scale, float grad_clip,
+                  float lr, float adam_eps, int adam_t, double* sumsq_scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Environment half: batched Cassie-v0.  Replaces the per-env FFI of cassie/cassiemujoco/cassiemujoco.py:33-336
+ * (cassie_sim_init / cassie_sim_step_pd / accessors, include/cassiemujoco.h:41-275) and the Python env logic of
+ * cassie/cassie.py:293-496,523-680,787-859 + cassie/rewards/clock_rewards.py:6-110 with ONE handle per GPU.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct apx_env apx_env_t;
+
+typedef struct apx_env_cfg {
+    int n_envs;                 /* envs on this GPU (multiple of 64) */
+    int simrate;                /* physics substeps per env step, apex.py:18 (default 50) */
+    int dynamics_randomization; /* apex.py:19 */
+    int reward_kind;            /* 0 clock_reward (clock_rewards.py:6-110), 1 early_clock_reward (:119-223) */
+    int stance_mode;            /* 0 zero, 1 grounded, 2 aerial (cassie.py:209-214) */
+    int have_incentive;         /* cassie.py:91 */
+    int max_traj_len;           /* apex.py:248: auto-reset horizon used by apx_env_step's truncation flag */
+    uint64_t seed;              /* Philox key; stream = (seed, env id) */
+    int device;                 /* HIP device ordinal */
+    int pgs_iters;              /* cassie.xml:5 iterations (50) */
+    int reserved[7];
+} apx_env_cfg;
+
+void apx_env_default_cfg(apx_env_cfg* cfg);
+int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out);
+int apx_env_destroy(apx_env_t* env);
+
+/* CassieEnv.reset (cassie/cassie.py:523-680) for envs whose mask byte is non-zero (mask NULL = all);
+ * obs_out[n_envs*50] f32 [dev] (rows of un-reset envs are left untouched). */
+int apx_env_reset(apx_env_t* env, const uint8_t* mask, float* obs_out, void* stream);
+
+/* CassieEnv.step (cassie/cassie.py:389-496) for every env: action[n_envs*10] f32 -> obs[n_envs*50] f32,
+ * reward[n_envs] f32, done[n_envs] u8 (1 terminated, 2 truncated at max_traj_len).  With auto_reset != 0 an env
+ * that finished is reset in the same launch; its terminal observation (needed for the bootstrap value, ppo.py:183)
+ * goes to final_obs (may be NULL) and obs gets the post-reset observation.                 all pointers [dev] */
+int apx_env_step(apx_env_t* env, const float* action, float* obs, float* reward, uint8_t* done, float* final_obs,
+                 int auto_reset, void* stream);
+
+/* Raw simulator state access (cassie_sim_qpos / cassie_sim_qvel, include/cassiemujoco.h:83-87): copies, SoA ->
+ * [n_envs, 35] / [n_envs, 32] row-major f32.  Used by tests and by apx_env_set_state for parity replays. */
+int apx_env_get_state(apx_env_t* env, float* qpos, float* qvel, void* stream);
+int apx_env_set_state(apx_env_t* env, const float* qpos, const float* qvel, void* stream);
+/* named per-env scalar/vector fields for tests and tools: returns count of floats per env, or <0 */
+int apx_env_get_field(apx_env_t* env, const char* name, float* out, void* stream);
+int apx_env_set_field(apx_env_t* env, const char* name, const float* in, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APX_H */

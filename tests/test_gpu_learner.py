@@ -1,0 +1,165 @@
+"""GPU parity tests for the learner kernels: HIP path (through the C ABI) vs the numpy oracle and vs the golden
+vectors produced by the reference itself.  Tolerances: bit-exact indices; <=1e-5 relative on returns, advantages
+and losses (BASELINE.json north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import learner as L
+from tests.test_oracle_learner import ACTOR_KEYS, CRITIC_KEYS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def test_returns_scan_vs_oracle(dev):
+    from apex_amd import engine
+    rng = np.random.RandomState(0)
+    for (T, N) in [(1, 64), (17, 5), (32, 4096), (400, 130), (7, 1)]:
+        rew = rng.randn(T, N).astype(np.float32)
+        end = (rng.rand(T, N) < 0.1).astype(np.uint8)
+        boot = (rng.randn(T, N) * (rng.rand(T, N) < 0.5)).astype(np.float32)
+        last = rng.randn(N).astype(np.float32)
+        ref = L.returns_scan_grid_boot(rew, end, boot, last, 0.99)
+        got = engine.returns_scan(torch.tensor(rew, device=dev), torch.tensor(end, device=dev),
+                                  torch.tensor(boot, device=dev), torch.tensor(last, device=dev), 0.99).cpu().numpy()
+        np.testing.assert_array_equal(got, ref.astype(np.float32))     # fp64 recurrence on both sides: bit-exact
+
+
+def test_returns_scan_golden_g1(dev, golden_dir):
+    """Reference finish_path outputs, replayed through the grid kernel one trajectory per column."""
+    from apex_amd import engine
+    g = np.load(os.path.join(golden_dir, "g1_finish_path.npz"))
+    for c in range(int(g["n_cases"])):
+        lens = g[f"c{c}_lens"]; T = int(lens.max()); N = len(lens)
+        rew = np.zeros((T, N), np.float32); end = np.zeros((T, N), np.uint8); boot = np.zeros((T, N), np.float32)
+        off = 0
+        r64 = g[f"c{c}_rewards"]
+        for n, Ln in enumerate(lens):
+            rew[:Ln, n] = r64[off:off + Ln]; end[Ln - 1, n] = 1; boot[Ln - 1, n] = g[f"c{c}_last_vals"][n]; off += Ln
+        got = engine.returns_scan(*(torch.tensor(x, device=dev) for x in (rew, end, boot)),
+                                  torch.zeros(N, device=dev), float(g[f"c{c}_gamma"])).cpu().numpy()
+        off = 0
+        for n, Ln in enumerate(lens):
+            # rewards were rounded to fp32 on the way in -> 1e-6 relative, well inside the 1e-5 bar
+            np.testing.assert_allclose(got[:Ln, n], g[f"c{c}_returns"][off:off + Ln], rtol=1e-5, atol=1e-6); off += Ln
+
+
+def test_adv_norm_golden_g2(dev, golden_dir):
+    from apex_amd import engine
+    g = np.load(os.path.join(golden_dir, "g2_adv_norm.npz"))
+    for c in range(int(g["n_cases"])):
+        adv = engine.normalize_advantages(torch.tensor(g[f"c{c}_returns"], device=dev),
+                                          torch.tensor(g[f"c{c}_values"], device=dev), 1e-5).cpu().numpy()
+        np.testing.assert_allclose(adv, g[f"c{c}_adv"].reshape(-1), rtol=1e-5, atol=2e-6)
+
+
+def test_mlp_forward_golden_g3(dev, golden_dir):
+    from apex_amd import engine
+    g = np.load(os.path.join(golden_dir, "g3_policy_forward.npz"))
+    actor = engine.Mlp(50, 256, 10, dev); actor.load_list([g["actor." + k] for k in ACTOR_KEYS])
+    critic = engine.Mlp(50, 256, 1, dev); critic.load_list([g["critic." + k] for k in CRITIC_KEYS])
+    obs = torch.tensor(g["obs"], device=dev)
+    om, os_ = torch.tensor(g["obs_mean"], device=dev), torch.tensor(g["obs_std"], device=dev)
+    np.testing.assert_allclose(actor.forward(obs, om, os_).cpu().numpy(), g["mean"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(critic.forward(obs).cpu().numpy(), g["value_train"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(critic.forward(obs, om, os_).cpu().numpy(), g["value_eval"], rtol=1e-5, atol=1e-5)
+
+
+def test_mlp_forward_ragged_shapes(dev):
+    """Empty, single-row and non-multiple-of-tile batches; gather + mirror path vs oracle."""
+    from apex_amd import engine
+    from tools.refprobe.common import MIRRORED_OBS_FULL_CLOCK
+    rng = np.random.RandomState(3)
+    net = engine.Mlp(50, 64, 10, dev)
+    W = [rng.randn(*v.shape).astype(np.float32) * 0.2 for v in net.views()]
+    net.load_list(W)
+    sp = torch.as_tensor(engine.signed_perm_from_mirror(MIRRORED_OBS_FULL_CLOCK), device=dev)
+    Mo = L.mirror_matrix(MIRRORED_OBS_FULL_CLOCK)
+    for B in [0, 1, 63, 65, 1000]:
+        x = rng.randn(max(B, 1) + 5, 50).astype(np.float32)
+        x[:, 46:48] = np.clip(x[:, 46:48], -1, 1)
+        idx = rng.randint(0, x.shape[0], size=B)
+        y = net.forward(torch.tensor(x, device=dev), idx=torch.tensor(idx, device=dev, dtype=torch.int64),
+                        sign_perm=sp, clock_mask=(1 << 46) | (1 << 47))
+        assert y.shape == (B, 10)
+        if B:
+            ref = L.mlp_forward(W, L.mirror_clock_observation(x[idx].astype(np.float64), Mo, [46, 47]))
+            np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+
+
+def _run_g4_case(dev, g, g5, c):
+    from apex_amd import engine
+    from tools.refprobe.common import MIRRORED_OBS_FULL_CLOCK, MIRRORED_ACTS
+    p = f"c{c}_"
+    H = int(g[p + "hidden"]); mirror = bool(g[p + "mirror"])
+    lr = engine.PPOLearner(50, 10, H, dev, fixed_std=np.exp(-1.5), entropy_coeff=float(g[p + "entropy_coeff"]),
+                           mirrored_obs=MIRRORED_OBS_FULL_CLOCK, mirrored_acts=MIRRORED_ACTS)
+    lr.actor.load_list([g[p + "actor0." + k] for k in ACTOR_KEYS])
+    lr.critic.load_list([g[p + "critic0." + k] for k in CRITIC_KEYS])
+    old = engine.Mlp(50, H, 10, dev); old.load_list([g[p + "old." + k] for k in ACTOR_KEYS])
+    lr.obs_mean.copy_(torch.tensor(g[p + "obs_mean"])); lr.obs_std.copy_(torch.tensor(g[p + "obs_std"]))
+    scal = []
+    for s in range(int(g[p + "nsteps"])):
+        obs, act, ret, adv = (torch.tensor(g[p + f"s{s}_{k}"], device=dev) for k in ("obs", "act", "ret", "adv"))
+        old_mu = old.forward(obs, lr.obs_mean, lr.obs_std)
+        scal.append(lr.minibatch(obs, act, ret.view(-1), adv.view(-1), old_mu, mirror=mirror))
+    return lr, np.array(scal)
+
+
+def test_ppo_update_golden_g4(dev, golden_dir):
+    """update_policy 6-tuple (<=1e-5 relative) and post-step parameters vs the reference's own outputs."""
+    g = np.load(os.path.join(golden_dir, "g4_update_policy.npz"))
+    g5 = np.load(os.path.join(golden_dir, "g5_mirror.npz"))
+    for c in range(int(g["n_cases"])):
+        lr, scal = _run_g4_case(dev, g, g5, c)
+        np.testing.assert_allclose(scal, g[f"c{c}_scalars"], rtol=1e-5, atol=1e-7)
+        for k, w in zip(ACTOR_KEYS, lr.actor.views()):
+            bad = np.abs(w.cpu().numpy() - g[f"c{c}_actor1." + k]) > 2e-6
+            assert bad.mean() < 2e-3, (c, k, bad.mean())
+        for k, w in zip(CRITIC_KEYS, lr.critic.views()):
+            bad = np.abs(w.cpu().numpy() - g[f"c{c}_critic1." + k]) > 2e-6
+            assert bad.mean() < 2e-3, (c, k, bad.mean())
+
+
+def test_ppo_update_large_minibatch_vs_oracle(dev):
+    """Throughput-sized minibatch (16 384) with index gather: gradients via grad_only vs the fp64 oracle."""
+    from apex_amd import engine
+    from tools.refprobe.common import MIRRORED_OBS_FULL_CLOCK, MIRRORED_ACTS
+    rng = np.random.RandomState(7)
+    H, Btot, mb = 64, 20000, 16384
+    lr = engine.PPOLearner(50, 10, H, dev, fixed_std=np.exp(-1.5), mirrored_obs=MIRRORED_OBS_FULL_CLOCK,
+                           mirrored_acts=MIRRORED_ACTS)
+    Wa = [rng.randn(*v.shape).astype(np.float32) * 0.1 for v in lr.actor.views()]
+    Wc = [rng.randn(*v.shape).astype(np.float32) * 0.1 for v in lr.critic.views()]
+    Wo = [w + rng.randn(*w.shape).astype(np.float32) * 0.01 for w in Wa]
+    lr.actor.load_list(Wa); lr.critic.load_list(Wc)
+    old = engine.Mlp(50, H, 10, dev); old.load_list(Wo)
+    obs = rng.randn(Btot, 50).astype(np.float32); ph = rng.rand(Btot) * 2 * np.pi
+    obs[:, 46] = np.sin(ph); obs[:, 47] = np.cos(ph)
+    act = (rng.randn(Btot, 10) * 0.3).astype(np.float32); ret = rng.randn(Btot).astype(np.float32)
+    adv = rng.randn(Btot).astype(np.float32); idx = rng.permutation(Btot)[:mb]
+    t = lambda x, **k: torch.tensor(x, device=dev, **k)
+    old_mu = old.forward(t(obs), lr.obs_mean, lr.obs_std)
+    scal = lr.minibatch(t(obs), t(act), t(ret), t(adv), old_mu, idx=t(idx, dtype=torch.int64), grad_only=True)
+    Mo, Ma = L.mirror_matrix(MIRRORED_OBS_FULL_CLOCK), L.mirror_matrix(MIRRORED_ACTS)
+
+    class Rec:           # capture the (clipped) gradients the oracle hands to Adam; use a huge clip so they are raw
+        def step(self, params, grads):
+            self.g = grads
+            return params
+    ra, rc = Rec(), Rec()
+    ref, _, _ = L.ppo_update(Wa, Wo, Wc, ra, rc, obs[idx], act[idx], ret[idx, None], adv[idx, None], np.zeros(50),
+                             np.ones(50), np.exp(-1.5), grad_clip=1e9, M_obs=Mo, M_act=Ma)
+    np.testing.assert_allclose(scal, ref, rtol=1e-5, atol=1e-7)
+    ga = np.concatenate([x.reshape(-1) for x in ra.g]); gc = np.concatenate([x.reshape(-1) for x in rc.g])
+    np.testing.assert_allclose(lr.actor_g.cpu().numpy(), ga, rtol=1e-3, atol=1e-6 * np.abs(ga).max() + 1e-9)
+    np.testing.assert_allclose(lr.critic_g.cpu().numpy(), gc, rtol=1e-3, atol=1e-5 * np.abs(gc).max() + 1e-9)
