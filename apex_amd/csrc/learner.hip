@@ -318,11 +318,11 @@ extern "C" int apx_mlp_forward(const float* params, int D, int H, int O, const f
                                const int32_t* sign_perm, uint64_t clock_mask, const float* obs_mean,
                                const float* obs_std, float* xn_out, float* act1, float* act2, float* y, int precision,
                                void* stream) {
-    APX_REQUIRE(params && x && y && xn_out && act1 && act2, "null pointer");
     APX_REQUIRE(D > 0 && H > 0 && O > 0 && B >= 0, "dims");
+    if (B == 0) return APX_OK;   // empty batch: nothing to do (empty tensors have NULL data pointers)
+    APX_REQUIRE(params && x && y && xn_out && act1 && act2, "null pointer");
     APX_REQUIRE(precision == 0, "only precision 0 (fp32 MFMA) is built in this round");
     APX_REQUIRE((obs_mean == nullptr) == (obs_std == nullptr), "obs_mean/obs_std");
-    if (B == 0) return APX_OK;
     hipStream_t s = (hipStream_t)stream;
     APX_TRY(prep_obs(x, B, D, idx, sign_perm, clock_mask, obs_mean, obs_std, xn_out, s));
     return mlp_forward_impl(params, D, H, O, xn_out, B, act1, act2, y, s);
