@@ -1,0 +1,132 @@
+// CPU ORACLE (test infrastructure only): C entry points for tests/ (ctypes) and bench.py's cpu_baseline leg.
+#include "cassie_env.h"
+#include <cstring>
+#include <thread>
+#include <vector>
+#include <chrono>
+#include <atomic>
+
+using namespace orc;
+
+extern "C" {
+
+void* orc_env_new(int simrate, int dyn_rand, int reward_kind, int stance_mode, int incentive, int max_traj_len,
+                  int pgs_iters, uint64_t seed, uint32_t env_id) {
+    EnvCfg c;
+    c.simrate = simrate; c.dynamics_randomization = dyn_rand; c.reward_kind = reward_kind; c.stance_mode = stance_mode;
+    c.have_incentive = incentive; c.max_traj_len = max_traj_len; c.pgs_iters = pgs_iters; c.seed = seed;
+    Env* e = new Env;
+    env_init(*e, c, env_id);
+    return e;
+}
+void orc_env_free(void* h) { delete (Env*)h; }
+void orc_env_reset(void* h, double* obs) { env_reset(*(Env*)h, obs); }
+int orc_env_step(void* h, const double* action, double* obs, double* reward) { return env_step(*(Env*)h, action, obs, reward); }
+void orc_env_substep(void* h) { sim_step_pd(*(Env*)h); }
+void orc_env_obs(void* h, double* obs) { env_obs(*(Env*)h, obs); }
+
+// raw physics: n plain mj_step-like steps with a fixed actuator-side ctrl[10]
+void orc_phys_step(void* h, const double* ctrl, int n) {
+    static thread_local Work w;
+    Env& e = *(Env*)h;
+    for (int i = 0; i < n; ++i) step(e.par, e.st, w, ctrl);
+}
+void orc_phys_forward(void* h, const double* ctrl) {
+    static thread_local Work w;
+    Env& e = *(Env*)h;
+    forward(e.par, e.st, w, ctrl);
+}
+double orc_constraint_violation(void* h) { return constraint_violation(((Env*)h)->st); }
+double orc_total_energy(void* h) { static thread_local Work w; Env& e = *(Env*)h; return total_energy(e.par, e.st, w); }
+
+#define FIELD(nm, ptr, cnt) if (!std::strcmp(name, nm)) { if (set) std::memcpy((void*)(ptr), io, sizeof(double) * (cnt)); else std::memcpy(io, (ptr), sizeof(double) * (cnt)); return cnt; }
+static int field(Env& e, const char* name, double* io, bool set) {
+    FIELD("qpos", e.st.qpos, NQ) FIELD("qvel", e.st.qvel, NV) FIELD("qacc", e.st.qacc, NV) FIELD("qacc_warm", e.st.qacc_warm, NV)
+    FIELD("mass", e.par.mass, NB) FIELD("damping", e.par.damping, NV) FIELD("friction", &e.par.friction, 1)
+    FIELD("floor_quat", &e.par.floor_quat, 4) FIELD("body_invweight0", e.par.body_invweight0, 2 * NB)
+    FIELD("dof_invweight0", e.par.dof_invweight0, NV)
+    FIELD("foot_force", e.st.foot_force, 6) FIELD("efc_force", e.st.efc_force, MAXEFC)
+    FIELD("motor_noise", e.motor_noise, 10) FIELD("joint_noise", e.joint_noise, 6)
+    FIELD("pd_target", e.pd_target, 10) FIELD("pd_P", e.pd_P, 10) FIELD("pd_D", e.pd_D, 10)
+    FIELD("speed", &e.speed, 1) FIELD("side_speed", &e.side_speed, 1) FIELD("orient_add", &e.orient_add, 1)
+    FIELD("so_mpos", e.so_mpos, 10) FIELD("so_mvel", e.so_mvel, 10) FIELD("so_torque", e.so_torque, 10)
+    FIELD("so_jpos", e.so_jpos, 6) FIELD("so_jvel", e.so_jvel, 6) FIELD("so_quat", e.so_quat, 4)
+    FIELD("so_rotvel", e.so_rotvel, 3) FIELD("so_tvel", e.so_tvel, 3) FIELD("so_tacc", e.so_tacc, 3) FIELD("so_height", &e.so_height, 1)
+    FIELD("snap_acc", e.snap_acc, 3) FIELD("snap_gyro", e.snap_gyro, 3) FIELD("snap_quat", e.snap_quat, 4)
+    FIELD("snap_mpos", e.snap_mpos, 10) FIELD("snap_jpos", e.snap_jpos, 6)
+    FIELD("l_foot_vel", e.l_foot_vel, 3) FIELD("r_foot_vel", e.r_foot_vel, 3)
+    FIELD("reward_terms", e.last_reward_terms, 8) FIELD("clock_x", e.clock.x, 8) FIELD("phaselen", &e.clock.phaselen, 1)
+    FIELD("prev_action", e.prev_action, 10) FIELD("prev_torque", e.prev_torque, 10)
+    FIELD("tq_fifo", e.tq_fifo, 60)
+    if (!std::strcmp(name, "xpos")) { if (!set) std::memcpy(io, e.st.xpos, sizeof(double) * 3 * NB); return 3 * NB; }
+    if (!std::strcmp(name, "xquat")) { if (!set) std::memcpy(io, e.st.xquat, sizeof(double) * 4 * NB); return 4 * NB; }
+    if (!std::strcmp(name, "ints")) {   // time, phase, counter, ncon, nefc, rng ctr, has_prev_action, has_prev_torque
+        int* p[8] = {&e.time, &e.phase, &e.counter, &e.st.ncon, &e.st.nefc, (int*)&e.rng.ctr, &e.has_prev_action, &e.has_prev_torque};
+        for (int i = 0; i < 8; ++i) { if (set) *p[i] = (int)io[i]; else io[i] = *p[i]; }
+        return 8;
+    }
+    return -1;
+}
+int orc_env_get(void* h, const char* name, double* out) { return field(*(Env*)h, name, out, false); }
+int orc_env_set(void* h, const char* name, const double* in) { return field(*(Env*)h, name, (double*)in, true); }
+void orc_env_set_const(void* h) { set_const(((Env*)h)->par); }
+
+void orc_clock_eval(double swing, double stance, double relax, int mode, int inc, int freq, int n, const double* ph,
+                    double* out, double* phaselen) {
+    Clock c;
+    make_clock(c, swing, stance, relax, mode, inc, freq);
+    *phaselen = c.phaselen;
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 4; ++k) out[4 * i + k] = c.eval(k, ph[i]);
+}
+
+// clock_reward on explicitly given inputs (golden G7): scal = l_frc, r_frc, l_orient, r_orient, speed, phase, swing, stance
+double orc_clock_reward_eval(void* h, const double* qpos, const double* qvel, const double* scal, const double* foot_vel,
+                             const double* rotvel, const double* tacc, const double* torque, const double* prev_torque,
+                             const double* prev_action, const double* action) {
+    Env& e = *(Env*)h;
+    std::memcpy(e.st.qpos, qpos, sizeof(double) * NQ); std::memcpy(e.st.qvel, qvel, sizeof(double) * NV);
+    e.l_foot_frc = scal[0]; e.r_foot_frc = scal[1]; e.l_foot_orient_cost = scal[2]; e.r_foot_orient_cost = scal[3];
+    e.speed = scal[4]; e.phase = (int)scal[5];
+    make_clock(e.clock, scal[6], scal[7], 0.1, e.cfg.stance_mode, e.cfg.have_incentive, 2000 / e.cfg.simrate);
+    for (int k = 0; k < 3; ++k) { e.l_foot_vel[k] = foot_vel[k]; e.r_foot_vel[k] = foot_vel[3 + k]; e.so_rotvel[k] = rotvel[k]; e.so_tacc[k] = tacc[k]; }
+    for (int u = 0; u < 10; ++u) { e.so_torque[u] = torque[u]; e.prev_torque[u] = prev_torque[u]; e.prev_action[u] = prev_action[u]; }
+    return eval_clock_reward(e, action);
+}
+
+uint32_t orc_philox(uint64_t seed, uint32_t env, uint32_t ctr) {
+    Philox p{(uint32_t)seed, (uint32_t)(seed >> 32), env, ctr};
+    return p.next_u32();
+}
+
+// CPU baseline (bench.py `cpu_baseline`, kind "port"): n_envs envs x n_steps env steps (auto-reset), zero-mean
+// pseudo-random actions, one env per task over `threads` std::threads.  Returns env-steps per second.
+double orc_rollout_bench(int n_envs, int n_steps, int threads, uint64_t seed, double act_std) {
+    std::vector<Env*> envs(n_envs);
+    EnvCfg c; c.seed = seed;
+    for (int i = 0; i < n_envs; ++i) { envs[i] = new Env; env_init(*envs[i], c, (uint32_t)i); }
+    std::atomic<int> next{0};
+    auto t0 = std::chrono::steady_clock::now();
+    auto work = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n_envs) return;
+            Env& e = *envs[i];
+            Philox an{(uint32_t)(seed ^ 0x5bd1e995u), 77u, (uint32_t)i, 0};
+            double obs[50], rew, act[10];
+            env_reset(e, obs);
+            for (int t = 0; t < n_steps; ++t) {
+                for (int u = 0; u < 10; ++u) act[u] = act_std * (an.uniform01() + an.uniform01() + an.uniform01() - 1.5) * 2.0;
+                if (env_step(e, act, obs, &rew)) env_reset(e, obs);
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 0; k < threads; ++k) th.emplace_back(work);
+    for (auto& t : th) t.join();
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (auto* e : envs) delete e;
+    return (double)n_envs * n_steps / dt;
+}
+
+}  // extern "C"

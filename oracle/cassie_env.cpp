@@ -1,0 +1,344 @@
+// CPU ORACLE (test infrastructure only).  See cassie_env.h.
+#include "cassie_env.h"
+#include <cstdio>
+
+namespace orc {
+
+// ---------------------------------------------------------------------------------------------- Philox4x32-10
+static inline void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+uint32_t Philox::next_u32() {
+    uint32_t c[4] = {ctr, env, 0x41505845u, 0};   // (draw index, env id, tag, 0)
+    uint32_t k0 = key0, k1 = key1;
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    ++ctr;
+    return c[0];
+}
+
+// ---------------------------------------------------------------------------------------------- clock splines
+// cassie/phase_function.py:5-136.  Every knot of the PCHIP interpolants is adjacent to a flat segment, so every
+// PCHIP derivative is 0 (scipy: d_k = 0 when a neighbouring secant is 0) and the interpolant is: constant on the
+// flat pieces, cubic smoothstep y1 + (y2-y1)(3t^2 - 2t^3) between them, periodic with period phaselen.
+void make_clock(Clock& c, double swing, double stance, double relax, int mode, int inc, int freq) {
+    const double total = 2 * swing + 2 * stance;
+    c.phaselen = total * freq;
+    const double seg[4][2] = {{0.0, swing}, {swing, swing + stance}, {swing + stance, 2 * swing + stance},
+                              {2 * swing + stance, total}};
+    for (int s = 0; s < 4; ++s) {
+        const double a = seg[s][0] * freq, b = seg[s][1] * freq, off = (b - a) * relax;
+        c.x[2 * s] = a + off; c.x[2 * s + 1] = b - off;
+    }
+    // value tables; names follow the reference's arrays: r_frc, r_vel, l_frc, l_vel (phase_function.py:16-19)
+    double r_frc[4], r_vel[4], l_frc[4], l_vel[4];
+    // right swing (:27-32)
+    l_vel[0] = r_frc[0] = -1; l_frc[0] = r_vel[0] = inc ? 1 : 0;
+    // double stances (:39-57, :78-96)
+    for (int s = 1; s <= 3; s += 2) {
+        if (mode == 2) {            // aerial
+            l_frc[s] = r_frc[s] = -1; l_vel[s] = r_vel[s] = inc ? 1 : 0;
+        } else if (mode == 0) {     // zero
+            l_frc[s] = r_frc[s] = 0; l_vel[s] = r_vel[s] = 0;
+        } else {                    // grounded
+            if (!inc) {
+                if (s == 1) {       // quirk :54-55: second assignment overwrites l_frc, l_vel keeps its initial 0
+                    r_frc[s] = 0; l_frc[s] = -1; r_vel[s] = -1; l_vel[s] = 0;
+                } else {            // :93-94 assign l_vel correctly
+                    l_frc[s] = r_frc[s] = 0; l_vel[s] = r_vel[s] = -1;
+                }
+            } else {
+                l_frc[s] = r_frc[s] = 1; l_vel[s] = r_vel[s] = -1;
+            }
+        }
+    }
+    // left swing (:64-70)
+    l_vel[2] = r_frc[2] = inc ? 1 : 0; l_frc[2] = r_vel[2] = -1;
+    for (int s = 0; s < 4; ++s)
+        for (int k = 0; k < 2; ++k) {
+            // create_phase_reward returns ([r_frc, r_vel], [l_frc, l_vel], ...) and cassie.py:559 binds them to
+            // (left_clock, right_clock): the "left" clock is the r_* pair.
+            c.y[0][2 * s + k] = r_frc[s]; c.y[1][2 * s + k] = r_vel[s];
+            c.y[2][2 * s + k] = l_frc[s]; c.y[3][2 * s + k] = l_vel[s];
+        }
+}
+
+double Clock::eval(int which, double ph) const {
+    // knots of the previous / next cycle are the same knots shifted by -/+ phaselen
+    const double* yy = y[which];
+    double xk[10], yk[10];
+    xk[0] = x[7] - phaselen; yk[0] = yy[7];
+    for (int i = 0; i < 8; ++i) { xk[i + 1] = x[i]; yk[i + 1] = yy[i]; }
+    xk[9] = x[0] + phaselen; yk[9] = yy[0];
+    // the reference evaluates at integer phase in [0, phaselen] (+1 before the wrap), inside [xk[0], xk[9]] for
+    // relax >= 0; beyond the last knot of the 3-cycle table it would extrapolate, which never happens here.
+    for (int i = 0; i < 9; ++i)
+        if (ph <= xk[i + 1]) {
+            if (ph < xk[i]) return yk[i];
+            const double t = (ph - xk[i]) / (xk[i + 1] - xk[i]);
+            return yk[i] + (yk[i + 1] - yk[i]) * (3 * t * t - 2 * t * t * t);
+        }
+    // ph beyond x[0] + phaselen: next-cycle pieces
+    return eval(which, ph - phaselen);
+}
+
+// ---------------------------------------------------------------------------------------------- helpers
+static const double PI = 3.14159265358979323846;
+static const double kP[5] = {100, 100, 88, 96, 50}, kD[5] = {10.0, 10.0, 8.0, 9.6, 5.0};   // cassie.py:57-58
+static const double kOffset[10] = {0.0045, 0.0, 0.4973, -1.1997, -1.5968, 0.0045, 0.0, 0.4973, -1.1997, -1.5968};  // :107
+static const double kNeutralFoot[4] = {-0.24790886454547323, -0.24679713195445646, -0.6609396704367185, 0.663921021343526};  // :121
+static const double kTorqueLimit[5] = {140.63, 140.63, 216.16, 216.16, 45.14};   // cassie_sim_init presets, SURVEY §2.2
+static const int kFir[9] = {2727, 534, -2658, -795, 72, 110, 19, -6, -3};
+
+static void forward_snapshot(Env& e, Work& w, const double* ctrl) {
+    forward(e.par, e.st, w, ctrl);
+    const State& s = e.st;
+    for (int u = 0; u < 10; ++u) { e.snap_mpos[u] = s.qpos[cm_act_qposadr[u]]; e.snap_mvel[u] = s.qvel[cm_act_dof[u]]; }
+    for (int k = 0; k < 6; ++k) { e.snap_jpos[k] = s.qpos[cm_jsens_qposadr[k]]; e.snap_jvel[k] = s.qvel[cm_jsens_dofadr[k]]; }
+    for (int k = 0; k < 4; ++k) e.snap_quat[k] = s.qpos[3 + k];
+    for (int k = 0; k < 3; ++k) { e.snap_gyro[k] = s.sens_gyro[k]; e.snap_acc[k] = s.sens_acc[k]; e.snap_vel[k] = s.qvel[k]; }
+    e.snap_pz = s.qpos[2];
+}
+
+static void foot_positions(const State& s, double* fp) {   // cassie_sim_foot_positions
+    fp[0] = s.xpos[13].x; fp[1] = s.xpos[13].y; fp[2] = s.xpos[13].z - 0.0550841220316708;
+    fp[3] = s.xpos[25].x; fp[4] = s.xpos[25].y; fp[5] = s.xpos[25].z - 0.0550841220316708;
+}
+
+// One 2 kHz substep: encoders + estimator -> PD -> safeties -> motor model/delay -> mj_step
+void sim_step_pd(Env& e) {
+    static thread_local Work w;
+    // --- drive encoders (10): truncating quantiser + 9-tap FIR velocity
+    for (int u = 0; u < 10; ++u) {
+        const double scale = 2 * PI / (double)(1 << cm_act_bits[u]);
+        const double n = std::trunc(e.snap_mpos[u] * cm_act_gear[u] / scale);
+        if (!e.menc_primed) for (int k = 0; k < 9; ++k) e.menc_hist[u][k] = n;
+        for (int k = 8; k > 0; --k) e.menc_hist[u][k] = e.menc_hist[u][k - 1];
+        e.menc_hist[u][0] = n;
+        double acc = 0;
+        for (int k = 0; k < 9; ++k) acc += kFir[k] * e.menc_hist[u][k];
+        e.so_mpos[u] = n * scale / cm_act_gear[u];
+        e.so_mvel[u] = acc * scale / cm_act_gear[u] / PI;
+    }
+    e.menc_primed = 1;
+    // --- joint encoders (6): quantiser + biquad velocity
+    for (int k = 0; k < 6; ++k) {
+        const double scale = 2 * PI / (double)(1 << cm_jsens_bits[k]);
+        const double x = std::trunc(e.snap_jpos[k] / scale) * scale;
+        if (!e.jenc_primed) { for (int i = 0; i < 4; ++i) e.jenc_x[k][i] = x; for (int i = 0; i < 3; ++i) e.jenc_y[k][i] = 0; }
+        for (int i = 3; i > 0; --i) e.jenc_x[k][i] = e.jenc_x[k][i - 1];
+        e.jenc_x[k][0] = x;
+        const double y = 12.348 * (e.jenc_x[k][0] + e.jenc_x[k][1] - e.jenc_x[k][2] - e.jenc_x[k][3]) + 1.7658 * e.jenc_y[k][0] - 0.79045 * e.jenc_y[k][1];
+        e.jenc_y[k][1] = e.jenc_y[k][0]; e.jenc_y[k][0] = y;
+        e.so_jpos[k] = x; e.so_jvel[k] = y;
+    }
+    e.jenc_primed = 1;
+    // --- state estimator: 39 pass-through fields + 7 filtered ones (estimator-lite)
+    for (int k = 0; k < 4; ++k) e.so_quat[k] = e.snap_quat[k];
+    for (int k = 0; k < 3; ++k) e.so_rotvel[k] = e.snap_gyro[k];
+    {
+        const M3 R = q2m(Q4{e.snap_quat[0], e.snap_quat[1], e.snap_quat[2], e.snap_quat[3]});
+        const V3 aw = mul(R, V3{e.snap_acc[0], e.snap_acc[1], e.snap_acc[2]});
+        e.so_tacc[0] = aw.x; e.so_tacc[1] = aw.y; e.so_tacc[2] = aw.z - GRAV;
+        for (int k = 0; k < 3; ++k) e.so_tvel[k] = e.snap_vel[k];
+        e.so_height = e.snap_pz - cm_floor_pos[2];
+    }
+    // --- pd_input_step: tau = P (pTarget - q) + D (dTarget - qd), no clamp (PdInput.h; SURVEY §2.2 bit-exact probe)
+    double tau[10], ctrl[10];
+    for (int u = 0; u < 10; ++u) tau[u] = e.pd_P[u] * (e.pd_target[u] - e.so_mpos[u]) + e.pd_D[u] * (0.0 - e.so_mvel[u]);
+    // --- cassie_core_sim_step: clamp to the drive torqueLimit (joint-limit safety zones: DESIGN.md §5, not yet modelled)
+    for (int u = 0; u < 10; ++u) tau[u] = std::min(std::max(tau[u], -kTorqueLimit[u % 5]), kTorqueLimit[u % 5]);
+    // --- cassie_sim_step_ethercat: torque-speed curve, 6-deep delay line
+    for (int u = 0; u < 10; ++u) {
+        const double wmax = cm_act_rpm[u] * 2 * PI / 60.0, tmax = cm_act_ctrlmax[u];
+        const double om = std::fabs(e.st.qvel[cm_act_dof[u]] * cm_act_gear[u]);
+        const double tlim = std::min(std::max(2 * tmax * (1 - om / wmax), 0.0), tmax);
+        const double cmd = tau[u] / cm_act_gear[u];
+        const double un = (cmd < 0 ? -1.0 : 1.0) * std::min(std::fabs(cmd), tlim);
+        for (int k = 5; k > 0; --k) e.tq_fifo[u][k] = e.tq_fifo[u][k - 1];
+        e.tq_fifo[u][0] = un;
+        ctrl[u] = e.tq_fifo[u][5];
+        e.so_torque[u] = cm_act_gear[u] * ctrl[u];
+    }
+    // --- mj_step1 + mj_step2
+    forward_snapshot(e, w, ctrl);
+    euler(e.par, e.st, w);
+}
+
+static void quat_yaw_inverse_apply(double yaw, const double* v, int n, double* out) {
+    // rotate_to_orient (cassie.py:280-291): q = euler2quat(z=yaw); iq = inverse(q)
+    const double cz = std::cos(yaw / 2), sz = std::sin(yaw / 2);
+    Q4 q = {cz, 0, 0, sz};
+    if (q.w < 0) q = {-q.w, -q.x, -q.y, -q.z};
+    const Q4 iq = {q.w, -q.x, -q.y, -q.z};
+    if (n == 3) {   // rotate_by_quaternion(vec, iq) = iq * (0,v) * inverse(iq)
+        const Q4 r = qmul(iq, qmul(Q4{0, v[0], v[1], v[2]}, q));
+        out[0] = r.x; out[1] = r.y; out[2] = r.z;
+    } else {
+        Q4 r = qmul(iq, Q4{v[0], v[1], v[2], v[3]});
+        if (r.w < 0) r = {-r.w, -r.x, -r.y, -r.z};
+        out[0] = r.w; out[1] = r.x; out[2] = r.y; out[3] = r.z;
+    }
+}
+
+// get_full_state, cassie.py:787-859 (input_profile full, command_profile clock)
+void env_obs(const Env& e, double* o) {
+    o[0] = e.so_height;
+    quat_yaw_inverse_apply(e.orient_add, e.so_quat, 4, o + 1);
+    for (int u = 0; u < 10; ++u) o[5 + u] = e.so_mpos[u] + e.motor_noise[u];
+    quat_yaw_inverse_apply(e.orient_add, e.so_tvel, 3, o + 15);
+    for (int k = 0; k < 3; ++k) o[18 + k] = e.so_rotvel[k];
+    for (int u = 0; u < 10; ++u) o[21 + u] = e.so_mvel[u];
+    quat_yaw_inverse_apply(e.orient_add, e.so_tacc, 3, o + 31);
+    for (int k = 0; k < 6; ++k) o[34 + k] = e.so_jpos[k] + e.joint_noise[k];
+    for (int k = 0; k < 6; ++k) o[40 + k] = e.so_jvel[k];
+    o[46] = std::sin(2 * PI * e.phase / e.clock.phaselen);
+    o[47] = std::cos(2 * PI * e.phase / e.clock.phaselen);
+    o[48] = e.speed; o[49] = e.side_speed;
+}
+
+void env_init(Env& e, const EnvCfg& cfg, uint32_t env_id) {
+    std::memset(&e, 0, sizeof(e));
+    e.cfg = cfg;
+    default_params(e.par);
+    e.par.pgs_iters = cfg.pgs_iters;
+    e.rng = Philox{(uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), env_id, 0};
+    reset_state(e.st);
+}
+
+static void set_clock_from_speed(Env& e) {   // cassie.py:556-559
+    const double total = (0.9 - 0.25 / 3.0 * std::fabs(e.speed)) / 2;
+    const double swing = (0.30 + ((0.70 - 0.30) / 3) * std::fabs(e.speed)) * total;
+    const double stance = (0.70 - ((0.70 - 0.30) / 3) * std::fabs(e.speed)) * total;
+    make_clock(e.clock, swing, stance, 0.1, e.cfg.stance_mode, e.cfg.have_incentive, 2000 / e.cfg.simrate);
+}
+
+// CassieEnv.reset, cassie.py:523-680
+void env_reset(Env& e, double* obs) {
+    static thread_local Work w;
+    Philox& r = e.rng;
+    e.speed = r.uniform(-0.3, 4.0);
+    e.side_speed = r.uniform(-0.3, 0.3);
+    set_clock_from_speed(e);
+    e.phase = (int)r.randint((uint32_t)std::floor(e.clock.phaselen) + 1);   // random.randint(0, floor(phaselen)) inclusive
+    e.time = 0; e.counter = 0;
+    if (e.cfg.dynamics_randomization) {
+        // damping (:569-597): hips, achilles, knee, shin, tarsus, foot-crank, foot x U[0.3,5]; pelvis, heel-spring, plantar fixed
+        static const int vary[13] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 0, 1};
+        for (int d = 0; d < 6; ++d) { (void)r.uniform01(); e.par.damping[d] = cm_dof_damping[d]; }
+        for (int leg = 0; leg < 2; ++leg)
+            for (int k = 0; k < 13; ++k) {
+                const int d = 6 + 13 * leg + k;
+                const double u = r.uniform01();
+                const double lo = vary[k] ? 0.3 : 1.0, hi = vary[k] ? 5.0 : 1.0;
+                e.par.damping[d] = std::max(0.0, cm_dof_damping[d] * (lo + (hi - lo) * u));
+            }
+        // mass (:599-622): every body x U[0.5,1.5]; world stays 0
+        (void)r.uniform01(); e.par.mass[0] = 0;
+        for (int b = 1; b < NB; ++b) e.par.mass[b] = std::max(0.0, cm_body_mass[b] * r.uniform(0.5, 1.5));
+        // friction (:627-632): translational U[0.4,1.1]; torsional / rolling are drawn but unused with condim 3
+        e.par.friction = r.uniform(0.4, 1.1); (void)r.uniform01(); (void)r.uniform01();
+        // floor tilt (:644-648): euler2quat(z=0, y=pitch, x=roll)
+        const double roll = r.uniform(-0.03, 0.03), pitch = r.uniform(-0.03, 0.03);
+        const double cy = std::cos(pitch / 2), sy = std::sin(pitch / 2), cx = std::cos(roll / 2), sx = std::sin(roll / 2);
+        Q4 fq = {cx * cy, cy * sx, cx * sy, sx * sy};     // quaternion_function.py:58-71 with z = 0
+        if (fq.w < 0) fq = {-fq.w, -fq.x, -fq.y, -fq.z};
+        e.par.floor_quat = fq;
+        for (int u = 0; u < 10; ++u) e.motor_noise[u] = r.uniform(-0.01, 0.01);
+        for (int k = 0; k < 6; ++k) e.joint_noise[k] = r.uniform(-0.01, 0.01);
+        set_const(e.par);                                   // sim.set_const -> mj_setConst
+    }
+    // cassie_sim_set_const: init qpos, zero qvel, mj_forward; PD / delay line / encoder / estimator state is NOT reset
+    for (int i = 0; i < NQ; ++i) e.st.qpos[i] = cm_init_qpos[i];
+    for (int i = 0; i < NV; ++i) { e.st.qvel[i] = 0; e.st.qacc_warm[i] = 0; }
+    double zero[10] = {0};
+    forward_snapshot(e, w, zero);
+    foot_positions(e.st, e.foot_pos_prev);
+    sim_step_pd(e);                                         // cassie.py:665: one step with the stale self.u
+    foot_positions(e.st, e.foot_pos_prev);
+    e.orient_add = 0;
+    e.speed = r.uniform(-0.3, 4.0);                         // cassie.py:669-670 (clock keeps the FIRST speed draw)
+    e.side_speed = r.uniform(-0.3, 0.3);
+    e.l_foot_frc = e.r_foot_frc = e.l_foot_orient_cost = e.r_foot_orient_cost = 0;
+    if (obs) env_obs(e, obs);
+}
+
+static double clock_reward(Env& e, const double* action) {   // cassie/rewards/clock_rewards.py:6-110
+    const State& s = e.st;
+    const double fmax = 250, vmax = 2.0;
+    const double nlf = std::min(e.l_foot_frc, fmax) / fmax, nrf = std::min(e.r_foot_frc, fmax) / fmax;
+    const double lv = std::sqrt(e.l_foot_vel[0] * e.l_foot_vel[0] + e.l_foot_vel[1] * e.l_foot_vel[1] + e.l_foot_vel[2] * e.l_foot_vel[2]);
+    const double rv = std::sqrt(e.r_foot_vel[0] * e.r_foot_vel[0] + e.r_foot_vel[1] * e.r_foot_vel[1] + e.r_foot_vel[2] * e.r_foot_vel[2]);
+    const double nlv = std::min(lv, vmax) / vmax, nrv = std::min(rv, vmax) / vmax;
+    const double com_orient = 10 * (1 - s.qpos[3] * s.qpos[3]);
+    const double foot_orient = 10 * (e.l_foot_orient_cost + e.r_foot_orient_cost);
+    const double com_vel_err = std::fabs(s.qvel[0] - e.speed);
+    double straight = std::fabs(s.qpos[1]);
+    if (straight < 0.05) straight = 0;
+    double hdiff = std::fabs(s.qpos[2] - 0.9);
+    if (hdiff < 0.05 + 0.05 * e.speed) hdiff = 0;
+    double pacc = 0;
+    for (int k = 0; k < 3; ++k) pacc += std::fabs(e.so_rotvel[k]) + std::fabs(e.so_tacc[k]);
+    const double pelvis_motion = straight + hdiff + 0.25 * pacc;
+    const double lfc = e.clock.eval(0, e.phase), lvc = e.clock.eval(1, e.phase), rfc = e.clock.eval(2, e.phase), rvc = e.clock.eval(3, e.phase);
+    const double frc_score = std::tan(PI / 4 * lfc * nlf) + std::tan(PI / 4 * rfc * nrf);
+    const double vel_score = std::tan(PI / 4 * lvc * nlv) + std::tan(PI / 4 * rvc * nrv);
+    const double hip_roll = std::fabs(s.qvel[6]) + std::fabs(s.qvel[13]);    // :74 indexes qvel[13] (left shin), sic
+    double tq = 0, ac = 0;
+    for (int u = 0; u < 10; ++u) { tq += std::fabs(e.prev_torque[u] - e.so_torque[u]); ac += std::fabs(e.prev_action[u] - action[u]); }
+    const double torque_pen = 0.25 * tq / 10, action_pen = 5 * ac / 10;
+    double* t = e.last_reward_terms;
+    t[0] = 0.200 * frc_score; t[1] = 0.200 * vel_score; t[2] = 0.200 * std::exp(-(com_orient + foot_orient));
+    t[3] = 0.150 * std::exp(-pelvis_motion); t[4] = 0.150 * std::exp(-com_vel_err); t[5] = 0.050 * std::exp(-hip_roll);
+    t[6] = 0.025 * std::exp(-torque_pen); t[7] = 0.025 * std::exp(-action_pen);
+    return t[0] + t[1] + t[2] + t[3] + t[4] + t[5] + t[6] + t[7];
+}
+
+double eval_clock_reward(Env& e, const double* action) { return clock_reward(e, action); }
+
+// CassieEnv.step, cassie.py:389-496
+int env_step(Env& e, const double* action, double* obs, double* reward) {
+    e.l_foot_frc = e.r_foot_frc = 0;
+    e.l_foot_orient_cost = e.r_foot_orient_cost = 0;
+    for (int u = 0; u < 10; ++u) {      // step_simulation :295-326
+        e.pd_target[u] = action[u] + kOffset[u] - (e.cfg.dynamics_randomization ? e.motor_noise[u] : 0.0);
+        e.pd_P[u] = kP[u % 5]; e.pd_D[u] = kD[u % 5];
+    }
+    for (int i = 0; i < e.cfg.simrate; ++i) {
+        sim_step_pd(e);
+        double fp[6];
+        foot_positions(e.st, fp);
+        for (int k = 0; k < 3; ++k) { e.l_foot_vel[k] = (fp[k] - e.foot_pos_prev[k]) / 0.0005; e.r_foot_vel[k] = (fp[3 + k] - e.foot_pos_prev[3 + k]) / 0.0005; }
+        for (int k = 0; k < 6; ++k) e.foot_pos_prev[k] = fp[k];
+        e.l_foot_frc += e.st.foot_force[0][2]; e.r_foot_frc += e.st.foot_force[1][2];
+        const Q4 ql = e.st.xquat[13], qr = e.st.xquat[25];
+        const double il = kNeutralFoot[0] * ql.w + kNeutralFoot[1] * ql.x + kNeutralFoot[2] * ql.y + kNeutralFoot[3] * ql.z;
+        const double ir = kNeutralFoot[0] * qr.w + kNeutralFoot[1] * qr.x + kNeutralFoot[2] * qr.y + kNeutralFoot[3] * qr.z;
+        e.l_foot_orient_cost += 1 - il * il; e.r_foot_orient_cost += 1 - ir * ir;
+    }
+    const double inv = 1.0 / e.cfg.simrate;
+    e.l_foot_frc *= inv; e.r_foot_frc *= inv; e.l_foot_orient_cost *= inv; e.r_foot_orient_cost *= inv;
+    const double height = e.st.qpos[2];
+    e.time += 1; e.phase += 1;
+    if (e.phase > e.clock.phaselen) { e.phase = 0; e.counter += 1; }
+    int done = (height < 0.4 || height > 3.0 || !(height == height)) ? 1 : 0;
+    if (!e.has_prev_action) { for (int u = 0; u < 10; ++u) e.prev_action[u] = action[u]; e.has_prev_action = 1; }
+    if (!e.has_prev_torque) { for (int u = 0; u < 10; ++u) e.prev_torque[u] = e.so_torque[u]; e.has_prev_torque = 1; }
+    *reward = clock_reward(e, action);
+    for (int u = 0; u < 10; ++u) { e.prev_action[u] = action[u]; e.prev_torque[u] = e.so_torque[u]; }
+    // early_term_cutoff is forced to -99 (cassie.py:773) => the reward never terminates
+    Philox& r = e.rng;   // command resampling :483-491, fixed 6 draws per step
+    { const uint32_t k = r.randint(300); const double u = r.uniform(-0.2, 0.2); if (k == 0) e.orient_add += u; }
+    { const uint32_t k = r.randint(100); const double u = r.uniform(-0.3, 4.0); if (k == 0) e.speed = std::min(std::max(u, -0.3), 4.0); }
+    { const uint32_t k = r.randint(300); const double u = r.uniform(-0.3, 0.3); if (k == 0) e.side_speed = u; }
+    if (obs) env_obs(e, obs);
+    if (!done && e.time >= e.cfg.max_traj_len) done = 2;
+    return done;
+}
+
+}  // namespace orc

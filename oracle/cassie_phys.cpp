@@ -1,0 +1,436 @@
+// CPU ORACLE (test infrastructure only).  See cassie_phys.h for scope and provenance.
+#include "cassie_phys.h"
+
+namespace orc {
+
+static int body_lastdof(int b) {
+    while (b > 0 && cm_body_dofnum[b] == 0) b = cm_body_parent[b];
+    return b > 0 ? cm_body_dofadr[b] + cm_body_dofnum[b] - 1 : -1;
+}
+
+static bool cholesky(const double A[NV][NV], double L[NV][NV]) {
+    for (int i = 0; i < NV; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = A[i][j];
+            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            if (i == j) {
+                if (s <= 0) return false;
+                L[i][i] = std::sqrt(s);
+            } else
+                L[i][j] = s / L[j][j];
+        }
+    return true;
+}
+static void chol_solve(const double L[NV][NV], const double* b, double* x) {
+    double y[NV];
+    for (int i = 0; i < NV; ++i) {
+        double s = b[i];
+        for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
+        y[i] = s / L[i][i];
+    }
+    for (int i = NV - 1; i >= 0; --i) {
+        double s = y[i];
+        for (int k = i + 1; k < NV; ++k) s -= L[k][i] * x[k];
+        x[i] = s / L[i][i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- kinematics
+// MuJoCo mj_kinematics + mj_comPos for the joint types cassie.xml uses (slide / hinge / ball; joint pos = 0).
+static void kinematics(const double* qpos, State& s, Work& w) {
+    s.xpos[0] = {0, 0, 0}; s.xquat[0] = {1, 0, 0, 0}; s.xmat[0] = q2m(s.xquat[0]);
+    V3 axis_w[NJ];
+    for (int b = 1; b < NB; ++b) {
+        const int p = cm_body_parent[b];
+        V3 pos = s.xpos[p] + mul(s.xmat[p], v3(cm_body_pos + 3 * b));
+        Q4 quat = qmul(s.xquat[p], Q4{cm_body_quat[4 * b], cm_body_quat[4 * b + 1], cm_body_quat[4 * b + 2], cm_body_quat[4 * b + 3]});
+        for (int j = 0; j < NJ; ++j) {
+            if (cm_jnt_body[j] != b) continue;
+            const int adr = cm_jnt_qposadr[j];
+            const M3 R = q2m(quat);
+            axis_w[j] = mul(R, v3(cm_jnt_axis + 3 * j));
+            w.anchor[j] = pos;
+            if (cm_jnt_type[j] == 0) pos = pos + axis_w[j] * (qpos[adr] - cm_jnt_ref[j]);
+            else if (cm_jnt_type[j] == 1) quat = qmul(quat, qaxisangle(v3(cm_jnt_axis + 3 * j), qpos[adr] - cm_jnt_ref[j]));
+            else quat = qmul(quat, qnormalize(Q4{qpos[adr], qpos[adr + 1], qpos[adr + 2], qpos[adr + 3]}));
+        }
+        s.xquat[b] = qnormalize(quat); s.xpos[b] = pos; s.xmat[b] = q2m(s.xquat[b]);
+    }
+    w.o = s.xpos[1];
+    for (int d = 0; d < NV; ++d) {
+        const int j = cm_dof_jnt[d], b = cm_dof_body[d];
+        if (cm_jnt_type[j] == 0) w.cdof[d] = {{0, 0, 0}, axis_w[j]};
+        else if (cm_jnt_type[j] == 1) w.cdof[d] = {axis_w[j], cross(axis_w[j], w.o - w.anchor[j])};
+        else {
+            const V3 ax = col(s.xmat[b], d - cm_jnt_dofadr[j]);
+            w.cdof[d] = {ax, cross(ax, w.o - w.anchor[j])};
+        }
+    }
+}
+
+static void inertias(const Params& p, const State& s, Work& w) {
+    for (int b = 0; b < NB; ++b) {
+        const M3& R = s.xmat[b];
+        const double* Ib = cm_body_inertia + 9 * b;
+        double RI[9], Iw[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double a = 0;
+                for (int k = 0; k < 3; ++k) a += R.m[3 * i + k] * Ib[3 * k + j];
+                RI[3 * i + j] = a;
+            }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double a = 0;
+                for (int k = 0; k < 3; ++k) a += RI[3 * i + k] * R.m[3 * j + k];
+                Iw[3 * i + j] = a;
+            }
+        const double m = p.mass[b];       // mass randomisation changes mass only; body_inertia stays (cassie.py:640)
+        const V3 r = s.xpos[b] + mul(R, v3(cm_body_ipos + 3 * b)) - w.o;
+        const double rr = dot(r, r);
+        SI c;
+        c.m = m; c.h = r * m;
+        c.I[0] = Iw[0] + m * (rr - r.x * r.x); c.I[1] = Iw[4] + m * (rr - r.y * r.y); c.I[2] = Iw[8] + m * (rr - r.z * r.z);
+        c.I[3] = Iw[1] - m * r.x * r.y; c.I[4] = Iw[2] - m * r.x * r.z; c.I[5] = Iw[5] - m * r.y * r.z;
+        w.cinert[b] = c; w.crb[b] = c;
+    }
+    for (int b = NB - 1; b >= 1; --b) w.crb[cm_body_parent[b]] = w.crb[cm_body_parent[b]] + w.crb[b];
+    // CRBA
+    for (int i = 0; i < NV; ++i)
+        for (int j = 0; j < NV; ++j) w.M[i][j] = 0;
+    for (int i = 0; i < NV; ++i) {
+        const SV f = imul(w.crb[cm_dof_body[i]], w.cdof[i]);
+        w.M[i][i] = sdot(w.cdof[i], f) + cm_dof_armature[i];
+        for (int j = cm_dof_parent[i]; j >= 0; j = cm_dof_parent[j]) w.M[i][j] = w.M[j][i] = sdot(w.cdof[j], f);
+    }
+}
+
+// point Jacobian (translational) of a point fixed to body b
+static void jac_point(const Work& w, int b, V3 p, double Jx[NV], double Jy[NV], double Jz[NV], double sign) {
+    const V3 r = p - w.o;
+    for (int d = body_lastdof(b); d >= 0; d = cm_dof_parent[d]) {
+        const V3 v = w.cdof[d].l + cross(w.cdof[d].a, r);
+        Jx[d] += sign * v.x; Jy[d] += sign * v.y; Jz[d] += sign * v.z;
+    }
+}
+
+static void impedance(double pos, double& imp) {
+    // MuJoCo solimp = (d0, dwidth, width, midpoint, power) default 0.9 0.95 0.001 0.5 2
+    const double d0 = 0.9, d1 = 0.95, width = 0.001, mid = 0.5, power = 2;
+    double x = std::fabs(pos) / width;
+    if (x >= 1) { imp = d1; return; }
+    if (x <= 0) { imp = d0; return; }
+    double y;
+    if (x <= mid) y = std::pow(x, power) / std::pow(mid, power - 1);
+    else y = 1 - std::pow(1 - x, power) / std::pow(1 - mid, power - 1);
+    imp = d0 + y * (d1 - d0);
+}
+
+static void finish_row(Row& r, const double* qvel, double imp_pos, double timeconst, double dampratio) {
+    const double dmax = 0.95;
+    const double K = 1.0 / std::max(MINVAL, dmax * dmax * timeconst * timeconst * dampratio * dampratio);
+    const double B = 2.0 / std::max(MINVAL, dmax * timeconst);
+    double imp;
+    impedance(imp_pos, imp);
+    r.vel = 0;
+    for (int d = 0; d < NV; ++d) r.vel += r.J[d] * qvel[d];
+    r.R = std::max(MINVAL, (1 - imp) / imp * r.diag);
+    r.aref = -B * r.vel - K * imp * r.pos;
+}
+
+void default_params(Params& p) {
+    for (int b = 0; b < NB; ++b) p.mass[b] = cm_body_mass[b];
+    for (int d = 0; d < NV; ++d) p.damping[d] = cm_dof_damping[d];
+    p.friction = 1.0;
+    p.floor_quat = {1, 0, 0, 0};
+    p.pgs_iters = 50;
+    set_const(p);
+}
+
+// mj_setConst subset: body_invweight0 / dof_invweight0 from M^-1 at qpos0 (used by the constraint regulariser R)
+void set_const(Params& p) {
+    static State s; static Work w;
+    kinematics(cm_qpos0, s, w);
+    inertias(p, s, w);
+    if (!cholesky(w.M, w.L)) return;
+    static double Minv[NV][NV];
+    for (int c = 0; c < NV; ++c) {
+        double e[NV] = {0}, x[NV];
+        e[c] = 1;
+        chol_solve(w.L, e, x);
+        for (int r = 0; r < NV; ++r) Minv[r][c] = x[r];
+    }
+    p.body_invweight0[0][0] = p.body_invweight0[0][1] = 0;
+    for (int b = 1; b < NB; ++b) {
+        double J[6][NV];
+        std::memset(J, 0, sizeof(J));
+        const V3 c = s.xpos[b] + mul(s.xmat[b], v3(cm_body_ipos + 3 * b));
+        jac_point(w, b, c, J[0], J[1], J[2], 1.0);
+        for (int d = body_lastdof(b); d >= 0; d = cm_dof_parent[d]) { J[3][d] = w.cdof[d].a.x; J[4][d] = w.cdof[d].a.y; J[5][d] = w.cdof[d].a.z; }
+        double tr[2] = {0, 0};
+        for (int k = 0; k < 6; ++k) {
+            double acc = 0;
+            for (int i = 0; i < NV; ++i)
+                for (int j = 0; j < NV; ++j) acc += J[k][i] * Minv[i][j] * J[k][j];
+            tr[k / 3] += acc;
+        }
+        p.body_invweight0[b][0] = tr[0] / 3; p.body_invweight0[b][1] = tr[1] / 3;
+    }
+    for (int j = 0; j < NJ; ++j) {
+        const int a = cm_jnt_dofadr[j];
+        if (cm_jnt_type[j] == 2) {
+            const double v = (Minv[a][a] + Minv[a + 1][a + 1] + Minv[a + 2][a + 2]) / 3;
+            p.dof_invweight0[a] = p.dof_invweight0[a + 1] = p.dof_invweight0[a + 2] = v;
+        } else
+            p.dof_invweight0[a] = Minv[a][a];
+    }
+}
+
+void reset_state(State& s) {
+    std::memset(&s, 0, sizeof(s));
+    for (int i = 0; i < NQ; ++i) s.qpos[i] = cm_init_qpos[i];
+}
+
+// ---------------------------------------------------------------------------------------------- forward dynamics
+void forward(const Params& p, State& s, Work& w, const double* ctrl) {
+    kinematics(s.qpos, s, w);
+    inertias(p, s, w);
+    // velocities (mj_comVel)
+    SV cvel_dofs[NB];
+    w.cvel[0] = {{0, 0, 0}, {0, 0, 0}};
+    for (int b = 1; b < NB; ++b) {
+        SV v = w.cvel[cm_body_parent[b]];
+        for (int j = 0; j < NJ; ++j) {
+            if (cm_jnt_body[j] != b) continue;
+            const int a = cm_jnt_dofadr[j], nd = cm_jnt_type[j] == 2 ? 3 : 1;
+            for (int k = 0; k < nd; ++k) w.cdofdot[a + k] = crossMotion(v, w.cdof[a + k]);   // ball: all 3 from the same v
+            for (int k = 0; k < nd; ++k) v = v + w.cdof[a + k] * s.qvel[a + k];
+        }
+        w.cvel[b] = v;
+    }
+    (void)cvel_dofs;
+    // bias forces: RNE with qacc = 0 and base acceleration = -gravity (mj_rne)
+    SV cacc[NB], cfrc[NB];
+    cacc[0] = {{0, 0, 0}, {0, 0, GRAV}};
+    for (int b = 1; b < NB; ++b) {
+        SV a = cacc[cm_body_parent[b]];
+        for (int d = cm_body_dofadr[b]; d < cm_body_dofadr[b] + cm_body_dofnum[b]; ++d) a = a + w.cdofdot[d] * s.qvel[d];
+        cacc[b] = a;
+        cfrc[b] = imul(w.cinert[b], a) + crossForce(w.cvel[b], imul(w.cinert[b], w.cvel[b]));
+    }
+    for (int b = NB - 1; b >= 1; --b)
+        if (cm_body_parent[b] > 0) cfrc[cm_body_parent[b]] = cfrc[cm_body_parent[b]] + cfrc[b];
+    for (int d = 0; d < NV; ++d) w.bias[d] = sdot(w.cdof[d], cfrc[cm_dof_body[d]]);
+    // passive: joint springs (springref = 0) and dampers (mj_passive)
+    for (int d = 0; d < NV; ++d) {
+        const int j = cm_dof_jnt[d];
+        double f = -p.damping[d] * s.qvel[d];
+        if (cm_jnt_type[j] != 2) f -= cm_jnt_stiffness[j] * s.qpos[cm_jnt_qposadr[j]];
+        w.passive[d] = f;
+    }
+    // actuation: motors, ctrl clamped to ctrlrange, force = gear * ctrl (mj_fwdActuation)
+    for (int d = 0; d < NV; ++d) w.smooth[d] = w.passive[d] - w.bias[d];
+    for (int u = 0; u < NU; ++u) {
+        const double c = std::min(std::max(ctrl ? ctrl[u] : 0.0, -cm_act_ctrlmax[u]), cm_act_ctrlmax[u]);
+        w.smooth[cm_act_dof[u]] += cm_act_gear[u] * c;
+    }
+    cholesky(w.M, w.L);
+    double qacc_smooth[NV];
+    chol_solve(w.L, w.smooth, qacc_smooth);
+
+    // ------------------------------------------------------------------ constraint rows (mj_makeConstraint)
+    int n = 0;
+    Row* rows = w.rows;
+    for (int e = 0; e < NEQ; ++e) {   // connect equalities, cassie.xml:225-230
+        const int b1 = cm_eq_body1[e], b2 = cm_eq_body2[e];
+        const V3 p1 = s.xpos[b1] + mul(s.xmat[b1], v3(cm_eq_anchor1 + 3 * e));
+        const V3 p2 = s.xpos[b2] + mul(s.xmat[b2], v3(cm_eq_anchor2 + 3 * e));
+        const V3 c = p1 - p2;
+        for (int k = 0; k < 3; ++k) std::memset(rows[n + k].J, 0, sizeof(rows[n + k].J));
+        jac_point(w, b1, p1, rows[n].J, rows[n + 1].J, rows[n + 2].J, 1.0);
+        jac_point(w, b2, p2, rows[n].J, rows[n + 1].J, rows[n + 2].J, -1.0);
+        const double cp[3] = {c.x, c.y, c.z};
+        const double tran = p.body_invweight0[b1][0] + p.body_invweight0[b2][0];
+        for (int k = 0; k < 3; ++k) {
+            rows[n + k].pos = cp[k]; rows[n + k].type = 0; rows[n + k].diag = tran;
+            finish_row(rows[n + k], s.qvel, norm(c), 0.005, 1.0);
+        }
+        n += 3;
+    }
+    int nlim = 0;
+    for (int j = 0; j < NJ && nlim < MAXLIM; ++j) {   // joint limits (mj_instantiateLimit), solreflimit default 0.02 1
+        if (!cm_jnt_limited[j]) continue;
+        const double q = s.qpos[cm_jnt_qposadr[j]];
+        for (int side = 0; side < 2 && nlim < MAXLIM; ++side) {
+            const double dist = side == 0 ? q - cm_jnt_range[2 * j] : cm_jnt_range[2 * j + 1] - q;
+            if (dist >= 0) continue;
+            Row& r = rows[n];
+            std::memset(r.J, 0, sizeof(r.J));
+            r.J[cm_jnt_dofadr[j]] = side == 0 ? 1.0 : -1.0;
+            r.pos = dist; r.type = 1; r.diag = p.dof_invweight0[cm_jnt_dofadr[j]];
+            finish_row(r, s.qvel, dist, 0.02, 1.0);
+            ++n; ++nlim;
+        }
+    }
+    // contacts: collision primitives vs the floor plane (mjc_PlaneSphere / mjc_PlaneCapsule), pyramidal cone, condim 3
+    const M3 Rf = q2m(p.floor_quat);
+    const V3 nrm = col(Rf, 2), p0 = v3(cm_floor_pos);
+    V3 t1 = std::fabs(nrm.y) < 0.5 ? V3{0, 1, 0} : V3{0, 0, 1};      // mju_makeFrame
+    t1 = t1 - nrm * dot(nrm, t1); t1 = t1 * (1.0 / norm(t1));
+    const V3 t2 = cross(nrm, t1);
+    s.ncon = 0;
+    int con_row[MAXCON];
+    for (int g = 0; g < NG && s.ncon < MAXCON; ++g) {
+        const int b = cm_geom_body[g];
+        const V3 c = s.xpos[b] + mul(s.xmat[b], v3(cm_geom_pos + 3 * g));
+        const V3 ax = mul(s.xmat[b], v3(cm_geom_axis + 3 * g));
+        const int nend = cm_geom_iscapsule[g] ? 2 : 1;
+        for (int e = 0; e < nend && s.ncon < MAXCON; ++e) {
+            const V3 ctr = cm_geom_iscapsule[g] ? c + ax * (e == 0 ? cm_geom_half[g] : -cm_geom_half[g]) : c;
+            const double dist = dot(ctr - p0, nrm) - cm_geom_radius[g];
+            if (dist >= 0) continue;
+            const V3 cp = ctr - nrm * (cm_geom_radius[g] + 0.5 * dist);
+            double Jx[NV] = {0}, Jy[NV] = {0}, Jz[NV] = {0};
+            jac_point(w, b, cp, Jx, Jy, Jz, 1.0);
+            const double mu = p.friction;
+            const double tran = p.body_invweight0[b][0];     // + world (0)
+            const V3 dirs[4] = {nrm + t1 * mu, nrm - t1 * mu, nrm + t2 * mu, nrm - t2 * mu};
+            con_row[s.ncon] = n; s.con_dist[s.ncon] = dist; s.con_geom[s.ncon] = g;
+            for (int k = 0; k < 4; ++k) {
+                Row& r = rows[n + k];
+                for (int d = 0; d < NV; ++d) r.J[d] = dirs[k].x * Jx[d] + dirs[k].y * Jy[d] + dirs[k].z * Jz[d];
+                r.pos = dist; r.type = 2; r.diag = tran + mu * mu * tran;
+                finish_row(r, s.qvel, dist, 0.005, 1.0);
+            }
+            // pyramidal regulariser: all rows of the contact share Rpy = 2 mu^2 R(first row), impratio = 1
+            const double Rpy = std::max(MINVAL, 2 * mu * mu * rows[n].R);
+            for (int k = 0; k < 4; ++k) rows[n + k].R = Rpy;
+            n += 4; ++s.ncon;
+        }
+    }
+    s.nefc = n;
+
+    // ------------------------------------------------------------------ dual problem + PGS (mj_projectConstraint, mj_solPGS)
+    static thread_local double MiJ[MAXEFC][NV], AR[MAXEFC][MAXEFC];
+    double b[MAXEFC], f[MAXEFC];
+    for (int i = 0; i < n; ++i) chol_solve(w.L, rows[i].J, MiJ[i]);
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j) {
+            double a = 0;
+            for (int d = 0; d < NV; ++d) a += rows[i].J[d] * MiJ[j][d];
+            AR[i][j] = a;
+        }
+        AR[i][i] += rows[i].R;
+        double a = 0;
+        for (int d = 0; d < NV; ++d) a += rows[i].J[d] * qacc_smooth[d];
+        b[i] = a - rows[i].aref;
+    }
+    // warm start from the previous qacc (mj_fwdConstraint + mj_constraintUpdate), kept only if it beats f = 0
+    for (int i = 0; i < n; ++i) {
+        double jar = -rows[i].aref;
+        for (int d = 0; d < NV; ++d) jar += rows[i].J[d] * s.qacc_warm[d];
+        double fi = -jar / rows[i].R;
+        if (rows[i].type != 0 && fi < 0) fi = 0;
+        f[i] = fi;
+    }
+    double cost = 0;
+    for (int i = 0; i < n; ++i) {
+        double a = 0;
+        for (int j = 0; j < n; ++j) a += AR[i][j] * f[j];
+        cost += f[i] * (0.5 * a + b[i]);
+    }
+    if (cost > 0) for (int i = 0; i < n; ++i) f[i] = 0;
+    for (int it = 0; it < p.pgs_iters; ++it)
+        for (int i = 0; i < n; ++i) {
+            double res = b[i];
+            for (int j = 0; j < n; ++j) res += AR[i][j] * f[j];
+            double fi = f[i] - res / AR[i][i];
+            if (rows[i].type != 0 && fi < 0) fi = 0;
+            f[i] = fi;
+        }
+    for (int d = 0; d < NV; ++d) {
+        double a = qacc_smooth[d];
+        for (int i = 0; i < n; ++i) a += MiJ[i][d] * f[i];
+        s.qacc[d] = a;
+    }
+    for (int i = 0; i < n; ++i) s.efc_force[i] = f[i];
+    // contact force on the foot bodies in world axes (cassie_sim_foot_forces: mj_contactForce summed per foot body)
+    std::memset(s.foot_force, 0, sizeof(s.foot_force));
+    for (int c = 0; c < s.ncon; ++c) {
+        const int b = cm_geom_body[s.con_geom[c]];
+        const int foot = b == 13 ? 0 : (b == 25 ? 1 : -1);
+        if (foot < 0) continue;
+        const double* ff = f + con_row[c];
+        const double fn = ff[0] + ff[1] + ff[2] + ff[3], f1 = p.friction * (ff[0] - ff[1]), f2 = p.friction * (ff[2] - ff[3]);
+        const V3 F = nrm * fn + t1 * f1 + t2 * f2;
+        s.foot_force[foot][0] += F.x; s.foot_force[foot][1] += F.y; s.foot_force[foot][2] += F.z;
+    }
+    // IMU (cassie.xml:265-268): gyro = pelvis angular velocity in the site (= pelvis) frame; accelerometer = classical
+    // acceleration of the site point minus gravity, site frame
+    {
+        SV A = cacc[0];
+        for (int d = 0; d < 6; ++d) A = A + w.cdofdot[d] * s.qvel[d] + w.cdof[d] * s.qacc[d];
+        const V3 r = mul(s.xmat[1], v3(cm_imu_pos));
+        const V3 om = w.cvel[1].a;
+        const V3 vp = w.cvel[1].l + cross(om, r);
+        const V3 a = A.l + cross(A.a, r) + cross(om, vp);
+        const M3& R = s.xmat[1];
+        s.sens_acc[0] = dot(col(R, 0), a); s.sens_acc[1] = dot(col(R, 1), a); s.sens_acc[2] = dot(col(R, 2), a);
+        s.sens_gyro[0] = s.qvel[3]; s.sens_gyro[1] = s.qvel[4]; s.sens_gyro[2] = s.qvel[5];
+    }
+}
+
+// mj_Euler: damping treated implicitly, (M + h D) a = M qacc; velocity first, then positions with the new velocity
+void euler(const Params& p, State& s, Work& w) {
+    double rhs[NV], a[NV];
+    for (int i = 0; i < NV; ++i) {
+        double acc = 0;
+        for (int j = 0; j < NV; ++j) acc += w.M[i][j] * s.qacc[j];
+        rhs[i] = acc;
+    }
+    static thread_local double MM[NV][NV], LL[NV][NV];
+    for (int i = 0; i < NV; ++i) {
+        for (int j = 0; j < NV; ++j) MM[i][j] = w.M[i][j];
+        MM[i][i] += DT * p.damping[i];
+    }
+    cholesky(MM, LL);
+    chol_solve(LL, rhs, a);
+    for (int d = 0; d < NV; ++d) { s.qacc_warm[d] = s.qacc[d]; s.qvel[d] += DT * a[d]; }
+    for (int j = 0; j < NJ; ++j) {
+        const int qa = cm_jnt_qposadr[j], da = cm_jnt_dofadr[j];
+        if (cm_jnt_type[j] != 2) { s.qpos[qa] += DT * s.qvel[da]; continue; }
+        const V3 wv = {s.qvel[da], s.qvel[da + 1], s.qvel[da + 2]};      // local-frame angular velocity (mju_quatIntegrate)
+        const double ang = norm(wv) * DT;
+        Q4 q = {s.qpos[qa], s.qpos[qa + 1], s.qpos[qa + 2], s.qpos[qa + 3]};
+        if (ang > 0) q = qmul(q, qaxisangle(wv * (1.0 / norm(wv)), ang));
+        q = qnormalize(q);
+        s.qpos[qa] = q.w; s.qpos[qa + 1] = q.x; s.qpos[qa + 2] = q.y; s.qpos[qa + 3] = q.z;
+    }
+}
+
+double constraint_violation(const State& s) {
+    double m = 0;
+    for (int e = 0; e < NEQ; ++e) {
+        const int b1 = cm_eq_body1[e], b2 = cm_eq_body2[e];
+        const V3 p1 = s.xpos[b1] + mul(s.xmat[b1], v3(cm_eq_anchor1 + 3 * e));
+        const V3 p2 = s.xpos[b2] + mul(s.xmat[b2], v3(cm_eq_anchor2 + 3 * e));
+        m = std::max(m, norm(p1 - p2));
+    }
+    return m;
+}
+
+double total_energy(const Params& p, const State& s0, Work& w) {
+    State s = s0;
+    kinematics(s.qpos, s, w);
+    inertias(p, s, w);
+    double ke = 0;
+    for (int i = 0; i < NV; ++i)
+        for (int j = 0; j < NV; ++j) ke += 0.5 * s.qvel[i] * w.M[i][j] * s.qvel[j];
+    double pe = 0;
+    for (int b = 1; b < NB; ++b) pe += p.mass[b] * GRAV * (s.xpos[b] + mul(s.xmat[b], v3(cm_body_ipos + 3 * b))).z;
+    for (int j = 0; j < NJ; ++j)
+        if (cm_jnt_type[j] != 2) pe += 0.5 * cm_jnt_stiffness[j] * s.qpos[cm_jnt_qposadr[j]] * s.qpos[cm_jnt_qposadr[j]];
+    return ke + pe;
+}
+
+}  // namespace orc

@@ -1,0 +1,133 @@
+// CPU ORACLE (test infrastructure only — see oracle/__init__.py): fp64 rigid-body step for the Cassie model.
+//
+// Restates, for the subset of features cassie.xml uses, the pipeline behind the reference's `cassie_sim_step_pd`
+// -> MuJoCo 2.00 `mj_step` (cassie/cassiemujoco/cassiemujoco.py:46-49).  MuJoCo 2.00 itself is a
+// closed-source, licence-gated third-party binary that is absent from /root/reference, so this follows MuJoCo's
+// PUBLISHED algorithm description (Computation chapter: kinematics, CRBA, RNE, soft-constraint model with
+// solref/solimp impedance, pyramidal friction cones, PGS on the dual, semi-implicit Euler with implicit joint
+// damping) and is anchored on the model file (cassie.xml) and the reference's call sites.
+// PARITY UNPINNED: no reference test, fixture or runnable binary pins a physics result.
+//
+// Deliberately written dense and simple (32x32 mass matrix, dense Jacobians, Cholesky) so that it shares no
+// structure with the HIP kernel it checks.
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+#include "cassie_model_gen.h"
+
+namespace orc {
+
+constexpr int NB = CM_NBODY, NV = CM_NV, NQ = CM_NQ, NJ = CM_NJNT, NG = CM_NGEOM, NEQ = CM_NEQ, NU = CM_NU;
+constexpr int MAXCON = 10;                         // contacts kept per step (deepest-first is NOT used: geom order)
+constexpr int MAXLIM = 8;                          // active joint-limit rows kept per step
+constexpr int MAXEFC = 3 * NEQ + MAXLIM + 4 * MAXCON;
+constexpr double MINVAL = 1e-15;
+constexpr double DT = 0.0005;                      // cassie.xml:5
+constexpr double GRAV = 9.81;
+
+struct V3 { double x, y, z; };
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline V3 v3(const double* p) { return {p[0], p[1], p[2]}; }
+inline double norm(V3 a) { return std::sqrt(dot(a, a)); }
+
+struct Q4 { double w, x, y, z; };
+inline Q4 qmul(Q4 a, Q4 b) {
+    return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+            a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+inline Q4 qnormalize(Q4 q) {
+    double n = std::sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    if (n < MINVAL) return {1, 0, 0, 0};
+    return {q.w / n, q.x / n, q.y / n, q.z / n};
+}
+inline Q4 qaxisangle(V3 axis, double ang) {
+    double s = std::sin(ang * 0.5);
+    return {std::cos(ang * 0.5), axis.x * s, axis.y * s, axis.z * s};
+}
+struct M3 { double m[9]; };   // row-major
+inline M3 q2m(Q4 q) {
+    double w = q.w, x = q.x, y = q.y, z = q.z;
+    return {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z),
+             1 - 2 * (x * x + z * z), 2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x),
+             1 - 2 * (x * x + y * y)}};
+}
+inline V3 mul(const M3& R, V3 v) {
+    return {R.m[0] * v.x + R.m[1] * v.y + R.m[2] * v.z, R.m[3] * v.x + R.m[4] * v.y + R.m[5] * v.z,
+            R.m[6] * v.x + R.m[7] * v.y + R.m[8] * v.z};
+}
+inline V3 col(const M3& R, int k) { return {R.m[k], R.m[3 + k], R.m[6 + k]}; }
+
+// spatial motion vector about the reference point o: [angular; linear velocity of the body point at o]
+struct SV { V3 a, l; };
+inline SV operator+(SV p, SV q) { return {p.a + q.a, p.l + q.l}; }
+inline SV operator*(SV p, double s) { return {p.a * s, p.l * s}; }
+inline SV crossMotion(SV v, SV s) { return {cross(v.a, s.a), cross(v.a, s.l) + cross(v.l, s.a)}; }
+inline SV crossForce(SV v, SV f) { return {cross(v.a, f.a) + cross(v.l, f.l), cross(v.a, f.l)}; }
+inline double sdot(SV m, SV f) { return dot(m.a, f.a) + dot(m.l, f.l); }
+
+// spatial inertia about o (world axes): mass, first moment h = m*r, rotational inertia about o (symmetric 3x3)
+struct SI { double m; V3 h; double I[6]; };   // I: xx yy zz xy xz yz
+inline SI operator+(SI p, SI q) {
+    SI r{p.m + q.m, p.h + q.h, {}};
+    for (int i = 0; i < 6; ++i) r.I[i] = p.I[i] + q.I[i];
+    return r;
+}
+inline V3 symmul(const double* I, V3 v) {
+    return {I[0] * v.x + I[3] * v.y + I[4] * v.z, I[3] * v.x + I[1] * v.y + I[5] * v.z,
+            I[4] * v.x + I[5] * v.y + I[2] * v.z};
+}
+// force = I * motion  ->  [moment about o; force]
+inline SV imul(const SI& s, SV v) { return {symmul(s.I, v.a) + cross(s.h, v.l), v.l * s.m - cross(s.h, v.a)}; }
+
+struct Params {                  // per-env model parameters touched by dynamics randomisation (cassie.py:568-657)
+    double mass[NB];
+    double damping[NV];
+    double friction;             // sliding friction of every geom (floor wins by priority, cassie.xml:73)
+    Q4 floor_quat;               // set_geom_quat(floor), cassie.py:644-648
+    double body_invweight0[NB][2];
+    double dof_invweight0[NV];
+    int pgs_iters;
+};
+
+struct Row { double J[NV]; double pos, vel, R, aref, diag; int type; };   // type 0 equality, 1 limit, 2 contact
+
+struct State {
+    double qpos[NQ], qvel[NV], qacc_warm[NV];
+    // products of the most recent forward pass (evaluated at the PRE-integration state, like mjData after mj_step)
+    V3 xpos[NB]; Q4 xquat[NB]; M3 xmat[NB];
+    double qacc[NV];
+    int ncon, nefc;
+    double efc_force[MAXEFC];
+    double foot_force[2][3];     // world contact force on the left / right foot body
+    double sens_acc[3];          // accelerometer at the imu site (cassie.xml:267), sensor frame
+    double sens_gyro[3];
+    double con_dist[MAXCON]; int con_geom[MAXCON];
+};
+
+struct Work {
+    SV cdof[NV], cdofdot[NV], cvel[NB];
+    SI cinert[NB], crb[NB];
+    double M[NV][NV], L[NV][NV];
+    double bias[NV], passive[NV], smooth[NV];
+    Row rows[MAXEFC];
+    V3 anchor[NJ];
+    V3 o;
+};
+
+void default_params(Params& p);
+void set_const(Params& p);                                        // mj_setConst subset: invweight0 at qpos0
+void reset_state(State& s);                                       // cassie_sim_set_const: init qpos, zero qvel
+void forward(const Params& p, State& s, Work& w, const double* ctrl);   // mj_forward (ctrl = actuator-side torque)
+void euler(const Params& p, State& s, Work& w);                   // mj_Euler with implicit joint damping
+inline void step(const Params& p, State& s, Work& w, const double* ctrl) { forward(p, s, w, ctrl); euler(p, s, w); }
+
+// diagnostics used by the invariant tests
+double constraint_violation(const State& s);                      // max |p1-p2| over the 4 connect constraints
+double total_energy(const Params& p, const State& s, Work& w);    // kinetic + gravity + spring potential
+
+}  // namespace orc

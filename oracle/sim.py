@@ -1,0 +1,133 @@
+"""ctypes front-end of the fp64 C++ oracle (oracle/_build/liboracle.so).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            subprocess.check_call(["make", "-C", _HERE])
+        L = C.CDLL(_SO)
+        L.orc_env_new.restype = C.c_void_p
+        L.orc_env_new.argtypes = [C.c_int] * 7 + [C.c_uint64, C.c_uint32]
+        L.orc_env_free.argtypes = [C.c_void_p]
+        L.orc_env_reset.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_env_step.restype = C.c_int
+        L.orc_env_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_env_substep.argtypes = [C.c_void_p]
+        L.orc_env_obs.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_phys_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_phys_forward.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_constraint_violation.restype = C.c_double
+        L.orc_constraint_violation.argtypes = [C.c_void_p]
+        L.orc_total_energy.restype = C.c_double
+        L.orc_total_energy.argtypes = [C.c_void_p]
+        L.orc_env_get.restype = C.c_int
+        L.orc_env_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+        L.orc_env_set.restype = C.c_int
+        L.orc_env_set.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+        L.orc_env_set_const.argtypes = [C.c_void_p]
+        L.orc_clock_eval.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]
+        L.orc_clock_reward_eval.restype = C.c_double
+        L.orc_clock_reward_eval.argtypes = [C.c_void_p] * 11
+        L.orc_philox.restype = C.c_uint32
+        L.orc_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+        L.orc_rollout_bench.restype = C.c_double
+        L.orc_rollout_bench.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_double]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleEnv:
+    def __init__(self, simrate=50, dyn_rand=True, reward_kind=0, stance_mode=0, incentive=True, max_traj_len=400,
+                 pgs_iters=50, seed=0, env_id=0):
+        self.h = lib().orc_env_new(simrate, int(dyn_rand), reward_kind, stance_mode, int(incentive), max_traj_len,
+                                   pgs_iters, seed, env_id)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_env_free(self.h)
+            self.h = None
+
+    def reset(self):
+        obs = np.zeros(50)
+        lib().orc_env_reset(self.h, _ptr(obs))
+        return obs
+
+    def step(self, action):
+        a = np.ascontiguousarray(action, dtype=np.float64)
+        obs = np.zeros(50); rew = np.zeros(1)
+        done = lib().orc_env_step(self.h, _ptr(a), _ptr(obs), _ptr(rew))
+        return obs, float(rew[0]), done
+
+    def substep(self):
+        lib().orc_env_substep(self.h)
+
+    def obs(self):
+        o = np.zeros(50)
+        lib().orc_env_obs(self.h, _ptr(o))
+        return o
+
+    def phys_step(self, ctrl, n=1):
+        c = np.ascontiguousarray(ctrl, dtype=np.float64)
+        lib().orc_phys_step(self.h, _ptr(c), n)
+
+    def phys_forward(self, ctrl=None):
+        c = np.zeros(10) if ctrl is None else np.ascontiguousarray(ctrl, dtype=np.float64)
+        lib().orc_phys_forward(self.h, _ptr(c))
+
+    def get(self, name):
+        buf = np.zeros(128)
+        n = lib().orc_env_get(self.h, name.encode(), _ptr(buf))
+        if n < 0:
+            raise KeyError(name)
+        return buf[:n].copy()
+
+    def set(self, name, val):
+        v = np.ascontiguousarray(np.asarray(val, dtype=np.float64).reshape(-1))
+        buf = np.zeros(128); buf[:v.size] = v
+        n = lib().orc_env_set(self.h, name.encode(), _ptr(buf))
+        if n < 0:
+            raise KeyError(name)
+
+    def clock_reward_eval(self, qpos, qvel, scal, foot_vel, rotvel, tacc, torque, prev_torque, prev_action, action):
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in
+                (qpos, qvel, scal, foot_vel, rotvel, tacc, torque, prev_torque, prev_action, action)]
+        return lib().orc_clock_reward_eval(self.h, *[_ptr(a) for a in arrs])
+
+    def set_const(self):
+        lib().orc_env_set_const(self.h)
+
+    def violation(self):
+        return lib().orc_constraint_violation(self.h)
+
+    def energy(self):
+        return lib().orc_total_energy(self.h)
+
+
+def clock_eval(swing, stance, relax, mode, inc, freq, phases):
+    ph = np.ascontiguousarray(phases, dtype=np.float64)
+    out = np.zeros((len(ph), 4)); pl = np.zeros(1)
+    lib().orc_clock_eval(swing, stance, relax, mode, int(inc), freq, len(ph), _ptr(ph), _ptr(out), _ptr(pl))
+    return out, float(pl[0])
+
+
+def philox(seed, env, ctr):
+    return lib().orc_philox(seed, env, ctr)
+
+
+def rollout_bench(n_envs, n_steps, threads, seed=0, act_std=0.2):
+    return lib().orc_rollout_bench(n_envs, n_steps, threads, seed, act_std)
