@@ -1,12 +1,823 @@
-// placeholder until the physics kernel lands (next commit)
+// Batched Cassie-v0 environment for gfx950: one HIP launch = one env step (simrate physics substeps at 2 kHz,
+// reward, termination, command resampling, observation, optional auto-reset) for every env on the GPU.
+//
+// Replaces cassie/cassie.py:293-496,523-680,787-859 + cassie/rewards/clock_rewards.py:6-110 +
+// cassie/phase_function.py:5-136 and the per-env ctypes FFI below them (cassie/cassiemujoco/cassiemujoco.py).
+//
+// Layout: env-per-lane.  All persistent state is SoA in HBM, field-major: st[field * n_envs + env], so every load
+// and store of a field is one coalesced 256-B transaction per wave.  Algorithmic HBM traffic per env step is the
+// state read + write (2 * F_TOTAL * 4 B ~ 4.7 KB) + action/obs/reward I/O (246 B): the kernel is VALU/LDS bound
+// (DESIGN.md §6), not HBM bound.
 #include "apx_common.h"
-extern "C" void apx_env_default_cfg(apx_env_cfg* c) { if (c) { *c = apx_env_cfg{}; c->n_envs = 4096; c->simrate = 50; c->dynamics_randomization = 1; c->have_incentive = 1; c->max_traj_len = 400; c->pgs_iters = 50; } }
-#define NI(name, ...) extern "C" int name(__VA_ARGS__) { apx_set_error(#name ": not implemented yet"); return APX_E_STATE; }
-NI(apx_env_create, const apx_env_cfg*, apx_env_t**)
-NI(apx_env_destroy, apx_env_t*)
-NI(apx_env_reset, apx_env_t*, const uint8_t*, float*, void*)
-NI(apx_env_step, apx_env_t*, const float*, float*, float*, uint8_t*, float*, int, void*)
-NI(apx_env_get_state, apx_env_t*, float*, float*, void*)
-NI(apx_env_set_state, apx_env_t*, const float*, const float*, void*)
-NI(apx_env_get_field, apx_env_t*, const char*, float*, void*)
-NI(apx_env_set_field, apx_env_t*, const char*, const float*, void*)
+#include "cassie_dev.h"
+#include <new>
+#include <cstring>
+
+using namespace cas;
+
+// ------------------------------------------------------------------------------------------------ state layout
+enum Field : int {
+    F_QPOS = 0, F_QVEL = F_QPOS + NQ, F_QACCW = F_QVEL + NV, F_MASS = F_QACCW + NV, F_DAMP = F_MASS + NB,
+    F_FRIC = F_DAMP + NV, F_FLOOR = F_FRIC + 1 /* n, t1, t2: 9 */, F_BIW = F_FLOOR + 9, F_DIW = F_BIW + NB,
+    F_MNOISE = F_DIW + NV, F_JNOISE = F_MNOISE + 10, F_PDT = F_JNOISE + 6, F_FIFO = F_PDT + 10, F_MENC = F_FIFO + 60,
+    F_JENCX = F_MENC + 90, F_JENCY = F_JENCX + 24, F_SNAP = F_JENCY + 12 /* mpos10 jpos6 quat4 gyro3 acc3 vel3 pz1 */,
+    F_SO = F_SNAP + 30 /* mpos10 mvel10 torque10 jpos6 jvel6 quat4 rotvel3 tvel3 tacc3 height1 */, F_FOOTPREV = F_SO + 56,
+    F_FOOTVEL = F_FOOTPREV + 6, F_PREVACT = F_FOOTVEL + 6, F_PREVTQ = F_PREVACT + 10,
+    F_CMD = F_PREVTQ + 10 /* speed side orient swing stance phaselen */, F_FWD = F_CMD + 6 /* foot force z L,R; foot quat L4 R4; foot pos 6 */,
+    F_TOTAL = F_FWD + 16
+};
+enum SnapOff { SN_MPOS = 0, SN_JPOS = 10, SN_QUAT = 16, SN_GYRO = 20, SN_ACC = 23, SN_VEL = 26, SN_PZ = 29 };
+enum SoOff { SO_MPOS = 0, SO_MVEL = 10, SO_TORQUE = 20, SO_JPOS = 30, SO_JVEL = 36, SO_QUAT = 42, SO_ROTVEL = 46, SO_TVEL = 49, SO_TACC = 52, SO_HEIGHT = 55 };
+enum IField : int { I_TIME = 0, I_PHASE, I_COUNTER, I_RNG, I_FLAGS /* bit0 menc primed, 1 jenc primed, 2 prev_action, 3 prev_torque */, I_TOTAL };
+
+struct apx_env {
+    apx_env_cfg cfg;
+    float* st;      // [F_TOTAL, n]
+    int* ist;       // [I_TOTAL, n]
+    int n;
+};
+
+struct St {
+    float* p; int* ip; int n, env;
+    __device__ __forceinline__ float& operator()(int f) const { return p[(size_t)f * n + env]; }
+    __device__ __forceinline__ int& I(int f) const { return ip[(size_t)f * n + env]; }
+};
+
+struct Cfg { int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi; };
+
+// ------------------------------------------------------------------------------------------------ Philox4x32-10
+__device__ __forceinline__ unsigned philox(unsigned k0, unsigned k1, unsigned env, unsigned ctr) {
+    unsigned c0 = ctr, c1 = env, c2 = 0x41505845u, c3 = 0;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+struct Rng {
+    unsigned k0, k1, env, ctr;
+    __device__ __forceinline__ unsigned u32() { return philox(k0, k1, env, ctr++); }
+    __device__ __forceinline__ float u01() { return ((float)(u32() >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+    __device__ __forceinline__ float uniform(float a, float b) { return a + (b - a) * u01(); }
+    __device__ __forceinline__ unsigned randint(unsigned n) { return (unsigned)(((unsigned long long)u32() * n) >> 32); }
+};
+
+// ------------------------------------------------------------------------------------------------ forward dynamics
+__device__ __forceinline__ void load_dyn(const St& S, Dyn& dy) {
+    for (int b = 0; b < NB; ++b) { dy.mass[b] = S(F_MASS + b); dy.biw[b] = S(F_BIW + b); }
+    for (int d = 0; d < NV; ++d) { dy.damping[d] = S(F_DAMP + d); dy.diw[d] = S(F_DIW + d); }
+    dy.friction = S(F_FRIC);
+    dy.fn = {S(F_FLOOR), S(F_FLOOR + 1), S(F_FLOOR + 2)};
+    dy.ft1 = {S(F_FLOOR + 3), S(F_FLOOR + 4), S(F_FLOOR + 5)};
+    dy.ft2 = {S(F_FLOOR + 6), S(F_FLOOR + 7), S(F_FLOOR + 8)};
+}
+
+// mj_forward for the current (qpos, qvel); ctrl = actuator-side torques.  Leaves qacc, u~ + z~, LD, M in `w`.
+__device__ void forward(const St& S, const Dyn& dy, Work& w, const Rows& Y, const float* ctrl, int pgs_iters) {
+    kin_crba([&](int i) { return S(F_QPOS + i); }, dy, w);
+    float qvel[NV];
+    for (int d = 0; d < NV; ++d) qvel[d] = S(F_QVEL + d);
+    // velocities + bias forces (mj_comVel + mj_rne with qacc = 0, base acceleration = -gravity)
+    SV cacc[NB], cfrc[NB];
+    w.cvel[0] = {{0, 0, 0}, {0, 0, 0}};
+    cacc[0] = {{0, 0, 0}, {0, 0, GRAV}};
+    {
+        int j = 0;
+        for (int b = 1; b < NB; ++b) {
+            const int p = cm_body_parent[b];
+            SV v = w.cvel[p], a = cacc[p];
+            while (j < NJ && cm_jnt_body[j] == b) {
+                const int d0 = cm_jnt_dofadr[j], nd = cm_jnt_type[j] == 2 ? 3 : 1;
+                const SV vpar = v;                                    // ball: all three cdofdot use the same velocity
+                for (int k = 0; k < nd; ++k) {
+                    a = a + crossMotion(vpar, w.cdof[d0 + k]) * qvel[d0 + k];
+                    v = v + w.cdof[d0 + k] * qvel[d0 + k];
+                }
+                ++j;
+            }
+            w.cvel[b] = v; cacc[b] = a;
+            cfrc[b] = imul(w.crb[b], a) + crossForce(v, imul(w.crb[b], v));
+        }
+    }
+    for (int b = NB - 1; b >= 2; --b) cfrc[cm_body_parent[b]] = cfrc[cm_body_parent[b]] + cfrc[b];
+    crba(w);
+    // qfrc_smooth = passive - bias + actuation
+    for (int d = 0; d < NV; ++d) {
+        const int j = cm_dof_jnt[d];
+        float f = -dy.damping[d] * qvel[d] - sdot(w.cdof[d], cfrc[cm_dof_body[d]]);
+        if (cm_jnt_type[j] != 2) f -= cm_jnt_stiffness[j] * S(F_QPOS + cm_jnt_qposadr[j]);
+        w.smooth[d] = f;
+    }
+    for (int u = 0; u < NU; ++u) {
+        const float c = fminf(fmaxf(ctrl[u], -cm_act_ctrlmax[u]), cm_act_ctrlmax[u]);
+        w.smooth[cm_act_dof[u]] += cm_act_gear[u] * c;
+    }
+    for (int i = 0; i < NM; ++i) w.LD[i] = w.M[i];
+    factor(w.LD, w.dsqrt, w.disqrt);
+    for (int d = 0; d < NV; ++d) w.ut[d] = w.smooth[d];
+    solve_LT(w.LD, w.ut);
+    for (int d = 0; d < NV; ++d) w.ut[d] *= w.disqrt[d];
+    float vt[NV], wt[NV], tmp[NV];
+    mul_L(w.LD, qvel, vt);
+    for (int d = 0; d < NV; ++d) { vt[d] *= w.dsqrt[d]; tmp[d] = S(F_QACCW + d); }
+    mul_L(w.LD, tmp, wt);
+    for (int d = 0; d < NV; ++d) wt[d] *= w.dsqrt[d];
+
+    // ---------------------------------------------------------------- constraint rows
+    int n = 0;
+    float jar[MAXEFC];
+    for (int e = 0; e < NEQ; ++e) {   // connect equalities (cassie.xml:225-230)
+        const int b1 = cm_eq_body1[e], b2 = cm_eq_body2[e], leg = b1 >= 14 ? 1 : 0;
+        const V3 p1 = w.xpos[b1] + mul(w.xmat[b1], ld3(cm_eq_anchor1 + 3 * e));
+        const V3 p2 = w.xpos[b2] + mul(w.xmat[b2], ld3(cm_eq_anchor2 + 3 * e));
+        const V3 c = p1 - p2;
+        float J[3][YW];
+        for (int k = 0; k < YW; ++k) J[0][k] = J[1][k] = J[2][k] = 0.f;
+        jac_point(w, b1, p1, 1.f, J[0], J[1], J[2]);
+        jac_point(w, b2, p2, -1.f, J[0], J[1], J[2]);
+        const float cp[3] = {c.x, c.y, c.z};
+        const float tran = dy.biw[b1] + dy.biw[b2], cn = sqrtf(dot(c, c));
+        for (int k = 0; k < 3; ++k) {
+            whiten_row(w, J[k], leg);
+            commit_row(w, Y, n, J[k], leg, 0, cp[k], cn, tran, 0.005f, vt, wt, &jar[n]);
+            ++n;
+        }
+    }
+    int nlim = 0;
+    for (int j = 0; j < NJ; ++j) {   // joint limits, solreflimit default (0.02, 1)
+        if (!cm_jnt_limited[j]) continue;
+        const float q = S(F_QPOS + cm_jnt_qposadr[j]);
+        for (int side = 0; side < 2; ++side) {
+            const float dist = side == 0 ? q - cm_jnt_range[2 * j] : cm_jnt_range[2 * j + 1] - q;
+            if (dist >= 0.f || nlim >= MAXLIM) continue;
+            const int d = cm_jnt_dofadr[j], leg = d >= 19 ? 1 : 0;
+            float J[YW];
+            for (int k = 0; k < YW; ++k) J[k] = 0.f;
+            J[dof2col(d)] = side == 0 ? 1.f : -1.f;
+            whiten_row(w, J, leg);
+            commit_row(w, Y, n, J, leg, 1, dist, dist, dy.diw[d], 0.02f, vt, wt, &jar[n]);
+            ++n; ++nlim;
+        }
+    }
+    w.ncon = 0;
+    const V3 p0 = ld3(cm_floor_pos);
+    for (int g = 0; g < NG; ++g) {   // collision primitives vs the floor plane, pyramidal cone (condim 3)
+        const int b = cm_geom_body[g], leg = b >= 14 ? 1 : 0;
+        const V3 c = w.xpos[b] + mul(w.xmat[b], ld3(cm_geom_pos + 3 * g));
+        const V3 ax = mul(w.xmat[b], ld3(cm_geom_axis + 3 * g));
+        const int nend = cm_geom_iscapsule[g] ? 2 : 1;
+        for (int e = 0; e < nend; ++e) {
+            const V3 ctr = cm_geom_iscapsule[g] ? c + ax * (e == 0 ? cm_geom_half[g] : -cm_geom_half[g]) : c;
+            const float dist = dot(ctr - p0, dy.fn) - cm_geom_radius[g];
+            if (dist >= 0.f || w.ncon >= MAXCON) continue;
+            const V3 cp = ctr - dy.fn * (cm_geom_radius[g] + 0.5f * dist);
+            float Jx[YW], Jy[YW], Jz[YW];
+            for (int k = 0; k < YW; ++k) Jx[k] = Jy[k] = Jz[k] = 0.f;
+            jac_point(w, b, cp, 1.f, Jx, Jy, Jz);
+            const float mu = dy.friction, tran = dy.biw[b];
+            const V3 dirs[4] = {dy.fn + dy.ft1 * mu, dy.fn - dy.ft1 * mu, dy.fn + dy.ft2 * mu, dy.fn - dy.ft2 * mu};
+            w.con_row[w.ncon] = n; w.con_geom[w.ncon] = (unsigned char)g;
+            for (int k = 0; k < 4; ++k) {
+                float J[YW];
+                for (int i = 0; i < YW; ++i) J[i] = dirs[k].x * Jx[i] + dirs[k].y * Jy[i] + dirs[k].z * Jz[i];
+                whiten_row(w, J, leg);
+                commit_row(w, Y, n + k, J, leg, 2, dist, dist, tran + mu * mu * tran, 0.005f, vt, wt, &jar[n + k]);
+            }
+            const float Rpy = fmaxf(MINVAL, 2.f * mu * mu * w.Rr[n]);     // pyramidal regulariser, impratio 1
+            for (int k = 0; k < 4; ++k) w.Rr[n + k] = Rpy;
+            n += 4; ++w.ncon;
+        }
+    }
+    w.nefc = n;
+
+    // ---------------------------------------------------------------- warm start + PGS in the whitened space
+    for (int d = 0; d < NV; ++d) w.zt[d] = 0.f;
+    float cost = 0.f;
+    for (int r = 0; r < n; ++r) {
+        float fr = -jar[r] / w.Rr[r];
+        if (w.typ[r] != 0 && fr < 0.f) fr = 0.f;
+        w.f[r] = fr;
+        const int leg = w.leg[r];
+        for (int k = 0; k < YW; ++k) w.zt[col2dof(k, leg)] += Y.at(r, k) * fr;
+        cost += fr * (0.5f * w.Rr[r] * fr + w.br[r]);
+    }
+    for (int d = 0; d < NV; ++d) cost += 0.5f * w.zt[d] * w.zt[d];
+    if (cost > 0.f) {
+        for (int r = 0; r < n; ++r) w.f[r] = 0.f;
+        for (int d = 0; d < NV; ++d) w.zt[d] = 0.f;
+    }
+    for (int it = 0; it < pgs_iters; ++it)
+        for (int r = 0; r < n; ++r) {
+            const int leg = w.leg[r];
+            float res = w.br[r] + w.Rr[r] * w.f[r];
+            for (int k = 0; k < YW; ++k) res += Y.at(r, k) * w.zt[col2dof(k, leg)];
+            float fr = w.f[r] - res / (w.diag[r] + w.Rr[r]);
+            if (w.typ[r] != 0 && fr < 0.f) fr = 0.f;
+            const float df = fr - w.f[r];
+            w.f[r] = fr;
+            for (int k = 0; k < YW; ++k) w.zt[col2dof(k, leg)] += Y.at(r, k) * df;
+        }
+    // qacc = L^-1 D^-1/2 (u~ + z~)
+    for (int d = 0; d < NV; ++d) w.qacc[d] = (w.ut[d] + w.zt[d]) * w.disqrt[d];
+    solve_L(w.LD, w.qacc);
+    // contact force on the foot bodies, world axes (cassie_sim_foot_forces)
+    for (int k = 0; k < 3; ++k) w.foot_force[0][k] = w.foot_force[1][k] = 0.f;
+    for (int c = 0; c < w.ncon; ++c) {
+        const int b = cm_geom_body[w.con_geom[c]];
+        if (b != 13 && b != 25) continue;
+        const float* ff = w.f + w.con_row[c];
+        const float fnn = ff[0] + ff[1] + ff[2] + ff[3], f1 = dy.friction * (ff[0] - ff[1]), f2 = dy.friction * (ff[2] - ff[3]);
+        const V3 F = dy.fn * fnn + dy.ft1 * f1 + dy.ft2 * f2;
+        float* o = w.foot_force[b == 13 ? 0 : 1];
+        o[0] += F.x; o[1] += F.y; o[2] += F.z;
+    }
+    // accelerometer at the imu site (cassie.xml:267): classical acceleration of the site point, site frame
+    {
+        SV A = cacc[1];
+        for (int d = 0; d < 6; ++d) A = A + w.cdof[d] * w.qacc[d];
+        const V3 r = mul(w.xmat[1], ld3(cm_imu_pos));
+        const V3 om = w.cvel[1].a;
+        const V3 vp = w.cvel[1].l + cross(om, r);
+        const V3 a = A.l + cross(A.a, r) + cross(om, vp);
+        const M3& R = w.xmat[1];
+        w.acc[0] = dot(col(R, 0), a); w.acc[1] = dot(col(R, 1), a); w.acc[2] = dot(col(R, 2), a);
+    }
+}
+
+// mj_Euler with implicit joint damping: (M + h D) a = qfrc_smooth + J^T f = L^T D^1/2 (u~ + z~)
+__device__ void euler(const St& S, const Dyn& dy, Work& w) {
+    float x[NV], rhs[NV];
+    for (int d = 0; d < NV; ++d) x[d] = (w.ut[d] + w.zt[d]) * w.dsqrt[d];
+    mul_LT(w.LD, x, rhs);
+    for (int i = 0; i < NM; ++i) w.LD[i] = w.M[i];
+    for (int d = 0; d < NV; ++d) w.LD[cm_dof_madr[d]] += DT * dy.damping[d];
+    factor(w.LD, nullptr, nullptr);
+    solve_LT(w.LD, rhs);
+    for (int d = 0; d < NV; ++d) rhs[d] /= w.LD[cm_dof_madr[d]];
+    solve_L(w.LD, rhs);
+    float qv[NV];
+    for (int d = 0; d < NV; ++d) { S(F_QACCW + d) = w.qacc[d]; qv[d] = S(F_QVEL + d) + DT * rhs[d]; S(F_QVEL + d) = qv[d]; }
+    for (int j = 0; j < NJ; ++j) {
+        const int qa = cm_jnt_qposadr[j], da = cm_jnt_dofadr[j];
+        if (cm_jnt_type[j] != 2) { S(F_QPOS + qa) += DT * qv[da]; continue; }
+        const V3 wv = {qv[da], qv[da + 1], qv[da + 2]};
+        const float nw = sqrtf(dot(wv, wv));
+        Q4 q = {S(F_QPOS + qa), S(F_QPOS + qa + 1), S(F_QPOS + qa + 2), S(F_QPOS + qa + 3)};
+        if (nw > 0.f) {
+            float sn, cs;
+            sincosf(0.5f * nw * DT, &sn, &cs);
+            const float s = sn / nw;
+            q = qmul(q, Q4{cs, wv.x * s, wv.y * s, wv.z * s});
+        }
+        q = qnormalize(q);
+        S(F_QPOS + qa) = q.w; S(F_QPOS + qa + 1) = q.x; S(F_QPOS + qa + 2) = q.y; S(F_QPOS + qa + 3) = q.z;
+    }
+}
+
+// mj_setConst subset at qpos0: translational body_invweight0 for the bodies that carry constraints and
+// dof_invweight0 for the limited joints, from the whitened rows (|y~|^2 = J M^-1 J^T)
+__device__ void set_const(const St& S, Dyn& dy, Work& w) {
+    kin_crba([&](int i) { return cm_qpos0[i]; }, dy, w);
+    crba(w);
+    for (int i = 0; i < NM; ++i) w.LD[i] = w.M[i];
+    factor(w.LD, w.dsqrt, w.disqrt);
+    for (int b = 1; b < NB; ++b) {
+        const int leg = b >= 14 ? 1 : 0;
+        float J[3][YW];
+        for (int k = 0; k < YW; ++k) J[0][k] = J[1][k] = J[2][k] = 0.f;
+        jac_point(w, b, w.xpos[b] + mul(w.xmat[b], ld3(cm_body_ipos + 3 * b)), 1.f, J[0], J[1], J[2]);
+        float tr = 0.f;
+        for (int a = 0; a < 3; ++a) {
+            whiten_row(w, J[a], leg);
+            for (int k = 0; k < YW; ++k) tr += J[a][k] * J[a][k];
+        }
+        dy.biw[b] = tr * (1.f / 3.f);
+        S(F_BIW + b) = dy.biw[b];
+    }
+    dy.biw[0] = 0.f; S(F_BIW) = 0.f;
+    for (int j = 0; j < NJ; ++j) {
+        const int d = cm_jnt_dofadr[j];
+        if (!cm_jnt_limited[j]) { const int nd = cm_jnt_type[j] == 2 ? 3 : 1; for (int k = 0; k < nd; ++k) { dy.diw[d + k] = 0.f; S(F_DIW + d + k) = 0.f; } continue; }
+        const int leg = d >= 19 ? 1 : 0;
+        float J[YW];
+        for (int k = 0; k < YW; ++k) J[k] = 0.f;
+        J[dof2col(d)] = 1.f;
+        whiten_row(w, J, leg);
+        float s = 0.f;
+        for (int k = 0; k < YW; ++k) s += J[k] * J[k];
+        dy.diw[d] = s; S(F_DIW + d) = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ native substep model
+__constant__ float kP[5] = {100.f, 100.f, 88.f, 96.f, 50.f};
+__constant__ float kD[5] = {10.f, 10.f, 8.f, 9.6f, 5.f};
+__constant__ float kOffset[10] = {0.0045f, 0.0f, 0.4973f, -1.1997f, -1.5968f, 0.0045f, 0.0f, 0.4973f, -1.1997f, -1.5968f};
+__constant__ float kNeutralFoot[4] = {-0.24790886454547323f, -0.24679713195445646f, -0.6609396704367185f, 0.663921021343526f};
+__constant__ float kTorqueLimit[5] = {140.63f, 140.63f, 216.16f, 216.16f, 45.14f};
+__constant__ float kFir[9] = {2727.f, 534.f, -2658.f, -795.f, 72.f, 110.f, 19.f, -6.f, -3.f};
+#define PI_F 3.14159265358979323846f
+
+// forward pass + sensor snapshot + per-forward accessor values (foot force / pose), no integration
+__device__ void forward_snapshot(const St& S, const Dyn& dy, Work& w, const Rows& Y, const float* ctrl, int pgs_iters) {
+    forward(S, dy, w, Y, ctrl, pgs_iters);
+    for (int u = 0; u < 10; ++u) S(F_SNAP + SN_MPOS + u) = S(F_QPOS + cm_act_qposadr[u]);
+    for (int k = 0; k < 6; ++k) S(F_SNAP + SN_JPOS + k) = S(F_QPOS + cm_jsens_qposadr[k]);
+    for (int k = 0; k < 4; ++k) S(F_SNAP + SN_QUAT + k) = S(F_QPOS + 3 + k);
+    for (int k = 0; k < 3; ++k) { S(F_SNAP + SN_GYRO + k) = S(F_QVEL + 3 + k); S(F_SNAP + SN_ACC + k) = w.acc[k]; S(F_SNAP + SN_VEL + k) = S(F_QVEL + k); }
+    S(F_SNAP + SN_PZ) = S(F_QPOS + 2);
+    S(F_FWD + 0) = w.foot_force[0][2]; S(F_FWD + 1) = w.foot_force[1][2];
+    S(F_FWD + 2) = w.xquat[13].w; S(F_FWD + 3) = w.xquat[13].x; S(F_FWD + 4) = w.xquat[13].y; S(F_FWD + 5) = w.xquat[13].z;
+    S(F_FWD + 6) = w.xquat[25].w; S(F_FWD + 7) = w.xquat[25].x; S(F_FWD + 8) = w.xquat[25].y; S(F_FWD + 9) = w.xquat[25].z;
+    S(F_FWD + 10) = w.xpos[13].x; S(F_FWD + 11) = w.xpos[13].y; S(F_FWD + 12) = w.xpos[13].z - 0.0550841220316708f;
+    S(F_FWD + 13) = w.xpos[25].x; S(F_FWD + 14) = w.xpos[25].y; S(F_FWD + 15) = w.xpos[25].z - 0.0550841220316708f;
+}
+
+// one 2 kHz substep: encoders + estimator -> PD -> safeties -> motor model / delay -> mj_step
+__device__ void sim_step_pd(const St& S, const Dyn& dy, Work& w, const Rows& Y, int pgs_iters) {
+    int flags = S.I(I_FLAGS);
+    float ctrl[10];
+    for (int u = 0; u < 10; ++u) {
+        // drive encoder: truncating quantiser + 9-tap FIR velocity
+        const float scale = 2.f * PI_F / (float)(1 << cm_act_bits[u]), gear = cm_act_gear[u];
+        const float nq = truncf(S(F_SNAP + SN_MPOS + u) * gear / scale);
+        float h[9];
+        if (!(flags & 1)) { for (int k = 0; k < 9; ++k) h[k] = nq; }
+        else { for (int k = 8; k > 0; --k) h[k] = S(F_MENC + u * 9 + k - 1); h[0] = nq; }
+        float acc = 0.f;
+        for (int k = 0; k < 9; ++k) { S(F_MENC + u * 9 + k) = h[k]; acc += kFir[k] * h[k]; }
+        const float mpos = nq * scale / gear, mvel = acc * scale / gear / PI_F;
+        S(F_SO + SO_MPOS + u) = mpos; S(F_SO + SO_MVEL + u) = mvel;
+        // pd_input_step -> cassie_core_sim_step clamp -> torque-speed curve -> 6-deep delay
+        float tau = kP[u % 5] * (S(F_PDT + u) - mpos) + kD[u % 5] * (0.f - mvel);
+        if (!(S.I(I_FLAGS) & 16)) tau = 0.f;       // pd_in_t zero until the first env.step (gains are set there)
+        tau = fminf(fmaxf(tau, -kTorqueLimit[u % 5]), kTorqueLimit[u % 5]);
+        const float wmax = cm_act_rpm[u] * 2.f * PI_F / 60.f, tmax = cm_act_ctrlmax[u];
+        const float om = fabsf(S(F_QVEL + cm_act_dof[u]) * gear);
+        const float tlim = fminf(fmaxf(2.f * tmax * (1.f - om / wmax), 0.f), tmax);
+        const float cmd = tau / gear;
+        const float un = (cmd < 0.f ? -1.f : 1.f) * fminf(fabsf(cmd), tlim);
+        float fifo[6];
+        for (int k = 5; k > 0; --k) fifo[k] = S(F_FIFO + u * 6 + k - 1);
+        fifo[0] = un;
+        for (int k = 0; k < 6; ++k) S(F_FIFO + u * 6 + k) = fifo[k];
+        ctrl[u] = fifo[5];
+        S(F_SO + SO_TORQUE + u) = gear * ctrl[u];
+    }
+    for (int k = 0; k < 6; ++k) {   // joint encoders: quantiser + biquad velocity
+        const float scale = 2.f * PI_F / (float)(1 << cm_jsens_bits[k]);
+        const float x = truncf(S(F_SNAP + SN_JPOS + k) / scale) * scale;
+        float xs[4], y0, y1;
+        if (!(flags & 2)) { xs[0] = xs[1] = xs[2] = xs[3] = x; y0 = y1 = 0.f; }
+        else { xs[0] = x; for (int i = 1; i < 4; ++i) xs[i] = S(F_JENCX + k * 4 + i - 1); y0 = S(F_JENCY + k * 2); y1 = S(F_JENCY + k * 2 + 1); }
+        const float y = 12.348f * (xs[0] + xs[1] - xs[2] - xs[3]) + 1.7658f * y0 - 0.79045f * y1;
+        for (int i = 0; i < 4; ++i) S(F_JENCX + k * 4 + i) = xs[i];
+        S(F_JENCY + k * 2) = y; S(F_JENCY + k * 2 + 1) = y0;
+        S(F_SO + SO_JPOS + k) = x; S(F_SO + SO_JVEL + k) = y;
+    }
+    S.I(I_FLAGS) = flags | 3;
+    // estimator: pass-through fields + estimator-lite for the 7 filtered ones
+    {
+        const Q4 q = {S(F_SNAP + SN_QUAT), S(F_SNAP + SN_QUAT + 1), S(F_SNAP + SN_QUAT + 2), S(F_SNAP + SN_QUAT + 3)};
+        for (int k = 0; k < 4; ++k) S(F_SO + SO_QUAT + k) = S(F_SNAP + SN_QUAT + k);
+        for (int k = 0; k < 3; ++k) { S(F_SO + SO_ROTVEL + k) = S(F_SNAP + SN_GYRO + k); S(F_SO + SO_TVEL + k) = S(F_SNAP + SN_VEL + k); }
+        const V3 aw = mul(q2m(q), V3{S(F_SNAP + SN_ACC), S(F_SNAP + SN_ACC + 1), S(F_SNAP + SN_ACC + 2)});
+        S(F_SO + SO_TACC) = aw.x; S(F_SO + SO_TACC + 1) = aw.y; S(F_SO + SO_TACC + 2) = aw.z - GRAV;
+        S(F_SO + SO_HEIGHT) = S(F_SNAP + SN_PZ) - cm_floor_pos[2];
+    }
+    forward_snapshot(S, dy, w, Y, ctrl, pgs_iters);
+    euler(S, dy, w);
+}
+
+// ------------------------------------------------------------------------------------------------ env logic
+struct ClockK { float x[8]; float phaselen; };
+__device__ __forceinline__ void clock_knots(float swing, float stance, int freq, ClockK& c) {
+    const float total = 2.f * swing + 2.f * stance;
+    c.phaselen = total * freq;
+    const float seg[5] = {0.f, swing, swing + stance, 2.f * swing + stance, total};
+    for (int s = 0; s < 4; ++s) {
+        const float a = seg[s] * freq, b = seg[s + 1] * freq, off = (b - a) * 0.1f;
+        c.x[2 * s] = a + off; c.x[2 * s + 1] = b - off;
+    }
+}
+// value of clock `which` (0 left_frc, 1 left_vel, 2 right_frc, 3 right_vel) on segment s (0 right swing, 1 dbl, 2 left swing, 3 dbl)
+__device__ __forceinline__ float clock_val(int which, int s, int mode, int inc) {
+    // reference arrays r_frc, r_vel, l_frc, l_vel (phase_function.py:16-96); "left" clock = the r_* pair (cassie.py:559)
+    float r_frc, r_vel, l_frc, l_vel;
+    const float pos = inc ? 1.f : 0.f;
+    if (s == 0) { l_vel = r_frc = -1.f; l_frc = r_vel = pos; }
+    else if (s == 2) { l_vel = r_frc = pos; l_frc = r_vel = -1.f; }
+    else if (mode == 2) { l_frc = r_frc = -1.f; l_vel = r_vel = pos; }
+    else if (mode == 0) { l_frc = r_frc = l_vel = r_vel = 0.f; }
+    else if (inc) { l_frc = r_frc = 1.f; l_vel = r_vel = -1.f; }
+    else if (s == 1) { r_frc = 0.f; l_frc = -1.f; r_vel = -1.f; l_vel = 0.f; }     // phase_function.py:54-55 quirk
+    else { l_frc = r_frc = 0.f; l_vel = r_vel = -1.f; }
+    return which == 0 ? r_frc : which == 1 ? r_vel : which == 2 ? l_frc : l_vel;
+}
+__device__ float clock_eval(const ClockK& c, int which, float ph, int mode, int inc) {
+    if (ph > c.x[0] + c.phaselen) ph -= c.phaselen;
+    // 10 knots: last of previous cycle, 8 of this cycle, first of the next
+    float xa = c.x[7] - c.phaselen, ya = clock_val(which, 3, mode, inc);
+    for (int i = 0; i < 9; ++i) {
+        const float xb = i < 8 ? c.x[i] : c.x[0] + c.phaselen;
+        const float yb = clock_val(which, i < 8 ? i / 2 : 0, mode, inc);
+        if (ph <= xb) {
+            if (ph < xa) return ya;
+            const float t = (ph - xa) / (xb - xa);
+            return ya + (yb - ya) * (3.f * t * t - 2.f * t * t * t);
+        }
+        xa = xb; ya = yb;
+    }
+    return ya;
+}
+
+__device__ __forceinline__ void yaw_inv_rotate3(float yaw, const float* v, float* out) {
+    float sz, cz;
+    sincosf(0.5f * yaw, &sz, &cz);
+    Q4 q = {cz, 0.f, 0.f, sz};
+    if (q.w < 0.f) q = {-q.w, 0.f, 0.f, -q.z};
+    const Q4 iq = {q.w, 0.f, 0.f, -q.z};
+    const Q4 r = qmul(iq, qmul(Q4{0.f, v[0], v[1], v[2]}, q));
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+// get_full_state (cassie/cassie.py:787-859), written straight to obs[env*50 ..]
+__device__ void write_obs(const St& S, const Cfg& cfg, float* o) {
+    const float yaw = S(F_CMD + 2);
+    o[0] = S(F_SO + SO_HEIGHT);
+    {
+        float sz, cz;
+        sincosf(0.5f * yaw, &sz, &cz);
+        Q4 q = {cz, 0.f, 0.f, sz};
+        if (q.w < 0.f) q = {-q.w, 0.f, 0.f, -q.z};
+        Q4 r = qmul(Q4{q.w, 0.f, 0.f, -q.z}, Q4{S(F_SO + SO_QUAT), S(F_SO + SO_QUAT + 1), S(F_SO + SO_QUAT + 2), S(F_SO + SO_QUAT + 3)});
+        if (r.w < 0.f) r = {-r.w, -r.x, -r.y, -r.z};
+        o[1] = r.w; o[2] = r.x; o[3] = r.y; o[4] = r.z;
+    }
+    for (int u = 0; u < 10; ++u) o[5 + u] = S(F_SO + SO_MPOS + u) + S(F_MNOISE + u);
+    float v[3];
+    for (int k = 0; k < 3; ++k) v[k] = S(F_SO + SO_TVEL + k);
+    yaw_inv_rotate3(yaw, v, o + 15);
+    for (int k = 0; k < 3; ++k) o[18 + k] = S(F_SO + SO_ROTVEL + k);
+    for (int u = 0; u < 10; ++u) o[21 + u] = S(F_SO + SO_MVEL + u);
+    for (int k = 0; k < 3; ++k) v[k] = S(F_SO + SO_TACC + k);
+    yaw_inv_rotate3(yaw, v, o + 31);
+    for (int k = 0; k < 6; ++k) o[34 + k] = S(F_SO + SO_JPOS + k) + S(F_JNOISE + k);
+    for (int k = 0; k < 6; ++k) o[40 + k] = S(F_SO + SO_JVEL + k);
+    const float ang = 2.f * PI_F * (float)S.I(I_PHASE) / S(F_CMD + 5);
+    o[46] = sinf(ang); o[47] = cosf(ang);
+    o[48] = S(F_CMD + 0); o[49] = S(F_CMD + 1);
+}
+
+__device__ __forceinline__ void clock_from_speed(const St& S, float speed, int freq) {   // cassie.py:556-559
+    const float total = (0.9f - 0.25f / 3.0f * fabsf(speed)) * 0.5f;
+    const float swing = (0.30f + ((0.70f - 0.30f) / 3.f) * fabsf(speed)) * total;
+    const float stance = (0.70f - ((0.70f - 0.30f) / 3.f) * fabsf(speed)) * total;
+    S(F_CMD + 3) = swing; S(F_CMD + 4) = stance; S(F_CMD + 5) = (2.f * swing + 2.f * stance) * freq;
+}
+
+// CassieEnv.reset (cassie/cassie.py:523-680)
+__device__ void env_reset(const St& S, const Cfg& cfg, Dyn& dy, Work& w, const Rows& Y) {
+    Rng r{cfg.seed_lo, cfg.seed_hi, (unsigned)S.env, (unsigned)S.I(I_RNG)};
+    const float speed0 = r.uniform(-0.3f, 4.0f);
+    (void)r.uniform(-0.3f, 0.3f);
+    clock_from_speed(S, speed0, 2000 / cfg.simrate);
+    S.I(I_PHASE) = (int)r.randint((unsigned)floorf(S(F_CMD + 5)) + 1u);
+    S.I(I_TIME) = 0; S.I(I_COUNTER) = 0;
+    if (cfg.dyn_rand) {
+        for (int d = 0; d < 6; ++d) { (void)r.u01(); S(F_DAMP + d) = cm_dof_damping[d]; }
+        for (int leg = 0; leg < 2; ++leg)
+            for (int k = 0; k < 13; ++k) {
+                const int d = 6 + 13 * leg + k;
+                const float u = r.u01();
+                const bool vary = !(k == 9 || k == 11);                  // heel-spring, plantar-rod keep their damping
+                const float lo = vary ? 0.3f : 1.f, hi = vary ? 5.f : 1.f;
+                S(F_DAMP + d) = fmaxf(0.f, cm_dof_damping[d] * (lo + (hi - lo) * u));
+            }
+        (void)r.u01(); S(F_MASS) = 0.f;
+        for (int b = 1; b < NB; ++b) S(F_MASS + b) = fmaxf(0.f, cm_body_mass[b] * r.uniform(0.5f, 1.5f));
+        S(F_FRIC) = r.uniform(0.4f, 1.1f); (void)r.u01(); (void)r.u01();
+        const float roll = r.uniform(-0.03f, 0.03f), pitch = r.uniform(-0.03f, 0.03f);
+        float sy, cy, sx, cx;
+        sincosf(0.5f * pitch, &sy, &cy); sincosf(0.5f * roll, &sx, &cx);
+        Q4 fq = {cx * cy, cy * sx, cx * sy, sx * sy};
+        if (fq.w < 0.f) fq = {-fq.w, -fq.x, -fq.y, -fq.z};
+        const M3 Rf = q2m(fq);
+        const V3 nrm = col(Rf, 2);
+        V3 t1 = fabsf(nrm.y) < 0.5f ? V3{0.f, 1.f, 0.f} : V3{0.f, 0.f, 1.f};
+        t1 = t1 - nrm * dot(nrm, t1); t1 = t1 * rsqrtf(dot(t1, t1));
+        const V3 t2 = cross(nrm, t1);
+        const float fl[9] = {nrm.x, nrm.y, nrm.z, t1.x, t1.y, t1.z, t2.x, t2.y, t2.z};
+        for (int k = 0; k < 9; ++k) S(F_FLOOR + k) = fl[k];
+        for (int u = 0; u < 10; ++u) S(F_MNOISE + u) = r.uniform(-0.01f, 0.01f);
+        for (int k = 0; k < 6; ++k) S(F_JNOISE + k) = r.uniform(-0.01f, 0.01f);
+        load_dyn(S, dy);
+        set_const(S, dy, w);
+    }
+    for (int i = 0; i < NQ; ++i) S(F_QPOS + i) = cm_init_qpos[i];
+    for (int i = 0; i < NV; ++i) { S(F_QVEL + i) = 0.f; S(F_QACCW + i) = 0.f; }
+    float zero[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    forward_snapshot(S, dy, w, Y, zero, cfg.pgs_iters);       // cassie_sim_set_const ends in mj_forward
+    sim_step_pd(S, dy, w, Y, cfg.pgs_iters);                  // cassie.py:665 (stale pd_in_t)
+    for (int k = 0; k < 6; ++k) S(F_FOOTPREV + k) = S(F_FWD + 10 + k);
+    S(F_CMD + 2) = 0.f;
+    S(F_CMD + 0) = r.uniform(-0.3f, 4.0f);
+    S(F_CMD + 1) = r.uniform(-0.3f, 0.3f);
+    S.I(I_RNG) = (int)r.ctr;
+}
+
+// clock_reward (cassie/rewards/clock_rewards.py:6-110)
+__device__ float clock_reward(const St& S, const Cfg& cfg, const float* action, float lfrc, float rfrc, float lor, float ror) {
+    const float fmax = 250.f, vmax = 2.0f;
+    const float nlf = fminf(lfrc, fmax) / fmax, nrf = fminf(rfrc, fmax) / fmax;
+    float lv = 0.f, rv = 0.f;
+    for (int k = 0; k < 3; ++k) { lv += S(F_FOOTVEL + k) * S(F_FOOTVEL + k); rv += S(F_FOOTVEL + 3 + k) * S(F_FOOTVEL + 3 + k); }
+    const float nlv = fminf(sqrtf(lv), vmax) / vmax, nrv = fminf(sqrtf(rv), vmax) / vmax;
+    const float qw = S(F_QPOS + 3), speed = S(F_CMD);
+    const float com_orient = 10.f * (1.f - qw * qw), foot_orient = 10.f * (lor + ror);
+    const float com_vel_err = fabsf(S(F_QVEL) - speed);
+    float straight = fabsf(S(F_QPOS + 1));
+    if (straight < 0.05f) straight = 0.f;
+    float hdiff = fabsf(S(F_QPOS + 2) - 0.9f);
+    if (hdiff < 0.05f + 0.05f * speed) hdiff = 0.f;
+    float pacc = 0.f;
+    for (int k = 0; k < 3; ++k) pacc += fabsf(S(F_SO + SO_ROTVEL + k)) + fabsf(S(F_SO + SO_TACC + k));
+    const float pelvis_motion = straight + hdiff + 0.25f * pacc;
+    ClockK ck;
+    clock_knots(S(F_CMD + 3), S(F_CMD + 4), 2000 / cfg.simrate, ck);
+    const float ph = (float)S.I(I_PHASE);
+    const float lfc = clock_eval(ck, 0, ph, cfg.stance_mode, cfg.incentive), lvc = clock_eval(ck, 1, ph, cfg.stance_mode, cfg.incentive);
+    const float rfc = clock_eval(ck, 2, ph, cfg.stance_mode, cfg.incentive), rvc = clock_eval(ck, 3, ph, cfg.stance_mode, cfg.incentive);
+    const float frc_score = tanf(PI_F / 4.f * lfc * nlf) + tanf(PI_F / 4.f * rfc * nrf);
+    const float vel_score = tanf(PI_F / 4.f * lvc * nlv) + tanf(PI_F / 4.f * rvc * nrv);
+    const float hip_roll = fabsf(S(F_QVEL + 6)) + fabsf(S(F_QVEL + 13));          // clock_rewards.py:74 (sic)
+    float tq = 0.f, ac = 0.f;
+    for (int u = 0; u < 10; ++u) { tq += fabsf(S(F_PREVTQ + u) - S(F_SO + SO_TORQUE + u)); ac += fabsf(S(F_PREVACT + u) - action[u]); }
+    return 0.200f * frc_score + 0.200f * vel_score + 0.200f * expf(-(com_orient + foot_orient)) +
+           0.150f * expf(-pelvis_motion) + 0.150f * expf(-com_vel_err) + 0.050f * expf(-hip_roll) +
+           0.025f * expf(-0.25f * tq / 10.f) + 0.025f * expf(-5.f * ac / 10.f);
+}
+
+// ------------------------------------------------------------------------------------------------ kernels
+#define ENV_SETUP                                                                                   \
+    extern __shared__ __attribute__((aligned(16))) float lds[];                                      \
+    const int lane = threadIdx.x & 63;                                                               \
+    const int env = blockIdx.x * 64 + lane;                                                          \
+    if (env >= n) return;                                                                            \
+    const St S{st, ist, n, env};                                                                     \
+    float yext[(MAXEFC - NLDS) * YW];                                                                \
+    const Rows Y{lds, lane, yext};                                                                   \
+    Dyn dy; Work w;
+
+__global__ __launch_bounds__(64) void env_init_kernel(float* st, int* ist, int n, Cfg cfg) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= n) return;
+    const St S{st, ist, n, env};
+    for (int f = 0; f < F_TOTAL; ++f) S(f) = 0.f;
+    for (int f = 0; f < I_TOTAL; ++f) S.I(f) = 0;
+    for (int i = 0; i < NQ; ++i) S(F_QPOS + i) = cm_init_qpos[i];
+    for (int b = 0; b < NB; ++b) S(F_MASS + b) = cm_body_mass[b];
+    for (int d = 0; d < NV; ++d) S(F_DAMP + d) = cm_dof_damping[d];
+    S(F_FRIC) = 1.f;
+    const float fl[9] = {0, 0, 1, 0, 1, 0, -1, 0, 0};     // n = z, t1 = y, t2 = n x t1 = -x
+    for (int k = 0; k < 9; ++k) S(F_FLOOR + k) = fl[k];
+}
+
+__global__ __launch_bounds__(64) void env_setconst_kernel(float* st, int* ist, int n, Cfg cfg) {
+    ENV_SETUP
+    load_dyn(S, dy);
+    set_const(S, dy, w);
+}
+
+__global__ __launch_bounds__(64) void env_reset_kernel(float* st, int* ist, int n, Cfg cfg, const uint8_t* mask, float* obs) {
+    ENV_SETUP
+    if (mask && !mask[env]) return;
+    load_dyn(S, dy);
+    env_reset(S, cfg, dy, w, Y);
+    if (obs) write_obs(S, cfg, obs + (size_t)env * APX_OBS_DIM);
+}
+
+__global__ __launch_bounds__(64) void env_step_kernel(float* st, int* ist, int n, Cfg cfg, const float* action, float* obs,
+                                                       float* reward, uint8_t* done, float* final_obs, int auto_reset) {
+    ENV_SETUP
+    load_dyn(S, dy);
+    float act[10];
+    for (int u = 0; u < 10; ++u) {
+        act[u] = action[(size_t)env * APX_ACT_DIM + u];
+        S(F_PDT + u) = act[u] + kOffset[u] - (cfg.dyn_rand ? S(F_MNOISE + u) : 0.f);     // cassie.py:295-298
+    }
+    S.I(I_FLAGS) |= 16;
+    float lfrc = 0.f, rfrc = 0.f, lor = 0.f, ror = 0.f;
+    for (int i = 0; i < cfg.simrate; ++i) {
+        sim_step_pd(S, dy, w, Y, cfg.pgs_iters);
+        for (int k = 0; k < 6; ++k) {                                            // cassie.py:328-331
+            const float fp = S(F_FWD + 10 + k);
+            S(F_FOOTVEL + k) = (fp - S(F_FOOTPREV + k)) / 0.0005f;
+            S(F_FOOTPREV + k) = fp;
+        }
+        lfrc += S(F_FWD + 0); rfrc += S(F_FWD + 1);                               // cassie.py:418-420
+        float il = 0.f, ir = 0.f;
+        for (int k = 0; k < 4; ++k) { il += kNeutralFoot[k] * S(F_FWD + 2 + k); ir += kNeutralFoot[k] * S(F_FWD + 6 + k); }
+        lor += 1.f - il * il; ror += 1.f - ir * ir;                               // cassie.py:426-427
+    }
+    const float inv = 1.f / (float)cfg.simrate;
+    lfrc *= inv; rfrc *= inv; lor *= inv; ror *= inv;
+    const float height = S(F_QPOS + 2);
+    int time = S.I(I_TIME) + 1, phase = S.I(I_PHASE) + 1;
+    if ((float)phase > S(F_CMD + 5)) { phase = 0; S.I(I_COUNTER) += 1; }
+    S.I(I_TIME) = time; S.I(I_PHASE) = phase;
+    int dn = (height < 0.4f || height > 3.0f || !(height == height)) ? 1 : 0;
+    int flags = S.I(I_FLAGS);
+    if (!(flags & 4)) for (int u = 0; u < 10; ++u) S(F_PREVACT + u) = act[u];
+    if (!(flags & 8)) for (int u = 0; u < 10; ++u) S(F_PREVTQ + u) = S(F_SO + SO_TORQUE + u);
+    S.I(I_FLAGS) = flags | 12;
+    const float rew = clock_reward(S, cfg, act, lfrc, rfrc, lor, ror);
+    for (int u = 0; u < 10; ++u) { S(F_PREVACT + u) = act[u]; S(F_PREVTQ + u) = S(F_SO + SO_TORQUE + u); }
+    {   // command resampling, cassie.py:483-491; fixed 6 draws per step
+        Rng r{cfg.seed_lo, cfg.seed_hi, (unsigned)env, (unsigned)S.I(I_RNG)};
+        { const unsigned k = r.randint(300); const float u = r.uniform(-0.2f, 0.2f); if (k == 0) S(F_CMD + 2) += u; }
+        { const unsigned k = r.randint(100); const float u = r.uniform(-0.3f, 4.0f); if (k == 0) S(F_CMD + 0) = fminf(fmaxf(u, -0.3f), 4.0f); }
+        { const unsigned k = r.randint(300); const float u = r.uniform(-0.3f, 0.3f); if (k == 0) S(F_CMD + 1) = u; }
+        S.I(I_RNG) = (int)r.ctr;
+    }
+    if (!dn && time >= cfg.max_traj_len) dn = 2;
+    reward[env] = rew;
+    done[env] = (uint8_t)dn;
+    if (dn && auto_reset) {
+        if (final_obs) write_obs(S, cfg, final_obs + (size_t)env * APX_OBS_DIM);
+        env_reset(S, cfg, dy, w, Y);
+    }
+    write_obs(S, cfg, obs + (size_t)env * APX_OBS_DIM);
+}
+
+// raw substeps with the current pd targets (tests): n_sub x cassie_sim_step_pd
+__global__ __launch_bounds__(64) void env_substep_kernel(float* st, int* ist, int n, Cfg cfg, int n_sub) {
+    ENV_SETUP
+    load_dyn(S, dy);
+    for (int i = 0; i < n_sub; ++i) sim_step_pd(S, dy, w, Y, cfg.pgs_iters);
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+static constexpr size_t LDS_BYTES = (size_t)NLDS * YW * 64 * sizeof(float);   // 160,512 B of the CU's 163,840
+
+static Cfg make_cfg(const apx_env_cfg& c) {
+    return Cfg{c.simrate, c.dynamics_randomization, c.stance_mode, c.have_incentive, c.max_traj_len, c.pgs_iters,
+               (unsigned)c.seed, (unsigned)(c.seed >> 32)};
+}
+
+extern "C" void apx_env_default_cfg(apx_env_cfg* c) {
+    if (!c) return;
+    *c = apx_env_cfg{};
+    c->n_envs = 4096; c->simrate = 50; c->dynamics_randomization = 1; c->reward_kind = 0; c->stance_mode = 0;
+    c->have_incentive = 1; c->max_traj_len = 400; c->seed = 0; c->device = 0; c->pgs_iters = 50;
+}
+
+extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
+    APX_REQUIRE(cfg && out, "null");
+    APX_REQUIRE(cfg->n_envs > 0 && cfg->n_envs % 64 == 0, "n_envs must be a positive multiple of 64");
+    APX_REQUIRE(cfg->simrate > 0 && 2000 % cfg->simrate == 0, "simrate must divide 2000");
+    APX_REQUIRE(cfg->reward_kind == 0, "only clock_reward is built in this round");
+    APX_REQUIRE(cfg->pgs_iters > 0 && cfg->max_traj_len > 0, "pgs_iters / max_traj_len");
+    APX_HIP(hipSetDevice(cfg->device));
+    apx_env* e = new (std::nothrow) apx_env;
+    APX_REQUIRE(e, "alloc");
+    e->cfg = *cfg; e->n = cfg->n_envs; e->st = nullptr; e->ist = nullptr;
+    APX_HIP(hipMalloc(&e->st, sizeof(float) * (size_t)F_TOTAL * e->n));
+    APX_HIP(hipMalloc(&e->ist, sizeof(int) * (size_t)I_TOTAL * e->n));
+    const Cfg c = make_cfg(*cfg);
+    hipLaunchKernelGGL(env_init_kernel, dim3(e->n / 64), dim3(64), 0, 0, e->st, e->ist, e->n, c);
+    APX_LAUNCH_CHECK();
+    APX_HIP(hipFuncSetAttribute((const void*)env_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    APX_HIP(hipFuncSetAttribute((const void*)env_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    APX_HIP(hipFuncSetAttribute((const void*)env_substep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    APX_HIP(hipFuncSetAttribute((const void*)env_setconst_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    hipLaunchKernelGGL(env_setconst_kernel, dim3(e->n / 64), dim3(64), LDS_BYTES, 0, e->st, e->ist, e->n, c);
+    APX_LAUNCH_CHECK();
+    APX_HIP(hipDeviceSynchronize());
+    *out = e;
+    return APX_OK;
+}
+
+extern "C" int apx_env_destroy(apx_env_t* e) {
+    if (!e) return APX_OK;
+    (void)hipFree(e->st); (void)hipFree(e->ist);
+    delete e;
+    return APX_OK;
+}
+
+extern "C" int apx_env_reset(apx_env_t* e, const uint8_t* mask, float* obs_out, void* stream) {
+    APX_REQUIRE(e, "env");
+    hipLaunchKernelGGL(env_reset_kernel, dim3(e->n / 64), dim3(64), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->n,
+                       make_cfg(e->cfg), mask, obs_out);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+}
+
+extern "C" int apx_env_step(apx_env_t* e, const float* action, float* obs, float* reward, uint8_t* done, float* final_obs,
+                            int auto_reset, void* stream) {
+    APX_REQUIRE(e && action && obs && reward && done, "null pointer");
+    hipLaunchKernelGGL(env_step_kernel, dim3(e->n / 64), dim3(64), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->n,
+                       make_cfg(e->cfg), action, obs, reward, done, final_obs, auto_reset);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+}
+
+// [F, n] SoA  <->  [n, cnt] row-major
+__global__ void gather_kernel(const float* st, int n, int f0, int cnt, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * cnt) return;
+    const int env = i / cnt, k = i - env * cnt;
+    out[i] = st[(size_t)(f0 + k) * n + env];
+}
+__global__ void scatter_kernel(float* st, int n, int f0, int cnt, const float* in) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * cnt) return;
+    const int env = i / cnt, k = i - env * cnt;
+    st[(size_t)(f0 + k) * n + env] = in[i];
+}
+__global__ void gather_int_kernel(const int* ist, int n, int cnt, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * cnt) return;
+    const int env = i / cnt, k = i - env * cnt;
+    out[i] = (float)ist[(size_t)k * n + env];
+}
+__global__ void scatter_int_kernel(int* ist, int n, int cnt, const float* in) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * cnt) return;
+    const int env = i / cnt, k = i - env * cnt;
+    ist[(size_t)k * n + env] = (int)in[i];
+}
+
+struct FieldDesc { const char* name; int f0, cnt; };
+static const FieldDesc kFields[] = {
+    {"qpos", F_QPOS, NQ}, {"qvel", F_QVEL, NV}, {"qacc_warm", F_QACCW, NV}, {"mass", F_MASS, NB}, {"damping", F_DAMP, NV},
+    {"friction", F_FRIC, 1}, {"floor", F_FLOOR, 9}, {"body_invweight0", F_BIW, NB}, {"dof_invweight0", F_DIW, NV},
+    {"motor_noise", F_MNOISE, 10}, {"joint_noise", F_JNOISE, 6}, {"pd_target", F_PDT, 10}, {"tq_fifo", F_FIFO, 60},
+    {"so_mpos", F_SO + SO_MPOS, 10}, {"so_mvel", F_SO + SO_MVEL, 10}, {"so_torque", F_SO + SO_TORQUE, 10},
+    {"so_jpos", F_SO + SO_JPOS, 6}, {"so_jvel", F_SO + SO_JVEL, 6}, {"so_quat", F_SO + SO_QUAT, 4},
+    {"so_rotvel", F_SO + SO_ROTVEL, 3}, {"so_tvel", F_SO + SO_TVEL, 3}, {"so_tacc", F_SO + SO_TACC, 3}, {"so_height", F_SO + SO_HEIGHT, 1},
+    {"foot_vel", F_FOOTVEL, 6}, {"prev_action", F_PREVACT, 10}, {"prev_torque", F_PREVTQ, 10}, {"cmd", F_CMD, 6}, {"fwd", F_FWD, 16},
+};
+
+static const FieldDesc* find_field(const char* name) {
+    for (const auto& f : kFields)
+        if (!strcmp(f.name, name)) return &f;
+    return nullptr;
+}
+
+extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, void* stream) {
+    APX_REQUIRE(e && name && out, "null pointer");
+    if (!strcmp(name, "ints")) {
+        hipLaunchKernelGGL(gather_int_kernel, dim3(apx_cdiv((long)e->n * I_TOTAL, 256)), dim3(256), 0, (hipStream_t)stream, e->ist, e->n, (int)I_TOTAL, out);
+        APX_LAUNCH_CHECK();
+        return I_TOTAL;
+    }
+    if (!strcmp(name, "substep")) {   // debugging hook: out[0] (host-readable count is not needed) - run one raw substep
+        hipLaunchKernelGGL(env_substep_kernel, dim3(e->n / 64), dim3(64), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->n, make_cfg(e->cfg), 1);
+        APX_LAUNCH_CHECK();
+        return 0;
+    }
+    const FieldDesc* f = find_field(name);
+    APX_REQUIRE(f, "unknown field");
+    hipLaunchKernelGGL(gather_kernel, dim3(apx_cdiv((long)e->n * f->cnt, 256)), dim3(256), 0, (hipStream_t)stream, e->st, e->n, f->f0, f->cnt, out);
+    APX_LAUNCH_CHECK();
+    return f->cnt;
+}
+
+extern "C" int apx_env_set_field(apx_env_t* e, const char* name, const float* in, void* stream) {
+    APX_REQUIRE(e && name, "null pointer");
+    if (!strcmp(name, "set_const")) {   // recompute invweight0 after mass edits (sim.set_const)
+        hipLaunchKernelGGL(env_setconst_kernel, dim3(e->n / 64), dim3(64), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->n, make_cfg(e->cfg));
+        APX_LAUNCH_CHECK();
+        return 0;
+    }
+    APX_REQUIRE(in, "null pointer");
+    if (!strcmp(name, "ints")) {
+        hipLaunchKernelGGL(scatter_int_kernel, dim3(apx_cdiv((long)e->n * I_TOTAL, 256)), dim3(256), 0, (hipStream_t)stream, e->ist, e->n, (int)I_TOTAL, in);
+        APX_LAUNCH_CHECK();
+        return I_TOTAL;
+    }
+    const FieldDesc* f = find_field(name);
+    APX_REQUIRE(f, "unknown field");
+    hipLaunchKernelGGL(scatter_kernel, dim3(apx_cdiv((long)e->n * f->cnt, 256)), dim3(256), 0, (hipStream_t)stream, e->st, e->n, f->f0, f->cnt, in);
+    APX_LAUNCH_CHECK();
+    return f->cnt;
+}
+
+extern "C" int apx_env_get_state(apx_env_t* e, float* qpos, float* qvel, void* stream) {
+    APX_REQUIRE(e && qpos && qvel, "null pointer");
+    int rc = apx_env_get_field(e, "qpos", qpos, stream);
+    if (rc < 0) return rc;
+    rc = apx_env_get_field(e, "qvel", qvel, stream);
+    return rc < 0 ? rc : APX_OK;
+}
+extern "C" int apx_env_set_state(apx_env_t* e, const float* qpos, const float* qvel, void* stream) {
+    APX_REQUIRE(e && qpos && qvel, "null pointer");
+    int rc = apx_env_set_field(e, "qpos", qpos, stream);
+    if (rc < 0) return rc;
+    rc = apx_env_set_field(e, "qvel", qvel, stream);
+    return rc < 0 ? rc : APX_OK;
+}

@@ -1,0 +1,115 @@
+"""Batched Cassie-v0 behind the Python env seam of the reference.
+
+`CassieVecEnv` exposes what rl/algos/ppo.py expects from `env_fn()` — reset(), step(action), observation_space,
+action_space, mirrored_obs, mirrored_acts, clock_inds, clock_based, simrate (util/env.py:8-52,
+rl/envs/wrappers.py:5-67, cassie/cassie.py:44-69,234-278) — for N environments at once, with every array a device
+tensor.  The work happens in libapx.so (apx_env_* in include/apx.h); there is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+from .engine import _p, _stream
+
+OBS_DIM, ACT_DIM = 50, 10
+
+# cassie/cassie.py:244 (input_profile "full") + :262-265 (command_profile "clock"); cassie/cassie.py:69
+MIRRORED_OBS = [0.1, 1, -2, 3, -4, -10, -11, 12, 13, 14, -5, -6, 7, 8, 9, 15, -16, 17, -18, 19, -20, -26, -27, 28, 29, 30,
+                -21, -22, 23, 24, 25, 31, -32, 33, 37, 38, 39, 34, 35, 36, 43, 44, 45, 40, 41, 42, 46, 47, 48, 49]
+MIRRORED_ACTS = [-5, -6, 7, 8, 9, -0.1, -1, 2, 3, 4]
+CLOCK_INDS = [46, 47]
+
+
+def parse_reward(reward):
+    """cassie/cassie.py:91,202-232,770-785: `--reward` is a substring-matched spec."""
+    if reward is None:
+        raise TypeError("argument of type 'NoneType' is not iterable")     # the reference crashes at cassie.py:91 too
+    have_incentive = "no_incentive" not in reward
+    early = "early" in reward
+    if "load" in reward:
+        raise NotImplementedError("load_clock rewards: no shipped clock file matches (SURVEY.md §8 a5b)")
+    stance = 1 if "grounded" in reward else 2 if "aerial" in reward else 0
+    if "max_vel" in reward:
+        raise NotImplementedError("max_vel_clock_reward is outside the north-star path")
+    return dict(reward_kind=1 if early else 0, stance_mode=stance, have_incentive=int(have_incentive))
+
+
+class CassieVecEnv:
+    clock_based = True
+    clock_inds = CLOCK_INDS
+    mirrored_obs = MIRRORED_OBS
+    mirrored_acts = MIRRORED_ACTS
+
+    def __init__(self, n_envs=4096, simrate=50, dynamics_randomization=True, reward="clock", max_traj_len=400, seed=0,
+                 device=0, pgs_iters=50, command_profile="clock", input_profile="full", history=0, learn_gains=False):
+        if command_profile != "clock" or input_profile != "full" or history != 0 or learn_gains:
+            raise NotImplementedError("only command_profile=clock, input_profile=full, history=0 are on the hot path")
+        if not torch.cuda.is_available():
+            raise _lib.ApxError("CassieVecEnv needs a GPU (there is no CPU fallback)")
+        lib = _lib.load()
+        cfg = _lib.EnvCfg()
+        lib.apx_env_default_cfg(C.byref(cfg))
+        r = parse_reward(reward)
+        cfg.n_envs, cfg.simrate, cfg.dynamics_randomization = n_envs, simrate, int(dynamics_randomization)
+        cfg.reward_kind, cfg.stance_mode, cfg.have_incentive = r["reward_kind"], r["stance_mode"], r["have_incentive"]
+        cfg.max_traj_len, cfg.seed, cfg.device, cfg.pgs_iters = max_traj_len, seed, device, pgs_iters
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self._h = C.c_void_p()
+        check(lib.apx_env_create(C.byref(cfg), C.byref(self._h)))
+        self.n_envs, self.simrate, self.max_traj_len = n_envs, simrate, max_traj_len
+        self.observation_space = np.zeros(OBS_DIM)
+        self.action_space = np.zeros(ACT_DIM)
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.obs = torch.zeros(n_envs, OBS_DIM, **f32)
+        self.final_obs = torch.zeros(n_envs, OBS_DIM, **f32)
+        self.reward = torch.zeros(n_envs, **f32)
+        self.done = torch.zeros(n_envs, dtype=torch.uint8, device=self.device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().apx_env_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, mask=None):
+        """CassieEnv.reset for every env (or those with mask != 0); returns the [N, 50] observation tensor."""
+        check(_lib.load().apx_env_reset(self._h, _p(mask), _p(self.obs), _stream()))
+        return self.obs
+
+    def step(self, action, auto_reset=True, f_term=0):
+        """CassieEnv.step for every env.  `f_term` is accepted and ignored exactly like cassie/cassie.py:389.
+        Returns (obs, reward, done, final_obs): done 1 = terminated, 2 = truncated at max_traj_len; with auto_reset the
+        finished envs restart inside the same launch and `final_obs` holds their last observation."""
+        action = action.contiguous()
+        assert action.shape == (self.n_envs, ACT_DIM) and action.dtype == torch.float32 and action.is_cuda
+        check(_lib.load().apx_env_step(self._h, _p(action), _p(self.obs), _p(self.reward), _p(self.done),
+                                       _p(self.final_obs), int(auto_reset), _stream()))
+        return self.obs, self.reward, self.done, self.final_obs
+
+    # ---- raw state access (tests, tools) ----
+    def get_field(self, name, count=None):
+        lib = _lib.load()
+        buf = torch.zeros(self.n_envs, 128, dtype=torch.float32, device=self.device)
+        n = lib.apx_env_get_field(self._h, name.encode(), _p(buf), _stream())
+        if n < 0:
+            check(n)
+        return buf.view(-1)[: self.n_envs * n].view(self.n_envs, n).clone() if n else None
+
+    def set_field(self, name, value=None):
+        lib = _lib.load()
+        v = None if value is None else value.to(self.device, torch.float32).contiguous()
+        n = lib.apx_env_set_field(self._h, name.encode(), _p(v), _stream())
+        if n < 0:
+            check(n)
+
+    def substep(self):
+        self.get_field("substep")

@@ -358,7 +358,7 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
     std::memset(s.foot_force, 0, sizeof(s.foot_force));
     for (int c = 0; c < s.ncon; ++c) {
         const int b = cm_geom_body[s.con_geom[c]];
-        const int foot = b == 13 ? 0 : (b == 25 ? 1 : -1);
+        const int foot = b == 13 ? 0 : (b == 25 ? 1 : -1);   // foot bodies (cassie.xml:140,203)
         if (foot < 0) continue;
         const double* ff = f + con_row[c];
         const double fn = ff[0] + ff[1] + ff[2] + ff[3], f1 = p.friction * (ff[0] - ff[1]), f2 = p.friction * (ff[2] - ff[3]);

@@ -1,0 +1,113 @@
+"""GPU parity: the HIP Cassie-v0 env (through the C ABI) vs the fp64 C++ oracle on the same seeds.
+
+Bit-exact: episode-step indices, phase, done flags, RNG counters (integer work).  Floating point: fp32 lane vs fp64
+host — tolerances are written next to each check; they widen with the number of 2 kHz substeps because the contact
+dynamics amplify round-off (the physics itself is parity-unpinned against MuJoCo)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sim as S
+
+pytestmark = pytest.mark.gpu
+N = 64
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _mk(dyn_rand, seed, n=N):
+    from apex_amd.vecenv import CassieVecEnv
+    genv = CassieVecEnv(n_envs=n, dynamics_randomization=dyn_rand, seed=seed)
+    oenv = [S.OracleEnv(dyn_rand=dyn_rand, seed=seed, env_id=i) for i in range(n)]
+    return genv, oenv
+
+
+def test_set_const_invweights(dev):
+    genv, oenv = _mk(False, 0, 64)
+    biw = genv.get_field("body_invweight0").cpu().numpy()[0]
+    diw = genv.get_field("dof_invweight0").cpu().numpy()[0]
+    ref_b = oenv[0].get("body_invweight0").reshape(26, 2)[:, 0]
+    ref_d = oenv[0].get("dof_invweight0")
+    np.testing.assert_allclose(biw, ref_b, rtol=2e-4, atol=1e-7)
+    lim = diw != 0                      # the kernel only computes it for limited joints
+    assert lim.sum() == 16
+    np.testing.assert_allclose(diw[lim], ref_d[lim], rtol=2e-4)
+
+
+def test_reset_obs_and_params(dev):
+    genv, oenv = _mk(True, 7)
+    obs = genv.reset().cpu().numpy()
+    ref = np.stack([e.reset() for e in oenv])
+    ints = genv.get_field("ints").cpu().numpy()
+    oints = np.stack([e.get("ints") for e in oenv])
+    np.testing.assert_array_equal(ints[:, [0, 1, 2, 3]], oints[:, [0, 1, 2, 5]])          # time, phase, counter, rng ctr
+    for name in ("mass", "damping", "friction", "motor_noise", "joint_noise"):
+        np.testing.assert_allclose(genv.get_field(name).cpu().numpy(), np.stack([e.get(name) for e in oenv]), rtol=2e-6, atol=1e-7)
+    # one substep of free fall from the init pose: fp32 round-off only
+    np.testing.assert_allclose(obs, ref, rtol=1e-4, atol=2e-4)
+
+
+def test_substeps_track_oracle(dev):
+    """20 raw 2 kHz substeps after reset (still airborne, loop-closure + spring dynamics): tight agreement."""
+    genv, oenv = _mk(False, 1)
+    genv.reset(); [e.reset() for e in oenv]
+    for _ in range(20):
+        genv.substep()
+    for e in oenv[:4]:
+        for _ in range(20):
+            e.substep()
+    q = genv.get_field("qpos").cpu().numpy(); v = genv.get_field("qvel").cpu().numpy()
+    for i, e in enumerate(oenv[:4]):
+        np.testing.assert_allclose(q[i], e.get("qpos"), atol=2e-5)
+        np.testing.assert_allclose(v[i], e.get("qvel"), atol=5e-3, rtol=1e-3)
+
+
+def test_env_steps_vs_oracle(dev):
+    """Full env steps (50 substeps each, contacts, reward, termination, command resampling, auto-reset)."""
+    genv, oenv = _mk(True, 3)
+    genv.reset(); [e.reset() for e in oenv]
+    rng = np.random.RandomState(0)
+    n_chk = 16
+    for t in range(12):
+        act = (rng.randn(N, 10) * 0.15).astype(np.float32)
+        obs, rew, done, fin = genv.step(torch.tensor(act, device=dev), auto_reset=False)
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        for i in range(n_chk):
+            o, r, d = oenv[i].step(act[i].astype(np.float64))
+            assert d == done[i], (t, i)
+            # height / orientation / motor positions: slow variables
+            np.testing.assert_allclose(obs[i, :15], o[:15], atol=3e-3 * (t + 1), err_msg=f"t={t} env={i}")
+            assert abs(rew[i] - r) < 0.02 * (t + 1), (t, i, rew[i], r)
+        ints = genv.get_field("ints").cpu().numpy()
+        oints = np.stack([e.get("ints") for e in oenv[:n_chk]])
+        np.testing.assert_array_equal(ints[:n_chk, [0, 1, 2, 3]], oints[:, [0, 1, 2, 5]])
+
+
+def test_step_invariants_full_size(dev):
+    """BASELINE size (4096 envs): finite outputs, quaternion norms, loop closure, reward range, auto-reset bookkeeping."""
+    from apex_amd.vecenv import CassieVecEnv
+    env = CassieVecEnv(n_envs=4096, seed=5, max_traj_len=30)
+    env.reset()
+    g = torch.Generator(device=dev).manual_seed(0)
+    lens = torch.zeros(4096, device=dev)
+    n_done = 0
+    for t in range(40):
+        act = torch.randn(4096, 10, device=dev, generator=g) * 0.2
+        obs, rew, done, fin = env.step(act)
+        assert torch.isfinite(obs).all() and torch.isfinite(rew).all()
+        assert (rew > -0.5).all() and (rew < 1.0).all()
+        lens += 1
+        assert (lens[done == 2] == 30).all()                     # truncation exactly at max_traj_len
+        lens[done != 0] = 0
+        n_done += int((done != 0).sum())
+        q = env.get_field("qpos")
+        for a in (3, 10, 24):
+            assert (q[:, a:a + 4].norm(dim=1) - 1).abs().max() < 1e-5
+        ints = env.get_field("ints")
+        assert (ints[:, 0] == lens).all()                        # time counter == steps since last reset
+    assert n_done >= 4096                                        # every env finished at least once (horizon 30 < 40 steps)

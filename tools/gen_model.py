@@ -131,6 +131,16 @@ def compile_model(xml_path=XML):
     for child in wb.findall("body"):
         walk(child, 0)
 
+    # contact priority order used by BOTH the oracle and the kernel when the per-step contact cap binds:
+    # feet, tarsi, shins, hip-pitch capsules, pelvis sphere (MuJoCo itself orders by geom id)
+    def _prio(g):
+        nm = bodies[g["body"]]["name"]
+        for k, key in enumerate(["foot", "tarsus", "shin", "hip-pitch", "pelvis"]):
+            if nm.endswith(key):
+                return (k, 0 if nm.startswith("left") else 1)
+        raise ValueError(nm)
+    geoms.sort(key=_prio)
+
     nbody, nv = len(bodies), len(dofs)
     assert nbody == 26 and nv == 32 and nq[0] == 35, (nbody, nv, nq[0])
 
@@ -185,6 +195,9 @@ def compile_model(xml_path=XML):
     return model
 
 
+DECL = "static const"
+
+
 def _carr(name, arr, ctype, per_line=8):
     flat = np.asarray(arr).reshape(-1)
     isint = ctype == "int"
@@ -193,10 +206,12 @@ def _carr(name, arr, ctype, per_line=8):
         chunk = flat[i:i + per_line]
         body.append("    " + ", ".join((str(int(v)) if isint else (repr(float(v)) + ("f" if ctype == "float" else "")))
                                        for v in chunk))
-    return f"static const {ctype} {name}[{len(flat)}] = {{\n" + ",\n".join(body) + "\n};\n"
+    return f"{DECL} {ctype} {name}[{len(flat)}] = {{\n" + ",\n".join(body) + "\n};\n"
 
 
-def emit_header(model, ctype, guard):
+def emit_header(model, ctype, guard, decl="static const"):
+    global DECL
+    DECL = decl
     m = model
     B, D, J = m["bodies"], m["dofs"], m["joints"]
     jt = {"slide": 0, "hinge": 1, "ball": 2}
@@ -237,6 +252,16 @@ def emit_header(model, ctype, guard):
                 p = B[p]["parent"]
             par.append(B[p]["dofadr"] + B[p]["dofnum"] - 1 if p > 0 else -1)
     out.append(_carr("cm_dof_parent", par, "int"))
+    # sparse mass-matrix addressing (MuJoCo dof_Madr): row i holds M[i][i], M[i][parent(i)], ... up to the root
+    madr, tot = [], 0
+    for i in range(len(D)):
+        madr.append(tot)
+        j = i
+        while j >= 0:
+            tot += 1
+            j = par[j]
+    out.append(_carr("cm_dof_madr", madr + [tot], "int"))
+    out.append(f"#define CM_NM {tot}\n")
     out.append(_carr("cm_dof_damping", [d["damping"] for d in D], R))
     out.append(_carr("cm_dof_armature", [d["armature"] for d in D], R))
     G = m["geoms"]
@@ -279,7 +304,7 @@ def main():
     with open(os.path.join(REPO, "oracle", "cassie_model_gen.h"), "w") as f:
         f.write(emit_header(model, "double", "ORACLE_CASSIE_MODEL_GEN_H"))
     with open(os.path.join(REPO, "apex_amd", "csrc", "cassie_model_gen.h"), "w") as f:
-        f.write(emit_header(model, "float", "APX_CASSIE_MODEL_GEN_H"))
+        f.write(emit_header(model, "float", "APX_CASSIE_MODEL_GEN_H", decl="static __device__ const"))
     tot = sum(b["mass"] for b in model["bodies"])
     print(f"nbody={model['nbody']} nv={model['nv']} ngeom(collision)={len(model['geoms'])} total mass={tot:.3f}")
     for e in model["equalities"]:
