@@ -1,0 +1,72 @@
+"""Command-line front-end reproducing the reference's `python apex.py ppo ...` (apex.py:16-39,214-255): same flag
+names and defaults, same run-directory layout, same checkpoint files — backed by the MI355X engine in apex_amd/.
+Extra flags (not in the reference): --n_envs (envs per GPU, default 4096) and --hidden."""
+import argparse
+import sys
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    # env flags, apex.py:16-39
+    p.add_argument("--command_profile", default="clock", type=str.lower, choices=["clock", "phase", "traj"])
+    p.add_argument("--input_profile", default="full", type=str.lower, choices=["full", "min"])
+    p.add_argument("--simrate", default=50, type=int)
+    p.add_argument("--not_dyn_random", default=True, action="store_false", dest="dyn_random")
+    p.add_argument("--learn_gains", default=False, action="store_true", dest="learn_gains")
+    p.add_argument("--traj", default="walking", type=str)
+    p.add_argument("--not_no_delta", default=True, action="store_false", dest="no_delta")
+    p.add_argument("--ik_baseline", default=False, action="store_true", dest="ik_baseline")
+    p.add_argument("--not_mirror", default=True, action="store_false", dest="mirror")
+    p.add_argument("--reward", default=None, type=str)
+    p.add_argument("--env_name", default="Cassie-v0")
+    p.add_argument("--run_name", default=None)
+    p.add_argument("--exchange_reward", default=None)
+    p.add_argument("--previous", type=str, default=None)
+    # ppo flags, apex.py:224-250
+    p.add_argument("--logdir", type=str, default="./trained_models/ppo/")
+    p.add_argument("--seed", default=0, type=int)
+    p.add_argument("--history", default=0, type=int)
+    p.add_argument("--redis_address", type=str, default=None)
+    p.add_argument("--viz_port", default=8097)
+    p.add_argument("--input_norm_steps", type=int, default=10000)
+    p.add_argument("--n_itr", type=int, default=10000)
+    p.add_argument("--lr", type=float, default=1e-4)
+    p.add_argument("--eps", type=float, default=1e-5)
+    p.add_argument("--lam", type=float, default=0.95)
+    p.add_argument("--gamma", type=float, default=0.99)
+    p.add_argument("--anneal", default=1.0, action="store_true")
+    p.add_argument("--learn_stddev", default=False, action="store_true")
+    p.add_argument("--std_dev", type=int, default=-1.5)
+    p.add_argument("--entropy_coeff", type=float, default=0.0)
+    p.add_argument("--clip", type=float, default=0.2)
+    p.add_argument("--minibatch_size", type=int, default=64)
+    p.add_argument("--epochs", type=int, default=3)
+    p.add_argument("--num_steps", type=int, default=5096)
+    p.add_argument("--use_gae", type=bool, default=True)
+    p.add_argument("--num_procs", type=int, default=30)
+    p.add_argument("--max_grad_norm", type=float, default=0.05)
+    p.add_argument("--max_traj_len", type=int, default=400)
+    p.add_argument("--recurrent", action="store_true")
+    p.add_argument("--bounded", type=bool, default=False)
+    # engine flags (additions)
+    p.add_argument("--n_envs", type=int, default=4096, help="lock-step envs per GPU (replaces Ray's num_procs)")
+    return p
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv or argv[0] != "ppo":
+        print("Usage: python apex.py ppo [flags]   (only the PPO / Cassie-v0 path is built; see DESIGN.md)")
+        return 2
+    args = build_parser().parse_args(argv[1:])
+    if args.env_name != "Cassie-v0" or args.recurrent or args.learn_stddev:
+        raise NotImplementedError("only Cassie-v0 feed-forward PPO with fixed std is on the hot path (SURVEY.md §8)")
+    from apex_amd.log import parse_previous
+    from apex_amd.ppo import run_experiment
+    args = parse_previous(args)
+    run_experiment(args)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

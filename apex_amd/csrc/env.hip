@@ -43,7 +43,7 @@ struct St {
     __device__ __forceinline__ int& I(int f) const { return ip[(size_t)f * n + env]; }
 };
 
-struct Cfg { int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi; };
+struct Cfg { int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; };
 
 // ------------------------------------------------------------------------------------------------ Philox4x32-10
 __device__ __forceinline__ unsigned philox(unsigned k0, unsigned k1, unsigned env, unsigned ctr) {
@@ -481,7 +481,7 @@ __device__ __forceinline__ void clock_from_speed(const St& S, float speed, int f
 
 // CassieEnv.reset (cassie/cassie.py:523-680)
 __device__ void env_reset(const St& S, const Cfg& cfg, Dyn& dy, Work& w, const Rows& Y) {
-    Rng r{cfg.seed_lo, cfg.seed_hi, (unsigned)S.env, (unsigned)S.I(I_RNG)};
+    Rng r{cfg.seed_lo, cfg.seed_hi, cfg.env_base + (unsigned)S.env, (unsigned)S.I(I_RNG)};
     const float speed0 = r.uniform(-0.3f, 4.0f);
     (void)r.uniform(-0.3f, 0.3f);
     clock_from_speed(S, speed0, 2000 / cfg.simrate);
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(float* st, int* ist, int n
     const float rew = clock_reward(S, cfg, act, lfrc, rfrc, lor, ror);
     for (int u = 0; u < 10; ++u) { S(F_PREVACT + u) = act[u]; S(F_PREVTQ + u) = S(F_SO + SO_TORQUE + u); }
     {   // command resampling, cassie.py:483-491; fixed 6 draws per step
-        Rng r{cfg.seed_lo, cfg.seed_hi, (unsigned)env, (unsigned)S.I(I_RNG)};
+        Rng r{cfg.seed_lo, cfg.seed_hi, cfg.env_base + (unsigned)env, (unsigned)S.I(I_RNG)};
         { const unsigned k = r.randint(300); const float u = r.uniform(-0.2f, 0.2f); if (k == 0) S(F_CMD + 2) += u; }
         { const unsigned k = r.randint(100); const float u = r.uniform(-0.3f, 4.0f); if (k == 0) S(F_CMD + 0) = fminf(fmaxf(u, -0.3f), 4.0f); }
         { const unsigned k = r.randint(300); const float u = r.uniform(-0.3f, 0.3f); if (k == 0) S(F_CMD + 1) = u; }
@@ -665,7 +665,7 @@ static constexpr size_t LDS_BYTES = (size_t)NLDS * YW * 64 * sizeof(float);   //
 
 static Cfg make_cfg(const apx_env_cfg& c) {
     return Cfg{c.simrate, c.dynamics_randomization, c.stance_mode, c.have_incentive, c.max_traj_len, c.pgs_iters,
-               (unsigned)c.seed, (unsigned)(c.seed >> 32)};
+               (unsigned)c.seed, (unsigned)(c.seed >> 32), (unsigned)c.env_id_base};
 }
 
 extern "C" void apx_env_default_cfg(apx_env_cfg* c) {

@@ -118,8 +118,11 @@ class PPOLearner:
         self.actor = Mlp(obs_dim, hidden, act_dim, device)
         self.critic = Mlp(obs_dim, hidden, 1, device)
         z = lambda m: torch.zeros(m.n, dtype=torch.float32, device=device)
-        self.actor_m, self.actor_v, self.actor_g = z(self.actor), z(self.actor), z(self.actor)
-        self.critic_m, self.critic_v, self.critic_g = z(self.critic), z(self.critic), z(self.critic)
+        self.actor_m, self.actor_v = z(self.actor), z(self.actor)
+        self.critic_m, self.critic_v = z(self.critic), z(self.critic)
+        # both gradients in ONE flat buffer so that N>1 ranks need a single RCCL all-reduce per optimiser step
+        self.grad_flat = torch.zeros(self.actor.n + self.critic.n, dtype=torch.float32, device=device)
+        self.actor_g, self.critic_g = self.grad_flat[:self.actor.n], self.grad_flat[self.actor.n:]
         self.obs_mean = torch.zeros(obs_dim, dtype=torch.float32, device=device)
         self.obs_std = torch.ones(obs_dim, dtype=torch.float32, device=device)
         self.fixed_std, self.lr, self.eps, self.clip = float(fixed_std), lr, eps, clip

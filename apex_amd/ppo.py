@@ -1,0 +1,250 @@
+"""PPO driver for the batched engine — the host-side mirror of the reference's rl/algos/ppo.py.
+
+Same control flow as PPO.train (ppo.py:347-505): sample -> returns -> normalised advantages -> `epochs` passes of
+random minibatches with the clipped-ratio / value / mirror losses and KL early stop -> logging / best-checkpoint save,
+but the Ray fan-out of one-env workers (ppo.py:188-237) becomes ONE lock-step batch of N envs per GPU and every array
+stays in HBM.  One process per GPU; with world_size > 1 the env shards are independent and the only collectives are
+one RCCL all-reduce of the 160 523-float gradient per optimiser step plus scalar moments.
+
+Rollout layout: [T, N] grids (env-per-column).  An episode that ends inside the grid bootstraps with
+(not done) * V(s_next) exactly like ppo.py:183-184; a column that is cut by the end of the grid bootstraps with
+V(s_T) (the reference never cuts mid-episode because its workers sample whole episodes; with a fixed grid the cut is
+treated like its max_traj_len truncation).
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import engine
+from .vecenv import CassieVecEnv, MIRRORED_ACTS, MIRRORED_OBS, CLOCK_INDS
+
+
+class PPO:
+    def __init__(self, args, save_path, env, rank=0, world_size=1, group=None, hidden=256):
+        self.gamma = args["gamma"]; self.lam = args["lam"]; self.lr = args["lr"]; self.eps = args["eps"]
+        self.entropy_coeff = args["entropy_coeff"]; self.clip = args["clip"]
+        self.minibatch_size = args["minibatch_size"]; self.epochs = args["epochs"]
+        self.num_steps = args["num_steps"]; self.max_traj_len = args["max_traj_len"]
+        self.grad_clip = args["max_grad_norm"]; self.mirror = args.get("mirror", True)
+        self.fixed_std = float(np.exp(args.get("std_dev", -1.5)))
+        self.env_name = args.get("env_name", "Cassie-v0")
+        self.save_path = save_path
+        self.env = env
+        self.rank, self.world, self.group = rank, world_size, group
+        self.device = env.device
+        self.N = env.n_envs
+        # steps per env per iteration: the reference samples >= num_steps in total (ppo.py:205)
+        self.T = max(1, -(-self.num_steps // (self.N * self.world)))
+        self.learner = engine.PPOLearner(50, 10, hidden, self.device, self.fixed_std, lr=self.lr, eps=self.eps,
+                                         clip=self.clip, entropy_coeff=self.entropy_coeff, grad_clip=self.grad_clip,
+                                         mirrored_obs=MIRRORED_OBS if self.mirror else None,
+                                         mirrored_acts=MIRRORED_ACTS if self.mirror else None, clock_inds=CLOCK_INDS)
+        self.total_steps = 0
+        self.highest_reward = -1
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(args.get("seed", 0)) * 1000003 + rank)
+        T, N = self.T, self.N
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.b_obs = torch.zeros(T, N, 50, **f32); self.b_act = torch.zeros(T, N, 10, **f32)
+        self.b_mu = torch.zeros(T, N, 10, **f32); self.b_rew = torch.zeros(T, N, **f32)
+        self.b_val = torch.zeros(T, N, **f32); self.b_boot = torch.zeros(T, N, **f32)
+        self.b_end = torch.zeros(T, N, dtype=torch.uint8, device=self.device)
+        self.ep_ret = torch.zeros(N, **f32); self.ep_len = torch.zeros(N, **f32)
+        self.obs = None
+
+    # ------------------------------------------------------------------------------------------ initialisation
+    def init_networks(self, seed):
+        """normc initialisation exactly as the reference constructs its nets (ppo.py:543-544, actor.py:175-178):
+        built with the checkpoint classes on the host under torch.manual_seed, then uploaded."""
+        from rl.policies.actor import Gaussian_FF_Actor
+        from rl.policies.critic import FF_V
+        torch.manual_seed(seed)
+        H = self.learner.actor.H
+        self.policy = Gaussian_FF_Actor(50, 10, layers=(H, H), fixed_std=np.exp(np.log(self.fixed_std)), env_name=self.env_name)
+        self.critic = FF_V(50, layers=(H, H))
+        self.upload()
+
+    def upload(self):
+        self.learner.actor.load_list([p.detach().numpy() for p in self.policy.parameters()])
+        self.learner.critic.load_list([p.detach().numpy() for p in self.critic.parameters()])
+        if torch.is_tensor(self.policy.obs_mean):
+            self.learner.obs_mean.copy_(self.policy.obs_mean); self.learner.obs_std.copy_(self.policy.obs_std)
+
+    def download(self):
+        with torch.no_grad():
+            for p, v in zip(self.policy.parameters(), self.learner.actor.views()):
+                p.copy_(v.cpu())
+            for p, v in zip(self.critic.parameters(), self.learner.critic.views()):
+                p.copy_(v.cpu())
+        self.policy.obs_mean = self.learner.obs_mean.cpu().clone(); self.policy.obs_std = self.learner.obs_std.cpu().clone()
+        self.critic.obs_mean = self.policy.obs_mean; self.critic.obs_std = self.policy.obs_std
+
+    def normalization_params(self, iters, noise_std=1.0):
+        """get_normalization_params (rl/envs/normalize.py:11-48): policy(state) + N(0, noise_std) actions, mean and
+        sqrt(var + 1e-8) of the raw observations; moments all-reduced over ranks."""
+        steps = max(iters // (self.N * self.world), 50)
+        obs = self.env.reset()
+        s = torch.zeros(50, dtype=torch.float64, device=self.device); ss = torch.zeros_like(s); n = 0
+        for _ in range(steps):
+            s += obs.double().sum(0); ss += (obs.double() ** 2).sum(0); n += obs.shape[0]
+            mu = self.learner.actor.forward(obs, self.learner.obs_mean, self.learner.obs_std)
+            act = mu + torch.randn(mu.shape, device=self.device, generator=self.gen) * noise_std
+            obs, _, _, _ = self.env.step(act)
+        mom = torch.cat([s, ss, torch.tensor([float(n)], dtype=torch.float64, device=self.device)])
+        if self.group is not None:
+            torch.distributed.all_reduce(mom, group=self.group)
+        cnt = mom[100]
+        mean = mom[:50] / cnt
+        var = (mom[50:100] / cnt - mean * mean).clamp_min(0)
+        self.learner.obs_mean.copy_(mean.float()); self.learner.obs_std.copy_(torch.sqrt(var + 1e-8).float())
+
+    # ------------------------------------------------------------------------------------------ sampling
+    @torch.no_grad()
+    def sample(self):
+        """T lock-step env steps for the N envs of this GPU (the batched PPO.sample, ppo.py:139-186)."""
+        L, env = self.learner, self.env
+        if self.obs is None:
+            self.obs = env.reset().clone()
+        obs = self.obs
+        ep_rets, ep_lens = [], []
+        for t in range(self.T):
+            mu = L.actor.forward(obs, L.obs_mean, L.obs_std)
+            val = L.critic.forward(obs).view(-1)
+            act = mu + self.fixed_std * torch.randn(mu.shape, device=self.device, generator=self.gen)
+            self.b_obs[t].copy_(obs); self.b_mu[t].copy_(mu); self.b_act[t].copy_(act); self.b_val[t].copy_(val)
+            nobs, rew, done, fin = env.step(act)
+            self.b_rew[t].copy_(rew)
+            ended = done != 0
+            self.b_end[t].copy_(ended.to(torch.uint8))
+            vfin = L.critic.forward(fin).view(-1)
+            self.b_boot[t].copy_(torch.where(done == 2, vfin, torch.zeros_like(vfin)))     # (not done) * V(s'), ppo.py:184
+            self.ep_ret += rew; self.ep_len += 1
+            if bool(ended.any()):
+                ep_rets.append(self.ep_ret[ended].clone()); ep_lens.append(self.ep_len[ended].clone())
+                self.ep_ret[ended] = 0; self.ep_len[ended] = 0
+            obs = nobs
+        self.obs = obs.clone()
+        last_val = L.critic.forward(self.obs).view(-1)
+        ret = engine.returns_scan(self.b_rew, self.b_end, self.b_boot, last_val, self.gamma)
+        cat = lambda xs: torch.cat(xs) if xs else torch.zeros(0, device=self.device)
+        return ret, cat(ep_rets), cat(ep_lens)
+
+    # ------------------------------------------------------------------------------------------ optimisation
+    def update(self, ret):
+        L = self.learner
+        B = self.T * self.N
+        obs, act, mu = self.b_obs.view(B, 50), self.b_act.view(B, 10), self.b_mu.view(B, 10)
+        ret, val = ret.view(B), self.b_val.view(B)
+        adv = engine.normalize_advantages(ret, val, self.eps, group=self.group)             # ppo.py:395-396
+        mb = min(self.minibatch_size or B, B)
+        losses, kl_last = None, 0.0
+        epochs_run = 0
+        for epoch in range(self.epochs):
+            perm = torch.randperm(B, device=self.device, generator=self.gen)                 # SubsetRandomSampler
+            acc = torch.zeros(6, dtype=torch.float64, device=self.device)
+            nb = B // mb                                                                     # drop_last=True, ppo.py:416
+            for k in range(nb):
+                idx = perm[k * mb:(k + 1) * mb]
+                if self.world > 1:
+                    scal = L.minibatch(obs, act, ret, adv, mu, idx=idx, mirror=self.mirror, grad_only=True, sync=False)
+                    flat = L.grad_flat
+                    torch.distributed.all_reduce(flat, group=self.group)                     # one RCCL all-reduce / step
+                    L.apply_grads(scale=1.0 / self.world)
+                else:
+                    scal = L.minibatch(obs, act, ret, adv, mu, idx=idx, mirror=self.mirror, sync=False)
+                acc += scal
+            if self.world > 1:
+                last = scal.clone()
+                torch.distributed.all_reduce(last, group=self.group); last /= self.world
+                torch.distributed.all_reduce(acc, group=self.group); acc /= self.world
+            else:
+                last = scal
+            losses = (acc / max(nb, 1)).cpu().numpy()
+            kl_last = float(last[4])
+            epochs_run += 1
+            if kl_last > 0.02:                                                               # ppo.py:449 (last minibatch's KL)
+                break
+        return losses, kl_last, epochs_run
+
+    # ------------------------------------------------------------------------------------------ training loop
+    def iteration(self):
+        t0 = time.time()
+        ret, ep_rets, ep_lens = self.sample()
+        torch.cuda.synchronize(self.device)
+        t1 = time.time()
+        losses, kl, epochs_run = self.update(ret)
+        torch.cuda.synchronize(self.device)
+        t2 = time.time()
+        steps = self.T * self.N * self.world
+        self.total_steps += steps
+        return dict(steps=steps, sample_time=t1 - t0, optimize_time=t2 - t1, losses=losses, kl=kl, epochs=epochs_run,
+                    ep_returns=ep_rets, ep_lens=ep_lens)
+
+    def train(self, n_itr, logger=None):
+        for itr in range(n_itr):
+            out = self.iteration()
+            er, el = out["ep_returns"], out["ep_lens"]
+            avg_ret = float(er.mean()) if er.numel() else float("nan")
+            avg_len = float(el.mean()) if el.numel() else float("nan")
+            if self.rank == 0:
+                print("********** Iteration {} ************".format(itr))
+                print("timesteps in batch: %i  sample %.2fs  optimize %.2fs  (%.0f env-steps/s)" % (
+                    out["steps"], out["sample_time"], out["optimize_time"],
+                    out["steps"] / (out["sample_time"] + out["optimize_time"])))
+                print(" ".join("%g" % x for x in out["losses"]))
+                if logger is not None:
+                    ml = out["losses"]
+                    logger.add_scalar("Test/Return", avg_ret, itr)          # eval rollouts == stochastic rollouts in the reference (ppo.py:171)
+                    logger.add_scalar("Train/Return", avg_ret, itr)
+                    logger.add_scalar("Train/Mean Eplen", avg_len, itr)
+                    logger.add_scalar("Train/Mean KL Div", ml[4], itr)
+                    logger.add_scalar("Train/Mean Entropy", ml[1], itr)
+                    logger.add_scalar("Misc/Critic Loss", ml[2], itr)
+                    logger.add_scalar("Misc/Actor Loss", ml[0], itr)
+                    logger.add_scalar("Misc/Mirror Loss", ml[5], itr)
+                    logger.add_scalar("Misc/Timesteps", self.total_steps, itr)
+                    logger.add_scalar("Misc/Sample Times", out["sample_time"], itr)
+                    logger.add_scalar("Misc/Optimize Times", out["optimize_time"], itr)
+                    logger.add_scalar("Misc/Evaluation Times", 0.0, itr)
+                    logger.add_scalar("Misc/Termination Threshold", 0.0, itr)
+                if avg_ret == avg_ret and self.highest_reward < avg_ret:
+                    self.highest_reward = avg_ret
+                    self.save()
+
+    def save(self):
+        """PPO.save (ppo.py:129-137): whole-module pickles actor.pt / critic.pt."""
+        os.makedirs(self.save_path, exist_ok=True)
+        self.download()
+        torch.save(self.policy, os.path.join(self.save_path, "actor.pt"))
+        torch.save(self.critic, os.path.join(self.save_path, "critic.pt"))
+
+
+def run_experiment(args):
+    """rl/algos/ppo.py:507-584 for the batched engine.  One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE)."""
+    from .log import create_logger
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    group = None
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        group = torch.distributed.group.WORLD
+    torch.manual_seed(args.seed); np.random.seed(args.seed)
+    n_envs = getattr(args, "n_envs", 4096)
+    env = CassieVecEnv(n_envs=n_envs, simrate=args.simrate, dynamics_randomization=args.dyn_random, reward=args.reward,
+                       max_traj_len=args.max_traj_len, seed=args.seed, device=local, env_id_base=rank * n_envs,
+                       command_profile=args.command_profile, input_profile=args.input_profile, history=args.history,
+                       learn_gains=args.learn_gains)
+    logger = create_logger(args) if rank == 0 else None
+    a = dict(vars(args)); a["mirror"] = args.mirror
+    algo = PPO(a, logger.dir if logger else "/tmp/apx_unused", env, rank=rank, world_size=world, group=group)
+    if args.previous is not None:
+        algo.policy = torch.load(os.path.join(args.previous, "actor.pt"), weights_only=False)
+        algo.critic = torch.load(os.path.join(args.previous, "critic.pt"), weights_only=False)
+        algo.upload()
+    else:
+        algo.init_networks(args.seed)
+        algo.normalization_params(args.input_norm_steps)
+    algo.train(args.n_itr, logger=logger)
+    return algo

@@ -1,0 +1,23 @@
+"""Algorithmic work of the dominant kernel, used by bench.py's `roofline` object.
+
+ENV_STEP_BYTES: HBM bytes one env step MUST move with all 50 substeps fused in one launch = read + write of the
+persistent per-env state (F_TOTAL fp32 fields + 5 int fields, env.hip `enum Field`) + action in, obs/reward/done out.
+ENV_STEP_FLOP: fp32 operations of one env step of the tree-sparse formulation, counted analytically per substep
+ x 50.
+"""
+F_TOTAL = 577          # floats of persistent state per env (env.hip: enum Field)
+I_TOTAL = 5
+ENV_STEP_BYTES = 2 * 4 * (F_TOTAL + I_TOTAL) + 4 * 10 + 4 * 50 + 4 + 1
+
+# per-substep fp32 op count (multiply-add = 2), typical walking state: 12 equality rows + 2 contacts (8 rows) = 20 rows
+_FK = 25 * 95 + 32 * 12
+_INERTIA = 25 * 110
+_VEL_RNE = 32 * 40 + 25 * 130 + 25 * 12 + 32 * 11
+_CRBA = 25 * 10 + 32 * 45 + 307 * 11
+_FACTOR = 2 * 2 * 1750              # two sparse LDL factorisations
+_SOLVES = 2 * 5 * 307               # u~, v~, w~, qacc, Euler rhs/solve
+_ROWS = 20 * (2 * 60 + 2 * 100 + 2 * 19 * 4)     # Jacobian + whitening + commit dots
+_PGS = 50 * 20 * (2 * 19 * 2 + 8)
+_MISC = 1500
+SUBSTEP_FLOP = _FK + _INERTIA + _VEL_RNE + _CRBA + _FACTOR + _SOLVES + _ROWS + _PGS + _MISC
+ENV_STEP_FLOP = 50 * SUBSTEP_FLOP

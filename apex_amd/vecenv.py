@@ -44,7 +44,7 @@ class CassieVecEnv:
     mirrored_acts = MIRRORED_ACTS
 
     def __init__(self, n_envs=4096, simrate=50, dynamics_randomization=True, reward="clock", max_traj_len=400, seed=0,
-                 device=0, pgs_iters=50, command_profile="clock", input_profile="full", history=0, learn_gains=False):
+                 device=0, pgs_iters=50, env_id_base=0, command_profile="clock", input_profile="full", history=0, learn_gains=False):
         if command_profile != "clock" or input_profile != "full" or history != 0 or learn_gains:
             raise NotImplementedError("only command_profile=clock, input_profile=full, history=0 are on the hot path")
         if not torch.cuda.is_available():
@@ -56,6 +56,7 @@ class CassieVecEnv:
         cfg.n_envs, cfg.simrate, cfg.dynamics_randomization = n_envs, simrate, int(dynamics_randomization)
         cfg.reward_kind, cfg.stance_mode, cfg.have_incentive = r["reward_kind"], r["stance_mode"], r["have_incentive"]
         cfg.max_traj_len, cfg.seed, cfg.device, cfg.pgs_iters = max_traj_len, seed, device, pgs_iters
+        cfg.env_id_base = env_id_base
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
         self._h = C.c_void_p()

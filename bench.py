@@ -1,0 +1,127 @@
+"""bench.py — env-steps/sec (whole job) of the Cassie-v0 PPO hot path on N MI355X GPUs.
+
+One "step" = one PPO iteration on every rank: a T-step lock-step rollout of 4096 envs per GPU (policy/value forward,
+50 x 2 kHz physics substeps per env step, reward, observation), the discounted-return scan, advantage normalisation
+and `epochs` passes of clipped-ratio/value/mirror minibatch updates (Adam, global-norm clip).  Inputs are resident in
+HBM when the timed region starts.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak
+
+
+def cpu_baseline(seconds_hint=12.0):
+    """The fp64 C++ oracle (kind "port") timed on this host's cores: sampling only, bounded sample."""
+    from oracle import sim
+    cores = os.cpu_count() or 1
+    probe = sim.rollout_bench(cores, 4, cores)                        # env-steps/s on a tiny probe
+    n_steps = int(max(8, min(400, seconds_hint * probe / cores)))
+    v = sim.rollout_bench(cores, n_steps, cores)
+    return {"value": round(v, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} envs x {n_steps} env steps (50 substeps each), sampling only, fp64 dense oracle, one env per thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n_envs", type=int, default=4096)
+    ap.add_argument("--rollout_len", type=int, default=32)
+    ap.add_argument("--minibatch", type=int, default=16384)
+    ap.add_argument("--epochs", type=int, default=3)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    group = None
+    torch.cuda.set_device(local)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        group = torch.distributed.group.WORLD
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd.ppo import PPO
+    env = CassieVecEnv(n_envs=a.n_envs, seed=0, device=local, env_id_base=rank * a.n_envs)
+    args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=a.minibatch,
+                epochs=a.epochs, num_steps=a.rollout_len * a.n_envs * world, max_traj_len=400, max_grad_norm=0.05,
+                mirror=True, std_dev=-1.5, seed=0)
+    algo = PPO(args, "/tmp/apx_bench_unused", env, rank=rank, world_size=world, group=group)
+    algo.init_networks(0)
+    algo.normalization_params(10000)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        algo.iteration()
+    # per-launch duration of the dominant kernel (env step), HIP events on the stream the kernel is launched on
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    act = torch.zeros(a.n_envs, 10, device=env.device)
+    barrier()
+    t0 = time.time()
+    samp = opt = 0.0
+    for _ in range(a.steps):
+        out = algo.iteration()
+        samp += out["sample_time"]; opt += out["optimize_time"]
+    barrier()
+    dt = time.time() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=env.device)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax)
+    # dominant-kernel timing, outside the timed region (same state distribution, same launch geometry)
+    n_launch = 8
+    ev0.record()
+    for _ in range(n_launch):
+        env.step(act)
+    ev1.record(); torch.cuda.synchronize()
+    k_ms = ev0.elapsed_time(ev1) / n_launch
+
+    if rank == 0:
+        steps_total = a.steps * a.rollout_len * a.n_envs * world
+        from apex_amd import roofline
+        bytes_per_env_step = roofline.ENV_STEP_BYTES
+        achieved = bytes_per_env_step * a.n_envs / (k_ms * 1e-3) / 1e9
+        res = {
+            "metric": "env-steps/sec (whole node) Cassie-v0 PPO @4096 envs/GPU", "value": round(steps_total / dt, 1),
+            "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Cassie-v0 PPO, 4096 batched envs/GPU, 2x256 MLP actor/critic (BASELINE.json configs[1])",
+                       "envs_per_gpu": a.n_envs, "rollout_len": a.rollout_len, "simrate": 50, "minibatch": a.minibatch,
+                       "epochs": a.epochs, "mirror_loss": True, "dynamics_randomization": True, "eval_rollouts": False,
+                       "parallelism": f"dp{world} (env shards, 1 RCCL grad all-reduce per optimiser step)"},
+            "sampling_env_steps_per_s": round(a.steps * a.rollout_len * a.n_envs * world / max(samp, 1e-9), 1),
+            "sample_s": round(samp / a.steps, 3), "optimize_s": round(opt / a.steps, 3),
+            "roofline": {"kernel": "env_step_kernel", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "ms_per_launch": round(k_ms, 3), "bytes_per_env_step": bytes_per_env_step,
+                         "valu": {"flop_per_env_step": roofline.ENV_STEP_FLOP,
+                                  "achieved_tflops": round(roofline.ENV_STEP_FLOP * a.n_envs / (k_ms * 1e-3) / 1e12, 4),
+                                  "peak_tflops": VALU_PEAK_TFLOPS,
+                                  "frac": round(roofline.ENV_STEP_FLOP * a.n_envs / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 6)}},
+        }
+        if not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -122,7 +122,8 @@ typedef struct apx_env_cfg {
     uint64_t seed;              /* Philox key; stream = (seed, env id) */
     int device;                 /* HIP device ordinal */
     int pgs_iters;              /* cassie.xml:5 iterations (50) */
-    int reserved[7];
+    int env_id_base;            /* global index of this shard's env 0 (RNG stream id = env_id_base + local env) */
+    int reserved[6];
 } apx_env_cfg;
 
 void apx_env_default_cfg(apx_env_cfg* cfg);

@@ -1,0 +1,51 @@
+"""FF_V with the reference's pickle surface (rl/policies/critic.py:37-77): critic_layers, network_out, obs_std,
+obs_mean, normc_init; normalises its input only when NOT in training mode (critic.py:66-67)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from rl.policies.base import Net, normc_fn
+
+
+class Critic(Net):
+    def __init__(self):
+        super().__init__()
+        self.welford_reward_mean = 0.0
+        self.welford_reward_mean_diff = 1.0
+        self.welford_reward_n = 1
+
+    def forward(self):
+        raise NotImplementedError
+
+
+class FF_V(Critic):
+    def __init__(self, state_dim, layers=(256, 256), env_name="NOT SET", nonlinearity=F.relu, normc_init=True,
+                 obs_std=None, obs_mean=None):
+        super().__init__()
+        self.critic_layers = nn.ModuleList()
+        self.critic_layers += [nn.Linear(state_dim, layers[0])]
+        for i in range(len(layers) - 1):
+            self.critic_layers += [nn.Linear(layers[i], layers[i + 1])]
+        self.network_out = nn.Linear(layers[-1], 1)
+        self.env_name = env_name
+        self.nonlinearity = nonlinearity
+        self.obs_std = obs_std
+        self.obs_mean = obs_mean
+        self.normc_init = normc_init
+        self.init_parameters()
+        self.train()
+
+    def init_parameters(self):
+        if self.normc_init:
+            self.apply(normc_fn)
+
+    def forward(self, inputs):
+        if self.training is False:
+            inputs = (inputs - self.obs_mean) / self.obs_std
+        x = inputs
+        for layer in self.critic_layers:
+            x = self.nonlinearity(layer(x))
+        return self.network_out(x)
+
+    def act(self, inputs):
+        return self(inputs)
