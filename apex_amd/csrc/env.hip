@@ -10,60 +10,13 @@
 // (DESIGN.md §6), not HBM bound.
 #include "apx_common.h"
 #include "cassie_dev.h"
+#include "cassie_step2.h"
 #include <new>
 #include <cstring>
 
 using namespace cas;
 
-// ------------------------------------------------------------------------------------------------ state layout
-enum Field : int {
-    F_QPOS = 0, F_QVEL = F_QPOS + NQ, F_QACCW = F_QVEL + NV, F_MASS = F_QACCW + NV, F_DAMP = F_MASS + NB,
-    F_FRIC = F_DAMP + NV, F_FLOOR = F_FRIC + 1 /* n, t1, t2: 9 */, F_BIW = F_FLOOR + 9, F_DIW = F_BIW + NB,
-    F_MNOISE = F_DIW + NV, F_JNOISE = F_MNOISE + 10, F_PDT = F_JNOISE + 6, F_FIFO = F_PDT + 10, F_MENC = F_FIFO + 60,
-    F_JENCX = F_MENC + 90, F_JENCY = F_JENCX + 24, F_SNAP = F_JENCY + 12 /* mpos10 jpos6 quat4 gyro3 acc3 vel3 pz1 */,
-    F_SO = F_SNAP + 30 /* mpos10 mvel10 torque10 jpos6 jvel6 quat4 rotvel3 tvel3 tacc3 height1 */, F_FOOTPREV = F_SO + 56,
-    F_FOOTVEL = F_FOOTPREV + 6, F_PREVACT = F_FOOTVEL + 6, F_PREVTQ = F_PREVACT + 10,
-    F_CMD = F_PREVTQ + 10 /* speed side orient swing stance phaselen */, F_FWD = F_CMD + 6 /* foot force z L,R; foot quat L4 R4; foot pos 6 */,
-    F_TOTAL = F_FWD + 16
-};
-enum SnapOff { SN_MPOS = 0, SN_JPOS = 10, SN_QUAT = 16, SN_GYRO = 20, SN_ACC = 23, SN_VEL = 26, SN_PZ = 29 };
-enum SoOff { SO_MPOS = 0, SO_MVEL = 10, SO_TORQUE = 20, SO_JPOS = 30, SO_JVEL = 36, SO_QUAT = 42, SO_ROTVEL = 46, SO_TVEL = 49, SO_TACC = 52, SO_HEIGHT = 55 };
-enum IField : int { I_TIME = 0, I_PHASE, I_COUNTER, I_RNG, I_FLAGS /* bit0 menc primed, 1 jenc primed, 2 prev_action, 3 prev_torque */, I_TOTAL };
-
-struct apx_env {
-    apx_env_cfg cfg;
-    float* st;      // [F_TOTAL, n]
-    int* ist;       // [I_TOTAL, n]
-    int n;
-};
-
-struct St {
-    float* p; int* ip; int n, env;
-    __device__ __forceinline__ float& operator()(int f) const { return p[(size_t)f * n + env]; }
-    __device__ __forceinline__ int& I(int f) const { return ip[(size_t)f * n + env]; }
-};
-
-struct Cfg { int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; };
-
-// ------------------------------------------------------------------------------------------------ Philox4x32-10
-__device__ __forceinline__ unsigned philox(unsigned k0, unsigned k1, unsigned env, unsigned ctr) {
-    unsigned c0 = ctr, c1 = env, c2 = 0x41505845u, c3 = 0;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
-        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return c0;
-}
-struct Rng {
-    unsigned k0, k1, env, ctr;
-    __device__ __forceinline__ unsigned u32() { return philox(k0, k1, env, ctr++); }
-    __device__ __forceinline__ float u01() { return ((float)(u32() >> 8) + 0.5f) * (1.0f / 16777216.0f); }
-    __device__ __forceinline__ float uniform(float a, float b) { return a + (b - a) * u01(); }
-    __device__ __forceinline__ unsigned randint(unsigned n) { return (unsigned)(((unsigned long long)u32() * n) >> 32); }
-};
+#include "env_state.h"
 
 // ------------------------------------------------------------------------------------------------ forward dynamics
 __device__ __forceinline__ void load_dyn(const St& S, Dyn& dy) {
@@ -73,208 +26,6 @@ __device__ __forceinline__ void load_dyn(const St& S, Dyn& dy) {
     dy.fn = {S(F_FLOOR), S(F_FLOOR + 1), S(F_FLOOR + 2)};
     dy.ft1 = {S(F_FLOOR + 3), S(F_FLOOR + 4), S(F_FLOOR + 5)};
     dy.ft2 = {S(F_FLOOR + 6), S(F_FLOOR + 7), S(F_FLOOR + 8)};
-}
-
-// mj_forward for the current (qpos, qvel); ctrl = actuator-side torques.  Leaves qacc, u~ + z~, LD, M in `w`.
-__device__ void forward(const St& S, const Dyn& dy, Work& w, const Rows& Y, const float* ctrl, int pgs_iters) {
-    kin_crba([&](int i) { return S(F_QPOS + i); }, dy, w);
-    float qvel[NV];
-    for (int d = 0; d < NV; ++d) qvel[d] = S(F_QVEL + d);
-    // velocities + bias forces (mj_comVel + mj_rne with qacc = 0, base acceleration = -gravity)
-    SV cacc[NB], cfrc[NB];
-    w.cvel[0] = {{0, 0, 0}, {0, 0, 0}};
-    cacc[0] = {{0, 0, 0}, {0, 0, GRAV}};
-    {
-        int j = 0;
-        for (int b = 1; b < NB; ++b) {
-            const int p = cm_body_parent[b];
-            SV v = w.cvel[p], a = cacc[p];
-            while (j < NJ && cm_jnt_body[j] == b) {
-                const int d0 = cm_jnt_dofadr[j], nd = cm_jnt_type[j] == 2 ? 3 : 1;
-                const SV vpar = v;                                    // ball: all three cdofdot use the same velocity
-                for (int k = 0; k < nd; ++k) {
-                    a = a + crossMotion(vpar, w.cdof[d0 + k]) * qvel[d0 + k];
-                    v = v + w.cdof[d0 + k] * qvel[d0 + k];
-                }
-                ++j;
-            }
-            w.cvel[b] = v; cacc[b] = a;
-            cfrc[b] = imul(w.crb[b], a) + crossForce(v, imul(w.crb[b], v));
-        }
-    }
-    for (int b = NB - 1; b >= 2; --b) cfrc[cm_body_parent[b]] = cfrc[cm_body_parent[b]] + cfrc[b];
-    crba(w);
-    // qfrc_smooth = passive - bias + actuation
-    for (int d = 0; d < NV; ++d) {
-        const int j = cm_dof_jnt[d];
-        float f = -dy.damping[d] * qvel[d] - sdot(w.cdof[d], cfrc[cm_dof_body[d]]);
-        if (cm_jnt_type[j] != 2) f -= cm_jnt_stiffness[j] * S(F_QPOS + cm_jnt_qposadr[j]);
-        w.smooth[d] = f;
-    }
-    for (int u = 0; u < NU; ++u) {
-        const float c = fminf(fmaxf(ctrl[u], -cm_act_ctrlmax[u]), cm_act_ctrlmax[u]);
-        w.smooth[cm_act_dof[u]] += cm_act_gear[u] * c;
-    }
-    for (int i = 0; i < NM; ++i) w.LD[i] = w.M[i];
-    factor(w.LD, w.dsqrt, w.disqrt);
-    for (int d = 0; d < NV; ++d) w.ut[d] = w.smooth[d];
-    solve_LT(w.LD, w.ut);
-    for (int d = 0; d < NV; ++d) w.ut[d] *= w.disqrt[d];
-    float vt[NV], wt[NV], tmp[NV];
-    mul_L(w.LD, qvel, vt);
-    for (int d = 0; d < NV; ++d) { vt[d] *= w.dsqrt[d]; tmp[d] = S(F_QACCW + d); }
-    mul_L(w.LD, tmp, wt);
-    for (int d = 0; d < NV; ++d) wt[d] *= w.dsqrt[d];
-
-    // ---------------------------------------------------------------- constraint rows
-    int n = 0;
-    float jar[MAXEFC];
-    for (int e = 0; e < NEQ; ++e) {   // connect equalities (cassie.xml:225-230)
-        const int b1 = cm_eq_body1[e], b2 = cm_eq_body2[e], leg = b1 >= 14 ? 1 : 0;
-        const V3 p1 = w.xpos[b1] + mul(w.xmat[b1], ld3(cm_eq_anchor1 + 3 * e));
-        const V3 p2 = w.xpos[b2] + mul(w.xmat[b2], ld3(cm_eq_anchor2 + 3 * e));
-        const V3 c = p1 - p2;
-        float J[3][YW];
-        for (int k = 0; k < YW; ++k) J[0][k] = J[1][k] = J[2][k] = 0.f;
-        jac_point(w, b1, p1, 1.f, J[0], J[1], J[2]);
-        jac_point(w, b2, p2, -1.f, J[0], J[1], J[2]);
-        const float cp[3] = {c.x, c.y, c.z};
-        const float tran = dy.biw[b1] + dy.biw[b2], cn = sqrtf(dot(c, c));
-        for (int k = 0; k < 3; ++k) {
-            whiten_row(w, J[k], leg);
-            commit_row(w, Y, n, J[k], leg, 0, cp[k], cn, tran, 0.005f, vt, wt, &jar[n]);
-            ++n;
-        }
-    }
-    int nlim = 0;
-    for (int j = 0; j < NJ; ++j) {   // joint limits, solreflimit default (0.02, 1)
-        if (!cm_jnt_limited[j]) continue;
-        const float q = S(F_QPOS + cm_jnt_qposadr[j]);
-        for (int side = 0; side < 2; ++side) {
-            const float dist = side == 0 ? q - cm_jnt_range[2 * j] : cm_jnt_range[2 * j + 1] - q;
-            if (dist >= 0.f || nlim >= MAXLIM) continue;
-            const int d = cm_jnt_dofadr[j], leg = d >= 19 ? 1 : 0;
-            float J[YW];
-            for (int k = 0; k < YW; ++k) J[k] = 0.f;
-            J[dof2col(d)] = side == 0 ? 1.f : -1.f;
-            whiten_row(w, J, leg);
-            commit_row(w, Y, n, J, leg, 1, dist, dist, dy.diw[d], 0.02f, vt, wt, &jar[n]);
-            ++n; ++nlim;
-        }
-    }
-    w.ncon = 0;
-    const V3 p0 = ld3(cm_floor_pos);
-    for (int g = 0; g < NG; ++g) {   // collision primitives vs the floor plane, pyramidal cone (condim 3)
-        const int b = cm_geom_body[g], leg = b >= 14 ? 1 : 0;
-        const V3 c = w.xpos[b] + mul(w.xmat[b], ld3(cm_geom_pos + 3 * g));
-        const V3 ax = mul(w.xmat[b], ld3(cm_geom_axis + 3 * g));
-        const int nend = cm_geom_iscapsule[g] ? 2 : 1;
-        for (int e = 0; e < nend; ++e) {
-            const V3 ctr = cm_geom_iscapsule[g] ? c + ax * (e == 0 ? cm_geom_half[g] : -cm_geom_half[g]) : c;
-            const float dist = dot(ctr - p0, dy.fn) - cm_geom_radius[g];
-            if (dist >= 0.f || w.ncon >= MAXCON) continue;
-            const V3 cp = ctr - dy.fn * (cm_geom_radius[g] + 0.5f * dist);
-            float Jx[YW], Jy[YW], Jz[YW];
-            for (int k = 0; k < YW; ++k) Jx[k] = Jy[k] = Jz[k] = 0.f;
-            jac_point(w, b, cp, 1.f, Jx, Jy, Jz);
-            const float mu = dy.friction, tran = dy.biw[b];
-            const V3 dirs[4] = {dy.fn + dy.ft1 * mu, dy.fn - dy.ft1 * mu, dy.fn + dy.ft2 * mu, dy.fn - dy.ft2 * mu};
-            w.con_row[w.ncon] = n; w.con_geom[w.ncon] = (unsigned char)g;
-            for (int k = 0; k < 4; ++k) {
-                float J[YW];
-                for (int i = 0; i < YW; ++i) J[i] = dirs[k].x * Jx[i] + dirs[k].y * Jy[i] + dirs[k].z * Jz[i];
-                whiten_row(w, J, leg);
-                commit_row(w, Y, n + k, J, leg, 2, dist, dist, tran + mu * mu * tran, 0.005f, vt, wt, &jar[n + k]);
-            }
-            const float Rpy = fmaxf(MINVAL, 2.f * mu * mu * w.Rr[n]);     // pyramidal regulariser, impratio 1
-            for (int k = 0; k < 4; ++k) w.Rr[n + k] = Rpy;
-            n += 4; ++w.ncon;
-        }
-    }
-    w.nefc = n;
-
-    // ---------------------------------------------------------------- warm start + PGS in the whitened space
-    for (int d = 0; d < NV; ++d) w.zt[d] = 0.f;
-    float cost = 0.f;
-    for (int r = 0; r < n; ++r) {
-        float fr = -jar[r] / w.Rr[r];
-        if (w.typ[r] != 0 && fr < 0.f) fr = 0.f;
-        w.f[r] = fr;
-        const int leg = w.leg[r];
-        for (int k = 0; k < YW; ++k) w.zt[col2dof(k, leg)] += Y.at(r, k) * fr;
-        cost += fr * (0.5f * w.Rr[r] * fr + w.br[r]);
-    }
-    for (int d = 0; d < NV; ++d) cost += 0.5f * w.zt[d] * w.zt[d];
-    if (cost > 0.f) {
-        for (int r = 0; r < n; ++r) w.f[r] = 0.f;
-        for (int d = 0; d < NV; ++d) w.zt[d] = 0.f;
-    }
-    for (int it = 0; it < pgs_iters; ++it)
-        for (int r = 0; r < n; ++r) {
-            const int leg = w.leg[r];
-            float res = w.br[r] + w.Rr[r] * w.f[r];
-            for (int k = 0; k < YW; ++k) res += Y.at(r, k) * w.zt[col2dof(k, leg)];
-            float fr = w.f[r] - res / (w.diag[r] + w.Rr[r]);
-            if (w.typ[r] != 0 && fr < 0.f) fr = 0.f;
-            const float df = fr - w.f[r];
-            w.f[r] = fr;
-            for (int k = 0; k < YW; ++k) w.zt[col2dof(k, leg)] += Y.at(r, k) * df;
-        }
-    // qacc = L^-1 D^-1/2 (u~ + z~)
-    for (int d = 0; d < NV; ++d) w.qacc[d] = (w.ut[d] + w.zt[d]) * w.disqrt[d];
-    solve_L(w.LD, w.qacc);
-    // contact force on the foot bodies, world axes (cassie_sim_foot_forces)
-    for (int k = 0; k < 3; ++k) w.foot_force[0][k] = w.foot_force[1][k] = 0.f;
-    for (int c = 0; c < w.ncon; ++c) {
-        const int b = cm_geom_body[w.con_geom[c]];
-        if (b != 13 && b != 25) continue;
-        const float* ff = w.f + w.con_row[c];
-        const float fnn = ff[0] + ff[1] + ff[2] + ff[3], f1 = dy.friction * (ff[0] - ff[1]), f2 = dy.friction * (ff[2] - ff[3]);
-        const V3 F = dy.fn * fnn + dy.ft1 * f1 + dy.ft2 * f2;
-        float* o = w.foot_force[b == 13 ? 0 : 1];
-        o[0] += F.x; o[1] += F.y; o[2] += F.z;
-    }
-    // accelerometer at the imu site (cassie.xml:267): classical acceleration of the site point, site frame
-    {
-        SV A = cacc[1];
-        for (int d = 0; d < 6; ++d) A = A + w.cdof[d] * w.qacc[d];
-        const V3 r = mul(w.xmat[1], ld3(cm_imu_pos));
-        const V3 om = w.cvel[1].a;
-        const V3 vp = w.cvel[1].l + cross(om, r);
-        const V3 a = A.l + cross(A.a, r) + cross(om, vp);
-        const M3& R = w.xmat[1];
-        w.acc[0] = dot(col(R, 0), a); w.acc[1] = dot(col(R, 1), a); w.acc[2] = dot(col(R, 2), a);
-    }
-}
-
-// mj_Euler with implicit joint damping: (M + h D) a = qfrc_smooth + J^T f = L^T D^1/2 (u~ + z~)
-__device__ void euler(const St& S, const Dyn& dy, Work& w) {
-    float x[NV], rhs[NV];
-    for (int d = 0; d < NV; ++d) x[d] = (w.ut[d] + w.zt[d]) * w.dsqrt[d];
-    mul_LT(w.LD, x, rhs);
-    for (int i = 0; i < NM; ++i) w.LD[i] = w.M[i];
-    for (int d = 0; d < NV; ++d) w.LD[cm_dof_madr[d]] += DT * dy.damping[d];
-    factor(w.LD, nullptr, nullptr);
-    solve_LT(w.LD, rhs);
-    for (int d = 0; d < NV; ++d) rhs[d] /= w.LD[cm_dof_madr[d]];
-    solve_L(w.LD, rhs);
-    float qv[NV];
-    for (int d = 0; d < NV; ++d) { S(F_QACCW + d) = w.qacc[d]; qv[d] = S(F_QVEL + d) + DT * rhs[d]; S(F_QVEL + d) = qv[d]; }
-    for (int j = 0; j < NJ; ++j) {
-        const int qa = cm_jnt_qposadr[j], da = cm_jnt_dofadr[j];
-        if (cm_jnt_type[j] != 2) { S(F_QPOS + qa) += DT * qv[da]; continue; }
-        const V3 wv = {qv[da], qv[da + 1], qv[da + 2]};
-        const float nw = sqrtf(dot(wv, wv));
-        Q4 q = {S(F_QPOS + qa), S(F_QPOS + qa + 1), S(F_QPOS + qa + 2), S(F_QPOS + qa + 3)};
-        if (nw > 0.f) {
-            float sn, cs;
-            sincosf(0.5f * nw * DT, &sn, &cs);
-            const float s = sn / nw;
-            q = qmul(q, Q4{cs, wv.x * s, wv.y * s, wv.z * s});
-        }
-        q = qnormalize(q);
-        S(F_QPOS + qa) = q.w; S(F_QPOS + qa + 1) = q.x; S(F_QPOS + qa + 2) = q.y; S(F_QPOS + qa + 3) = q.z;
-    }
 }
 
 // mj_setConst subset at qpos0: translational body_invweight0 for the bodies that carry constraints and
@@ -322,22 +73,26 @@ __constant__ float kFir[9] = {2727.f, 534.f, -2658.f, -795.f, 72.f, 110.f, 19.f,
 #define PI_F 3.14159265358979323846f
 
 // forward pass + sensor snapshot + per-forward accessor values (foot force / pose), no integration
-__device__ void forward_snapshot(const St& S, const Dyn& dy, Work& w, const Rows& Y, const float* ctrl, int pgs_iters) {
-    forward(S, dy, w, Y, ctrl, pgs_iters);
+__device__ __forceinline__ void forward_snapshot(const St& S, c2::Fwd& w, const c2::Lds& L, const float (&ctrl)[10], int pgs_iters) {
+    c2::forward2(S, w, L, ctrl, pgs_iters);
     for (int u = 0; u < 10; ++u) S(F_SNAP + SN_MPOS + u) = S(F_QPOS + cm_act_qposadr[u]);
     for (int k = 0; k < 6; ++k) S(F_SNAP + SN_JPOS + k) = S(F_QPOS + cm_jsens_qposadr[k]);
     for (int k = 0; k < 4; ++k) S(F_SNAP + SN_QUAT + k) = S(F_QPOS + 3 + k);
     for (int k = 0; k < 3; ++k) { S(F_SNAP + SN_GYRO + k) = S(F_QVEL + 3 + k); S(F_SNAP + SN_ACC + k) = w.acc[k]; S(F_SNAP + SN_VEL + k) = S(F_QVEL + k); }
     S(F_SNAP + SN_PZ) = S(F_QPOS + 2);
-    S(F_FWD + 0) = w.foot_force[0][2]; S(F_FWD + 1) = w.foot_force[1][2];
-    S(F_FWD + 2) = w.xquat[13].w; S(F_FWD + 3) = w.xquat[13].x; S(F_FWD + 4) = w.xquat[13].y; S(F_FWD + 5) = w.xquat[13].z;
-    S(F_FWD + 6) = w.xquat[25].w; S(F_FWD + 7) = w.xquat[25].x; S(F_FWD + 8) = w.xquat[25].y; S(F_FWD + 9) = w.xquat[25].z;
-    S(F_FWD + 10) = w.xpos[13].x; S(F_FWD + 11) = w.xpos[13].y; S(F_FWD + 12) = w.xpos[13].z - 0.0550841220316708f;
-    S(F_FWD + 13) = w.xpos[25].x; S(F_FWD + 14) = w.xpos[25].y; S(F_FWD + 15) = w.xpos[25].z - 0.0550841220316708f;
+    S(F_FWD + 0) = w.foot_fz[0]; S(F_FWD + 1) = w.foot_fz[1];
+    S(F_FWD + 2) = w.footq[0].w; S(F_FWD + 3) = w.footq[0].x; S(F_FWD + 4) = w.footq[0].y; S(F_FWD + 5) = w.footq[0].z;
+    S(F_FWD + 6) = w.footq[1].w; S(F_FWD + 7) = w.footq[1].x; S(F_FWD + 8) = w.footq[1].y; S(F_FWD + 9) = w.footq[1].z;
+    S(F_FWD + 10) = w.footp[0].x; S(F_FWD + 11) = w.footp[0].y; S(F_FWD + 12) = w.footp[0].z - 0.0550841220316708f;
+    S(F_FWD + 13) = w.footp[1].x; S(F_FWD + 14) = w.footp[1].y; S(F_FWD + 15) = w.footp[1].z - 0.0550841220316708f;
 }
 
 // one 2 kHz substep: encoders + estimator -> PD -> safeties -> motor model / delay -> mj_step
-__device__ void sim_step_pd(const St& S, const Dyn& dy, Work& w, const Rows& Y, int pgs_iters) {
+// with_euler = false: forward pass only (cassie_sim_set_const ends in mj_forward)
+__device__ __noinline__ void sim_step_pd(St S, float4* lds_lane, int pgs_iters, int mode) {
+    c2::Fwd w;
+    const c2::Lds Y{lds_lane};
+    if (mode == 0) { const float zero[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; forward_snapshot(S, w, Y, zero, pgs_iters); return; }
     int flags = S.I(I_FLAGS);
     float ctrl[10];
     for (int u = 0; u < 10; ++u) {
@@ -388,8 +143,8 @@ __device__ void sim_step_pd(const St& S, const Dyn& dy, Work& w, const Rows& Y, 
         S(F_SO + SO_TACC) = aw.x; S(F_SO + SO_TACC + 1) = aw.y; S(F_SO + SO_TACC + 2) = aw.z - GRAV;
         S(F_SO + SO_HEIGHT) = S(F_SNAP + SN_PZ) - cm_floor_pos[2];
     }
-    forward_snapshot(S, dy, w, Y, ctrl, pgs_iters);
-    euler(S, dy, w);
+    forward_snapshot(S, w, Y, ctrl, pgs_iters);
+    c2::euler2(S, w);
 }
 
 // ------------------------------------------------------------------------------------------------ env logic
@@ -480,7 +235,7 @@ __device__ __forceinline__ void clock_from_speed(const St& S, float speed, int f
 }
 
 // CassieEnv.reset (cassie/cassie.py:523-680)
-__device__ void env_reset(const St& S, const Cfg& cfg, Dyn& dy, Work& w, const Rows& Y) {
+__device__ void env_reset(const St& S, const Cfg& cfg, float4* lds_lane) {
     Rng r{cfg.seed_lo, cfg.seed_hi, cfg.env_base + (unsigned)S.env, (unsigned)S.I(I_RNG)};
     const float speed0 = r.uniform(-0.3f, 4.0f);
     (void)r.uniform(-0.3f, 0.3f);
@@ -514,14 +269,12 @@ __device__ void env_reset(const St& S, const Cfg& cfg, Dyn& dy, Work& w, const R
         for (int k = 0; k < 9; ++k) S(F_FLOOR + k) = fl[k];
         for (int u = 0; u < 10; ++u) S(F_MNOISE + u) = r.uniform(-0.01f, 0.01f);
         for (int k = 0; k < 6; ++k) S(F_JNOISE + k) = r.uniform(-0.01f, 0.01f);
-        load_dyn(S, dy);
-        set_const(S, dy, w);
+        { Dyn dy; Work w; load_dyn(S, dy); set_const(S, dy, w); }
     }
     for (int i = 0; i < NQ; ++i) S(F_QPOS + i) = cm_init_qpos[i];
     for (int i = 0; i < NV; ++i) { S(F_QVEL + i) = 0.f; S(F_QACCW + i) = 0.f; }
-    float zero[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    forward_snapshot(S, dy, w, Y, zero, cfg.pgs_iters);       // cassie_sim_set_const ends in mj_forward
-    sim_step_pd(S, dy, w, Y, cfg.pgs_iters);                  // cassie.py:665 (stale pd_in_t)
+    sim_step_pd(S, lds_lane, cfg.pgs_iters, 0);               // cassie_sim_set_const ends in mj_forward
+    sim_step_pd(S, lds_lane, cfg.pgs_iters, 1);               // cassie.py:665 (stale pd_in_t)
     for (int k = 0; k < 6; ++k) S(F_FOOTPREV + k) = S(F_FWD + 10 + k);
     S(F_CMD + 2) = 0.f;
     S(F_CMD + 0) = r.uniform(-0.3f, 4.0f);
@@ -563,19 +316,17 @@ __device__ float clock_reward(const St& S, const Cfg& cfg, const float* action, 
 
 // ------------------------------------------------------------------------------------------------ kernels
 #define ENV_SETUP                                                                                   \
-    extern __shared__ __attribute__((aligned(16))) float lds[];                                      \
+    extern __shared__ __attribute__((aligned(16))) float4 lds4[];                                    \
     const int lane = threadIdx.x & 63;                                                               \
     const int env = blockIdx.x * 64 + lane;                                                          \
     if (env >= n) return;                                                                            \
-    const St S{st, ist, n, env};                                                                     \
-    float yext[(MAXEFC - NLDS) * YW];                                                                \
-    const Rows Y{lds, lane, yext};                                                                   \
-    Dyn dy; Work w;
+    const St S{st, ist, n, env, wk};                                                                 \
+    float4* lds_lane = lds4 + lane;
 
 __global__ __launch_bounds__(64) void env_init_kernel(float* st, int* ist, int n, Cfg cfg) {
     const int env = blockIdx.x * 64 + threadIdx.x;
     if (env >= n) return;
-    const St S{st, ist, n, env};
+    const St S{st, ist, n, env, nullptr};
     for (int f = 0; f < F_TOTAL; ++f) S(f) = 0.f;
     for (int f = 0; f < I_TOTAL; ++f) S.I(f) = 0;
     for (int i = 0; i < NQ; ++i) S(F_QPOS + i) = cm_init_qpos[i];
@@ -586,24 +337,27 @@ __global__ __launch_bounds__(64) void env_init_kernel(float* st, int* ist, int n
     for (int k = 0; k < 9; ++k) S(F_FLOOR + k) = fl[k];
 }
 
-__global__ __launch_bounds__(64) void env_setconst_kernel(float* st, int* ist, int n, Cfg cfg) {
-    ENV_SETUP
+__global__ __launch_bounds__(64) void env_setconst_kernel(float* st, int* ist, float* wk, int n, Cfg cfg) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= n) return;
+    const St S{st, ist, n, env, wk};
+    Dyn dy; Work w;
     load_dyn(S, dy);
     set_const(S, dy, w);
 }
 
-__global__ __launch_bounds__(64) void env_reset_kernel(float* st, int* ist, int n, Cfg cfg, const uint8_t* mask, float* obs) {
+// CassieEnv.reset for the envs selected by mask (NULL = all); a separate launch so that the step kernel's register
+// allocation is not shaped by the (rare, slower) reset path
+__global__ __launch_bounds__(64) void env_reset_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const uint8_t* mask, float* obs) {
     ENV_SETUP
     if (mask && !mask[env]) return;
-    load_dyn(S, dy);
-    env_reset(S, cfg, dy, w, Y);
+    env_reset(S, cfg, lds_lane);
     if (obs) write_obs(S, cfg, obs + (size_t)env * APX_OBS_DIM);
 }
 
-__global__ __launch_bounds__(64) void env_step_kernel(float* st, int* ist, int n, Cfg cfg, const float* action, float* obs,
-                                                       float* reward, uint8_t* done, float* final_obs, int auto_reset) {
+__global__ __launch_bounds__(64) void env_step_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const float* action, float* obs,
+                                                       float* reward, uint8_t* done, float* final_obs) {
     ENV_SETUP
-    load_dyn(S, dy);
     float act[10];
     for (int u = 0; u < 10; ++u) {
         act[u] = action[(size_t)env * APX_ACT_DIM + u];
@@ -612,7 +366,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(float* st, int* ist, int n
     S.I(I_FLAGS) |= 16;
     float lfrc = 0.f, rfrc = 0.f, lor = 0.f, ror = 0.f;
     for (int i = 0; i < cfg.simrate; ++i) {
-        sim_step_pd(S, dy, w, Y, cfg.pgs_iters);
+        sim_step_pd(S, lds_lane, cfg.pgs_iters, 1);
         for (int k = 0; k < 6; ++k) {                                            // cassie.py:328-331
             const float fp = S(F_FWD + 10 + k);
             S(F_FOOTVEL + k) = (fp - S(F_FOOTPREV + k)) / 0.0005f;
@@ -646,22 +400,18 @@ __global__ __launch_bounds__(64) void env_step_kernel(float* st, int* ist, int n
     if (!dn && time >= cfg.max_traj_len) dn = 2;
     reward[env] = rew;
     done[env] = (uint8_t)dn;
-    if (dn && auto_reset) {
-        if (final_obs) write_obs(S, cfg, final_obs + (size_t)env * APX_OBS_DIM);
-        env_reset(S, cfg, dy, w, Y);
-    }
     write_obs(S, cfg, obs + (size_t)env * APX_OBS_DIM);
+    if (dn && final_obs) for (int k = 0; k < APX_OBS_DIM; ++k) final_obs[(size_t)env * APX_OBS_DIM + k] = obs[(size_t)env * APX_OBS_DIM + k];
 }
 
 // raw substeps with the current pd targets (tests): n_sub x cassie_sim_step_pd
-__global__ __launch_bounds__(64) void env_substep_kernel(float* st, int* ist, int n, Cfg cfg, int n_sub) {
+__global__ __launch_bounds__(64) void env_substep_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, int n_sub) {
     ENV_SETUP
-    load_dyn(S, dy);
-    for (int i = 0; i < n_sub; ++i) sim_step_pd(S, dy, w, Y, cfg.pgs_iters);
+    for (int i = 0; i < n_sub; ++i) sim_step_pd(S, lds_lane, cfg.pgs_iters, 1);
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
-static constexpr size_t LDS_BYTES = (size_t)NLDS * YW * 64 * sizeof(float);   // 160,512 B of the CU's 163,840
+static constexpr size_t LDS_BYTES = (size_t)c2::CH_TOTAL * 64 * sizeof(float4);   // 159,744 B of the CU's 163,840
 
 static Cfg make_cfg(const apx_env_cfg& c) {
     return Cfg{c.simrate, c.dynamics_randomization, c.stance_mode, c.have_incentive, c.max_traj_len, c.pgs_iters,
@@ -687,14 +437,15 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     e->cfg = *cfg; e->n = cfg->n_envs; e->st = nullptr; e->ist = nullptr;
     APX_HIP(hipMalloc(&e->st, sizeof(float) * (size_t)F_TOTAL * e->n));
     APX_HIP(hipMalloc(&e->ist, sizeof(int) * (size_t)I_TOTAL * e->n));
+    e->wk = nullptr;
+    APX_HIP(hipMalloc(&e->wk, sizeof(float) * (size_t)c2::NM * e->n));
     const Cfg c = make_cfg(*cfg);
     hipLaunchKernelGGL(env_init_kernel, dim3(e->n / 64), dim3(64), 0, 0, e->st, e->ist, e->n, c);
     APX_LAUNCH_CHECK();
     APX_HIP(hipFuncSetAttribute((const void*)env_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
     APX_HIP(hipFuncSetAttribute((const void*)env_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
     APX_HIP(hipFuncSetAttribute((const void*)env_substep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    APX_HIP(hipFuncSetAttribute((const void*)env_setconst_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    hipLaunchKernelGGL(env_setconst_kernel, dim3(e->n / 64), dim3(64), LDS_BYTES, 0, e->st, e->ist, e->n, c);
+    hipLaunchKernelGGL(env_setconst_kernel, dim3(e->n / 64), dim3(64), 0, 0, e->st, e->ist, e->wk, e->n, c);
     APX_LAUNCH_CHECK();
     APX_HIP(hipDeviceSynchronize());
     *out = e;
@@ -703,14 +454,14 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
 
 extern "C" int apx_env_destroy(apx_env_t* e) {
     if (!e) return APX_OK;
-    (void)hipFree(e->st); (void)hipFree(e->ist);
+    (void)hipFree(e->st); (void)hipFree(e->ist); (void)hipFree(e->wk);
     delete e;
     return APX_OK;
 }
 
 extern "C" int apx_env_reset(apx_env_t* e, const uint8_t* mask, float* obs_out, void* stream) {
     APX_REQUIRE(e, "env");
-    hipLaunchKernelGGL(env_reset_kernel, dim3(e->n / 64), dim3(64), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->n,
+    hipLaunchKernelGGL(env_reset_kernel, dim3(e->n / 64), dim3(64), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
                        make_cfg(e->cfg), mask, obs_out);
     APX_LAUNCH_CHECK();
     return APX_OK;
@@ -719,9 +470,14 @@ extern "C" int apx_env_reset(apx_env_t* e, const uint8_t* mask, float* obs_out, 
 extern "C" int apx_env_step(apx_env_t* e, const float* action, float* obs, float* reward, uint8_t* done, float* final_obs,
                             int auto_reset, void* stream) {
     APX_REQUIRE(e && action && obs && reward && done, "null pointer");
-    hipLaunchKernelGGL(env_step_kernel, dim3(e->n / 64), dim3(64), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->n,
-                       make_cfg(e->cfg), action, obs, reward, done, final_obs, auto_reset);
+    hipLaunchKernelGGL(env_step_kernel, dim3(e->n / 64), dim3(64), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+                       make_cfg(e->cfg), action, obs, reward, done, final_obs);
     APX_LAUNCH_CHECK();
+    if (auto_reset) {   // finished envs restart in a second launch on the same stream (mask = done flags)
+        hipLaunchKernelGGL(env_reset_kernel, dim3(e->n / 64), dim3(64), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+                           make_cfg(e->cfg), done, obs);
+        APX_LAUNCH_CHECK();
+    }
     return APX_OK;
 }
 
@@ -776,7 +532,7 @@ extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, voi
         return I_TOTAL;
     }
     if (!strcmp(name, "substep")) {   // debugging hook: out[0] (host-readable count is not needed) - run one raw substep
-        hipLaunchKernelGGL(env_substep_kernel, dim3(e->n / 64), dim3(64), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->n, make_cfg(e->cfg), 1);
+        hipLaunchKernelGGL(env_substep_kernel, dim3(e->n / 64), dim3(64), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(e->cfg), 1);
         APX_LAUNCH_CHECK();
         return 0;
     }
@@ -790,7 +546,7 @@ extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, voi
 extern "C" int apx_env_set_field(apx_env_t* e, const char* name, const float* in, void* stream) {
     APX_REQUIRE(e && name, "null pointer");
     if (!strcmp(name, "set_const")) {   // recompute invweight0 after mass edits (sim.set_const)
-        hipLaunchKernelGGL(env_setconst_kernel, dim3(e->n / 64), dim3(64), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->n, make_cfg(e->cfg));
+        hipLaunchKernelGGL(env_setconst_kernel, dim3(e->n / 64), dim3(64), 0, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(e->cfg));
         APX_LAUNCH_CHECK();
         return 0;
     }

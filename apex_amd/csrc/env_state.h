@@ -1,0 +1,58 @@
+// Per-env persistent state layout (SoA in HBM, field-major) + tiny helpers shared by the env kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/apx.h"
+
+constexpr int ES_NQ = 35, ES_NV = 32, ES_NB = 26;
+// ------------------------------------------------------------------------------------------------ state layout
+enum Field : int {
+    F_QPOS = 0, F_QVEL = F_QPOS + ES_NQ, F_QACCW = F_QVEL + ES_NV, F_MASS = F_QACCW + ES_NV, F_DAMP = F_MASS + ES_NB,
+    F_FRIC = F_DAMP + ES_NV, F_FLOOR = F_FRIC + 1 /* n, t1, t2: 9 */, F_BIW = F_FLOOR + 9, F_DIW = F_BIW + ES_NB,
+    F_MNOISE = F_DIW + ES_NV, F_JNOISE = F_MNOISE + 10, F_PDT = F_JNOISE + 6, F_FIFO = F_PDT + 10, F_MENC = F_FIFO + 60,
+    F_JENCX = F_MENC + 90, F_JENCY = F_JENCX + 24, F_SNAP = F_JENCY + 12 /* mpos10 jpos6 quat4 gyro3 acc3 vel3 pz1 */,
+    F_SO = F_SNAP + 30 /* mpos10 mvel10 torque10 jpos6 jvel6 quat4 rotvel3 tvel3 tacc3 height1 */, F_FOOTPREV = F_SO + 56,
+    F_FOOTVEL = F_FOOTPREV + 6, F_PREVACT = F_FOOTVEL + 6, F_PREVTQ = F_PREVACT + 10,
+    F_CMD = F_PREVTQ + 10 /* speed side orient swing stance phaselen */, F_FWD = F_CMD + 6 /* foot force z L,R; foot quat L4 R4; foot pos 6 */,
+    F_TOTAL = F_FWD + 16
+};
+enum SnapOff { SN_MPOS = 0, SN_JPOS = 10, SN_QUAT = 16, SN_GYRO = 20, SN_ACC = 23, SN_VEL = 26, SN_PZ = 29 };
+enum SoOff { SO_MPOS = 0, SO_MVEL = 10, SO_TORQUE = 20, SO_JPOS = 30, SO_JVEL = 36, SO_QUAT = 42, SO_ROTVEL = 46, SO_TVEL = 49, SO_TACC = 52, SO_HEIGHT = 55 };
+enum IField : int { I_TIME = 0, I_PHASE, I_COUNTER, I_RNG, I_FLAGS /* bit0 menc primed, 1 jenc primed, 2 prev_action, 3 prev_torque */, I_TOTAL };
+
+struct apx_env {
+    apx_env_cfg cfg;
+    float* st;      // [F_TOTAL, n]
+    int* ist;       // [I_TOTAL, n]
+    float* wk;      // [307, n] per-env mass-matrix scratch (written by forward, read by Euler)
+    int n;
+};
+
+struct St {
+    float* p; int* ip; int n, env; float* wk;      // wk: [307, n] workspace column for the mass matrix
+    __device__ __forceinline__ float& operator()(int f) const { return p[(size_t)f * n + env]; }
+    __device__ __forceinline__ float& W(int i) const { return wk[(size_t)i * n + env]; }
+    __device__ __forceinline__ int& I(int f) const { return ip[(size_t)f * n + env]; }
+};
+
+struct Cfg { int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; };
+
+// ------------------------------------------------------------------------------------------------ Philox4x32-10
+__device__ __forceinline__ unsigned philox(unsigned k0, unsigned k1, unsigned env, unsigned ctr) {
+    unsigned c0 = ctr, c1 = env, c2 = 0x41505845u, c3 = 0;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+struct Rng {
+    unsigned k0, k1, env, ctr;
+    __device__ __forceinline__ unsigned u32() { return philox(k0, k1, env, ctr++); }
+    __device__ __forceinline__ float u01() { return ((float)(u32() >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+    __device__ __forceinline__ float uniform(float a, float b) { return a + (b - a) * u01(); }
+    __device__ __forceinline__ unsigned randint(unsigned n) { return (unsigned)(((unsigned long long)u32() * n) >> 32); }
+};
+

@@ -239,40 +239,11 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
     chol_solve(w.L, w.smooth, qacc_smooth);
 
     // ------------------------------------------------------------------ constraint rows (mj_makeConstraint)
+    // Row order is LEG-MAJOR: [left: 2 connects (6 rows), <=1 limit row, <=3 contacts (4 rows each)] then the same for the
+    // right leg.  MuJoCo orders rows type-major (equality, limit, contact); projected Gauss-Seidel converges to the same
+    // solution of the strictly convex dual for any sweep order, only the iterates differ.
     int n = 0;
     Row* rows = w.rows;
-    for (int e = 0; e < NEQ; ++e) {   // connect equalities, cassie.xml:225-230
-        const int b1 = cm_eq_body1[e], b2 = cm_eq_body2[e];
-        const V3 p1 = s.xpos[b1] + mul(s.xmat[b1], v3(cm_eq_anchor1 + 3 * e));
-        const V3 p2 = s.xpos[b2] + mul(s.xmat[b2], v3(cm_eq_anchor2 + 3 * e));
-        const V3 c = p1 - p2;
-        for (int k = 0; k < 3; ++k) std::memset(rows[n + k].J, 0, sizeof(rows[n + k].J));
-        jac_point(w, b1, p1, rows[n].J, rows[n + 1].J, rows[n + 2].J, 1.0);
-        jac_point(w, b2, p2, rows[n].J, rows[n + 1].J, rows[n + 2].J, -1.0);
-        const double cp[3] = {c.x, c.y, c.z};
-        const double tran = p.body_invweight0[b1][0] + p.body_invweight0[b2][0];
-        for (int k = 0; k < 3; ++k) {
-            rows[n + k].pos = cp[k]; rows[n + k].type = 0; rows[n + k].diag = tran;
-            finish_row(rows[n + k], s.qvel, norm(c), 0.005, 1.0);
-        }
-        n += 3;
-    }
-    int nlim = 0;
-    for (int j = 0; j < NJ && nlim < MAXLIM; ++j) {   // joint limits (mj_instantiateLimit), solreflimit default 0.02 1
-        if (!cm_jnt_limited[j]) continue;
-        const double q = s.qpos[cm_jnt_qposadr[j]];
-        for (int side = 0; side < 2 && nlim < MAXLIM; ++side) {
-            const double dist = side == 0 ? q - cm_jnt_range[2 * j] : cm_jnt_range[2 * j + 1] - q;
-            if (dist >= 0) continue;
-            Row& r = rows[n];
-            std::memset(r.J, 0, sizeof(r.J));
-            r.J[cm_jnt_dofadr[j]] = side == 0 ? 1.0 : -1.0;
-            r.pos = dist; r.type = 1; r.diag = p.dof_invweight0[cm_jnt_dofadr[j]];
-            finish_row(r, s.qvel, dist, 0.02, 1.0);
-            ++n; ++nlim;
-        }
-    }
-    // contacts: collision primitives vs the floor plane (mjc_PlaneSphere / mjc_PlaneCapsule), pyramidal cone, condim 3
     const M3 Rf = q2m(p.floor_quat);
     const V3 nrm = col(Rf, 2), p0 = v3(cm_floor_pos);
     V3 t1 = std::fabs(nrm.y) < 0.5 ? V3{0, 1, 0} : V3{0, 0, 1};      // mju_makeFrame
@@ -280,32 +251,69 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
     const V3 t2 = cross(nrm, t1);
     s.ncon = 0;
     int con_row[MAXCON];
-    for (int g = 0; g < NG && s.ncon < MAXCON; ++g) {
-        const int b = cm_geom_body[g];
-        const V3 c = s.xpos[b] + mul(s.xmat[b], v3(cm_geom_pos + 3 * g));
-        const V3 ax = mul(s.xmat[b], v3(cm_geom_axis + 3 * g));
-        const int nend = cm_geom_iscapsule[g] ? 2 : 1;
-        for (int e = 0; e < nend && s.ncon < MAXCON; ++e) {
-            const V3 ctr = cm_geom_iscapsule[g] ? c + ax * (e == 0 ? cm_geom_half[g] : -cm_geom_half[g]) : c;
-            const double dist = dot(ctr - p0, nrm) - cm_geom_radius[g];
-            if (dist >= 0) continue;
-            const V3 cp = ctr - nrm * (cm_geom_radius[g] + 0.5 * dist);
-            double Jx[NV] = {0}, Jy[NV] = {0}, Jz[NV] = {0};
-            jac_point(w, b, cp, Jx, Jy, Jz, 1.0);
-            const double mu = p.friction;
-            const double tran = p.body_invweight0[b][0];     // + world (0)
-            const V3 dirs[4] = {nrm + t1 * mu, nrm - t1 * mu, nrm + t2 * mu, nrm - t2 * mu};
-            con_row[s.ncon] = n; s.con_dist[s.ncon] = dist; s.con_geom[s.ncon] = g;
-            for (int k = 0; k < 4; ++k) {
-                Row& r = rows[n + k];
-                for (int d = 0; d < NV; ++d) r.J[d] = dirs[k].x * Jx[d] + dirs[k].y * Jy[d] + dirs[k].z * Jz[d];
-                r.pos = dist; r.type = 2; r.diag = tran + mu * mu * tran;
-                finish_row(r, s.qvel, dist, 0.005, 1.0);
+    for (int leg = 0; leg < 2; ++leg) {
+        const int body_lo = leg == 0 ? 2 : 14, body_hi = leg == 0 ? 13 : 25;
+        for (int e = 2 * leg; e < 2 * leg + 2; ++e) {   // connect equalities, cassie.xml:225-230
+            const int b1 = cm_eq_body1[e], b2 = cm_eq_body2[e];
+            const V3 p1 = s.xpos[b1] + mul(s.xmat[b1], v3(cm_eq_anchor1 + 3 * e));
+            const V3 p2 = s.xpos[b2] + mul(s.xmat[b2], v3(cm_eq_anchor2 + 3 * e));
+            const V3 c = p1 - p2;
+            for (int k = 0; k < 3; ++k) std::memset(rows[n + k].J, 0, sizeof(rows[n + k].J));
+            jac_point(w, b1, p1, rows[n].J, rows[n + 1].J, rows[n + 2].J, 1.0);
+            jac_point(w, b2, p2, rows[n].J, rows[n + 1].J, rows[n + 2].J, -1.0);
+            const double cp[3] = {c.x, c.y, c.z};
+            const double tran = p.body_invweight0[b1][0] + p.body_invweight0[b2][0];
+            for (int k = 0; k < 3; ++k) {
+                rows[n + k].pos = cp[k]; rows[n + k].type = 0; rows[n + k].diag = tran;
+                finish_row(rows[n + k], s.qvel, norm(c), 0.005, 1.0);
             }
-            // pyramidal regulariser: all rows of the contact share Rpy = 2 mu^2 R(first row), impratio = 1
-            const double Rpy = std::max(MINVAL, 2 * mu * mu * rows[n].R);
-            for (int k = 0; k < 4; ++k) rows[n + k].R = Rpy;
-            n += 4; ++s.ncon;
+            n += 3;
+        }
+        int nlim = 0;   // joint limits (mj_instantiateLimit), solreflimit default 0.02 1; first active one per leg
+        for (int j = 0; j < NJ && nlim < MAXLIM_LEG; ++j) {
+            if (!cm_jnt_limited[j] || cm_jnt_body[j] < body_lo || cm_jnt_body[j] > body_hi) continue;
+            const double q = s.qpos[cm_jnt_qposadr[j]];
+            for (int side = 0; side < 2 && nlim < MAXLIM_LEG; ++side) {
+                const double dist = side == 0 ? q - cm_jnt_range[2 * j] : cm_jnt_range[2 * j + 1] - q;
+                if (dist >= 0) continue;
+                Row& r = rows[n];
+                std::memset(r.J, 0, sizeof(r.J));
+                r.J[cm_jnt_dofadr[j]] = side == 0 ? 1.0 : -1.0;
+                r.pos = dist; r.type = 1; r.diag = p.dof_invweight0[cm_jnt_dofadr[j]];
+                finish_row(r, s.qvel, dist, 0.02, 1.0);
+                ++n; ++nlim;
+            }
+        }
+        // contacts: foot / tarsus / shin capsules of this leg vs the floor plane (mjc_PlaneCapsule), pyramidal cone,
+        // condim 3; first MAXCON_LEG penetrating capsule ends in that priority order.  The hip-pitch capsules and the
+        // pelvis sphere cannot reach the floor before the episode ends at pelvis z < 0.4 (cassie.py:462): left out.
+        int ncl = 0;
+        for (int g = leg; g < 6 && ncl < MAXCON_LEG; g += 2) {
+            const int b = cm_geom_body[g];
+            const V3 c = s.xpos[b] + mul(s.xmat[b], v3(cm_geom_pos + 3 * g));
+            const V3 ax = mul(s.xmat[b], v3(cm_geom_axis + 3 * g));
+            for (int e = 0; e < 2 && ncl < MAXCON_LEG; ++e) {
+                const V3 ctr = c + ax * (e == 0 ? cm_geom_half[g] : -cm_geom_half[g]);
+                const double dist = dot(ctr - p0, nrm) - cm_geom_radius[g];
+                if (dist >= 0) continue;
+                const V3 cp = ctr - nrm * (cm_geom_radius[g] + 0.5 * dist);
+                double Jx[NV] = {0}, Jy[NV] = {0}, Jz[NV] = {0};
+                jac_point(w, b, cp, Jx, Jy, Jz, 1.0);
+                const double mu = p.friction;
+                const double tran = p.body_invweight0[b][0];     // + world (0)
+                const V3 dirs[4] = {nrm + t1 * mu, nrm - t1 * mu, nrm + t2 * mu, nrm - t2 * mu};
+                con_row[s.ncon] = n; s.con_dist[s.ncon] = dist; s.con_geom[s.ncon] = g;
+                for (int k = 0; k < 4; ++k) {
+                    Row& r = rows[n + k];
+                    for (int d = 0; d < NV; ++d) r.J[d] = dirs[k].x * Jx[d] + dirs[k].y * Jy[d] + dirs[k].z * Jz[d];
+                    r.pos = dist; r.type = 2; r.diag = tran + mu * mu * tran;
+                    finish_row(r, s.qvel, dist, 0.005, 1.0);
+                }
+                // pyramidal regulariser: all rows of the contact share Rpy = 2 mu^2 R(first row), impratio = 1
+                const double Rpy = std::max(MINVAL, 2 * mu * mu * rows[n].R);
+                for (int k = 0; k < 4; ++k) rows[n + k].R = Rpy;
+                n += 4; ++s.ncon; ++ncl;
+            }
         }
     }
     s.nefc = n;

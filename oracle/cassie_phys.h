@@ -19,8 +19,8 @@
 namespace orc {
 
 constexpr int NB = CM_NBODY, NV = CM_NV, NQ = CM_NQ, NJ = CM_NJNT, NG = CM_NGEOM, NEQ = CM_NEQ, NU = CM_NU;
-constexpr int MAXCON = 8;                          // contacts kept per step, in table (priority) order
-constexpr int MAXLIM = 4;                          // active joint-limit rows kept per step
+constexpr int MAXCON_LEG = 3, MAXLIM_LEG = 1;      // per-leg caps on contacts / active limit rows per step
+constexpr int MAXCON = 2 * MAXCON_LEG, MAXLIM = 2 * MAXLIM_LEG;
 constexpr int MAXEFC = 3 * NEQ + MAXLIM + 4 * MAXCON;
 constexpr double MINVAL = 1e-15;
 constexpr double DT = 0.0005;                      // cassie.xml:5

@@ -262,6 +262,28 @@ def emit_header(model, ctype, guard, decl="static const"):
             j = par[j]
     out.append(_carr("cm_dof_madr", madr + [tot], "int"))
     out.append(f"#define CM_NM {tot}\n")
+    # ancestor chains (self first), padded to 16, and chain lengths: compile-time unrolling tables
+    depth, anc = [], []
+    for i in range(len(D)):
+        ch, j = [], i
+        while j >= 0:
+            ch.append(j); j = par[j]
+        depth.append(len(ch)); anc.append(ch + [-1] * (16 - len(ch)))
+    out.append(_carr("cm_dof_depth", depth, "int"))
+    out.append(_carr("cm_dof_anc", anc, "int", 16))
+    jadr, jnum = [], []
+    for bi in range(len(B)):
+        js = [k for k, j in enumerate(J) if j["body"] == bi]
+        jadr.append(js[0] if js else -1); jnum.append(len(js))
+    out.append(_carr("cm_body_jntadr", jadr, "int"))
+    out.append(_carr("cm_body_jntnum", jnum, "int"))
+    lastdof = []
+    for bi in range(len(B)):
+        b = bi
+        while b > 0 and B[b]["dofnum"] == 0:
+            b = B[b]["parent"]
+        lastdof.append(B[b]["dofadr"] + B[b]["dofnum"] - 1 if b > 0 else -1)
+    out.append(_carr("cm_body_lastdof", lastdof, "int"))
     out.append(_carr("cm_dof_damping", [d["damping"] for d in D], R))
     out.append(_carr("cm_dof_armature", [d["armature"] for d in D], R))
     G = m["geoms"]
@@ -305,6 +327,11 @@ def main():
         f.write(emit_header(model, "double", "ORACLE_CASSIE_MODEL_GEN_H"))
     with open(os.path.join(REPO, "apex_amd", "csrc", "cassie_model_gen.h"), "w") as f:
         f.write(emit_header(model, "float", "APX_CASSIE_MODEL_GEN_H", decl="static __device__ const"))
+    with open(os.path.join(REPO, "apex_amd", "csrc", "cassie_tables.h"), "w") as f:
+        txt = emit_header(model, "float", "APX_CASSIE_TABLES_H", decl="constexpr")
+        txt = txt.replace("cm_", "ct_")      # constexpr twins of the device tables: distinct names, usable as constants
+        txt = txt.replace("#define APX_CASSIE_TABLES_H\n", "#define APX_CASSIE_TABLES_H\nnamespace cmt {\n").replace("#endif  // APX_CASSIE_TABLES_H", "}  // namespace cmt\n#endif  // APX_CASSIE_TABLES_H")
+        f.write(txt)
     tot = sum(b["mass"] for b in model["bodies"])
     print(f"nbody={model['nbody']} nv={model['nv']} ngeom(collision)={len(model['geoms'])} total mass={tot:.3f}")
     for e in model["equalities"]:
