@@ -10,7 +10,9 @@
 // (DESIGN.md §6), not HBM bound.
 #include "apx_common.h"
 #include "cassie_dev.h"
-#include "cassie_step2.h"
+#include "cassie_step3.h"
+
+extern __shared__ __attribute__((aligned(16))) float4 apx_lds4[];   // dynamic LDS: the constraint-row store
 #include <new>
 #include <cstring>
 
@@ -72,64 +74,66 @@ __constant__ float kTorqueLimit[5] = {140.63f, 140.63f, 216.16f, 216.16f, 45.14f
 __constant__ float kFir[9] = {2727.f, 534.f, -2658.f, -795.f, 72.f, 110.f, 19.f, -6.f, -3.f};
 #define PI_F 3.14159265358979323846f
 
-// forward pass + sensor snapshot + per-forward accessor values (foot force / pose), no integration
-__device__ __forceinline__ void forward_snapshot(const St& S, c2::Fwd& w, const c2::Lds& L, const float (&ctrl)[10], int pgs_iters) {
-    c2::forward2(S, w, L, ctrl, pgs_iters);
-    for (int u = 0; u < 10; ++u) S(F_SNAP + SN_MPOS + u) = S(F_QPOS + cm_act_qposadr[u]);
-    for (int k = 0; k < 6; ++k) S(F_SNAP + SN_JPOS + k) = S(F_QPOS + cm_jsens_qposadr[k]);
+// forward pass + sensor snapshot + per-forward accessor values (foot force; the foot pose is written by the tree walk)
+__device__ __forceinline__ void forward_snapshot(const St& S, c3::Fw3& w, const c2::Lds& L, const float (&ctrl)[10], int pgs_iters) {
+    c3::forward3(S, w, L, ctrl, pgs_iters);
+#pragma unroll
+    for (int u = 0; u < 10; ++u) S(F_SNAP + SN_MPOS + u) = S(F_QPOS + cmt::ct_act_qposadr[u]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) S(F_SNAP + SN_JPOS + k) = S(F_QPOS + cmt::ct_jsens_qposadr[k]);
+#pragma unroll
     for (int k = 0; k < 4; ++k) S(F_SNAP + SN_QUAT + k) = S(F_QPOS + 3 + k);
+#pragma unroll
     for (int k = 0; k < 3; ++k) { S(F_SNAP + SN_GYRO + k) = S(F_QVEL + 3 + k); S(F_SNAP + SN_ACC + k) = w.acc[k]; S(F_SNAP + SN_VEL + k) = S(F_QVEL + k); }
     S(F_SNAP + SN_PZ) = S(F_QPOS + 2);
     S(F_FWD + 0) = w.foot_fz[0]; S(F_FWD + 1) = w.foot_fz[1];
-    S(F_FWD + 2) = w.footq[0].w; S(F_FWD + 3) = w.footq[0].x; S(F_FWD + 4) = w.footq[0].y; S(F_FWD + 5) = w.footq[0].z;
-    S(F_FWD + 6) = w.footq[1].w; S(F_FWD + 7) = w.footq[1].x; S(F_FWD + 8) = w.footq[1].y; S(F_FWD + 9) = w.footq[1].z;
-    S(F_FWD + 10) = w.footp[0].x; S(F_FWD + 11) = w.footp[0].y; S(F_FWD + 12) = w.footp[0].z - 0.0550841220316708f;
-    S(F_FWD + 13) = w.footp[1].x; S(F_FWD + 14) = w.footp[1].y; S(F_FWD + 15) = w.footp[1].z - 0.0550841220316708f;
 }
 
 // one 2 kHz substep: encoders + estimator -> PD -> safeties -> motor model / delay -> mj_step
 // with_euler = false: forward pass only (cassie_sim_set_const ends in mj_forward)
-__device__ __noinline__ void sim_step_pd(St S, float4* lds_lane, int pgs_iters, int mode) {
-    c2::Fwd w;
-    const c2::Lds Y{lds_lane};
+__device__ __noinline__ void sim_step_pd(St S, int pgs_iters, int mode) {
+    c3::Fw3 w;
+    const c2::Lds Y{apx_lds4 + (threadIdx.x & 63)};
     if (mode == 0) { const float zero[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; forward_snapshot(S, w, Y, zero, pgs_iters); return; }
     int flags = S.I(I_FLAGS);
     float ctrl[10];
+#pragma unroll
     for (int u = 0; u < 10; ++u) {
         // drive encoder: truncating quantiser + 9-tap FIR velocity
-        const float scale = 2.f * PI_F / (float)(1 << cm_act_bits[u]), gear = cm_act_gear[u];
+        const float scale = 2.f * PI_F / (float)(1 << cmt::ct_act_bits[u]), gear = cmt::ct_act_gear[u];
         const float nq = truncf(S(F_SNAP + SN_MPOS + u) * gear / scale);
         float h[9];
-        if (!(flags & 1)) { for (int k = 0; k < 9; ++k) h[k] = nq; }
-        else { for (int k = 8; k > 0; --k) h[k] = S(F_MENC + u * 9 + k - 1); h[0] = nq; }
+        if (!(flags & 1)) { _Pragma("unroll") for (int k = 0; k < 9; ++k) h[k] = nq; }
+        else { _Pragma("unroll") for (int k = 8; k > 0; --k) h[k] = S(F_MENC + u * 9 + k - 1); h[0] = nq; }
         float acc = 0.f;
-        for (int k = 0; k < 9; ++k) { S(F_MENC + u * 9 + k) = h[k]; acc += kFir[k] * h[k]; }
+        _Pragma("unroll") for (int k = 0; k < 9; ++k) { S(F_MENC + u * 9 + k) = h[k]; acc += kFir[k] * h[k]; }
         const float mpos = nq * scale / gear, mvel = acc * scale / gear / PI_F;
         S(F_SO + SO_MPOS + u) = mpos; S(F_SO + SO_MVEL + u) = mvel;
         // pd_input_step -> cassie_core_sim_step clamp -> torque-speed curve -> 6-deep delay
         float tau = kP[u % 5] * (S(F_PDT + u) - mpos) + kD[u % 5] * (0.f - mvel);
         if (!(S.I(I_FLAGS) & 16)) tau = 0.f;       // pd_in_t zero until the first env.step (gains are set there)
         tau = fminf(fmaxf(tau, -kTorqueLimit[u % 5]), kTorqueLimit[u % 5]);
-        const float wmax = cm_act_rpm[u] * 2.f * PI_F / 60.f, tmax = cm_act_ctrlmax[u];
-        const float om = fabsf(S(F_QVEL + cm_act_dof[u]) * gear);
+        const float wmax = cmt::ct_act_rpm[u] * 2.f * PI_F / 60.f, tmax = cmt::ct_act_ctrlmax[u];
+        const float om = fabsf(S(F_QVEL + cmt::ct_act_dof[u]) * gear);
         const float tlim = fminf(fmaxf(2.f * tmax * (1.f - om / wmax), 0.f), tmax);
         const float cmd = tau / gear;
         const float un = (cmd < 0.f ? -1.f : 1.f) * fminf(fabsf(cmd), tlim);
         float fifo[6];
-        for (int k = 5; k > 0; --k) fifo[k] = S(F_FIFO + u * 6 + k - 1);
+        _Pragma("unroll") for (int k = 5; k > 0; --k) fifo[k] = S(F_FIFO + u * 6 + k - 1);
         fifo[0] = un;
-        for (int k = 0; k < 6; ++k) S(F_FIFO + u * 6 + k) = fifo[k];
+        _Pragma("unroll") for (int k = 0; k < 6; ++k) S(F_FIFO + u * 6 + k) = fifo[k];
         ctrl[u] = fifo[5];
         S(F_SO + SO_TORQUE + u) = gear * ctrl[u];
     }
+#pragma unroll
     for (int k = 0; k < 6; ++k) {   // joint encoders: quantiser + biquad velocity
-        const float scale = 2.f * PI_F / (float)(1 << cm_jsens_bits[k]);
+        const float scale = 2.f * PI_F / (float)(1 << cmt::ct_jsens_bits[k]);
         const float x = truncf(S(F_SNAP + SN_JPOS + k) / scale) * scale;
         float xs[4], y0, y1;
         if (!(flags & 2)) { xs[0] = xs[1] = xs[2] = xs[3] = x; y0 = y1 = 0.f; }
-        else { xs[0] = x; for (int i = 1; i < 4; ++i) xs[i] = S(F_JENCX + k * 4 + i - 1); y0 = S(F_JENCY + k * 2); y1 = S(F_JENCY + k * 2 + 1); }
+        else { xs[0] = x; _Pragma("unroll") for (int i = 1; i < 4; ++i) xs[i] = S(F_JENCX + k * 4 + i - 1); y0 = S(F_JENCY + k * 2); y1 = S(F_JENCY + k * 2 + 1); }
         const float y = 12.348f * (xs[0] + xs[1] - xs[2] - xs[3]) + 1.7658f * y0 - 0.79045f * y1;
-        for (int i = 0; i < 4; ++i) S(F_JENCX + k * 4 + i) = xs[i];
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) S(F_JENCX + k * 4 + i) = xs[i];
         S(F_JENCY + k * 2) = y; S(F_JENCY + k * 2 + 1) = y0;
         S(F_SO + SO_JPOS + k) = x; S(F_SO + SO_JVEL + k) = y;
     }
@@ -137,14 +141,14 @@ __device__ __noinline__ void sim_step_pd(St S, float4* lds_lane, int pgs_iters, 
     // estimator: pass-through fields + estimator-lite for the 7 filtered ones
     {
         const Q4 q = {S(F_SNAP + SN_QUAT), S(F_SNAP + SN_QUAT + 1), S(F_SNAP + SN_QUAT + 2), S(F_SNAP + SN_QUAT + 3)};
-        for (int k = 0; k < 4; ++k) S(F_SO + SO_QUAT + k) = S(F_SNAP + SN_QUAT + k);
-        for (int k = 0; k < 3; ++k) { S(F_SO + SO_ROTVEL + k) = S(F_SNAP + SN_GYRO + k); S(F_SO + SO_TVEL + k) = S(F_SNAP + SN_VEL + k); }
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) S(F_SO + SO_QUAT + k) = S(F_SNAP + SN_QUAT + k);
+        _Pragma("unroll") for (int k = 0; k < 3; ++k) { S(F_SO + SO_ROTVEL + k) = S(F_SNAP + SN_GYRO + k); S(F_SO + SO_TVEL + k) = S(F_SNAP + SN_VEL + k); }
         const V3 aw = mul(q2m(q), V3{S(F_SNAP + SN_ACC), S(F_SNAP + SN_ACC + 1), S(F_SNAP + SN_ACC + 2)});
         S(F_SO + SO_TACC) = aw.x; S(F_SO + SO_TACC + 1) = aw.y; S(F_SO + SO_TACC + 2) = aw.z - GRAV;
-        S(F_SO + SO_HEIGHT) = S(F_SNAP + SN_PZ) - cm_floor_pos[2];
+        S(F_SO + SO_HEIGHT) = S(F_SNAP + SN_PZ) - cmt::ct_floor_pos[2];
     }
     forward_snapshot(S, w, Y, ctrl, pgs_iters);
-    c2::euler2(S, w);
+    c3::euler3(S, w);
 }
 
 // ------------------------------------------------------------------------------------------------ env logic
@@ -235,7 +239,7 @@ __device__ __forceinline__ void clock_from_speed(const St& S, float speed, int f
 }
 
 // CassieEnv.reset (cassie/cassie.py:523-680)
-__device__ void env_reset(const St& S, const Cfg& cfg, float4* lds_lane) {
+__device__ void env_reset(const St& S, const Cfg& cfg) {
     Rng r{cfg.seed_lo, cfg.seed_hi, cfg.env_base + (unsigned)S.env, (unsigned)S.I(I_RNG)};
     const float speed0 = r.uniform(-0.3f, 4.0f);
     (void)r.uniform(-0.3f, 0.3f);
@@ -273,8 +277,8 @@ __device__ void env_reset(const St& S, const Cfg& cfg, float4* lds_lane) {
     }
     for (int i = 0; i < NQ; ++i) S(F_QPOS + i) = cm_init_qpos[i];
     for (int i = 0; i < NV; ++i) { S(F_QVEL + i) = 0.f; S(F_QACCW + i) = 0.f; }
-    sim_step_pd(S, lds_lane, cfg.pgs_iters, 0);               // cassie_sim_set_const ends in mj_forward
-    sim_step_pd(S, lds_lane, cfg.pgs_iters, 1);               // cassie.py:665 (stale pd_in_t)
+    sim_step_pd(S, cfg.pgs_iters, 0);               // cassie_sim_set_const ends in mj_forward
+    sim_step_pd(S, cfg.pgs_iters, 1);               // cassie.py:665 (stale pd_in_t)
     for (int k = 0; k < 6; ++k) S(F_FOOTPREV + k) = S(F_FWD + 10 + k);
     S(F_CMD + 2) = 0.f;
     S(F_CMD + 0) = r.uniform(-0.3f, 4.0f);
@@ -316,17 +320,15 @@ __device__ float clock_reward(const St& S, const Cfg& cfg, const float* action, 
 
 // ------------------------------------------------------------------------------------------------ kernels
 #define ENV_SETUP                                                                                   \
-    extern __shared__ __attribute__((aligned(16))) float4 lds4[];                                    \
     const int lane = threadIdx.x & 63;                                                               \
     const int env = blockIdx.x * 64 + lane;                                                          \
     if (env >= n) return;                                                                            \
-    const St S{st, ist, n, env, wk};                                                                 \
-    float4* lds_lane = lds4 + lane;
+    const St S = make_st(st, ist, n, env, wk);
 
 __global__ __launch_bounds__(64) void env_init_kernel(float* st, int* ist, int n, Cfg cfg) {
     const int env = blockIdx.x * 64 + threadIdx.x;
     if (env >= n) return;
-    const St S{st, ist, n, env, nullptr};
+    const St S = make_st(st, ist, n, env, nullptr);
     for (int f = 0; f < F_TOTAL; ++f) S(f) = 0.f;
     for (int f = 0; f < I_TOTAL; ++f) S.I(f) = 0;
     for (int i = 0; i < NQ; ++i) S(F_QPOS + i) = cm_init_qpos[i];
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(64) void env_init_kernel(float* st, int* ist, int n
 __global__ __launch_bounds__(64) void env_setconst_kernel(float* st, int* ist, float* wk, int n, Cfg cfg) {
     const int env = blockIdx.x * 64 + threadIdx.x;
     if (env >= n) return;
-    const St S{st, ist, n, env, wk};
+    const St S = make_st(st, ist, n, env, wk);
     Dyn dy; Work w;
     load_dyn(S, dy);
     set_const(S, dy, w);
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(64) void env_setconst_kernel(float* st, int* ist, f
 __global__ __launch_bounds__(64) void env_reset_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const uint8_t* mask, float* obs) {
     ENV_SETUP
     if (mask && !mask[env]) return;
-    env_reset(S, cfg, lds_lane);
+    env_reset(S, cfg);
     if (obs) write_obs(S, cfg, obs + (size_t)env * APX_OBS_DIM);
 }
 
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(float* st, int* ist, float
     S.I(I_FLAGS) |= 16;
     float lfrc = 0.f, rfrc = 0.f, lor = 0.f, ror = 0.f;
     for (int i = 0; i < cfg.simrate; ++i) {
-        sim_step_pd(S, lds_lane, cfg.pgs_iters, 1);
+        sim_step_pd(S, cfg.pgs_iters, 1);
         for (int k = 0; k < 6; ++k) {                                            // cassie.py:328-331
             const float fp = S(F_FWD + 10 + k);
             S(F_FOOTVEL + k) = (fp - S(F_FOOTPREV + k)) / 0.0005f;
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(float* st, int* ist, float
 // raw substeps with the current pd targets (tests): n_sub x cassie_sim_step_pd
 __global__ __launch_bounds__(64) void env_substep_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, int n_sub) {
     ENV_SETUP
-    for (int i = 0; i < n_sub; ++i) sim_step_pd(S, lds_lane, cfg.pgs_iters, 1);
+    for (int i = 0; i < n_sub; ++i) sim_step_pd(S, cfg.pgs_iters, 1);
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -438,7 +440,7 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     APX_HIP(hipMalloc(&e->st, sizeof(float) * (size_t)F_TOTAL * e->n));
     APX_HIP(hipMalloc(&e->ist, sizeof(int) * (size_t)I_TOTAL * e->n));
     e->wk = nullptr;
-    APX_HIP(hipMalloc(&e->wk, sizeof(float) * (size_t)c2::NM * e->n));
+    APX_HIP(hipMalloc(&e->wk, sizeof(float) * (size_t)c3::WK_TOTAL * e->n));
     const Cfg c = make_cfg(*cfg);
     hipLaunchKernelGGL(env_init_kernel, dim3(e->n / 64), dim3(64), 0, 0, e->st, e->ist, e->n, c);
     APX_LAUNCH_CHECK();

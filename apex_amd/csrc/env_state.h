@@ -27,12 +27,19 @@ struct apx_env {
     int n;
 };
 
+// global-address-space pointers: St is passed by value into a non-inlined device function, where the compiler could
+// not otherwise prove the address space and would fall back to flat_load / flat_store
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(1))) int gint;
 struct St {
-    float* p; int* ip; int n, env; float* wk;      // wk: [307, n] workspace column for the mass matrix
-    __device__ __forceinline__ float& operator()(int f) const { return p[(size_t)f * n + env]; }
-    __device__ __forceinline__ float& W(int i) const { return wk[(size_t)i * n + env]; }
-    __device__ __forceinline__ int& I(int f) const { return ip[(size_t)f * n + env]; }
+    gfloat* p; gint* ip; int n, env; gfloat* wk;      // wk: [WK_TOTAL, n] per-env workspace column (cassie_step3.h)
+    __device__ __forceinline__ gfloat& operator()(int f) const { return p[(size_t)f * n + env]; }
+    __device__ __forceinline__ gfloat& W(int i) const { return wk[(size_t)i * n + env]; }
+    __device__ __forceinline__ gint& I(int f) const { return ip[(size_t)f * n + env]; }
 };
+__device__ __forceinline__ St make_st(float* st, int* ist, int n, int env, float* wk) {
+    return St{(gfloat*)st, (gint*)ist, n, env, (gfloat*)wk};
+}
 
 struct Cfg { int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; };
 

@@ -284,6 +284,9 @@ def emit_header(model, ctype, guard, decl="static const"):
             b = B[b]["parent"]
         lastdof.append(B[b]["dofadr"] + B[b]["dofnum"] - 1 if b > 0 else -1)
     out.append(_carr("cm_body_lastdof", lastdof, "int"))
+    kids = [[k for k in range(len(B)) if k > 0 and B[k]["parent"] == bi and k != bi] for bi in range(len(B))]
+    out.append(_carr("cm_body_nchild", [len(k) for k in kids], "int"))
+    out.append(_carr("cm_body_child", [k + [-1] * (4 - len(k)) for k in kids], "int", 4))
     out.append(_carr("cm_dof_damping", [d["damping"] for d in D], R))
     out.append(_carr("cm_dof_armature", [d["armature"] for d in D], R))
     G = m["geoms"]
