@@ -16,6 +16,17 @@
 namespace c3 {
 using namespace c2;
 
+// optional phase profiling (lane 0 of workgroup 0): cumulative shader cycles per phase, read by tools/t_prof.py
+#ifdef APX_PROF
+__device__ unsigned long long g_prof_acc[12];
+__device__ unsigned long long g_prof_last;
+#define PROF(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long t__ = clock64(); g_prof_acc[i] += t__ - g_prof_last; g_prof_last = t__; } } while (0)
+#define PROF_START() do { if (threadIdx.x == 0 && blockIdx.x == 0) g_prof_last = clock64(); } while (0)
+#else
+#define PROF(i) do {} while (0)
+#define PROF_START() do {} while (0)
+#endif
+
 // workspace column layout (floats per env)
 constexpr int WK_M = 0, WK_CDOF = WK_M + NM, WK_SMOOTH = WK_CDOF + 6 * NV, WK_QS = WK_SMOOTH + NV, WK_PTS = WK_QS + NV,
               WK_PEL = WK_PTS + 60, WK_TOTAL = WK_PEL + 24;
@@ -151,6 +162,7 @@ __device__ __forceinline__ Acc visit(const St& S, const QP& qp, const Node& par,
         acc.crb.m += sub.crb.m; acc.crb.h = acc.crb.h + sub.crb.h;
         sfor<0, 6>([&](auto I) { acc.crb.I[I] += sub.crb.I[I]; });
         if constexpr (!QPOS0) acc.frc = acc.frc + sub.frc;
+        __builtin_amdgcn_sched_barrier(0);     // keep sibling subtrees from being interleaved (register pressure)
     });
     // subtree complete: mass-matrix rows (CRBA) and bias of this body's dofs
     sfor<0, nd>([&](auto K) {
@@ -232,6 +244,7 @@ __device__ __forceinline__ void commit3(Fw3& w, const Lds& L, int chunk0, float 
     L.wr(chunk0 + NCH, make_float4(b, R, invA, f));
     sfor<0, 19>([&](auto C) { constexpr int c = C; if constexpr (has<SET>(c)) w.zt[c2d<LEG>(c)] += y[c] * f; });
     cost += f * (0.5f * R * f + b);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int LEG>
@@ -345,6 +358,7 @@ __device__ __forceinline__ void build_rows3(const St& S, Fw3& w, const Lds& L, c
             L.wr(ch + 12, make_float4(bk[0], bk[1], bk[2], bk[3]));
             L.wr(ch + 13, make_float4(fk[0], fk[1], fk[2], fk[3]));
             if (G == 0) w.footmask |= 1u << slot;
+            __builtin_amdgcn_sched_barrier(0);
         }
     });
 }
@@ -357,8 +371,9 @@ __device__ __forceinline__ void pgs_leg3(Fw3& w, const Lds& L, float mu) {
         float y[16];
         sfor<0, 4>([&](auto C) { const float4 v = L.rd(ch + C); y[4 * C] = v.x; y[4 * C + 1] = v.y; y[4 * C + 2] = v.z; y[4 * C + 3] = v.w; });
         const float4 m = L.rd(ch + 4);          // b R invA f
-        float res = m.x + m.y * m.w;
-        sfor<0, 16>([&](auto I) { constexpr int i = I, c = Rw < 3 ? SetPL::c[i] : SetAC::c[i]; if constexpr (c >= 0) res += y[i] * w.zt[c2d<LEG>(c)]; });
+        float r4[4] = {m.x + m.y * m.w, 0.f, 0.f, 0.f};       // 4 partial sums: break the 16-deep dependent FMA chain
+        sfor<0, 16>([&](auto I) { constexpr int i = I, c = Rw < 3 ? SetPL::c[i] : SetAC::c[i]; if constexpr (c >= 0) r4[i & 3] += y[i] * w.zt[c2d<LEG>(c)]; });
+        const float res = (r4[0] + r4[1]) + (r4[2] + r4[3]);
         const float df = -res * m.z;
         sfor<0, 16>([&](auto I) { constexpr int i = I, c = Rw < 3 ? SetPL::c[i] : SetAC::c[i]; if constexpr (c >= 0) w.zt[c2d<LEG>(c)] += y[i] * df; });
         L.wr(ch + 4, make_float4(m.x, m.y, m.z, m.w + df));
@@ -384,8 +399,9 @@ __device__ __forceinline__ void pgs_leg3(Fw3& w, const Lds& L, float mu) {
         sfor<0, 10>([&](auto C) { const float4 q = L.rd(ch + C); v[4 * C] = q.x; v[4 * C + 1] = q.y; v[4 * C + 2] = q.z; v[4 * C + 3] = q.w; });
         const float4 g0 = L.rd(ch + 10), g1 = L.rd(ch + 11), bb = L.rd(ch + 12), ff = L.rd(ch + 13);
         const float gnn = g0.x, gn1 = g0.y, gn2 = g0.z, g11 = g0.w, g12 = g1.x, g22 = g1.y, R = g1.z;
-        float dn = 0.f, d1 = 0.f, d2 = 0.f;
-        sfor<0, 13>([&](auto I) { constexpr int d = c2d<LEG>(SetFT::c[I]); dn += v[I] * w.zt[d]; d1 += v[13 + I] * w.zt[d]; d2 += v[26 + I] * w.zt[d]; });
+        float dn2[2] = {0.f, 0.f}, d12[2] = {0.f, 0.f}, d22[2] = {0.f, 0.f};
+        sfor<0, 13>([&](auto I) { constexpr int d = c2d<LEG>(SetFT::c[I]); dn2[I & 1] += v[I] * w.zt[d]; d12[I & 1] += v[13 + I] * w.zt[d]; d22[I & 1] += v[26 + I] * w.zt[d]; });
+        const float dn = dn2[0] + dn2[1], d1 = d12[0] + d12[1], d2 = d22[0] + d22[1];
         float f[4] = {ff.x, ff.y, ff.z, ff.w};
         const float b[4] = {bb.x, bb.y, bb.z, bb.w};
         float sdn = 0.f, sd1 = 0.f, sd2 = 0.f;
@@ -430,6 +446,8 @@ __device__ __forceinline__ void forward3(const St& S, Fw3& w, const Lds& L, cons
         const float c = fminf(fmaxf(ctrl[u], -ct_act_ctrlmax[u]), ct_act_ctrlmax[u]);
         S.W(WK_SMOOTH + ct_act_dof[u]) += ct_act_gear[u] * c;
     });
+    PROF(1);
+    __builtin_amdgcn_sched_barrier(0);
     {   // phase B
         float dsq[NV];
         sfor<0, NM>([&](auto I) { w.LD[I] = S.W(WK_M + I); });
@@ -441,6 +459,8 @@ __device__ __forceinline__ void forward3(const St& S, Fw3& w, const Lds& L, cons
         solve_L(w.LD, x);
         sfor<0, NV>([&](auto D) { S.W(WK_QS + D) = x[D]; });
     }
+    PROF(2);
+    __builtin_amdgcn_sched_barrier(0);
     Dyn2 dy;
     dy.friction = S(F_FRIC);
     dy.fn = {S(F_FLOOR), S(F_FLOOR + 1), S(F_FLOOR + 2)};
@@ -456,10 +476,13 @@ __device__ __forceinline__ void forward3(const St& S, Fw3& w, const Lds& L, cons
         zero_forces3<0>(w, L); zero_forces3<1>(w, L);
         sfor<0, NV>([&](auto D) { w.zt[D] = 0.f; });
     }
+    PROF(3);
     for (int it = 0; it < pgs_iters; ++it) {   // phase D
         pgs_leg3<0>(w, L, dy.friction);
         pgs_leg3<1>(w, L, dy.friction);
     }
+    PROF(4);
+    __builtin_amdgcn_sched_barrier(0);
     // phase E: qacc = qacc_smooth + L^-1 D^-1/2 z~
     sfor<0, NV>([&](auto D) { w.qacc[D] = w.zt[D] * w.disqrt[D]; });
     solve_L(w.LD, w.qacc);

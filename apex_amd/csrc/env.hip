@@ -92,6 +92,7 @@ __device__ __forceinline__ void forward_snapshot(const St& S, c3::Fw3& w, const 
 // one 2 kHz substep: encoders + estimator -> PD -> safeties -> motor model / delay -> mj_step
 // with_euler = false: forward pass only (cassie_sim_set_const ends in mj_forward)
 __device__ __noinline__ void sim_step_pd(St S, int pgs_iters, int mode) {
+    PROF_START();
     c3::Fw3 w;
     const c2::Lds Y{apx_lds4 + (threadIdx.x & 63)};
     if (mode == 0) { const float zero[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; forward_snapshot(S, w, Y, zero, pgs_iters); return; }
@@ -147,8 +148,11 @@ __device__ __noinline__ void sim_step_pd(St S, int pgs_iters, int mode) {
         S(F_SO + SO_TACC) = aw.x; S(F_SO + SO_TACC + 1) = aw.y; S(F_SO + SO_TACC + 2) = aw.z - GRAV;
         S(F_SO + SO_HEIGHT) = S(F_SNAP + SN_PZ) - cmt::ct_floor_pos[2];
     }
+    PROF(0);
     forward_snapshot(S, w, Y, ctrl, pgs_iters);
+    PROF(5);
     c3::euler3(S, w);
+    PROF(6);
 }
 
 // ------------------------------------------------------------------------------------------------ env logic
@@ -533,6 +537,18 @@ extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, voi
         APX_LAUNCH_CHECK();
         return I_TOTAL;
     }
+#ifdef APX_PROF
+    if (!strcmp(name, "prof")) {   // 12 cumulative phase cycle counters, then reset
+        unsigned long long h[12];
+        APX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(c3::g_prof_acc), sizeof(h)));
+        float hf[12];
+        for (int i = 0; i < 12; ++i) hf[i] = (float)h[i];
+        APX_HIP(hipMemcpy(out, hf, sizeof(hf), hipMemcpyHostToDevice));
+        unsigned long long z[12] = {0};
+        APX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c3::g_prof_acc), z, sizeof(z)));
+        return 12;
+    }
+#endif
     if (!strcmp(name, "substep")) {   // debugging hook: out[0] (host-readable count is not needed) - run one raw substep
         hipLaunchKernelGGL(env_substep_kernel, dim3(e->n / 64), dim3(64), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(e->cfg), 1);
         APX_LAUNCH_CHECK();

@@ -60,14 +60,13 @@ def normalize_advantages(ret, val, eps=1e-5, group=None):
     """rl/algos/ppo.py:395-396.  With a process group the three moments are all-reduced (RCCL) first so that every
     rank normalises with the statistics of the union batch."""
     ret, val = ret.contiguous().view(-1), val.contiguous().view(-1)
+    from . import dist as adist
     mom = adv_moments(ret, val)
     if group is not None:
-        torch.distributed.all_reduce(mom, group=group)
-    s, ss, n = mom.tolist()
-    mean = s / n
-    var = max(ss - n * mean * mean, 0.0) / max(n - 1.0, 1.0)
+        adist.allreduce_moments(mom, group=group)
+    mean, std = adist.adv_stats_from_moments(mom.tolist())
     adv = torch.empty_like(ret)
-    check(_lib.load().apx_adv_apply(_p(ret), _p(val), ret.numel(), mean, var ** 0.5, eps, _p(adv), _stream()))
+    check(_lib.load().apx_adv_apply(_p(ret), _p(val), ret.numel(), mean, std, eps, _p(adv), _stream()))
     return adv
 
 

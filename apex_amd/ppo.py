@@ -17,6 +17,7 @@ import time
 import numpy as np
 import torch
 
+from . import dist as adist
 from . import engine
 from .vecenv import CassieVecEnv, MIRRORED_ACTS, MIRRORED_OBS, CLOCK_INDS
 
@@ -36,7 +37,7 @@ class PPO:
         self.device = env.device
         self.N = env.n_envs
         # steps per env per iteration: the reference samples >= num_steps in total (ppo.py:205)
-        self.T = max(1, -(-self.num_steps // (self.N * self.world)))
+        self.T = adist.rollout_len(self.num_steps, self.N, self.world)
         self.learner = engine.PPOLearner(50, 10, hidden, self.device, self.fixed_std, lr=self.lr, eps=self.eps,
                                          clip=self.clip, entropy_coeff=self.entropy_coeff, grad_clip=self.grad_clip,
                                          mirrored_obs=MIRRORED_OBS if self.mirror else None,
@@ -149,16 +150,14 @@ class PPO:
                 idx = perm[k * mb:(k + 1) * mb]
                 if self.world > 1:
                     scal = L.minibatch(obs, act, ret, adv, mu, idx=idx, mirror=self.mirror, grad_only=True, sync=False)
-                    flat = L.grad_flat
-                    torch.distributed.all_reduce(flat, group=self.group)                     # one RCCL all-reduce / step
-                    L.apply_grads(scale=1.0 / self.world)
+                    adist.allreduce_mean_(L.grad_flat, group=self.group, world=self.world)   # one RCCL all-reduce / step
+                    L.apply_grads(scale=1.0)
                 else:
                     scal = L.minibatch(obs, act, ret, adv, mu, idx=idx, mirror=self.mirror, sync=False)
                 acc += scal
             if self.world > 1:
-                last = scal.clone()
-                torch.distributed.all_reduce(last, group=self.group); last /= self.world
-                torch.distributed.all_reduce(acc, group=self.group); acc /= self.world
+                last = adist.allreduce_mean_(scal.clone(), group=self.group, world=self.world)
+                adist.allreduce_mean_(acc, group=self.group, world=self.world)
             else:
                 last = scal
             losses = (acc / max(nb, 1)).cpu().numpy()
@@ -233,7 +232,7 @@ def run_experiment(args):
     torch.manual_seed(args.seed); np.random.seed(args.seed)
     n_envs = getattr(args, "n_envs", 4096)
     env = CassieVecEnv(n_envs=n_envs, simrate=args.simrate, dynamics_randomization=args.dyn_random, reward=args.reward,
-                       max_traj_len=args.max_traj_len, seed=args.seed, device=local, env_id_base=rank * n_envs,
+                       max_traj_len=args.max_traj_len, seed=args.seed, device=local, env_id_base=adist.shard_env_base(rank, n_envs),
                        command_profile=args.command_profile, input_profile=args.input_profile, history=args.history,
                        learn_gains=args.learn_gains)
     logger = create_logger(args) if rank == 0 else None

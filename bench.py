@@ -53,7 +53,8 @@ def main():
         group = torch.distributed.group.WORLD
     from apex_amd.vecenv import CassieVecEnv
     from apex_amd.ppo import PPO
-    env = CassieVecEnv(n_envs=a.n_envs, seed=0, device=local, env_id_base=rank * a.n_envs)
+    from apex_amd import dist as adist
+    env = CassieVecEnv(n_envs=a.n_envs, seed=0, device=local, env_id_base=adist.shard_env_base(rank, a.n_envs))
     args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=a.minibatch,
                 epochs=a.epochs, num_steps=a.rollout_len * a.n_envs * world, max_traj_len=400, max_grad_norm=0.05,
                 mirror=True, std_dev=-1.5, seed=0)

@@ -1,0 +1,86 @@
+"""CPU-side host logic: CLI flags, run-directory layout (G13), checkpoint surface (G12), reward-string parsing."""
+import argparse
+import json
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cli_flags_match_reference_defaults():
+    import apex
+    a = apex.build_parser().parse_args(["--reward", "clock"])
+    # apex.py:16-39,224-250 defaults
+    assert (a.simrate, a.dyn_random, a.mirror, a.env_name, a.command_profile, a.input_profile) == (50, True, True, "Cassie-v0", "clock", "full")
+    assert (a.lr, a.eps, a.lam, a.gamma, a.clip, a.minibatch_size, a.epochs, a.num_steps) == (1e-4, 1e-5, 0.95, 0.99, 0.2, 64, 3, 5096)
+    assert (a.num_procs, a.max_grad_norm, a.max_traj_len, a.std_dev, a.entropy_coeff, a.input_norm_steps, a.n_itr) == (30, 0.05, 400, -1.5, 0.0, 10000, 10000)
+    assert a.logdir == "./trained_models/ppo/" and a.seed == 0 and a.previous is None and a.recurrent is False
+    b = apex.build_parser().parse_args(["--reward", "clock", "--not_mirror", "--not_dyn_random", "--n_envs", "128"])
+    assert (b.mirror, b.dyn_random, b.n_envs) == (False, False, 128)
+
+
+def test_g13_run_directory_layout(golden_dir, tmp_path):
+    from apex_amd.log import create_logger
+    cases = json.load(open(os.path.join(golden_dir, "g13_logdir.json")))
+    for c in cases:
+        ns = argparse.Namespace(**c["args"], logdir=str(tmp_path) + "/")
+        logger = create_logger(ns)
+        assert os.path.relpath(logger.dir, str(tmp_path)) == c["rel_dir"]            # md5(args)[:6]-seed<seed> or run_name
+        info = open(os.path.join(logger.dir, "experiment.info")).read().replace(str(tmp_path), "<LOGDIR>")
+        assert info == c["info"]
+        assert {"experiment.info", "experiment.pkl"} <= set(os.listdir(logger.dir))
+        back = pickle.load(open(os.path.join(logger.dir, "experiment.pkl"), "rb"))
+        assert vars(back) == vars(ns)
+        for tag in ("Test/Return", "Train/Return", "Train/Mean Eplen", "Misc/Timesteps"):
+            logger.add_scalar(tag, 1.0, 0)
+
+
+def test_g12_checkpoint_roundtrip(tmp_path):
+    """Whole-module pickles with the reference's class paths and attribute names."""
+    from rl.policies.actor import Gaussian_FF_Actor
+    from rl.policies.critic import FF_V
+    torch.manual_seed(0)
+    actor = Gaussian_FF_Actor(50, 10, fixed_std=np.exp(-1.5), env_name="Cassie-v0")
+    critic = FF_V(50)
+    actor.obs_mean, actor.obs_std = torch.zeros(50), torch.ones(50)
+    critic.obs_mean, critic.obs_std = actor.obs_mean, actor.obs_std
+    torch.save(actor, tmp_path / "actor.pt"); torch.save(critic, tmp_path / "critic.pt")
+    a2 = torch.load(tmp_path / "actor.pt", weights_only=False); c2 = torch.load(tmp_path / "critic.pt", weights_only=False)
+    assert type(a2).__module__ == "rl.policies.actor" and type(a2).__name__ == "Gaussian_FF_Actor"
+    assert type(c2).__module__ == "rl.policies.critic" and type(c2).__name__ == "FF_V"
+    assert list(a2.state_dict().keys()) == ["actor_layers.0.weight", "actor_layers.0.bias", "actor_layers.1.weight",
+                                            "actor_layers.1.bias", "means.weight", "means.bias"]
+    assert list(c2.state_dict().keys()) == ["critic_layers.0.weight", "critic_layers.0.bias", "critic_layers.1.weight",
+                                            "critic_layers.1.bias", "network_out.weight", "network_out.bias"]
+    for attr in ("actor_layers", "means", "is_recurrent", "welford_state_mean", "welford_state_mean_diff", "welford_state_n",
+                 "env_name", "fixed_std", "learn_std", "action", "action_dim", "nonlinearity", "obs_std", "obs_mean",
+                 "normc_init", "bounded"):
+        assert hasattr(a2, attr), attr
+    x = torch.randn(5, 50)
+    assert torch.equal(a2(x), actor(x)) and torch.equal(c2(x), critic(x))
+    assert sum(p.numel() for p in a2.parameters()) == 81418 and sum(p.numel() for p in c2.parameters()) == 79105
+    # normc init statistics (reference rl/policies/base.py:7-13, actor.py:175-178)
+    assert torch.allclose(actor.actor_layers[0].weight.pow(2).sum(1).sqrt(), torch.ones(256), atol=1e-5)
+    assert torch.allclose(actor.means.weight.pow(2).sum(1).sqrt(), torch.full((10,), 0.01), atol=1e-6)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/trained_models/5k_retrain/actor.pt"), reason="reference tree only exists in the build container")
+def test_g12_reference_fixture_loads_with_our_classes():
+    a = torch.load("/root/reference/trained_models/5k_retrain/actor.pt", weights_only=False)
+    assert type(a).__module__ == "rl.policies.actor" and a.actor_layers[0].in_features == 49      # older env variant
+    out = a(torch.zeros(1, 49))
+    assert out.shape == (1, 10)
+
+
+def test_reward_string_parsing():
+    from apex_amd.vecenv import parse_reward
+    assert parse_reward("clock") == dict(reward_kind=0, stance_mode=0, have_incentive=1)
+    assert parse_reward("early_grounded_no_incentive_clock") == dict(reward_kind=1, stance_mode=1, have_incentive=0)
+    assert parse_reward("aerial_clock")["stance_mode"] == 2
+    with pytest.raises(TypeError):
+        parse_reward(None)              # the reference crashes on `"..." in None` too (cassie.py:91)
