@@ -20,8 +20,8 @@ using namespace c2;
 #ifdef APX_PROF
 __device__ unsigned long long g_prof_acc[12];
 __device__ unsigned long long g_prof_last;
-#define PROF(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long t__ = clock64(); g_prof_acc[i] += t__ - g_prof_last; g_prof_last = t__; } } while (0)
-#define PROF_START() do { if (threadIdx.x == 0 && blockIdx.x == 0) g_prof_last = clock64(); } while (0)
+#define PROF(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long t__ = clock64(); c3::g_prof_acc[i] += t__ - c3::g_prof_last; c3::g_prof_last = t__; } } while (0)
+#define PROF_START() do { if (threadIdx.x == 0 && blockIdx.x == 0) c3::g_prof_last = clock64(); } while (0)
 #else
 #define PROF(i) do {} while (0)
 #define PROF_START() do {} while (0)
@@ -29,17 +29,15 @@ __device__ unsigned long long g_prof_last;
 
 // workspace column layout (floats per env)
 constexpr int WK_M = 0, WK_CDOF = WK_M + NM, WK_SMOOTH = WK_CDOF + 6 * NV, WK_QS = WK_SMOOTH + NV, WK_PTS = WK_QS + NV,
-              WK_PEL = WK_PTS + 60, WK_TOTAL = WK_PEL + 24;
+              WK_PEL = WK_PTS + 60, WK_LD = WK_PEL + 24, WK_DISQ = WK_LD + NM, WK_ZT = WK_DISQ + NV, WK_QACC = WK_ZT + NV,
+              WK_MISC = WK_QACC + NV /* ncon0 ncon1 nlim0 nlim1 footmask */, WK_TOTAL = WK_MISC + 8;
 // WK_PTS per leg (30): eq0 p1,p2 | eq1 p1,p2 | capsule ends: foot e0,e1, tarsus e0,e1, shin e0,e1
 
 struct Node { V3 pos; Q4 quat; M3 mat; SV vel, acc; };
 struct Acc { SI crb; SV frc; };
 
 struct Fw3 {
-    float LD[NM];
-    float disqrt[NV];
     float zt[NV];
-    float qacc[NV];
     int ncon[2], nlim[2];
     unsigned footmask;
     float foot_fz[2];
@@ -207,8 +205,18 @@ __device__ __forceinline__ void rawdots(const LegVec<LEG>& lv, const float (&J)[
     vel = ju = jw = 0.f;
     sfor<0, 19>([&](auto C) { constexpr int c = C; if constexpr (has<SET>(c)) { vel += J[c] * lv.qv[c]; ju += J[c] * lv.qs[c]; jw += J[c] * lv.qw[c]; } });
 }
+// per-leg view of the factor: only the entries of the pelvis + leg-LEG dofs are ever loaded / referenced (164 of 307)
+template <int LEG> struct LegLD { float LD[NM]; float disqrt[NV]; };
+template <int LEG>
+__device__ __forceinline__ void load_leg_factor(const St& S, LegLD<LEG>& f) {
+    sfor<0, 19>([&](auto C) {
+        constexpr int i = c2d<LEG>(C);
+        sfor<0, ct_dof_depth[i]>([&](auto A) { constexpr int k = ct_dof_madr[i] + A; f.LD[k] = S.W(WK_LD + k); });
+        f.disqrt[i] = S.W(WK_DISQ + i);
+    });
+}
 template <int LEG, class SET>
-__device__ __forceinline__ void whiten3(const Fw3& w, float (&J)[19]) {
+__device__ __forceinline__ void whiten3(const LegLD<LEG>& w, float (&J)[19]) {
     srfor<0, 19>([&](auto C) {
         constexpr int c = C;
         if constexpr (has<SET>(c)) {
@@ -220,11 +228,11 @@ __device__ __forceinline__ void whiten3(const Fw3& w, float (&J)[19]) {
 }
 
 template <int LEG, class SET, int NCH>
-__device__ __forceinline__ void commit3(Fw3& w, const Lds& L, int chunk0, float (&y)[19], const LegVec<LEG>& lv, bool unilateral,
+__device__ __forceinline__ void commit3(Fw3& w, const LegLD<LEG>& lf, const Lds& L, int chunk0, float (&y)[19], const LegVec<LEG>& lv, bool unilateral,
                                         float pos, float imp_pos, float diag, float timeconst, float& cost) {
     float vel, ju, jw;
     rawdots<LEG, SET>(lv, y, vel, ju, jw);
-    whiten3<LEG, SET>(w, y);
+    whiten3<LEG, SET>(lf, y);
     float nn = 0.f;
     sfor<0, 19>([&](auto C) { constexpr int c = C; if constexpr (has<SET>(c)) nn += y[c] * y[c]; });
     const RowK kb = solref(timeconst);
@@ -251,6 +259,9 @@ template <int LEG>
 __device__ __forceinline__ void build_rows3(const St& S, Fw3& w, const Lds& L, const Dyn2& dy, V3 o, float& cost) {
     LegVec<LEG> lv;
     sfor<0, 19>([&](auto C) { constexpr int d = c2d<LEG>(C); lv.qv[C] = S(F_QVEL + d); lv.qw[C] = S(F_QACCW + d); lv.qs[C] = S.W(WK_QS + d); });
+    LegLD<LEG> lf;
+    load_leg_factor<LEG>(S, lf);
+    __builtin_amdgcn_sched_barrier(0);
     constexpr int base = WK_PTS + 30 * LEG;
     // ---- 2 connect equalities (cassie.xml:225-230)
     sfor<0, 2>([&](auto E) {
@@ -265,8 +276,8 @@ __device__ __forceinline__ void build_rows3(const St& S, Fw3& w, const Lds& L, c
         const float tran = S(F_BIW + b1) + S(F_BIW + b2), cn = sqrtf(dot(c, c));
         sfor<0, 3>([&](auto K) {
             constexpr int k = K, row = LEG * 6 + E * 3 + k;
-            if constexpr (E == 0) commit3<LEG, SetPL, 4>(w, L, CH_EQ + 5 * row, J[k], lv, false, cp[k], cn, tran, 0.005f, cost);
-            else commit3<LEG, SetAC, 4>(w, L, CH_EQ + 5 * row, J[k], lv, false, cp[k], cn, tran, 0.005f, cost);
+            if constexpr (E == 0) commit3<LEG, SetPL, 4>(w, lf, L, CH_EQ + 5 * row, J[k], lv, false, cp[k], cn, tran, 0.005f, cost);
+            else commit3<LEG, SetAC, 4>(w, lf, L, CH_EQ + 5 * row, J[k], lv, false, cp[k], cn, tran, 0.005f, cost);
         });
     });
     // ---- first active joint limit of this leg
@@ -282,7 +293,7 @@ __device__ __forceinline__ void build_rows3(const St& S, Fw3& w, const Lds& L, c
                 float Jl[19];
                 sfor<0, 19>([&](auto K) { Jl[K] = 0.f; });
                 Jl[d2c(d)] = dlo < 0.f ? 1.f : -1.f;
-                commit3<LEG, SetALL, 5>(w, L, CH_LIM + 6 * LEG, Jl, lv, true, dist, dist, S(F_DIW + d), 0.02f, cost);
+                commit3<LEG, SetALL, 5>(w, lf, L, CH_LIM + 6 * LEG, Jl, lv, true, dist, dist, S(F_DIW + d), 0.02f, cost);
                 w.nlim[LEG] = 1;
             }
         }
@@ -323,7 +334,7 @@ __device__ __forceinline__ void build_rows3(const St& S, Fw3& w, const Lds& L, c
             });
             float vn, un, wn, v1, u1, w1, v2, u2, w2;
             rawdots<LEG, SetFT>(lv, yn, vn, un, wn); rawdots<LEG, SetFT>(lv, y1, v1, u1, w1); rawdots<LEG, SetFT>(lv, y2, v2, u2, w2);
-            whiten3<LEG, SetFT>(w, yn); whiten3<LEG, SetFT>(w, y1); whiten3<LEG, SetFT>(w, y2);
+            whiten3<LEG, SetFT>(lf, yn); whiten3<LEG, SetFT>(lf, y1); whiten3<LEG, SetFT>(lf, y2);
             float gnn = 0.f, g11 = 0.f, g22 = 0.f, gn1 = 0.f, gn2 = 0.f, g12 = 0.f;
             sfor<0, 13>([&](auto I) {
                 constexpr int k = SetFT::c[I];
@@ -364,6 +375,12 @@ __device__ __forceinline__ void build_rows3(const St& S, Fw3& w, const Lds& L, c
 }
 
 // PGS sweep of one leg on the Fw3 register set (same arithmetic as c2::pgs_leg)
+struct LdsV {       // same store, reads the compiler must re-issue every sweep (streamed, 1 instruction per 4 floats)
+    float4* base;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    __device__ __forceinline__ float4 rd(int c) const { const f4v v = *(volatile f4v*)(base + c * 64); return make_float4(v.x, v.y, v.z, v.w); }
+    __device__ __forceinline__ void wr(int c, float4 v) const { base[c * 64] = v; }
+};
 template <int LEG>
 __device__ __forceinline__ void pgs_leg3(Fw3& w, const Lds& L, float mu) {
     sfor<0, 6>([&](auto Rw) {
@@ -431,36 +448,43 @@ __device__ __forceinline__ void zero_forces3(const Fw3& w, const Lds& L) {
     sfor<0, 3>([&](auto Sl) { if (Sl < w.ncon[LEG]) L.wr(CH_CON + 14 * (3 * LEG + Sl) + 13, make_float4(0.f, 0.f, 0.f, 0.f)); });
 }
 
-// ---------------------------------------------------------------------------------------------- the substep
-// mj_forward: leaves qacc, z~, LD (factor of M), disqrt in `w`; M, smooth, qacc_smooth in the workspace column
-__device__ __forceinline__ void forward3(const St& S, Fw3& w, const Lds& L, const float (&ctrl)[10], int pgs_iters) {
-    V3 o;
-    {   // phase A
-        SV pc[14];
-        Node world{};
-        o = {S(F_QPOS), S(F_QPOS + 1), S(F_QPOS + 2)};
-        (void)visit<false, 1>(S, [&](int i) { return S(F_QPOS + i); }, world, o, pc);
-    }
+// ---------------------------------------------------------------------------------------------- the substep, staged
+// Each stage is a separate (non-inlined) function so that the register allocator sees one phase at a time: the
+// 307-entry factor lives in VGPRs+AGPRs inside a stage and crosses stage boundaries through the workspace column.
+
+// stage A: tree walk (phase A) + actuation.  ctrl = actuator-side torques.
+__device__ __forceinline__ void stage_tree(const St& S, const float (&ctrl)[10]) {
+    SV pc[14];
+    Node world{};
+    const V3 o = {S(F_QPOS), S(F_QPOS + 1), S(F_QPOS + 2)};
+    (void)visit<false, 1>(S, [&](int i) { return S(F_QPOS + i); }, world, o, pc);
     sfor<0, NU>([&](auto U) {
         constexpr int u = U;
         const float c = fminf(fmaxf(ctrl[u], -ct_act_ctrlmax[u]), ct_act_ctrlmax[u]);
         S.W(WK_SMOOTH + ct_act_dof[u]) += ct_act_gear[u] * c;
     });
-    PROF(1);
-    __builtin_amdgcn_sched_barrier(0);
-    {   // phase B
-        float dsq[NV];
-        sfor<0, NM>([&](auto I) { w.LD[I] = S.W(WK_M + I); });
-        factor<true>(w.LD, dsq, w.disqrt);
-        float x[NV];
-        sfor<0, NV>([&](auto D) { x[D] = S.W(WK_SMOOTH + D); });
-        solve_LT(w.LD, x);
-        sfor<0, NV>([&](auto D) { x[D] *= w.disqrt[D] * w.disqrt[D]; });
-        solve_L(w.LD, x);
-        sfor<0, NV>([&](auto D) { S.W(WK_QS + D) = x[D]; });
-    }
-    PROF(2);
-    __builtin_amdgcn_sched_barrier(0);
+}
+
+// stage B: factorisation + qacc_smooth; the factor goes to the workspace (each leg reloads only its 164 entries)
+__device__ __forceinline__ void stage_factor(const St& S) {
+    float LD[NM], dsq[NV], disq[NV];
+    sfor<0, NM>([&](auto I) { LD[I] = S.W(WK_M + I); });
+    factor<true>(LD, dsq, disq);
+    float x[NV];
+    sfor<0, NV>([&](auto D) { x[D] = S.W(WK_SMOOTH + D); });
+    solve_LT(LD, x);
+    sfor<0, NV>([&](auto D) { x[D] *= disq[D] * disq[D]; });
+    solve_L(LD, x);
+    sfor<0, NV>([&](auto D) { S.W(WK_QS + D) = x[D]; S.W(WK_DISQ + D) = disq[D]; S.W(WK_ZT + D) = 0.f; });
+    sfor<0, NM>([&](auto I) { S.W(WK_LD + I) = LD[I]; });
+    S.W(WK_MISC + 4) = 0.f; S.W(WK_MISC + 5) = 0.f;      // footmask, warm-start cost
+}
+
+// stage C: constraint rows of one leg (whitened into LDS) + warm start contributions; z~ / cost accumulate in the workspace
+template <int LEG>
+__device__ __forceinline__ void stage_rows_leg(const St& S, const Lds& L) {
+    Fw3 w;
+    const V3 o = {S(F_QPOS), S(F_QPOS + 1), S(F_QPOS + 2)};
     Dyn2 dy;
     dy.friction = S(F_FRIC);
     dy.fn = {S(F_FLOOR), S(F_FLOOR + 1), S(F_FLOOR + 2)};
@@ -469,61 +493,89 @@ __device__ __forceinline__ void forward3(const St& S, Fw3& w, const Lds& L, cons
     sfor<0, NV>([&](auto D) { w.zt[D] = 0.f; });
     w.footmask = 0u;
     float cost = 0.f;
-    build_rows3<0>(S, w, L, dy, o, cost);      // phase C
-    build_rows3<1>(S, w, L, dy, o, cost);
-    sfor<0, NV>([&](auto D) { cost += 0.5f * w.zt[D] * w.zt[D]; });
-    if (cost > 0.f) {                          // warm start loses to f = 0 (mj_fwdConstraint)
+    build_rows3<LEG>(S, w, L, dy, o, cost);
+    sfor<0, 19>([&](auto C) { constexpr int d = c2d<LEG>(C); S.W(WK_ZT + d) += w.zt[d]; });
+    S.W(WK_MISC + LEG) = (float)w.ncon[LEG]; S.W(WK_MISC + 2 + LEG) = (float)w.nlim[LEG];
+    S.W(WK_MISC + 4) += (float)w.footmask; S.W(WK_MISC + 5) += cost;
+}
+
+// warm start loses to f = 0 (mj_fwdConstraint) when its dual cost is positive
+__device__ __forceinline__ void stage_warm_check(const St& S, const Lds& L) {
+    float cost = S.W(WK_MISC + 5);
+    sfor<0, NV>([&](auto D) { const float z = S.W(WK_ZT + D); cost += 0.5f * z * z; });
+    if (cost > 0.f) {
+        Fw3 w;
+        w.ncon[0] = (int)S.W(WK_MISC + 0); w.ncon[1] = (int)S.W(WK_MISC + 1);
+        w.nlim[0] = (int)S.W(WK_MISC + 2); w.nlim[1] = (int)S.W(WK_MISC + 3);
         zero_forces3<0>(w, L); zero_forces3<1>(w, L);
-        sfor<0, NV>([&](auto D) { w.zt[D] = 0.f; });
+        sfor<0, NV>([&](auto D) { S.W(WK_ZT + D) = 0.f; });
     }
-    PROF(3);
-    for (int it = 0; it < pgs_iters; ++it) {   // phase D
-        pgs_leg3<0>(w, L, dy.friction);
-        pgs_leg3<1>(w, L, dy.friction);
+}
+
+// stage D: projected Gauss-Seidel; only z~ (32 registers) + one row at a time are live
+__device__ __forceinline__ void stage_pgs(const St& S, const Lds& L, int pgs_iters) {
+    stage_warm_check(S, L);
+    Fw3 w;     // only zt / ncon / nlim are touched
+    sfor<0, NV>([&](auto D) { w.zt[D] = S.W(WK_ZT + D); });
+    w.ncon[0] = (int)S.W(WK_MISC + 0); w.ncon[1] = (int)S.W(WK_MISC + 1);
+    w.nlim[0] = (int)S.W(WK_MISC + 2); w.nlim[1] = (int)S.W(WK_MISC + 3);
+    const float mu = S(F_FRIC);
+    for (int it = 0; it < pgs_iters; ++it) {
+        pgs_leg3<0>(w, L, mu);
+        pgs_leg3<1>(w, L, mu);
     }
-    PROF(4);
-    __builtin_amdgcn_sched_barrier(0);
-    // phase E: qacc = qacc_smooth + L^-1 D^-1/2 z~
-    sfor<0, NV>([&](auto D) { w.qacc[D] = w.zt[D] * w.disqrt[D]; });
-    solve_L(w.LD, w.qacc);
-    sfor<0, NV>([&](auto D) { w.qacc[D] += S.W(WK_QS + D); });
-    w.foot_fz[0] = w.foot_fz[1] = 0.f;
-    sfor<0, 6>([&](auto Sl) {
-        constexpr int sl = Sl, lg = sl / 3;
-        if ((sl % 3) < w.ncon[lg] && ((w.footmask >> sl) & 1u)) {
-            const float4 ff = L.rd(CH_CON + 14 * sl + 13);
-            w.foot_fz[lg] += dy.fn.z * (ff.x + ff.y + ff.z + ff.w) + dy.friction * (dy.ft1.z * (ff.x - ff.y) + dy.ft2.z * (ff.z - ff.w));
-        }
-    });
-    {   // accelerometer at the imu site (cassie.xml:267)
+    sfor<0, NV>([&](auto D) { S.W(WK_ZT + D) = w.zt[D]; });
+}
+
+// stage E: qacc, foot force, IMU; then (do_euler) mj_Euler with implicit joint damping:
+// (M + h D) a = qfrc_smooth + J^T f = qfrc_smooth + L^T D^1/2 z~
+__device__ __forceinline__ void stage_finish(const St& S, const Lds& L, bool do_euler, float (&acc_out)[3], float (&foot_fz)[2]) {
+    float LD[NM], zt[NV], disq[NV], qacc[NV];
+    sfor<0, NM>([&](auto I) { LD[I] = S.W(WK_LD + I); });
+    sfor<0, NV>([&](auto D) { zt[D] = S.W(WK_ZT + D); disq[D] = S.W(WK_DISQ + D); });
+    sfor<0, NV>([&](auto D) { qacc[D] = zt[D] * disq[D]; });
+    solve_L(LD, qacc);
+    sfor<0, NV>([&](auto D) { qacc[D] += S.W(WK_QS + D); });
+    {   // world z of the contact force on the foot bodies (cassie_sim_foot_forces -> get_foot_forces()[2], [8])
+        const int nc[2] = {(int)S.W(WK_MISC + 0), (int)S.W(WK_MISC + 1)};
+        const unsigned footmask = (unsigned)S.W(WK_MISC + 4);
+        const float mu = S(F_FRIC), nz = S(F_FLOOR + 2), t1z = S(F_FLOOR + 5), t2z = S(F_FLOOR + 8);
+        foot_fz[0] = foot_fz[1] = 0.f;
+        sfor<0, 6>([&](auto Sl) {
+            constexpr int sl = Sl, lg = sl / 3;
+            if ((sl % 3) < nc[lg] && ((footmask >> sl) & 1u)) {
+                const float4 ff = L.rd(CH_CON + 14 * sl + 13);
+                foot_fz[lg] += nz * (ff.x + ff.y + ff.z + ff.w) + mu * (t1z * (ff.x - ff.y) + t2z * (ff.z - ff.w));
+            }
+        });
+    }
+    {   // accelerometer at the imu site (cassie.xml:267): classical acceleration of the site point, site frame
         SV A = {{S.W(WK_PEL), S.W(WK_PEL + 1), S.W(WK_PEL + 2)}, {S.W(WK_PEL + 3), S.W(WK_PEL + 4), S.W(WK_PEL + 5)}};
         const SV V = {{S.W(WK_PEL + 6), S.W(WK_PEL + 7), S.W(WK_PEL + 8)}, {S.W(WK_PEL + 9), S.W(WK_PEL + 10), S.W(WK_PEL + 11)}};
         M3 R;
         sfor<0, 9>([&](auto K) { R.m[K] = S.W(WK_PEL + 12 + K); });
-        A.l = A.l + V3{w.qacc[0], w.qacc[1], w.qacc[2]};
-        sfor<0, 3>([&](auto K) { A.a = A.a + col(R, K) * w.qacc[3 + K]; });
+        A.l = A.l + V3{qacc[0], qacc[1], qacc[2]};
+        sfor<0, 3>([&](auto K) { A.a = A.a + col(R, K) * qacc[3 + K]; });
         const V3 r = mul(R, V3{ct_imu_pos[0], ct_imu_pos[1], ct_imu_pos[2]});
         const V3 vp = V.l + cross(V.a, r);
         const V3 a = A.l + cross(A.a, r) + cross(V.a, vp);
-        w.acc[0] = dot(col(R, 0), a); w.acc[1] = dot(col(R, 1), a); w.acc[2] = dot(col(R, 2), a);
+        acc_out[0] = dot(col(R, 0), a); acc_out[1] = dot(col(R, 1), a); acc_out[2] = dot(col(R, 2), a);
     }
-}
-
-// mj_Euler with implicit joint damping: (M + h D) a = qfrc_smooth + J^T f = qfrc_smooth + L^T D^1/2 z~
-__device__ __forceinline__ void euler3(const St& S, Fw3& w) {
+    if (!do_euler) return;
     float x[NV], rhs[NV];
-    sfor<0, NV>([&](auto D) { x[D] = w.zt[D] * w.LD[ct_dof_madr[D]] * w.disqrt[D]; });     // D^1/2 = D * D^-1/2
-    mul_LT(w.LD, x, rhs);
+    sfor<0, NV>([&](auto D) { x[D] = zt[D] * LD[ct_dof_madr[D]] * disq[D]; });     // D^1/2 = D * D^-1/2
+    mul_LT(LD, x, rhs);
     sfor<0, NV>([&](auto D) { rhs[D] += S.W(WK_SMOOTH + D); });
-    sfor<0, NM>([&](auto I) { w.LD[I] = S.W(WK_M + I); });
-    sfor<0, NV>([&](auto D) { w.LD[ct_dof_madr[D]] += DT * S(F_DAMP + D); });
+    __builtin_amdgcn_sched_barrier(0);
+    sfor<0, NM>([&](auto I) { LD[I] = S.W(WK_M + I); });
+    sfor<0, NV>([&](auto D) { LD[ct_dof_madr[D]] += DT * S(F_DAMP + D); });
     float d1[NV], d2[NV];
-    factor<false>(w.LD, d1, d2);
-    solve_LT(w.LD, rhs);
-    sfor<0, NV>([&](auto D) { rhs[D] *= __frcp_rn(w.LD[ct_dof_madr[D]]); });
-    solve_L(w.LD, rhs);
+    factor<false>(LD, d1, d2);
+    solve_LT(LD, rhs);
+    sfor<0, NV>([&](auto D) { rhs[D] *= __frcp_rn(LD[ct_dof_madr[D]]); });
+    solve_L(LD, rhs);
     float qv[NV];
-    sfor<0, NV>([&](auto D) { S(F_QACCW + D) = w.qacc[D]; qv[D] = S(F_QVEL + D) + DT * rhs[D]; S(F_QVEL + D) = qv[D]; });
+    sfor<0, NV>([&](auto D) { S(F_QACCW + D) = qacc[D]; qv[D] = S(F_QVEL + D) + DT * rhs[D]; S(F_QVEL + D) = qv[D]; });
     sfor<0, NJ>([&](auto Jn) {
         constexpr int j = Jn, qa = ct_jnt_qposadr[j], da = ct_jnt_dofadr[j];
         if constexpr (ct_jnt_type[j] != 2) S(F_QPOS + qa) += DT * qv[da];

@@ -74,30 +74,14 @@ __constant__ float kTorqueLimit[5] = {140.63f, 140.63f, 216.16f, 216.16f, 45.14f
 __constant__ float kFir[9] = {2727.f, 534.f, -2658.f, -795.f, 72.f, 110.f, 19.f, -6.f, -3.f};
 #define PI_F 3.14159265358979323846f
 
-// forward pass + sensor snapshot + per-forward accessor values (foot force; the foot pose is written by the tree walk)
-__device__ __forceinline__ void forward_snapshot(const St& S, c3::Fw3& w, const c2::Lds& L, const float (&ctrl)[10], int pgs_iters) {
-    c3::forward3(S, w, L, ctrl, pgs_iters);
-#pragma unroll
-    for (int u = 0; u < 10; ++u) S(F_SNAP + SN_MPOS + u) = S(F_QPOS + cmt::ct_act_qposadr[u]);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) S(F_SNAP + SN_JPOS + k) = S(F_QPOS + cmt::ct_jsens_qposadr[k]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) S(F_SNAP + SN_QUAT + k) = S(F_QPOS + 3 + k);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { S(F_SNAP + SN_GYRO + k) = S(F_QVEL + 3 + k); S(F_SNAP + SN_ACC + k) = w.acc[k]; S(F_SNAP + SN_VEL + k) = S(F_QVEL + k); }
-    S(F_SNAP + SN_PZ) = S(F_QPOS + 2);
-    S(F_FWD + 0) = w.foot_fz[0]; S(F_FWD + 1) = w.foot_fz[1];
-}
-
-// one 2 kHz substep: encoders + estimator -> PD -> safeties -> motor model / delay -> mj_step
-// with_euler = false: forward pass only (cassie_sim_set_const ends in mj_forward)
-__device__ __noinline__ void sim_step_pd(St S, int pgs_iters, int mode) {
+// ---- the substep as four non-inlined stages (cassie_step3.h): state crosses stages through HBM/L2 and LDS only
+// stage 1: encoders + estimator -> PD -> safeties -> motor model / delay, then the tree walk.
+// mode 0: forward pass only with zero ctrl (cassie_sim_set_const ends in mj_forward)
+__device__ __noinline__ void stage1_io_tree(St S, int mode) {
     PROF_START();
-    c3::Fw3 w;
-    const c2::Lds Y{apx_lds4 + (threadIdx.x & 63)};
-    if (mode == 0) { const float zero[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; forward_snapshot(S, w, Y, zero, pgs_iters); return; }
+    float ctrl[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (mode != 0) {
     int flags = S.I(I_FLAGS);
-    float ctrl[10];
 #pragma unroll
     for (int u = 0; u < 10; ++u) {
         // drive encoder: truncating quantiser + 9-tap FIR velocity
@@ -148,11 +132,56 @@ __device__ __noinline__ void sim_step_pd(St S, int pgs_iters, int mode) {
         S(F_SO + SO_TACC) = aw.x; S(F_SO + SO_TACC + 1) = aw.y; S(F_SO + SO_TACC + 2) = aw.z - GRAV;
         S(F_SO + SO_HEIGHT) = S(F_SNAP + SN_PZ) - cmt::ct_floor_pos[2];
     }
+    }
     PROF(0);
-    forward_snapshot(S, w, Y, ctrl, pgs_iters);
-    PROF(5);
-    c3::euler3(S, w);
-    PROF(6);
+    c3::stage_tree(S, ctrl);
+    PROF(1);
+}
+__device__ __noinline__ void stage2a_factor(St S) {
+    PROF_START();
+    c3::stage_factor(S);
+    PROF(2);
+}
+template <int LEG>
+__device__ __noinline__ void stage2b_rows(St S) {
+    PROF_START();
+    const c2::Lds Y{apx_lds4 + (threadIdx.x & 63)};
+    c3::stage_rows_leg<LEG>(S, Y);
+    PROF(5 + LEG);
+}
+__device__ __noinline__ void stage3_pgs(St S, int pgs_iters) {
+    PROF_START();
+    const c2::Lds Y{apx_lds4 + (threadIdx.x & 63)};
+    c3::stage_pgs(S, Y, pgs_iters);
+    PROF(3);
+}
+__device__ __noinline__ void stage4_finish(St S, int mode) {
+    PROF_START();
+    const c2::Lds Y{apx_lds4 + (threadIdx.x & 63)};
+    float acc[3], fz[2];
+    // sensor snapshot of the PRE-integration state (sensordata is one mj_step1 old when step_ethercat reads it)
+#pragma unroll
+    for (int u = 0; u < 10; ++u) S(F_SNAP + SN_MPOS + u) = S(F_QPOS + cmt::ct_act_qposadr[u]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) S(F_SNAP + SN_JPOS + k) = S(F_QPOS + cmt::ct_jsens_qposadr[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) S(F_SNAP + SN_QUAT + k) = S(F_QPOS + 3 + k);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { S(F_SNAP + SN_GYRO + k) = S(F_QVEL + 3 + k); S(F_SNAP + SN_VEL + k) = S(F_QVEL + k); }
+    S(F_SNAP + SN_PZ) = S(F_QPOS + 2);
+    c3::stage_finish(S, Y, mode != 0, acc, fz);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) S(F_SNAP + SN_ACC + k) = acc[k];
+    S(F_FWD + 0) = fz[0]; S(F_FWD + 1) = fz[1];
+    PROF(4);
+}
+__device__ __forceinline__ void sim_step_pd(const St& S, int pgs_iters, int mode) {
+    stage1_io_tree(S, mode);
+    stage2a_factor(S);
+    stage2b_rows<0>(S);
+    stage2b_rows<1>(S);
+    stage3_pgs(S, pgs_iters);
+    stage4_finish(S, mode);
 }
 
 // ------------------------------------------------------------------------------------------------ env logic
