@@ -521,8 +521,14 @@ __device__ __forceinline__ void stage_pgs(const St& S, const Lds& L, int pgs_ite
     w.nlim[0] = (int)S.W(WK_MISC + 2); w.nlim[1] = (int)S.W(WK_MISC + 3);
     const float mu = S(F_FRIC);
     for (int it = 0; it < pgs_iters; ++it) {
-        pgs_leg3<0>(w, L, mu);
-        pgs_leg3<1>(w, L, mu);
+        // the rows are loop-invariant; without this the compiler hoists ~400 row values out of the loop and then
+        // spills them.  An opaque (always zero) chunk offset keeps them streaming from LDS every sweep instead; it is an
+        // integer so that the pointer keeps its LDS address space (ds_read_b128, not flat_load).
+        int zero_off = 0;
+        asm volatile("" : "+v"(zero_off));
+        const Lds Ls{L.base + zero_off};
+        pgs_leg3<0>(w, Ls, mu);
+        pgs_leg3<1>(w, Ls, mu);
     }
     sfor<0, NV>([&](auto D) { S.W(WK_ZT + D) = w.zt[D]; });
 }

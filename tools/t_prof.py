@@ -1,5 +1,5 @@
 import sys, torch, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from apex_amd.vecenv import CassieVecEnv
 env = CassieVecEnv(n_envs=4096, seed=0)
 env.reset()
