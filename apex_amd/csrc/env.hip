@@ -82,6 +82,7 @@ __device__ __noinline__ void stage1_io_tree(St S, int mode) {
     float ctrl[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (mode != 0) {
     int flags = S.I(I_FLAGS);
+    float tau_cmd[10], mpos_a[10], mvel_a[10];
 #pragma unroll
     for (int u = 0; u < 10; ++u) {
         // drive encoder: truncating quantiser + 9-tap FIR velocity
@@ -94,10 +95,30 @@ __device__ __noinline__ void stage1_io_tree(St S, int mode) {
         _Pragma("unroll") for (int k = 0; k < 9; ++k) { S(F_MENC + u * 9 + k) = h[k]; acc += kFir[k] * h[k]; }
         const float mpos = nq * scale / gear, mvel = acc * scale / gear / PI_F;
         S(F_SO + SO_MPOS + u) = mpos; S(F_SO + SO_MVEL + u) = mvel;
-        // pd_input_step -> cassie_core_sim_step clamp -> torque-speed curve -> 6-deep delay
-        float tau = kP[u % 5] * (S(F_PDT + u) - mpos) + kD[u % 5] * (0.f - mvel);
-        if (!(S.I(I_FLAGS) & 16)) tau = 0.f;       // pd_in_t zero until the first env.step (gains are set there)
+        // pd_input_step: tau = P (pTarget - q) + D (0 - qd), no clamp (G9)
+        tau_cmd[u] = (S.I(I_FLAGS) & 16) ? kP[u % 5] * (S(F_PDT + u) - mpos) + kD[u % 5] * (0.f - mvel) : 0.f;   // pd_in_t is zero until the first env.step
+        mpos_a[u] = mpos; mvel_a[u] = mvel;
+    }
+    // cassie_core_sim_step (G10): soft joint-limit zones 0.15 rad inside the drive limits, global torque scale,
+    // restoring PD on the intruding drive, clamp to the drive torqueLimit
+    float sdepth[10], ssign[10], sscale = 1.f;
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+        constexpr float DEG = PI_F / 180.f;
+        const float lo_deg[5] = {-15.f, -22.f, -50.f, -156.f, -140.f}, hi_deg[5] = {20.f, 22.f, 80.f, -42.f, -35.f};
+        float lo = lo_deg[u % 5] * DEG + 0.15f, hi = hi_deg[u % 5] * DEG - 0.15f;
+        if (u >= 5 && (u % 5) < 2) { const float t = lo; lo = -hi; hi = -t; }      // roll / yaw mirror on the right leg
+        sdepth[u] = fmaxf(0.f, fmaxf(mpos_a[u] - hi, lo - mpos_a[u]));
+        ssign[u] = mpos_a[u] > hi ? -1.f : 1.f;
+        sscale *= fmaxf(0.f, 1.f - sdepth[u] * (1.f / 0.15f));
+    }
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+        const float sKp[5] = {1000.f, 800.f, 1200.f, 1200.f, 100.f}, sKd[5] = {12.f, 12.f, 36.f, 36.f, 7.f};
+        const float gear = cmt::ct_act_gear[u], d = sdepth[u];
+        float tau = sscale * tau_cmd[u] + ssign[u] * sKp[u % 5] * d * (1.f + d * (1.f / 0.15f)) - fminf(1.f, d * (1.f / 0.15f)) * sKd[u % 5] * mvel_a[u];
         tau = fminf(fmaxf(tau, -kTorqueLimit[u % 5]), kTorqueLimit[u % 5]);
+        // cassie_sim_step_ethercat: torque-speed curve, 6-deep delay line
         const float wmax = cmt::ct_act_rpm[u] * 2.f * PI_F / 60.f, tmax = cmt::ct_act_ctrlmax[u];
         const float om = fabsf(S(F_QVEL + cmt::ct_act_dof[u]) * gear);
         const float tlim = fminf(fmaxf(2.f * tmax * (1.f - om / wmax), 0.f), tmax);

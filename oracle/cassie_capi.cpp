@@ -94,6 +94,8 @@ double orc_clock_reward_eval(void* h, const double* qpos, const double* qvel, co
     return eval_clock_reward(e, action);
 }
 
+void orc_core_safety(const double* q, const double* qd, const double* cmd, double radio, double* out) { core_safety(q, qd, cmd, radio, out); }
+
 uint32_t orc_philox(uint64_t seed, uint32_t env, uint32_t ctr) {
     Philox p{(uint32_t)seed, (uint32_t)(seed >> 32), env, ctr};
     return p.next_u32();

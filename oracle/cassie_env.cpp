@@ -4,6 +4,8 @@
 
 namespace orc {
 
+static const double PI = 3.14159265358979323846;
+static const double kTorqueLimit[5] = {140.63, 140.63, 216.16, 216.16, 45.14};   // cassie_sim_init presets, SURVEY §2.2
 // ---------------------------------------------------------------------------------------------- Philox4x32-10
 static inline void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
@@ -88,12 +90,39 @@ double Clock::eval(int which, double ph) const {
 }
 
 // ---------------------------------------------------------------------------------------------- helpers
-static const double PI = 3.14159265358979323846;
+
 static const double kP[5] = {100, 100, 88, 96, 50}, kD[5] = {10.0, 10.0, 8.0, 9.6, 5.0};   // cassie.py:57-58
 static const double kOffset[10] = {0.0045, 0.0, 0.4973, -1.1997, -1.5968, 0.0045, 0.0, 0.4973, -1.1997, -1.5968};  // :107
 static const double kNeutralFoot[4] = {-0.24790886454547323, -0.24679713195445646, -0.6609396704367185, 0.663921021343526};  // :121
-static const double kTorqueLimit[5] = {140.63, 140.63, 216.16, 216.16, 45.14};   // cassie_sim_init presets, SURVEY §2.2
 static const int kFir[9] = {2727, 534, -2658, -795, 72, 110, 19, -6, -3};
+
+// cassie_core_sim_step (include/CassieCoreSim.h), characterised through the reference's callable binary
+// (tools/refprobe/probe_safety*.py) and pinned by golden G10 to 1e-13:
+//   * each drive has a soft zone that starts 0.15 rad inside its limits [-15,20] [-22,22] [-50,80] [-156,-42] [-140,-35]
+//     deg (roll / yaw mirrored on the right leg); intrusion depth d_i
+//   * every commanded torque on both legs is scaled by  s = prod_i max(0, 1 - d_i / 0.15)
+//   * the intruding drive additionally gets  -+ Kp d (1 + d/0.15) - min(1, d/0.15) Kd qd   (Kp 1000 800 1200 1200 100,
+//     Kd 12 12 36 36 7), then everything is clamped to the drive torqueLimit; radio channel 8 <= 0 zeroes all torques.
+// Not modelled: the coupled hip-pitch + knee zone (pitch + knee < ~-2.36 rad, a deep squat).
+void core_safety(const double* q, const double* qd, const double* cmd, double radio, double* out) {
+    static const double lo_deg[5] = {-15, -22, -50, -156, -140}, hi_deg[5] = {20, 22, 80, -42, -35};
+    static const double Kp[5] = {1000, 800, 1200, 1200, 100}, Kd[5] = {12, 12, 36, 36, 7};
+    double d[10], sg[10], s = 1.0;
+    for (int u = 0; u < 10; ++u) {
+        const int j = u % 5;
+        double lo = lo_deg[j] * PI / 180 + 0.15, hi = hi_deg[j] * PI / 180 - 0.15;
+        if (u >= 5 && j < 2) { const double t = lo; lo = -hi; hi = -t; }
+        d[u] = std::max(0.0, std::max(q[u] - hi, lo - q[u]));
+        sg[u] = q[u] > hi ? -1.0 : 1.0;
+        s *= std::max(0.0, 1.0 - d[u] / 0.15);
+    }
+    for (int u = 0; u < 10; ++u) {
+        const int j = u % 5;
+        double t = s * cmd[u] + sg[u] * Kp[j] * d[u] * (1.0 + d[u] / 0.15) - std::min(1.0, d[u] / 0.15) * Kd[j] * qd[u];
+        t = std::min(std::max(t, -kTorqueLimit[j]), kTorqueLimit[j]);
+        out[u] = radio > 0 ? t : 0.0;
+    }
+}
 
 static void forward_snapshot(Env& e, Work& w, const double* ctrl) {
     forward(e.par, e.st, w, ctrl);
@@ -151,8 +180,8 @@ void sim_step_pd(Env& e) {
     // --- pd_input_step: tau = P (pTarget - q) + D (dTarget - qd), no clamp (PdInput.h; SURVEY §2.2 bit-exact probe)
     double tau[10], ctrl[10];
     for (int u = 0; u < 10; ++u) tau[u] = e.pd_P[u] * (e.pd_target[u] - e.so_mpos[u]) + e.pd_D[u] * (0.0 - e.so_mvel[u]);
-    // --- cassie_core_sim_step: clamp to the drive torqueLimit (joint-limit safety zones: DESIGN.md §5, not yet modelled)
-    for (int u = 0; u < 10; ++u) tau[u] = std::min(std::max(tau[u], -kTorqueLimit[u % 5]), kTorqueLimit[u % 5]);
+    // --- cassie_core_sim_step: joint-limit safety zones + clamp to the drive torqueLimit
+    core_safety(e.so_mpos, e.so_mvel, tau, 1.0, tau);
     // --- cassie_sim_step_ethercat: torque-speed curve, 6-deep delay line
     for (int u = 0; u < 10; ++u) {
         const double wmax = cm_act_rpm[u] * 2 * PI / 60.0, tmax = cm_act_ctrlmax[u];

@@ -74,6 +74,7 @@ void env_reset(Env& e, double* obs);
 int env_step(Env& e, const double* action, double* obs, double* reward);
 void env_obs(const Env& e, double* obs);
 void sim_step_pd(Env& e);
+void core_safety(const double* q, const double* qd, const double* cmd, double radio, double* out);   // cassie_core_sim_step model
 double eval_clock_reward(Env& e, const double* action);   // exposed for the golden-vector tests          // one 2 kHz substep with the current pd targets (cassie_sim_step_pd)
 
 }  // namespace orc

@@ -39,6 +39,7 @@ def lib():
                                      C.c_void_p, C.c_void_p]
         L.orc_clock_reward_eval.restype = C.c_double
         L.orc_clock_reward_eval.argtypes = [C.c_void_p] * 11
+        L.orc_core_safety.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
         L.orc_philox.restype = C.c_uint32
         L.orc_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
         L.orc_rollout_bench.restype = C.c_double
@@ -123,6 +124,13 @@ def clock_eval(swing, stance, relax, mode, inc, freq, phases):
     out = np.zeros((len(ph), 4)); pl = np.zeros(1)
     lib().orc_clock_eval(swing, stance, relax, mode, int(inc), freq, len(ph), _ptr(ph), _ptr(out), _ptr(pl))
     return out, float(pl[0])
+
+
+def core_safety(q, qd, cmd, radio=1.0):
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (q, qd, cmd)]
+    out = np.zeros(10)
+    lib().orc_core_safety(_ptr(a[0]), _ptr(a[1]), _ptr(a[2]), float(radio), _ptr(out))
+    return out
 
 
 def philox(seed, env, ctr):

@@ -88,6 +88,28 @@ def test_env_steps_vs_oracle(dev):
         np.testing.assert_array_equal(ints[:n_chk, [0, 1, 2, 3]], oints[:, [0, 1, 2, 5]])
 
 
+def test_safety_zones_vs_oracle(dev):
+    """Large hip-roll / hip-yaw / foot targets drive the joints into cassie_core_sim_step's soft zones (G10 model):
+    the delayed drive torques and the joint positions must track the oracle."""
+    genv, oenv = _mk(False, 4)
+    genv.reset(); [e.reset() for e in oenv[:8]]
+    rng = np.random.RandomState(1)
+    hit = 0
+    for t in range(3):
+        act = (rng.randn(N, 10) * 0.05).astype(np.float32)
+        act[:, [0, 1, 5, 6]] += rng.choice([-0.5, 0.5], size=(N, 4)).astype(np.float32)      # roll / yaw far past +-0.2
+        act[:, [4, 9]] += 0.9                                                                # foot past its -35 deg limit
+        obs, rew, done, _ = genv.step(torch.tensor(act, device=dev), auto_reset=False)
+        tq = genv.get_field("so_torque").cpu().numpy(); mp = genv.get_field("so_mpos").cpu().numpy()
+        for i, e in enumerate(oenv[:8]):
+            e.step(act[i].astype(np.float64))
+            np.testing.assert_allclose(mp[i], e.get("so_mpos"), atol=2e-3 * (t + 1))
+            np.testing.assert_allclose(tq[i], e.get("so_torque"), atol=1.5 * (t + 1), rtol=0.05)
+            q = e.get("so_mpos")
+            hit += int(q[0] > 0.2 or q[0] < -0.112 or abs(q[1]) > 0.234 or q[5] < -0.2 or q[5] > 0.112 or abs(q[6]) > 0.234 or q[4] > -0.761)
+    assert hit > 0            # the zones were actually reached
+
+
 def test_step_invariants_full_size(dev):
     """BASELINE size (4096 envs): finite outputs, quaternion norms, loop closure, reward range, auto-reset bookkeeping."""
     from apex_amd.vecenv import CassieVecEnv

@@ -43,6 +43,21 @@ def test_g8_full_state(golden_dir):
         np.testing.assert_allclose(e.obs(), g[p + "obs"], atol=1e-12)
 
 
+def test_g9_pd_law(golden_dir):
+    """pd_input_step of the reference binary: tau = ff + P (pTarget - q) + D (dTarget - qd), no clamp (bit-exact)."""
+    g = np.load(os.path.join(golden_dir, "g9_pd_input.npz"))
+    tau = g["ff"] + g["P"] * (g["pTarget"] - g["q"]) + g["D"] * (g["dTarget"] - g["v"])
+    np.testing.assert_array_equal(tau, g["tau"])
+
+
+def test_g10_core_sim_safety(golden_dir):
+    """cassie_core_sim_step of the reference binary on 400 random multi-joint states (zones, clamp, radio gate)."""
+    g = np.load(os.path.join(golden_dir, "g10_core_sim.npz"))
+    for k in range(g["q"].shape[0]):
+        out = S.core_safety(g["q"][k], g["v"][k], g["cmd"][k], g["radio"][k])
+        np.testing.assert_allclose(out, g["tau"][k], rtol=1e-12, atol=1e-10)
+
+
 def test_philox_known_answer():
     # Philox4x32-10 known-answer vectors (Random123 kat_vectors): counter 0, key 0 -> 6627e8d5 ...
     import ctypes
