@@ -149,9 +149,13 @@ __device__ __noinline__ void stage1_io_tree(St S, int mode) {
         const Q4 q = {S(F_SNAP + SN_QUAT), S(F_SNAP + SN_QUAT + 1), S(F_SNAP + SN_QUAT + 2), S(F_SNAP + SN_QUAT + 3)};
         _Pragma("unroll") for (int k = 0; k < 4; ++k) S(F_SO + SO_QUAT + k) = S(F_SNAP + SN_QUAT + k);
         _Pragma("unroll") for (int k = 0; k < 3; ++k) { S(F_SO + SO_ROTVEL + k) = S(F_SNAP + SN_GYRO + k); S(F_SO + SO_TVEL + k) = S(F_SNAP + SN_VEL + k); }
-        const V3 aw = mul(q2m(q), V3{S(F_SNAP + SN_ACC), S(F_SNAP + SN_ACC + 1), S(F_SNAP + SN_ACC + 2)});
-        S(F_SO + SO_TACC) = aw.x; S(F_SO + SO_TACC + 1) = aw.y; S(F_SO + SO_TACC + 2) = aw.z - GRAV;
-        S(F_SO + SO_HEIGHT) = S(F_SNAP + SN_PZ) - cmt::ct_floor_pos[2];
+        // estimator-lite (golden G11): pelvis-frame specific force minus gravity, pelvis-frame velocity, z - 0.0818
+        const M3 R = q2m(q);
+        S(F_SO + SO_TACC) = S(F_SNAP + SN_ACC) - R.m[6] * GRAV; S(F_SO + SO_TACC + 1) = S(F_SNAP + SN_ACC + 1) - R.m[7] * GRAV;
+        S(F_SO + SO_TACC + 2) = S(F_SNAP + SN_ACC + 2) - R.m[8] * GRAV;
+        const V3 vw = {S(F_SNAP + SN_VEL), S(F_SNAP + SN_VEL + 1), S(F_SNAP + SN_VEL + 2)};
+        S(F_SO + SO_TVEL) = dot(col(R, 0), vw); S(F_SO + SO_TVEL + 1) = dot(col(R, 1), vw); S(F_SO + SO_TVEL + 2) = dot(col(R, 2), vw);
+        S(F_SO + SO_HEIGHT) = S(F_SNAP + SN_PZ) - 0.0818f;
     }
     }
     PROF(0);

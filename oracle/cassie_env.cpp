@@ -171,11 +171,15 @@ void sim_step_pd(Env& e) {
     for (int k = 0; k < 4; ++k) e.so_quat[k] = e.snap_quat[k];
     for (int k = 0; k < 3; ++k) e.so_rotvel[k] = e.snap_gyro[k];
     {
+        // estimator-lite, chosen by pushing this simulator's sensor stream through the reference's state_output_step
+        // (tools/refprobe/probe_estimator.py, golden G11): acceleration = specific force minus gravity in the PELVIS frame,
+        // velocity in the pelvis frame, height = pelvis z - 0.0818 (the filter's foot-referenced height)
         const M3 R = q2m(Q4{e.snap_quat[0], e.snap_quat[1], e.snap_quat[2], e.snap_quat[3]});
-        const V3 aw = mul(R, V3{e.snap_acc[0], e.snap_acc[1], e.snap_acc[2]});
-        e.so_tacc[0] = aw.x; e.so_tacc[1] = aw.y; e.so_tacc[2] = aw.z - GRAV;
-        for (int k = 0; k < 3; ++k) e.so_tvel[k] = e.snap_vel[k];
-        e.so_height = e.snap_pz - cm_floor_pos[2];
+        const V3 gb = {R.m[6] * GRAV, R.m[7] * GRAV, R.m[8] * GRAV};                       // R^T (0,0,g)
+        e.so_tacc[0] = e.snap_acc[0] - gb.x; e.so_tacc[1] = e.snap_acc[1] - gb.y; e.so_tacc[2] = e.snap_acc[2] - gb.z;
+        const V3 vw = {e.snap_vel[0], e.snap_vel[1], e.snap_vel[2]};
+        e.so_tvel[0] = dot(col(R, 0), vw); e.so_tvel[1] = dot(col(R, 1), vw); e.so_tvel[2] = dot(col(R, 2), vw);
+        e.so_height = e.snap_pz - 0.0818;
     }
     // --- pd_input_step: tau = P (pTarget - q) + D (dTarget - qd), no clamp (PdInput.h; SURVEY §2.2 bit-exact probe)
     double tau[10], ctrl[10];

@@ -58,6 +58,25 @@ def test_g10_core_sim_safety(golden_dir):
         np.testing.assert_allclose(out, g["tau"][k], rtol=1e-12, atol=1e-10)
 
 
+def test_g11_estimator_lite_vs_reference_filter(golden_dir):
+    """The 7 filtered estimator outputs: our closed-form estimator-lite vs the reference's state_output_step run on this
+    simulator's own sensor stream (a falling robot under random actions).  The reference filter is a stateful black box,
+    so this pins the FRAMES and offsets with stated tolerances, not bit parity; the 39 pass-through fields are exact."""
+    g = np.load(os.path.join(golden_dir, "g11_estimator.npz"))
+    def q2m(q):
+        w, x, y, z = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                         [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                         [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    Rm = np.stack([q2m(q) for q in g["quat"]])
+    tacc = g["acc"] - np.einsum("nji,j->ni", Rm, np.array([0, 0, 9.81]))
+    tvel = np.einsum("nji,nj->ni", Rm, g["v_world"])
+    assert np.abs(tacc - g["ref_tacc"]).mean(0).max() < 0.3                 # m/s^2 (world-frame alternative: 0.6)
+    assert np.abs(tvel[:, :2] - g["ref_tvel"][:, :2]).mean(0).max() < 0.06  # m/s, x and y (z is leg-kinematics based in the filter)
+    assert abs(np.mean(g["z"] - 0.0818 - g["ref_height"])) < 0.005 and np.std(g["z"] - 0.0818 - g["ref_height"]) < 0.03
+    np.testing.assert_allclose(g["ref_quat"], g["quat"], atol=1e-12); np.testing.assert_allclose(g["ref_rotvel"], g["gyro"], atol=1e-12)
+
+
 def test_philox_known_answer():
     # Philox4x32-10 known-answer vectors (Random123 kat_vectors): counter 0, key 0 -> 6627e8d5 ...
     import ctypes
