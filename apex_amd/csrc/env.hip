@@ -366,6 +366,12 @@ __device__ float clock_reward(const St& S, const Cfg& cfg, const float* action, 
     const float ph = (float)S.I(I_PHASE);
     const float lfc = clock_eval(ck, 0, ph, cfg.stance_mode, cfg.incentive), lvc = clock_eval(ck, 1, ph, cfg.stance_mode, cfg.incentive);
     const float rfc = clock_eval(ck, 2, ph, cfg.stance_mode, cfg.incentive), rvc = clock_eval(ck, 3, ph, cfg.stance_mode, cfg.incentive);
+    if (cfg.reward_kind == 1) {   // early_clock_reward (clock_rewards.py:119-223): caps 350 N / 3 m/s, tanh scores, 5 terms
+        const float elf = fminf(lfrc, 350.f) / 350.f, erf = fminf(rfrc, 350.f) / 350.f;
+        const float elv = fminf(sqrtf(lv), 3.f) / 3.f, erv = fminf(sqrtf(rv), 3.f) / 3.f;
+        return 0.250f * (tanhf(lfc * elf) + tanhf(rfc * erf)) + 0.350f * (tanhf(lvc * elv) + tanhf(rvc * erv)) +
+               0.200f * expf(-com_vel_err) + 0.100f * expf(-((1.f - qw * qw) + (lor + ror))) + 0.100f * expf(-(straight + hdiff));
+    }
     const float frc_score = tanf(PI_F / 4.f * lfc * nlf) + tanf(PI_F / 4.f * rfc * nrf);
     const float vel_score = tanf(PI_F / 4.f * lvc * nlv) + tanf(PI_F / 4.f * rvc * nrv);
     const float hip_roll = fabsf(S(F_QVEL + 6)) + fabsf(S(F_QVEL + 13));          // clock_rewards.py:74 (sic)
@@ -475,7 +481,7 @@ static constexpr size_t LDS_BYTES = (size_t)c2::CH_TOTAL * 64 * sizeof(float4); 
 
 static Cfg make_cfg(const apx_env_cfg& c) {
     return Cfg{c.simrate, c.dynamics_randomization, c.stance_mode, c.have_incentive, c.max_traj_len, c.pgs_iters,
-               (unsigned)c.seed, (unsigned)(c.seed >> 32), (unsigned)c.env_id_base};
+               (unsigned)c.seed, (unsigned)(c.seed >> 32), (unsigned)c.env_id_base, c.reward_kind};
 }
 
 extern "C" void apx_env_default_cfg(apx_env_cfg* c) {
@@ -489,7 +495,7 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     APX_REQUIRE(cfg && out, "null");
     APX_REQUIRE(cfg->n_envs > 0 && cfg->n_envs % 64 == 0, "n_envs must be a positive multiple of 64");
     APX_REQUIRE(cfg->simrate > 0 && 2000 % cfg->simrate == 0, "simrate must divide 2000");
-    APX_REQUIRE(cfg->reward_kind == 0, "only clock_reward is built in this round");
+    APX_REQUIRE(cfg->reward_kind == 0 || cfg->reward_kind == 1, "reward_kind: 0 clock_reward, 1 early_clock_reward");
     APX_REQUIRE(cfg->pgs_iters > 0 && cfg->max_traj_len > 0, "pgs_iters / max_traj_len");
     APX_HIP(hipSetDevice(cfg->device));
     apx_env* e = new (std::nothrow) apx_env;

@@ -41,7 +41,7 @@ __device__ __forceinline__ St make_st(float* st, int* ist, int n, int env, float
     return St{(gfloat*)st, (gint*)ist, n, env, (gfloat*)wk};
 }
 
-struct Cfg { int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; };
+struct Cfg { int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; int reward_kind; };
 
 // ------------------------------------------------------------------------------------------------ Philox4x32-10
 __device__ __forceinline__ unsigned philox(unsigned k0, unsigned k1, unsigned env, unsigned ctr) {

@@ -332,7 +332,28 @@ static double clock_reward(Env& e, const double* action) {   // cassie/rewards/c
     return t[0] + t[1] + t[2] + t[3] + t[4] + t[5] + t[6] + t[7];
 }
 
-double eval_clock_reward(Env& e, const double* action) { return clock_reward(e, action); }
+// early_clock_reward (cassie/rewards/clock_rewards.py:119-223): tanh scores, caps 350 N / 3 m/s, no torque / action /
+// hip-roll / pelvis-acceleration terms
+static double early_clock_reward(Env& e, const double* action) {
+    (void)action;
+    const State& s = e.st;
+    const double fmax = 350, vmax = 3.0;
+    const double nlf = std::min(e.l_foot_frc, fmax) / fmax, nrf = std::min(e.r_foot_frc, fmax) / fmax;
+    const double lv = std::sqrt(e.l_foot_vel[0] * e.l_foot_vel[0] + e.l_foot_vel[1] * e.l_foot_vel[1] + e.l_foot_vel[2] * e.l_foot_vel[2]);
+    const double rv = std::sqrt(e.r_foot_vel[0] * e.r_foot_vel[0] + e.r_foot_vel[1] * e.r_foot_vel[1] + e.r_foot_vel[2] * e.r_foot_vel[2]);
+    const double nlv = std::min(lv, vmax) / vmax, nrv = std::min(rv, vmax) / vmax;
+    const double com_orient = 1 - s.qpos[3] * s.qpos[3], foot_orient = e.l_foot_orient_cost + e.r_foot_orient_cost;
+    const double com_vel_err = std::fabs(e.speed - s.qvel[0]);
+    double straight = std::fabs(s.qpos[1]);
+    if (straight < 0.05) straight = 0;
+    double hdiff = std::fabs(s.qpos[2] - 0.9);
+    if (hdiff < 0.05 + 0.05 * e.speed) hdiff = 0;
+    const double lfc = e.clock.eval(0, e.phase), lvc = e.clock.eval(1, e.phase), rfc = e.clock.eval(2, e.phase), rvc = e.clock.eval(3, e.phase);
+    const double frc_score = std::tanh(lfc * nlf) + std::tanh(rfc * nrf), vel_score = std::tanh(lvc * nlv) + std::tanh(rvc * nrv);
+    return 0.250 * frc_score + 0.350 * vel_score + 0.200 * std::exp(-com_vel_err) + 0.100 * std::exp(-(com_orient + foot_orient)) +
+           0.100 * std::exp(-(straight + hdiff));
+}
+double eval_clock_reward(Env& e, const double* action) { return e.cfg.reward_kind == 1 ? early_clock_reward(e, action) : clock_reward(e, action); }
 
 // CassieEnv.step, cassie.py:389-496
 int env_step(Env& e, const double* action, double* obs, double* reward) {
@@ -362,7 +383,7 @@ int env_step(Env& e, const double* action, double* obs, double* reward) {
     int done = (height < 0.4 || height > 3.0 || !(height == height)) ? 1 : 0;
     if (!e.has_prev_action) { for (int u = 0; u < 10; ++u) e.prev_action[u] = action[u]; e.has_prev_action = 1; }
     if (!e.has_prev_torque) { for (int u = 0; u < 10; ++u) e.prev_torque[u] = e.so_torque[u]; e.has_prev_torque = 1; }
-    *reward = clock_reward(e, action);
+    *reward = eval_clock_reward(e, action);
     for (int u = 0; u < 10; ++u) { e.prev_action[u] = action[u]; e.prev_torque[u] = e.so_torque[u]; }
     // early_term_cutoff is forced to -99 (cassie.py:773) => the reward never terminates
     Philox& r = e.rng;   // command resampling :483-491, fixed 6 draws per step

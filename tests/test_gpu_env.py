@@ -110,6 +110,22 @@ def test_safety_zones_vs_oracle(dev):
     assert hit > 0            # the zones were actually reached
 
 
+def test_early_clock_reward_vs_oracle(dev):
+    """--reward early_clock selects early_clock_reward (cassie.py:202-204, clock_rewards.py:119-223)."""
+    from apex_amd.vecenv import CassieVecEnv
+    genv = CassieVecEnv(n_envs=N, dynamics_randomization=True, seed=6, reward="early_clock")
+    oenv = [S.OracleEnv(dyn_rand=True, seed=6, env_id=i, reward_kind=1) for i in range(8)]
+    genv.reset(); [e.reset() for e in oenv]
+    rng = np.random.RandomState(2)
+    for t in range(4):
+        act = (rng.randn(N, 10) * 0.1).astype(np.float32)
+        _, rew, done, _ = genv.step(torch.tensor(act, device=dev), auto_reset=False)
+        rew = rew.cpu().numpy()
+        for i, e in enumerate(oenv):
+            _, r, d = e.step(act[i].astype(np.float64))
+            assert abs(rew[i] - r) < 0.02 * (t + 1), (t, i, rew[i], r)
+
+
 def test_step_invariants_full_size(dev):
     """BASELINE size (4096 envs): finite outputs, quaternion norms, loop closure, reward range, auto-reset bookkeeping."""
     from apex_amd.vecenv import CassieVecEnv

@@ -26,6 +26,12 @@ def test_g7_clock_reward(golden_dir):
         r = e.clock_reward_eval(g[p + "qpos"], g[p + "qvel"], g[p + "scal"], g[p + "foot_vel"], g[p + "rotvel"], g[p + "tacc"],
                                 g[p + "torque"], g[p + "prev_torque"], g[p + "prev_action"], g[p + "action"])
         assert abs(r - float(g[p + "reward"])) < 1e-12, (c, r, float(g[p + "reward"]))
+    e1 = S.OracleEnv(reward_kind=1)             # early_clock_reward (clock_rewards.py:119-223)
+    for c in range(int(g["n_cases"])):
+        p = f"c{c}_"
+        r = e1.clock_reward_eval(g[p + "qpos"], g[p + "qvel"], g[p + "scal"], g[p + "foot_vel"], g[p + "rotvel"], g[p + "tacc"],
+                                 g[p + "torque"], g[p + "prev_torque"], g[p + "prev_action"], g[p + "action"])
+        assert abs(r - float(g[p + "reward_early"])) < 1e-12, (c, r)
 
 
 def test_g8_full_state(golden_dir):
