@@ -32,20 +32,6 @@ def discounted_returns(rewards, lens, last_vals, gamma):
     return out
 
 
-def returns_scan_grid(rew, val, done, last_val, gamma):
-    """Same recurrence laid out the way the batched engine stores a rollout: [T, N] grids, env-per-column.
-
-    Episode boundaries inside a column are marked by done[t, n] (terminal at t: bootstrap 0) or by
-    trunc semantics handled by the caller through `boot[t, n]` = value to bootstrap from when an episode is cut
-    at t without termination (ppo.py:183-184: last_val = (not done) * critic(state_after)).
-    Here: last_val[n] is V(s_T) for the still-running episode at the end of the grid; done[t,n] in {0,1,2}:
-    0 running, 1 terminated (bootstrap 0), 2 truncated at max_traj_len (bootstrap val_next[t,n] given in `val`
-    convention: caller passes boot values through rew-side channel, see apex_amd.ppo).  Kept minimal: the grid
-    oracle used by tests takes an explicit boot array instead.
-    """
-    raise NotImplementedError("use returns_scan_grid_boot")
-
-
 def returns_scan_grid_boot(rew, end, boot, last_val, gamma):
     """[T,N] layout.  end[t,n] != 0 marks the last step of an episode; boot[t,n] is the bootstrap value used there
     ((not done)*V(s_{t+1}), ppo.py:183-184).  Column tail uses last_val[n].  fp64 like finish_path."""

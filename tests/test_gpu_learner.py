@@ -53,6 +53,17 @@ def test_returns_scan_golden_g1(dev, golden_dir):
             np.testing.assert_allclose(got[:Ln, n], g[f"c{c}_returns"][off:off + Ln], rtol=1e-5, atol=1e-6); off += Ln
 
 
+def test_returns_scan_golden_g15a(dev, golden_dir):
+    """Returns of the reference's own PPO.sample run (toy env) through the HIP scan: <= 1e-5 relative."""
+    from apex_amd import engine
+    from tests.test_oracle_learner import _g15a_grid
+    g = np.load(os.path.join(golden_dir, "g15a_ppo_sample.npz"))
+    rew, end, boot = _g15a_grid(g)
+    got = engine.returns_scan(torch.tensor(rew, dtype=torch.float32, device=dev), torch.tensor(end, device=dev),
+                              torch.tensor(boot, dtype=torch.float32, device=dev), torch.zeros(1, device=dev), float(g["gamma"]))
+    np.testing.assert_allclose(got.cpu().numpy()[:, 0], g["returns"], rtol=1e-5, atol=1e-6)
+
+
 def test_adv_norm_golden_g2(dev, golden_dir):
     from apex_amd import engine
     g = np.load(os.path.join(golden_dir, "g2_adv_norm.npz"))

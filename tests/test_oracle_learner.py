@@ -95,3 +95,28 @@ def test_g4_update_policy(golden_dir):
         for k, w in zip(CRITIC_KEYS, critic):
             bad = np.abs(w - g[p + "critic1." + k]) > 2e-6
             assert bad.mean() < 1e-3, (c, k, bad.mean())
+
+
+def _g15a_grid(g):
+    idx = g["traj_idx"]; T = int(idx[-1])
+    rew = g["rewards"].reshape(T, 1); end = np.zeros((T, 1), np.uint8); boot = np.zeros((T, 1))
+    for k, e in enumerate(idx[1:]):
+        end[e - 1, 0] = 1; boot[e - 1, 0] = g["last_vals"][k]
+    return rew, end, boot
+
+
+def test_g15a_ppo_sample_control_flow(golden_dir):
+    """The reference's own PPO.sample on a scripted toy env: episode boundaries bit-exact, truncation at max_traj_len
+    bootstraps with V(s_T), termination with 0, returns reproduced by the grid scan."""
+    g = np.load(os.path.join(golden_dir, "g15a_ppo_sample.npz"))
+    lens = np.diff(g["traj_idx"])
+    want = [min(int(L), int(g["max_traj_len"])) for L in g["scripted_lens"]]
+    assert list(lens) == [want[k % len(want)] for k in range(len(lens))]                    # bit-exact episode-step indices
+    assert list(lens) == list(g["ep_lens"])
+    truncated = np.array([g["scripted_lens"][k % 8] > g["max_traj_len"] for k in range(len(lens))])
+    assert ((np.abs(g["last_vals"]) > 0) == truncated).all()                                # (not done) * V(s_T), ppo.py:183-184
+    rew, end, boot = _g15a_grid(g)
+    ret = L.returns_scan_grid_boot(rew, end, boot, np.zeros(1), float(g["gamma"]))
+    np.testing.assert_allclose(ret[:, 0], g["returns"], rtol=1e-6, atol=1e-7)
+    for k in range(len(lens)):
+        np.testing.assert_allclose(g["ep_returns"][k], g["rewards"][g["traj_idx"][k]:g["traj_idx"][k + 1]].sum(), rtol=1e-12)
