@@ -125,6 +125,9 @@ __device__ __forceinline__ Acc visit(const St& S, const QP& qp, const Node& par,
         acc.crb = c;
         if constexpr (!QPOS0) acc.frc = imul(c, me.acc) + crossForce(me.vel, imul(c, me.vel));
     }
+    // mj_setConst pass: world COM of the bodies that carry constraints (slot layout = cslot: achilles, heel-spring,
+    // plantar-rod, foot, tarsus, shin), 3 floats each, 18 per leg
+    if constexpr (QPOS0 && cslot(B) >= 0) stv3<WK_PTS + 30 * (B >= 14 ? 1 : 0) + 3 * cslot(B)>(S, me.pos + mul(me.mat, cv3<B>(ct_body_ipos)));
     // points the constraints need, sensors
     if constexpr (!QPOS0) {
         constexpr int leg = B >= 14 ? 1 : 0, lb = B - 12 * leg, base = WK_PTS + 30 * leg;
@@ -597,6 +600,55 @@ __device__ __forceinline__ void stage_finish(const St& S, const Lds& L, bool do_
             }
             q = qnormalize(q);
             S(F_QPOS + qa) = q.w; S(F_QPOS + qa + 1) = q.x; S(F_QPOS + qa + 2) = q.y; S(F_QPOS + qa + 3) = q.z;
+        }
+    });
+}
+
+// ---------------------------------------------------------------------------------------------- mj_setConst subset
+// body_invweight0 (translational part) of the constraint bodies and dof_invweight0 of the limited joints, at qpos0, from
+// the whitened rows: |y~|^2 = J M^-1 J^T.  Runs at every reset with dynamics randomisation (cassie.py:634-660).
+__device__ __forceinline__ void setconst_tree(const St& S) {
+    SV pc[14];
+    Node world{};
+    const V3 o = {ct_qpos0[0], ct_qpos0[1], ct_qpos0[2]};
+    (void)visit<true, 1>(S, [&](int i) { return ct_qpos0[i]; }, world, o, pc);
+}
+__device__ __forceinline__ void setconst_factor(const St& S) {
+    float LD[NM], dsq[NV], disq[NV];
+    sfor<0, NM>([&](auto I) { LD[I] = S.W(WK_M + I); });
+    factor<true>(LD, dsq, disq);
+    sfor<0, NV>([&](auto D) { S.W(WK_DISQ + D) = disq[D]; });
+    sfor<0, NM>([&](auto I) { S.W(WK_LD + I) = LD[I]; });
+    S(F_BIW) = 0.f;
+}
+template <int LEG>
+__device__ __forceinline__ void setconst_leg(const St& S) {
+    LegLD<LEG> lf;
+    load_leg_factor<LEG>(S, lf);
+    const V3 o = {ct_qpos0[0], ct_qpos0[1], ct_qpos0[2]};
+    sfor<0, 6>([&](auto Sl) {
+        constexpr int b = cbody<LEG>(Sl);
+        const V3 c = ldv3<WK_PTS + 30 * LEG + 3 * Sl>(S);
+        float J[3][19];
+        sfor<0, 19>([&](auto K) { J[0][K] = 0.f; J[1][K] = 0.f; J[2][K] = 0.f; });
+        jac_point3<b>(S, c - o, 1.f, J[0], J[1], J[2]);
+        float tr = 0.f;
+        sfor<0, 3>([&](auto A) { whiten3<LEG, SetALL>(lf, J[A]); sfor<0, 19>([&](auto K) { tr += J[A][K] * J[A][K]; }); });
+        S(F_BIW + b) = tr * (1.f / 3.f);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    sfor<0, NJ>([&](auto Jn) {
+        constexpr int j = Jn;
+        if constexpr (ct_jnt_limited[j] && ((ct_jnt_body[j] >= 14) == (LEG == 1)) && ct_jnt_body[j] >= 2) {
+            constexpr int d = ct_jnt_dofadr[j];
+            float Jl[19];
+            sfor<0, 19>([&](auto K) { Jl[K] = 0.f; });
+            Jl[d2c(d)] = 1.f;
+            whiten3<LEG, SetALL>(lf, Jl);
+            float s2 = 0.f;
+            sfor<0, 19>([&](auto K) { s2 += Jl[K] * Jl[K]; });
+            S(F_DIW + d) = s2;
+            __builtin_amdgcn_sched_barrier(0);
         }
     });
 }

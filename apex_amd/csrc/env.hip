@@ -9,61 +9,25 @@
 // state read + write (2 * F_TOTAL * 4 B ~ 4.7 KB) + action/obs/reward I/O (246 B): the kernel is VALU/LDS bound
 // (DESIGN.md §6), not HBM bound.
 #include "apx_common.h"
-#include "cassie_dev.h"
+#include "cassie_model_gen.h"
 #include "cassie_step3.h"
 
 extern __shared__ __attribute__((aligned(16))) float4 apx_lds4[];   // dynamic LDS: the constraint-row store
 #include <new>
 #include <cstring>
 
-using namespace cas;
+using namespace cmt;
+using c2::V3; using c2::Q4; using c2::M3; using c2::qmul; using c2::q2m; using c2::col; using c2::cross; using c2::dot; using c2::mul;
+constexpr int NQ = CM_NQ, NV = CM_NV, NB = CM_NBODY;
+constexpr float GRAV = 9.81f;
 
 #include "env_state.h"
 
 // ------------------------------------------------------------------------------------------------ forward dynamics
-__device__ __forceinline__ void load_dyn(const St& S, Dyn& dy) {
-    for (int b = 0; b < NB; ++b) { dy.mass[b] = S(F_MASS + b); dy.biw[b] = S(F_BIW + b); }
-    for (int d = 0; d < NV; ++d) { dy.damping[d] = S(F_DAMP + d); dy.diw[d] = S(F_DIW + d); }
-    dy.friction = S(F_FRIC);
-    dy.fn = {S(F_FLOOR), S(F_FLOOR + 1), S(F_FLOOR + 2)};
-    dy.ft1 = {S(F_FLOOR + 3), S(F_FLOOR + 4), S(F_FLOOR + 5)};
-    dy.ft2 = {S(F_FLOOR + 6), S(F_FLOOR + 7), S(F_FLOOR + 8)};
-}
-
-// mj_setConst subset at qpos0: translational body_invweight0 for the bodies that carry constraints and
-// dof_invweight0 for the limited joints, from the whitened rows (|y~|^2 = J M^-1 J^T)
-__device__ void set_const(const St& S, Dyn& dy, Work& w) {
-    kin_crba([&](int i) { return cm_qpos0[i]; }, dy, w);
-    crba(w);
-    for (int i = 0; i < NM; ++i) w.LD[i] = w.M[i];
-    factor(w.LD, w.dsqrt, w.disqrt);
-    for (int b = 1; b < NB; ++b) {
-        const int leg = b >= 14 ? 1 : 0;
-        float J[3][YW];
-        for (int k = 0; k < YW; ++k) J[0][k] = J[1][k] = J[2][k] = 0.f;
-        jac_point(w, b, w.xpos[b] + mul(w.xmat[b], ld3(cm_body_ipos + 3 * b)), 1.f, J[0], J[1], J[2]);
-        float tr = 0.f;
-        for (int a = 0; a < 3; ++a) {
-            whiten_row(w, J[a], leg);
-            for (int k = 0; k < YW; ++k) tr += J[a][k] * J[a][k];
-        }
-        dy.biw[b] = tr * (1.f / 3.f);
-        S(F_BIW + b) = dy.biw[b];
-    }
-    dy.biw[0] = 0.f; S(F_BIW) = 0.f;
-    for (int j = 0; j < NJ; ++j) {
-        const int d = cm_jnt_dofadr[j];
-        if (!cm_jnt_limited[j]) { const int nd = cm_jnt_type[j] == 2 ? 3 : 1; for (int k = 0; k < nd; ++k) { dy.diw[d + k] = 0.f; S(F_DIW + d + k) = 0.f; } continue; }
-        const int leg = d >= 19 ? 1 : 0;
-        float J[YW];
-        for (int k = 0; k < YW; ++k) J[k] = 0.f;
-        J[dof2col(d)] = 1.f;
-        whiten_row(w, J, leg);
-        float s = 0.f;
-        for (int k = 0; k < YW; ++k) s += J[k] * J[k];
-        dy.diw[d] = s; S(F_DIW + d) = s;
-    }
-}
+// mj_setConst subset (cassie_step3.h), staged like the substep
+__device__ __noinline__ void setconst_a(St S) { c3::setconst_tree(S); c3::setconst_factor(S); }
+template <int LEG> __device__ __noinline__ void setconst_b(St S) { c3::setconst_leg<LEG>(S); }
+__device__ __forceinline__ void set_const(const St& S) { setconst_a(S); setconst_b<0>(S); setconst_b<1>(S); }
 
 // ------------------------------------------------------------------------------------------------ native substep model
 __constant__ float kP[5] = {100.f, 100.f, 88.f, 96.f, 50.f};
@@ -331,7 +295,7 @@ __device__ void env_reset(const St& S, const Cfg& cfg) {
         for (int k = 0; k < 9; ++k) S(F_FLOOR + k) = fl[k];
         for (int u = 0; u < 10; ++u) S(F_MNOISE + u) = r.uniform(-0.01f, 0.01f);
         for (int k = 0; k < 6; ++k) S(F_JNOISE + k) = r.uniform(-0.01f, 0.01f);
-        { Dyn dy; Work w; load_dyn(S, dy); set_const(S, dy, w); }
+        set_const(S);
     }
     for (int i = 0; i < NQ; ++i) S(F_QPOS + i) = cm_init_qpos[i];
     for (int i = 0; i < NV; ++i) { S(F_QVEL + i) = 0.f; S(F_QACCW + i) = 0.f; }
@@ -407,9 +371,7 @@ __global__ __launch_bounds__(64) void env_setconst_kernel(float* st, int* ist, f
     const int env = blockIdx.x * 64 + threadIdx.x;
     if (env >= n) return;
     const St S = make_st(st, ist, n, env, wk);
-    Dyn dy; Work w;
-    load_dyn(S, dy);
-    set_const(S, dy, w);
+    set_const(S);
 }
 
 // CassieEnv.reset for the envs selected by mask (NULL = all); a separate launch so that the step kernel's register
