@@ -78,7 +78,7 @@ template <int K> constexpr V3 cv3(const float* p) { return V3{p[3 * K], p[3 * K 
 constexpr int CH_EQ = 0;          // 12 equality rows x 5 chunks  [16 cols | b R invA f]
 constexpr int CH_LIM = 60;        // 2 limit slots x 6 chunks     [19 cols + pad | b R invA f]
 constexpr int CH_CON = 72;        // 6 contact slots x 14 chunks  [n,t1,t2: 3 x 13 cols + pad | G6 R mu | b4 | f4 | invA4]
-constexpr int CH_TOTAL = 156;     // 159,744 B of the CU's 163,840 (one wave per CU)
+constexpr int CH_TOTAL = 158;     // 161,792 B of the CU's 163,840 (156 row chunks + 2 hand-off chunks; one workgroup per CU)
 struct Lds {
     float4* base;   // already offset by lane
     __device__ __forceinline__ float4 rd(int c) const { return base[c * 64]; }

@@ -30,9 +30,11 @@ __device__ unsigned long long g_prof_last;
 // workspace column layout (floats per env)
 constexpr int WK_M = 0, WK_CDOF = WK_M + NM, WK_SMOOTH = WK_CDOF + 6 * NV, WK_QS = WK_SMOOTH + NV, WK_PTS = WK_QS + NV,
               WK_PEL = WK_PTS + 60, WK_LD = WK_PEL + 24, WK_DISQ = WK_LD + NM, WK_ZT = WK_DISQ + NV, WK_QACC = WK_ZT + NV,
-              WK_MISC = WK_QACC + NV /* ncon0 ncon1 nlim0 nlim1 footmask */, WK_TOTAL = WK_MISC + 8;
+              WK_MISC = WK_QACC + NV /* ncon0 ncon1 nlim0 nlim1 footmaskL footmaskR costL costR */, WK_ZP2 = WK_MISC + 8 /* z~ pelvis warm-start parts L, R */,
+              WK_TOTAL = WK_ZP2 + 12;
 // WK_PTS per leg (30): eq0 p1,p2 | eq1 p1,p2 | capsule ends: foot e0,e1, tarsus e0,e1, shin e0,e1
 
+constexpr int MAXC = 2;      // contacts kept per leg per step (oracle: MAXCON_LEG); LDS keeps 3 slots per leg for layout stability
 struct Node { V3 pos; Q4 quat; M3 mat; SV vel, acc; };
 struct Acc { SI crb; SV frc; };
 
@@ -306,18 +308,18 @@ __device__ __forceinline__ void build_rows3(const St& S, Fw3& w, const Lds& L, c
     // body masked out (tarsus contact: no foot dof; shin contact: no tarsus / foot dof).
     const V3 p0 = {ct_floor_pos[0], ct_floor_pos[1], ct_floor_pos[2]};
     int nc = 0;
-    V3 cpt[3]; float cdist[3]; int cgeo[3];
+    V3 cpt[MAXC]; float cdist[MAXC]; int cgeo[MAXC];
     sfor<0, 6>([&](auto I) {
         constexpr int G = I / 2;
         const V3 ctr = ldv3<base + 12 + 3 * I>(S);
         const float dist = dot(ctr - p0, dy.fn) - ct_geom_radius[2 * G + LEG];
-        const bool hit = dist < 0.f && nc < 3;
+        const bool hit = dist < 0.f && nc < MAXC;
         const V3 cp = ctr - dy.fn * (ct_geom_radius[2 * G + LEG] + 0.5f * dist);
-        sfor<0, 3>([&](auto Sl) { if (hit && nc == Sl) { cpt[Sl] = cp; cdist[Sl] = dist; cgeo[Sl] = G; } });
+        sfor<0, MAXC>([&](auto Sl) { if (hit && nc == Sl) { cpt[Sl] = cp; cdist[Sl] = dist; cgeo[Sl] = G; } });
         nc += hit ? 1 : 0;
     });
     w.ncon[LEG] = nc;
-    sfor<0, 3>([&](auto Sl) {
+    sfor<0, MAXC>([&](auto Sl) {
         constexpr int s = Sl, slot = 3 * LEG + s;
         if (s < nc) {
             const int G = cgeo[s];
@@ -411,7 +413,7 @@ __device__ __forceinline__ void pgs_leg3(Fw3& w, const Lds& L, float mu) {
         sfor<0, 19>([&](auto I) { w.zt[c2d<LEG>(I)] += y[I] * df; });
         L.wr(ch + 5, make_float4(m.x, m.y, m.z, fn));
     }
-    sfor<0, 3>([&](auto Sl) {
+    sfor<0, MAXC>([&](auto Sl) {
         constexpr int s = Sl;
         if (s >= w.ncon[LEG]) return;
         constexpr int ch = CH_CON + 14 * (3 * LEG + s);
@@ -448,7 +450,7 @@ template <int LEG>
 __device__ __forceinline__ void zero_forces3(const Fw3& w, const Lds& L) {
     sfor<0, 6>([&](auto Rw) { constexpr int ch = CH_EQ + 5 * (LEG * 6 + Rw) + 4; float4 m = L.rd(ch); m.w = 0.f; L.wr(ch, m); });
     if (w.nlim[LEG]) { constexpr int ch = CH_LIM + 6 * LEG + 5; float4 m = L.rd(ch); m.w = 0.f; L.wr(ch, m); }
-    sfor<0, 3>([&](auto Sl) { if (Sl < w.ncon[LEG]) L.wr(CH_CON + 14 * (3 * LEG + Sl) + 13, make_float4(0.f, 0.f, 0.f, 0.f)); });
+    sfor<0, MAXC>([&](auto Sl) { if (Sl < w.ncon[LEG]) L.wr(CH_CON + 14 * (3 * LEG + Sl) + 13, make_float4(0.f, 0.f, 0.f, 0.f)); });
 }
 
 // ---------------------------------------------------------------------------------------------- the substep, staged
@@ -478,9 +480,8 @@ __device__ __forceinline__ void stage_factor(const St& S) {
     solve_LT(LD, x);
     sfor<0, NV>([&](auto D) { x[D] *= disq[D] * disq[D]; });
     solve_L(LD, x);
-    sfor<0, NV>([&](auto D) { S.W(WK_QS + D) = x[D]; S.W(WK_DISQ + D) = disq[D]; S.W(WK_ZT + D) = 0.f; });
+    sfor<0, NV>([&](auto D) { S.W(WK_QS + D) = x[D]; S.W(WK_DISQ + D) = disq[D]; });
     sfor<0, NM>([&](auto I) { S.W(WK_LD + I) = LD[I]; });
-    S.W(WK_MISC + 4) = 0.f; S.W(WK_MISC + 5) = 0.f;      // footmask, warm-start cost
 }
 
 // stage C: constraint rows of one leg (whitened into LDS) + warm start contributions; z~ / cost accumulate in the workspace
@@ -497,14 +498,18 @@ __device__ __forceinline__ void stage_rows_leg(const St& S, const Lds& L) {
     w.footmask = 0u;
     float cost = 0.f;
     build_rows3<LEG>(S, w, L, dy, o, cost);
-    sfor<0, 19>([&](auto C) { constexpr int d = c2d<LEG>(C); S.W(WK_ZT + d) += w.zt[d]; });
+    // the two legs may run concurrently on two waves: each writes its own slots, stage_warm_check sums them
+    sfor<0, 6>([&](auto C) { S.W(WK_ZP2 + 6 * LEG + C) = w.zt[C]; });
+    sfor<6, 19>([&](auto C) { constexpr int d = c2d<LEG>(C); S.W(WK_ZT + d) = w.zt[d]; });
     S.W(WK_MISC + LEG) = (float)w.ncon[LEG]; S.W(WK_MISC + 2 + LEG) = (float)w.nlim[LEG];
-    S.W(WK_MISC + 4) += (float)w.footmask; S.W(WK_MISC + 5) += cost;
+    S.W(WK_MISC + 4 + LEG) = (float)w.footmask; S.W(WK_MISC + 6 + LEG) = cost;
 }
 
 // warm start loses to f = 0 (mj_fwdConstraint) when its dual cost is positive
 __device__ __forceinline__ void stage_warm_check(const St& S, const Lds& L) {
-    float cost = S.W(WK_MISC + 5);
+    float cost = S.W(WK_MISC + 6) + S.W(WK_MISC + 7);
+    sfor<0, 6>([&](auto C) { S.W(WK_ZT + C) = S.W(WK_ZP2 + C) + S.W(WK_ZP2 + 6 + C); });
+    S.W(WK_MISC + 4) = (float)((unsigned)S.W(WK_MISC + 4) | (unsigned)S.W(WK_MISC + 5));     // merged foot mask
     sfor<0, NV>([&](auto D) { const float z = S.W(WK_ZT + D); cost += 0.5f * z * z; });
     if (cost > 0.f) {
         Fw3 w;
@@ -534,6 +539,106 @@ __device__ __forceinline__ void stage_pgs(const St& S, const Lds& L, int pgs_ite
         pgs_leg3<1>(w, Ls, mu);
     }
     sfor<0, NV>([&](auto D) { S.W(WK_ZT + D) = w.zt[D]; });
+}
+
+// stage D, dual-wave form: the workgroup has two waves working on the SAME 64 envs; wave LEG owns the rows of leg LEG and
+// keeps them in registers for all sweeps (no LDS re-reads).  Gauss-Seidel order is unchanged (left rows, then right rows):
+// the waves alternate, handing the 6 pelvis components of z~ over through LDS at a workgroup barrier.
+constexpr int CH_X = 156;        // 2 chunks: z~ pelvis hand-off
+template <int LEG>
+__device__ __forceinline__ void stage_pgs_wave(const St& S, const Lds& L, int pgs_iters) {
+    float z[19];                 // z~ in local columns: pelvis 6 | own leg 13
+    sfor<0, 19>([&](auto C) { z[C] = S.W(WK_ZT + c2d<LEG>(C)); });
+    const int ncon = (int)S.W(WK_MISC + LEG), nlim = (int)S.W(WK_MISC + 2 + LEG);
+    const float mu = S(F_FRIC);
+    // ---- rows -> registers
+    float y[6][16], eb[6], eR[6], eiA[6], ef[6];
+    sfor<0, 6>([&](auto Rw) {
+        constexpr int ch = CH_EQ + 5 * (LEG * 6 + Rw);
+        sfor<0, 4>([&](auto C) { const float4 v = L.rd(ch + C); y[Rw][4 * C] = v.x; y[Rw][4 * C + 1] = v.y; y[Rw][4 * C + 2] = v.z; y[Rw][4 * C + 3] = v.w; });
+        const float4 m = L.rd(ch + 4);
+        eb[Rw] = m.x; eR[Rw] = m.y; eiA[Rw] = m.z; ef[Rw] = m.w;
+    });
+    float cv[MAXC][40], cG[MAXC][6], cR[MAXC], cb[MAXC][4], cf[MAXC][4], ciA[MAXC][4];
+    sfor<0, MAXC>([&](auto Sl) {
+        constexpr int ch = CH_CON + 14 * (3 * LEG + Sl);
+        if (Sl < ncon) {
+            sfor<0, 10>([&](auto C) { const float4 q = L.rd(ch + C); cv[Sl][4 * C] = q.x; cv[Sl][4 * C + 1] = q.y; cv[Sl][4 * C + 2] = q.z; cv[Sl][4 * C + 3] = q.w; });
+            const float4 g0 = L.rd(ch + 10), g1 = L.rd(ch + 11), bb = L.rd(ch + 12), ff = L.rd(ch + 13);
+            cG[Sl][0] = g0.x; cG[Sl][1] = g0.y; cG[Sl][2] = g0.z; cG[Sl][3] = g0.w; cG[Sl][4] = g1.x; cG[Sl][5] = g1.y; cR[Sl] = g1.z;
+            cb[Sl][0] = bb.x; cb[Sl][1] = bb.y; cb[Sl][2] = bb.z; cb[Sl][3] = bb.w;
+            cf[Sl][0] = ff.x; cf[Sl][1] = ff.y; cf[Sl][2] = ff.z; cf[Sl][3] = ff.w;
+            sfor<0, 4>([&](auto K) {      // A_kk + R of the pyramid rows n + s mu t_j is sweep-invariant
+                constexpr int k = K;
+                const float sm = ((k & 1) ? -mu : mu), gnj = k < 2 ? cG[Sl][1] : cG[Sl][2], gjj = k < 2 ? cG[Sl][3] : cG[Sl][5];
+                ciA[Sl][k] = __frcp_rn(cG[Sl][0] + 2.f * sm * gnj + mu * mu * gjj + cR[Sl]);
+            });
+        }
+    });
+    for (int it = 0; it < pgs_iters; ++it) {
+        if (LEG == 1) {          // wait for the left sweep, take over z~ pelvis
+            __syncthreads();
+            const float4 a = L.rd(CH_X), b = L.rd(CH_X + 1);
+            z[0] = a.x; z[1] = a.y; z[2] = a.z; z[3] = a.w; z[4] = b.x; z[5] = b.y;
+        }
+        // equalities: 6 bilateral rows
+        sfor<0, 6>([&](auto Rw) {
+            float r4[4] = {eb[Rw] + eR[Rw] * ef[Rw], 0.f, 0.f, 0.f};
+            sfor<0, 16>([&](auto I) { constexpr int i = I, c = Rw < 3 ? SetPL::c[i] : SetAC::c[i]; if constexpr (c >= 0) r4[i & 3] += y[Rw][i] * z[c]; });
+            const float df = -((r4[0] + r4[1]) + (r4[2] + r4[3])) * eiA[Rw];
+            sfor<0, 16>([&](auto I) { constexpr int i = I, c = Rw < 3 ? SetPL::c[i] : SetAC::c[i]; if constexpr (c >= 0) z[c] += y[Rw][i] * df; });
+            ef[Rw] += df;
+        });
+        if (nlim) {              // rare: the limit row streams from LDS
+            constexpr int ch = CH_LIM + 6 * LEG;
+            float yl[20];
+            sfor<0, 5>([&](auto C) { const float4 v = L.rd(ch + C); yl[4 * C] = v.x; yl[4 * C + 1] = v.y; yl[4 * C + 2] = v.z; yl[4 * C + 3] = v.w; });
+            const float4 m = L.rd(ch + 5);
+            float res = m.x + m.y * m.w;
+            sfor<0, 19>([&](auto I) { res += yl[I] * z[I]; });
+            float fn = m.w - res * m.z;
+            fn = fn < 0.f ? 0.f : fn;
+            const float df = fn - m.w;
+            sfor<0, 19>([&](auto I) { z[I] += yl[I] * df; });
+            L.wr(ch + 5, make_float4(m.x, m.y, m.z, fn));
+        }
+        // contacts: 4 pyramid rows each, swept through running basis residuals (rn, r1, r2) = (n, t1, t2) . z~
+        sfor<0, MAXC>([&](auto Sl) {
+            if (Sl < ncon) {
+                float rn2[2] = {0.f, 0.f}, r12[2] = {0.f, 0.f}, r22[2] = {0.f, 0.f};
+                sfor<0, 13>([&](auto I) { constexpr int c = SetFT::c[I]; rn2[I & 1] += cv[Sl][I] * z[c]; r12[I & 1] += cv[Sl][13 + I] * z[c]; r22[I & 1] += cv[Sl][26 + I] * z[c]; });
+                float rn = rn2[0] + rn2[1], r1 = r12[0] + r12[1], r2 = r22[0] + r22[1];
+                const float gnn = cG[Sl][0], gn1 = cG[Sl][1], gn2 = cG[Sl][2], g11 = cG[Sl][3], g12 = cG[Sl][4], g22 = cG[Sl][5];
+                float sdn = 0.f, sd1 = 0.f, sd2 = 0.f;
+                sfor<0, 4>([&](auto K) {
+                    constexpr int k = K;
+                    const float sm = (k & 1) ? -mu : mu;
+                    const float res = cb[Sl][k] + cR[Sl] * cf[Sl][k] + rn + sm * (k < 2 ? r1 : r2);
+                    float fn = cf[Sl][k] - res * ciA[Sl][k];
+                    fn = fn < 0.f ? 0.f : fn;
+                    const float df = fn - cf[Sl][k];
+                    cf[Sl][k] = fn;
+                    // y_k = n + sm t_j moves the basis residuals by df * (G n-col + sm G j-col)
+                    if constexpr (k < 2) { rn += df * (gnn + sm * gn1); r1 += df * (gn1 + sm * g11); r2 += df * (gn2 + sm * g12); sd1 += sm * df; }
+                    else { rn += df * (gnn + sm * gn2); r1 += df * (gn1 + sm * g12); r2 += df * (gn2 + sm * g22); sd2 += sm * df; }
+                    sdn += df;
+                });
+                sfor<0, 13>([&](auto I) { constexpr int c = SetFT::c[I]; z[c] += cv[Sl][I] * sdn + cv[Sl][13 + I] * sd1 + cv[Sl][26 + I] * sd2; });
+            }
+        });
+        // hand z~ pelvis to the other wave
+        L.wr(CH_X, make_float4(z[0], z[1], z[2], z[3])); L.wr(CH_X + 1, make_float4(z[4], z[5], 0.f, 0.f));
+        __syncthreads();
+        if (LEG == 0) {          // wait for the right sweep
+            __syncthreads();
+            const float4 a = L.rd(CH_X), b = L.rd(CH_X + 1);
+            z[0] = a.x; z[1] = a.y; z[2] = a.z; z[3] = a.w; z[4] = b.x; z[5] = b.y;
+        }
+    }
+    // results: forces back to LDS (foot-force readout), z~ to the workspace (pelvis part: both waves hold the final value)
+    sfor<0, 6>([&](auto Rw) { L.wr(CH_EQ + 5 * (LEG * 6 + Rw) + 4, make_float4(eb[Rw], eR[Rw], eiA[Rw], ef[Rw])); });
+    sfor<0, MAXC>([&](auto Sl) { if (Sl < ncon) L.wr(CH_CON + 14 * (3 * LEG + Sl) + 13, make_float4(cf[Sl][0], cf[Sl][1], cf[Sl][2], cf[Sl][3])); });
+    sfor<0, 19>([&](auto C) { if (LEG == 1 || C >= 6) S.W(WK_ZT + c2d<LEG>(C)) = z[C]; });
 }
 
 // stage E: qacc, foot force, IMU; then (do_euler) mj_Euler with implicit joint damping:

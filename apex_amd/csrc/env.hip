@@ -27,7 +27,7 @@ constexpr float GRAV = 9.81f;
 // mj_setConst subset (cassie_step3.h), staged like the substep
 __device__ __noinline__ void setconst_a(St S) { c3::setconst_tree(S); c3::setconst_factor(S); }
 template <int LEG> __device__ __noinline__ void setconst_b(St S) { c3::setconst_leg<LEG>(S); }
-__device__ __forceinline__ void set_const(const St& S) { setconst_a(S); setconst_b<0>(S); setconst_b<1>(S); }
+__device__ __forceinline__ void set_const_single_wave(const St& S) { setconst_a(S); setconst_b<0>(S); setconst_b<1>(S); }
 
 // ------------------------------------------------------------------------------------------------ native substep model
 __constant__ float kP[5] = {100.f, 100.f, 88.f, 96.f, 50.f};
@@ -138,10 +138,15 @@ __device__ __noinline__ void stage2b_rows(St S) {
     c3::stage_rows_leg<LEG>(S, Y);
     PROF(5 + LEG);
 }
+__device__ __noinline__ void stage3a_warm(St S) {
+    const c2::Lds Y{apx_lds4 + (threadIdx.x & 63)};
+    c3::stage_warm_check(S, Y);
+}
+template <int LEG>
 __device__ __noinline__ void stage3_pgs(St S, int pgs_iters) {
     PROF_START();
     const c2::Lds Y{apx_lds4 + (threadIdx.x & 63)};
-    c3::stage_pgs(S, Y, pgs_iters);
+    c3::stage_pgs_wave<LEG>(S, Y, pgs_iters);
     PROF(3);
 }
 __device__ __noinline__ void stage4_finish(St S, int mode) {
@@ -164,13 +169,21 @@ __device__ __noinline__ void stage4_finish(St S, int mode) {
     S(F_FWD + 0) = fz[0]; S(F_FWD + 1) = fz[1];
     PROF(4);
 }
+// The workgroup is TWO waves over the same 64 envs (lane l of both waves = env l): wave 0 runs the serial stages, the
+// constraint rows of the two legs are built concurrently, and the Gauss-Seidel sweeps alternate between the waves with
+// each wave's rows resident in its registers.  Every call site must be reached by both waves (barriers inside).
 __device__ __forceinline__ void sim_step_pd(const St& S, int pgs_iters, int mode) {
-    stage1_io_tree(S, mode);
-    stage2a_factor(S);
-    stage2b_rows<0>(S);
-    stage2b_rows<1>(S);
-    stage3_pgs(S, pgs_iters);
-    stage4_finish(S, mode);
+    const int wave = threadIdx.x >> 6;
+    if (wave == 0) { stage1_io_tree(S, mode); stage2a_factor(S); }
+    __syncthreads();
+    if (wave == 0) stage2b_rows<0>(S); else stage2b_rows<1>(S);
+    __syncthreads();
+    if (wave == 0) stage3a_warm(S);
+    __syncthreads();
+    if (wave == 0) stage3_pgs<0>(S, pgs_iters); else stage3_pgs<1>(S, pgs_iters);
+    __syncthreads();
+    if (wave == 0) stage4_finish(S, mode);
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------ env logic
@@ -261,7 +274,8 @@ __device__ __forceinline__ void clock_from_speed(const St& S, float speed, int f
 }
 
 // CassieEnv.reset (cassie/cassie.py:523-680)
-__device__ void env_reset(const St& S, const Cfg& cfg) {
+// reset, part 1 (wave 0): command / clock / dynamics-randomisation draws (cassie.py:525-657) and the init pose
+__device__ void env_reset_draws(const St& S, const Cfg& cfg) {
     Rng r{cfg.seed_lo, cfg.seed_hi, cfg.env_base + (unsigned)S.env, (unsigned)S.I(I_RNG)};
     const float speed0 = r.uniform(-0.3f, 4.0f);
     (void)r.uniform(-0.3f, 0.3f);
@@ -295,17 +309,34 @@ __device__ void env_reset(const St& S, const Cfg& cfg) {
         for (int k = 0; k < 9; ++k) S(F_FLOOR + k) = fl[k];
         for (int u = 0; u < 10; ++u) S(F_MNOISE + u) = r.uniform(-0.01f, 0.01f);
         for (int k = 0; k < 6; ++k) S(F_JNOISE + k) = r.uniform(-0.01f, 0.01f);
-        set_const(S);
     }
     for (int i = 0; i < NQ; ++i) S(F_QPOS + i) = cm_init_qpos[i];
     for (int i = 0; i < NV; ++i) { S(F_QVEL + i) = 0.f; S(F_QACCW + i) = 0.f; }
-    sim_step_pd(S, cfg.pgs_iters, 0);               // cassie_sim_set_const ends in mj_forward
-    sim_step_pd(S, cfg.pgs_iters, 1);               // cassie.py:665 (stale pd_in_t)
+    S.I(I_RNG) = (int)r.ctr;
+}
+// reset, part 3 (wave 0): command redraw after the settle step (cassie.py:667-670)
+__device__ void env_reset_finish(const St& S, const Cfg& cfg) {
+    Rng r{cfg.seed_lo, cfg.seed_hi, cfg.env_base + (unsigned)S.env, (unsigned)S.I(I_RNG)};
     for (int k = 0; k < 6; ++k) S(F_FOOTPREV + k) = S(F_FWD + 10 + k);
     S(F_CMD + 2) = 0.f;
     S(F_CMD + 0) = r.uniform(-0.3f, 4.0f);
     S(F_CMD + 1) = r.uniform(-0.3f, 0.3f);
     S.I(I_RNG) = (int)r.ctr;
+}
+// CassieEnv.reset (cassie/cassie.py:523-680); called by BOTH waves of the workgroup
+__device__ __forceinline__ void env_reset(const St& S, const Cfg& cfg) {
+    const int wave = threadIdx.x >> 6;
+    if (wave == 0) env_reset_draws(S, cfg);
+    __syncthreads();
+    if (cfg.dyn_rand) {                               // sim.set_const -> mj_setConst, legs on the two waves
+        if (wave == 0) setconst_a(S);
+        __syncthreads();
+        if (wave == 0) setconst_b<0>(S); else setconst_b<1>(S);
+        __syncthreads();
+    }
+    sim_step_pd(S, cfg.pgs_iters, 0);               // cassie_sim_set_const ends in mj_forward
+    sim_step_pd(S, cfg.pgs_iters, 1);               // cassie.py:665 (stale pd_in_t)
+    if (wave == 0) env_reset_finish(S, cfg);
 }
 
 // clock_reward (cassie/rewards/clock_rewards.py:6-110)
@@ -348,7 +379,7 @@ __device__ float clock_reward(const St& S, const Cfg& cfg, const float* action, 
 
 // ------------------------------------------------------------------------------------------------ kernels
 #define ENV_SETUP                                                                                   \
-    const int lane = threadIdx.x & 63;                                                               \
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;                                      \
     const int env = blockIdx.x * 64 + lane;                                                          \
     if (env >= n) return;                                                                            \
     const St S = make_st(st, ist, n, env, wk);
@@ -371,30 +402,33 @@ __global__ __launch_bounds__(64) void env_setconst_kernel(float* st, int* ist, f
     const int env = blockIdx.x * 64 + threadIdx.x;
     if (env >= n) return;
     const St S = make_st(st, ist, n, env, wk);
-    set_const(S);
+    set_const_single_wave(S);
 }
 
 // CassieEnv.reset for the envs selected by mask (NULL = all); a separate launch so that the step kernel's register
 // allocation is not shaped by the (rare, slower) reset path
-__global__ __launch_bounds__(64) void env_reset_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const uint8_t* mask, float* obs) {
+__global__ __launch_bounds__(128) void env_reset_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const uint8_t* mask, float* obs) {
     ENV_SETUP
     if (mask && !mask[env]) return;
     env_reset(S, cfg);
-    if (obs) write_obs(S, cfg, obs + (size_t)env * APX_OBS_DIM);
+    if (obs && wave == 0) write_obs(S, cfg, obs + (size_t)env * APX_OBS_DIM);
 }
 
-__global__ __launch_bounds__(64) void env_step_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const float* action, float* obs,
+__global__ __launch_bounds__(128) void env_step_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const float* action, float* obs,
                                                        float* reward, uint8_t* done, float* final_obs) {
     ENV_SETUP
     float act[10];
-    for (int u = 0; u < 10; ++u) {
-        act[u] = action[(size_t)env * APX_ACT_DIM + u];
-        S(F_PDT + u) = act[u] + kOffset[u] - (cfg.dyn_rand ? S(F_MNOISE + u) : 0.f);     // cassie.py:295-298
+    if (wave == 0) {
+        for (int u = 0; u < 10; ++u) {
+            act[u] = action[(size_t)env * APX_ACT_DIM + u];
+            S(F_PDT + u) = act[u] + kOffset[u] - (cfg.dyn_rand ? S(F_MNOISE + u) : 0.f);     // cassie.py:295-298
+        }
+        S.I(I_FLAGS) |= 16;
     }
-    S.I(I_FLAGS) |= 16;
     float lfrc = 0.f, rfrc = 0.f, lor = 0.f, ror = 0.f;
     for (int i = 0; i < cfg.simrate; ++i) {
-        sim_step_pd(S, cfg.pgs_iters, 1);
+        sim_step_pd(S, cfg.pgs_iters, 1);                                        // both waves (barriers inside)
+        if (wave != 0) continue;
         for (int k = 0; k < 6; ++k) {                                            // cassie.py:328-331
             const float fp = S(F_FWD + 10 + k);
             S(F_FOOTVEL + k) = (fp - S(F_FOOTPREV + k)) / 0.0005f;
@@ -405,6 +439,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(float* st, int* ist, float
         for (int k = 0; k < 4; ++k) { il += kNeutralFoot[k] * S(F_FWD + 2 + k); ir += kNeutralFoot[k] * S(F_FWD + 6 + k); }
         lor += 1.f - il * il; ror += 1.f - ir * ir;                               // cassie.py:426-427
     }
+    if (wave != 0) return;
     const float inv = 1.f / (float)cfg.simrate;
     lfrc *= inv; rfrc *= inv; lor *= inv; ror *= inv;
     const float height = S(F_QPOS + 2);
@@ -433,7 +468,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(float* st, int* ist, float
 }
 
 // raw substeps with the current pd targets (tests): n_sub x cassie_sim_step_pd
-__global__ __launch_bounds__(64) void env_substep_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, int n_sub) {
+__global__ __launch_bounds__(128) void env_substep_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, int n_sub) {
     ENV_SETUP
     for (int i = 0; i < n_sub; ++i) sim_step_pd(S, cfg.pgs_iters, 1);
 }
@@ -489,7 +524,7 @@ extern "C" int apx_env_destroy(apx_env_t* e) {
 
 extern "C" int apx_env_reset(apx_env_t* e, const uint8_t* mask, float* obs_out, void* stream) {
     APX_REQUIRE(e, "env");
-    hipLaunchKernelGGL(env_reset_kernel, dim3(e->n / 64), dim3(64), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+    hipLaunchKernelGGL(env_reset_kernel, dim3(e->n / 64), dim3(128), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
                        make_cfg(e->cfg), mask, obs_out);
     APX_LAUNCH_CHECK();
     return APX_OK;
@@ -498,11 +533,11 @@ extern "C" int apx_env_reset(apx_env_t* e, const uint8_t* mask, float* obs_out, 
 extern "C" int apx_env_step(apx_env_t* e, const float* action, float* obs, float* reward, uint8_t* done, float* final_obs,
                             int auto_reset, void* stream) {
     APX_REQUIRE(e && action && obs && reward && done, "null pointer");
-    hipLaunchKernelGGL(env_step_kernel, dim3(e->n / 64), dim3(64), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+    hipLaunchKernelGGL(env_step_kernel, dim3(e->n / 64), dim3(128), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
                        make_cfg(e->cfg), action, obs, reward, done, final_obs);
     APX_LAUNCH_CHECK();
     if (auto_reset) {   // finished envs restart in a second launch on the same stream (mask = done flags)
-        hipLaunchKernelGGL(env_reset_kernel, dim3(e->n / 64), dim3(64), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+        hipLaunchKernelGGL(env_reset_kernel, dim3(e->n / 64), dim3(128), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
                            make_cfg(e->cfg), done, obs);
         APX_LAUNCH_CHECK();
     }
@@ -572,7 +607,7 @@ extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, voi
     }
 #endif
     if (!strcmp(name, "substep")) {   // debugging hook: out[0] (host-readable count is not needed) - run one raw substep
-        hipLaunchKernelGGL(env_substep_kernel, dim3(e->n / 64), dim3(64), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(e->cfg), 1);
+        hipLaunchKernelGGL(env_substep_kernel, dim3(e->n / 64), dim3(128), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(e->cfg), 1);
         APX_LAUNCH_CHECK();
         return 0;
     }

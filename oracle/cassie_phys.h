@@ -19,7 +19,7 @@
 namespace orc {
 
 constexpr int NB = CM_NBODY, NV = CM_NV, NQ = CM_NQ, NJ = CM_NJNT, NG = CM_NGEOM, NEQ = CM_NEQ, NU = CM_NU;
-constexpr int MAXCON_LEG = 3, MAXLIM_LEG = 1;      // per-leg caps on contacts / active limit rows per step
+constexpr int MAXCON_LEG = 2, MAXLIM_LEG = 1;      // per-leg caps on contacts / active limit rows per step
 constexpr int MAXCON = 2 * MAXCON_LEG, MAXLIM = 2 * MAXLIM_LEG;
 constexpr int MAXEFC = 3 * NEQ + MAXLIM + 4 * MAXCON;
 constexpr double MINVAL = 1e-15;
