@@ -74,15 +74,23 @@ __device__ __forceinline__ SV imul(const SI& s, SV v) { return {symmul(s.I, v.a)
 template <int K> constexpr V3 cv3(const float* p) { return V3{p[3 * K], p[3 * K + 1], p[3 * K + 2]}; }
 
 // ------------------------------------------------------------------------------------------------ LDS row store
-// float4 chunk c of this lane lives at ((c * 64 + lane) * 16) bytes: every access is one ds_read/write_b128.
+// float4 chunk c of this lane lives at ((c * EPW + lane) * 16) bytes: every access is one ds_read/write_b128.
+// EPW = environments per workgroup = active lanes per wave (launch geometry knob).  Measured on MI355X at 4096 envs:
+// EPW 64 (64 workgroups, one per CU) 12.8 ms per env step, EPW 8 (512 workgroups, 2 per CU) 22.8 ms: the substep is a serial
+// per-env program, so spreading the same lanes over more waves buys nothing and the co-resident workgroups contend for the
+// CU's instruction cache / LDS pipe.  Kept as a knob for large env counts only.
+#ifndef APX_EPW
+#define APX_EPW 64
+#endif
+constexpr int EPW = APX_EPW;
 constexpr int CH_EQ = 0;          // 12 equality rows x 5 chunks  [16 cols | b R invA f]
 constexpr int CH_LIM = 60;        // 2 limit slots x 6 chunks     [19 cols + pad | b R invA f]
 constexpr int CH_CON = 72;        // 6 contact slots x 14 chunks  [n,t1,t2: 3 x 13 cols + pad | G6 R mu | b4 | f4 | invA4]
 constexpr int CH_TOTAL = 158;     // 161,792 B of the CU's 163,840 (156 row chunks + 2 hand-off chunks; one workgroup per CU)
 struct Lds {
     float4* base;   // already offset by lane
-    __device__ __forceinline__ float4 rd(int c) const { return base[c * 64]; }
-    __device__ __forceinline__ void wr(int c, float4 v) const { base[c * 64] = v; }
+    __device__ __forceinline__ float4 rd(int c) const { return base[c * EPW]; }
+    __device__ __forceinline__ void wr(int c, float4 v) const { base[c * EPW] = v; }
 };
 
 // local column (0..18) of a row of leg LEG -> global dof

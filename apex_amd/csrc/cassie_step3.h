@@ -383,8 +383,8 @@ __device__ __forceinline__ void build_rows3(const St& S, Fw3& w, const Lds& L, c
 struct LdsV {       // same store, reads the compiler must re-issue every sweep (streamed, 1 instruction per 4 floats)
     float4* base;
     typedef float f4v __attribute__((ext_vector_type(4)));
-    __device__ __forceinline__ float4 rd(int c) const { const f4v v = *(volatile f4v*)(base + c * 64); return make_float4(v.x, v.y, v.z, v.w); }
-    __device__ __forceinline__ void wr(int c, float4 v) const { base[c * 64] = v; }
+    __device__ __forceinline__ float4 rd(int c) const { const f4v v = *(volatile f4v*)(base + c * EPW); return make_float4(v.x, v.y, v.z, v.w); }
+    __device__ __forceinline__ void wr(int c, float4 v) const { base[c * EPW] = v; }
 };
 template <int LEG>
 __device__ __forceinline__ void pgs_leg3(Fw3& w, const Lds& L, float mu) {

@@ -380,8 +380,8 @@ __device__ float clock_reward(const St& S, const Cfg& cfg, const float* action, 
 // ------------------------------------------------------------------------------------------------ kernels
 #define ENV_SETUP                                                                                   \
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;                                      \
-    const int env = blockIdx.x * 64 + lane;                                                          \
-    if (env >= n) return;                                                                            \
+    const int env = blockIdx.x * c2::EPW + lane;                                                     \
+    if (lane >= c2::EPW || env >= n) return;                                                                            \
     const St S = make_st(st, ist, n, env, wk);
 
 __global__ __launch_bounds__(64) void env_init_kernel(float* st, int* ist, int n, Cfg cfg) {
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(128) void env_substep_kernel(float* st, int* ist, f
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
-static constexpr size_t LDS_BYTES = (size_t)c2::CH_TOTAL * 64 * sizeof(float4);   // 159,744 B of the CU's 163,840
+static constexpr size_t LDS_BYTES = (size_t)c2::CH_TOTAL * c2::EPW * sizeof(float4);   // 161,792 B of the CU's 163,840 at EPW = 64
 
 static Cfg make_cfg(const apx_env_cfg& c) {
     return Cfg{c.simrate, c.dynamics_randomization, c.stance_mode, c.have_incentive, c.max_traj_len, c.pgs_iters,
@@ -524,7 +524,7 @@ extern "C" int apx_env_destroy(apx_env_t* e) {
 
 extern "C" int apx_env_reset(apx_env_t* e, const uint8_t* mask, float* obs_out, void* stream) {
     APX_REQUIRE(e, "env");
-    hipLaunchKernelGGL(env_reset_kernel, dim3(e->n / 64), dim3(128), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+    hipLaunchKernelGGL(env_reset_kernel, dim3(e->n / c2::EPW), dim3(128), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
                        make_cfg(e->cfg), mask, obs_out);
     APX_LAUNCH_CHECK();
     return APX_OK;
@@ -533,11 +533,11 @@ extern "C" int apx_env_reset(apx_env_t* e, const uint8_t* mask, float* obs_out, 
 extern "C" int apx_env_step(apx_env_t* e, const float* action, float* obs, float* reward, uint8_t* done, float* final_obs,
                             int auto_reset, void* stream) {
     APX_REQUIRE(e && action && obs && reward && done, "null pointer");
-    hipLaunchKernelGGL(env_step_kernel, dim3(e->n / 64), dim3(128), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+    hipLaunchKernelGGL(env_step_kernel, dim3(e->n / c2::EPW), dim3(128), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
                        make_cfg(e->cfg), action, obs, reward, done, final_obs);
     APX_LAUNCH_CHECK();
     if (auto_reset) {   // finished envs restart in a second launch on the same stream (mask = done flags)
-        hipLaunchKernelGGL(env_reset_kernel, dim3(e->n / 64), dim3(128), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+        hipLaunchKernelGGL(env_reset_kernel, dim3(e->n / c2::EPW), dim3(128), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
                            make_cfg(e->cfg), done, obs);
         APX_LAUNCH_CHECK();
     }
@@ -607,7 +607,7 @@ extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, voi
     }
 #endif
     if (!strcmp(name, "substep")) {   // debugging hook: out[0] (host-readable count is not needed) - run one raw substep
-        hipLaunchKernelGGL(env_substep_kernel, dim3(e->n / 64), dim3(128), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(e->cfg), 1);
+        hipLaunchKernelGGL(env_substep_kernel, dim3(e->n / c2::EPW), dim3(128), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(e->cfg), 1);
         APX_LAUNCH_CHECK();
         return 0;
     }
