@@ -82,7 +82,11 @@ template <int K> constexpr V3 cv3(const float* p) { return V3{p[3 * K], p[3 * K 
 #ifndef APX_EPW
 #define APX_EPW 64
 #endif
+#if defined(APX_GEN) && APX_GEN == 4
+constexpr int EPW = 1;      // generation 4: the row store of an env is contiguous in its own LDS region
+#else
 constexpr int EPW = APX_EPW;
+#endif
 constexpr int CH_EQ = 0;          // 12 equality rows x 5 chunks  [16 cols | b R invA f]
 constexpr int CH_LIM = 60;        // 2 limit slots x 6 chunks     [19 cols + pad | b R invA f]
 constexpr int CH_CON = 72;        // 6 contact slots x 14 chunks  [n,t1,t2: 3 x 13 cols + pad | G6 R mu | b4 | f4 | invA4]

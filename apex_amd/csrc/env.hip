@@ -11,6 +11,9 @@
 #include "apx_common.h"
 #include "cassie_model_gen.h"
 #include "cassie_step3.h"
+#if defined(APX_GEN) && APX_GEN == 4
+#include "cassie_lane.h"
+#endif
 
 extern __shared__ __attribute__((aligned(16))) float4 apx_lds4[];   // dynamic LDS: the constraint-row store
 #include <new>
@@ -37,6 +40,12 @@ __constant__ float kNeutralFoot[4] = {-0.24790886454547323f, -0.2467971319544564
 __constant__ float kTorqueLimit[5] = {140.63f, 140.63f, 216.16f, 216.16f, 45.14f};
 __constant__ float kFir[9] = {2727.f, 534.f, -2658.f, -795.f, 72.f, 110.f, 19.f, -6.f, -3.f};
 #define PI_F 3.14159265358979323846f
+
+#if APX_GEN == 4
+__device__ __forceinline__ c2::Lds row_store() { return c2::Lds{apx_lds4 + ((threadIdx.x >> 4) * L4_ES + L4_ROWS) / 4}; }
+#else
+__device__ __forceinline__ c2::Lds row_store() { return c2::Lds{apx_lds4 + (threadIdx.x & 63)}; }
+#endif
 
 // ---- the substep as four non-inlined stages (cassie_step3.h): state crosses stages through HBM/L2 and LDS only
 // stage 1: encoders + estimator -> PD -> safeties -> motor model / delay, then the tree walk.
@@ -134,24 +143,32 @@ __device__ __noinline__ void stage2a_factor(St S) {
 template <int LEG>
 __device__ __noinline__ void stage2b_rows(St S) {
     PROF_START();
-    const c2::Lds Y{apx_lds4 + (threadIdx.x & 63)};
+    const c2::Lds Y = row_store();
     c3::stage_rows_leg<LEG>(S, Y);
     PROF(5 + LEG);
 }
 __device__ __noinline__ void stage3a_warm(St S) {
-    const c2::Lds Y{apx_lds4 + (threadIdx.x & 63)};
+    const c2::Lds Y = row_store();
     c3::stage_warm_check(S, Y);
 }
+#if APX_GEN == 4
+__device__ __noinline__ void stage3_pgs_lane(St S, int pgs_iters) {
+    PROF_START();
+    c4::stage_pgs_lane(S, (const float*)(apx_lds4 + ((threadIdx.x >> 4) * L4_ES + L4_ROWS) / 4), pgs_iters);
+    PROF(3);
+}
+#else
 template <int LEG>
 __device__ __noinline__ void stage3_pgs(St S, int pgs_iters) {
     PROF_START();
-    const c2::Lds Y{apx_lds4 + (threadIdx.x & 63)};
+    const c2::Lds Y = row_store();
     c3::stage_pgs_wave<LEG>(S, Y, pgs_iters);
     PROF(3);
 }
+#endif
 __device__ __noinline__ void stage4_finish(St S, int mode) {
     PROF_START();
-    const c2::Lds Y{apx_lds4 + (threadIdx.x & 63)};
+    const c2::Lds Y = row_store();
     float acc[3], fz[2];
     // sensor snapshot of the PRE-integration state (sensordata is one mj_step1 old when step_ethercat reads it)
 #pragma unroll
@@ -169,6 +186,19 @@ __device__ __noinline__ void stage4_finish(St S, int mode) {
     S(F_FWD + 0) = fz[0]; S(F_FWD + 1) = fz[1];
     PROF(4);
 }
+#if APX_GEN == 4
+// Generation 4: the wave holds 4 envs, one per 16-lane row.  Stages not yet converted to the lane-parallel form run on the
+// row's lead lane; every call site is reached by all lanes.
+__device__ __forceinline__ void sim_step_pd(const St& S, int pgs_iters, int mode) {
+    const bool lead = (threadIdx.x & 15) == 0;
+    if (lead) { stage1_io_tree(S, mode); stage2a_factor(S); stage2b_rows<0>(S); stage2b_rows<1>(S); stage3a_warm(S); }
+    __syncthreads();
+    stage3_pgs_lane(S, pgs_iters);
+    __syncthreads();
+    if (lead) stage4_finish(S, mode);
+    __syncthreads();
+}
+#else
 // The workgroup is TWO waves over the same 64 envs (lane l of both waves = env l): wave 0 runs the serial stages, the
 // constraint rows of the two legs are built concurrently, and the Gauss-Seidel sweeps alternate between the waves with
 // each wave's rows resident in its registers.  Every call site must be reached by both waves (barriers inside).
@@ -185,6 +215,8 @@ __device__ __forceinline__ void sim_step_pd(const St& S, int pgs_iters, int mode
     if (wave == 0) stage4_finish(S, mode);
     __syncthreads();
 }
+
+#endif
 
 // ------------------------------------------------------------------------------------------------ env logic
 struct ClockK { float x[8]; float phaselen; };
@@ -323,6 +355,21 @@ __device__ void env_reset_finish(const St& S, const Cfg& cfg) {
     S(F_CMD + 1) = r.uniform(-0.3f, 0.3f);
     S.I(I_RNG) = (int)r.ctr;
 }
+#if APX_GEN == 4
+// CassieEnv.reset (cassie/cassie.py:523-680); called by all 16 lanes of the env's row
+__device__ __forceinline__ void env_reset(const St& S, const Cfg& cfg) {
+    const bool lead = (threadIdx.x & 15) == 0;
+    if (lead) {
+        env_reset_draws(S, cfg);
+        if (cfg.dyn_rand) set_const_single_wave(S);     // sim.set_const -> mj_setConst
+    }
+    __syncthreads();
+    sim_step_pd(S, cfg.pgs_iters, 0);               // cassie_sim_set_const ends in mj_forward
+    sim_step_pd(S, cfg.pgs_iters, 1);               // cassie.py:665 (stale pd_in_t)
+    if (lead) env_reset_finish(S, cfg);
+    __syncthreads();
+}
+#else
 // CassieEnv.reset (cassie/cassie.py:523-680); called by BOTH waves of the workgroup
 __device__ __forceinline__ void env_reset(const St& S, const Cfg& cfg) {
     const int wave = threadIdx.x >> 6;
@@ -338,6 +385,8 @@ __device__ __forceinline__ void env_reset(const St& S, const Cfg& cfg) {
     sim_step_pd(S, cfg.pgs_iters, 1);               // cassie.py:665 (stale pd_in_t)
     if (wave == 0) env_reset_finish(S, cfg);
 }
+
+#endif
 
 // clock_reward (cassie/rewards/clock_rewards.py:6-110)
 __device__ float clock_reward(const St& S, const Cfg& cfg, const float* action, float lfrc, float rfrc, float lor, float ror) {
@@ -378,6 +427,127 @@ __device__ float clock_reward(const St& S, const Cfg& cfg, const float* action, 
 }
 
 // ------------------------------------------------------------------------------------------------ kernels
+#if APX_GEN == 4
+// one env per 16-lane row: the env's whole state is staged HBM -> LDS at the top of a launch and back at the end
+#define ENV_SETUP                                                                                   \
+    const int l = threadIdx.x & 15, row = threadIdx.x >> 4;                                          \
+    const int env = blockIdx.x * L4_EPW + row;                                                       \
+    if (env >= n) return;                                                                            \
+    const bool lead = l == 0;                                                                        \
+    const St S{(lfloat*)apx_lds4 + row * L4_ES, env};
+__device__ __forceinline__ void load_state(const St& S, const float* st, const int* ist, int n) {
+    const int l = threadIdx.x & 15;
+    for (int f = l; f < F_TOTAL; f += 16) S(f) = st[(size_t)f * n + S.env];
+    if (l < I_TOTAL) S.I(l) = ist[(size_t)l * n + S.env];
+    __syncthreads();
+}
+__device__ __forceinline__ void store_state(const St& S, float* st, int* ist, int n) {
+    __syncthreads();
+    const int l = threadIdx.x & 15;
+    for (int f = l; f < F_TOTAL; f += 16) st[(size_t)f * n + S.env] = S(f);
+    if (l < I_TOTAL) ist[(size_t)l * n + S.env] = S.I(l);
+}
+
+__global__ __launch_bounds__(64) void env_init_kernel(float* st, int* ist, int n, Cfg cfg) {
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= n) return;
+    auto G = [&](int f) -> float& { return st[(size_t)f * n + env]; };
+    for (int f = 0; f < F_TOTAL; ++f) G(f) = 0.f;
+    for (int f = 0; f < I_TOTAL; ++f) ist[(size_t)f * n + env] = 0;
+    for (int i = 0; i < NQ; ++i) G(F_QPOS + i) = cm_init_qpos[i];
+    for (int b = 0; b < NB; ++b) G(F_MASS + b) = cm_body_mass[b];
+    for (int d = 0; d < NV; ++d) G(F_DAMP + d) = cm_dof_damping[d];
+    G(F_FRIC) = 1.f;
+    const float fl[9] = {0, 0, 1, 0, 1, 0, -1, 0, 0};     // n = z, t1 = y, t2 = n x t1 = -x
+    for (int k = 0; k < 9; ++k) G(F_FLOOR + k) = fl[k];
+}
+
+__global__ __launch_bounds__(64) void env_setconst_kernel(float* st, int* ist, float* wk, int n, Cfg cfg) {
+    ENV_SETUP
+    load_state(S, st, ist, n);
+    if (lead) set_const_single_wave(S);
+    store_state(S, st, ist, n);
+}
+
+__global__ __launch_bounds__(64) void env_reset_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const uint8_t* mask, float* obs) {
+    ENV_SETUP
+    if (mask && !mask[env]) return;
+    load_state(S, st, ist, n);
+    env_reset(S, cfg);
+    if (obs && lead) write_obs(S, cfg, obs + (size_t)env * APX_OBS_DIM);
+    store_state(S, st, ist, n);
+}
+
+__global__ __launch_bounds__(64) void env_step_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const float* action, float* obs,
+                                                      float* reward, uint8_t* done, float* final_obs) {
+    ENV_SETUP
+    load_state(S, st, ist, n);
+    float act[10];
+    if (lead) {
+        for (int u = 0; u < 10; ++u) {
+            act[u] = action[(size_t)env * APX_ACT_DIM + u];
+            S(F_PDT + u) = act[u] + kOffset[u] - (cfg.dyn_rand ? S(F_MNOISE + u) : 0.f);     // cassie.py:295-298
+        }
+        S.I(I_FLAGS) |= 16;
+    }
+    __syncthreads();
+    float lfrc = 0.f, rfrc = 0.f, lor = 0.f, ror = 0.f;
+    for (int i = 0; i < cfg.simrate; ++i) {
+        sim_step_pd(S, cfg.pgs_iters, 1);                                        // all lanes (barriers inside)
+        if (!lead) continue;
+        for (int k = 0; k < 6; ++k) {                                            // cassie.py:328-331
+            const float fp = S(F_FWD + 10 + k);
+            S(F_FOOTVEL + k) = (fp - S(F_FOOTPREV + k)) / 0.0005f;
+            S(F_FOOTPREV + k) = fp;
+        }
+        lfrc += S(F_FWD + 0); rfrc += S(F_FWD + 1);                               // cassie.py:418-420
+        float il = 0.f, ir = 0.f;
+        for (int k = 0; k < 4; ++k) { il += kNeutralFoot[k] * S(F_FWD + 2 + k); ir += kNeutralFoot[k] * S(F_FWD + 6 + k); }
+        lor += 1.f - il * il; ror += 1.f - ir * ir;                               // cassie.py:426-427
+    }
+    if (lead) {
+        const float inv = 1.f / (float)cfg.simrate;
+        lfrc *= inv; rfrc *= inv; lor *= inv; ror *= inv;
+        const float height = S(F_QPOS + 2);
+        int time = S.I(I_TIME) + 1, phase = S.I(I_PHASE) + 1;
+        if ((float)phase > S(F_CMD + 5)) { phase = 0; S.I(I_COUNTER) += 1; }
+        S.I(I_TIME) = time; S.I(I_PHASE) = phase;
+        int dn = (height < 0.4f || height > 3.0f || !(height == height)) ? 1 : 0;
+        int flags = S.I(I_FLAGS);
+        if (!(flags & 4)) for (int u = 0; u < 10; ++u) S(F_PREVACT + u) = act[u];
+        if (!(flags & 8)) for (int u = 0; u < 10; ++u) S(F_PREVTQ + u) = S(F_SO + SO_TORQUE + u);
+        S.I(I_FLAGS) = flags | 12;
+        const float rew = clock_reward(S, cfg, act, lfrc, rfrc, lor, ror);
+        for (int u = 0; u < 10; ++u) { S(F_PREVACT + u) = act[u]; S(F_PREVTQ + u) = S(F_SO + SO_TORQUE + u); }
+        {   // command resampling, cassie.py:483-491; fixed 6 draws per step
+            Rng r{cfg.seed_lo, cfg.seed_hi, cfg.env_base + (unsigned)env, (unsigned)S.I(I_RNG)};
+            { const unsigned k = r.randint(300); const float u = r.uniform(-0.2f, 0.2f); if (k == 0) S(F_CMD + 2) += u; }
+            { const unsigned k = r.randint(100); const float u = r.uniform(-0.3f, 4.0f); if (k == 0) S(F_CMD + 0) = fminf(fmaxf(u, -0.3f), 4.0f); }
+            { const unsigned k = r.randint(300); const float u = r.uniform(-0.3f, 0.3f); if (k == 0) S(F_CMD + 1) = u; }
+            S.I(I_RNG) = (int)r.ctr;
+        }
+        if (!dn && time >= cfg.max_traj_len) dn = 2;
+        reward[env] = rew;
+        done[env] = (uint8_t)dn;
+        write_obs(S, cfg, obs + (size_t)env * APX_OBS_DIM);
+        if (dn && final_obs) for (int k = 0; k < APX_OBS_DIM; ++k) final_obs[(size_t)env * APX_OBS_DIM + k] = obs[(size_t)env * APX_OBS_DIM + k];
+    }
+    store_state(S, st, ist, n);
+}
+
+// raw substeps with the current pd targets (tests): n_sub x cassie_sim_step_pd
+__global__ __launch_bounds__(64) void env_substep_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, int n_sub) {
+    ENV_SETUP
+    load_state(S, st, ist, n);
+    for (int i = 0; i < n_sub; ++i) sim_step_pd(S, cfg.pgs_iters, 1);
+    store_state(S, st, ist, n);
+}
+static constexpr size_t LDS_BYTES = (size_t)L4_EPW * L4_ES * sizeof(float);   // 37,120 B per wave, 4 waves per CU
+#define ENV_GRID(n) dim3((n) / L4_EPW)
+#define ENV_BLOCK dim3(64)
+#define SETCONST_GRID(n) dim3((n) / L4_EPW)
+#define SETCONST_LDS LDS_BYTES
+#else
 #define ENV_SETUP                                                                                   \
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;                                      \
     const int env = blockIdx.x * c2::EPW + lane;                                                     \
@@ -473,8 +643,14 @@ __global__ __launch_bounds__(128) void env_substep_kernel(float* st, int* ist, f
     for (int i = 0; i < n_sub; ++i) sim_step_pd(S, cfg.pgs_iters, 1);
 }
 
-// ------------------------------------------------------------------------------------------------ C ABI
 static constexpr size_t LDS_BYTES = (size_t)c2::CH_TOTAL * c2::EPW * sizeof(float4);   // 161,792 B of the CU's 163,840 at EPW = 64
+#define ENV_GRID(n) dim3((n) / c2::EPW)
+#define ENV_BLOCK dim3(128)
+#define SETCONST_GRID(n) dim3((n) / 64)
+#define SETCONST_LDS 0
+#endif
+
+// ------------------------------------------------------------------------------------------------ C ABI
 
 static Cfg make_cfg(const apx_env_cfg& c) {
     return Cfg{c.simrate, c.dynamics_randomization, c.stance_mode, c.have_incentive, c.max_traj_len, c.pgs_iters,
@@ -508,7 +684,7 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     APX_HIP(hipFuncSetAttribute((const void*)env_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
     APX_HIP(hipFuncSetAttribute((const void*)env_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
     APX_HIP(hipFuncSetAttribute((const void*)env_substep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    hipLaunchKernelGGL(env_setconst_kernel, dim3(e->n / 64), dim3(64), 0, 0, e->st, e->ist, e->wk, e->n, c);
+    hipLaunchKernelGGL(env_setconst_kernel, SETCONST_GRID(e->n), dim3(64), SETCONST_LDS, 0, e->st, e->ist, e->wk, e->n, c);
     APX_LAUNCH_CHECK();
     APX_HIP(hipDeviceSynchronize());
     *out = e;
@@ -524,7 +700,7 @@ extern "C" int apx_env_destroy(apx_env_t* e) {
 
 extern "C" int apx_env_reset(apx_env_t* e, const uint8_t* mask, float* obs_out, void* stream) {
     APX_REQUIRE(e, "env");
-    hipLaunchKernelGGL(env_reset_kernel, dim3(e->n / c2::EPW), dim3(128), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+    hipLaunchKernelGGL(env_reset_kernel, ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
                        make_cfg(e->cfg), mask, obs_out);
     APX_LAUNCH_CHECK();
     return APX_OK;
@@ -533,11 +709,11 @@ extern "C" int apx_env_reset(apx_env_t* e, const uint8_t* mask, float* obs_out, 
 extern "C" int apx_env_step(apx_env_t* e, const float* action, float* obs, float* reward, uint8_t* done, float* final_obs,
                             int auto_reset, void* stream) {
     APX_REQUIRE(e && action && obs && reward && done, "null pointer");
-    hipLaunchKernelGGL(env_step_kernel, dim3(e->n / c2::EPW), dim3(128), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+    hipLaunchKernelGGL(env_step_kernel, ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
                        make_cfg(e->cfg), action, obs, reward, done, final_obs);
     APX_LAUNCH_CHECK();
     if (auto_reset) {   // finished envs restart in a second launch on the same stream (mask = done flags)
-        hipLaunchKernelGGL(env_reset_kernel, dim3(e->n / c2::EPW), dim3(128), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+        hipLaunchKernelGGL(env_reset_kernel, ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
                            make_cfg(e->cfg), done, obs);
         APX_LAUNCH_CHECK();
     }
@@ -607,7 +783,7 @@ extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, voi
     }
 #endif
     if (!strcmp(name, "substep")) {   // debugging hook: out[0] (host-readable count is not needed) - run one raw substep
-        hipLaunchKernelGGL(env_substep_kernel, dim3(e->n / c2::EPW), dim3(128), LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(e->cfg), 1);
+        hipLaunchKernelGGL(env_substep_kernel, ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(e->cfg), 1);
         APX_LAUNCH_CHECK();
         return 0;
     }
@@ -621,7 +797,7 @@ extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, voi
 extern "C" int apx_env_set_field(apx_env_t* e, const char* name, const float* in, void* stream) {
     APX_REQUIRE(e && name, "null pointer");
     if (!strcmp(name, "set_const")) {   // recompute invweight0 after mass edits (sim.set_const)
-        hipLaunchKernelGGL(env_setconst_kernel, dim3(e->n / 64), dim3(64), 0, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(e->cfg));
+        hipLaunchKernelGGL(env_setconst_kernel, SETCONST_GRID(e->n), dim3(64), SETCONST_LDS, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(e->cfg));
         APX_LAUNCH_CHECK();
         return 0;
     }

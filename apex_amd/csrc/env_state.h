@@ -27,10 +27,30 @@ struct apx_env {
     int n;
 };
 
+// Kernel generation: 3 = env-per-lane (two waves over 64 envs, state in HBM/L2), 4 = one env per 16-lane DPP row
+// (4 envs per wave, whole env resident in LDS for the launch).
+#ifndef APX_GEN
+#define APX_GEN 4
+#endif
+
 // global-address-space pointers: St is passed by value into a non-inlined device function, where the compiler could
 // not otherwise prove the address space and would fall back to flat_load / flat_store
 typedef __attribute__((address_space(1))) float gfloat;
 typedef __attribute__((address_space(1))) int gint;
+#if APX_GEN == 4
+// Per-env LDS region (floats): [0,577) state fields | [580,585) int fields | [L4_WK, +WK_TOTAL) stage hand-off |
+// [L4_ROWS, +632) constraint-row store (158 float4 chunks).  Stride L4_ES = 16 (mod 64): the four envs of a wave sit
+// on disjoint LDS bank groups, so a 16-lane access with consecutive addresses is conflict-free.
+typedef __attribute__((address_space(3))) float lfloat;
+typedef __attribute__((address_space(3))) int lint;
+constexpr int L4_INT = 580, L4_WK = 592, L4_ROWS = 1664, L4_ES = 2320, L4_EPW = 4;
+struct St {
+    lfloat* p; int env;
+    __device__ __forceinline__ lfloat& operator()(int f) const { return p[f]; }
+    __device__ __forceinline__ lfloat& W(int i) const { return p[L4_WK + i]; }
+    __device__ __forceinline__ lint& I(int f) const { return ((lint*)p)[L4_INT + f]; }
+};
+#else
 struct St {
     gfloat* p; gint* ip; int n, env; gfloat* wk;      // wk: [WK_TOTAL, n] per-env workspace column (cassie_step3.h)
     __device__ __forceinline__ gfloat& operator()(int f) const { return p[(size_t)f * n + env]; }
@@ -40,6 +60,7 @@ struct St {
 __device__ __forceinline__ St make_st(float* st, int* ist, int n, int env, float* wk) {
     return St{(gfloat*)st, (gint*)ist, n, env, (gfloat*)wk};
 }
+#endif
 
 struct Cfg { int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; int reward_kind; };
 
