@@ -15,7 +15,7 @@
 
 namespace c4 {
 using namespace c3;
-static_assert(L4_WK + WK_TOTAL <= L4_ROWS && L4_ROWS % 4 == 0 && L4_ROWS + 4 * CH_TOTAL <= L4_ES && L4_ES % 64 == 16, "per-env LDS layout");
+static_assert(L4_WK + WK_TOTAL <= L4_ROWS && L4_ROWS % 4 == 0 && L4_ROWS + 704 <= L4_ES && L4_ES % 64 == 16, "per-env LDS layout");
 
 template <int CTRL> __device__ __forceinline__ float dpp(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
@@ -29,64 +29,224 @@ __device__ __forceinline__ float red16(float t) {
     return t;
 }
 
-// position of local column c (0..18) inside the packed value list of a whitened support, -1 = structurally zero
-__device__ __forceinline__ int pos_PL(int c) { return c <= 8 ? c : (c >= 12 && c <= 14) ? c - 3 : c >= 16 ? c - 4 : -1; }
-__device__ __forceinline__ int pos_AC(int c) { return c <= 15 ? c : -1; }
-__device__ __forceinline__ int pos_FT(int c) { return c <= 8 ? c : (c >= 12 && c <= 14) ? c - 3 : c == 18 ? 12 : -1; }
+// ------------------------------------------------------------------------------------------------ row store (LDS)
+// row vector r = 13 * leg + lane (lane 0-2: plantar-rod<->foot connect x,y,z; 3-5: achilles<->heel-spring connect; 6: first
+// active joint limit; 7-9 / 10-12: contact slot 0 / 1 basis n, t1, t2) at rows[24 r]: [0..18] whitened columns,
+// [20..23] b, R, 1/(A+R), f (equality and limit rows).  Contact slot s = 2 * leg + slot at rows[R4_CON + 20 s]:
+// [0..5] Gram (nn, n1, n2, 11, 12, 22), [6] R of the pyramid rows, [7] 1 if a foot capsule, [8..11] b, [12..15] f.
+constexpr int R4_ROW = 24, R4_CON = 26 * R4_ROW, R4_CONSZ = 20, R4_TOTAL = R4_CON + 4 * R4_CONSZ;
+static_assert(MAXC == 2, "lane map has two contact slots per leg");
 
-struct Pair { float a, p; };
-// gather this lane's (ya, yp) of a row of leg LEG from the packed list at float offset `off` of the env's row store
-template <int LEG, class POS>
-__device__ __forceinline__ Pair lane_cols(const float* rows, int off, int l, POS pos) {
-    const int cA = l < 13 ? 6 + l : l - 13, cP = l - 10;
-    const int iA = pos(cA), iP = l < 13 ? -1 : pos(cP);
-    const float vA = iA >= 0 ? rows[off + iA] : 0.f, vP = iP >= 0 ? rows[off + iP] : 0.f;
-    if (l < 13) return LEG == 0 ? Pair{vA, 0.f} : Pair{0.f, vA};
-    return Pair{vA, vP};
+// local-column bitmask of the dofs that move `body` (its ancestor chain)
+template <int LEG> constexpr unsigned chain_mask(int body) {
+    unsigned m = 0;
+    const int last = ct_body_lastdof[body];
+    for (int a = 0; a < ct_dof_depth[last]; ++a) m |= 1u << d2c(ct_dof_anc[16 * last + a]);
+    return m;
 }
 
-// Projected Gauss-Seidel, leg-major (left: 6 equality rows, limit, contacts; then right), in the whitened space.
-// rows = the env's row store (gen-3 chunk format, written by the row stage); S.W(WK_ZT) = warm-started z~.
-__device__ __forceinline__ void stage_pgs_lane(const St& S, const float* rows, int pgs_iters) {
+// Constraint rows of leg LEG, one row vector per lane: Jacobian from the stored motion axes, dots against
+// qvel / qacc_smooth / qacc_warmstart on the raw row, whitening y~ = D^-1/2 L^-T J^T (L streamed from LDS, uniform
+// addresses), row scalars.  Same arithmetic as c3::build_rows3, except that a connect row takes the common ancestors of
+// its two bodies as axis x (p1 - p2) instead of the difference of two point Jacobians.
+template <int LEG>
+__device__ __forceinline__ void stage_rows_lane(const St& S, float* rows) {
     const int l = threadIdx.x & 15;
-    float zA = S.W(WK_ZT + (l < 13 ? 6 + l : l - 13)), zB = S.W(WK_ZT + (l < 13 ? 19 + l : l - 10));
-    const int ncon[2] = {(int)S.W(WK_MISC + 0), (int)S.W(WK_MISC + 1)}, nlim[2] = {(int)S.W(WK_MISC + 2), (int)S.W(WK_MISC + 3)};
+    const V3 o = {S(F_QPOS), S(F_QPOS + 1), S(F_QPOS + 2)};
+    const V3 fn = {S(F_FLOOR), S(F_FLOOR + 1), S(F_FLOOR + 2)}, ft1 = {S(F_FLOOR + 3), S(F_FLOOR + 4), S(F_FLOOR + 5)},
+             ft2 = {S(F_FLOOR + 6), S(F_FLOOR + 7), S(F_FLOOR + 8)};
     const float mu = S(F_FRIC);
-    float ea[12], ep[12], eb[12], eR[12], eiA[12], ef[12];
-    sfor<0, 12>([&](auto Rw) {
-        constexpr int row = Rw, ch = CH_EQ + 5 * row;
-        Pair v;
-        if constexpr ((row % 6) < 3) v = lane_cols<row / 6>(rows, 4 * ch, l, pos_PL); else v = lane_cols<row / 6>(rows, 4 * ch, l, pos_AC);
-        ea[row] = v.a; ep[row] = v.p;
-        eb[row] = rows[4 * ch + 16]; eR[row] = rows[4 * ch + 17]; eiA[row] = rows[4 * ch + 18]; ef[row] = rows[4 * ch + 19];
-    });
-    float la[2] = {0.f, 0.f}, lp[2] = {0.f, 0.f}, lb[2] = {0.f, 0.f}, lR[2] = {0.f, 0.f}, liA[2] = {0.f, 0.f}, lf[2] = {0.f, 0.f};
-    sfor<0, 2>([&](auto Lg) {
-        constexpr int ch = CH_LIM + 6 * Lg;
-        if (nlim[Lg]) {
-            const Pair v = lane_cols<Lg>(rows, 4 * ch, l, [](int c) { return c; });
-            la[Lg] = v.a; lp[Lg] = v.p;
-            lb[Lg] = rows[4 * ch + 20]; lR[Lg] = rows[4 * ch + 21]; liA[Lg] = rows[4 * ch + 22]; lf[Lg] = rows[4 * ch + 23];
+    constexpr int base = WK_PTS + 30 * LEG;
+    // ---- uniform over the env's lanes: first active joint limit of this leg
+    int nlim = 0, clim = -1;
+    float lsign = 0.f, ldist = 0.f, ldiw = 0.f;
+    sfor<0, NJ>([&](auto Jn) {
+        constexpr int j = Jn;
+        if constexpr (ct_jnt_limited[j] && ((ct_jnt_body[j] >= 14) == (LEG == 1)) && ct_jnt_body[j] >= 2) {
+            const float q = S(F_QPOS + ct_jnt_qposadr[j]);
+            const float dlo = q - ct_jnt_range[2 * j], dhi = ct_jnt_range[2 * j + 1] - q;
+            if ((dlo < 0.f || dhi < 0.f) && nlim == 0) {
+                constexpr int d = ct_jnt_dofadr[j];
+                clim = d2c(d); lsign = dlo < 0.f ? 1.f : -1.f; ldist = dlo < 0.f ? dlo : dhi; ldiw = S(F_DIW + d); nlim = 1;
+            }
         }
     });
-    constexpr int NCS = 2 * MAXC;
-    float na[NCS], np[NCS], t1a[NCS], t1p[NCS], t2a[NCS], t2p[NCS], cG[NCS][6], cR[NCS], cb[NCS][4], cf[NCS][4], ciA[NCS][4];
-    sfor<0, NCS>([&](auto Sl) {
-        constexpr int s = Sl, leg = s / MAXC, ch = CH_CON + 14 * (3 * leg + s % MAXC);
-        na[s] = np[s] = t1a[s] = t1p[s] = t2a[s] = t2p[s] = 0.f;
-        if ((s % MAXC) < ncon[leg]) {
-            const Pair vn = lane_cols<leg>(rows, 4 * ch, l, pos_FT), v1 = lane_cols<leg>(rows, 4 * ch + 13, l, pos_FT), v2 = lane_cols<leg>(rows, 4 * ch + 26, l, pos_FT);
-            na[s] = vn.a; np[s] = vn.p; t1a[s] = v1.a; t1p[s] = v1.p; t2a[s] = v2.a; t2p[s] = v2.p;
-            sfor<0, 6>([&](auto K) { cG[s][K] = rows[4 * ch + 40 + K]; });
-            cR[s] = rows[4 * ch + 46];
+    // ---- uniform: first MAXC penetrating capsule ends in the order foot e0,e1, tarsus e0,e1, shin e0,e1
+    const V3 p0 = {ct_floor_pos[0], ct_floor_pos[1], ct_floor_pos[2]};
+    int nc = 0;
+    V3 cpt[MAXC]; float cdist[MAXC]; int cgeo[MAXC];
+    sfor<0, MAXC>([&](auto Sl) { cpt[Sl] = {0.f, 0.f, 0.f}; cdist[Sl] = 0.f; cgeo[Sl] = 0; });
+    sfor<0, 6>([&](auto I) {
+        constexpr int G = I / 2;
+        const V3 ctr = ldv3<base + 12 + 3 * I>(S);
+        const float dist = dot(ctr - p0, fn) - ct_geom_radius[2 * G + LEG];
+        const bool hit = dist < 0.f && nc < MAXC;
+        const V3 cp = ctr - fn * (ct_geom_radius[2 * G + LEG] + 0.5f * dist);
+        sfor<0, MAXC>([&](auto Sl) { if (hit && nc == Sl) { cpt[Sl] = cp; cdist[Sl] = dist; cgeo[Sl] = G; } });
+        nc += hit ? 1 : 0;
+    });
+    // ---- this lane's row
+    const bool isEq = l < 6, isLim = l == 6;
+    const int E = l >= 3 ? 1 : 0, cs = l >= 10 ? 1 : 0;
+    const bool isCon = l >= 7 && l < 13 && cs < nc;
+    const int ax = isEq ? l - 3 * E : (l - 7) - 3 * cs;              // component / basis index 0..2
+    constexpr unsigned mPL1 = chain_mask<LEG>(ct_eq_body1[2 * LEG]), mPL2 = chain_mask<LEG>(ct_eq_body2[2 * LEG]);
+    constexpr unsigned mAC1 = chain_mask<LEG>(ct_eq_body1[2 * LEG + 1]), mAC2 = chain_mask<LEG>(ct_eq_body2[2 * LEG + 1]);
+    constexpr unsigned mFT = chain_mask<LEG>(13 + 12 * LEG);
+    const int G = cs ? cgeo[1] : cgeo[0];
+    const unsigned mcon = mFT & ~(G >= 1 ? (1u << 18) : 0u) & ~(G >= 2 ? (1u << 14) : 0u);   // tarsus / shin contact: dofs below do not move the point
+    const unsigned m1 = isEq ? (E ? mAC1 : mPL1) : isCon ? mcon : 0u, m2 = isEq ? (E ? mAC2 : mPL2) : 0u;
+    V3 p1, p2;
+    {
+        const V3 e1 = {S.W(base + 6 * E), S.W(base + 6 * E + 1), S.W(base + 6 * E + 2)};
+        const V3 e2 = {S.W(base + 6 * E + 3), S.W(base + 6 * E + 4), S.W(base + 6 * E + 5)};
+        const V3 cp = cs ? cpt[1] : cpt[0];
+        p1 = isEq ? e1 : cp; p2 = e2;
+    }
+    V3 dir;
+    {
+        const V3 dc = ax == 0 ? fn : ax == 1 ? ft1 : ft2;
+        const V3 de = {ax == 0 ? 1.f : 0.f, ax == 1 ? 1.f : 0.f, ax == 2 ? 1.f : 0.f};
+        dir = isEq ? de : dc;
+    }
+    const V3 q1 = cross(p1 - o, dir), q2 = cross(p2 - o, dir);       // dir . (a x r) = a . (r x dir)
+    float J[19];
+    sfor<0, 19>([&](auto C) {
+        constexpr int c = C, d = c2d<LEG>(c);
+        const V3 ca = {S.W(WK_CDOF + 6 * d), S.W(WK_CDOF + 6 * d + 1), S.W(WK_CDOF + 6 * d + 2)};
+        const V3 cl = {S.W(WK_CDOF + 6 * d + 3), S.W(WK_CDOF + 6 * d + 4), S.W(WK_CDOF + 6 * d + 5)};
+        const float dl = dot(dir, cl);
+        const float g1 = dl + dot(q1, ca), g2 = dl + dot(q2, ca);
+        float v = ((m1 >> c) & 1u) ? g1 : 0.f;
+        v -= ((m2 >> c) & 1u) ? g2 : 0.f;
+        if (isLim && nlim && c == clim) v = lsign;
+        J[c] = v;
+    });
+    float vel = 0.f, ju = 0.f, jw = 0.f;
+    sfor<0, 19>([&](auto C) {
+        constexpr int c = C, d = c2d<LEG>(c);
+        vel += J[c] * S(F_QVEL + d); ju += J[c] * S.W(WK_QS + d); jw += J[c] * S(F_QACCW + d);
+    });
+    srfor<0, 19>([&](auto C) {
+        constexpr int c = C, i = c2d<LEG>(c);
+        sfor<1, ct_dof_depth[i]>([&](auto A) { constexpr int a = A; J[d2c(ct_dof_anc[16 * i + a])] -= S.W(WK_LD + ct_dof_madr[i] + a) * J[c]; });
+    });
+    float nn = 0.f;
+    sfor<0, 19>([&](auto C) { constexpr int c = C; J[c] *= S.W(WK_DISQ + c2d<LEG>(c)); nn += J[c] * J[c]; });
+    float* row = rows + R4_ROW * (13 * LEG + l);
+    if (l < 13) sfor<0, 19>([&](auto C) { row[C] = J[C]; });
+    // ---- equality / limit scalars (mj_makeImpedance, mj_referenceConstraint, warm start from qacc_warmstart)
+    {
+        const V3 cv = p1 - p2;
+        const float cpos = ax == 0 ? cv.x : ax == 1 ? cv.y : cv.z;
+        const float tranPL = S(F_BIW + ct_eq_body1[2 * LEG]) + S(F_BIW + ct_eq_body2[2 * LEG]);
+        const float tranAC = S(F_BIW + ct_eq_body1[2 * LEG + 1]) + S(F_BIW + ct_eq_body2[2 * LEG + 1]);
+        const float pos = isEq ? cpos : ldist, imp_pos = isEq ? sqrtf(dot(cv, cv)) : ldist;
+        const float diag = isEq ? (E ? tranAC : tranPL) : ldiw;
+        const RowK kb = solref(isEq ? 0.005f : 0.02f);
+        const float imp = impedance(imp_pos);
+        const float R = fmaxf(MINVAL, (1.f - imp) / imp * diag);
+        const float aref = -kb.B * vel - kb.K * imp * pos;
+        float b = ju - aref;
+        float f = -(jw - aref) / R;
+        if (isLim && f < 0.f) f = 0.f;
+        float invA = 1.f / (nn + R), Rw = R;
+        if (isLim && !nlim) { b = 0.f; f = 0.f; invA = 0.f; Rw = 1.f; }
+        if (l < 7) { row[20] = b; row[21] = Rw; row[22] = invA; row[23] = f; }
+    }
+    // ---- contact scalars: Gram matrix of (n, t1, t2) across the three basis lanes, pyramid rows n +- mu t_j
+    float a1 = 0.f, a2 = 0.f;
+    sfor<0, 19>([&](auto C) { a1 += J[C] * dpp<0x111>(J[C]); a2 += J[C] * dpp<0x112>(J[C]); });     // row_shr:1, row_shr:2
+    sfor<0, MAXC>([&](auto Sl) {
+        constexpr int s = Sl, ln = 7 + 3 * s;
+        const float gnn = dpp<0x150 + ln>(nn), g11 = dpp<0x150 + ln + 1>(nn), g22 = dpp<0x150 + ln + 2>(nn);
+        const float gn1 = dpp<0x150 + ln + 1>(a1), g12 = dpp<0x150 + ln + 2>(a1), gn2 = dpp<0x150 + ln + 2>(a2);
+        const float vn = dpp<0x150 + ln>(vel), v1 = dpp<0x150 + ln + 1>(vel), v2 = dpp<0x150 + ln + 2>(vel);
+        const float un = dpp<0x150 + ln>(ju), u1 = dpp<0x150 + ln + 1>(ju), u2 = dpp<0x150 + ln + 2>(ju);
+        const float wn = dpp<0x150 + ln>(jw), w1 = dpp<0x150 + ln + 1>(jw), w2 = dpp<0x150 + ln + 2>(jw);
+        if (s < nc && l == 0) {
+            const int Gs = cgeo[s];
+            const float dist = cdist[s];
+            const float tran = Gs == 0 ? S(F_BIW + 13 + 12 * LEG) : Gs == 1 ? S(F_BIW + 9 + 12 * LEG) : S(F_BIW + 8 + 12 * LEG);
+            const RowK kb = solref(0.005f);
+            const float imp = impedance(dist);
+            const float R1 = fmaxf(MINVAL, (1.f - imp) / imp * (tran + mu * mu * tran));
+            const float Rpy = fmaxf(MINVAL, 2.f * mu * mu * R1);       // pyramidal regulariser, impratio 1
+            const float sv[4] = {mu * v1, -mu * v1, mu * v2, -mu * v2}, su[4] = {mu * u1, -mu * u1, mu * u2, -mu * u2};
+            const float sw[4] = {mu * w1, -mu * w1, mu * w2, -mu * w2};
+            float* cr = rows + R4_CON + R4_CONSZ * (2 * LEG + s);
+            cr[0] = gnn; cr[1] = gn1; cr[2] = gn2; cr[3] = g11; cr[4] = g12; cr[5] = g22; cr[6] = Rpy; cr[7] = Gs == 0 ? 1.f : 0.f;
             sfor<0, 4>([&](auto K) {
                 constexpr int k = K;
-                cb[s][k] = rows[4 * ch + 48 + k]; cf[s][k] = rows[4 * ch + 52 + k];
-                const float sm = ((k & 1) ? -mu : mu), gnj = k < 2 ? cG[s][1] : cG[s][2], gjj = k < 2 ? cG[s][3] : cG[s][5];
-                ciA[s][k] = __frcp_rn(cG[s][0] + 2.f * sm * gnj + mu * mu * gjj + cR[s]);      // A_kk + R of row n + s mu t_j
+                const float aref = -kb.B * (vn + sv[k]) - kb.K * imp * dist;
+                cr[8 + k] = un + su[k] - aref;
+                const float f = -((wn + sw[k]) - aref) / Rpy;
+                cr[12 + k] = f < 0.f ? 0.f : f;
             });
         }
     });
+    if (l == 0) { S.W(WK_MISC + LEG) = (float)nc; S.W(WK_MISC + 2 + LEG) = (float)nlim; }
+}
+
+// Projected Gauss-Seidel, leg-major (left: 6 equality rows, limit, contacts; then right), in the whitened space, with the
+// warm-start selection of mj_fwdConstraint in the prologue (warm start loses to f = 0 when its dual cost is positive).
+__device__ __forceinline__ void stage_pgs_lane(const St& S, float* rows, int pgs_iters) {
+    const int l = threadIdx.x & 15;
+    const int ncon[2] = {(int)S.W(WK_MISC + 0), (int)S.W(WK_MISC + 1)}, nlim[2] = {(int)S.W(WK_MISC + 2), (int)S.W(WK_MISC + 3)};
+    const float mu = S(F_FRIC);
+    const int cA = l < 13 ? 6 + l : l - 13, cP = l < 13 ? 6 + l : l - 10;
+    auto cols = [&](int r, float& a, float& p) {      // r = 13 * leg + row lane
+        const float vA = rows[R4_ROW * r + cA], vP = rows[R4_ROW * r + cP];
+        if (l < 13) { a = r < 13 ? vA : 0.f; p = r < 13 ? 0.f : vA; } else { a = vA; p = vP; }
+    };
+    float ea[12], ep[12], eb[12], eR[12], eiA[12], ef[12];
+    sfor<0, 12>([&](auto Rw) {
+        constexpr int row = Rw, r = 13 * (row / 6) + row % 6;
+        cols(r, ea[row], ep[row]);
+        eb[row] = rows[R4_ROW * r + 20]; eR[row] = rows[R4_ROW * r + 21]; eiA[row] = rows[R4_ROW * r + 22]; ef[row] = rows[R4_ROW * r + 23];
+    });
+    float la[2], lp[2], lb[2], lR[2], liA[2], lf[2];
+    sfor<0, 2>([&](auto Lg) {
+        constexpr int r = 13 * Lg + 6;
+        cols(r, la[Lg], lp[Lg]);
+        lb[Lg] = rows[R4_ROW * r + 20]; lR[Lg] = rows[R4_ROW * r + 21]; liA[Lg] = rows[R4_ROW * r + 22]; lf[Lg] = rows[R4_ROW * r + 23];
+    });
+    constexpr int NCS = 2 * MAXC;
+    float na[NCS], np[NCS], t1a[NCS], t1p[NCS], t2a[NCS], t2p[NCS], cG[NCS][6], cR[NCS], cb[NCS][4], cf[NCS][4], ciA[NCS][4];
+    bool con[NCS];
+    sfor<0, NCS>([&](auto Sl) {
+        constexpr int s = Sl, leg = s / MAXC, r = 13 * leg + 7 + 3 * (s % MAXC);
+        con[s] = (s % MAXC) < ncon[leg];
+        cols(r, na[s], np[s]); cols(r + 1, t1a[s], t1p[s]); cols(r + 2, t2a[s], t2p[s]);
+        const float* cr = rows + R4_CON + R4_CONSZ * s;
+        sfor<0, 6>([&](auto K) { cG[s][K] = cr[K]; });
+        cR[s] = cr[6];
+        sfor<0, 4>([&](auto K) {
+            constexpr int k = K;
+            cb[s][k] = cr[8 + k]; cf[s][k] = con[s] ? cr[12 + k] : 0.f;
+            const float sm = ((k & 1) ? -mu : mu), gnj = k < 2 ? cG[s][1] : cG[s][2], gjj = k < 2 ? cG[s][3] : cG[s][5];
+            ciA[s][k] = __frcp_rn(cG[s][0] + 2.f * sm * gnj + mu * mu * gjj + cR[s]);      // A_kk + R of row n + s mu t_j
+        });
+    });
+    // ---- warm start: z~ = sum y~ f, dual cost 1/2 z~.z~ + sum f (R f / 2 + b)
+    float zA = 0.f, zB = 0.f, cost = 0.f;
+    sfor<0, 12>([&](auto R) { zA += ea[R] * ef[R]; zB += ep[R] * ef[R]; cost += ef[R] * (0.5f * eR[R] * ef[R] + eb[R]); });
+    sfor<0, 2>([&](auto Lg) { if (nlim[Lg]) { zA += la[Lg] * lf[Lg]; zB += lp[Lg] * lf[Lg]; cost += lf[Lg] * (0.5f * lR[Lg] * lf[Lg] + lb[Lg]); } });
+    sfor<0, NCS>([&](auto Sl) {
+        constexpr int s = Sl;
+        if (con[s]) {
+            const float dn = cf[s][0] + cf[s][1] + cf[s][2] + cf[s][3], d1 = mu * (cf[s][0] - cf[s][1]), d2 = mu * (cf[s][2] - cf[s][3]);
+            zA += na[s] * dn + t1a[s] * d1 + t2a[s] * d2; zB += np[s] * dn + t1p[s] * d1 + t2p[s] * d2;
+            sfor<0, 4>([&](auto K) { cost += cf[s][K] * (0.5f * cR[s] * cf[s][K] + cb[s][K]); });
+        }
+    });
+    cost += 0.5f * red16(zA * zA + zB * zB);
+    if (cost > 0.f) {
+        zA = zB = 0.f;
+        sfor<0, 12>([&](auto R) { ef[R] = 0.f; });
+        lf[0] = lf[1] = 0.f;
+        sfor<0, NCS>([&](auto Sl) { sfor<0, 4>([&](auto K) { cf[Sl][K] = 0.f; }); });
+    }
     for (int it = 0; it < pgs_iters; ++it) {
         sfor<0, 2>([&](auto Lg) {
             constexpr int leg = Lg;
@@ -107,7 +267,7 @@ __device__ __forceinline__ void stage_pgs_lane(const St& S, const float* rows, i
             }
             sfor<0, MAXC>([&](auto Sl) {
                 constexpr int s = leg * MAXC + Sl;
-                if (Sl < ncon[leg]) {
+                if (con[s]) {
                     float rn = red16(na[s] * zA + np[s] * zB), r1 = red16(t1a[s] * zA + t1p[s] * zB), r2 = red16(t2a[s] * zA + t2p[s] * zB);
                     const float gnn = cG[s][0], gn1 = cG[s][1], gn2 = cG[s][2], g11 = cG[s][3], g12 = cG[s][4], g22 = cG[s][5];
                     float sdn = 0.f, sd1 = 0.f, sd2 = 0.f;
@@ -119,6 +279,7 @@ __device__ __forceinline__ void stage_pgs_lane(const St& S, const float* rows, i
                         fn = fn < 0.f ? 0.f : fn;
                         const float df = fn - cf[s][k];
                         cf[s][k] = fn;
+                        // y_k = n + sm t_j moves the basis residuals by df * (G n-col + sm G j-col)
                         if constexpr (k < 2) { rn += df * (gnn + sm * gn1); r1 += df * (gn1 + sm * g11); r2 += df * (gn2 + sm * g12); sd1 += sm * df; }
                         else { rn += df * (gnn + sm * gn2); r1 += df * (gn1 + sm * g12); r2 += df * (gn2 + sm * g22); sd2 += sm * df; }
                         sdn += df;
@@ -131,13 +292,7 @@ __device__ __forceinline__ void stage_pgs_lane(const St& S, const float* rows, i
     }
     S.W(WK_ZT + (l < 13 ? 6 + l : l - 13)) = zA; S.W(WK_ZT + (l < 13 ? 19 + l : l - 10)) = zB;
     // contact forces back to the row store (foot-force readout in the finish stage)
-    if (l == 0) {
-        float* w = const_cast<float*>(rows);
-        sfor<0, NCS>([&](auto Sl) {
-            constexpr int s = Sl, leg = s / MAXC, ch = CH_CON + 14 * (3 * leg + s % MAXC);
-            if ((s % MAXC) < ncon[leg]) sfor<0, 4>([&](auto K) { w[4 * ch + 52 + K] = cf[s][K]; });
-        });
-    }
+    if (l == 0) sfor<0, NCS>([&](auto Sl) { if (con[Sl]) sfor<0, 4>([&](auto K) { rows[R4_CON + R4_CONSZ * Sl + 12 + K] = cf[Sl][K]; }); });
 }
 
 }  // namespace c4

@@ -643,7 +643,7 @@ __device__ __forceinline__ void stage_pgs_wave(const St& S, const Lds& L, int pg
 
 // stage E: qacc, foot force, IMU; then (do_euler) mj_Euler with implicit joint damping:
 // (M + h D) a = qfrc_smooth + J^T f = qfrc_smooth + L^T D^1/2 z~
-__device__ __forceinline__ void stage_finish(const St& S, const Lds& L, bool do_euler, float (&acc_out)[3], float (&foot_fz)[2]) {
+__device__ __forceinline__ void stage_finish(const St& S, const Lds& L, bool do_euler, float (&acc_out)[3], float (&foot_fz)[2], const float* rows4 = nullptr) {
     float LD[NM], zt[NV], disq[NV], qacc[NV];
     sfor<0, NM>([&](auto I) { LD[I] = S.W(WK_LD + I); });
     sfor<0, NV>([&](auto D) { zt[D] = S.W(WK_ZT + D); disq[D] = S.W(WK_DISQ + D); });
@@ -652,9 +652,17 @@ __device__ __forceinline__ void stage_finish(const St& S, const Lds& L, bool do_
     sfor<0, NV>([&](auto D) { qacc[D] += S.W(WK_QS + D); });
     {   // world z of the contact force on the foot bodies (cassie_sim_foot_forces -> get_foot_forces()[2], [8])
         const int nc[2] = {(int)S.W(WK_MISC + 0), (int)S.W(WK_MISC + 1)};
-        const unsigned footmask = (unsigned)S.W(WK_MISC + 4);
         const float mu = S(F_FRIC), nz = S(F_FLOOR + 2), t1z = S(F_FLOOR + 5), t2z = S(F_FLOOR + 8);
         foot_fz[0] = foot_fz[1] = 0.f;
+#if defined(APX_GEN) && APX_GEN == 4
+        sfor<0, 2 * MAXC>([&](auto Sl) {      // generation-4 row store (cassie_lane.h): slot s at rows4[624 + 20 s], [7] foot flag, [12..15] f
+            constexpr int sl = Sl, lg = sl / MAXC;
+            const float* cr = rows4 + 624 + 20 * sl;
+            if ((sl % MAXC) < nc[lg] && cr[7] != 0.f)
+                foot_fz[lg] += nz * (cr[12] + cr[13] + cr[14] + cr[15]) + mu * (t1z * (cr[12] - cr[13]) + t2z * (cr[14] - cr[15]));
+        });
+#else
+        const unsigned footmask = (unsigned)S.W(WK_MISC + 4);
         sfor<0, 6>([&](auto Sl) {
             constexpr int sl = Sl, lg = sl / 3;
             if ((sl % 3) < nc[lg] && ((footmask >> sl) & 1u)) {
@@ -662,6 +670,7 @@ __device__ __forceinline__ void stage_finish(const St& S, const Lds& L, bool do_
                 foot_fz[lg] += nz * (ff.x + ff.y + ff.z + ff.w) + mu * (t1z * (ff.x - ff.y) + t2z * (ff.z - ff.w));
             }
         });
+#endif
     }
     {   // accelerometer at the imu site (cassie.xml:267): classical acceleration of the site point, site frame
         SV A = {{S.W(WK_PEL), S.W(WK_PEL + 1), S.W(WK_PEL + 2)}, {S.W(WK_PEL + 3), S.W(WK_PEL + 4), S.W(WK_PEL + 5)}};

@@ -152,9 +152,16 @@ __device__ __noinline__ void stage3a_warm(St S) {
     c3::stage_warm_check(S, Y);
 }
 #if APX_GEN == 4
+__device__ __forceinline__ float* rows4() { return (float*)(apx_lds4 + ((threadIdx.x >> 4) * L4_ES + L4_ROWS) / 4); }
+template <int LEG>
+__device__ __noinline__ void stage2b_rows_lane(St S) {
+    PROF_START();
+    c4::stage_rows_lane<LEG>(S, rows4());
+    PROF(5 + LEG);
+}
 __device__ __noinline__ void stage3_pgs_lane(St S, int pgs_iters) {
     PROF_START();
-    c4::stage_pgs_lane(S, (const float*)(apx_lds4 + ((threadIdx.x >> 4) * L4_ES + L4_ROWS) / 4), pgs_iters);
+    c4::stage_pgs_lane(S, rows4(), pgs_iters);
     PROF(3);
 }
 #else
@@ -180,7 +187,11 @@ __device__ __noinline__ void stage4_finish(St S, int mode) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) { S(F_SNAP + SN_GYRO + k) = S(F_QVEL + 3 + k); S(F_SNAP + SN_VEL + k) = S(F_QVEL + k); }
     S(F_SNAP + SN_PZ) = S(F_QPOS + 2);
+#if APX_GEN == 4
+    c3::stage_finish(S, Y, mode != 0, acc, fz, rows4());
+#else
     c3::stage_finish(S, Y, mode != 0, acc, fz);
+#endif
 #pragma unroll
     for (int k = 0; k < 3; ++k) S(F_SNAP + SN_ACC + k) = acc[k];
     S(F_FWD + 0) = fz[0]; S(F_FWD + 1) = fz[1];
@@ -191,7 +202,9 @@ __device__ __noinline__ void stage4_finish(St S, int mode) {
 // row's lead lane; every call site is reached by all lanes.
 __device__ __forceinline__ void sim_step_pd(const St& S, int pgs_iters, int mode) {
     const bool lead = (threadIdx.x & 15) == 0;
-    if (lead) { stage1_io_tree(S, mode); stage2a_factor(S); stage2b_rows<0>(S); stage2b_rows<1>(S); stage3a_warm(S); }
+    if (lead) { stage1_io_tree(S, mode); stage2a_factor(S); }
+    __syncthreads();
+    stage2b_rows_lane<0>(S); stage2b_rows_lane<1>(S);
     __syncthreads();
     stage3_pgs_lane(S, pgs_iters);
     __syncthreads();

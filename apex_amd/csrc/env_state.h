@@ -43,7 +43,7 @@ typedef __attribute__((address_space(1))) int gint;
 // on disjoint LDS bank groups, so a 16-lane access with consecutive addresses is conflict-free.
 typedef __attribute__((address_space(3))) float lfloat;
 typedef __attribute__((address_space(3))) int lint;
-constexpr int L4_INT = 580, L4_WK = 592, L4_ROWS = 1664, L4_ES = 2320, L4_EPW = 4;
+constexpr int L4_INT = 580, L4_WK = 592, L4_ROWS = 1664, L4_ES = 2384, L4_EPW = 4;
 struct St {
     lfloat* p; int env;
     __device__ __forceinline__ lfloat& operator()(int f) const { return p[f]; }
