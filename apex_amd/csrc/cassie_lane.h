@@ -49,8 +49,14 @@ template <int LEG> constexpr unsigned chain_mask(int body) {
 // qvel / qacc_smooth / qacc_warmstart on the raw row, whitening y~ = D^-1/2 L^-T J^T (L streamed from LDS, uniform
 // addresses), row scalars.  Same arithmetic as c3::build_rows3, except that a connect row takes the common ancestors of
 // its two bodies as axis x (p1 - p2) instead of the difference of two point Jacobians.
+struct LegRows {
+    float J[19];                 // this lane's whitened row vector (local columns)
+    float b, R, invA, f;         // this lane's row scalars (equality / limit lanes)
+    int nc, nlim;                // uniform over the env's lanes from here on
+    float cG[MAXC][6], cR[MAXC], cb[MAXC][4], cf[MAXC][4], isfoot[MAXC];
+};
 template <int LEG>
-__device__ __forceinline__ void stage_rows_lane(const St& S, float* rows) {
+__device__ __forceinline__ void rows_lane(const St& S, LegRows& out) {
     const int l = threadIdx.x & 15;
     const V3 o = {S(F_QPOS), S(F_QPOS + 1), S(F_QPOS + 2)};
     const V3 fn = {S(F_FLOOR), S(F_FLOOR + 1), S(F_FLOOR + 2)}, ft1 = {S(F_FLOOR + 3), S(F_FLOOR + 4), S(F_FLOOR + 5)},
@@ -110,7 +116,7 @@ __device__ __forceinline__ void stage_rows_lane(const St& S, float* rows) {
         dir = isEq ? de : dc;
     }
     const V3 q1 = cross(p1 - o, dir), q2 = cross(p2 - o, dir);       // dir . (a x r) = a . (r x dir)
-    float J[19];
+    float (&J)[19] = out.J;
     sfor<0, 19>([&](auto C) {
         constexpr int c = C, d = c2d<LEG>(c);
         const V3 ca = {S.W(WK_CDOF + 6 * d), S.W(WK_CDOF + 6 * d + 1), S.W(WK_CDOF + 6 * d + 2)};
@@ -133,8 +139,6 @@ __device__ __forceinline__ void stage_rows_lane(const St& S, float* rows) {
     });
     float nn = 0.f;
     sfor<0, 19>([&](auto C) { constexpr int c = C; J[c] *= S.W(WK_DISQ + c2d<LEG>(c)); nn += J[c] * J[c]; });
-    float* row = rows + R4_ROW * (13 * LEG + l);
-    if (l < 13) sfor<0, 19>([&](auto C) { row[C] = J[C]; });
     // ---- equality / limit scalars (mj_makeImpedance, mj_referenceConstraint, warm start from qacc_warmstart)
     {
         const V3 cv = p1 - p2;
@@ -152,7 +156,7 @@ __device__ __forceinline__ void stage_rows_lane(const St& S, float* rows) {
         if (isLim && f < 0.f) f = 0.f;
         float invA = 1.f / (nn + R), Rw = R;
         if (isLim && !nlim) { b = 0.f; f = 0.f; invA = 0.f; Rw = 1.f; }
-        if (l < 7) { row[20] = b; row[21] = Rw; row[22] = invA; row[23] = f; }
+        out.b = b; out.R = Rw; out.invA = invA; out.f = f;
     }
     // ---- contact scalars: Gram matrix of (n, t1, t2) across the three basis lanes, pyramid rows n +- mu t_j
     float a1 = 0.f, a2 = 0.f;
@@ -164,111 +168,132 @@ __device__ __forceinline__ void stage_rows_lane(const St& S, float* rows) {
         const float vn = dpp<0x150 + ln>(vel), v1 = dpp<0x150 + ln + 1>(vel), v2 = dpp<0x150 + ln + 2>(vel);
         const float un = dpp<0x150 + ln>(ju), u1 = dpp<0x150 + ln + 1>(ju), u2 = dpp<0x150 + ln + 2>(ju);
         const float wn = dpp<0x150 + ln>(jw), w1 = dpp<0x150 + ln + 1>(jw), w2 = dpp<0x150 + ln + 2>(jw);
-        if (s < nc && l == 0) {
-            const int Gs = cgeo[s];
-            const float dist = cdist[s];
-            const float tran = Gs == 0 ? S(F_BIW + 13 + 12 * LEG) : Gs == 1 ? S(F_BIW + 9 + 12 * LEG) : S(F_BIW + 8 + 12 * LEG);
-            const RowK kb = solref(0.005f);
-            const float imp = impedance(dist);
-            const float R1 = fmaxf(MINVAL, (1.f - imp) / imp * (tran + mu * mu * tran));
-            const float Rpy = fmaxf(MINVAL, 2.f * mu * mu * R1);       // pyramidal regulariser, impratio 1
-            const float sv[4] = {mu * v1, -mu * v1, mu * v2, -mu * v2}, su[4] = {mu * u1, -mu * u1, mu * u2, -mu * u2};
-            const float sw[4] = {mu * w1, -mu * w1, mu * w2, -mu * w2};
-            float* cr = rows + R4_CON + R4_CONSZ * (2 * LEG + s);
-            cr[0] = gnn; cr[1] = gn1; cr[2] = gn2; cr[3] = g11; cr[4] = g12; cr[5] = g22; cr[6] = Rpy; cr[7] = Gs == 0 ? 1.f : 0.f;
-            sfor<0, 4>([&](auto K) {
-                constexpr int k = K;
-                const float aref = -kb.B * (vn + sv[k]) - kb.K * imp * dist;
-                cr[8 + k] = un + su[k] - aref;
-                const float f = -((wn + sw[k]) - aref) / Rpy;
-                cr[12 + k] = f < 0.f ? 0.f : f;
-            });
-        }
-    });
-    if (l == 0) { S.W(WK_MISC + LEG) = (float)nc; S.W(WK_MISC + 2 + LEG) = (float)nlim; }
-}
-
-// Projected Gauss-Seidel, leg-major (left: 6 equality rows, limit, contacts; then right), in the whitened space, with the
-// warm-start selection of mj_fwdConstraint in the prologue (warm start loses to f = 0 when its dual cost is positive).
-__device__ __forceinline__ void stage_pgs_lane(const St& S, float* rows, int pgs_iters) {
-    const int l = threadIdx.x & 15;
-    const int ncon[2] = {(int)S.W(WK_MISC + 0), (int)S.W(WK_MISC + 1)}, nlim[2] = {(int)S.W(WK_MISC + 2), (int)S.W(WK_MISC + 3)};
-    const float mu = S(F_FRIC);
-    const int cA = l < 13 ? 6 + l : l - 13, cP = l < 13 ? 6 + l : l - 10;
-    auto cols = [&](int r, float& a, float& p) {      // r = 13 * leg + row lane
-        const float vA = rows[R4_ROW * r + cA], vP = rows[R4_ROW * r + cP];
-        if (l < 13) { a = r < 13 ? vA : 0.f; p = r < 13 ? 0.f : vA; } else { a = vA; p = vP; }
-    };
-    float ea[12], ep[12], eb[12], eR[12], eiA[12], ef[12];
-    sfor<0, 12>([&](auto Rw) {
-        constexpr int row = Rw, r = 13 * (row / 6) + row % 6;
-        cols(r, ea[row], ep[row]);
-        eb[row] = rows[R4_ROW * r + 20]; eR[row] = rows[R4_ROW * r + 21]; eiA[row] = rows[R4_ROW * r + 22]; ef[row] = rows[R4_ROW * r + 23];
-    });
-    float la[2], lp[2], lb[2], lR[2], liA[2], lf[2];
-    sfor<0, 2>([&](auto Lg) {
-        constexpr int r = 13 * Lg + 6;
-        cols(r, la[Lg], lp[Lg]);
-        lb[Lg] = rows[R4_ROW * r + 20]; lR[Lg] = rows[R4_ROW * r + 21]; liA[Lg] = rows[R4_ROW * r + 22]; lf[Lg] = rows[R4_ROW * r + 23];
-    });
-    constexpr int NCS = 2 * MAXC;
-    float na[NCS], np[NCS], t1a[NCS], t1p[NCS], t2a[NCS], t2p[NCS], cG[NCS][6], cR[NCS], cb[NCS][4], cf[NCS][4], ciA[NCS][4];
-    bool con[NCS];
-    sfor<0, NCS>([&](auto Sl) {
-        constexpr int s = Sl, leg = s / MAXC, r = 13 * leg + 7 + 3 * (s % MAXC);
-        con[s] = (s % MAXC) < ncon[leg];
-        cols(r, na[s], np[s]); cols(r + 1, t1a[s], t1p[s]); cols(r + 2, t2a[s], t2p[s]);
-        const float* cr = rows + R4_CON + R4_CONSZ * s;
-        sfor<0, 6>([&](auto K) { cG[s][K] = cr[K]; });
-        cR[s] = cr[6];
+        const int Gs = cgeo[s];
+        const float dist = cdist[s];
+        const float tran = Gs == 0 ? S(F_BIW + 13 + 12 * LEG) : Gs == 1 ? S(F_BIW + 9 + 12 * LEG) : S(F_BIW + 8 + 12 * LEG);
+        const RowK kb = solref(0.005f);
+        const float imp = impedance(dist);
+        const float R1 = fmaxf(MINVAL, (1.f - imp) / imp * (tran + mu * mu * tran));
+        const float Rpy = fmaxf(MINVAL, 2.f * mu * mu * R1);       // pyramidal regulariser, impratio 1
+        const float sv[4] = {mu * v1, -mu * v1, mu * v2, -mu * v2}, su[4] = {mu * u1, -mu * u1, mu * u2, -mu * u2};
+        const float sw[4] = {mu * w1, -mu * w1, mu * w2, -mu * w2};
+        out.cG[s][0] = gnn; out.cG[s][1] = gn1; out.cG[s][2] = gn2; out.cG[s][3] = g11; out.cG[s][4] = g12; out.cG[s][5] = g22;
+        out.cR[s] = Rpy; out.isfoot[s] = Gs == 0 ? 1.f : 0.f;
         sfor<0, 4>([&](auto K) {
             constexpr int k = K;
-            cb[s][k] = cr[8 + k]; cf[s][k] = con[s] ? cr[12 + k] : 0.f;
+            const float aref = -kb.B * (vn + sv[k]) - kb.K * imp * dist;
+            out.cb[s][k] = un + su[k] - aref;
+            const float f = -((wn + sw[k]) - aref) / Rpy;
+            out.cf[s][k] = (s < nc && f > 0.f) ? f : 0.f;
+        });
+    });
+    out.nc = nc; out.nlim = nlim;
+}
+
+// Projected Gauss-Seidel in GRAM SPACE.  Lane r (0..12) owns basis vector r of both legs (A = left, B = right): 6 connect
+// rows, the limit row, and n, t1, t2 of two contact slots.  Instead of z~ the sweep carries rho_r = y~_r . z~ for every
+// basis vector; a change d of the coefficient of basis s moves it by G[r][s] d, with G = Y~ Y~^T formed once per substep
+// (19-term fma with a DPP row broadcast operand; the two legs only meet in the 6 pelvis columns).  A row update is then
+// broadcast + scalar update + 2 fma: no cross-lane reduction inside the 50 sweeps.  Order is leg-major as before (left: 6
+// equality rows, limit, contacts; then right), a pyramidal contact sweeps its 4 rows through the 3x3 Gram block.
+__device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, int pgs_iters) {
+    const int l = threadIdx.x & 15;
+    const float mu = S(F_FRIC);
+    LegRows A, B;
+    rows_lane<0>(S, A);
+    __builtin_amdgcn_sched_barrier(0);
+    rows_lane<1>(S, B);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- Gram columns of this lane's two rows
+    float GAA[13], GBB[13], GAB[13], GBA[13];      // GXY[s] = y~_(r,X) . y~_(s,Y)
+    sfor<0, 13>([&](auto Sx) {
+        constexpr int s = Sx;
+        float aa = 0.f, bb = 0.f, ab = 0.f, ba = 0.f;
+        sfor<0, 19>([&](auto C) {
+            constexpr int c = C;
+            const float sa = dpp<0x150 + s>(A.J[c]), sb = dpp<0x150 + s>(B.J[c]);
+            aa += A.J[c] * sa; bb += B.J[c] * sb;
+            if constexpr (c < 6) { ab += A.J[c] * sb; ba += B.J[c] * sa; }
+        });
+        // pin the sums here: LLVM otherwise sinks the fma chains into the conditional contact blocks that consume them while the
+        // (convergent) broadcasts stay put, and ~500 broadcast values get spilled to scratch in between
+        asm volatile("" : "+v"(aa), "+v"(bb), "+v"(ab), "+v"(ba));
+        GAA[s] = aa; GBB[s] = bb; GAB[s] = ab; GBA[s] = ba;
+    });
+    // ---- row scalars to every lane: c = b + R f, R, 1/(A+R), f
+    float ec[2][7], eR[2][7], eiA[2][7], ef[2][7];
+    sfor<0, 7>([&](auto Sx) {
+        constexpr int s = Sx;
+        eR[0][s] = dpp<0x150 + s>(A.R); eiA[0][s] = dpp<0x150 + s>(A.invA); ef[0][s] = dpp<0x150 + s>(A.f); ec[0][s] = dpp<0x150 + s>(A.b);
+        eR[1][s] = dpp<0x150 + s>(B.R); eiA[1][s] = dpp<0x150 + s>(B.invA); ef[1][s] = dpp<0x150 + s>(B.f); ec[1][s] = dpp<0x150 + s>(B.b);
+    });
+    constexpr int NCS = 2 * MAXC;
+    float cG[NCS][6], cR[NCS], cb[NCS][4], cf[NCS][4], ciA[NCS][4];
+    bool con[NCS];
+    sfor<0, NCS>([&](auto Sl) {
+        constexpr int s = Sl, leg = s / MAXC, j = s % MAXC;
+        const LegRows& Lr = leg ? B : A;
+        con[s] = j < Lr.nc;
+        sfor<0, 6>([&](auto K) { cG[s][K] = Lr.cG[j][K]; });
+        cR[s] = Lr.cR[j];
+        sfor<0, 4>([&](auto K) {
+            constexpr int k = K;
+            cb[s][k] = Lr.cb[j][k]; cf[s][k] = Lr.cf[j][k];
             const float sm = ((k & 1) ? -mu : mu), gnj = k < 2 ? cG[s][1] : cG[s][2], gjj = k < 2 ? cG[s][3] : cG[s][5];
             ciA[s][k] = __frcp_rn(cG[s][0] + 2.f * sm * gnj + mu * mu * gjj + cR[s]);      // A_kk + R of row n + s mu t_j
         });
     });
-    // ---- warm start: z~ = sum y~ f, dual cost 1/2 z~.z~ + sum f (R f / 2 + b)
-    float zA = 0.f, zB = 0.f, cost = 0.f;
-    sfor<0, 12>([&](auto R) { zA += ea[R] * ef[R]; zB += ep[R] * ef[R]; cost += ef[R] * (0.5f * eR[R] * ef[R] + eb[R]); });
-    sfor<0, 2>([&](auto Lg) { if (nlim[Lg]) { zA += la[Lg] * lf[Lg]; zB += lp[Lg] * lf[Lg]; cost += lf[Lg] * (0.5f * lR[Lg] * lf[Lg] + lb[Lg]); } });
+    const int nlim[2] = {A.nlim, B.nlim};
+    // ---- warm start (mj_fwdConstraint): coefficient F_s of every basis vector, rho = G F, dual cost 1/2 F.rho + sum f (R f / 2 + b)
+    float FA[13], FB[13];
+    sfor<0, 7>([&](auto Sx) { FA[Sx] = ef[0][Sx]; FB[Sx] = ef[1][Sx]; });
     sfor<0, NCS>([&](auto Sl) {
-        constexpr int s = Sl;
-        if (con[s]) {
-            const float dn = cf[s][0] + cf[s][1] + cf[s][2] + cf[s][3], d1 = mu * (cf[s][0] - cf[s][1]), d2 = mu * (cf[s][2] - cf[s][3]);
-            zA += na[s] * dn + t1a[s] * d1 + t2a[s] * d2; zB += np[s] * dn + t1p[s] * d1 + t2p[s] * d2;
-            sfor<0, 4>([&](auto K) { cost += cf[s][K] * (0.5f * cR[s] * cf[s][K] + cb[s][K]); });
-        }
+        constexpr int s = Sl, leg = s / MAXC, j = s % MAXC;
+        const float dn = cf[s][0] + cf[s][1] + cf[s][2] + cf[s][3], d1 = mu * (cf[s][0] - cf[s][1]), d2 = mu * (cf[s][2] - cf[s][3]);
+        float (&F)[13] = leg ? FB : FA;
+        F[7 + 3 * j] = dn; F[8 + 3 * j] = d1; F[9 + 3 * j] = d2;
     });
-    cost += 0.5f * red16(zA * zA + zB * zB);
+    float rA = 0.f, rB = 0.f, cost = 0.f;
+    sfor<0, 13>([&](auto Sx) { rA += GAA[Sx] * FA[Sx] + GAB[Sx] * FB[Sx]; rB += GBA[Sx] * FA[Sx] + GBB[Sx] * FB[Sx]; });
+    {
+        float own = 0.f;       // F of this lane's own rows times rho
+        sfor<0, 13>([&](auto Sx) { if (l == Sx) own = FA[Sx] * rA + FB[Sx] * rB; });
+        cost = 0.5f * red16(own);
+    }
+    sfor<0, 2>([&](auto Lg) { sfor<0, 7>([&](auto Sx) { cost += ef[Lg][Sx] * (0.5f * eR[Lg][Sx] * ef[Lg][Sx] + ec[Lg][Sx]); }); });
+    sfor<0, NCS>([&](auto Sl) { sfor<0, 4>([&](auto K) { cost += cf[Sl][K] * (0.5f * cR[Sl] * cf[Sl][K] + cb[Sl][K]); }); });
     if (cost > 0.f) {
-        zA = zB = 0.f;
-        sfor<0, 12>([&](auto R) { ef[R] = 0.f; });
-        lf[0] = lf[1] = 0.f;
+        rA = rB = 0.f;
+        sfor<0, 2>([&](auto Lg) { sfor<0, 7>([&](auto Sx) { ef[Lg][Sx] = 0.f; }); });
         sfor<0, NCS>([&](auto Sl) { sfor<0, 4>([&](auto K) { cf[Sl][K] = 0.f; }); });
     }
+    sfor<0, 2>([&](auto Lg) { sfor<0, 7>([&](auto Sx) { ec[Lg][Sx] += eR[Lg][Sx] * ef[Lg][Sx]; }); });      // c = b + R f
+    // ---- sweeps
     for (int it = 0; it < pgs_iters; ++it) {
         sfor<0, 2>([&](auto Lg) {
             constexpr int leg = Lg;
-            sfor<0, 6>([&](auto Rw) {
-                constexpr int r = 6 * leg + Rw;
-                const float t = red16(ea[r] * zA + ep[r] * zB);
-                const float df = -(t + eb[r] + eR[r] * ef[r]) * eiA[r];
-                ef[r] += df;
-                zA += ea[r] * df; zB += ep[r] * df;
+            const float (&Ga)[13] = leg ? GAB : GAA;      // how a coefficient of this leg's basis s moves rho_A, rho_B
+            const float (&Gb)[13] = leg ? GBB : GBA;
+            sfor<0, 6>([&](auto Sx) {
+                constexpr int s = Sx;
+                const float t = (leg ? dpp<0x150 + s>(rB) : dpp<0x150 + s>(rA)) + ec[leg][s];
+                const float df = -t * eiA[leg][s];
+                ec[leg][s] += eR[leg][s] * df; ef[leg][s] += df;
+                rA += Ga[s] * df; rB += Gb[s] * df;
             });
             if (nlim[leg]) {
-                const float t = red16(la[leg] * zA + lp[leg] * zB);
-                float fn = lf[leg] - (t + lb[leg] + lR[leg] * lf[leg]) * liA[leg];
+                const float t = (leg ? dpp<0x150 + 6>(rB) : dpp<0x150 + 6>(rA)) + ec[leg][6];
+                float fn = ef[leg][6] - t * eiA[leg][6];
                 fn = fn < 0.f ? 0.f : fn;
-                const float df = fn - lf[leg];
-                lf[leg] = fn;
-                zA += la[leg] * df; zB += lp[leg] * df;
+                const float df = fn - ef[leg][6];
+                ef[leg][6] = fn; ec[leg][6] += eR[leg][6] * df;
+                rA += Ga[6] * df; rB += Gb[6] * df;
             }
             sfor<0, MAXC>([&](auto Sl) {
-                constexpr int s = leg * MAXC + Sl;
+                constexpr int j = Sl, s = leg * MAXC + j, ln = 7 + 3 * j;
                 if (con[s]) {
-                    float rn = red16(na[s] * zA + np[s] * zB), r1 = red16(t1a[s] * zA + t1p[s] * zB), r2 = red16(t2a[s] * zA + t2p[s] * zB);
+                    float rn = leg ? dpp<0x150 + ln>(rB) : dpp<0x150 + ln>(rA), r1 = leg ? dpp<0x150 + ln + 1>(rB) : dpp<0x150 + ln + 1>(rA),
+                          r2 = leg ? dpp<0x150 + ln + 2>(rB) : dpp<0x150 + ln + 2>(rA);
                     const float gnn = cG[s][0], gn1 = cG[s][1], gn2 = cG[s][2], g11 = cG[s][3], g12 = cG[s][4], g22 = cG[s][5];
                     float sdn = 0.f, sd1 = 0.f, sd2 = 0.f;
                     sfor<0, 4>([&](auto K) {
@@ -284,15 +309,39 @@ __device__ __forceinline__ void stage_pgs_lane(const St& S, float* rows, int pgs
                         else { rn += df * (gnn + sm * gn2); r1 += df * (gn1 + sm * g12); r2 += df * (gn2 + sm * g22); sd2 += sm * df; }
                         sdn += df;
                     });
-                    zA += na[s] * sdn + t1a[s] * sd1 + t2a[s] * sd2;
-                    zB += np[s] * sdn + t1p[s] * sd1 + t2p[s] * sd2;
+                    rA += Ga[ln] * sdn + Ga[ln + 1] * sd1 + Ga[ln + 2] * sd2;
+                    rB += Gb[ln] * sdn + Gb[ln + 1] * sd1 + Gb[ln + 2] * sd2;
                 }
             });
         });
     }
-    S.W(WK_ZT + (l < 13 ? 6 + l : l - 13)) = zA; S.W(WK_ZT + (l < 13 ? 19 + l : l - 10)) = zB;
-    // contact forces back to the row store (foot-force readout in the finish stage)
-    if (l == 0) sfor<0, NCS>([&](auto Sl) { if (con[Sl]) sfor<0, 4>([&](auto K) { rows[R4_CON + R4_CONSZ * Sl + 12 + K] = cf[Sl][K]; }); });
+    // ---- z~ = sum_r y~_r F_r back to the dof layout of the finish stage
+    float ownA = 0.f, ownB = 0.f;
+    sfor<0, 7>([&](auto Sx) { if (l == Sx) { ownA = ef[0][Sx]; ownB = ef[1][Sx]; } });
+    sfor<0, NCS>([&](auto Sl) {
+        constexpr int s = Sl, leg = s / MAXC, ln = 7 + 3 * (s % MAXC);
+        const float dn = cf[s][0] + cf[s][1] + cf[s][2] + cf[s][3], d1 = mu * (cf[s][0] - cf[s][1]), d2 = mu * (cf[s][2] - cf[s][3]);
+        float& own = leg ? ownB : ownA;
+        if (l == ln) own = dn;
+        if (l == ln + 1) own = d1;
+        if (l == ln + 2) own = d2;
+    });
+    if (l >= 13) ownA = ownB = 0.f;
+    sfor<0, 19>([&](auto C) {
+        constexpr int c = C;
+        if constexpr (c < 6) { const float z = red16(A.J[c] * ownA + B.J[c] * ownB); if (l == 0) S.W(WK_ZT + c) = z; }
+        else { const float za = red16(A.J[c] * ownA), zb = red16(B.J[c] * ownB); if (l == 0) { S.W(WK_ZT + c) = za; S.W(WK_ZT + c + 13) = zb; } }
+    });
+    if (l == 0) {
+        S.W(WK_MISC + 0) = (float)A.nc; S.W(WK_MISC + 1) = (float)B.nc; S.W(WK_MISC + 2) = (float)A.nlim; S.W(WK_MISC + 3) = (float)B.nlim;
+        // contact forces to the row store (foot-force readout in the finish stage)
+        sfor<0, NCS>([&](auto Sl) {
+            constexpr int s = Sl, leg = s / MAXC, j = s % MAXC;
+            float* cr = rows + R4_CON + R4_CONSZ * s;
+            cr[7] = (leg ? B : A).isfoot[j];
+            sfor<0, 4>([&](auto K) { cr[12 + K] = cf[s][K]; });
+        });
+    }
 }
 
 }  // namespace c4

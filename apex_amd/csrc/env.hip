@@ -153,15 +153,9 @@ __device__ __noinline__ void stage3a_warm(St S) {
 }
 #if APX_GEN == 4
 __device__ __forceinline__ float* rows4() { return (float*)(apx_lds4 + ((threadIdx.x >> 4) * L4_ES + L4_ROWS) / 4); }
-template <int LEG>
-__device__ __noinline__ void stage2b_rows_lane(St S) {
+__device__ __noinline__ void stage3_rows_pgs_lane(St S, int pgs_iters) {
     PROF_START();
-    c4::stage_rows_lane<LEG>(S, rows4());
-    PROF(5 + LEG);
-}
-__device__ __noinline__ void stage3_pgs_lane(St S, int pgs_iters) {
-    PROF_START();
-    c4::stage_pgs_lane(S, rows4(), pgs_iters);
+    c4::stage_rows_pgs_lane(S, rows4(), pgs_iters);
     PROF(3);
 }
 #else
@@ -204,9 +198,7 @@ __device__ __forceinline__ void sim_step_pd(const St& S, int pgs_iters, int mode
     const bool lead = (threadIdx.x & 15) == 0;
     if (lead) { stage1_io_tree(S, mode); stage2a_factor(S); }
     __syncthreads();
-    stage2b_rows_lane<0>(S); stage2b_rows_lane<1>(S);
-    __syncthreads();
-    stage3_pgs_lane(S, pgs_iters);
+    stage3_rows_pgs_lane(S, pgs_iters);
     __syncthreads();
     if (lead) stage4_finish(S, mode);
     __syncthreads();
