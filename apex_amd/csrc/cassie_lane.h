@@ -45,6 +45,283 @@ template <int LEG> constexpr unsigned chain_mask(int body) {
     return m;
 }
 
+// ------------------------------------------------------------------------------------------------ tree stage
+// Kinematics, velocities, RNE bias forces, composite inertias and the mass matrix, lane-parallel over the 12 bodies of a
+// leg (lane b: left body 2+b in slot 0, right body 14+b in slot 1); the pelvis is computed by every lane.  Bodies are
+// numbered depth-first, so a subtree is the contiguous range [b, b + ndesc].  Same formulas as c3::visit (all spatial
+// quantities about the pelvis origin o, world axes); results go to the same workspace slots (WK_M in MuJoCo's
+// ancestor-chain layout, WK_CDOF, WK_SMOOTH, WK_PTS, WK_PEL, F_FWD foot pose).
+constexpr int WK_CTRL = WK_QACC;                        // actuator-side torques from the io stage (10)
+constexpr int XB_SZ = 20;                               // exchange record per body: pos3 quat4 vel6 acc6 | crb10 frc6
+constexpr unsigned long long nib(int a0, int a1, int a2, int a3, int a4, int a5, int a6, int a7, int a8, int a9, int a10, int a11) {
+    return (unsigned long long)a0 | (unsigned long long)a1 << 4 | (unsigned long long)a2 << 8 | (unsigned long long)a3 << 12 |
+           (unsigned long long)a4 << 16 | (unsigned long long)a5 << 20 | (unsigned long long)a6 << 24 | (unsigned long long)a7 << 28 |
+           (unsigned long long)a8 << 32 | (unsigned long long)a9 << 36 | (unsigned long long)a10 << 40 | (unsigned long long)a11 << 44;
+}
+// leg-local body b = 0..11: hip-roll, hip-yaw, hip-pitch, achilles-rod, knee, knee-spring, shin, tarsus, heel-spring, foot-crank, plantar-rod, foot
+constexpr unsigned long long TB_DEPTH = nib(1, 2, 3, 4, 4, 5, 5, 6, 7, 7, 8, 7);         // pelvis = 0
+constexpr unsigned long long TB_PARENT = nib(15, 0, 1, 2, 2, 4, 4, 6, 7, 7, 9, 7);       // leg-local, 15 = pelvis
+constexpr unsigned long long TB_NDESC = nib(11, 10, 9, 0, 7, 0, 5, 4, 0, 1, 0, 0);
+constexpr unsigned long long TB_QOFF = nib(0, 1, 2, 3, 7, 15, 8, 9, 10, 11, 12, 13);     // qpos offset inside the leg block (15 = no joint)
+constexpr unsigned long long TB_DOFF = nib(0, 1, 2, 3, 6, 15, 7, 8, 9, 10, 11, 12);      // dof offset inside the leg block
+// leg-local dof k = 0..12 -> leg-local body
+constexpr unsigned long long TD_BODY = nib(0, 1, 2, 3, 3, 3, 4, 6, 7, 8, 9, 10) | (11ull << 48);
+constexpr unsigned long long TD_PDOF = nib(15, 0, 1, 2, 3, 4, 2, 6, 7, 8, 8, 10) | (8ull << 48);        // parent dof inside the leg (15 = pelvis)
+constexpr unsigned long long TD_DEPTH = nib(7, 8, 9, 10, 11, 12, 10, 11, 12, 13, 13, 14) | (13ull << 48);   // = ct_dof_depth (6 pelvis ancestors included)
+static_assert(ct_dof_depth[6 + 11] == 14 && ct_dof_depth[6 + 12] == 13 && ct_dof_depth[6 + 6] == 10 && ct_dof_anc[16 * 17 + 1] == 16 && ct_dof_anc[16 * 18 + 1] == 14, "dof chains");
+__device__ __forceinline__ int nibble(unsigned long long t, int i) { return (int)((t >> (4 * i)) & 15ull); }
+static_assert(ct_body_parent[8] == 6 && ct_body_parent[13] == 9 && ct_body_parent[12] == 11 && ct_body_dofadr[8] == 13 && ct_jnt_qposadr[9] == 15 &&
+              ct_body_dofadr[13] == 18 && ct_jnt_qposadr[14] == 20 && ct_body_dofnum[5] == 3 && ct_body_dofnum[7] == 0, "leg topology tables");
+
+struct XRec { V3 pos; Q4 quat; SV vel, acc; };
+__device__ __forceinline__ XRec xb_read(const float* xb, int body) {
+    const float* p = xb + XB_SZ * body;
+    return {{p[0], p[1], p[2]}, {p[3], p[4], p[5], p[6]}, {{p[7], p[8], p[9]}, {p[10], p[11], p[12]}}, {{p[13], p[14], p[15]}, {p[16], p[17], p[18]}}};
+}
+__device__ __forceinline__ void xb_write(float* xb, int body, const XRec& r) {
+    float* p = xb + XB_SZ * body;
+    p[0] = r.pos.x; p[1] = r.pos.y; p[2] = r.pos.z; p[3] = r.quat.w; p[4] = r.quat.x; p[5] = r.quat.y; p[6] = r.quat.z;
+    p[7] = r.vel.a.x; p[8] = r.vel.a.y; p[9] = r.vel.a.z; p[10] = r.vel.l.x; p[11] = r.vel.l.y; p[12] = r.vel.l.z;
+    p[13] = r.acc.a.x; p[14] = r.acc.a.y; p[15] = r.acc.a.z; p[16] = r.acc.l.x; p[17] = r.acc.l.y; p[18] = r.acc.l.z;
+}
+// spatial inertia of a body about o in world axes + its RNE force (c3::visit)
+__device__ __forceinline__ void body_inertia_force(const M3& R, V3 pos, V3 o, const float (&Ib)[9], V3 ipos, float m, const SV& vel, const SV& acc, SI& c, SV& frc) {
+    float RI[9], Iw[9];
+    sfor<0, 3>([&](auto I) { sfor<0, 3>([&](auto K) { RI[3 * I + K] = R.m[3 * I] * Ib[K] + R.m[3 * I + 1] * Ib[3 + K] + R.m[3 * I + 2] * Ib[6 + K]; }); });
+    sfor<0, 3>([&](auto I) { sfor<0, 3>([&](auto K) { if constexpr (K >= I) Iw[3 * I + K] = RI[3 * I] * R.m[3 * K] + RI[3 * I + 1] * R.m[3 * K + 1] + RI[3 * I + 2] * R.m[3 * K + 2]; }); });
+    const V3 r = pos + mul(R, ipos) - o;
+    const float rr = dot(r, r);
+    c.m = m; c.h = r * m;
+    c.I[0] = Iw[0] + m * (rr - r.x * r.x); c.I[1] = Iw[4] + m * (rr - r.y * r.y); c.I[2] = Iw[8] + m * (rr - r.z * r.z);
+    c.I[3] = Iw[1] - m * r.x * r.y; c.I[4] = Iw[2] - m * r.x * r.z; c.I[5] = Iw[5] - m * r.y * r.z;
+    frc = imul(c, acc) + crossForce(vel, imul(c, vel));
+}
+
+__device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
+    const int l = threadIdx.x & 15;
+    const int lb = l < 12 ? l : 11;                                     // lanes 12..15 shadow the foot lane (their body results are not stored)
+    const bool bl = l < 12;
+    // ---- per-lane model constants of the two bodies (left, right)
+    int body[2], qadr[2], dadr[2];
+    const int depth = nibble(TB_DEPTH, lb), par = nibble(TB_PARENT, lb), ndesc = nibble(TB_NDESC, lb), qoff = nibble(TB_QOFF, lb), doff = nibble(TB_DOFF, lb);
+    const bool hasj = qoff != 15, ball = lb == 3;
+    V3 bpos[2], ipos[2]; Q4 bquat[2]; float Ib[2][9], mass[2];
+    sfor<0, 2>([&](auto Sd) {
+        constexpr int sd = Sd;
+        body[sd] = 2 + 12 * sd + lb; qadr[sd] = 7 + 14 * sd + qoff; dadr[sd] = 6 + 13 * sd + doff;
+        const int b = body[sd];
+        bpos[sd] = {cm_body_pos[3 * b], cm_body_pos[3 * b + 1], cm_body_pos[3 * b + 2]};
+        ipos[sd] = {cm_body_ipos[3 * b], cm_body_ipos[3 * b + 1], cm_body_ipos[3 * b + 2]};
+        bquat[sd] = {cm_body_quat[4 * b], cm_body_quat[4 * b + 1], cm_body_quat[4 * b + 2], cm_body_quat[4 * b + 3]};
+        sfor<0, 9>([&](auto K) { Ib[sd][K] = cm_body_inertia[9 * b + K]; });
+        mass[sd] = S(F_MASS + b);
+    });
+    const float jref = lb == 4 ? ct_jnt_ref[8] : lb == 7 ? ct_jnt_ref[10] : 0.f;          // knee, tarsus
+    static_assert(ct_jnt_ref[19] == ct_jnt_ref[8] && ct_jnt_ref[21] == ct_jnt_ref[10] && ct_jnt_ref[9] == 0.f, "joint refs");
+    // ---- pelvis (every lane)
+    const V3 o = {S(F_QPOS), S(F_QPOS + 1), S(F_QPOS + 2)};
+    XRec pel;
+    pel.pos = o;
+    pel.quat = qnormalize(Q4{S(F_QPOS + 3), S(F_QPOS + 4), S(F_QPOS + 5), S(F_QPOS + 6)});
+    const M3 pmat = q2m(pel.quat);
+    SV pc[6] = {{{0, 0, 0}, {1, 0, 0}}, {{0, 0, 0}, {0, 1, 0}}, {{0, 0, 0}, {0, 0, 1}}, {col(pmat, 0), {0, 0, 0}}, {col(pmat, 1), {0, 0, 0}}, {col(pmat, 2), {0, 0, 0}}};
+    {
+        SV v = {{0, 0, 0}, {S(F_QVEL), S(F_QVEL + 1), S(F_QVEL + 2)}};
+        SV a = {{0, 0, 0}, {0, 0, GRAV}};
+        const SV vp = v;
+        sfor<3, 6>([&](auto D) { const float qd = S(F_QVEL + D); a = a + crossMotion(vp, pc[D]) * qd; v = v + pc[D] * qd; });
+        pel.vel = v; pel.acc = a;
+    }
+    if (l == 0) {
+        xb_write(xb, 1, pel);
+        sfor<0, 6>([&](auto D) {
+            S.W(WK_CDOF + 6 * D) = pc[D].a.x; S.W(WK_CDOF + 6 * D + 1) = pc[D].a.y; S.W(WK_CDOF + 6 * D + 2) = pc[D].a.z;
+            S.W(WK_CDOF + 6 * D + 3) = pc[D].l.x; S.W(WK_CDOF + 6 * D + 4) = pc[D].l.y; S.W(WK_CDOF + 6 * D + 5) = pc[D].l.z;
+        });
+        S.W(WK_PEL + 0) = pel.acc.a.x; S.W(WK_PEL + 1) = pel.acc.a.y; S.W(WK_PEL + 2) = pel.acc.a.z;
+        S.W(WK_PEL + 3) = pel.acc.l.x; S.W(WK_PEL + 4) = pel.acc.l.y; S.W(WK_PEL + 5) = pel.acc.l.z;
+        S.W(WK_PEL + 6) = pel.vel.a.x; S.W(WK_PEL + 7) = pel.vel.a.y; S.W(WK_PEL + 8) = pel.vel.a.z;
+        S.W(WK_PEL + 9) = pel.vel.l.x; S.W(WK_PEL + 10) = pel.vel.l.y; S.W(WK_PEL + 11) = pel.vel.l.z;
+        sfor<0, 9>([&](auto K) { S.W(WK_PEL + 12 + K) = pmat.m[K]; });
+    }
+    // ---- local joint rotation and joint velocity of this lane's bodies
+    Q4 lq[2]; float qd0[2];
+    sfor<0, 2>([&](auto Sd) {
+        constexpr int sd = Sd;
+        Q4 jq = {1.f, 0.f, 0.f, 0.f};
+        if (hasj) {
+            if (ball) jq = qnormalize(Q4{S(F_QPOS + qadr[sd]), S(F_QPOS + qadr[sd] + 1), S(F_QPOS + qadr[sd] + 2), S(F_QPOS + qadr[sd] + 3)});
+            else { float sn, cs; __sincosf(0.5f * (S(F_QPOS + qadr[sd]) - jref), &sn, &cs); jq = {cs, 0.f, 0.f, sn}; }
+        }
+        lq[sd] = qmul(bquat[sd], jq);
+        qd0[sd] = (hasj && !ball) ? S(F_QVEL + dadr[sd]) : 0.f;
+    });
+    __syncthreads();
+    // ---- level sweep: a body at depth d is final after iteration d (its parent was final after d-1)
+    for (int level = 1; level <= 8; ++level) {
+        sfor<0, 2>([&](auto Sd) {
+            constexpr int sd = Sd;
+            const XRec P = xb_read(xb, par == 15 ? 1 : 2 + 12 * sd + par);
+            const M3 Pm = q2m(P.quat);
+            XRec me;
+            me.pos = P.pos + mul(Pm, bpos[sd]);
+            me.quat = qnormalize(qmul(P.quat, lq[sd]));
+            const M3 mat = q2m(me.quat);
+            const V3 ax = col(mat, 2);
+            const SV cd = {ax, cross(ax, o - me.pos)};            // hinge axis = local z (ball joints: leaf body, fixed up below)
+            me.acc = P.acc + crossMotion(P.vel, cd) * qd0[sd];
+            me.vel = P.vel + cd * qd0[sd];
+            if (bl && depth == level) xb_write(xb, body[sd], me);
+        });
+        __syncthreads();
+    }
+    // ---- own pose, motion axes, velocity / acceleration
+    M3 mat[2]; V3 pos[2]; Q4 quat[2]; SV vel[2], acc[2]; SV cdof[2][3];
+    sfor<0, 2>([&](auto Sd) {
+        constexpr int sd = Sd;
+        XRec me = xb_read(xb, body[sd]);
+        mat[sd] = q2m(me.quat); pos[sd] = me.pos; quat[sd] = me.quat;
+        const V3 r = o - me.pos;
+        sfor<0, 3>([&](auto K) { const V3 ax = col(mat[sd], K); cdof[sd][K] = {ax, cross(ax, r)}; });
+        if (ball) {                                                  // 3 dofs: axes x, y, z in order
+            const XRec P = xb_read(xb, 2 + 12 * sd + par);
+            SV v = P.vel, a = P.acc;
+            const SV vp = v;
+            sfor<0, 3>([&](auto K) { const float qd = S(F_QVEL + dadr[sd] + K); a = a + crossMotion(vp, cdof[sd][K]) * qd; v = v + cdof[sd][K] * qd; });
+            me.vel = v; me.acc = a;
+        }
+        vel[sd] = me.vel; acc[sd] = me.acc;
+        if (bl && hasj) {
+            if (ball) sfor<0, 3>([&](auto K) {
+                float* c = (float*)&S.W(WK_CDOF + 6 * (dadr[sd] + K));
+                c[0] = cdof[sd][K].a.x; c[1] = cdof[sd][K].a.y; c[2] = cdof[sd][K].a.z; c[3] = cdof[sd][K].l.x; c[4] = cdof[sd][K].l.y; c[5] = cdof[sd][K].l.z;
+            });
+            else {
+                float* c = (float*)&S.W(WK_CDOF + 6 * dadr[sd]);
+                c[0] = cdof[sd][2].a.x; c[1] = cdof[sd][2].a.y; c[2] = cdof[sd][2].a.z; c[3] = cdof[sd][2].l.x; c[4] = cdof[sd][2].l.y; c[5] = cdof[sd][2].l.z;
+            }
+        }
+    });
+    __syncthreads();                                                  // every lane is done reading poses: the records become (crb, frc)
+    // ---- inertia + RNE force of the own bodies and of the pelvis
+    SI crb[2]; SV frc[2];
+    sfor<0, 2>([&](auto Sd) {
+        constexpr int sd = Sd;
+        body_inertia_force(mat[sd], pos[sd], o, Ib[sd], ipos[sd], mass[sd], vel[sd], acc[sd], crb[sd], frc[sd]);
+        if (bl) {
+            float* p = xb + XB_SZ * body[sd];
+            p[0] = crb[sd].m; p[1] = crb[sd].h.x; p[2] = crb[sd].h.y; p[3] = crb[sd].h.z;
+            sfor<0, 6>([&](auto K) { p[4 + K] = crb[sd].I[K]; });
+            p[10] = frc[sd].a.x; p[11] = frc[sd].a.y; p[12] = frc[sd].a.z; p[13] = frc[sd].l.x; p[14] = frc[sd].l.y; p[15] = frc[sd].l.z;
+        }
+    });
+    SI pcrb; SV pfrc;
+    {
+        float Ipel[9];
+        sfor<0, 9>([&](auto K) { Ipel[K] = ct_body_inertia[9 + K]; });
+        body_inertia_force(pmat, o, o, Ipel, cv3<1>(ct_body_ipos), S(F_MASS + 1), pel.vel, pel.acc, pcrb, pfrc);
+    }
+    __syncthreads();
+    // ---- subtree sums (composite inertia, subtree force): descendants are the next ndesc bodies
+    sfor<0, 2>([&](auto Sd) {
+        constexpr int sd = Sd;
+        for (int i = 1; i <= 11; ++i) {
+            if (i <= ndesc) {
+                const float* p = xb + XB_SZ * (body[sd] + i);
+                crb[sd].m += p[0]; crb[sd].h = crb[sd].h + V3{p[1], p[2], p[3]};
+                sfor<0, 6>([&](auto K) { crb[sd].I[K] += p[4 + K]; });
+                frc[sd].a = frc[sd].a + V3{p[10], p[11], p[12]}; frc[sd].l = frc[sd].l + V3{p[13], p[14], p[15]};
+            }
+        }
+    });
+    __syncthreads();
+    sfor<0, 2>([&](auto Sd) {
+        constexpr int sd = Sd;
+        if (bl) {
+            float* p = xb + XB_SZ * body[sd];
+            p[0] = crb[sd].m; p[1] = crb[sd].h.x; p[2] = crb[sd].h.y; p[3] = crb[sd].h.z;
+            sfor<0, 6>([&](auto K) { p[4 + K] = crb[sd].I[K]; });
+            p[10] = frc[sd].a.x; p[11] = frc[sd].a.y; p[12] = frc[sd].a.z; p[13] = frc[sd].l.x; p[14] = frc[sd].l.y; p[15] = frc[sd].l.z;
+        }
+    });
+    __syncthreads();
+    {   // pelvis composite = own + the two hip-roll subtrees
+        sfor<0, 2>([&](auto Sd) {
+            const float* p = xb + XB_SZ * (2 + 12 * Sd);
+            pcrb.m += p[0]; pcrb.h = pcrb.h + V3{p[1], p[2], p[3]};
+            sfor<0, 6>([&](auto K) { pcrb.I[K] += p[4 + K]; });
+            pfrc.a = pfrc.a + V3{p[10], p[11], p[12]}; pfrc.l = pfrc.l + V3{p[13], p[14], p[15]};
+        });
+    }
+    // ---- anchor points, capsule ends, foot pose (body lanes that own them)
+    sfor<0, 2>([&](auto Sd) {
+        constexpr int sd = Sd, base = WK_PTS + 30 * sd;
+        auto put = [&](int off, V3 p) { S.W(off) = p.x; S.W(off + 1) = p.y; S.W(off + 2) = p.z; };
+        auto cap = [&](int off, V3 cpos, V3 cax, float half) {
+            const V3 c = pos[sd] + mul(mat[sd], cpos), ax = mul(mat[sd], cax) * half;
+            put(off, c + ax); put(off + 3, c - ax);
+        };
+        static_assert(ct_eq_body1[0] == 12 && ct_eq_body2[0] == 13 && ct_eq_body1[1] == 5 && ct_eq_body2[1] == 10, "connect bodies");
+        static_assert(ct_geom_body[0] == 13 && ct_geom_body[2] == 9 && ct_geom_body[4] == 8, "capsule bodies");
+        if (l == 10) put(base + 0, pos[sd] + mul(mat[sd], cv3<2 * sd>(ct_eq_anchor1)));            // plantar-rod: connect 0, anchor 1
+        if (l == 11) {                                                                             // foot: connect 0 anchor 2, capsule, pose
+            put(base + 3, pos[sd] + mul(mat[sd], cv3<2 * sd>(ct_eq_anchor2)));
+            cap(base + 12, cv3<0 + sd>(ct_geom_pos), cv3<0 + sd>(ct_geom_axis), ct_geom_half[0 + sd]);
+        }
+        if (l == 3) put(base + 6, pos[sd] + mul(mat[sd], cv3<2 * sd + 1>(ct_eq_anchor1)));         // achilles-rod: connect 1, anchor 1
+        if (l == 8) put(base + 9, pos[sd] + mul(mat[sd], cv3<2 * sd + 1>(ct_eq_anchor2)));         // heel-spring: connect 1, anchor 2
+        if (l == 7) cap(base + 18, cv3<2 + sd>(ct_geom_pos), cv3<2 + sd>(ct_geom_axis), ct_geom_half[2 + sd]);      // tarsus capsule
+        if (l == 6) cap(base + 24, cv3<4 + sd>(ct_geom_pos), cv3<4 + sd>(ct_geom_axis), ct_geom_half[4 + sd]);      // shin capsule
+    });
+    // ---- mass-matrix rows and bias forces, dof lanes: k = 0..12 -> leg dof k of both legs; 13..15 -> pelvis dofs (l-13, l-10)
+    sfor<0, 2>([&](auto Sd) {
+        constexpr int sd = Sd;
+        const int d = l < 13 ? 6 + 13 * sd + l : (l - 13) + 3 * sd;
+        const int db = l < 13 ? 2 + 12 * sd + (l == 12 ? 11 : nibble(TD_BODY, l)) : 1;
+        SI c; SV fsub;
+        if (l < 13) {
+            const float* p = xb + XB_SZ * db;
+            c.m = p[0]; c.h = {p[1], p[2], p[3]};
+            sfor<0, 6>([&](auto K) { c.I[K] = p[4 + K]; });
+            fsub = {{p[10], p[11], p[12]}, {p[13], p[14], p[15]}};
+        } else { c = pcrb; fsub = pfrc; }
+        const float* cp = (const float*)&S.W(WK_CDOF + 6 * d);
+        const SV cd = {{cp[0], cp[1], cp[2]}, {cp[3], cp[4], cp[5]}};
+        const SV f = imul(c, cd);
+        const int dep = l < 13 ? (l == 12 ? 13 : nibble(TD_DEPTH, l)) : d + 1, madr = cm_dof_madr[d];
+        S.W(WK_M + madr) = sdot(cd, f) + cm_dof_armature[d];
+        int cur = l;                                                  // walk the ancestor chain: leg dofs first, then pelvis dofs 5..0
+        sfor<1, 14>([&](auto An) {
+            constexpr int a = An;
+            if (a < dep) {
+                int ad;
+                if (a < dep - 6) { cur = cur == 12 ? 8 : nibble(TD_PDOF, cur); ad = 6 + 13 * sd + cur; } else ad = dep - 1 - a;
+                const float* ap = (const float*)&S.W(WK_CDOF + 6 * ad);
+                S.W(WK_M + madr + a) = sdot(SV{{ap[0], ap[1], ap[2]}, {ap[3], ap[4], ap[5]}}, f);
+            }
+        });
+        // qfrc_smooth = passive - bias + actuation
+        const int k = l;       // leg-local dof
+        float fs = -S(F_DAMP + d) * S(F_QVEL + d) - sdot(cd, fsub);
+        if (l == 7) fs -= ct_jnt_stiffness[9] * S(F_QPOS + ct_jnt_qposadr[9] + 14 * sd);            // shin spring
+        if (l == 9) fs -= ct_jnt_stiffness[11] * S(F_QPOS + ct_jnt_qposadr[11] + 14 * sd);          // heel spring
+        static_assert(ct_jnt_stiffness[20] == ct_jnt_stiffness[9] && ct_jnt_stiffness[22] == ct_jnt_stiffness[11] && ct_jnt_qposadr[20] == ct_jnt_qposadr[9] + 14, "springs");
+        const int u = k == 0 ? 0 : k == 1 ? 1 : k == 2 ? 2 : k == 6 ? 3 : k == 12 ? 4 : -1;       // actuated dofs: hip roll, yaw, pitch, knee, foot
+        if (u >= 0) {
+            const int ua = u + 5 * sd;
+            const float cmax = cm_act_ctrlmax[ua];
+            fs += cm_act_gear[ua] * fminf(fmaxf(S.W(WK_CTRL + ua), -cmax), cmax);
+        }
+        S.W(WK_SMOOTH + d) = fs;
+    });
+    // ---- foot pose for the reward / foot velocity (cassie.py:328-331,426-427)
+    if (l == 11) sfor<0, 2>([&](auto Sd) {
+        constexpr int sd = Sd;
+        S(F_FWD + 2 + 4 * sd) = quat[sd].w; S(F_FWD + 3 + 4 * sd) = quat[sd].x; S(F_FWD + 4 + 4 * sd) = quat[sd].y; S(F_FWD + 5 + 4 * sd) = quat[sd].z;
+        S(F_FWD + 10 + 3 * sd) = pos[sd].x; S(F_FWD + 11 + 3 * sd) = pos[sd].y; S(F_FWD + 12 + 3 * sd) = pos[sd].z - 0.0550841220316708f;
+    });
+}
+
 // Constraint rows of leg LEG, one row vector per lane: Jacobian from the stored motion axes, dots against
 // qvel / qacc_smooth / qacc_warmstart on the raw row, whitening y~ = D^-1/2 L^-T J^T (L streamed from LDS, uniform
 // addresses), row scalars.  Same arithmetic as c3::build_rows3, except that a connect row takes the common ancestors of

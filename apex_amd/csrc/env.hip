@@ -42,6 +42,7 @@ __constant__ float kFir[9] = {2727.f, 534.f, -2658.f, -795.f, 72.f, 110.f, 19.f,
 #define PI_F 3.14159265358979323846f
 
 #if APX_GEN == 4
+__device__ __forceinline__ float* rows4() { return (float*)(apx_lds4 + ((threadIdx.x >> 4) * L4_ES + L4_ROWS) / 4); }
 __device__ __forceinline__ c2::Lds row_store() { return c2::Lds{apx_lds4 + ((threadIdx.x >> 4) * L4_ES + L4_ROWS) / 4}; }
 #else
 __device__ __forceinline__ c2::Lds row_store() { return c2::Lds{apx_lds4 + (threadIdx.x & 63)}; }
@@ -132,9 +133,19 @@ __device__ __noinline__ void stage1_io_tree(St S, int mode) {
     }
     }
     PROF(0);
+#if APX_GEN == 4
+    for (int u = 0; u < 10; ++u) S.W(c4::WK_CTRL + u) = ctrl[u];
+}
+__device__ __noinline__ void stage1b_tree_lane(St S) {
+    PROF_START();
+    c4::stage_tree_lane(S, rows4());
+    PROF(1);
+}
+#else
     c3::stage_tree(S, ctrl);
     PROF(1);
 }
+#endif
 __device__ __noinline__ void stage2a_factor(St S) {
     PROF_START();
     c3::stage_factor(S);
@@ -152,7 +163,6 @@ __device__ __noinline__ void stage3a_warm(St S) {
     c3::stage_warm_check(S, Y);
 }
 #if APX_GEN == 4
-__device__ __forceinline__ float* rows4() { return (float*)(apx_lds4 + ((threadIdx.x >> 4) * L4_ES + L4_ROWS) / 4); }
 __device__ __noinline__ void stage3_rows_pgs_lane(St S, int pgs_iters) {
     PROF_START();
     c4::stage_rows_pgs_lane(S, rows4(), pgs_iters);
@@ -196,7 +206,11 @@ __device__ __noinline__ void stage4_finish(St S, int mode) {
 // row's lead lane; every call site is reached by all lanes.
 __device__ __forceinline__ void sim_step_pd(const St& S, int pgs_iters, int mode) {
     const bool lead = (threadIdx.x & 15) == 0;
-    if (lead) { stage1_io_tree(S, mode); stage2a_factor(S); }
+    if (lead) stage1_io_tree(S, mode);
+    __syncthreads();
+    stage1b_tree_lane(S);
+    __syncthreads();
+    if (lead) stage2a_factor(S);
     __syncthreads();
     stage3_rows_pgs_lane(S, pgs_iters);
     __syncthreads();
