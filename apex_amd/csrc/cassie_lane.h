@@ -322,6 +322,285 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
     });
 }
 
+// ------------------------------------------------------------------------------------------------ factor / solve, dof lanes
+// M = L^T D L (MuJoCo's reverse Cholesky on the kinematic tree), lane-parallel over the 13 dofs of a leg (slot 0 = left,
+// 1 = right); the 6 pelvis dofs are carried uniformly by every lane.  A lane keeps its row of the (symmetric) leg block by
+// IDENTITY of the other dof (R[j], j = 0..12, zero when j is neither ancestor nor descendant) plus the 6 pelvis couplings, so
+// eliminating dof k is: broadcast row k (lane k), every lane i < k does R_i[j] -= (R_i[k] / D_k) * R_k[j].  The elimination
+// leaves D_i L[i][j] below the diagonal and L[j][i] above it, i.e. both the row and the column view the solves need.
+constexpr bool leg_anc(int k, int j) {       // is leg dof j a proper ancestor of leg dof k
+    for (int a = 1; a < ct_dof_depth[6 + k]; ++a) if (ct_dof_anc[16 * (6 + k) + a] == 6 + j) return true;
+    return false;
+}
+struct MIdx { unsigned short v[16 * 13]; };
+constexpr MIdx make_midx() {            // offset of M[k][j] inside a leg's block of the ancestor-chain layout, 0xFFFF = structural zero
+    MIdx t{};
+    for (int k = 0; k < 16; ++k)
+        for (int j = 0; j < 13; ++j) {
+            int off = 0xFFFF;
+            if (k < 13) {
+                const int lo = k > j ? k : j, hi = k > j ? j : k;      // the entry is stored in the row of the deeper dof
+                for (int a = 0; a < ct_dof_depth[6 + lo]; ++a)
+                    if (ct_dof_anc[16 * (6 + lo) + a] == 6 + hi) off = ct_dof_madr[6 + lo] + a - ct_dof_madr[6];
+            }
+            t.v[13 * k + j] = (unsigned short)off;
+        }
+    return t;
+}
+__device__ const MIdx kMidx = make_midx();
+constexpr int M_LEG0 = ct_dof_madr[6], M_LEGSZ = ct_dof_madr[19] - ct_dof_madr[6];
+static_assert(M_LEG0 == 21 && M_LEGSZ == 143 && CM_NM == M_LEG0 + 2 * M_LEGSZ, "mass-matrix layout");
+
+struct LaneFac {
+    float Lr[2][13], Lc[2][13], w[2][6], D[2], invD[2];      // row view L[me][j], column view L[i][me], pelvis couplings L[me][p]
+    float Lp[6][6], Dp[6], invDp[6];                          // pelvis block (uniform): L[i][j] for j < i
+};
+struct LaneVec { float a[2]; float p[6]; };                   // a[slot] = this lane's leg dof, p = pelvis dofs (uniform)
+struct LaneIdx { int l, own, dep; unsigned short mi[13]; };   // own = offset of the lane's diagonal entry inside the leg block
+__device__ __forceinline__ LaneIdx lane_idx() {
+    LaneIdx x;
+    x.l = threadIdx.x & 15;
+    const int lc = x.l < 13 ? x.l : 12;
+    x.own = cm_dof_madr[6 + lc] - M_LEG0;
+    x.dep = lc == 12 ? 13 : nibble(TD_DEPTH, lc);
+    sfor<0, 13>([&](auto J) { x.mi[J] = kMidx.v[13 * x.l + J]; });
+    return x;
+}
+
+// factorise WK_M (+ hdamp * joint damping on the diagonal: mj_Euler's implicit damping)
+__device__ __forceinline__ void factor_lane(const St& S, const LaneIdx& X, float hdamp, LaneFac& F) {
+    const int l = X.l;
+    float R[2][13], P[2][6];
+    sfor<0, 2>([&](auto Sd) {
+        constexpr int sd = Sd, blk = WK_M + M_LEG0 + M_LEGSZ * sd;
+        sfor<0, 13>([&](auto J) {
+            float v = X.mi[J] != 0xFFFF ? S.W(blk + X.mi[J]) : 0.f;
+            if (l == J) v += hdamp * S(F_DAMP + 6 + 13 * sd + J);
+            R[sd][J] = v;
+        });
+        sfor<0, 6>([&](auto Pp) { P[sd][Pp] = l < 13 ? S.W(blk + X.own + X.dep - 1 - Pp) : 0.f; });
+    });
+    // ---- legs: eliminate dof 12 .. 0 of both legs at once
+    srfor<0, 13>([&](auto K) {
+        constexpr int k = K;
+        sfor<0, 2>([&](auto Sd) {
+            constexpr int sd = Sd;
+            const float inv = __frcp_rn(dpp<0x150 + k>(R[sd][k]));
+            const float tmp = l < k ? R[sd][k] * inv : 0.f;
+            sfor<0, k>([&](auto J) { constexpr int j = J; if constexpr (leg_anc(k, j)) R[sd][j] -= tmp * dpp<0x150 + k>(R[sd][j]); });
+            sfor<0, 6>([&](auto Pp) { P[sd][Pp] -= tmp * dpp<0x150 + k>(P[sd][Pp]); });
+            R[sd][k] = l < k ? tmp : R[sd][k];
+        });
+    });
+    sfor<0, 2>([&](auto Sd) {
+        constexpr int sd = Sd;
+        float D = 1.f;
+        sfor<0, 13>([&](auto J) { if (l == J) D = R[sd][J]; });
+        F.D[sd] = D; F.invD[sd] = __frcp_rn(D);
+        sfor<0, 13>([&](auto J) { F.Lr[sd][J] = (J < l && l < 13) ? R[sd][J] * F.invD[sd] : 0.f; F.Lc[sd][J] = J > l ? R[sd][J] : 0.f; });
+        sfor<0, 6>([&](auto Pp) { F.w[sd][Pp] = P[sd][Pp] * F.invD[sd]; });
+    });
+    // ---- pelvis block: Schur complement of the two legs, then a 6x6 factorisation carried by every lane
+    float Pm[6][6];
+    sfor<0, 6>([&](auto Pi) {
+        sfor<0, Pi + 1>([&](auto Qi) {
+            constexpr int p = Pi, q = Qi;
+            float m = S.W(WK_M + ct_dof_madr[p] + (p - q));
+            if constexpr (p == q) m += hdamp * S(F_DAMP + p);
+            Pm[p][q] = m - red16(F.w[0][q] * P[0][p] + F.w[1][q] * P[1][p]);
+        });
+    });
+    srfor<0, 6>([&](auto K) {
+        constexpr int k = K;
+        F.Dp[k] = Pm[k][k]; F.invDp[k] = __frcp_rn(Pm[k][k]);
+        sfor<0, k>([&](auto I) {
+            constexpr int i = I;
+            const float tmp = Pm[k][i] * F.invDp[k];
+            sfor<0, i + 1>([&](auto J) { Pm[i][J] -= tmp * Pm[k][J]; });
+            F.Lp[k][i] = tmp;
+        });
+    });
+}
+// factor -> WK_LD (ancestor-chain layout, read by the row stage) and WK_DISQ
+__device__ __forceinline__ void fac_store(const St& S, const LaneIdx& X, const LaneFac& F) {
+    const int l = X.l;
+    if (l < 13) sfor<0, 2>([&](auto Sd) {
+        constexpr int sd = Sd, blk = WK_LD + M_LEG0 + M_LEGSZ * sd;
+        S.W(blk + X.own) = F.D[sd];
+        sfor<0, 12>([&](auto J) { if (J < l && X.mi[J] != 0xFFFF) S.W(blk + X.mi[J]) = F.Lr[sd][J]; });
+        sfor<0, 6>([&](auto Pp) { S.W(blk + X.own + X.dep - 1 - Pp) = F.w[sd][Pp]; });
+        S.W(WK_DISQ + 6 + 13 * sd + l) = rsqrtf(F.D[sd]);
+    });
+    if (l == 0) sfor<0, 6>([&](auto Pi) {
+        constexpr int p = Pi;
+        S.W(WK_LD + ct_dof_madr[p]) = F.Dp[p]; S.W(WK_DISQ + p) = rsqrtf(F.Dp[p]);
+        sfor<0, p>([&](auto Qi) { S.W(WK_LD + ct_dof_madr[p] + (p - Qi)) = F.Lp[p][Qi]; });
+    });
+}
+// ... and back (finish stage)
+__device__ __forceinline__ void fac_load(const St& S, const LaneIdx& X, LaneFac& F) {
+    const int l = X.l;
+    sfor<0, 2>([&](auto Sd) {
+        constexpr int sd = Sd, blk = WK_LD + M_LEG0 + M_LEGSZ * sd;
+        F.D[sd] = l < 13 ? S.W(blk + X.own) : 1.f; F.invD[sd] = __frcp_rn(F.D[sd]);
+        sfor<0, 13>([&](auto J) {
+            const float v = (X.mi[J] != 0xFFFF && l != J) ? S.W(blk + X.mi[J]) : 0.f;
+            F.Lr[sd][J] = J < l ? v : 0.f; F.Lc[sd][J] = J > l ? v : 0.f;
+        });
+        sfor<0, 6>([&](auto Pp) { F.w[sd][Pp] = l < 13 ? S.W(blk + X.own + X.dep - 1 - Pp) : 0.f; });
+    });
+    sfor<0, 6>([&](auto Pi) {
+        constexpr int p = Pi;
+        F.Dp[p] = S.W(WK_LD + ct_dof_madr[p]); F.invDp[p] = __frcp_rn(F.Dp[p]);
+        sfor<0, p>([&](auto Qi) { F.Lp[p][Qi] = S.W(WK_LD + ct_dof_madr[p] + (p - Qi)); });
+    });
+}
+__device__ __forceinline__ LaneVec vec_load(const St& S, const LaneIdx& X, int off_state /* -1 = workspace */, int off) {
+    LaneVec x;
+    const int lc = X.l < 13 ? X.l : 12;
+    sfor<0, 2>([&](auto Sd) { x.a[Sd] = off_state >= 0 ? S(off_state + 6 + 13 * Sd + lc) : S.W(off + 6 + 13 * Sd + lc); });
+    sfor<0, 6>([&](auto Pp) { x.p[Pp] = off_state >= 0 ? S(off_state + Pp) : S.W(off + Pp); });
+    if (X.l >= 13) x.a[0] = x.a[1] = 0.f;
+    return x;
+}
+// x <- L^-T x (leaves -> root)
+__device__ __forceinline__ void solve_LT_lane(const LaneFac& F, LaneVec& x) {
+    srfor<0, 13>([&](auto I) { constexpr int i = I; sfor<0, 2>([&](auto Sd) { x.a[Sd] -= F.Lc[Sd][i] * dpp<0x150 + i>(x.a[Sd]); }); });
+    sfor<0, 6>([&](auto Pp) { x.p[Pp] -= red16(F.w[0][Pp] * x.a[0] + F.w[1][Pp] * x.a[1]); });
+    srfor<1, 6>([&](auto I) { constexpr int i = I; sfor<0, i>([&](auto J) { x.p[J] -= F.Lp[i][J] * x.p[i]; }); });
+}
+// x <- L^-1 x (root -> leaves)
+__device__ __forceinline__ void solve_L_lane(const LaneFac& F, LaneVec& x) {
+    sfor<1, 6>([&](auto I) { constexpr int i = I; sfor<0, i>([&](auto J) { x.p[i] -= F.Lp[i][J] * x.p[J]; }); });
+    sfor<0, 2>([&](auto Sd) { sfor<0, 6>([&](auto Pp) { x.a[Sd] -= F.w[Sd][Pp] * x.p[Pp]; }); });
+    sfor<0, 13>([&](auto Jj) { constexpr int j = Jj; sfor<0, 2>([&](auto Sd) { x.a[Sd] -= F.Lr[Sd][j] * dpp<0x150 + j>(x.a[Sd]); }); });
+}
+// y = L^T x
+__device__ __forceinline__ LaneVec mul_LT_lane(const LaneFac& F, const LaneVec& x) {
+    LaneVec y = x;
+    sfor<0, 13>([&](auto I) { constexpr int i = I; sfor<0, 2>([&](auto Sd) { y.a[Sd] += F.Lc[Sd][i] * dpp<0x150 + i>(x.a[Sd]); }); });
+    sfor<0, 6>([&](auto Pp) { y.p[Pp] += red16(F.w[0][Pp] * x.a[0] + F.w[1][Pp] * x.a[1]); });
+    sfor<1, 6>([&](auto I) { constexpr int i = I; sfor<0, i>([&](auto J) { y.p[J] += F.Lp[i][J] * x.p[i]; }); });
+    return y;
+}
+
+// stage B: factorisation + qacc_smooth = M^-1 qfrc_smooth
+__device__ __forceinline__ void stage_factor_lane(const St& S) {
+    const LaneIdx X = lane_idx();
+    LaneFac F;
+    factor_lane(S, X, 0.f, F);
+    fac_store(S, X, F);
+    LaneVec x = vec_load(S, X, -1, WK_SMOOTH);
+    solve_LT_lane(F, x);
+    sfor<0, 2>([&](auto Sd) { x.a[Sd] *= F.invD[Sd]; });
+    sfor<0, 6>([&](auto Pp) { x.p[Pp] *= F.invDp[Pp]; });
+    solve_L_lane(F, x);
+    if (X.l < 13) sfor<0, 2>([&](auto Sd) { S.W(WK_QS + 6 + 13 * Sd + X.l) = x.a[Sd]; });
+    if (X.l == 0) sfor<0, 6>([&](auto Pp) { S.W(WK_QS + Pp) = x.p[Pp]; });
+}
+
+// stage E: qacc, foot force, IMU, then (do_euler) mj_Euler with implicit joint damping:
+// (M + h D) a = qfrc_smooth + J^T f = qfrc_smooth + L^T D^1/2 z~
+__device__ __forceinline__ void stage_finish_lane(const St& S, const float* rows, bool do_euler) {
+    const LaneIdx X = lane_idx();
+    const int l = X.l, lc = l < 13 ? l : 12;
+    LaneFac F;
+    fac_load(S, X, F);
+    const LaneVec z = vec_load(S, X, -1, WK_ZT), qs = vec_load(S, X, -1, WK_QS);
+    float disq[2], disqp[6];
+    sfor<0, 2>([&](auto Sd) { disq[Sd] = S.W(WK_DISQ + 6 + 13 * Sd + lc); });
+    sfor<0, 6>([&](auto Pp) { disqp[Pp] = S.W(WK_DISQ + Pp); });
+    LaneVec qacc;
+    sfor<0, 2>([&](auto Sd) { qacc.a[Sd] = z.a[Sd] * disq[Sd]; });
+    sfor<0, 6>([&](auto Pp) { qacc.p[Pp] = z.p[Pp] * disqp[Pp]; });
+    solve_L_lane(F, qacc);
+    sfor<0, 2>([&](auto Sd) { qacc.a[Sd] += qs.a[Sd]; });
+    sfor<0, 6>([&](auto Pp) { qacc.p[Pp] += qs.p[Pp]; });
+    if (l == 0) {
+        // sensor snapshot of the PRE-integration state (sensordata is one mj_step1 old when step_ethercat reads it)
+        sfor<0, 10>([&](auto U) { S(F_SNAP + SN_MPOS + U) = S(F_QPOS + ct_act_qposadr[U]); });
+        sfor<0, 6>([&](auto K) { S(F_SNAP + SN_JPOS + K) = S(F_QPOS + ct_jsens_qposadr[K]); });
+        sfor<0, 4>([&](auto K) { S(F_SNAP + SN_QUAT + K) = S(F_QPOS + 3 + K); });
+        sfor<0, 3>([&](auto K) { S(F_SNAP + SN_GYRO + K) = S(F_QVEL + 3 + K); S(F_SNAP + SN_VEL + K) = S(F_QVEL + K); });
+        S(F_SNAP + SN_PZ) = S(F_QPOS + 2);
+        {   // world z of the contact force on the foot bodies (cassie_sim_foot_forces -> get_foot_forces()[2], [8])
+            const int nc[2] = {(int)S.W(WK_MISC + 0), (int)S.W(WK_MISC + 1)};
+            const float mu = S(F_FRIC), nz = S(F_FLOOR + 2), t1z = S(F_FLOOR + 5), t2z = S(F_FLOOR + 8);
+            float fz[2] = {0.f, 0.f};
+            sfor<0, 2 * MAXC>([&](auto Sl) {
+                constexpr int sl = Sl, lg = sl / MAXC;
+                const float* cr = rows + R4_CON + R4_CONSZ * sl;
+                if ((sl % MAXC) < nc[lg] && cr[7] != 0.f)
+                    fz[lg] += nz * (cr[12] + cr[13] + cr[14] + cr[15]) + mu * (t1z * (cr[12] - cr[13]) + t2z * (cr[14] - cr[15]));
+            });
+            S(F_FWD + 0) = fz[0]; S(F_FWD + 1) = fz[1];
+        }
+        {   // accelerometer at the imu site (cassie.xml:267): classical acceleration of the site point, site frame
+            SV A = {{S.W(WK_PEL), S.W(WK_PEL + 1), S.W(WK_PEL + 2)}, {S.W(WK_PEL + 3), S.W(WK_PEL + 4), S.W(WK_PEL + 5)}};
+            const SV V = {{S.W(WK_PEL + 6), S.W(WK_PEL + 7), S.W(WK_PEL + 8)}, {S.W(WK_PEL + 9), S.W(WK_PEL + 10), S.W(WK_PEL + 11)}};
+            M3 R;
+            sfor<0, 9>([&](auto K) { R.m[K] = S.W(WK_PEL + 12 + K); });
+            A.l = A.l + V3{qacc.p[0], qacc.p[1], qacc.p[2]};
+            sfor<0, 3>([&](auto K) { A.a = A.a + col(R, K) * qacc.p[3 + K]; });
+            const V3 r = mul(R, V3{ct_imu_pos[0], ct_imu_pos[1], ct_imu_pos[2]});
+            const V3 vp = V.l + cross(V.a, r);
+            const V3 a = A.l + cross(A.a, r) + cross(V.a, vp);
+            S(F_SNAP + SN_ACC) = dot(col(R, 0), a); S(F_SNAP + SN_ACC + 1) = dot(col(R, 1), a); S(F_SNAP + SN_ACC + 2) = dot(col(R, 2), a);
+        }
+    }
+    if (!do_euler) return;
+    // rhs = qfrc_smooth + L^T D^1/2 z~
+    LaneVec x;
+    sfor<0, 2>([&](auto Sd) { x.a[Sd] = z.a[Sd] * F.D[Sd] * disq[Sd]; });
+    sfor<0, 6>([&](auto Pp) { x.p[Pp] = z.p[Pp] * F.Dp[Pp] * disqp[Pp]; });
+    LaneVec rhs = mul_LT_lane(F, x);
+    const LaneVec sm = vec_load(S, X, -1, WK_SMOOTH);
+    sfor<0, 2>([&](auto Sd) { rhs.a[Sd] += sm.a[Sd]; });
+    sfor<0, 6>([&](auto Pp) { rhs.p[Pp] += sm.p[Pp]; });
+    __builtin_amdgcn_sched_barrier(0);
+    factor_lane(S, X, DT, F);
+    solve_LT_lane(F, rhs);
+    sfor<0, 2>([&](auto Sd) { rhs.a[Sd] *= F.invD[Sd]; });
+    sfor<0, 6>([&](auto Pp) { rhs.p[Pp] *= F.invDp[Pp]; });
+    solve_L_lane(F, rhs);
+    // ---- integrate: qvel += h a; hinges / slides qpos += h qvel; ball joints rotate by h w
+    float qv[2], qvp[6];
+    sfor<0, 2>([&](auto Sd) {
+        constexpr int sd = Sd;
+        qv[sd] = S(F_QVEL + 6 + 13 * sd + lc) + DT * rhs.a[sd];
+        if (l < 13) { S(F_QVEL + 6 + 13 * sd + l) = qv[sd]; S(F_QACCW + 6 + 13 * sd + l) = qacc.a[sd]; }
+    });
+    sfor<0, 6>([&](auto Pp) { qvp[Pp] = S(F_QVEL + Pp) + DT * rhs.p[Pp]; });
+    auto rotate = [&](int qa, V3 wv) {
+        const float nw = sqrtf(dot(wv, wv));
+        Q4 q = {S(F_QPOS + qa), S(F_QPOS + qa + 1), S(F_QPOS + qa + 2), S(F_QPOS + qa + 3)};
+        if (nw > 0.f) {
+            float sn, cs;
+            __sincosf(0.5f * nw * DT, &sn, &cs);
+            const float sc = sn / nw;
+            q = qmul(q, Q4{cs, wv.x * sc, wv.y * sc, wv.z * sc});
+        }
+        q = qnormalize(q);
+        S(F_QPOS + qa) = q.w; S(F_QPOS + qa + 1) = q.x; S(F_QPOS + qa + 2) = q.y; S(F_QPOS + qa + 3) = q.z;
+    };
+    sfor<0, 2>([&](auto Sd) {
+        constexpr int sd = Sd;
+        const float w1 = dpp<0x150 + 4>(qv[sd]), w2 = dpp<0x150 + 5>(qv[sd]);      // achilles ball joint: dofs k = 3, 4, 5 on lanes 3..5
+        if (l == 3) rotate(ct_jnt_qposadr[7] + 14 * sd, V3{qv[sd], w1, w2});
+        else if (l < 13 && l != 4 && l != 5) {
+            // leg-local hinge dof k -> qpos offset inside the leg block: k 0,1,2 -> 0,1,2; k >= 6 -> k + 1 (the ball's quaternion takes 4)
+            const int qa = 7 + 14 * sd + (l < 3 ? l : l + 1);
+            S(F_QPOS + qa) += DT * qv[sd];
+        }
+    });
+    static_assert(ct_jnt_qposadr[7] == 10 && ct_jnt_qposadr[8] == 14 && ct_jnt_qposadr[14] == 20 && ct_jnt_qposadr[18] == 24, "qpos layout");
+    if (l == 0) {
+        sfor<0, 6>([&](auto Pp) { S(F_QVEL + Pp) = qvp[Pp]; S(F_QACCW + Pp) = qacc.p[Pp]; });
+        sfor<0, 3>([&](auto K) { S(F_QPOS + K) += DT * qvp[K]; });
+        rotate(3, V3{qvp[3], qvp[4], qvp[5]});
+    }
+}
+
 // Constraint rows of leg LEG, one row vector per lane: Jacobian from the stored motion axes, dots against
 // qvel / qacc_smooth / qacc_warmstart on the raw row, whitening y~ = D^-1/2 L^-T J^T (L streamed from LDS, uniform
 // addresses), row scalars.  Same arithmetic as c3::build_rows3, except that a connect row takes the common ancestors of

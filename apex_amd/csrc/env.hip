@@ -148,7 +148,11 @@ __device__ __noinline__ void stage1b_tree_lane(St S) {
 #endif
 __device__ __noinline__ void stage2a_factor(St S) {
     PROF_START();
+#if APX_GEN == 4
+    c4::stage_factor_lane(S);
+#else
     c3::stage_factor(S);
+#endif
     PROF(2);
 }
 template <int LEG>
@@ -177,6 +181,13 @@ __device__ __noinline__ void stage3_pgs(St S, int pgs_iters) {
     PROF(3);
 }
 #endif
+#if APX_GEN == 4
+__device__ __noinline__ void stage4_finish(St S, int mode) {
+    PROF_START();
+    c4::stage_finish_lane(S, rows4(), mode != 0);
+    PROF(4);
+}
+#else
 __device__ __noinline__ void stage4_finish(St S, int mode) {
     PROF_START();
     const c2::Lds Y = row_store();
@@ -201,6 +212,7 @@ __device__ __noinline__ void stage4_finish(St S, int mode) {
     S(F_FWD + 0) = fz[0]; S(F_FWD + 1) = fz[1];
     PROF(4);
 }
+#endif
 #if APX_GEN == 4
 // Generation 4: the wave holds 4 envs, one per 16-lane row.  Stages not yet converted to the lane-parallel form run on the
 // row's lead lane; every call site is reached by all lanes.
@@ -210,11 +222,11 @@ __device__ __forceinline__ void sim_step_pd(const St& S, int pgs_iters, int mode
     __syncthreads();
     stage1b_tree_lane(S);
     __syncthreads();
-    if (lead) stage2a_factor(S);
+    stage2a_factor(S);
     __syncthreads();
     stage3_rows_pgs_lane(S, pgs_iters);
     __syncthreads();
-    if (lead) stage4_finish(S, mode);
+    stage4_finish(S, mode);
     __syncthreads();
 }
 #else
