@@ -136,6 +136,85 @@ __device__ __noinline__ void stage1_io_tree(St S, int mode) {
 #if APX_GEN == 4
     for (int u = 0; u < 10; ++u) S.W(c4::WK_CTRL + u) = ctrl[u];
 }
+// The same model, lane-parallel: lanes 0..9 = the ten drives, lanes 10..15 = the six joint encoders, lane 0 = estimator.
+__device__ __forceinline__ void stage1_io_lane(St S, int mode) {
+    PROF_START();
+    const int l = threadIdx.x & 15;
+    if (mode == 0) { if (l < 10) S.W(c4::WK_CTRL + l) = 0.f; PROF(0); return; }
+    const int flags = S.I(I_FLAGS);
+    const bool mot = l < 10;
+    const int u = mot ? l : 0, u5 = u >= 5 ? u - 5 : u, k = mot ? 0 : l - 10;
+    float sdepth = 0.f, ssign = 1.f, tau_cmd = 0.f, mvel = 0.f;
+    const float gear = cm_act_gear[u];
+    if (mot) {
+        // drive encoder: truncating quantiser + 9-tap FIR velocity
+        const float scale = 2.f * PI_F / (float)(1 << cm_act_bits[u]);
+        const float nq = truncf(S(F_SNAP + SN_MPOS + u) * gear / scale);
+        float h[9];
+        if (!(flags & 1)) { _Pragma("unroll") for (int i = 0; i < 9; ++i) h[i] = nq; }
+        else { _Pragma("unroll") for (int i = 8; i > 0; --i) h[i] = S(F_MENC + u * 9 + i - 1); h[0] = nq; }
+        float acc = 0.f;
+        _Pragma("unroll") for (int i = 0; i < 9; ++i) { S(F_MENC + u * 9 + i) = h[i]; acc += kFir[i] * h[i]; }
+        const float mpos = nq * scale / gear;
+        mvel = acc * scale / gear / PI_F;
+        S(F_SO + SO_MPOS + u) = mpos; S(F_SO + SO_MVEL + u) = mvel;
+        // pd_input_step: tau = P (pTarget - q) + D (0 - qd), no clamp (G9); pd_in_t is zero until the first env.step
+        tau_cmd = (flags & 16) ? kP[u5] * (S(F_PDT + u) - mpos) + kD[u5] * (0.f - mvel) : 0.f;
+        // cassie_core_sim_step (G10): soft joint-limit zones 0.15 rad inside the drive limits
+        constexpr float DEG = PI_F / 180.f;
+        const float lo_deg = u5 == 0 ? -15.f : u5 == 1 ? -22.f : u5 == 2 ? -50.f : u5 == 3 ? -156.f : -140.f;
+        const float hi_deg = u5 == 0 ? 20.f : u5 == 1 ? 22.f : u5 == 2 ? 80.f : u5 == 3 ? -42.f : -35.f;
+        float lo = lo_deg * DEG + 0.15f, hi = hi_deg * DEG - 0.15f;
+        if (u >= 5 && u5 < 2) { const float t = lo; lo = -hi; hi = -t; }      // roll / yaw mirror on the right leg
+        sdepth = fmaxf(0.f, fmaxf(mpos - hi, lo - mpos));
+        ssign = mpos > hi ? -1.f : 1.f;
+    }
+    // global torque scale = product over the drives
+    float sscale = fmaxf(0.f, 1.f - sdepth * (1.f / 0.15f));
+    sscale *= c4::dpp<0xB1>(sscale); sscale *= c4::dpp<0x4E>(sscale); sscale *= c4::dpp<0x141>(sscale); sscale *= c4::dpp<0x140>(sscale);
+    if (mot) {
+        const float sKp = u5 == 0 ? 1000.f : u5 == 1 ? 800.f : u5 == 4 ? 100.f : 1200.f, sKd = u5 < 2 ? 12.f : u5 == 4 ? 7.f : 36.f;
+        const float d = sdepth;
+        float tau = sscale * tau_cmd + ssign * sKp * d * (1.f + d * (1.f / 0.15f)) - fminf(1.f, d * (1.f / 0.15f)) * sKd * mvel;
+        tau = fminf(fmaxf(tau, -kTorqueLimit[u5]), kTorqueLimit[u5]);
+        // cassie_sim_step_ethercat: torque-speed curve, 6-deep delay line
+        const float wmax = cm_act_rpm[u] * 2.f * PI_F / 60.f, tmax = cm_act_ctrlmax[u];
+        const float om = fabsf(S(F_QVEL + cm_act_dof[u]) * gear);
+        const float tlim = fminf(fmaxf(2.f * tmax * (1.f - om / wmax), 0.f), tmax);
+        const float cmd = tau / gear;
+        const float un = (cmd < 0.f ? -1.f : 1.f) * fminf(fabsf(cmd), tlim);
+        float fifo[6];
+        _Pragma("unroll") for (int i = 5; i > 0; --i) fifo[i] = S(F_FIFO + u * 6 + i - 1);
+        fifo[0] = un;
+        _Pragma("unroll") for (int i = 0; i < 6; ++i) S(F_FIFO + u * 6 + i) = fifo[i];
+        S.W(c4::WK_CTRL + u) = fifo[5];
+        S(F_SO + SO_TORQUE + u) = gear * fifo[5];
+    } else {   // joint encoders: quantiser + biquad velocity
+        const float scale = 2.f * PI_F / (float)(1 << cm_jsens_bits[k]);
+        const float x = truncf(S(F_SNAP + SN_JPOS + k) / scale) * scale;
+        float xs[4], y0, y1;
+        if (!(flags & 2)) { xs[0] = xs[1] = xs[2] = xs[3] = x; y0 = y1 = 0.f; }
+        else { xs[0] = x; _Pragma("unroll") for (int i = 1; i < 4; ++i) xs[i] = S(F_JENCX + k * 4 + i - 1); y0 = S(F_JENCY + k * 2); y1 = S(F_JENCY + k * 2 + 1); }
+        const float y = 12.348f * (xs[0] + xs[1] - xs[2] - xs[3]) + 1.7658f * y0 - 0.79045f * y1;
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) S(F_JENCX + k * 4 + i) = xs[i];
+        S(F_JENCY + k * 2) = y; S(F_JENCY + k * 2 + 1) = y0;
+        S(F_SO + SO_JPOS + k) = x; S(F_SO + SO_JVEL + k) = y;
+    }
+    if (l == 0) {
+        S.I(I_FLAGS) = flags | 3;
+        // estimator: pass-through fields + estimator-lite for the 7 filtered ones (golden G11)
+        const Q4 q = {S(F_SNAP + SN_QUAT), S(F_SNAP + SN_QUAT + 1), S(F_SNAP + SN_QUAT + 2), S(F_SNAP + SN_QUAT + 3)};
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) S(F_SO + SO_QUAT + i) = S(F_SNAP + SN_QUAT + i);
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) S(F_SO + SO_ROTVEL + i) = S(F_SNAP + SN_GYRO + i);
+        const M3 R = q2m(q);
+        S(F_SO + SO_TACC) = S(F_SNAP + SN_ACC) - R.m[6] * GRAV; S(F_SO + SO_TACC + 1) = S(F_SNAP + SN_ACC + 1) - R.m[7] * GRAV;
+        S(F_SO + SO_TACC + 2) = S(F_SNAP + SN_ACC + 2) - R.m[8] * GRAV;
+        const V3 vw = {S(F_SNAP + SN_VEL), S(F_SNAP + SN_VEL + 1), S(F_SNAP + SN_VEL + 2)};
+        S(F_SO + SO_TVEL) = dot(col(R, 0), vw); S(F_SO + SO_TVEL + 1) = dot(col(R, 1), vw); S(F_SO + SO_TVEL + 2) = dot(col(R, 2), vw);
+        S(F_SO + SO_HEIGHT) = S(F_SNAP + SN_PZ) - 0.0818f;
+    }
+    PROF(0);
+}
 __device__ __noinline__ void stage1b_tree_lane(St S) {
     PROF_START();
     c4::stage_tree_lane(S, rows4());
@@ -218,7 +297,7 @@ __device__ __noinline__ void stage4_finish(St S, int mode) {
 // row's lead lane; every call site is reached by all lanes.
 __device__ __forceinline__ void sim_step_pd(const St& S, int pgs_iters, int mode) {
     const bool lead = (threadIdx.x & 15) == 0;
-    if (lead) stage1_io_tree(S, mode);
+    stage1_io_lane(S, mode);
     __syncthreads();
     stage1b_tree_lane(S);
     __syncthreads();
