@@ -760,6 +760,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     __builtin_amdgcn_sched_barrier(0);
     rows_lane<1>(S, B);
     __builtin_amdgcn_sched_barrier(0);
+    PROF(5);
     // ---- Gram columns of this lane's two rows
     float GAA[13], GBB[13], GAB[13], GBA[13];      // GXY[s] = y~_(r,X) . y~_(s,Y)
     sfor<0, 13>([&](auto Sx) {
@@ -784,7 +785,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
         eR[1][s] = dpp<0x150 + s>(B.R); eiA[1][s] = dpp<0x150 + s>(B.invA); ef[1][s] = dpp<0x150 + s>(B.f); ec[1][s] = dpp<0x150 + s>(B.b);
     });
     constexpr int NCS = 2 * MAXC;
-    float cG[NCS][6], cR[NCS], cb[NCS][4], cf[NCS][4], ciA[NCS][4];
+    float cG[NCS][6], cR[NCS], cb[NCS][4], cf[NCS][4], ciA[NCS][4], kn[NCS][4], k1[NCS][4], k2[NCS][4];
     bool con[NCS];
     sfor<0, NCS>([&](auto Sl) {
         constexpr int s = Sl, leg = s / MAXC, j = s % MAXC;
@@ -797,6 +798,8 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
             cb[s][k] = Lr.cb[j][k]; cf[s][k] = Lr.cf[j][k];
             const float sm = ((k & 1) ? -mu : mu), gnj = k < 2 ? cG[s][1] : cG[s][2], gjj = k < 2 ? cG[s][3] : cG[s][5];
             ciA[s][k] = __frcp_rn(cG[s][0] + 2.f * sm * gnj + mu * mu * gjj + cR[s]);      // A_kk + R of row n + s mu t_j
+            // row k = n + sm t_j moves the basis residuals (rn, r1, r2) by df * (G n-col + sm G j-col)
+            kn[s][k] = cG[s][0] + sm * gnj; k1[s][k] = cG[s][1] + sm * (k < 2 ? cG[s][3] : cG[s][4]); k2[s][k] = cG[s][2] + sm * (k < 2 ? cG[s][4] : cG[s][5]);
         });
     });
     const int nlim[2] = {A.nlim, B.nlim};
@@ -824,6 +827,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
         sfor<0, NCS>([&](auto Sl) { sfor<0, 4>([&](auto K) { cf[Sl][K] = 0.f; }); });
     }
     sfor<0, 2>([&](auto Lg) { sfor<0, 7>([&](auto Sx) { ec[Lg][Sx] += eR[Lg][Sx] * ef[Lg][Sx]; }); });      // c = b + R f
+    PROF(6);
     // ---- sweeps
     for (int it = 0; it < pgs_iters; ++it) {
         sfor<0, 2>([&](auto Lg) {
@@ -839,8 +843,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
             });
             if (nlim[leg]) {
                 const float t = (leg ? dpp<0x150 + 6>(rB) : dpp<0x150 + 6>(rA)) + ec[leg][6];
-                float fn = ef[leg][6] - t * eiA[leg][6];
-                fn = fn < 0.f ? 0.f : fn;
+                const float fn = fmaxf(ef[leg][6] - t * eiA[leg][6], 0.f);
                 const float df = fn - ef[leg][6];
                 ef[leg][6] = fn; ec[leg][6] += eR[leg][6] * df;
                 rA += Ga[6] * df; rB += Gb[6] * df;
@@ -850,19 +853,16 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
                 if (con[s]) {
                     float rn = leg ? dpp<0x150 + ln>(rB) : dpp<0x150 + ln>(rA), r1 = leg ? dpp<0x150 + ln + 1>(rB) : dpp<0x150 + ln + 1>(rA),
                           r2 = leg ? dpp<0x150 + ln + 2>(rB) : dpp<0x150 + ln + 2>(rA);
-                    const float gnn = cG[s][0], gn1 = cG[s][1], gn2 = cG[s][2], g11 = cG[s][3], g12 = cG[s][4], g22 = cG[s][5];
                     float sdn = 0.f, sd1 = 0.f, sd2 = 0.f;
                     sfor<0, 4>([&](auto K) {
                         constexpr int k = K;
                         const float sm = (k & 1) ? -mu : mu;
                         const float res = cb[s][k] + cR[s] * cf[s][k] + rn + sm * (k < 2 ? r1 : r2);
-                        float fn = cf[s][k] - res * ciA[s][k];
-                        fn = fn < 0.f ? 0.f : fn;
+                        const float fn = fmaxf(cf[s][k] - res * ciA[s][k], 0.f);
                         const float df = fn - cf[s][k];
                         cf[s][k] = fn;
-                        // y_k = n + sm t_j moves the basis residuals by df * (G n-col + sm G j-col)
-                        if constexpr (k < 2) { rn += df * (gnn + sm * gn1); r1 += df * (gn1 + sm * g11); r2 += df * (gn2 + sm * g12); sd1 += sm * df; }
-                        else { rn += df * (gnn + sm * gn2); r1 += df * (gn1 + sm * g12); r2 += df * (gn2 + sm * g22); sd2 += sm * df; }
+                        rn += df * kn[s][k]; r1 += df * k1[s][k]; r2 += df * k2[s][k];
+                        if constexpr (k < 2) sd1 += sm * df; else sd2 += sm * df;
                         sdn += df;
                     });
                     rA += Ga[ln] * sdn + Ga[ln + 1] * sd1 + Ga[ln + 2] * sd2;
@@ -871,6 +871,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
             });
         });
     }
+    PROF(7);
     // ---- z~ = sum_r y~_r F_r back to the dof layout of the finish stage
     float ownA = 0.f, ownB = 0.f;
     sfor<0, 7>([&](auto Sx) { if (l == Sx) { ownA = ef[0][Sx]; ownB = ef[1][Sx]; } });

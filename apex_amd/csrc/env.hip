@@ -48,6 +48,9 @@ __device__ __forceinline__ c2::Lds row_store() { return c2::Lds{apx_lds4 + ((thr
 __device__ __forceinline__ c2::Lds row_store() { return c2::Lds{apx_lds4 + (threadIdx.x & 63)}; }
 #endif
 
+#ifndef APX_STAGE
+#define APX_STAGE __noinline__
+#endif
 // ---- the substep as four non-inlined stages (cassie_step3.h): state crosses stages through HBM/L2 and LDS only
 // stage 1: encoders + estimator -> PD -> safeties -> motor model / delay, then the tree walk.
 // mode 0: forward pass only with zero ctrl (cassie_sim_set_const ends in mj_forward)
@@ -137,7 +140,7 @@ __device__ __noinline__ void stage1_io_tree(St S, int mode) {
     for (int u = 0; u < 10; ++u) S.W(c4::WK_CTRL + u) = ctrl[u];
 }
 // The same model, lane-parallel: lanes 0..9 = the ten drives, lanes 10..15 = the six joint encoders, lane 0 = estimator.
-__device__ __forceinline__ void stage1_io_lane(St S, int mode) {
+__device__ __forceinline__ void stage1_io_lane(St S, int mode) {   // (as a called function the reset kernel faults: kept inline)
     PROF_START();
     const int l = threadIdx.x & 15;
     if (mode == 0) { if (l < 10) S.W(c4::WK_CTRL + l) = 0.f; PROF(0); return; }
@@ -215,7 +218,7 @@ __device__ __forceinline__ void stage1_io_lane(St S, int mode) {
     }
     PROF(0);
 }
-__device__ __noinline__ void stage1b_tree_lane(St S) {
+__device__ APX_STAGE void stage1b_tree_lane(St S) {
     PROF_START();
     c4::stage_tree_lane(S, rows4());
     PROF(1);
@@ -225,7 +228,7 @@ __device__ __noinline__ void stage1b_tree_lane(St S) {
     PROF(1);
 }
 #endif
-__device__ __noinline__ void stage2a_factor(St S) {
+__device__ APX_STAGE void stage2a_factor(St S) {
     PROF_START();
 #if APX_GEN == 4
     c4::stage_factor_lane(S);
@@ -261,7 +264,7 @@ __device__ __noinline__ void stage3_pgs(St S, int pgs_iters) {
 }
 #endif
 #if APX_GEN == 4
-__device__ __noinline__ void stage4_finish(St S, int mode) {
+__device__ APX_STAGE void stage4_finish(St S, int mode) {
     PROF_START();
     c4::stage_finish_lane(S, rows4(), mode != 0);
     PROF(4);

@@ -15,7 +15,7 @@ for _ in range(K): env.step(act, auto_reset=False)
 torch.cuda.synchronize(); dt=(time.time()-t0)/K
 lib.apx_env_get_field(env._h, b"prof", _p(buf), _stream())
 p = buf[:12].cpu().numpy() / (K*50)
-names=["io_model","tree_walk","factor","pgs","finish+euler","rows_leg0","rows_leg1"]
+names=["io_model","tree_walk","factor","pgs_tail(z~)","finish+euler","rows(2 legs)","gram+warm","pgs_sweeps"]
 print("env step ms %.1f"%(dt*1e3))
 for n,v in zip(names,p): print("%-16s %9.0f cycles/substep"%(n,v))
-print("total %.0f cycles/substep"%p[:7].sum())
+print("total %.0f cycles/substep"%p[:8].sum())
