@@ -249,7 +249,7 @@ __device__ __noinline__ void stage3a_warm(St S) {
     c3::stage_warm_check(S, Y);
 }
 #if APX_GEN == 4
-__device__ __noinline__ void stage3_rows_pgs_lane(St S, int pgs_iters) {
+__device__ __forceinline__ void stage3_rows_pgs_lane(St S, int pgs_iters) {
     PROF_START();
     c4::stage_rows_pgs_lane(S, rows4(), pgs_iters);
     PROF(3);
@@ -541,11 +541,14 @@ __device__ float clock_reward(const St& S, const Cfg& cfg, const float* action, 
 
 // ------------------------------------------------------------------------------------------------ kernels
 #if APX_GEN == 4
+#ifndef APX_WAVES_PER_EU
+#define APX_WAVES_PER_EU 1
+#endif
 // one env per 16-lane row: the env's whole state is staged HBM -> LDS at the top of a launch and back at the end
 #define ENV_SETUP                                                                                   \
     const int l = threadIdx.x & 15, row = threadIdx.x >> 4;                                          \
     const int env = blockIdx.x * L4_EPW + row;                                                       \
-    if (env >= n) return;                                                                            \
+    if (row >= L4_EPW || env >= n) return;                                                                            \
     const bool lead = l == 0;                                                                        \
     const St S{(lfloat*)apx_lds4 + row * L4_ES, env};
 __device__ __forceinline__ void load_state(const St& S, const float* st, const int* ist, int n) {
@@ -575,14 +578,14 @@ __global__ __launch_bounds__(64) void env_init_kernel(float* st, int* ist, int n
     for (int k = 0; k < 9; ++k) G(F_FLOOR + k) = fl[k];
 }
 
-__global__ __launch_bounds__(64) void env_setconst_kernel(float* st, int* ist, float* wk, int n, Cfg cfg) {
+__global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_setconst_kernel(float* st, int* ist, float* wk, int n, Cfg cfg) {
     ENV_SETUP
     load_state(S, st, ist, n);
     if (lead) set_const_single_wave(S);
     store_state(S, st, ist, n);
 }
 
-__global__ __launch_bounds__(64) void env_reset_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const uint8_t* mask, float* obs) {
+__global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const uint8_t* mask, float* obs) {
     ENV_SETUP
     if (mask && !mask[env]) return;
     load_state(S, st, ist, n);
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(64) void env_reset_kernel(float* st, int* ist, floa
     store_state(S, st, ist, n);
 }
 
-__global__ __launch_bounds__(64) void env_step_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const float* action, float* obs,
+__global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const float* action, float* obs,
                                                       float* reward, uint8_t* done, float* final_obs) {
     ENV_SETUP
     load_state(S, st, ist, n);
@@ -649,7 +652,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(float* st, int* ist, float
 }
 
 // raw substeps with the current pd targets (tests): n_sub x cassie_sim_step_pd
-__global__ __launch_bounds__(64) void env_substep_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, int n_sub) {
+__global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_substep_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, int n_sub) {
     ENV_SETUP
     load_state(S, st, ist, n);
     for (int i = 0; i < n_sub; ++i) sim_step_pd(S, cfg.pgs_iters, 1);

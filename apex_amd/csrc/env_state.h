@@ -43,7 +43,10 @@ typedef __attribute__((address_space(1))) int gint;
 // on disjoint LDS bank groups, so a 16-lane access with consecutive addresses is conflict-free.
 typedef __attribute__((address_space(3))) float lfloat;
 typedef __attribute__((address_space(3))) int lint;
-constexpr int L4_INT = 580, L4_WK = 592, L4_ROWS = 1664, L4_ES = 2384, L4_EPW = 4;
+#ifndef APX_L4_EPW
+#define APX_L4_EPW 4
+#endif
+constexpr int L4_INT = 580, L4_WK = 592, L4_ROWS = 1664, L4_ES = 2384, L4_EPW = APX_L4_EPW;      // envs per wave (16 lanes each)
 struct St {
     lfloat* p; int env;
     __device__ __forceinline__ lfloat& operator()(int f) const { return p[f]; }

@@ -32,6 +32,21 @@ def cpu_baseline(seconds_hint=12.0):
             "sample": f"{cores} envs x {n_steps} env steps (50 substeps each), sampling only, fp64 dense oracle, one env per thread"}
 
 
+
+def _pmc_traffic_bytes():
+    """HBM bytes per env_step_kernel launch from the committed rocprofv3 PMC passes (profiles/r01_env_step_pmc_hbm_gen4.txt,
+    4096 envs): 2 x FETCH_SIZE (gfx950 correction of the microarchitecture guide) + WRITE_SIZE, both in KB. None if absent."""
+    import os, re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_env_step_pmc_hbm_gen4.txt")
+    try:
+        txt = open(path).read()
+        f = float(re.search(r"env_step_kernel: FETCH_SIZE=([0-9.e+]+)", txt).group(1))
+        w = float(re.search(r"env_step_kernel: WRITE_SIZE=([0-9.e+]+)", txt).group(1))
+        return int((2.0 * f + w) * 1024)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,7 +125,7 @@ def main():
             "sampling_env_steps_per_s": round(a.steps * a.rollout_len * a.n_envs * world / max(samp, 1e-9), 1),
             "sample_s": round(samp / a.steps, 3), "optimize_s": round(opt / a.steps, 3),
             "roofline": {"kernel": "env_step_kernel", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": _pmc_traffic_bytes(),
                          "ms_per_launch": round(k_ms, 3), "bytes_per_env_step": bytes_per_env_step,
                          "valu": {"flop_per_env_step": roofline.ENV_STEP_FLOP,
                                   "achieved_tflops": round(roofline.ENV_STEP_FLOP * a.n_envs / (k_ms * 1e-3) / 1e12, 4),
