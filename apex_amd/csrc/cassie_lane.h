@@ -757,7 +757,6 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     const float mu = S(F_FRIC);
     LegRows A, B;
     rows_lane<0>(S, A);
-    __builtin_amdgcn_sched_barrier(0);
     rows_lane<1>(S, B);
     __builtin_amdgcn_sched_barrier(0);
     PROF(5);

@@ -22,6 +22,34 @@ from . import engine
 from .vecenv import CassieVecEnv, MIRRORED_ACTS, MIRRORED_OBS, CLOCK_INDS
 
 
+def episode_stats(rew, ended, ret0, len0):
+    """Returns / lengths of the episodes that end inside a [T, N] rollout grid, without a per-step host round trip.
+    rew [T, N] float, ended [T, N] bool, ret0 / len0 [N] = partial sums of the episodes still running at entry.
+    -> (ep_returns, ep_lens) in (t, env) order, and the new partial sums.  Same numbers as accumulating per step and
+    resetting at every end (rl/algos/ppo.py:166-186)."""
+    T, N = rew.shape
+    dev = rew.device
+    cs = torch.cumsum(rew.double(), 0) + ret0.double()
+    steps = torch.arange(1, T + 1, device=dev, dtype=torch.float64).view(T, 1) + len0.double()
+    t_idx = torch.arange(T, device=dev).view(T, 1).expand(T, N)
+    last_end = torch.cummax(torch.where(ended, t_idx, torch.full_like(t_idx, -1)), 0).values       # last end at or before t
+    prev_end = torch.cat([torch.full((1, N), -1, device=dev, dtype=last_end.dtype), last_end[:-1]], 0)
+    has_prev = prev_end >= 0
+    gi = prev_end.clamp(min=0)
+    zero = torch.zeros_like(cs)
+    base_r = torch.where(has_prev, torch.gather(cs, 0, gi), zero)
+    base_l = torch.where(has_prev, torch.gather(steps, 0, gi), zero)
+    ep_rets = (cs - base_r)[ended].float()
+    ep_lens = (steps - base_l)[ended].float()
+    fin_end = last_end[-1]
+    has = fin_end >= 0
+    gl = fin_end.clamp(min=0).view(1, N)
+    zn = torch.zeros(N, device=dev, dtype=torch.float64)
+    ret1 = (cs[-1] - torch.where(has, torch.gather(cs, 0, gl).view(N), zn)).float()
+    len1 = (steps[-1] - torch.where(has, torch.gather(steps, 0, gl).view(N), zn)).float()
+    return ep_rets, ep_lens, ret1, len1
+
+
 class PPO:
     def __init__(self, args, save_path, env, rank=0, world_size=1, group=None, hidden=256):
         self.gamma = args["gamma"]; self.lam = args["lam"]; self.lr = args["lr"]; self.eps = args["eps"]
@@ -52,6 +80,9 @@ class PPO:
         self.b_mu = torch.zeros(T, N, 10, **f32); self.b_rew = torch.zeros(T, N, **f32)
         self.b_val = torch.zeros(T, N, **f32); self.b_boot = torch.zeros(T, N, **f32)
         self.b_end = torch.zeros(T, N, dtype=torch.uint8, device=self.device)
+        self.b_done = torch.zeros(T, N, dtype=torch.uint8, device=self.device)
+        self.b_endb = torch.zeros(T, N, dtype=torch.bool, device=self.device)
+        self.b_fin = torch.zeros(T, N, 50, **f32)
         self.ep_ret = torch.zeros(N, **f32); self.ep_len = torch.zeros(N, **f32)
         self.obs = None
 
@@ -104,33 +135,34 @@ class PPO:
     # ------------------------------------------------------------------------------------------ sampling
     @torch.no_grad()
     def sample(self):
-        """T lock-step env steps for the N envs of this GPU (the batched PPO.sample, ppo.py:139-186)."""
+        """T lock-step env steps for the N envs of this GPU (the batched PPO.sample, ppo.py:139-186).
+
+        The loop enqueues work only: no host synchronisation inside the rollout (a `.any()` per step would expose every
+        launch latency).  Bootstrap values V(s') of the time-limit truncations (ppo.py:184) are one batched critic pass
+        over the recorded final observations, and the episode statistics are a scan over the [T, N] done/reward grids
+        afterwards (same numbers as the per-step bookkeeping)."""
         L, env = self.learner, self.env
         if self.obs is None:
             self.obs = env.reset().clone()
         obs = self.obs
-        ep_rets, ep_lens = [], []
-        for t in range(self.T):
+        T, N = self.T, self.N
+        for t in range(T):
             mu = L.actor.forward(obs, L.obs_mean, L.obs_std)
             val = L.critic.forward(obs).view(-1)
             act = mu + self.fixed_std * torch.randn(mu.shape, device=self.device, generator=self.gen)
             self.b_obs[t].copy_(obs); self.b_mu[t].copy_(mu); self.b_act[t].copy_(act); self.b_val[t].copy_(val)
             nobs, rew, done, fin = env.step(act)
-            self.b_rew[t].copy_(rew)
-            ended = done != 0
-            self.b_end[t].copy_(ended.to(torch.uint8))
-            vfin = L.critic.forward(fin).view(-1)
-            self.b_boot[t].copy_(torch.where(done == 2, vfin, torch.zeros_like(vfin)))     # (not done) * V(s'), ppo.py:184
-            self.ep_ret += rew; self.ep_len += 1
-            if bool(ended.any()):
-                ep_rets.append(self.ep_ret[ended].clone()); ep_lens.append(self.ep_len[ended].clone())
-                self.ep_ret[ended] = 0; self.ep_len[ended] = 0
+            self.b_rew[t].copy_(rew); self.b_done[t].copy_(done); self.b_fin[t].copy_(fin)
             obs = nobs
         self.obs = obs.clone()
+        torch.ne(self.b_done, 0, out=self.b_endb)
+        self.b_end.copy_(self.b_endb)
+        vfin = L.critic.forward(self.b_fin.view(T * N, 50)).view(T, N)
+        self.b_boot.copy_(torch.where(self.b_done == 2, vfin, torch.zeros_like(vfin)))      # (not done) * V(s'), ppo.py:184
         last_val = L.critic.forward(self.obs).view(-1)
         ret = engine.returns_scan(self.b_rew, self.b_end, self.b_boot, last_val, self.gamma)
-        cat = lambda xs: torch.cat(xs) if xs else torch.zeros(0, device=self.device)
-        return ret, cat(ep_rets), cat(ep_lens)
+        ep_rets, ep_lens, self.ep_ret, self.ep_len = episode_stats(self.b_rew, self.b_endb, self.ep_ret, self.ep_len)
+        return ret, ep_rets, ep_lens
 
     # ------------------------------------------------------------------------------------------ optimisation
     def update(self, ret):

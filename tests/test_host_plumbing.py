@@ -84,3 +84,29 @@ def test_reward_string_parsing():
     assert parse_reward("aerial_clock")["stance_mode"] == 2
     with pytest.raises(TypeError):
         parse_reward(None)              # the reference crashes on `"..." in None` too (cassie.py:91)
+
+
+def test_episode_stats_scan_matches_per_step_bookkeeping():
+    """apex_amd.ppo.episode_stats (one scan over the [T, N] grids) == accumulating per step and resetting at every end."""
+    import torch
+    from apex_amd.ppo import episode_stats
+    g = torch.Generator().manual_seed(3)
+    T, N = 17, 23
+    ret0 = torch.rand(N, generator=g) * 5
+    len0 = torch.randint(0, 40, (N,), generator=g).float()
+    for trial in range(3):
+        rew = torch.rand(T, N, generator=g)
+        ended = torch.rand(T, N, generator=g) < (0.0 if trial == 2 else 0.12)
+        er, el, r1, l1 = episode_stats(rew, ended, ret0, len0)
+        acc_r, acc_l, rets, lens = ret0.clone().double(), len0.clone().double(), [], []
+        for t in range(T):
+            acc_r += rew[t].double(); acc_l += 1
+            for i in range(N):
+                if ended[t, i]:
+                    rets.append(float(acc_r[i])); lens.append(float(acc_l[i])); acc_r[i] = 0; acc_l[i] = 0
+        assert er.numel() == len(rets)
+        torch.testing.assert_close(er.double(), torch.tensor(rets, dtype=torch.float64), rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(el.double(), torch.tensor(lens, dtype=torch.float64), rtol=0, atol=0)
+        torch.testing.assert_close(r1.double(), acc_r, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(l1.double(), acc_l, rtol=0, atol=0)
+        ret0, len0 = r1, l1
