@@ -17,6 +17,8 @@ namespace c4 {
 using namespace c3;
 static_assert(L4_WK + WK_TOTAL <= L4_ROWS && L4_ROWS % 4 == 0 && L4_ROWS + 704 <= L4_ES && L4_ES % 64 == 16, "per-env LDS layout");
 
+// v_rcp_f32 (1 ulp): __frcp_rn and '/' expand to the ~10-instruction correctly rounded division sequence
+__device__ __forceinline__ float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
 template <int CTRL> __device__ __forceinline__ float dpp(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
 }
@@ -52,6 +54,7 @@ template <int LEG> constexpr unsigned chain_mask(int body) {
 // quantities about the pelvis origin o, world axes); results go to the same workspace slots (WK_M in MuJoCo's
 // ancestor-chain layout, WK_CDOF, WK_SMOOTH, WK_PTS, WK_PEL, F_FWD foot pose).
 constexpr int WK_CTRL = WK_QACC;                        // actuator-side torques from the io stage (10)
+constexpr int WK_DUMMY = WK_QACC + 16;                  // sink for predicated-off stores (keeps them branch-free)
 constexpr int XB_SZ = 20;                               // exchange record per body: pos3 quat4 vel6 acc6 | crb10 frc6
 constexpr unsigned long long nib(int a0, int a1, int a2, int a3, int a4, int a5, int a6, int a7, int a8, int a9, int a10, int a11) {
     return (unsigned long long)a0 | (unsigned long long)a1 << 4 | (unsigned long long)a2 << 8 | (unsigned long long)a3 << 12 |
@@ -61,6 +64,8 @@ constexpr unsigned long long nib(int a0, int a1, int a2, int a3, int a4, int a5,
 // leg-local body b = 0..11: hip-roll, hip-yaw, hip-pitch, achilles-rod, knee, knee-spring, shin, tarsus, heel-spring, foot-crank, plantar-rod, foot
 constexpr unsigned long long TB_DEPTH = nib(1, 2, 3, 4, 4, 5, 5, 6, 7, 7, 8, 7);         // pelvis = 0
 constexpr unsigned long long TB_PARENT = nib(15, 0, 1, 2, 2, 4, 4, 6, 7, 7, 9, 7);       // leg-local, 15 = pelvis
+constexpr unsigned long long TB_PAR2 = nib(15, 15, 0, 1, 1, 2, 2, 4, 6, 6, 7, 6);         // parent of parent
+constexpr unsigned long long TB_PAR4 = nib(15, 15, 15, 15, 15, 0, 0, 1, 2, 2, 4, 2);     // 4th ancestor
 constexpr unsigned long long TB_NDESC = nib(11, 10, 9, 0, 7, 0, 5, 4, 0, 1, 0, 0);
 constexpr unsigned long long TB_QOFF = nib(0, 1, 2, 3, 7, 15, 8, 9, 10, 11, 12, 13);     // qpos offset inside the leg block (15 = no joint)
 constexpr unsigned long long TB_DOFF = nib(0, 1, 2, 3, 6, 15, 7, 8, 9, 10, 11, 12);      // dof offset inside the leg block
@@ -144,53 +149,90 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         S.W(WK_PEL + 9) = pel.vel.l.x; S.W(WK_PEL + 10) = pel.vel.l.y; S.W(WK_PEL + 11) = pel.vel.l.z;
         sfor<0, 9>([&](auto K) { S.W(WK_PEL + 12 + K) = pmat.m[K]; });
     }
-    // ---- local joint rotation and joint velocity of this lane's bodies
-    Q4 lq[2]; float qd0[2];
+    // ---- local joint rotation and joint velocities of this lane's bodies (hinge axis = local z, ball = x, y, z)
+    Q4 lq[2]; float qd[2][3];
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
         Q4 jq = {1.f, 0.f, 0.f, 0.f};
+        qd[sd][0] = qd[sd][1] = qd[sd][2] = 0.f;
         if (hasj) {
-            if (ball) jq = qnormalize(Q4{S(F_QPOS + qadr[sd]), S(F_QPOS + qadr[sd] + 1), S(F_QPOS + qadr[sd] + 2), S(F_QPOS + qadr[sd] + 3)});
-            else { float sn, cs; __sincosf(0.5f * (S(F_QPOS + qadr[sd]) - jref), &sn, &cs); jq = {cs, 0.f, 0.f, sn}; }
+            if (ball) {
+                jq = qnormalize(Q4{S(F_QPOS + qadr[sd]), S(F_QPOS + qadr[sd] + 1), S(F_QPOS + qadr[sd] + 2), S(F_QPOS + qadr[sd] + 3)});
+                sfor<0, 3>([&](auto K) { qd[sd][K] = S(F_QVEL + dadr[sd] + K); });
+            } else {
+                float sn, cs;
+                __sincosf(0.5f * (S(F_QPOS + qadr[sd]) - jref), &sn, &cs);
+                jq = {cs, 0.f, 0.f, sn};
+                qd[sd][2] = S(F_QVEL + dadr[sd]);
+            }
         }
         lq[sd] = qmul(bquat[sd], jq);
-        qd0[sd] = (hasj && !ball) ? S(F_QVEL + dadr[sd]) : 0.f;
     });
-    __syncthreads();
-    // ---- level sweep: a body at depth d is final after iteration d (its parent was final after d-1)
-    for (int level = 1; level <= 8; ++level) {
-        sfor<0, 2>([&](auto Sd) {
-            constexpr int sd = Sd;
-            const XRec P = xb_read(xb, par == 15 ? 1 : 2 + 12 * sd + par);
-            const M3 Pm = q2m(P.quat);
-            XRec me;
-            me.pos = P.pos + mul(Pm, bpos[sd]);
-            me.quat = qnormalize(qmul(P.quat, lq[sd]));
-            const M3 mat = q2m(me.quat);
-            const V3 ax = col(mat, 2);
-            const SV cd = {ax, cross(ax, o - me.pos)};            // hinge axis = local z (ball joints: leaf body, fixed up below)
-            me.acc = P.acc + crossMotion(P.vel, cd) * qd0[sd];
-            me.vel = P.vel + cd * qd0[sd];
-            if (bl && depth == level) xb_write(xb, body[sd], me);
+    // ---- pointer jumping over the ancestor chain (depth <= 8: 3 rounds).  Round r composes a body's transform with the
+    // record of its 2^r-th ancestor, which by then spans 2^r levels itself; the same rounds give the chain sums below.
+    const int jump[3] = {par, nibble(TB_PAR2, lb), nibble(TB_PAR4, lb)};
+    V3 tp[2]; Q4 tq[2];
+    sfor<0, 2>([&](auto Sd) { tp[Sd] = bpos[Sd]; tq[Sd] = lq[Sd]; });
+    sfor<0, 3>([&](auto Rn) {
+        constexpr int r = Rn;
+        __syncthreads();
+        if (bl) sfor<0, 2>([&](auto Sd) {
+            float* p = xb + XB_SZ * body[Sd];
+            p[0] = tp[Sd].x; p[1] = tp[Sd].y; p[2] = tp[Sd].z; p[3] = tq[Sd].w; p[4] = tq[Sd].x; p[5] = tq[Sd].y; p[6] = tq[Sd].z;
         });
         __syncthreads();
-    }
-    // ---- own pose, motion axes, velocity / acceleration
+        sfor<0, 2>([&](auto Sd) {
+            constexpr int sd = Sd;
+            const float* p = xb + XB_SZ * (2 + 12 * sd + (jump[r] == 15 ? lb : jump[r]));
+            const V3 ap = {p[0], p[1], p[2]}; const Q4 aq = {p[3], p[4], p[5], p[6]};
+            const V3 np = ap + mul(q2m(aq), tp[sd]);
+            const Q4 nq = qmul(aq, tq[sd]);
+            if (jump[r] != 15) { tp[sd] = np; tq[sd] = nq; }
+        });
+    });
     M3 mat[2]; V3 pos[2]; Q4 quat[2]; SV vel[2], acc[2]; SV cdof[2][3];
+    SV own[2];                                                        // this body's joint velocity contribution sum_K cdof_K qd_K
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
-        XRec me = xb_read(xb, body[sd]);
-        mat[sd] = q2m(me.quat); pos[sd] = me.pos; quat[sd] = me.quat;
-        const V3 r = o - me.pos;
-        sfor<0, 3>([&](auto K) { const V3 ax = col(mat[sd], K); cdof[sd][K] = {ax, cross(ax, r)}; });
-        if (ball) {                                                  // 3 dofs: axes x, y, z in order
-            const XRec P = xb_read(xb, 2 + 12 * sd + par);
-            SV v = P.vel, a = P.acc;
-            const SV vp = v;
-            sfor<0, 3>([&](auto K) { const float qd = S(F_QVEL + dadr[sd] + K); a = a + crossMotion(vp, cdof[sd][K]) * qd; v = v + cdof[sd][K] * qd; });
-            me.vel = v; me.acc = a;
-        }
-        vel[sd] = me.vel; acc[sd] = me.acc;
+        pos[sd] = o + mul(pmat, tp[sd]);
+        quat[sd] = qnormalize(qmul(pel.quat, tq[sd]));
+        mat[sd] = q2m(quat[sd]);
+        const V3 r = o - pos[sd];
+        own[sd] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        sfor<0, 3>([&](auto K) { const V3 ax = col(mat[sd], K); cdof[sd][K] = {ax, cross(ax, r)}; own[sd] = own[sd] + cdof[sd][K] * qd[sd][K]; });
+    });
+    // chain sum of a spatial vector (6 floats per body record)
+    auto chain_sum = [&](SV (&val)[2]) {
+        sfor<0, 3>([&](auto Rn) {
+            constexpr int r = Rn;
+            __syncthreads();
+            if (bl) sfor<0, 2>([&](auto Sd) {
+                float* p = xb + XB_SZ * body[Sd];
+                p[0] = val[Sd].a.x; p[1] = val[Sd].a.y; p[2] = val[Sd].a.z; p[3] = val[Sd].l.x; p[4] = val[Sd].l.y; p[5] = val[Sd].l.z;
+            });
+            __syncthreads();
+            sfor<0, 2>([&](auto Sd) {
+                constexpr int sd = Sd;
+                const float* p = xb + XB_SZ * (2 + 12 * sd + (jump[r] == 15 ? lb : jump[r]));
+                const SV av = {{p[0], p[1], p[2]}, {p[3], p[4], p[5]}};
+                if (jump[r] != 15) val[sd] = val[sd] + av;
+            });
+        });
+    };
+    sfor<0, 2>([&](auto Sd) { vel[Sd] = own[Sd]; });
+    chain_sum(vel);
+    sfor<0, 2>([&](auto Sd) {
+        constexpr int sd = Sd;
+        vel[sd] = vel[sd] + pel.vel;
+        const SV vp = {vel[sd].a - own[sd].a, vel[sd].l - own[sd].l};        // parent body's velocity
+        SV t = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+        sfor<0, 3>([&](auto K) { t = t + crossMotion(vp, cdof[sd][K]) * qd[sd][K]; });
+        acc[sd] = t;
+    });
+    chain_sum(acc);
+    sfor<0, 2>([&](auto Sd) {
+        constexpr int sd = Sd;
+        acc[sd] = acc[sd] + pel.acc;
         if (bl && hasj) {
             if (ball) sfor<0, 3>([&](auto K) {
                 float* c = (float*)&S.W(WK_CDOF + 6 * (dadr[sd] + K));
@@ -374,18 +416,20 @@ __device__ __forceinline__ void factor_lane(const St& S, const LaneIdx& X, float
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd, blk = WK_M + M_LEG0 + M_LEGSZ * sd;
         sfor<0, 13>([&](auto J) {
-            float v = X.mi[J] != 0xFFFF ? S.W(blk + X.mi[J]) : 0.f;
-            if (l == J) v += hdamp * S(F_DAMP + 6 + 13 * sd + J);
+            const bool ok = X.mi[J] != 0xFFFF;
+            float v = S.W(blk + (ok ? X.mi[J] : 0));            // unconditional load from a clamped address + select: no exec-mask region
+            v = ok ? v : 0.f;
+            v += l == J ? hdamp * S(F_DAMP + 6 + 13 * sd + J) : 0.f;
             R[sd][J] = v;
         });
-        sfor<0, 6>([&](auto Pp) { P[sd][Pp] = l < 13 ? S.W(blk + X.own + X.dep - 1 - Pp) : 0.f; });
+        sfor<0, 6>([&](auto Pp) { const float v = S.W(blk + X.own + X.dep - 1 - Pp); P[sd][Pp] = l < 13 ? v : 0.f; });
     });
     // ---- legs: eliminate dof 12 .. 0 of both legs at once
     srfor<0, 13>([&](auto K) {
         constexpr int k = K;
         sfor<0, 2>([&](auto Sd) {
             constexpr int sd = Sd;
-            const float inv = __frcp_rn(dpp<0x150 + k>(R[sd][k]));
+            const float inv = rcpf(dpp<0x150 + k>(R[sd][k]));
             const float tmp = l < k ? R[sd][k] * inv : 0.f;
             sfor<0, k>([&](auto J) { constexpr int j = J; if constexpr (leg_anc(k, j)) R[sd][j] -= tmp * dpp<0x150 + k>(R[sd][j]); });
             sfor<0, 6>([&](auto Pp) { P[sd][Pp] -= tmp * dpp<0x150 + k>(P[sd][Pp]); });
@@ -396,7 +440,7 @@ __device__ __forceinline__ void factor_lane(const St& S, const LaneIdx& X, float
         constexpr int sd = Sd;
         float D = 1.f;
         sfor<0, 13>([&](auto J) { if (l == J) D = R[sd][J]; });
-        F.D[sd] = D; F.invD[sd] = __frcp_rn(D);
+        F.D[sd] = D; F.invD[sd] = rcpf(D);
         sfor<0, 13>([&](auto J) { F.Lr[sd][J] = (J < l && l < 13) ? R[sd][J] * F.invD[sd] : 0.f; F.Lc[sd][J] = J > l ? R[sd][J] : 0.f; });
         sfor<0, 6>([&](auto Pp) { F.w[sd][Pp] = P[sd][Pp] * F.invD[sd]; });
     });
@@ -412,7 +456,7 @@ __device__ __forceinline__ void factor_lane(const St& S, const LaneIdx& X, float
     });
     srfor<0, 6>([&](auto K) {
         constexpr int k = K;
-        F.Dp[k] = Pm[k][k]; F.invDp[k] = __frcp_rn(Pm[k][k]);
+        F.Dp[k] = Pm[k][k]; F.invDp[k] = rcpf(Pm[k][k]);
         sfor<0, k>([&](auto I) {
             constexpr int i = I;
             const float tmp = Pm[k][i] * F.invDp[k];
@@ -424,12 +468,13 @@ __device__ __forceinline__ void factor_lane(const St& S, const LaneIdx& X, float
 // factor -> WK_LD (ancestor-chain layout, read by the row stage) and WK_DISQ
 __device__ __forceinline__ void fac_store(const St& S, const LaneIdx& X, const LaneFac& F) {
     const int l = X.l;
-    if (l < 13) sfor<0, 2>([&](auto Sd) {
+    sfor<0, 2>([&](auto Sd) {      // branch-free: stores that do not apply go to the env's dummy word
         constexpr int sd = Sd, blk = WK_LD + M_LEG0 + M_LEGSZ * sd;
-        S.W(blk + X.own) = F.D[sd];
-        sfor<0, 12>([&](auto J) { if (J < l && X.mi[J] != 0xFFFF) S.W(blk + X.mi[J]) = F.Lr[sd][J]; });
-        sfor<0, 6>([&](auto Pp) { S.W(blk + X.own + X.dep - 1 - Pp) = F.w[sd][Pp]; });
-        S.W(WK_DISQ + 6 + 13 * sd + l) = rsqrtf(F.D[sd]);
+        const bool leg = l < 13;
+        S.W(leg ? blk + X.own : WK_DUMMY) = F.D[sd];
+        sfor<0, 12>([&](auto J) { S.W((J < l && leg && X.mi[J] != 0xFFFF) ? blk + X.mi[J] : WK_DUMMY) = F.Lr[sd][J]; });
+        sfor<0, 6>([&](auto Pp) { S.W(leg ? blk + X.own + X.dep - 1 - Pp : WK_DUMMY) = F.w[sd][Pp]; });
+        S.W(leg ? WK_DISQ + 6 + 13 * sd + l : WK_DUMMY) = rsqrtf(F.D[sd]);
     });
     if (l == 0) sfor<0, 6>([&](auto Pi) {
         constexpr int p = Pi;
@@ -442,16 +487,19 @@ __device__ __forceinline__ void fac_load(const St& S, const LaneIdx& X, LaneFac&
     const int l = X.l;
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd, blk = WK_LD + M_LEG0 + M_LEGSZ * sd;
-        F.D[sd] = l < 13 ? S.W(blk + X.own) : 1.f; F.invD[sd] = __frcp_rn(F.D[sd]);
+        const float dv = S.W(blk + X.own);
+        F.D[sd] = l < 13 ? dv : 1.f; F.invD[sd] = rcpf(F.D[sd]);
         sfor<0, 13>([&](auto J) {
-            const float v = (X.mi[J] != 0xFFFF && l != J) ? S.W(blk + X.mi[J]) : 0.f;
+            const bool ok = X.mi[J] != 0xFFFF && l != J;
+            float v = S.W(blk + (ok ? X.mi[J] : 0));
+            v = ok ? v : 0.f;
             F.Lr[sd][J] = J < l ? v : 0.f; F.Lc[sd][J] = J > l ? v : 0.f;
         });
-        sfor<0, 6>([&](auto Pp) { F.w[sd][Pp] = l < 13 ? S.W(blk + X.own + X.dep - 1 - Pp) : 0.f; });
+        sfor<0, 6>([&](auto Pp) { const float v = S.W(blk + X.own + X.dep - 1 - Pp); F.w[sd][Pp] = l < 13 ? v : 0.f; });
     });
     sfor<0, 6>([&](auto Pi) {
         constexpr int p = Pi;
-        F.Dp[p] = S.W(WK_LD + ct_dof_madr[p]); F.invDp[p] = __frcp_rn(F.Dp[p]);
+        F.Dp[p] = S.W(WK_LD + ct_dof_madr[p]); F.invDp[p] = rcpf(F.Dp[p]);
         sfor<0, p>([&](auto Qi) { F.Lp[p][Qi] = S.W(WK_LD + ct_dof_madr[p] + (p - Qi)); });
     });
 }
@@ -577,7 +625,7 @@ __device__ __forceinline__ void stage_finish_lane(const St& S, const float* rows
         if (nw > 0.f) {
             float sn, cs;
             __sincosf(0.5f * nw * DT, &sn, &cs);
-            const float sc = sn / nw;
+            const float sc = sn * rcpf(nw);
             q = qmul(q, Q4{cs, wv.x * sc, wv.y * sc, wv.z * sc});
         }
         q = qnormalize(q);
@@ -705,12 +753,12 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out) {
         const float diag = isEq ? (E ? tranAC : tranPL) : ldiw;
         const RowK kb = solref(isEq ? 0.005f : 0.02f);
         const float imp = impedance(imp_pos);
-        const float R = fmaxf(MINVAL, (1.f - imp) / imp * diag);
+        const float R = fmaxf(MINVAL, (1.f - imp) * rcpf(imp) * diag);
         const float aref = -kb.B * vel - kb.K * imp * pos;
         float b = ju - aref;
-        float f = -(jw - aref) / R;
+        float f = -(jw - aref) * rcpf(R);
         if (isLim && f < 0.f) f = 0.f;
-        float invA = 1.f / (nn + R), Rw = R;
+        float invA = rcpf(nn + R), Rw = R;
         if (isLim && !nlim) { b = 0.f; f = 0.f; invA = 0.f; Rw = 1.f; }
         out.b = b; out.R = Rw; out.invA = invA; out.f = f;
     }
@@ -729,8 +777,9 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out) {
         const float tran = Gs == 0 ? S(F_BIW + 13 + 12 * LEG) : Gs == 1 ? S(F_BIW + 9 + 12 * LEG) : S(F_BIW + 8 + 12 * LEG);
         const RowK kb = solref(0.005f);
         const float imp = impedance(dist);
-        const float R1 = fmaxf(MINVAL, (1.f - imp) / imp * (tran + mu * mu * tran));
+        const float R1 = fmaxf(MINVAL, (1.f - imp) * rcpf(imp) * (tran + mu * mu * tran));
         const float Rpy = fmaxf(MINVAL, 2.f * mu * mu * R1);       // pyramidal regulariser, impratio 1
+        const float iRpy = rcpf(Rpy);
         const float sv[4] = {mu * v1, -mu * v1, mu * v2, -mu * v2}, su[4] = {mu * u1, -mu * u1, mu * u2, -mu * u2};
         const float sw[4] = {mu * w1, -mu * w1, mu * w2, -mu * w2};
         out.cG[s][0] = gnn; out.cG[s][1] = gn1; out.cG[s][2] = gn2; out.cG[s][3] = g11; out.cG[s][4] = g12; out.cG[s][5] = g22;
@@ -739,7 +788,7 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out) {
             constexpr int k = K;
             const float aref = -kb.B * (vn + sv[k]) - kb.K * imp * dist;
             out.cb[s][k] = un + su[k] - aref;
-            const float f = -((wn + sw[k]) - aref) / Rpy;
+            const float f = -((wn + sw[k]) - aref) * iRpy;
             out.cf[s][k] = (s < nc && f > 0.f) ? f : 0.f;
         });
     });
@@ -796,7 +845,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
             constexpr int k = K;
             cb[s][k] = Lr.cb[j][k]; cf[s][k] = Lr.cf[j][k];
             const float sm = ((k & 1) ? -mu : mu), gnj = k < 2 ? cG[s][1] : cG[s][2], gjj = k < 2 ? cG[s][3] : cG[s][5];
-            ciA[s][k] = __frcp_rn(cG[s][0] + 2.f * sm * gnj + mu * mu * gjj + cR[s]);      // A_kk + R of row n + s mu t_j
+            ciA[s][k] = rcpf(cG[s][0] + 2.f * sm * gnj + mu * mu * gjj + cR[s]);      // A_kk + R of row n + s mu t_j
             // row k = n + sm t_j moves the basis residuals (rn, r1, r2) by df * (G n-col + sm G j-col)
             kn[s][k] = cG[s][0] + sm * gnj; k1[s][k] = cG[s][1] + sm * (k < 2 ? cG[s][3] : cG[s][4]); k2[s][k] = cG[s][2] + sm * (k < 2 ? cG[s][4] : cG[s][5]);
         });

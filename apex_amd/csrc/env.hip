@@ -299,7 +299,9 @@ __device__ __noinline__ void stage4_finish(St S, int mode) {
 // Generation 4: the wave holds 4 envs, one per 16-lane row.  Stages not yet converted to the lane-parallel form run on the
 // row's lead lane; every call site is reached by all lanes.
 __device__ __forceinline__ void sim_step_pd(const St& S, int pgs_iters, int mode) {
-    const bool lead = (threadIdx.x & 15) == 0;
+#ifdef APX_PROF
+    const unsigned long long t0__ = clock64();
+#endif
     stage1_io_lane(S, mode);
     __syncthreads();
     stage1b_tree_lane(S);
@@ -310,6 +312,9 @@ __device__ __forceinline__ void sim_step_pd(const St& S, int pgs_iters, int mode
     __syncthreads();
     stage4_finish(S, mode);
     __syncthreads();
+#ifdef APX_PROF
+    if (threadIdx.x == 0 && blockIdx.x == 0) c3::g_prof_acc[8] += clock64() - t0__;
+#endif
 }
 #else
 // The workgroup is TWO waves over the same 64 envs (lane l of both waves = env l): wave 0 runs the serial stages, the

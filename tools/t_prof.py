@@ -3,7 +3,7 @@ import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__
 from apex_amd.vecenv import CassieVecEnv
 env = CassieVecEnv(n_envs=4096, seed=0)
 env.reset()
-act = torch.randn(4096,10,device='cuda')*0.2
+torch.manual_seed(0); act = torch.randn(4096,10,device="cuda")*0.2
 for _ in range(2): env.step(act, auto_reset=False)
 buf = torch.zeros(4096*128, device='cuda')
 from apex_amd import _lib; from apex_amd.engine import _p, _stream
@@ -18,4 +18,4 @@ p = buf[:12].cpu().numpy() / (K*50)
 names=["io_model","tree_walk","factor","pgs_tail(z~)","finish+euler","rows(2 legs)","gram+warm","pgs_sweeps"]
 print("env step ms %.1f"%(dt*1e3))
 for n,v in zip(names,p): print("%-16s %9.0f cycles/substep"%(n,v))
-print("total %.0f cycles/substep"%p[:8].sum())
+print("total %.0f cycles/substep"%p[:8].sum()); print("whole sim_step_pd %.0f cycles/substep" % p[8])
