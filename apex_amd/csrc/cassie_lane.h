@@ -874,6 +874,8 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
         sfor<0, 2>([&](auto Lg) { sfor<0, 7>([&](auto Sx) { ef[Lg][Sx] = 0.f; }); });
         sfor<0, NCS>([&](auto Sl) { sfor<0, 4>([&](auto K) { cf[Sl][K] = 0.f; }); });
     }
+    float eb[2][6];
+    sfor<0, 2>([&](auto Lg) { sfor<0, 6>([&](auto Sx) { eb[Lg][Sx] = ec[Lg][Sx]; }); });
     sfor<0, 2>([&](auto Lg) { sfor<0, 7>([&](auto Sx) { ec[Lg][Sx] += eR[Lg][Sx] * ef[Lg][Sx]; }); });      // c = b + R f
     PROF(6);
     // ---- sweeps
@@ -886,7 +888,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
                 constexpr int s = Sx;
                 const float t = (leg ? dpp<0x150 + s>(rB) : dpp<0x150 + s>(rA)) + ec[leg][s];
                 const float df = -t * eiA[leg][s];
-                ec[leg][s] += eR[leg][s] * df; ef[leg][s] += df;
+                ec[leg][s] += eR[leg][s] * df;                  // f itself is recovered from c = b + R f after the sweeps
                 rA += Ga[s] * df; rB += Gb[s] * df;
             });
             if (nlim[leg]) {
@@ -921,6 +923,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     }
     PROF(7);
     // ---- z~ = sum_r y~_r F_r back to the dof layout of the finish stage
+    sfor<0, 2>([&](auto Lg) { sfor<0, 6>([&](auto Sx) { ef[Lg][Sx] = (ec[Lg][Sx] - eb[Lg][Sx]) * rcpf(eR[Lg][Sx]); }); });
     float ownA = 0.f, ownB = 0.f;
     sfor<0, 7>([&](auto Sx) { if (l == Sx) { ownA = ef[0][Sx]; ownB = ef[1][Sx]; } });
     sfor<0, NCS>([&](auto Sl) {
