@@ -160,21 +160,38 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     floatx16 acc = {0};
     const bool a_kmajor = (g.a_cs == 1);   // k contiguous in memory
     const bool b_kmajor = (g.b_rs == 1);
-    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+    // software pipeline: the global loads of k-tile t+1 are in flight while the MFMAs of tile t run out of LDS
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int m, k;
             if (a_kmajor) { k = tid & 15; m = (tid >> 4) + 16 * i; }
             else          { m = tid & 63; k = (tid >> 6) + 4 * i; }
             const int gm = m0 + m, gk = k0 + k;
-            As[k][m] = (gm < g.M && gk < kend) ? g.A[gm * g.a_rs + gk * g.a_cs] : 0.f;
+            ra[i] = (gm < g.M && gk < kend) ? g.A[gm * g.a_rs + gk * g.a_cs] : 0.f;
             int n, kk;
             if (b_kmajor) { kk = tid & 15; n = (tid >> 4) + 16 * i; }
             else          { n = tid & 63; kk = (tid >> 6) + 4 * i; }
             const int gn = n0 + n, gkk = k0 + kk;
-            Bs[kk][n] = (gn < g.N && gkk < kend) ? g.B[gkk * g.b_rs + gn * g.b_cs] : 0.f;
+            rb[i] = (gn < g.N && gkk < kend) ? g.B[gkk * g.b_rs + gn * g.b_cs] : 0.f;
+        }
+    };
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int m, k;
+            if (a_kmajor) { k = tid & 15; m = (tid >> 4) + 16 * i; }
+            else          { m = tid & 63; k = (tid >> 6) + 4 * i; }
+            As[k][m] = ra[i];
+            int n, kk;
+            if (b_kmajor) { kk = tid & 15; n = (tid >> 4) + 16 * i; }
+            else          { n = tid & 63; kk = (tid >> 6) + 4 * i; }
+            Bs[kk][n] = rb[i];
         }
         __syncthreads();
+        if (k0 + GBK < kend) fetch(k0 + GBK);
 #pragma unroll
         for (int kk = 0; kk < GBK; kk += 2) {
             const float a = As[kk + (lane >> 5)][wm + (lane & 31)];
