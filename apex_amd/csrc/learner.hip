@@ -160,6 +160,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     floatx16 acc = {0};
     const bool a_kmajor = (g.a_cs == 1);   // k contiguous in memory
     const bool b_kmajor = (g.b_rs == 1);
+    const bool bias_grad = EPI == EPI_ATOMIC && g.aux != nullptr && blockIdx.y == 0;
+    float bsum = 0.f;
     // software pipeline: the global loads of k-tile t+1 are in flight while the MFMAs of tile t run out of LDS
     float ra[4], rb[4];
     auto fetch = [&](int k0) {
@@ -192,6 +194,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
         __syncthreads();
         if (k0 + GBK < kend) fetch(k0 + GBK);
+        if (EPI == EPI_ATOMIC && bias_grad && tid < GBM) {      // fused bias gradient: column sums of dY ride on the A tile
+#pragma unroll
+            for (int kk = 0; kk < GBK; ++kk) bsum += As[kk][tid];
+        }
 #pragma unroll
         for (int kk = 0; kk < GBK; kk += 2) {
             const float a = As[kk + (lane >> 5)][wm + (lane & 31)];
@@ -200,6 +206,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
         __syncthreads();
     }
+    if (EPI == EPI_ATOMIC && bias_grad && tid < GBM && m0 + tid < g.M) atomicAdd(const_cast<float*>(g.aux) + m0 + tid, bsum);
     const int col = n0 + wn + (lane & 31);
     if (col >= g.N) return;
     float bias = 0.f;
@@ -252,31 +259,13 @@ static int linear_bwd_input(const float* dY, const float* W, const float* mask, 
     return launch_gemm(mask ? EPI_MASK : EPI_STORE, g, 1, s);
 }
 // dW[Dout,Din] += dY^T X  (split-K over the batch, fp32 atomics)
-static int linear_bwd_weight(const float* dY, const float* X, float* dW, long B, int Din, int Dout, hipStream_t s) {
-    GemmArgs g{dY, 1, Dout, X, Din, 1, dW, Din, nullptr, 0, Dout, Din, (int)B, 0};
+// db[Dout] += column sums of dY, fused into the same launch (they ride on the dY tile already in LDS)
+static int linear_bwd_weight(const float* dY, const float* X, float* dW, float* db, long B, int Din, int Dout, hipStream_t s) {
+    GemmArgs g{dY, 1, Dout, X, Din, 1, dW, Din, db, 0, Dout, Din, (int)B, 0};
     int ksplit = (int)(B / 256);
     if (ksplit < 1) ksplit = 1;
     if (ksplit > 64) ksplit = 64;
     return launch_gemm(EPI_ATOMIC, g, ksplit, s);
-}
-
-// db[n] += sum_m dY[m, n]
-__global__ void colsum_kernel(const float* __restrict__ dY, long B, int N, float* __restrict__ db) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    const long rows_per = (B + gridDim.y - 1) / gridDim.y;
-    const long r0 = blockIdx.y * rows_per, r1 = min(B, r0 + rows_per);
-    float s = 0.f;
-    for (long r = r0; r < r1; ++r) s += dY[r * N + n];
-    atomicAdd(db + n, s);
-}
-static int colsum(const float* dY, long B, int N, float* db, hipStream_t s) {
-    int chunks = (int)(B / 64);
-    if (chunks < 1) chunks = 1;
-    if (chunks > 256) chunks = 256;
-    hipLaunchKernelGGL(colsum_kernel, dim3(apx_cdiv(N, 64), chunks), dim3(64), 0, s, dY, B, N, db);
-    APX_LAUNCH_CHECK();
-    return APX_OK;
 }
 
 extern "C" size_t apx_mlp_param_count(int D, int H, int O) {
@@ -312,14 +301,11 @@ static int mlp_backward_impl(const float* params, float* grads, int D, int H, in
                              const float* a2, const float* dy, long B, float* dh2, float* dh1, hipStream_t s) {
     MlpView p(params, D, H, O);
     MlpGrad g(grads, D, H, O);
-    APX_TRY(linear_bwd_weight(dy, a2, g.W2, B, H, O, s));
-    APX_TRY(colsum(dy, B, O, g.b2, s));
+    APX_TRY(linear_bwd_weight(dy, a2, g.W2, g.b2, B, H, O, s));
     APX_TRY(linear_bwd_input(dy, p.W2, a2, dh2, B, H, O, s));
-    APX_TRY(linear_bwd_weight(dh2, a1, g.W1, B, H, H, s));
-    APX_TRY(colsum(dh2, B, H, g.b1, s));
+    APX_TRY(linear_bwd_weight(dh2, a1, g.W1, g.b1, B, H, H, s));
     APX_TRY(linear_bwd_input(dh2, p.W1, a1, dh1, B, H, H, s));
-    APX_TRY(linear_bwd_weight(dh1, xn, g.W0, B, D, H, s));
-    APX_TRY(colsum(dh1, B, H, g.b0, s));
+    APX_TRY(linear_bwd_weight(dh1, xn, g.W0, g.b0, B, D, H, s));
     return APX_OK;
 }
 
