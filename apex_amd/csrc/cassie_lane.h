@@ -811,20 +811,26 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     PROF(5);
     // ---- Gram columns of this lane's two rows
     float GAA[13], GBB[13], GAB[13], GBA[13];      // GXY[s] = y~_(r,X) . y~_(s,Y)
-    sfor<0, 13>([&](auto Sx) {
-        constexpr int s = Sx;
-        float aa = 0.f, bb = 0.f, ab = 0.f, ba = 0.f;
-        sfor<0, 19>([&](auto C) {
-            constexpr int c = C;
-            const float sa = dpp<0x150 + s>(A.J[c]), sb = dpp<0x150 + s>(B.J[c]);
-            aa += A.J[c] * sa; bb += B.J[c] * sb;
-            if constexpr (c < 6) { ab += A.J[c] * sb; ba += B.J[c] * sa; }
+    {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 JP[19];                                 // (left, right) row of this lane, packed for v_pk_fma_f32
+        sfor<0, 19>([&](auto C) { JP[C] = f2{A.J[C], B.J[C]}; });
+        sfor<0, 13>([&](auto Sx) {
+            constexpr int s = Sx;
+            f2 d = {0.f, 0.f}, x = {0.f, 0.f};     // (aa, bb), (ab, ba)
+            sfor<0, 19>([&](auto C) {
+                constexpr int c = C;
+                const f2 sv = {dpp<0x150 + s>(A.J[c]), dpp<0x150 + s>(B.J[c])};
+                d += JP[c] * sv;
+                if constexpr (c < 6) x += JP[c] * f2{sv.y, sv.x};      // the legs only meet in the pelvis columns
+            });
+            // pin the sums here: LLVM otherwise sinks the fma chains into the conditional contact blocks that consume them while the
+            // (convergent) broadcasts stay put, and ~500 broadcast values get spilled to scratch in between
+            float aa = d.x, bb = d.y, ab = x.x, ba = x.y;
+            asm volatile("" : "+v"(aa), "+v"(bb), "+v"(ab), "+v"(ba));
+            GAA[s] = aa; GBB[s] = bb; GAB[s] = ab; GBA[s] = ba;
         });
-        // pin the sums here: LLVM otherwise sinks the fma chains into the conditional contact blocks that consume them while the
-        // (convergent) broadcasts stay put, and ~500 broadcast values get spilled to scratch in between
-        asm volatile("" : "+v"(aa), "+v"(bb), "+v"(ab), "+v"(ba));
-        GAA[s] = aa; GBB[s] = bb; GAB[s] = ab; GBA[s] = ba;
-    });
+    }
     // ---- row scalars to every lane: c = b + R f, R, 1/(A+R), f
     float ec[2][7], eR[2][7], eiA[2][7], ef[2][7];
     sfor<0, 7>([&](auto Sx) {
@@ -878,49 +884,61 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     sfor<0, 2>([&](auto Lg) { sfor<0, 6>([&](auto Sx) { eb[Lg][Sx] = ec[Lg][Sx]; }); });
     sfor<0, 2>([&](auto Lg) { sfor<0, 7>([&](auto Sx) { ec[Lg][Sx] += eR[Lg][Sx] * ef[Lg][Sx]; }); });      // c = b + R f
     PROF(6);
-    // ---- sweeps
+    // ---- sweeps.  Packed fp32 (v_pk_fma_f32) wherever two independent updates share the multiplier: (rho_A, rho_B), the
+    // running (n, active tangent) residuals of a pyramid, and its (sum df, sum +-mu df) accumulators.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 r = {rA, rB};
+    f2 Gp[2][13];                                           // how a coefficient of leg L's basis s moves (rho_A, rho_B)
+    sfor<0, 13>([&](auto Sx) { Gp[0][Sx] = f2{GAA[Sx], GBA[Sx]}; Gp[1][Sx] = f2{GAB[Sx], GBB[Sx]}; });
+    f2 kk[NCS][4]; float ko[NCS][4];                        // row k moves (r_n, r_active) by kk df and the other tangent's residual by ko df
+    sfor<0, NCS>([&](auto Sl) { sfor<0, 4>([&](auto K) {
+        constexpr int k = K;
+        kk[Sl][k] = f2{kn[Sl][k], k < 2 ? k1[Sl][k] : k2[Sl][k]}; ko[Sl][k] = k < 2 ? k2[Sl][k] : k1[Sl][k];
+    }); });
+    const f2 cplus = {1.f, mu}, cminus = {1.f, -mu};
     for (int it = 0; it < pgs_iters; ++it) {
         sfor<0, 2>([&](auto Lg) {
             constexpr int leg = Lg;
-            const float (&Ga)[13] = leg ? GAB : GAA;      // how a coefficient of this leg's basis s moves rho_A, rho_B
-            const float (&Gb)[13] = leg ? GBB : GBA;
             sfor<0, 6>([&](auto Sx) {
                 constexpr int s = Sx;
-                const float t = (leg ? dpp<0x150 + s>(rB) : dpp<0x150 + s>(rA)) + ec[leg][s];
+                const float t = (leg ? dpp<0x150 + s>(r.y) : dpp<0x150 + s>(r.x)) + ec[leg][s];
                 const float df = -t * eiA[leg][s];
                 ec[leg][s] += eR[leg][s] * df;                  // f itself is recovered from c = b + R f after the sweeps
-                rA += Ga[s] * df; rB += Gb[s] * df;
+                r += Gp[leg][s] * df;
             });
             if (nlim[leg]) {
-                const float t = (leg ? dpp<0x150 + 6>(rB) : dpp<0x150 + 6>(rA)) + ec[leg][6];
+                const float t = (leg ? dpp<0x150 + 6>(r.y) : dpp<0x150 + 6>(r.x)) + ec[leg][6];
                 const float fn = fmaxf(ef[leg][6] - t * eiA[leg][6], 0.f);
                 const float df = fn - ef[leg][6];
                 ef[leg][6] = fn; ec[leg][6] += eR[leg][6] * df;
-                rA += Ga[6] * df; rB += Gb[6] * df;
+                r += Gp[leg][6] * df;
             }
             sfor<0, MAXC>([&](auto Sl) {
                 constexpr int j = Sl, s = leg * MAXC + j, ln = 7 + 3 * j;
                 if (con[s]) {
-                    float rn = leg ? dpp<0x150 + ln>(rB) : dpp<0x150 + ln>(rA), r1 = leg ? dpp<0x150 + ln + 1>(rB) : dpp<0x150 + ln + 1>(rA),
-                          r2 = leg ? dpp<0x150 + ln + 2>(rB) : dpp<0x150 + ln + 2>(rA);
-                    float sdn = 0.f, sd1 = 0.f, sd2 = 0.f;
+                    const float rn0 = leg ? dpp<0x150 + ln>(r.y) : dpp<0x150 + ln>(r.x), r10 = leg ? dpp<0x150 + ln + 1>(r.y) : dpp<0x150 + ln + 1>(r.x),
+                                r20 = leg ? dpp<0x150 + ln + 2>(r.y) : dpp<0x150 + ln + 2>(r.x);
+                    f2 pr = {rn0, r10};          // (r_n, r_t1) while rows n +- mu t1 are swept
+                    float ro = r20;              // the other tangent's residual
+                    f2 q01 = {0.f, 0.f}, q23 = {0.f, 0.f};      // (sum df, sum +-mu df) of rows 0,1 / 2,3
                     sfor<0, 4>([&](auto K) {
                         constexpr int k = K;
+                        if constexpr (k == 2) { const float t1 = pr.y; pr.y = ro; ro = t1; }      // now (r_n, r_t2), other = r_t1
                         const float sm = (k & 1) ? -mu : mu;
-                        const float res = cb[s][k] + cR[s] * cf[s][k] + rn + sm * (k < 2 ? r1 : r2);
+                        const float res = cb[s][k] + cR[s] * cf[s][k] + pr.x + sm * pr.y;
                         const float fn = fmaxf(cf[s][k] - res * ciA[s][k], 0.f);
                         const float df = fn - cf[s][k];
                         cf[s][k] = fn;
-                        rn += df * kn[s][k]; r1 += df * k1[s][k]; r2 += df * k2[s][k];
-                        if constexpr (k < 2) sd1 += sm * df; else sd2 += sm * df;
-                        sdn += df;
+                        pr += kk[s][k] * df; ro += ko[s][k] * df;
+                        if constexpr (k < 2) q01 += ((k & 1) ? cminus : cplus) * df; else q23 += ((k & 1) ? cminus : cplus) * df;
                     });
-                    rA += Ga[ln] * sdn + Ga[ln + 1] * sd1 + Ga[ln + 2] * sd2;
-                    rB += Gb[ln] * sdn + Gb[ln + 1] * sd1 + Gb[ln + 2] * sd2;
+                    const float sdn = q01.x + q23.x;
+                    r += Gp[leg][ln] * sdn + Gp[leg][ln + 1] * q01.y + Gp[leg][ln + 2] * q23.y;
                 }
             });
         });
     }
+    rA = r.x; rB = r.y;
     PROF(7);
     // ---- z~ = sum_r y~_r F_r back to the dof layout of the finish stage
     sfor<0, 2>([&](auto Lg) { sfor<0, 6>([&](auto Sx) { ef[Lg][Sx] = (ec[Lg][Sx] - eb[Lg][Sx]) * rcpf(eR[Lg][Sx]); }); });
