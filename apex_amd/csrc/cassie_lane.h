@@ -102,7 +102,15 @@ __device__ __forceinline__ void body_inertia_force(const M3& R, V3 pos, V3 o, co
     frc = imul(c, acc) + crossForce(vel, imul(c, vel));
 }
 
+struct Qpos0 { float v[CM_NQ]; };
+constexpr Qpos0 make_qpos0() { Qpos0 q{}; for (int i = 0; i < CM_NQ; ++i) q.v[i] = ct_qpos0[i]; return q; }
+__device__ const Qpos0 kQpos0 = make_qpos0();
+
+// QPOS0 = true: the configuration-only pass of mj_setConst (qpos0, zero velocities; emits the COM of the bodies that carry
+// constraints instead of anchors / capsule ends)
+template <bool QPOS0>
 __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
+    auto qp = [&](int i) -> float { if constexpr (QPOS0) return kQpos0.v[i]; else return S(F_QPOS + i); };
     const int l = threadIdx.x & 15;
     const int lb = l < 12 ? l : 11;                                     // lanes 12..15 shadow the foot lane (their body results are not stored)
     const bool bl = l < 12;
@@ -124,10 +132,10 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
     const float jref = lb == 4 ? ct_jnt_ref[8] : lb == 7 ? ct_jnt_ref[10] : 0.f;          // knee, tarsus
     static_assert(ct_jnt_ref[19] == ct_jnt_ref[8] && ct_jnt_ref[21] == ct_jnt_ref[10] && ct_jnt_ref[9] == 0.f, "joint refs");
     // ---- pelvis (every lane)
-    const V3 o = {S(F_QPOS), S(F_QPOS + 1), S(F_QPOS + 2)};
+    const V3 o = {qp(0), qp(1), qp(2)};
     XRec pel;
     pel.pos = o;
-    pel.quat = qnormalize(Q4{S(F_QPOS + 3), S(F_QPOS + 4), S(F_QPOS + 5), S(F_QPOS + 6)});
+    pel.quat = qnormalize(Q4{qp(3), qp(4), qp(5), qp(6)});
     const M3 pmat = q2m(pel.quat);
     SV pc[6] = {{{0, 0, 0}, {1, 0, 0}}, {{0, 0, 0}, {0, 1, 0}}, {{0, 0, 0}, {0, 0, 1}}, {col(pmat, 0), {0, 0, 0}}, {col(pmat, 1), {0, 0, 0}}, {col(pmat, 2), {0, 0, 0}}};
     {
@@ -157,11 +165,11 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         qd[sd][0] = qd[sd][1] = qd[sd][2] = 0.f;
         if (hasj) {
             if (ball) {
-                jq = qnormalize(Q4{S(F_QPOS + qadr[sd]), S(F_QPOS + qadr[sd] + 1), S(F_QPOS + qadr[sd] + 2), S(F_QPOS + qadr[sd] + 3)});
+                jq = qnormalize(Q4{qp(qadr[sd]), qp(qadr[sd] + 1), qp(qadr[sd] + 2), qp(qadr[sd] + 3)});
                 sfor<0, 3>([&](auto K) { qd[sd][K] = S(F_QVEL + dadr[sd] + K); });
             } else {
                 float sn, cs;
-                __sincosf(0.5f * (S(F_QPOS + qadr[sd]) - jref), &sn, &cs);
+                __sincosf(0.5f * (qp(qadr[sd]) - jref), &sn, &cs);
                 jq = {cs, 0.f, 0.f, sn};
                 qd[sd][2] = S(F_QVEL + dadr[sd]);
             }
@@ -303,6 +311,11 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             const V3 c = pos[sd] + mul(mat[sd], cpos), ax = mul(mat[sd], cax) * half;
             put(off, c + ax); put(off + 3, c - ax);
         };
+        if constexpr (QPOS0) {      // world COM of the constraint bodies, slot order of c2::cslot: achilles, heel-spring, plantar-rod, foot, tarsus, shin
+            const int cs = l == 3 ? 0 : l == 8 ? 1 : l == 10 ? 2 : l == 11 ? 3 : l == 7 ? 4 : l == 6 ? 5 : -1;
+            if (cs >= 0) put(base + 3 * cs, pos[sd] + mul(mat[sd], ipos[sd]));
+            return;
+        }
         static_assert(ct_eq_body1[0] == 12 && ct_eq_body2[0] == 13 && ct_eq_body1[1] == 5 && ct_eq_body2[1] == 10, "connect bodies");
         static_assert(ct_geom_body[0] == 13 && ct_geom_body[2] == 9 && ct_geom_body[4] == 8, "capsule bodies");
         if (l == 10) put(base + 0, pos[sd] + mul(mat[sd], cv3<2 * sd>(ct_eq_anchor1)));            // plantar-rod: connect 0, anchor 1
@@ -345,8 +358,8 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         // qfrc_smooth = passive - bias + actuation
         const int k = l;       // leg-local dof
         float fs = -S(F_DAMP + d) * S(F_QVEL + d) - sdot(cd, fsub);
-        if (l == 7) fs -= ct_jnt_stiffness[9] * S(F_QPOS + ct_jnt_qposadr[9] + 14 * sd);            // shin spring
-        if (l == 9) fs -= ct_jnt_stiffness[11] * S(F_QPOS + ct_jnt_qposadr[11] + 14 * sd);          // heel spring
+        if (l == 7) fs -= ct_jnt_stiffness[9] * qp(ct_jnt_qposadr[9] + 14 * sd);            // shin spring
+        if (l == 9) fs -= ct_jnt_stiffness[11] * qp(ct_jnt_qposadr[11] + 14 * sd);          // heel spring
         static_assert(ct_jnt_stiffness[20] == ct_jnt_stiffness[9] && ct_jnt_stiffness[22] == ct_jnt_stiffness[11] && ct_jnt_qposadr[20] == ct_jnt_qposadr[9] + 14, "springs");
         const int u = k == 0 ? 0 : k == 1 ? 1 : k == 2 ? 2 : k == 6 ? 3 : k == 12 ? 4 : -1;       // actuated dofs: hip roll, yaw, pitch, knee, foot
         if (u >= 0) {
@@ -357,7 +370,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         S.W(WK_SMOOTH + d) = fs;
     });
     // ---- foot pose for the reward / foot velocity (cassie.py:328-331,426-427)
-    if (l == 11) sfor<0, 2>([&](auto Sd) {
+    if (!QPOS0 && l == 11) sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
         S(F_FWD + 2 + 4 * sd) = quat[sd].w; S(F_FWD + 3 + 4 * sd) = quat[sd].x; S(F_FWD + 4 + 4 * sd) = quat[sd].y; S(F_FWD + 5 + 4 * sd) = quat[sd].z;
         S(F_FWD + 10 + 3 * sd) = pos[sd].x; S(F_FWD + 11 + 3 * sd) = pos[sd].y; S(F_FWD + 12 + 3 * sd) = pos[sd].z - 0.0550841220316708f;
@@ -649,6 +662,60 @@ __device__ __forceinline__ void stage_finish_lane(const St& S, const float* rows
     }
 }
 
+// y~ = D^-1/2 L^-T J^T for this lane's row over the 19 local columns of leg LEG (L streamed from LDS, uniform addresses); returns |y~|^2
+template <int LEG>
+__device__ __forceinline__ float whiten_lane(const St& S, float (&J)[19]) {
+    srfor<0, 19>([&](auto C) {
+        constexpr int c = C, i = c2d<LEG>(c);
+        sfor<1, ct_dof_depth[i]>([&](auto A) { constexpr int a = A; J[d2c(ct_dof_anc[16 * i + a])] -= S.W(WK_LD + ct_dof_madr[i] + a) * J[c]; });
+    });
+    float nn = 0.f;
+    sfor<0, 19>([&](auto C) { constexpr int c = C; J[c] *= S.W(WK_DISQ + c2d<LEG>(c)); nn += J[c] * J[c]; });
+    return nn;
+}
+
+// mj_setConst subset, lane-parallel (after stage_tree_lane<true> and stage_factor_lane): body_invweight0 (translational) of the
+// six constraint bodies of leg LEG and dof_invweight0 of its eight limited joints, |y~|^2 = J M^-1 J^T of unit rows.
+// Two passes of 13 row vectors: pass 0 = bodies 0..3 (x, y, z) + limit 0, pass 1 = bodies 4, 5 + limits 1..7.
+template <int LEG>
+__device__ __forceinline__ void setconst_rows_lane(const St& S) {
+    const int l = threadIdx.x & 15;
+    const V3 o = {ct_qpos0[0], ct_qpos0[1], ct_qpos0[2]};
+    sfor<0, 2>([&](auto Ps) {
+        constexpr int pass = Ps;
+        const bool isBody = pass == 0 ? l < 12 : l < 6;
+        const int sl = (pass == 0 ? 0 : 4) + l / 3, ax = l % 3;                       // body slot, world axis
+        const int jl = pass == 0 ? 0 : l - 5;                                      // limited-joint index 0..7 (pass 0: lane 12, pass 1: lanes 6..12)
+        const int kl = jl == 0 ? 0 : jl == 1 ? 1 : jl == 2 ? 2 : jl == 3 ? 6 : jl == 4 ? 7 : jl == 5 ? 8 : jl == 6 ? 10 : 12;      // its leg dof
+        static_assert(ct_jnt_limited[4] == 1 && ct_jnt_limited[8] == 1 && ct_jnt_limited[9] == 1 && ct_jnt_limited[10] == 1 && ct_jnt_limited[12] == 1 && ct_jnt_limited[14] == 1 &&
+                      ct_jnt_limited[11] == 0 && ct_jnt_limited[13] == 0 && ct_jnt_dofadr[12] == 16 && ct_jnt_dofadr[14] == 18, "limited joints of a leg");
+        const bool isLim = !isBody && l < 13;
+        unsigned m = 0u;
+        sfor<0, 6>([&](auto Sl) { if (sl == Sl) m = chain_mask<LEG>(cbody<LEG>(Sl)); });
+        if (!isBody) m = 0u;
+        const int slc = sl < 6 ? sl : 5;
+        const V3 com = {S.W(WK_PTS + 30 * LEG + 3 * slc), S.W(WK_PTS + 30 * LEG + 3 * slc + 1), S.W(WK_PTS + 30 * LEG + 3 * slc + 2)};
+        const V3 dir = {ax == 0 ? 1.f : 0.f, ax == 1 ? 1.f : 0.f, ax == 2 ? 1.f : 0.f};
+        const V3 q = cross(com - o, dir);
+        float J[19];
+        sfor<0, 19>([&](auto C) {
+            constexpr int c = C, d = c2d<LEG>(c);
+            const V3 ca = {S.W(WK_CDOF + 6 * d), S.W(WK_CDOF + 6 * d + 1), S.W(WK_CDOF + 6 * d + 2)};
+            const V3 cl = {S.W(WK_CDOF + 6 * d + 3), S.W(WK_CDOF + 6 * d + 4), S.W(WK_CDOF + 6 * d + 5)};
+            float v = ((m >> c) & 1u) ? dot(dir, cl) + dot(q, ca) : 0.f;
+            if (isLim && c == 6 + kl) v = 1.f;
+            J[c] = v;
+        });
+        const float nn = whiten_lane<LEG>(S, J);
+        const float tr = nn + dpp<0x111>(nn) + dpp<0x112>(nn);                     // x + y + z on the z lane (row_shr 1, 2)
+        int bsel = 0;
+        sfor<0, 6>([&](auto Sl) { if (sl == Sl) bsel = cbody<LEG>(Sl); });
+        if (isBody && ax == 2) S(F_BIW + bsel) = tr * (1.f / 3.f);
+        if (isLim) S(F_DIW + 6 + 13 * LEG + kl) = nn;
+    });
+    if (l == 0) S(F_BIW) = 0.f;
+}
+
 // Constraint rows of leg LEG, one row vector per lane: Jacobian from the stored motion axes, dots against
 // qvel / qacc_smooth / qacc_warmstart on the raw row, whitening y~ = D^-1/2 L^-T J^T (L streamed from LDS, uniform
 // addresses), row scalars.  Same arithmetic as c3::build_rows3, except that a connect row takes the common ancestors of
@@ -737,12 +804,7 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out) {
         constexpr int c = C, d = c2d<LEG>(c);
         vel += J[c] * S(F_QVEL + d); ju += J[c] * S.W(WK_QS + d); jw += J[c] * S(F_QACCW + d);
     });
-    srfor<0, 19>([&](auto C) {
-        constexpr int c = C, i = c2d<LEG>(c);
-        sfor<1, ct_dof_depth[i]>([&](auto A) { constexpr int a = A; J[d2c(ct_dof_anc[16 * i + a])] -= S.W(WK_LD + ct_dof_madr[i] + a) * J[c]; });
-    });
-    float nn = 0.f;
-    sfor<0, 19>([&](auto C) { constexpr int c = C; J[c] *= S.W(WK_DISQ + c2d<LEG>(c)); nn += J[c] * J[c]; });
+    const float nn = whiten_lane<LEG>(S, J);
     // ---- equality / limit scalars (mj_makeImpedance, mj_referenceConstraint, warm start from qacc_warmstart)
     {
         const V3 cv = p1 - p2;

@@ -28,9 +28,11 @@ constexpr float GRAV = 9.81f;
 
 // ------------------------------------------------------------------------------------------------ forward dynamics
 // mj_setConst subset (cassie_step3.h), staged like the substep
+#if APX_GEN != 4
 __device__ __noinline__ void setconst_a(St S) { c3::setconst_tree(S); c3::setconst_factor(S); }
 template <int LEG> __device__ __noinline__ void setconst_b(St S) { c3::setconst_leg<LEG>(S); }
 __device__ __forceinline__ void set_const_single_wave(const St& S) { setconst_a(S); setconst_b<0>(S); setconst_b<1>(S); }
+#endif
 
 // ------------------------------------------------------------------------------------------------ native substep model
 __constant__ float kP[5] = {100.f, 100.f, 88.f, 96.f, 50.f};
@@ -220,7 +222,7 @@ __device__ __forceinline__ void stage1_io_lane(St S, int mode) {   // (as a call
 }
 __device__ APX_STAGE void stage1b_tree_lane(St S) {
     PROF_START();
-    c4::stage_tree_lane(S, rows4());
+    c4::stage_tree_lane<false>(S, rows4());
     PROF(1);
 }
 #else
@@ -296,6 +298,16 @@ __device__ __noinline__ void stage4_finish(St S, int mode) {
 }
 #endif
 #if APX_GEN == 4
+// mj_setConst (sim.set_const after dynamics randomisation), lane-parallel: tree at qpos0 -> factor -> |y~|^2 of unit rows
+__device__ __forceinline__ void setconst_lane(const St& S) {
+    c4::stage_tree_lane<true>(S, rows4());
+    __syncthreads();
+    c4::stage_factor_lane(S);
+    __syncthreads();
+    c4::setconst_rows_lane<0>(S);
+    c4::setconst_rows_lane<1>(S);
+    __syncthreads();
+}
 // Generation 4: the wave holds 4 envs, one per 16-lane row.  Stages not yet converted to the lane-parallel form run on the
 // row's lead lane; every call site is reached by all lanes.
 __device__ __forceinline__ void sim_step_pd(const St& S, int pgs_iters, int mode) {
@@ -477,11 +489,10 @@ __device__ void env_reset_finish(const St& S, const Cfg& cfg) {
 // CassieEnv.reset (cassie/cassie.py:523-680); called by all 16 lanes of the env's row
 __device__ __forceinline__ void env_reset(const St& S, const Cfg& cfg) {
     const bool lead = (threadIdx.x & 15) == 0;
-    if (lead) {
-        env_reset_draws(S, cfg);
-        if (cfg.dyn_rand) set_const_single_wave(S);     // sim.set_const -> mj_setConst
-    }
+    if (lead) env_reset_draws(S, cfg);
     __syncthreads();
+    if (cfg.dyn_rand) setconst_lane(S);               // sim.set_const -> mj_setConst
+
     sim_step_pd(S, cfg.pgs_iters, 0);               // cassie_sim_set_const ends in mj_forward
     sim_step_pd(S, cfg.pgs_iters, 1);               // cassie.py:665 (stale pd_in_t)
     if (lead) env_reset_finish(S, cfg);
@@ -586,7 +597,7 @@ __global__ __launch_bounds__(64) void env_init_kernel(float* st, int* ist, int n
 __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_setconst_kernel(float* st, int* ist, float* wk, int n, Cfg cfg) {
     ENV_SETUP
     load_state(S, st, ist, n);
-    if (lead) set_const_single_wave(S);
+    setconst_lane(S);
     store_state(S, st, ist, n);
 }
 
