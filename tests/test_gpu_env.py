@@ -150,3 +150,54 @@ def test_step_invariants_full_size(dev):
         ints = env.get_field("ints")
         assert (ints[:, 0] == lens).all()                        # time counter == steps since last reset
     assert n_done >= 4096                                        # every env finished at least once (horizon 30 < 40 steps)
+
+
+def test_single_substep_crafted_states(dev):
+    """One 2 kHz substep from crafted states, HIP vs oracle: low / pitched pelvis poses put foot, tarsus AND shin capsule ends
+    into the floor (every contact-geometry branch of the row stage), knee / hip-roll / foot joints start past their range
+    (limit rows).  A single substep keeps the comparison free of chaotic divergence: qacc and the integrated qvel must agree to
+    fp32 solver accuracy."""
+    genv, oenv = _mk(False, 11)
+    genv.reset(); [e.reset() for e in oenv[:12]]
+    rng = np.random.RandomState(5)
+    qpos = genv.get_field("qpos").cpu().numpy().astype(np.float64)
+    qvel = genv.get_field("qvel").cpu().numpy().astype(np.float64)
+    cases = []
+    for i in range(12):
+        q = qpos[i].copy(); v = 0.05 * rng.randn(32)
+        kind = i % 4
+        if kind == 0:                       # standing low: both feet pressed into the floor
+            q[2] = 0.80 + 0.02 * rng.rand()
+        elif kind == 1:                     # pelvis pitched forward and low: tarsus / shin ends reach the floor
+            q[2] = 0.45 + 0.05 * rng.rand()
+            ang = 0.9 + 0.3 * rng.rand()
+            q[3:7] = [np.cos(ang / 2), 0.0, np.sin(ang / 2), 0.0]
+        elif kind == 2:                     # joint limits: hip roll, knee, foot beyond their ranges
+            q[2] = 1.2
+            q[7] = 0.45; q[14] = -0.60; q[20] = -0.45; q[21] = -0.45; q[28] = -2.95; q[34] = -2.50
+        else:                               # rolled and low: one-sided contacts with mixed geoms
+            q[2] = 0.50 + 0.05 * rng.rand()
+            ang = 0.7
+            q[3:7] = [np.cos(ang / 2), np.sin(ang / 2), 0.0, 0.0]
+        cases.append((q, v))
+        qpos[i] = q; qvel[i] = v
+    genv.set_field("qpos", torch.tensor(qpos, dtype=torch.float32))
+    genv.set_field("qvel", torch.tensor(qvel, dtype=torch.float32))
+    genv.set_field("qacc_warm", torch.zeros(N, 32))
+    genv.substep()
+    qa = genv.get_field("qacc_warm").cpu().numpy(); qv = genv.get_field("qvel").cpu().numpy()
+    ncon_seen, nlim_cases = 0, 0
+    for i, e in enumerate(oenv[:12]):
+        q, v = cases[i]
+        e.set("qpos", q.astype(np.float32).astype(np.float64)); e.set("qvel", v.astype(np.float32).astype(np.float64)); e.set("qacc_warm", np.zeros(32))
+        e.substep()
+        ints = e.get("ints")
+        ncon_seen = max(ncon_seen, int(ints[3]))
+        nlim_cases += int(i % 4 == 2)
+        ref_a, ref_v = e.get("qacc_warm"), e.get("qvel")
+        scale = np.maximum(1.0, np.abs(ref_a))
+        assert np.all(np.isfinite(qa[i]))
+        tol = np.full(32, 3e-2); tol[[9, 22]] = 0.25      # spin of the achilles rods about their own axis: inertia 3.8e-6, fp32 solver noise
+        assert np.all(np.abs(qa[i] - ref_a) / scale <= tol), ("case %d" % i, np.abs(qa[i] - ref_a) / scale)
+        np.testing.assert_allclose(qv[i], ref_v, atol=2e-3 + 5e-4 * np.abs(ref_a).max(), rtol=2e-3, err_msg="case %d" % i)
+    assert ncon_seen >= 3          # more than the two foot ends: tarsus / shin geometry took part
