@@ -93,7 +93,7 @@ class Mlp:
         for v, t in zip(self.views(), tensors):
             v.copy_(torch.as_tensor(np.asarray(t), dtype=torch.float32))
 
-    def forward(self, x, obs_mean=None, obs_std=None, idx=None, sign_perm=None, clock_mask=0, keep=False):
+    def forward(self, x, obs_mean=None, obs_std=None, idx=None, sign_perm=None, clock_mask=0, keep=False, out=None):
         _need_gpu(x)
         x = x.contiguous()
         B = x.shape[0] if idx is None else idx.numel()
@@ -101,7 +101,11 @@ class Mlp:
         xn = torch.empty(B, self.D, dtype=torch.float32, device=dev)
         a1 = torch.empty(B, self.H, dtype=torch.float32, device=dev)
         a2 = torch.empty(B, self.H, dtype=torch.float32, device=dev)
-        y = torch.empty(B, self.O, dtype=torch.float32, device=dev)
+        if out is not None:
+            assert out.is_contiguous() and out.numel() == B * self.O and out.dtype == torch.float32 and out.is_cuda
+            y = out
+        else:
+            y = torch.empty(B, self.O, dtype=torch.float32, device=dev)
         check(_lib.load().apx_mlp_forward(_p(self.params), self.D, self.H, self.O, _p(x), B, _p(idx), _p(sign_perm),
                                           int(clock_mask), _p(obs_mean), _p(obs_std), _p(xn), _p(a1), _p(a2), _p(y), 0,
                                           _stream()))

@@ -83,6 +83,7 @@ class PPO:
         self.b_done = torch.zeros(T, N, dtype=torch.uint8, device=self.device)
         self.b_endb = torch.zeros(T, N, dtype=torch.bool, device=self.device)
         self.b_fin = torch.zeros(T, N, 50, **f32)
+        self.noise = torch.zeros(N, 10, **f32)
         self.ep_ret = torch.zeros(N, **f32); self.ep_len = torch.zeros(N, **f32)
         self.obs = None
 
@@ -144,17 +145,16 @@ class PPO:
         L, env = self.learner, self.env
         if self.obs is None:
             self.obs = env.reset().clone()
-        obs = self.obs
         T, N = self.T, self.N
-        for t in range(T):
-            mu = L.actor.forward(obs, L.obs_mean, L.obs_std)
-            val = L.critic.forward(obs).view(-1)
-            act = mu + self.fixed_std * torch.randn(mu.shape, device=self.device, generator=self.gen)
-            self.b_obs[t].copy_(obs); self.b_mu[t].copy_(mu); self.b_act[t].copy_(act); self.b_val[t].copy_(val)
-            nobs, rew, done, fin = env.step(act)
-            self.b_rew[t].copy_(rew); self.b_done[t].copy_(done); self.b_fin[t].copy_(fin)
-            obs = nobs
-        self.obs = obs.clone()
+        self.b_obs[0].copy_(self.obs)
+        for t in range(T):      # every kernel writes straight into the rollout grids: no staging copies
+            obs = self.b_obs[t]
+            mu = L.actor.forward(obs, L.obs_mean, L.obs_std, out=self.b_mu[t])
+            L.critic.forward(obs, out=self.b_val[t])
+            torch.randn(mu.shape, device=self.device, generator=self.gen, out=self.noise)
+            torch.add(mu, self.noise, alpha=self.fixed_std, out=self.b_act[t])
+            nxt = self.b_obs[t + 1] if t + 1 < T else self.obs
+            env.step(self.b_act[t], out=(nxt, self.b_rew[t], self.b_done[t], self.b_fin[t]))
         torch.ne(self.b_done, 0, out=self.b_endb)
         self.b_end.copy_(self.b_endb)
         vfin = L.critic.forward(self.b_fin.view(T * N, 50)).view(T, N)

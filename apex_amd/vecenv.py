@@ -86,15 +86,20 @@ class CassieVecEnv:
         check(_lib.load().apx_env_reset(self._h, _p(mask), _p(self.obs), _stream()))
         return self.obs
 
-    def step(self, action, auto_reset=True, f_term=0):
+    def step(self, action, auto_reset=True, f_term=0, out=None):
         """CassieEnv.step for every env.  `f_term` is accepted and ignored exactly like cassie/cassie.py:389.
         Returns (obs, reward, done, final_obs): done 1 = terminated, 2 = truncated at max_traj_len; with auto_reset the
-        finished envs restart inside the same launch and `final_obs` holds their last observation."""
+        finished envs restart inside the same launch and `final_obs` holds their last observation (rows of envs that did not
+        finish are left untouched).  `out` = (obs, reward, done, final_obs) lets the kernels write straight into caller-owned
+        contiguous device buffers (e.g. slices of a rollout grid) instead of the env's own."""
         action = action.contiguous()
         assert action.shape == (self.n_envs, ACT_DIM) and action.dtype == torch.float32 and action.is_cuda
-        check(_lib.load().apx_env_step(self._h, _p(action), _p(self.obs), _p(self.reward), _p(self.done),
-                                       _p(self.final_obs), int(auto_reset), _stream()))
-        return self.obs, self.reward, self.done, self.final_obs
+        obs, rew, done, fin = out if out is not None else (self.obs, self.reward, self.done, self.final_obs)
+        if out is not None:
+            assert obs.is_contiguous() and rew.is_contiguous() and done.is_contiguous() and fin.is_contiguous()
+            assert obs.shape == (self.n_envs, OBS_DIM) and fin.shape == (self.n_envs, OBS_DIM) and done.dtype == torch.uint8
+        check(_lib.load().apx_env_step(self._h, _p(action), _p(obs), _p(rew), _p(done), _p(fin), int(auto_reset), _stream()))
+        return obs, rew, done, fin
 
     # ---- raw state access (tests, tools) ----
     def get_field(self, name, count=None):
