@@ -136,3 +136,65 @@ def test_env_episode_runs_and_terminates():
         assert np.isfinite(obs).all() and np.isfinite(r) and -0.5 < r < 1.0
         t += 1
     assert done in (1, 2)
+
+
+def test_g14_reset_draws_and_randomisation_tables(golden_dir):
+    """G14: the reference's CassieEnv.__init__ + reset run on a recording CassieSim stand-in with intercepted RNG
+    (tools/refprobe/gen_golden_dynrand.py).  (1) the reference's draw order and ranges have the structure the env code
+    assumes; (2) the oracle's reset, re-derived draw by draw from its Philox stream with the REFERENCE's range factors,
+    reproduces the oracle's parameters exactly (the GPU kernel is tied to the oracle by tests/test_gpu_env.py)."""
+    g = np.load(os.path.join(golden_dir, "g14_dynrand.npz"))
+    dr = g["draws"]                                            # rows: kind (0 uniform, 1 randint), lo, hi, count
+    assert len(dr) == 145 and int(dr[:, 3].sum()) == 159
+    c = g["consts"]                                            # damping lo/hi, mass lo/hi, fric lo/hi, roll, pitch, enc noise, speed, side speed
+    np.testing.assert_allclose(c, [0.3, 5.0, 0.5, 1.5, 0.4, 1.1, 0.03, 0.03, 0.01, -0.3, 4.0, -0.3, 0.3])
+    # ---- (1) structure of the reference's reset
+    assert tuple(dr[0][:3]) == (0, -0.3, 4.0) and tuple(dr[1][:3]) == (0, -0.3, 0.3)                 # speed, side speed
+    assert dr[2][0] == 1 and dr[2][1] == 0 and dr[2][2] == np.floor(g["phase"][1])                  # random.randint(0, floor(phaselen))
+    dd, dm = g["default_damping"], g["default_mass"]
+    # quirk (cassie.py:595-597, 619-622): the right leg's ranges are the LEFT leg's list appended a second time, i.e. they are
+    # built from the left defaults; on cassie.xml left and right defaults are equal, so the env code uses each dof's own default
+    dd_ref = np.concatenate([dd[:19], dd[6:19]]); dm_ref = np.concatenate([dm[:14], dm[2:14]])
+    d_lo, d_hi = dr[3:35, 1] / dd_ref, dr[3:35, 2] / dd_ref
+    vary = np.array([1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 0, 1], bool)                                  # heel-spring (k=9), plantar-rod (k=11) fixed
+    exp_lo = np.concatenate([np.ones(6), np.where(vary, 0.3, 1.0), np.where(vary, 0.3, 1.0)])
+    exp_hi = np.concatenate([np.ones(6), np.where(vary, 5.0, 1.0), np.where(vary, 5.0, 1.0)])
+    np.testing.assert_allclose(d_lo, exp_lo, rtol=1e-12); np.testing.assert_allclose(d_hi, exp_hi, rtol=1e-12)
+    assert tuple(dr[35][1:3]) == (0.0, 0.0)                                                          # world body
+    np.testing.assert_allclose(dr[36:61, 1] / dm_ref[1:], 0.5, rtol=1e-12); np.testing.assert_allclose(dr[36:61, 2] / dm_ref[1:], 1.5, rtol=1e-12)
+    assert np.all(dr[61:136, 1] == dr[61:136, 2])                                                    # 75 COM draws with delta = 0: consumed, no effect
+    np.testing.assert_allclose(dr[136:139, 1:3], [[0.4, 1.1], [1e-4, 5e-4], [1e-4, 2e-4]])
+    fr = g["set_friction"].reshape(-1, 3)
+    assert np.all(fr == fr[0])                                                                       # one triple for every geom
+    np.testing.assert_allclose(dr[139:141, 1:3], [[-0.03, 0.03], [-0.03, 0.03]])                     # roll, pitch
+    assert tuple(dr[141]) == (0, -0.01, 0.01, 10) and tuple(dr[142]) == (0, -0.01, 0.01, 6)          # encoder noise
+    assert tuple(dr[143][:3]) == (0, -0.3, 4.0) and tuple(dr[144][:3]) == (0, -0.3, 0.3)             # commands redrawn after the settle step
+    assert int(g["n_set_const"][0]) == 1 and int(g["n_step_pd"][0]) == 1                             # one sim.set_const (:660), one step_pd (:665)
+    # floor quaternion = euler2quat(z=0, y=pitch, x=roll) of the two slope draws; our closed form (cx cy, cy sx, cx sy, sx sy)
+    def unit(k): return ((k + 1) * 0.61803398875) % 1.0
+    roll, pitch = -0.03 + 0.06 * unit(139), -0.03 + 0.06 * unit(140)                                 # draws 139, 140 (all earlier draws are scalars)
+    cx, sx, cy, sy = np.cos(roll / 2), np.sin(roll / 2), np.cos(pitch / 2), np.sin(pitch / 2)
+    np.testing.assert_allclose(g["set_geom_quat"][:4], [cx * cy, cy * sx, cx * sy, sx * sy], atol=1e-12)
+    # clipping at 0 and the clock from the FIRST speed draw
+    assert np.all(g["set_damping"] >= 0) and np.all(g["set_mass"] >= 0)
+    sp0 = -0.3 + 4.3 * unit(0)
+    total = (0.9 - 0.25 / 3.0 * abs(sp0)) / 2
+    np.testing.assert_allclose(g["swing_stance"], [(0.30 + (0.40 / 3) * abs(sp0)) * total, (0.70 - (0.40 / 3) * abs(sp0)) * total], rtol=1e-12)
+    # ---- (2) the oracle's reset, draw by draw, with the reference's factors
+    for seed, eid in ((3, 0), (3, 5), (11, 2)):
+        e = S.OracleEnv(dyn_rand=True, seed=seed, env_id=eid)
+        d0, m0 = e.get("damping").copy(), e.get("mass").copy()
+        e.reset()
+        u01 = lambda k: ((S.philox(seed, eid, k) >> 8) + 0.5) / 16777216.0
+        uni = lambda k, a, b: a + (b - a) * u01(k)
+        np.testing.assert_allclose(e.get("damping"), [d0[d] * (d_lo[d] + (d_hi[d] - d_lo[d]) * u01(3 + d)) for d in range(32)], rtol=1e-12)
+        exp_m = [0.0] + [m0[b] * uni(35 + b, 0.5, 1.5) for b in range(1, 26)]
+        np.testing.assert_allclose(e.get("mass"), exp_m, rtol=1e-12)
+        np.testing.assert_allclose(e.get("friction")[0], uni(61, *dr[136, 1:3]), rtol=1e-12)
+        r_, p_ = uni(64, -0.03, 0.03), uni(65, -0.03, 0.03)
+        cx, sx, cy, sy = np.cos(r_ / 2), np.sin(r_ / 2), np.cos(p_ / 2), np.sin(p_ / 2)
+        np.testing.assert_allclose(e.get("floor_quat"), [cx * cy, cy * sx, cx * sy, sx * sy], atol=1e-12)
+        np.testing.assert_allclose(e.get("motor_noise"), [uni(66 + u, -0.01, 0.01) for u in range(10)], rtol=1e-12)
+        np.testing.assert_allclose(e.get("joint_noise"), [uni(76 + k, -0.01, 0.01) for k in range(6)], rtol=1e-12)
+        np.testing.assert_allclose([e.get("speed")[0], e.get("side_speed")[0]], [uni(82, -0.3, 4.0), uni(83, -0.3, 0.3)], rtol=1e-12)
+        assert int(e.get("ints")[5]) == 84                                                           # draws consumed by one reset
