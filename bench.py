@@ -62,9 +62,18 @@ def main():
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     group = None
+    # test hook (tools/t_two_ranks.sh): APX_BENCH_SHARE_GPU=1 puts every rank on cuda:0 with the gloo backend, so that the
+    # N > 1 control flow (env shards, gradient / moment all-reduces, max-over-ranks timing) can be exercised on a 1-GPU box.
+    # The driver's multi-GPU runs use one GPU per rank over RCCL.
+    share = os.environ.get("APX_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if share:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
         group = torch.distributed.group.WORLD
     from apex_amd.vecenv import CassieVecEnv
     from apex_amd.ppo import PPO
