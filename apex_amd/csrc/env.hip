@@ -91,11 +91,17 @@ __device__ __noinline__ void stage1_io_tree(St S, int mode) {
         ssign[u] = mpos_a[u] > hi ? -1.f : 1.f;
         sscale *= fmaxf(0.f, 1.f - sdepth[u] * (1.f / 0.15f));
     }
+    float cdep[2];      // coupled hip-pitch + knee zone below -135 deg (golden G10b)
+    for (int leg = 0; leg < 2; ++leg) {
+        cdep[leg] = fmaxf(0.f, -0.75f * PI_F - (mpos_a[5 * leg + 2] + mpos_a[5 * leg + 3]));
+        sscale *= fmaxf(0.f, 1.f - cdep[leg] * (1.f / 0.15f));
+    }
 #pragma unroll
     for (int u = 0; u < 10; ++u) {
         const float sKp[5] = {1000.f, 800.f, 1200.f, 1200.f, 100.f}, sKd[5] = {12.f, 12.f, 36.f, 36.f, 7.f};
         const float gear = cmt::ct_act_gear[u], d = sdepth[u];
         float tau = sscale * tau_cmd[u] + ssign[u] * sKp[u % 5] * d * (1.f + d * (1.f / 0.15f)) - fminf(1.f, d * (1.f / 0.15f)) * sKd[u % 5] * mvel_a[u];
+        if (u % 5 == 2 || u % 5 == 3) { const float c = cdep[u / 5]; tau += sKp[u % 5] * c * (1.f + c * (1.f / 0.15f)) - fminf(1.f, c * (1.f / 0.15f)) * sKd[u % 5] * mvel_a[u]; }
         tau = fminf(fmaxf(tau, -kTorqueLimit[u % 5]), kTorqueLimit[u % 5]);
         // cassie_sim_step_ethercat: torque-speed curve, 6-deep delay line
         const float wmax = cmt::ct_act_rpm[u] * 2.f * PI_F / 60.f, tmax = cmt::ct_act_ctrlmax[u];
@@ -149,7 +155,7 @@ __device__ __forceinline__ void stage1_io_lane(St S, int mode) {   // (as a call
     const int flags = S.I(I_FLAGS);
     const bool mot = l < 10;
     const int u = mot ? l : 0, u5 = u >= 5 ? u - 5 : u, k = mot ? 0 : l - 10;
-    float sdepth = 0.f, ssign = 1.f, tau_cmd = 0.f, mvel = 0.f;
+    float sdepth = 0.f, ssign = 1.f, tau_cmd = 0.f, mvel = 0.f, mpos_l = 0.f;
     const float gear = cm_act_gear[u];
     if (mot) {
         // drive encoder: truncating quantiser + 9-tap FIR velocity
@@ -161,6 +167,7 @@ __device__ __forceinline__ void stage1_io_lane(St S, int mode) {   // (as a call
         float acc = 0.f;
         _Pragma("unroll") for (int i = 0; i < 9; ++i) { S(F_MENC + u * 9 + i) = h[i]; acc += kFir[i] * h[i]; }
         const float mpos = nq * scale / gear;
+        mpos_l = mpos;
         mvel = acc * scale / gear / PI_F;
         S(F_SO + SO_MPOS + u) = mpos; S(F_SO + SO_MVEL + u) = mvel;
         // pd_input_step: tau = P (pTarget - q) + D (0 - qd), no clamp (G9); pd_in_t is zero until the first env.step
@@ -174,13 +181,22 @@ __device__ __forceinline__ void stage1_io_lane(St S, int mode) {   // (as a call
         sdepth = fmaxf(0.f, fmaxf(mpos - hi, lo - mpos));
         ssign = mpos > hi ? -1.f : 1.f;
     }
-    // global torque scale = product over the drives
-    float sscale = fmaxf(0.f, 1.f - sdepth * (1.f / 0.15f));
+    // coupled zone (golden G10b): hip pitch + knee below -135 deg is one more zone acting on both drives of the leg
+    float cdepth = 0.f;
+    {
+        const float pk = mpos_l + c4::dpp<0x101>(mpos_l);                          // row_shl:1 brings lane u+1 (knee) to the pitch lane
+        const float dcp = fmaxf(0.f, -0.75f * PI_F - pk);                          // valid on the pitch lanes u = 2, 7
+        const float dck = c4::dpp<0x111>(dcp);                                     // row_shr:1: the knee lanes u = 3, 8 take their leg's depth
+        cdepth = (mot && u5 == 2) ? dcp : (mot && u5 == 3) ? dck : 0.f;
+    }
+    // global torque scale = product over the drives (the coupled zone counts once per leg: on the pitch lane)
+    float sscale = fmaxf(0.f, 1.f - sdepth * (1.f / 0.15f)) * ((mot && u5 == 2) ? fmaxf(0.f, 1.f - cdepth * (1.f / 0.15f)) : 1.f);
     sscale *= c4::dpp<0xB1>(sscale); sscale *= c4::dpp<0x4E>(sscale); sscale *= c4::dpp<0x141>(sscale); sscale *= c4::dpp<0x140>(sscale);
     if (mot) {
         const float sKp = u5 == 0 ? 1000.f : u5 == 1 ? 800.f : u5 == 4 ? 100.f : 1200.f, sKd = u5 < 2 ? 12.f : u5 == 4 ? 7.f : 36.f;
         const float d = sdepth;
         float tau = sscale * tau_cmd + ssign * sKp * d * (1.f + d * (1.f / 0.15f)) - fminf(1.f, d * (1.f / 0.15f)) * sKd * mvel;
+        tau += sKp * cdepth * (1.f + cdepth * (1.f / 0.15f)) - fminf(1.f, cdepth * (1.f / 0.15f)) * sKd * mvel;      // coupled zone (0 off the pitch / knee lanes)
         tau = fminf(fmaxf(tau, -kTorqueLimit[u5]), kTorqueLimit[u5]);
         // cassie_sim_step_ethercat: torque-speed curve, 6-deep delay line
         const float wmax = cm_act_rpm[u] * 2.f * PI_F / 60.f, tmax = cm_act_ctrlmax[u];

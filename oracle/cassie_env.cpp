@@ -116,9 +116,17 @@ void core_safety(const double* q, const double* qd, const double* cmd, double ra
         sg[u] = q[u] > hi ? -1.0 : 1.0;
         s *= std::max(0.0, 1.0 - d[u] / 0.15);
     }
+    // coupled zone (golden G10b): hip pitch + knee below -135 deg behaves like one more zone whose restoring spring-damper acts
+    // on BOTH drives (each with its own velocity) and whose depth enters the global scale
+    double dc[2];
+    for (int leg = 0; leg < 2; ++leg) {
+        dc[leg] = std::max(0.0, -0.75 * PI - (q[5 * leg + 2] + q[5 * leg + 3]));
+        s *= std::max(0.0, 1.0 - dc[leg] / 0.15);
+    }
     for (int u = 0; u < 10; ++u) {
         const int j = u % 5;
         double t = s * cmd[u] + sg[u] * Kp[j] * d[u] * (1.0 + d[u] / 0.15) - std::min(1.0, d[u] / 0.15) * Kd[j] * qd[u];
+        if (j == 2 || j == 3) { const double c = dc[u / 5]; t += Kp[j] * c * (1.0 + c / 0.15) - std::min(1.0, c / 0.15) * Kd[j] * qd[u]; }
         t = std::min(std::max(t, -kTorqueLimit[j]), kTorqueLimit[j]);
         out[u] = radio > 0 ? t : 0.0;
     }

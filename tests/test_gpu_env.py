@@ -111,6 +111,26 @@ def test_safety_zones_vs_oracle(dev):
     assert hit > 0            # the zones were actually reached
 
 
+def test_coupled_pitch_knee_zone_vs_oracle(dev):
+    """Deep-crouch targets drive hip pitch + knee below -135 deg: the coupled zone of cassie_core_sim_step (golden G10b)."""
+    genv, oenv = _mk(False, 9)
+    genv.reset(); [e.reset() for e in oenv[:8]]
+    rng = np.random.RandomState(3)
+    hit = 0
+    for t in range(8):
+        act = (rng.randn(N, 10) * 0.03).astype(np.float32)
+        act[:, [2, 7]] -= 1.1; act[:, [3, 8]] -= 1.3                     # pitch target -0.6, knee target -2.5
+        genv.step(torch.tensor(act, device=dev), auto_reset=False)
+        tq = genv.get_field("so_torque").cpu().numpy(); mp = genv.get_field("so_mpos").cpu().numpy()
+        for i, e in enumerate(oenv[:8]):
+            e.step(act[i].astype(np.float64))
+            np.testing.assert_allclose(mp[i], e.get("so_mpos"), atol=3e-3 * (t + 1))
+            np.testing.assert_allclose(tq[i], e.get("so_torque"), atol=2.5 * (t + 1), rtol=0.05)
+            q = e.get("so_mpos")
+            hit += int(q[2] + q[3] < -0.75 * np.pi or q[7] + q[8] < -0.75 * np.pi)
+    assert hit > 0            # the coupled zone was actually reached
+
+
 def test_early_clock_reward_vs_oracle(dev):
     """--reward early_clock selects early_clock_reward (cassie.py:202-204, clock_rewards.py:119-223)."""
     from apex_amd.vecenv import CassieVecEnv

@@ -64,6 +64,17 @@ def test_g10_core_sim_safety(golden_dir):
         np.testing.assert_allclose(out, g["tau"][k], rtol=1e-12, atol=1e-10)
 
 
+def test_g10b_core_sim_coupled_pitch_knee_zone(golden_dir):
+    """The coupled zone of cassie_core_sim_step (hip pitch + knee < -135 deg): 300 states of the reference binary, 269 inside."""
+    g = np.load(os.path.join(golden_dir, "g10b_core_sim_coupled.npz"))
+    inside = 0
+    for k in range(g["q"].shape[0]):
+        out = S.core_safety(g["q"][k], g["v"][k], g["cmd"][k], 1.0)
+        np.testing.assert_allclose(out, g["tau"][k], rtol=1e-12, atol=1e-10)
+        inside += int(g["q"][k, 2] + g["q"][k, 3] < -0.75 * np.pi or g["q"][k, 7] + g["q"][k, 8] < -0.75 * np.pi)
+    assert inside > 200
+
+
 def test_g11_estimator_lite_vs_reference_filter(golden_dir):
     """The 7 filtered estimator outputs: our closed-form estimator-lite vs the reference's state_output_step run on this
     simulator's own sensor stream (a falling robot under random actions).  The reference filter is a stateful black box,

@@ -50,7 +50,34 @@ def g10():
     np.savez(os.path.join(GOLD, "g10_core_sim.npz"), q=q, v=v, cmd=cmd, radio=radio, tau=tau, lo=lo, hi=hi)
 
 
+def g10b():
+    """Coupled zone of cassie_core_sim_step: hip pitch + knee below -135 deg (probe_safety5.py).  Random states around and inside
+    it (both legs, with and without the single-joint zones active at the same time), random velocities and commands."""
+    rng = np.random.RandomState(1010)
+    n = 300
+    lo = np.deg2rad([-15, -22, -50, -156, -140.0]) + 0.15; hi = np.deg2rad([20, 22, 80, -42, -35.0]) - 0.15
+    q = np.zeros((n, 10)); v = rng.randn(n, 10) * 2; cmd = rng.randn(n, 10) * 60; tau = np.zeros((n, 10))
+    T = -0.75 * np.pi
+    for k in range(n):
+        for i in range(10):
+            j = i % 5
+            lo_i, hi_i = (lo[j], hi[j]) if (i < 5 or j >= 2) else (-hi[j], -lo[j])
+            q[k, i] = rng.uniform(lo_i, hi_i) if rng.rand() < 0.85 else (hi_i + rng.uniform(0, 0.1) if rng.rand() < 0.5 else lo_i - rng.uniform(0, 0.1))
+        for off in (0, 5):
+            mode = rng.randint(3)
+            if mode == 0: continue                                                   # wherever the draw above put it
+            depth = rng.uniform(-0.05, 0.20) if mode == 1 else rng.uniform(0.0, 0.14)
+            qp = rng.uniform(lo[2] - (0.08 if mode == 2 and rng.rand() < 0.3 else 0.0), 0.2)
+            q[k, off + 2] = qp; q[k, off + 3] = T - depth - qp
+        out = make_out()
+        for i in range(10): set_motor(out, i, pos=q[k, i], vel=v[k, i])
+        tau[k] = core_step(new_core(), out, cmd[k])
+    inside = ((q[:, 2] + q[:, 3] < T) | (q[:, 7] + q[:, 8] < T)).sum()
+    np.savez(os.path.join(GOLD, "g10b_core_sim_coupled.npz"), q=q, v=v, cmd=cmd, tau=tau)
+    print("g10b: %d of %d states inside the coupled zone" % (inside, n))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    g9(); g10()
-    print("wrote g9, g10")
+    g9(); g10(); g10b()
+    print("wrote g9, g10, g10b")
