@@ -221,3 +221,36 @@ def test_single_substep_crafted_states(dev):
         assert np.all(np.abs(qa[i] - ref_a) / scale <= tol), ("case %d" % i, np.abs(qa[i] - ref_a) / scale)
         np.testing.assert_allclose(qv[i], ref_v, atol=2e-3 + 5e-4 * np.abs(ref_a).max(), rtol=2e-3, err_msg="case %d" % i)
     assert ncon_seen >= 3          # more than the two foot ends: tarsus / shin geometry took part
+
+
+def test_random_policy_statistics_match_oracle(dev):
+    """Statistical parity at BASELINE size: random-policy rollouts with auto-reset, 4096 HIP envs vs 40 fp64 oracle envs on
+    other streams of the same generator.  Episode-length and reward statistics must agree within sampling error (the
+    trajectories themselves are chaotic, so this is the long-horizon counterpart of the per-step comparisons above)."""
+    from apex_amd.vecenv import CassieVecEnv
+    T, n, no = 240, 4096, 40
+    g = CassieVecEnv(n_envs=n, seed=21)
+    g.reset()
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    ep_len = torch.zeros(n, device=dev); lens = []; rsum = 0.0; bad = 0
+    for t in range(T):
+        obs, rew, done, _ = g.step(0.2 * torch.randn(n, 10, device=dev, generator=gen))
+        ep_len += 1
+        d = done != 0
+        bad += int((~torch.isfinite(obs)).sum() + (~torch.isfinite(rew)).sum())
+        rsum += float(rew.sum())
+        if bool(d.any()):
+            lens.append(ep_len[d].cpu().numpy()); ep_len[d] = 0
+    lens = np.concatenate(lens)
+    assert bad == 0 and lens.size > 10000
+    rng = np.random.RandomState(7); olens = []; orsum = 0.0; osteps = 0
+    for i in range(no):
+        e = S.OracleEnv(dyn_rand=True, seed=21, env_id=i); e.reset(); L = 0
+        for t in range(T // 2):
+            _, r, d = e.step(0.2 * rng.randn(10)); L += 1; orsum += r; osteps += 1
+            if d:
+                olens.append(L); L = 0; e.reset()
+    olens = np.array(olens)
+    se = np.sqrt(lens.var() / lens.size + olens.var() / olens.size)
+    assert abs(lens.mean() - olens.mean()) < 4.0 * se + 0.3, (lens.mean(), olens.mean(), se)
+    assert abs(rsum / (T * n) - orsum / osteps) < 0.01, (rsum / (T * n), orsum / osteps)
