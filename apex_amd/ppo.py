@@ -84,6 +84,8 @@ class PPO:
         self.b_endb = torch.zeros(T, N, dtype=torch.bool, device=self.device)
         self.b_fin = torch.zeros(T, N, 50, **f32)
         self.noise = torch.zeros(N, 10, **f32)
+        self.use_graph = bool(args.get("graph", False)) and self.world == 1
+        self._graph = None
         self.ep_ret = torch.zeros(N, **f32); self.ep_len = torch.zeros(N, **f32)
         self.obs = None
 
@@ -135,6 +137,18 @@ class PPO:
 
     # ------------------------------------------------------------------------------------------ sampling
     @torch.no_grad()
+    def _rollout_loop(self):
+        L, env, T = self.learner, self.env, self.T
+        self.b_obs[0].copy_(self.obs)
+        for t in range(T):      # every kernel writes straight into the rollout grids: no staging copies
+            obs = self.b_obs[t]
+            mu = L.actor.forward(obs, L.obs_mean, L.obs_std, out=self.b_mu[t])
+            L.critic.forward(obs, out=self.b_val[t])
+            self.noise.normal_(generator=self.gen)
+            torch.add(mu, self.noise, alpha=self.fixed_std, out=self.b_act[t])
+            nxt = self.b_obs[t + 1] if t + 1 < T else self.obs
+            env.step(self.b_act[t], out=(nxt, self.b_rew[t], self.b_done[t], self.b_fin[t]))
+
     def sample(self):
         """T lock-step env steps for the N envs of this GPU (the batched PPO.sample, ppo.py:139-186).
 
@@ -146,15 +160,19 @@ class PPO:
         if self.obs is None:
             self.obs = env.reset().clone()
         T, N = self.T, self.N
-        self.b_obs[0].copy_(self.obs)
-        for t in range(T):      # every kernel writes straight into the rollout grids: no staging copies
-            obs = self.b_obs[t]
-            mu = L.actor.forward(obs, L.obs_mean, L.obs_std, out=self.b_mu[t])
-            L.critic.forward(obs, out=self.b_val[t])
-            torch.randn(mu.shape, device=self.device, generator=self.gen, out=self.noise)
-            torch.add(mu, self.noise, alpha=self.fixed_std, out=self.b_act[t])
-            nxt = self.b_obs[t + 1] if t + 1 < T else self.obs
-            env.step(self.b_act[t], out=(nxt, self.b_rew[t], self.b_done[t], self.b_fin[t]))
+        if self.use_graph:
+            # the T-step rollout is one captured HIP graph (12 launches per step, no host work between them on replay)
+            if self._graph is None:
+                self._rollout_loop()                              # one eager pass first: lazy initialisation, allocator warm-up
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                g.register_generator_state(self.gen)
+                with torch.cuda.graph(g):
+                    self._rollout_loop()
+                self._graph = g
+            self._graph.replay()
+        else:
+            self._rollout_loop()
         torch.ne(self.b_done, 0, out=self.b_endb)
         self.b_end.copy_(self.b_endb)
         vfin = L.critic.forward(self.b_fin.view(T * N, 50)).view(T, N)

@@ -81,7 +81,7 @@ def main():
     env = CassieVecEnv(n_envs=a.n_envs, seed=0, device=local, env_id_base=adist.shard_env_base(rank, a.n_envs))
     args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=a.minibatch,
                 epochs=a.epochs, num_steps=a.rollout_len * a.n_envs * world, max_traj_len=400, max_grad_norm=0.05,
-                mirror=True, std_dev=-1.5, seed=0)
+                mirror=True, std_dev=-1.5, seed=0, graph=os.environ.get("APX_ROLLOUT_GRAPH", "0") == "1")
     algo = PPO(args, "/tmp/apx_bench_unused", env, rank=rank, world_size=world, group=group)
     algo.init_networks(0)
     algo.normalization_params(10000)
