@@ -585,7 +585,12 @@ __device__ float clock_reward(const St& S, const Cfg& cfg, const float* action, 
     const St S{(lfloat*)apx_lds4 + row * L4_ES, env};
 __device__ __forceinline__ void load_state(const St& S, const float* st, const int* ist, int n) {
     const int l = threadIdx.x & 15;
-    for (int f = l; f < F_TOTAL; f += 16) S(f) = st[(size_t)f * n + S.env];
+    constexpr int NIT = (F_TOTAL + 15) / 16;
+    float v[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) { const int f = 16 * i + l; v[i] = f < F_TOTAL ? st[(size_t)f * n + S.env] : 0.f; }      // all loads in flight
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) { const int f = 16 * i + l; if (f < F_TOTAL) S(f) = v[i]; }
     if (l < I_TOTAL) S.I(l) = ist[(size_t)l * n + S.env];
     __syncthreads();
 }

@@ -175,8 +175,11 @@ class PPO:
             self._rollout_loop()
         torch.ne(self.b_done, 0, out=self.b_endb)
         self.b_end.copy_(self.b_endb)
-        vfin = L.critic.forward(self.b_fin.view(T * N, 50)).view(T, N)
-        self.b_boot.copy_(torch.where(self.b_done == 2, vfin, torch.zeros_like(vfin)))      # (not done) * V(s'), ppo.py:184
+        # bootstrap value (not done) * V(s') of the time-limit truncations only (ppo.py:184): gather those rows, one critic pass
+        self.b_boot.zero_()
+        tr_idx = (self.b_done.view(-1) == 2).nonzero().view(-1)
+        if tr_idx.numel():
+            self.b_boot.view(-1)[tr_idx] = L.critic.forward(self.b_fin.view(T * N, 50), idx=tr_idx).view(-1)
         last_val = L.critic.forward(self.obs).view(-1)
         ret = engine.returns_scan(self.b_rew, self.b_end, self.b_boot, last_val, self.gamma)
         ep_rets, ep_lens, self.ep_ret, self.ep_len = episode_stats(self.b_rew, self.b_endb, self.ep_ret, self.ep_len)
