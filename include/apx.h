@@ -136,8 +136,9 @@ int apx_env_reset(apx_env_t* env, const uint8_t* mask, float* obs_out, void* str
 
 /* CassieEnv.step (cassie/cassie.py:389-496) for every env: action[n_envs*10] f32 -> obs[n_envs*50] f32,
  * reward[n_envs] f32, done[n_envs] u8 (1 terminated, 2 truncated at max_traj_len).  With auto_reset != 0 an env
- * that finished is reset in the same launch; its terminal observation (needed for the bootstrap value, ppo.py:183)
- * goes to final_obs (may be NULL) and obs gets the post-reset observation.                 all pointers [dev] */
+ * that finished is reset by a second launch on the same stream; its terminal observation (needed for the bootstrap
+ * value, ppo.py:183) goes to final_obs (may be NULL; rows of envs that did not finish are left untouched) and obs gets
+ * the post-reset observation.                                                                all pointers [dev] */
 int apx_env_step(apx_env_t* env, const float* action, float* obs, float* reward, uint8_t* done, float* final_obs,
                  int auto_reset, void* stream);
 
