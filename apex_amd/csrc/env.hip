@@ -695,6 +695,36 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_substep_kernel(float
     for (int i = 0; i < n_sub; ++i) sim_step_pd(S, cfg.pgs_iters, 1);
     store_state(S, st, ist, n);
 }
+// CassieEnv.reset_for_test(full_reset=False) (cassie/cassie.py:682-742)
+__global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_for_test_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, float* obs) {
+    ENV_SETUP
+    load_state(S, st, ist, n);
+    if (lead) {
+        S.I(I_PHASE) = 0; S.I(I_TIME) = 0; S.I(I_COUNTER) = 0;
+        S(F_CMD + 0) = 0.f; S(F_CMD + 2) = 0.f;                                  // speed, orient_add (side speed is NOT reset)
+        S(F_CMD + 3) = 0.15f; S(F_CMD + 4) = 0.25f; S(F_CMD + 5) = (2.f * 0.15f + 2.f * 0.25f) * (float)(2000 / cfg.simrate);
+    }
+    __syncthreads();
+    sim_step_pd(S, cfg.pgs_iters, 1);                                            // self.cassie_state = self.sim.step_pd(self.u), stale targets
+    if (cfg.dyn_rand) {                                                          // default dynamics, set_const (back to the init pose), flat floor, no encoder offsets
+        if (lead) {
+            for (int b = 0; b < NB; ++b) S(F_MASS + b) = cm_body_mass[b];
+            for (int d = 0; d < NV; ++d) S(F_DAMP + d) = cm_dof_damping[d];
+            S(F_FRIC) = 1.f;
+            const float fl[9] = {0, 0, 1, 0, 1, 0, -1, 0, 0};
+            for (int k = 0; k < 9; ++k) S(F_FLOOR + k) = fl[k];
+            for (int u = 0; u < 10; ++u) S(F_MNOISE + u) = 0.f;
+            for (int k = 0; k < 6; ++k) S(F_JNOISE + k) = 0.f;
+            for (int i = 0; i < NQ; ++i) S(F_QPOS + i) = cm_init_qpos[i];
+            for (int i = 0; i < NV; ++i) { S(F_QVEL + i) = 0.f; S(F_QACCW + i) = 0.f; }
+        }
+        __syncthreads();
+        setconst_lane(S);
+        sim_step_pd(S, cfg.pgs_iters, 0);                                        // cassie_sim_set_const ends in mj_forward
+    }
+    if (lead) write_obs(S, cfg, obs + (size_t)env * APX_OBS_DIM);
+    store_state(S, st, ist, n);
+}
 static constexpr size_t LDS_BYTES = (size_t)L4_EPW * L4_ES * sizeof(float);   // 37,120 B per wave, 4 waves per CU
 #define ENV_GRID(n) dim3((n) / L4_EPW)
 #define ENV_BLOCK dim3(64)
@@ -803,6 +833,23 @@ static constexpr size_t LDS_BYTES = (size_t)c2::CH_TOTAL * c2::EPW * sizeof(floa
 #define SETCONST_LDS 0
 #endif
 
+// CassieEnv.update_speed (cassie/cassie.py:757-775), clock command profile; the phase rescale is done in fp64 like the reference
+// (the old cycle length comes from the stored fp32 swing / stance, so the truncation can differ from an all-fp64 evaluation only
+// when the quotient is within fp32 rounding of an integer)
+__global__ void env_update_speed_kernel(float* st, int* ist, int n, Cfg cfg, const float* speed, const float* side) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= n) return;
+    auto F = [&](int f) -> float& { return st[(size_t)f * n + env]; };
+    const float sp = fminf(fmaxf(speed[env], -0.3f), 4.0f), sd = side ? fminf(fmaxf(side[env], -0.3f), 0.3f) : 0.f;
+    const double s = sp, total = (0.9 - 0.25 / 3.0 * s) / 2;
+    const double swing = (0.30 + ((0.70 - 0.30) / 3) * s) * total, stance = (0.70 - ((0.70 - 0.30) / 3) * s) * total;
+    const double freq = (double)(2000 / cfg.simrate);
+    const double old_len = (2.0 * (double)F(F_CMD + 3) + 2.0 * (double)F(F_CMD + 4)) * freq, new_len = (2.0 * swing + 2.0 * stance) * freq;
+    int& phase = ist[(size_t)I_PHASE * n + env];
+    phase = (int)(new_len * (double)phase / old_len);
+    F(F_CMD + 0) = sp; F(F_CMD + 1) = sd; F(F_CMD + 3) = (float)swing; F(F_CMD + 4) = (float)stance; F(F_CMD + 5) = (float)new_len;
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI
 
 static Cfg make_cfg(const apx_env_cfg& c) {
@@ -857,6 +904,27 @@ extern "C" int apx_env_reset(apx_env_t* e, const uint8_t* mask, float* obs_out, 
                        make_cfg(e->cfg), mask, obs_out);
     APX_LAUNCH_CHECK();
     return APX_OK;
+}
+
+extern "C" int apx_env_update_speed(apx_env_t* e, const float* speed, const float* side_speed, void* stream) {
+    APX_REQUIRE(e && speed, "null pointer");
+    hipLaunchKernelGGL(env_update_speed_kernel, dim3(apx_cdiv((long)e->n, 256)), dim3(256), 0, (hipStream_t)stream, e->st, e->ist, e->n,
+                       make_cfg(e->cfg), speed, side_speed);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+}
+
+extern "C" int apx_env_reset_for_test(apx_env_t* e, float* obs_out, void* stream) {
+    APX_REQUIRE(e && obs_out, "null pointer");
+#if APX_GEN == 4
+    e->cfg.stance_mode = 1;                               // reset_for_test switches to the grounded clock (cassie.py:702)
+    hipLaunchKernelGGL(env_reset_for_test_kernel, ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+                       make_cfg(e->cfg), obs_out);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+#else
+    APX_REQUIRE(false, "apx_env_reset_for_test is implemented by the generation-4 kernel only (build with GEN=4)");
+#endif
 }
 
 extern "C" int apx_env_step(apx_env_t* e, const float* action, float* obs, float* reward, uint8_t* done, float* final_obs,

@@ -86,6 +86,17 @@ class CassieVecEnv:
         check(_lib.load().apx_env_reset(self._h, _p(mask), _p(self.obs), _stream()))
         return self.obs
 
+    def update_speed(self, new_speed, new_side_speed=None):
+        """CassieEnv.update_speed (cassie.py:757-775) for every env; arguments are [N] tensors (or floats)."""
+        f = lambda v: None if v is None else torch.as_tensor(v, dtype=torch.float32, device=self.device).expand(self.n_envs).contiguous()
+        sp, sd = f(new_speed), f(new_side_speed)
+        check(_lib.load().apx_env_update_speed(self._h, _p(sp), _p(sd), _stream()))
+
+    def reset_for_test(self):
+        """CassieEnv.reset_for_test(full_reset=False) (cassie.py:682-742) for every env; returns the [N, 50] observation."""
+        check(_lib.load().apx_env_reset_for_test(self._h, _p(self.obs), _stream()))
+        return self.obs
+
     def step(self, action, auto_reset=True, f_term=0, out=None):
         """CassieEnv.step for every env.  `f_term` is accepted and ignored exactly like cassie/cassie.py:389.
         Returns (obs, reward, done, final_obs): done 1 = terminated, 2 = truncated at max_traj_len; with auto_reset the

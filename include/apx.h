@@ -134,6 +134,16 @@ int apx_env_destroy(apx_env_t* env);
  * obs_out[n_envs*50] f32 [dev] (rows of un-reset envs are left untouched). */
 int apx_env_reset(apx_env_t* env, const uint8_t* mask, float* obs_out, void* stream);
 
+/* Evaluation-side API.
+ * CassieEnv.update_speed (cassie/cassie.py:757-775, clock command profile) for every env: speed[n_envs] f32 [dev],
+ * side_speed[n_envs] f32 [dev] or NULL (= 0): commands are clipped to [-0.3, 4] / [-0.3, 0.3], the clock is rebuilt from the
+ * new speed and the phase is rescaled to the new cycle length. */
+int apx_env_update_speed(apx_env_t* env, const float* speed, const float* side_speed, void* stream);
+/* CassieEnv.reset_for_test(full_reset=False) (cassie/cassie.py:682-742) for every env: counters / commands to zero, the
+ * fixed 0.15 / 0.25 grounded clock (the handle's stance mode becomes grounded), one step_pd with the stale pd targets, then
+ * default dynamics + set_const, flat floor, zero encoder offsets; obs_out[n_envs*50] f32 [dev]. */
+int apx_env_reset_for_test(apx_env_t* env, float* obs_out, void* stream);
+
 /* CassieEnv.step (cassie/cassie.py:389-496) for every env: action[n_envs*10] f32 -> obs[n_envs*50] f32,
  * reward[n_envs] f32, done[n_envs] u8 (1 terminated, 2 truncated at max_traj_len).  With auto_reset != 0 an env
  * that finished is reset by a second launch on the same stream; its terminal observation (needed for the bootstrap

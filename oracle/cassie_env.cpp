@@ -259,6 +259,47 @@ static void set_clock_from_speed(Env& e) {   // cassie.py:556-559
     make_clock(e.clock, swing, stance, 0.1, e.cfg.stance_mode, e.cfg.have_incentive, 2000 / e.cfg.simrate);
 }
 
+void env_clock_from_speed(Env& e) { set_clock_from_speed(e); }
+
+// CassieEnv.update_speed (cassie.py:757-775), clock command profile: clip the commands, rebuild the clock from the NEW speed
+// (no abs() here, unlike reset) and rescale the phase to the new cycle length
+void env_update_speed(Env& e, double new_speed, double new_side_speed) {
+    e.speed = std::min(std::max(new_speed, -0.3), 4.0);
+    e.side_speed = std::min(std::max(new_side_speed, -0.3), 0.3);
+    const double total = (0.9 - 0.25 / 3.0 * e.speed) / 2;
+    const double swing = (0.30 + ((0.70 - 0.30) / 3) * e.speed) * total;
+    const double stance = (0.70 - ((0.70 - 0.30) / 3) * e.speed) * total;
+    const double old_phaselen = e.clock.phaselen;
+    make_clock(e.clock, swing, stance, 0.1, e.cfg.stance_mode, e.cfg.have_incentive, 2000 / e.cfg.simrate);
+    e.phase = (int)(e.clock.phaselen * e.phase / old_phaselen);
+}
+
+// CassieEnv.reset_for_test(full_reset=False) (cassie.py:682-742): evaluation start.  Counters and commands to zero, the fixed
+// 0.15 / 0.25 grounded clock, ONE step_pd with the stale pd targets, THEN the default dynamics + set_const (which also puts the
+// robot back into the init pose), flat floor, zero encoder offsets.  The returned observation is built from the state estimate
+// of that one step_pd (self.cassie_state), i.e. from before set_const.
+void env_reset_for_test(Env& e, double* obs) {
+    static thread_local Work w;
+    e.phase = 0; e.time = 0; e.counter = 0; e.orient_add = 0; e.speed = 0;
+    e.cfg.stance_mode = 1;
+    make_clock(e.clock, 0.15, 0.25, 0.1, e.cfg.stance_mode, e.cfg.have_incentive, 2000 / e.cfg.simrate);
+    e.l_foot_frc = e.r_foot_frc = e.l_foot_orient_cost = e.r_foot_orient_cost = 0;
+    sim_step_pd(e);
+    if (e.cfg.dynamics_randomization) {
+        const int iters = e.par.pgs_iters;
+        default_params(e.par);
+        e.par.pgs_iters = iters;
+        set_const(e.par);
+        for (int i = 0; i < NQ; ++i) e.st.qpos[i] = cm_init_qpos[i];
+        for (int i = 0; i < NV; ++i) { e.st.qvel[i] = 0; e.st.qacc_warm[i] = 0; }
+        double zero[10] = {0};
+        forward_snapshot(e, w, zero);
+        for (int u = 0; u < 10; ++u) e.motor_noise[u] = 0;
+        for (int k = 0; k < 6; ++k) e.joint_noise[k] = 0;
+    }
+    env_obs(e, obs);
+}
+
 // CassieEnv.reset, cassie.py:523-680
 void env_reset(Env& e, double* obs) {
     static thread_local Work w;

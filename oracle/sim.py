@@ -23,6 +23,9 @@ def lib():
         L.orc_env_step.restype = C.c_int
         L.orc_env_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_env_substep.argtypes = [C.c_void_p]
+        L.orc_env_update_speed.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.orc_env_reset_for_test.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_env_set_command.argtypes = [C.c_void_p, C.c_double, C.c_int]
         L.orc_env_obs.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_phys_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_phys_forward.argtypes = [C.c_void_p, C.c_void_p]
@@ -76,6 +79,17 @@ class OracleEnv:
 
     def substep(self):
         lib().orc_env_substep(self.h)
+
+    def update_speed(self, speed, side_speed=0.0):
+        lib().orc_env_update_speed(self.h, float(speed), float(side_speed))
+
+    def set_command(self, speed0, phase):
+        lib().orc_env_set_command(self.h, float(speed0), int(phase))
+
+    def reset_for_test(self):
+        obs = np.zeros(50)
+        lib().orc_env_reset_for_test(self.h, _ptr(obs))
+        return obs
 
     def obs(self):
         o = np.zeros(50)

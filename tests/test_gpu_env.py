@@ -254,3 +254,51 @@ def test_random_policy_statistics_match_oracle(dev):
     se = np.sqrt(lens.var() / lens.size + olens.var() / olens.size)
     assert abs(lens.mean() - olens.mean()) < 4.0 * se + 0.3, (lens.mean(), olens.mean(), se)
     assert abs(rsum / (T * n) - orsum / osteps) < 0.01, (rsum / (T * n), orsum / osteps)
+
+
+def test_update_speed_and_reset_for_test_vs_oracle(dev):
+    """Evaluation-side API (next row f3): CassieEnv.update_speed and reset_for_test through the C ABI vs the oracle (which is
+    pinned to the reference by golden G16)."""
+    genv, oenv = _mk(True, 13)
+    genv.reset(); [e.reset() for e in oenv[:16]]
+    rng = np.random.RandomState(4)
+    act = (rng.randn(N, 10) * 0.1).astype(np.float32)
+    for t in range(2):
+        genv.step(torch.tensor(act, device=dev), auto_reset=False)
+        [e.step(act[i].astype(np.float64)) for i, e in enumerate(oenv[:16])]
+    # ---- update_speed: commands beyond the clip range included; phase rescale is integer work
+    ns = rng.uniform(-0.8, 4.6, N).astype(np.float32); nd = rng.uniform(-0.5, 0.5, N).astype(np.float32)
+    genv.update_speed(torch.tensor(ns), torch.tensor(nd))
+    ints = genv.get_field("ints").cpu().numpy()
+    mism = 0
+    for i, e in enumerate(oenv[:16]):
+        e.update_speed(float(ns[i]), float(nd[i]))
+        mism += int(ints[i, 1] != int(e.get("ints")[1]))
+    assert mism <= 1                                           # the old cycle length is fp32 state: a tie within fp32 rounding may flip
+    obs, rew, done, _ = genv.step(torch.tensor(act, device=dev), auto_reset=False)
+    obs = obs.cpu().numpy()
+    for i, e in enumerate(oenv[:16]):
+        o, r, d = e.step(act[i].astype(np.float64))
+        np.testing.assert_allclose(obs[i, 48:50], o[48:50], atol=1e-6)                    # clipped commands
+        np.testing.assert_allclose(obs[i, 46:48], o[46:48], atol=0.3 if mism else 1e-4)   # clock input sin / cos(2 pi phase / phaselen)
+    # ---- reset_for_test
+    gobs = genv.reset_for_test().cpu().numpy()
+    for i, e in enumerate(oenv[:16]):
+        o = e.reset_for_test()
+        tol = np.full(50, 2e-2 * 4); tol[21:31] = 0.3; tol[31:34] = 0.6; tol[40:46] = 0.3       # 4 env steps of fp32 vs fp64 dynamics behind it; velocities / accelerations are the noisy entries
+        assert np.all(np.abs(gobs[i] - o) <= tol + 5e-3 * np.abs(o)), ("env %d" % i, np.abs(gobs[i] - o).max())
+    gi = genv.get_field("ints").cpu().numpy()
+    assert np.all(gi[:, :3] == 0)
+    d0 = S.OracleEnv(dyn_rand=False, seed=0, env_id=0)
+    np.testing.assert_allclose(genv.get_field("mass").cpu().numpy()[:4], np.tile(d0.get("mass"), (4, 1)), rtol=1e-6)
+    np.testing.assert_allclose(genv.get_field("damping").cpu().numpy()[:4], np.tile(d0.get("damping"), (4, 1)), rtol=1e-6)
+    assert np.all(genv.get_field("motor_noise").cpu().numpy() == 0) and np.all(genv.get_field("joint_noise").cpu().numpy() == 0)
+    np.testing.assert_allclose(genv.get_field("friction").cpu().numpy()[:4, 0], 1.0)
+    # after reset_for_test the envs run the fixed grounded clock from the init pose
+    for t in range(2):
+        obs, rew, done, _ = genv.step(torch.tensor(act, device=dev), auto_reset=False)
+        obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+        for i, e in enumerate(oenv[:8]):
+            o, r, d = e.step(act[i].astype(np.float64))
+            assert np.all(np.abs(obs[i] - o) <= tol * (t + 1) / 2 + 5e-3 * np.abs(o)), ("env %d step %d" % (i, t), np.abs(obs[i] - o).max())
+            assert abs(rew[i] - r) < 0.02 * (t + 1)

@@ -53,3 +53,16 @@ def test_iteration_grids_bootstrap_and_returns(dev, graph):
         assert el.size == int((done != 0).sum()) and el.max() <= mtl and el.min() >= 1
         losses, kl, epochs_run = algo.update(ret)
         assert np.all(np.isfinite(losses)) and np.isfinite(kl) and epochs_run >= 1
+
+
+def test_batched_deterministic_evaluation(dev):
+    """apex_amd.eval.evaluate: one deterministic episode per env from reset_for_test at a commanded speed."""
+    from apex_amd.eval import evaluate
+    algo, N, T, mtl = _mk(False)
+    out = evaluate(algo.learner.actor, algo.env, algo.learner.obs_mean, algo.learner.obs_std, speed=1.0)
+    ln = out["lengths"].cpu().numpy(); rt = out["returns"].cpu().numpy()
+    assert ln.min() >= 1 and ln.max() <= mtl and np.all(np.isfinite(rt)) and np.all(rt >= 0)
+    assert bool((out["terminated"] ^ out["truncated"]).all())            # every env finished exactly one way
+    # default dynamics, one deterministic policy, one command: the episodes differ only through what reset_for_test keeps
+    # (stale pd targets, delay line, encoder filters), so the returns are close but not identical
+    assert np.ptp(rt) < 0.5 * max(1.0, abs(rt).max())

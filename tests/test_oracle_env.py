@@ -209,3 +209,37 @@ def test_g14_reset_draws_and_randomisation_tables(golden_dir):
         np.testing.assert_allclose(e.get("joint_noise"), [uni(76 + k, -0.01, 0.01) for k in range(6)], rtol=1e-12)
         np.testing.assert_allclose([e.get("speed")[0], e.get("side_speed")[0]], [uni(82, -0.3, 4.0), uni(83, -0.3, 0.3)], rtol=1e-12)
         assert int(e.get("ints")[5]) == 84                                                           # draws consumed by one reset
+
+
+def test_g16_update_speed_and_reset_for_test(golden_dir):
+    """G16 (next row f3): CassieEnv.update_speed on 200 random (first speed, phase, new command) states and the call order /
+    field values of CassieEnv.reset_for_test, both from the reference (tools/refprobe/gen_golden_evalapi.py)."""
+    g = np.load(os.path.join(golden_dir, "g16_eval_api.npz"))
+    e = S.OracleEnv(dyn_rand=True, seed=0, env_id=0)
+    for sp0, ph0, pl0, ns, nside, sp, side, swing, stance, ph1 in g["update_speed"]:
+        e.set_command(sp0, int(ph0))
+        assert abs(e.get("phaselen")[0] - pl0) < 1e-9
+        e.update_speed(ns, nside)
+        assert abs(e.get("speed")[0] - sp) < 1e-12 and abs(e.get("side_speed")[0] - side) < 1e-12
+        assert abs(e.get("phaselen")[0] - (2 * swing + 2 * stance) * 40) < 1e-9
+        assert int(e.get("ints")[1]) == int(ph1)                                   # phase rescaled with int() truncation: bit exact
+    # reset_for_test: one step_pd with the stale targets FIRST, then defaults + set_const, then the floor
+    assert list(g["rft_order"]) == ["step_pd", "damping", "mass", "ipos", "friction", "set_const", "geom_quat:floor"]
+    ph, tm, cnt, oadd, sp, side, swing, stance, plen, padd = g["rft_scalars"]
+    assert (ph, tm, cnt, oadd, sp, swing, stance, plen, padd) == (0, 0, 0, 0, 0, 0.15, 0.25, 32.0, 1) and side == 0.2   # side speed is NOT reset
+    assert str(g["rft_stance_mode"][0]) == "grounded" and np.all(g["rft_noise"] == 0)
+    np.testing.assert_allclose(g["rft_floor"], [1, 0, 0, 0])
+    e = S.OracleEnv(dyn_rand=True, seed=5, env_id=1)
+    e.reset()
+    d0 = S.OracleEnv(dyn_rand=False, seed=0, env_id=0)
+    e.set("side_speed", 0.2)
+    for _ in range(3):
+        e.step(np.zeros(10))
+    obs = e.reset_for_test()
+    ints = e.get("ints")
+    assert (ints[0], ints[1], ints[2]) == (0, 0, 0) and e.get("speed")[0] == 0 and e.get("side_speed")[0] == 0.2 and e.get("orient_add")[0] == 0
+    assert abs(e.get("phaselen")[0] - 32.0) < 1e-12
+    np.testing.assert_allclose(e.get("damping"), d0.get("damping")); np.testing.assert_allclose(e.get("mass"), d0.get("mass"))
+    np.testing.assert_allclose(e.get("friction"), d0.get("friction")); np.testing.assert_allclose(e.get("floor_quat"), [1, 0, 0, 0])
+    assert np.all(e.get("motor_noise") == 0) and np.all(e.get("joint_noise") == 0)
+    assert np.all(np.isfinite(obs)) and obs[48] == 0 and abs(obs[49] - 0.2) < 1e-12 and obs[46] == 0 and obs[47] == 1     # commands, clock at phase 0
