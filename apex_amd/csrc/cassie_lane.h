@@ -19,6 +19,9 @@ static_assert(L4_WK + WK_TOTAL <= L4_ROWS && L4_ROWS % 4 == 0 && L4_ROWS + 704 <
 
 // v_rcp_f32 (1 ulp): __frcp_rn and '/' expand to the ~10-instruction correctly rounded division sequence
 __device__ __forceinline__ float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
+// The workgroup is ONE wave: LDS operations of a wave are processed in issue order, so a write -> read hand-off between lanes needs
+// no s_barrier / s_waitcnt drain, only a fence that keeps the compiler from reordering across it.
+__device__ __forceinline__ void wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 template <int CTRL> __device__ __forceinline__ float dpp(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
 }
@@ -183,12 +186,12 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
     sfor<0, 2>([&](auto Sd) { tp[Sd] = bpos[Sd]; tq[Sd] = lq[Sd]; });
     sfor<0, 3>([&](auto Rn) {
         constexpr int r = Rn;
-        __syncthreads();
+        wsync();
         if (bl) sfor<0, 2>([&](auto Sd) {
             float* p = xb + XB_SZ * body[Sd];
             p[0] = tp[Sd].x; p[1] = tp[Sd].y; p[2] = tp[Sd].z; p[3] = tq[Sd].w; p[4] = tq[Sd].x; p[5] = tq[Sd].y; p[6] = tq[Sd].z;
         });
-        __syncthreads();
+        wsync();
         sfor<0, 2>([&](auto Sd) {
             constexpr int sd = Sd;
             const float* p = xb + XB_SZ * (2 + 12 * sd + (jump[r] == 15 ? lb : jump[r]));
@@ -213,12 +216,12 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
     auto chain_sum = [&](SV (&val)[2]) {
         sfor<0, 3>([&](auto Rn) {
             constexpr int r = Rn;
-            __syncthreads();
+            wsync();
             if (bl) sfor<0, 2>([&](auto Sd) {
                 float* p = xb + XB_SZ * body[Sd];
                 p[0] = val[Sd].a.x; p[1] = val[Sd].a.y; p[2] = val[Sd].a.z; p[3] = val[Sd].l.x; p[4] = val[Sd].l.y; p[5] = val[Sd].l.z;
             });
-            __syncthreads();
+            wsync();
             sfor<0, 2>([&](auto Sd) {
                 constexpr int sd = Sd;
                 const float* p = xb + XB_SZ * (2 + 12 * sd + (jump[r] == 15 ? lb : jump[r]));
@@ -252,7 +255,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             }
         }
     });
-    __syncthreads();                                                  // every lane is done reading poses: the records become (crb, frc)
+    wsync();                                                  // every lane is done reading poses: the records become (crb, frc)
     // ---- inertia + RNE force of the own bodies and of the pelvis
     SI crb[2]; SV frc[2];
     sfor<0, 2>([&](auto Sd) {
@@ -271,7 +274,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         sfor<0, 9>([&](auto K) { Ipel[K] = ct_body_inertia[9 + K]; });
         body_inertia_force(pmat, o, o, Ipel, cv3<1>(ct_body_ipos), S(F_MASS + 1), pel.vel, pel.acc, pcrb, pfrc);
     }
-    __syncthreads();
+    wsync();
     // ---- subtree sums (composite inertia, subtree force): descendants are the next ndesc bodies
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
@@ -284,7 +287,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             }
         }
     });
-    __syncthreads();
+    wsync();
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
         if (bl) {
@@ -294,7 +297,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             p[10] = frc[sd].a.x; p[11] = frc[sd].a.y; p[12] = frc[sd].a.z; p[13] = frc[sd].l.x; p[14] = frc[sd].l.y; p[15] = frc[sd].l.z;
         }
     });
-    __syncthreads();
+    wsync();
     {   // pelvis composite = own + the two hip-roll subtrees
         sfor<0, 2>([&](auto Sd) {
             const float* p = xb + XB_SZ * (2 + 12 * Sd);

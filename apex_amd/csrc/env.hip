@@ -317,12 +317,12 @@ __device__ __noinline__ void stage4_finish(St S, int mode) {
 // mj_setConst (sim.set_const after dynamics randomisation), lane-parallel: tree at qpos0 -> factor -> |y~|^2 of unit rows
 __device__ __forceinline__ void setconst_lane(const St& S) {
     c4::stage_tree_lane<true>(S, rows4());
-    __syncthreads();
+    c4::wsync();
     c4::stage_factor_lane(S);
-    __syncthreads();
+    c4::wsync();
     c4::setconst_rows_lane<0>(S);
     c4::setconst_rows_lane<1>(S);
-    __syncthreads();
+    c4::wsync();
 }
 // Generation 4: the wave holds 4 envs, one per 16-lane row.  Stages not yet converted to the lane-parallel form run on the
 // row's lead lane; every call site is reached by all lanes.
@@ -331,15 +331,15 @@ __device__ __forceinline__ void sim_step_pd(const St& S, int pgs_iters, int mode
     const unsigned long long t0__ = clock64();
 #endif
     stage1_io_lane(S, mode);
-    __syncthreads();
+    c4::wsync();
     stage1b_tree_lane(S);
-    __syncthreads();
+    c4::wsync();
     stage2a_factor(S);
-    __syncthreads();
+    c4::wsync();
     stage3_rows_pgs_lane(S, pgs_iters);
-    __syncthreads();
+    c4::wsync();
     stage4_finish(S, mode);
-    __syncthreads();
+    c4::wsync();
 #ifdef APX_PROF
     if (threadIdx.x == 0 && blockIdx.x == 0) c3::g_prof_acc[8] += clock64() - t0__;
 #endif
@@ -506,13 +506,13 @@ __device__ void env_reset_finish(const St& S, const Cfg& cfg) {
 __device__ __forceinline__ void env_reset(const St& S, const Cfg& cfg) {
     const bool lead = (threadIdx.x & 15) == 0;
     if (lead) env_reset_draws(S, cfg);
-    __syncthreads();
+    c4::wsync();
     if (cfg.dyn_rand) setconst_lane(S);               // sim.set_const -> mj_setConst
 
     sim_step_pd(S, cfg.pgs_iters, 0);               // cassie_sim_set_const ends in mj_forward
     sim_step_pd(S, cfg.pgs_iters, 1);               // cassie.py:665 (stale pd_in_t)
     if (lead) env_reset_finish(S, cfg);
-    __syncthreads();
+    c4::wsync();
 }
 #else
 // CassieEnv.reset (cassie/cassie.py:523-680); called by BOTH waves of the workgroup
@@ -592,10 +592,10 @@ __device__ __forceinline__ void load_state(const St& S, const float* st, const i
 #pragma unroll
     for (int i = 0; i < NIT; ++i) { const int f = 16 * i + l; if (f < F_TOTAL) S(f) = v[i]; }
     if (l < I_TOTAL) S.I(l) = ist[(size_t)l * n + S.env];
-    __syncthreads();
+    c4::wsync();
 }
 __device__ __forceinline__ void store_state(const St& S, float* st, int* ist, int n) {
-    __syncthreads();
+    c4::wsync();
     const int l = threadIdx.x & 15;
     for (int f = l; f < F_TOTAL; f += 16) st[(size_t)f * n + S.env] = S(f);
     if (l < I_TOTAL) ist[(size_t)l * n + S.env] = S.I(l);
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
         }
         S.I(I_FLAGS) |= 16;
     }
-    __syncthreads();
+    c4::wsync();
     float lfrc = 0.f, rfrc = 0.f, lor = 0.f, ror = 0.f;
     for (int i = 0; i < cfg.simrate; ++i) {
         sim_step_pd(S, cfg.pgs_iters, 1);                                        // all lanes (barriers inside)
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_for_test_kerne
         S(F_CMD + 0) = 0.f; S(F_CMD + 2) = 0.f;                                  // speed, orient_add (side speed is NOT reset)
         S(F_CMD + 3) = 0.15f; S(F_CMD + 4) = 0.25f; S(F_CMD + 5) = (2.f * 0.15f + 2.f * 0.25f) * (float)(2000 / cfg.simrate);
     }
-    __syncthreads();
+    c4::wsync();
     sim_step_pd(S, cfg.pgs_iters, 1);                                            // self.cassie_state = self.sim.step_pd(self.u), stale targets
     if (cfg.dyn_rand) {                                                          // default dynamics, set_const (back to the init pose), flat floor, no encoder offsets
         if (lead) {
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_for_test_kerne
             for (int i = 0; i < NQ; ++i) S(F_QPOS + i) = cm_init_qpos[i];
             for (int i = 0; i < NV; ++i) { S(F_QVEL + i) = 0.f; S(F_QACCW + i) = 0.f; }
         }
-        __syncthreads();
+        c4::wsync();
         setconst_lane(S);
         sim_step_pd(S, cfg.pgs_iters, 0);                                        // cassie_sim_set_const ends in mj_forward
     }
