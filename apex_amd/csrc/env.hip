@@ -688,11 +688,26 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
     store_state(S, st, ist, n);
 }
 
-// raw substeps with the current pd targets (tests): n_sub x cassie_sim_step_pd
-__global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_substep_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, int n_sub) {
+// action == NULL: raw substeps with the current pd targets (tests): n_sub x cassie_sim_step_pd.
+// action != NULL: CassieEnv.step_basic (cassie/cassie.py:498-521, 355-387): new pd targets, n_sub substeps, time / phase bookkeeping,
+// observation; no reward, termination, trackers or command resampling
+__global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_substep_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, int n_sub,
+                                                                            const float* action, float* obs) {
     ENV_SETUP
     load_state(S, st, ist, n);
+    if (action && lead) {
+        for (int u = 0; u < 10; ++u) S(F_PDT + u) = action[(size_t)env * APX_ACT_DIM + u] + kOffset[u] - (cfg.dyn_rand ? S(F_MNOISE + u) : 0.f);
+        S.I(I_FLAGS) |= 16;
+    }
+    c4::wsync();
     for (int i = 0; i < n_sub; ++i) sim_step_pd(S, cfg.pgs_iters, 1);
+    if (action && lead) {
+        int phase = S.I(I_PHASE) + 1;
+        S.I(I_TIME) += 1;
+        if ((float)phase > S(F_CMD + 5)) { phase = 0; S.I(I_COUNTER) += 1; }
+        S.I(I_PHASE) = phase;
+        if (obs) write_obs(S, cfg, obs + (size_t)env * APX_OBS_DIM);
+    }
     store_state(S, st, ist, n);
 }
 // CassieEnv.reset_for_test(full_reset=False) (cassie/cassie.py:682-742)
@@ -821,7 +836,7 @@ __global__ __launch_bounds__(128) void env_step_kernel(float* st, int* ist, floa
 }
 
 // raw substeps with the current pd targets (tests): n_sub x cassie_sim_step_pd
-__global__ __launch_bounds__(128) void env_substep_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, int n_sub) {
+__global__ __launch_bounds__(128) void env_substep_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, int n_sub, const float*, float*) {
     ENV_SETUP
     for (int i = 0; i < n_sub; ++i) sim_step_pd(S, cfg.pgs_iters, 1);
 }
@@ -914,6 +929,18 @@ extern "C" int apx_env_update_speed(apx_env_t* e, const float* speed, const floa
     return APX_OK;
 }
 
+extern "C" int apx_env_step_basic(apx_env_t* e, const float* action, float* obs, void* stream) {
+    APX_REQUIRE(e && action && obs, "null pointer");
+#if APX_GEN == 4
+    hipLaunchKernelGGL(env_substep_kernel, ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(e->cfg),
+                       e->cfg.simrate, action, obs);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+#else
+    APX_REQUIRE(false, "apx_env_step_basic is implemented by the generation-4 kernel only (build with GEN=4)");
+#endif
+}
+
 extern "C" int apx_env_reset_for_test(apx_env_t* e, float* obs_out, void* stream) {
     APX_REQUIRE(e && obs_out, "null pointer");
 #if APX_GEN == 4
@@ -1004,7 +1031,8 @@ extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, voi
     }
 #endif
     if (!strcmp(name, "substep")) {   // debugging hook: out[0] (host-readable count is not needed) - run one raw substep
-        hipLaunchKernelGGL(env_substep_kernel, ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(e->cfg), 1);
+        hipLaunchKernelGGL(env_substep_kernel, ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(e->cfg), 1,
+                           (const float*)nullptr, (float*)nullptr);
         APX_LAUNCH_CHECK();
         return 0;
     }

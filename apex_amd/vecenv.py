@@ -97,6 +97,13 @@ class CassieVecEnv:
         check(_lib.load().apx_env_reset_for_test(self._h, _p(self.obs), _stream()))
         return self.obs
 
+    def step_basic(self, action):
+        """CassieEnv.step_basic (cassie.py:498-521) for every env: no reward / termination / command resampling; returns obs."""
+        action = action.contiguous()
+        assert action.shape == (self.n_envs, ACT_DIM) and action.dtype == torch.float32 and action.is_cuda
+        check(_lib.load().apx_env_step_basic(self._h, _p(action), _p(self.obs), _stream()))
+        return self.obs
+
     def step(self, action, auto_reset=True, f_term=0, out=None):
         """CassieEnv.step for every env.  `f_term` is accepted and ignored exactly like cassie/cassie.py:389.
         Returns (obs, reward, done, final_obs): done 1 = terminated, 2 = truncated at max_traj_len; with auto_reset the

@@ -143,6 +143,9 @@ int apx_env_update_speed(apx_env_t* env, const float* speed, const float* side_s
  * fixed 0.15 / 0.25 grounded clock (the handle's stance mode becomes grounded), one step_pd with the stale pd targets, then
  * default dynamics + set_const, flat floor, zero encoder offsets; obs_out[n_envs*50] f32 [dev]. */
 int apx_env_reset_for_test(apx_env_t* env, float* obs_out, void* stream);
+/* CassieEnv.step_basic (cassie/cassie.py:498-521, 355-387) for every env: the substeps and the time / phase bookkeeping of a
+ * step, without reward, termination, trackers or command resampling (evaluation at a fixed command); obs[n_envs*50]. */
+int apx_env_step_basic(apx_env_t* env, const float* action, float* obs, void* stream);
 
 /* CassieEnv.step (cassie/cassie.py:389-496) for every env: action[n_envs*10] f32 -> obs[n_envs*50] f32,
  * reward[n_envs] f32, done[n_envs] u8 (1 terminated, 2 truncated at max_traj_len).  With auto_reset != 0 an env

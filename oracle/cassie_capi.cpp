@@ -23,6 +23,7 @@ void orc_env_free(void* h) { delete (Env*)h; }
 void orc_env_reset(void* h, double* obs) { env_reset(*(Env*)h, obs); }
 int orc_env_step(void* h, const double* action, double* obs, double* reward) { return env_step(*(Env*)h, action, obs, reward); }
 void orc_env_substep(void* h) { sim_step_pd(*(Env*)h); }
+void orc_env_step_basic(void* h, const double* action, double* obs) { env_step_basic(*(Env*)h, action, obs); }
 void orc_env_update_speed(void* h, double speed, double side_speed) { env_update_speed(*(Env*)h, speed, side_speed); }
 void orc_env_reset_for_test(void* h, double* obs) { env_reset_for_test(*(Env*)h, obs); }
 // test helper: the command / clock / phase state a training reset with first speed draw `speed0` leaves behind (cassie.py:553-563)

@@ -259,6 +259,21 @@ static void set_clock_from_speed(Env& e) {   // cassie.py:556-559
     make_clock(e.clock, swing, stance, 0.1, e.cfg.stance_mode, e.cfg.have_incentive, 2000 / e.cfg.simrate);
 }
 
+// CassieEnv.step_basic (cassie.py:498-521): simrate x step_sim_basic (PD targets = action + offset - encoder offsets, cassie.py:355-387),
+// time / phase bookkeeping, NO reward, termination, trackers or command resampling
+void env_step_basic(Env& e, const double* action, double* obs) {
+    static const double offset[10] = {0.0045, 0.0, 0.4973, -1.1997, -1.5968, 0.0045, 0.0, 0.4973, -1.1997, -1.5968};
+    static const double P[5] = {100, 100, 88, 96, 50}, D[5] = {10.0, 10.0, 8.0, 9.6, 5.0};
+    for (int u = 0; u < 10; ++u) {
+        e.pd_target[u] = action[u] + offset[u] - (e.cfg.dynamics_randomization ? e.motor_noise[u] : 0.0);
+        e.pd_P[u] = P[u % 5]; e.pd_D[u] = D[u % 5];
+    }
+    for (int i = 0; i < e.cfg.simrate; ++i) sim_step_pd(e);
+    e.time += 1; e.phase += 1;
+    if (e.phase > e.clock.phaselen) { e.phase = 0; e.counter += 1; }
+    env_obs(e, obs);
+}
+
 void env_clock_from_speed(Env& e) { set_clock_from_speed(e); }
 
 // CassieEnv.update_speed (cassie.py:757-775), clock command profile: clip the commands, rebuild the clock from the NEW speed

@@ -70,6 +70,7 @@ struct Env {
 
 void env_init(Env& e, const EnvCfg& cfg, uint32_t env_id);
 void env_reset(Env& e, double* obs);
+void env_step_basic(Env& e, const double* action, double* obs);           // CassieEnv.step_basic, cassie.py:498-521
 void env_clock_from_speed(Env& e);                                         // swing / stance / clock from e.speed, cassie.py:556-559
 void env_update_speed(Env& e, double new_speed, double new_side_speed);   // CassieEnv.update_speed, cassie.py:757-775
 void env_reset_for_test(Env& e, double* obs);                              // CassieEnv.reset_for_test(full_reset=False), cassie.py:682-742

@@ -24,6 +24,7 @@ def lib():
         L.orc_env_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_env_substep.argtypes = [C.c_void_p]
         L.orc_env_update_speed.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.orc_env_step_basic.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_env_reset_for_test.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_env_set_command.argtypes = [C.c_void_p, C.c_double, C.c_int]
         L.orc_env_obs.argtypes = [C.c_void_p, C.c_void_p]
@@ -79,6 +80,11 @@ class OracleEnv:
 
     def substep(self):
         lib().orc_env_substep(self.h)
+
+    def step_basic(self, action):
+        a = np.ascontiguousarray(action, dtype=np.float64); obs = np.zeros(50)
+        lib().orc_env_step_basic(self.h, _ptr(a), _ptr(obs))
+        return obs
 
     def update_speed(self, speed, side_speed=0.0):
         lib().orc_env_update_speed(self.h, float(speed), float(side_speed))

@@ -302,3 +302,25 @@ def test_update_speed_and_reset_for_test_vs_oracle(dev):
             o, r, d = e.step(act[i].astype(np.float64))
             assert np.all(np.abs(obs[i] - o) <= tol * (t + 1) / 2 + 5e-3 * np.abs(o)), ("env %d step %d" % (i, t), np.abs(obs[i] - o).max())
             assert abs(rew[i] - r) < 0.02 * (t + 1)
+
+
+def test_step_basic_vs_oracle(dev):
+    """CassieEnv.step_basic through the C ABI vs the oracle: observation, counters; commands and RNG counter untouched."""
+    genv, oenv = _mk(True, 17)
+    genv.reset(); [e.reset() for e in oenv[:8]]
+    genv.reset_for_test(); [e.reset_for_test() for e in oenv[:8]]
+    genv.update_speed(torch.full((N,), 1.0)); [e.update_speed(1.0) for e in oenv[:8]]
+    rng = np.random.RandomState(8)
+    rc0 = genv.get_field("ints").cpu().numpy()[:, 3].copy()
+    for t in range(4):
+        act = (rng.randn(N, 10) * 0.1).astype(np.float32)
+        obs = genv.step_basic(torch.tensor(act, device=dev)).cpu().numpy()
+        gi = genv.get_field("ints").cpu().numpy()
+        for i, e in enumerate(oenv[:8]):
+            o = e.step_basic(act[i].astype(np.float64))
+            tol = np.full(50, 2e-2 * (t + 1)); tol[21:31] = 0.3 * (t + 1); tol[31:34] = 0.6 * (t + 1); tol[40:46] = 0.3 * (t + 1)
+            assert np.all(np.abs(obs[i] - o) <= tol + 5e-3 * np.abs(o)), (t, i, np.abs(obs[i] - o).max())
+            oi = e.get("ints")
+            assert (gi[i, 0], gi[i, 1], gi[i, 2]) == (oi[0], oi[1], oi[2])
+            assert obs[i, 48] == 1.0 and obs[i, 49] == 0.0                       # the commanded speed stays put
+    assert np.array_equal(genv.get_field("ints").cpu().numpy()[:, 3], rc0)       # no random draws

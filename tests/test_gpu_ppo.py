@@ -66,3 +66,6 @@ def test_batched_deterministic_evaluation(dev):
     # default dynamics, one deterministic policy, one command: the episodes differ only through what reset_for_test keeps
     # (stale pd targets, delay line, encoder filters), so the returns are close but not identical
     assert np.ptp(rt) < 0.5 * max(1.0, abs(rt).max())
+    ob = evaluate(algo.learner.actor, algo.env, algo.learner.obs_mean, algo.learner.obs_std, speed=1.0, basic=True, max_steps=60)
+    lb = ob["lengths"].cpu().numpy()
+    assert lb.min() >= 1 and lb.max() <= 60 and bool((ob["terminated"] ^ ob["truncated"]).all())

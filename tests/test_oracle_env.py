@@ -243,3 +243,19 @@ def test_g16_update_speed_and_reset_for_test(golden_dir):
     np.testing.assert_allclose(e.get("friction"), d0.get("friction")); np.testing.assert_allclose(e.get("floor_quat"), [1, 0, 0, 0])
     assert np.all(e.get("motor_noise") == 0) and np.all(e.get("joint_noise") == 0)
     assert np.all(np.isfinite(obs)) and obs[48] == 0 and abs(obs[49] - 0.2) < 1e-12 and obs[46] == 0 and obs[47] == 1     # commands, clock at phase 0
+
+
+def test_g16_step_basic_bookkeeping(golden_dir):
+    """CassieEnv.step_basic (cassie.py:498-521): 70 calls after reset_for_test on the 32-step clock: time, phase wrap (phase > phaselen),
+    counter, and simrate step_pd calls per step, from the reference; the oracle reproduces the bookkeeping."""
+    g = np.load(os.path.join(golden_dir, "g16_eval_api.npz"))
+    assert int(g["step_basic_pd_calls"][0]) == 70 * 50
+    e = S.OracleEnv(dyn_rand=True, seed=2, env_id=0)
+    e.reset(); e.reset_for_test()
+    for k in range(40):
+        obs = e.step_basic(np.zeros(10))
+        ints = e.get("ints")
+        assert (ints[0], ints[1], ints[2]) == tuple(g["step_basic"][k]), k
+        if e.get("qpos")[2] < 0.3:
+            break
+    assert np.all(np.isfinite(obs))

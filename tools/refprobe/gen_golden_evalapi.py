@@ -51,9 +51,18 @@ def main():
     env.speed = 2.5; env.side_speed = 0.2; env.phase = 17; env.time = 99; env.counter = 3; env.orient_add = 0.4
     env.motor_encoder_noise = np.full(10, 0.005); env.joint_encoder_noise = np.full(6, -0.004)
     env.reset_for_test()
-    out = dict(update_speed=rec, phaselen_new=pl1,
-               rft_order=np.array(env.sim.order), rft_scalars=np.array([env.phase, env.time, env.counter, env.orient_add, env.speed, env.side_speed,
-                                                                       env.swing_duration, env.stance_duration, env.phaselen, env.phase_add], dtype=np.float64),
+    rft_scalars = np.array([env.phase, env.time, env.counter, env.orient_add, env.speed, env.side_speed,
+                            env.swing_duration, env.stance_duration, env.phaselen, env.phase_add], dtype=np.float64)
+    # step_basic bookkeeping after reset_for_test (cassie.py:498-521): 70 calls on the 32-step grounded clock
+    n_pd0 = env.sim.order.count("step_pd")
+    sb = []
+    for k in range(70):
+        env.step_basic(np.zeros(10))
+        sb.append([env.time, env.phase, env.counter])
+    n_pd = env.sim.order.count("step_pd") - n_pd0
+    rft_order = list(env.sim.order[:env.sim.order.index("geom_quat:floor") + 1])
+    out = dict(update_speed=rec, phaselen_new=pl1, step_basic=np.array(sb, dtype=np.float64), step_basic_pd_calls=np.array([n_pd]),
+               rft_order=np.array(rft_order), rft_scalars_after_steps=np.array([env.speed, env.side_speed]), rft_scalars=rft_scalars,
                rft_stance_mode=np.array([env.stance_mode]), rft_damping=env.sim.calls["damping"], rft_mass=env.sim.calls["mass"],
                rft_friction=env.sim.calls["friction"], rft_floor=env.sim.calls["geom_quat"],
                rft_noise=np.concatenate([env.motor_encoder_noise, env.joint_encoder_noise]))
