@@ -53,10 +53,44 @@ def build_parser():
     return p
 
 
+def eval_main(argv):
+    """`apex.py eval --path <run dir>` (reference apex.py:257-280): score a saved actor.pt.  The reference opens a viewer /
+    perturbation harness; here every env of the batch runs one deterministic episode from reset_for_test at the commanded speed
+    (apex_amd/eval.py) and the statistics are printed."""
+    import argparse, os
+    import torch
+    p = argparse.ArgumentParser()
+    p.add_argument("--path", type=str, required=True)
+    p.add_argument("--speed", type=float, default=None)
+    p.add_argument("--side_speed", type=float, default=0.0)
+    p.add_argument("--n_envs", type=int, default=256)
+    p.add_argument("--max_traj_len", type=int, default=400)
+    p.add_argument("--reward", type=str, default="clock")
+    p.add_argument("--basic", action="store_true", help="CassieEnv.step_basic: fixed command, survival time only")
+    a = p.parse_args(argv)
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd.engine import Mlp
+    from apex_amd.eval import evaluate
+    policy = torch.load(os.path.join(a.path, "actor.pt"), weights_only=False)
+    env = CassieVecEnv(n_envs=a.n_envs, reward=a.reward, max_traj_len=a.max_traj_len, dynamics_randomization=False)
+    params = [q.detach().numpy() for q in policy.parameters()]
+    actor = Mlp(params[0].shape[1], params[0].shape[0], params[-1].shape[0], env.device)
+    actor.load_list(params)
+    mean = torch.as_tensor(policy.obs_mean, dtype=torch.float32).to(env.device) if torch.is_tensor(policy.obs_mean) else None
+    std = torch.as_tensor(policy.obs_std, dtype=torch.float32).to(env.device) if torch.is_tensor(policy.obs_std) else None
+    out = evaluate(actor, env, mean, std, speed=a.speed, side_speed=a.side_speed, max_steps=a.max_traj_len, basic=a.basic)
+    ln, rt = out["lengths"].cpu(), out["returns"].cpu()
+    print("episodes %d  mean length %.1f (min %d, max %d)  mean return %.3f  fell %d  reached the time limit %d" % (
+        a.n_envs, float(ln.mean()), int(ln.min()), int(ln.max()), float(rt.mean()), int(out["terminated"].sum()), int(out["truncated"].sum())))
+    return 0
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
+    if argv and argv[0] == "eval":
+        return eval_main(argv[1:])
     if not argv or argv[0] != "ppo":
-        print("Usage: python apex.py ppo [flags]   (only the PPO / Cassie-v0 path is built; see DESIGN.md)")
+        print("Usage: python apex.py ppo [flags] | python apex.py eval --path RUN_DIR [--speed S]   (only the PPO / Cassie-v0 path is built; see DESIGN.md)")
         return 2
     args = build_parser().parse_args(argv[1:])
     if args.env_name != "Cassie-v0" or args.recurrent or args.learn_stddev:

@@ -69,3 +69,16 @@ def test_batched_deterministic_evaluation(dev):
     ob = evaluate(algo.learner.actor, algo.env, algo.learner.obs_mean, algo.learner.obs_std, speed=1.0, basic=True, max_steps=60)
     lb = ob["lengths"].cpu().numpy()
     assert lb.min() >= 1 and lb.max() <= 60 and bool((ob["terminated"] ^ ob["truncated"]).all())
+
+
+def test_cli_eval_scores_a_saved_checkpoint(dev, tmp_path, capsys):
+    """`apex.py eval --path RUN_DIR`: loads the whole-module actor.pt pickle the trainer writes and scores it on the batch."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import apex
+    algo, N, T, mtl = _mk(False)
+    algo.save_path = str(tmp_path)
+    algo.save()
+    rc = apex.main(["eval", "--path", str(tmp_path), "--n_envs", "64", "--speed", "0.5", "--max_traj_len", "40"])
+    out = capsys.readouterr().out
+    assert rc == 0 and "episodes 64" in out and "mean length" in out
