@@ -63,9 +63,10 @@ class OracleEnv:
                                    pgs_iters, seed, env_id)
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().orc_env_free(self.h)
-            self.h = None
+        try:
+            lib().orc_env_destroy(self.h)
+        except Exception:      # interpreter shutdown: the module globals may already be gone
+            pass
 
     def reset(self):
         obs = np.zeros(50)
