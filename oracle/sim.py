@@ -64,7 +64,9 @@ class OracleEnv:
 
     def __del__(self):
         try:
-            lib().orc_env_destroy(self.h)
+            if getattr(self, "h", None):
+                lib().orc_env_free(self.h)
+                self.h = None
         except Exception:      # interpreter shutdown: the module globals may already be gone
             pass
 
