@@ -892,7 +892,11 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     APX_HIP(hipMalloc(&e->st, sizeof(float) * (size_t)F_TOTAL * e->n));
     APX_HIP(hipMalloc(&e->ist, sizeof(int) * (size_t)I_TOTAL * e->n));
     e->wk = nullptr;
+#if APX_GEN == 4
+    APX_HIP(hipMalloc(&e->wk, 256));      // generation 4 keeps the stage hand-off in LDS: no HBM workspace
+#else
     APX_HIP(hipMalloc(&e->wk, sizeof(float) * (size_t)c3::WK_TOTAL * e->n));
+#endif
     const Cfg c = make_cfg(*cfg);
     hipLaunchKernelGGL(env_init_kernel, dim3(e->n / 64), dim3(64), 0, 0, e->st, e->ist, e->n, c);
     APX_LAUNCH_CHECK();
