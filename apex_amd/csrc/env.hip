@@ -665,7 +665,9 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
         int time = S.I(I_TIME) + 1, phase = S.I(I_PHASE) + 1;
         if ((float)phase > S(F_CMD + 5)) { phase = 0; S.I(I_COUNTER) += 1; }
         S.I(I_TIME) = time; S.I(I_PHASE) = phase;
-        int dn = (height < 0.4f || height > 3.0f || !(height == height)) ? 1 : 0;
+        // NaN test on the bit pattern: it must survive -ffast-math (finite-math-only would fold `h != h` away)
+        const bool h_nan = (__float_as_uint(height) & 0x7fffffffu) > 0x7f800000u;
+        int dn = (height < 0.4f || height > 3.0f || h_nan) ? 1 : 0;
         int flags = S.I(I_FLAGS);
         if (!(flags & 4)) for (int u = 0; u < 10; ++u) S(F_PREVACT + u) = act[u];
         if (!(flags & 8)) for (int u = 0; u < 10; ++u) S(F_PREVTQ + u) = S(F_SO + SO_TORQUE + u);
@@ -814,7 +816,8 @@ __global__ __launch_bounds__(128) void env_step_kernel(float* st, int* ist, floa
     int time = S.I(I_TIME) + 1, phase = S.I(I_PHASE) + 1;
     if ((float)phase > S(F_CMD + 5)) { phase = 0; S.I(I_COUNTER) += 1; }
     S.I(I_TIME) = time; S.I(I_PHASE) = phase;
-    int dn = (height < 0.4f || height > 3.0f || !(height == height)) ? 1 : 0;
+    const bool h_nan = (__float_as_uint(height) & 0x7fffffffu) > 0x7f800000u;
+    int dn = (height < 0.4f || height > 3.0f || h_nan) ? 1 : 0;
     int flags = S.I(I_FLAGS);
     if (!(flags & 4)) for (int u = 0; u < 10; ++u) S(F_PREVACT + u) = act[u];
     if (!(flags & 8)) for (int u = 0; u < 10; ++u) S(F_PREVTQ + u) = S(F_SO + SO_TORQUE + u);
