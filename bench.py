@@ -110,12 +110,16 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax)
     # dominant-kernel timing, outside the timed region (same state distribution, same launch geometry)
+    # (events bracket env_step_kernel alone: the restart of finished envs is a second launch and is issued outside the pair)
     n_launch = 8
-    ev0.record()
-    for _ in range(n_launch):
-        env.step(act)
-    ev1.record(); torch.cuda.synchronize()
-    k_ms = ev0.elapsed_time(ev1) / n_launch
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_launch)]
+    for e0, e1 in evs:
+        e0.record()
+        env.step(act, auto_reset=False)
+        e1.record()
+        env.reset(mask=env.done)
+    torch.cuda.synchronize()
+    k_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / n_launch
 
     if rank == 0:
         steps_total = a.steps * a.rollout_len * a.n_envs * world
