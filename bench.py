@@ -121,6 +121,19 @@ def main():
     torch.cuda.synchronize()
     k_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / n_launch
 
+    # MFMA side: the actor's 3-layer fp32 forward on one minibatch (50 -> 256 -> 256 -> 10), events on the launch stream
+    mb_rows = min(a.minibatch, a.rollout_len * a.n_envs)
+    xb = algo.b_obs.view(-1, 50)[:mb_rows].contiguous()
+    for _ in range(3):
+        algo.learner.actor.forward(xb, algo.learner.obs_mean, algo.learner.obs_std)
+    g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g0.record()
+    for _ in range(20):
+        algo.learner.actor.forward(xb, algo.learner.obs_mean, algo.learner.obs_std)
+    g1.record(); torch.cuda.synchronize()
+    mlp_ms = g0.elapsed_time(g1) / 20
+    mlp_flop = 2.0 * mb_rows * (50 * 256 + 256 * 256 + 256 * 10)
+
     if rank == 0:
         steps_total = a.steps * a.rollout_len * a.n_envs * world
         from apex_amd import roofline
@@ -140,6 +153,9 @@ def main():
             "roofline": {"kernel": "env_step_kernel", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": _pmc_traffic_bytes(),
                          "ms_per_launch": round(k_ms, 3), "bytes_per_env_step": bytes_per_env_step,
+                         "mlp_forward_mfma": {"what": "actor forward, %d x (50-256-256-10), fp32 MFMA (v_mfma_f32_32x32x2_f32), 3 GEMM launches + input prep" % mb_rows,
+                                              "ms": round(mlp_ms, 4), "achieved_tflops": round(mlp_flop / (mlp_ms * 1e-3) / 1e12, 2),
+                                              "peak_tflops": VALU_PEAK_TFLOPS, "frac": round(mlp_flop / (mlp_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)},
                          "valu": {"flop_per_env_step": roofline.ENV_STEP_FLOP,
                                   "achieved_tflops": round(roofline.ENV_STEP_FLOP * a.n_envs / (k_ms * 1e-3) / 1e12, 4),
                                   "peak_tflops": VALU_PEAK_TFLOPS,
