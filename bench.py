@@ -161,7 +161,7 @@ def main():
                                   "peak_tflops": VALU_PEAK_TFLOPS,
                                   "frac": round(roofline.ENV_STEP_FLOP * a.n_envs / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 6)}},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # the CPU baseline is timed on rank 0 at N = 1 only
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
     if world > 1:
