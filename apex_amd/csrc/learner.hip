@@ -287,9 +287,100 @@ struct MlpGrad {
 
 #define APX_TRY(x) do { int rc__ = (x); if (rc__ != APX_OK) return rc__; } while (0)
 
+// ------------------------------------------------------------------------------------------------ fused 3-layer forward
+// One workgroup carries 32 rows through Linear-ReLU-Linear-ReLU-Linear (H = 256, D <= 64, O <= 128) with the activations resident
+// in LDS (k-major, so the MFMA operand fetch stays a conflict-free ds_read_b32); only the weight tiles stream in, through a
+// register pipeline FPF tiles deep (an L2 hit costs ~0.7 us, one 16-deep k-tile of MFMAs only ~0.25 us).  Each of the 4 waves
+// owns a 32-column slice of a 128-column pass, i.e. one 32x32 MFMA accumulator.  a1 / a2 are still written to HBM: the backward
+// pass needs them.  LDS: A1[256][33] + A2[256][33] (X aliases the head of A2) + W tile [16][129] = 75 840 B: two workgroups per CU.
+#define FH 256
+#define FBM 32
+#define FBN 128
+#define FPF 4
+struct FusedLds { float (*A1s)[FBM + 1]; float (*A2s)[FBM + 1]; float (*Ws)[FBN + 1]; };
+// one layer: out[32, N] = act(In[32, K] W^T + b), In = k-major LDS, W torch layout [N, K]; NKT = ceil(K / 16) k-tiles
+template <int NKT>
+__device__ __forceinline__ void fused_layer(const FusedLds& L, float (*In)[FBM + 1], int K, const float* __restrict__ W, const float* __restrict__ bias,
+                                            int N, bool relu, float (*OutS)[FBM + 1], float* __restrict__ outG, int ldo, long m0, long B) {
+    const int tid = threadIdx.x, lane = tid & 63, wn = (tid >> 6) * 32;
+    for (int nb = 0; nb * FBN < N; ++nb) {
+        floatx16 acc = {0};
+        float rw[FPF][8];
+        auto fetch = [&](int kt, float (&r)[8]) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int kk = tid & 15, n = (tid >> 4) + 16 * i;      // k contiguous in memory: coalesced 64-B runs
+                const int gn = nb * FBN + n, gk = kt * GBK + kk;
+                r[i] = (gn < N && gk < K) ? W[(long)gn * K + gk] : 0.f;
+            }
+        };
+#pragma unroll
+        for (int p = 0; p < FPF; ++p) if (p < NKT) fetch(p, rw[p]);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) L.Ws[tid & 15][(tid >> 4) + 16 * i] = rw[kt % FPF][i];
+            __syncthreads();
+            if (kt + FPF < NKT) fetch(kt + FPF, rw[kt % FPF]);
+            if (nb * FBN + wn < N) {                 // a wave whose 32-column slice lies beyond N (output layer) leaves the MFMA pipe to the co-resident workgroup
+#pragma unroll
+                for (int kk = 0; kk < GBK; kk += 2) {
+                    const float av = In[kt * GBK + kk + (lane >> 5)][lane & 31];
+                    const float bv = L.Ws[kk + (lane >> 5)][wn + (lane & 31)];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+        const int col = nb * FBN + wn + (lane & 31);
+        const float bs = col < N ? bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            float v = acc[r] + bs;
+            if (relu) v = fmaxf(v, 0.f);
+            if (OutS && col < N) OutS[col][row] = v;
+            if (col < N && m0 + row < B) outG[(m0 + row) * ldo + col] = v;
+        }
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(const float* __restrict__ W0, const float* __restrict__ b0, const float* __restrict__ W1,
+                                                            const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
+                                                            const float* __restrict__ xn, long B, int D, int O, float* __restrict__ a1,
+                                                            float* __restrict__ a2, float* __restrict__ y) {
+    extern __shared__ float fls[];
+    FusedLds L;
+    L.A1s = reinterpret_cast<float (*)[FBM + 1]>(fls);
+    L.A2s = reinterpret_cast<float (*)[FBM + 1]>(fls + FH * (FBM + 1));
+    L.Ws = reinterpret_cast<float (*)[FBN + 1]>(fls + 2 * FH * (FBM + 1));
+    const int tid = threadIdx.x;
+    const long m0 = (long)blockIdx.x * FBM;
+    for (int e = tid; e < FBM * 64; e += 256) {        // X tile -> A2s[k][m], zero padded to 64 columns
+        const int m = e >> 6, k = e & 63;
+        L.A2s[k][m] = (m0 + m < B && k < D) ? xn[(m0 + m) * D + k] : 0.f;
+    }
+    __syncthreads();
+    fused_layer<4>(L, L.A2s, D, W0, b0, FH, true, L.A1s, a1, FH, m0, B);      // k-tiles beyond D: zero-padded X rows, zero-guarded weights
+    fused_layer<FH / GBK>(L, L.A1s, FH, W1, b1, FH, true, L.A2s, a2, FH, m0, B);
+    fused_layer<FH / GBK>(L, L.A2s, FH, W2, b2, O, false, nullptr, y, O, m0, B);
+}
+
+static bool g_fused_attr_set = false;
 static int mlp_forward_impl(const float* params, int D, int H, int O, const float* xn, long B, float* a1, float* a2,
                             float* y, hipStream_t s) {
     MlpView p(params, D, H, O);
+    static const bool use_fused = getenv("APX_MLP_UNFUSED") == nullptr;
+    if (use_fused && H == FH && D <= 64 && O <= FBN) {     // the reference's 2 x 256 nets: one launch, activations stay in LDS
+        const size_t lds = sizeof(float) * (2 * FH * (FBM + 1) + GBK * (FBN + 1));
+        if (!g_fused_attr_set) {
+            APX_HIP(hipFuncSetAttribute((const void*)mlp_fused_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            g_fused_attr_set = true;
+        }
+        hipLaunchKernelGGL(mlp_fused_fwd_kernel, dim3(apx_cdiv(B, FBM)), dim3(256), lds, s, p.W0, p.b0, p.W1, p.b1, p.W2, p.b2, xn, B, D, O, a1, a2, y);
+        APX_LAUNCH_CHECK();
+        return APX_OK;
+    }
     APX_TRY(linear_fwd(xn, p.W0, p.b0, a1, B, D, H, true, s));
     APX_TRY(linear_fwd(a1, p.W1, p.b1, a2, B, H, H, true, s));
     APX_TRY(linear_fwd(a2, p.W2, p.b2, y, B, H, O, false, s));
