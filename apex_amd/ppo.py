@@ -88,6 +88,10 @@ class PPO:
         self._graph = None
         self.ep_ret = torch.zeros(N, **f32); self.ep_len = torch.zeros(N, **f32)
         self.obs = None
+        # parity mode: replay captured draw streams instead of the Philox generator.
+        # noise_fn(t, out[N,10]) fills the action noise of rollout step t; perm_fn(epoch) -> int64[B] minibatch order;
+        # trace, when a list, receives every minibatch's 6 scalars (device tensors).
+        self.noise_fn = None; self.perm_fn = None; self.trace = None
 
     # ------------------------------------------------------------------------------------------ initialisation
     def init_networks(self, seed):
@@ -144,7 +148,10 @@ class PPO:
             obs = self.b_obs[t]
             mu = L.actor.forward(obs, L.obs_mean, L.obs_std, out=self.b_mu[t])
             L.critic.forward(obs, out=self.b_val[t])
-            self.noise.normal_(generator=self.gen)
+            if self.noise_fn is None:
+                self.noise.normal_(generator=self.gen)
+            else:
+                self.noise_fn(t, self.noise)
             torch.add(mu, self.noise, alpha=self.fixed_std, out=self.b_act[t])
             nxt = self.b_obs[t + 1] if t + 1 < T else self.obs
             env.step(self.b_act[t], out=(nxt, self.b_rew[t], self.b_done[t], self.b_fin[t]))
@@ -196,7 +203,10 @@ class PPO:
         losses, kl_last = None, 0.0
         epochs_run = 0
         for epoch in range(self.epochs):
-            perm = torch.randperm(B, device=self.device, generator=self.gen)                 # SubsetRandomSampler
+            if self.perm_fn is None:
+                perm = torch.randperm(B, device=self.device, generator=self.gen)             # SubsetRandomSampler
+            else:
+                perm = self.perm_fn(epoch)
             acc = torch.zeros(6, dtype=torch.float64, device=self.device)
             nb = B // mb                                                                     # drop_last=True, ppo.py:416
             for k in range(nb):
@@ -208,6 +218,8 @@ class PPO:
                 else:
                     scal = L.minibatch(obs, act, ret, adv, mu, idx=idx, mirror=self.mirror, sync=False)
                 acc += scal
+                if self.trace is not None:
+                    self.trace.append(scal.clone())
             if self.world > 1:
                 last = adist.allreduce_mean_(scal.clone(), group=self.group, world=self.world)
                 adist.allreduce_mean_(acc, group=self.group, world=self.world)

@@ -82,3 +82,97 @@ def test_cli_eval_scores_a_saved_checkpoint(dev, tmp_path, capsys):
     rc = apex.main(["eval", "--path", str(tmp_path), "--n_envs", "64", "--speed", "0.5", "--max_traj_len", "40"])
     out = capsys.readouterr().out
     assert rc == 0 and "episodes 64" in out and "mean length" in out
+
+
+class _ToyVecEnv:
+    """The toy dynamics of tools/refprobe/gen_golden_train.py (G15b) as a one-column device env with the CassieVecEnv
+    surface the driver uses: reset(), step(act, out=(next_obs, rew, done, final_obs)), done codes 1 = terminated,
+    2 = time-limit truncation.  `ks` is the list of episode counters the reference consumed for this iteration."""
+    def __init__(self, dev, lens, max_traj_len):
+        self.device, self.n_envs, self.lens, self.mtl = dev, 1, [int(x) for x in lens], int(max_traj_len)
+        self.ks = []
+
+    def _start(self):
+        k = self.ks.pop(0) if self.ks else 1
+        self.t = 0; self.L = self.lens[(k - 1) % len(self.lens)]
+        self.x = torch.cos(torch.arange(50, dtype=torch.float64, device=self.device) * 0.1 * k)
+
+    def _obs(self):
+        o = self.x.clone(); o[46] = np.sin(0.2 * self.t); o[47] = np.cos(0.2 * self.t)
+        return o.float().view(1, 50)
+
+    def reset(self):
+        self._start()
+        return self._obs()
+
+    def step(self, act, out):
+        nxt, rew, done, fin = out
+        self.t += 1
+        self.x = 0.9 * self.x + 0.1 * act.double().view(10).repeat(5) + 0.01
+        rew.copy_(torch.exp(-self.x.abs().mean()).float().view(1))
+        fin.copy_(self._obs())
+        code = 1 if self.t >= self.L else (2 if self.t >= self.mtl else 0)       # done wins over the time limit (ppo.py:174,184)
+        done.fill_(code)
+        if code:
+            self._start()
+        nxt.copy_(self._obs())
+
+
+def test_whole_train_loop_golden_g15b(dev, golden_dir):
+    """G15b: the reference's whole PPO.train (3 iterations: sample -> returns -> normalised advantages -> 3 epochs x 7 random
+    minibatches with the mirror loss -> Adam/clip) on a toy env, replayed through the build's driver + HIP learner with the
+    captured noise / minibatch-order streams.  Episode indices bit-exact; values, returns, advantages' inputs, every
+    minibatch's six scalars and the parameters after each iteration within the north-star tolerance."""
+    import os
+    from apex_amd.ppo import PPO
+    from rl.policies.actor import Gaussian_FF_Actor
+    from rl.policies.critic import FF_V
+    g = np.load(os.path.join(golden_dir, "g15b_ppo_train.npz"))
+    H, mb = int(g["hidden"]), int(g["minibatch"])
+    env = _ToyVecEnv(dev, g["lens"], g["max_traj_len"])
+    args = dict(gamma=float(g["gamma"]), lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=mb,
+                epochs=int(g["epochs"]), num_steps=int(g["num_steps"]), max_traj_len=int(g["max_traj_len"]), max_grad_norm=0.05,
+                mirror=True, std_dev=-1.5, seed=0)
+    algo = PPO(args, "/tmp/apx_test_unused", env, rank=0, world_size=1, group=None, hidden=H)
+    algo.policy = Gaussian_FF_Actor(50, 10, layers=(H, H), fixed_std=np.exp(-1.5)); algo.critic = FF_V(50, layers=(H, H))
+    algo.policy.load_state_dict({k: torch.as_tensor(g["actor0." + k]) for k in algo.policy.state_dict()})
+    algo.critic.load_state_dict({k: torch.as_tensor(g["critic0." + k]) for k in algo.critic.state_dict()})
+    algo.policy.obs_mean = torch.as_tensor(g["obs_mean"]); algo.policy.obs_std = torch.as_tensor(g["obs_std"])
+    algo.upload()
+    sigma = float(np.exp(-1.5))
+    for it in range(int(g["n_itr"])):
+        p = "it%d." % it
+        B = len(g[p + "rewards"])
+        assert B == algo.T
+        n_ep = len(g[p + "ep_lens"])
+        env.ks = [int(g[p + "k0"]) + 1 + j for j in range(n_ep)]
+        noise = torch.as_tensor((g[p + "actions"].astype(np.float64) - g[p + "mu"]) / sigma, dtype=torch.float32, device=dev)
+        algo.noise_fn = lambda t, out: out.copy_(noise[t].view(1, 10))
+        perms = torch.as_tensor(g[p + "idx"], device=dev)
+        algo.perm_fn = lambda e: perms[e]
+        algo.trace = []
+        algo.obs = None; algo.ep_ret.zero_(); algo.ep_len.zero_()
+        ret, ep_rets, ep_lens = algo.sample()
+        # --- sample: episode-step indices bit-exact, data within fp32 round-off of the reference's buffer
+        ends = np.nonzero(algo.b_end.view(-1).cpu().numpy())[0] + 1
+        assert np.array_equal(ends, g[p + "traj_idx"][1:])
+        assert np.array_equal(ep_lens.cpu().numpy().astype(np.int64), g[p + "ep_lens"])
+        np.testing.assert_allclose(ep_rets.cpu().numpy(), g[p + "ep_returns"], rtol=2e-6)
+        np.testing.assert_allclose(algo.b_obs.view(B, 50).cpu().numpy(), g[p + "states"], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(algo.b_act.view(B, 10).cpu().numpy(), g[p + "actions"], rtol=1e-5, atol=5e-6)
+        np.testing.assert_allclose(algo.b_rew.view(B).cpu().numpy(), g[p + "rewards"], rtol=2e-6)
+        np.testing.assert_allclose(algo.b_val.view(B).cpu().numpy(), g[p + "values"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(ret.view(B).cpu().numpy(), g[p + "returns"], rtol=1e-5, atol=1e-5)
+        # --- optimise: every minibatch's (actor loss, entropy, critic loss, ratio, kl, mirror loss)
+        losses, kl, epochs_run = algo.update(ret)
+        assert epochs_run == int(g[p + "epochs_run"])
+        scal = torch.stack(algo.trace).cpu().numpy().reshape(epochs_run, -1, 6)
+        ref = g[p + "scal"]
+        assert scal.shape == ref.shape
+        for c, (rt, at) in enumerate([(1e-5, 2e-6), (1e-6, 0), (1e-5, 0), (1e-5, 0), (1e-3, 2e-8), (1e-4, 1e-9)]):
+            np.testing.assert_allclose(scal[..., c], ref[..., c], rtol=rt, atol=at, err_msg="scalar %d itr %d" % (c, it))
+        # --- parameters after the iteration (21 Adam steps each)
+        for nm, views, ref_p in (("actor", algo.learner.actor.views(), algo.policy), ("critic", algo.learner.critic.views(), algo.critic)):
+            for k, v in zip(ref_p.state_dict(), views):
+                d = np.abs(v.cpu().numpy() - g[p + nm + "." + k])
+                assert (d > 5e-6).mean() < 2e-3 and d.max() < 5e-4, (it, nm, k, (d > 5e-6).mean(), d.max())

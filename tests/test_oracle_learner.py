@@ -120,3 +120,55 @@ def test_g15a_ppo_sample_control_flow(golden_dir):
     np.testing.assert_allclose(ret[:, 0], g["returns"], rtol=1e-6, atol=1e-7)
     for k in range(len(lens)):
         np.testing.assert_allclose(g["ep_returns"][k], g["rewards"][g["traj_idx"][k]:g["traj_idx"][k + 1]].sum(), rtol=1e-12)
+
+
+def test_g15b_whole_train_loop(golden_dir):
+    """G15b: the reference's whole PPO.train on a toy env (tools/refprobe/gen_golden_train.py).  The oracle replays the
+    recorded buffers: returns from (rewards, traj_idx, bootstrap rule), normalised advantages, then all 3 x 7 minibatch
+    updates per iteration in the recorded order -> every 6-tuple and the parameters after each iteration."""
+    g = np.load(os.path.join(golden_dir, "g15b_ppo_train.npz"))
+    g5 = np.load(os.path.join(golden_dir, "g5_mirror.npz"))
+    actor = [g["actor0." + k] for k in ACTOR_KEYS]; critic = [g["critic0." + k] for k in CRITIC_KEYS]
+    oa, oc = L.Adam(actor), L.Adam(critic)
+    mb, mtl = int(g["minibatch"]), int(g["max_traj_len"])
+    want_lens = [min(int(x), mtl) for x in g["lens"]]
+    steps = 0
+    for it in range(int(g["n_itr"])):
+        p = "it%d." % it
+        idx = g[p + "traj_idx"]; lens = np.diff(idx)
+        assert list(lens) == [want_lens[(int(g[p + "k0"]) + j) % len(want_lens)] for j in range(len(lens))]   # bit-exact indices
+        assert list(lens) == list(g[p + "ep_lens"])
+        obs, act = g[p + "states"].astype(np.float64), g[p + "actions"].astype(np.float64)
+        # values / means of the sampling policy from the oracle's forward
+        np.testing.assert_allclose(L.critic_value(critic, obs).reshape(-1), g[p + "values"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(L.actor_mean(actor, obs, g["obs_mean"], g["obs_std"]), g[p + "mu"], rtol=1e-4, atol=2e-6)
+        # bootstrap rule: truncated episodes (scripted length > max_traj_len) carry V(s_T), terminated ones 0
+        rew = g[p + "rewards"]; ret_ref = g[p + "returns"]
+        last_vals = np.array([(ret_ref[e - 1] - rew[e - 1]) / float(g["gamma"]) for e in idx[1:]])
+        trunc = np.array([int(g["lens"][(int(g[p + "k0"]) + j) % len(want_lens)]) > mtl for j in range(len(lens))])
+        assert ((np.abs(last_vals) > 1e-12) == trunc).all()
+        ret = L.discounted_returns(rew, lens, last_vals, float(g["gamma"]))
+        np.testing.assert_allclose(ret, ret_ref, rtol=1e-7, atol=1e-7)      # last_vals are recovered from the returns
+        adv = L.normalize_advantages(ret.astype(np.float32), g[p + "values"])
+        old = [w.copy() for w in actor]
+        scal_all = []
+        for e in range(int(g[p + "epochs_run"])):
+            order = g[p + "idx"][e]
+            for k in range(len(order) // mb):
+                ii = order[k * mb:(k + 1) * mb]
+                scal, actor, critic = L.ppo_update(actor, old, critic, oa, oc, obs[ii], act[ii], ret[ii].astype(np.float32).reshape(-1, 1),
+                                                   np.asarray(adv).reshape(-1, 1)[ii],
+                                                   g["obs_mean"], g["obs_std"], np.exp(-1.5), M_obs=g5["obs_mirror_matrix"],
+                                                   M_act=g5["act_mirror_matrix"])
+                scal_all.append(scal)
+        ref = g[p + "scal"].reshape(-1, 6)
+        np.testing.assert_allclose(np.array(scal_all), ref, rtol=3e-5, atol=2e-7)
+        for k, w in zip(ACTOR_KEYS, actor):
+            d = np.abs(w - g[p + "actor." + k]); assert (d > 5e-6).mean() < 2e-3 and d.max() < 5e-4, (it, k, d.max())
+        for k, w in zip(CRITIC_KEYS, critic):
+            d = np.abs(w - g[p + "critic." + k]); assert (d > 5e-6).mean() < 2e-3 and d.max() < 5e-4, (it, k, d.max())
+        steps += len(rew)
+        assert steps == int(g["timesteps"][it])
+        np.testing.assert_allclose(g["train_return"][it], g[p + "ep_returns"].mean(), rtol=1e-12)
+        np.testing.assert_allclose(g["mean_eplen"][it], g[p + "ep_lens"].mean(), rtol=1e-12)
+    assert len(g["scalar_names"]) == 13
