@@ -340,14 +340,17 @@ __device__ __forceinline__ void fused_layer(const FusedLds& L, float (*In)[FBM +
             float v = acc[r] + bs;
             if (relu) v = fmaxf(v, 0.f);
             if (OutS && col < N) OutS[col][row] = v;
-            if (col < N && m0 + row < B) outG[(m0 + row) * ldo + col] = v;
+            if (outG && col < N && m0 + row < B) outG[(m0 + row) * ldo + col] = v;
         }
     }
     __syncthreads();
 }
+struct FusedIn {           // where the 32 x D input tile comes from: prepared rows (everything else NULL) or raw observations + the prep of prep_obs_kernel
+    const float* x; const int64_t* idx; const int32_t* sign_perm; uint64_t clock_mask; const float *mean, *stdv; float* xn_out;
+};
 __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(const float* __restrict__ W0, const float* __restrict__ b0, const float* __restrict__ W1,
                                                             const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
-                                                            const float* __restrict__ xn, long B, int D, int O, float* __restrict__ a1,
+                                                            FusedIn I, long B, int D, int O, float* __restrict__ a1,
                                                             float* __restrict__ a2, float* __restrict__ y) {
     extern __shared__ float fls[];
     FusedLds L;
@@ -358,7 +361,20 @@ __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(const float* __restr
     const long m0 = (long)blockIdx.x * FBM;
     for (int e = tid; e < FBM * 64; e += 256) {        // X tile -> A2s[k][m], zero padded to 64 columns
         const int m = e >> 6, k = e & 63;
-        L.A2s[k][m] = (m0 + m < B && k < D) ? xn[(m0 + m) * D + k] : 0.f;
+        float v = 0.f;
+        if (m0 + m < B && k < D) {
+            const long row = I.idx ? I.idx[m0 + m] : m0 + m;
+            if (I.sign_perm) {
+                const int32_t sp = I.sign_perm[k];
+                v = sp >= 0 ? I.x[row * D + sp] : -I.x[row * D + (-sp - 1)];
+                if ((I.clock_mask >> k) & 1ull) v = sinf(asinf(v) + 3.14159265358979323846f);      // wrappers.py:65-66
+            } else {
+                v = I.x[row * D + k];
+            }
+            if (I.mean) v = (v - I.mean[k]) / I.stdv[k];
+            if (I.xn_out) I.xn_out[(m0 + m) * D + k] = v;
+        }
+        L.A2s[k][m] = v;
     }
     __syncthreads();
     fused_layer<4>(L, L.A2s, D, W0, b0, FH, true, L.A1s, a1, FH, m0, B);      // k-tiles beyond D: zero-padded X rows, zero-guarded weights
@@ -367,20 +383,26 @@ __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(const float* __restr
 }
 
 static bool g_fused_attr_set = false;
+static bool fused_ok(int D, int H, int O) {
+    static const bool use_fused = getenv("APX_MLP_UNFUSED") == nullptr;
+    return use_fused && H == FH && D <= 64 && O <= FBN;     // the reference's 2 x 256 nets
+}
+static int mlp_fused_launch(const float* params, int D, int H, int O, const FusedIn& in, long B, float* a1, float* a2, float* y, hipStream_t s) {
+    MlpView p(params, D, H, O);
+    const size_t lds = sizeof(float) * (2 * FH * (FBM + 1) + GBK * (FBN + 1));
+    if (!g_fused_attr_set) {
+        APX_HIP(hipFuncSetAttribute((const void*)mlp_fused_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        g_fused_attr_set = true;
+    }
+    hipLaunchKernelGGL(mlp_fused_fwd_kernel, dim3(apx_cdiv(B, FBM)), dim3(256), lds, s, p.W0, p.b0, p.W1, p.b1, p.W2, p.b2, in, B, D, O, a1, a2, y);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+}
 static int mlp_forward_impl(const float* params, int D, int H, int O, const float* xn, long B, float* a1, float* a2,
                             float* y, hipStream_t s) {
     MlpView p(params, D, H, O);
-    static const bool use_fused = getenv("APX_MLP_UNFUSED") == nullptr;
-    if (use_fused && H == FH && D <= 64 && O <= FBN) {     // the reference's 2 x 256 nets: one launch, activations stay in LDS
-        const size_t lds = sizeof(float) * (2 * FH * (FBM + 1) + GBK * (FBN + 1));
-        if (!g_fused_attr_set) {
-            APX_HIP(hipFuncSetAttribute((const void*)mlp_fused_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            g_fused_attr_set = true;
-        }
-        hipLaunchKernelGGL(mlp_fused_fwd_kernel, dim3(apx_cdiv(B, FBM)), dim3(256), lds, s, p.W0, p.b0, p.W1, p.b1, p.W2, p.b2, xn, B, D, O, a1, a2, y);
-        APX_LAUNCH_CHECK();
-        return APX_OK;
-    }
+    if (fused_ok(D, H, O))       // one launch, activations stay in LDS
+        return mlp_fused_launch(params, D, H, O, FusedIn{xn, nullptr, nullptr, 0, nullptr, nullptr, nullptr}, B, a1, a2, y, s);
     APX_TRY(linear_fwd(xn, p.W0, p.b0, a1, B, D, H, true, s));
     APX_TRY(linear_fwd(a1, p.W1, p.b1, a2, B, H, H, true, s));
     APX_TRY(linear_fwd(a2, p.W2, p.b2, y, B, H, O, false, s));
@@ -414,10 +436,13 @@ extern "C" int apx_mlp_forward(const float* params, int D, int H, int O, const f
                                void* stream) {
     APX_REQUIRE(D > 0 && H > 0 && O > 0 && B >= 0, "dims");
     if (B == 0) return APX_OK;   // empty batch: nothing to do (empty tensors have NULL data pointers)
-    APX_REQUIRE(params && x && y && xn_out && act1 && act2, "null pointer");
+    APX_REQUIRE(params && x && y, "null pointer");
     APX_REQUIRE(precision == 0, "only precision 0 (fp32 MFMA) is built in this round");
     APX_REQUIRE((obs_mean == nullptr) == (obs_std == nullptr), "obs_mean/obs_std");
     hipStream_t s = (hipStream_t)stream;
+    if (fused_ok(D, H, O))      // input prep inside the fused kernel; NULL outputs are simply not written
+        return mlp_fused_launch(params, D, H, O, FusedIn{x, idx, sign_perm, clock_mask, obs_mean, obs_std, xn_out}, B, act1, act2, y, s);
+    APX_REQUIRE(xn_out && act1 && act2, "xn_out / act1 / act2 may only be NULL for the fused shapes (H = 256, D <= 64, O <= 128)");
     APX_TRY(prep_obs(x, B, D, idx, sign_perm, clock_mask, obs_mean, obs_std, xn_out, s));
     return mlp_forward_impl(params, D, H, O, xn_out, B, act1, act2, y, s);
 }

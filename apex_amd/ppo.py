@@ -83,7 +83,7 @@ class PPO:
         self.b_done = torch.zeros(T, N, dtype=torch.uint8, device=self.device)
         self.b_endb = torch.zeros(T, N, dtype=torch.bool, device=self.device)
         self.b_fin = torch.zeros(T, N, 50, **f32)
-        self.noise = torch.zeros(N, 10, **f32)
+        self.noise = torch.zeros(T, N, 10, **f32)
         self.use_graph = bool(args.get("graph", False)) and self.world == 1
         self._graph = None
         self.ep_ret = torch.zeros(N, **f32); self.ep_len = torch.zeros(N, **f32)
@@ -144,17 +144,18 @@ class PPO:
     def _rollout_loop(self):
         L, env, T = self.learner, self.env, self.T
         self.b_obs[0].copy_(self.obs)
+        if self.noise_fn is None:
+            self.noise.normal_(generator=self.gen)                # the whole rollout's action noise in one launch
         for t in range(T):      # every kernel writes straight into the rollout grids: no staging copies
             obs = self.b_obs[t]
             mu = L.actor.forward(obs, L.obs_mean, L.obs_std, out=self.b_mu[t])
-            L.critic.forward(obs, out=self.b_val[t])
-            if self.noise_fn is None:
-                self.noise.normal_(generator=self.gen)
-            else:
-                self.noise_fn(t, self.noise)
-            torch.add(mu, self.noise, alpha=self.fixed_std, out=self.b_act[t])
+            if self.noise_fn is not None:
+                self.noise_fn(t, self.noise[t])
+            torch.add(mu, self.noise[t], alpha=self.fixed_std, out=self.b_act[t])
             nxt = self.b_obs[t + 1] if t + 1 < T else self.obs
             env.step(self.b_act[t], out=(nxt, self.b_rew[t], self.b_done[t], self.b_fin[t]))
+        # V(s_t) is not on the stepping path: one batched critic pass over the whole grid instead of T small ones
+        L.critic.forward(self.b_obs.view(T * self.N, 50), out=self.b_val.view(T * self.N, 1))
 
     def sample(self):
         """T lock-step env steps for the N envs of this GPU (the batched PPO.sample, ppo.py:139-186).

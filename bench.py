@@ -153,7 +153,7 @@ def main():
             "roofline": {"kernel": "env_step_kernel", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": _pmc_traffic_bytes(),
                          "ms_per_launch": round(k_ms, 3), "bytes_per_env_step": bytes_per_env_step,
-                         "mlp_forward_mfma": {"what": "actor forward, %d x (50-256-256-10), fp32 MFMA (v_mfma_f32_32x32x2_f32), fused 3-layer kernel + input prep launch" % mb_rows,
+                         "mlp_forward_mfma": {"what": "actor forward, %d x (50-256-256-10), fp32 MFMA (v_mfma_f32_32x32x2_f32), one fused launch (input normalisation + 3 layers, activations in LDS)" % mb_rows,
                                               "ms": round(mlp_ms, 4), "achieved_tflops": round(mlp_flop / (mlp_ms * 1e-3) / 1e12, 2),
                                               "peak_tflops": VALU_PEAK_TFLOPS, "frac": round(mlp_flop / (mlp_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)},
                          "valu": {"flop_per_env_step": roofline.ENV_STEP_FLOP,

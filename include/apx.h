@@ -59,11 +59,13 @@ int apx_adv_apply(const float* ret, const float* val, int64_t n, double mean, do
 size_t apx_mlp_param_count(int D, int H, int O);
 
 /* y[B,O] = MLP(x) with optional input normalisation (obs_mean/obs_std may be NULL = none; FF_V in train mode,
- * critic.py:66-67).  act1/act2 (may be NULL) receive the post-ReLU hidden activations [B,H] for a later backward.
+ * critic.py:66-67).  xn_out [B,D] receives the prepared input and act1/act2 the post-ReLU hidden activations [B,H]
+ * for a later backward; all three may be NULL (inference: nothing but y is written) for the fused shapes H = 256,
+ * D <= 64, O <= 128 (the reference's 2 x 256 nets), otherwise they are required as scratch.
  * idx (may be NULL) gathers rows: x_row = x[idx[b]].  sign_perm (may be NULL) = int32[D] signed permutation
  * applied BEFORE normalisation (SymmetricEnv.mirror_clock_observation, rl/envs/wrappers.py:59-67): entry j>=0 takes
  * +x[j], entry -(j+1) takes -x[j]; clock_mask bit c set => column c additionally gets sin(asin(.)+pi).
- * precision: 0 = fp32 MFMA (parity mode), 1 = bf16 MFMA inputs with fp32 accumulate.       all pointers [dev] */
+ * precision: 0 = fp32 MFMA; 1 (bf16 MFMA inputs, fp32 accumulate) is reserved and rejected.       all pointers [dev] */
 int apx_mlp_forward(const float* params, int D, int H, int O, const float* x, int64_t B, const int64_t* idx,
                     const int32_t* sign_perm, uint64_t clock_mask, const float* obs_mean, const float* obs_std,
                     float* xn_out, float* act1, float* act2, float* y, int precision, void* stream);
@@ -90,7 +92,7 @@ typedef struct apx_ppo_args {
     /* hyper-parameters */
     float fixed_std, clip, entropy_coeff, grad_clip, lr, adam_eps, mirror_coeff;
     int adam_t;            /* 1-based optimiser step count (bias correction) */
-    int precision;         /* 0 fp32 MFMA, 1 bf16 MFMA */
+    int precision;         /* 0 fp32 MFMA (1 = bf16 MFMA inputs is reserved and rejected) */
     int grad_only;         /* 1 = stop after gradients (no clip/Adam): lets N>1 ranks all-reduce actor_grad/critic_grad */
     /* scratch: apx_ppo_workspace_bytes(mb, D, H, A) bytes [dev] */
     void* workspace; size_t workspace_bytes;
