@@ -555,6 +555,14 @@ __device__ float clock_reward(const St& S, const Cfg& cfg, const float* action, 
     const float ph = (float)S.I(I_PHASE);
     const float lfc = clock_eval(ck, 0, ph, cfg.stance_mode, cfg.incentive), lvc = clock_eval(ck, 1, ph, cfg.stance_mode, cfg.incentive);
     const float rfc = clock_eval(ck, 2, ph, cfg.stance_mode, cfg.incentive), rvc = clock_eval(ck, 3, ph, cfg.stance_mode, cfg.incentive);
+    if (cfg.reward_kind == 2) {   // max_vel_clock_reward (clock_rewards.py:416-480): caps 400 N / 3 m/s, tanh terms, forward-velocity bonus
+        const float mlf = fminf(lfrc, 400.f) / 400.f, mrf = fminf(rfrc, 400.f) / 400.f;
+        const float mlv = fminf(sqrtf(lv), 3.f) / 3.f, mrv = fminf(sqrtf(rv), 3.f) / 3.f;
+        float hd = fabsf(S(F_QPOS + 2) - 1.0f);
+        if (hd < 0.2f) hd = 0.f;
+        return 0.1f * expf(-15.f * (1.f - qw * qw)) + 0.1f * expf(-foot_orient) + 0.1f * expf(-(straight + hd)) +
+               0.2f * (tanhf(lfc * mlf) + tanhf(rfc * mrf)) + 0.2f * (tanhf(lvc * mlv) + tanhf(rvc * mrv)) + 0.3f * (S(F_QVEL) / 3.0f);
+    }
     if (cfg.reward_kind == 1) {   // early_clock_reward (clock_rewards.py:119-223): caps 350 N / 3 m/s, tanh scores, 5 terms
         const float elf = fminf(lfrc, 350.f) / 350.f, erf = fminf(rfrc, 350.f) / 350.f;
         const float elv = fminf(sqrtf(lv), 3.f) / 3.f, erv = fminf(sqrtf(rv), 3.f) / 3.f;
@@ -886,7 +894,7 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     APX_REQUIRE(cfg && out, "null");
     APX_REQUIRE(cfg->n_envs > 0 && cfg->n_envs % 64 == 0, "n_envs must be a positive multiple of 64");
     APX_REQUIRE(cfg->simrate > 0 && 2000 % cfg->simrate == 0, "simrate must divide 2000");
-    APX_REQUIRE(cfg->reward_kind == 0 || cfg->reward_kind == 1, "reward_kind: 0 clock_reward, 1 early_clock_reward");
+    APX_REQUIRE(cfg->reward_kind >= 0 && cfg->reward_kind <= 2, "reward_kind: 0 clock_reward, 1 early_clock_reward, 2 max_vel_clock_reward");
     APX_REQUIRE(cfg->pgs_iters > 0 && cfg->max_traj_len > 0, "pgs_iters / max_traj_len");
     APX_HIP(hipSetDevice(cfg->device));
     apx_env* e = new (std::nothrow) apx_env;

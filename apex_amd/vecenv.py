@@ -32,9 +32,10 @@ def parse_reward(reward):
     if "load" in reward:
         raise NotImplementedError("load_clock rewards: no shipped clock file matches (SURVEY.md §8 a5b)")
     stance = 1 if "grounded" in reward else 2 if "aerial" in reward else 0
-    if "max_vel" in reward:
-        raise NotImplementedError("max_vel_clock_reward is outside the north-star path")
-    return dict(reward_kind=1 if early else 0, stance_mode=stance, have_incentive=int(have_incentive))
+    # cassie.py:223-224 + :781-783: "max_vel" selects max_vel_clock_reward whatever the `early` flag says; "switch" only sets an
+    # unused switch_speed (the switch_clock branch at :551 is unreachable) and stays on clock_reward
+    kind = 2 if "max_vel" in reward else 1 if early else 0
+    return dict(reward_kind=kind, stance_mode=stance, have_incentive=int(have_incentive))
 
 
 class CassieVecEnv:

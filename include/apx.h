@@ -117,7 +117,7 @@ typedef struct apx_env_cfg {
     int n_envs;                 /* envs on this GPU (multiple of 64) */
     int simrate;                /* physics substeps per env step, apex.py:18 (default 50) */
     int dynamics_randomization; /* apex.py:19 */
-    int reward_kind;            /* 0 clock_reward (clock_rewards.py:6-110), 1 early_clock_reward (:119-223) */
+    int reward_kind;            /* 0 clock_reward (clock_rewards.py:6-110), 1 early_clock_reward (:119-223), 2 max_vel_clock_reward (:416-480) */
     int stance_mode;            /* 0 zero, 1 grounded, 2 aerial (cassie.py:209-214) */
     int have_incentive;         /* cassie.py:91 */
     int max_traj_len;           /* apex.py:248: auto-reset horizon used by apx_env_step's truncation flag */

@@ -417,7 +417,28 @@ static double early_clock_reward(Env& e, const double* action) {
     return 0.250 * frc_score + 0.350 * vel_score + 0.200 * std::exp(-com_vel_err) + 0.100 * std::exp(-(com_orient + foot_orient)) +
            0.100 * std::exp(-(straight + hdiff));
 }
-double eval_clock_reward(Env& e, const double* action) { return e.cfg.reward_kind == 1 ? early_clock_reward(e, action) : clock_reward(e, action); }
+// max_vel_clock_reward (cassie/rewards/clock_rewards.py:416-480): caps 400 N / 3 m/s, tanh clock terms, forward-velocity bonus
+static double max_vel_clock_reward(Env& e, const double* action) {
+    (void)action;
+    const State& s = e.st;
+    const double fmax = 400, vmax = 3.0;
+    const double nlf = std::min(e.l_foot_frc, fmax) / fmax, nrf = std::min(e.r_foot_frc, fmax) / fmax;
+    const double lv = std::sqrt(e.l_foot_vel[0] * e.l_foot_vel[0] + e.l_foot_vel[1] * e.l_foot_vel[1] + e.l_foot_vel[2] * e.l_foot_vel[2]);
+    const double rv = std::sqrt(e.r_foot_vel[0] * e.r_foot_vel[0] + e.r_foot_vel[1] * e.r_foot_vel[1] + e.r_foot_vel[2] * e.r_foot_vel[2]);
+    const double nlv = std::min(lv, vmax) / vmax, nrv = std::min(rv, vmax) / vmax;
+    const double com_orient = 15 * (1 - s.qpos[3] * s.qpos[3]), foot_orient = 10 * (e.l_foot_orient_cost + e.r_foot_orient_cost);
+    double straight = std::fabs(s.qpos[1]);
+    if (straight < 0.05) straight = 0;
+    double hdiff = std::fabs(s.qpos[2] - 1.0);               // +- 0.2 m dead zone around 1.0 m (:452-455)
+    if (hdiff < 0.2) hdiff = 0;
+    const double lfc = e.clock.eval(0, e.phase), lvc = e.clock.eval(1, e.phase), rfc = e.clock.eval(2, e.phase), rvc = e.clock.eval(3, e.phase);
+    const double frc = std::tanh(lfc * nlf) + std::tanh(rfc * nrf), vel = std::tanh(lvc * nlv) + std::tanh(rvc * nrv);
+    return 0.1 * std::exp(-com_orient) + 0.1 * std::exp(-foot_orient) + 0.1 * std::exp(-(straight + hdiff)) + 0.2 * frc + 0.2 * vel +
+           0.3 * (s.qvel[0] / 3.0);
+}
+double eval_clock_reward(Env& e, const double* action) {
+    return e.cfg.reward_kind == 2 ? max_vel_clock_reward(e, action) : e.cfg.reward_kind == 1 ? early_clock_reward(e, action) : clock_reward(e, action);
+}
 
 // CassieEnv.step, cassie.py:389-496
 int env_step(Env& e, const double* action, double* obs, double* reward) {

@@ -22,7 +22,7 @@ struct Philox {
 struct EnvCfg {
     int simrate = 50;
     int dynamics_randomization = 1;
-    int reward_kind = 0;      // 0 clock_reward, 1 early_clock_reward
+    int reward_kind = 0;      // 0 clock_reward, 1 early_clock_reward, 2 max_vel_clock_reward
     int stance_mode = 0;      // 0 zero, 1 grounded, 2 aerial
     int have_incentive = 1;
     int max_traj_len = 400;

@@ -131,11 +131,13 @@ def test_coupled_pitch_knee_zone_vs_oracle(dev):
     assert hit > 0            # the coupled zone was actually reached
 
 
-def test_early_clock_reward_vs_oracle(dev):
-    """--reward early_clock selects early_clock_reward (cassie.py:202-204, clock_rewards.py:119-223)."""
+@pytest.mark.parametrize("reward,kind", [("early_clock", 1), ("max_vel_clock", 2)])
+def test_early_and_max_vel_clock_reward_vs_oracle(dev, reward, kind):
+    """--reward early_clock selects early_clock_reward (cassie.py:202-204, clock_rewards.py:119-223), --reward max_vel_clock
+    selects max_vel_clock_reward (cassie.py:223-224, clock_rewards.py:416-480)."""
     from apex_amd.vecenv import CassieVecEnv
-    genv = CassieVecEnv(n_envs=N, dynamics_randomization=True, seed=6, reward="early_clock")
-    oenv = [S.OracleEnv(dyn_rand=True, seed=6, env_id=i, reward_kind=1) for i in range(8)]
+    genv = CassieVecEnv(n_envs=N, dynamics_randomization=True, seed=6, reward=reward)
+    oenv = [S.OracleEnv(dyn_rand=True, seed=6, env_id=i, reward_kind=kind) for i in range(8)]
     genv.reset(); [e.reset() for e in oenv]
     rng = np.random.RandomState(2)
     for t in range(4):

@@ -82,6 +82,8 @@ def test_reward_string_parsing():
     assert parse_reward("clock") == dict(reward_kind=0, stance_mode=0, have_incentive=1)
     assert parse_reward("early_grounded_no_incentive_clock") == dict(reward_kind=1, stance_mode=1, have_incentive=0)
     assert parse_reward("aerial_clock")["stance_mode"] == 2
+    assert parse_reward("max_vel_clock")["reward_kind"] == 2 and parse_reward("early_max_vel_clock")["reward_kind"] == 2   # cassie.py:223, :781
+    assert parse_reward("switch_clock")["reward_kind"] == 0                                                                 # cassie.py:225-228
     with pytest.raises(TypeError):
         parse_reward(None)              # the reference crashes on `"..." in None` too (cassie.py:91)
 

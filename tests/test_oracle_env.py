@@ -32,6 +32,12 @@ def test_g7_clock_reward(golden_dir):
         r = e1.clock_reward_eval(g[p + "qpos"], g[p + "qvel"], g[p + "scal"], g[p + "foot_vel"], g[p + "rotvel"], g[p + "tacc"],
                                  g[p + "torque"], g[p + "prev_torque"], g[p + "prev_action"], g[p + "action"])
         assert abs(r - float(g[p + "reward_early"])) < 1e-12, (c, r)
+    e2 = S.OracleEnv(reward_kind=2)             # max_vel_clock_reward (clock_rewards.py:416-480)
+    for c in range(int(g["n_cases"])):
+        p = f"c{c}_"
+        r = e2.clock_reward_eval(g[p + "qpos"], g[p + "qvel"], g[p + "scal"], g[p + "foot_vel"], g[p + "rotvel"], g[p + "tacc"],
+                                 g[p + "torque"], g[p + "prev_torque"], g[p + "prev_action"], g[p + "action"])
+        assert abs(r - float(g[p + "reward_max_vel"])) < 1e-12, (c, r)
 
 
 def test_g8_full_state(golden_dir):

@@ -10,7 +10,7 @@ import numpy as np
 
 import cassie  # noqa: F401  (prints the MuJoCo load failure; harmless)
 from cassie.phase_function import create_phase_reward
-from cassie.rewards.clock_rewards import clock_reward, early_clock_reward
+from cassie.rewards.clock_rewards import clock_reward, early_clock_reward, max_vel_clock_reward
 from cassie.cassie import CassieEnv
 
 
@@ -71,6 +71,7 @@ def g7():
         action = rng.randn(10) * 0.2
         r = clock_reward(s, action)
         r_early = early_clock_reward(s, action)
+        r_maxvel = max_vel_clock_reward(s, action)
         pre = f"c{c}_"
         out[pre + "qpos"] = qpos; out[pre + "qvel"] = qvel
         out[pre + "scal"] = np.array([s.l_foot_frc, s.r_foot_frc, s.l_foot_orient_cost, s.r_foot_orient_cost, s.speed,
@@ -81,6 +82,7 @@ def g7():
         out[pre + "prev_action"] = s.prev_action; out[pre + "action"] = action
         out[pre + "reward"] = r
         out[pre + "reward_early"] = r_early
+        out[pre + "reward_max_vel"] = r_maxvel
     out["n_cases"] = n
     np.savez_compressed(os.path.join(GOLD, "g7_clock_reward.npz"), **out)
 
