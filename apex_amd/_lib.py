@@ -56,7 +56,8 @@ SIGNATURES = {
     "apx_env_destroy": (C.c_int, [c_ptr]),
     "apx_env_reset": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
     "apx_env_update_speed": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
-    "apx_env_reset_for_test": (C.c_int, [c_ptr, c_ptr, c_ptr]),
+    "apx_env_reset_for_test": (C.c_int, [c_ptr, c_ptr, C.c_int, c_ptr]),
+    "apx_env_apply_force": (C.c_int, [c_ptr, c_ptr, c_ptr]),
     "apx_env_step_basic": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
     "apx_env_step": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, c_ptr]),
     "apx_env_get_state": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),

@@ -370,6 +370,13 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             const float cmax = cm_act_ctrlmax[ua];
             fs += cm_act_gear[ua] * fminf(fmaxf(S.W(WK_CTRL + ua), -cmax), cmax);
         }
+        if constexpr (!QPOS0) {
+            if (l >= 13) {      // external wrench on the pelvis (mjData.xfrc_applied, applied at the body's COM): J^T (f, tau) on the 6 free-joint dofs
+                const V3 xf = {S(F_XFRC), S(F_XFRC + 1), S(F_XFRC + 2)}, xt = {S(F_XFRC + 3), S(F_XFRC + 4), S(F_XFRC + 5)};
+                const V3 rp = mul(pmat, V3{cm_body_ipos[3], cm_body_ipos[4], cm_body_ipos[5]});      // xipos - o
+                fs += dot(cd.a, xt + cross(rp, xf)) + dot(cd.l, xf);
+            }
+        }
         S.W(WK_SMOOTH + d) = fs;
     });
     // ---- foot pose for the reward / foot velocity (cassie.py:328-331,426-427)

@@ -721,7 +721,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_substep_kernel(float
     store_state(S, st, ist, n);
 }
 // CassieEnv.reset_for_test(full_reset=False) (cassie/cassie.py:682-742)
-__global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_for_test_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, float* obs) {
+__global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_for_test_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, float* obs, int full) {
     ENV_SETUP
     load_state(S, st, ist, n);
     if (lead) {
@@ -730,7 +730,25 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_for_test_kerne
         S(F_CMD + 3) = 0.15f; S(F_CMD + 4) = 0.25f; S(F_CMD + 5) = (2.f * 0.15f + 2.f * 0.25f) * (float)(2000 / cfg.simrate);
     }
     c4::wsync();
-    sim_step_pd(S, cfg.pgs_iters, 1);                                            // self.cassie_state = self.sim.step_pd(self.u), stale targets
+    if (full) {
+        // cassie_sim_full_reset (binary: qpos <- init pose, qvel / ctrl / qfrc_applied / xfrc_applied / qacc <- 0, the 6 x 10 torque delay
+        // line <- 0, state_output_setup; qacc_warmstart and the encoder filters are NOT touched) + reset_cassie_state (cassie.py:733-746)
+        if (lead) {
+            for (int i = 0; i < NQ; ++i) S(F_QPOS + i) = cm_init_qpos[i];
+            for (int i = 0; i < NV; ++i) S(F_QVEL + i) = 0.f;
+            for (int i = 0; i < 60; ++i) S(F_FIFO + i) = 0.f;
+            for (int i = 0; i < 6; ++i) S(F_XFRC + i) = 0.f;
+            const float mp[5] = {0.0045f, 0.f, 0.4973f, -1.1997f, -1.5968f}, jp[3] = {0.f, 1.4267f, -1.5968f};
+            for (int u = 0; u < 10; ++u) { S(F_SO + SO_MPOS + u) = mp[u % 5]; S(F_SO + SO_MVEL + u) = 0.f; }
+            for (int k = 0; k < 6; ++k) { S(F_SO + SO_JPOS + k) = jp[k % 3]; S(F_SO + SO_JVEL + k) = 0.f; }
+            S(F_SO + SO_QUAT) = 1.f;
+            for (int k = 0; k < 3; ++k) { S(F_SO + SO_QUAT + 1 + k) = 0.f; S(F_SO + SO_ROTVEL + k) = 0.f; S(F_SO + SO_TVEL + k) = 0.f; S(F_SO + SO_TACC + k) = 0.f; }
+            S(F_SO + SO_HEIGHT) = 1.01f;                                         // pelvis.position[2] = 1.01, terrain.height = 0
+        }
+        c4::wsync();
+    } else {
+        sim_step_pd(S, cfg.pgs_iters, 1);                                        // self.cassie_state = self.sim.step_pd(self.u), stale targets
+    }
     if (cfg.dyn_rand) {                                                          // default dynamics, set_const (back to the init pose), flat floor, no encoder offsets
         if (lead) {
             for (int b = 0; b < NB; ++b) S(F_MASS + b) = cm_body_mass[b];
@@ -956,17 +974,25 @@ extern "C" int apx_env_step_basic(apx_env_t* e, const float* action, float* obs,
 #endif
 }
 
-extern "C" int apx_env_reset_for_test(apx_env_t* e, float* obs_out, void* stream) {
+extern "C" int apx_env_reset_for_test(apx_env_t* e, float* obs_out, int full_reset, void* stream) {
     APX_REQUIRE(e && obs_out, "null pointer");
 #if APX_GEN == 4
     e->cfg.stance_mode = 1;                               // reset_for_test switches to the grounded clock (cassie.py:702)
     hipLaunchKernelGGL(env_reset_for_test_kernel, ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
-                       make_cfg(e->cfg), obs_out);
+                       make_cfg(e->cfg), obs_out, full_reset);
     APX_LAUNCH_CHECK();
     return APX_OK;
 #else
     APX_REQUIRE(false, "apx_env_reset_for_test is implemented by the generation-4 kernel only (build with GEN=4)");
 #endif
+}
+
+__global__ void scatter_kernel(float* st, int n, int f0, int cnt, const float* in);
+extern "C" int apx_env_apply_force(apx_env_t* e, const float* xfrc, void* stream) {
+    APX_REQUIRE(e && xfrc, "null pointer");
+    hipLaunchKernelGGL(scatter_kernel, dim3(apx_cdiv((long)e->n * 6, 256)), dim3(256), 0, (hipStream_t)stream, e->st, e->n, (int)F_XFRC, 6, xfrc);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
 }
 
 extern "C" int apx_env_step(apx_env_t* e, const float* action, float* obs, float* reward, uint8_t* done, float* final_obs,
@@ -1017,7 +1043,7 @@ static const FieldDesc kFields[] = {
     {"so_mpos", F_SO + SO_MPOS, 10}, {"so_mvel", F_SO + SO_MVEL, 10}, {"so_torque", F_SO + SO_TORQUE, 10},
     {"so_jpos", F_SO + SO_JPOS, 6}, {"so_jvel", F_SO + SO_JVEL, 6}, {"so_quat", F_SO + SO_QUAT, 4},
     {"so_rotvel", F_SO + SO_ROTVEL, 3}, {"so_tvel", F_SO + SO_TVEL, 3}, {"so_tacc", F_SO + SO_TACC, 3}, {"so_height", F_SO + SO_HEIGHT, 1},
-    {"foot_vel", F_FOOTVEL, 6}, {"prev_action", F_PREVACT, 10}, {"prev_torque", F_PREVTQ, 10}, {"cmd", F_CMD, 6}, {"fwd", F_FWD, 16},
+    {"foot_vel", F_FOOTVEL, 6}, {"prev_action", F_PREVACT, 10}, {"prev_torque", F_PREVTQ, 10}, {"cmd", F_CMD, 6}, {"fwd", F_FWD, 16}, {"xfrc", F_XFRC, 6},
 };
 
 static const FieldDesc* find_field(const char* name) {

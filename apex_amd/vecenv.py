@@ -93,10 +93,32 @@ class CassieVecEnv:
         sp, sd = f(new_speed), f(new_side_speed)
         check(_lib.load().apx_env_update_speed(self._h, _p(sp), _p(sd), _stream()))
 
-    def reset_for_test(self):
-        """CassieEnv.reset_for_test(full_reset=False) (cassie.py:682-742) for every env; returns the [N, 50] observation."""
-        check(_lib.load().apx_env_reset_for_test(self._h, _p(self.obs), _stream()))
+    def reset_for_test(self, full_reset=False):
+        """CassieEnv.reset_for_test(full_reset) (cassie.py:682-742) for every env; returns the [N, 50] observation."""
+        check(_lib.load().apx_env_reset_for_test(self._h, _p(self.obs), int(bool(full_reset)), _stream()))
         return self.obs
+
+    def apply_force(self, xfrc, body_name="cassie-pelvis"):
+        """CassieSim.apply_force (cassiemujoco.py:99-103) for every env: xfrc [N, 6] (or [6]) = world-frame force xyz + torque xyz on
+        the pelvis; stays applied until overwritten (tools/eval_perturb.py:62,70)."""
+        if body_name != "cassie-pelvis":
+            raise NotImplementedError("external wrenches are supported on cassie-pelvis only")
+        x = torch.as_tensor(xfrc, dtype=torch.float32, device=self.device).expand(self.n_envs, 6).contiguous()
+        check(_lib.load().apx_env_apply_force(self._h, _p(x), _stream()))
+
+    def set_command(self, speed=None, side_speed=None, orient_add=None, phase=None):
+        """Plain attribute writes `env.speed = ...`, `env.orient_add = ...`, `env.phase = ...` of the reference's test harnesses
+        (tools/eval_perturb.py:32, tools/test_commands.py:66-120): no clipping, the clock is NOT rebuilt (unlike update_speed)."""
+        if speed is not None or side_speed is not None or orient_add is not None:
+            cmd = self.get_field("cmd")
+            for col, v in ((0, speed), (1, side_speed), (2, orient_add)):
+                if v is not None:
+                    cmd[:, col] = torch.as_tensor(v, dtype=torch.float32, device=self.device)
+            self.set_field("cmd", cmd)
+        if phase is not None:
+            ints = self.get_field("ints")
+            ints[:, 1] = torch.as_tensor(phase, dtype=torch.float32, device=self.device)
+            self.set_field("ints", ints)
 
     def step_basic(self, action):
         """CassieEnv.step_basic (cassie.py:498-521) for every env: no reward / termination / command resampling; returns obs."""

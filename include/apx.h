@@ -141,10 +141,16 @@ int apx_env_reset(apx_env_t* env, const uint8_t* mask, float* obs_out, void* str
  * side_speed[n_envs] f32 [dev] or NULL (= 0): commands are clipped to [-0.3, 4] / [-0.3, 0.3], the clock is rebuilt from the
  * new speed and the phase is rescaled to the new cycle length. */
 int apx_env_update_speed(apx_env_t* env, const float* speed, const float* side_speed, void* stream);
-/* CassieEnv.reset_for_test(full_reset=False) (cassie/cassie.py:682-742) for every env: counters / commands to zero, the
- * fixed 0.15 / 0.25 grounded clock (the handle's stance mode becomes grounded), one step_pd with the stale pd targets, then
- * default dynamics + set_const, flat floor, zero encoder offsets; obs_out[n_envs*50] f32 [dev]. */
-int apx_env_reset_for_test(apx_env_t* env, float* obs_out, void* stream);
+/* CassieEnv.reset_for_test(full_reset) (cassie/cassie.py:682-742) for every env: counters / commands to zero, the fixed
+ * 0.15 / 0.25 grounded clock (the handle's stance mode becomes grounded); full_reset = 0: one step_pd with the stale pd targets;
+ * full_reset = 1: cassie_sim_full_reset (include/cassiemujoco.h:202: init pose, zero velocities, external wrench and torque
+ * delay line) + reset_cassie_state (cassie.py:733-746); then default dynamics + set_const, flat floor, zero encoder offsets;
+ * obs_out[n_envs*50] f32 [dev]. */
+int apx_env_reset_for_test(apx_env_t* env, float* obs_out, int full_reset, void* stream);
+/* CassieSim.apply_force(xfrc, "cassie-pelvis") (cassiemujoco.py:99-103, cassie_sim_apply_force include/cassiemujoco.h:184):
+ * xfrc[n_envs*6] f32 [dev] = world-frame force xyz then torque xyz on the pelvis at its centre of mass; it stays applied
+ * until overwritten (tools/eval_perturb.py:62,70) or a full reset.  Only the pelvis body is supported. */
+int apx_env_apply_force(apx_env_t* env, const float* xfrc, void* stream);
 /* CassieEnv.step_basic (cassie/cassie.py:498-521, 355-387) for every env: the substeps and the time / phase bookkeeping of a
  * step, without reward, termination, trackers or command resampling (evaluation at a fixed command); obs[n_envs*50]. */
 int apx_env_step_basic(apx_env_t* env, const float* action, float* obs, void* stream);

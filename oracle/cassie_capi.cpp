@@ -25,7 +25,8 @@ int orc_env_step(void* h, const double* action, double* obs, double* reward) { r
 void orc_env_substep(void* h) { sim_step_pd(*(Env*)h); }
 void orc_env_step_basic(void* h, const double* action, double* obs) { env_step_basic(*(Env*)h, action, obs); }
 void orc_env_update_speed(void* h, double speed, double side_speed) { env_update_speed(*(Env*)h, speed, side_speed); }
-void orc_env_reset_for_test(void* h, double* obs) { env_reset_for_test(*(Env*)h, obs); }
+void orc_env_reset_for_test(void* h, double* obs, int full_reset) { env_reset_for_test(*(Env*)h, obs, full_reset != 0); }
+void orc_env_apply_force(void* h, const double* xfrc) { for (int k = 0; k < 6; ++k) ((Env*)h)->st.xfrc[k] = xfrc[k]; }   // CassieSim.apply_force on cassie-pelvis
 // test helper: the command / clock / phase state a training reset with first speed draw `speed0` leaves behind (cassie.py:553-563)
 void orc_env_set_command(void* h, double speed0, int phase) { Env& e = *(Env*)h; e.speed = speed0; env_clock_from_speed(e); e.phase = phase; }
 void orc_env_obs(void* h, double* obs) { env_obs(*(Env*)h, obs); }
@@ -42,6 +43,7 @@ void orc_phys_forward(void* h, const double* ctrl) {
     forward(e.par, e.st, w, ctrl);
 }
 double orc_constraint_violation(void* h) { return constraint_violation(((Env*)h)->st); }
+void orc_com_velocity(void* h, double* out) { static thread_local Work w; Env& e = *(Env*)h; com_velocity(e.par, e.st, w, out); }
 double orc_total_energy(void* h) { static thread_local Work w; Env& e = *(Env*)h; return total_energy(e.par, e.st, w); }
 
 #define FIELD(nm, ptr, cnt) if (!std::strcmp(name, nm)) { if (set) std::memcpy((void*)(ptr), io, sizeof(double) * (cnt)); else std::memcpy(io, (ptr), sizeof(double) * (cnt)); return cnt; }

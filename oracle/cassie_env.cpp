@@ -293,13 +293,29 @@ void env_update_speed(Env& e, double new_speed, double new_side_speed) {
 // 0.15 / 0.25 grounded clock, ONE step_pd with the stale pd targets, THEN the default dynamics + set_const (which also puts the
 // robot back into the init pose), flat floor, zero encoder offsets.  The returned observation is built from the state estimate
 // of that one step_pd (self.cassie_state), i.e. from before set_const.
-void env_reset_for_test(Env& e, double* obs) {
+void env_reset_for_test(Env& e, double* obs, bool full_reset) {
     static thread_local Work w;
     e.phase = 0; e.time = 0; e.counter = 0; e.orient_add = 0; e.speed = 0;
     e.cfg.stance_mode = 1;
     make_clock(e.clock, 0.15, 0.25, 0.1, e.cfg.stance_mode, e.cfg.have_incentive, 2000 / e.cfg.simrate);
-    e.l_foot_frc = e.r_foot_frc = e.l_foot_orient_cost = e.r_foot_orient_cost = 0;
-    sim_step_pd(e);
+    if (!full_reset) {
+        e.l_foot_frc = e.r_foot_frc = e.l_foot_orient_cost = e.r_foot_orient_cost = 0;
+        sim_step_pd(e);
+    } else {
+        // cassie_sim_full_reset as the shipped binary does it (disassembly): qpos <- the 35 init values, mju_zero of qvel, ctrl,
+        // qfrc_applied, xfrc_applied, qacc; the 60-double torque delay line zeroed; state_output_setup.  qacc_warmstart, time, the
+        // encoder filters and the PD block are left alone.  Then CassieEnv.reset_cassie_state (cassie.py:733-746).
+        for (int i = 0; i < NQ; ++i) e.st.qpos[i] = cm_init_qpos[i];
+        for (int i = 0; i < NV; ++i) e.st.qvel[i] = 0;
+        for (int u = 0; u < 10; ++u) for (int k = 0; k < 6; ++k) e.tq_fifo[u][k] = 0;
+        for (int k = 0; k < 6; ++k) e.st.xfrc[k] = 0;
+        static const double mp[5] = {0.0045, 0, 0.4973, -1.1997, -1.5968}, jp[3] = {0, 1.4267, -1.5968};
+        for (int u = 0; u < 10; ++u) { e.so_mpos[u] = mp[u % 5]; e.so_mvel[u] = 0; }
+        for (int k = 0; k < 6; ++k) { e.so_jpos[k] = jp[k % 3]; e.so_jvel[k] = 0; }
+        e.so_quat[0] = 1; e.so_quat[1] = e.so_quat[2] = e.so_quat[3] = 0;
+        for (int k = 0; k < 3; ++k) e.so_rotvel[k] = e.so_tvel[k] = e.so_tacc[k] = 0;
+        e.so_height = 1.01;
+    }
     if (e.cfg.dynamics_randomization) {
         const int iters = e.par.pgs_iters;
         default_params(e.par);

@@ -73,7 +73,7 @@ void env_reset(Env& e, double* obs);
 void env_step_basic(Env& e, const double* action, double* obs);           // CassieEnv.step_basic, cassie.py:498-521
 void env_clock_from_speed(Env& e);                                         // swing / stance / clock from e.speed, cassie.py:556-559
 void env_update_speed(Env& e, double new_speed, double new_side_speed);   // CassieEnv.update_speed, cassie.py:757-775
-void env_reset_for_test(Env& e, double* obs);                              // CassieEnv.reset_for_test(full_reset=False), cassie.py:682-742
+void env_reset_for_test(Env& e, double* obs, bool full_reset = false);    // CassieEnv.reset_for_test(full_reset), cassie.py:682-742
 // returns done flag: 0 running, 1 terminated (height), 2 truncated at max_traj_len (only reported, no reset here)
 int env_step(Env& e, const double* action, double* obs, double* reward);
 void env_obs(const Env& e, double* obs);

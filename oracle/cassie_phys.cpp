@@ -234,6 +234,12 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
         const double c = std::min(std::max(ctrl ? ctrl[u] : 0.0, -cm_act_ctrlmax[u]), cm_act_ctrlmax[u]);
         w.smooth[cm_act_dof[u]] += cm_act_gear[u] * c;
     }
+    {   // mj_xfrcAccumulate for the pelvis: J^T (f, tau) with the wrench acting at xipos; only the 6 free-joint dofs see it
+        const V3 f = {s.xfrc[0], s.xfrc[1], s.xfrc[2]}, t = {s.xfrc[3], s.xfrc[4], s.xfrc[5]};
+        const V3 p = s.xpos[1] + mul(s.xmat[1], v3(cm_body_ipos + 3));
+        const V3 to = t + cross(p - w.o, f);
+        for (int d = 0; d < 6; ++d) w.smooth[d] += dot(w.cdof[d].a, to) + dot(w.cdof[d].l, f);
+    }
     cholesky(w.M, w.L);
     double qacc_smooth[NV];
     chol_solve(w.L, w.smooth, qacc_smooth);
@@ -425,6 +431,20 @@ double constraint_violation(const State& s) {
         m = std::max(m, norm(p1 - p2));
     }
     return m;
+}
+
+// total linear momentum / total mass: the translational rows of the free joint are world-aligned, so p = M[0:3, :] qvel
+void com_velocity(const Params& p, const State& s0, Work& w, double out[3]) {
+    State s = s0;
+    kinematics(s.qpos, s, w);
+    inertias(p, s, w);
+    double m = 0;
+    for (int b = 1; b < NB; ++b) m += p.mass[b];
+    for (int k = 0; k < 3; ++k) {
+        double a = 0;
+        for (int j = 0; j < NV; ++j) a += w.M[k][j] * s.qvel[j];
+        out[k] = a / m;
+    }
 }
 
 double total_energy(const Params& p, const State& s0, Work& w) {

@@ -107,6 +107,7 @@ struct State {
     double sens_acc[3];          // accelerometer at the imu site (cassie.xml:267), sensor frame
     double sens_gyro[3];
     double con_dist[MAXCON]; int con_geom[MAXCON];
+    double xfrc[6] = {0, 0, 0, 0, 0, 0};   // mjData.xfrc_applied row of cassie-pelvis: world force xyz, torque xyz, applied at the body COM
 };
 
 struct Work {
@@ -128,6 +129,7 @@ inline void step(const Params& p, State& s, Work& w, const double* ctrl) { forwa
 
 // diagnostics used by the invariant tests
 double constraint_violation(const State& s);                      // max |p1-p2| over the 4 connect constraints
+void com_velocity(const Params& p, const State& s, Work& w, double out[3]);   // total linear momentum / total mass
 double total_energy(const Params& p, const State& s, Work& w);    // kinetic + gravity + spring potential
 
 }  // namespace orc

@@ -25,10 +25,12 @@ def lib():
         L.orc_env_substep.argtypes = [C.c_void_p]
         L.orc_env_update_speed.argtypes = [C.c_void_p, C.c_double, C.c_double]
         L.orc_env_step_basic.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        L.orc_env_reset_for_test.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_env_reset_for_test.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_env_apply_force.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_env_set_command.argtypes = [C.c_void_p, C.c_double, C.c_int]
         L.orc_env_obs.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_phys_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_com_velocity.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_phys_forward.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_constraint_violation.restype = C.c_double
         L.orc_constraint_violation.argtypes = [C.c_void_p]
@@ -95,15 +97,25 @@ class OracleEnv:
     def set_command(self, speed0, phase):
         lib().orc_env_set_command(self.h, float(speed0), int(phase))
 
-    def reset_for_test(self):
+    def reset_for_test(self, full_reset=False):
         obs = np.zeros(50)
-        lib().orc_env_reset_for_test(self.h, _ptr(obs))
+        lib().orc_env_reset_for_test(self.h, _ptr(obs), int(bool(full_reset)))
         return obs
+
+    def apply_force(self, xfrc):
+        x = np.ascontiguousarray(xfrc, dtype=np.float64)
+        assert x.shape == (6,)
+        lib().orc_env_apply_force(self.h, _ptr(x))
 
     def obs(self):
         o = np.zeros(50)
         lib().orc_env_obs(self.h, _ptr(o))
         return o
+
+    def com_velocity(self):
+        v = np.zeros(3)
+        lib().orc_com_velocity(self.h, _ptr(v))
+        return v
 
     def phys_step(self, ctrl, n=1):
         c = np.ascontiguousarray(ctrl, dtype=np.float64)

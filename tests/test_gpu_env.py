@@ -326,3 +326,54 @@ def test_step_basic_vs_oracle(dev):
             assert (gi[i, 0], gi[i, 1], gi[i, 2]) == (oi[0], oi[1], oi[2])
             assert obs[i, 48] == 1.0 and obs[i, 49] == 0.0                       # the commanded speed stays put
     assert np.array_equal(genv.get_field("ints").cpu().numpy()[:, 3], rc0)       # no random draws
+
+
+def test_full_reset_and_apply_force_vs_oracle(dev, golden_dir):
+    """Row f3: reset_for_test(full_reset=True) and CassieSim.apply_force on the pelvis (tools/eval_perturb.py:31,62,70).
+    The observation after the full reset is the reference's own (golden G16, real get_full_state on reset_cassie_state); after
+    it every env is in the SAME state (init pose, default dynamics, zero delay line), so the pushed trajectories compare
+    kernel vs oracle without accumulated history: per-env wrenches of different size / direction, 8 env steps of push, then
+    release."""
+    import os
+    g = np.load(os.path.join(golden_dir, "g16_eval_api.npz"))
+    genv, oenv = _mk(True, 21)
+    K = 12
+    genv.reset(); [e.reset() for e in oenv[:K]]
+    rng = np.random.RandomState(9)
+    act = (rng.randn(N, 10) * 0.1).astype(np.float32)
+    for t in range(2):
+        genv.step(torch.tensor(act, device=dev), auto_reset=False)
+        [e.step(act[i].astype(np.float64)) for i, e in enumerate(oenv[:K])]
+    genv.set_command(side_speed=-0.1)
+    genv.apply_force(torch.tensor([30.0, 0, 0, 0, 0, 0]))                 # must be cleared by the full reset
+    gobs = genv.reset_for_test(full_reset=True).cpu().numpy()
+    np.testing.assert_allclose(gobs, np.tile(g["rft_full_obs"], (N, 1)), atol=1e-6)
+    assert np.all(genv.get_field("xfrc").cpu().numpy() == 0) and np.all(genv.get_field("tq_fifo").cpu().numpy() == 0)
+    for e in oenv[:K]:
+        e.set("side_speed", -0.1); e.reset_for_test(full_reset=True)
+    # plain attribute writes of the harness (env.speed = 0.5): no clock rebuild
+    genv.set_command(speed=0.5)
+    [e.set("speed", 0.5) for e in oenv[:K]]
+    xfrc = np.zeros((N, 6), np.float32)
+    ang = -2 * np.pi * np.arange(N) / 8.0
+    size = 20.0 + 15.0 * (np.arange(N) % 7)
+    xfrc[:, 0] = size * np.cos(ang); xfrc[:, 1] = size * np.sin(ang)
+    xfrc[1::3, 3:] = rng.uniform(-5, 5, (len(xfrc[1::3]), 3))             # some envs also get a torque
+    genv.apply_force(torch.tensor(xfrc))
+    [e.apply_force(xfrc[i].astype(np.float64)) for i, e in enumerate(oenv[:K])]
+    zero = torch.zeros(N, 10, device=dev)
+    tol = np.full(50, 1e-2); tol[21:31] = 0.15; tol[31:34] = 0.3; tol[40:46] = 0.15
+    for t in range(10):
+        if t == 8:
+            genv.apply_force(torch.zeros(6)); [e.apply_force(np.zeros(6)) for e in oenv[:K]]
+        obs, rew, done, _ = genv.step(zero, auto_reset=False)
+        obs = obs.cpu().numpy(); qp = genv.get_field("qpos").cpu().numpy(); qv = genv.get_field("qvel").cpu().numpy()
+        for i, e in enumerate(oenv[:K]):
+            o, r, d = e.step(np.zeros(10))
+            sc = 1.0 + t
+            np.testing.assert_allclose(qp[i, :3], e.get("qpos")[:3], atol=2e-3 * sc, err_msg="pelvis position env %d step %d" % (i, t))
+            np.testing.assert_allclose(qv[i, :3], e.get("qvel")[:3], atol=3e-2 * sc, err_msg="pelvis velocity env %d step %d" % (i, t))
+            assert np.all(np.abs(obs[i] - o) <= tol * sc + 5e-3 * np.abs(o)), ("env %d step %d" % (i, t), np.abs(obs[i] - o).max())
+    # the push actually moved the robots apart: lateral pelvis velocity follows the direction of the wrench
+    vy = genv.get_field("qvel").cpu().numpy()[:, 1]
+    assert np.corrcoef(vy[:64], xfrc[:64, 1])[0, 1] > 0.5

@@ -251,6 +251,58 @@ def test_g16_update_speed_and_reset_for_test(golden_dir):
     assert np.all(np.isfinite(obs)) and obs[48] == 0 and abs(obs[49] - 0.2) < 1e-12 and obs[46] == 0 and obs[47] == 1     # commands, clock at phase 0
 
 
+def test_g16_reset_for_test_full_reset(golden_dir):
+    """reset_for_test(full_reset=True) (tools/eval_perturb.py:31): call order full_reset -> defaults -> set_const -> floor, and the
+    observation the REAL get_full_state builds from reset_cassie_state's constants (side speed is NOT reset), from the reference."""
+    g = np.load(os.path.join(golden_dir, "g16_eval_api.npz"))
+    assert list(g["rft_full_order"]) == ["full_reset", "damping", "mass", "ipos", "friction", "set_const", "geom_quat:floor"]
+    e = S.OracleEnv(dyn_rand=True, seed=3, env_id=2)
+    e.reset()
+    for _ in range(4):
+        e.step(np.full(10, 0.3))
+    e.set("side_speed", -0.1)
+    e.apply_force([50.0, 0, 0, 0, 0, 0])
+    obs = e.reset_for_test(full_reset=True)
+    np.testing.assert_allclose(obs, g["rft_full_obs"], atol=1e-12)
+    ph, tm, cnt, oadd, sp, side, swing, stance, plen = g["rft_full_scalars"]
+    ints = e.get("ints")
+    assert (ints[0], ints[1], ints[2]) == (tm, ph, cnt) and e.get("speed")[0] == sp and e.get("side_speed")[0] == side
+    assert abs(e.get("phaselen")[0] - plen) < 1e-12
+    d0 = S.OracleEnv(dyn_rand=False, seed=0, env_id=0)
+    np.testing.assert_allclose(e.get("qpos"), d0.get("qpos")); assert np.all(e.get("qvel") == 0)       # init pose (set_const follows)
+    # the wrench was cleared by the full reset: the next steps equal those of an env that never had one
+    e2 = S.OracleEnv(dyn_rand=True, seed=3, env_id=2)
+    e2.reset()
+    for _ in range(4):
+        e2.step(np.full(10, 0.3))
+    e2.set("side_speed", -0.1)
+    e2.reset_for_test(full_reset=True)
+    for _ in range(3):
+        o1 = e.step_basic(np.zeros(10)); o2 = e2.step_basic(np.zeros(10))
+    np.testing.assert_allclose(o1, o2, atol=1e-12)
+
+
+def test_apply_force_on_the_pelvis():
+    """CassieSim.apply_force([fx, fy, 0, 0, 0, 0], "cassie-pelvis") (tools/eval_perturb.py:62): momentum balance on the whole
+    robot.  While airborne (first substeps after set_const the feet are off the ground) the only external forces are gravity and
+    the wrench, so the COM acceleration must be g + f / M; and a pure torque must not move the COM at all."""
+    e = S.OracleEnv(dyn_rand=False, seed=0, env_id=0)
+    e.reset_for_test(full_reset=True)
+    M = e.get("mass").sum()
+    def com_vel(env):
+        return np.asarray(env.com_velocity())
+    for xfrc in ([60.0, -25.0, 10.0, 0, 0, 0], [0, 0, 0, 3.0, -2.0, 4.0], [40.0, 10.0, 0, 1.0, 0.5, -0.5]):
+        e = S.OracleEnv(dyn_rand=False, seed=0, env_id=0)
+        e.reset_for_test(full_reset=True)
+        e.apply_force(xfrc)
+        v0 = com_vel(e)
+        n = 6
+        e.phys_step(np.zeros(10), n)
+        a = (com_vel(e) - v0) / (n * 0.0005)
+        # semi-implicit Euler with a configuration-dependent M conserves momentum to O(h): 5e-5 relative here
+        np.testing.assert_allclose(a, np.array([0, 0, -9.81]) + np.array(xfrc[:3]) / M, atol=5e-4)
+
+
 def test_g16_step_basic_bookkeeping(golden_dir):
     """CassieEnv.step_basic (cassie.py:498-521): 70 calls after reset_for_test on the 32-step clock: time, phase wrap (phase > phaselen),
     counter, and simrate step_pd calls per step, from the reference; the oracle reproduces the bookkeeping."""

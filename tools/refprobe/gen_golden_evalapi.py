@@ -21,6 +21,7 @@ class OrderSim(RecSim):
     def set_geom_quat(self, v, name=None): self.order.append("geom_quat:%s" % name); self.calls["geom_quat"] = np.array(v, dtype=np.float64)
     def set_const(self): self.order.append("set_const"); super().set_const()
     def step_pd(self, u): self.order.append("step_pd"); return super().step_pd(u)
+    def full_reset(self): self.order.append("full_reset")
 
 
 def main():
@@ -66,7 +67,18 @@ def main():
                rft_stance_mode=np.array([env.stance_mode]), rft_damping=env.sim.calls["damping"], rft_mass=env.sim.calls["mass"],
                rft_friction=env.sim.calls["friction"], rft_floor=env.sim.calls["geom_quat"],
                rft_noise=np.concatenate([env.motor_encoder_noise, env.joint_encoder_noise]))
+    # reset_for_test(full_reset=True) (tools/eval_perturb.py:31,109) with the REAL get_full_state on the reset cassie_state
+    env2 = cc.CassieEnv(dynamics_randomization=True, reward="clock", config="unused")
+    env2.strict_relaxer = 0.1; env2.have_incentive = True; env2.stance_mode = "zero"; env2.u = None
+    env2.speed = 1.5; env2.side_speed = -0.1; env2.phase = 9; env2.time = 12; env2.counter = 2; env2.orient_add = -0.3
+    env2.motor_encoder_noise = np.full(10, 0.005); env2.joint_encoder_noise = np.full(6, -0.004)
+    obs_full = np.array(env2.reset_for_test(full_reset=True), dtype=np.float64)
+    out["rft_full_order"] = np.array(list(env2.sim.order))
+    out["rft_full_obs"] = obs_full
+    out["rft_full_scalars"] = np.array([env2.phase, env2.time, env2.counter, env2.orient_add, env2.speed, env2.side_speed,
+                                        env2.swing_duration, env2.stance_duration, env2.phaselen], dtype=np.float64)
     np.savez_compressed(os.path.join(GOLD, "g16_eval_api.npz"), **out)
+    print("full order:", env2.sim.order); print("full obs:", obs_full)
     print("order:", env.sim.order); print("scalars:", out["rft_scalars"]); print(rec[:2])
 
 
