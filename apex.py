@@ -85,10 +85,58 @@ def eval_main(argv):
     return 0
 
 
+def _load_actor(path, device):
+    import os
+    import torch
+    from apex_amd.engine import Mlp
+    policy = torch.load(os.path.join(path, "actor.pt"), weights_only=False)
+    params = [q.detach().numpy() for q in policy.parameters()]
+    actor = Mlp(params[0].shape[1], params[0].shape[0], params[-1].shape[0], device)
+    actor.load_list(params)
+    mean = torch.as_tensor(policy.obs_mean, dtype=torch.float32).to(device) if torch.is_tensor(policy.obs_mean) else None
+    std = torch.as_tensor(policy.obs_std, dtype=torch.float32).to(device) if torch.is_tensor(policy.obs_std) else None
+    return actor, mean, std
+
+
+def eval_perturb_main(argv):
+    """`apex.py eval_perturb --path <run dir>`: the reference's tools/eval_perturb.py sweep (largest survivable pelvis push per gait
+    phase and direction), every (direction, phase, size) trial as one env of a single batch; writes eval_perturbs.npy next to
+    actor.pt like the reference (test_policy.py:78-89)."""
+    import argparse, os, time
+    import numpy as np
+    import torch
+    p = argparse.ArgumentParser()
+    p.add_argument("--path", type=str, required=True)
+    p.add_argument("--num_angles", type=int, default=4)
+    p.add_argument("--wait_time", type=float, default=4.0)
+    p.add_argument("--perturb_duration", type=float, default=0.2)
+    p.add_argument("--perturb_size", type=float, default=100.0)
+    p.add_argument("--perturb_incr", type=float, default=10.0)
+    p.add_argument("--n_sizes", type=int, default=40)
+    p.add_argument("--reward", type=str, default="clock")
+    a = p.parse_args(argv)
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd.eval import compute_perturbs
+    mk = lambda n: CassieVecEnv(n_envs=n, reward=a.reward, max_traj_len=100000, dynamics_randomization=False)
+    actor, mean, std = _load_actor(a.path, torch.device("cuda", 0))
+    t0 = time.time()
+    mf, fell = compute_perturbs(actor, mk, mean, std, wait_time=a.wait_time, perturb_duration=a.perturb_duration,
+                                perturb_size=a.perturb_size, perturb_incr=a.perturb_incr, num_angles=a.num_angles, n_sizes=a.n_sizes)
+    dt = time.time() - t0
+    np.save(os.path.join(a.path, "eval_perturbs.npy"), mf)
+    print("push-recovery sweep: %d trials in %.1f s" % (fell.size, dt))
+    for i in range(a.num_angles):
+        print("direction %6.1f deg: max force over the %d phases  min %.0f  mean %.1f  max %.0f N" % (
+            -360.0 * i / a.num_angles, mf.shape[0], mf[:, i].min(), mf[:, i].mean(), mf[:, i].max()))
+    return 0
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     if argv and argv[0] == "eval":
         return eval_main(argv[1:])
+    if argv and argv[0] == "eval_perturb":
+        return eval_perturb_main(argv[1:])
     if not argv or argv[0] != "ppo":
         print("Usage: python apex.py ppo [flags] | python apex.py eval --path RUN_DIR [--speed S]   (only the PPO / Cassie-v0 path is built; see DESIGN.md)")
         return 2

@@ -176,3 +176,23 @@ def test_whole_train_loop_golden_g15b(dev, golden_dir):
             for k, v in zip(ref_p.state_dict(), views):
                 d = np.abs(v.cpu().numpy() - g[p + nm + "." + k])
                 assert (d > 5e-6).mean() < 2e-3 and d.max() < 5e-4, (it, nm, k, (d > 5e-6).mean(), d.max())
+
+
+def test_compute_perturbs_batched(dev):
+    """tools/eval_perturb.py's sweep as one batch (apex_amd/eval.py::compute_perturbs) with the PD-hold "policy" (zero action =
+    nominal standing pose, cassie.py:107,295; it keeps the pelvis above 0.4 m for ~1 s, enough for a short window): no push ->
+    nobody falls; 1250 N for 0.1 s -> every trial falls; failures are monotone in the push size; the reported max force is
+    (first failing size - increment) per (phase, direction)."""
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd.eval import compute_perturbs
+    mk = lambda n: CassieVecEnv(n_envs=n, max_traj_len=100000, dynamics_randomization=False)
+    stand = lambda o: torch.zeros(o.shape[0], 10, device=o.device)
+    mf, fell = compute_perturbs(stand, mk, wait_time=0.3, perturb_duration=0.1, perturb_size=0.0, perturb_incr=250.0, num_angles=4,
+                                n_sizes=6, num_phases=2)
+    assert mf.shape == (2, 4) and fell.shape == (2, 4, 6)
+    assert not fell[:, :, 0].any()                   # 0 N
+    assert fell[:, :, 5].all()                       # 1250 N
+    assert (np.diff(fell.astype(int), axis=-1) >= 0).all()
+    first = np.where(fell.any(-1), fell.argmax(-1), 6)
+    np.testing.assert_allclose(mf, 250.0 * first - 250.0)
+    assert (mf >= 250).all() and (mf <= 1000).all()
