@@ -761,15 +761,18 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out) {
     // ---- uniform: first MAXC penetrating capsule ends in the order foot e0,e1, tarsus e0,e1, shin e0,e1
     const V3 p0 = {ct_floor_pos[0], ct_floor_pos[1], ct_floor_pos[2]};
     int nc = 0;
-    V3 cpt[MAXC]; float cdist[MAXC]; int cgeo[MAXC];
-    sfor<0, MAXC>([&](auto Sl) { cpt[Sl] = {0.f, 0.f, 0.f}; cdist[Sl] = 0.f; cgeo[Sl] = 0; });
+    static_assert(MAXC == 2, "two contact slots per leg");
+    V3 cpt0 = {0.f, 0.f, 0.f}, cpt1 = {0.f, 0.f, 0.f}; float cdist[MAXC]; int cgeo[MAXC];
+    sfor<0, MAXC>([&](auto Sl) { cdist[Sl] = 0.f; cgeo[Sl] = 0; });
     sfor<0, 6>([&](auto I) {
         constexpr int G = I / 2;
         const V3 ctr = ldv3<base + 12 + 3 * I>(S);
         const float dist = dot(ctr - p0, fn) - ct_geom_radius[2 * G + LEG];
         const bool hit = dist < 0.f && nc < MAXC;
         const V3 cp = ctr - fn * (ct_geom_radius[2 * G + LEG] + 0.5f * dist);
-        sfor<0, MAXC>([&](auto Sl) { if (hit && nc == Sl) { cpt[Sl] = cp; cdist[Sl] = dist; cgeo[Sl] = G; } });
+        if (hit && nc == 0) cpt0 = cp;
+        if (hit && nc == 1) cpt1 = cp;
+        sfor<0, MAXC>([&](auto Sl) { if (hit && nc == Sl) { cdist[Sl] = dist; cgeo[Sl] = G; } });
         nc += hit ? 1 : 0;
     });
     // ---- this lane's row
@@ -787,14 +790,16 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out) {
     {
         const V3 e1 = {S.W(base + 6 * E), S.W(base + 6 * E + 1), S.W(base + 6 * E + 2)};
         const V3 e2 = {S.W(base + 6 * E + 3), S.W(base + 6 * E + 4), S.W(base + 6 * E + 5)};
-        const V3 cp = cs ? cpt[1] : cpt[0];
+        const V3 cp = {cs ? cpt1.x : cpt0.x, cs ? cpt1.y : cpt0.y, cs ? cpt1.z : cpt0.z};
         p1 = isEq ? e1 : cp; p2 = e2;
     }
     V3 dir;
     {
-        const V3 dc = ax == 0 ? fn : ax == 1 ? ft1 : ft2;
-        const V3 de = {ax == 0 ? 1.f : 0.f, ax == 1 ? 1.f : 0.f, ax == 2 ? 1.f : 0.f};
-        dir = isEq ? de : dc;
+        // scalar selects only: `isEq ? de : dc` on two V3 temporaries becomes a load through a selected POINTER, which keeps both
+        // temporaries in scratch (6 stores + 3 loads per leg per substep = 8x the algorithmic HBM traffic of the whole kernel)
+        const float dcx = ax == 0 ? fn.x : ax == 1 ? ft1.x : ft2.x, dcy = ax == 0 ? fn.y : ax == 1 ? ft1.y : ft2.y,
+                    dcz = ax == 0 ? fn.z : ax == 1 ? ft1.z : ft2.z;
+        dir = {isEq ? (ax == 0 ? 1.f : 0.f) : dcx, isEq ? (ax == 1 ? 1.f : 0.f) : dcy, isEq ? (ax == 2 ? 1.f : 0.f) : dcz};
     }
     const V3 q1 = cross(p1 - o, dir), q2 = cross(p2 - o, dir);       // dir . (a x r) = a . (r x dir)
     float (&J)[19] = out.J;

@@ -282,7 +282,9 @@ __device__ __noinline__ void stage3_pgs(St S, int pgs_iters) {
 }
 #endif
 #if APX_GEN == 4
-__device__ APX_STAGE void stage4_finish(St S, int mode) {
+// inlined like the rows / PGS stage: as a function it needs 36 callee-saved VGPRs, i.e. 36 scratch stores + 36 loads per lane per
+// substep (9 KB per wave-substep), several times the algorithmic HBM traffic of the whole kernel
+__device__ __forceinline__ void stage4_finish(St S, int mode) {
     PROF_START();
     c4::stage_finish_lane(S, rows4(), mode != 0);
     PROF(4);
@@ -587,7 +589,10 @@ __device__ float clock_reward(const St& S, const Cfg& cfg, const float* action, 
 // one env per 16-lane row: the env's whole state is staged HBM -> LDS at the top of a launch and back at the end
 #define ENV_SETUP                                                                                   \
     const int l = threadIdx.x & 15, row = threadIdx.x >> 4;                                          \
-    const int env = blockIdx.x * L4_EPW + row;                                                       \
+    /* XCD-aware: workgroup i runs on XCD i % 8 (own L2 each); give every XCD a CONTIGUOUS eighth of the envs so that the  \
+       8 workgroups sharing a 128-B line of a state row (4 envs x 4 B each) hit the same L2 instead of fetching it 8 times */ \
+    const int blk = (gridDim.x & 7) == 0 ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x; \
+    const int env = blk * L4_EPW + row;                                                              \
     if (row >= L4_EPW || env >= n) return;                                                                            \
     const bool lead = l == 0;                                                                        \
     const St S{(lfloat*)apx_lds4 + row * L4_ES, env};
