@@ -131,10 +131,41 @@ def eval_perturb_main(argv):
     return 0
 
 
+def eval_commands_main(argv):
+    """`apex.py eval_commands --path <run dir>`: tools/test_commands.py's random speed / heading command schedules, one schedule per
+    env of a single batch; writes eval_commands.npy next to actor.pt like test_policy.py:76 and prints report_stats-style totals."""
+    import argparse, os, time
+    import numpy as np
+    import torch
+    p = argparse.ArgumentParser()
+    p.add_argument("--path", type=str, required=True)
+    p.add_argument("--n_steps", type=int, default=200)
+    p.add_argument("--n_commands", type=int, default=6)
+    p.add_argument("--max_speed", type=float, default=3.0)
+    p.add_argument("--min_speed", type=float, default=0.0)
+    p.add_argument("--n_iter", type=int, default=1024)
+    p.add_argument("--reward", type=str, default="clock")
+    a = p.parse_args(argv)
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd.eval import eval_commands
+    mk = lambda n: CassieVecEnv(n_envs=n, reward=a.reward, max_traj_len=100000, dynamics_randomization=False)
+    actor, mean, std = _load_actor(a.path, torch.device("cuda", 0))
+    t0 = time.time()
+    d = eval_commands(actor, mk, mean, std, num_steps=a.n_steps, num_commands=a.n_commands, max_speed=a.max_speed,
+                      min_speed=a.min_speed, num_iters=a.n_iter)
+    np.save(os.path.join(a.path, "eval_commands.npy"), d)
+    fail = d[d[:, 0] == 0]
+    print("command test: %d schedules x %d commands in %.1f s: pass rate %.3f; failures after a speed change %d, after an orientation change %d" % (
+        len(d), a.n_commands, time.time() - t0, float(d[:, 0].mean()), int((fail[:, 1] == 0).sum()), int((fail[:, 1] == 1).sum())))
+    return 0
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     if argv and argv[0] == "eval":
         return eval_main(argv[1:])
+    if argv and argv[0] == "eval_commands":
+        return eval_commands_main(argv[1:])
     if argv and argv[0] == "eval_perturb":
         return eval_perturb_main(argv[1:])
     if not argv or argv[0] != "ppo":

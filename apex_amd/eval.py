@@ -89,3 +89,77 @@ def compute_perturbs(actor, make_env, obs_mean=None, obs_std=None, wait_time=4.0
     first = np.where(fell.any(-1), fell.argmax(-1), n_sizes)            # index of the first failing size (n_sizes = never)
     max_force = (perturb_size + perturb_incr * first - perturb_incr).astype(np.float32)
     return max_force, fell
+
+
+def _yaw_unrotate_obs(obs, orient_add):
+    """The harness-side command rotation of tools/test_commands.py:94-107: pelvis quaternion obs[1:5] <- q_yaw^-1 * q (sign fixed to
+    w >= 0) and translational velocity obs[15:18] <- rotated by q_yaw^-1, on [N, 50] device tensors; orient_add [N]."""
+    c, s = torch.cos(0.5 * orient_add), torch.sin(0.5 * orient_add)          # q_yaw = (c, 0, 0, s); inverse = (c, 0, 0, -s)
+    w, x, y, z = obs[:, 1], obs[:, 2], obs[:, 3], obs[:, 4]
+    nw, nx, ny, nz = c * w + s * z, c * x + s * y, c * y - s * x, c * z - s * w
+    sign = torch.where(nw < 0, -torch.ones_like(nw), torch.ones_like(nw))
+    out = obs.clone()
+    out[:, 1], out[:, 2], out[:, 3], out[:, 4] = nw * sign, nx * sign, ny * sign, nz * sign
+    cy, sy = torch.cos(orient_add), torch.sin(orient_add)
+    vx, vy = obs[:, 15], obs[:, 16]
+    out[:, 15], out[:, 16] = cy * vx + sy * vy, -sy * vx + cy * vy            # R_z(-yaw) v
+    return out
+
+
+@torch.no_grad()
+def eval_commands(actor, make_env, obs_mean=None, obs_std=None, num_steps=200, num_commands=4, max_speed=3.0, min_speed=0.0,
+                  num_iters=256, seed=0):
+    """The reference's command-following test (tools/test_commands.py:56-122 `eval_worker.run_test`, :124-172 schedules) with every
+    iteration as one env of a lock-step batch: reset_for_test(full_reset=True), speed 0.5, then every `num_steps` steps a new speed
+    (previous +- U[0.4, 1.3], reflected into [min_speed, max_speed]) and, half a period later, a yaw command change of
+    +- U[pi/6, pi/3] applied to the policy input; failed when qpos[2] < 0.4.  Returns save_data [num_iters, 6] float32 numpy with the
+    reference's columns: passed, (-1 | 0 = failed in the half period after a speed change, 1 = after an orientation change), speed,
+    orient_add, last speed change, last orientation change.  Not reproduced: phase_add = 1.5 above 1.4 m/s (test_commands.py:87-90;
+    the phase counter of the kernel is an integer)."""
+    import numpy as np
+    n = ((num_iters + 63) // 64) * 64
+    env = make_env(n)
+    dev = env.device
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    U = lambda lo, hi, *shape: lo + (hi - lo) * torch.rand(*shape, device=dev, generator=g)
+    sign = lambda *shape: torch.where(torch.rand(*shape, device=dev, generator=g) < 0.5, -1.0, 1.0)
+    speeds = torch.zeros(n, num_commands, device=dev); speeds[:, 0] = 0.5
+    for i in range(num_commands - 1):
+        add = sign(n) * U(0.4, 1.3, n)
+        nxt = speeds[:, i] + add
+        add = torch.where((nxt < min_speed) | (nxt > max_speed), -add, add)
+        speeds[:, i + 1] = speeds[:, i] + add
+    orients = U(np.pi / 6, np.pi / 3, n, num_commands) * sign(n, num_commands)
+    fwd = (lambda o: actor.forward(o, obs_mean, obs_std)) if hasattr(actor, "forward") else actor
+    obs = env.reset_for_test(full_reset=True)
+    env.set_command(speed=0.5, side_speed=0.0)
+    orient_add = torch.zeros(n, device=dev); speed = torch.full((n,), 0.5, device=dev)
+    passed = torch.ones(n, dtype=torch.bool, device=dev)
+    data = torch.zeros(n, 6, device=dev)
+    count, speed_ind, orient_ind = 0, 1, 0
+    last_dspeed = torch.zeros(n, device=dev); last_dorient = torch.zeros(n, device=dev)
+    while not (speed_ind == num_commands and orient_ind == num_commands and count == num_steps):
+        if count == num_steps:
+            count = 0
+            new = speeds[:, speed_ind].clamp(min_speed, max_speed)
+            last_dspeed = new - speeds[:, max(0, speed_ind - 1)]
+            speed = new
+            env.set_command(speed=speed)
+            speed_ind += 1
+        elif count == num_steps // 2:
+            last_dorient = orients[:, orient_ind]
+            orient_add = orient_add + last_dorient
+            orient_ind += 1
+        obs, _, _, _ = env.step(fwd(_yaw_unrotate_obs(obs, orient_add)), auto_reset=False)
+        count += 1
+        fell = passed & (env.get_field("qpos")[:, 2] < 0.4)
+        if bool(fell.any()):
+            row = torch.stack([torch.zeros(n, device=dev), torch.full((n,), float(count // (num_steps // 2)), device=dev), speed, orient_add,
+                               last_dspeed, last_dorient], 1)
+            data = torch.where(fell.view(n, 1), row, data)
+            passed &= ~fell
+        if not bool(passed.any()):
+            break
+    ok = torch.zeros(n, 6, device=dev); ok[:, 0] = 1.0; ok[:, 1] = -1.0
+    data = torch.where(passed.view(n, 1), ok, data)
+    return data[:num_iters].cpu().numpy()

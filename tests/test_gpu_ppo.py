@@ -196,3 +196,34 @@ def test_compute_perturbs_batched(dev):
     first = np.where(fell.any(-1), fell.argmax(-1), 6)
     np.testing.assert_allclose(mf, 250.0 * first - 250.0)
     assert (mf >= 250).all() and (mf <= 1000).all()
+
+
+def test_eval_commands_batched(dev):
+    """tools/test_commands.py's schedule test as one batch.  (a) the harness-side yaw rotation of the policy input equals the env's own
+    orient_add rotation of the pelvis quaternion / velocity entries (cassie.py:280-291,822-835); (b) bookkeeping: with the PD-hold
+    "policy" every schedule fails within the first half period, and the failure rows carry speed 0.5, no orientation change."""
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd.eval import eval_commands, _yaw_unrotate_obs
+    env = CassieVecEnv(n_envs=64, max_traj_len=1000, dynamics_randomization=False, seed=3)
+    env.reset()
+    act = torch.randn(64, 10, device=dev) * 0.2
+    for _ in range(3):
+        env.step(act, auto_reset=False)
+    yaw = torch.linspace(-1.2, 1.2, 64, device=dev)
+    st = {k: env.get_field(k) for k in ("qpos", "qvel")}
+    env.set_command(orient_add=torch.zeros(64, device=dev))
+    o0, _, _, _ = env.step(act, auto_reset=False); o0 = o0.clone()
+    env.set_field("qpos", st["qpos"]); env.set_field("qvel", st["qvel"])          # (the estimator inputs are a function of the state)
+    rot = _yaw_unrotate_obs(o0, yaw)
+    from oracle import sim as OS
+    e = OS.OracleEnv(dyn_rand=False)
+    for i in (0, 13, 40, 63):                                                       # the oracle's rotate_to_orient is pinned by golden G8
+        e.set("orient_add", [float(yaw[i])]); e.set("so_quat", o0[i, 1:5].double().cpu().numpy()); e.set("so_tvel", o0[i, 15:18].double().cpu().numpy())
+        ob = e.obs()
+        np.testing.assert_allclose(rot[i, 1:5].cpu().numpy(), ob[1:5], atol=2e-6)
+        np.testing.assert_allclose(rot[i, 15:18].cpu().numpy(), ob[15:18], atol=2e-6)
+    mk = lambda n: CassieVecEnv(n_envs=n, max_traj_len=100000, dynamics_randomization=False)
+    stand = lambda o: torch.zeros(o.shape[0], 10, device=o.device)
+    d = eval_commands(stand, mk, num_steps=200, num_commands=3, num_iters=64)
+    assert d.shape == (64, 6) and (d[:, 0] == 0).all() and (d[:, 1] == 0).all()
+    np.testing.assert_allclose(d[:, 2], 0.5); assert (d[:, 3] == 0).all() and (d[:, 5] == 0).all()
