@@ -957,20 +957,30 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
         sfor<0, 2>([&](auto Lg) { sfor<0, 7>([&](auto Sx) { ef[Lg][Sx] = 0.f; }); });
         sfor<0, NCS>([&](auto Sl) { sfor<0, 4>([&](auto K) { cf[Sl][K] = 0.f; }); });
     }
-    float eb[2][6];
-    sfor<0, 2>([&](auto Lg) { sfor<0, 6>([&](auto Sx) { eb[Lg][Sx] = ec[Lg][Sx]; }); });
-    sfor<0, 2>([&](auto Lg) { sfor<0, 7>([&](auto Sx) { ec[Lg][Sx] += eR[Lg][Sx] * ef[Lg][Sx]; }); });      // c = b + R f
     PROF(6);
     // ---- sweeps.  Packed fp32 (v_pk_fma_f32) wherever two independent updates share the multiplier: (rho_A, rho_B), the
     // running (n, active tangent) residuals of a pyramid, and its (sum df, sum +-mu df) accumulators.
+    // The regulariser of the equality / limit rows rides on the Gram diagonal: the sweep carries rho' = rho + R f on the row's own
+    // lane (G'[s][s] = G[s][s] + R_s), so a row's residual is rho'_s + b_s with b constant and no per-row bookkeeping of c = b + R f
+    // is left in the loop; the coefficient f_s itself is accumulated on its own lane only (one fma that fills the DPP hazard slot).
     typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 r = {rA, rB};
-    f2 Gp[2][13];                                           // how a coefficient of leg L's basis s moves (rho_A, rho_B)
-    sfor<0, 13>([&](auto Sx) { Gp[0][Sx] = f2{GAA[Sx], GBA[Sx]}; Gp[1][Sx] = f2{GAB[Sx], GBB[Sx]}; });
+    const float f0A = l < 7 ? (cost > 0.f ? 0.f : A.f) : 0.f, f0B = l < 7 ? (cost > 0.f ? 0.f : B.f) : 0.f;      // this lane's own coefficients
+    f2 r = {rA + (l < 7 ? A.R * f0A : 0.f), rB + (l < 7 ? B.R * f0B : 0.f)};
+    f2 Gp[2][13];                                           // how a coefficient of leg L's basis s moves (rho'_A, rho'_B)
+    sfor<0, 13>([&](auto Sx) {
+        constexpr int s = Sx;
+        Gp[0][s] = f2{GAA[s] + ((s < 7 && l == s) ? A.R : 0.f), GBA[s]};
+        Gp[1][s] = f2{GAB[s], GBB[s] + ((s < 7 && l == s) ? B.R : 0.f)};
+    });
+    float tsum[2][6];                                       // sum over the sweeps of a row's residual: f_s = f0_s - sum_it t_s / (A_ss + R_s)
+    sfor<0, 2>([&](auto Lg) { sfor<0, 6>([&](auto Sx) { tsum[Lg][Sx] = 0.f; }); });
+    // pyramid row k of slot s: f <- max(alpha f + beta - iA (r_n + sm r_t), 0) with alpha = 1 - iA R, beta = -iA b (one fma off the chain)
+    float calpha[NCS][4], cbeta[NCS][4];
     f2 kk[NCS][4]; float ko[NCS][4];                        // row k moves (r_n, r_active) by kk df and the other tangent's residual by ko df
     sfor<0, NCS>([&](auto Sl) { sfor<0, 4>([&](auto K) {
         constexpr int k = K;
         kk[Sl][k] = f2{kn[Sl][k], k < 2 ? k1[Sl][k] : k2[Sl][k]}; ko[Sl][k] = k < 2 ? k2[Sl][k] : k1[Sl][k];
+        calpha[Sl][k] = 1.f - ciA[Sl][k] * cR[Sl]; cbeta[Sl][k] = -ciA[Sl][k] * cb[Sl][k];
     }); });
     const f2 cplus = {1.f, mu}, cminus = {1.f, -mu};
     for (int it = 0; it < pgs_iters; ++it) {
@@ -978,16 +988,16 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
             constexpr int leg = Lg;
             sfor<0, 6>([&](auto Sx) {
                 constexpr int s = Sx;
-                const float t = (leg ? dpp<0x150 + s>(r.y) : dpp<0x150 + s>(r.x)) + ec[leg][s];
+                const float t = (leg ? dpp<0x150 + s>(r.y) : dpp<0x150 + s>(r.x)) + ec[leg][s];      // ec = b here (never updated)
                 const float df = -t * eiA[leg][s];
-                ec[leg][s] += eR[leg][s] * df;                  // f itself is recovered from c = b + R f after the sweeps
                 r += Gp[leg][s] * df;
+                tsum[leg][s] += t;
             });
             if (nlim[leg]) {
                 const float t = (leg ? dpp<0x150 + 6>(r.y) : dpp<0x150 + 6>(r.x)) + ec[leg][6];
                 const float fn = fmaxf(ef[leg][6] - t * eiA[leg][6], 0.f);
                 const float df = fn - ef[leg][6];
-                ef[leg][6] = fn; ec[leg][6] += eR[leg][6] * df;
+                ef[leg][6] = fn;
                 r += Gp[leg][6] * df;
             }
             sfor<0, MAXC>([&](auto Sl) {
@@ -1002,8 +1012,10 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
                         constexpr int k = K;
                         if constexpr (k == 2) { const float t1 = pr.y; pr.y = ro; ro = t1; }      // now (r_n, r_t2), other = r_t1
                         const float sm = (k & 1) ? -mu : mu;
-                        const float res = cb[s][k] + cR[s] * cf[s][k] + pr.x + sm * pr.y;
-                        const float fn = fmaxf(cf[s][k] - res * ciA[s][k], 0.f);
+                        float w = calpha[s][k] * cf[s][k] + cbeta[s][k];
+                        asm volatile("" : "+v"(w));                 // keep the off-chain fma: fast-math would re-associate it back into the chain
+                        const float u = pr.x + sm * pr.y;
+                        const float fn = fmaxf(w - ciA[s][k] * u, 0.f);
                         const float df = fn - cf[s][k];
                         cf[s][k] = fn;
                         pr += kk[s][k] * df; ro += ko[s][k] * df;
@@ -1018,9 +1030,9 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     rA = r.x; rB = r.y;
     PROF(7);
     // ---- z~ = sum_r y~_r F_r back to the dof layout of the finish stage
-    sfor<0, 2>([&](auto Lg) { sfor<0, 6>([&](auto Sx) { ef[Lg][Sx] = (ec[Lg][Sx] - eb[Lg][Sx]) * rcpf(eR[Lg][Sx]); }); });
-    float ownA = 0.f, ownB = 0.f;
-    sfor<0, 7>([&](auto Sx) { if (l == Sx) { ownA = ef[0][Sx]; ownB = ef[1][Sx]; } });
+    float ownA = 0.f, ownB = 0.f;                           // lanes 0..5: f0 - iA sum t; the limit lane's f is uniform (ef[.][6])
+    sfor<0, 6>([&](auto Sx) { if (l == Sx) { ownA = f0A - eiA[0][Sx] * tsum[0][Sx]; ownB = f0B - eiA[1][Sx] * tsum[1][Sx]; } });
+    if (l == 6) { ownA = ef[0][6]; ownB = ef[1][6]; }
     sfor<0, NCS>([&](auto Sl) {
         constexpr int s = Sl, leg = s / MAXC, ln = 7 + 3 * (s % MAXC);
         const float dn = cf[s][0] + cf[s][1] + cf[s][2] + cf[s][3], d1 = mu * (cf[s][0] - cf[s][1]), d2 = mu * (cf[s][2] - cf[s][3]);
