@@ -594,6 +594,10 @@ __device__ __forceinline__ void stage_finish_lane(const St& S, const float* rows
         sfor<0, 4>([&](auto K) { S(F_SNAP + SN_QUAT + K) = S(F_QPOS + 3 + K); });
         sfor<0, 3>([&](auto K) { S(F_SNAP + SN_GYRO + K) = S(F_QVEL + 3 + K); S(F_SNAP + SN_VEL + K) = S(F_QVEL + K); });
         S(F_SNAP + SN_PZ) = S(F_QPOS + 2);
+        {   // lowest world z of the two foot soles (foot capsule end centre - radius), same pre-integration kinematics as the rest
+            const float zl = fminf(S.W(WK_PTS + 14), S.W(WK_PTS + 17)) - ct_geom_radius[0], zr = fminf(S.W(WK_PTS + 44), S.W(WK_PTS + 47)) - ct_geom_radius[1];
+            S(F_EST + 1) = fminf(zl, zr);
+        }
         {   // world z of the contact force on the foot bodies (cassie_sim_foot_forces -> get_foot_forces()[2], [8])
             const int nc[2] = {(int)S.W(WK_MISC + 0), (int)S.W(WK_MISC + 1)};
             const float mu = S(F_FRIC), nz = S(F_FLOOR + 2), t1z = S(F_FLOOR + 5), t2z = S(F_FLOOR + 8);

@@ -134,13 +134,13 @@ __device__ __noinline__ void stage1_io_tree(St S, int mode) {
         const Q4 q = {S(F_SNAP + SN_QUAT), S(F_SNAP + SN_QUAT + 1), S(F_SNAP + SN_QUAT + 2), S(F_SNAP + SN_QUAT + 3)};
         _Pragma("unroll") for (int k = 0; k < 4; ++k) S(F_SO + SO_QUAT + k) = S(F_SNAP + SN_QUAT + k);
         _Pragma("unroll") for (int k = 0; k < 3; ++k) { S(F_SO + SO_ROTVEL + k) = S(F_SNAP + SN_GYRO + k); S(F_SO + SO_TVEL + k) = S(F_SNAP + SN_VEL + k); }
-        // estimator-lite (golden G11): pelvis-frame specific force minus gravity, pelvis-frame velocity, z - 0.0818
+        // estimator-lite (goldens G11, G11c): pelvis-frame specific force minus gravity, pelvis-frame velocity, z - low-passed lowest sole height
         const M3 R = q2m(q);
         S(F_SO + SO_TACC) = S(F_SNAP + SN_ACC) - R.m[6] * GRAV; S(F_SO + SO_TACC + 1) = S(F_SNAP + SN_ACC + 1) - R.m[7] * GRAV;
         S(F_SO + SO_TACC + 2) = S(F_SNAP + SN_ACC + 2) - R.m[8] * GRAV;
         const V3 vw = {S(F_SNAP + SN_VEL), S(F_SNAP + SN_VEL + 1), S(F_SNAP + SN_VEL + 2)};
         S(F_SO + SO_TVEL) = dot(col(R, 0), vw); S(F_SO + SO_TVEL + 1) = dot(col(R, 1), vw); S(F_SO + SO_TVEL + 2) = dot(col(R, 2), vw);
-        S(F_SO + SO_HEIGHT) = S(F_SNAP + SN_PZ) - 0.0818f;
+        { const float L = S(F_EST) + EST_ALPHA * (S(F_EST + 1) - S(F_EST)); S(F_EST) = L; S(F_SO + SO_HEIGHT) = S(F_SNAP + SN_PZ) - L; }      // golden G11c
     }
     }
     PROF(0);
@@ -232,7 +232,7 @@ __device__ __forceinline__ void stage1_io_lane(St S, int mode) {   // (as a call
         S(F_SO + SO_TACC + 2) = S(F_SNAP + SN_ACC + 2) - R.m[8] * GRAV;
         const V3 vw = {S(F_SNAP + SN_VEL), S(F_SNAP + SN_VEL + 1), S(F_SNAP + SN_VEL + 2)};
         S(F_SO + SO_TVEL) = dot(col(R, 0), vw); S(F_SO + SO_TVEL + 1) = dot(col(R, 1), vw); S(F_SO + SO_TVEL + 2) = dot(col(R, 2), vw);
-        S(F_SO + SO_HEIGHT) = S(F_SNAP + SN_PZ) - 0.0818f;
+        { const float L = S(F_EST) + EST_ALPHA * (S(F_EST + 1) - S(F_EST)); S(F_EST) = L; S(F_SO + SO_HEIGHT) = S(F_SNAP + SN_PZ) - L; }      // golden G11c
     }
     PROF(0);
 }
@@ -620,6 +620,7 @@ __global__ __launch_bounds__(64) void env_init_kernel(float* st, int* ist, int n
     auto G = [&](int f) -> float& { return st[(size_t)f * n + env]; };
     for (int f = 0; f < F_TOTAL; ++f) G(f) = 0.f;
     for (int f = 0; f < I_TOTAL; ++f) ist[(size_t)f * n + env] = 0;
+    G(F_EST) = EST_L0; G(F_EST + 1) = EST_L0;                     // state_output_setup
     for (int i = 0; i < NQ; ++i) G(F_QPOS + i) = cm_init_qpos[i];
     for (int b = 0; b < NB; ++b) G(F_MASS + b) = cm_body_mass[b];
     for (int d = 0; d < NV; ++d) G(F_DAMP + d) = cm_dof_damping[d];
@@ -749,6 +750,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_for_test_kerne
             S(F_SO + SO_QUAT) = 1.f;
             for (int k = 0; k < 3; ++k) { S(F_SO + SO_QUAT + 1 + k) = 0.f; S(F_SO + SO_ROTVEL + k) = 0.f; S(F_SO + SO_TVEL + k) = 0.f; S(F_SO + SO_TACC + k) = 0.f; }
             S(F_SO + SO_HEIGHT) = 1.01f;                                         // pelvis.position[2] = 1.01, terrain.height = 0
+            S(F_EST) = EST_L0;                                                   // state_output_setup: the height filter restarts
         }
         c4::wsync();
     } else {
@@ -1048,7 +1050,7 @@ static const FieldDesc kFields[] = {
     {"so_mpos", F_SO + SO_MPOS, 10}, {"so_mvel", F_SO + SO_MVEL, 10}, {"so_torque", F_SO + SO_TORQUE, 10},
     {"so_jpos", F_SO + SO_JPOS, 6}, {"so_jvel", F_SO + SO_JVEL, 6}, {"so_quat", F_SO + SO_QUAT, 4},
     {"so_rotvel", F_SO + SO_ROTVEL, 3}, {"so_tvel", F_SO + SO_TVEL, 3}, {"so_tacc", F_SO + SO_TACC, 3}, {"so_height", F_SO + SO_HEIGHT, 1},
-    {"foot_vel", F_FOOTVEL, 6}, {"prev_action", F_PREVACT, 10}, {"prev_torque", F_PREVTQ, 10}, {"cmd", F_CMD, 6}, {"fwd", F_FWD, 16}, {"xfrc", F_XFRC, 6},
+    {"foot_vel", F_FOOTVEL, 6}, {"prev_action", F_PREVACT, 10}, {"prev_torque", F_PREVTQ, 10}, {"cmd", F_CMD, 6}, {"fwd", F_FWD, 16}, {"xfrc", F_XFRC, 6}, {"est", F_EST, 2},
 };
 
 static const FieldDesc* find_field(const char* name) {

@@ -14,7 +14,8 @@ enum Field : int {
     F_FOOTVEL = F_FOOTPREV + 6, F_PREVACT = F_FOOTVEL + 6, F_PREVTQ = F_PREVACT + 10,
     F_CMD = F_PREVTQ + 10 /* speed side orient swing stance phaselen */, F_FWD = F_CMD + 6 /* foot force z L,R; foot quat L4 R4; foot pos 6 */,
     F_XFRC = F_FWD + 16 /* external wrench on the pelvis, world frame: force xyz, torque xyz (mjData.xfrc_applied row of cassie-pelvis) */,
-    F_TOTAL = F_XFRC + 6
+    F_EST = F_XFRC + 6 /* height filter of the state estimator: [0] L = low-passed lowest sole height, [1] lowest sole world z of the last forward pass */,
+    F_TOTAL = F_EST + 2
 };
 enum SnapOff { SN_MPOS = 0, SN_JPOS = 10, SN_QUAT = 16, SN_GYRO = 20, SN_ACC = 23, SN_VEL = 26, SN_PZ = 29 };
 enum SoOff { SO_MPOS = 0, SO_MVEL = 10, SO_TORQUE = 20, SO_JPOS = 30, SO_JVEL = 36, SO_QUAT = 42, SO_ROTVEL = 46, SO_TVEL = 49, SO_TACC = 52, SO_HEIGHT = 55 };
@@ -39,7 +40,7 @@ struct apx_env {
 typedef __attribute__((address_space(1))) float gfloat;
 typedef __attribute__((address_space(1))) int gint;
 #if APX_GEN == 4
-// Per-env LDS region (floats): [0,583) state fields | [584,589) int fields | [L4_WK, +WK_TOTAL) stage hand-off |
+// Per-env LDS region (floats): [0,585) state fields | [586,591) int fields | [L4_WK, +WK_TOTAL) stage hand-off |
 // [L4_ROWS, +632) constraint-row store (158 float4 chunks).  Stride L4_ES = 16 (mod 64): the four envs of a wave sit
 // on disjoint LDS bank groups, so a 16-lane access with consecutive addresses is conflict-free.
 typedef __attribute__((address_space(3))) float lfloat;
@@ -47,7 +48,7 @@ typedef __attribute__((address_space(3))) int lint;
 #ifndef APX_L4_EPW
 #define APX_L4_EPW 4
 #endif
-constexpr int L4_INT = 584, L4_WK = 592, L4_ROWS = 1664, L4_ES = 2384, L4_EPW = APX_L4_EPW;      // envs per wave (16 lanes each)
+constexpr int L4_INT = 586, L4_WK = 592, L4_ROWS = 1664, L4_ES = 2384, L4_EPW = APX_L4_EPW;      // envs per wave (16 lanes each)
 static_assert(F_TOTAL <= L4_INT && L4_INT + I_TOTAL <= L4_WK, "LDS state region");
 struct St {
     lfloat* p; int env;
@@ -67,6 +68,8 @@ __device__ __forceinline__ St make_st(float* st, int* ist, int n, int env, float
 }
 #endif
 
+// state estimator height model (golden G11c): height = z - L, L' = (lowest sole z - L) / EST_TAU, L = EST_L0 after state_output_setup
+constexpr float EST_TAU = 0.86f, EST_L0 = 0.126f, EST_ALPHA = 0.0005f / EST_TAU;
 struct Cfg { int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; int reward_kind; };
 
 // ------------------------------------------------------------------------------------------------ Philox4x32-10

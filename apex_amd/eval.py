@@ -10,7 +10,7 @@ def evaluate(actor, env, obs_mean=None, obs_std=None, speed=None, side_speed=0.0
 
     basic=False: training semantics (CassieEnv.step: reward, termination, command resampling) from CassieEnv.reset_for_test
     (+ update_speed when `speed` is given).  basic=True: CassieEnv.step_basic at the fixed command (no reward, no resampling);
-    an env counts as fallen when the estimated pelvis height obs[0] + 0.0818 drops below 0.4 m (cassie.py:462's threshold).
+    an env counts as fallen when the pelvis height qpos[2] drops below 0.4 m (cassie.py:462's threshold, as the harnesses test it).
     Returns dict(returns [N] (zeros when basic), lengths [N], terminated [N] bool, truncated [N] bool)."""
     n = env.n_envs
     max_steps = max_steps or env.max_traj_len
@@ -25,7 +25,7 @@ def evaluate(actor, env, obs_mean=None, obs_std=None, speed=None, side_speed=0.0
     for t in range(max_steps):
         if basic:
             obs = env.step_basic(fwd(obs))
-            fell = (obs[:, 0] + 0.0818) < 0.4
+            fell = env.get_field("qpos")[:, 2] < 0.4
             length += alive.float()
             term |= alive & fell
             alive &= ~fell

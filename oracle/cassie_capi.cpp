@@ -48,6 +48,15 @@ double orc_total_energy(void* h) { static thread_local Work w; Env& e = *(Env*)h
 
 #define FIELD(nm, ptr, cnt) if (!std::strcmp(name, nm)) { if (set) std::memcpy((void*)(ptr), io, sizeof(double) * (cnt)); else std::memcpy(io, (ptr), sizeof(double) * (cnt)); return cnt; }
 static int field(Env& e, const char* name, double* io, bool set) {
+    if (!set && !std::strcmp(name, "foot_low")) {      // per leg: world z of the foot body origin, lowest world z of the foot capsule (end centre - radius)
+        for (int leg = 0; leg < 2; ++leg) {
+            const int g = leg, b = cm_geom_body[g];
+            const V3 c = e.st.xpos[b] + mul(e.st.xmat[b], v3(cm_geom_pos + 3 * g)), ax = mul(e.st.xmat[b], v3(cm_geom_axis + 3 * g));
+            const double z0 = (c + ax * cm_geom_half[g]).z, z1 = (c - ax * cm_geom_half[g]).z;
+            io[2 * leg] = e.st.xpos[b].z; io[2 * leg + 1] = std::min(z0, z1) - cm_geom_radius[g];
+        }
+        return 4;
+    }
     FIELD("qpos", e.st.qpos, NQ) FIELD("qvel", e.st.qvel, NV) FIELD("qacc", e.st.qacc, NV) FIELD("qacc_warm", e.st.qacc_warm, NV)
     FIELD("mass", e.par.mass, NB) FIELD("damping", e.par.damping, NV) FIELD("friction", &e.par.friction, 1)
     FIELD("floor_quat", &e.par.floor_quat, 4) FIELD("body_invweight0", e.par.body_invweight0, 2 * NB)
@@ -58,7 +67,7 @@ static int field(Env& e, const char* name, double* io, bool set) {
     FIELD("speed", &e.speed, 1) FIELD("side_speed", &e.side_speed, 1) FIELD("orient_add", &e.orient_add, 1)
     FIELD("so_mpos", e.so_mpos, 10) FIELD("so_mvel", e.so_mvel, 10) FIELD("so_torque", e.so_torque, 10)
     FIELD("so_jpos", e.so_jpos, 6) FIELD("so_jvel", e.so_jvel, 6) FIELD("so_quat", e.so_quat, 4)
-    FIELD("so_rotvel", e.so_rotvel, 3) FIELD("so_tvel", e.so_tvel, 3) FIELD("so_tacc", e.so_tacc, 3) FIELD("so_height", &e.so_height, 1)
+    FIELD("so_rotvel", e.so_rotvel, 3) FIELD("so_tvel", e.so_tvel, 3) FIELD("so_tacc", e.so_tacc, 3) FIELD("so_height", &e.so_height, 1) FIELD("est_L", &e.est_L, 1) FIELD("snap_sole", &e.snap_sole, 1) FIELD("snap_pz", &e.snap_pz, 1)
     FIELD("snap_acc", e.snap_acc, 3) FIELD("snap_gyro", e.snap_gyro, 3) FIELD("snap_quat", e.snap_quat, 4)
     FIELD("snap_mpos", e.snap_mpos, 10) FIELD("snap_jpos", e.snap_jpos, 6)
     FIELD("l_foot_vel", e.l_foot_vel, 3) FIELD("r_foot_vel", e.r_foot_vel, 3)

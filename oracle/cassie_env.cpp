@@ -140,6 +140,12 @@ static void forward_snapshot(Env& e, Work& w, const double* ctrl) {
     for (int k = 0; k < 4; ++k) e.snap_quat[k] = s.qpos[3 + k];
     for (int k = 0; k < 3; ++k) { e.snap_gyro[k] = s.sens_gyro[k]; e.snap_acc[k] = s.sens_acc[k]; e.snap_vel[k] = s.qvel[k]; }
     e.snap_pz = s.qpos[2];
+    e.snap_sole = 1e9;
+    for (int g = 0; g < 2; ++g) {            // foot capsules (geoms 0, 1)
+        const int b = cm_geom_body[g];
+        const V3 c = s.xpos[b] + mul(s.xmat[b], v3(cm_geom_pos + 3 * g)), ax = mul(s.xmat[b], v3(cm_geom_axis + 3 * g));
+        e.snap_sole = std::min(e.snap_sole, std::min((c + ax * cm_geom_half[g]).z, (c - ax * cm_geom_half[g]).z) - cm_geom_radius[g]);
+    }
 }
 
 static void foot_positions(const State& s, double* fp) {   // cassie_sim_foot_positions
@@ -181,13 +187,17 @@ void sim_step_pd(Env& e) {
     {
         // estimator-lite, chosen by pushing this simulator's sensor stream through the reference's state_output_step
         // (tools/refprobe/probe_estimator.py, golden G11): acceleration = specific force minus gravity in the PELVIS frame,
-        // velocity in the pelvis frame, height = pelvis z - 0.0818 (the filter's foot-referenced height)
+        // velocity in the pelvis frame
         const M3 R = q2m(Q4{e.snap_quat[0], e.snap_quat[1], e.snap_quat[2], e.snap_quat[3]});
         const V3 gb = {R.m[6] * GRAV, R.m[7] * GRAV, R.m[8] * GRAV};                       // R^T (0,0,g)
         e.so_tacc[0] = e.snap_acc[0] - gb.x; e.so_tacc[1] = e.snap_acc[1] - gb.y; e.so_tacc[2] = e.snap_acc[2] - gb.z;
         const V3 vw = {e.snap_vel[0], e.snap_vel[1], e.snap_vel[2]};
         e.so_tvel[0] = dot(col(R, 0), vw); e.so_tvel[1] = dot(col(R, 1), vw); e.so_tvel[2] = dot(col(R, 2), vw);
-        e.so_height = e.snap_pz - 0.0818;
+        // height = pelvis.position[2] - terrain.height of the reference filter, reproduced to < 1 cm on a 3 s walking stream by
+        // z - L with L a first-order low-pass (0.86 s) of the lowest sole height, L = 0.126 right after state_output_setup (golden
+        // G11c); the filter state persists across episodes exactly like the reference's estimator object
+        e.est_L += 0.0005 / EST_TAU * (e.snap_sole - e.est_L);
+        e.so_height = e.snap_pz - e.est_L;
     }
     // --- pd_input_step: tau = P (pTarget - q) + D (dTarget - qd), no clamp (PdInput.h; SURVEY §2.2 bit-exact probe)
     double tau[10], ctrl[10];
@@ -246,6 +256,7 @@ void env_obs(const Env& e, double* o) {
 void env_init(Env& e, const EnvCfg& cfg, uint32_t env_id) {
     std::memset(&e, 0, sizeof(e));
     e.cfg = cfg;
+    e.est_L = EST_L0; e.snap_sole = EST_L0;            // state_output_setup
     default_params(e.par);
     e.par.pgs_iters = cfg.pgs_iters;
     e.rng = Philox{(uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), env_id, 0};
@@ -315,6 +326,7 @@ void env_reset_for_test(Env& e, double* obs, bool full_reset) {
         e.so_quat[0] = 1; e.so_quat[1] = e.so_quat[2] = e.so_quat[3] = 0;
         for (int k = 0; k < 3; ++k) e.so_rotvel[k] = e.so_tvel[k] = e.so_tacc[k] = 0;
         e.so_height = 1.01;
+        e.est_L = EST_L0;                                 // state_output_setup
     }
     if (e.cfg.dynamics_randomization) {
         const int iters = e.par.pgs_iters;

@@ -374,6 +374,11 @@ def test_full_reset_and_apply_force_vs_oracle(dev, golden_dir):
             np.testing.assert_allclose(qp[i, :3], e.get("qpos")[:3], atol=2e-3 * sc, err_msg="pelvis position env %d step %d" % (i, t))
             np.testing.assert_allclose(qv[i, :3], e.get("qvel")[:3], atol=3e-2 * sc, err_msg="pelvis velocity env %d step %d" % (i, t))
             assert np.all(np.abs(obs[i] - o) <= tol * sc + 5e-3 * np.abs(o)), ("env %d step %d" % (i, t), np.abs(obs[i] - o).max())
+    # the estimator's height filter (golden G11c): restarted by the full reset, then 10 env steps = 500 updates in both implementations
+    est = genv.get_field("est").cpu().numpy()
+    for i, e in enumerate(oenv[:K]):
+        assert abs(est[i, 0] - e.get("est_L")[0]) < 2e-4 and abs(est[i, 1] - e.get("snap_sole")[0]) < 3e-3 * 10, (i, est[i], e.get("est_L"), e.get("snap_sole"))
+    assert 0.09 < est[:, 0].mean() < 0.126                                  # relaxing from 0.126 towards the sole height (~0)
     # the push actually moved the robots apart: lateral pelvis velocity follows the direction of the wrench
     vy = genv.get_field("qvel").cpu().numpy()[:, 1]
     assert np.corrcoef(vy[:64], xfrc[:64, 1])[0, 1] > 0.5

@@ -319,11 +319,45 @@ def test_g16_step_basic_bookkeeping(golden_dir):
     assert np.all(np.isfinite(obs))
 
 
+def test_g11c_estimator_height_model(golden_dir):
+    """G11c: the reference filter's height output (pelvis.position[2] - terrain.height, observation entry 0) on our sensor stream while
+    the policy of trained_models/r01_cassie_v0_clock walks for 3 s (6000 substeps of 2 kHz), with the true pelvis z and the lowest sole
+    height per substep (tools/refprobe/gen_golden_estheight.py).  The build's model, height = z - L with L a first-order low-pass
+    (EST_TAU) of the lowest sole height started at EST_L0 by state_output_setup, stays within 1.2 cm of the reference over the whole
+    stream (the former constant offset z - 0.0818 is off by up to 8.4 cm on it); the oracle env implements exactly this recursion."""
+    g = np.load(os.path.join(golden_dir, "g11c_estimator_height.npz"))
+    z, sole, ref = g["z"].astype(np.float64), g["sole_low"].astype(np.float64), g["ref_height"].astype(np.float64)
+    tau, L0 = 0.86, 0.126
+    L = L0; err = np.zeros(len(z))
+    for i in range(len(z)):
+        L += 0.0005 / tau * (sole[i] - L)
+        err[i] = z[i] - L - ref[i]
+    assert np.abs(err[10:]).max() < 0.012 and np.abs(err[10:]).mean() < 0.008          # first 10 substeps: the filter's own start-up
+    assert np.abs(z - 0.0818 - ref)[10:].max() > 0.08                                   # what the constant offset did on this stream
+    e = S.OracleEnv(dyn_rand=False, seed=1)
+    assert e.get("est_L")[0] == L0
+    e.reset()
+    rng = np.random.RandomState(0)
+    for t in range(3):
+        e.set("pd_target", rng.randn(10) * 0.1 + np.array([0.0045, 0, 0.4973, -1.1997, -1.5968] * 2))
+        for sub in range(20):
+            L_old, sole_old, z_old = e.get("est_L")[0], e.get("snap_sole")[0], e.get("snap_pz")[0]
+            e.substep()
+            L_new = L_old + 0.0005 / tau * (sole_old - L_old)
+            assert abs(e.get("est_L")[0] - L_new) < 1e-15 and abs(e.get("so_height")[0] - (z_old - L_new)) < 1e-15
+    assert -0.02 < e.get("snap_sole")[0] < 0.2
+    L_before = e.get("est_L")[0]
+    e.reset()                                                                            # a training reset keeps the filter state
+    assert abs(e.get("est_L")[0] - L_before) < 0.01 * abs(L_before) + 1e-3
+    e.reset_for_test(full_reset=True)                                                    # state_output_setup restarts it
+    assert e.get("est_L")[0] == L0
+
+
 def test_g11b_estimator_lite_on_a_walking_stream(golden_dir):
     """G11b: the reference's state_output_step on our sensor stream while a TRAINED policy stands / steps for 200 env steps
-    (tools/refprobe/probe_estimator_walk.py).  Velocity and acceleration frames hold on this stream too.  The height entry
-    documents a KNOWN GAP: once the feet are on the ground the reference filter's terrain estimate converges (time constant
-    about 1.1 s) and its height tends to the pelvis z itself, while estimator-lite keeps the airborne offset 0.0818."""
+    (tools/refprobe/probe_estimator_walk.py).  Velocity and acceleration frames hold on this stream too.  The height entry shows
+    why a constant offset is not enough: once the feet are on the ground the reference filter's terrain estimate converges (time
+    constant about 1 s) and its height tends to the pelvis z itself; the height model that follows this is pinned by G11c."""
     g = np.load(os.path.join(golden_dir, "g11b_estimator_walk.npz"))
     def q2m(q):
         w, x, y, z = q
@@ -337,4 +371,4 @@ def test_g11b_estimator_lite_on_a_walking_stream(golden_dir):
     assert np.abs(tvel[:, :2] - g["ref_tvel"][:, :2]).mean(0).max() < 0.08
     d = g["z"] - g["ref_height"]
     assert abs(d[120:].mean()) < 0.02 and d[0] > 0.08                  # reference: offset decays to ~0 on the ground
-    assert np.abs(g["z"] - 0.0818 - g["ref_height"]).mean() < 0.09     # estimator-lite: constant offset (the documented gap)
+    assert np.abs(g["z"] - 0.0818 - g["ref_height"]).mean() < 0.09     # a constant offset is off by centimetres here (see G11c)
