@@ -118,19 +118,31 @@ class _ToyVecEnv:
         nxt.copy_(self._obs())
 
 
+def test_kl_early_stop_golden_g15c(dev, golden_dir):
+    """G15c: the same whole-loop replay with lr = 1.2e-2 and 64-unit nets (unfused GEMM path): the reference stops iteration 0 after
+    ONE epoch (KL of the last minibatch 0.046 > 0.02, ppo.py:449) and runs all three epochs of iteration 1 (0.010, 0.008 below the
+    threshold).  The build must take the same decisions; the scalars agree to a few percent (each Adam step moves a weight by
+    +-1.2e-2, so a sign tie at g ~ 0 is visible at this learning rate)."""
+    _replay_train_golden(dev, golden_dir, "g15c_ppo_train_earlystop.npz", strict=False)
+
+
 def test_whole_train_loop_golden_g15b(dev, golden_dir):
     """G15b: the reference's whole PPO.train (3 iterations: sample -> returns -> normalised advantages -> 3 epochs x 7 random
     minibatches with the mirror loss -> Adam/clip) on a toy env, replayed through the build's driver + HIP learner with the
     captured noise / minibatch-order streams.  Episode indices bit-exact; values, returns, advantages' inputs, every
     minibatch's six scalars and the parameters after each iteration within the north-star tolerance."""
+    _replay_train_golden(dev, golden_dir, "g15b_ppo_train.npz")
+
+
+def _replay_train_golden(dev, golden_dir, fname, strict=True):
     import os
     from apex_amd.ppo import PPO
     from rl.policies.actor import Gaussian_FF_Actor
     from rl.policies.critic import FF_V
-    g = np.load(os.path.join(golden_dir, "g15b_ppo_train.npz"))
+    g = np.load(os.path.join(golden_dir, fname))
     H, mb = int(g["hidden"]), int(g["minibatch"])
     env = _ToyVecEnv(dev, g["lens"], g["max_traj_len"])
-    args = dict(gamma=float(g["gamma"]), lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=mb,
+    args = dict(gamma=float(g["gamma"]), lam=0.95, lr=float(g["lr"]) if "lr" in g.files else 1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=mb,
                 epochs=int(g["epochs"]), num_steps=int(g["num_steps"]), max_traj_len=int(g["max_traj_len"]), max_grad_norm=0.05,
                 mirror=True, std_dev=-1.5, seed=0)
     algo = PPO(args, "/tmp/apx_test_unused", env, rank=0, world_size=1, group=None, hidden=H)
@@ -153,29 +165,35 @@ def test_whole_train_loop_golden_g15b(dev, golden_dir):
         algo.trace = []
         algo.obs = None; algo.ep_ret.zero_(); algo.ep_len.zero_()
         ret, ep_rets, ep_lens = algo.sample()
+        loose = (not strict) and it > 0          # after a high-learning-rate iteration the two parameter sets differ visibly
+        tol = (lambda r, a: dict(rtol=5e-2, atol=5e-2)) if loose else (lambda r, a: dict(rtol=r, atol=a))
         # --- sample: episode-step indices bit-exact, data within fp32 round-off of the reference's buffer
         ends = np.nonzero(algo.b_end.view(-1).cpu().numpy())[0] + 1
         assert np.array_equal(ends, g[p + "traj_idx"][1:])
         assert np.array_equal(ep_lens.cpu().numpy().astype(np.int64), g[p + "ep_lens"])
-        np.testing.assert_allclose(ep_rets.cpu().numpy(), g[p + "ep_returns"], rtol=2e-6)
-        np.testing.assert_allclose(algo.b_obs.view(B, 50).cpu().numpy(), g[p + "states"], rtol=1e-5, atol=2e-6)
-        np.testing.assert_allclose(algo.b_act.view(B, 10).cpu().numpy(), g[p + "actions"], rtol=1e-5, atol=5e-6)
-        np.testing.assert_allclose(algo.b_rew.view(B).cpu().numpy(), g[p + "rewards"], rtol=2e-6)
-        np.testing.assert_allclose(algo.b_val.view(B).cpu().numpy(), g[p + "values"], rtol=1e-5, atol=1e-5)
-        np.testing.assert_allclose(ret.view(B).cpu().numpy(), g[p + "returns"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(ep_rets.cpu().numpy(), g[p + "ep_returns"], **tol(2e-6, 0))
+        np.testing.assert_allclose(algo.b_obs.view(B, 50).cpu().numpy(), g[p + "states"], **tol(1e-5, 2e-6))
+        np.testing.assert_allclose(algo.b_act.view(B, 10).cpu().numpy(), g[p + "actions"], **tol(1e-5, 5e-6))
+        np.testing.assert_allclose(algo.b_rew.view(B).cpu().numpy(), g[p + "rewards"], **tol(2e-6, 0))
+        np.testing.assert_allclose(algo.b_val.view(B).cpu().numpy(), g[p + "values"], **tol(1e-5, 1e-5))
+        np.testing.assert_allclose(ret.view(B).cpu().numpy(), g[p + "returns"], **(dict(rtol=5e-2, atol=0.5) if loose else dict(rtol=1e-5, atol=1e-5)))
         # --- optimise: every minibatch's (actor loss, entropy, critic loss, ratio, kl, mirror loss)
         losses, kl, epochs_run = algo.update(ret)
         assert epochs_run == int(g[p + "epochs_run"])
         scal = torch.stack(algo.trace).cpu().numpy().reshape(epochs_run, -1, 6)
         ref = g[p + "scal"]
         assert scal.shape == ref.shape
-        for c, (rt, at) in enumerate([(1e-5, 2e-6), (1e-6, 0), (1e-5, 0), (1e-5, 0), (1e-3, 2e-8), (1e-4, 1e-9)]):
+        stol = [(1e-5, 2e-6), (1e-6, 0), (1e-5, 0), (1e-5, 0), (1e-3, 2e-8), (1e-4, 1e-9)] if strict else [(0.2, 0.02), (1e-6, 0), (0.1, 0), (0.02, 0), (0.25, 2e-3), (0.25, 2e-4)]
+        for c, (rt, at) in enumerate(stol):
             np.testing.assert_allclose(scal[..., c], ref[..., c], rtol=rt, atol=at, err_msg="scalar %d itr %d" % (c, it))
         # --- parameters after the iteration (21 Adam steps each)
         for nm, views, ref_p in (("actor", algo.learner.actor.views(), algo.policy), ("critic", algo.learner.critic.views(), algo.critic)):
             for k, v in zip(ref_p.state_dict(), views):
                 d = np.abs(v.cpu().numpy() - g[p + nm + "." + k])
-                assert (d > 5e-6).mean() < 2e-3 and d.max() < 5e-4, (it, nm, k, (d > 5e-6).mean(), d.max())
+                if strict:
+                    assert (d > 5e-6).mean() < 2e-3 and d.max() < 5e-4, (it, nm, k, (d > 5e-6).mean(), d.max())
+                else:
+                    assert d.mean() < 4e-3, (it, nm, k, d.mean())
 
 
 def test_compute_perturbs_batched(dev):

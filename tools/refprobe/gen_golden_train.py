@@ -56,10 +56,11 @@ class FakeLogger:
     def add_scalar(self, name, val, itr): self.rows.append((name, float(val), int(itr)))
 
 
-def main():
-    torch.manual_seed(151); np.random.seed(151)
-    H, n_itr, mb, epochs = 256, 3, 64, 3
-    args = dict(env_name="Cassie-v0", gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=mb,
+def main(name="g15b_ppo_train", lr=1e-4, H=256, n_itr=3, seed=151):
+    torch.manual_seed(seed); np.random.seed(seed)
+    ToyEnv.k = 0; ToyEnv.log = []
+    mb, epochs = 64, 3
+    args = dict(env_name="Cassie-v0", gamma=0.99, lam=0.95, lr=lr, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=mb,
                 epochs=epochs, num_steps=2 * PERIOD, max_traj_len=MAX_TRAJ, use_gae=True, num_procs=1, max_grad_norm=0.05,
                 recurrent=False)
     os.makedirs("/tmp/g15b", exist_ok=True)
@@ -141,7 +142,8 @@ def main():
     out["train_return"] = np.array([r[1] for r in logger.rows if r[0] == "Train/Return"])
     out["mean_eplen"] = np.array([r[1] for r in logger.rows if r[0] == "Train/Mean Eplen"])
     out["timesteps"] = np.array([r[1] for r in logger.rows if r[0] == "Misc/Timesteps"])
-    np.savez_compressed(os.path.join(GOLD, "g15b_ppo_train.npz"), **out)
+    out["lr"] = lr
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
     for i, b in enumerate(rec["batches"]):
         print("itr", i, "B", len(b["rewards"]), "episodes", list(b["ep_lens"]), "k0", b["k0"], "epochs", out["it%d.epochs_run" % i],
               "mean scal last epoch", out["it%d.scal" % i][-1].mean(0))
@@ -149,4 +151,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "earlystop":      # G15c: a learning rate large enough for the KL test (ppo.py:449) to cut epochs short; 64-unit nets
+        main("g15c_ppo_train_earlystop", lr=float(sys.argv[2]) if len(sys.argv) > 2 else 1.2e-2, H=64, n_itr=2, seed=152)
+    else:
+        main()
