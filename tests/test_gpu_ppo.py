@@ -245,3 +245,32 @@ def test_eval_commands_batched(dev):
     d = eval_commands(stand, mk, num_steps=200, num_commands=3, num_iters=64)
     assert d.shape == (64, 6) and (d[:, 0] == 0).all() and (d[:, 1] == 0).all()
     np.testing.assert_allclose(d[:, 2], 0.5); assert (d[:, 3] == 0).all() and (d[:, 5] == 0).all()
+
+
+def test_cli_ppo_run_directory_checkpoints_and_scalars(dev, tmp_path, golden_dir):
+    """BASELINE configs[0] analogue on the GPU: `apex.py ppo --env_name Cassie-v0 --reward clock ...` end to end for 2 iterations:
+    run directory <logdir>/Cassie-v0/<md5[:6]>-seed0 with experiment.info / experiment.pkl (util/log.py:11-70), whole-module
+    actor.pt / critic.pt that load with `torch.load` and this repo's rl.policies classes (ppo.py:129-137), and the reference's 13
+    scalar names (ppo.py:476-491; the golden G15b run emitted exactly these)."""
+    import json, os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import apex
+    rc = apex.main(["ppo", "--env_name", "Cassie-v0", "--reward", "clock", "--n_envs", "256", "--num_steps", "4096", "--minibatch_size", "1024",
+                    "--n_itr", "2", "--input_norm_steps", "512", "--logdir", str(tmp_path), "--seed", "0"])
+    assert rc in (0, None)
+    runs = os.listdir(os.path.join(str(tmp_path), "Cassie-v0"))
+    assert len(runs) == 1 and runs[0].endswith("-seed0") and len(runs[0].split("-")[0]) == 6
+    run = os.path.join(str(tmp_path), "Cassie-v0", runs[0])
+    for f in ("actor.pt", "critic.pt", "experiment.info", "experiment.pkl"):
+        assert os.path.exists(os.path.join(run, f)), f
+    actor = torch.load(os.path.join(run, "actor.pt"), weights_only=False)
+    assert type(actor).__module__ == "rl.policies.actor" and type(actor).__name__ == "Gaussian_FF_Actor"
+    assert torch.is_tensor(actor.obs_mean) and actor.obs_mean.shape == (50,) and abs(float(actor.fixed_std) - np.exp(-1.5)) < 1e-6
+    y = actor(torch.zeros(50), deterministic=True)
+    assert y.shape[-1] == 10 and torch.isfinite(y).all()
+    g = np.load(os.path.join(golden_dir, "g15b_ppo_train.npz"))
+    if os.path.exists(os.path.join(run, "scalars.jsonl")):          # no TensorBoard in this image: same tags, one JSON object per line
+        names = set(json.loads(line)["tag"] for line in open(os.path.join(run, "scalars.jsonl")))
+        assert names == set(str(x) for x in g["scalar_names"])
+    else:
+        assert any(f.startswith("events.out.tfevents") for f in os.listdir(run))
