@@ -25,6 +25,7 @@ constexpr int NQ = CM_NQ, NV = CM_NV, NB = CM_NBODY;
 constexpr float GRAV = 9.81f;
 
 #include "env_state.h"
+#include "cassie_traj_gen.h"
 
 // ------------------------------------------------------------------------------------------------ forward dynamics
 // mj_setConst subset (cassie_step3.h), staged like the substep
@@ -453,12 +454,25 @@ __device__ __forceinline__ void clock_from_speed(const St& S, float speed, int f
     S(F_CMD + 3) = swing; S(F_CMD + 4) = stance; S(F_CMD + 5) = (2.f * swing + 2.f * stance) * freq;
 }
 
+// CassieTrajEnv.get_ref_state (cassie/cassie_traj.py:926-972), walking trajectory at simrate 50, written into qpos / qvel
+__device__ void traj_pose(const St& S, float phase, float phaselen, float speed, int counter) {
+    if (phase > phaselen) phase = 0.f;
+    if (phase > floorf((float)TRAJ_LEN / 50.f) - 1.f) phase = floorf((phase / phaselen) * (float)TRAJ_LEN / 50.f);
+    const int row = (int)phase;
+    for (int i = 0; i < NQ; ++i) S(F_QPOS + i) = traj_table[row][i];
+    for (int i = 0; i < NV; ++i) S(F_QVEL + i) = traj_table[row][35 + i];
+    S(F_QPOS) = S(F_QPOS) * speed + TRAJ_DX * (float)counter * speed;
+    S(F_QPOS + 1) = 0.f;
+    S(F_QVEL) *= speed;
+}
+
 // CassieEnv.reset (cassie/cassie.py:523-680)
 // reset, part 1 (wave 0): command / clock / dynamics-randomisation draws (cassie.py:525-657) and the init pose
 __device__ void env_reset_draws(const St& S, const Cfg& cfg) {
     Rng r{cfg.seed_lo, cfg.seed_hi, cfg.env_base + (unsigned)S.env, (unsigned)S.I(I_RNG)};
-    const float speed0 = r.uniform(-0.3f, 4.0f);
+    const float speed0 = cfg.env_kind == 1 ? (float)r.randint(41u) / 10.f : r.uniform(-0.3f, 4.0f);      // cassie_traj.py:608: random.randint(0, 40) / 10
     (void)r.uniform(-0.3f, 0.3f);
+    S(F_CMD) = speed0;                                   // kept for the trajectory-pose reset; replaced by the command redraw after the settle step
     clock_from_speed(S, speed0, 2000 / cfg.simrate);
     S.I(I_PHASE) = (int)r.randint((unsigned)floorf(S(F_CMD + 5)) + 1u);
     S.I(I_TIME) = 0; S.I(I_COUNTER) = 0;
@@ -512,6 +526,10 @@ __device__ __forceinline__ void env_reset(const St& S, const Cfg& cfg) {
     if (cfg.dyn_rand) setconst_lane(S);               // sim.set_const -> mj_setConst
 
     sim_step_pd(S, cfg.pgs_iters, 0);               // cassie_sim_set_const ends in mj_forward
+    if (cfg.env_kind == 1) {                          // CassieTrajEnv.reset: set_qpos / set_qvel with the reference state of the start phase
+        if (lead) traj_pose(S, (float)S.I(I_PHASE), S(F_CMD + 5), S(F_CMD), 0);      // (cassie_traj.py:752-758); no mj_forward follows, so the
+        c4::wsync();                                  // settle step below still reads the init-pose sensor snapshot, like the reference
+    }
     sim_step_pd(S, cfg.pgs_iters, 1);               // cassie.py:665 (stale pd_in_t)
     if (lead) env_reset_finish(S, cfg);
     c4::wsync();
@@ -690,6 +708,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
         for (int u = 0; u < 10; ++u) { S(F_PREVACT + u) = act[u]; S(F_PREVTQ + u) = S(F_SO + SO_TORQUE + u); }
         {   // command resampling, cassie.py:483-491; fixed 6 draws per step
             Rng r{cfg.seed_lo, cfg.seed_hi, cfg.env_base + (unsigned)env, (unsigned)S.I(I_RNG)};
+            if (cfg.env_kind == 1 && cfg.dyn_rand) (void)r.u01();                 // cassie_traj.py:463-464 draws a simrate the loop never uses
             { const unsigned k = r.randint(300); const float u = r.uniform(-0.2f, 0.2f); if (k == 0) S(F_CMD + 2) += u; }
             { const unsigned k = r.randint(100); const float u = r.uniform(-0.3f, 4.0f); if (k == 0) S(F_CMD + 0) = fminf(fmaxf(u, -0.3f), 4.0f); }
             { const unsigned k = r.randint(300); const float u = r.uniform(-0.3f, 0.3f); if (k == 0) S(F_CMD + 1) = u; }
@@ -859,7 +878,8 @@ __global__ __launch_bounds__(128) void env_step_kernel(float* st, int* ist, floa
     for (int u = 0; u < 10; ++u) { S(F_PREVACT + u) = act[u]; S(F_PREVTQ + u) = S(F_SO + SO_TORQUE + u); }
     {   // command resampling, cassie.py:483-491; fixed 6 draws per step
         Rng r{cfg.seed_lo, cfg.seed_hi, cfg.env_base + (unsigned)env, (unsigned)S.I(I_RNG)};
-        { const unsigned k = r.randint(300); const float u = r.uniform(-0.2f, 0.2f); if (k == 0) S(F_CMD + 2) += u; }
+        if (cfg.env_kind == 1 && cfg.dyn_rand) (void)r.u01();                 // cassie_traj.py:463-464 draws a simrate the loop never uses
+            { const unsigned k = r.randint(300); const float u = r.uniform(-0.2f, 0.2f); if (k == 0) S(F_CMD + 2) += u; }
         { const unsigned k = r.randint(100); const float u = r.uniform(-0.3f, 4.0f); if (k == 0) S(F_CMD + 0) = fminf(fmaxf(u, -0.3f), 4.0f); }
         { const unsigned k = r.randint(300); const float u = r.uniform(-0.3f, 0.3f); if (k == 0) S(F_CMD + 1) = u; }
         S.I(I_RNG) = (int)r.ctr;
@@ -905,7 +925,7 @@ __global__ void env_update_speed_kernel(float* st, int* ist, int n, Cfg cfg, con
 
 static Cfg make_cfg(const apx_env_cfg& c) {
     return Cfg{c.simrate, c.dynamics_randomization, c.stance_mode, c.have_incentive, c.max_traj_len, c.pgs_iters,
-               (unsigned)c.seed, (unsigned)(c.seed >> 32), (unsigned)c.env_id_base, c.reward_kind};
+               (unsigned)c.seed, (unsigned)(c.seed >> 32), (unsigned)c.env_id_base, c.reward_kind, c.env_kind};
 }
 
 extern "C" void apx_env_default_cfg(apx_env_cfg* c) {
@@ -919,6 +939,7 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     APX_REQUIRE(cfg && out, "null");
     APX_REQUIRE(cfg->n_envs > 0 && cfg->n_envs % 64 == 0, "n_envs must be a positive multiple of 64");
     APX_REQUIRE(cfg->simrate > 0 && 2000 % cfg->simrate == 0, "simrate must divide 2000");
+    APX_REQUIRE(cfg->env_kind == 0 || (cfg->env_kind == 1 && cfg->simrate == 50), "env_kind: 0 Cassie-v0, 1 CassieTraj-v0 (walking trajectory table is for simrate 50)");
     APX_REQUIRE(cfg->reward_kind >= 0 && cfg->reward_kind <= 2, "reward_kind: 0 clock_reward, 1 early_clock_reward, 2 max_vel_clock_reward");
     APX_REQUIRE(cfg->pgs_iters > 0 && cfg->max_traj_len > 0, "pgs_iters / max_traj_len");
     APX_HIP(hipSetDevice(cfg->device));

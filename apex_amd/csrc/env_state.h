@@ -70,7 +70,7 @@ __device__ __forceinline__ St make_st(float* st, int* ist, int n, int env, float
 
 // state estimator height model (golden G11c): height = z - L, L' = (lowest sole z - L) / EST_TAU, L = EST_L0 after state_output_setup
 constexpr float EST_TAU = 0.86f, EST_L0 = 0.126f, EST_ALPHA = 0.0005f / EST_TAU;
-struct Cfg { int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; int reward_kind; };
+struct Cfg { int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; int reward_kind, env_kind; };
 
 // ------------------------------------------------------------------------------------------------ Philox4x32-10
 __device__ __forceinline__ unsigned philox(unsigned k0, unsigned k1, unsigned env, unsigned ctr) {

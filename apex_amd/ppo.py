@@ -300,7 +300,8 @@ def run_experiment(args):
     env = CassieVecEnv(n_envs=n_envs, simrate=args.simrate, dynamics_randomization=args.dyn_random, reward=args.reward,
                        max_traj_len=args.max_traj_len, seed=args.seed, device=local, env_id_base=adist.shard_env_base(rank, n_envs),
                        command_profile=args.command_profile, input_profile=args.input_profile, history=args.history,
-                       learn_gains=args.learn_gains)
+                       learn_gains=args.learn_gains, env_name=args.env_name, traj=args.traj, no_delta=args.no_delta,
+                       ik_baseline=args.ik_baseline)
     logger = create_logger(args) if rank == 0 else None
     a = dict(vars(args)); a["mirror"] = args.mirror
     algo = PPO(a, logger.dir if logger else "/tmp/apx_unused", env, rank=rank, world_size=world, group=group)

@@ -45,9 +45,17 @@ class CassieVecEnv:
     mirrored_acts = MIRRORED_ACTS
 
     def __init__(self, n_envs=4096, simrate=50, dynamics_randomization=True, reward="clock", max_traj_len=400, seed=0,
-                 device=0, pgs_iters=50, env_id_base=0, command_profile="clock", input_profile="full", history=0, learn_gains=False):
+                 device=0, pgs_iters=50, env_id_base=0, command_profile="clock", input_profile="full", history=0, learn_gains=False,
+                 env_name="Cassie-v0", traj="walking", no_delta=True, ik_baseline=False):
         if command_profile != "clock" or input_profile != "full" or history != 0 or learn_gains:
             raise NotImplementedError("only command_profile=clock, input_profile=full, history=0 are on the hot path")
+        # util/env.py:22-32: Cassie-v0 -> CassieEnv; CassieTraj-v0 -> CassieTrajEnv, which with the CLI defaults (traj=walking,
+        # command_profile=clock, no_delta) has Cassie-v0's step and observation and resets to the reference trajectory's pose
+        if env_name not in ("Cassie-v0", "CassieTraj-v0"):
+            raise NotImplementedError("env_name %r: only Cassie-v0 and CassieTraj-v0 are built" % (env_name,))
+        if env_name == "CassieTraj-v0" and (traj != "walking" or not no_delta or ik_baseline or simrate != 50):
+            raise NotImplementedError("CassieTraj-v0 is built for traj=walking, no_delta, simrate 50 (the CLI defaults)")
+        self.env_name = env_name
         if not torch.cuda.is_available():
             raise _lib.ApxError("CassieVecEnv needs a GPU (there is no CPU fallback)")
         lib = _lib.load()
@@ -58,6 +66,7 @@ class CassieVecEnv:
         cfg.reward_kind, cfg.stance_mode, cfg.have_incentive = r["reward_kind"], r["stance_mode"], r["have_incentive"]
         cfg.max_traj_len, cfg.seed, cfg.device, cfg.pgs_iters = max_traj_len, seed, device, pgs_iters
         cfg.env_id_base = env_id_base
+        cfg.env_kind = 1 if env_name == "CassieTraj-v0" else 0
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
         self._h = C.c_void_p()

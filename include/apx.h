@@ -125,7 +125,10 @@ typedef struct apx_env_cfg {
     int device;                 /* HIP device ordinal */
     int pgs_iters;              /* cassie.xml:5 iterations (50) */
     int env_id_base;            /* global index of this shard's env 0 (RNG stream id = env_id_base + local env) */
-    int reserved[6];
+    int env_kind;               /* 0 Cassie-v0 (cassie/cassie.py), 1 CassieTraj-v0 with the CLI defaults traj=walking, command_profile=clock,
+                                 * input_profile=full, no_delta (cassie/cassie_traj.py): same step, reset to the reference trajectory's pose
+                                 * of the random start phase (:599-778, get_ref_state :926-972); needs simrate 50 */
+    int reserved[5];
 } apx_env_cfg;
 
 void apx_env_default_cfg(apx_env_cfg* cfg);

@@ -24,6 +24,8 @@ void orc_env_reset(void* h, double* obs) { env_reset(*(Env*)h, obs); }
 int orc_env_step(void* h, const double* action, double* obs, double* reward) { return env_step(*(Env*)h, action, obs, reward); }
 void orc_env_substep(void* h) { sim_step_pd(*(Env*)h); }
 void orc_env_step_basic(void* h, const double* action, double* obs) { env_step_basic(*(Env*)h, action, obs); }
+void orc_env_set_kind(void* h, int kind) { ((Env*)h)->cfg.env_kind = kind; }     // 1 = CassieTraj-v0 (trajectory-pose reset)
+void orc_traj_ref_state(double phase, double phaselen, double speed, int counter, double* qpos, double* qvel) { traj_ref_state(phase, phaselen, speed, counter, qpos, qvel); }
 void orc_env_update_speed(void* h, double speed, double side_speed) { env_update_speed(*(Env*)h, speed, side_speed); }
 void orc_env_reset_for_test(void* h, double* obs, int full_reset) { env_reset_for_test(*(Env*)h, obs, full_reset != 0); }
 void orc_env_apply_force(void* h, const double* xfrc) { for (int k = 0; k < 6; ++k) ((Env*)h)->st.xfrc[k] = xfrc[k]; }   // CassieSim.apply_force on cassie-pelvis

@@ -1,5 +1,6 @@
 // CPU ORACLE (test infrastructure only).  See cassie_env.h.
 #include "cassie_env.h"
+#include "cassie_traj_gen.h"
 #include <cstdio>
 
 namespace orc {
@@ -343,11 +344,26 @@ void env_reset_for_test(Env& e, double* obs, bool full_reset) {
     env_obs(e, obs);
 }
 
-// CassieEnv.reset, cassie.py:523-680
+// CassieTrajEnv.get_ref_state (cassie_traj.py:926-972) for the walking trajectory at simrate 50: the row is phase * simrate of the 2 kHz
+// trajectory; a phase beyond the trajectory's own cycle (floor(len / simrate) - 1 = 32) is rescaled by phase / phaselen; x scales with
+// the commanded speed and advances by one cycle length per completed cycle, the lateral target is 0
+void traj_ref_state(double phase, double phaselen, double speed, int counter, double* qpos, double* qvel) {
+    if (phase > phaselen) phase = 0;
+    if (phase > std::floor(TRAJ_LEN / 50.0) - 1) phase = std::floor((phase / phaselen) * TRAJ_LEN / 50.0);
+    const int row = (int)phase;                                  // int(phase * simrate) / simrate
+    for (int i = 0; i < NQ; ++i) qpos[i] = traj_table[row][i];
+    for (int i = 0; i < NV; ++i) qvel[i] = traj_table[row][35 + i];
+    qpos[0] *= speed;
+    qpos[0] += TRAJ_DX * counter * speed;
+    qpos[1] = 0;
+    qvel[0] *= speed;
+}
+
+// CassieEnv.reset, cassie.py:523-680 (env_kind 1: CassieTrajEnv.reset, cassie_traj.py:599-778)
 void env_reset(Env& e, double* obs) {
     static thread_local Work w;
     Philox& r = e.rng;
-    e.speed = r.uniform(-0.3, 4.0);
+    e.speed = e.cfg.env_kind == 1 ? (double)r.randint(41) / 10 : r.uniform(-0.3, 4.0);      // cassie_traj.py:608: random.randint(0, 40) / 10
     e.side_speed = r.uniform(-0.3, 0.3);
     set_clock_from_speed(e);
     e.phase = (int)r.randint((uint32_t)std::floor(e.clock.phaselen) + 1);   // random.randint(0, floor(phaselen)) inclusive
@@ -384,6 +400,8 @@ void env_reset(Env& e, double* obs) {
     double zero[10] = {0};
     forward_snapshot(e, w, zero);
     foot_positions(e.st, e.foot_pos_prev);
+    if (e.cfg.env_kind == 1)     // cassie_traj.py:752-758: set_qpos / set_qvel with the reference state of the start phase; no mj_forward, so the
+        traj_ref_state(e.phase, e.clock.phaselen, e.speed, 0, e.st.qpos, e.st.qvel);      // next step_pd still reads the init-pose sensors
     sim_step_pd(e);                                         // cassie.py:665: one step with the stale self.u
     foot_positions(e.st, e.foot_pos_prev);
     e.orient_add = 0;
@@ -470,6 +488,7 @@ double eval_clock_reward(Env& e, const double* action) {
 
 // CassieEnv.step, cassie.py:389-496
 int env_step(Env& e, const double* action, double* obs, double* reward) {
+    if (e.cfg.env_kind == 1 && e.cfg.dynamics_randomization) (void)e.rng.uniform01();   // cassie_traj.py:463-464 draws a simrate that the loop never uses
     e.l_foot_frc = e.r_foot_frc = 0;
     e.l_foot_orient_cost = e.r_foot_orient_cost = 0;
     for (int u = 0; u < 10; ++u) {      // step_simulation :295-326

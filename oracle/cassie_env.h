@@ -28,6 +28,7 @@ struct EnvCfg {
     int max_traj_len = 400;
     int pgs_iters = 50;
     uint64_t seed = 0;
+    int env_kind = 0;         // 0 Cassie-v0 (cassie/cassie.py), 1 CassieTraj-v0 with the CLI defaults (cassie/cassie_traj.py: trajectory-pose reset)
 };
 
 struct Clock {                // the four clock splines of create_phase_reward, as knot tables for ONE cycle
@@ -76,6 +77,7 @@ void env_reset(Env& e, double* obs);
 void env_step_basic(Env& e, const double* action, double* obs);           // CassieEnv.step_basic, cassie.py:498-521
 void env_clock_from_speed(Env& e);                                         // swing / stance / clock from e.speed, cassie.py:556-559
 void env_update_speed(Env& e, double new_speed, double new_side_speed);   // CassieEnv.update_speed, cassie.py:757-775
+void traj_ref_state(double phase, double phaselen, double speed, int counter, double* qpos, double* qvel);   // CassieTrajEnv.get_ref_state, cassie_traj.py:926-972 (walking trajectory, simrate 50)
 void env_reset_for_test(Env& e, double* obs, bool full_reset = false);    // CassieEnv.reset_for_test(full_reset), cassie.py:682-742
 // returns done flag: 0 running, 1 terminated (height), 2 truncated at max_traj_len (only reported, no reset here)
 int env_step(Env& e, const double* action, double* obs, double* reward);

@@ -27,6 +27,8 @@ def lib():
         L.orc_env_step_basic.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_env_reset_for_test.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_env_apply_force.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_env_set_kind.argtypes = [C.c_void_p, C.c_int]
+        L.orc_traj_ref_state.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_env_set_command.argtypes = [C.c_void_p, C.c_double, C.c_int]
         L.orc_env_obs.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_phys_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
@@ -60,9 +62,11 @@ def _ptr(a):
 
 class OracleEnv:
     def __init__(self, simrate=50, dyn_rand=True, reward_kind=0, stance_mode=0, incentive=True, max_traj_len=400,
-                 pgs_iters=50, seed=0, env_id=0):
+                 pgs_iters=50, seed=0, env_id=0, env_kind=0):
         self.h = lib().orc_env_new(simrate, int(dyn_rand), reward_kind, stance_mode, int(incentive), max_traj_len,
                                    pgs_iters, seed, env_id)
+        if env_kind:
+            lib().orc_env_set_kind(self.h, int(env_kind))
 
     def __del__(self):
         try:
@@ -174,3 +178,10 @@ def philox(seed, env, ctr):
 
 def rollout_bench(n_envs, n_steps, threads, seed=0, act_std=0.2):
     return lib().orc_rollout_bench(n_envs, n_steps, threads, seed, act_std)
+
+
+def traj_ref_state(phase, phaselen, speed, counter=0):
+    """CassieTrajEnv.get_ref_state of the oracle (walking trajectory, simrate 50) -> (qpos[35], qvel[32])."""
+    q, v = np.zeros(35), np.zeros(32)
+    lib().orc_traj_ref_state(float(phase), float(phaselen), float(speed), int(counter), _ptr(q), _ptr(v))
+    return q, v

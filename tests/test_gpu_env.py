@@ -382,3 +382,41 @@ def test_full_reset_and_apply_force_vs_oracle(dev, golden_dir):
     # the push actually moved the robots apart: lateral pelvis velocity follows the direction of the wrench
     vy = genv.get_field("qvel").cpu().numpy()[:, 1]
     assert np.corrcoef(vy[:64], xfrc[:64, 1])[0, 1] > 0.5
+
+
+def test_cassie_traj_v0_reset_and_steps_vs_oracle(dev):
+    """CassieTraj-v0 with the CLI defaults (next row f1, env half; golden G17 pins the oracle to the reference): same Philox streams
+    in kernel and oracle -> same start phase / first speed, the robot starts from the reference trajectory's pose of that phase
+    (not from the init pose), and the following env steps agree like Cassie-v0's."""
+    from apex_amd.vecenv import CassieVecEnv
+    genv = CassieVecEnv(n_envs=N, dynamics_randomization=True, seed=17, env_name="CassieTraj-v0")
+    K = 12
+    oenv = [S.OracleEnv(dyn_rand=True, seed=17, env_id=i, env_kind=1) for i in range(K)]
+    gobs = genv.reset().cpu().numpy()
+    oobs = np.stack([e.reset() for e in oenv])
+    gi = genv.get_field("ints").cpu().numpy(); gq = genv.get_field("qpos").cpu().numpy(); gv = genv.get_field("qvel").cpu().numpy()
+    cmd = genv.get_field("cmd").cpu().numpy()
+    for i, e in enumerate(oenv):
+        assert int(gi[i, 1]) == int(e.get("ints")[1])                                    # start phase: integer draw, bit-exact
+        assert abs(cmd[i, 5] - e.get("phaselen")[0]) < 1e-4                              # clock from the randint speed
+        np.testing.assert_allclose(gq[i], e.get("qpos"), atol=2e-4); np.testing.assert_allclose(gv[i], e.get("qvel"), atol=3e-2)
+        np.testing.assert_allclose(gobs[i, 46:50], oobs[i, 46:50], atol=1e-5)
+    assert np.abs(gq[:, 2] - 1.01).max() > 5e-3 and len(np.unique(np.round(gq[:, 7], 3))) > 8        # poses differ from env to env: not the init pose
+    rng = np.random.RandomState(3)
+    tol = np.full(50, 1e-2); tol[21:31] = 0.3; tol[31:34] = 0.6; tol[40:46] = 0.3
+    for t in range(3):
+        act = (rng.randn(N, 10) * 0.1).astype(np.float32)
+        obs, rew, done, _ = genv.step(torch.tensor(act, device=dev), auto_reset=False)
+        obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+        for i, e in enumerate(oenv):
+            o, r, d = e.step(act[i].astype(np.float64))
+            assert np.all(np.abs(obs[i] - o) <= tol * (t + 1) + 5e-3 * np.abs(o)), ("env %d step %d" % (i, t), np.abs(obs[i] - o).max())
+            assert abs(rew[i] - r) < 0.02 * (t + 1)
+    # the masked restart inside apx_env_step uses the same trajectory-pose reset
+    genv2 = CassieVecEnv(n_envs=N, dynamics_randomization=False, seed=4, env_name="CassieTraj-v0", max_traj_len=2)
+    genv2.reset()
+    z = torch.zeros(N, 10, device=dev)
+    genv2.step(z); _, _, done, _ = genv2.step(z)
+    assert (done == 2).all()
+    q = genv2.get_field("qpos").cpu().numpy()
+    assert np.abs(q[:, 2] - 1.01).max() > 5e-3 and np.isfinite(q).all()

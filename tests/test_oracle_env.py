@@ -372,3 +372,38 @@ def test_g11b_estimator_lite_on_a_walking_stream(golden_dir):
     d = g["z"] - g["ref_height"]
     assert abs(d[120:].mean()) < 0.02 and d[0] > 0.08                  # reference: offset decays to ~0 on the ground
     assert np.abs(g["z"] - 0.0818 - g["ref_height"]).mean() < 0.09     # a constant offset is off by centimetres here (see G11c)
+
+
+def test_g17_traj_env_reset_and_ref_state(golden_dir):
+    """G17 (next row f1, env half): CassieTrajEnv.get_ref_state on 300 random (phase, phaselen, speed, counter) of the reference
+    (bit-exact in the oracle: same table, same arithmetic), and CassieTrajEnv.reset on a recording sim: set_const -> set_qpos ->
+    set_qvel -> step_pd, the first speed is randint(0, 40) / 10, the pose written is get_ref_state(start phase) with that speed."""
+    g = np.load(os.path.join(golden_dir, "g17_traj_env.npz"))
+    for k in range(len(g["inp"])):
+        ph, pl, sp, cn = g["inp"][k]
+        q, v = S.traj_ref_state(ph, pl, sp, int(cn))
+        assert np.array_equal(q, g["pos"][k]) and np.array_equal(v, g["vel"][k]), k
+    assert list(g["reset_order"]) == ["set_const", "set_qpos", "set_qvel", "step_pd"]
+    (a0, b0, v0), (a1, b1, v1) = g["reset_randint"]
+    assert (a0, b0) == (0, 40) and (a1, b1) == (0, np.floor(g["reset_phaselen"][0])) and int(g["reset_phase"][0]) == int(v1)
+    assert abs(g["reset_phaselen"][0] - g["reset_phaselen"][1]) < 1e-12                 # the clock is built from the randint speed
+    np.testing.assert_array_equal(g["reset_qpos"], g["reset_ref_qpos"]); np.testing.assert_array_equal(g["reset_qvel"], g["reset_ref_qvel"])
+    assert -0.3 <= g["reset_speed_after"][0] <= 4.0 and g["reset_speed_after"][2] == 0
+    np.testing.assert_allclose(g["offset"], [0.0045, 0.0, 0.4973, -1.1997, -1.5968] * 2)   # no_delta: the PD offset is Cassie-v0's
+    # the oracle env in CassieTraj mode: after reset the robot sits one substep after the reference pose of its start phase, and the
+    # first speeds it saw are multiples of 0.1 in [0, 4] (the commanded speed itself is redrawn from U[-0.3, 4] afterwards)
+    for seed in range(6):
+        e = S.OracleEnv(dyn_rand=True, seed=seed, env_id=3, env_kind=1)
+        e.reset()
+        ph, pl = int(e.get("ints")[1]), e.get("phaselen")[0]
+        # recover the first speed from the clock: phaselen = 40 (0.9 - 0.25 / 3 |s|)
+        s0 = (0.9 - pl / 40.0) * 3 / 0.25
+        assert abs(s0 * 10 - round(s0 * 10)) < 1e-9 and -1e-9 <= s0 <= 4.0 + 1e-9
+        q, v = S.traj_ref_state(ph, pl, s0, 0)
+        qe, ve = e.get("qpos"), e.get("qvel")
+        assert np.abs(qe[[2, 7, 8, 9, 14, 20]] - q[[2, 7, 8, 9, 14, 20]]).max() < 5e-3       # one 0.5 ms substep away from the pose
+        assert abs(qe[0] - q[0]) < 5e-3 and abs(qe[1]) < 1e-3
+        assert -0.3 <= e.get("speed")[0] <= 4.0
+    e0 = S.OracleEnv(dyn_rand=True, seed=1, env_id=3)                                      # Cassie-v0 for contrast: the init pose
+    e0.reset()
+    assert abs(e0.get("qpos")[2] - 1.01) < 2e-3
