@@ -45,6 +45,11 @@ SIGNATURES = {
     "apx_adv_moments": (C.c_int, [c_ptr, c_ptr, C.c_int64, c_ptr, c_ptr]),
     "apx_adv_apply": (C.c_int, [c_ptr, c_ptr, C.c_int64, C.c_double, C.c_double, C.c_double, c_ptr, c_ptr]),
     "apx_mlp_param_count": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "apx_lstm_param_count": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "apx_lstm_workspace_floats": (C.c_size_t, [C.c_int, C.c_int64, C.c_int, C.c_int]),
+    "apx_lstm_bwd_scratch_floats": (C.c_size_t, [C.c_int, C.c_int64, C.c_int, C.c_int]),
+    "apx_lstm_forward": (C.c_int, [c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, C.c_int, C.c_int64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "apx_lstm_backward": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, C.c_int, C.c_int64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "apx_mlp_forward": (C.c_int, [c_ptr, C.c_int, C.c_int, C.c_int, c_ptr, C.c_int64, c_ptr, c_ptr, C.c_uint64, c_ptr,
                                   c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, c_ptr]),
     "apx_ppo_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int, C.c_int]),

@@ -447,6 +447,145 @@ extern "C" int apx_mlp_forward(const float* params, int D, int H, int O, const f
     return mlp_forward_impl(params, D, H, O, xn_out, B, act1, act2, y, s);
 }
 
+// ------------------------------------------------------------------------------------------------ LSTM (recurrent actor / critic)
+// Gaussian_LSTM_Actor / LSTM_V (rl/policies/actor.py:218-311, critic.py:236-296): L stacked nn.LSTMCell(H) + Linear(H, O), run over a
+// padded batch of trajectories x[T, B, D] from zero state (or one step from a carried state).  Parameters in state_dict order: per
+// cell weight_ih[4H, in] weight_hh[4H, H] bias_ih[4H] bias_hh[4H] (gate order i, f, g, o), then network_out weight[O, H] bias[O].
+// The input projections of ALL time steps are one GEMM per layer; only h_{t-1} W_hh^T + the gate non-linearities are sequential
+// (one accumulate-GEMM + one pointwise launch per step and layer).  Saved for the backward pass per layer: activated gates
+// [T, B, 4H], cell state [T, B, H], hidden state [T, B, H].
+struct LstmView {
+    const float *Wih[4], *Whh[4], *bih[4], *bhh[4], *Wo, *bo; int in[4];
+    LstmView(const float* p, int D, int H, int L, int O) {
+        for (int l = 0; l < L; ++l) {
+            in[l] = l ? H : D;
+            Wih[l] = p; p += (size_t)4 * H * in[l]; Whh[l] = p; p += (size_t)4 * H * H; bih[l] = p; p += 4 * H; bhh[l] = p; p += 4 * H;
+        }
+        Wo = p; bo = p + (size_t)O * H;
+    }
+};
+extern "C" size_t apx_lstm_param_count(int D, int H, int L, int O) {
+    size_t n = 0;
+    for (int l = 0; l < L; ++l) n += (size_t)4 * H * (l ? H : D) + (size_t)4 * H * H + 8 * H;
+    return n + (size_t)O * H + O;
+}
+extern "C" size_t apx_lstm_workspace_floats(int T, int64_t B, int H, int L) { return (size_t)L * T * B * 6 * H; }
+
+__device__ __forceinline__ float sigmf(float x) { return 1.f / (1.f + expf(-x)); }
+// gates[B, 4H]: pre-activations (x W_ih^T + b_ih + h W_hh^T) in, activated (i, f, g, o) out
+__global__ void lstm_cell_fwd_kernel(float* __restrict__ gates, const float* __restrict__ bhh, const float* __restrict__ c_prev,
+                                     float* __restrict__ c_out, float* __restrict__ h_out, long B, int H) {
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= B * H) return;
+    const long b = e / H; const int j = (int)(e - b * H);
+    float* g = gates + b * 4 * H;
+    const float i = sigmf(g[j] + bhh[j]), f = sigmf(g[H + j] + bhh[H + j]), gg = tanhf(g[2 * H + j] + bhh[2 * H + j]),
+                o = sigmf(g[3 * H + j] + bhh[3 * H + j]);
+    const float c = f * (c_prev ? c_prev[e] : 0.f) + i * gg;
+    g[j] = i; g[H + j] = f; g[2 * H + j] = gg; g[3 * H + j] = o;
+    c_out[e] = c; h_out[e] = o * tanhf(c);
+}
+// dgates[B, 4H] <- d(loss)/d(pre-activations); dc_io[B, H]: d(loss)/d(c_t) from step t+1 in, d(loss)/d(c_{t-1}) out
+__global__ void lstm_cell_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c, const float* __restrict__ c_prev,
+                                     const float* __restrict__ dh_a, const float* __restrict__ dh_b, float* __restrict__ dc_io,
+                                     float* __restrict__ dgates, long B, int H) {
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= B * H) return;
+    const long b = e / H; const int j = (int)(e - b * H);
+    const float* g = gates + b * 4 * H;
+    const float i = g[j], f = g[H + j], gg = g[2 * H + j], o = g[3 * H + j];
+    const float dh = (dh_a ? dh_a[e] : 0.f) + (dh_b ? dh_b[e] : 0.f);
+    const float tc = tanhf(c[e]);
+    const float dc = dh * o * (1.f - tc * tc) + dc_io[e];
+    float* d = dgates + b * 4 * H;
+    d[j] = dc * gg * i * (1.f - i);
+    d[H + j] = dc * (c_prev ? c_prev[e] : 0.f) * f * (1.f - f);
+    d[2 * H + j] = dc * i * (1.f - gg * gg);
+    d[3 * H + j] = dh * tc * o * (1.f - o);
+    dc_io[e] = dc * f;
+}
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, long n) {
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e < n) y[e] += x[e];
+}
+
+// x[T, B, D] prepared input; hc = [L][2][B][H] carried (h, c) in / out, or NULL (zero start, final state dropped);
+// save = apx_lstm_workspace_floats(T, B, H, L) floats; y[T, B, O]
+extern "C" int apx_lstm_forward(const float* params, int D, int H, int L, int O, const float* x, int T, int64_t B, float* hc,
+                                float* save, float* y, void* stream) {
+    APX_REQUIRE(params && x && save && y && T > 0 && B > 0 && L >= 1 && L <= 4 && D > 0 && H > 0 && O > 0, "lstm forward arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const LstmView P(params, D, H, L, O);
+    const long TB = (long)T * B;
+    const float* in = x;
+    for (int l = 0; l < L; ++l) {
+        float* G = save + (size_t)l * TB * 6 * H; float* Cc = G + TB * 4 * H; float* Hh = Cc + TB * H;
+        APX_TRY(linear_fwd(in, P.Wih[l], P.bih[l], G, TB, P.in[l], 4 * H, false, s));            // all time steps at once
+        for (int t = 0; t < T; ++t) {
+            const float* hp = t ? Hh + (size_t)(t - 1) * B * H : (hc ? hc + (size_t)(2 * l) * B * H : nullptr);
+            const float* cp = t ? Cc + (size_t)(t - 1) * B * H : (hc ? hc + (size_t)(2 * l + 1) * B * H : nullptr);
+            float* Gt = G + (size_t)t * B * 4 * H;
+            if (hp) {       // G_t += h_{t-1} W_hh^T
+                GemmArgs g{hp, H, 1, P.Whh[l], 1, H, Gt, 4 * H, nullptr, 0, (int)B, 4 * H, H, 0};
+                APX_TRY(launch_gemm(EPI_ATOMIC, g, 1, s));
+            }
+            hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(apx_cdiv(B * H, 256)), dim3(256), 0, s, Gt, P.bhh[l], cp, Cc + (size_t)t * B * H,
+                               Hh + (size_t)t * B * H, (long)B, H);
+            APX_LAUNCH_CHECK();
+        }
+        if (hc) {
+            APX_HIP(hipMemcpyAsync(hc + (size_t)(2 * l) * B * H, Hh + (size_t)(T - 1) * B * H, sizeof(float) * B * H, hipMemcpyDeviceToDevice, s));
+            APX_HIP(hipMemcpyAsync(hc + (size_t)(2 * l + 1) * B * H, Cc + (size_t)(T - 1) * B * H, sizeof(float) * B * H, hipMemcpyDeviceToDevice, s));
+        }
+        in = Hh;
+    }
+    return linear_fwd(in, P.Wo, P.bo, y, TB, H, O, false, s);
+}
+
+// grads += d(loss)/d(params) for dy[T, B, O] (zero start state).  scratch: (8H + max(D, H)) * T * B ... see apx_lstm_bwd_scratch_floats
+extern "C" size_t apx_lstm_bwd_scratch_floats(int T, int64_t B, int D, int H) { return (size_t)T * B * (4 * H + 2 * H) + (size_t)B * 2 * H + 4 * H; }
+extern "C" int apx_lstm_backward(const float* params, float* grads, int D, int H, int L, int O, const float* x, int T, int64_t B,
+                                 const float* save, const float* dy, float* scratch, void* stream) {
+    APX_REQUIRE(params && grads && x && save && dy && scratch && T > 0 && B > 0 && L >= 1 && L <= 4, "lstm backward arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const LstmView P(params, D, H, L, O);
+    const LstmView Gd(grads, D, H, L, O);
+    const long TB = (long)T * B;
+    float* dG = scratch;                         // [T, B, 4H]
+    float* dHa = dG + TB * 4 * H;                // [T, B, H]  d(loss)/d(h_t) from the layer above (or the output layer)
+    float* dHx = dHa + TB * H;                   // [T, B, H]  input gradient of the current layer = dHa of the layer below
+    float* dhr = dHx + TB * H;                   // [B, H]     recurrent d(loss)/d(h_{t-1})
+    float* dc = dhr + B * H;                     // [B, H]
+    float* dbt = dc + B * H;                     // [4H]
+    const float* Htop = save + (size_t)(L - 1) * TB * 6 * H + TB * 5 * H;
+    APX_TRY(linear_bwd_weight(dy, Htop, const_cast<float*>(Gd.Wo), const_cast<float*>(Gd.bo), TB, H, O, s));
+    APX_TRY(linear_bwd_input(dy, P.Wo, nullptr, dHa, TB, H, O, s));
+    for (int l = L - 1; l >= 0; --l) {
+        const float* G = save + (size_t)l * TB * 6 * H; const float* Cc = G + TB * 4 * H; const float* Hh = Cc + TB * H;
+        const float* in = l ? save + (size_t)(l - 1) * TB * 6 * H + TB * 5 * H : x;
+        APX_HIP(hipMemsetAsync(dc, 0, sizeof(float) * B * H, s));
+        for (int t = T - 1; t >= 0; --t) {
+            hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(apx_cdiv(B * H, 256)), dim3(256), 0, s, G + (size_t)t * B * 4 * H, Cc + (size_t)t * B * H,
+                               t ? Cc + (size_t)(t - 1) * B * H : nullptr, dHa + (size_t)t * B * H, t < T - 1 ? dhr : nullptr, dc,
+                               dG + (size_t)t * B * 4 * H, (long)B, H);
+            APX_LAUNCH_CHECK();
+            if (t) APX_TRY(linear_bwd_input(dG + (size_t)t * B * 4 * H, P.Whh[l], nullptr, dhr, B, H, 4 * H, s));      // dh_{t-1} = dG_t W_hh
+        }
+        APX_HIP(hipMemsetAsync(dbt, 0, sizeof(float) * 4 * H, s));
+        APX_TRY(linear_bwd_weight(dG, in, const_cast<float*>(Gd.Wih[l]), dbt, TB, P.in[l], 4 * H, s));
+        hipLaunchKernelGGL(axpy_kernel, dim3(apx_cdiv(4 * H, 256)), dim3(256), 0, s, const_cast<float*>(Gd.bih[l]), dbt, (long)4 * H);
+        hipLaunchKernelGGL(axpy_kernel, dim3(apx_cdiv(4 * H, 256)), dim3(256), 0, s, const_cast<float*>(Gd.bhh[l]), dbt, (long)4 * H);
+        APX_LAUNCH_CHECK();
+        if (T > 1)      // dW_hh += sum_{t >= 1} dG_t^T h_{t-1}
+            APX_TRY(linear_bwd_weight(dG + (size_t)B * 4 * H, Hh, const_cast<float*>(Gd.Whh[l]), nullptr, (long)(T - 1) * B, H, 4 * H, s));
+        if (l) {
+            APX_TRY(linear_bwd_input(dG, P.Wih[l], nullptr, dHx, TB, P.in[l], 4 * H, s));
+            float* tmp = dHa; dHa = dHx; dHx = tmp;
+        }
+    }
+    return APX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ PPO losses
 // One thread per sample.  Produces d(loss)/d(mu) for the policy branch and the mirrored branch, d(loss)/d(v), and
 // the six scalars of update_policy (sums; divided on the host side of the ABI by nothing: already means).

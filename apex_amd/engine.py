@@ -115,6 +115,54 @@ class Mlp:
         return (y, xn, a1, a2) if keep else y
 
 
+class Lstm:
+    """Flat fp32 parameter block of L stacked LSTM cells + a linear head in the state_dict order of Gaussian_LSTM_Actor / LSTM_V
+    (rl/policies/actor.py:218-311, critic.py:236-296)."""
+
+    def __init__(self, D, H, L, O, device):
+        self.D, self.H, self.L, self.O = D, H, L, O
+        self.n = int(_lib.load().apx_lstm_param_count(D, H, L, O))
+        self.params = torch.zeros(self.n, dtype=torch.float32, device=device)
+        self.device = device
+
+    def views(self, flat=None):
+        flat = self.params if flat is None else flat
+        H, out, off = self.H, [], 0
+        shapes = []
+        for l in range(self.L):
+            i = self.D if l == 0 else H
+            shapes += [(4 * H, i), (4 * H, H), (4 * H,), (4 * H,)]
+        shapes += [(self.O, H), (self.O,)]
+        for sh in shapes:
+            k = int(np.prod(sh)); out.append(flat[off:off + k].view(*sh)); off += k
+        return out
+
+    def load_list(self, tensors):
+        for v, t in zip(self.views(), tensors):
+            v.copy_(torch.as_tensor(np.asarray(t), dtype=torch.float32))
+
+    def forward(self, x, hc=None, keep=False):
+        """x [T, B, D] prepared input (or [B, D] for one step with the carried state hc [L, 2, B, H], updated in place)."""
+        _need_gpu(x)
+        step = x.dim() == 2
+        x3 = (x.unsqueeze(0) if step else x).contiguous()
+        T, B, _ = x3.shape
+        lib = _lib.load()
+        save = torch.empty(int(lib.apx_lstm_workspace_floats(T, B, self.H, self.L)), dtype=torch.float32, device=x.device)
+        y = torch.empty(T, B, self.O, dtype=torch.float32, device=x.device)
+        check(lib.apx_lstm_forward(_p(self.params), self.D, self.H, self.L, self.O, _p(x3), T, B, _p(hc), _p(save), _p(y), _stream()))
+        y = y[0] if step else y
+        return (y, x3, save) if keep else y
+
+    def backward(self, grads, x3, save, dy):
+        """grads (flat, same layout) += d(loss)/d(params) for dy [T, B, O]; x3 / save from forward(keep=True) with a zero start state."""
+        T, B, _ = x3.shape
+        lib = _lib.load()
+        scratch = torch.empty(int(lib.apx_lstm_bwd_scratch_floats(T, B, self.D, self.H)), dtype=torch.float32, device=x3.device)
+        check(lib.apx_lstm_backward(_p(self.params), _p(grads), self.D, self.H, self.L, self.O, _p(x3), T, B, _p(save), _p(dy.contiguous()),
+                                    _p(scratch), _stream()))
+
+
 class PPOLearner:
     """Device-resident actor/critic + Adam state; one call = one PPO.update_policy (rl/algos/ppo.py:276-345)."""
 

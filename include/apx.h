@@ -70,6 +70,23 @@ int apx_mlp_forward(const float* params, int D, int H, int O, const float* x, in
                     const int32_t* sign_perm, uint64_t clock_mask, const float* obs_mean, const float* obs_std,
                     float* xn_out, float* act1, float* act2, float* y, int precision, void* stream);
 
+/* Recurrent actor / critic (next row f1): Gaussian_LSTM_Actor (rl/policies/actor.py:218-311) and LSTM_V (rl/policies/critic.py:236-296) =
+ * L stacked nn.LSTMCell(H) + Linear(H, O).  Parameter block in state_dict order: per cell weight_ih[4H,in] weight_hh[4H,H] bias_ih[4H]
+ * bias_hh[4H] (gate order i,f,g,o), then network_out weight[O,H] bias[O].
+ * apx_lstm_forward: x[T,B,D] f32 [dev] = prepared (normalised) inputs of a padded batch of trajectories (actor.py:259-269) or T = 1 for
+ * a rollout step; hc = [L][2][B][H] carried (h, c), read as the start state and overwritten with the final one, or NULL = zero start
+ * (init_hidden_state, actor.py:291-293); save = apx_lstm_workspace_floats(T,B,H,L) floats (gates / cell / hidden states, kept for
+ * apx_lstm_backward); y[T,B,O].
+ * apx_lstm_backward: grads (same layout as params) += d(loss)/d(params) for dy[T,B,O], zero start state; scratch =
+ * apx_lstm_bwd_scratch_floats(T,B,D,H) floats. */
+size_t apx_lstm_param_count(int D, int H, int L, int O);
+size_t apx_lstm_workspace_floats(int T, int64_t B, int H, int L);
+size_t apx_lstm_bwd_scratch_floats(int T, int64_t B, int D, int H);
+int apx_lstm_forward(const float* params, int D, int H, int L, int O, const float* x, int T, int64_t B, float* hc, float* save,
+                     float* y, void* stream);
+int apx_lstm_backward(const float* params, float* grads, int D, int H, int L, int O, const float* x, int T, int64_t B,
+                      const float* save, const float* dy, float* scratch, void* stream);
+
 /* One PPO minibatch step: rl/algos/ppo.py:276-345 PPO.update_policy (feed-forward branch).
  * All device pointers; scalars_out[6] f64 [dev] receives (actor_loss, entropy, critic_loss, ratio.mean, kl.mean,
  * mirror_loss) exactly as update_policy returns them. */
