@@ -592,6 +592,7 @@ extern "C" int apx_lstm_backward(const float* params, float* grads, int D, int H
 struct LossArgs {
     const float *mu, *mum, *v;            // [mb,A], [mb,A] or NULL, [mb]
     const float *act, *ret, *adv, *old_mu; const int64_t* idx;
+    const float* mask;                    // [rows] 0/1 weights of the padded recurrent batch (ppo.py:293-299: actor and critic terms only), or NULL
     const int32_t* act_sp;                // mirror_action as signed permutation, or NULL
     float *dmu, *dmum, *dv;
     double* acc;                          // [8]: actor_loss, ratio, kl, mirror, critic_loss
@@ -616,7 +617,8 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs L) {
             klsum += 0.5f * z * z;
         }
         const float ratio = expf(dlp);
-        const float adv = L.adv[row];
+        const float mk = L.mask ? L.mask[row] : 1.f;
+        const float adv = L.adv[row] * mk;
         const float cpi = ratio * adv;
         const float lo = 1.f - L.clip, hi = 1.f + L.clip;
         const float rc = fminf(fmaxf(ratio, lo), hi);
@@ -648,8 +650,8 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(LossArgs L) {
         }
         acc[3] = (double)L.mirror_coeff * msum * inv_mb / A;
         const float v = L.v[b], r = L.ret[row];
-        acc[4] = 0.5 * (double)(r - v) * (double)(r - v) * inv_mb;
-        L.dv[b] = -(r - v) * inv_mb;
+        acc[4] = 0.5 * (double)(r - v) * (double)(r - v) * inv_mb * mk * mk;
+        L.dv[b] = -(r - v) * inv_mb * mk * mk;
     }
     block_atomic_add<5>(acc, L.acc);
 }
@@ -661,6 +663,23 @@ __global__ void finish_scalars_kernel(const double* acc, float sd, double* out) 
     out[3] = acc[1];
     out[4] = acc[2];
     out[5] = acc[3];
+}
+
+// The loss stage alone, for callers that run their own forward / backward (the recurrent path): rows = T * B entries of a padded batch
+extern "C" int apx_ppo_loss(const float* mu, const float* mum, const float* v, const float* act, const float* ret, const float* adv,
+                            const float* old_mu, const float* mask, const int32_t* act_sign_perm, int64_t rows, int A, float fixed_std,
+                            float clip, float mirror_coeff, float* dmu, float* dmum, float* dv, double* scalars_out, double* acc_ws,
+                            void* stream) {
+    APX_REQUIRE(mu && v && act && ret && adv && old_mu && dmu && dv && scalars_out && acc_ws && rows > 0 && A > 0, "ppo loss arguments");
+    APX_REQUIRE((mum == nullptr) == (act_sign_perm == nullptr) && (mum == nullptr) == (dmum == nullptr), "mirror branch: mum, dmum and act_sign_perm together");
+    hipStream_t s = (hipStream_t)stream;
+    APX_HIP(hipMemsetAsync(acc_ws, 0, 8 * sizeof(double), s));
+    LossArgs L{mu, mum, v, act, ret, adv, old_mu, nullptr, mask, act_sign_perm, dmu, dmum, dv, acc_ws, (long)rows, A, fixed_std, clip, mirror_coeff};
+    hipLaunchKernelGGL(ppo_loss_kernel, dim3(apx_cdiv(rows, 256)), dim3(256), 0, s, L);
+    APX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(finish_scalars_kernel, dim3(1), dim3(1), 0, s, acc_ws, fixed_std, scalars_out);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ clip + Adam
@@ -760,7 +779,7 @@ extern "C" int apx_ppo_minibatch(const apx_ppo_args* a, void* stream) {
     APX_TRY(prep_obs(a->obs, mb, D, a->idx, nullptr, 0, nullptr, nullptr, w.xr, s));   // critic: raw obs (critic.py:66)
     APX_TRY(mlp_forward_impl(a->critic, D, H, 1, w.xr, mb, w.c1, w.c2, w.v, s));
     // losses
-    LossArgs L{w.mu, mirror ? w.mum : nullptr, w.v, a->act, a->ret, a->adv, a->old_mu, a->idx, a->act_sign_perm,
+    LossArgs L{w.mu, mirror ? w.mum : nullptr, w.v, a->act, a->ret, a->adv, a->old_mu, a->idx, nullptr, a->act_sign_perm,
                w.dmu, w.dmum, w.dv, w.acc, mb, A, a->fixed_std, a->clip, a->mirror_coeff};
     hipLaunchKernelGGL(ppo_loss_kernel, dim3(apx_cdiv(mb, 256)), dim3(256), 0, s, L);
     APX_LAUNCH_CHECK();

@@ -231,3 +231,79 @@ class PPOLearner:
                                 scale, self.grad_clip, self.lr, self.eps, self.t, _p(sc[0:1]), _stream()))
         check(lib.apx_clip_adam(_p(self.critic.params), _p(self.critic_m), _p(self.critic_v), _p(self.critic_g),
                                 self.critic.n, scale, self.grad_clip, self.lr, self.eps, self.t, _p(sc[1:2]), _stream()))
+
+
+class RecurrentPPOLearner:
+    """PPO.update_policy in recurrent mode (rl/algos/ppo.py:276-345 on the padded [T_max, B, .] batch of :411-430): Gaussian_LSTM_Actor +
+    LSTM_V through apx_lstm_forward / apx_ppo_loss / apx_lstm_backward / apx_clip_adam.  The old policy is a frozen copy of the actor's
+    parameter block (ppo.py:400 old_policy.load_state_dict)."""
+
+    def __init__(self, obs_dim, act_dim, hidden, layers, device, fixed_std, lr=1e-4, eps=1e-5, clip=0.2, grad_clip=0.05,
+                 mirrored_obs=None, mirrored_acts=None, clock_inds=(46, 47), mirror_coeff=0.4):
+        self.device = device
+        self.actor = Lstm(obs_dim, hidden, layers, act_dim, device)
+        self.critic = Lstm(obs_dim, hidden, layers, 1, device)
+        self.old_actor = Lstm(obs_dim, hidden, layers, act_dim, device)
+        z = lambda m: torch.zeros(m.n, dtype=torch.float32, device=device)
+        self.actor_m, self.actor_v, self.critic_m, self.critic_v = z(self.actor), z(self.actor), z(self.critic), z(self.critic)
+        self.grad_flat = torch.zeros(self.actor.n + self.critic.n, dtype=torch.float32, device=device)
+        self.actor_g, self.critic_g = self.grad_flat[:self.actor.n], self.grad_flat[self.actor.n:]
+        self.obs_mean = torch.zeros(obs_dim, dtype=torch.float32, device=device); self.obs_std = torch.ones(obs_dim, dtype=torch.float32, device=device)
+        self.fixed_std, self.lr, self.eps, self.clip, self.grad_clip, self.mirror_coeff = float(fixed_std), lr, eps, clip, grad_clip, mirror_coeff
+        self.t = 0
+        self.act_sp = None
+        if mirrored_obs is not None:
+            sp = signed_perm_from_mirror(mirrored_obs)
+            self.obs_src = torch.as_tensor(np.where(sp >= 0, sp, -sp - 1), dtype=torch.long, device=device)
+            self.obs_sgn = torch.as_tensor(np.where(sp >= 0, 1.0, -1.0), dtype=torch.float32, device=device)
+            self.act_sp = torch.as_tensor(signed_perm_from_mirror(mirrored_acts), device=device)
+            self.clock_cols = [int(c) for c in clock_inds]
+        self._scal = torch.zeros(6, dtype=torch.float64, device=device)
+        self._acc = torch.zeros(8, dtype=torch.float64, device=device)
+
+    def sync_old(self):
+        self.old_actor.params.copy_(self.actor.params)
+
+    def mirror_obs(self, obs):
+        """SymmetricEnv.mirror_clock_observation (rl/envs/wrappers.py:59-67) on [..., D] raw observations."""
+        m = obs.index_select(-1, self.obs_src) * self.obs_sgn
+        for c in self.clock_cols:
+            m[..., c] = torch.sin(torch.asin(m[..., c]) + np.pi)
+        return m
+
+    def minibatch(self, obs, act, ret, adv, mask, mirror=True, grad_only=False):
+        """obs [T, B, D], act [T, B, A], ret / adv / mask [T, B, 1] padded like torch's pad_sequence.  Returns the six scalars (device f64)."""
+        lib = _lib.load()
+        T, B, _ = obs.shape
+        A = self.actor.O
+        norm = lambda o: ((o - self.obs_mean) / self.obs_std).contiguous()
+        xn = norm(obs)
+        use_mirror = mirror and self.act_sp is not None
+        old_mu = self.old_actor.forward(xn)
+        mu, x3, save = self.actor.forward(xn, keep=True)
+        if use_mirror:
+            mum, xm3, save_m = self.actor.forward(norm(self.mirror_obs(obs)), keep=True)
+        v, xc3, save_c = self.critic.forward(obs.contiguous(), keep=True)            # LSTM_V in train mode: raw inputs (critic.py:262-263)
+        rows = T * B
+        dmu = torch.empty(rows, A, dtype=torch.float32, device=self.device); dv = torch.empty(rows, dtype=torch.float32, device=self.device)
+        dmum = torch.empty(rows, A, dtype=torch.float32, device=self.device) if use_mirror else None
+        check(lib.apx_ppo_loss(_p(mu), _p(mum) if use_mirror else None, _p(v), _p(act.contiguous()), _p(ret.contiguous()), _p(adv.contiguous()),
+                               _p(old_mu), _p(mask.contiguous()) if mask is not None else None, _p(self.act_sp) if use_mirror else None, rows, A,
+                               self.fixed_std, self.clip, self.mirror_coeff, _p(dmu), _p(dmum), _p(dv), _p(self._scal), _p(self._acc), _stream()))
+        self.grad_flat.zero_()
+        self.actor.backward(self.actor_g, x3, save, dmu.view(T, B, A))
+        if use_mirror:
+            self.actor.backward(self.actor_g, xm3, save_m, dmum.view(T, B, A))
+        self.critic.backward(self.critic_g, xc3, save_c, dv.view(T, B, 1))
+        if not grad_only:
+            self.apply_grads()
+        return self._scal
+
+    def apply_grads(self, scale=1.0):
+        lib = _lib.load()
+        self.t += 1
+        sc = torch.zeros(2, dtype=torch.float64, device=self.device)
+        check(lib.apx_clip_adam(_p(self.actor.params), _p(self.actor_m), _p(self.actor_v), _p(self.actor_g), self.actor.n, scale, self.grad_clip,
+                                self.lr, self.eps, self.t, _p(sc[0:1]), _stream()))
+        check(lib.apx_clip_adam(_p(self.critic.params), _p(self.critic_m), _p(self.critic_v), _p(self.critic_g), self.critic.n, scale,
+                                self.grad_clip, self.lr, self.eps, self.t, _p(sc[1:2]), _stream()))

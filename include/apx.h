@@ -87,6 +87,15 @@ int apx_lstm_forward(const float* params, int D, int H, int L, int O, const floa
 int apx_lstm_backward(const float* params, float* grads, int D, int H, int L, int O, const float* x, int T, int64_t B,
                       const float* save, const float* dy, float* scratch, void* stream);
 
+/* The loss stage of PPO.update_policy alone (rl/algos/ppo.py:284-318,338-345) for callers that run their own forward / backward (the
+ * recurrent path): rows = T*B entries of a padded batch, mu / mum (mirrored branch, NULL = no mirror loss) [rows,A], v [rows], act
+ * [rows,A], ret / adv / mask [rows] (mask NULL = all ones; it weights the actor and critic terms only, every mean is over ALL rows like
+ * the reference's plain .mean() over the padded tensor), old_mu [rows,A].  Writes d(loss)/d(mu), d(loss)/d(mum), d(loss)/d(v) and the
+ * six scalars (actor loss, entropy, critic loss, ratio mean, KL mean, mirror loss) f64 [dev]; acc_ws = 8 doubles [dev]. */
+int apx_ppo_loss(const float* mu, const float* mum, const float* v, const float* act, const float* ret, const float* adv,
+                 const float* old_mu, const float* mask, const int32_t* act_sign_perm, int64_t rows, int A, float fixed_std,
+                 float clip, float mirror_coeff, float* dmu, float* dmum, float* dv, double* scalars_out, double* acc_ws, void* stream);
+
 /* One PPO minibatch step: rl/algos/ppo.py:276-345 PPO.update_policy (feed-forward branch).
  * All device pointers; scalars_out[6] f64 [dev] receives (actor_loss, entropy, critic_loss, ratio.mean, kl.mean,
  * mirror_loss) exactly as update_policy returns them. */

@@ -199,3 +199,28 @@ def test_lstm_forward_backward_golden_g18(dev, golden_dir):
             steps = torch.stack([net.forward(inp[t, 2:3].contiguous(), hc=hc) for t in range(inp.shape[0])])
             np.testing.assert_allclose(steps[:, 0].cpu().numpy(), g["mu_step_env2"], rtol=2e-5, atol=2e-6)
             np.testing.assert_allclose(steps[:, 0].cpu().numpy(), y[:, 2].cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_recurrent_update_policy_golden_g19(dev, golden_dir):
+    """G19 (next row f1): the reference's PPO.update_policy in recurrent mode on padded batches (4 trajectories of different lengths, mirror
+    loss on), two consecutive steps: six scalars per step (masked actor / critic terms, unmasked ratio / KL / mirror means over the padded
+    tensor) and the parameters after each step."""
+    import os
+    from apex_amd import engine
+    from apex_amd.vecenv import MIRRORED_OBS, MIRRORED_ACTS, CLOCK_INDS
+    g = np.load(os.path.join(golden_dir, "g19_lstm_update.npz"))
+    H = int(g["hidden"])
+    L = engine.RecurrentPPOLearner(50, 10, H, 2, dev, float(g["fixed_std"]), mirrored_obs=MIRRORED_OBS, mirrored_acts=MIRRORED_ACTS, clock_inds=CLOCK_INDS)
+    L.actor.load_list([g["actor0." + str(k)] for k in g["actor_keys"]])
+    L.old_actor.load_list([g["old." + str(k)] for k in g["actor_keys"]])
+    L.critic.load_list([g["critic0." + str(k)] for k in g["critic_keys"]])
+    L.obs_mean.copy_(torch.tensor(g["obs_mean"])); L.obs_std.copy_(torch.tensor(g["obs_std"]))
+    t = lambda a: torch.tensor(a, device=dev)
+    for s in range(2):
+        p = "s%d_" % s
+        scal = L.minibatch(t(g[p + "obs"]), t(g[p + "act"]), t(g[p + "ret"]), t(g[p + "adv"]), t(g[p + "mask"])).cpu().numpy()
+        np.testing.assert_allclose(scal, g["scalars"][s], rtol=2e-4, atol=2e-6, err_msg="step %d" % s)
+        for nm, net, keys in (("actor", L.actor, g["actor_keys"]), ("critic", L.critic, g["critic_keys"])):
+            for k, v in zip(keys, net.views()):
+                d = np.abs(v.cpu().numpy() - g[p + nm + "." + str(k)])
+                assert (d > 3e-6).mean() < 5e-3 and d.max() < 4.1e-4, (s, nm, str(k), (d > 3e-6).mean(), d.max())
