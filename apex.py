@@ -172,8 +172,8 @@ def main(argv=None):
         print("Usage: python apex.py ppo [flags] | python apex.py eval --path RUN_DIR [--speed S]   (only the PPO / Cassie-v0 path is built; see DESIGN.md)")
         return 2
     args = build_parser().parse_args(argv[1:])
-    if args.env_name not in ("Cassie-v0", "CassieTraj-v0") or args.recurrent or args.learn_stddev:
-        raise NotImplementedError("only Cassie-v0 / CassieTraj-v0 feed-forward PPO with fixed std is built (SURVEY.md §8)")
+    if args.env_name not in ("Cassie-v0", "CassieTraj-v0") or args.learn_stddev:
+        raise NotImplementedError("only Cassie-v0 / CassieTraj-v0 PPO (feed-forward or --recurrent) with fixed std is built (SURVEY.md §8)")
     from apex_amd.log import parse_previous
     from apex_amd.ppo import run_experiment
     args = parse_previous(args)

@@ -304,7 +304,13 @@ def run_experiment(args):
                        ik_baseline=args.ik_baseline)
     logger = create_logger(args) if rank == 0 else None
     a = dict(vars(args)); a["mirror"] = args.mirror
-    algo = PPO(a, logger.dir if logger else "/tmp/apx_unused", env, rank=rank, world_size=world, group=group)
+    if getattr(args, "recurrent", False):
+        from .ppo_recurrent import RecurrentPPO
+        a.setdefault("std_dev", -2.0)
+        a["std_dev"] = -2.0                                   # ppo.py:537: recurrent policies are built with fixed_std = exp(-2)
+        algo = RecurrentPPO(a, logger.dir if logger else "/tmp/apx_unused", env, rank=rank, world_size=world, group=group)
+    else:
+        algo = PPO(a, logger.dir if logger else "/tmp/apx_unused", env, rank=rank, world_size=world, group=group)
     if args.previous is not None:
         algo.policy = torch.load(os.path.join(args.previous, "actor.pt"), weights_only=False)
         algo.critic = torch.load(os.path.join(args.previous, "critic.pt"), weights_only=False)

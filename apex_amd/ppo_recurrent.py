@@ -1,0 +1,213 @@
+"""Recurrent PPO for the batched engine: the reference's `--recurrent` path (rl/algos/ppo.py:139-186 rollout
+with per-episode hidden state, :411-430 minibatches of whole trajectories padded to [T_max, B, .] with a mask, :276-345 update) with
+Gaussian_LSTM_Actor / LSTM_V in HIP (apex_amd.engine.Lstm, RecurrentPPOLearner).
+
+Rollout: N envs in lock step for T steps; the hidden state of an env is zeroed when its episode ends (ppo.py:164-168).  Every iteration
+starts from a reset of all envs, so that every trajectory in the batch starts at zero hidden state exactly like the padded training pass
+assumes; the last (unfinished) trajectory of a column is cut at the grid end and bootstrapped with V(s_T) like a time-limit truncation.
+A minibatch is `minibatch_size` TRAJECTORIES (ppo.py:412-413), not steps."""
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import dist as adist
+from . import engine
+from .vecenv import MIRRORED_ACTS, MIRRORED_OBS, CLOCK_INDS
+
+
+class RecurrentPPO:
+    def __init__(self, args, save_path, env, rank=0, world_size=1, group=None, hidden=128, layers=2):
+        self.gamma = args["gamma"]; self.lr = args["lr"]; self.eps = args["eps"]; self.clip = args["clip"]
+        self.minibatch_size = args["minibatch_size"]; self.epochs = args["epochs"]
+        self.num_steps = args["num_steps"]; self.max_traj_len = args["max_traj_len"]
+        self.grad_clip = args["max_grad_norm"]; self.mirror = args.get("mirror", True)
+        self.fixed_std = float(np.exp(args.get("std_dev", -2.0)))                  # ppo.py:537: recurrent policies use exp(-2)
+        self.env_name = args.get("env_name", "Cassie-v0")
+        self.save_path, self.env = save_path, env
+        self.rank, self.world, self.group = rank, world_size, group
+        self.device, self.N = env.device, env.n_envs
+        self.T = adist.rollout_len(self.num_steps, self.N, self.world)
+        self.H, self.L = hidden, layers
+        self.learner = engine.RecurrentPPOLearner(50, 10, hidden, layers, self.device, self.fixed_std, lr=self.lr, eps=self.eps, clip=self.clip,
+                                                  grad_clip=self.grad_clip, mirrored_obs=MIRRORED_OBS if self.mirror else None,
+                                                  mirrored_acts=MIRRORED_ACTS if self.mirror else None, clock_inds=CLOCK_INDS)
+        self.gen = torch.Generator(device=self.device); self.gen.manual_seed(int(args.get("seed", 0)) * 1000003 + rank)
+        T, N = self.T, self.N
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.b_obs = torch.zeros(T, N, 50, **f32); self.b_act = torch.zeros(T, N, 10, **f32)
+        self.b_rew = torch.zeros(T, N, **f32); self.b_val = torch.zeros(T, N, **f32); self.b_boot = torch.zeros(T, N, **f32)
+        self.b_done = torch.zeros(T, N, dtype=torch.uint8, device=self.device); self.b_fin = torch.zeros(T, N, 50, **f32)
+        self.b_end = torch.zeros(T, N, dtype=torch.uint8, device=self.device)
+        self.total_steps = 0; self.highest_reward = -1
+        self.noise_fn = None; self.perm_fn = None; self.trace = None              # parity hooks, as in apex_amd.ppo.PPO
+
+    # ------------------------------------------------------------------------------------------ networks / checkpoints
+    def init_networks(self, seed):
+        from rl.policies.actor import Gaussian_LSTM_Actor
+        from rl.policies.critic import LSTM_V
+        torch.manual_seed(seed)
+        self.policy = Gaussian_LSTM_Actor(50, 10, layers=(self.H,) * self.L, fixed_std=self.fixed_std, env_name=self.env_name)
+        self.critic = LSTM_V(50, layers=(self.H,) * self.L)
+        self.upload()
+
+    def upload(self):
+        self.learner.actor.load_list([p.detach().numpy() for p in self.policy.parameters()])
+        self.learner.critic.load_list([p.detach().numpy() for p in self.critic.parameters()])
+        if torch.is_tensor(self.policy.obs_mean):
+            self.learner.obs_mean.copy_(self.policy.obs_mean); self.learner.obs_std.copy_(self.policy.obs_std)
+
+    def download(self):
+        with torch.no_grad():
+            for p, v in zip(self.policy.parameters(), self.learner.actor.views()):
+                p.copy_(v.cpu())
+            for p, v in zip(self.critic.parameters(), self.learner.critic.views()):
+                p.copy_(v.cpu())
+        self.policy.obs_mean = self.learner.obs_mean.cpu().clone(); self.policy.obs_std = self.learner.obs_std.cpu().clone()
+        self.critic.obs_mean = self.policy.obs_mean; self.critic.obs_std = self.policy.obs_std
+
+    def save(self):
+        os.makedirs(self.save_path, exist_ok=True)
+        self.download()
+        torch.save(self.policy, os.path.join(self.save_path, "actor.pt")); torch.save(self.critic, os.path.join(self.save_path, "critic.pt"))
+
+    def normalization_params(self, iters, noise_std=1.0):
+        """get_normalization_params (rl/envs/normalize.py:11-48) with the recurrent policy stepping its hidden state."""
+        L = self.learner
+        steps = max(iters // (self.N * self.world), 50)
+        obs = self.env.reset()
+        hc = torch.zeros(self.L, 2, self.N, self.H, device=self.device)
+        s = torch.zeros(50, dtype=torch.float64, device=self.device); ss = torch.zeros_like(s); n = 0
+        for _ in range(steps):
+            s += obs.double().sum(0); ss += (obs.double() ** 2).sum(0); n += obs.shape[0]
+            mu = L.actor.forward(((obs - L.obs_mean) / L.obs_std).contiguous(), hc=hc)
+            obs, _, done, _ = self.env.step(mu + torch.randn(mu.shape, device=self.device, generator=self.gen) * noise_std)
+            hc[:, :, done != 0] = 0
+        mom = torch.cat([s, ss, torch.tensor([float(n)], dtype=torch.float64, device=self.device)])
+        if self.group is not None:
+            torch.distributed.all_reduce(mom, group=self.group)
+        mean = mom[:50] / mom[100]
+        var = (mom[50:100] / mom[100] - mean * mean).clamp_min(0)
+        L.obs_mean.copy_(mean.float()); L.obs_std.copy_(torch.sqrt(var + 1e-8).float())
+
+    # ------------------------------------------------------------------------------------------ sampling
+    @torch.no_grad()
+    def sample(self):
+        L, env, T, N = self.learner, self.env, self.T, self.N
+        obs = env.reset()
+        hc_a = torch.zeros(self.L, 2, N, self.H, device=self.device); hc_c = torch.zeros_like(hc_a)
+        noise = torch.zeros(N, 10, device=self.device)
+        norm = lambda o: ((o - L.obs_mean) / L.obs_std).contiguous()
+        self.b_boot.zero_()
+        for t in range(T):
+            self.b_obs[t].copy_(obs)
+            mu = L.actor.forward(norm(obs), hc=hc_a)
+            self.b_val[t].copy_(L.critic.forward(obs.contiguous(), hc=hc_c).view(-1))
+            if self.noise_fn is None:
+                noise.normal_(generator=self.gen)
+            else:
+                self.noise_fn(t, noise)
+            torch.add(mu, noise, alpha=self.fixed_std, out=self.b_act[t])
+            obs, _, _, _ = env.step(self.b_act[t], out=(obs, self.b_rew[t], self.b_done[t], self.b_fin[t]))
+            tr = self.b_done[t] == 2
+            last = t == T - 1
+            if bool(tr.any()) or last:                      # V(s') with the critic's carried state (ppo.py:183-184), without advancing it
+                rows = tr if not last else (tr | (self.b_done[t] == 0))
+                src = torch.where((self.b_done[t] != 0).view(N, 1), self.b_fin[t], obs)      # the episode's own next observation
+                v_next = L.critic.forward(src.contiguous(), hc=hc_c.clone()).view(-1)
+                self.b_boot[t] = torch.where(rows, v_next, torch.zeros_like(v_next))
+            ended = self.b_done[t] != 0
+            hc_a[:, :, ended] = 0; hc_c[:, :, ended] = 0    # init_hidden_state at every episode start (ppo.py:164-168)
+        self.b_end.copy_((self.b_done != 0).to(torch.uint8)); self.b_end[T - 1] = 1      # the grid end cuts the last trajectory of every column
+        ret = engine.returns_scan(self.b_rew, self.b_end, self.b_boot, torch.zeros(N, device=self.device), self.gamma)
+        return ret
+
+    def trajectories(self):
+        """(column, t0, t1) of every trajectory in the grid, in (column, time) order -> int64 [n_traj, 3] on the host."""
+        end = self.b_end.t().contiguous().cpu().numpy()                              # [N, T]
+        out = []
+        for n in range(self.N):
+            t0 = 0
+            for t1 in np.nonzero(end[n])[0]:
+                out.append((n, t0, int(t1) + 1)); t0 = int(t1) + 1
+        return np.array(out, dtype=np.int64)
+
+    def padded_index(self, trajs):
+        """Flat grid indices t * N + n of a set of trajectories as a [T_max, B] tensor, -1 where padded (torch's pad_sequence layout)."""
+        lens = trajs[:, 2] - trajs[:, 1]
+        Tm, B = int(lens.max()), len(trajs)
+        idx = np.full((Tm, B), -1, dtype=np.int64)
+        for b, (n, t0, t1) in enumerate(trajs):
+            idx[: t1 - t0, b] = np.arange(t0, t1) * self.N + n
+        return torch.as_tensor(idx, device=self.device)
+
+    # ------------------------------------------------------------------------------------------ optimisation
+    def update(self, ret):
+        L, T, N = self.learner, self.T, self.N
+        flat = lambda x, d: x.view(T * N, d)
+        val = self.b_val.view(-1); retf = ret.view(-1)
+        adv = engine.normalize_advantages(retf, val, self.eps, group=self.group)
+        trajs = self.trajectories()
+        mb = self.minibatch_size or len(trajs)
+        L.sync_old()
+        losses, kl_last, epochs_run = None, 0.0, 0
+        for epoch in range(self.epochs):
+            if self.perm_fn is not None:
+                order = np.asarray(self.perm_fn(epoch))
+            else:
+                order = torch.randperm(len(trajs), device=self.device, generator=self.gen).cpu().numpy()      # SubsetRandomSampler over trajectories
+            acc = torch.zeros(6, dtype=torch.float64, device=self.device); nb = 0
+            for k in range(0, len(order), mb):                                   # BatchSampler(..., drop_last=False), ppo.py:413
+                idx = self.padded_index(trajs[order[k:k + mb]])
+                valid = idx >= 0
+                gi = idx.clamp(min=0).view(-1)
+                pick = lambda x, d: (flat(x, d).index_select(0, gi) * valid.view(-1, 1)).view(idx.shape[0], idx.shape[1], d)
+                scal = L.minibatch(pick(self.b_obs, 50), pick(self.b_act, 10), pick(retf, 1), pick(adv, 1), valid.float().unsqueeze(-1),
+                                   mirror=self.mirror, grad_only=self.world > 1)
+                if self.world > 1:
+                    adist.allreduce_mean_(L.grad_flat, group=self.group, world=self.world)
+                    L.apply_grads()
+                acc += scal; nb += 1
+                if self.trace is not None:
+                    self.trace.append(scal.clone())
+            losses = (acc / max(nb, 1)).cpu().numpy()
+            kl_last = float(scal[4]); epochs_run += 1
+            if kl_last > 0.02:
+                break
+        return losses, kl_last, epochs_run
+
+    def iteration(self):
+        t0 = time.time()
+        ret = self.sample()
+        torch.cuda.synchronize(self.device); t1 = time.time()
+        losses, kl, epochs_run = self.update(ret)
+        torch.cuda.synchronize(self.device); t2 = time.time()
+        ended = self.b_done != 0
+        from .ppo import episode_stats
+        z = torch.zeros(self.N, device=self.device)
+        ep_rets, ep_lens, _, _ = episode_stats(self.b_rew, ended, z, z)
+        steps = self.T * self.N * self.world
+        self.total_steps += steps
+        return dict(steps=steps, sample_time=t1 - t0, optimize_time=t2 - t1, losses=losses, kl=kl, epochs=epochs_run, ep_returns=ep_rets, ep_lens=ep_lens)
+
+    def train(self, n_itr, logger=None):
+        for itr in range(n_itr):
+            out = self.iteration()
+            er, el = out["ep_returns"], out["ep_lens"]
+            avg_ret = float(er.mean()) if er.numel() else float("nan"); avg_len = float(el.mean()) if el.numel() else float("nan")
+            if self.rank == 0:
+                print("********** Iteration {} ************".format(itr))
+                print("timesteps in batch: %i  sample %.2fs  optimize %.2fs  (%.0f env-steps/s)  mean eplen %.1f" % (
+                    out["steps"], out["sample_time"], out["optimize_time"], out["steps"] / (out["sample_time"] + out["optimize_time"]), avg_len))
+                print(" ".join("%g" % x for x in out["losses"]))
+                if logger is not None:
+                    ml = out["losses"]
+                    for tag, v in (("Test/Return", avg_ret), ("Train/Return", avg_ret), ("Train/Mean Eplen", avg_len), ("Train/Mean KL Div", ml[4]),
+                                   ("Train/Mean Entropy", ml[1]), ("Misc/Critic Loss", ml[2]), ("Misc/Actor Loss", ml[0]), ("Misc/Mirror Loss", ml[5]),
+                                   ("Misc/Timesteps", self.total_steps), ("Misc/Sample Times", out["sample_time"]),
+                                   ("Misc/Optimize Times", out["optimize_time"]), ("Misc/Evaluation Times", 0.0), ("Misc/Termination Threshold", 0.0)):
+                        logger.add_scalar(tag, v, itr)
+                if avg_ret == avg_ret and self.highest_reward < avg_ret:
+                    self.highest_reward = avg_ret
+                    self.save()

@@ -49,3 +49,46 @@ class FF_V(Critic):
 
     def act(self, inputs):
         return self(inputs)
+
+
+class LSTM_V(Critic):
+    """Recurrent critic with the reference's pickle surface (rl/policies/critic.py:236-296): critic_layers = stacked nn.LSTMCell,
+    network_out; raw inputs in training mode."""
+
+    def __init__(self, input_dim, layers=(128, 128), env_name="NOT SET", normc_init=True):
+        super().__init__()
+        self.critic_layers = nn.ModuleList()
+        self.critic_layers += [nn.LSTMCell(input_dim, layers[0])]
+        for i in range(len(layers) - 1):
+            self.critic_layers += [nn.LSTMCell(layers[i], layers[i + 1])]
+        self.network_out = nn.Linear(layers[-1], 1)
+        self.init_hidden_state()
+        self.is_recurrent = True
+        self.env_name = env_name
+        self.obs_std = 1.0
+        self.obs_mean = 0.0
+        if normc_init:
+            self.initialize_parameters()
+
+    def get_hidden_state(self):
+        return self.hidden, self.cells
+
+    def init_hidden_state(self, batch_size=1):
+        self.hidden = [torch.zeros(batch_size, l.hidden_size) for l in self.critic_layers]
+        self.cells = [torch.zeros(batch_size, l.hidden_size) for l in self.critic_layers]
+
+    def _step(self, x):
+        for idx, layer in enumerate(self.critic_layers):
+            self.hidden[idx], self.cells[idx] = layer(x, (self.hidden[idx], self.cells[idx]))
+            x = self.hidden[idx]
+        return self.network_out(x)
+
+    def forward(self, state):
+        if self.training is False:
+            state = (state - self.obs_mean) / self.obs_std
+        if state.dim() == 3:
+            self.init_hidden_state(batch_size=state.size(1))
+            return torch.stack([self._step(s_t) for s_t in state])
+        flat = state.dim() == 1
+        x = self._step(state.view(1, -1) if flat else state)
+        return x.view(-1) if flat else x
