@@ -112,3 +112,22 @@ def test_episode_stats_scan_matches_per_step_bookkeeping():
         torch.testing.assert_close(r1.double(), acc_r, rtol=1e-6, atol=1e-6)
         torch.testing.assert_close(l1.double(), acc_l, rtol=0, atol=0)
         ret0, len0 = r1, l1
+
+
+def test_g18_lstm_checkpoint_classes_match_the_reference(golden_dir):
+    """This repo's Gaussian_LSTM_Actor / LSTM_V (checkpoint classes of the recurrent path) have the reference's state_dict keys and
+    reproduce its outputs on golden G18 (padded batch from zero state, raw inputs for the critic in train mode)."""
+    import os
+    from rl.policies.actor import Gaussian_LSTM_Actor
+    from rl.policies.critic import LSTM_V
+    g = np.load(os.path.join(golden_dir, "g18_lstm.npz"))
+    a = Gaussian_LSTM_Actor(50, 10, layers=(128, 128), fixed_std=np.exp(-2.0)); c = LSTM_V(50, layers=(128, 128))
+    assert list(a.state_dict().keys()) == [str(k) for k in g["actor_keys"]] and list(c.state_dict().keys()) == [str(k) for k in g["critic_keys"]]
+    a.load_state_dict({str(k): torch.tensor(g["actor." + str(k)]) for k in g["actor_keys"]})
+    c.load_state_dict({str(k): torch.tensor(g["critic." + str(k)]) for k in g["critic_keys"]})
+    a.obs_mean = torch.tensor(g["obs_mean"]); a.obs_std = torch.tensor(g["obs_std"]); c.train()
+    x = torch.tensor(g["x"])
+    np.testing.assert_allclose(a(x).detach().numpy(), g["mu"], atol=1e-6); np.testing.assert_allclose(c(x).detach().numpy(), g["v"], atol=1e-6)
+    a.init_hidden_state()
+    steps = torch.stack([a(x[t, 2], deterministic=True) for t in range(x.shape[0])]).detach().numpy()
+    np.testing.assert_allclose(steps, g["mu_step_env2"], atol=1e-6)
