@@ -109,7 +109,7 @@ class RecurrentPPO:
             else:
                 self.noise_fn(t, noise)
             torch.add(mu, noise, alpha=self.fixed_std, out=self.b_act[t])
-            obs, _, _, _ = env.step(self.b_act[t], out=(obs, self.b_rew[t], self.b_done[t], self.b_fin[t]))
+            env.step(self.b_act[t], out=(obs, self.b_rew[t], self.b_done[t], self.b_fin[t]))      # writes the next observation into `obs`
             tr = self.b_done[t] == 2
             last = t == T - 1
             if bool(tr.any()) or last:                      # V(s') with the critic's carried state (ppo.py:183-184), without advancing it

@@ -314,3 +314,55 @@ def test_recurrent_ppo_iteration_on_the_hip_env(dev, tmp_path):
     assert type(pol).__name__ == "Gaussian_LSTM_Actor" and pol.is_recurrent
     pol.init_hidden_state()
     assert pol(torch.zeros(50), deterministic=True).shape[-1] == 10
+
+
+def test_whole_train_loop_recurrent_golden_g15d(dev, golden_dir):
+    """G15d: the reference's whole PPO.train in RECURRENT mode (LSTM 2 x 32, 2 iterations, 16 trajectories per batch, minibatches of 4
+    whole trajectories padded by pad_sequence, mirror loss, truncation bootstrap with the critic's carried hidden state) on the toy env,
+    replayed through apex_amd.ppo_recurrent.RecurrentPPO with the captured noise / trajectory-order streams."""
+    import os
+    from apex_amd.ppo_recurrent import RecurrentPPO
+    from rl.policies.actor import Gaussian_LSTM_Actor
+    from rl.policies.critic import LSTM_V
+    g = np.load(os.path.join(golden_dir, "g15d_ppo_train_recurrent.npz"))
+    H, mb = int(g["hidden"]), int(g["minibatch"])
+    env = _ToyVecEnv(dev, g["lens"], g["max_traj_len"])
+    args = dict(gamma=float(g["gamma"]), lam=0.95, lr=float(g["lr"]), eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=mb, epochs=int(g["epochs"]),
+                num_steps=int(g["num_steps"]), max_traj_len=int(g["max_traj_len"]), max_grad_norm=0.05, mirror=True, seed=0,
+                std_dev=float(np.log(g["fixed_std"])))
+    algo = RecurrentPPO(args, "/tmp/apx_test_unused", env, hidden=H, layers=2)
+    algo.policy = Gaussian_LSTM_Actor(50, 10, layers=(H, H), fixed_std=float(g["fixed_std"])); algo.critic = LSTM_V(50, layers=(H, H))
+    algo.policy.load_state_dict({k: torch.as_tensor(g["actor0." + k]) for k in algo.policy.state_dict()})
+    algo.critic.load_state_dict({k: torch.as_tensor(g["critic0." + k]) for k in algo.critic.state_dict()})
+    algo.policy.obs_mean = torch.as_tensor(g["obs_mean"]); algo.policy.obs_std = torch.as_tensor(g["obs_std"])
+    algo.upload()
+    sigma = float(g["fixed_std"])
+    for it in range(int(g["n_itr"])):
+        p = "it%d." % it
+        B = len(g[p + "rewards"])
+        assert B == algo.T
+        env.ks = [int(g[p + "k0"]) + 1 + j for j in range(len(g[p + "ep_lens"]))]
+        noise = torch.as_tensor((g[p + "actions"].astype(np.float64) - g[p + "mu"]) / sigma, dtype=torch.float32, device=dev)
+        algo.noise_fn = lambda t, out: out.copy_(noise[t].view(1, 10))
+        order = g[p + "idx"]
+        algo.perm_fn = lambda e: order[e]
+        algo.trace = []
+        ret = algo.sample()
+        ends = np.nonzero(algo.b_end.view(-1).cpu().numpy())[0] + 1
+        assert np.array_equal(ends, g[p + "traj_idx"][1:])                                  # bit-exact episode-step indices
+        assert np.array_equal(algo.trajectories()[:, 2] - algo.trajectories()[:, 1], g[p + "ep_lens"])
+        np.testing.assert_allclose(algo.b_obs.view(B, 50).cpu().numpy(), g[p + "states"], rtol=1e-5, atol=3e-6)
+        np.testing.assert_allclose(algo.b_act.view(B, 10).cpu().numpy(), g[p + "actions"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(algo.b_val.view(B).cpu().numpy(), g[p + "values"], rtol=1e-4, atol=2e-5)      # hidden state carried per episode
+        np.testing.assert_allclose(ret.view(B).cpu().numpy(), g[p + "returns"], rtol=1e-4, atol=2e-5)           # incl. carried-state bootstrap
+        losses, kl, epochs_run = algo.update(ret)
+        assert epochs_run == int(g[p + "epochs_run"])
+        scal = torch.stack(algo.trace).cpu().numpy().reshape(epochs_run, -1, 6)
+        ref = g[p + "scal"]
+        assert scal.shape == ref.shape
+        for c, (rt, at) in enumerate([(2e-4, 5e-6), (1e-6, 0), (2e-4, 0), (1e-4, 0), (5e-3, 1e-7), (1e-3, 1e-8)]):
+            np.testing.assert_allclose(scal[..., c], ref[..., c], rtol=rt, atol=at, err_msg="scalar %d itr %d" % (c, it))
+        for nm, views, ref_p in (("actor", algo.learner.actor.views(), algo.policy), ("critic", algo.learner.critic.views(), algo.critic)):
+            for k, v in zip(ref_p.state_dict(), views):
+                d = np.abs(v.cpu().numpy() - g[p + nm + "." + k])
+                assert (d > 5e-6).mean() < 1e-2 and d.max() < 5e-4, (it, nm, k, (d > 5e-6).mean(), d.max())

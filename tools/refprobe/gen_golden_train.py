@@ -56,16 +56,21 @@ class FakeLogger:
     def add_scalar(self, name, val, itr): self.rows.append((name, float(val), int(itr)))
 
 
-def main(name="g15b_ppo_train", lr=1e-4, H=256, n_itr=3, seed=151):
+def main(name="g15b_ppo_train", lr=1e-4, H=256, n_itr=3, seed=151, recurrent=False, mb=64):
     torch.manual_seed(seed); np.random.seed(seed)
     ToyEnv.k = 0; ToyEnv.log = []
-    mb, epochs = 64, 3
+    epochs = 3
     args = dict(env_name="Cassie-v0", gamma=0.99, lam=0.95, lr=lr, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=mb,
                 epochs=epochs, num_steps=2 * PERIOD, max_traj_len=MAX_TRAJ, use_gae=True, num_procs=1, max_grad_norm=0.05,
-                recurrent=False)
+                recurrent=recurrent)
     os.makedirs("/tmp/g15b", exist_ok=True)
     algo = PPO(args, "/tmp/g15b")
-    policy = Gaussian_FF_Actor(50, 10, layers=(H, H), fixed_std=np.exp(-1.5)); critic = FF_V(50, layers=(H, H))
+    if recurrent:
+        from rl.policies.actor import Gaussian_LSTM_Actor
+        from rl.policies.critic import LSTM_V
+        policy = Gaussian_LSTM_Actor(50, 10, layers=(H, H), fixed_std=np.exp(-2.0)); critic = LSTM_V(50, layers=(H, H))
+    else:
+        policy = Gaussian_FF_Actor(50, 10, layers=(H, H), fixed_std=np.exp(-1.5)); critic = FF_V(50, layers=(H, H))
     rs = np.random.RandomState(7)
     policy.obs_mean = torch.Tensor(rs.uniform(-0.2, 0.2, 50)); policy.obs_std = torch.Tensor(rs.uniform(0.7, 1.4, 50))
     critic.obs_mean, critic.obs_std = policy.obs_mean, policy.obs_std
@@ -85,7 +90,11 @@ def main(name="g15b_ppo_train", lr=1e-4, H=256, n_itr=3, seed=151):
         if not deterministic:                    # the training batch (the evaluation pass asks for deterministic=True)
             st = torch.Tensor(np.array(buf.states)).view(-1, 50)
             with torch.no_grad():
-                mu = pol(st, deterministic=True).numpy()
+                if recurrent:      # means of the sampling policy: every trajectory from zero hidden state, like the rollout
+                    ti = buf.traj_idx
+                    mu = np.concatenate([pol(st[ti[j]:ti[j + 1]].unsqueeze(1), deterministic=True).numpy()[:, 0] for j in range(len(ti) - 1)])
+                else:
+                    mu = pol(st, deterministic=True).numpy()
             rec["batches"].append(dict(states=st.numpy(), actions=np.array(buf.actions, dtype=np.float32).reshape(-1, 10), mu=mu,
                                        rewards=np.array(buf.rewards, dtype=np.float64).reshape(-1),
                                        values=np.array(buf.values, dtype=np.float32).reshape(-1),
@@ -133,7 +142,7 @@ def main(name="g15b_ppo_train", lr=1e-4, H=256, n_itr=3, seed=151):
         for k, v in b.items(): out[p + k] = v
         nb = [len(e) for e in rec["idx"][i]]
         out[p + "epochs_run"] = len(nb)
-        out[p + "idx"] = np.array([sum(e, []) for e in rec["idx"][i]], dtype=np.int64)       # [epochs_run, nb * mb]
+        out[p + "idx"] = np.array([sum(e, []) for e in rec["idx"][i]], dtype=np.int64)       # [epochs_run, nb * mb] (recurrent: trajectory indices)
         out[p + "scal"] = np.array(rec["scal"][i], dtype=np.float64).reshape(len(nb), -1, 6)
         for k, v in snaps[i][0].items(): out[p + "actor." + k] = v
         for k, v in snaps[i][1].items(): out[p + "critic." + k] = v
@@ -142,7 +151,7 @@ def main(name="g15b_ppo_train", lr=1e-4, H=256, n_itr=3, seed=151):
     out["train_return"] = np.array([r[1] for r in logger.rows if r[0] == "Train/Return"])
     out["mean_eplen"] = np.array([r[1] for r in logger.rows if r[0] == "Train/Mean Eplen"])
     out["timesteps"] = np.array([r[1] for r in logger.rows if r[0] == "Misc/Timesteps"])
-    out["lr"] = lr
+    out["lr"] = lr; out["recurrent"] = int(recurrent); out["fixed_std"] = float(policy.fixed_std)
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
     for i, b in enumerate(rec["batches"]):
         print("itr", i, "B", len(b["rewards"]), "episodes", list(b["ep_lens"]), "k0", b["k0"], "epochs", out["it%d.epochs_run" % i],
@@ -152,7 +161,9 @@ def main(name="g15b_ppo_train", lr=1e-4, H=256, n_itr=3, seed=151):
 
 if __name__ == "__main__":
     import sys
-    if len(sys.argv) > 1 and sys.argv[1] == "earlystop":      # G15c: a learning rate large enough for the KL test (ppo.py:449) to cut epochs short; 64-unit nets
+    if len(sys.argv) > 1 and sys.argv[1] == "recurrent":      # G15d: the whole loop in recurrent mode (LSTM 2 x 32, minibatches of 4 trajectories)
+        main("g15d_ppo_train_recurrent", lr=1e-4, H=32, n_itr=2, seed=153, recurrent=True, mb=4)
+    elif len(sys.argv) > 1 and sys.argv[1] == "earlystop":      # G15c: a learning rate large enough for the KL test (ppo.py:449) to cut epochs short; 64-unit nets
         main("g15c_ppo_train_earlystop", lr=float(sys.argv[2]) if len(sys.argv) > 2 else 1.2e-2, H=64, n_itr=2, seed=152)
     else:
         main()
