@@ -47,6 +47,51 @@ def _pmc_traffic_bytes():
         return None
 
 
+def main_recurrent(a):
+    """BASELINE.json configs[3] (next row f1): CassieTraj-v0 recurrent PPO, 2048 envs/GPU, whole-trajectory minibatches.  Same contract:
+    W warm-up iterations, K timed ones between barriers, one JSON line on rank 0."""
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == a.gpus
+    torch.cuda.set_device(local)
+    group = None
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local)); group = torch.distributed.group.WORLD
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd.ppo_recurrent import RecurrentPPO
+    from apex_amd import dist as adist
+    n_envs, T = 2048, 100
+    env = CassieVecEnv(n_envs=n_envs, seed=0, device=local, env_id_base=adist.shard_env_base(rank, n_envs), env_name="CassieTraj-v0")
+    args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=1024, epochs=a.epochs,
+                num_steps=T * n_envs * world, max_traj_len=400, max_grad_norm=0.05, mirror=True, seed=0)
+    algo = RecurrentPPO(args, "/tmp/apx_bench_unused", env, rank=rank, world_size=world, group=group)
+    algo.init_networks(0); algo.normalization_params(10000)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier(); torch.cuda.synchronize()
+    for _ in range(a.warmup):
+        algo.iteration()
+    barrier(); t0 = time.time(); samp = opt = 0.0
+    for _ in range(a.steps):
+        out = algo.iteration(); samp += out["sample_time"]; opt += out["optimize_time"]
+    barrier(); dt = time.time() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=env.device)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax)
+    if rank == 0:
+        steps_total = a.steps * T * n_envs * world
+        print(json.dumps({"metric": "env-steps/sec (whole node) CassieTraj-v0 recurrent PPO @2048 envs/GPU", "value": round(steps_total / dt, 1),
+                          "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "CassieTraj-v0 recurrent PPO (LSTM 2x128 actor/critic, whole-trajectory minibatches), 2048 envs/GPU (BASELINE.json configs[3])",
+                                     "envs_per_gpu": n_envs, "rollout_len": T, "minibatch_trajectories": 1024, "epochs": a.epochs, "mirror_loss": True},
+                          "sample_s": round(samp / a.steps, 3), "optimize_s": round(opt / a.steps, 3)}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,7 +102,11 @@ def main():
     ap.add_argument("--minibatch", type=int, default=16384)
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--workload", default="cassie_ppo", choices=["cassie_ppo", "cassietraj_recurrent"],
+                    help="cassie_ppo = BASELINE.json configs[1] (the headline, default); cassietraj_recurrent = configs[3]: CassieTraj-v0, LSTM 2x128, 2048 envs/GPU")
     a = ap.parse_args()
+    if a.workload == "cassietraj_recurrent":
+        return main_recurrent(a)
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
