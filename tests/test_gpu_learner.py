@@ -177,7 +177,7 @@ def test_ppo_update_large_minibatch_vs_oracle(dev):
 
 
 def test_lstm_forward_backward_golden_g18(dev, golden_dir):
-    """G18 (next row f1): the reference's Gaussian_LSTM_Actor / LSTM_V (2 x 128 LSTM cells + linear head) on a padded batch [9, 5, 50]
+    """G18 (next row f1): the reference's Gaussian_LSTM_Actor / LSTM_V (2 LSTM cells + linear head; 64 units in the fixture) on a padded batch [9, 5, 50]
     from zero state: outputs, BPTT parameter gradients of sum(w * y), and the step-by-step rollout with the carried state."""
     import os
     from apex_amd import engine
@@ -185,7 +185,7 @@ def test_lstm_forward_backward_golden_g18(dev, golden_dir):
     x = torch.tensor(g["x"], device=dev)
     xn = (x - torch.tensor(g["obs_mean"], device=dev)) / torch.tensor(g["obs_std"], device=dev)
     for name, keys, inp, yref, w, O in (("actor", g["actor_keys"], xn, g["mu"], g["wa"], 10), ("critic", g["critic_keys"], x, g["v"], g["wc"], 1)):
-        net = engine.Lstm(50, 128, 2, O, dev)
+        net = engine.Lstm(50, int(g["hidden"]), 2, O, dev)
         net.load_list([g[name + "." + str(k)] for k in keys])
         y, x3, save = net.forward(inp, keep=True)
         np.testing.assert_allclose(y.cpu().numpy(), yref, rtol=2e-5, atol=2e-6)
@@ -195,7 +195,7 @@ def test_lstm_forward_backward_golden_g18(dev, golden_dir):
             ref = g[name + "_grad." + str(k)]
             np.testing.assert_allclose(gv.cpu().numpy(), ref, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg="%s %s" % (name, k))
         if name == "actor":      # rollout: one env, step by step, carried (h, c)
-            hc = torch.zeros(2, 2, 1, 128, device=dev)
+            hc = torch.zeros(2, 2, 1, int(g["hidden"]), device=dev)
             steps = torch.stack([net.forward(inp[t, 2:3].contiguous(), hc=hc) for t in range(inp.shape[0])])
             np.testing.assert_allclose(steps[:, 0].cpu().numpy(), g["mu_step_env2"], rtol=2e-5, atol=2e-6)
             np.testing.assert_allclose(steps[:, 0].cpu().numpy(), y[:, 2].cpu().numpy(), rtol=1e-6, atol=1e-7)

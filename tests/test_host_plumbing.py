@@ -121,7 +121,8 @@ def test_g18_lstm_checkpoint_classes_match_the_reference(golden_dir):
     from rl.policies.actor import Gaussian_LSTM_Actor
     from rl.policies.critic import LSTM_V
     g = np.load(os.path.join(golden_dir, "g18_lstm.npz"))
-    a = Gaussian_LSTM_Actor(50, 10, layers=(128, 128), fixed_std=np.exp(-2.0)); c = LSTM_V(50, layers=(128, 128))
+    H = int(g["hidden"])
+    a = Gaussian_LSTM_Actor(50, 10, layers=(H, H), fixed_std=np.exp(-2.0)); c = LSTM_V(50, layers=(H, H))
     assert list(a.state_dict().keys()) == [str(k) for k in g["actor_keys"]] and list(c.state_dict().keys()) == [str(k) for k in g["critic_keys"]]
     a.load_state_dict({str(k): torch.tensor(g["actor." + str(k)]) for k in g["actor_keys"]})
     c.load_state_dict({str(k): torch.tensor(g["critic." + str(k)]) for k in g["critic_keys"]})

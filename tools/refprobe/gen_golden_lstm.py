@@ -15,15 +15,16 @@ from rl.policies.critic import LSTM_V
 def main():
     torch.manual_seed(18)
     T, B, D = 9, 5, 50
-    actor = Gaussian_LSTM_Actor(D, 10, layers=(128, 128), fixed_std=np.exp(-2.0))
-    critic = LSTM_V(D, layers=(128, 128))
+    H = 64
+    actor = Gaussian_LSTM_Actor(D, 10, layers=(H, H), fixed_std=np.exp(-2.0))
+    critic = LSTM_V(D, layers=(H, H))
     rs = np.random.RandomState(18)
     actor.obs_mean = torch.Tensor(rs.uniform(-0.2, 0.2, D)); actor.obs_std = torch.Tensor(rs.uniform(0.7, 1.4, D))
     critic.obs_mean, critic.obs_std = actor.obs_mean, actor.obs_std
     critic.train()
     x = torch.Tensor(rs.randn(T, B, D) * 0.7)
     wa = torch.Tensor(rs.randn(T, B, 10)); wc = torch.Tensor(rs.randn(T, B, 1))
-    out = {"x": x.numpy(), "wa": wa.numpy(), "wc": wc.numpy(), "obs_mean": actor.obs_mean.numpy(), "obs_std": actor.obs_std.numpy(),
+    out = {"hidden": H, "x": x.numpy(), "wa": wa.numpy(), "wc": wc.numpy(), "obs_mean": actor.obs_mean.numpy(), "obs_std": actor.obs_std.numpy(),
            "actor_keys": np.array(list(actor.state_dict().keys())), "critic_keys": np.array(list(critic.state_dict().keys()))}
     for k, v in actor.state_dict().items(): out["actor." + k] = v.numpy().copy()
     for k, v in critic.state_dict().items(): out["critic." + k] = v.numpy().copy()
