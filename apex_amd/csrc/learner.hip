@@ -134,7 +134,7 @@ __global__ void prep_obs_kernel(const float* __restrict__ x, int64_t B, int D, c
 // Block tile 64x64x16, 4 waves, each wave one 32x32 v_mfma_f32_32x32x2_f32 accumulator.
 // LDS tiles are k-major ([k][m], [k][n]) so the MFMA operand fetch (lane l: k = l>>5, m|n = l&31) is a
 // conflict-free ds_read_b32 (two 32-lane halves, 32 consecutive dwords each).
-enum { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_MASK = 3, EPI_ATOMIC = 4 };
+enum { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_MASK = 3, EPI_ATOMIC = 4, EPI_ACC = 5 /* C += AB, no split-K */ };
 
 struct GemmArgs {
     const float* A; long a_rs, a_cs;
@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
         if (EPI == EPI_MASK) v = g.aux[(long)row * g.ld_aux + col] > 0.f ? v : 0.f;
         if (EPI == EPI_ATOMIC) atomicAdd(c, v);
+        else if (EPI == EPI_ACC) *c += v;
         else *c = v;
     }
 }
@@ -240,6 +241,7 @@ static int launch_gemm(int epi, const GemmArgs& g0, int ksplit, hipStream_t s) {
         case EPI_BIAS_RELU: hipLaunchKernelGGL(gemm_f32_kernel<EPI_BIAS_RELU>, grid, block, 0, s, g); break;
         case EPI_MASK: hipLaunchKernelGGL(gemm_f32_kernel<EPI_MASK>, grid, block, 0, s, g); break;
         case EPI_ATOMIC: hipLaunchKernelGGL(gemm_f32_kernel<EPI_ATOMIC>, grid, block, 0, s, g); break;
+        case EPI_ACC: hipLaunchKernelGGL(gemm_f32_kernel<EPI_ACC>, grid, block, 0, s, g); break;
         default: return APX_E_ARG;
     }
     APX_LAUNCH_CHECK();
@@ -527,7 +529,7 @@ extern "C" int apx_lstm_forward(const float* params, int D, int H, int L, int O,
             float* Gt = G + (size_t)t * B * 4 * H;
             if (hp) {       // G_t += h_{t-1} W_hh^T
                 GemmArgs g{hp, H, 1, P.Whh[l], 1, H, Gt, 4 * H, nullptr, 0, (int)B, 4 * H, H, 0};
-                APX_TRY(launch_gemm(EPI_ATOMIC, g, 1, s));
+                APX_TRY(launch_gemm(EPI_ACC, g, 1, s));
             }
             hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(apx_cdiv(B * H, 256)), dim3(256), 0, s, Gt, P.bhh[l], cp, Cc + (size_t)t * B * H,
                                Hh + (size_t)t * B * H, (long)B, H);
