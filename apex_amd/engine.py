@@ -272,18 +272,29 @@ class RecurrentPPOLearner:
         return m
 
     def minibatch(self, obs, act, ret, adv, mask, mirror=True, grad_only=False):
-        """obs [T, B, D], act [T, B, A], ret / adv / mask [T, B, 1] padded like torch's pad_sequence.  Returns the six scalars (device f64)."""
+        """obs [T, B, D], act [T, B, A], ret / adv / mask [T, B, 1] padded like torch's pad_sequence.  Returns the six scalars (device f64).
+        The three sequence passes that do not depend on each other (old policy, new policy, critic) are latency-bound chains of small
+        launches; they run on three HIP streams side by side, and so do the actor's and the critic's backward passes."""
         lib = _lib.load()
         T, B, _ = obs.shape
         A = self.actor.O
         norm = lambda o: ((o - self.obs_mean) / self.obs_std).contiguous()
         xn = norm(obs)
+        obs_c = obs.contiguous()
         use_mirror = mirror and self.act_sp is not None
-        old_mu = self.old_actor.forward(xn)
-        mu, x3, save = self.actor.forward(xn, keep=True)
-        if use_mirror:
-            mum, xm3, save_m = self.actor.forward(norm(self.mirror_obs(obs)), keep=True)
-        v, xc3, save_c = self.critic.forward(obs.contiguous(), keep=True)            # LSTM_V in train mode: raw inputs (critic.py:262-263)
+        xa = torch.cat([xn, norm(self.mirror_obs(obs))], dim=1) if use_mirror else xn      # pi(s) and pi(M s) share the weights: one pass over 2B columns
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side", None) is None:
+            self._side = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+        s_old, s_cri = self._side
+        s_old.wait_stream(main); s_cri.wait_stream(main)
+        with torch.cuda.stream(s_old):
+            old_mu = self.old_actor.forward(xn)
+        with torch.cuda.stream(s_cri):
+            v, xc3, save_c = self.critic.forward(obs_c, keep=True)               # LSTM_V in train mode: raw inputs (critic.py:262-263)
+        y, x3, save = self.actor.forward(xa, keep=True)
+        mu, mum = (y[:, :B].contiguous(), y[:, B:].contiguous()) if use_mirror else (y, None)
+        main.wait_stream(s_old); main.wait_stream(s_cri)
         rows = T * B
         dmu = torch.empty(rows, A, dtype=torch.float32, device=self.device); dv = torch.empty(rows, dtype=torch.float32, device=self.device)
         dmum = torch.empty(rows, A, dtype=torch.float32, device=self.device) if use_mirror else None
@@ -291,10 +302,12 @@ class RecurrentPPOLearner:
                                _p(old_mu), _p(mask.contiguous()) if mask is not None else None, _p(self.act_sp) if use_mirror else None, rows, A,
                                self.fixed_std, self.clip, self.mirror_coeff, _p(dmu), _p(dmum), _p(dv), _p(self._scal), _p(self._acc), _stream()))
         self.grad_flat.zero_()
-        self.actor.backward(self.actor_g, x3, save, dmu.view(T, B, A))
-        if use_mirror:
-            self.actor.backward(self.actor_g, xm3, save_m, dmum.view(T, B, A))
-        self.critic.backward(self.critic_g, xc3, save_c, dv.view(T, B, 1))
+        dy = torch.cat([dmu.view(T, B, A), dmum.view(T, B, A)], dim=1) if use_mirror else dmu.view(T, B, A)
+        s_cri.wait_stream(main)
+        with torch.cuda.stream(s_cri):
+            self.critic.backward(self.critic_g, xc3, save_c, dv.view(T, B, 1))
+        self.actor.backward(self.actor_g, x3, save, dy)
+        main.wait_stream(s_cri)
         if not grad_only:
             self.apply_grads()
         return self._scal
