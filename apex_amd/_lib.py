@@ -45,6 +45,11 @@ SIGNATURES = {
     "apx_adv_moments": (C.c_int, [c_ptr, c_ptr, C.c_int64, c_ptr, c_ptr]),
     "apx_adv_apply": (C.c_int, [c_ptr, c_ptr, C.c_int64, C.c_double, C.c_double, C.c_double, c_ptr, c_ptr]),
     "apx_mlp_param_count": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "apx_mlp_backward": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int64, c_ptr, c_ptr, c_ptr]),
+    "apx_polyak": (C.c_int, [c_ptr, c_ptr, C.c_int64, C.c_float, c_ptr]),
+    "apx_td3_cat_action": (C.c_int, [c_ptr, c_ptr, c_ptr, C.c_float, C.c_float, C.c_int64, C.c_int, C.c_int, c_ptr, c_ptr]),
+    "apx_td3_critic_loss": (C.c_int, [c_ptr] * 6 + [C.c_float, C.c_int64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "apx_td3_actor_grad": (C.c_int, [c_ptr, c_ptr, C.c_float, C.c_int64, C.c_int, C.c_int, c_ptr, c_ptr]),
     "apx_ppo_loss": (C.c_int, [c_ptr] * 9 + [C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float] + [c_ptr] * 6),
     "apx_lstm_param_count": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "apx_lstm_workspace_floats": (C.c_size_t, [C.c_int, C.c_int64, C.c_int, C.c_int]),

@@ -449,6 +449,92 @@ extern "C" int apx_mlp_forward(const float* params, int D, int H, int O, const f
     return mlp_forward_impl(params, D, H, O, xn_out, B, act1, act2, y, s);
 }
 
+// ------------------------------------------------------------------------------------------------ TD3 primitives (next row f2)
+// grads += d(loss)/d(params) of a 3-layer ReLU MLP for dy[B,O] (xn, a1, a2 from apx_mlp_forward), optionally dx[B,D] = d(loss)/d(input)
+extern "C" int apx_mlp_backward(const float* params, float* grads, int D, int H, int O, const float* xn, const float* a1, const float* a2,
+                                const float* dy, int64_t B, float* dx, float* scratch /* 2*B*H floats */, void* stream) {
+    APX_REQUIRE(params && xn && a1 && a2 && dy && scratch && B > 0 && (grads || dx), "mlp backward arguments");
+    hipStream_t s = (hipStream_t)stream;
+    float* dh2 = scratch; float* dh1 = scratch + (size_t)B * H;
+    if (grads) APX_TRY(mlp_backward_impl(params, grads, D, H, O, xn, a1, a2, dy, B, dh2, dh1, s));
+    else {      // input gradient only (the actor loss -Q1(s, pi(s)) must not touch the critic's parameter gradients)
+        MlpView p(params, D, H, O);
+        APX_TRY(linear_bwd_input(dy, p.W2, a2, dh2, B, H, O, s));
+        APX_TRY(linear_bwd_input(dh2, p.W1, a1, dh1, B, H, H, s));
+    }
+    if (dx) { MlpView p(params, D, H, O); APX_TRY(linear_bwd_input(dh1, p.W0, nullptr, dx, B, D, H, s)); }
+    return APX_OK;
+}
+__global__ void polyak_kernel(float* __restrict__ target, const float* __restrict__ param, long n, float tau) {
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e < n) target[e] = tau * param[e] + (1.f - tau) * target[e];
+}
+// target <- tau * param + (1 - tau) * target (sync_td3.py:196-202)
+extern "C" int apx_polyak(float* target, const float* param, int64_t n, float tau, void* stream) {
+    APX_REQUIRE(target && param && n > 0, "polyak arguments");
+    hipLaunchKernelGGL(polyak_kernel, dim3(apx_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, target, param, (long)n, tau);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+}
+// out[b, :D] = s[b], out[b, D + j] = max_action * tanh(pre[b, j]) (+ clamp(noise)) clamped to +-max_action: the critic input cat(state, action)
+__global__ void td3_cat_action_kernel(const float* __restrict__ s, const float* __restrict__ pre, const float* __restrict__ noise, float noise_clip,
+                                      float max_action, long B, int D, int A, float* __restrict__ out) {
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= B * (D + A)) return;
+    const long b = e / (D + A); const int c = (int)(e - b * (D + A));
+    if (c < D) { out[e] = s[b * D + c]; return; }
+    const int j = c - D;
+    float a = max_action * tanhf(pre[b * A + j]);
+    if (noise) a = fminf(fmaxf(a + fminf(fmaxf(noise[b * A + j], -noise_clip), noise_clip), -max_action), max_action);
+    out[e] = a;
+}
+extern "C" int apx_td3_cat_action(const float* state, const float* pre_tanh, const float* noise, float noise_clip, float max_action, int64_t B,
+                                  int D, int A, float* out, void* stream) {
+    APX_REQUIRE(state && pre_tanh && out && B > 0, "td3 cat arguments");
+    hipLaunchKernelGGL(td3_cat_action_kernel, dim3(apx_cdiv(B * (D + A), 256)), dim3(256), 0, (hipStream_t)stream, state, pre_tanh, noise, noise_clip,
+                       max_action, (long)B, D, A, out);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+}
+// target = r + notdone * discount * min(tq1, tq2); dq1 = 2 (q1 - target) / B, dq2 likewise; acc += (critic loss, sum q1, sum q2)
+__global__ void td3_critic_loss_kernel(const float* __restrict__ q1, const float* __restrict__ q2, const float* __restrict__ tq1, const float* __restrict__ tq2,
+                                       const float* __restrict__ r, const float* __restrict__ notdone, float discount, long B, float* __restrict__ dq1,
+                                       float* __restrict__ dq2, double* __restrict__ acc) {
+    const long b = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    double a[3] = {0, 0, 0};
+    if (b < B) {
+        const float t = r[b] + notdone[b] * discount * fminf(tq1[b], tq2[b]);
+        const float e1 = q1[b] - t, e2 = q2[b] - t;
+        dq1[b] = 2.f * e1 / (float)B; dq2[b] = 2.f * e2 / (float)B;
+        a[0] = ((double)e1 * e1 + (double)e2 * e2) / (double)B; a[1] = q1[b]; a[2] = q2[b];
+    }
+    block_atomic_add<3>(a, acc);
+}
+extern "C" int apx_td3_critic_loss(const float* q1, const float* q2, const float* tq1, const float* tq2, const float* reward, const float* notdone,
+                                   float discount, int64_t B, float* dq1, float* dq2, double* acc3, void* stream) {
+    APX_REQUIRE(q1 && q2 && tq1 && tq2 && reward && notdone && dq1 && dq2 && acc3 && B > 0, "td3 critic loss arguments");
+    hipStream_t s = (hipStream_t)stream;
+    APX_HIP(hipMemsetAsync(acc3, 0, 3 * sizeof(double), s));
+    hipLaunchKernelGGL(td3_critic_loss_kernel, dim3(apx_cdiv(B, 256)), dim3(256), 0, s, q1, q2, tq1, tq2, reward, notdone, discount, (long)B, dq1, dq2, acc3);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+}
+// actor loss -mean Q1(s, pi(s)): d(loss)/d(pre_tanh)[b, j] = dx[b, D + j] * max_action * (1 - tanh(pre)^2), with dx = d(-mean q1)/d(critic input)
+__global__ void td3_actor_grad_kernel(const float* __restrict__ dx, const float* __restrict__ pre, float max_action, long B, int D, int A,
+                                      float* __restrict__ dpre) {
+    const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (e >= B * A) return;
+    const long b = e / A; const int j = (int)(e - b * A);
+    const float t = tanhf(pre[e]);
+    dpre[e] = dx[b * (D + A) + D + j] * max_action * (1.f - t * t);
+}
+extern "C" int apx_td3_actor_grad(const float* dx, const float* pre_tanh, float max_action, int64_t B, int D, int A, float* dpre, void* stream) {
+    APX_REQUIRE(dx && pre_tanh && dpre && B > 0, "td3 actor grad arguments");
+    hipLaunchKernelGGL(td3_actor_grad_kernel, dim3(apx_cdiv(B * A, 256)), dim3(256), 0, (hipStream_t)stream, dx, pre_tanh, max_action, (long)B, D, A, dpre);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ LSTM (recurrent actor / critic)
 // Gaussian_LSTM_Actor / LSTM_V (rl/policies/actor.py:218-311, critic.py:236-296): L stacked nn.LSTMCell(H) + Linear(H, O), run over a
 // padded batch of trajectories x[T, B, D] from zero state (or one step from a carried state).  Parameters in state_dict order: per

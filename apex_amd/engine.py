@@ -320,3 +320,81 @@ class RecurrentPPOLearner:
                                 self.lr, self.eps, self.t, _p(sc[0:1]), _stream()))
         check(lib.apx_clip_adam(_p(self.critic.params), _p(self.critic_m), _p(self.critic_v), _p(self.critic_g), self.critic.n, scale,
                                 self.grad_clip, self.lr, self.eps, self.t, _p(sc[1:2]), _stream()))
+
+
+class TD3Learner:
+    """TD3.train (rl/algos/sync_td3.py:133-209): FF_Actor with tanh head + Dual_Q_Critic (two 3-layer ReLU MLPs on cat(state, action)),
+    target networks, target-policy smoothing, clipped double-Q target, delayed policy update, Polyak averaging - on apx_mlp_forward /
+    apx_mlp_backward / the apx_td3_* kernels / apx_clip_adam (clip disabled, Adam eps 1e-8 like torch.optim.Adam's default)."""
+
+    def __init__(self, obs_dim, act_dim, hidden, device, max_action=1.0, a_lr=1e-3, c_lr=1e-3):
+        self.D, self.A, self.H, self.device, self.max_action = obs_dim, act_dim, hidden, device, float(max_action)
+        mk = lambda d, o: Mlp(d, hidden, o, device)
+        self.actor, self.actor_t = mk(obs_dim, act_dim), mk(obs_dim, act_dim)
+        # Dual_Q_Critic's state_dict order is q1 (W0 b0 W1 b1 Wout bout) then q2: one flat block, two views
+        n1 = int(_lib.load().apx_mlp_param_count(obs_dim + act_dim, hidden, 1))
+        self.critic_flat = torch.zeros(2 * n1, dtype=torch.float32, device=device); self.critic_t_flat = torch.zeros_like(self.critic_flat)
+        self.q = [mk(obs_dim + act_dim, 1), mk(obs_dim + act_dim, 1)]; self.q_t = [mk(obs_dim + act_dim, 1), mk(obs_dim + act_dim, 1)]
+        for i in range(2):
+            self.q[i].params = self.critic_flat[i * n1:(i + 1) * n1]; self.q_t[i].params = self.critic_t_flat[i * n1:(i + 1) * n1]
+        z = lambda n: torch.zeros(n, dtype=torch.float32, device=device)
+        self.a_m, self.a_v, self.a_g = z(self.actor.n), z(self.actor.n), z(self.actor.n)
+        self.c_m, self.c_v, self.c_g = z(2 * n1), z(2 * n1), z(2 * n1)
+        self.n1, self.a_lr, self.c_lr = n1, a_lr, c_lr
+        self.t_a = self.t_c = 0
+        self._acc = torch.zeros(3, dtype=torch.float64, device=device)
+        self._nrm = torch.zeros(2, dtype=torch.float64, device=device)
+
+    def _cat(self, state, pre, noise=None, noise_clip=0.0):
+        B = state.shape[0]
+        out = torch.empty(B, self.D + self.A, dtype=torch.float32, device=self.device)
+        check(_lib.load().apx_td3_cat_action(_p(state), _p(pre), _p(noise), float(noise_clip), self.max_action, B, self.D, self.A, _p(out), _stream()))
+        return out
+
+    def _adam(self, p, m, v, g, lr, t):
+        check(_lib.load().apx_clip_adam(_p(p), _p(m), _p(v), _p(g), p.numel(), 1.0, 1e30, lr, 1e-8, t, _p(self._nrm[0:1]), _stream()))
+
+    def act(self, state):
+        """FF_Actor.forward: max_action * tanh(network_out(...))."""
+        return self.max_action * torch.tanh(self.actor.forward(state))
+
+    def train_step(self, state, action, next_state, reward, notdone, noise, it, discount=0.99, tau=0.005, noise_clip=0.5, policy_freq=2):
+        """One iteration of TD3.train's loop on a sampled batch; noise [B, A] ~ N(0, policy_noise) (clamped inside).  Returns
+        (critic loss, mean q1, mean q2, actor loss or None) as host floats only when asked via .item() by the caller: device tensors."""
+        lib = _lib.load()
+        B = state.shape[0]
+        state, action, next_state = state.contiguous(), action.contiguous(), next_state.contiguous()
+        xin_t = self._cat(next_state, self.actor_t.forward(next_state), noise.contiguous(), noise_clip)
+        tq1, tq2 = self.q_t[0].forward(xin_t), self.q_t[1].forward(xin_t)
+        xin = torch.cat([state, action], 1).contiguous()
+        kept = [self.q[i].forward(xin, keep=True) for i in range(2)]
+        dq = [torch.empty(B, dtype=torch.float32, device=self.device) for _ in range(2)]
+        check(lib.apx_td3_critic_loss(_p(kept[0][0]), _p(kept[1][0]), _p(tq1), _p(tq2), _p(reward.contiguous()), _p(notdone.contiguous()), float(discount), B,
+                                      _p(dq[0]), _p(dq[1]), _p(self._acc), _stream()))
+        stats = self._acc.clone()
+        self.c_g.zero_()
+        scratch = torch.empty(2 * B * self.H, dtype=torch.float32, device=self.device)
+        for i in range(2):
+            y, xn, a1, a2 = kept[i]
+            check(lib.apx_mlp_backward(_p(self.q[i].params), _p(self.c_g[i * self.n1:(i + 1) * self.n1]), self.D + self.A, self.H, 1, _p(xn), _p(a1), _p(a2),
+                                       _p(dq[i]), B, None, _p(scratch), _stream()))
+        self.t_c += 1
+        self._adam(self.critic_flat, self.c_m, self.c_v, self.c_g, self.c_lr, self.t_c)
+        pi_loss = None
+        if it % policy_freq == 0:
+            pre, xs, s1, s2 = self.actor.forward(state, keep=True)
+            xin_pi = self._cat(state, pre)
+            q1, xq, q11, q12 = self.q[0].forward(xin_pi, keep=True)
+            pi_loss = -q1.mean()
+            dy = torch.full((B,), -1.0 / B, dtype=torch.float32, device=self.device)
+            dx = torch.empty(B, self.D + self.A, dtype=torch.float32, device=self.device)
+            check(lib.apx_mlp_backward(_p(self.q[0].params), None, self.D + self.A, self.H, 1, _p(xq), _p(q11), _p(q12), _p(dy), B, _p(dx), _p(scratch), _stream()))
+            dpre = torch.empty(B, self.A, dtype=torch.float32, device=self.device)
+            check(lib.apx_td3_actor_grad(_p(dx), _p(pre), self.max_action, B, self.D, self.A, _p(dpre), _stream()))
+            self.a_g.zero_()
+            check(lib.apx_mlp_backward(_p(self.actor.params), _p(self.a_g), self.D, self.H, self.A, _p(xs), _p(s1), _p(s2), _p(dpre), B, None, _p(scratch), _stream()))
+            self.t_a += 1
+            self._adam(self.actor.params, self.a_m, self.a_v, self.a_g, self.a_lr, self.t_a)
+            check(lib.apx_polyak(_p(self.critic_t_flat), _p(self.critic_flat), self.critic_flat.numel(), float(tau), _stream()))
+            check(lib.apx_polyak(_p(self.actor_t.params), _p(self.actor.params), self.actor.n, float(tau), _stream()))
+        return stats, pi_loss

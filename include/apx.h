@@ -70,6 +70,26 @@ int apx_mlp_forward(const float* params, int D, int H, int O, const float* x, in
                     const int32_t* sign_perm, uint64_t clock_mask, const float* obs_mean, const float* obs_std,
                     float* xn_out, float* act1, float* act2, float* y, int precision, void* stream);
 
+/* TD3 primitives (next row f2; rl/algos/sync_td3.py:133-209 TD3.train with FF_Actor, rl/policies/actor.py:43-72, and Dual_Q_Critic,
+ * rl/policies/critic.py:118-168, each Q a 3-layer ReLU MLP on cat(state, action)).  The networks run through apx_mlp_forward (no
+ * normalisation); these entry points add what PPO did not need:
+ * apx_mlp_backward: grads += d(loss)/d(params) for dy[B,O] (grads NULL = skip the parameter gradients) and optionally
+ *   dx[B,D] = d(loss)/d(input); xn / a1 / a2 are the arrays apx_mlp_forward kept; scratch = 2*B*H floats.
+ * apx_polyak: target <- tau*param + (1-tau)*target (sync_td3.py:196-202).
+ * apx_td3_cat_action: critic input [B, D+A] = cat(state, max_action*tanh(pre_tanh) [+ clamp(noise, +-noise_clip), clamped to
+ *   +-max_action]) (FF_Actor.forward; target-policy smoothing sync_td3.py:146-151 when noise != NULL).
+ * apx_td3_critic_loss: target_Q = reward + notdone*discount*min(tq1, tq2) (:154-156); dq1 / dq2 = gradients of
+ *   mse(q1, target) + mse(q2, target) (:168-169); acc3 = (critic loss, sum q1, sum q2) f64 [dev].
+ * apx_td3_actor_grad: d(loss)/d(pre_tanh) from dx = d(-mean Q1)/d(critic input) (:183). */
+int apx_mlp_backward(const float* params, float* grads, int D, int H, int O, const float* xn, const float* a1, const float* a2,
+                     const float* dy, int64_t B, float* dx, float* scratch, void* stream);
+int apx_polyak(float* target, const float* param, int64_t n, float tau, void* stream);
+int apx_td3_cat_action(const float* state, const float* pre_tanh, const float* noise, float noise_clip, float max_action, int64_t B,
+                       int D, int A, float* out, void* stream);
+int apx_td3_critic_loss(const float* q1, const float* q2, const float* tq1, const float* tq2, const float* reward, const float* notdone,
+                        float discount, int64_t B, float* dq1, float* dq2, double* acc3, void* stream);
+int apx_td3_actor_grad(const float* dx, const float* pre_tanh, float max_action, int64_t B, int D, int A, float* dpre, void* stream);
+
 /* Recurrent actor / critic (next row f1): Gaussian_LSTM_Actor (rl/policies/actor.py:218-311) and LSTM_V (rl/policies/critic.py:236-296) =
  * L stacked nn.LSTMCell(H) + Linear(H, O).  Parameter block in state_dict order: per cell weight_ih[4H,in] weight_hh[4H,H] bias_ih[4H]
  * bias_hh[4H] (gate order i,f,g,o), then network_out weight[O,H] bias[O].

@@ -224,3 +224,35 @@ def test_recurrent_update_policy_golden_g19(dev, golden_dir):
             for k, v in zip(keys, net.views()):
                 d = np.abs(v.cpu().numpy() - g[p + nm + "." + str(k)])
                 assert (d > 3e-6).mean() < 5e-3 and d.max() < 4.1e-4, (s, nm, str(k), (d > 3e-6).mean(), d.max())
+
+
+def test_td3_train_golden_g20(dev, golden_dir):
+    """G20 (next row f2): the reference's TD3.train for 4 iterations on recorded batches (target smoothing with the recorded noise, clipped
+    double-Q target, two delayed policy updates, Polyak averaging): returned statistics and all four parameter sets afterwards."""
+    import os
+    from apex_amd import engine
+    g = np.load(os.path.join(golden_dir, "g20_td3.npz"))
+    H = int(g["hidden"])
+    L = engine.TD3Learner(50, 10, H, dev, max_action=1.0, a_lr=float(g["lr"]), c_lr=float(g["lr"]))
+    ak, ck = [str(k) for k in g["actor_keys"]], [str(k) for k in g["critic_keys"]]
+    L.actor.load_list([g["actor0." + k] for k in ak]); L.actor_t.load_list([g["actor_target0." + k] for k in ak])
+    for i in range(2):
+        L.q[i].load_list([g["critic0." + k] for k in ck[6 * i:6 * i + 6]]); L.q_t[i].load_list([g["critic_target0." + k] for k in ck[6 * i:6 * i + 6]])
+    t = lambda a: torch.tensor(a, device=dev)
+    q_loss = pi_loss = avg_q1 = 0.0
+    for it in range(int(g["iters"])):
+        p = "b%d_" % it
+        stats, pl = L.train_step(t(g[p + "x"]), t(g[p + "u"]), t(g[p + "y"]), t(g[p + "r"]).view(-1), 1.0 - t(g[p + "d"]).view(-1), t(g[p + "noise"]), it,
+                                 discount=float(g["discount"]), tau=float(g["tau"]), noise_clip=float(g["noise_clip"]), policy_freq=int(g["policy_freq"]))
+        s = stats.cpu().numpy()
+        q_loss += s[0]; avg_q1 += s[1] / 64
+        if pl is not None:
+            pi_loss += float(pl)
+    n = int(g["iters"])
+    np.testing.assert_allclose([avg_q1 / n, q_loss / n, pi_loss / n], [float(g["ret_avg_q1"]), float(g["ret_q_loss"]), float(g["ret_pi_loss"])], rtol=2e-4, atol=2e-6)
+    for nm, nets, keys in (("actor1", [L.actor], ak), ("actor_target1", [L.actor_t], ak), ("critic1", L.q, ck), ("critic_target1", L.q_t, ck)):
+        views = [v for net in nets for v in net.views()]
+        for k, v in zip(keys, views):
+            d = np.abs(v.cpu().numpy() - g[nm + "." + k])
+            lim = 2.1e-3 if "target" not in nm else 2e-5           # Adam at lr 1e-3: a sign tie at g ~ 0 moves a weight by 2e-3
+            assert (d > 2e-5).mean() < (5e-3 if "target" not in nm else 1e-9 + 5e-3) and d.max() < lim + 1e-9, (nm, k, (d > 2e-5).mean(), d.max())
