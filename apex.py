@@ -160,10 +160,36 @@ def eval_commands_main(argv):
     return 0
 
 
+def td3_main(argv):
+    """`apex.py td3 ...` (row f2): synchronous TD3 (reference apex.py:140-166 flags of syncTD3 where they still apply) on the batched env with
+    the replay buffer in HBM.  --n_envs / --collect_steps / --updates_per_step replace the Ray worker counts."""
+    import argparse
+    p = argparse.ArgumentParser()
+    p.add_argument("--env_name", default="Cassie-v0"); p.add_argument("--reward", default="clock", type=str)
+    p.add_argument("--seed", type=int, default=0); p.add_argument("--logdir", type=str, default="./trained_models/syncTD3/")
+    p.add_argument("--run_name", type=str, default=None); p.add_argument("--previous", type=str, default=None)
+    p.add_argument("--max_timesteps", type=float, default=1e8); p.add_argument("--max_traj_len", type=int, default=400)
+    p.add_argument("--a_lr", type=float, default=1e-3); p.add_argument("--c_lr", type=float, default=1e-3)
+    p.add_argument("--discount", type=float, default=0.99); p.add_argument("--tau", type=float, default=0.005)
+    p.add_argument("--act_noise", type=float, default=0.3); p.add_argument("--policy_noise", type=float, default=0.2)
+    p.add_argument("--noise_clip", type=float, default=0.5); p.add_argument("--policy_freq", type=int, default=2)
+    p.add_argument("--batch_size", type=int, default=256); p.add_argument("--hidden", type=int, default=256)
+    p.add_argument("--n_envs", type=int, default=4096); p.add_argument("--collect_steps", type=int, default=32)
+    p.add_argument("--updates_per_step", type=int, default=1); p.add_argument("--replay_size", type=int, default=1000000)
+    p.add_argument("--eval_every", type=int, default=10)
+    a = p.parse_args(argv)
+    a.max_timesteps = int(a.max_timesteps)
+    from apex_amd.td3 import run_experiment
+    run_experiment(a)
+    return 0
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     if argv and argv[0] == "eval":
         return eval_main(argv[1:])
+    if argv and argv[0] == "td3":
+        return td3_main(argv[1:])
     if argv and argv[0] == "eval_commands":
         return eval_commands_main(argv[1:])
     if argv and argv[0] == "eval_perturb":

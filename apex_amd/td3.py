@@ -1,0 +1,140 @@
+"""TD3 for the batched engine (BASELINE configs[4]): the reference's synchronous TD3 (rl/algos/sync_td3.py)
+with the replay buffer resident in HBM and the twin-critic update in HIP (apex_amd.engine.TD3Learner).
+
+Reference loop (sync_td3.py:286-330): workers collect whole episodes with action = clip(actor(s) + N(0, act_noise), -1, 1) - ONE scalar
+draw added to all action dimensions (np.random.normal(..., size=1), :77) -, transitions (s, s', a, r, done_bool) go to a ring replay
+(done_bool is also 1 at the time limit, :82), then one TD3.train iteration per collected step on a uniform-with-replacement batch
+(rl/utils/remote_replay.py:78-90).  Here N envs collect in lock step and every lock-step env step is followed by `updates_per_step`
+updates; the replay is five device tensors written with a ring index."""
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import engine
+
+
+class HbmReplay:
+    """Ring replay of (s, s', a, r, notdone) in device memory; 10^6 x (50 + 50 + 10 + 1 + 1) fp32 = 448 MB."""
+
+    def __init__(self, capacity, obs_dim, act_dim, device):
+        f = dict(dtype=torch.float32, device=device)
+        self.cap, self.device = int(capacity), device
+        self.s = torch.zeros(self.cap, obs_dim, **f); self.s2 = torch.zeros(self.cap, obs_dim, **f); self.a = torch.zeros(self.cap, act_dim, **f)
+        self.r = torch.zeros(self.cap, **f); self.nd = torch.zeros(self.cap, **f)
+        self.ptr, self.size = 0, 0
+
+    def add(self, s, s2, a, r, notdone):
+        n = s.shape[0]
+        idx = (torch.arange(n, device=self.device) + self.ptr) % self.cap          # remote_replay.py:70-74: overwrite the oldest
+        self.s.index_copy_(0, idx, s); self.s2.index_copy_(0, idx, s2); self.a.index_copy_(0, idx, a)
+        self.r.index_copy_(0, idx, r); self.nd.index_copy_(0, idx, notdone)
+        self.ptr = (self.ptr + n) % self.cap; self.size = min(self.size + n, self.cap)
+
+    def sample(self, batch_size, gen):
+        ind = torch.randint(0, self.size, (batch_size,), device=self.device, generator=gen)      # np.random.randint(0, len, size): with replacement
+        g = lambda x: x.index_select(0, ind)
+        return g(self.s), g(self.s2), g(self.a), g(self.r), g(self.nd)
+
+
+class TD3:
+    def __init__(self, env, save_path, hidden=256, a_lr=1e-3, c_lr=1e-3, discount=0.99, tau=0.005, policy_noise=0.2, noise_clip=0.5, policy_freq=2,
+                 act_noise=0.3, batch_size=256, updates_per_step=1, replay_size=1_000_000, seed=0):
+        self.env, self.save_path, self.device, self.N = env, save_path, env.device, env.n_envs
+        self.learner = engine.TD3Learner(50, 10, hidden, self.device, 1.0, a_lr, c_lr)
+        self.replay = HbmReplay(replay_size, 50, 10, self.device)
+        self.discount, self.tau, self.policy_noise, self.noise_clip, self.policy_freq = discount, tau, policy_noise, noise_clip, policy_freq
+        self.act_noise, self.batch_size, self.updates_per_step, self.hidden = act_noise, batch_size, updates_per_step, hidden
+        self.gen = torch.Generator(device=self.device); self.gen.manual_seed(int(seed) * 1000003 + 17)
+        self.it = 0; self.total_steps = 0; self.obs = None
+
+    def init_networks(self, seed):
+        from rl.policies.actor import FF_Actor
+        from rl.policies.critic import Dual_Q_Critic
+        torch.manual_seed(seed)
+        self.policy = FF_Actor(50, 10, layers=(self.hidden, self.hidden), max_action=1.0)
+        self.critic = Dual_Q_Critic(50, 10, hidden_size=self.hidden)
+        L = self.learner
+        L.actor.load_list([p.detach().numpy() for p in self.policy.parameters()]); L.actor_t.params.copy_(L.actor.params)
+        ps = [p.detach().numpy() for p in self.critic.parameters()]
+        L.q[0].load_list(ps[:6]); L.q[1].load_list(ps[6:]); L.critic_t_flat.copy_(L.critic_flat)
+
+    def save(self):
+        os.makedirs(self.save_path, exist_ok=True)
+        with torch.no_grad():
+            for p, v in zip(self.policy.parameters(), self.learner.actor.views()):
+                p.copy_(v.cpu())
+            for p, v in zip(self.critic.parameters(), self.learner.q[0].views() + self.learner.q[1].views()):
+                p.copy_(v.cpu())
+        torch.save(self.policy, os.path.join(self.save_path, "actor.pt")); torch.save(self.critic, os.path.join(self.save_path, "critic.pt"))
+
+    @torch.no_grad()
+    def collect_and_train(self, steps):
+        """`steps` lock-step env steps; after each one the N new transitions enter the replay and `updates_per_step` updates run."""
+        L, env = self.learner, self.env
+        if self.obs is None:
+            self.obs = env.reset().clone()
+        stats = torch.zeros(3, dtype=torch.float64, device=self.device); n_upd = 0
+        ep_done = 0
+        for _ in range(steps):
+            a = L.act(self.obs)
+            if self.act_noise != 0:
+                a = (a + torch.randn(self.N, 1, device=self.device, generator=self.gen) * self.act_noise).clamp(-1, 1)      # one scalar per env step (:77)
+            nxt, rew, done, fin = env.step(a)
+            ended = done != 0
+            s2 = torch.where(ended.view(-1, 1), fin, nxt)
+            self.replay.add(self.obs, s2, a, rew, (~ended).float())
+            self.obs = nxt.clone()
+            for _ in range(self.updates_per_step):
+                if self.replay.size < self.batch_size:
+                    break
+                s, sn, ac, r, nd = self.replay.sample(self.batch_size, self.gen)
+                noise = torch.randn(self.batch_size, 10, device=self.device, generator=self.gen) * self.policy_noise
+                st, _ = L.train_step(s, ac, sn, r, nd, noise, self.it, self.discount, self.tau, self.noise_clip, self.policy_freq)
+                stats += st; n_upd += 1; self.it += 1
+        self.total_steps += steps * self.N
+        s = (stats / max(n_upd, 1)).cpu().numpy()
+        return dict(q_loss=float(s[0]), avg_q1=float(s[1] / self.batch_size), avg_q2=float(s[2] / self.batch_size), updates=n_upd)
+
+    @torch.no_grad()
+    def evaluate(self, n_envs=256, max_traj_len=400):
+        """evaluate_policy (sync_td3.py:23-46) as one batch of deterministic episodes on a fresh env batch."""
+        from .vecenv import CassieVecEnv
+        from .eval import evaluate
+        ev = CassieVecEnv(n_envs=n_envs, max_traj_len=max_traj_len, dynamics_randomization=False, device=self.device.index or 0)
+        ev.reset()
+        out = evaluate(lambda o: self.learner.act(o), ev, max_steps=max_traj_len)
+        ev.close()
+        return float(out["returns"].mean()), float(out["lengths"].mean())
+
+
+def run_experiment(args):
+    from .vecenv import CassieVecEnv
+    from .log import create_logger
+    torch.manual_seed(args.seed); np.random.seed(args.seed)
+    env = CassieVecEnv(n_envs=args.n_envs, reward=args.reward, max_traj_len=args.max_traj_len, seed=args.seed, env_name=args.env_name)
+    logger = create_logger(args)
+    algo = TD3(env, logger.dir, hidden=args.hidden, a_lr=args.a_lr, c_lr=args.c_lr, discount=args.discount, tau=args.tau, policy_noise=args.policy_noise,
+               noise_clip=args.noise_clip, policy_freq=args.policy_freq, act_noise=args.act_noise, batch_size=args.batch_size,
+               updates_per_step=args.updates_per_step, replay_size=args.replay_size, seed=args.seed)
+    algo.init_networks(args.seed)
+    updates = 0
+    ret, eplen = algo.evaluate()
+    logger.add_scalar("Test/Return", ret, updates); logger.add_scalar("Test/Eplen", eplen, updates)
+    while algo.total_steps < args.max_timesteps:
+        t0 = time.time()
+        out = algo.collect_and_train(args.collect_steps)
+        torch.cuda.synchronize(); dt = time.time() - t0
+        updates += out["updates"]
+        for k in ("avg_q1", "avg_q2", "q_loss"):
+            logger.add_scalar("Train/" + k, out[k], updates)
+        print("Total T: %d  updates %d  q_loss %.4f  avg_q1 %.3f  (%.0f env-steps/s, %.0f updates/s)" % (
+            algo.total_steps, updates, out["q_loss"], out["avg_q1"], args.collect_steps * args.n_envs / dt, out["updates"] / dt))
+        if (algo.total_steps // (args.collect_steps * args.n_envs)) % args.eval_every == 0:
+            ret, eplen = algo.evaluate()
+            logger.add_scalar("Test/Return", ret, updates); logger.add_scalar("Test/Eplen", eplen, updates); logger.add_scalar("Misc/Timesteps", algo.total_steps, updates)
+            logger.add_scalar("Misc/ReplaySize", algo.replay.size, updates)
+            print("Total T: %d\tEval Return: %.2f\t Eval Eplen: %.1f" % (algo.total_steps, ret, eplen))
+            algo.save()
+    return algo

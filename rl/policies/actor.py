@@ -141,3 +141,31 @@ class Gaussian_LSTM_Actor(Actor):
     def distribution(self, inputs):
         mu, sd = self._get_dist_params(inputs)
         return torch.distributions.Normal(mu, sd)
+
+
+class FF_Actor(Actor):
+    """Deterministic tanh actor of TD3 / DDPG with the reference's pickle surface (rl/policies/actor.py:43-72)."""
+
+    def __init__(self, state_dim, action_dim, layers=(256, 256), env_name=None, nonlinearity=F.relu, max_action=1):
+        super().__init__()
+        self.actor_layers = nn.ModuleList()
+        self.actor_layers += [nn.Linear(state_dim, layers[0])]
+        for i in range(len(layers) - 1):
+            self.actor_layers += [nn.Linear(layers[i], layers[i + 1])]
+        self.network_out = nn.Linear(layers[-1], action_dim)
+        self.action = None
+        self.action_dim = action_dim
+        self.env_name = env_name
+        self.nonlinearity = nonlinearity
+        self.initialize_parameters()
+        self.max_action = max_action
+
+    def forward(self, state, deterministic=True):
+        x = state
+        for layer in self.actor_layers:
+            x = self.nonlinearity(layer(x))
+        self.action = torch.tanh(self.network_out(x))
+        return self.action * self.max_action
+
+    def get_action(self):
+        return self.action

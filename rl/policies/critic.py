@@ -92,3 +92,27 @@ class LSTM_V(Critic):
         flat = state.dim() == 1
         x = self._step(state.view(1, -1) if flat else state)
         return x.view(-1) if flat else x
+
+
+class Dual_Q_Critic(Critic):
+    """Twin Q network of TD3 with the reference's pickle surface (rl/policies/critic.py:118-168): q1_layers / q1_out, q2_layers / q2_out."""
+
+    def __init__(self, state_dim, action_dim, hidden_size=256, hidden_layers=2, env_name="NOT SET"):
+        super().__init__()
+        self.q1_layers = nn.ModuleList([nn.Linear(state_dim + action_dim, hidden_size)] + [nn.Linear(hidden_size, hidden_size) for _ in range(hidden_layers - 1)])
+        self.q1_out = nn.Linear(hidden_size, 1)
+        self.q2_layers = nn.ModuleList([nn.Linear(state_dim + action_dim, hidden_size)] + [nn.Linear(hidden_size, hidden_size) for _ in range(hidden_layers - 1)])
+        self.q2_out = nn.Linear(hidden_size, 1)
+        self.env_name = env_name
+
+    def Q1(self, state, action):
+        x = torch.cat([state, action], state.dim() - 1)
+        for layer in self.q1_layers:
+            x = F.relu(layer(x))
+        return self.q1_out(x)
+
+    def forward(self, state, action):
+        x2 = torch.cat([state, action], state.dim() - 1)
+        for layer in self.q2_layers:
+            x2 = F.relu(layer(x2))
+        return self.Q1(state, action), self.q2_out(x2)

@@ -366,3 +366,36 @@ def test_whole_train_loop_recurrent_golden_g15d(dev, golden_dir):
             for k, v in zip(ref_p.state_dict(), views):
                 d = np.abs(v.cpu().numpy() - g[p + nm + "." + k])
                 assert (d > 5e-6).mean() < 1e-2 and d.max() < 5e-4, (it, nm, k, (d > 5e-6).mean(), d.max())
+
+
+def test_td3_driver_hbm_replay_and_updates(dev, tmp_path):
+    """Row f2: TD3 on the HIP env with the replay buffer in HBM.  Ring semantics (overwrite the oldest, remote_replay.py:70-74), the
+    stored transitions (s' of a finished env is its FINAL observation, done_bool also at the time limit, sync_td3.py:82), uniform sampling
+    with replacement, and a few collect + update rounds: finite statistics, moving weights, Polyak-averaged targets, checkpoint classes."""
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd.td3 import TD3, HbmReplay
+    rb = HbmReplay(100, 3, 2, dev)
+    for k in range(3):
+        n = 40
+        base = torch.arange(n, device=dev).float() + 40 * k
+        rb.add(base.view(n, 1).repeat(1, 3), base.view(n, 1).repeat(1, 3) + 0.5, base.view(n, 1).repeat(1, 2), base, torch.ones(n, device=dev))
+    assert rb.size == 100 and rb.ptr == 20
+    np.testing.assert_allclose(rb.r.cpu().numpy()[:20], np.arange(100, 120)); np.testing.assert_allclose(rb.r.cpu().numpy()[20:], np.arange(20, 100))
+    g = torch.Generator(device=dev); g.manual_seed(0)
+    s, s2, a, r, nd = rb.sample(4096, g)
+    assert s.shape == (4096, 3) and torch.equal(s[:, 0], r) and torch.equal(s2[:, 0], r + 0.5) and len(torch.unique(r)) > 90      # with replacement, whole ring
+    env = CassieVecEnv(n_envs=64, seed=3, max_traj_len=15)
+    algo = TD3(env, str(tmp_path), hidden=64, batch_size=128, updates_per_step=2, replay_size=5000, seed=1)
+    algo.init_networks(0)
+    a0 = algo.learner.actor.params.clone(); t0 = algo.learner.actor_t.params.clone()
+    out = algo.collect_and_train(20)
+    assert out["updates"] > 20 and np.isfinite([out["q_loss"], out["avg_q1"], out["avg_q2"]]).all()
+    assert algo.replay.size == 20 * 64 and (algo.replay.nd[:1280] == 0).sum() > 0           # episodes ended (height or the 15-step limit)
+    assert (algo.replay.a[:1280].abs() <= 1).all()
+    da = (algo.learner.actor.params - a0).abs().max(); dt = (algo.learner.actor_t.params - t0).abs().max()
+    assert da > 1e-4 and 0 < dt < da                                                          # targets trail the live actor (tau = 0.005)
+    ret, eplen = algo.evaluate(n_envs=64, max_traj_len=30)
+    assert np.isfinite(ret) and 1 <= eplen <= 30
+    algo.save()
+    pol = torch.load(str(tmp_path / "actor.pt"), weights_only=False)
+    assert type(pol).__name__ == "FF_Actor" and pol(torch.zeros(50)).abs().max() <= 1
