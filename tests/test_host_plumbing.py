@@ -132,3 +132,44 @@ def test_g18_lstm_checkpoint_classes_match_the_reference(golden_dir):
     a.init_hidden_state()
     steps = torch.stack([a(x[t, 2], deterministic=True) for t in range(x.shape[0])]).detach().numpy()
     np.testing.assert_allclose(steps, g["mu_step_env2"], atol=1e-6)
+
+
+def test_g20_td3_checkpoint_classes_replay_the_reference(golden_dir):
+    """This repo's FF_Actor / Dual_Q_Critic (checkpoint classes of the TD3 path) carry the reference's state_dict keys; with plain torch
+    autograd they reproduce golden G20 (the reference's TD3.train, 4 iterations on recorded batches and noises) - the CPU-side pin of the
+    algorithm the HIP learner is tested against."""
+    import copy
+    import torch.nn.functional as F
+    from rl.policies.actor import FF_Actor
+    from rl.policies.critic import Dual_Q_Critic
+    g = np.load(os.path.join(golden_dir, "g20_td3.npz"))
+    H = int(g["hidden"])
+    ak, ck = [str(k) for k in g["actor_keys"]], [str(k) for k in g["critic_keys"]]
+    mk_a = lambda pre: (lambda n: (n.load_state_dict({k: torch.tensor(g[pre + "." + k]) for k in ak}), n)[1])(FF_Actor(50, 10, layers=(H, H), max_action=1.0))
+    mk_c = lambda pre: (lambda n: (n.load_state_dict({k: torch.tensor(g[pre + "." + k]) for k in ck}), n)[1])(Dual_Q_Critic(50, 10, hidden_size=H))
+    actor, actor_t, critic, critic_t = mk_a("actor0"), mk_a("actor_target0"), mk_c("critic0"), mk_c("critic_target0")
+    assert list(actor.state_dict().keys()) == ak and list(critic.state_dict().keys()) == ck
+    oa = torch.optim.Adam(actor.parameters(), lr=float(g["lr"])); oc = torch.optim.Adam(critic.parameters(), lr=float(g["lr"]))
+    q_loss = pi_loss = 0.0
+    for it in range(int(g["iters"])):
+        p = "b%d_" % it
+        s, s2, a, r, nd = (torch.tensor(g[p + k]) for k in ("x", "y", "u", "r", "d")); nd = 1 - nd
+        noise = torch.tensor(g[p + "noise"]).clamp(-float(g["noise_clip"]), float(g["noise_clip"]))
+        with torch.no_grad():
+            na = (actor_t(s2) + noise).clamp(-1, 1)
+            tq = torch.min(*critic_t(s2, na)); tq = r + nd * float(g["discount"]) * tq
+        q1, q2 = critic(s, a)
+        cl = F.mse_loss(q1, tq) + F.mse_loss(q2, tq); q_loss += float(cl.detach())
+        oc.zero_grad(); cl.backward(); oc.step()
+        if it % int(g["policy_freq"]) == 0:
+            al = -critic.Q1(s, actor(s)).mean(); pi_loss += float(al.detach())
+            oa.zero_grad(); al.backward(); oa.step()
+            with torch.no_grad():
+                for net, tgt in ((critic, critic_t), (actor, actor_t)):
+                    for pp, tp in zip(net.parameters(), tgt.parameters()):
+                        tp.copy_(float(g["tau"]) * pp + (1 - float(g["tau"])) * tp)
+    n = int(g["iters"])
+    np.testing.assert_allclose([q_loss / n, pi_loss / n], [float(g["ret_q_loss"]), float(g["ret_pi_loss"])], rtol=1e-5)
+    for nm, net, keys in (("actor1", actor, ak), ("actor_target1", actor_t, ak), ("critic1", critic, ck), ("critic_target1", critic_t, ck)):
+        for k, v in net.state_dict().items():
+            np.testing.assert_allclose(v.numpy(), g[nm + "." + k], atol=1e-6, err_msg=nm + "." + k)
