@@ -364,20 +364,32 @@ class TD3Learner:
         lib = _lib.load()
         B = state.shape[0]
         state, action, next_state = state.contiguous(), action.contiguous(), next_state.contiguous()
+        # the twin critics are independent, latency-bound chains at these batch sizes: Q2's passes run on a second HIP stream
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side
         xin_t = self._cat(next_state, self.actor_t.forward(next_state), noise.contiguous(), noise_clip)
-        tq1, tq2 = self.q_t[0].forward(xin_t), self.q_t[1].forward(xin_t)
         xin = torch.cat([state, action], 1).contiguous()
-        kept = [self.q[i].forward(xin, keep=True) for i in range(2)]
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            tq2 = self.q_t[1].forward(xin_t); k2 = self.q[1].forward(xin, keep=True)
+        tq1 = self.q_t[0].forward(xin_t); k1 = self.q[0].forward(xin, keep=True)
+        main.wait_stream(side)
+        kept = [k1, k2]
         dq = [torch.empty(B, dtype=torch.float32, device=self.device) for _ in range(2)]
         check(lib.apx_td3_critic_loss(_p(kept[0][0]), _p(kept[1][0]), _p(tq1), _p(tq2), _p(reward.contiguous()), _p(notdone.contiguous()), float(discount), B,
                                       _p(dq[0]), _p(dq[1]), _p(self._acc), _stream()))
         stats = self._acc.clone()
         self.c_g.zero_()
-        scratch = torch.empty(2 * B * self.H, dtype=torch.float32, device=self.device)
-        for i in range(2):
+        scratch = torch.empty(2 * B * self.H, dtype=torch.float32, device=self.device); scratch2 = torch.empty_like(scratch)
+        side.wait_stream(main)
+        for i, (strm, scr) in enumerate(((main, scratch), (side, scratch2))):
             y, xn, a1, a2 = kept[i]
-            check(lib.apx_mlp_backward(_p(self.q[i].params), _p(self.c_g[i * self.n1:(i + 1) * self.n1]), self.D + self.A, self.H, 1, _p(xn), _p(a1), _p(a2),
-                                       _p(dq[i]), B, None, _p(scratch), _stream()))
+            with torch.cuda.stream(strm):
+                check(lib.apx_mlp_backward(_p(self.q[i].params), _p(self.c_g[i * self.n1:(i + 1) * self.n1]), self.D + self.A, self.H, 1, _p(xn), _p(a1), _p(a2),
+                                           _p(dq[i]), B, None, _p(scr), _stream()))
+        main.wait_stream(side)
         self.t_c += 1
         self._adam(self.critic_flat, self.c_m, self.c_v, self.c_g, self.c_lr, self.t_c)
         pi_loss = None
