@@ -173,3 +173,36 @@ def test_g20_td3_checkpoint_classes_replay_the_reference(golden_dir):
     for nm, net, keys in (("actor1", actor, ak), ("actor_target1", actor_t, ak), ("critic1", critic, ck), ("critic_target1", critic_t, ck)):
         for k, v in net.state_dict().items():
             np.testing.assert_allclose(v.numpy(), g[nm + "." + k], atol=1e-6, err_msg=nm + "." + k)
+
+
+def test_hbm_replay_ring_semantics_on_host_tensors():
+    """The TD3 replay (apex_amd/td3.py) is index arithmetic on tensors: ring overwrite of the oldest entries (remote_replay.py:70-74) and
+    uniform sampling with replacement (:78-90); checked here on CPU tensors (the class itself is device-agnostic plumbing)."""
+    from apex_amd.td3 import HbmReplay
+    dev = torch.device("cpu")
+    rb = HbmReplay(10, 2, 1, dev)
+    for k in range(3):
+        base = torch.arange(4).float() + 4 * k
+        rb.add(base.view(4, 1).repeat(1, 2), base.view(4, 1).repeat(1, 2) + 0.5, base.view(4, 1), base, (base % 2 == 0).float())
+    assert rb.size == 10 and rb.ptr == 2
+    np.testing.assert_allclose(rb.r.numpy(), [10, 11, 2, 3, 4, 5, 6, 7, 8, 9])
+    g = torch.Generator(device=dev); g.manual_seed(0)
+    s, s2, a, r, nd = rb.sample(2000, g)
+    assert torch.equal(s[:, 0], r) and torch.equal(s2[:, 1], r + 0.5) and torch.equal(a[:, 0], r) and torch.equal(nd, (r % 2 == 0).float())
+    assert set(r.long().tolist()) == set(range(2, 12))
+
+
+def test_recurrent_trajectory_bookkeeping():
+    """apex_amd/ppo_recurrent.py: trajectories of a [T, N] end-flag grid in (column, time) order and their padded flat-index tensor in the
+    layout of torch's pad_sequence (rl/algos/ppo.py:411-430)."""
+    from apex_amd.ppo_recurrent import RecurrentPPO
+    algo = object.__new__(RecurrentPPO)
+    T, N = 7, 3
+    end = torch.zeros(T, N, dtype=torch.uint8)
+    end[2, 0] = end[6, 0] = 1; end[6, 1] = 1; end[0, 2] = end[1, 2] = end[6, 2] = 1
+    algo.b_end, algo.N, algo.device = end, N, torch.device("cpu")
+    tr = algo.trajectories()
+    assert tr.tolist() == [[0, 0, 3], [0, 3, 7], [1, 0, 7], [2, 0, 1], [2, 1, 2], [2, 2, 7]]
+    idx = algo.padded_index(tr[[0, 2, 3]])
+    ref = torch.nn.utils.rnn.pad_sequence([torch.arange(t0, t1) * N + n for n, t0, t1 in tr[[0, 2, 3]]], batch_first=False, padding_value=-1)
+    assert torch.equal(idx, ref) and idx.shape == (7, 3)
