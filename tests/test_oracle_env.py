@@ -321,7 +321,7 @@ def test_g16_step_basic_bookkeeping(golden_dir):
 
 def test_g11c_estimator_height_model(golden_dir):
     """G11c: the reference filter's height output (pelvis.position[2] - terrain.height, observation entry 0) on our sensor stream while
-    the policy of trained_models/r01_cassie_v0_clock walks for 3 s (6000 substeps of 2 kHz), with the true pelvis z and the lowest sole
+    a 1000-iteration policy trained with this build (the predecessor of trained_models/r01_cassie_v0_clock) walks for 3 s (6000 substeps of 2 kHz), with the true pelvis z and the lowest sole
     height per substep (tools/refprobe/gen_golden_estheight.py).  The build's model, height = z - L with L a first-order low-pass
     (EST_TAU) of the lowest sole height started at EST_L0 by state_output_setup, stays within 1.2 cm of the reference over the whole
     stream (the former constant offset z - 0.0818 is off by up to 8.4 cm on it); the oracle env implements exactly this recursion."""

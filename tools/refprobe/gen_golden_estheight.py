@@ -1,5 +1,5 @@
 """Golden G11c: the reference state estimator's HEIGHT output (pelvis.position[2] - terrain.height, the first observation entry,
-cassie.py:793) on our sensor stream while the trained policy of trained_models/r01_cassie_v0_clock walks for 3 s, per 2 kHz substep,
+cassie.py:793) on our sensor stream while a policy trained with this build (any actor.pt of apex.py ppo; the committed fixture used a 1000-iteration one) walks for 3 s, per 2 kHz substep,
 together with the true pelvis z and the lowest world z of the two foot soles (foot capsule end - radius).  Pins the height model of
 the build: height = z - L, L' = (lowest sole z - L) / tau."""
 import sys, os
