@@ -142,8 +142,10 @@ class CassieVecEnv:
         finished envs restart inside the same launch and `final_obs` holds their last observation (rows of envs that did not
         finish are left untouched).  `out` = (obs, reward, done, final_obs) lets the kernels write straight into caller-owned
         contiguous device buffers (e.g. slices of a rollout grid) instead of the env's own."""
+        if not action.is_cuda:
+            raise _lib.ApxError("CassieVecEnv.step needs a device tensor (there is no CPU path)")
         action = action.contiguous()
-        assert action.shape == (self.n_envs, ACT_DIM) and action.dtype == torch.float32 and action.is_cuda
+        assert action.shape == (self.n_envs, ACT_DIM) and action.dtype == torch.float32
         obs, rew, done, fin = out if out is not None else (self.obs, self.reward, self.done, self.final_obs)
         if out is not None:
             assert obs.is_contiguous() and rew.is_contiguous() and done.is_contiguous() and fin.is_contiguous()

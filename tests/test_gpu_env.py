@@ -420,3 +420,35 @@ def test_cassie_traj_v0_reset_and_steps_vs_oracle(dev):
     assert (done == 2).all()
     q = genv2.get_field("qpos").cpu().numpy()
     assert np.abs(q[:, 2] - 1.01).max() > 5e-3 and np.isfinite(q).all()
+
+
+def test_edge_cases_simrate_empty_mask_and_bad_arguments(dev):
+    """Edge cases through the C ABI: a non-default simrate (apex.py:18 --simrate; phase length and the clock follow 2000 // simrate) against
+    the oracle; a reset with an all-zero mask is a no-op; invalid configurations fail loudly with a message instead of launching."""
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd import _lib
+    genv = CassieVecEnv(n_envs=N, dynamics_randomization=True, seed=8, simrate=40)
+    oenv = [S.OracleEnv(simrate=40, dyn_rand=True, seed=8, env_id=i) for i in range(6)]
+    gobs = genv.reset().cpu().numpy()
+    for i, e in enumerate(oenv):
+        np.testing.assert_allclose(gobs[i, 46:50], e.reset()[46:50], atol=1e-5)
+        assert abs(genv.get_field("cmd").cpu().numpy()[i, 5] - e.get("phaselen")[0]) < 1e-4          # 2 (swing + stance) * (2000 // 40)
+    act = (np.random.RandomState(1).randn(N, 10) * 0.1).astype(np.float32)
+    obs, rew, done, _ = genv.step(torch.tensor(act, device=dev), auto_reset=False)
+    obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
+    tol = np.full(50, 1.2e-2); tol[21:31] = 0.3; tol[31:34] = 0.6; tol[40:46] = 0.3
+    for i, e in enumerate(oenv):
+        o, r, d = e.step(act[i].astype(np.float64))
+        assert np.all(np.abs(obs[i] - o) <= tol + 5e-3 * np.abs(o)), (i, np.abs(obs[i] - o).max())
+        assert abs(rew[i] - r) < 0.02
+    # reset with an empty mask: nothing changes
+    q0 = genv.get_field("qpos").clone(); i0 = genv.get_field("ints").clone()
+    genv.reset(mask=torch.zeros(N, dtype=torch.uint8, device=dev))
+    assert torch.equal(genv.get_field("qpos"), q0) and torch.equal(genv.get_field("ints"), i0)
+    # loud failures
+    for kw, frag in ((dict(n_envs=100), "multiple of 64"), (dict(n_envs=64, env_name="CassieTraj-v0", simrate=40), "simrate")):
+        with pytest.raises((_lib.ApxError, NotImplementedError)) as ei:
+            CassieVecEnv(**kw)
+        assert frag in str(ei.value)
+    with pytest.raises(_lib.ApxError):
+        genv.step(torch.zeros(N, 10))                                       # host tensor: no CPU path
