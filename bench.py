@@ -47,6 +47,31 @@ def _pmc_traffic_bytes():
         return None
 
 
+def main_td3(a):
+    """BASELINE.json configs[4] (next row f2): Cassie-v0 TD3, 1 GPU, 10^6-transition replay in HBM; a "step" = 32 lock-step env steps of 4096
+    envs, each followed by 4 twin-critic updates on 1024 samples."""
+    assert a.gpus == 1 and int(os.environ.get("WORLD_SIZE", 1)) == 1, "the TD3 workload is single-GPU (BASELINE.json configs[4])"
+    torch.cuda.set_device(0)
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd.td3 import TD3
+    n_envs, T, upd, bs = 4096, 32, 4, 1024
+    env = CassieVecEnv(n_envs=n_envs, seed=0)
+    algo = TD3(env, "/tmp/apx_bench_unused", batch_size=bs, updates_per_step=upd, replay_size=1_000_000, seed=0)
+    algo.init_networks(0)
+    for _ in range(a.warmup):
+        algo.collect_and_train(T)
+    torch.cuda.synchronize(); t0 = time.time()
+    for _ in range(a.steps):
+        out = algo.collect_and_train(T)
+    torch.cuda.synchronize(); dt = time.time() - t0
+    print(json.dumps({"metric": "env-steps/sec Cassie-v0 TD3 @4096 envs, replay in HBM", "value": round(a.steps * T * n_envs / dt, 1), "unit": "env-steps/s",
+                      "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
+                      "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": "Cassie-v0 TD3, 1M-transition replay buffer in HBM, twin-critic update in HIP (BASELINE.json configs[4])",
+                                 "envs_per_gpu": n_envs, "collect_steps": T, "updates_per_env_step": upd, "batch_size": bs, "replay_capacity": 1000000},
+                      "updates_per_s": round(a.steps * T * upd / dt, 1), "replay_size": int(algo.replay.size)}))
+
+
 def main_recurrent(a):
     """BASELINE.json configs[3] (next row f1): CassieTraj-v0 recurrent PPO, 2048 envs/GPU, whole-trajectory minibatches.  Same contract:
     W warm-up iterations, K timed ones between barriers, one JSON line on rank 0."""
@@ -102,11 +127,13 @@ def main():
     ap.add_argument("--minibatch", type=int, default=16384)
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--workload", default="cassie_ppo", choices=["cassie_ppo", "cassietraj_recurrent"],
-                    help="cassie_ppo = BASELINE.json configs[1] (the headline, default); cassietraj_recurrent = configs[3]: CassieTraj-v0, LSTM 2x128, 2048 envs/GPU")
+    ap.add_argument("--workload", default="cassie_ppo", choices=["cassie_ppo", "cassietraj_recurrent", "cassie_td3"],
+                    help="cassie_ppo = BASELINE.json configs[1] (the headline, default); cassietraj_recurrent = configs[3]: CassieTraj-v0, LSTM 2x128, 2048 envs/GPU; cassie_td3 = configs[4]: TD3, 1M-transition replay in HBM")
     a = ap.parse_args()
     if a.workload == "cassietraj_recurrent":
         return main_recurrent(a)
+    if a.workload == "cassie_td3":
+        return main_td3(a)
 
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
