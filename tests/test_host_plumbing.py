@@ -206,3 +206,20 @@ def test_recurrent_trajectory_bookkeeping():
     idx = algo.padded_index(tr[[0, 2, 3]])
     ref = torch.nn.utils.rnn.pad_sequence([torch.arange(t0, t1) * N + n for n, t0, t1 in tr[[0, 2, 3]]], batch_first=False, padding_value=-1)
     assert torch.equal(idx, ref) and idx.shape == (7, 3)
+
+
+def test_product_code_never_touches_the_oracle_or_the_reference():
+    """The oracle is test infrastructure: nothing under apex_amd/, rl/ or apex.py may import it (only tests/, __graft_entry__.smoke() and
+    bench.py's cpu_baseline do), and nothing shipped reads /root/reference at run time."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "apex.py")]
+    for d in ("apex_amd", "rl"):
+        for dp, _, fs in os.walk(os.path.join(root, d)):
+            files += [os.path.join(dp, f) for f in fs if f.endswith((".py", ".hip", ".h"))]
+    for f in files:
+        txt = open(f, errors="ignore").read()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f
+        assert "/root/reference" not in txt, f
+    bench = open(os.path.join(root, "bench.py")).read()
+    assert bench.count("from oracle") == 1 and "def cpu_baseline" in bench            # the one allowed use
