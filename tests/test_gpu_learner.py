@@ -256,3 +256,49 @@ def test_td3_train_golden_g20(dev, golden_dir):
             d = np.abs(v.cpu().numpy() - g[nm + "." + k])
             lim = 2.1e-3 if "target" not in nm else 2e-5           # Adam at lr 1e-3: a sign tie at g ~ 0 moves a weight by 2e-3
             assert (d > 2e-5).mean() < (5e-3 if "target" not in nm else 1e-9 + 5e-3) and d.max() < lim + 1e-9, (nm, k, (d > 2e-5).mean(), d.max())
+
+
+def test_full_size_properties_of_the_learner_kernels(dev):
+    """BASELINE sizes (T = 32, N = 4096 -> 131 072 samples, minibatch 16 384) through size-independent properties: the return scan is linear
+    in (rewards, bootstrap values) and splits at episode ends; normalised advantages have mean 0 / unbiased std 1 and are invariant to an
+    affine change of the returns; the mirror loss of a mirror-symmetric policy is zero and grows when the symmetry is broken; a PPO step
+    with old == new policy has ratio 1 and KL 0 on the whole minibatch."""
+    from apex_amd import engine
+    from apex_amd.vecenv import MIRRORED_OBS, MIRRORED_ACTS, CLOCK_INDS
+    T, N = 32, 4096
+    g = torch.Generator(device=dev); g.manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    r1, r2, b1, b2 = rnd(T, N), rnd(T, N), rnd(T, N), rnd(T, N)
+    end = (torch.rand(T, N, device=dev, generator=g) < 0.05).to(torch.uint8)
+    l1, l2 = rnd(N), rnd(N)
+    R = lambda r, b, l: engine.returns_scan(r, end, b, l, 0.99)
+    np.testing.assert_allclose(R(2 * r1 - 3 * r2, 2 * b1 - 3 * b2, 2 * l1 - 3 * l2).cpu().numpy(), (2 * R(r1, b1, l1) - 3 * R(r2, b2, l2)).cpu().numpy(), rtol=1e-4, atol=1e-4)
+    ret = R(r1, b1, l1)
+    e = end.bool()
+    np.testing.assert_allclose(ret[e].cpu().numpy(), (r1 + 0.99 * b1)[e].cpu().numpy(), rtol=1e-6, atol=1e-6)        # an episode end sees only its own reward + bootstrap
+    val = rnd(T, N)
+    adv = engine.normalize_advantages(ret, val)
+    assert abs(float(adv.mean())) < 1e-4 and abs(float(adv.std()) - 1) < 1e-3
+    adv2 = engine.normalize_advantages(5 * ret + 7, 5 * val)
+    np.testing.assert_allclose(adv2.cpu().numpy(), adv.cpu().numpy(), rtol=1e-3, atol=2e-4)
+    # learner on a 16 384-row minibatch
+    L = engine.PPOLearner(50, 10, 256, dev, float(np.exp(-1.5)), mirrored_obs=MIRRORED_OBS, mirrored_acts=MIRRORED_ACTS, clock_inds=CLOCK_INDS)
+    L.actor.params.copy_(rnd(L.actor.n) * 0.05); L.critic.params.copy_(rnd(L.critic.n) * 0.05)
+    B = 16384
+    obs = rnd(B, 50) * 0.5; ph = torch.rand(B, device=dev, generator=g) * 6.28; obs[:, 46] = torch.sin(ph); obs[:, 47] = torch.cos(ph)
+    act = rnd(B, 10) * 0.3; retb = rnd(B); advb = rnd(B)
+    mu = L.old_means(obs)
+    scal = L.minibatch(obs, act, retb, advb, mu, grad_only=True)
+    assert abs(scal[3] - 1) < 1e-6 and abs(scal[4]) < 1e-9 and scal[5] > 0          # ratio 1, KL 0, a random net is not mirror-symmetric
+    np.testing.assert_allclose(scal[0], -float(advb.mean()), rtol=1e-4, atol=1e-6)   # ratio 1 everywhere: actor loss = -mean(adv)
+    # a mirror-symmetric policy: pi(s) := (f(s) + M_a f(M_s s)) / 2 is symmetric; the plain net is not, but its mirror loss must equal
+    # 0.4 * mean((f(s) - M_a f(M_s s))^2) computed from two plain forwards
+    sp = engine.signed_perm_from_mirror(MIRRORED_OBS); ap = engine.signed_perm_from_mirror(MIRRORED_ACTS)
+    src = torch.as_tensor(np.where(sp >= 0, sp, -sp - 1), device=dev); sgn = torch.as_tensor(np.where(sp >= 0, 1.0, -1.0), dtype=torch.float32, device=dev)
+    mobs = obs.index_select(1, src) * sgn
+    for c in CLOCK_INDS:
+        mobs[:, c] = torch.sin(torch.asin(mobs[:, c].clamp(-1, 1)) + np.pi)
+    f_m = L.actor.forward(mobs.contiguous(), L.obs_mean, L.obs_std)
+    asrc = torch.as_tensor(np.where(ap >= 0, ap, -ap - 1), device=dev); asgn = torch.as_tensor(np.where(ap >= 0, 1.0, -1.0), dtype=torch.float32, device=dev)
+    mir = f_m.index_select(1, asrc) * asgn
+    np.testing.assert_allclose(scal[5], 0.4 * float(((mu - mir) ** 2).mean()), rtol=2e-4)
