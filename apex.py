@@ -71,13 +71,8 @@ def eval_main(argv):
     from apex_amd.vecenv import CassieVecEnv
     from apex_amd.engine import Mlp
     from apex_amd.eval import evaluate
-    policy = torch.load(os.path.join(a.path, "actor.pt"), weights_only=False)
     env = CassieVecEnv(n_envs=a.n_envs, reward=a.reward, max_traj_len=a.max_traj_len, dynamics_randomization=False)
-    params = [q.detach().numpy() for q in policy.parameters()]
-    actor = Mlp(params[0].shape[1], params[0].shape[0], params[-1].shape[0], env.device)
-    actor.load_list(params)
-    mean = torch.as_tensor(policy.obs_mean, dtype=torch.float32).to(env.device) if torch.is_tensor(policy.obs_mean) else None
-    std = torch.as_tensor(policy.obs_std, dtype=torch.float32).to(env.device) if torch.is_tensor(policy.obs_std) else None
+    actor, mean, std = _load_actor(a.path, env.device)
     out = evaluate(actor, env, mean, std, speed=a.speed, side_speed=a.side_speed, max_steps=a.max_traj_len, basic=a.basic)
     ln, rt = out["lengths"].cpu(), out["returns"].cpu()
     print("episodes %d  mean length %.1f (min %d, max %d)  mean return %.3f  fell %d  reached the time limit %d" % (
@@ -91,10 +86,17 @@ def _load_actor(path, device):
     from apex_amd.engine import Mlp
     policy = torch.load(os.path.join(path, "actor.pt"), weights_only=False)
     params = [q.detach().numpy() for q in policy.parameters()]
-    actor = Mlp(params[0].shape[1], params[0].shape[0], params[-1].shape[0], device)
-    actor.load_list(params)
     mean = torch.as_tensor(policy.obs_mean, dtype=torch.float32).to(device) if torch.is_tensor(policy.obs_mean) else None
     std = torch.as_tensor(policy.obs_std, dtype=torch.float32).to(device) if torch.is_tensor(policy.obs_std) else None
+    if getattr(policy, "is_recurrent", False):        # Gaussian_LSTM_Actor: step the HIP LSTM with one carried (h, c) per env
+        from apex_amd.engine import Lstm
+        from apex_amd.eval import RecurrentActor
+        H, L = policy.actor_layers[0].hidden_size, len(policy.actor_layers)
+        net = Lstm(params[0].shape[1], H, L, params[-1].shape[0], device)
+        net.load_list(params)
+        return RecurrentActor(net, mean, std), None, None
+    actor = Mlp(params[0].shape[1], params[0].shape[0], params[-1].shape[0], device)
+    actor.load_list(params)
     return actor, mean, std
 
 

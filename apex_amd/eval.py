@@ -4,6 +4,23 @@ update_speed / step_basic): every env runs ONE episode with the policy mean as a
 import torch
 
 
+class RecurrentActor:
+    """Callable wrapper that steps an apex_amd.engine.Lstm actor with one carried (h, c) per env (zero at construction / reset_state):
+    what `policy(state)` does for a Gaussian_LSTM_Actor between init_hidden_state() calls (rl/policies/actor.py:270-281)."""
+
+    def __init__(self, net, obs_mean=None, obs_std=None):
+        self.net, self.mean, self.std, self.hc = net, obs_mean, obs_std, None
+
+    def reset_state(self):
+        self.hc = None
+
+    def __call__(self, obs):
+        if self.hc is None or self.hc.shape[2] != obs.shape[0]:
+            self.hc = torch.zeros(self.net.L, 2, obs.shape[0], self.net.H, device=obs.device)
+        x = obs if self.mean is None else (obs - self.mean) / self.std
+        return self.net.forward(x.contiguous(), hc=self.hc)
+
+
 @torch.no_grad()
 def evaluate(actor, env, obs_mean=None, obs_std=None, speed=None, side_speed=0.0, max_steps=None, basic=False):
     """actor: apex_amd.engine.Mlp (or any callable obs -> action mean on device tensors).
@@ -14,6 +31,8 @@ def evaluate(actor, env, obs_mean=None, obs_std=None, speed=None, side_speed=0.0
     Returns dict(returns [N] (zeros when basic), lengths [N], terminated [N] bool, truncated [N] bool)."""
     n = env.n_envs
     max_steps = max_steps or env.max_traj_len
+    if hasattr(actor, "reset_state"):
+        actor.reset_state()
     env.reset_for_test()
     if speed is not None:
         env.update_speed(speed, side_speed)

@@ -314,6 +314,17 @@ def test_recurrent_ppo_iteration_on_the_hip_env(dev, tmp_path):
     assert type(pol).__name__ == "Gaussian_LSTM_Actor" and pol.is_recurrent
     pol.init_hidden_state()
     assert pol(torch.zeros(50), deterministic=True).shape[-1] == 10
+    # the recurrent checkpoint is scored by the same CLI: one carried (h, c) per env through the HIP LSTM
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import apex
+    assert apex.main(["eval", "--path", str(tmp_path), "--n_envs", "64", "--speed", "0.5", "--max_traj_len", "30"]) == 0
+    from apex_amd.eval import RecurrentActor
+    ra = RecurrentActor(algo.learner.actor, algo.learner.obs_mean, algo.learner.obs_std)
+    o = torch.randn(5, 64, 50, device=dev)
+    steps = torch.stack([ra(o[t]) for t in range(5)])
+    seq = algo.learner.actor.forward(((o - algo.learner.obs_mean) / algo.learner.obs_std).contiguous())
+    np.testing.assert_allclose(steps.cpu().numpy(), seq.cpu().numpy(), rtol=1e-5, atol=1e-6)       # stepping == the sequence pass from zero state
 
 
 def test_whole_train_loop_recurrent_golden_g15d(dev, golden_dir):
