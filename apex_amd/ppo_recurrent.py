@@ -26,6 +26,8 @@ class RecurrentPPO:
         self.fixed_std = float(np.exp(args.get("std_dev", -2.0)))                  # ppo.py:537: recurrent policies use exp(-2)
         self.env_name = args.get("env_name", "Cassie-v0")
         self.save_path, self.env = save_path, env
+        if world_size > 1:      # ranks would hold different numbers of trajectories -> different minibatch counts per epoch: not arranged yet
+            raise NotImplementedError("recurrent PPO is single-GPU in this round (the feed-forward path shards over ranks)")
         self.rank, self.world, self.group = rank, world_size, group
         self.device, self.N = env.device, env.n_envs
         self.T = adist.rollout_len(self.num_steps, self.N, self.world)

@@ -76,7 +76,7 @@ def main_recurrent(a):
     """BASELINE.json configs[3] (next row f1): CassieTraj-v0 recurrent PPO, 2048 envs/GPU, whole-trajectory minibatches.  Same contract:
     W warm-up iterations, K timed ones between barriers, one JSON line on rank 0."""
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == a.gpus
+    assert world == a.gpus == 1, "the recurrent workload is single-GPU in this round"
     torch.cuda.set_device(local)
     group = None
     if world > 1:
