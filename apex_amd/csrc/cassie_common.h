@@ -1,0 +1,109 @@
+// Shared pieces of the Cassie substep kernels (gfx950): model constants, compile-time loops, 3-vector / quaternion / spatial algebra,
+// MuJoCo's soft-constraint scalars (solref / solimp defaults), the per-env LDS hand-off layout and the optional phase profiler.
+//
+// What the substep replaces: cassie_sim_step_pd -> mj_step inside libcassiemujoco.so / MuJoCo 2.00
+// (cassie/cassiemujoco/cassiemujoco.py:46-49, include/cassiemujoco.h:80).  The robot's topology is a
+// compile-time constant (cassie_tables.h, generated from cassie.xml by tools/gen_model.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <utility>
+#include "cassie_tables.h"
+#include "env_state.h"
+
+namespace c4 {
+using namespace cmt;
+
+constexpr int NB = CM_NBODY, NV = CM_NV, NQ = CM_NQ, NJ = CM_NJNT, NU = CM_NU, NM = CM_NM;
+constexpr float DT = 0.0005f, GRAV = 9.81f, MINVAL = 1e-15f;
+
+template <int B, int E, class F> __device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); sfor<B + 1, E>(f); }
+}
+template <int B, int E, class F> __device__ __forceinline__ void srfor(F&& f) {   // E-1 down to B
+    if constexpr (B < E) { f(std::integral_constant<int, E - 1>{}); srfor<B, E - 1>(f); }
+}
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+struct Q4 { float w, x, y, z; };
+__device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
+    return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+            a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+__device__ __forceinline__ Q4 qnormalize(Q4 q) {
+    const float n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+    if (!(n2 > 1e-30f)) return {1.f, 0.f, 0.f, 0.f};
+    const float s = rsqrtf(n2);
+    return {q.w * s, q.x * s, q.y * s, q.z * s};
+}
+struct M3 { float m[9]; };
+__device__ __forceinline__ M3 q2m(Q4 q) {
+    const float w = q.w, x = q.x, y = q.y, z = q.z;
+    return {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z),
+             1 - 2 * (x * x + z * z), 2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x),
+             1 - 2 * (x * x + y * y)}};
+}
+__device__ __forceinline__ V3 mul(const M3& R, V3 v) {
+    return {R.m[0] * v.x + R.m[1] * v.y + R.m[2] * v.z, R.m[3] * v.x + R.m[4] * v.y + R.m[5] * v.z,
+            R.m[6] * v.x + R.m[7] * v.y + R.m[8] * v.z};
+}
+__device__ __forceinline__ V3 col(const M3& R, int k) { return {R.m[k], R.m[3 + k], R.m[6 + k]}; }
+struct SV { V3 a, l; };
+__device__ __forceinline__ SV operator+(SV p, SV q) { return {p.a + q.a, p.l + q.l}; }
+__device__ __forceinline__ SV operator*(SV p, float s) { return {p.a * s, p.l * s}; }
+__device__ __forceinline__ SV crossMotion(SV v, SV s) { return {cross(v.a, s.a), cross(v.a, s.l) + cross(v.l, s.a)}; }
+__device__ __forceinline__ SV crossForce(SV v, SV f) { return {cross(v.a, f.a) + cross(v.l, f.l), cross(v.a, f.l)}; }
+__device__ __forceinline__ float sdot(SV m, SV f) { return dot(m.a, f.a) + dot(m.l, f.l); }
+struct SI { float m; V3 h; float I[6]; };
+__device__ __forceinline__ V3 symmul(const float* I, V3 v) {
+    return {I[0] * v.x + I[3] * v.y + I[4] * v.z, I[3] * v.x + I[1] * v.y + I[5] * v.z, I[4] * v.x + I[5] * v.y + I[2] * v.z};
+}
+__device__ __forceinline__ SV imul(const SI& s, SV v) { return {symmul(s.I, v.a) + cross(s.h, v.l), v.l * s.m - cross(s.h, v.a)}; }
+template <int K> constexpr V3 cv3(const float* p) { return V3{p[3 * K], p[3 * K + 1], p[3 * K + 2]}; }
+
+// local column (0..18) of a row of leg LEG -> global dof
+template <int LEG> constexpr int c2d(int c) { return c < 6 ? c : c + 13 * LEG; }
+constexpr int d2c(int d) { return d < 6 ? d : (d < 19 ? d : d - 13); }
+// bodies whose poses the constraints need: per leg slot 0 achilles, 1 heel-spring, 2 plantar-rod, 3 foot, 4 tarsus, 5 shin
+template <int LEG> constexpr int cbody(int s) { constexpr int t[6] = {5, 10, 12, 13, 9, 8}; return t[s] + 12 * LEG; }
+static_assert(ct_jnt_type[0] == 0 && ct_jnt_type[1] == 0 && ct_jnt_type[2] == 0 && ct_jnt_type[3] == 2, "pelvis = 3 slides + ball");
+static_assert(ct_body_parent[1] == 0, "pelvis hangs off the world");
+
+__device__ __forceinline__ float impedance(float pos) {   // MuJoCo solimp defaults 0.9 0.95 0.001 0.5 2
+    const float x = fabsf(pos) * 1000.f;
+    if (x >= 1.f) return 0.95f;
+    if (x <= 0.f) return 0.9f;
+    const float y = x <= 0.5f ? 2.f * x * x : 1.f - 2.f * (1.f - x) * (1.f - x);
+    return 0.9f + y * 0.05f;
+}
+struct RowK { float K, B; };
+__device__ __forceinline__ RowK solref(float timeconst) {   // dampratio 1, dmax 0.95
+    return {1.f / (0.95f * 0.95f * timeconst * timeconst), 2.f / (0.95f * timeconst)};
+}
+
+// optional phase profiling (lane 0 of workgroup 0): cumulative shader cycles per phase, read by tools/t_prof.py
+#ifdef APX_PROF
+__device__ unsigned long long g_prof_acc[12];
+__device__ unsigned long long g_prof_last;
+#define PROF(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long t__ = clock64(); c4::g_prof_acc[i] += t__ - c4::g_prof_last; c4::g_prof_last = t__; } } while (0)
+#define PROF_START() do { if (threadIdx.x == 0 && blockIdx.x == 0) c4::g_prof_last = clock64(); } while (0)
+#else
+#define PROF(i) do {} while (0)
+#define PROF_START() do {} while (0)
+#endif
+
+// stage hand-off layout inside the per-env LDS region (floats, offsets from L4_WK)
+constexpr int WK_M = 0, WK_CDOF = WK_M + NM, WK_SMOOTH = WK_CDOF + 6 * NV, WK_QS = WK_SMOOTH + NV, WK_PTS = WK_QS + NV,
+              WK_PEL = WK_PTS + 60, WK_LD = WK_PEL + 24, WK_DISQ = WK_LD + NM, WK_ZT = WK_DISQ + NV, WK_QACC = WK_ZT + NV,
+              WK_MISC = WK_QACC + NV /* ncon0 ncon1 nlim0 nlim1 footmaskL footmaskR costL costR */, WK_ZP2 = WK_MISC + 8 /* z~ pelvis warm-start parts L, R */,
+              WK_TOTAL = WK_ZP2 + 12;
+// WK_PTS per leg (30): eq0 p1,p2 | eq1 p1,p2 | capsule ends: foot e0,e1, tarsus e0,e1, shin e0,e1
+
+constexpr int MAXC = 2;      // contact slots per leg per substep (oracle: MAXCON_LEG)
+template <int K> __device__ __forceinline__ V3 ldv3(const St& S) { return {S.W(K), S.W(K + 1), S.W(K + 2)}; }
+
+}  // namespace c4

@@ -11,10 +11,9 @@
 //   A constraint row of leg LEG is stored as two floats per lane (ya, yp): value that multiplies zA, value that
 //   multiplies zB.  Left rows: (col, 0) on leg lanes; right rows: (0, col); pelvis lanes: (col l-13, col l-10).
 #pragma once
-#include "cassie_step3.h"
+#include "cassie_common.h"
 
 namespace c4 {
-using namespace c3;
 static_assert(L4_WK + WK_TOTAL <= L4_ROWS && L4_ROWS % 4 == 0 && L4_ROWS + 704 <= L4_ES && L4_ES % 64 == 16, "per-env LDS layout");
 
 // v_rcp_f32 (1 ulp): __frcp_rn and '/' expand to the ~10-instruction correctly rounded division sequence

@@ -4,36 +4,24 @@
 // Replaces cassie/cassie.py:293-496,523-680,787-859 + cassie/rewards/clock_rewards.py:6-110 +
 // cassie/phase_function.py:5-136 and the per-env ctypes FFI below them (cassie/cassiemujoco/cassiemujoco.py).
 //
-// Layout: env-per-lane.  All persistent state is SoA in HBM, field-major: st[field * n_envs + env], so every load
-// and store of a field is one coalesced 256-B transaction per wave.  Algorithmic HBM traffic per env step is the
-// state read + write (2 * F_TOTAL * 4 B ~ 4.7 KB) + action/obs/reward I/O (246 B): the kernel is VALU/LDS bound
-// (DESIGN.md §6), not HBM bound.
+// Layout: one env per 16-lane DPP row (4 envs per wave64), the env's whole state resident in LDS for the launch.  Persistent
+// state is SoA in HBM, field-major: st[field * n_envs + env].  Algorithmic HBM traffic per env step is the state read + write
+// (2 * 590 words) + action/obs/reward I/O (246 B) = 4 965 B: the kernel is VALU-issue / LDS-latency bound.
 #include "apx_common.h"
 #include "cassie_model_gen.h"
-#include "cassie_step3.h"
-#if defined(APX_GEN) && APX_GEN == 4
 #include "cassie_lane.h"
-#endif
 
 extern __shared__ __attribute__((aligned(16))) float4 apx_lds4[];   // dynamic LDS: the constraint-row store
 #include <new>
 #include <cstring>
 
 using namespace cmt;
-using c2::V3; using c2::Q4; using c2::M3; using c2::qmul; using c2::q2m; using c2::col; using c2::cross; using c2::dot; using c2::mul;
+using c4::V3; using c4::Q4; using c4::M3; using c4::qmul; using c4::q2m; using c4::col; using c4::cross; using c4::dot; using c4::mul;
 constexpr int NQ = CM_NQ, NV = CM_NV, NB = CM_NBODY;
 constexpr float GRAV = 9.81f;
 
 #include "env_state.h"
 #include "cassie_traj_gen.h"
-
-// ------------------------------------------------------------------------------------------------ forward dynamics
-// mj_setConst subset (cassie_step3.h), staged like the substep
-#if APX_GEN != 4
-__device__ __noinline__ void setconst_a(St S) { c3::setconst_tree(S); c3::setconst_factor(S); }
-template <int LEG> __device__ __noinline__ void setconst_b(St S) { c3::setconst_leg<LEG>(S); }
-__device__ __forceinline__ void set_const_single_wave(const St& S) { setconst_a(S); setconst_b<0>(S); setconst_b<1>(S); }
-#endif
 
 // ------------------------------------------------------------------------------------------------ native substep model
 __constant__ float kP[5] = {100.f, 100.f, 88.f, 96.f, 50.f};
@@ -44,111 +32,15 @@ __constant__ float kTorqueLimit[5] = {140.63f, 140.63f, 216.16f, 216.16f, 45.14f
 __constant__ float kFir[9] = {2727.f, 534.f, -2658.f, -795.f, 72.f, 110.f, 19.f, -6.f, -3.f};
 #define PI_F 3.14159265358979323846f
 
-#if APX_GEN == 4
 __device__ __forceinline__ float* rows4() { return (float*)(apx_lds4 + ((threadIdx.x >> 4) * L4_ES + L4_ROWS) / 4); }
-__device__ __forceinline__ c2::Lds row_store() { return c2::Lds{apx_lds4 + ((threadIdx.x >> 4) * L4_ES + L4_ROWS) / 4}; }
-#else
-__device__ __forceinline__ c2::Lds row_store() { return c2::Lds{apx_lds4 + (threadIdx.x & 63)}; }
-#endif
 
 #ifndef APX_STAGE
 #define APX_STAGE __noinline__
 #endif
-// ---- the substep as four non-inlined stages (cassie_step3.h): state crosses stages through HBM/L2 and LDS only
-// stage 1: encoders + estimator -> PD -> safeties -> motor model / delay, then the tree walk.
-// mode 0: forward pass only with zero ctrl (cassie_sim_set_const ends in mj_forward)
-__device__ __noinline__ void stage1_io_tree(St S, int mode) {
-    PROF_START();
-    float ctrl[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (mode != 0) {
-    int flags = S.I(I_FLAGS);
-    float tau_cmd[10], mpos_a[10], mvel_a[10];
-#pragma unroll
-    for (int u = 0; u < 10; ++u) {
-        // drive encoder: truncating quantiser + 9-tap FIR velocity
-        const float scale = 2.f * PI_F / (float)(1 << cmt::ct_act_bits[u]), gear = cmt::ct_act_gear[u];
-        const float nq = truncf(S(F_SNAP + SN_MPOS + u) * gear / scale);
-        float h[9];
-        if (!(flags & 1)) { _Pragma("unroll") for (int k = 0; k < 9; ++k) h[k] = nq; }
-        else { _Pragma("unroll") for (int k = 8; k > 0; --k) h[k] = S(F_MENC + u * 9 + k - 1); h[0] = nq; }
-        float acc = 0.f;
-        _Pragma("unroll") for (int k = 0; k < 9; ++k) { S(F_MENC + u * 9 + k) = h[k]; acc += kFir[k] * h[k]; }
-        const float mpos = nq * scale / gear, mvel = acc * scale / gear / PI_F;
-        S(F_SO + SO_MPOS + u) = mpos; S(F_SO + SO_MVEL + u) = mvel;
-        // pd_input_step: tau = P (pTarget - q) + D (0 - qd), no clamp (G9)
-        tau_cmd[u] = (S.I(I_FLAGS) & 16) ? kP[u % 5] * (S(F_PDT + u) - mpos) + kD[u % 5] * (0.f - mvel) : 0.f;   // pd_in_t is zero until the first env.step
-        mpos_a[u] = mpos; mvel_a[u] = mvel;
-    }
-    // cassie_core_sim_step (G10): soft joint-limit zones 0.15 rad inside the drive limits, global torque scale,
-    // restoring PD on the intruding drive, clamp to the drive torqueLimit
-    float sdepth[10], ssign[10], sscale = 1.f;
-#pragma unroll
-    for (int u = 0; u < 10; ++u) {
-        constexpr float DEG = PI_F / 180.f;
-        const float lo_deg[5] = {-15.f, -22.f, -50.f, -156.f, -140.f}, hi_deg[5] = {20.f, 22.f, 80.f, -42.f, -35.f};
-        float lo = lo_deg[u % 5] * DEG + 0.15f, hi = hi_deg[u % 5] * DEG - 0.15f;
-        if (u >= 5 && (u % 5) < 2) { const float t = lo; lo = -hi; hi = -t; }      // roll / yaw mirror on the right leg
-        sdepth[u] = fmaxf(0.f, fmaxf(mpos_a[u] - hi, lo - mpos_a[u]));
-        ssign[u] = mpos_a[u] > hi ? -1.f : 1.f;
-        sscale *= fmaxf(0.f, 1.f - sdepth[u] * (1.f / 0.15f));
-    }
-    float cdep[2];      // coupled hip-pitch + knee zone below -135 deg (golden G10b)
-    for (int leg = 0; leg < 2; ++leg) {
-        cdep[leg] = fmaxf(0.f, -0.75f * PI_F - (mpos_a[5 * leg + 2] + mpos_a[5 * leg + 3]));
-        sscale *= fmaxf(0.f, 1.f - cdep[leg] * (1.f / 0.15f));
-    }
-#pragma unroll
-    for (int u = 0; u < 10; ++u) {
-        const float sKp[5] = {1000.f, 800.f, 1200.f, 1200.f, 100.f}, sKd[5] = {12.f, 12.f, 36.f, 36.f, 7.f};
-        const float gear = cmt::ct_act_gear[u], d = sdepth[u];
-        float tau = sscale * tau_cmd[u] + ssign[u] * sKp[u % 5] * d * (1.f + d * (1.f / 0.15f)) - fminf(1.f, d * (1.f / 0.15f)) * sKd[u % 5] * mvel_a[u];
-        if (u % 5 == 2 || u % 5 == 3) { const float c = cdep[u / 5]; tau += sKp[u % 5] * c * (1.f + c * (1.f / 0.15f)) - fminf(1.f, c * (1.f / 0.15f)) * sKd[u % 5] * mvel_a[u]; }
-        tau = fminf(fmaxf(tau, -kTorqueLimit[u % 5]), kTorqueLimit[u % 5]);
-        // cassie_sim_step_ethercat: torque-speed curve, 6-deep delay line
-        const float wmax = cmt::ct_act_rpm[u] * 2.f * PI_F / 60.f, tmax = cmt::ct_act_ctrlmax[u];
-        const float om = fabsf(S(F_QVEL + cmt::ct_act_dof[u]) * gear);
-        const float tlim = fminf(fmaxf(2.f * tmax * (1.f - om / wmax), 0.f), tmax);
-        const float cmd = tau / gear;
-        const float un = (cmd < 0.f ? -1.f : 1.f) * fminf(fabsf(cmd), tlim);
-        float fifo[6];
-        _Pragma("unroll") for (int k = 5; k > 0; --k) fifo[k] = S(F_FIFO + u * 6 + k - 1);
-        fifo[0] = un;
-        _Pragma("unroll") for (int k = 0; k < 6; ++k) S(F_FIFO + u * 6 + k) = fifo[k];
-        ctrl[u] = fifo[5];
-        S(F_SO + SO_TORQUE + u) = gear * ctrl[u];
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {   // joint encoders: quantiser + biquad velocity
-        const float scale = 2.f * PI_F / (float)(1 << cmt::ct_jsens_bits[k]);
-        const float x = truncf(S(F_SNAP + SN_JPOS + k) / scale) * scale;
-        float xs[4], y0, y1;
-        if (!(flags & 2)) { xs[0] = xs[1] = xs[2] = xs[3] = x; y0 = y1 = 0.f; }
-        else { xs[0] = x; _Pragma("unroll") for (int i = 1; i < 4; ++i) xs[i] = S(F_JENCX + k * 4 + i - 1); y0 = S(F_JENCY + k * 2); y1 = S(F_JENCY + k * 2 + 1); }
-        const float y = 12.348f * (xs[0] + xs[1] - xs[2] - xs[3]) + 1.7658f * y0 - 0.79045f * y1;
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) S(F_JENCX + k * 4 + i) = xs[i];
-        S(F_JENCY + k * 2) = y; S(F_JENCY + k * 2 + 1) = y0;
-        S(F_SO + SO_JPOS + k) = x; S(F_SO + SO_JVEL + k) = y;
-    }
-    S.I(I_FLAGS) = flags | 3;
-    // estimator: pass-through fields + estimator-lite for the 7 filtered ones
-    {
-        const Q4 q = {S(F_SNAP + SN_QUAT), S(F_SNAP + SN_QUAT + 1), S(F_SNAP + SN_QUAT + 2), S(F_SNAP + SN_QUAT + 3)};
-        _Pragma("unroll") for (int k = 0; k < 4; ++k) S(F_SO + SO_QUAT + k) = S(F_SNAP + SN_QUAT + k);
-        _Pragma("unroll") for (int k = 0; k < 3; ++k) { S(F_SO + SO_ROTVEL + k) = S(F_SNAP + SN_GYRO + k); S(F_SO + SO_TVEL + k) = S(F_SNAP + SN_VEL + k); }
-        // estimator-lite (goldens G11, G11c): pelvis-frame specific force minus gravity, pelvis-frame velocity, z - low-passed lowest sole height
-        const M3 R = q2m(q);
-        S(F_SO + SO_TACC) = S(F_SNAP + SN_ACC) - R.m[6] * GRAV; S(F_SO + SO_TACC + 1) = S(F_SNAP + SN_ACC + 1) - R.m[7] * GRAV;
-        S(F_SO + SO_TACC + 2) = S(F_SNAP + SN_ACC + 2) - R.m[8] * GRAV;
-        const V3 vw = {S(F_SNAP + SN_VEL), S(F_SNAP + SN_VEL + 1), S(F_SNAP + SN_VEL + 2)};
-        S(F_SO + SO_TVEL) = dot(col(R, 0), vw); S(F_SO + SO_TVEL + 1) = dot(col(R, 1), vw); S(F_SO + SO_TVEL + 2) = dot(col(R, 2), vw);
-        { const float L = S(F_EST) + EST_ALPHA * (S(F_EST + 1) - S(F_EST)); S(F_EST) = L; S(F_SO + SO_HEIGHT) = S(F_SNAP + SN_PZ) - L; }      // golden G11c
-    }
-    }
-    PROF(0);
-#if APX_GEN == 4
-    for (int u = 0; u < 10; ++u) S.W(c4::WK_CTRL + u) = ctrl[u];
-}
-// The same model, lane-parallel: lanes 0..9 = the ten drives, lanes 10..15 = the six joint encoders, lane 0 = estimator.
+// ---- the substep in five stages (cassie_lane.h); the env's state and every stage hand-off live in the env's LDS region
+// stage 1: encoders + estimator -> PD -> safeties -> motor model / delay: lanes 0..9 = the ten drives,
+// lanes 10..15 = the six joint encoders, lane 0 = estimator.  mode 0: forward pass only with zero ctrl (cassie_sim_set_const ends
+// in mj_forward)
 __device__ __forceinline__ void stage1_io_lane(St S, int mode) {   // (as a called function the reset kernel faults: kept inline)
     PROF_START();
     const int l = threadIdx.x & 15;
@@ -242,47 +134,16 @@ __device__ APX_STAGE void stage1b_tree_lane(St S) {
     c4::stage_tree_lane<false>(S, rows4());
     PROF(1);
 }
-#else
-    c3::stage_tree(S, ctrl);
-    PROF(1);
-}
-#endif
 __device__ APX_STAGE void stage2a_factor(St S) {
     PROF_START();
-#if APX_GEN == 4
     c4::stage_factor_lane(S);
-#else
-    c3::stage_factor(S);
-#endif
     PROF(2);
 }
-template <int LEG>
-__device__ __noinline__ void stage2b_rows(St S) {
-    PROF_START();
-    const c2::Lds Y = row_store();
-    c3::stage_rows_leg<LEG>(S, Y);
-    PROF(5 + LEG);
-}
-__device__ __noinline__ void stage3a_warm(St S) {
-    const c2::Lds Y = row_store();
-    c3::stage_warm_check(S, Y);
-}
-#if APX_GEN == 4
 __device__ __forceinline__ void stage3_rows_pgs_lane(St S, int pgs_iters) {
     PROF_START();
     c4::stage_rows_pgs_lane(S, rows4(), pgs_iters);
     PROF(3);
 }
-#else
-template <int LEG>
-__device__ __noinline__ void stage3_pgs(St S, int pgs_iters) {
-    PROF_START();
-    const c2::Lds Y = row_store();
-    c3::stage_pgs_wave<LEG>(S, Y, pgs_iters);
-    PROF(3);
-}
-#endif
-#if APX_GEN == 4
 // inlined like the rows / PGS stage: as a function it needs 36 callee-saved VGPRs, i.e. 36 scratch stores + 36 loads per lane per
 // substep (9 KB per wave-substep), several times the algorithmic HBM traffic of the whole kernel
 __device__ __forceinline__ void stage4_finish(St S, int mode) {
@@ -290,33 +151,6 @@ __device__ __forceinline__ void stage4_finish(St S, int mode) {
     c4::stage_finish_lane(S, rows4(), mode != 0);
     PROF(4);
 }
-#else
-__device__ __noinline__ void stage4_finish(St S, int mode) {
-    PROF_START();
-    const c2::Lds Y = row_store();
-    float acc[3], fz[2];
-    // sensor snapshot of the PRE-integration state (sensordata is one mj_step1 old when step_ethercat reads it)
-#pragma unroll
-    for (int u = 0; u < 10; ++u) S(F_SNAP + SN_MPOS + u) = S(F_QPOS + cmt::ct_act_qposadr[u]);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) S(F_SNAP + SN_JPOS + k) = S(F_QPOS + cmt::ct_jsens_qposadr[k]);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) S(F_SNAP + SN_QUAT + k) = S(F_QPOS + 3 + k);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { S(F_SNAP + SN_GYRO + k) = S(F_QVEL + 3 + k); S(F_SNAP + SN_VEL + k) = S(F_QVEL + k); }
-    S(F_SNAP + SN_PZ) = S(F_QPOS + 2);
-#if APX_GEN == 4
-    c3::stage_finish(S, Y, mode != 0, acc, fz, rows4());
-#else
-    c3::stage_finish(S, Y, mode != 0, acc, fz);
-#endif
-#pragma unroll
-    for (int k = 0; k < 3; ++k) S(F_SNAP + SN_ACC + k) = acc[k];
-    S(F_FWD + 0) = fz[0]; S(F_FWD + 1) = fz[1];
-    PROF(4);
-}
-#endif
-#if APX_GEN == 4
 // mj_setConst (sim.set_const after dynamics randomisation), lane-parallel: tree at qpos0 -> factor -> |y~|^2 of unit rows
 __device__ __forceinline__ void setconst_lane(const St& S) {
     c4::stage_tree_lane<true>(S, rows4());
@@ -327,8 +161,7 @@ __device__ __forceinline__ void setconst_lane(const St& S) {
     c4::setconst_rows_lane<1>(S);
     c4::wsync();
 }
-// Generation 4: the wave holds 4 envs, one per 16-lane row.  Stages not yet converted to the lane-parallel form run on the
-// row's lead lane; every call site is reached by all lanes.
+// one 2 kHz substep (cassie_sim_step_pd): the wave holds 4 envs, one per 16-lane row; every call site is reached by all lanes
 __device__ __forceinline__ void sim_step_pd(const St& S, int pgs_iters, int mode) {
 #ifdef APX_PROF
     const unsigned long long t0__ = clock64();
@@ -344,28 +177,9 @@ __device__ __forceinline__ void sim_step_pd(const St& S, int pgs_iters, int mode
     stage4_finish(S, mode);
     c4::wsync();
 #ifdef APX_PROF
-    if (threadIdx.x == 0 && blockIdx.x == 0) c3::g_prof_acc[8] += clock64() - t0__;
+    if (threadIdx.x == 0 && blockIdx.x == 0) c4::g_prof_acc[8] += clock64() - t0__;
 #endif
 }
-#else
-// The workgroup is TWO waves over the same 64 envs (lane l of both waves = env l): wave 0 runs the serial stages, the
-// constraint rows of the two legs are built concurrently, and the Gauss-Seidel sweeps alternate between the waves with
-// each wave's rows resident in its registers.  Every call site must be reached by both waves (barriers inside).
-__device__ __forceinline__ void sim_step_pd(const St& S, int pgs_iters, int mode) {
-    const int wave = threadIdx.x >> 6;
-    if (wave == 0) { stage1_io_tree(S, mode); stage2a_factor(S); }
-    __syncthreads();
-    if (wave == 0) stage2b_rows<0>(S); else stage2b_rows<1>(S);
-    __syncthreads();
-    if (wave == 0) stage3a_warm(S);
-    __syncthreads();
-    if (wave == 0) stage3_pgs<0>(S, pgs_iters); else stage3_pgs<1>(S, pgs_iters);
-    __syncthreads();
-    if (wave == 0) stage4_finish(S, mode);
-    __syncthreads();
-}
-
-#endif
 
 // ------------------------------------------------------------------------------------------------ env logic
 struct ClockK { float x[8]; float phaselen; };
@@ -517,7 +331,6 @@ __device__ void env_reset_finish(const St& S, const Cfg& cfg) {
     S(F_CMD + 1) = r.uniform(-0.3f, 0.3f);
     S.I(I_RNG) = (int)r.ctr;
 }
-#if APX_GEN == 4
 // CassieEnv.reset (cassie/cassie.py:523-680); called by all 16 lanes of the env's row
 __device__ __forceinline__ void env_reset(const St& S, const Cfg& cfg) {
     const bool lead = (threadIdx.x & 15) == 0;
@@ -534,24 +347,6 @@ __device__ __forceinline__ void env_reset(const St& S, const Cfg& cfg) {
     if (lead) env_reset_finish(S, cfg);
     c4::wsync();
 }
-#else
-// CassieEnv.reset (cassie/cassie.py:523-680); called by BOTH waves of the workgroup
-__device__ __forceinline__ void env_reset(const St& S, const Cfg& cfg) {
-    const int wave = threadIdx.x >> 6;
-    if (wave == 0) env_reset_draws(S, cfg);
-    __syncthreads();
-    if (cfg.dyn_rand) {                               // sim.set_const -> mj_setConst, legs on the two waves
-        if (wave == 0) setconst_a(S);
-        __syncthreads();
-        if (wave == 0) setconst_b<0>(S); else setconst_b<1>(S);
-        __syncthreads();
-    }
-    sim_step_pd(S, cfg.pgs_iters, 0);               // cassie_sim_set_const ends in mj_forward
-    sim_step_pd(S, cfg.pgs_iters, 1);               // cassie.py:665 (stale pd_in_t)
-    if (wave == 0) env_reset_finish(S, cfg);
-}
-
-#endif
 
 // clock_reward (cassie/rewards/clock_rewards.py:6-110)
 __device__ float clock_reward(const St& S, const Cfg& cfg, const float* action, float lfrc, float rfrc, float lor, float ror) {
@@ -600,7 +395,6 @@ __device__ float clock_reward(const St& S, const Cfg& cfg, const float* action, 
 }
 
 // ------------------------------------------------------------------------------------------------ kernels
-#if APX_GEN == 4
 #ifndef APX_WAVES_PER_EU
 #define APX_WAVES_PER_EU 1
 #endif
@@ -799,110 +593,6 @@ static constexpr size_t LDS_BYTES = (size_t)L4_EPW * L4_ES * sizeof(float);   //
 #define ENV_BLOCK dim3(64)
 #define SETCONST_GRID(n) dim3((n) / L4_EPW)
 #define SETCONST_LDS LDS_BYTES
-#else
-#define ENV_SETUP                                                                                   \
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;                                      \
-    const int env = blockIdx.x * c2::EPW + lane;                                                     \
-    if (lane >= c2::EPW || env >= n) return;                                                                            \
-    const St S = make_st(st, ist, n, env, wk);
-
-__global__ __launch_bounds__(64) void env_init_kernel(float* st, int* ist, int n, Cfg cfg) {
-    const int env = blockIdx.x * 64 + threadIdx.x;
-    if (env >= n) return;
-    const St S = make_st(st, ist, n, env, nullptr);
-    for (int f = 0; f < F_TOTAL; ++f) S(f) = 0.f;
-    for (int f = 0; f < I_TOTAL; ++f) S.I(f) = 0;
-    for (int i = 0; i < NQ; ++i) S(F_QPOS + i) = cm_init_qpos[i];
-    for (int b = 0; b < NB; ++b) S(F_MASS + b) = cm_body_mass[b];
-    for (int d = 0; d < NV; ++d) S(F_DAMP + d) = cm_dof_damping[d];
-    S(F_FRIC) = 1.f;
-    const float fl[9] = {0, 0, 1, 0, 1, 0, -1, 0, 0};     // n = z, t1 = y, t2 = n x t1 = -x
-    for (int k = 0; k < 9; ++k) S(F_FLOOR + k) = fl[k];
-}
-
-__global__ __launch_bounds__(64) void env_setconst_kernel(float* st, int* ist, float* wk, int n, Cfg cfg) {
-    const int env = blockIdx.x * 64 + threadIdx.x;
-    if (env >= n) return;
-    const St S = make_st(st, ist, n, env, wk);
-    set_const_single_wave(S);
-}
-
-// CassieEnv.reset for the envs selected by mask (NULL = all); a separate launch so that the step kernel's register
-// allocation is not shaped by the (rare, slower) reset path
-__global__ __launch_bounds__(128) void env_reset_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const uint8_t* mask, float* obs) {
-    ENV_SETUP
-    if (mask && !mask[env]) return;
-    env_reset(S, cfg);
-    if (obs && wave == 0) write_obs(S, cfg, obs + (size_t)env * APX_OBS_DIM);
-}
-
-__global__ __launch_bounds__(128) void env_step_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const float* action, float* obs,
-                                                       float* reward, uint8_t* done, float* final_obs) {
-    ENV_SETUP
-    float act[10];
-    if (wave == 0) {
-        for (int u = 0; u < 10; ++u) {
-            act[u] = action[(size_t)env * APX_ACT_DIM + u];
-            S(F_PDT + u) = act[u] + kOffset[u] - (cfg.dyn_rand ? S(F_MNOISE + u) : 0.f);     // cassie.py:295-298
-        }
-        S.I(I_FLAGS) |= 16;
-    }
-    float lfrc = 0.f, rfrc = 0.f, lor = 0.f, ror = 0.f;
-    for (int i = 0; i < cfg.simrate; ++i) {
-        sim_step_pd(S, cfg.pgs_iters, 1);                                        // both waves (barriers inside)
-        if (wave != 0) continue;
-        for (int k = 0; k < 6; ++k) {                                            // cassie.py:328-331
-            const float fp = S(F_FWD + 10 + k);
-            S(F_FOOTVEL + k) = (fp - S(F_FOOTPREV + k)) / 0.0005f;
-            S(F_FOOTPREV + k) = fp;
-        }
-        lfrc += S(F_FWD + 0); rfrc += S(F_FWD + 1);                               // cassie.py:418-420
-        float il = 0.f, ir = 0.f;
-        for (int k = 0; k < 4; ++k) { il += kNeutralFoot[k] * S(F_FWD + 2 + k); ir += kNeutralFoot[k] * S(F_FWD + 6 + k); }
-        lor += 1.f - il * il; ror += 1.f - ir * ir;                               // cassie.py:426-427
-    }
-    if (wave != 0) return;
-    const float inv = 1.f / (float)cfg.simrate;
-    lfrc *= inv; rfrc *= inv; lor *= inv; ror *= inv;
-    const float height = S(F_QPOS + 2);
-    int time = S.I(I_TIME) + 1, phase = S.I(I_PHASE) + 1;
-    if ((float)phase > S(F_CMD + 5)) { phase = 0; S.I(I_COUNTER) += 1; }
-    S.I(I_TIME) = time; S.I(I_PHASE) = phase;
-    const bool h_nan = (__float_as_uint(height) & 0x7fffffffu) > 0x7f800000u;
-    int dn = (height < 0.4f || height > 3.0f || h_nan) ? 1 : 0;
-    int flags = S.I(I_FLAGS);
-    if (!(flags & 4)) for (int u = 0; u < 10; ++u) S(F_PREVACT + u) = act[u];
-    if (!(flags & 8)) for (int u = 0; u < 10; ++u) S(F_PREVTQ + u) = S(F_SO + SO_TORQUE + u);
-    S.I(I_FLAGS) = flags | 12;
-    const float rew = clock_reward(S, cfg, act, lfrc, rfrc, lor, ror);
-    for (int u = 0; u < 10; ++u) { S(F_PREVACT + u) = act[u]; S(F_PREVTQ + u) = S(F_SO + SO_TORQUE + u); }
-    {   // command resampling, cassie.py:483-491; fixed 6 draws per step
-        Rng r{cfg.seed_lo, cfg.seed_hi, cfg.env_base + (unsigned)env, (unsigned)S.I(I_RNG)};
-        if (cfg.env_kind == 1 && cfg.dyn_rand) (void)r.u01();                 // cassie_traj.py:463-464 draws a simrate the loop never uses
-            { const unsigned k = r.randint(300); const float u = r.uniform(-0.2f, 0.2f); if (k == 0) S(F_CMD + 2) += u; }
-        { const unsigned k = r.randint(100); const float u = r.uniform(-0.3f, 4.0f); if (k == 0) S(F_CMD + 0) = fminf(fmaxf(u, -0.3f), 4.0f); }
-        { const unsigned k = r.randint(300); const float u = r.uniform(-0.3f, 0.3f); if (k == 0) S(F_CMD + 1) = u; }
-        S.I(I_RNG) = (int)r.ctr;
-    }
-    if (!dn && time >= cfg.max_traj_len) dn = 2;
-    reward[env] = rew;
-    done[env] = (uint8_t)dn;
-    write_obs(S, cfg, obs + (size_t)env * APX_OBS_DIM);
-    if (dn && final_obs) for (int k = 0; k < APX_OBS_DIM; ++k) final_obs[(size_t)env * APX_OBS_DIM + k] = obs[(size_t)env * APX_OBS_DIM + k];
-}
-
-// raw substeps with the current pd targets (tests): n_sub x cassie_sim_step_pd
-__global__ __launch_bounds__(128) void env_substep_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, int n_sub, const float*, float*) {
-    ENV_SETUP
-    for (int i = 0; i < n_sub; ++i) sim_step_pd(S, cfg.pgs_iters, 1);
-}
-
-static constexpr size_t LDS_BYTES = (size_t)c2::CH_TOTAL * c2::EPW * sizeof(float4);   // 161,792 B of the CU's 163,840 at EPW = 64
-#define ENV_GRID(n) dim3((n) / c2::EPW)
-#define ENV_BLOCK dim3(128)
-#define SETCONST_GRID(n) dim3((n) / 64)
-#define SETCONST_LDS 0
-#endif
 
 // CassieEnv.update_speed (cassie/cassie.py:757-775), clock command profile; the phase rescale is done in fp64 like the reference
 // (the old cycle length comes from the stored fp32 swing / stance, so the truncation can differ from an all-fp64 evaluation only
@@ -949,11 +639,7 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     APX_HIP(hipMalloc(&e->st, sizeof(float) * (size_t)F_TOTAL * e->n));
     APX_HIP(hipMalloc(&e->ist, sizeof(int) * (size_t)I_TOTAL * e->n));
     e->wk = nullptr;
-#if APX_GEN == 4
     APX_HIP(hipMalloc(&e->wk, 256));      // generation 4 keeps the stage hand-off in LDS: no HBM workspace
-#else
-    APX_HIP(hipMalloc(&e->wk, sizeof(float) * (size_t)c3::WK_TOTAL * e->n));
-#endif
     const Cfg c = make_cfg(*cfg);
     hipLaunchKernelGGL(env_init_kernel, dim3(e->n / 64), dim3(64), 0, 0, e->st, e->ist, e->n, c);
     APX_LAUNCH_CHECK();
@@ -992,27 +678,19 @@ extern "C" int apx_env_update_speed(apx_env_t* e, const float* speed, const floa
 
 extern "C" int apx_env_step_basic(apx_env_t* e, const float* action, float* obs, void* stream) {
     APX_REQUIRE(e && action && obs, "null pointer");
-#if APX_GEN == 4
     hipLaunchKernelGGL(env_substep_kernel, ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(e->cfg),
                        e->cfg.simrate, action, obs);
     APX_LAUNCH_CHECK();
     return APX_OK;
-#else
-    APX_REQUIRE(false, "apx_env_step_basic is implemented by the generation-4 kernel only (build with GEN=4)");
-#endif
 }
 
 extern "C" int apx_env_reset_for_test(apx_env_t* e, float* obs_out, int full_reset, void* stream) {
     APX_REQUIRE(e && obs_out, "null pointer");
-#if APX_GEN == 4
     e->cfg.stance_mode = 1;                               // reset_for_test switches to the grounded clock (cassie.py:702)
     hipLaunchKernelGGL(env_reset_for_test_kernel, ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
                        make_cfg(e->cfg), obs_out, full_reset);
     APX_LAUNCH_CHECK();
     return APX_OK;
-#else
-    APX_REQUIRE(false, "apx_env_reset_for_test is implemented by the generation-4 kernel only (build with GEN=4)");
-#endif
 }
 
 __global__ void scatter_kernel(float* st, int n, int f0, int cnt, const float* in);
@@ -1090,12 +768,12 @@ extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, voi
 #ifdef APX_PROF
     if (!strcmp(name, "prof")) {   // 12 cumulative phase cycle counters, then reset
         unsigned long long h[12];
-        APX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(c3::g_prof_acc), sizeof(h)));
+        APX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(c4::g_prof_acc), sizeof(h)));
         float hf[12];
         for (int i = 0; i < 12; ++i) hf[i] = (float)h[i];
         APX_HIP(hipMemcpy(out, hf, sizeof(hf), hipMemcpyHostToDevice));
         unsigned long long z[12] = {0};
-        APX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c3::g_prof_acc), z, sizeof(z)));
+        APX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c4::g_prof_acc), z, sizeof(z)));
         return 12;
     }
 #endif

@@ -29,17 +29,10 @@ struct apx_env {
     int n;
 };
 
-// Kernel generation: 3 = env-per-lane (two waves over 64 envs, state in HBM/L2), 4 = one env per 16-lane DPP row
-// (4 envs per wave, whole env resident in LDS for the launch).
-#ifndef APX_GEN
-#define APX_GEN 4
-#endif
-
 // global-address-space pointers: St is passed by value into a non-inlined device function, where the compiler could
 // not otherwise prove the address space and would fall back to flat_load / flat_store
 typedef __attribute__((address_space(1))) float gfloat;
 typedef __attribute__((address_space(1))) int gint;
-#if APX_GEN == 4
 // Per-env LDS region (floats): [0,585) state fields | [586,591) int fields | [L4_WK, +WK_TOTAL) stage hand-off |
 // [L4_ROWS, +632) constraint-row store (158 float4 chunks).  Stride L4_ES = 16 (mod 64): the four envs of a wave sit
 // on disjoint LDS bank groups, so a 16-lane access with consecutive addresses is conflict-free.
@@ -56,17 +49,6 @@ struct St {
     __device__ __forceinline__ lfloat& W(int i) const { return p[L4_WK + i]; }
     __device__ __forceinline__ lint& I(int f) const { return ((lint*)p)[L4_INT + f]; }
 };
-#else
-struct St {
-    gfloat* p; gint* ip; int n, env; gfloat* wk;      // wk: [WK_TOTAL, n] per-env workspace column (cassie_step3.h)
-    __device__ __forceinline__ gfloat& operator()(int f) const { return p[(size_t)f * n + env]; }
-    __device__ __forceinline__ gfloat& W(int i) const { return wk[(size_t)i * n + env]; }
-    __device__ __forceinline__ gint& I(int f) const { return ip[(size_t)f * n + env]; }
-};
-__device__ __forceinline__ St make_st(float* st, int* ist, int n, int env, float* wk) {
-    return St{(gfloat*)st, (gint*)ist, n, env, (gfloat*)wk};
-}
-#endif
 
 // state estimator height model (golden G11c): height = z - L, L' = (lowest sole z - L) / EST_TAU, L = EST_L0 after state_output_setup
 constexpr float EST_TAU = 0.86f, EST_L0 = 0.126f, EST_ALPHA = 0.0005f / EST_TAU;

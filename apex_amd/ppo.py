@@ -126,10 +126,15 @@ class PPO:
         steps = max(iters // (self.N * self.world), 50)
         obs = self.env.reset()
         s = torch.zeros(50, dtype=torch.float64, device=self.device); ss = torch.zeros_like(s); n = 0
-        for _ in range(steps):
+        nz = torch.zeros(self.N, 10, dtype=torch.float32, device=self.device)
+        for t in range(steps):
             s += obs.double().sum(0); ss += (obs.double() ** 2).sum(0); n += obs.shape[0]
             mu = self.learner.actor.forward(obs, self.learner.obs_mean, self.learner.obs_std)
-            act = mu + torch.randn(mu.shape, device=self.device, generator=self.gen) * noise_std
+            if self.noise_fn is not None:      # parity mode: replay a captured draw stream (golden G21)
+                self.noise_fn(t, nz)
+            else:
+                nz.normal_(generator=self.gen)
+            act = mu + nz * noise_std
             obs, _, _, _ = self.env.step(act)
         mom = torch.cat([s, ss, torch.tensor([float(n)], dtype=torch.float64, device=self.device)])
         if self.group is not None:

@@ -220,3 +220,21 @@ def ppo_update(actor, old_actor, critic, opt_a, opt_c, obs, act, ret, adv, obs_m
     kl = (0.5 * ((mu - mu_old) / sd) ** 2).mean()               # kl_divergence(Normal, Normal), equal std
     scal = np.array([actor_loss, entropy, critic_loss, ratio.mean(), kl, mirror_loss], dtype=np.float64)
     return scal, new_actor, new_critic
+
+
+def normalization_params(policy_W, envs, noise, noise_std=1.0):
+    """get_normalization_params (rl/envs/normalize.py:11-48): every worker records the state BEFORE each step, acts with
+    policy(state) + noise_std * N(0, 1) (un-normalised policy), resets on done (the terminal state is dropped);
+    returns mean and sqrt(var + 1e-8) over all recorded states.  envs: objects with reset() / step(a) -> (s, r, done, info);
+    noise [workers, steps, act_dim] replays the workers' draws."""
+    states = []
+    for w, env in enumerate(envs):
+        s = env.reset()
+        for t in range(noise.shape[1]):
+            states.append(np.asarray(s, dtype=np.float64).copy())
+            a = mlp_forward(policy_W, np.asarray(s, dtype=np.float32)[None].astype(np.float64))[0] + noise_std * noise[w, t]
+            s, _, done, _ = env.step(a.astype(np.float32).astype(np.float64))
+            if done:
+                s = env.reset()
+    states = np.array(states)
+    return states.mean(0), np.sqrt(states.var(0) + 1e-8)

@@ -6,6 +6,8 @@ import pytest
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
+if os.path.join(REPO, "tests") not in sys.path:
+    sys.path.insert(1, os.path.join(REPO, "tests"))      # golden_util (shared with tools/refprobe)
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
 

@@ -172,3 +172,26 @@ def test_g15b_whole_train_loop(golden_dir):
         np.testing.assert_allclose(g["train_return"][it], g[p + "ep_returns"].mean(), rtol=1e-12)
         np.testing.assert_allclose(g["mean_eplen"][it], g[p + "ep_lens"].mean(), rtol=1e-12)
     assert len(g["scalar_names"]) == 13
+
+
+def test_g21_normalization_params(golden_dir):
+    """Row a12: the numpy restatement of get_normalization_params (rl/envs/normalize.py:11-48) reproduces the reference's (mean, std)
+    on the toy envs of golden G21 with the captured noise."""
+    g = np.load(os.path.join(golden_dir, "g21_normalization_params.npz"))
+    lens = [int(x) for x in g["lens"]]
+
+    class Toy:
+        def __init__(self, w): self.k = 100 * w
+        def reset(self):
+            self.k += 1; self.t = 0; self.L = lens[(self.k - 1) % len(lens)]
+            self.x = np.cos(np.arange(50) * 0.1 * self.k)
+            return self.x.copy()
+        def step(self, a):
+            self.t += 1
+            self.x = 0.9 * self.x + 0.1 * np.tile(a, 5) + 0.01
+            return self.x.copy(), 0.0, self.t >= self.L, {}
+
+    W = [g["actor." + k].astype(np.float64) for k in ACTOR_KEYS]
+    mean, std = L.normalization_params(W, [Toy(w) for w in range(int(g["procs"]))], g["noise"].astype(np.float64), float(g["noise_std"]))
+    np.testing.assert_allclose(mean, g["mean"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(std, g["std"], rtol=1e-6, atol=1e-6)

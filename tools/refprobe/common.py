@@ -17,7 +17,7 @@ GOLD = os.path.join(REPO, "tests", "golden")
 def setup_reference_path():
     if not os.path.isdir(REF):
         raise SystemExit("reference tree not present; golden generators only run in the build container")
-    sys.path[:0] = [os.path.join(HERE, "stubs"), REF]
+    sys.path[:0] = [os.path.join(HERE, "stubs"), REF, os.path.join(REPO, "tests")]      # tests/: golden_util (seeded inputs, slim records)
     os.makedirs(GOLD, exist_ok=True)
 
 

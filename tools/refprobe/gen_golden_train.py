@@ -56,7 +56,8 @@ class FakeLogger:
     def add_scalar(self, name, val, itr): self.rows.append((name, float(val), int(itr)))
 
 
-def main(name="g15b_ppo_train", lr=1e-4, H=256, n_itr=3, seed=151, recurrent=False, mb=64):
+def main(name="g15b_ppo_train", lr=1e-4, H=256, n_itr=3, seed=151, recurrent=False, mb=64, big=False):
+    from golden_util import seeded_params, slim
     torch.manual_seed(seed); np.random.seed(seed)
     ToyEnv.k = 0; ToyEnv.log = []
     epochs = 3
@@ -71,14 +72,24 @@ def main(name="g15b_ppo_train", lr=1e-4, H=256, n_itr=3, seed=151, recurrent=Fal
         policy = Gaussian_LSTM_Actor(50, 10, layers=(H, H), fixed_std=np.exp(-2.0)); critic = LSTM_V(50, layers=(H, H))
     else:
         policy = Gaussian_FF_Actor(50, 10, layers=(H, H), fixed_std=np.exp(-1.5)); critic = FF_V(50, layers=(H, H))
+    if big:        # BASELINE-size nets: parameters from a seed (golden_util), snapshots as slim records
+        for net, sd_seed in ((policy, 1501), (critic, 1502)):
+            sd = net.state_dict()
+            net.load_state_dict({k: torch.tensor(w) for k, w in zip(sd.keys(), seeded_params([v.shape for v in sd.values()], sd_seed))})
     rs = np.random.RandomState(7)
     policy.obs_mean = torch.Tensor(rs.uniform(-0.2, 0.2, 50)); policy.obs_std = torch.Tensor(rs.uniform(0.7, 1.4, 50))
     critic.obs_mean, critic.obs_std = policy.obs_mean, policy.obs_std
     policy.train(); critic.train()
     out = {"obs_mean": policy.obs_mean.numpy(), "obs_std": policy.obs_std.numpy(), "lens": np.array(LENS), "max_traj_len": MAX_TRAJ,
            "n_itr": n_itr, "minibatch": mb, "epochs": epochs, "gamma": 0.99, "hidden": H, "num_steps": 2 * PERIOD}
-    for k, v in policy.state_dict().items(): out["actor0." + k] = v.numpy().copy()
-    for k, v in critic.state_dict().items(): out["critic0." + k] = v.numpy().copy()
+    if big:
+        out["actor_seed"], out["critic_seed"] = 1501, 1502
+        out["actor_keys"] = np.array(list(policy.state_dict().keys())); out["critic_keys"] = np.array(list(critic.state_dict().keys()))
+        out["actor_shapes"] = np.array([list(v.shape) + [0] * (2 - v.dim()) for v in policy.state_dict().values()])
+        out["critic_shapes"] = np.array([list(v.shape) + [0] * (2 - v.dim()) for v in critic.state_dict().values()])
+    else:
+        for k, v in policy.state_dict().items(): out["actor0." + k] = v.numpy().copy()
+        for k, v in critic.state_dict().items(): out["critic0." + k] = v.numpy().copy()
 
     env_fn = lambda: SymmetricEnv(lambda: ToyEnv(), mirrored_obs=MIRRORED_OBS_FULL_CLOCK, mirrored_act=MIRRORED_ACTS)
     rec = {"batches": [], "idx": [], "scal": [], "calls": 0}
@@ -144,8 +155,8 @@ def main(name="g15b_ppo_train", lr=1e-4, H=256, n_itr=3, seed=151, recurrent=Fal
         out[p + "epochs_run"] = len(nb)
         out[p + "idx"] = np.array([sum(e, []) for e in rec["idx"][i]], dtype=np.int64)       # [epochs_run, nb * mb] (recurrent: trajectory indices)
         out[p + "scal"] = np.array(rec["scal"][i], dtype=np.float64).reshape(len(nb), -1, 6)
-        for k, v in snaps[i][0].items(): out[p + "actor." + k] = v
-        for k, v in snaps[i][1].items(): out[p + "critic." + k] = v
+        for k, v in snaps[i][0].items(): out[p + "actor." + k] = slim(v) if big else v
+        for k, v in snaps[i][1].items(): out[p + "critic." + k] = slim(v) if big else v
     out["saved_after_itr"] = np.array(saves)
     out["scalar_names"] = np.array(sorted({r[0] for r in logger.rows}))
     out["train_return"] = np.array([r[1] for r in logger.rows if r[0] == "Train/Return"])
@@ -161,7 +172,9 @@ def main(name="g15b_ppo_train", lr=1e-4, H=256, n_itr=3, seed=151, recurrent=Fal
 
 if __name__ == "__main__":
     import sys
-    if len(sys.argv) > 1 and sys.argv[1] == "recurrent":      # G15d: the whole loop in recurrent mode (LSTM 2 x 32, minibatches of 4 trajectories)
+    if len(sys.argv) > 1 and sys.argv[1] == "recurrent_big":    # G15e: as G15d with the LSTM 2 x 128 of BASELINE configs[3]
+        main("g15e_ppo_train_recurrent_h128", lr=1e-4, H=128, n_itr=2, seed=154, recurrent=True, mb=4, big=True)
+    elif len(sys.argv) > 1 and sys.argv[1] == "recurrent":      # G15d: the whole loop in recurrent mode (LSTM 2 x 32, minibatches of 4 trajectories)
         main("g15d_ppo_train_recurrent", lr=1e-4, H=32, n_itr=2, seed=153, recurrent=True, mb=4)
     elif len(sys.argv) > 1 and sys.argv[1] == "earlystop":      # G15c: a learning rate large enough for the KL test (ppo.py:449) to cut epochs short; 64-unit nets
         main("g15c_ppo_train_earlystop", lr=float(sys.argv[2]) if len(sys.argv) > 2 else 1.2e-2, H=64, n_itr=2, seed=152)
