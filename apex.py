@@ -50,7 +50,34 @@ def build_parser():
     p.add_argument("--bounded", type=bool, default=False)
     # engine flags (additions)
     p.add_argument("--n_envs", type=int, default=4096, help="lock-step envs per GPU (replaces Ray's num_procs)")
+    p.add_argument("--eval_every", type=int, default=10, help="deterministic evaluation pass (ppo.py:464) every k iterations; 1 = the reference's cadence, 0 = off")
+    p.add_argument("--eval_envs", type=int, default=256, help="envs (= episodes) of the evaluation pass")
     return p
+
+
+def resolve_horizon(args, argv):
+    """The reference's --num_steps default (5096) is a TOTAL per iteration for ~30 one-env workers sampling whole episodes.  On a
+    lock-step batch of n_envs envs it would mean T = 2 steps per env, i.e. 2-step TD targets instead of episode returns.  When
+    --num_steps is not given the horizon is therefore scaled to the batch: T = 32 steps per env (feed-forward; the headline
+    configuration) or T = max_traj_len (recurrent: every trajectory must start at an episode start with zero hidden state).  An explicit
+    --num_steps is honoured but a horizon below 8 steps per env is refused."""
+    world = 1
+    import os
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    given = any(x == "--num_steps" or x.startswith("--num_steps=") for x in argv)
+    if not given:
+        per_env = args.max_traj_len if args.recurrent else 32
+        args.num_steps = args.n_envs * world * per_env
+        print("--num_steps not given: %d (= %d envs x %d steps per env and iteration)" % (args.num_steps, args.n_envs * world, per_env))
+    if not any(x == "--minibatch_size" or x.startswith("--minibatch_size=") for x in argv) and not args.recurrent:
+        # 5096 / 64 = 80 optimiser steps per epoch in the reference; on a 131 072-sample batch the headline run uses 8 steps of 16 384
+        args.minibatch_size = max(64, min(16384, args.num_steps // world // 8))
+        print("--minibatch_size not given: %d" % args.minibatch_size)
+    T = -(-args.num_steps // (args.n_envs * world))
+    if T < 8:
+        raise SystemExit("--num_steps %d with --n_envs %d is a %d-step horizon per env: returns would be %d-step bootstraps, not episode returns; "
+                         "raise --num_steps (>= 8 x n_envs) or lower --n_envs" % (args.num_steps, args.n_envs, T, T))
+    return args
 
 
 def eval_main(argv):
@@ -205,6 +232,7 @@ def main(argv=None):
     from apex_amd.log import parse_previous
     from apex_amd.ppo import run_experiment
     args = parse_previous(args)
+    args = resolve_horizon(args, argv[1:])
     run_experiment(args)
     return 0
 

@@ -44,6 +44,7 @@ SIGNATURES = {
     "apx_returns_scan": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_double, C.c_int, C.c_int, c_ptr, c_ptr]),
     "apx_adv_moments": (C.c_int, [c_ptr, c_ptr, C.c_int64, c_ptr, c_ptr]),
     "apx_adv_apply": (C.c_int, [c_ptr, c_ptr, C.c_int64, C.c_double, C.c_double, C.c_double, c_ptr, c_ptr]),
+    "apx_adv_apply_moments": (C.c_int, [c_ptr, c_ptr, C.c_int64, c_ptr, C.c_double, c_ptr, c_ptr]),
     "apx_mlp_param_count": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "apx_mlp_backward": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int64, c_ptr, c_ptr, c_ptr]),
     "apx_polyak": (C.c_int, [c_ptr, c_ptr, C.c_int64, C.c_float, c_ptr]),

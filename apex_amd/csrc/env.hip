@@ -498,7 +498,10 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
         if (!(flags & 4)) for (int u = 0; u < 10; ++u) S(F_PREVACT + u) = act[u];
         if (!(flags & 8)) for (int u = 0; u < 10; ++u) S(F_PREVTQ + u) = S(F_SO + SO_TORQUE + u);
         S.I(I_FLAGS) = flags | 12;
-        const float rew = clock_reward(S, cfg, act, lfrc, rfrc, lor, ror);
+        float rew = clock_reward(S, cfg, act, lfrc, rfrc, lor, ror);
+        // a diverged env (non-finite height or reward) ends its episode with reward 0: one NaN in the rollout grid would poison the
+        // return scan, the advantage moments and from there every parameter (bit-pattern tests: they must survive -ffast-math)
+        if ((__float_as_uint(rew) & 0x7f800000u) == 0x7f800000u || h_nan) { rew = 0.f; dn = 1; }
         for (int u = 0; u < 10; ++u) { S(F_PREVACT + u) = act[u]; S(F_PREVTQ + u) = S(F_SO + SO_TORQUE + u); }
         {   // command resampling, cassie.py:483-491; fixed 6 draws per step
             Rng r{cfg.seed_lo, cfg.seed_hi, cfg.env_base + (unsigned)env, (unsigned)S.I(I_RNG)};

@@ -87,6 +87,26 @@ __global__ void adv_apply_kernel(const float* __restrict__ ret, const float* __r
         adv[i] = ((ret[i] - val[i]) - mean) / denom;
 }
 
+// same as adv_apply_kernel with (mean, unbiased std) taken from the moments on the device: no host round trip between the
+// moments (possibly all-reduced over ranks) and the normalisation
+__global__ void adv_apply_moments_kernel(const float* __restrict__ ret, const float* __restrict__ val, int64_t n,
+                                         const double* __restrict__ mom, float eps, float* __restrict__ adv) {
+    const double cnt = mom[2], mean_d = mom[0] / cnt;
+    double var = (mom[1] - cnt * mean_d * mean_d) / (cnt - 1.0 > 1.0 ? cnt - 1.0 : 1.0);
+    var = var > 0.0 ? var : 0.0;
+    const float mean = (float)mean_d, denom = (float)sqrt(var) + eps;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        adv[i] = ((ret[i] - val[i]) - mean) / denom;
+}
+
+extern "C" int apx_adv_apply_moments(const float* ret, const float* val, int64_t n, const double* moments, double eps, float* adv, void* stream) {
+    APX_REQUIRE(ret && val && adv && moments && n > 0, "args");
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(adv_apply_moments_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ret, val, n, moments, (float)eps, adv);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+}
+
 extern "C" int apx_adv_moments(const float* ret, const float* val, int64_t n, double* moments, void* stream) {
     APX_REQUIRE(ret && val && moments && n > 0, "args");
     APX_HIP(hipMemsetAsync(moments, 0, 3 * sizeof(double), (hipStream_t)stream));

@@ -64,9 +64,8 @@ def normalize_advantages(ret, val, eps=1e-5, group=None):
     mom = adv_moments(ret, val)
     if group is not None:
         adist.allreduce_moments(mom, group=group)
-    mean, std = adist.adv_stats_from_moments(mom.tolist())
-    adv = torch.empty_like(ret)
-    check(_lib.load().apx_adv_apply(_p(ret), _p(val), ret.numel(), mean, std, eps, _p(adv), _stream()))
+    adv = torch.empty_like(ret)      # mean / unbiased std are derived from the moments on the device: no host sync here
+    check(_lib.load().apx_adv_apply_moments(_p(ret), _p(val), ret.numel(), _p(mom), eps, _p(adv), _stream()))
     return adv
 
 

@@ -92,6 +92,12 @@ class PPO:
         # noise_fn(t, out[N,10]) fills the action noise of rollout step t; perm_fn(epoch) -> int64[B] minibatch order;
         # trace, when a list, receives every minibatch's 6 scalars (device tensors).
         self.noise_fn = None; self.perm_fn = None; self.trace = None
+        # evaluation pass + curriculum variables of PPO.train (ppo.py:374-386,456-470)
+        self.eval_every = int(args.get("eval_every", 0)); self.eval_envs = int(args.get("eval_envs", 256))
+        self.anneal_rate = float(args.get("anneal", 1.0))
+        self.curr_anneal, self.curr_thresh, self.start_itr, self.ep_counter, self.do_term = 1.0, 0.0, 0, 0, False
+        self._eval_env = None
+        self.env_kwargs = dict(args.get("env_kwargs", {}))
 
     # ------------------------------------------------------------------------------------------ initialisation
     def init_networks(self, seed):
@@ -156,7 +162,7 @@ class PPO:
             mu = L.actor.forward(obs, L.obs_mean, L.obs_std, out=self.b_mu[t])
             if self.noise_fn is not None:
                 self.noise_fn(t, self.noise[t])
-            torch.add(mu, self.noise[t], alpha=self.fixed_std, out=self.b_act[t])
+            torch.add(mu, self.noise[t], alpha=self.fixed_std * self.curr_anneal, out=self.b_act[t])
             nxt = self.b_obs[t + 1] if t + 1 < T else self.obs
             env.step(self.b_act[t], out=(nxt, self.b_rew[t], self.b_done[t], self.b_fin[t]))
         # V(s_t) is not on the stepping path: one batched critic pass over the whole grid instead of T small ones
@@ -226,17 +232,43 @@ class PPO:
                 acc += scal
                 if self.trace is not None:
                     self.trace.append(scal.clone())
+            both = torch.cat([acc / max(nb, 1), scal.to(acc.dtype)])                         # epoch means + the last minibatch (KL test)
             if self.world > 1:
-                last = adist.allreduce_mean_(scal.clone(), group=self.group, world=self.world)
-                adist.allreduce_mean_(acc, group=self.group, world=self.world)
-            else:
-                last = scal
-            losses = (acc / max(nb, 1)).cpu().numpy()
-            kl_last = float(last[4])
+                adist.allreduce_mean_(both, group=self.group, world=self.world)              # ONE scalar all-reduce per epoch
+            both = both.cpu().numpy()                                                        # the epoch's only host sync: the KL decision
+            losses, kl_last = both[:6], float(both[10])
+            if not np.isfinite(losses).all():
+                raise FloatingPointError("non-finite PPO losses %r (a diverged env or exploding update)" % (losses,))
             epochs_run += 1
             if kl_last > 0.02:                                                               # ppo.py:449 (last minibatch's KL)
                 break
         return losses, kl_last, epochs_run
+
+    # ------------------------------------------------------------------------------------------ evaluation pass
+    @torch.no_grad()
+    def evaluate_pass(self):
+        """The evaluation pass of PPO.train (ppo.py:464: sample_parallel(..., deterministic=True) on the TRAINING env_fn): whole
+        episodes with the policy mean as action from CassieEnv.reset (dynamics randomisation as in training) on a separate small
+        env batch, one episode per env.  Returns the mean episode return (rank-local; all-reduced by the caller when N > 1)."""
+        if self._eval_env is None:
+            kw = dict(self.env_kwargs)
+            kw.update(n_envs=self.eval_envs, max_traj_len=self.max_traj_len, device=self.device.index or 0,
+                      seed=int(kw.get("seed", 0)) + 7919, env_id_base=(self.rank + 1) * 1000003)
+            self._eval_env = type(self.env)(**kw)
+        env, L = self._eval_env, self.learner
+        n = env.n_envs
+        obs = env.reset()
+        ret = torch.zeros(n, device=self.device); alive = torch.ones(n, dtype=torch.bool, device=self.device)
+        for t in range(self.max_traj_len):
+            obs, rew, done, _ = env.step(L.actor.forward(obs, L.obs_mean, L.obs_std), auto_reset=False)
+            ret += torch.where(alive, rew, torch.zeros_like(rew))
+            alive &= done == 0
+            if t % 32 == 31 and not bool(alive.any()):
+                break
+        m = ret.double().mean().view(1)
+        if self.group is not None:
+            adist.allreduce_mean_(m, group=self.group, world=self.world)
+        return float(m)
 
     # ------------------------------------------------------------------------------------------ training loop
     def iteration(self):
@@ -253,20 +285,46 @@ class PPO:
                     ep_returns=ep_rets, ep_lens=ep_lens)
 
     def train(self, n_itr, logger=None):
+        """PPO.train's outer loop (ppo.py:374-505).  The evaluation pass runs every `eval_every` iterations (the reference: every
+        iteration; on the batched engine one whole-episode pass costs ~10 training iterations, so the default CLI setting is 10 and
+        Test/Return holds its last value in between); eval_every = 0 disables it and Test/Return falls back to the batch return,
+        labelled as such on stdout."""
+        avg_eval = float("nan")
         for itr in range(n_itr):
+            # curriculum variables exactly as ppo.py:378-381 / :456-460 (no-ops for Cassie-v0: anneal_rate 1.0, f_term ignored by the env)
+            if self.highest_reward > (2 / 3) * self.max_traj_len and self.curr_anneal > 0.5:
+                self.curr_anneal *= self.anneal_rate
+            if self.do_term and self.curr_thresh < 0.35:
+                self.curr_thresh = 0.1 * 1.0006 ** (itr - self.start_itr)
             out = self.iteration()
             er, el = out["ep_returns"], out["ep_lens"]
-            avg_ret = float(er.mean()) if er.numel() else float("nan")
-            avg_len = float(el.mean()) if el.numel() else float("nan")
+            stats = torch.stack([er.double().sum(), torch.tensor(float(er.numel()), dtype=torch.float64, device=self.device),
+                                 el.double().sum()]) if er.numel() else torch.zeros(3, dtype=torch.float64, device=self.device)
+            if self.group is not None:
+                torch.distributed.all_reduce(stats, group=self.group)
+            stats = stats.cpu().numpy()
+            avg_ret = stats[0] / stats[1] if stats[1] > 0 else float("nan")
+            avg_len = stats[2] / stats[1] if stats[1] > 0 else float("nan")
+            if avg_len == avg_len and avg_len >= self.max_traj_len * 0.75:
+                self.ep_counter += 1
+            if not self.do_term and self.ep_counter > 50:
+                self.do_term = True; self.start_itr = itr
+            eval_time = 0.0
+            if self.eval_every > 0 and itr % self.eval_every == 0:
+                t0 = time.time()
+                avg_eval = self.evaluate_pass()
+                torch.cuda.synchronize(self.device); eval_time = time.time() - t0
+            test_ret = avg_eval if self.eval_every > 0 else avg_ret
             if self.rank == 0:
                 print("********** Iteration {} ************".format(itr))
                 print("timesteps in batch: %i  sample %.2fs  optimize %.2fs  (%.0f env-steps/s)" % (
                     out["steps"], out["sample_time"], out["optimize_time"],
                     out["steps"] / (out["sample_time"] + out["optimize_time"])))
+                print("Return (%s) %.3f  Return (batch) %.3f  Mean Eplen %.1f" % ("test" if self.eval_every > 0 else "batch, no eval pass", test_ret, avg_ret, avg_len))
                 print(" ".join("%g" % x for x in out["losses"]))
                 if logger is not None:
                     ml = out["losses"]
-                    logger.add_scalar("Test/Return", avg_ret, itr)          # eval rollouts == stochastic rollouts in the reference (ppo.py:171)
+                    logger.add_scalar("Test/Return", test_ret, itr)
                     logger.add_scalar("Train/Return", avg_ret, itr)
                     logger.add_scalar("Train/Mean Eplen", avg_len, itr)
                     logger.add_scalar("Train/Mean KL Div", ml[4], itr)
@@ -277,10 +335,11 @@ class PPO:
                     logger.add_scalar("Misc/Timesteps", self.total_steps, itr)
                     logger.add_scalar("Misc/Sample Times", out["sample_time"], itr)
                     logger.add_scalar("Misc/Optimize Times", out["optimize_time"], itr)
-                    logger.add_scalar("Misc/Evaluation Times", 0.0, itr)
-                    logger.add_scalar("Misc/Termination Threshold", 0.0, itr)
-                if avg_ret == avg_ret and self.highest_reward < avg_ret:
-                    self.highest_reward = avg_ret
+                    logger.add_scalar("Misc/Evaluation Times", eval_time, itr)
+                    logger.add_scalar("Misc/Termination Threshold", self.curr_thresh, itr)
+            if test_ret == test_ret and self.highest_reward < test_ret:            # ppo.py:502-504: best evaluation return so far
+                self.highest_reward = test_ret
+                if self.rank == 0:
                     self.save()
 
     def save(self):
@@ -302,13 +361,13 @@ def run_experiment(args):
         group = torch.distributed.group.WORLD
     torch.manual_seed(args.seed); np.random.seed(args.seed)
     n_envs = getattr(args, "n_envs", 4096)
-    env = CassieVecEnv(n_envs=n_envs, simrate=args.simrate, dynamics_randomization=args.dyn_random, reward=args.reward,
-                       max_traj_len=args.max_traj_len, seed=args.seed, device=local, env_id_base=adist.shard_env_base(rank, n_envs),
-                       command_profile=args.command_profile, input_profile=args.input_profile, history=args.history,
-                       learn_gains=args.learn_gains, env_name=args.env_name, traj=args.traj, no_delta=args.no_delta,
-                       ik_baseline=args.ik_baseline)
+    env_kwargs = dict(simrate=args.simrate, dynamics_randomization=args.dyn_random, reward=args.reward, seed=args.seed,
+                      command_profile=args.command_profile, input_profile=args.input_profile, history=args.history,
+                      learn_gains=args.learn_gains, env_name=args.env_name, traj=args.traj, no_delta=args.no_delta,
+                      ik_baseline=args.ik_baseline)
+    env = CassieVecEnv(n_envs=n_envs, max_traj_len=args.max_traj_len, device=local, env_id_base=adist.shard_env_base(rank, n_envs), **env_kwargs)
     logger = create_logger(args) if rank == 0 else None
-    a = dict(vars(args)); a["mirror"] = args.mirror
+    a = dict(vars(args)); a["mirror"] = args.mirror; a["env_kwargs"] = env_kwargs
     if getattr(args, "recurrent", False):
         from .ppo_recurrent import RecurrentPPO
         a.setdefault("std_dev", -2.0)

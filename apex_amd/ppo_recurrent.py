@@ -31,6 +31,11 @@ class RecurrentPPO:
         self.rank, self.world, self.group = rank, world_size, group
         self.device, self.N = env.device, env.n_envs
         self.T = adist.rollout_len(self.num_steps, self.N, self.world)
+        # every iteration restarts all envs (each trajectory must begin at an episode start with zero hidden state, like the padded
+        # training pass assumes), so a grid shorter than max_traj_len would never show the policy the later part of an episode
+        if self.T < self.max_traj_len and not args.get("allow_short_rollout", False):
+            raise ValueError("recurrent PPO: %d steps per env and iteration < max_traj_len %d: the policy would only ever train on the first %d steps "
+                             "of an episode; raise num_steps to n_envs x max_traj_len (or pass allow_short_rollout for a smoke run)" % (self.T, self.max_traj_len, self.T))
         self.H, self.L = hidden, layers
         self.learner = engine.RecurrentPPOLearner(50, 10, hidden, layers, self.device, self.fixed_std, lr=self.lr, eps=self.eps, clip=self.clip,
                                                   grad_clip=self.grad_clip, mirrored_obs=MIRRORED_OBS if self.mirror else None,

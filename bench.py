@@ -84,7 +84,7 @@ def main_recurrent(a):
     from apex_amd.vecenv import CassieVecEnv
     from apex_amd.ppo_recurrent import RecurrentPPO
     from apex_amd import dist as adist
-    n_envs, T = 2048, 100
+    n_envs, T = 2048, 400          # whole episodes: T = max_traj_len (every trajectory starts at an episode start, zero hidden state)
     env = CassieVecEnv(n_envs=n_envs, seed=0, device=local, env_id_base=adist.shard_env_base(rank, n_envs), env_name="CassieTraj-v0")
     args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=1024, epochs=a.epochs,
                 num_steps=T * n_envs * world, max_traj_len=400, max_grad_norm=0.05, mirror=True, seed=0)

@@ -53,6 +53,10 @@ int apx_returns_scan(const float* rew, const uint8_t* end, const float* boot, co
 int apx_adv_moments(const float* ret, const float* val, int64_t n, double* moments, void* stream);
 int apx_adv_apply(const float* ret, const float* val, int64_t n, double mean, double std_unbiased, double eps,
                   float* adv, void* stream);
+/*   apx_adv_apply_moments: the same with (mean, unbiased std) derived on the device from moments[3] (as written by
+ *   apx_adv_moments, summed over ranks by the caller's all-reduce): no host round trip inside an iteration. */
+int apx_adv_apply_moments(const float* ret, const float* val, int64_t n, const double* moments, double eps, float* adv,
+                          void* stream);
 
 /* Parameter block of one 3-layer ReLU MLP (rl/policies/actor.py:142-215, critic.py:37-77), fp32, torch layout
  * [out,in], packed in state_dict order: W0[H*D] b0[H] W1[H*H] b1[H] W2[O*H] b2[O]. */

@@ -149,9 +149,10 @@ def test_ppo_update_large_minibatch_vs_oracle(dev):
     H, Btot, mb = 256, 20000, 16384          # the fused 2 x 256 forward + split-K backward of BASELINE configs[1]
     lr = engine.PPOLearner(50, 10, H, dev, fixed_std=np.exp(-1.5), mirrored_obs=MIRRORED_OBS_FULL_CLOCK,
                            mirrored_acts=MIRRORED_ACTS)
-    Wa = [rng.randn(*v.shape).astype(np.float32) * 0.1 for v in lr.actor.views()]
-    Wc = [rng.randn(*v.shape).astype(np.float32) * 0.1 for v in lr.critic.views()]
-    Wo = [w + rng.randn(*w.shape).astype(np.float32) * 0.01 for w in Wa]
+    sc = [0.1, 0.1, 0.05, 0.1, 0.02, 0.1]            # layer scales that keep |mu| ~ 0.1 and the probability ratio within [0.4, 2] at H = 256
+    Wa = [rng.randn(*v.shape).astype(np.float32) * c for v, c in zip(lr.actor.views(), sc)]
+    Wc = [rng.randn(*v.shape).astype(np.float32) * c for v, c in zip(lr.critic.views(), sc)]
+    Wo = [w + rng.randn(*w.shape).astype(np.float32) * 0.002 for w in Wa]
     lr.actor.load_list(Wa); lr.critic.load_list(Wc)
     old = engine.Mlp(50, H, 10, dev); old.load_list(Wo)
     obs = rng.randn(Btot, 50).astype(np.float32); ph = rng.rand(Btot) * 2 * np.pi

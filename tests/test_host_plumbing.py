@@ -24,6 +24,24 @@ def test_cli_flags_match_reference_defaults():
     assert (b.mirror, b.dyn_random, b.n_envs) == (False, False, 128)
 
 
+def test_cli_horizon_defaults_scale_with_the_env_batch():
+    """the reference's --num_steps default (5096 in total) on a 4096-env lock-step batch would be a 2-step horizon.  Without
+    --num_steps the CLI scales it to 32 steps per env (feed-forward) / max_traj_len (recurrent); explicit short horizons are refused."""
+    import apex
+    argv = ["--reward", "clock"]
+    a = apex.resolve_horizon(apex.build_parser().parse_args(argv), argv)
+    assert a.num_steps == 4096 * 32 and a.minibatch_size == 16384
+    argv = ["--reward", "clock", "--recurrent", "--n_envs", "2048"]
+    a = apex.resolve_horizon(apex.build_parser().parse_args(argv), argv)
+    assert a.num_steps == 2048 * 400 and a.minibatch_size == 64            # recurrent: minibatch_size counts trajectories (ppo.py:412-413)
+    argv = ["--reward", "clock", "--num_steps", "131072", "--minibatch_size", "2048"]
+    a = apex.resolve_horizon(apex.build_parser().parse_args(argv), argv)
+    assert a.num_steps == 131072 and a.minibatch_size == 2048
+    argv = ["--reward", "clock", "--num_steps", "5096"]
+    with pytest.raises(SystemExit):
+        apex.resolve_horizon(apex.build_parser().parse_args(argv), argv)
+
+
 def test_g13_run_directory_layout(golden_dir, tmp_path):
     from apex_amd.log import create_logger
     cases = json.load(open(os.path.join(golden_dir, "g13_logdir.json")))
