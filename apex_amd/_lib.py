@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libapx.so")
+# APX_LIB selects an A/B build of the SAME HIP library (make VARIANT=...; kernel experiments under tools/); there is no non-HIP path
+LIB_PATH = os.environ.get("APX_LIB") or os.path.join(_HERE, "lib", "libapx.so")
 
 c_f32p = C.c_void_p
 c_ptr = C.c_void_p

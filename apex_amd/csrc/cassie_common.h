@@ -87,13 +87,19 @@ __device__ __forceinline__ RowK solref(float timeconst) {   // dampratio 1, dmax
 
 // optional phase profiling (lane 0 of workgroup 0): cumulative shader cycles per phase, read by tools/t_prof.py
 #ifdef APX_PROF
-__device__ unsigned long long g_prof_acc[12];
+__device__ unsigned long long g_prof_acc[48];
 __device__ unsigned long long g_prof_last;
 #define PROF(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long t__ = clock64(); c4::g_prof_acc[i] += t__ - c4::g_prof_last; c4::g_prof_last = t__; } } while (0)
 #define PROF_START() do { if (threadIdx.x == 0 && blockIdx.x == 0) c4::g_prof_last = clock64(); } while (0)
+#if APX_PROF >= 2      // fine probes inside the stages (slots 12..47); they add s_memtime + a full LDS drain each, so the coarse totals shift a little
+#define PROF2(i) PROF(i)
+#else
+#define PROF2(i) do {} while (0)
+#endif
 #else
 #define PROF(i) do {} while (0)
 #define PROF_START() do {} while (0)
+#define PROF2(i) do {} while (0)
 #endif
 
 // stage hand-off layout inside the per-env LDS region (floats, offsets from L4_WK)

@@ -178,6 +178,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         }
         lq[sd] = qmul(bquat[sd], jq);
     });
+    PROF2(12);
     // ---- pointer jumping over the ancestor chain (depth <= 8: 3 rounds).  Round r composes a body's transform with the
     // record of its 2^r-th ancestor, which by then spans 2^r levels itself; the same rounds give the chain sums below.
     const int jump[3] = {par, nibble(TB_PAR2, lb), nibble(TB_PAR4, lb)};
@@ -200,6 +201,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             if (jump[r] != 15) { tp[sd] = np; tq[sd] = nq; }
         });
     });
+    PROF2(13);
     M3 mat[2]; V3 pos[2]; Q4 quat[2]; SV vel[2], acc[2]; SV cdof[2][3];
     SV own[2];                                                        // this body's joint velocity contribution sum_K cdof_K qd_K
     sfor<0, 2>([&](auto Sd) {
@@ -240,6 +242,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         acc[sd] = t;
     });
     chain_sum(acc);
+    PROF2(14);
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
         acc[sd] = acc[sd] + pel.acc;
@@ -255,6 +258,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         }
     });
     wsync();                                                  // every lane is done reading poses: the records become (crb, frc)
+    PROF2(15);
     // ---- inertia + RNE force of the own bodies and of the pelvis
     SI crb[2]; SV frc[2];
     sfor<0, 2>([&](auto Sd) {
@@ -274,6 +278,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         body_inertia_force(pmat, o, o, Ipel, cv3<1>(ct_body_ipos), S(F_MASS + 1), pel.vel, pel.acc, pcrb, pfrc);
     }
     wsync();
+    PROF2(16);
     // ---- subtree sums (composite inertia, subtree force): descendants are the next ndesc bodies
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
@@ -297,6 +302,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         }
     });
     wsync();
+    PROF2(17);
     {   // pelvis composite = own + the two hip-roll subtrees
         sfor<0, 2>([&](auto Sd) {
             const float* p = xb + XB_SZ * (2 + 12 * Sd);
@@ -330,6 +336,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         if (l == 7) cap(base + 18, cv3<2 + sd>(ct_geom_pos), cv3<2 + sd>(ct_geom_axis), ct_geom_half[2 + sd]);      // tarsus capsule
         if (l == 6) cap(base + 24, cv3<4 + sd>(ct_geom_pos), cv3<4 + sd>(ct_geom_axis), ct_geom_half[4 + sd]);      // shin capsule
     });
+    PROF2(18);
     // ---- mass-matrix rows and bias forces, dof lanes: k = 0..12 -> leg dof k of both legs; 13..15 -> pelvis dofs (l-13, l-10)
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
@@ -378,6 +385,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         }
         S.W(WK_SMOOTH + d) = fs;
     });
+    PROF2(19);
     // ---- foot pose for the reward / foot velocity (cassie.py:328-331,426-427)
     if (!QPOS0 && l == 11) sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
@@ -559,7 +567,9 @@ __device__ __forceinline__ void stage_factor_lane(const St& S) {
     const LaneIdx X = lane_idx();
     LaneFac F;
     factor_lane(S, X, 0.f, F);
+    PROF2(20);
     fac_store(S, X, F);
+    PROF2(21);
     LaneVec x = vec_load(S, X, -1, WK_SMOOTH);
     solve_LT_lane(F, x);
     sfor<0, 2>([&](auto Sd) { x.a[Sd] *= F.invD[Sd]; });
@@ -583,6 +593,7 @@ __device__ __forceinline__ void stage_finish_lane(const St& S, const float* rows
     LaneVec qacc;
     sfor<0, 2>([&](auto Sd) { qacc.a[Sd] = z.a[Sd] * disq[Sd]; });
     sfor<0, 6>([&](auto Pp) { qacc.p[Pp] = z.p[Pp] * disqp[Pp]; });
+    PROF2(28);
     solve_L_lane(F, qacc);
     sfor<0, 2>([&](auto Sd) { qacc.a[Sd] += qs.a[Sd]; });
     sfor<0, 6>([&](auto Pp) { qacc.p[Pp] += qs.p[Pp]; });
@@ -622,6 +633,7 @@ __device__ __forceinline__ void stage_finish_lane(const St& S, const float* rows
             S(F_SNAP + SN_ACC) = dot(col(R, 0), a); S(F_SNAP + SN_ACC + 1) = dot(col(R, 1), a); S(F_SNAP + SN_ACC + 2) = dot(col(R, 2), a);
         }
     }
+    PROF2(29);
     if (!do_euler) return;
     // rhs = qfrc_smooth + L^T D^1/2 z~
     LaneVec x;
@@ -632,11 +644,14 @@ __device__ __forceinline__ void stage_finish_lane(const St& S, const float* rows
     sfor<0, 2>([&](auto Sd) { rhs.a[Sd] += sm.a[Sd]; });
     sfor<0, 6>([&](auto Pp) { rhs.p[Pp] += sm.p[Pp]; });
     __builtin_amdgcn_sched_barrier(0);
+    PROF2(30);
     factor_lane(S, X, DT, F);
+    PROF2(31);
     solve_LT_lane(F, rhs);
     sfor<0, 2>([&](auto Sd) { rhs.a[Sd] *= F.invD[Sd]; });
     sfor<0, 6>([&](auto Pp) { rhs.p[Pp] *= F.invDp[Pp]; });
     solve_L_lane(F, rhs);
+    PROF2(32);
     // ---- integrate: qvel += h a; hinges / slides qpos += h qvel; ball joints rotate by h w
     float qv[2], qvp[6];
     sfor<0, 2>([&](auto Sd) {
@@ -817,12 +832,15 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out) {
         if (isLim && nlim && c == clim) v = lsign;
         J[c] = v;
     });
+    PROF2(25);
     float vel = 0.f, ju = 0.f, jw = 0.f;
     sfor<0, 19>([&](auto C) {
         constexpr int c = C, d = c2d<LEG>(c);
         vel += J[c] * S(F_QVEL + d); ju += J[c] * S.W(WK_QS + d); jw += J[c] * S(F_QACCW + d);
     });
+    PROF2(26);
     const float nn = whiten_lane<LEG>(S, J);
+    PROF2(27);
     // ---- equality / limit scalars (mj_makeImpedance, mj_referenceConstraint, warm start from qacc_warmstart)
     {
         const V3 cv = p1 - p2;
@@ -886,7 +904,9 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     const float mu = S(F_FRIC);
     LegRows A, B;
     rows_lane<0>(S, A);
+    PROF2(23);
     rows_lane<1>(S, B);
+    PROF2(24);
     __builtin_amdgcn_sched_barrier(0);
     PROF(5);
     // ---- Gram columns of this lane's two rows

@@ -769,15 +769,15 @@ extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, voi
         return I_TOTAL;
     }
 #ifdef APX_PROF
-    if (!strcmp(name, "prof")) {   // 12 cumulative phase cycle counters, then reset
-        unsigned long long h[12];
+    if (!strcmp(name, "prof")) {   // 48 cumulative phase cycle counters, then reset
+        unsigned long long h[48];
         APX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(c4::g_prof_acc), sizeof(h)));
-        float hf[12];
-        for (int i = 0; i < 12; ++i) hf[i] = (float)h[i];
+        float hf[48];
+        for (int i = 0; i < 48; ++i) hf[i] = (float)h[i];
         APX_HIP(hipMemcpy(out, hf, sizeof(hf), hipMemcpyHostToDevice));
-        unsigned long long z[12] = {0};
+        unsigned long long z[48] = {0};
         APX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c4::g_prof_acc), z, sizeof(z)));
-        return 12;
+        return 48;
     }
 #endif
     if (!strcmp(name, "substep")) {   // debugging hook: out[0] (host-readable count is not needed) - run one raw substep
