@@ -311,6 +311,22 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             pfrc.a = pfrc.a + V3{p[10], p[11], p[12]}; pfrc.l = pfrc.l + V3{p[13], p[14], p[15]};
         });
     }
+    // ---- collision geoms the constraint stage does not instantiate (pelvis sphere cassie.xml:87, hip-pitch capsules :101,164): only
+    // tested against the floor plane here; a hit is reported through I_SAT (SAT_BODY_FLOOR) by the constraint stage
+    if constexpr (!QPOS0) {
+        const V3 fn = {S(F_FLOOR), S(F_FLOOR + 1), S(F_FLOOR + 2)}, p0 = {ct_floor_pos[0], ct_floor_pos[1], ct_floor_pos[2]};
+        static_assert(ct_geom_body[8] == 1 && ct_geom_body[6] == 4 && ct_geom_body[7] == 16, "pelvis sphere, hip-pitch capsules");
+        float hitb = 0.f;
+        if (l == 0) hitb = dot(o + mul(pmat, cv3<8>(ct_geom_pos)) - p0, fn) - ct_geom_radius[8] < 0.f ? 1.f : 0.f;
+        if (l == 2) sfor<0, 2>([&](auto Sd) {
+            constexpr int sd = Sd;
+            const V3 c = pos[sd] + mul(mat[sd], cv3<6 + sd>(ct_geom_pos)), ax = mul(mat[sd], cv3<6 + sd>(ct_geom_axis)) * ct_geom_half[6 + sd];
+            const float d = fminf(dot(c + ax - p0, fn), dot(c - ax - p0, fn)) - ct_geom_radius[6 + sd];
+            hitb = d < 0.f ? 1.f : hitb;
+        });
+        if (l == 0) S.W(WK_MISC + 4) = hitb;
+        if (l == 2) S.W(WK_MISC + 5) = hitb;
+    }
     // ---- anchor points, capsule ends, foot pose (body lanes that own them)
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd, base = WK_PTS + 30 * sd;
@@ -744,6 +760,48 @@ __device__ __forceinline__ void setconst_rows_lane(const St& S) {
     if (l == 0) S(F_BIW) = 0.f;
 }
 
+// left-leg vs right-leg capsules (foot, tarsus, shin against foot, tarsus, shin: cassie.xml:23-35, condim 1, frictionless): lane 3 i + j
+// tests the pair (left geom i, right geom j) like mjc_CapsuleCapsule's general case (closest points of the two axes), records go to the
+// row scratch; every lane then counts the hits, and lane 13 + k takes the k-th penetrating pair as ITS constraint row (MAXX rows; more
+// is reported through SAT_LEG_LEG).  Pair order = the oracle's (left geom outer, right geom inner).
+constexpr int MAXX = 3;
+struct XPair { int nx; int gi, gj; V3 n, cp; float dist; };
+__device__ __forceinline__ XPair legleg_pairs_lane(const St& S, float* rec) {
+    const int l = threadIdx.x & 15, li = l < 9 ? l / 3 : 0, rj = l < 9 ? l - 3 * (l / 3) : 0;
+    {
+        const lfloat* pl = &S.W(WK_PTS + 12 + 6 * li); const lfloat* pr = &S.W(WK_PTS + 30 + 12 + 6 * rj);
+        const V3 p1 = {pl[0], pl[1], pl[2]}, q1 = {pl[3], pl[4], pl[5]}, p2 = {pr[0], pr[1], pr[2]}, q2 = {pr[3], pr[4], pr[5]};
+        const V3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
+        const float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), c = dot(d1, r), b = dot(d1, d2), den = a * e - b * b;
+        float sp = den > 1e-12f ? fminf(fmaxf((b * f - c * e) * rcpf(den), 0.f), 1.f) : 0.f;
+        float tp = (b * sp + f) * rcpf(e);
+        if (tp < 0.f) { tp = 0.f; sp = fminf(fmaxf(-c * rcpf(a), 0.f), 1.f); }
+        else if (tp > 1.f) { tp = 1.f; sp = fminf(fmaxf((b - c) * rcpf(a), 0.f), 1.f); }
+        const V3 c1 = p1 + d1 * sp, dv = (p2 + d2 * tp) - c1;
+        const float len = sqrtf(dot(dv, dv));
+        const float rl = li == 0 ? ct_geom_radius[0] : ct_geom_radius[2], rr = rj == 0 ? ct_geom_radius[1] : ct_geom_radius[3];
+        static_assert(ct_geom_radius[2] == ct_geom_radius[4] && ct_geom_radius[3] == ct_geom_radius[5], "tarsus / shin capsule radii");
+        const float dist = len - rl - rr;
+        const V3 nn = dv * rcpf(fmaxf(len, 1e-12f));                 // from the left geom to the right geom
+        const V3 cp = c1 + nn * (rl + 0.5f * dist);
+        if (l < 9) {
+            float* p = rec + 8 * l;
+            p[0] = (dist < 0.f && len > 1e-9f) ? 1.f : 0.f; p[1] = dist; p[2] = nn.x; p[3] = nn.y; p[4] = nn.z; p[5] = cp.x; p[6] = cp.y; p[7] = cp.z;
+        }
+    }
+    wsync();
+    XPair x; x.nx = 0; x.gi = 0; x.gj = 0; x.n = {0.f, 0.f, 0.f}; x.cp = {0.f, 0.f, 0.f}; x.dist = 0.f;
+    const int k = l - 13;
+    sfor<0, 9>([&](auto P) {
+        constexpr int p = P;
+        const float* q = rec + 8 * p;
+        const bool h = q[0] != 0.f;
+        if (h && x.nx == k) { x.gi = p / 3; x.gj = p % 3; x.dist = q[1]; x.n = {q[2], q[3], q[4]}; x.cp = {q[5], q[6], q[7]}; }
+        x.nx += h ? 1 : 0;
+    });
+    return x;
+}
+
 // Constraint rows of leg LEG, one row vector per lane: Jacobian from the stored motion axes, dots against
 // qvel / qacc_smooth / qacc_warmstart on the raw row, whitening y~ = D^-1/2 L^-T J^T (L streamed from LDS, uniform
 // addresses), row scalars.  Same arithmetic as c3::build_rows3, except that a connect row takes the common ancestors of
@@ -751,11 +809,13 @@ __device__ __forceinline__ void setconst_rows_lane(const St& S) {
 struct LegRows {
     float J[19];                 // this lane's whitened row vector (local columns)
     float b, R, invA, f;         // this lane's row scalars (equality / limit lanes)
+    float vel, ju, jw, nn;       // this lane's raw dots J . qvel, J . qacc_smooth, J . qacc_warmstart and |y~|^2 (the leg-leg lanes combine the two legs)
     int nc, nlim;                // uniform over the env's lanes from here on
+    int over;                    // SAT_LIMITS / SAT_CONTACTS: more active limits / penetrating capsule ends than the lane map has slots for
     float cG[MAXC][6], cR[MAXC], cb[MAXC][4], cf[MAXC][4], isfoot[MAXC];
 };
 template <int LEG>
-__device__ __forceinline__ void rows_lane(const St& S, LegRows& out) {
+__device__ __forceinline__ void rows_lane(const St& S, LegRows& out, const XPair& xp) {
     const int l = threadIdx.x & 15;
     const V3 o = {S(F_QPOS), S(F_QPOS + 1), S(F_QPOS + 2)};
     const V3 fn = {S(F_FLOOR), S(F_FLOOR + 1), S(F_FLOOR + 2)}, ft1 = {S(F_FLOOR + 3), S(F_FLOOR + 4), S(F_FLOOR + 5)},
@@ -763,16 +823,18 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out) {
     const float mu = S(F_FRIC);
     constexpr int base = WK_PTS + 30 * LEG;
     // ---- uniform over the env's lanes: first active joint limit of this leg
-    int nlim = 0, clim = -1;
+    int nlim = 0, clim = -1, over = 0;
     float lsign = 0.f, ldist = 0.f, ldiw = 0.f;
     sfor<0, NJ>([&](auto Jn) {
         constexpr int j = Jn;
         if constexpr (ct_jnt_limited[j] && ((ct_jnt_body[j] >= 14) == (LEG == 1)) && ct_jnt_body[j] >= 2) {
             const float q = S(F_QPOS + ct_jnt_qposadr[j]);
             const float dlo = q - ct_jnt_range[2 * j], dhi = ct_jnt_range[2 * j + 1] - q;
-            if ((dlo < 0.f || dhi < 0.f) && nlim == 0) {
-                constexpr int d = ct_jnt_dofadr[j];
-                clim = d2c(d); lsign = dlo < 0.f ? 1.f : -1.f; ldist = dlo < 0.f ? dlo : dhi; ldiw = S(F_DIW + d); nlim = 1;
+            if (dlo < 0.f || dhi < 0.f) {
+                if (nlim == 0) {
+                    constexpr int d = ct_jnt_dofadr[j];
+                    clim = d2c(d); lsign = dlo < 0.f ? 1.f : -1.f; ldist = dlo < 0.f ? dlo : dhi; ldiw = S(F_DIW + d); nlim = 1;
+                } else over |= SAT_LIMITS;
             }
         }
     });
@@ -787,6 +849,7 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out) {
         const V3 ctr = ldv3<base + 12 + 3 * I>(S);
         const float dist = dot(ctr - p0, fn) - ct_geom_radius[2 * G + LEG];
         const bool hit = dist < 0.f && nc < MAXC;
+        over |= (dist < 0.f && nc >= MAXC) ? SAT_CONTACTS : 0;
         const V3 cp = ctr - fn * (ct_geom_radius[2 * G + LEG] + 0.5f * dist);
         if (hit && nc == 0) cpt0 = cp;
         if (hit && nc == 1) cpt1 = cp;
@@ -801,14 +864,17 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out) {
     constexpr unsigned mPL1 = chain_mask<LEG>(ct_eq_body1[2 * LEG]), mPL2 = chain_mask<LEG>(ct_eq_body2[2 * LEG]);
     constexpr unsigned mAC1 = chain_mask<LEG>(ct_eq_body1[2 * LEG + 1]), mAC2 = chain_mask<LEG>(ct_eq_body2[2 * LEG + 1]);
     constexpr unsigned mFT = chain_mask<LEG>(13 + 12 * LEG);
-    const int G = cs ? cgeo[1] : cgeo[0];
+    // leg-leg row of lane 13 + k: this leg's half of n . (J_right(cp) - J_left(cp)); the pelvis columns cancel between the halves exactly
+    // (both bodies hang off the pelvis) and are left out of both
+    const bool isX = l >= 13 && (l - 13) < xp.nx && (l - 13) < MAXX;
+    const int G = isX ? (LEG == 0 ? xp.gi : xp.gj) : (cs ? cgeo[1] : cgeo[0]);
     const unsigned mcon = mFT & ~(G >= 1 ? (1u << 18) : 0u) & ~(G >= 2 ? (1u << 14) : 0u);   // tarsus / shin contact: dofs below do not move the point
-    const unsigned m1 = isEq ? (E ? mAC1 : mPL1) : isCon ? mcon : 0u, m2 = isEq ? (E ? mAC2 : mPL2) : 0u;
+    const unsigned m1 = isEq ? (E ? mAC1 : mPL1) : isCon ? mcon : isX ? (mcon & ~0x3Fu) : 0u, m2 = isEq ? (E ? mAC2 : mPL2) : 0u;
     V3 p1, p2;
     {
         const V3 e1 = {S.W(base + 6 * E), S.W(base + 6 * E + 1), S.W(base + 6 * E + 2)};
         const V3 e2 = {S.W(base + 6 * E + 3), S.W(base + 6 * E + 4), S.W(base + 6 * E + 5)};
-        const V3 cp = {cs ? cpt1.x : cpt0.x, cs ? cpt1.y : cpt0.y, cs ? cpt1.z : cpt0.z};
+        const V3 cp = {isX ? xp.cp.x : cs ? cpt1.x : cpt0.x, isX ? xp.cp.y : cs ? cpt1.y : cpt0.y, isX ? xp.cp.z : cs ? cpt1.z : cpt0.z};
         p1 = isEq ? e1 : cp; p2 = e2;
     }
     V3 dir;
@@ -818,6 +884,8 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out) {
         const float dcx = ax == 0 ? fn.x : ax == 1 ? ft1.x : ft2.x, dcy = ax == 0 ? fn.y : ax == 1 ? ft1.y : ft2.y,
                     dcz = ax == 0 ? fn.z : ax == 1 ? ft1.z : ft2.z;
         dir = {isEq ? (ax == 0 ? 1.f : 0.f) : dcx, isEq ? (ax == 1 ? 1.f : 0.f) : dcy, isEq ? (ax == 2 ? 1.f : 0.f) : dcz};
+        constexpr float sx = LEG == 0 ? -1.f : 1.f;
+        if (isX) dir = {sx * xp.n.x, sx * xp.n.y, sx * xp.n.z};
     }
     const V3 q1 = cross(p1 - o, dir), q2 = cross(p2 - o, dir);       // dir . (a x r) = a . (r x dir)
     float (&J)[19] = out.J;
@@ -840,6 +908,7 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out) {
     });
     PROF2(26);
     const float nn = whiten_lane<LEG>(S, J);
+    out.vel = vel; out.ju = ju; out.jw = jw; out.nn = nn;
     PROF2(27);
     // ---- equality / limit scalars (mj_makeImpedance, mj_referenceConstraint, warm start from qacc_warmstart)
     {
@@ -890,7 +959,7 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out) {
             out.cf[s][k] = (s < nc && f > 0.f) ? f : 0.f;
         });
     });
-    out.nc = nc; out.nlim = nlim;
+    out.nc = nc; out.nlim = nlim; out.over = over;
 }
 
 // Projected Gauss-Seidel in GRAM SPACE.  Lane r (0..12) owns basis vector r of both legs (A = left, B = right): 6 connect
@@ -903,14 +972,37 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     const int l = threadIdx.x & 15;
     const float mu = S(F_FRIC);
     LegRows A, B;
-    rows_lane<0>(S, A);
+    const XPair xp = legleg_pairs_lane(S, rows);
+    rows_lane<0>(S, A, xp);
     PROF2(23);
-    rows_lane<1>(S, B);
+    rows_lane<1>(S, B, xp);
     PROF2(24);
+    // ---- leg-leg rows (lanes 13 + k): scalars from the two halves.  Row = (XL | XR) with XL = A.J, XR = B.J on that lane; its pelvis
+    // part is the SUM of the two whitened pelvis parts, so |y~|^2 = |XL|^2 + |XR|^2 + 2 XL_pel . XR_pel
+    const int nx = xp.nx < MAXX ? xp.nx : MAXX;
+    const bool anyx = __builtin_amdgcn_ballot_w64(xp.nx > 0) != 0ull;         // wave-uniform: some env of the wave has a leg-leg contact
+    float xb_l = 0.f, xR_l = 1.f, xiA_l = 0.f, xf_l = 0.f;
+    if (anyx) {
+        float pp = 0.f;
+        sfor<0, 6>([&](auto C) { pp += A.J[C] * B.J[C]; });
+        const float nnx = A.nn + B.nn + 2.f * pp;
+        const int bi = xp.gi == 0 ? 13 : xp.gi == 1 ? 9 : 8, bj = xp.gj == 0 ? 25 : xp.gj == 1 ? 21 : 20;
+        static_assert(ct_geom_body[0] == 13 && ct_geom_body[2] == 9 && ct_geom_body[4] == 8 && ct_geom_body[1] == 25 && ct_geom_body[3] == 21 && ct_geom_body[5] == 20, "capsule bodies");
+        const float tran = S(F_BIW + bi) + S(F_BIW + bj);
+        const RowK kb = solref(0.005f);
+        const float imp = impedance(xp.dist);
+        const float R = fmaxf(MINVAL, (1.f - imp) * rcpf(imp) * tran);
+        const float aref = -kb.B * (A.vel + B.vel) - kb.K * imp * xp.dist;
+        const bool isX = l >= 13 && (l - 13) < nx;
+        xb_l = isX ? (A.ju + B.ju) - aref : 0.f;
+        xR_l = isX ? R : 1.f;
+        xiA_l = isX ? rcpf(nnx + R) : 0.f;
+        xf_l = isX ? fmaxf(-((A.jw + B.jw) - aref) * rcpf(R), 0.f) : 0.f;
+    }
     __builtin_amdgcn_sched_barrier(0);
     PROF(5);
     // ---- Gram columns of this lane's two rows
-    float GAA[13], GBB[13], GAB[13], GBA[13];      // GXY[s] = y~_(r,X) . y~_(s,Y)
+    float GAA[16], GBB[16], GAB[16], GBA[16];      // GXY[s] = y~_(r,X) . y~_(s,Y); s = 13 + k: the halves (XL, XR) of leg-leg row k
     {
         typedef float f2 __attribute__((ext_vector_type(2)));
         f2 JP[19];                                 // (left, right) row of this lane, packed for v_pk_fma_f32
@@ -930,7 +1022,28 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
             asm volatile("" : "+v"(aa), "+v"(bb), "+v"(ab), "+v"(ba));
             GAA[s] = aa; GBB[s] = bb; GAB[s] = ab; GBA[s] = ba;
         });
+        sfor<13, 16>([&](auto Sx) { GAA[Sx] = GBB[Sx] = GAB[Sx] = GBA[Sx] = 0.f; });
+        if (anyx) sfor<13, 13 + MAXX>([&](auto Sx) {
+            constexpr int s = Sx;
+            f2 d = {0.f, 0.f}, x = {0.f, 0.f};
+            sfor<0, 19>([&](auto C) {
+                constexpr int c = C;
+                const f2 sv = {dpp<0x150 + s>(A.J[c]), dpp<0x150 + s>(B.J[c])};
+                d += JP[c] * sv;
+                if constexpr (c < 6) x += JP[c] * f2{sv.y, sv.x};
+            });
+            float aa = d.x, bb = d.y, ab = x.x, ba = x.y;
+            asm volatile("" : "+v"(aa), "+v"(bb), "+v"(ab), "+v"(ba));
+            GAA[s] = aa; GBB[s] = bb; GAB[s] = ab; GBA[s] = ba;
+        });
     }
+    // leg-leg row scalars to every lane
+    float xb[MAXX], xR[MAXX], xiA[MAXX], xf[MAXX]; bool xact[MAXX];
+    sfor<0, MAXX>([&](auto K) {
+        constexpr int k = K;
+        xb[k] = dpp<0x150 + 13 + k>(xb_l); xR[k] = dpp<0x150 + 13 + k>(xR_l); xiA[k] = dpp<0x150 + 13 + k>(xiA_l); xf[k] = dpp<0x150 + 13 + k>(xf_l);
+        xact[k] = k < nx;
+    });
     // ---- row scalars to every lane: c = b + R f, R, 1/(A+R), f
     float ec[2][7], eR[2][7], eiA[2][7], ef[2][7];
     sfor<0, 7>([&](auto Sx) {
@@ -968,17 +1081,22 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     });
     float rA = 0.f, rB = 0.f, cost = 0.f;
     sfor<0, 13>([&](auto Sx) { rA += GAA[Sx] * FA[Sx] + GAB[Sx] * FB[Sx]; rB += GBA[Sx] * FA[Sx] + GBB[Sx] * FB[Sx]; });
+    // a coefficient of leg-leg row k moves z~ by (XL | XR): rho_A by XL . A_r + XR_pel . A_r,pel, rho_B likewise
+    sfor<0, MAXX>([&](auto K) { constexpr int s = 13 + K; rA += (GAA[s] + GAB[s]) * xf[K]; rB += (GBB[s] + GBA[s]) * xf[K]; });
     {
         float own = 0.f;       // F of this lane's own rows times rho
         sfor<0, 13>([&](auto Sx) { if (l == Sx) own = FA[Sx] * rA + FB[Sx] * rB; });
+        sfor<0, MAXX>([&](auto K) { if (l == 13 + K) own = xf[K] * (rA + rB); });
         cost = 0.5f * red16(own);
     }
+    sfor<0, MAXX>([&](auto K) { cost += xf[K] * (0.5f * xR[K] * xf[K] + xb[K]); });
     sfor<0, 2>([&](auto Lg) { sfor<0, 7>([&](auto Sx) { cost += ef[Lg][Sx] * (0.5f * eR[Lg][Sx] * ef[Lg][Sx] + ec[Lg][Sx]); }); });
     sfor<0, NCS>([&](auto Sl) { sfor<0, 4>([&](auto K) { cost += cf[Sl][K] * (0.5f * cR[Sl] * cf[Sl][K] + cb[Sl][K]); }); });
     if (cost > 0.f) {
         rA = rB = 0.f;
         sfor<0, 2>([&](auto Lg) { sfor<0, 7>([&](auto Sx) { ef[Lg][Sx] = 0.f; }); });
         sfor<0, NCS>([&](auto Sl) { sfor<0, 4>([&](auto K) { cf[Sl][K] = 0.f; }); });
+        sfor<0, MAXX>([&](auto K) { xf[K] = 0.f; });
     }
     PROF(6);
     // ---- sweeps.  Packed fp32 (v_pk_fma_f32) wherever two independent updates share the multiplier: (rho_A, rho_B), the
@@ -989,6 +1107,12 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     typedef float f2 __attribute__((ext_vector_type(2)));
     const float f0A = l < 7 ? (cost > 0.f ? 0.f : A.f) : 0.f, f0B = l < 7 ? (cost > 0.f ? 0.f : B.f) : 0.f;      // this lane's own coefficients
     f2 r = {rA + (l < 7 ? A.R * f0A : 0.f), rB + (l < 7 ? B.R * f0B : 0.f)};
+    f2 GpX[MAXX];                                           // how the coefficient of leg-leg row k moves (rho'_A, rho'_B); its regulariser rides on rho'_A of lane 13 + k
+    sfor<0, MAXX>([&](auto K) {
+        constexpr int s = 13 + K;
+        GpX[K] = f2{GAA[s] + GAB[s] + (l == s ? xR[K] : 0.f), GBB[s] + GBA[s]};
+        r.x += l == s ? xR[K] * xf[K] : 0.f;
+    });
     f2 Gp[2][13];                                           // how a coefficient of leg L's basis s moves (rho'_A, rho'_B)
     sfor<0, 13>([&](auto Sx) {
         constexpr int s = Sx;
@@ -1049,6 +1173,16 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
                 }
             });
         });
+        if (anyx) sfor<0, MAXX>([&](auto K) {               // leg-leg rows last, in pair order (frictionless: one unilateral row each)
+            constexpr int k = K, s = 13 + k;
+            if (xact[k]) {
+                const float t = dpp<0x150 + s>(r.x) + dpp<0x150 + s>(r.y) + xb[k];
+                const float fn = fmaxf(xf[k] - t * xiA[k], 0.f);
+                const float df = fn - xf[k];
+                xf[k] = fn;
+                r += GpX[k] * df;
+            }
+        });
     }
     rA = r.x; rB = r.y;
     PROF(7);
@@ -1065,12 +1199,15 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
         if (l == ln + 2) own = d2;
     });
     if (l >= 13) ownA = ownB = 0.f;
+    sfor<0, MAXX>([&](auto K) { if (l == 13 + K && xact[K]) ownA = ownB = xf[K]; });
     sfor<0, 19>([&](auto C) {
         constexpr int c = C;
         if constexpr (c < 6) { const float z = red16(A.J[c] * ownA + B.J[c] * ownB); if (l == 0) S.W(WK_ZT + c) = z; }
         else { const float za = red16(A.J[c] * ownA), zb = red16(B.J[c] * ownB); if (l == 0) { S.W(WK_ZT + c) = za; S.W(WK_ZT + c + 13) = zb; } }
     });
     if (l == 0) {
+        const int sat = A.over | B.over | ((S.W(WK_MISC + 4) + S.W(WK_MISC + 5) > 0.f) ? SAT_BODY_FLOOR : 0) | (xp.nx > MAXX ? SAT_LEG_LEG : 0);
+        if (sat) S.I(I_SAT) = (S.I(I_SAT) | sat) + 256;
         S.W(WK_MISC + 0) = (float)A.nc; S.W(WK_MISC + 1) = (float)B.nc; S.W(WK_MISC + 2) = (float)A.nlim; S.W(WK_MISC + 3) = (float)B.nlim;
         // contact forces to the row store (foot-force readout in the finish stage)
         sfor<0, NCS>([&](auto Sl) {

@@ -19,7 +19,11 @@ enum Field : int {
 };
 enum SnapOff { SN_MPOS = 0, SN_JPOS = 10, SN_QUAT = 16, SN_GYRO = 20, SN_ACC = 23, SN_VEL = 26, SN_PZ = 29 };
 enum SoOff { SO_MPOS = 0, SO_MVEL = 10, SO_TORQUE = 20, SO_JPOS = 30, SO_JVEL = 36, SO_QUAT = 42, SO_ROTVEL = 46, SO_TVEL = 49, SO_TACC = 52, SO_HEIGHT = 55 };
-enum IField : int { I_TIME = 0, I_PHASE, I_COUNTER, I_RNG, I_FLAGS /* bit0 menc primed, 1 jenc primed, 2 prev_action, 3 prev_torque */, I_TOTAL };
+enum IField : int { I_TIME = 0, I_PHASE, I_COUNTER, I_RNG, I_FLAGS /* bit0 menc primed, 1 jenc primed, 2 prev_action, 3 prev_torque */,
+                    I_SAT /* constraint sets beyond what the kernel instantiates: bits 0-3 = SAT_* flags seen since env creation, bits 8.. = number of such forward passes */, I_TOTAL };
+// what a forward pass needed beyond the kernel's per-leg caps (same bits as oracle/cassie_phys.h SatFlag): > 2 penetrating capsule ends on a
+// leg, > 1 active joint limit on a leg, pelvis sphere / hip-pitch capsule on the floor, a left-right capsule pair in contact
+enum SatFlag : int { SAT_CONTACTS = 1, SAT_LIMITS = 2, SAT_BODY_FLOOR = 4, SAT_LEG_LEG = 8 };
 
 struct apx_env {
     apx_env_cfg cfg;

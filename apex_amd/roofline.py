@@ -6,7 +6,7 @@ ENV_STEP_FLOP: fp32 operations of one env step of the tree-sparse formulation, c
  x 50.
 """
 F_TOTAL = 585          # floats of persistent state per env (env_state.h: enum Field)
-I_TOTAL = 5
+I_TOTAL = 6
 ENV_STEP_BYTES = 2 * 4 * (F_TOTAL + I_TOTAL) + 4 * 10 + 4 * 50 + 4 + 1
 
 # per-substep fp32 op count (multiply-add = 2), typical walking state: 12 equality rows + 2 contacts (8 rows) = 20 rows

@@ -37,12 +37,13 @@ void orc_env_obs(void* h, double* obs) { env_obs(*(Env*)h, obs); }
 void orc_phys_step(void* h, const double* ctrl, int n) {
     static thread_local Work w;
     Env& e = *(Env*)h;
-    for (int i = 0; i < n; ++i) step(e.par, e.st, w, ctrl);
+    for (int i = 0; i < n; ++i) { step(e.par, e.st, w, ctrl); e.sat_acc |= e.st.sat; }
 }
 void orc_phys_forward(void* h, const double* ctrl) {
     static thread_local Work w;
     Env& e = *(Env*)h;
     forward(e.par, e.st, w, ctrl);
+    e.sat_acc |= e.st.sat;
 }
 double orc_constraint_violation(void* h) { return constraint_violation(((Env*)h)->st); }
 void orc_com_velocity(void* h, double* out) { static thread_local Work w; Env& e = *(Env*)h; com_velocity(e.par, e.st, w, out); }
@@ -78,16 +79,19 @@ static int field(Env& e, const char* name, double* io, bool set) {
     FIELD("tq_fifo", e.tq_fifo, 60)
     if (!std::strcmp(name, "xpos")) { if (!set) std::memcpy(io, e.st.xpos, sizeof(double) * 3 * NB); return 3 * NB; }
     if (!std::strcmp(name, "xquat")) { if (!set) std::memcpy(io, e.st.xquat, sizeof(double) * 4 * NB); return 4 * NB; }
-    if (!std::strcmp(name, "ints")) {   // time, phase, counter, ncon, nefc, rng ctr, has_prev_action, has_prev_torque
-        int* p[8] = {&e.time, &e.phase, &e.counter, &e.st.ncon, &e.st.nefc, (int*)&e.rng.ctr, &e.has_prev_action, &e.has_prev_torque};
-        for (int i = 0; i < 8; ++i) { if (set) *p[i] = (int)io[i]; else io[i] = *p[i]; }
-        return 8;
+    if (!std::strcmp(name, "efc_type")) { if (!set) for (int i = 0; i < MAXEFC; ++i) io[i] = e.st.efc_type[i]; return MAXEFC; }
+    if (!std::strcmp(name, "ints")) {   // time, phase, counter, ncon, nefc, rng ctr, has_prev_action, has_prev_torque, sat flags (accumulated), ncon1
+        int* p[10] = {&e.time, &e.phase, &e.counter, &e.st.ncon, &e.st.nefc, (int*)&e.rng.ctr, &e.has_prev_action, &e.has_prev_torque, &e.sat_acc, &e.st.ncon1};
+        if (set) { for (int i = 0; i < 8; ++i) *p[i] = (int)io[i]; return 8; }     // the first 8 are settable (tests); sat / ncon1 are read-only
+        for (int i = 0; i < 10; ++i) io[i] = *p[i];
+        return 10;
     }
     return -1;
 }
 int orc_env_get(void* h, const char* name, double* out) { return field(*(Env*)h, name, out, false); }
 int orc_env_set(void* h, const char* name, const double* in) { return field(*(Env*)h, name, (double*)in, true); }
 void orc_env_set_const(void* h) { set_const(((Env*)h)->par); }
+void orc_env_set_kernel_caps(void* h, int on) { ((Env*)h)->par.kernel_caps = on; }
 
 void orc_clock_eval(double swing, double stance, double relax, int mode, int inc, int freq, int n, const double* ph,
                     double* out, double* phaselen) {

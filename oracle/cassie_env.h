@@ -70,6 +70,7 @@ struct Env {
     double l_foot_frc, r_foot_frc, l_foot_orient_cost, r_foot_orient_cost;
     double prev_action[10], prev_torque[10]; int has_prev_action, has_prev_torque;
     double last_reward_terms[8];
+    int sat_acc;               // OR of State::sat over every forward pass since env_init (SatFlag bits)
 };
 
 void env_init(Env& e, const EnvCfg& cfg, uint32_t env_id);

@@ -114,6 +114,28 @@ static void jac_point(const Work& w, int b, V3 p, double Jx[NV], double Jy[NV], 
     }
 }
 
+// closest points of two segments p1 + s d1, p2 + t d2, s, t in [0, 1] (mjc_CapsuleCapsule reduces to this for non-parallel axes; for
+// parallel axes MuJoCo may emit two contacts, here the clamped solution gives one)
+static void closest_seg_seg(V3 p1, V3 q1, V3 p2, V3 q2, V3& c1, V3& c2) {
+    const V3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
+    const double a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
+    double sp, tp;
+    if (a <= MINVAL && e <= MINVAL) { c1 = p1; c2 = p2; return; }
+    if (a <= MINVAL) { sp = 0; tp = std::min(std::max(f / e, 0.0), 1.0); }
+    else {
+        const double c = dot(d1, r);
+        if (e <= MINVAL) { tp = 0; sp = std::min(std::max(-c / a, 0.0), 1.0); }
+        else {
+            const double b = dot(d1, d2), den = a * e - b * b;
+            sp = den > MINVAL ? std::min(std::max((b * f - c * e) / den, 0.0), 1.0) : 0.0;
+            tp = (b * sp + f) / e;
+            if (tp < 0) { tp = 0; sp = std::min(std::max(-c / a, 0.0), 1.0); }
+            else if (tp > 1) { tp = 1; sp = std::min(std::max((b - c) / a, 0.0), 1.0); }
+        }
+    }
+    c1 = p1 + d1 * sp; c2 = p2 + d2 * tp;
+}
+
 static void impedance(double pos, double& imp) {
     // MuJoCo solimp = (d0, dwidth, width, midpoint, power) default 0.9 0.95 0.001 0.5 2
     const double d0 = 0.9, d1 = 0.95, width = 0.001, mid = 0.5, power = 2;
@@ -255,7 +277,7 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
     V3 t1 = std::fabs(nrm.y) < 0.5 ? V3{0, 1, 0} : V3{0, 0, 1};      // mju_makeFrame
     t1 = t1 - nrm * dot(nrm, t1); t1 = t1 * (1.0 / norm(t1));
     const V3 t2 = cross(nrm, t1);
-    s.ncon = 0;
+    s.ncon = 0; s.sat = 0;
     int con_row[MAXCON];
     for (int leg = 0; leg < 2; ++leg) {
         const int body_lo = leg == 0 ? 2 : 14, body_hi = leg == 0 ? 13 : 25;
@@ -275,13 +297,14 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
             }
             n += 3;
         }
-        int nlim = 0;   // joint limits (mj_instantiateLimit), solreflimit default 0.02 1; first active one per leg
+        int nlim = 0;   // joint limits (mj_instantiateLimit), solreflimit default 0.02 1: every active one
         for (int j = 0; j < NJ && nlim < MAXLIM_LEG; ++j) {
             if (!cm_jnt_limited[j] || cm_jnt_body[j] < body_lo || cm_jnt_body[j] > body_hi) continue;
             const double q = s.qpos[cm_jnt_qposadr[j]];
             for (int side = 0; side < 2 && nlim < MAXLIM_LEG; ++side) {
                 const double dist = side == 0 ? q - cm_jnt_range[2 * j] : cm_jnt_range[2 * j + 1] - q;
                 if (dist >= 0) continue;
+                if (nlim >= KERNEL_MAXLIM_LEG) { s.sat |= SAT_LIMITS; if (p.kernel_caps) continue; }
                 Row& r = rows[n];
                 std::memset(r.J, 0, sizeof(r.J));
                 r.J[cm_jnt_dofadr[j]] = side == 0 ? 1.0 : -1.0;
@@ -290,11 +313,10 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
                 ++n; ++nlim;
             }
         }
-        // contacts: foot / tarsus / shin capsules of this leg vs the floor plane (mjc_PlaneCapsule), pyramidal cone,
-        // condim 3; first MAXCON_LEG penetrating capsule ends in that priority order.  The hip-pitch capsules and the
-        // pelvis sphere cannot reach the floor before the episode ends at pelvis z < 0.4 (cassie.py:462): left out.
+        // contacts: foot / tarsus / shin / hip-pitch capsules of this leg vs the floor plane (mjc_PlaneCapsule: one contact per
+        // penetrating end), pyramidal cone, condim 3 (the floor's condim / friction win through its priority, cassie.xml:73)
         int ncl = 0;
-        for (int g = leg; g < 6 && ncl < MAXCON_LEG; g += 2) {
+        for (int g = leg; g < 8 && ncl < MAXCON_LEG; g += 2) {
             const int b = cm_geom_body[g];
             const V3 c = s.xpos[b] + mul(s.xmat[b], v3(cm_geom_pos + 3 * g));
             const V3 ax = mul(s.xmat[b], v3(cm_geom_axis + 3 * g));
@@ -302,6 +324,8 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
                 const V3 ctr = c + ax * (e == 0 ? cm_geom_half[g] : -cm_geom_half[g]);
                 const double dist = dot(ctr - p0, nrm) - cm_geom_radius[g];
                 if (dist >= 0) continue;
+                if (g >= 6) { s.sat |= SAT_BODY_FLOOR; if (p.kernel_caps) continue; }
+                else if (ncl >= KERNEL_MAXCON_LEG) { s.sat |= SAT_CONTACTS; if (p.kernel_caps) continue; }
                 const V3 cp = ctr - nrm * (cm_geom_radius[g] + 0.5 * dist);
                 double Jx[NV] = {0}, Jy[NV] = {0}, Jz[NV] = {0};
                 jac_point(w, b, cp, Jx, Jy, Jz, 1.0);
@@ -322,6 +346,54 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
             }
         }
     }
+    {   // pelvis sphere vs the floor (cassie.xml:87; mjc_PlaneSphere), pyramidal like the other floor contacts
+        const int g = 8, b = cm_geom_body[g];
+        const V3 ctr = s.xpos[b] + mul(s.xmat[b], v3(cm_geom_pos + 3 * g));
+        const double dist = dot(ctr - p0, nrm) - cm_geom_radius[g];
+        if (dist < 0) s.sat |= SAT_BODY_FLOOR;
+        if (dist < 0 && !p.kernel_caps) {
+            const V3 cp = ctr - nrm * (cm_geom_radius[g] + 0.5 * dist);
+            double Jx[NV] = {0}, Jy[NV] = {0}, Jz[NV] = {0};
+            jac_point(w, b, cp, Jx, Jy, Jz, 1.0);
+            const double mu = p.friction, tran = p.body_invweight0[b][0];
+            const V3 dirs[4] = {nrm + t1 * mu, nrm - t1 * mu, nrm + t2 * mu, nrm - t2 * mu};
+            con_row[s.ncon] = n; s.con_dist[s.ncon] = dist; s.con_geom[s.ncon] = g;
+            for (int k = 0; k < 4; ++k) {
+                Row& r = rows[n + k];
+                for (int d = 0; d < NV; ++d) r.J[d] = dirs[k].x * Jx[d] + dirs[k].y * Jy[d] + dirs[k].z * Jz[d];
+                r.pos = dist; r.type = 2; r.diag = tran + mu * mu * tran;
+                finish_row(r, s.qvel, dist, 0.005, 1.0);
+            }
+            const double Rpy = std::max(MINVAL, 2 * mu * mu * rows[n].R);
+            for (int k = 0; k < 4; ++k) rows[n + k].R = Rpy;
+            n += 4; ++s.ncon;
+        }
+    }
+    // left-leg vs right-leg capsules (contype 2 / conaffinity 4 against contype 4 / conaffinity 2, cassie.xml:23-35): foot, tarsus, shin
+    // of one leg against foot, tarsus, shin of the other, condim 1 (frictionless): one unilateral row along the contact normal
+    s.ncon1 = 0;
+    for (int gl = 0; gl < 6; gl += 2)
+        for (int gr = 1; gr < 6; gr += 2) {
+            const int bl = cm_geom_body[gl], br = cm_geom_body[gr];
+            const V3 cl = s.xpos[bl] + mul(s.xmat[bl], v3(cm_geom_pos + 3 * gl)), al = mul(s.xmat[bl], v3(cm_geom_axis + 3 * gl)) * cm_geom_half[gl];
+            const V3 cr = s.xpos[br] + mul(s.xmat[br], v3(cm_geom_pos + 3 * gr)), ar = mul(s.xmat[br], v3(cm_geom_axis + 3 * gr)) * cm_geom_half[gr];
+            V3 c1, c2;
+            closest_seg_seg(cl - al, cl + al, cr - ar, cr + ar, c1, c2);
+            const V3 dv = c2 - c1;
+            const double len = norm(dv), dist = len - cm_geom_radius[gl] - cm_geom_radius[gr];
+            if (dist >= 0 || len < MINVAL) continue;
+            if (s.ncon1 >= KERNEL_MAXLEGLEG) { s.sat |= SAT_LEG_LEG; if (p.kernel_caps) continue; }
+            const V3 nn = dv * (1.0 / len);                                     // from the left geom to the right geom
+            const V3 cp = c1 + nn * (cm_geom_radius[gl] + 0.5 * dist);
+            double Jx[NV] = {0}, Jy[NV] = {0}, Jz[NV] = {0};
+            jac_point(w, br, cp, Jx, Jy, Jz, 1.0);
+            jac_point(w, bl, cp, Jx, Jy, Jz, -1.0);
+            Row& r = rows[n];
+            for (int d = 0; d < NV; ++d) r.J[d] = nn.x * Jx[d] + nn.y * Jy[d] + nn.z * Jz[d];
+            r.pos = dist; r.type = 2; r.diag = p.body_invweight0[bl][0] + p.body_invweight0[br][0];
+            finish_row(r, s.qvel, dist, 0.005, 1.0);
+            ++n; ++s.ncon1;
+        }
     s.nefc = n;
 
     // ------------------------------------------------------------------ dual problem + PGS (mj_projectConstraint, mj_solPGS)
@@ -367,7 +439,7 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
         for (int i = 0; i < n; ++i) a += MiJ[i][d] * f[i];
         s.qacc[d] = a;
     }
-    for (int i = 0; i < n; ++i) s.efc_force[i] = f[i];
+    for (int i = 0; i < n; ++i) { s.efc_force[i] = f[i]; s.efc_type[i] = rows[i].type; }
     // contact force on the foot bodies in world axes (cassie_sim_foot_forces: mj_contactForce summed per foot body)
     std::memset(s.foot_force, 0, sizeof(s.foot_force));
     for (int c = 0; c < s.ncon; ++c) {

@@ -19,9 +19,16 @@
 namespace orc {
 
 constexpr int NB = CM_NBODY, NV = CM_NV, NQ = CM_NQ, NJ = CM_NJNT, NG = CM_NGEOM, NEQ = CM_NEQ, NU = CM_NU;
-constexpr int MAXCON_LEG = 2, MAXLIM_LEG = 1;      // per-leg caps on contacts / active limit rows per step
-constexpr int MAXCON = 2 * MAXCON_LEG, MAXLIM = 2 * MAXLIM_LEG;
-constexpr int MAXEFC = 3 * NEQ + MAXLIM + 4 * MAXCON;
+// The oracle instantiates EVERY constraint cassie.xml can produce (cassie.xml:18-35,73,87,101,119-144 and the limited joints): all
+// active joint limits, both ends of the foot / tarsus / shin / hip-pitch capsules and the pelvis sphere against the floor (condim 3,
+// pyramidal), and the 3 x 3 left-right capsule pairs (condim 1, frictionless).  The HIP kernel keeps the first KERNEL_MAXCON_LEG floor
+// contacts (order foot, tarsus, shin), the first KERNEL_MAXLIM_LEG limit per leg and the first KERNEL_MAXLEGLEG leg-leg pairs; `State::sat` reports when a
+// substep needed more, so that the cap is a checked property of a rollout, not an assumption.
+constexpr int KERNEL_MAXCON_LEG = 2, KERNEL_MAXLIM_LEG = 1, KERNEL_MAXLEGLEG = 3;
+constexpr int MAXCON_LEG = 8, MAXLIM_LEG = 8;      // 4 capsules x 2 ends; 8 limited joints per leg
+constexpr int MAXCON = 2 * MAXCON_LEG + 1, MAXLIM = 2 * MAXLIM_LEG, MAXCON1 = 9;      // + pelvis sphere; 9 frictionless leg-leg contacts
+constexpr int MAXEFC = 3 * NEQ + MAXLIM + 4 * MAXCON + MAXCON1;
+enum SatFlag { SAT_CONTACTS = 1, SAT_LIMITS = 2, SAT_BODY_FLOOR = 4, SAT_LEG_LEG = 8 };
 constexpr double MINVAL = 1e-15;
 constexpr double DT = 0.0005;                      // cassie.xml:5
 constexpr double GRAV = 9.81;
@@ -92,6 +99,8 @@ struct Params {                  // per-env model parameters touched by dynamics
     double body_invweight0[NB][2];
     double dof_invweight0[NV];
     int pgs_iters;
+    int kernel_caps = 0;         // 1: instantiate only what the HIP kernel instantiates (first KERNEL_MAX* per leg, no pelvis / hip-pitch / leg-leg rows);
+                                 // `State::sat` is reported either way, so a test can check the kernel's arithmetic on a saturated state AND its flag
 };
 
 struct Row { double J[NV]; double pos, vel, R, aref, diag; int type; };   // type 0 equality, 1 limit, 2 contact
@@ -103,10 +112,13 @@ struct State {
     double qacc[NV];
     int ncon, nefc;
     double efc_force[MAXEFC];
+    int efc_type[MAXEFC];        // 0 equality, 1 limit, 2 contact (pyramid edge or frictionless)
     double foot_force[2][3];     // world contact force on the left / right foot body
     double sens_acc[3];          // accelerometer at the imu site (cassie.xml:267), sensor frame
     double sens_gyro[3];
     double con_dist[MAXCON]; int con_geom[MAXCON];
+    int sat;                     // SatFlag bits of the most recent forward pass: the constraint set exceeded what the HIP kernel instantiates
+    int ncon1;                   // leg-leg (frictionless) contacts of the most recent forward pass
     double xfrc[6] = {0, 0, 0, 0, 0, 0};   // mjData.xfrc_applied row of cassie-pelvis: world force xyz, torque xyz, applied at the body COM
 };
 

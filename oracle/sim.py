@@ -43,6 +43,7 @@ def lib():
         L.orc_env_set.restype = C.c_int
         L.orc_env_set.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
         L.orc_env_set_const.argtypes = [C.c_void_p]
+        L.orc_env_set_kernel_caps.argtypes = [C.c_void_p, C.c_int]
         L.orc_clock_eval.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p]
         L.orc_clock_reward_eval.restype = C.c_double
@@ -147,6 +148,12 @@ class OracleEnv:
         arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in
                 (qpos, qvel, scal, foot_vel, rotvel, tacc, torque, prev_torque, prev_action, action)]
         return lib().orc_clock_reward_eval(self.h, *[_ptr(a) for a in arrs])
+
+    def kernel_caps(self, on=True):
+        """Instantiate only the constraint rows the HIP kernel instantiates (first 2 floor contacts / first limit per leg); the
+        saturation flags (`get("ints")[8]`) still report everything cassie.xml would add."""
+        lib().orc_env_set_kernel_caps(self.h, int(bool(on)))
+        return self
 
     def set_const(self):
         lib().orc_env_set_const(self.h)

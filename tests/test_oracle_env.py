@@ -407,3 +407,63 @@ def test_g17_traj_env_reset_and_ref_state(golden_dir):
     e0 = S.OracleEnv(dyn_rand=True, seed=1, env_id=3)                                      # Cassie-v0 for contrast: the init pose
     e0.reset()
     assert abs(e0.get("qpos")[2] - 1.01) < 2e-3
+
+
+def _flags(e):
+    return int(e.get("ints")[8])
+
+
+def test_full_collision_set_of_cassie_xml():
+    """The oracle instantiates every constraint cassie.xml can produce (cassie.xml:18-35,87,101,119-144 + all limited joints), not only
+    what the HIP kernel keeps per leg: pelvis sphere and hip-pitch capsules against the floor, the 3 x 3 left-right capsule pairs
+    (condim 1), every active limit, every penetrating capsule end; `sat` says when a forward pass needed more than the kernel's caps."""
+    SAT_CONTACTS, SAT_LIMITS, SAT_BODY_FLOOR, SAT_LEG_LEG = 1, 2, 4, 8
+    # --- standing: nothing beyond the caps
+    e = S.OracleEnv(dyn_rand=False); e.reset()
+    for _ in range(3):
+        e.step(np.zeros(10))
+    assert _flags(e) == 0 and int(e.get("ints")[9]) == 0
+    # --- pelvis sphere (r = 0.15) pushed into the floor plane (z = -0.01): a pyramidal floor contact on body 1 that pushes the pelvis up
+    e = S.OracleEnv(dyn_rand=False)
+    q = e.get("qpos"); q[2] = 0.10
+    q[[9, 23]] = 1.3; q[[14, 28]] = -2.4                                   # fold the legs up so that the feet are not the deeper contact
+    e.set("qpos", q); e.phys_forward()
+    ints = e.get("ints")
+    assert _flags(e) & SAT_BODY_FLOOR
+    acc_with = e.get("qacc")[2]
+    q[2] = 0.30; e2 = S.OracleEnv(dyn_rand=False); e2.set("qpos", q); e2.phys_forward()      # same pose, sphere clear of the floor
+    assert acc_with > e2.get("qacc")[2] + 50.0                              # the sphere contact decelerates the fall strongly
+    nefc = int(ints[4]); f, ty = e.get("efc_force")[:nefc], e.get("efc_type")[:nefc]
+    assert (f[ty != 0] >= 0).all() and (ty == 2).sum() == 4 * int(ints[3])
+    # --- crossed legs: both hip rolls inward -> a left-right capsule pair penetrates; one frictionless row that pushes the legs apart
+    e = S.OracleEnv(dyn_rand=False)
+    q = e.get("qpos"); q[2] = 1.5; q[7] = -0.10; q[21] = 0.10
+    e.set("qpos", q); e.phys_forward()
+    ints = e.get("ints")
+    assert int(ints[9]) >= 1 and not (_flags(e) & SAT_LEG_LEG)               # up to 3 pairs are rows in the kernel too: not a saturation
+    nefc, n1 = int(ints[4]), int(ints[9])
+    f = e.get("efc_force")[:nefc]
+    assert (f[nefc - n1:] >= 0).all() and f[nefc - n1:].sum() > 10 and (e.get("efc_type")[nefc - n1:nefc] == 2).all()      # unilateral rows, placed last, pushing
+    qa = e.get("qacc")
+    q0 = e.get("qpos"); q0[7] = -0.08; q0[21] = 0.08
+    e3 = S.OracleEnv(dyn_rand=False); e3.set("qpos", q0); e3.phys_forward()
+    assert int(e3.get("ints")[9]) == 0 and not (_flags(e3) & SAT_LEG_LEG)
+    assert qa[6] - e3.get("qacc")[6] > 1.0 and e3.get("qacc")[19] - qa[19] > 1.0      # left roll accelerates outward (+), right roll outward (-)
+    q0[7] = -0.15; q0[21] = 0.15                                            # legs pushed through each other: 6 pairs, beyond the kernel's 3 rows
+    e4 = S.OracleEnv(dyn_rand=False); e4.set("qpos", q0); e4.phys_forward()
+    assert int(e4.get("ints")[9]) > 3 and _flags(e4) & SAT_LEG_LEG
+    # --- two limits of one leg at once (knee and foot beyond their ranges): two limit rows, flagged
+    e = S.OracleEnv(dyn_rand=False)
+    q = e.get("qpos"); q[2] = 1.5; q[14] = -2.9; q[20] = -2.5
+    e.set("qpos", q); e.phys_forward()
+    assert _flags(e) & SAT_LIMITS
+    nefc = int(e.get("ints")[4])
+    assert nefc >= 12 + 2
+    # --- more than two penetrating capsule ends on a leg (feet pressed 8 cm into the floor with the toes down): flagged, all instantiated
+    e = S.OracleEnv(dyn_rand=False)
+    q = e.get("qpos"); q[2] = 0.78
+    e.set("qpos", q); e.phys_forward()
+    ints = e.get("ints")
+    if int(ints[3]) > 4:
+        assert _flags(e) & SAT_CONTACTS
+    assert int(ints[4]) == 12 + 4 * int(ints[3]) + int(ints[9]) or (_flags(e) & SAT_LIMITS)
