@@ -762,9 +762,9 @@ __device__ __forceinline__ void setconst_rows_lane(const St& S) {
 
 // left-leg vs right-leg capsules (foot, tarsus, shin against foot, tarsus, shin: cassie.xml:23-35, condim 1, frictionless): lane 3 i + j
 // tests the pair (left geom i, right geom j) like mjc_CapsuleCapsule's general case (closest points of the two axes), records go to the
-// row scratch; every lane then counts the hits, and lane 13 + k takes the k-th penetrating pair as ITS constraint row (MAXX rows; more
+// row scratch; every lane then counts the hits, and lane 13 + k takes the k-th penetrating pair as ITS constraint row (MAXX = 2 rows; more
 // is reported through SAT_LEG_LEG).  Pair order = the oracle's (left geom outer, right geom inner).
-constexpr int MAXX = 3;
+constexpr int MAXX = 2;
 struct XPair { int nx; int gi, gj; V3 n, cp; float dist; };
 __device__ __forceinline__ XPair legleg_pairs_lane(const St& S, float* rec) {
     const int l = threadIdx.x & 15, li = l < 9 ? l / 3 : 0, rj = l < 9 ? l - 3 * (l / 3) : 0;
@@ -784,9 +784,15 @@ __device__ __forceinline__ XPair legleg_pairs_lane(const St& S, float* rec) {
         const float dist = len - rl - rr;
         const V3 nn = dv * rcpf(fmaxf(len, 1e-12f));                 // from the left geom to the right geom
         const V3 cp = c1 + nn * (rl + 0.5f * dist);
+        const bool hit = l < 9 && dist < 0.f && len > 1e-9f;
+        // wave-uniform early out: almost every substep has no penetrating pair in any of the wave's 4 envs
+        if (__builtin_amdgcn_ballot_w64(hit) == 0ull) {
+            XPair z; z.nx = 0; z.gi = 0; z.gj = 0; z.n = {0.f, 0.f, 0.f}; z.cp = {0.f, 0.f, 0.f}; z.dist = 0.f;
+            return z;
+        }
         if (l < 9) {
             float* p = rec + 8 * l;
-            p[0] = (dist < 0.f && len > 1e-9f) ? 1.f : 0.f; p[1] = dist; p[2] = nn.x; p[3] = nn.y; p[4] = nn.z; p[5] = cp.x; p[6] = cp.y; p[7] = cp.z;
+            p[0] = hit ? 1.f : 0.f; p[1] = dist; p[2] = nn.x; p[3] = nn.y; p[4] = nn.z; p[5] = cp.x; p[6] = cp.y; p[7] = cp.z;
         }
     }
     wsync();
@@ -1002,7 +1008,9 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     __builtin_amdgcn_sched_barrier(0);
     PROF(5);
     // ---- Gram columns of this lane's two rows
-    float GAA[16], GBB[16], GAB[16], GBA[16];      // GXY[s] = y~_(r,X) . y~_(s,Y); s = 13 + k: the halves (XL, XR) of leg-leg row k
+    float GAA[13], GBB[13], GAB[13], GBA[13];      // GXY[s] = y~_(r,X) . y~_(s,Y)
+    typedef float f2g __attribute__((ext_vector_type(2)));
+    f2g GX[MAXX];                                  // leg-leg row k = (XL | XR) on lane 13 + k: how its coefficient moves (rho_A, rho_B) of this lane
     {
         typedef float f2 __attribute__((ext_vector_type(2)));
         f2 JP[19];                                 // (left, right) row of this lane, packed for v_pk_fma_f32
@@ -1022,19 +1030,19 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
             asm volatile("" : "+v"(aa), "+v"(bb), "+v"(ab), "+v"(ba));
             GAA[s] = aa; GBB[s] = bb; GAB[s] = ab; GBA[s] = ba;
         });
-        sfor<13, 16>([&](auto Sx) { GAA[Sx] = GBB[Sx] = GAB[Sx] = GBA[Sx] = 0.f; });
-        if (anyx) sfor<13, 13 + MAXX>([&](auto Sx) {
-            constexpr int s = Sx;
-            f2 d = {0.f, 0.f}, x = {0.f, 0.f};
+        sfor<0, MAXX>([&](auto K) { GX[K] = f2g{0.f, 0.f}; });
+        if (anyx) sfor<0, MAXX>([&](auto K) {
+            constexpr int s = 13 + K;
+            f2 d = {0.f, 0.f};                      // (A_r . XL + A_r,pel . XR_pel, B_r . XR + B_r,pel . XL_pel)
             sfor<0, 19>([&](auto C) {
                 constexpr int c = C;
                 const f2 sv = {dpp<0x150 + s>(A.J[c]), dpp<0x150 + s>(B.J[c])};
                 d += JP[c] * sv;
-                if constexpr (c < 6) x += JP[c] * f2{sv.y, sv.x};
+                if constexpr (c < 6) d += JP[c] * f2{sv.y, sv.x};
             });
-            float aa = d.x, bb = d.y, ab = x.x, ba = x.y;
-            asm volatile("" : "+v"(aa), "+v"(bb), "+v"(ab), "+v"(ba));
-            GAA[s] = aa; GBB[s] = bb; GAB[s] = ab; GBA[s] = ba;
+            float aa = d.x, bb = d.y;
+            asm volatile("" : "+v"(aa), "+v"(bb));
+            GX[K] = f2g{aa, bb};
         });
     }
     // leg-leg row scalars to every lane
@@ -1082,7 +1090,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     float rA = 0.f, rB = 0.f, cost = 0.f;
     sfor<0, 13>([&](auto Sx) { rA += GAA[Sx] * FA[Sx] + GAB[Sx] * FB[Sx]; rB += GBA[Sx] * FA[Sx] + GBB[Sx] * FB[Sx]; });
     // a coefficient of leg-leg row k moves z~ by (XL | XR): rho_A by XL . A_r + XR_pel . A_r,pel, rho_B likewise
-    sfor<0, MAXX>([&](auto K) { constexpr int s = 13 + K; rA += (GAA[s] + GAB[s]) * xf[K]; rB += (GBB[s] + GBA[s]) * xf[K]; });
+    sfor<0, MAXX>([&](auto K) { rA += GX[K].x * xf[K]; rB += GX[K].y * xf[K]; });
     {
         float own = 0.f;       // F of this lane's own rows times rho
         sfor<0, 13>([&](auto Sx) { if (l == Sx) own = FA[Sx] * rA + FB[Sx] * rB; });
@@ -1110,7 +1118,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     f2 GpX[MAXX];                                           // how the coefficient of leg-leg row k moves (rho'_A, rho'_B); its regulariser rides on rho'_A of lane 13 + k
     sfor<0, MAXX>([&](auto K) {
         constexpr int s = 13 + K;
-        GpX[K] = f2{GAA[s] + GAB[s] + (l == s ? xR[K] : 0.f), GBB[s] + GBA[s]};
+        GpX[K] = f2{GX[K].x + (l == s ? xR[K] : 0.f), GX[K].y};
         r.x += l == s ? xR[K] * xf[K] : 0.f;
     });
     f2 Gp[2][13];                                           // how a coefficient of leg L's basis s moves (rho'_A, rho'_B)

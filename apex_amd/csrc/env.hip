@@ -29,7 +29,7 @@ __constant__ float kD[5] = {10.f, 10.f, 8.f, 9.6f, 5.f};
 __constant__ float kOffset[10] = {0.0045f, 0.0f, 0.4973f, -1.1997f, -1.5968f, 0.0045f, 0.0f, 0.4973f, -1.1997f, -1.5968f};
 __constant__ float kNeutralFoot[4] = {-0.24790886454547323f, -0.24679713195445646f, -0.6609396704367185f, 0.663921021343526f};
 __constant__ float kTorqueLimit[5] = {140.63f, 140.63f, 216.16f, 216.16f, 45.14f};
-__constant__ float kFir[9] = {2727.f, 534.f, -2658.f, -795.f, 72.f, 110.f, 19.f, -6.f, -3.f};
+constexpr float cFir[9] = {2727.f, 534.f, -2658.f, -795.f, 72.f, 110.f, 19.f, -6.f, -3.f};
 #define PI_F 3.14159265358979323846f
 
 __device__ __forceinline__ float* rows4() { return (float*)(apx_lds4 + ((threadIdx.x >> 4) * L4_ES + L4_ROWS) / 4); }
@@ -41,30 +41,39 @@ __device__ __forceinline__ float* rows4() { return (float*)(apx_lds4 + ((threadI
 // stage 1: encoders + estimator -> PD -> safeties -> motor model / delay: lanes 0..9 = the ten drives,
 // lanes 10..15 = the six joint encoders, lane 0 = estimator.  mode 0: forward pass only with zero ctrl (cassie_sim_set_const ends
 // in mj_forward)
+// per-drive model constants as selects on the drive index inside a leg (u5 = 0 roll, 1 yaw, 2 pitch, 3 knee, 4 foot) instead of table
+// loads: a lane-indexed table needs a 64-bit address per lane that the compiler keeps alive across all 50 substeps (2 VGPRs each)
+template <class T> __device__ __forceinline__ T sel5(int u5, T a0, T a1, T a2, T a3, T a4) { return u5 == 0 ? a0 : u5 == 1 ? a1 : u5 == 2 ? a2 : u5 == 3 ? a3 : a4; }
+static_assert(cmt::ct_act_gear[5] == cmt::ct_act_gear[0] && cmt::ct_act_gear[9] == cmt::ct_act_gear[4] && cmt::ct_act_bits[7] == cmt::ct_act_bits[2] &&
+              cmt::ct_act_rpm[8] == cmt::ct_act_rpm[3] && cmt::ct_act_ctrlmax[6] == cmt::ct_act_ctrlmax[1] && cmt::ct_act_dof[5] == cmt::ct_act_dof[0] + 13 &&
+              cmt::ct_act_dof[9] == cmt::ct_act_dof[4] + 13, "the two legs carry the same drives");
 __device__ __forceinline__ void stage1_io_lane(St S, int mode) {   // (as a called function the reset kernel faults: kept inline)
     PROF_START();
-    const int l = threadIdx.x & 15;
+    int l = threadIdx.x & 15;
+    asm volatile("" : "+v"(l));      // opaque: otherwise every per-lane constant below is hoisted out of the 50-substep loop and has to be
+                                     // kept (= spilled to scratch) across the constraint stage, which needs the whole register file
     if (mode == 0) { if (l < 10) S.W(c4::WK_CTRL + l) = 0.f; PROF(0); return; }
     const int flags = S.I(I_FLAGS);
     const bool mot = l < 10;
     const int u = mot ? l : 0, u5 = u >= 5 ? u - 5 : u, k = mot ? 0 : l - 10;
     float sdepth = 0.f, ssign = 1.f, tau_cmd = 0.f, mvel = 0.f, mpos_l = 0.f;
-    const float gear = cm_act_gear[u];
+    const float gear = sel5(u5, cmt::ct_act_gear[0], cmt::ct_act_gear[1], cmt::ct_act_gear[2], cmt::ct_act_gear[3], cmt::ct_act_gear[4]);
     if (mot) {
         // drive encoder: truncating quantiser + 9-tap FIR velocity
-        const float scale = 2.f * PI_F / (float)(1 << cm_act_bits[u]);
+        const float scale = 2.f * PI_F / (float)(1 << sel5(u5, cmt::ct_act_bits[0], cmt::ct_act_bits[1], cmt::ct_act_bits[2], cmt::ct_act_bits[3], cmt::ct_act_bits[4]));
         const float nq = truncf(S(F_SNAP + SN_MPOS + u) * gear / scale);
         float h[9];
         if (!(flags & 1)) { _Pragma("unroll") for (int i = 0; i < 9; ++i) h[i] = nq; }
         else { _Pragma("unroll") for (int i = 8; i > 0; --i) h[i] = S(F_MENC + u * 9 + i - 1); h[0] = nq; }
         float acc = 0.f;
-        _Pragma("unroll") for (int i = 0; i < 9; ++i) { S(F_MENC + u * 9 + i) = h[i]; acc += kFir[i] * h[i]; }
+        _Pragma("unroll") for (int i = 0; i < 9; ++i) { S(F_MENC + u * 9 + i) = h[i]; acc += cFir[i] * h[i]; }
         const float mpos = nq * scale / gear;
         mpos_l = mpos;
         mvel = acc * scale / gear / PI_F;
         S(F_SO + SO_MPOS + u) = mpos; S(F_SO + SO_MVEL + u) = mvel;
         // pd_input_step: tau = P (pTarget - q) + D (0 - qd), no clamp (G9); pd_in_t is zero until the first env.step
-        tau_cmd = (flags & 16) ? kP[u5] * (S(F_PDT + u) - mpos) + kD[u5] * (0.f - mvel) : 0.f;
+        const float kp = sel5(u5, 100.f, 100.f, 88.f, 96.f, 50.f), kd = sel5(u5, 10.f, 10.f, 8.f, 9.6f, 5.f);      // cassie.py:57-58
+        tau_cmd = (flags & 16) ? kp * (S(F_PDT + u) - mpos) + kd * (0.f - mvel) : 0.f;
         // cassie_core_sim_step (G10): soft joint-limit zones 0.15 rad inside the drive limits
         constexpr float DEG = PI_F / 180.f;
         const float lo_deg = u5 == 0 ? -15.f : u5 == 1 ? -22.f : u5 == 2 ? -50.f : u5 == 3 ? -156.f : -140.f;
@@ -90,10 +99,13 @@ __device__ __forceinline__ void stage1_io_lane(St S, int mode) {   // (as a call
         const float d = sdepth;
         float tau = sscale * tau_cmd + ssign * sKp * d * (1.f + d * (1.f / 0.15f)) - fminf(1.f, d * (1.f / 0.15f)) * sKd * mvel;
         tau += sKp * cdepth * (1.f + cdepth * (1.f / 0.15f)) - fminf(1.f, cdepth * (1.f / 0.15f)) * sKd * mvel;      // coupled zone (0 off the pitch / knee lanes)
-        tau = fminf(fmaxf(tau, -kTorqueLimit[u5]), kTorqueLimit[u5]);
+        const float tql = sel5(u5, 140.63f, 140.63f, 216.16f, 216.16f, 45.14f);
+        tau = fminf(fmaxf(tau, -tql), tql);
         // cassie_sim_step_ethercat: torque-speed curve, 6-deep delay line
-        const float wmax = cm_act_rpm[u] * 2.f * PI_F / 60.f, tmax = cm_act_ctrlmax[u];
-        const float om = fabsf(S(F_QVEL + cm_act_dof[u]) * gear);
+        const float wmax = sel5(u5, cmt::ct_act_rpm[0], cmt::ct_act_rpm[1], cmt::ct_act_rpm[2], cmt::ct_act_rpm[3], cmt::ct_act_rpm[4]) * 2.f * PI_F / 60.f;
+        const float tmax = sel5(u5, cmt::ct_act_ctrlmax[0], cmt::ct_act_ctrlmax[1], cmt::ct_act_ctrlmax[2], cmt::ct_act_ctrlmax[3], cmt::ct_act_ctrlmax[4]);
+        const int adof = sel5(u5, cmt::ct_act_dof[0], cmt::ct_act_dof[1], cmt::ct_act_dof[2], cmt::ct_act_dof[3], cmt::ct_act_dof[4]) + (u >= 5 ? 13 : 0);
+        const float om = fabsf(S(F_QVEL + adof) * gear);
         const float tlim = fminf(fmaxf(2.f * tmax * (1.f - om / wmax), 0.f), tmax);
         const float cmd = tau / gear;
         const float un = (cmd < 0.f ? -1.f : 1.f) * fminf(fabsf(cmd), tlim);
@@ -104,7 +116,8 @@ __device__ __forceinline__ void stage1_io_lane(St S, int mode) {   // (as a call
         S.W(c4::WK_CTRL + u) = fifo[5];
         S(F_SO + SO_TORQUE + u) = gear * fifo[5];
     } else {   // joint encoders: quantiser + biquad velocity
-        const float scale = 2.f * PI_F / (float)(1 << cm_jsens_bits[k]);
+        static_assert(cmt::ct_jsens_bits[0] == 18 && cmt::ct_jsens_bits[1] == 18 && cmt::ct_jsens_bits[2] == 13 && cmt::ct_jsens_bits[3] == 18 && cmt::ct_jsens_bits[4] == 18 && cmt::ct_jsens_bits[5] == 13, "joint encoder bits");
+        const float scale = 2.f * PI_F / (float)(1 << ((k == 2 || k == 5) ? 13 : 18));
         const float x = truncf(S(F_SNAP + SN_JPOS + k) / scale) * scale;
         float xs[4], y0, y1;
         if (!(flags & 2)) { xs[0] = xs[1] = xs[2] = xs[3] = x; y0 = y1 = 0.f; }
@@ -461,16 +474,16 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
                                                       float* reward, uint8_t* done, float* final_obs) {
     ENV_SETUP
     load_state(S, st, ist, n);
-    float act[10];
+    // nothing of the env-step bookkeeping stays in registers across the substeps (the constraint stage needs every one of the 512):
+    // the action is re-read at the end, the four per-substep accumulators live in spare hand-off words of the env's LDS region
+    constexpr int ACC = c4::WK_ZP2;                     // lfrc, rfrc, lor, ror
     if (lead) {
-        for (int u = 0; u < 10; ++u) {
-            act[u] = action[(size_t)env * APX_ACT_DIM + u];
-            S(F_PDT + u) = act[u] + kOffset[u] - (cfg.dyn_rand ? S(F_MNOISE + u) : 0.f);     // cassie.py:295-298
-        }
+        for (int u = 0; u < 10; ++u)
+            S(F_PDT + u) = action[(size_t)env * APX_ACT_DIM + u] + kOffset[u] - (cfg.dyn_rand ? S(F_MNOISE + u) : 0.f);     // cassie.py:295-298
         S.I(I_FLAGS) |= 16;
+        for (int k = 0; k < 4; ++k) S.W(ACC + k) = 0.f;
     }
     c4::wsync();
-    float lfrc = 0.f, rfrc = 0.f, lor = 0.f, ror = 0.f;
     for (int i = 0; i < cfg.simrate; ++i) {
         sim_step_pd(S, cfg.pgs_iters, 1);                                        // all lanes (barriers inside)
         if (!lead) continue;
@@ -479,14 +492,16 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
             S(F_FOOTVEL + k) = (fp - S(F_FOOTPREV + k)) / 0.0005f;
             S(F_FOOTPREV + k) = fp;
         }
-        lfrc += S(F_FWD + 0); rfrc += S(F_FWD + 1);                               // cassie.py:418-420
+        S.W(ACC + 0) += S(F_FWD + 0); S.W(ACC + 1) += S(F_FWD + 1);               // cassie.py:418-420
         float il = 0.f, ir = 0.f;
         for (int k = 0; k < 4; ++k) { il += kNeutralFoot[k] * S(F_FWD + 2 + k); ir += kNeutralFoot[k] * S(F_FWD + 6 + k); }
-        lor += 1.f - il * il; ror += 1.f - ir * ir;                               // cassie.py:426-427
+        S.W(ACC + 2) += 1.f - il * il; S.W(ACC + 3) += 1.f - ir * ir;             // cassie.py:426-427
     }
     if (lead) {
+        float act[10];
+        for (int u = 0; u < 10; ++u) act[u] = action[(size_t)env * APX_ACT_DIM + u];
         const float inv = 1.f / (float)cfg.simrate;
-        lfrc *= inv; rfrc *= inv; lor *= inv; ror *= inv;
+        const float lfrc = S.W(ACC + 0) * inv, rfrc = S.W(ACC + 1) * inv, lor = S.W(ACC + 2) * inv, ror = S.W(ACC + 3) * inv;
         const float height = S(F_QPOS + 2);
         int time = S.I(I_TIME) + 1, phase = S.I(I_PHASE) + 1;
         if ((float)phase > S(F_CMD + 5)) { phase = 0; S.I(I_COUNTER) += 1; }
