@@ -94,11 +94,16 @@ def eval_main(argv):
     p.add_argument("--max_traj_len", type=int, default=400)
     p.add_argument("--reward", type=str, default="clock")
     p.add_argument("--basic", action="store_true", help="CassieEnv.step_basic: fixed command, survival time only")
+    p.add_argument("--terrain", default=None, type=str, help="height-field file (.npy, 500 x 500 like cassie/cassiemujoco/terrains/*.npy): reference apex.py:265, util/eval.py:73-76")
     a = p.parse_args(argv)
     from apex_amd.vecenv import CassieVecEnv
     from apex_amd.engine import Mlp
     from apex_amd.eval import evaluate
     env = CassieVecEnv(n_envs=a.n_envs, reward=a.reward, max_traj_len=a.max_traj_len, dynamics_randomization=False)
+    if a.terrain is not None and ".npy" in a.terrain:            # env.sim = CassieSim("cassie_hfield.xml"); sim.set_hfield_data(np.load(terrain).flatten())
+        import numpy as np
+        path = a.terrain if os.path.exists(a.terrain) else os.path.join("./cassie/cassiemujoco/terrains/", a.terrain)
+        env.set_hfield(np.load(path), size=(50.0, 50.0, 0.15))  # cassie_hfield.xml:69
     actor, mean, std = _load_actor(a.path, env.device)
     out = evaluate(actor, env, mean, std, speed=a.speed, side_speed=a.side_speed, max_steps=a.max_traj_len, basic=a.basic)
     ln, rt = out["lengths"].cpu(), out["returns"].cpu()

@@ -33,7 +33,7 @@ class EnvCfg(C.Structure):
     _fields_ = [
         ("n_envs", C.c_int), ("simrate", C.c_int), ("dynamics_randomization", C.c_int), ("reward_kind", C.c_int),
         ("stance_mode", C.c_int), ("have_incentive", C.c_int), ("max_traj_len", C.c_int),
-        ("seed", C.c_uint64), ("device", C.c_int), ("pgs_iters", C.c_int), ("env_id_base", C.c_int), ("env_kind", C.c_int), ("reserved", C.c_int * 5),
+        ("seed", C.c_uint64), ("device", C.c_int), ("pgs_iters", C.c_int), ("env_id_base", C.c_int), ("env_kind", C.c_int), ("command_profile", C.c_int), ("reserved", C.c_int * 4),
     ]
 
 
@@ -67,6 +67,7 @@ SIGNATURES = {
     "apx_env_default_cfg": (None, [C.POINTER(EnvCfg)]),
     "apx_env_create": (C.c_int, [C.POINTER(EnvCfg), C.POINTER(c_ptr)]),
     "apx_env_destroy": (C.c_int, [c_ptr]),
+    "apx_env_set_hfield": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, c_ptr]),
     "apx_env_reset": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
     "apx_env_update_speed": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
     "apx_env_reset_for_test": (C.c_int, [c_ptr, c_ptr, C.c_int, c_ptr]),

@@ -626,13 +626,13 @@ __device__ __forceinline__ void stage_finish_lane(const St& S, const float* rows
         }
         {   // world z of the contact force on the foot bodies (cassie_sim_foot_forces -> get_foot_forces()[2], [8])
             const int nc[2] = {(int)S.W(WK_MISC + 0), (int)S.W(WK_MISC + 1)};
-            const float mu = S(F_FRIC), nz = S(F_FLOOR + 2), t1z = S(F_FLOOR + 5), t2z = S(F_FLOOR + 8);
+            const float mu = S(F_FRIC);
             float fz[2] = {0.f, 0.f};
             sfor<0, 2 * MAXC>([&](auto Sl) {
                 constexpr int sl = Sl, lg = sl / MAXC;
                 const float* cr = rows + R4_CON + R4_CONSZ * sl;
-                if ((sl % MAXC) < nc[lg] && cr[7] != 0.f)
-                    fz[lg] += nz * (cr[12] + cr[13] + cr[14] + cr[15]) + mu * (t1z * (cr[12] - cr[13]) + t2z * (cr[14] - cr[15]));
+                if ((sl % MAXC) < nc[lg] && cr[7] != 0.f)      // cr[8..10] = world z of the slot's contact frame (n, t1, t2)
+                    fz[lg] += cr[8] * (cr[12] + cr[13] + cr[14] + cr[15]) + mu * (cr[9] * (cr[12] - cr[13]) + cr[10] * (cr[14] - cr[15]));
             });
             S(F_FWD + 0) = fz[0]; S(F_FWD + 1) = fz[1];
         }
@@ -764,9 +764,35 @@ __device__ __forceinline__ void setconst_rows_lane(const St& S) {
 // tests the pair (left geom i, right geom j) like mjc_CapsuleCapsule's general case (closest points of the two axes), records go to the
 // row scratch; every lane then counts the hits, and lane 13 + k takes the k-th penetrating pair as ITS constraint row (MAXX = 2 rows; more
 // is reported through SAT_LEG_LEG).  Pair order = the oracle's (left geom outer, right geom inner).
+// surface under a point: signed distance of a sphere (centre c, radius rad) to the floor plane (n = fn) or, with a height field, to the
+// plane of the grid triangle under it ((00, 10, 01) / (11, 01, 10) split of a cell, as in the oracle's floor_query); n = that surface normal
+template <bool HF>
+__device__ __forceinline__ float floor_dist_dev(const Hf& hf, V3 fn, V3 c, float rad, V3& n) {
+    if constexpr (!HF) { n = fn; return dot(c - V3{ct_floor_pos[0], ct_floor_pos[1], ct_floor_pos[2]}, fn) - rad; }
+    else {
+    const float dx = 2.f * hf.sx / (float)(hf.ncol - 1), dy = 2.f * hf.sy / (float)(hf.nrow - 1);
+    const float u = fminf(fmaxf((c.x + hf.sx) / dx, 0.f), (float)(hf.ncol - 1) - 1e-4f), v = fminf(fmaxf((c.y + hf.sy) / dy, 0.f), (float)(hf.nrow - 1) - 1e-4f);
+    const int ci = (int)u, ri = (int)v;
+    const float fu = u - (float)ci, fv = v - (float)ri;
+    const float* q = hf.data + (size_t)ri * hf.ncol + ci;
+    const float h00 = hf.sz * q[0], h10 = hf.sz * q[1], h01 = hf.sz * q[hf.ncol], h11 = hf.sz * q[hf.ncol + 1];
+    const bool lo = fu + fv <= 1.f;
+    const float gx = (lo ? h10 - h00 : h11 - h01) / dx, gy = (lo ? h01 - h00 : h11 - h10) / dy;
+    const float hh = lo ? h00 + fu * (h10 - h00) + fv * (h01 - h00) : h11 + (1.f - fu) * (h01 - h11) + (1.f - fv) * (h10 - h11);
+    const float inv = rsqrtf(gx * gx + gy * gy + 1.f);
+    n = {-gx * inv, -gy * inv, inv};
+    return (c.z - hh) * inv - rad;
+    }
+}
 constexpr int MAXX = 2;
-struct XPair { int nx; int gi, gj; V3 n, cp; float dist; };
-__device__ __forceinline__ XPair legleg_pairs_lane(const St& S, float* rec) {
+struct XPair { int gi, gj; V3 n, cp; float dist; };
+constexpr int XSEL = 80, XSEL_SZ = 12;                    // compacted records of the MAXX selected pairs behind the 9 pair records (floats in the row scratch)
+// the selected pair of lane 13 + k (k < nx), re-read where it is needed instead of being carried in registers through the row stage
+__device__ __forceinline__ XPair xpair_load(const float* rec, int l) {
+    const float* q = rec + XSEL + XSEL_SZ * (l >= 13 && l < 13 + MAXX ? l - 13 : 0);
+    return XPair{(int)q[8], (int)q[9], {q[2], q[3], q[4]}, {q[5], q[6], q[7]}, q[1]};
+}
+__device__ __forceinline__ int legleg_pairs_lane(const St& S, float* rec) {
     const int l = threadIdx.x & 15, li = l < 9 ? l / 3 : 0, rj = l < 9 ? l - 3 * (l / 3) : 0;
     {
         const lfloat* pl = &S.W(WK_PTS + 12 + 6 * li); const lfloat* pr = &S.W(WK_PTS + 30 + 12 + 6 * rj);
@@ -786,26 +812,29 @@ __device__ __forceinline__ XPair legleg_pairs_lane(const St& S, float* rec) {
         const V3 cp = c1 + nn * (rl + 0.5f * dist);
         const bool hit = l < 9 && dist < 0.f && len > 1e-9f;
         // wave-uniform early out: almost every substep has no penetrating pair in any of the wave's 4 envs
-        if (__builtin_amdgcn_ballot_w64(hit) == 0ull) {
-            XPair z; z.nx = 0; z.gi = 0; z.gj = 0; z.n = {0.f, 0.f, 0.f}; z.cp = {0.f, 0.f, 0.f}; z.dist = 0.f;
-            return z;
-        }
+        if (__builtin_amdgcn_ballot_w64(hit) == 0ull) return 0;
         if (l < 9) {
             float* p = rec + 8 * l;
             p[0] = hit ? 1.f : 0.f; p[1] = dist; p[2] = nn.x; p[3] = nn.y; p[4] = nn.z; p[5] = cp.x; p[6] = cp.y; p[7] = cp.z;
         }
     }
     wsync();
-    XPair x; x.nx = 0; x.gi = 0; x.gj = 0; x.n = {0.f, 0.f, 0.f}; x.cp = {0.f, 0.f, 0.f}; x.dist = 0.f;
+    XPair x; x.gi = 0; x.gj = 0; x.n = {0.f, 0.f, 0.f}; x.cp = {0.f, 0.f, 0.f}; x.dist = 0.f;
+    int nx = 0;
     const int k = l - 13;
     sfor<0, 9>([&](auto P) {
         constexpr int p = P;
         const float* q = rec + 8 * p;
         const bool h = q[0] != 0.f;
-        if (h && x.nx == k) { x.gi = p / 3; x.gj = p % 3; x.dist = q[1]; x.n = {q[2], q[3], q[4]}; x.cp = {q[5], q[6], q[7]}; }
-        x.nx += h ? 1 : 0;
+        if (h && nx == k) { x.gi = p / 3; x.gj = p % 3; x.dist = q[1]; x.n = {q[2], q[3], q[4]}; x.cp = {q[5], q[6], q[7]}; }
+        nx += h ? 1 : 0;
     });
-    return x;
+    if (k >= 0 && k < MAXX) {
+        float* q = rec + XSEL + XSEL_SZ * k;
+        q[1] = x.dist; q[2] = x.n.x; q[3] = x.n.y; q[4] = x.n.z; q[5] = x.cp.x; q[6] = x.cp.y; q[7] = x.cp.z; q[8] = (float)x.gi; q[9] = (float)x.gj;
+    }
+    wsync();
+    return nx;
 }
 
 // Constraint rows of leg LEG, one row vector per lane: Jacobian from the stored motion axes, dots against
@@ -819,9 +848,10 @@ struct LegRows {
     int nc, nlim;                // uniform over the env's lanes from here on
     int over;                    // SAT_LIMITS / SAT_CONTACTS: more active limits / penetrating capsule ends than the lane map has slots for
     float cG[MAXC][6], cR[MAXC], cb[MAXC][4], cf[MAXC][4], isfoot[MAXC];
+    float cfz[MAXC][3];          // world z of the contact frame (n, t1, t2) of each slot: the foot-force readout (cassie_sim_foot_forces)
 };
-template <int LEG>
-__device__ __forceinline__ void rows_lane(const St& S, LegRows& out, const XPair& xp) {
+template <int LEG, bool HF>
+__device__ __forceinline__ void rows_lane(const St& S, LegRows& out, int nxp, bool anyx, const float* rec, const Hf& hf) {
     const int l = threadIdx.x & 15;
     const V3 o = {S(F_QPOS), S(F_QPOS + 1), S(F_QPOS + 2)};
     const V3 fn = {S(F_FLOOR), S(F_FLOOR + 1), S(F_FLOOR + 2)}, ft1 = {S(F_FLOOR + 3), S(F_FLOOR + 4), S(F_FLOOR + 5)},
@@ -848,17 +878,18 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out, const XPair
     const V3 p0 = {ct_floor_pos[0], ct_floor_pos[1], ct_floor_pos[2]};
     int nc = 0;
     static_assert(MAXC == 2, "two contact slots per leg");
-    V3 cpt0 = {0.f, 0.f, 0.f}, cpt1 = {0.f, 0.f, 0.f}; float cdist[MAXC]; int cgeo[MAXC];
+    V3 cpt0 = {0.f, 0.f, 0.f}, cpt1 = {0.f, 0.f, 0.f}, cn0 = fn, cn1 = fn; float cdist[MAXC]; int cgeo[MAXC];
     sfor<0, MAXC>([&](auto Sl) { cdist[Sl] = 0.f; cgeo[Sl] = 0; });
     sfor<0, 6>([&](auto I) {
         constexpr int G = I / 2;
         const V3 ctr = ldv3<base + 12 + 3 * I>(S);
-        const float dist = dot(ctr - p0, fn) - ct_geom_radius[2 * G + LEG];
+        V3 sn;
+        const float dist = floor_dist_dev<HF>(hf, fn, ctr, ct_geom_radius[2 * G + LEG], sn);
         const bool hit = dist < 0.f && nc < MAXC;
         over |= (dist < 0.f && nc >= MAXC) ? SAT_CONTACTS : 0;
-        const V3 cp = ctr - fn * (ct_geom_radius[2 * G + LEG] + 0.5f * dist);
-        if (hit && nc == 0) cpt0 = cp;
-        if (hit && nc == 1) cpt1 = cp;
+        const V3 cp = ctr - sn * (ct_geom_radius[2 * G + LEG] + 0.5f * dist);
+        if (hit && nc == 0) { cpt0 = cp; cn0 = sn; }
+        if (hit && nc == 1) { cpt1 = cp; cn1 = sn; }
         sfor<0, MAXC>([&](auto Sl) { if (hit && nc == Sl) { cdist[Sl] = dist; cgeo[Sl] = G; } });
         nc += hit ? 1 : 0;
     });
@@ -872,7 +903,9 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out, const XPair
     constexpr unsigned mFT = chain_mask<LEG>(13 + 12 * LEG);
     // leg-leg row of lane 13 + k: this leg's half of n . (J_right(cp) - J_left(cp)); the pelvis columns cancel between the halves exactly
     // (both bodies hang off the pelvis) and are left out of both
-    const bool isX = l >= 13 && (l - 13) < xp.nx && (l - 13) < MAXX;
+    XPair xp = {0, 0, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, 0.f};
+    if (anyx) xp = xpair_load(rec, l);                   // wave-uniform: some env of the wave has a leg-leg contact
+    const bool isX = l >= 13 && (l - 13) < nxp && (l - 13) < MAXX;
     const int G = isX ? (LEG == 0 ? xp.gi : xp.gj) : (cs ? cgeo[1] : cgeo[0]);
     const unsigned mcon = mFT & ~(G >= 1 ? (1u << 18) : 0u) & ~(G >= 2 ? (1u << 14) : 0u);   // tarsus / shin contact: dofs below do not move the point
     const unsigned m1 = isEq ? (E ? mAC1 : mPL1) : isCon ? mcon : isX ? (mcon & ~0x3Fu) : 0u, m2 = isEq ? (E ? mAC2 : mPL2) : 0u;
@@ -887,8 +920,16 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out, const XPair
     {
         // scalar selects only: `isEq ? de : dc` on two V3 temporaries becomes a load through a selected POINTER, which keeps both
         // temporaries in scratch (6 stores + 3 loads per leg per substep = 8x the algorithmic HBM traffic of the whole kernel)
-        const float dcx = ax == 0 ? fn.x : ax == 1 ? ft1.x : ft2.x, dcy = ax == 0 ? fn.y : ax == 1 ? ft1.y : ft2.y,
-                    dcz = ax == 0 ? fn.z : ax == 1 ? ft1.z : ft2.z;
+        // contact frame of this lane's slot: the floor frame, or (height field) mju_makeFrame of the triangle normal
+        V3 cn = fn, c1 = ft1, c2 = ft2;
+        if constexpr (HF) {
+            cn = {cs ? cn1.x : cn0.x, cs ? cn1.y : cn0.y, cs ? cn1.z : cn0.z};
+            const bool uy = fabsf(cn.y) < 0.5f;
+            V3 t = {0.f, uy ? 1.f : 0.f, uy ? 0.f : 1.f};
+            t = t - cn * dot(cn, t); c1 = t * rsqrtf(dot(t, t)); c2 = cross(cn, c1);
+        }
+        const float dcx = ax == 0 ? cn.x : ax == 1 ? c1.x : c2.x, dcy = ax == 0 ? cn.y : ax == 1 ? c1.y : c2.y,
+                    dcz = ax == 0 ? cn.z : ax == 1 ? c1.z : c2.z;
         dir = {isEq ? (ax == 0 ? 1.f : 0.f) : dcx, isEq ? (ax == 1 ? 1.f : 0.f) : dcy, isEq ? (ax == 2 ? 1.f : 0.f) : dcz};
         constexpr float sx = LEG == 0 ? -1.f : 1.f;
         if (isX) dir = {sx * xp.n.x, sx * xp.n.y, sx * xp.n.z};
@@ -966,6 +1007,16 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out, const XPair
         });
     });
     out.nc = nc; out.nlim = nlim; out.over = over;
+    sfor<0, MAXC>([&](auto Sl) {
+        V3 cn = fn, c1 = ft1, c2 = ft2;
+        if constexpr (HF) {
+            cn = Sl ? cn1 : cn0;
+            const bool uy = fabsf(cn.y) < 0.5f;
+            V3 t = {0.f, uy ? 1.f : 0.f, uy ? 0.f : 1.f};
+            t = t - cn * dot(cn, t); c1 = t * rsqrtf(dot(t, t)); c2 = cross(cn, c1);
+        }
+        out.cfz[Sl][0] = cn.z; out.cfz[Sl][1] = c1.z; out.cfz[Sl][2] = c2.z;
+    });
 }
 
 // Projected Gauss-Seidel in GRAM SPACE.  Lane r (0..12) owns basis vector r of both legs (A = left, B = right): 6 connect
@@ -974,21 +1025,36 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out, const XPair
 // (19-term fma with a DPP row broadcast operand; the two legs only meet in the 6 pelvis columns).  A row update is then
 // broadcast + scalar update + 2 fma: no cross-lane reduction inside the 50 sweeps.  Order is leg-major as before (left: 6
 // equality rows, limit, contacts; then right), a pyramidal contact sweeps its 4 rows through the 3x3 Gram block.
-__device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, int pgs_iters) {
+template <bool HF>
+__device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, int pgs_iters, const Hf& hf) {
     const int l = threadIdx.x & 15;
     const float mu = S(F_FRIC);
     LegRows A, B;
-    const XPair xp = legleg_pairs_lane(S, rows);
-    rows_lane<0>(S, A, xp);
+    const int nxp = legleg_pairs_lane(S, rows);
+    const bool anyx = __builtin_amdgcn_ballot_w64(nxp > 0) != 0ull;          // wave-uniform: some env of the wave has a leg-leg contact
+    rows_lane<0, HF>(S, A, nxp, anyx, rows, hf);
     PROF2(23);
-    rows_lane<1>(S, B, xp);
+    rows_lane<1, HF>(S, B, nxp, anyx, rows, hf);
     PROF2(24);
+    // bookkeeping that must not stay live across the sweeps: saturation report, contact / limit counts, and the contact slot records for
+    // the foot-force readout of the finish stage (foot flag, world z of the slot's frame)
+    if (l == 0) {
+        const int sat = A.over | B.over | ((S.W(WK_MISC + 4) + S.W(WK_MISC + 5) > 0.f) ? SAT_BODY_FLOOR : 0) | (nxp > MAXX ? SAT_LEG_LEG : 0);
+        if (sat) S.I(I_SAT) = (S.I(I_SAT) | sat) + 256;
+        S.W(WK_MISC + 0) = (float)A.nc; S.W(WK_MISC + 1) = (float)B.nc; S.W(WK_MISC + 2) = (float)A.nlim; S.W(WK_MISC + 3) = (float)B.nlim;
+    }
+    if (l == 0) sfor<0, 2 * MAXC>([&](auto Sl) {
+        constexpr int s = Sl, leg = s / MAXC, j = s % MAXC;
+        float* cr = rows + R4_CON + R4_CONSZ * s;
+        cr[7] = (leg ? B : A).isfoot[j];
+        sfor<0, 3>([&](auto K) { cr[8 + K] = (leg ? B : A).cfz[j][K]; });
+    });
     // ---- leg-leg rows (lanes 13 + k): scalars from the two halves.  Row = (XL | XR) with XL = A.J, XR = B.J on that lane; its pelvis
     // part is the SUM of the two whitened pelvis parts, so |y~|^2 = |XL|^2 + |XR|^2 + 2 XL_pel . XR_pel
-    const int nx = xp.nx < MAXX ? xp.nx : MAXX;
-    const bool anyx = __builtin_amdgcn_ballot_w64(xp.nx > 0) != 0ull;         // wave-uniform: some env of the wave has a leg-leg contact
+    const int nx = nxp < MAXX ? nxp : MAXX;
     float xb_l = 0.f, xR_l = 1.f, xiA_l = 0.f, xf_l = 0.f;
     if (anyx) {
+        const XPair xp = xpair_load(rows, l);
         float pp = 0.f;
         sfor<0, 6>([&](auto C) { pp += A.J[C] * B.J[C]; });
         const float nnx = A.nn + B.nn + 2.f * pp;
@@ -1214,14 +1280,10 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
         else { const float za = red16(A.J[c] * ownA), zb = red16(B.J[c] * ownB); if (l == 0) { S.W(WK_ZT + c) = za; S.W(WK_ZT + c + 13) = zb; } }
     });
     if (l == 0) {
-        const int sat = A.over | B.over | ((S.W(WK_MISC + 4) + S.W(WK_MISC + 5) > 0.f) ? SAT_BODY_FLOOR : 0) | (xp.nx > MAXX ? SAT_LEG_LEG : 0);
-        if (sat) S.I(I_SAT) = (S.I(I_SAT) | sat) + 256;
-        S.W(WK_MISC + 0) = (float)A.nc; S.W(WK_MISC + 1) = (float)B.nc; S.W(WK_MISC + 2) = (float)A.nlim; S.W(WK_MISC + 3) = (float)B.nlim;
         // contact forces to the row store (foot-force readout in the finish stage)
         sfor<0, NCS>([&](auto Sl) {
             constexpr int s = Sl, leg = s / MAXC, j = s % MAXC;
             float* cr = rows + R4_CON + R4_CONSZ * s;
-            cr[7] = (leg ? B : A).isfoot[j];
             sfor<0, 4>([&](auto K) { cr[12 + K] = cf[s][K]; });
         });
     }

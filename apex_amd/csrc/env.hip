@@ -152,9 +152,10 @@ __device__ APX_STAGE void stage2a_factor(St S) {
     c4::stage_factor_lane(S);
     PROF(2);
 }
-__device__ __forceinline__ void stage3_rows_pgs_lane(St S, int pgs_iters) {
+template <bool HF>
+__device__ __forceinline__ void stage3_rows_pgs_lane(St S, const Cfg& cfg) {
     PROF_START();
-    c4::stage_rows_pgs_lane(S, rows4(), pgs_iters);
+    c4::stage_rows_pgs_lane<HF>(S, rows4(), cfg.pgs_iters, cfg.hf);
     PROF(3);
 }
 // inlined like the rows / PGS stage: as a function it needs 36 callee-saved VGPRs, i.e. 36 scratch stores + 36 loads per lane per
@@ -175,7 +176,8 @@ __device__ __forceinline__ void setconst_lane(const St& S) {
     c4::wsync();
 }
 // one 2 kHz substep (cassie_sim_step_pd): the wave holds 4 envs, one per 16-lane row; every call site is reached by all lanes
-__device__ __forceinline__ void sim_step_pd(const St& S, int pgs_iters, int mode) {
+template <bool HF>
+__device__ __forceinline__ void sim_step_pd(const St& S, const Cfg& cfg, int mode) {
 #ifdef APX_PROF
     const unsigned long long t0__ = clock64();
 #endif
@@ -185,7 +187,7 @@ __device__ __forceinline__ void sim_step_pd(const St& S, int pgs_iters, int mode
     c4::wsync();
     stage2a_factor(S);
     c4::wsync();
-    stage3_rows_pgs_lane(S, pgs_iters);
+    stage3_rows_pgs_lane<HF>(S, cfg);
     c4::wsync();
     stage4_finish(S, mode);
     c4::wsync();
@@ -271,7 +273,12 @@ __device__ void write_obs(const St& S, const Cfg& cfg, float* o) {
     for (int k = 0; k < 6; ++k) o[40 + k] = S(F_SO + SO_JVEL + k);
     const float ang = 2.f * PI_F * (float)S.I(I_PHASE) / S(F_CMD + 5);
     o[46] = sinf(ang); o[47] = cosf(ang);
-    o[48] = S(F_CMD + 0); o[49] = S(F_CMD + 1);
+    if (cfg.command_profile == 0) { o[48] = S(F_CMD + 0); o[49] = S(F_CMD + 1); return; }
+    // command_profile "phase" (cassie.py:805-808): clock, swing / stance duration, one-hot stance mode (grounded, aerial, zero), speed, side speed
+    const int sm = (int)S(F_CMD + 6);
+    o[48] = S(F_CMD + 3); o[49] = S(F_CMD + 4);
+    o[50] = sm == 1 ? 1.f : 0.f; o[51] = sm == 2 ? 1.f : 0.f; o[52] = sm == 0 ? 1.f : 0.f;
+    o[53] = S(F_CMD + 0); o[54] = S(F_CMD + 1);
 }
 
 __device__ __forceinline__ void clock_from_speed(const St& S, float speed, int freq) {   // cassie.py:556-559
@@ -300,7 +307,18 @@ __device__ void env_reset_draws(const St& S, const Cfg& cfg) {
     const float speed0 = cfg.env_kind == 1 ? (float)r.randint(41u) / 10.f : r.uniform(-0.3f, 4.0f);      // cassie_traj.py:608: random.randint(0, 40) / 10
     (void)r.uniform(-0.3f, 0.3f);
     S(F_CMD) = speed0;                                   // kept for the trajectory-pose reset; replaced by the command redraw after the settle step
-    clock_from_speed(S, speed0, 2000 / cfg.simrate);
+    if (cfg.command_profile == 0) { clock_from_speed(S, speed0, 2000 / cfg.simrate); S(F_CMD + 6) = (float)cfg.stance_mode; }
+    else {      // command_profile "phase" (cassie.py:529-545): swing / stance duration and stance mode drawn per episode
+        float swing, stance;
+        if (cfg.command_profile == 2) {                  // "library" reward variant (:531-539)
+            S(F_CMD) = (float)r.randint(31u) / 10.f;
+            const float total = (float)(3u + r.randint(4u)) / 10.f, ratio = (float)(2u + r.randint(7u)) / 10.f;
+            swing = total * ratio; stance = total - swing;
+        } else { swing = (float)(1u + r.randint(50u)) / 100.f; stance = (float)(1u + r.randint(30u)) / 100.f; }
+        const unsigned pick = r.randint(3u);             // np.random.choice(["grounded", "aerial", "zero"])
+        S(F_CMD + 3) = swing; S(F_CMD + 4) = stance; S(F_CMD + 5) = (2.f * swing + 2.f * stance) * (float)(2000 / cfg.simrate);
+        S(F_CMD + 6) = pick == 0u ? 1.f : pick == 1u ? 2.f : 0.f;
+    }
     S.I(I_PHASE) = (int)r.randint((unsigned)floorf(S(F_CMD + 5)) + 1u);
     S.I(I_TIME) = 0; S.I(I_COUNTER) = 0;
     if (cfg.dyn_rand) {
@@ -345,18 +363,19 @@ __device__ void env_reset_finish(const St& S, const Cfg& cfg) {
     S.I(I_RNG) = (int)r.ctr;
 }
 // CassieEnv.reset (cassie/cassie.py:523-680); called by all 16 lanes of the env's row
+template <bool HF>
 __device__ __forceinline__ void env_reset(const St& S, const Cfg& cfg) {
     const bool lead = (threadIdx.x & 15) == 0;
     if (lead) env_reset_draws(S, cfg);
     c4::wsync();
     if (cfg.dyn_rand) setconst_lane(S);               // sim.set_const -> mj_setConst
 
-    sim_step_pd(S, cfg.pgs_iters, 0);               // cassie_sim_set_const ends in mj_forward
+    sim_step_pd<HF>(S, cfg, 0);               // cassie_sim_set_const ends in mj_forward
     if (cfg.env_kind == 1) {                          // CassieTrajEnv.reset: set_qpos / set_qvel with the reference state of the start phase
         if (lead) traj_pose(S, (float)S.I(I_PHASE), S(F_CMD + 5), S(F_CMD), 0);      // (cassie_traj.py:752-758); no mj_forward follows, so the
         c4::wsync();                                  // settle step below still reads the init-pose sensor snapshot, like the reference
     }
-    sim_step_pd(S, cfg.pgs_iters, 1);               // cassie.py:665 (stale pd_in_t)
+    sim_step_pd<HF>(S, cfg, 1);               // cassie.py:665 (stale pd_in_t)
     if (lead) env_reset_finish(S, cfg);
     c4::wsync();
 }
@@ -381,8 +400,9 @@ __device__ float clock_reward(const St& S, const Cfg& cfg, const float* action, 
     ClockK ck;
     clock_knots(S(F_CMD + 3), S(F_CMD + 4), 2000 / cfg.simrate, ck);
     const float ph = (float)S.I(I_PHASE);
-    const float lfc = clock_eval(ck, 0, ph, cfg.stance_mode, cfg.incentive), lvc = clock_eval(ck, 1, ph, cfg.stance_mode, cfg.incentive);
-    const float rfc = clock_eval(ck, 2, ph, cfg.stance_mode, cfg.incentive), rvc = clock_eval(ck, 3, ph, cfg.stance_mode, cfg.incentive);
+    const int smode = (int)S(F_CMD + 6);                  // per env: the phase command profile draws it at every reset
+    const float lfc = clock_eval(ck, 0, ph, smode, cfg.incentive), lvc = clock_eval(ck, 1, ph, smode, cfg.incentive);
+    const float rfc = clock_eval(ck, 2, ph, smode, cfg.incentive), rvc = clock_eval(ck, 3, ph, smode, cfg.incentive);
     if (cfg.reward_kind == 2) {   // max_vel_clock_reward (clock_rewards.py:416-480): caps 400 N / 3 m/s, tanh terms, forward-velocity bonus
         const float mlf = fminf(lfrc, 400.f) / 400.f, mrf = fminf(rfrc, 400.f) / 400.f;
         const float mlv = fminf(sqrtf(lv), 3.f) / 3.f, mrv = fminf(sqrtf(rv), 3.f) / 3.f;
@@ -449,7 +469,7 @@ __global__ __launch_bounds__(64) void env_init_kernel(float* st, int* ist, int n
     for (int i = 0; i < NQ; ++i) G(F_QPOS + i) = cm_init_qpos[i];
     for (int b = 0; b < NB; ++b) G(F_MASS + b) = cm_body_mass[b];
     for (int d = 0; d < NV; ++d) G(F_DAMP + d) = cm_dof_damping[d];
-    G(F_FRIC) = 1.f;
+    G(F_FRIC) = 1.f; G(F_CMD + 6) = (float)cfg.stance_mode;
     const float fl[9] = {0, 0, 1, 0, 1, 0, -1, 0, 0};     // n = z, t1 = y, t2 = n x t1 = -x
     for (int k = 0; k < 9; ++k) G(F_FLOOR + k) = fl[k];
 }
@@ -461,15 +481,17 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_setconst_kernel(floa
     store_state(S, st, ist, n);
 }
 
+template <bool HF>
 __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const uint8_t* mask, float* obs) {
     ENV_SETUP
     if (mask && !mask[env]) return;
     load_state(S, st, ist, n);
-    env_reset(S, cfg);
-    if (obs && lead) write_obs(S, cfg, obs + (size_t)env * APX_OBS_DIM);
+    env_reset<HF>(S, cfg);
+    if (obs && lead) write_obs(S, cfg, obs + (size_t)env * cfg.obs_dim);
     store_state(S, st, ist, n);
 }
 
+template <bool HF>
 __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const float* action, float* obs,
                                                       float* reward, uint8_t* done, float* final_obs) {
     ENV_SETUP
@@ -485,7 +507,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
     }
     c4::wsync();
     for (int i = 0; i < cfg.simrate; ++i) {
-        sim_step_pd(S, cfg.pgs_iters, 1);                                        // all lanes (barriers inside)
+        sim_step_pd<HF>(S, cfg, 1);                                        // all lanes (barriers inside)
         if (!lead) continue;
         for (int k = 0; k < 6; ++k) {                                            // cassie.py:328-331
             const float fp = S(F_FWD + 10 + k);
@@ -529,8 +551,8 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
         if (!dn && time >= cfg.max_traj_len) dn = 2;
         reward[env] = rew;
         done[env] = (uint8_t)dn;
-        write_obs(S, cfg, obs + (size_t)env * APX_OBS_DIM);
-        if (dn && final_obs) for (int k = 0; k < APX_OBS_DIM; ++k) final_obs[(size_t)env * APX_OBS_DIM + k] = obs[(size_t)env * APX_OBS_DIM + k];
+        write_obs(S, cfg, obs + (size_t)env * cfg.obs_dim);
+        if (dn && final_obs) for (int k = 0; k < cfg.obs_dim; ++k) final_obs[(size_t)env * cfg.obs_dim + k] = obs[(size_t)env * cfg.obs_dim + k];
     }
     store_state(S, st, ist, n);
 }
@@ -538,6 +560,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
 // action == NULL: raw substeps with the current pd targets (tests): n_sub x cassie_sim_step_pd.
 // action != NULL: CassieEnv.step_basic (cassie/cassie.py:498-521, 355-387): new pd targets, n_sub substeps, time / phase bookkeeping,
 // observation; no reward, termination, trackers or command resampling
+template <bool HF>
 __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_substep_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, int n_sub,
                                                                             const float* action, float* obs) {
     ENV_SETUP
@@ -547,24 +570,25 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_substep_kernel(float
         S.I(I_FLAGS) |= 16;
     }
     c4::wsync();
-    for (int i = 0; i < n_sub; ++i) sim_step_pd(S, cfg.pgs_iters, 1);
+    for (int i = 0; i < n_sub; ++i) sim_step_pd<HF>(S, cfg, 1);
     if (action && lead) {
         int phase = S.I(I_PHASE) + 1;
         S.I(I_TIME) += 1;
         if ((float)phase > S(F_CMD + 5)) { phase = 0; S.I(I_COUNTER) += 1; }
         S.I(I_PHASE) = phase;
-        if (obs) write_obs(S, cfg, obs + (size_t)env * APX_OBS_DIM);
+        if (obs) write_obs(S, cfg, obs + (size_t)env * cfg.obs_dim);
     }
     store_state(S, st, ist, n);
 }
 // CassieEnv.reset_for_test(full_reset=False) (cassie/cassie.py:682-742)
+template <bool HF>
 __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_for_test_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, float* obs, int full) {
     ENV_SETUP
     load_state(S, st, ist, n);
     if (lead) {
         S.I(I_PHASE) = 0; S.I(I_TIME) = 0; S.I(I_COUNTER) = 0;
         S(F_CMD + 0) = 0.f; S(F_CMD + 2) = 0.f;                                  // speed, orient_add (side speed is NOT reset)
-        S(F_CMD + 3) = 0.15f; S(F_CMD + 4) = 0.25f; S(F_CMD + 5) = (2.f * 0.15f + 2.f * 0.25f) * (float)(2000 / cfg.simrate);
+        S(F_CMD + 3) = 0.15f; S(F_CMD + 4) = 0.25f; S(F_CMD + 5) = (2.f * 0.15f + 2.f * 0.25f) * (float)(2000 / cfg.simrate); S(F_CMD + 6) = 1.f;      // grounded (cassie.py:699-702)
     }
     c4::wsync();
     if (full) {
@@ -585,7 +609,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_for_test_kerne
         }
         c4::wsync();
     } else {
-        sim_step_pd(S, cfg.pgs_iters, 1);                                        // self.cassie_state = self.sim.step_pd(self.u), stale targets
+        sim_step_pd<HF>(S, cfg, 1);                                        // self.cassie_state = self.sim.step_pd(self.u), stale targets
     }
     if (cfg.dyn_rand) {                                                          // default dynamics, set_const (back to the init pose), flat floor, no encoder offsets
         if (lead) {
@@ -601,9 +625,9 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_for_test_kerne
         }
         c4::wsync();
         setconst_lane(S);
-        sim_step_pd(S, cfg.pgs_iters, 0);                                        // cassie_sim_set_const ends in mj_forward
+        sim_step_pd<HF>(S, cfg, 0);                                        // cassie_sim_set_const ends in mj_forward
     }
-    if (lead) write_obs(S, cfg, obs + (size_t)env * APX_OBS_DIM);
+    if (lead) write_obs(S, cfg, obs + (size_t)env * cfg.obs_dim);
     store_state(S, st, ist, n);
 }
 static constexpr size_t LDS_BYTES = (size_t)L4_EPW * L4_ES * sizeof(float);   // 37,120 B per wave, 4 waves per CU
@@ -620,6 +644,7 @@ __global__ void env_update_speed_kernel(float* st, int* ist, int n, Cfg cfg, con
     if (env >= n) return;
     auto F = [&](int f) -> float& { return st[(size_t)f * n + env]; };
     const float sp = fminf(fmaxf(speed[env], -0.3f), 4.0f), sd = side ? fminf(fmaxf(side[env], -0.3f), 0.3f) : 0.f;
+    if (cfg.command_profile != 0) { F(F_CMD + 0) = sp; F(F_CMD + 1) = sd; return; }      // cassie.py:756-761: durations kept (>= 0.01 by construction), phase unchanged
     const double s = sp, total = (0.9 - 0.25 / 3.0 * s) / 2;
     const double swing = (0.30 + ((0.70 - 0.30) / 3) * s) * total, stance = (0.70 - ((0.70 - 0.30) / 3) * s) * total;
     const double freq = (double)(2000 / cfg.simrate);
@@ -631,9 +656,11 @@ __global__ void env_update_speed_kernel(float* st, int* ist, int n, Cfg cfg, con
 
 // ------------------------------------------------------------------------------------------------ C ABI
 
-static Cfg make_cfg(const apx_env_cfg& c) {
-    return Cfg{c.simrate, c.dynamics_randomization, c.stance_mode, c.have_incentive, c.max_traj_len, c.pgs_iters,
-               (unsigned)c.seed, (unsigned)(c.seed >> 32), (unsigned)c.env_id_base, c.reward_kind, c.env_kind};
+static Cfg make_cfg(const apx_env& env) {
+    const apx_env_cfg& c = env.cfg;
+    return Cfg{Hf{env.hf, env.hf_nrow, env.hf_ncol, env.hf_size[0], env.hf_size[1], env.hf_size[2]}, c.simrate, c.dynamics_randomization, c.stance_mode, c.have_incentive, c.max_traj_len, c.pgs_iters,
+               (unsigned)c.seed, (unsigned)(c.seed >> 32), (unsigned)c.env_id_base, c.reward_kind, c.env_kind, c.command_profile,
+               c.command_profile == 0 ? APX_OBS_DIM : APX_OBS_DIM_PHASE};
 }
 
 extern "C" void apx_env_default_cfg(apx_env_cfg* c) {
@@ -650,6 +677,7 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     APX_REQUIRE(cfg->env_kind == 0 || (cfg->env_kind == 1 && cfg->simrate == 50), "env_kind: 0 Cassie-v0, 1 CassieTraj-v0 (walking trajectory table is for simrate 50)");
     APX_REQUIRE(cfg->reward_kind >= 0 && cfg->reward_kind <= 2, "reward_kind: 0 clock_reward, 1 early_clock_reward, 2 max_vel_clock_reward");
     APX_REQUIRE(cfg->pgs_iters > 0 && cfg->max_traj_len > 0, "pgs_iters / max_traj_len");
+    APX_REQUIRE(cfg->command_profile >= 0 && cfg->command_profile <= 2 && (cfg->command_profile == 0 || cfg->env_kind == 0), "command_profile: 0 clock, 1 phase, 2 phase (library draws); phase needs Cassie-v0");
     APX_HIP(hipSetDevice(cfg->device));
     apx_env* e = new (std::nothrow) apx_env;
     APX_REQUIRE(e, "alloc");
@@ -658,12 +686,14 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     APX_HIP(hipMalloc(&e->ist, sizeof(int) * (size_t)I_TOTAL * e->n));
     e->wk = nullptr;
     APX_HIP(hipMalloc(&e->wk, 256));      // generation 4 keeps the stage hand-off in LDS: no HBM workspace
-    const Cfg c = make_cfg(*cfg);
+    e->hf = nullptr; e->hf_nrow = e->hf_ncol = 0; e->hf_size[0] = e->hf_size[1] = e->hf_size[2] = 0.f;
+    const Cfg c = make_cfg(*e);
     hipLaunchKernelGGL(env_init_kernel, dim3(e->n / 64), dim3(64), 0, 0, e->st, e->ist, e->n, c);
     APX_LAUNCH_CHECK();
-    APX_HIP(hipFuncSetAttribute((const void*)env_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    APX_HIP(hipFuncSetAttribute((const void*)env_reset_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    APX_HIP(hipFuncSetAttribute((const void*)env_substep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    for (const void* fn : {(const void*)env_step_kernel<false>, (const void*)env_step_kernel<true>, (const void*)env_reset_kernel<false>, (const void*)env_reset_kernel<true>,
+                           (const void*)env_substep_kernel<false>, (const void*)env_substep_kernel<true>, (const void*)env_reset_for_test_kernel<false>,
+                           (const void*)env_reset_for_test_kernel<true>})
+        APX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
     hipLaunchKernelGGL(env_setconst_kernel, SETCONST_GRID(e->n), dim3(64), SETCONST_LDS, 0, e->st, e->ist, e->wk, e->n, c);
     APX_LAUNCH_CHECK();
     APX_HIP(hipDeviceSynchronize());
@@ -673,15 +703,29 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
 
 extern "C" int apx_env_destroy(apx_env_t* e) {
     if (!e) return APX_OK;
-    (void)hipFree(e->st); (void)hipFree(e->ist); (void)hipFree(e->wk);
+    (void)hipFree(e->st); (void)hipFree(e->ist); (void)hipFree(e->wk); (void)hipFree(e->hf);
     delete e;
+    return APX_OK;
+}
+
+extern "C" int apx_env_set_hfield(apx_env_t* e, const float* data, int nrow, int ncol, const float* size3, void* stream) {
+    APX_REQUIRE(e, "env");
+    APX_HIP(hipStreamSynchronize((hipStream_t)stream));           // kernels in flight still read the old field
+    (void)hipFree(e->hf); e->hf = nullptr; e->hf_nrow = e->hf_ncol = 0;
+    if (!data) return APX_OK;                                     // back to the plane
+    APX_REQUIRE(nrow >= 2 && ncol >= 2 && size3 && size3[0] > 0.f && size3[1] > 0.f, "height field: nrow, ncol >= 2 and positive half extents");
+    APX_HIP(hipMalloc(&e->hf, sizeof(float) * (size_t)nrow * ncol));
+    APX_HIP(hipMemcpy(e->hf, data, sizeof(float) * (size_t)nrow * ncol, hipMemcpyDefault));      // host or device source
+    e->hf_nrow = nrow; e->hf_ncol = ncol; e->hf_size[0] = size3[0]; e->hf_size[1] = size3[1]; e->hf_size[2] = size3[2];
     return APX_OK;
 }
 
 extern "C" int apx_env_reset(apx_env_t* e, const uint8_t* mask, float* obs_out, void* stream) {
     APX_REQUIRE(e, "env");
-    hipLaunchKernelGGL(env_reset_kernel, ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
-                       make_cfg(e->cfg), mask, obs_out);
+    if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+                       make_cfg(*e), mask, obs_out);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_kernel<false>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+                       make_cfg(*e), mask, obs_out);
     APX_LAUNCH_CHECK();
     return APX_OK;
 }
@@ -689,14 +733,16 @@ extern "C" int apx_env_reset(apx_env_t* e, const uint8_t* mask, float* obs_out, 
 extern "C" int apx_env_update_speed(apx_env_t* e, const float* speed, const float* side_speed, void* stream) {
     APX_REQUIRE(e && speed, "null pointer");
     hipLaunchKernelGGL(env_update_speed_kernel, dim3(apx_cdiv((long)e->n, 256)), dim3(256), 0, (hipStream_t)stream, e->st, e->ist, e->n,
-                       make_cfg(e->cfg), speed, side_speed);
+                       make_cfg(*e), speed, side_speed);
     APX_LAUNCH_CHECK();
     return APX_OK;
 }
 
 extern "C" int apx_env_step_basic(apx_env_t* e, const float* action, float* obs, void* stream) {
     APX_REQUIRE(e && action && obs, "null pointer");
-    hipLaunchKernelGGL(env_substep_kernel, ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(e->cfg),
+    if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_substep_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e),
+                       e->cfg.simrate, action, obs);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_substep_kernel<false>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e),
                        e->cfg.simrate, action, obs);
     APX_LAUNCH_CHECK();
     return APX_OK;
@@ -705,8 +751,10 @@ extern "C" int apx_env_step_basic(apx_env_t* e, const float* action, float* obs,
 extern "C" int apx_env_reset_for_test(apx_env_t* e, float* obs_out, int full_reset, void* stream) {
     APX_REQUIRE(e && obs_out, "null pointer");
     e->cfg.stance_mode = 1;                               // reset_for_test switches to the grounded clock (cassie.py:702)
-    hipLaunchKernelGGL(env_reset_for_test_kernel, ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
-                       make_cfg(e->cfg), obs_out, full_reset);
+    if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_for_test_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+                       make_cfg(*e), obs_out, full_reset);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_for_test_kernel<false>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+                       make_cfg(*e), obs_out, full_reset);
     APX_LAUNCH_CHECK();
     return APX_OK;
 }
@@ -722,12 +770,16 @@ extern "C" int apx_env_apply_force(apx_env_t* e, const float* xfrc, void* stream
 extern "C" int apx_env_step(apx_env_t* e, const float* action, float* obs, float* reward, uint8_t* done, float* final_obs,
                             int auto_reset, void* stream) {
     APX_REQUIRE(e && action && obs && reward && done, "null pointer");
-    hipLaunchKernelGGL(env_step_kernel, ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
-                       make_cfg(e->cfg), action, obs, reward, done, final_obs);
+    if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_step_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+                       make_cfg(*e), action, obs, reward, done, final_obs);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_step_kernel<false>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+                       make_cfg(*e), action, obs, reward, done, final_obs);
     APX_LAUNCH_CHECK();
     if (auto_reset) {   // finished envs restart in a second launch on the same stream (mask = done flags)
-        hipLaunchKernelGGL(env_reset_kernel, ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
-                           make_cfg(e->cfg), done, obs);
+        if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+                           make_cfg(*e), done, obs);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_kernel<false>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
+                           make_cfg(*e), done, obs);
         APX_LAUNCH_CHECK();
     }
     return APX_OK;
@@ -767,7 +819,7 @@ static const FieldDesc kFields[] = {
     {"so_mpos", F_SO + SO_MPOS, 10}, {"so_mvel", F_SO + SO_MVEL, 10}, {"so_torque", F_SO + SO_TORQUE, 10},
     {"so_jpos", F_SO + SO_JPOS, 6}, {"so_jvel", F_SO + SO_JVEL, 6}, {"so_quat", F_SO + SO_QUAT, 4},
     {"so_rotvel", F_SO + SO_ROTVEL, 3}, {"so_tvel", F_SO + SO_TVEL, 3}, {"so_tacc", F_SO + SO_TACC, 3}, {"so_height", F_SO + SO_HEIGHT, 1},
-    {"foot_vel", F_FOOTVEL, 6}, {"prev_action", F_PREVACT, 10}, {"prev_torque", F_PREVTQ, 10}, {"cmd", F_CMD, 6}, {"fwd", F_FWD, 16}, {"xfrc", F_XFRC, 6}, {"est", F_EST, 2},
+    {"foot_vel", F_FOOTVEL, 6}, {"prev_action", F_PREVACT, 10}, {"prev_torque", F_PREVTQ, 10}, {"cmd", F_CMD, 7}, {"fwd", F_FWD, 16}, {"xfrc", F_XFRC, 6}, {"est", F_EST, 2},
 };
 
 static const FieldDesc* find_field(const char* name) {
@@ -796,7 +848,9 @@ extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, voi
     }
 #endif
     if (!strcmp(name, "substep")) {   // debugging hook: out[0] (host-readable count is not needed) - run one raw substep
-        hipLaunchKernelGGL(env_substep_kernel, ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(e->cfg), 1,
+        if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_substep_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), 1,
+                           (const float*)nullptr, (float*)nullptr);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_substep_kernel<false>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), 1,
                            (const float*)nullptr, (float*)nullptr);
         APX_LAUNCH_CHECK();
         return 0;
@@ -811,7 +865,7 @@ extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, voi
 extern "C" int apx_env_set_field(apx_env_t* e, const char* name, const float* in, void* stream) {
     APX_REQUIRE(e && name, "null pointer");
     if (!strcmp(name, "set_const")) {   // recompute invweight0 after mass edits (sim.set_const)
-        hipLaunchKernelGGL(env_setconst_kernel, SETCONST_GRID(e->n), dim3(64), SETCONST_LDS, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(e->cfg));
+        hipLaunchKernelGGL(env_setconst_kernel, SETCONST_GRID(e->n), dim3(64), SETCONST_LDS, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e));
         APX_LAUNCH_CHECK();
         return 0;
     }

@@ -12,7 +12,7 @@ enum Field : int {
     F_JENCX = F_MENC + 90, F_JENCY = F_JENCX + 24, F_SNAP = F_JENCY + 12 /* mpos10 jpos6 quat4 gyro3 acc3 vel3 pz1 */,
     F_SO = F_SNAP + 30 /* mpos10 mvel10 torque10 jpos6 jvel6 quat4 rotvel3 tvel3 tacc3 height1 */, F_FOOTPREV = F_SO + 56,
     F_FOOTVEL = F_FOOTPREV + 6, F_PREVACT = F_FOOTVEL + 6, F_PREVTQ = F_PREVACT + 10,
-    F_CMD = F_PREVTQ + 10 /* speed side orient swing stance phaselen */, F_FWD = F_CMD + 6 /* foot force z L,R; foot quat L4 R4; foot pos 6 */,
+    F_CMD = F_PREVTQ + 10 /* speed side orient swing stance phaselen stance_mode */, F_FWD = F_CMD + 7 /* foot force z L,R; foot quat L4 R4; foot pos 6 */,
     F_XFRC = F_FWD + 16 /* external wrench on the pelvis, world frame: force xyz, torque xyz (mjData.xfrc_applied row of cassie-pelvis) */,
     F_EST = F_XFRC + 6 /* height filter of the state estimator: [0] L = low-passed lowest sole height, [1] lowest sole world z of the last forward pass */,
     F_TOTAL = F_EST + 2
@@ -29,8 +29,9 @@ struct apx_env {
     apx_env_cfg cfg;
     float* st;      // [F_TOTAL, n]
     int* ist;       // [I_TOTAL, n]
-    float* wk;      // [307, n] per-env mass-matrix scratch (written by forward, read by Euler)
+    float* wk;      // unused placeholder allocation (the stage hand-off lives in LDS)
     int n;
+    float* hf; int hf_nrow, hf_ncol; float hf_size[3];      // device copy of the height field (apx_env_set_hfield), or nullptr
 };
 
 // global-address-space pointers: St is passed by value into a non-inlined device function, where the compiler could
@@ -45,7 +46,7 @@ typedef __attribute__((address_space(3))) int lint;
 #ifndef APX_L4_EPW
 #define APX_L4_EPW 4
 #endif
-constexpr int L4_INT = 586, L4_WK = 592, L4_ROWS = 1664, L4_ES = 2384, L4_EPW = APX_L4_EPW;      // envs per wave (16 lanes each)
+constexpr int L4_INT = 586 /* >= F_TOTAL */, L4_WK = 592, L4_ROWS = 1664, L4_ES = 2384, L4_EPW = APX_L4_EPW;      // envs per wave (16 lanes each)
 static_assert(F_TOTAL <= L4_INT && L4_INT + I_TOTAL <= L4_WK, "LDS state region");
 struct St {
     lfloat* p; int env;
@@ -56,7 +57,10 @@ struct St {
 
 // state estimator height model (golden G11c): height = z - L, L' = (lowest sole z - L) / EST_TAU, L = EST_L0 after state_output_setup
 constexpr float EST_TAU = 0.86f, EST_L0 = 0.126f, EST_ALPHA = 0.0005f / EST_TAU;
-struct Cfg { int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; int reward_kind, env_kind; };
+// terrain of cassie_hfield.xml (util/eval.py:73-76): nrow x ncol raw elevations (rows along y, columns along x) over [-sx, sx] x [-sy, sy],
+// elevation = data * sz; data == nullptr: the floor plane of cassie.xml:73
+struct Hf { const float* data; int nrow, ncol; float sx, sy, sz; };
+struct Cfg { Hf hf; int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; int reward_kind, env_kind, command_profile, obs_dim; };
 
 // ------------------------------------------------------------------------------------------------ Philox4x32-10
 __device__ __forceinline__ unsigned philox(unsigned k0, unsigned k1, unsigned env, unsigned ctr) {

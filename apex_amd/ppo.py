@@ -64,11 +64,12 @@ class PPO:
         self.rank, self.world, self.group = rank, world_size, group
         self.device = env.device
         self.N = env.n_envs
+        self.D = int(getattr(env, "obs_dim", 50))              # 50 (command_profile clock) or 55 (phase)
         # steps per env per iteration: the reference samples >= num_steps in total (ppo.py:205)
         self.T = adist.rollout_len(self.num_steps, self.N, self.world)
-        self.learner = engine.PPOLearner(50, 10, hidden, self.device, self.fixed_std, lr=self.lr, eps=self.eps,
+        self.learner = engine.PPOLearner(self.D, 10, hidden, self.device, self.fixed_std, lr=self.lr, eps=self.eps,
                                          clip=self.clip, entropy_coeff=self.entropy_coeff, grad_clip=self.grad_clip,
-                                         mirrored_obs=MIRRORED_OBS if self.mirror else None,
+                                         mirrored_obs=list(getattr(env, "mirrored_obs", MIRRORED_OBS)) if self.mirror else None,
                                          mirrored_acts=MIRRORED_ACTS if self.mirror else None, clock_inds=CLOCK_INDS)
         self.total_steps = 0
         self.highest_reward = -1
@@ -76,13 +77,13 @@ class PPO:
         self.gen.manual_seed(int(args.get("seed", 0)) * 1000003 + rank)
         T, N = self.T, self.N
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.b_obs = torch.zeros(T, N, 50, **f32); self.b_act = torch.zeros(T, N, 10, **f32)
+        self.b_obs = torch.zeros(T, N, self.D, **f32); self.b_act = torch.zeros(T, N, 10, **f32)
         self.b_mu = torch.zeros(T, N, 10, **f32); self.b_rew = torch.zeros(T, N, **f32)
         self.b_val = torch.zeros(T, N, **f32); self.b_boot = torch.zeros(T, N, **f32)
         self.b_end = torch.zeros(T, N, dtype=torch.uint8, device=self.device)
         self.b_done = torch.zeros(T, N, dtype=torch.uint8, device=self.device)
         self.b_endb = torch.zeros(T, N, dtype=torch.bool, device=self.device)
-        self.b_fin = torch.zeros(T, N, 50, **f32)
+        self.b_fin = torch.zeros(T, N, self.D, **f32)
         self.noise = torch.zeros(T, N, 10, **f32)
         self.use_graph = bool(args.get("graph", False)) and self.world == 1
         self._graph = None
@@ -107,8 +108,8 @@ class PPO:
         from rl.policies.critic import FF_V
         torch.manual_seed(seed)
         H = self.learner.actor.H
-        self.policy = Gaussian_FF_Actor(50, 10, layers=(H, H), fixed_std=np.exp(np.log(self.fixed_std)), env_name=self.env_name)
-        self.critic = FF_V(50, layers=(H, H))
+        self.policy = Gaussian_FF_Actor(self.D, 10, layers=(H, H), fixed_std=np.exp(np.log(self.fixed_std)), env_name=self.env_name)
+        self.critic = FF_V(self.D, layers=(H, H))
         self.upload()
 
     def upload(self):
@@ -131,7 +132,8 @@ class PPO:
         sqrt(var + 1e-8) of the raw observations; moments all-reduced over ranks."""
         steps = max(iters // (self.N * self.world), 50)
         obs = self.env.reset()
-        s = torch.zeros(50, dtype=torch.float64, device=self.device); ss = torch.zeros_like(s); n = 0
+        D = self.D
+        s = torch.zeros(D, dtype=torch.float64, device=self.device); ss = torch.zeros_like(s); n = 0
         nz = torch.zeros(self.N, 10, dtype=torch.float32, device=self.device)
         for t in range(steps):
             s += obs.double().sum(0); ss += (obs.double() ** 2).sum(0); n += obs.shape[0]
@@ -145,9 +147,9 @@ class PPO:
         mom = torch.cat([s, ss, torch.tensor([float(n)], dtype=torch.float64, device=self.device)])
         if self.group is not None:
             torch.distributed.all_reduce(mom, group=self.group)
-        cnt = mom[100]
-        mean = mom[:50] / cnt
-        var = (mom[50:100] / cnt - mean * mean).clamp_min(0)
+        cnt = mom[2 * D]
+        mean = mom[:D] / cnt
+        var = (mom[D:2 * D] / cnt - mean * mean).clamp_min(0)
         self.learner.obs_mean.copy_(mean.float()); self.learner.obs_std.copy_(torch.sqrt(var + 1e-8).float())
 
     # ------------------------------------------------------------------------------------------ sampling
@@ -166,7 +168,7 @@ class PPO:
             nxt = self.b_obs[t + 1] if t + 1 < T else self.obs
             env.step(self.b_act[t], out=(nxt, self.b_rew[t], self.b_done[t], self.b_fin[t]))
         # V(s_t) is not on the stepping path: one batched critic pass over the whole grid instead of T small ones
-        L.critic.forward(self.b_obs.view(T * self.N, 50), out=self.b_val.view(T * self.N, 1))
+        L.critic.forward(self.b_obs.view(T * self.N, self.D), out=self.b_val.view(T * self.N, 1))
 
     def sample(self):
         """T lock-step env steps for the N envs of this GPU (the batched PPO.sample, ppo.py:139-186).
@@ -198,7 +200,7 @@ class PPO:
         self.b_boot.zero_()
         tr_idx = (self.b_done.view(-1) == 2).nonzero().view(-1)
         if tr_idx.numel():
-            self.b_boot.view(-1)[tr_idx] = L.critic.forward(self.b_fin.view(T * N, 50), idx=tr_idx).view(-1)
+            self.b_boot.view(-1)[tr_idx] = L.critic.forward(self.b_fin.view(T * N, self.D), idx=tr_idx).view(-1)
         last_val = L.critic.forward(self.obs).view(-1)
         ret = engine.returns_scan(self.b_rew, self.b_end, self.b_boot, last_val, self.gamma)
         ep_rets, ep_lens, self.ep_ret, self.ep_len = episode_stats(self.b_rew, self.b_endb, self.ep_ret, self.ep_len)
@@ -208,7 +210,7 @@ class PPO:
     def update(self, ret):
         L = self.learner
         B = self.T * self.N
-        obs, act, mu = self.b_obs.view(B, 50), self.b_act.view(B, 10), self.b_mu.view(B, 10)
+        obs, act, mu = self.b_obs.view(B, self.D), self.b_act.view(B, 10), self.b_mu.view(B, 10)
         ret, val = ret.view(B), self.b_val.view(B)
         adv = engine.normalize_advantages(ret, val, self.eps, group=self.group)             # ppo.py:395-396
         mb = min(self.minibatch_size or B, B)

@@ -5,7 +5,7 @@ persistent per-env state (F_TOTAL fp32 fields + 5 int fields, env.hip `enum Fiel
 ENV_STEP_FLOP: fp32 operations of one env step of the tree-sparse formulation, counted analytically per substep
  x 50.
 """
-F_TOTAL = 585          # floats of persistent state per env (env_state.h: enum Field)
+F_TOTAL = 586          # floats of persistent state per env (env_state.h: enum Field)
 I_TOTAL = 6
 ENV_STEP_BYTES = 2 * 4 * (F_TOTAL + I_TOTAL) + 4 * 10 + 4 * 50 + 4 + 1
 

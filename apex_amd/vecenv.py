@@ -21,6 +21,20 @@ MIRRORED_OBS = [0.1, 1, -2, 3, -4, -10, -11, 12, 13, 14, -5, -6, 7, 8, 9, 15, -1
                 -21, -22, 23, 24, 25, 31, -32, 33, 37, 38, 39, 34, 35, 36, 43, 44, 45, 40, 41, 42, 46, 47, 48, 49]
 MIRRORED_ACTS = [-5, -6, 7, 8, 9, -0.1, -1, 2, 3, 4]
 CLOCK_INDS = [46, 47]
+OBS_DIM_PHASE = 55
+# command_profile "phase" (cassie/cassie.py:266-271): the 46 base entries, then clock (2), swing / stance duration + one-hot stance mode (5),
+# speed / side speed (2) mirror onto themselves
+MIRRORED_OBS_PHASE = MIRRORED_OBS[:46] + list(range(46, 55))
+
+
+def parse_phase_reward(reward):
+    """cassie/cassie.py:186-199 (set_up_phase_reward, command_profile "phase"): "early" -> early_clock_reward, "library" -> the library
+    draws of reset (:531-539), "no_speed" -> no_speed_clock_reward (not built), anything else -> clock_reward."""
+    if reward is None:
+        raise TypeError("argument of type 'NoneType' is not iterable")
+    if "no_speed" in reward:
+        raise NotImplementedError("no_speed_clock_reward (cassie/rewards/clock_rewards.py) is not built")
+    return dict(reward_kind=1 if "early" in reward else 0, stance_mode=0, have_incentive=int("no_incentive" not in reward), library="library" in reward)
 
 
 def parse_reward(reward):
@@ -47,8 +61,10 @@ class CassieVecEnv:
     def __init__(self, n_envs=4096, simrate=50, dynamics_randomization=True, reward="clock", max_traj_len=400, seed=0,
                  device=0, pgs_iters=50, env_id_base=0, command_profile="clock", input_profile="full", history=0, learn_gains=False,
                  env_name="Cassie-v0", traj="walking", no_delta=True, ik_baseline=False):
-        if command_profile != "clock" or input_profile != "full" or history != 0 or learn_gains:
-            raise NotImplementedError("only command_profile=clock, input_profile=full, history=0 are on the hot path")
+        if command_profile not in ("clock", "phase") or input_profile != "full" or history != 0 or learn_gains:
+            raise NotImplementedError("command_profile clock / phase with input_profile=full, history=0 are built (traj / min / history are not)")
+        if command_profile == "phase" and env_name != "Cassie-v0":
+            raise NotImplementedError("command_profile=phase is built for Cassie-v0")
         # util/env.py:22-32: Cassie-v0 -> CassieEnv; CassieTraj-v0 -> CassieTrajEnv, which with the CLI defaults (traj=walking,
         # command_profile=clock, no_delta) has Cassie-v0's step and observation and resets to the reference trajectory's pose
         if env_name not in ("Cassie-v0", "CassieTraj-v0"):
@@ -61,7 +77,12 @@ class CassieVecEnv:
         lib = _lib.load()
         cfg = _lib.EnvCfg()
         lib.apx_env_default_cfg(C.byref(cfg))
-        r = parse_reward(reward)
+        r = parse_reward(reward) if command_profile == "clock" else parse_phase_reward(reward)
+        cfg.command_profile = 0 if command_profile == "clock" else (2 if r["library"] else 1)
+        self.command_profile = command_profile
+        self.obs_dim = OBS_DIM if command_profile == "clock" else OBS_DIM_PHASE
+        if command_profile == "phase":
+            self.mirrored_obs = MIRRORED_OBS_PHASE
         cfg.n_envs, cfg.simrate, cfg.dynamics_randomization = n_envs, simrate, int(dynamics_randomization)
         cfg.reward_kind, cfg.stance_mode, cfg.have_incentive = r["reward_kind"], r["stance_mode"], r["have_incentive"]
         cfg.max_traj_len, cfg.seed, cfg.device, cfg.pgs_iters = max_traj_len, seed, device, pgs_iters
@@ -72,11 +93,11 @@ class CassieVecEnv:
         self._h = C.c_void_p()
         check(lib.apx_env_create(C.byref(cfg), C.byref(self._h)))
         self.n_envs, self.simrate, self.max_traj_len = n_envs, simrate, max_traj_len
-        self.observation_space = np.zeros(OBS_DIM)
+        self.observation_space = np.zeros(self.obs_dim)
         self.action_space = np.zeros(ACT_DIM)
         f32 = dict(dtype=torch.float32, device=self.device)
-        self.obs = torch.zeros(n_envs, OBS_DIM, **f32)
-        self.final_obs = torch.zeros(n_envs, OBS_DIM, **f32)
+        self.obs = torch.zeros(n_envs, self.obs_dim, **f32)
+        self.final_obs = torch.zeros(n_envs, self.obs_dim, **f32)
         self.reward = torch.zeros(n_envs, **f32)
         self.done = torch.zeros(n_envs, dtype=torch.uint8, device=self.device)
 
@@ -149,7 +170,7 @@ class CassieVecEnv:
         obs, rew, done, fin = out if out is not None else (self.obs, self.reward, self.done, self.final_obs)
         if out is not None:
             assert obs.is_contiguous() and rew.is_contiguous() and done.is_contiguous() and fin.is_contiguous()
-            assert obs.shape == (self.n_envs, OBS_DIM) and fin.shape == (self.n_envs, OBS_DIM) and done.dtype == torch.uint8
+            assert obs.shape == (self.n_envs, self.obs_dim) and fin.shape == (self.n_envs, self.obs_dim) and done.dtype == torch.uint8
         check(_lib.load().apx_env_step(self._h, _p(action), _p(obs), _p(rew), _p(done), _p(fin), int(auto_reset), _stream()))
         return obs, rew, done, fin
 
@@ -168,6 +189,17 @@ class CassieVecEnv:
         n = lib.apx_env_set_field(self._h, name.encode(), _p(v), _stream())
         if n < 0:
             check(n)
+
+    def set_hfield(self, data, size=(50.0, 50.0, 0.15)):
+        """CassieSim("cassie_hfield.xml") + sim.set_hfield_data(data) (util/eval.py:73-76) for every env of the batch: data [nrow, ncol] raw
+        elevations (numpy / tensor; x size[2] = metres), rows along y, columns along x, over [-size[0], size[0]] x [-size[1], size[1]]
+        (cassie_hfield.xml:69: 500 x 500 over 100 m x 100 m, scale 0.15).  None restores the floor plane."""
+        lib = _lib.load()
+        if data is None:
+            check(lib.apx_env_set_hfield(self._h, None, 0, 0, None, _stream())); return
+        d = torch.as_tensor(np.asarray(data, dtype=np.float32) if not torch.is_tensor(data) else data, dtype=torch.float32).contiguous().cpu()
+        sz = (C.c_float * 3)(*[float(x) for x in size])
+        check(lib.apx_env_set_hfield(self._h, C.c_void_p(d.data_ptr()), int(d.shape[0]), int(d.shape[1]), C.cast(sz, C.c_void_p), _stream()))
 
     def saturation(self):
         """(flags [N] int64, passes [N] int64): SAT_* bits (1 = more than 2 penetrating capsule ends on a leg, 2 = more than 1 active joint

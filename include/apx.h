@@ -24,7 +24,8 @@ extern "C" {
 #define APX_E_HIP (-2)
 #define APX_E_STATE (-3)
 
-#define APX_OBS_DIM 50   /* cassie/cassie.py:236-265  (46 estimator + 2 clock + 2 speed) */
+#define APX_OBS_DIM 50   /* cassie/cassie.py:236-265  (46 estimator + 2 clock + 2 speed), command_profile clock */
+#define APX_OBS_DIM_PHASE 55   /* + swing, stance, one-hot stance mode (cassie.py:266-271) */
 #define APX_ACT_DIM 10   /* cassie/cassie.py:68 */
 #define APX_NQ 35        /* cassie/cassiemujoco/cassiemujoco.py:36-39 */
 #define APX_NV 32
@@ -178,7 +179,10 @@ typedef struct apx_env_cfg {
     int env_kind;               /* 0 Cassie-v0 (cassie/cassie.py), 1 CassieTraj-v0 with the CLI defaults traj=walking, command_profile=clock,
                                  * input_profile=full, no_delta (cassie/cassie_traj.py): same step, reset to the reference trajectory's pose
                                  * of the random start phase (:599-778, get_ref_state :926-972); needs simrate 50 */
-    int reserved[5];
+    int command_profile;        /* 0 clock (obs 50: ..., sin, cos, speed, side speed), 1 phase (cassie.py:266-271,529-545,805-808: swing / stance
+                                 * duration and the stance mode are drawn per reset, obs 55: ..., sin, cos, swing, stance, one-hot stance mode,
+                                 * speed, side speed), 2 phase with the "library" draws (:531-539) */
+    int reserved[4];
 } apx_env_cfg;
 
 void apx_env_default_cfg(apx_env_cfg* cfg);
@@ -187,6 +191,12 @@ int apx_env_destroy(apx_env_t* env);
 
 /* CassieEnv.reset (cassie/cassie.py:523-680) for envs whose mask byte is non-zero (mask NULL = all);
  * obs_out[n_envs*50] f32 [dev] (rows of un-reset envs are left untouched). */
+/* Terrain: CassieSim("cassie_hfield.xml") + set_hfield_data (cassie/cassiemujoco/cassiemujoco.py:309-315, util/eval.py:73-76,
+ * cassie_hfield.xml:69,74).  data [nrow, ncol] raw elevations (host or device pointer, copied; rows along y, columns along x),
+ * size3 = (x half extent, y half extent, elevation scale); elevation = data * size3[2].  Replaces the floor plane for every env of
+ * the handle (foot / tarsus / shin capsule ends against the triangle under them); data == NULL restores the plane. */
+int apx_env_set_hfield(apx_env_t* env, const float* data, int nrow, int ncol, const float* size3, void* stream);
+
 int apx_env_reset(apx_env_t* env, const uint8_t* mask, float* obs_out, void* stream);
 
 /* Evaluation-side API.

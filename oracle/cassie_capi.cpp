@@ -1,4 +1,5 @@
 // CPU ORACLE (test infrastructure only): C entry points for tests/ (ctypes) and bench.py's cpu_baseline leg.
+#include <cstdlib>
 #include "cassie_env.h"
 #include <cstring>
 #include <thread>
@@ -19,11 +20,12 @@ void* orc_env_new(int simrate, int dyn_rand, int reward_kind, int stance_mode, i
     env_init(*e, c, env_id);
     return e;
 }
-void orc_env_free(void* h) { delete (Env*)h; }
+void orc_env_free(void* h) { std::free(const_cast<float*>(((Env*)h)->par.hf_data)); delete (Env*)h; }
 void orc_env_reset(void* h, double* obs) { env_reset(*(Env*)h, obs); }
 int orc_env_step(void* h, const double* action, double* obs, double* reward) { return env_step(*(Env*)h, action, obs, reward); }
 void orc_env_substep(void* h) { sim_step_pd(*(Env*)h); }
 void orc_env_step_basic(void* h, const double* action, double* obs) { env_step_basic(*(Env*)h, action, obs); }
+void orc_env_set_command_profile(void* h, int cp) { ((Env*)h)->cfg.command_profile = cp; }     // 1 / 2 = phase (obs 55)
 void orc_env_set_kind(void* h, int kind) { ((Env*)h)->cfg.env_kind = kind; }     // 1 = CassieTraj-v0 (trajectory-pose reset)
 void orc_traj_ref_state(double phase, double phaselen, double speed, int counter, double* qpos, double* qvel) { traj_ref_state(phase, phaselen, speed, counter, qpos, qvel); }
 void orc_env_update_speed(void* h, double speed, double side_speed) { env_update_speed(*(Env*)h, speed, side_speed); }
@@ -75,7 +77,7 @@ static int field(Env& e, const char* name, double* io, bool set) {
     FIELD("snap_mpos", e.snap_mpos, 10) FIELD("snap_jpos", e.snap_jpos, 6)
     FIELD("l_foot_vel", e.l_foot_vel, 3) FIELD("r_foot_vel", e.r_foot_vel, 3)
     FIELD("reward_terms", e.last_reward_terms, 8) FIELD("clock_x", e.clock.x, 8) FIELD("phaselen", &e.clock.phaselen, 1)
-    FIELD("prev_action", e.prev_action, 10) FIELD("prev_torque", e.prev_torque, 10)
+    FIELD("swing_stance", &e.swing_duration, 2) FIELD("prev_action", e.prev_action, 10) FIELD("prev_torque", e.prev_torque, 10)
     FIELD("tq_fifo", e.tq_fifo, 60)
     if (!std::strcmp(name, "xpos")) { if (!set) std::memcpy(io, e.st.xpos, sizeof(double) * 3 * NB); return 3 * NB; }
     if (!std::strcmp(name, "xquat")) { if (!set) std::memcpy(io, e.st.xquat, sizeof(double) * 4 * NB); return 4 * NB; }
@@ -92,6 +94,16 @@ int orc_env_get(void* h, const char* name, double* out) { return field(*(Env*)h,
 int orc_env_set(void* h, const char* name, const double* in) { return field(*(Env*)h, name, (double*)in, true); }
 void orc_env_set_const(void* h) { set_const(((Env*)h)->par); }
 void orc_env_set_kernel_caps(void* h, int on) { ((Env*)h)->par.kernel_caps = on; }
+// CassieSim("cassie_hfield.xml") + set_hfield_data (util/eval.py:73-76): the env keeps its own copy; data == nullptr goes back to the plane
+void orc_env_set_hfield(void* h, const float* data, int nrow, int ncol, double sx, double sy, double sz) {
+    Env& e = *(Env*)h;
+    std::free(const_cast<float*>(e.par.hf_data)); e.par.hf_data = nullptr;
+    if (!data) return;
+    float* own = (float*)std::malloc(sizeof(float) * (size_t)nrow * ncol);
+    std::memcpy(own, data, sizeof(float) * (size_t)nrow * ncol);
+    e.par.hf_data = own; e.par.hf_nrow = nrow; e.par.hf_ncol = ncol; e.par.hf_size[0] = sx; e.par.hf_size[1] = sy; e.par.hf_size[2] = sz;
+}
+void orc_floor_query(void* h, double x, double y, double* out) { double hh; V3 n; floor_query(((Env*)h)->par, x, y, hh, n); out[0] = hh; out[1] = n.x; out[2] = n.y; out[3] = n.z; }
 
 void orc_clock_eval(double swing, double stance, double relax, int mode, int inc, int freq, int n, const double* ph,
                     double* out, double* phaselen) {

@@ -252,7 +252,11 @@ void env_obs(const Env& e, double* o) {
     for (int k = 0; k < 6; ++k) o[40 + k] = e.so_jvel[k];
     o[46] = std::sin(2 * PI * e.phase / e.clock.phaselen);
     o[47] = std::cos(2 * PI * e.phase / e.clock.phaselen);
-    o[48] = e.speed; o[49] = e.side_speed;
+    if (e.cfg.command_profile == 0) { o[48] = e.speed; o[49] = e.side_speed; return; }
+    // command_profile "phase" (cassie.py:805-808): clock, swing / stance duration, encode_stance_mode (grounded, aerial, zero), speed, side speed
+    o[48] = e.swing_duration; o[49] = e.stance_duration;
+    o[50] = e.cfg.stance_mode == 1; o[51] = e.cfg.stance_mode == 2; o[52] = e.cfg.stance_mode == 0;
+    o[53] = e.speed; o[54] = e.side_speed;
 }
 
 void env_init(Env& e, const EnvCfg& cfg, uint32_t env_id) {
@@ -269,6 +273,7 @@ static void set_clock_from_speed(Env& e) {   // cassie.py:556-559
     const double total = (0.9 - 0.25 / 3.0 * std::fabs(e.speed)) / 2;
     const double swing = (0.30 + ((0.70 - 0.30) / 3) * std::fabs(e.speed)) * total;
     const double stance = (0.70 - ((0.70 - 0.30) / 3) * std::fabs(e.speed)) * total;
+    e.swing_duration = swing; e.stance_duration = stance;
     make_clock(e.clock, swing, stance, 0.1, e.cfg.stance_mode, e.cfg.have_incentive, 2000 / e.cfg.simrate);
 }
 
@@ -294,10 +299,12 @@ void env_clock_from_speed(Env& e) { set_clock_from_speed(e); }
 void env_update_speed(Env& e, double new_speed, double new_side_speed) {
     e.speed = std::min(std::max(new_speed, -0.3), 4.0);
     e.side_speed = std::min(std::max(new_side_speed, -0.3), 0.3);
+    if (e.cfg.command_profile != 0) return;      // cassie.py:756-761: the phase profile keeps its durations (set_up_phase_reward only resets flags), phase unchanged
     const double total = (0.9 - 0.25 / 3.0 * e.speed) / 2;
     const double swing = (0.30 + ((0.70 - 0.30) / 3) * e.speed) * total;
     const double stance = (0.70 - ((0.70 - 0.30) / 3) * e.speed) * total;
     const double old_phaselen = e.clock.phaselen;
+    e.swing_duration = swing; e.stance_duration = stance;
     make_clock(e.clock, swing, stance, 0.1, e.cfg.stance_mode, e.cfg.have_incentive, 2000 / e.cfg.simrate);
     e.phase = (int)(e.clock.phaselen * e.phase / old_phaselen);
 }
@@ -310,6 +317,7 @@ void env_reset_for_test(Env& e, double* obs, bool full_reset) {
     static thread_local Work w;
     e.phase = 0; e.time = 0; e.counter = 0; e.orient_add = 0; e.speed = 0;
     e.cfg.stance_mode = 1;
+    e.swing_duration = 0.15; e.stance_duration = 0.25;
     make_clock(e.clock, 0.15, 0.25, 0.1, e.cfg.stance_mode, e.cfg.have_incentive, 2000 / e.cfg.simrate);
     if (!full_reset) {
         e.l_foot_frc = e.r_foot_frc = e.l_foot_orient_cost = e.r_foot_orient_cost = 0;
@@ -366,7 +374,19 @@ void env_reset(Env& e, double* obs) {
     Philox& r = e.rng;
     e.speed = e.cfg.env_kind == 1 ? (double)r.randint(41) / 10 : r.uniform(-0.3, 4.0);      // cassie_traj.py:608: random.randint(0, 40) / 10
     e.side_speed = r.uniform(-0.3, 0.3);
-    set_clock_from_speed(e);
+    if (e.cfg.command_profile == 0) set_clock_from_speed(e);
+    else {      // command_profile "phase", cassie.py:529-545: swing / stance duration and stance mode drawn per episode
+        double swing, stance;
+        if (e.cfg.command_profile == 2) {                // "library" in the reward string (:531-539)
+            e.speed = (double)r.randint(31) / 10;
+            const double total = (double)(3 + r.randint(4)) / 10, ratio = (double)(2 + r.randint(7)) / 10;
+            swing = total * ratio; stance = total - swing;
+        } else { swing = (double)(1 + r.randint(50)) / 100; stance = (double)(1 + r.randint(30)) / 100; }
+        const uint32_t pick = r.randint(3);              // np.random.choice(["grounded", "aerial", "zero"])
+        e.cfg.stance_mode = pick == 0 ? 1 : pick == 1 ? 2 : 0;
+        e.swing_duration = swing; e.stance_duration = stance;
+        make_clock(e.clock, swing, stance, 0.1, e.cfg.stance_mode, e.cfg.have_incentive, 2000 / e.cfg.simrate);
+    }
     e.phase = (int)r.randint((uint32_t)std::floor(e.clock.phaselen) + 1);   // random.randint(0, floor(phaselen)) inclusive
     e.time = 0; e.counter = 0;
     if (e.cfg.dynamics_randomization) {

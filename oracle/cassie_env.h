@@ -28,6 +28,7 @@ struct EnvCfg {
     int max_traj_len = 400;
     int pgs_iters = 50;
     uint64_t seed = 0;
+    int command_profile = 0;  // 0 clock (obs 50), 1 phase (cassie.py:266-271,529-545,805-808: obs 55), 2 phase with the "library" draws (:531-539)
     int env_kind = 0;         // 0 Cassie-v0 (cassie/cassie.py), 1 CassieTraj-v0 with the CLI defaults (cassie/cassie_traj.py: trajectory-pose reset)
 };
 
@@ -49,6 +50,7 @@ struct Env {
     int time, phase, counter;
     double speed, side_speed, orient_add;
     Clock clock;
+    double swing_duration, stance_duration;     // of the current clock (observed by the phase command profile)
     // encoder offsets (cassie.py:652-654)
     double motor_noise[10], joint_noise[6];
     // pd_in_t persists across resets (cassie.py:665 steps with the stale self.u)

@@ -160,6 +160,31 @@ static void finish_row(Row& r, const double* qvel, double imp_pos, double timeco
     r.aref = -B * r.vel - K * imp * r.pos;
 }
 
+// Height field of cassie_hfield.xml as MuJoCo lays it out (hfield_data row-major, rows along y, columns along x, elevation =
+// data * size[2]; the geom sits at the origin).  Every grid cell is split into the two triangles (00, 10, 01) and (11, 01, 10); a point
+// collides with the plane of the triangle under it.  MuJoCo itself collides the capsule with triangular PRISMS through its general
+// convex routine (mjc_ConvexHField, closed source): same surface, contact point / normal can differ near cell edges.
+void floor_query(const Params& p, double x, double y, double& hh, V3& n) {
+    if (!p.hf_data) {
+        const M3 Rf = q2m(p.floor_quat);
+        n = col(Rf, 2);
+        const V3 p0 = v3(cm_floor_pos);
+        hh = p0.z - (n.x * (x - p0.x) + n.y * (y - p0.y)) / n.z;
+        return;
+    }
+    const int nc = p.hf_ncol, nr = p.hf_nrow;
+    const double dx = 2 * p.hf_size[0] / (nc - 1), dy = 2 * p.hf_size[1] / (nr - 1);
+    double u = std::min(std::max((x + p.hf_size[0]) / dx, 0.0), nc - 1 - 1e-9), v = std::min(std::max((y + p.hf_size[1]) / dy, 0.0), nr - 1 - 1e-9);
+    const int c = (int)u, r = (int)v;
+    const double fu = u - c, fv = v - r, sz = p.hf_size[2];
+    const double h00 = sz * p.hf_data[r * nc + c], h10 = sz * p.hf_data[r * nc + c + 1], h01 = sz * p.hf_data[(r + 1) * nc + c], h11 = sz * p.hf_data[(r + 1) * nc + c + 1];
+    double gx, gy;
+    if (fu + fv <= 1) { gx = (h10 - h00) / dx; gy = (h01 - h00) / dy; hh = h00 + fu * (h10 - h00) + fv * (h01 - h00); }
+    else { gx = (h11 - h01) / dx; gy = (h11 - h10) / dy; hh = h11 + (1 - fu) * (h01 - h11) + (1 - fv) * (h10 - h11); }
+    const double inv = 1.0 / std::sqrt(gx * gx + gy * gy + 1);
+    n = {-gx * inv, -gy * inv, inv};
+}
+
 void default_params(Params& p) {
     for (int b = 0; b < NB; ++b) p.mass[b] = cm_body_mass[b];
     for (int d = 0; d < NV; ++d) p.damping[d] = cm_dof_damping[d];
@@ -272,13 +297,39 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
     // solution of the strictly convex dual for any sweep order, only the iterates differ.
     int n = 0;
     Row* rows = w.rows;
-    const M3 Rf = q2m(p.floor_quat);
-    const V3 nrm = col(Rf, 2), p0 = v3(cm_floor_pos);
-    V3 t1 = std::fabs(nrm.y) < 0.5 ? V3{0, 1, 0} : V3{0, 0, 1};      // mju_makeFrame
-    t1 = t1 - nrm * dot(nrm, t1); t1 = t1 * (1.0 / norm(t1));
-    const V3 t2 = cross(nrm, t1);
     s.ncon = 0; s.sat = 0;
     int con_row[MAXCON];
+    // signed distance of a sphere (centre ctr, radius rad) to the floor under it: the plane (cassie.xml:73, tilted by dynamics randomisation)
+    // or the height-field triangle (cassie_hfield.xml:74); nrm = that surface's unit normal
+    auto floor_dist = [&](V3 ctr, double rad, V3& nrm) {
+        double hh;
+        floor_query(p, ctr.x, ctr.y, hh, nrm);
+        return (ctr.z - hh) * nrm.z - rad;       // (ctr - (x, y, h)) . n
+    };
+    // pyramidal floor contact (condim 3): 4 rows n +- mu t1, n +- mu t2 in the contact's own frame (mju_makeFrame)
+    auto add_floor_contact = [&](int g, int b, V3 ctr, double dist, V3 nrm) {
+        V3 t1 = std::fabs(nrm.y) < 0.5 ? V3{0, 1, 0} : V3{0, 0, 1};
+        t1 = t1 - nrm * dot(nrm, t1); t1 = t1 * (1.0 / norm(t1));
+        const V3 t2 = cross(nrm, t1);
+        const V3 cp = ctr - nrm * (cm_geom_radius[g] + 0.5 * dist);
+        double Jx[NV] = {0}, Jy[NV] = {0}, Jz[NV] = {0};
+        jac_point(w, b, cp, Jx, Jy, Jz, 1.0);
+        const double mu = p.friction;
+        const double tran = p.body_invweight0[b][0];     // + world (0)
+        const V3 dirs[4] = {nrm + t1 * mu, nrm - t1 * mu, nrm + t2 * mu, nrm - t2 * mu};
+        con_row[s.ncon] = n; s.con_dist[s.ncon] = dist; s.con_geom[s.ncon] = g;
+        s.con_frame[s.ncon][0] = nrm; s.con_frame[s.ncon][1] = t1; s.con_frame[s.ncon][2] = t2;
+        for (int k = 0; k < 4; ++k) {
+            Row& r = rows[n + k];
+            for (int d = 0; d < NV; ++d) r.J[d] = dirs[k].x * Jx[d] + dirs[k].y * Jy[d] + dirs[k].z * Jz[d];
+            r.pos = dist; r.type = 2; r.diag = tran + mu * mu * tran;
+            finish_row(r, s.qvel, dist, 0.005, 1.0);
+        }
+        // pyramidal regulariser: all rows of the contact share Rpy = 2 mu^2 R(first row), impratio = 1
+        const double Rpy = std::max(MINVAL, 2 * mu * mu * rows[n].R);
+        for (int k = 0; k < 4; ++k) rows[n + k].R = Rpy;
+        n += 4; ++s.ncon;
+    };
     for (int leg = 0; leg < 2; ++leg) {
         const int body_lo = leg == 0 ? 2 : 14, body_hi = leg == 0 ? 13 : 25;
         for (int e = 2 * leg; e < 2 * leg + 2; ++e) {   // connect equalities, cassie.xml:225-230
@@ -322,52 +373,23 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
             const V3 ax = mul(s.xmat[b], v3(cm_geom_axis + 3 * g));
             for (int e = 0; e < 2 && ncl < MAXCON_LEG; ++e) {
                 const V3 ctr = c + ax * (e == 0 ? cm_geom_half[g] : -cm_geom_half[g]);
-                const double dist = dot(ctr - p0, nrm) - cm_geom_radius[g];
+                V3 nrm;
+                const double dist = floor_dist(ctr, cm_geom_radius[g], nrm);
                 if (dist >= 0) continue;
                 if (g >= 6) { s.sat |= SAT_BODY_FLOOR; if (p.kernel_caps) continue; }
                 else if (ncl >= KERNEL_MAXCON_LEG) { s.sat |= SAT_CONTACTS; if (p.kernel_caps) continue; }
-                const V3 cp = ctr - nrm * (cm_geom_radius[g] + 0.5 * dist);
-                double Jx[NV] = {0}, Jy[NV] = {0}, Jz[NV] = {0};
-                jac_point(w, b, cp, Jx, Jy, Jz, 1.0);
-                const double mu = p.friction;
-                const double tran = p.body_invweight0[b][0];     // + world (0)
-                const V3 dirs[4] = {nrm + t1 * mu, nrm - t1 * mu, nrm + t2 * mu, nrm - t2 * mu};
-                con_row[s.ncon] = n; s.con_dist[s.ncon] = dist; s.con_geom[s.ncon] = g;
-                for (int k = 0; k < 4; ++k) {
-                    Row& r = rows[n + k];
-                    for (int d = 0; d < NV; ++d) r.J[d] = dirs[k].x * Jx[d] + dirs[k].y * Jy[d] + dirs[k].z * Jz[d];
-                    r.pos = dist; r.type = 2; r.diag = tran + mu * mu * tran;
-                    finish_row(r, s.qvel, dist, 0.005, 1.0);
-                }
-                // pyramidal regulariser: all rows of the contact share Rpy = 2 mu^2 R(first row), impratio = 1
-                const double Rpy = std::max(MINVAL, 2 * mu * mu * rows[n].R);
-                for (int k = 0; k < 4; ++k) rows[n + k].R = Rpy;
-                n += 4; ++s.ncon; ++ncl;
+                add_floor_contact(g, b, ctr, dist, nrm);
+                ++ncl;
             }
         }
     }
     {   // pelvis sphere vs the floor (cassie.xml:87; mjc_PlaneSphere), pyramidal like the other floor contacts
         const int g = 8, b = cm_geom_body[g];
         const V3 ctr = s.xpos[b] + mul(s.xmat[b], v3(cm_geom_pos + 3 * g));
-        const double dist = dot(ctr - p0, nrm) - cm_geom_radius[g];
+        V3 nrm;
+        const double dist = floor_dist(ctr, cm_geom_radius[g], nrm);
         if (dist < 0) s.sat |= SAT_BODY_FLOOR;
-        if (dist < 0 && !p.kernel_caps) {
-            const V3 cp = ctr - nrm * (cm_geom_radius[g] + 0.5 * dist);
-            double Jx[NV] = {0}, Jy[NV] = {0}, Jz[NV] = {0};
-            jac_point(w, b, cp, Jx, Jy, Jz, 1.0);
-            const double mu = p.friction, tran = p.body_invweight0[b][0];
-            const V3 dirs[4] = {nrm + t1 * mu, nrm - t1 * mu, nrm + t2 * mu, nrm - t2 * mu};
-            con_row[s.ncon] = n; s.con_dist[s.ncon] = dist; s.con_geom[s.ncon] = g;
-            for (int k = 0; k < 4; ++k) {
-                Row& r = rows[n + k];
-                for (int d = 0; d < NV; ++d) r.J[d] = dirs[k].x * Jx[d] + dirs[k].y * Jy[d] + dirs[k].z * Jz[d];
-                r.pos = dist; r.type = 2; r.diag = tran + mu * mu * tran;
-                finish_row(r, s.qvel, dist, 0.005, 1.0);
-            }
-            const double Rpy = std::max(MINVAL, 2 * mu * mu * rows[n].R);
-            for (int k = 0; k < 4; ++k) rows[n + k].R = Rpy;
-            n += 4; ++s.ncon;
-        }
+        if (dist < 0 && !p.kernel_caps) add_floor_contact(g, b, ctr, dist, nrm);
     }
     // left-leg vs right-leg capsules (contype 2 / conaffinity 4 against contype 4 / conaffinity 2, cassie.xml:23-35): foot, tarsus, shin
     // of one leg against foot, tarsus, shin of the other, condim 1 (frictionless): one unilateral row along the contact normal
@@ -448,7 +470,7 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
         if (foot < 0) continue;
         const double* ff = f + con_row[c];
         const double fn = ff[0] + ff[1] + ff[2] + ff[3], f1 = p.friction * (ff[0] - ff[1]), f2 = p.friction * (ff[2] - ff[3]);
-        const V3 F = nrm * fn + t1 * f1 + t2 * f2;
+        const V3 F = s.con_frame[c][0] * fn + s.con_frame[c][1] * f1 + s.con_frame[c][2] * f2;
         s.foot_force[foot][0] += F.x; s.foot_force[foot][1] += F.y; s.foot_force[foot][2] += F.z;
     }
     // IMU (cassie.xml:265-268): gyro = pelvis angular velocity in the site (= pelvis) frame; accelerometer = classical

@@ -99,6 +99,9 @@ struct Params {                  // per-env model parameters touched by dynamics
     double body_invweight0[NB][2];
     double dof_invweight0[NV];
     int pgs_iters;
+    // terrain (cassie_hfield.xml:69,74, util/eval.py:73-76): when hf_data != nullptr the floor is a height field instead of the plane:
+    // hf_nrow x hf_ncol samples (row = y, column = x) over [-hf_size[0], hf_size[0]] x [-hf_size[1], hf_size[1]], elevation = data * hf_size[2]
+    const float* hf_data = nullptr; int hf_nrow = 0, hf_ncol = 0; double hf_size[3] = {0, 0, 0};
     int kernel_caps = 0;         // 1: instantiate only what the HIP kernel instantiates (first KERNEL_MAX* per leg, no pelvis / hip-pitch / leg-leg rows);
                                  // `State::sat` is reported either way, so a test can check the kernel's arithmetic on a saturated state AND its flag
 };
@@ -117,6 +120,7 @@ struct State {
     double sens_acc[3];          // accelerometer at the imu site (cassie.xml:267), sensor frame
     double sens_gyro[3];
     double con_dist[MAXCON]; int con_geom[MAXCON];
+    V3 con_frame[MAXCON][3];     // contact frames (normal, two tangents) of the floor contacts of the most recent forward pass
     int sat;                     // SatFlag bits of the most recent forward pass: the constraint set exceeded what the HIP kernel instantiates
     int ncon1;                   // leg-leg (frictionless) contacts of the most recent forward pass
     double xfrc[6] = {0, 0, 0, 0, 0, 0};   // mjData.xfrc_applied row of cassie-pelvis: world force xyz, torque xyz, applied at the body COM
@@ -140,6 +144,8 @@ void euler(const Params& p, State& s, Work& w);                   // mj_Euler wi
 inline void step(const Params& p, State& s, Work& w, const double* ctrl) { forward(p, s, w, ctrl); euler(p, s, w); }
 
 // diagnostics used by the invariant tests
+// surface under (x, y): elevation and unit normal of the height-field triangle there (flat plane z = floor pos when no height field is set)
+void floor_query(const Params& p, double x, double y, double& h, V3& n);
 double constraint_violation(const State& s);                      // max |p1-p2| over the 4 connect constraints
 void com_velocity(const Params& p, const State& s, Work& w, double out[3]);   // total linear momentum / total mass
 double total_energy(const Params& p, const State& s, Work& w);    // kinetic + gravity + spring potential

@@ -28,6 +28,7 @@ def lib():
         L.orc_env_reset_for_test.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_env_apply_force.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_env_set_kind.argtypes = [C.c_void_p, C.c_int]
+        L.orc_env_set_command_profile.argtypes = [C.c_void_p, C.c_int]
         L.orc_traj_ref_state.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_env_set_command.argtypes = [C.c_void_p, C.c_double, C.c_int]
         L.orc_env_obs.argtypes = [C.c_void_p, C.c_void_p]
@@ -44,6 +45,8 @@ def lib():
         L.orc_env_set.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
         L.orc_env_set_const.argtypes = [C.c_void_p]
         L.orc_env_set_kernel_caps.argtypes = [C.c_void_p, C.c_int]
+        L.orc_env_set_hfield.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
+        L.orc_floor_query.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p]
         L.orc_clock_eval.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p]
         L.orc_clock_reward_eval.restype = C.c_double
@@ -63,11 +66,14 @@ def _ptr(a):
 
 class OracleEnv:
     def __init__(self, simrate=50, dyn_rand=True, reward_kind=0, stance_mode=0, incentive=True, max_traj_len=400,
-                 pgs_iters=50, seed=0, env_id=0, env_kind=0):
+                 pgs_iters=50, seed=0, env_id=0, env_kind=0, command_profile=0):
         self.h = lib().orc_env_new(simrate, int(dyn_rand), reward_kind, stance_mode, int(incentive), max_traj_len,
                                    pgs_iters, seed, env_id)
+        self.obs_dim = 50 if command_profile == 0 else 55
         if env_kind:
             lib().orc_env_set_kind(self.h, int(env_kind))
+        if command_profile:      # 1 phase, 2 phase with the "library" draws
+            lib().orc_env_set_command_profile(self.h, int(command_profile))
 
     def __del__(self):
         try:
@@ -78,13 +84,13 @@ class OracleEnv:
             pass
 
     def reset(self):
-        obs = np.zeros(50)
+        obs = np.zeros(self.obs_dim)
         lib().orc_env_reset(self.h, _ptr(obs))
         return obs
 
     def step(self, action):
         a = np.ascontiguousarray(action, dtype=np.float64)
-        obs = np.zeros(50); rew = np.zeros(1)
+        obs = np.zeros(self.obs_dim); rew = np.zeros(1)
         done = lib().orc_env_step(self.h, _ptr(a), _ptr(obs), _ptr(rew))
         return obs, float(rew[0]), done
 
@@ -92,7 +98,7 @@ class OracleEnv:
         lib().orc_env_substep(self.h)
 
     def step_basic(self, action):
-        a = np.ascontiguousarray(action, dtype=np.float64); obs = np.zeros(50)
+        a = np.ascontiguousarray(action, dtype=np.float64); obs = np.zeros(self.obs_dim)
         lib().orc_env_step_basic(self.h, _ptr(a), _ptr(obs))
         return obs
 
@@ -103,7 +109,7 @@ class OracleEnv:
         lib().orc_env_set_command(self.h, float(speed0), int(phase))
 
     def reset_for_test(self, full_reset=False):
-        obs = np.zeros(50)
+        obs = np.zeros(self.obs_dim)
         lib().orc_env_reset_for_test(self.h, _ptr(obs), int(bool(full_reset)))
         return obs
 
@@ -113,7 +119,7 @@ class OracleEnv:
         lib().orc_env_apply_force(self.h, _ptr(x))
 
     def obs(self):
-        o = np.zeros(50)
+        o = np.zeros(self.obs_dim)
         lib().orc_env_obs(self.h, _ptr(o))
         return o
 
@@ -154,6 +160,19 @@ class OracleEnv:
         saturation flags (`get("ints")[8]`) still report everything cassie.xml would add."""
         lib().orc_env_set_kernel_caps(self.h, int(bool(on)))
         return self
+
+    def set_hfield(self, data, size=(50.0, 50.0, 0.15)):
+        """CassieSim("cassie_hfield.xml").set_hfield_data(data) (util/eval.py:73-76): data [nrow, ncol] raw elevations (x size[2]), rows along y."""
+        if data is None:
+            lib().orc_env_set_hfield(self.h, None, 0, 0, 0.0, 0.0, 0.0); return self
+        d = np.ascontiguousarray(data, dtype=np.float32)
+        lib().orc_env_set_hfield(self.h, _ptr(d), d.shape[0], d.shape[1], float(size[0]), float(size[1]), float(size[2]))
+        return self
+
+    def floor_query(self, x, y):
+        out = np.zeros(4)
+        lib().orc_floor_query(self.h, float(x), float(y), _ptr(out))
+        return out[0], out[1:]
 
     def set_const(self):
         lib().orc_env_set_const(self.h)

@@ -604,3 +604,121 @@ def test_physics_invariants_on_the_hip_side(dev):
         fz_sum += fwd[:, :2].sum(1)
     w = 33.3 * 9.81
     assert 0.5 * w < float(fz_sum.mean()) / 8 < 1.5 * w          # the feet carry the robot's weight on average
+
+
+@pytest.mark.parametrize("reward,cp", [("clock", 1), ("library_clock", 2)])
+def test_phase_command_profile_vs_oracle(dev, reward, cp):
+    """Row f4: command_profile="phase" (cassie.py:266-271,529-545,805-808).  Per-reset swing / stance duration and stance mode (integer
+    draws: bit-exact vs the oracle, which golden G22 pins against the reference), the 55-entry observation with the 9-entry command tail,
+    per-env clocks in the reward, update_speed that keeps the clock."""
+    from apex_amd.vecenv import CassieVecEnv
+    g = CassieVecEnv(n_envs=N, seed=13, command_profile="phase", reward=reward)
+    assert g.obs_dim == 55 and g.observation_space.shape == (55,) and len(g.mirrored_obs) == 55
+    o = [S.OracleEnv(dyn_rand=True, seed=13, env_id=i, command_profile=cp) for i in range(8)]
+    obs = g.reset().cpu().numpy()
+    assert obs.shape == (N, 55)
+    cmd = g.get_field("cmd").cpu().numpy(); ints = g.get_field("ints").cpu().numpy()
+    modes = set()
+    for i, e in enumerate(o):
+        ob = e.reset()
+        sw = e.get("swing_stance")
+        np.testing.assert_allclose(cmd[i, 3:5], sw, rtol=1e-6)                  # (k / 100) in fp32
+        assert abs(cmd[i, 5] - e.get("phaselen")[0]) < 1e-4 and int(ints[i, 1]) == int(e.get("ints")[1])
+        np.testing.assert_allclose(obs[i, 46:], ob[46:], atol=2e-6)               # clock, swing, stance, one-hot mode, speeds
+        np.testing.assert_allclose(obs[i, :46], ob[:46], rtol=1e-4, atol=3e-4)
+        assert obs[i, 50:53].sum() == 1.0
+        modes.add(int(cmd[i, 6]))
+    assert set(np.unique(cmd[:, 6]).astype(int)) == {0, 1, 2}                     # all three stance modes occur over the batch
+    rng = np.random.RandomState(1)
+    for t in range(6):
+        act = (rng.randn(N, 10) * 0.15).astype(np.float32)
+        ob, rew, done, _ = g.step(torch.tensor(act, device=dev), auto_reset=False)
+        ob, rew, done = ob.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        for i, e in enumerate(o):
+            oo, rr, dd = e.step(act[i].astype(np.float64))
+            assert dd == done[i]
+            np.testing.assert_allclose(ob[i, 46:], oo[46:], atol=2e-6)
+            np.testing.assert_allclose(ob[i, :15], oo[:15], atol=3e-3 * (t + 1))
+            assert abs(rew[i] - rr) < 0.02 * (t + 1), (t, i, rew[i], rr)
+    g.update_speed(1.5, 0.1)
+    c2 = g.get_field("cmd").cpu().numpy()
+    np.testing.assert_allclose(c2[:, :2], [[1.5, 0.1]] * N); np.testing.assert_allclose(c2[:, 3:7], cmd[:, 3:7])      # durations / mode kept
+
+
+def test_ppo_iteration_on_the_phase_profile(dev, tmp_path):
+    """The driver + HIP learner with the 55-entry observation of command_profile="phase": mirror lists of length 55, fused 2 x 256 forward
+    with D = 55, one whole iteration, checkpoint classes with 55 inputs."""
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd.ppo import PPO
+    env = CassieVecEnv(n_envs=256, seed=2, command_profile="phase", reward="clock", max_traj_len=20)
+    args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=1024, epochs=2, num_steps=256 * 16, max_traj_len=20,
+                max_grad_norm=0.05, mirror=True, std_dev=-1.5, seed=0)
+    algo = PPO(args, str(tmp_path), env)
+    algo.init_networks(0); algo.normalization_params(256 * 50)
+    assert algo.D == 55 and algo.learner.actor.D == 55 and algo.b_obs.shape == (16, 256, 55)
+    out = algo.iteration()
+    assert np.isfinite(out["losses"]).all() and out["losses"][3] > 0.5 and out["losses"][5] >= 0
+    # mirror loss of the phase-profile lists: a policy is compared with itself on M_s s; the command tail maps onto itself
+    o = algo.b_obs.view(-1, 55)[:64]
+    sp = algo.learner.obs_sp.cpu().numpy()
+    assert (sp[46:] == np.arange(46, 55)).all()
+    algo.save()
+    pol = torch.load(str(tmp_path / "actor.pt"), weights_only=False)
+    assert pol(torch.zeros(55), deterministic=True).shape[-1] == 10
+
+
+def _terrain(kind, n=41, seed=0):
+    """small synthetic height fields over [-4, 4] x [-4, 4] (0.2 m cells like cassie_hfield.xml's 500 x 500 over 100 m): raw values, scale 0.15"""
+    xs = np.linspace(-4, 4, n)
+    X, Y = np.meshgrid(xs, xs)                       # rows along y, columns along x
+    if kind == "slope":
+        return (0.5 + 0.6 * X / 4).astype(np.float32)                     # 2.25 % grade in x after the 0.15 scale
+    if kind == "noise":                                                   # like terrains/noise*.npy: values in [0, 0.25] -> bumps up to 3.75 cm
+        return (0.25 * np.random.RandomState(seed).rand(n, n)).astype(np.float32)
+    return (0.3 + 0.3 * np.sin(1.3 * X) * np.cos(0.9 * Y)).astype(np.float32)      # rolling hills, +-4.5 cm
+
+
+@pytest.mark.parametrize("kind", ["slope", "noise", "hills"])
+def test_heightfield_terrain_vs_oracle(dev, kind):
+    """Row f4, terrain: CassieSim("cassie_hfield.xml") + set_hfield_data (util/eval.py:73-76) as apx_env_set_hfield.  The foot / tarsus /
+    shin capsule ends collide with the grid triangle under them, each contact in its own frame.  HIP vs the fp64 oracle (same triangle
+    rule): single substeps on crafted poses (qacc), then env steps from reset_for_test with the PD hold."""
+    from apex_amd.vecenv import CassieVecEnv
+    hf = _terrain(kind)
+    size = (4.0, 4.0, 0.15)
+    g = CassieVecEnv(n_envs=N, seed=4, dynamics_randomization=False, max_traj_len=1000)
+    g.set_hfield(hf, size)
+    o = [S.OracleEnv(dyn_rand=False, seed=4, env_id=i).set_hfield(hf, size) for i in range(6)]
+    g.reset_for_test(); [e.reset_for_test() for e in o]
+    # the robot starts at the origin: lift / shift it so that the feet meet the terrain at different places
+    q = g.get_field("qpos").cpu().numpy().astype(np.float64)
+    rng = np.random.RandomState(3)
+    for i in range(N):
+        q[i, 0] = rng.uniform(-2.5, 2.5); q[i, 1] = rng.uniform(-2.5, 2.5)
+        hh, _ = o[0].floor_query(q[i, 0], q[i, 1])
+        q[i, 2] = 1.0 + hh + rng.uniform(-0.06, 0.0)                     # feet 1-6 cm into the surface
+    g.set_field("qpos", torch.tensor(q, dtype=torch.float32)); g.set_field("qvel", torch.zeros(N, 32)); g.set_field("qacc_warm", torch.zeros(N, 32))
+    g.substep()
+    qa = g.get_field("qacc_warm").cpu().numpy()
+    ncon = 0
+    for i, e in enumerate(o):
+        e.set("qpos", q[i].astype(np.float32).astype(np.float64)); e.set("qvel", np.zeros(32)); e.set("qacc_warm", np.zeros(32))
+        e.kernel_caps(True)
+        e.substep()
+        ncon += int(e.get("ints")[3])
+        ref = e.get("qacc_warm"); scale = np.maximum(1.0, np.abs(ref))
+        tol = np.full(32, 3e-2); tol[[9, 22]] = 0.25
+        assert np.all(np.abs(qa[i] - ref) / scale <= tol), (kind, i, np.abs(qa[i] - ref) / scale)
+    assert ncon >= 6
+    # env steps with the PD hold from those states
+    for t in range(4):
+        ob = g.step_basic(torch.zeros(N, 10, device=dev)).cpu().numpy()
+        for i, e in enumerate(o):
+            oo = e.step_basic(np.zeros(10))
+            np.testing.assert_allclose(ob[i, :15], oo[:15], atol=4e-3 * (t + 1), err_msg="%s t=%d env=%d" % (kind, t, i))
+    assert np.isfinite(g.get_field("qpos").cpu().numpy()).all()
+    g.set_hfield(None)                                                   # back to the plane: a robot at the origin stands at the usual height
+    g.reset_for_test()
+    for _ in range(3):
+        g.step_basic(torch.zeros(N, 10, device=dev))
+    assert abs(float(g.get_field("qpos")[:, 2].mean()) - 0.95) < 0.08

@@ -467,3 +467,56 @@ def test_full_collision_set_of_cassie_xml():
     if int(ints[3]) > 4:
         assert _flags(e) & SAT_CONTACTS
     assert int(ints[4]) == 12 + 4 * int(ints[3]) + int(ints[9]) or (_flags(e) & SAT_LIMITS)
+
+
+def test_g22_phase_command_profile(golden_dir):
+    """Row f4, command_profile="phase" (golden G22, tools/refprobe/gen_golden_phase.py): (a) state space 55 / clock indices / mirror list;
+    (b) the reference's draw order and ranges at reset (plain and "library"), and the oracle's reset re-derived draw by draw from its
+    Philox stream with those ranges; (c) the clock splines for phase-profile durations; (d) get_full_state with the 9-entry command tail."""
+    from apex_amd import vecenv as V
+    g = np.load(os.path.join(golden_dir, "g22_phase_profile.npz"))
+    # (a)
+    assert int(g["obs_size"]) == V.OBS_DIM_PHASE == 55 and list(g["clock_inds"]) == V.CLOCK_INDS
+    np.testing.assert_allclose(g["mirrored_obs"], V.MIRRORED_OBS_PHASE); np.testing.assert_allclose(g["mirrored_acts"], V.MIRRORED_ACTS)
+    assert str(g["plain_reward_func"]) == "clock" and str(g["library_reward_func"]) == "clock"
+    # (b) structure of the reference's reset (kind 0 uniform, 1 randint inclusive, 2 choice of n)
+    dp, dl = g["plain_draws"], g["library_draws"]
+    assert [tuple(r[:3]) for r in dp[:5]] == [(0, -0.3, 4.0), (0, -0.3, 0.3), (1, 1, 50), (1, 1, 30), (2, 0, 3)]
+    assert dp[5][0] == 1 and dp[5][1] == 0 and dp[5][2] == np.floor(g["plain_phase"][1])
+    assert [tuple(r[:3]) for r in dl[:6]] == [(0, -0.3, 4.0), (0, -0.3, 0.3), (1, 0, 30), (1, 3, 6), (1, 2, 8), (2, 0, 3)]
+    assert dl[6][0] == 1 and dl[6][2] == np.floor(g["library_phase"][1])
+    assert tuple(dp[-2][:3]) == (0, -0.3, 4.0) and tuple(dp[-1][:3]) == (0, -0.3, 0.3)             # commands redrawn after the settle step
+    np.testing.assert_allclose(g["plain_phase"][1], (2 * g["plain_swing_stance"].sum()) * 40)         # phaselen = (2 swing + 2 stance) * FREQ
+    # the oracle's reset, draw by draw
+    for cp, seed, eid in ((1, 3, 0), (1, 9, 4), (2, 3, 1), (2, 5, 7)):
+        e = S.OracleEnv(dyn_rand=False, seed=seed, env_id=eid, command_profile=cp)
+        obs = e.reset()
+        assert obs.shape == (55,)
+        u01 = lambda k: ((S.philox(seed, eid, k) >> 8) + 0.5) / 16777216.0
+        ri = lambda k, n: (S.philox(seed, eid, k) * n) >> 32
+        if cp == 1:
+            swing, stance, pick, k = (1 + ri(2, 50)) / 100, (1 + ri(3, 30)) / 100, ri(4, 3), 5
+        else:
+            total, ratio = (3 + ri(3, 4)) / 10, (2 + ri(4, 7)) / 10
+            swing, stance, pick, k = total * ratio, total - total * ratio, ri(5, 3), 6
+        np.testing.assert_allclose(e.get("swing_stance"), [swing, stance], rtol=1e-12)
+        plen = (2 * swing + 2 * stance) * 40
+        assert abs(e.get("phaselen")[0] - plen) < 1e-12 and int(e.get("ints")[1]) == ri(k, int(np.floor(plen)) + 1)       # random.randint(0, floor(phaselen))
+    # (c)
+    for c in range(int(g["n_cases"])):
+        swing, stance, relax, mode, inc, freq = g[f"c{c}_params"]
+        vals, pl = S.clock_eval(swing, stance, relax, int(mode), bool(inc), int(freq), g[f"c{c}_phases"])
+        assert abs(pl - float(g[f"c{c}_phaselen"])) < 1e-12
+        np.testing.assert_allclose(vals, g[f"c{c}_vals"], atol=1e-12, err_msg=f"case {c}")
+    # (d)
+    for k in range(int(g["n_obs_cases"])):
+        p = f"o{k}_"
+        phase, phaselen, speed, side, orient, pz, th, swing, stance, mode = g[p + "scal"]
+        e = S.OracleEnv(command_profile=1, stance_mode=int(mode))
+        ints = e.get("ints"); ints[1] = phase; e.set("ints", ints)
+        e.set("phaselen", [phaselen]); e.set("speed", [speed]); e.set("side_speed", [side]); e.set("orient_add", [orient]); e.set("swing_stance", [swing, stance])
+        e.set("so_height", [pz - th]); e.set("so_quat", g[p + "quat"]); e.set("so_rotvel", g[p + "rotvel"])
+        e.set("so_tvel", g[p + "tvel"]); e.set("so_tacc", g[p + "tacc"]); e.set("so_mpos", g[p + "mpos"])
+        e.set("so_mvel", g[p + "mvel"]); e.set("so_jpos", g[p + "jpos"]); e.set("so_jvel", g[p + "jvel"])
+        e.set("motor_noise", g[p + "mnoise"]); e.set("joint_noise", g[p + "jnoise"])
+        np.testing.assert_allclose(e.obs(), g[p + "obs"], atol=1e-12)
