@@ -785,6 +785,30 @@ extern "C" int apx_env_step(apx_env_t* e, const float* action, float* obs, float
     return APX_OK;
 }
 
+// ---- apx_rollout: PPO.sample's inner loop (rl/algos/ppo.py:160-181) for the whole batch as ONE C-ABI call: T x (actor forward -> action =
+// mean + sigma * noise -> env step with auto-reset), every result written straight into the caller's [T, N, .] rollout grids
+__global__ void act_noise_kernel(const float* __restrict__ mu, const float* __restrict__ noise, float sigma, long n, float* __restrict__ act) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < n) act[i] = mu[i] + (noise ? sigma * noise[i] : 0.f);
+}
+extern "C" int apx_rollout(apx_env_t* e, const float* actor, int H, const float* obs_mean, const float* obs_std, float sigma, const float* noise, int T,
+                           float* obs_grid, float* act_grid, float* mu_grid, float* rew_grid, uint8_t* done_grid, float* fin_grid, float* obs_next, void* stream) {
+    APX_REQUIRE(e && actor && obs_grid && act_grid && mu_grid && rew_grid && done_grid && fin_grid && obs_next && T > 0, "rollout arguments");
+    const int D = e->cfg.command_profile == 0 ? APX_OBS_DIM : APX_OBS_DIM_PHASE, A = APX_ACT_DIM;
+    const long N = e->n;
+    for (int t = 0; t < T; ++t) {
+        float* obs = obs_grid + (size_t)t * N * D; float* mu = mu_grid + (size_t)t * N * A; float* act = act_grid + (size_t)t * N * A;
+        int rc = apx_mlp_forward(actor, D, H, A, obs, N, nullptr, nullptr, 0, obs_mean, obs_std, nullptr, nullptr, nullptr, mu, 0, stream);
+        if (rc != APX_OK) return rc;
+        hipLaunchKernelGGL(act_noise_kernel, dim3(apx_cdiv(N * A, 256)), dim3(256), 0, (hipStream_t)stream, mu, noise ? noise + (size_t)t * N * A : nullptr, sigma, N * A, act);
+        APX_LAUNCH_CHECK();
+        rc = apx_env_step(e, act, t + 1 < T ? obs_grid + (size_t)(t + 1) * N * D : obs_next, rew_grid + (size_t)t * N, done_grid + (size_t)t * N,
+                          fin_grid + (size_t)t * N * D, 1, stream);
+        if (rc != APX_OK) return rc;
+    }
+    return APX_OK;
+}
+
 // [F, n] SoA  <->  [n, cnt] row-major
 __global__ void gather_kernel(const float* st, int n, int f0, int cnt, float* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -159,6 +159,14 @@ class PPO:
         self.b_obs[0].copy_(self.obs)
         if self.noise_fn is None:
             self.noise.normal_(generator=self.gen)                # the whole rollout's action noise in one launch
+        if self.noise_fn is None and hasattr(env, "_h"):          # the HIP env: the T-step loop is one C-ABI call (apx_rollout)
+            from ._lib import load, check
+            from .engine import _p, _stream
+            check(load().apx_rollout(env._h, _p(L.actor.params), L.actor.H, _p(L.obs_mean), _p(L.obs_std), float(self.fixed_std * self.curr_anneal),
+                                     _p(self.noise), T, _p(self.b_obs), _p(self.b_act), _p(self.b_mu), _p(self.b_rew), _p(self.b_done), _p(self.b_fin),
+                                     _p(self.obs), _stream()))
+            L.critic.forward(self.b_obs.view(T * self.N, self.D), out=self.b_val.view(T * self.N, 1))
+            return
         for t in range(T):      # every kernel writes straight into the rollout grids: no staging copies
             obs = self.b_obs[t]
             mu = L.actor.forward(obs, L.obs_mean, L.obs_std, out=self.b_mu[t])

@@ -21,3 +21,8 @@ _PGS = 50 * 20 * (2 * 19 * 2 + 8)
 _MISC = 1500
 SUBSTEP_FLOP = _FK + _INERTIA + _VEL_RNE + _CRBA + _FACTOR + _SOLVES + _ROWS + _PGS + _MISC
 ENV_STEP_FLOP = 50 * SUBSTEP_FLOP
+# The figure the roofline uses: INSTRUMENTED count of the fp64 CPU restatement (oracle/cassie_phys.cpp counts every multiply / add where it
+# happens, skipping structural zeros of its dense loops), mean over 60 env steps of a random-action rollout with
+# resets: `python -c "from oracle import sim; print(sim.count_flops(60))"` -> 6.86e6.  bench.py re-measures it in its cpu_baseline leg and
+# reports both; this constant is what is used when that leg is skipped.
+ENV_STEP_FLOP_COUNTED = 6_860_000

@@ -21,27 +21,64 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak
 
 
-def cpu_baseline(seconds_hint=12.0):
-    """The fp64 C++ oracle (kind "port") timed on this host's cores: sampling only, bounded sample."""
-    from oracle import sim
+def cpu_baseline(seconds_hint=12.0, n_envs=4096, rollout_len=32, minibatch=16384, epochs=3):
+    """The fp64 C++ oracle (kind "port") timed on this host's cores, bounded sample: sampling (one env per thread) and, beside it, the
+    end-to-end rate of one PPO iteration of the same shape (sampling at that rate + the numpy fp64 learner of oracle/learner.py timed on
+    ONE minibatch and scaled to the iteration's minibatch count).  Also returns the instrumented flop count of an env step."""
+    from oracle import sim, learner as L
+    from apex_amd.vecenv import MIRRORED_OBS, MIRRORED_ACTS
     cores = os.cpu_count() or 1
     probe = sim.rollout_bench(cores, 4, cores)                        # env-steps/s on a tiny probe
     n_steps = int(max(8, min(400, seconds_hint * probe / cores)))
     v = sim.rollout_bench(cores, n_steps, cores)
+    flop = sim.count_flops(20)
+    # learner: one minibatch of the bench shape through the fp64 numpy oracle (BLAS threads as numpy is configured)
+    rng = np.random.RandomState(0)
+    H, mb = 256, min(minibatch, 4096)
+    shapes = [(H, 50), (H,), (H, H), (H,), (10, H), (10,)]
+    Wa = [rng.randn(*s) * 0.05 for s in shapes]; Wc = [rng.randn(*s) * 0.05 for s in shapes[:4] + [(1, H), (1,)]]
+    obs = rng.randn(mb, 50); ph = rng.rand(mb) * 6.28; obs[:, 46] = np.sin(ph); obs[:, 47] = np.cos(ph); act = rng.randn(mb, 10) * 0.3; ret = rng.randn(mb, 1); adv = rng.randn(mb, 1)
+    class Keep:
+        def step(self, p, g): return p
+    t0 = time.time()
+    L.ppo_update(Wa, Wa, Wc, Keep(), Keep(), obs, act, ret, adv, np.zeros(50), np.ones(50), float(np.exp(-1.5)), M_obs=L.mirror_matrix(MIRRORED_OBS), M_act=L.mirror_matrix(MIRRORED_ACTS))
+    t_mb = (time.time() - t0) * (minibatch / mb)
+    steps_it = n_envs * rollout_len
+    t_update = t_mb * epochs * (steps_it // minibatch)
+    e2e = steps_it / (steps_it / v + t_update)
     return {"value": round(v, 1), "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} envs x {n_steps} env steps (50 substeps each), sampling only, fp64 dense oracle, one env per thread"}
+            "sample": f"{cores} envs x {n_steps} env steps (50 substeps each), sampling only, fp64 dense oracle, one env per thread",
+            "end_to_end": {"value": round(e2e, 1), "unit": "env-steps/s",
+                           "sample": f"one iteration of {steps_it} env steps at the sampling rate above + {epochs} epochs x {steps_it // minibatch} minibatches of {minibatch} "
+                                     f"through the fp64 numpy learner (timed on one {mb}-row minibatch: {t_mb:.2f} s per {minibatch} rows)"},
+            "flop_per_env_step_counted": int(flop)}
 
+
+
+def kernel_source_hash():
+    """sha1 over the env kernel's sources: a PMC profile is only quoted while it was taken on THIS kernel"""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("env.hip", "cassie_lane.h", "cassie_common.h", "env_state.h"):
+        h.update(open(os.path.join(REPO, "apex_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:12]
 
 
 def _pmc_traffic_bytes():
-    """HBM bytes per env_step_kernel launch from the committed rocprofv3 PMC passes (profiles/r01_env_step_pmc_hbm_gen4.txt,
-    4096 envs): 2 x FETCH_SIZE (gfx950 correction of the microarchitecture guide) + WRITE_SIZE, both in KB. None if absent."""
-    import os, re
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_env_step_pmc_hbm_gen4.txt")
+    """HBM bytes per env_step_kernel launch from the committed rocprofv3 PMC passes (profiles/r02_env_step_pmc_hbm.txt, 4096 envs): 2 x
+    FETCH_SIZE (gfx950 correction of the microarchitecture guide) + WRITE_SIZE, both in KB.  The profile records the hash of the kernel
+    sources it was taken on (tools/profile_round.sh); a profile of another kernel is NOT quoted: None + a note on stderr."""
+    import re
+    path = os.path.join(REPO, "profiles", "r02_env_step_pmc_hbm.txt")
     try:
         txt = open(path).read()
-        f = float(re.search(r"env_step_kernel: FETCH_SIZE=([0-9.e+]+)", txt).group(1))
-        w = float(re.search(r"env_step_kernel: WRITE_SIZE=([0-9.e+]+)", txt).group(1))
+        m = re.search(r"kernel sources sha1: (\w+)", txt)
+        if not m or m.group(1) != kernel_source_hash():
+            print("bench.py: %s was taken on another build of the env kernel (%s vs %s): roofline.traffic = null; re-run tools/profile_round.sh" % (
+                path, m.group(1) if m else "no hash", kernel_source_hash()), file=sys.stderr)
+            return None
+        f = float(re.search(r"env_step_kernel[^:]*: .*?FETCH_SIZE=([0-9.e+]+)", txt).group(1))
+        w = float(re.search(r"env_step_kernel[^:]*: .*?WRITE_SIZE=([0-9.e+]+)", txt).group(1))
         return int((2.0 * f + w) * 1024)
     except Exception:
         return None
@@ -215,6 +252,10 @@ def main():
         from apex_amd import roofline
         bytes_per_env_step = roofline.ENV_STEP_BYTES
         achieved = bytes_per_env_step * a.n_envs / (k_ms * 1e-3) / 1e9
+        cpu = None
+        if not a.no_cpu_baseline and world == 1:      # the CPU baseline is timed on rank 0 at N = 1 only; it also re-measures the flop count
+            cpu = cpu_baseline(n_envs=a.n_envs, rollout_len=a.rollout_len, minibatch=a.minibatch, epochs=a.epochs)
+        flop_step = cpu["flop_per_env_step_counted"] if cpu else roofline.ENV_STEP_FLOP_COUNTED
         res = {
             "metric": "env-steps/sec (whole node) Cassie-v0 PPO @4096 envs/GPU", "value": round(steps_total / dt, 1),
             "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -226,19 +267,20 @@ def main():
                        "parallelism": f"dp{world} (env shards, 1 RCCL grad all-reduce per optimiser step)"},
             "sampling_env_steps_per_s": round(a.steps * a.rollout_len * a.n_envs * world / max(samp, 1e-9), 1),
             "sample_s": round(samp / a.steps, 3), "optimize_s": round(opt / a.steps, 3),
-            "roofline": {"kernel": "env_step_kernel", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": _pmc_traffic_bytes(),
-                         "ms_per_launch": round(k_ms, 3), "bytes_per_env_step": bytes_per_env_step,
+            # the binding bound of the dominant kernel is the fp32 vector pipe (HBM traffic is 1.1 x the algorithmic bytes and
+            # < 0.1 % of the peak): achieved = instrumented flops of the CPU restatement per env step x envs / launch time.  The HBM view
+            # north_star asks for is reported beside it.
+            "roofline": {"kernel": "env_step_kernel", "bound": "valu", "achieved": round(flop_step * a.n_envs / (k_ms * 1e-3) / 1e12, 4),
+                         "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop_step * a.n_envs / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 6),
+                         "traffic": _pmc_traffic_bytes(), "ms_per_launch": round(k_ms, 3),
+                         "flop_per_env_step": flop_step, "flop_source": "instrumented count of oracle/cassie_phys.cpp (oracle.sim.count_flops); hand count of the tree-sparse formulation: %d" % roofline.ENV_STEP_FLOP,
+                         "hbm": {"bytes_per_env_step": bytes_per_env_step, "achieved_GBps": round(achieved, 3), "peak_GBps": HBM_PEAK_GBS, "frac": round(achieved / HBM_PEAK_GBS, 6)},
                          "mlp_forward_mfma": {"what": "actor forward, %d x (50-256-256-10), fp32 MFMA (v_mfma_f32_32x32x2_f32), one fused launch (input normalisation + 3 layers, activations in LDS)" % mb_rows,
                                               "ms": round(mlp_ms, 4), "achieved_tflops": round(mlp_flop / (mlp_ms * 1e-3) / 1e12, 2),
-                                              "peak_tflops": VALU_PEAK_TFLOPS, "frac": round(mlp_flop / (mlp_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)},
-                         "valu": {"flop_per_env_step": roofline.ENV_STEP_FLOP,
-                                  "achieved_tflops": round(roofline.ENV_STEP_FLOP * a.n_envs / (k_ms * 1e-3) / 1e12, 4),
-                                  "peak_tflops": VALU_PEAK_TFLOPS,
-                                  "frac": round(roofline.ENV_STEP_FLOP * a.n_envs / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 6)}},
+                                              "peak_tflops": VALU_PEAK_TFLOPS, "frac": round(mlp_flop / (mlp_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)}},
         }
-        if not a.no_cpu_baseline and world == 1:      # the CPU baseline is timed on rank 0 at N = 1 only
-            res["cpu_baseline"] = cpu_baseline()
+        if cpu:
+            res["cpu_baseline"] = cpu
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -223,6 +223,15 @@ int apx_env_step_basic(apx_env_t* env, const float* action, float* obs, void* st
  * that finished is reset by a second launch on the same stream; its terminal observation (needed for the bootstrap
  * value, ppo.py:183) goes to final_obs (may be NULL; rows of envs that did not finish are left untouched) and obs gets
  * the post-reset observation.                                                                all pointers [dev] */
+/* PPO.sample's rollout loop (rl/algos/ppo.py:160-181) for the whole batch as ONE call: for t < T:
+ * mu_grid[t] = actor(obs_grid[t]) (3-layer ReLU MLP, hidden H, input normalisation obs_mean / obs_std or NULL),
+ * act_grid[t] = mu_grid[t] + sigma * noise[t] (noise [T, N, act] ~ N(0, 1) supplied by the caller; NULL = deterministic),
+ * env step with auto-reset -> obs_grid[t + 1] (obs_next after the last step), rew_grid[t], done_grid[t] (1 terminated, 2 time limit),
+ * fin_grid[t] (final observation of the envs that finished).  obs_grid[0] holds the current observation on entry.  All [dev]. */
+int apx_rollout(apx_env_t* env, const float* actor, int H, const float* obs_mean, const float* obs_std, float sigma, const float* noise, int T,
+                float* obs_grid, float* act_grid, float* mu_grid, float* rew_grid, uint8_t* done_grid, float* fin_grid, float* obs_next,
+                void* stream);
+
 int apx_env_step(apx_env_t* env, const float* action, float* obs, float* reward, uint8_t* done, float* final_obs,
                  int auto_reset, void* stream);
 

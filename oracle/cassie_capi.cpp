@@ -92,6 +92,7 @@ static int field(Env& e, const char* name, double* io, bool set) {
 }
 int orc_env_get(void* h, const char* name, double* out) { return field(*(Env*)h, name, out, false); }
 int orc_env_set(void* h, const char* name, const double* in) { return field(*(Env*)h, name, (double*)in, true); }
+unsigned long long orc_flops(int reset) { const unsigned long long v = g_flops; if (reset) g_flops = 0; return v; }      // instrumented op count of this thread
 void orc_env_set_const(void* h) { set_const(((Env*)h)->par); }
 void orc_env_set_kernel_caps(void* h, int on) { ((Env*)h)->par.kernel_caps = on; }
 // CassieSim("cassie_hfield.xml") + set_hfield_data (util/eval.py:73-76): the env keeps its own copy; data == nullptr goes back to the plane

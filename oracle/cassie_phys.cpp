@@ -3,6 +3,10 @@
 
 namespace orc {
 
+thread_local unsigned long long g_flops = 0;
+#define CNT(n) (g_flops += (unsigned long long)(n))
+#define NZ(a, b) (((a) != 0.0 && (b) != 0.0) ? 2 : 0)
+
 static int body_lastdof(int b) {
     while (b > 0 && cm_body_dofnum[b] == 0) b = cm_body_parent[b];
     return b > 0 ? cm_body_dofadr[b] + cm_body_dofnum[b] - 1 : -1;
@@ -12,12 +16,13 @@ static bool cholesky(const double A[NV][NV], double L[NV][NV]) {
     for (int i = 0; i < NV; ++i)
         for (int j = 0; j <= i; ++j) {
             double s = A[i][j];
-            for (int k = 0; k < j; ++k) s -= L[i][k] * L[j][k];
+            for (int k = 0; k < j; ++k) { CNT(NZ(L[i][k], L[j][k])); s -= L[i][k] * L[j][k]; }
             if (i == j) {
                 if (s <= 0) return false;
-                L[i][i] = std::sqrt(s);
-            } else
-                L[i][j] = s / L[j][j];
+                L[i][i] = std::sqrt(s); CNT(1);
+            } else {
+                L[i][j] = s / L[j][j]; CNT(s != 0.0 ? 1 : 0);
+            }
         }
     return true;
 }
@@ -25,13 +30,13 @@ static void chol_solve(const double L[NV][NV], const double* b, double* x) {
     double y[NV];
     for (int i = 0; i < NV; ++i) {
         double s = b[i];
-        for (int k = 0; k < i; ++k) s -= L[i][k] * y[k];
-        y[i] = s / L[i][i];
+        for (int k = 0; k < i; ++k) { CNT(NZ(L[i][k], y[k])); s -= L[i][k] * y[k]; }
+        y[i] = s / L[i][i]; CNT(s != 0.0 ? 1 : 0);
     }
     for (int i = NV - 1; i >= 0; --i) {
         double s = y[i];
-        for (int k = i + 1; k < NV; ++k) s -= L[k][i] * x[k];
-        x[i] = s / L[i][i];
+        for (int k = i + 1; k < NV; ++k) { CNT(NZ(L[k][i], x[k])); s -= L[k][i] * x[k]; }
+        x[i] = s / L[i][i]; CNT(s != 0.0 ? 1 : 0);
     }
 }
 
@@ -55,15 +60,16 @@ static void kinematics(const double* qpos, State& s, Work& w) {
             else quat = qmul(quat, qnormalize(Q4{qpos[adr], qpos[adr + 1], qpos[adr + 2], qpos[adr + 3]}));
         }
         s.xquat[b] = qnormalize(quat); s.xpos[b] = pos; s.xmat[b] = q2m(s.xquat[b]);
+        CNT(15 + 3 + 28 + 13 + 30 + (cm_body_jntnum[b] ? 15 + 40 : 0));      // frame composition, joint rotation, normalisation, matrix
     }
     w.o = s.xpos[1];
     for (int d = 0; d < NV; ++d) {
         const int j = cm_dof_jnt[d], b = cm_dof_body[d];
         if (cm_jnt_type[j] == 0) w.cdof[d] = {{0, 0, 0}, axis_w[j]};
-        else if (cm_jnt_type[j] == 1) w.cdof[d] = {axis_w[j], cross(axis_w[j], w.o - w.anchor[j])};
+        else if (cm_jnt_type[j] == 1) { w.cdof[d] = {axis_w[j], cross(axis_w[j], w.o - w.anchor[j])}; CNT(12); }
         else {
             const V3 ax = col(s.xmat[b], d - cm_jnt_dofadr[j]);
-            w.cdof[d] = {ax, cross(ax, w.o - w.anchor[j])};
+            w.cdof[d] = {ax, cross(ax, w.o - w.anchor[j])}; CNT(12);
         }
     }
 }
@@ -92,16 +98,16 @@ static void inertias(const Params& p, const State& s, Work& w) {
         c.m = m; c.h = r * m;
         c.I[0] = Iw[0] + m * (rr - r.x * r.x); c.I[1] = Iw[4] + m * (rr - r.y * r.y); c.I[2] = Iw[8] + m * (rr - r.z * r.z);
         c.I[3] = Iw[1] - m * r.x * r.y; c.I[4] = Iw[2] - m * r.x * r.z; c.I[5] = Iw[5] - m * r.y * r.z;
-        w.cinert[b] = c; w.crb[b] = c;
+        w.cinert[b] = c; w.crb[b] = c; CNT(54 + 54 + 18 + 3 + 24);
     }
-    for (int b = NB - 1; b >= 1; --b) w.crb[cm_body_parent[b]] = w.crb[cm_body_parent[b]] + w.crb[b];
+    for (int b = NB - 1; b >= 1; --b) { w.crb[cm_body_parent[b]] = w.crb[cm_body_parent[b]] + w.crb[b]; CNT(10); }
     // CRBA
     for (int i = 0; i < NV; ++i)
         for (int j = 0; j < NV; ++j) w.M[i][j] = 0;
     for (int i = 0; i < NV; ++i) {
         const SV f = imul(w.crb[cm_dof_body[i]], w.cdof[i]);
-        w.M[i][i] = sdot(w.cdof[i], f) + cm_dof_armature[i];
-        for (int j = cm_dof_parent[i]; j >= 0; j = cm_dof_parent[j]) w.M[i][j] = w.M[j][i] = sdot(w.cdof[j], f);
+        w.M[i][i] = sdot(w.cdof[i], f) + cm_dof_armature[i]; CNT(45 + 12);
+        for (int j = cm_dof_parent[i]; j >= 0; j = cm_dof_parent[j]) { w.M[i][j] = w.M[j][i] = sdot(w.cdof[j], f); CNT(11); }
     }
 }
 
@@ -110,7 +116,7 @@ static void jac_point(const Work& w, int b, V3 p, double Jx[NV], double Jy[NV], 
     const V3 r = p - w.o;
     for (int d = body_lastdof(b); d >= 0; d = cm_dof_parent[d]) {
         const V3 v = w.cdof[d].l + cross(w.cdof[d].a, r);
-        Jx[d] += sign * v.x; Jy[d] += sign * v.y; Jz[d] += sign * v.z;
+        Jx[d] += sign * v.x; Jy[d] += sign * v.y; Jz[d] += sign * v.z; CNT(12 + 6);
     }
 }
 
@@ -155,7 +161,8 @@ static void finish_row(Row& r, const double* qvel, double imp_pos, double timeco
     double imp;
     impedance(imp_pos, imp);
     r.vel = 0;
-    for (int d = 0; d < NV; ++d) r.vel += r.J[d] * qvel[d];
+    for (int d = 0; d < NV; ++d) { CNT(NZ(r.J[d], qvel[d])); r.vel += r.J[d] * qvel[d]; }
+    CNT(20);
     r.R = std::max(MINVAL, (1 - imp) / imp * r.diag);
     r.aref = -B * r.vel - K * imp * r.pos;
 }
@@ -252,6 +259,7 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
             const int a = cm_jnt_dofadr[j], nd = cm_jnt_type[j] == 2 ? 3 : 1;
             for (int k = 0; k < nd; ++k) w.cdofdot[a + k] = crossMotion(v, w.cdof[a + k]);   // ball: all 3 from the same v
             for (int k = 0; k < nd; ++k) v = v + w.cdof[a + k] * s.qvel[a + k];
+            CNT(nd * (27 + 12));
         }
         w.cvel[b] = v;
     }
@@ -264,10 +272,12 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
         for (int d = cm_body_dofadr[b]; d < cm_body_dofadr[b] + cm_body_dofnum[b]; ++d) a = a + w.cdofdot[d] * s.qvel[d];
         cacc[b] = a;
         cfrc[b] = imul(w.cinert[b], a) + crossForce(w.cvel[b], imul(w.cinert[b], w.cvel[b]));
+        CNT(cm_body_dofnum[b] * 12 + 45 + 45 + 27 + 6);
     }
     for (int b = NB - 1; b >= 1; --b)
-        if (cm_body_parent[b] > 0) cfrc[cm_body_parent[b]] = cfrc[cm_body_parent[b]] + cfrc[b];
-    for (int d = 0; d < NV; ++d) w.bias[d] = sdot(w.cdof[d], cfrc[cm_dof_body[d]]);
+        if (cm_body_parent[b] > 0) { cfrc[cm_body_parent[b]] = cfrc[cm_body_parent[b]] + cfrc[b]; CNT(6); }
+    for (int d = 0; d < NV; ++d) { w.bias[d] = sdot(w.cdof[d], cfrc[cm_dof_body[d]]); CNT(11); }
+    CNT(NV * 4 + NU * 3 + 40);      // passive, actuation, external wrench
     // passive: joint springs (springref = 0) and dampers (mj_passive)
     for (int d = 0; d < NV; ++d) {
         const int j = cm_dof_jnt[d];
@@ -321,7 +331,7 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
         s.con_frame[s.ncon][0] = nrm; s.con_frame[s.ncon][1] = t1; s.con_frame[s.ncon][2] = t2;
         for (int k = 0; k < 4; ++k) {
             Row& r = rows[n + k];
-            for (int d = 0; d < NV; ++d) r.J[d] = dirs[k].x * Jx[d] + dirs[k].y * Jy[d] + dirs[k].z * Jz[d];
+            for (int d = 0; d < NV; ++d) { CNT(Jx[d] != 0.0 || Jy[d] != 0.0 || Jz[d] != 0.0 ? 5 : 0); r.J[d] = dirs[k].x * Jx[d] + dirs[k].y * Jy[d] + dirs[k].z * Jz[d]; }
             r.pos = dist; r.type = 2; r.diag = tran + mu * mu * tran;
             finish_row(r, s.qvel, dist, 0.005, 1.0);
         }
@@ -425,18 +435,18 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
     for (int i = 0; i < n; ++i) {
         for (int j = 0; j < n; ++j) {
             double a = 0;
-            for (int d = 0; d < NV; ++d) a += rows[i].J[d] * MiJ[j][d];
+            for (int d = 0; d < NV; ++d) { CNT(NZ(rows[i].J[d], MiJ[j][d])); a += rows[i].J[d] * MiJ[j][d]; }
             AR[i][j] = a;
         }
         AR[i][i] += rows[i].R;
         double a = 0;
-        for (int d = 0; d < NV; ++d) a += rows[i].J[d] * qacc_smooth[d];
+        for (int d = 0; d < NV; ++d) { CNT(NZ(rows[i].J[d], qacc_smooth[d])); a += rows[i].J[d] * qacc_smooth[d]; }
         b[i] = a - rows[i].aref;
     }
     // warm start from the previous qacc (mj_fwdConstraint + mj_constraintUpdate), kept only if it beats f = 0
     for (int i = 0; i < n; ++i) {
         double jar = -rows[i].aref;
-        for (int d = 0; d < NV; ++d) jar += rows[i].J[d] * s.qacc_warm[d];
+        for (int d = 0; d < NV; ++d) { CNT(NZ(rows[i].J[d], s.qacc_warm[d])); jar += rows[i].J[d] * s.qacc_warm[d]; }
         double fi = -jar / rows[i].R;
         if (rows[i].type != 0 && fi < 0) fi = 0;
         f[i] = fi;
@@ -444,7 +454,7 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
     double cost = 0;
     for (int i = 0; i < n; ++i) {
         double a = 0;
-        for (int j = 0; j < n; ++j) a += AR[i][j] * f[j];
+        for (int j = 0; j < n; ++j) { CNT(NZ(AR[i][j], f[j])); a += AR[i][j] * f[j]; }
         cost += f[i] * (0.5 * a + b[i]);
     }
     if (cost > 0) for (int i = 0; i < n; ++i) f[i] = 0;
@@ -452,13 +462,14 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
         for (int i = 0; i < n; ++i) {
             double res = b[i];
             for (int j = 0; j < n; ++j) res += AR[i][j] * f[j];
+            CNT(2 * n + 3);                                  // the residual of a row touches every multiplier (A is dense: every row reaches the pelvis)
             double fi = f[i] - res / AR[i][i];
             if (rows[i].type != 0 && fi < 0) fi = 0;
             f[i] = fi;
         }
     for (int d = 0; d < NV; ++d) {
         double a = qacc_smooth[d];
-        for (int i = 0; i < n; ++i) a += MiJ[i][d] * f[i];
+        for (int i = 0; i < n; ++i) { CNT(NZ(MiJ[i][d], f[i])); a += MiJ[i][d] * f[i]; }
         s.qacc[d] = a;
     }
     for (int i = 0; i < n; ++i) { s.efc_force[i] = f[i]; s.efc_type[i] = rows[i].type; }
@@ -493,7 +504,7 @@ void euler(const Params& p, State& s, Work& w) {
     double rhs[NV], a[NV];
     for (int i = 0; i < NV; ++i) {
         double acc = 0;
-        for (int j = 0; j < NV; ++j) acc += w.M[i][j] * s.qacc[j];
+        for (int j = 0; j < NV; ++j) { CNT(NZ(w.M[i][j], s.qacc[j])); acc += w.M[i][j] * s.qacc[j]; }
         rhs[i] = acc;
     }
     static thread_local double MM[NV][NV], LL[NV][NV];
@@ -504,6 +515,7 @@ void euler(const Params& p, State& s, Work& w) {
     cholesky(MM, LL);
     chol_solve(LL, rhs, a);
     for (int d = 0; d < NV; ++d) { s.qacc_warm[d] = s.qacc[d]; s.qvel[d] += DT * a[d]; }
+    CNT(NV * 2 + NQ * 2 + 3 * 60);      // integration (three ball joints)
     for (int j = 0; j < NJ; ++j) {
         const int qa = cm_jnt_qposadr[j], da = cm_jnt_dofadr[j];
         if (cm_jnt_type[j] != 2) { s.qpos[qa] += DT * s.qvel[da]; continue; }

@@ -136,6 +136,9 @@ struct Work {
     V3 o;
 };
 
+// instrumented operation count: floating-point multiplies + adds of the restatement, counted where they happen and only
+// when both operands are structurally nonzero (the dense loops below run over zeros that a tree-sparse implementation never touches)
+extern thread_local unsigned long long g_flops;
 void default_params(Params& p);
 void set_const(Params& p);                                        // mj_setConst subset: invweight0 at qpos0
 void reset_state(State& s);                                       // cassie_sim_set_const: init qpos, zero qvel

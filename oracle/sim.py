@@ -44,6 +44,8 @@ def lib():
         L.orc_env_set.restype = C.c_int
         L.orc_env_set.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
         L.orc_env_set_const.argtypes = [C.c_void_p]
+        L.orc_flops.restype = C.c_uint64
+        L.orc_flops.argtypes = [C.c_int]
         L.orc_env_set_kernel_caps.argtypes = [C.c_void_p, C.c_int]
         L.orc_env_set_hfield.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
         L.orc_floor_query.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p]
@@ -211,3 +213,23 @@ def traj_ref_state(phase, phaselen, speed, counter=0):
     q, v = np.zeros(35), np.zeros(32)
     lib().orc_traj_ref_state(float(phase), float(phaselen), float(speed), int(counter), _ptr(q), _ptr(v))
     return q, v
+
+
+def count_flops(n_steps=40, act_std=0.2, seed=0):
+    """Instrumented floating-point operation count of the restatement: multiplies + adds per ENV STEP (50 substeps + env
+    logic is negligible), averaged over `n_steps` steps of a random-action rollout with resets, structural zeros of the dense loops skipped."""
+    rng = np.random.RandomState(seed)
+    e = OracleEnv(seed=seed, env_id=0)
+    e.reset()
+    lib().orc_flops(1)
+    done_steps = 0
+    for _ in range(n_steps):
+        _, _, d = e.step(act_std * rng.randn(10))
+        done_steps += 1
+        if d:
+            f = lib().orc_flops(0); e.reset(); lib().orc_flops(1); lib().orc_flops(0)      # do not count the reset's own forward passes
+            # restore the running total (reset zeroed it): add back
+            count_flops._acc = getattr(count_flops, "_acc", 0) + f
+    total = getattr(count_flops, "_acc", 0) + lib().orc_flops(1)
+    count_flops._acc = 0
+    return total / done_steps

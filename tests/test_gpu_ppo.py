@@ -572,3 +572,32 @@ def test_full_size_config4_td3_million_ring(dev, tmp_path):
     out = algo.collect_and_train(5)
     assert out["updates"] == 10 and np.isfinite([out["q_loss"], out["avg_q1"], out["avg_q2"]]).all()
     env.close()
+
+
+def test_apx_rollout_equals_the_stepwise_loop(dev):
+    """apx_rollout (the T-step PPO.sample loop as one C-ABI call) against the step-by-step Python loop over
+    apx_mlp_forward / apx_env_step fed with the same action noise.  Same kernels in the same order; only the action mu + sigma * noise is
+    rounded differently (fused multiply-add in the C path), so the first steps agree to round-off and the contact dynamics amplify it later."""
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd.ppo import PPO
+    def mk():
+        env = CassieVecEnv(n_envs=256, seed=6, max_traj_len=10)
+        args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=1024, epochs=1, num_steps=256 * 24, max_traj_len=10,
+                    max_grad_norm=0.05, mirror=True, std_dev=-1.5, seed=0)
+        a = PPO(args, "/tmp/apx_test_unused", env); a.init_networks(0); a.normalization_params(256 * 50)
+        return a
+    a = mk()
+    a.sample()                                              # one C call for the 24 steps
+    noise = a.noise.clone()
+    b = mk()
+    b.noise_fn = lambda t, out: out.copy_(noise[t])          # the Python loop, replaying the same draws
+    b.sample()
+    assert torch.equal(a.b_obs[0], b.b_obs[0]) and torch.equal(a.b_mu[0], b.b_mu[0])
+    np.testing.assert_allclose(a.b_act.cpu().numpy(), (a.b_mu + a.fixed_std * noise).cpu().numpy(), rtol=0, atol=2e-7)
+    for t in range(1, 3):
+        np.testing.assert_allclose(a.b_obs[t].cpu().numpy(), b.b_obs[t].cpu().numpy(), atol=5e-4 * t)
+        np.testing.assert_allclose(a.b_rew[t - 1].cpu().numpy(), b.b_rew[t - 1].cpu().numpy(), atol=2e-3)
+    assert torch.equal(a.b_done[:2], b.b_done[:2])
+    na, nb = int((a.b_done != 0).sum()), int((b.b_done != 0).sum())
+    assert na > 256 and abs(na - nb) <= 0.05 * na                                # episodes ended and restarted inside the call, at the same rate
+    assert torch.isfinite(a.b_obs).all() and torch.isfinite(a.b_val).all()

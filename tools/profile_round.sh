@@ -1,0 +1,26 @@
+#!/bin/bash
+# Profiles of one round, run on the GPU box from the repo root: bash tools/profile_round.sh r02
+#   1. rocprofv3 --kernel-trace --stats of the default bench command      -> profiles/<tag>_bench_kernel_stats.txt + the bench line
+#   2. SQ counters of the env kernel (own --pmc pass, no trace domains)    -> profiles/<tag>_env_step_pmc_sq.txt
+#   3. FETCH_SIZE / WRITE_SIZE, two separate --pmc passes (guide: HBM)     -> profiles/<tag>_env_step_pmc_hbm.txt (+ hash of the kernel sources)
+# Everything is written under gpurun_out/prof_<tag>/ (merged back by gpurun); copy the .txt / .json files into profiles/ afterwards.
+set -e
+TAG=${1:-r02}
+ROOT=$PWD
+OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $ROOT/bench.py --steps 5 --warmup 1 > $OUT/bench_under_rocprof.log 2>&1 || true
+tail -1 $OUT/bench_under_rocprof.log > $OUT/${TAG}_bench_line_under_rocprof.json
+python $ROOT/tools/rocprof_summary.py $(ls $OUT/kt/*/*.db | head -1) $OUT/${TAG}_bench_kernel_stats.txt > /dev/null
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/sq -- python $ROOT/tools/t_pmc.py > $OUT/sq.log 2>&1 || true
+python $ROOT/tools/pmc_summary.py $OUT/sq $OUT/${TAG}_env_step_pmc_sq.txt "# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -- python tools/t_pmc.py (per-dispatch means)" > /dev/null
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python $ROOT/tools/t_pmc.py > $OUT/fetch.log 2>&1 || true
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python $ROOT/tools/t_pmc.py > $OUT/write.log 2>&1 || true
+mkdir -p $OUT/hbm; cp -r $OUT/fetch $OUT/hbm/; cp -r $OUT/write $OUT/hbm/
+HASH=$(cd $ROOT && python -c "import bench; print(bench.kernel_source_hash())")
+python $ROOT/tools/pmc_summary.py $OUT/hbm $OUT/${TAG}_env_step_pmc_hbm.txt "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KB per dispatch) -- python tools/t_pmc.py; kernel sources sha1: $HASH" > /dev/null
+cd $ROOT
+python bench.py --steps 20 --warmup 2 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line.json
+rm -rf $OUT/kt $OUT/sq $OUT/fetch $OUT/write $OUT/hbm
+ls -la $OUT
