@@ -134,8 +134,11 @@ __device__ __forceinline__ void stage1_io_lane(St S, int mode) {   // (as a call
         _Pragma("unroll") for (int i = 0; i < 4; ++i) S(F_SO + SO_QUAT + i) = S(F_SNAP + SN_QUAT + i);
         _Pragma("unroll") for (int i = 0; i < 3; ++i) S(F_SO + SO_ROTVEL + i) = S(F_SNAP + SN_GYRO + i);
         const M3 R = q2m(q);
-        S(F_SO + SO_TACC) = S(F_SNAP + SN_ACC) - R.m[6] * GRAV; S(F_SO + SO_TACC + 1) = S(F_SNAP + SN_ACC + 1) - R.m[7] * GRAV;
-        S(F_SO + SO_TACC + 2) = S(F_SNAP + SN_ACC + 2) - R.m[8] * GRAV;
+        // state_output_step: translationalAcceleration = accelerometer - R^T (0, 0, 9.806) in the sensor frame, unfiltered (step-response
+        // probe of the reference binary, DESIGN.md section 5: the filter's gravity constant is 9.806, not the model's 9.81)
+        constexpr float EST_G = 9.806f;
+        S(F_SO + SO_TACC) = S(F_SNAP + SN_ACC) - R.m[6] * EST_G; S(F_SO + SO_TACC + 1) = S(F_SNAP + SN_ACC + 1) - R.m[7] * EST_G;
+        S(F_SO + SO_TACC + 2) = S(F_SNAP + SN_ACC + 2) - R.m[8] * EST_G;
         const V3 vw = {S(F_SNAP + SN_VEL), S(F_SNAP + SN_VEL + 1), S(F_SNAP + SN_VEL + 2)};
         S(F_SO + SO_TVEL) = dot(col(R, 0), vw); S(F_SO + SO_TVEL + 1) = dot(col(R, 1), vw); S(F_SO + SO_TVEL + 2) = dot(col(R, 2), vw);
         { const float L = S(F_EST) + EST_ALPHA * (S(F_EST + 1) - S(F_EST)); S(F_EST) = L; S(F_SO + SO_HEIGHT) = S(F_SNAP + SN_PZ) - L; }      // golden G11c

@@ -68,7 +68,7 @@ class PPO:
         # steps per env per iteration: the reference samples >= num_steps in total (ppo.py:205)
         self.T = adist.rollout_len(self.num_steps, self.N, self.world)
         self.learner = engine.PPOLearner(self.D, 10, hidden, self.device, self.fixed_std, lr=self.lr, eps=self.eps,
-                                         clip=self.clip, entropy_coeff=self.entropy_coeff, grad_clip=self.grad_clip,
+                                         clip=self.clip, entropy_coeff=self.entropy_coeff, grad_clip=self.grad_clip, precision=int(args.get("precision", 0)),
                                          mirrored_obs=list(getattr(env, "mirrored_obs", MIRRORED_OBS)) if self.mirror else None,
                                          mirrored_acts=MIRRORED_ACTS if self.mirror else None, clock_inds=CLOCK_INDS)
         self.total_steps = 0

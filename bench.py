@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--minibatch", type=int, default=16384)
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
+                    help="learner GEMMs: f32 = fp32 MFMA (parity mode, the default headline line); bf16 = bf16 MFMA inputs, fp32 accumulate, fp32 master weights (BASELINE configs[1] throughput variant)")
     ap.add_argument("--workload", default="cassie_ppo", choices=["cassie_ppo", "cassietraj_recurrent", "cassie_td3"],
                     help="cassie_ppo = BASELINE.json configs[1] (the headline, default); cassietraj_recurrent = configs[3]: CassieTraj-v0, LSTM 2x128, 2048 envs/GPU; cassie_td3 = configs[4]: TD3, 1M-transition replay in HBM")
     a = ap.parse_args()
@@ -194,7 +196,7 @@ def main():
     env = CassieVecEnv(n_envs=a.n_envs, seed=0, device=local, env_id_base=adist.shard_env_base(rank, a.n_envs))
     args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=a.minibatch,
                 epochs=a.epochs, num_steps=a.rollout_len * a.n_envs * world, max_traj_len=400, max_grad_norm=0.05,
-                mirror=True, std_dev=-1.5, seed=0, graph=os.environ.get("APX_ROLLOUT_GRAPH", "0") == "1")
+                mirror=True, std_dev=-1.5, seed=0, graph=os.environ.get("APX_ROLLOUT_GRAPH", "0") == "1", precision=1 if a.precision == "bf16" else 0)
     algo = PPO(args, "/tmp/apx_bench_unused", env, rank=rank, world_size=world, group=group)
     algo.init_networks(0)
     algo.normalization_params(10000)
@@ -260,7 +262,7 @@ def main():
             "metric": "env-steps/sec (whole node) Cassie-v0 PPO @4096 envs/GPU", "value": round(steps_total / dt, 1),
             "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if a.precision == "f32" else "bf16 (learner GEMM inputs; fp32 accumulate, master weights, physics and rollout policy)", "data": "synthetic",
             "config": {"workload": "Cassie-v0 PPO, 4096 batched envs/GPU, 2x256 MLP actor/critic (BASELINE.json configs[1])",
                        "envs_per_gpu": a.n_envs, "rollout_len": a.rollout_len, "simrate": 50, "minibatch": a.minibatch,
                        "epochs": a.epochs, "mirror_loss": True, "dynamics_randomization": True, "eval_rollouts": False,

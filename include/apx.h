@@ -70,7 +70,8 @@ size_t apx_mlp_param_count(int D, int H, int O);
  * idx (may be NULL) gathers rows: x_row = x[idx[b]].  sign_perm (may be NULL) = int32[D] signed permutation
  * applied BEFORE normalisation (SymmetricEnv.mirror_clock_observation, rl/envs/wrappers.py:59-67): entry j>=0 takes
  * +x[j], entry -(j+1) takes -x[j]; clock_mask bit c set => column c additionally gets sin(asin(.)+pi).
- * precision: 0 = fp32 MFMA; 1 (bf16 MFMA inputs, fp32 accumulate) is reserved and rejected.       all pointers [dev] */
+ * precision: 0 = fp32 MFMA (exact fp32 products, the parity mode); 1 = operands rounded to bf16, fp32 accumulate (three GEMM launches,
+ * xn_out / act1 / act2 required).                                                             all pointers [dev] */
 int apx_mlp_forward(const float* params, int D, int H, int O, const float* x, int64_t B, const int64_t* idx,
                     const int32_t* sign_perm, uint64_t clock_mask, const float* obs_mean, const float* obs_std,
                     float* xn_out, float* act1, float* act2, float* y, int precision, void* stream);
@@ -143,7 +144,8 @@ typedef struct apx_ppo_args {
     /* hyper-parameters */
     float fixed_std, clip, entropy_coeff, grad_clip, lr, adam_eps, mirror_coeff;
     int adam_t;            /* 1-based optimiser step count (bias correction) */
-    int precision;         /* 0 fp32 MFMA (1 = bf16 MFMA inputs is reserved and rejected) */
+    int precision;         /* 0 fp32 MFMA (parity mode); 1 = bf16 MFMA inputs, fp32 accumulate, fp32 master weights and Adam (throughput mode,
+                            * BASELINE configs[1] / SURVEY section 8d cfg-2) */
     int grad_only;         /* 1 = stop after gradients (no clip/Adam): lets N>1 ranks all-reduce actor_grad/critic_grad */
     /* scratch: apx_ppo_workspace_bytes(mb, D, H, A) bytes [dev] */
     void* workspace; size_t workspace_bytes;

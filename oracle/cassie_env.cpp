@@ -191,7 +191,10 @@ void sim_step_pd(Env& e) {
         // (tools/refprobe/probe_estimator.py, golden G11): acceleration = specific force minus gravity in the PELVIS frame,
         // velocity in the pelvis frame
         const M3 R = q2m(Q4{e.snap_quat[0], e.snap_quat[1], e.snap_quat[2], e.snap_quat[3]});
-        const V3 gb = {R.m[6] * GRAV, R.m[7] * GRAV, R.m[8] * GRAV};                       // R^T (0,0,g)
+        // step-response probe of the binary: translationalAcceleration = accelerometer - R^T (0, 0, 9.806), sensor frame, unfiltered (exact on
+        // static and tilted inputs); the filter's gravity constant is 9.806, not the model's 9.81
+        const double EST_G = 9.806;
+        const V3 gb = {R.m[6] * EST_G, R.m[7] * EST_G, R.m[8] * EST_G};                    // R^T (0,0,g)
         e.so_tacc[0] = e.snap_acc[0] - gb.x; e.so_tacc[1] = e.snap_acc[1] - gb.y; e.so_tacc[2] = e.snap_acc[2] - gb.z;
         const V3 vw = {e.snap_vel[0], e.snap_vel[1], e.snap_vel[2]};
         e.so_tvel[0] = dot(col(R, 0), vw); e.so_tvel[1] = dot(col(R, 1), vw); e.so_tvel[2] = dot(col(R, 2), vw);
