@@ -26,8 +26,6 @@ class RecurrentPPO:
         self.fixed_std = float(np.exp(args.get("std_dev", -2.0)))                  # ppo.py:537: recurrent policies use exp(-2)
         self.env_name = args.get("env_name", "Cassie-v0")
         self.save_path, self.env = save_path, env
-        if world_size > 1:      # ranks would hold different numbers of trajectories -> different minibatch counts per epoch: not arranged yet
-            raise NotImplementedError("recurrent PPO is single-GPU in this round (the feed-forward path shards over ranks)")
         self.rank, self.world, self.group = rank, world_size, group
         self.device, self.N = env.device, env.n_envs
         self.T = adist.rollout_len(self.num_steps, self.N, self.world)
@@ -157,6 +155,14 @@ class RecurrentPPO:
         adv = engine.normalize_advantages(retf, val, self.eps, group=self.group)
         trajs = self.trajectories()
         mb = self.minibatch_size or len(trajs)
+        # N > 1: the ranks hold different numbers of trajectories (their env shards end episodes at different times), so the number of
+        # optimiser steps per epoch is agreed first (max over ranks); a rank that has run out of trajectories contributes a zero gradient to
+        # the remaining all-reduces.  Every rank therefore issues the same sequence of collectives and ends with the same parameters.
+        n_mb = -(-len(trajs) // mb)
+        if self.world > 1:
+            cnt = torch.tensor([n_mb], dtype=torch.int64, device=self.device)
+            torch.distributed.all_reduce(cnt, op=torch.distributed.ReduceOp.MAX, group=self.group)
+            n_mb = int(cnt)
         L.sync_old()
         losses, kl_last, epochs_run = None, 0.0, 0
         for epoch in range(self.epochs):
@@ -165,7 +171,13 @@ class RecurrentPPO:
             else:
                 order = torch.randperm(len(trajs), device=self.device, generator=self.gen).cpu().numpy()      # SubsetRandomSampler over trajectories
             acc = torch.zeros(6, dtype=torch.float64, device=self.device); nb = 0
-            for k in range(0, len(order), mb):                                   # BatchSampler(..., drop_last=False), ppo.py:413
+            for kk in range(n_mb):                                               # BatchSampler(..., drop_last=False), ppo.py:413
+                k = kk * mb
+                if k >= len(order):                                              # (N > 1 only) this rank has no trajectories left in this epoch
+                    L.grad_flat.zero_()
+                    adist.allreduce_mean_(L.grad_flat, group=self.group, world=self.world)
+                    L.apply_grads()
+                    continue
                 idx = self.padded_index(trajs[order[k:k + mb]])
                 valid = idx >= 0
                 gi = idx.clamp(min=0).view(-1)
@@ -178,8 +190,11 @@ class RecurrentPPO:
                 acc += scal; nb += 1
                 if self.trace is not None:
                     self.trace.append(scal.clone())
-            losses = (acc / max(nb, 1)).cpu().numpy()
-            kl_last = float(scal[4]); epochs_run += 1
+            both = torch.cat([acc / max(nb, 1), scal.to(acc.dtype)])
+            if self.world > 1:
+                adist.allreduce_mean_(both, group=self.group, world=self.world)          # the KL decision must be the same on every rank
+            both = both.cpu().numpy()
+            losses, kl_last = both[:6], float(both[10]); epochs_run += 1
             if kl_last > 0.02:
                 break
         return losses, kl_last, epochs_run

@@ -83,3 +83,62 @@ def test_two_ranks_equal_union_minibatch_on_the_hip_learner():
         d = np.abs(x2 - x1)
         # Adam's first steps move every weight by ~lr * sign(g): identical up to fp32 summation order, except a vanishing fraction at g ~ 0
         assert (d > 2e-6).mean() < 2e-3 and d.max() < 4e-4, ((d > 2e-6).mean(), d.max())
+
+
+def _rec_worker(rank, world, port, q):
+    """one rank of a recurrent-PPO iteration: its own env shard (different trajectory counts per rank), shared cuda:0, gloo"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd.ppo_recurrent import RecurrentPPO
+    from apex_amd import dist as adist
+    n = 64
+    env = CassieVecEnv(n_envs=n, seed=5, max_traj_len=10 - 3 * rank, env_id_base=adist.shard_env_base(rank, n), env_name="CassieTraj-v0")
+    args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=48, epochs=2, num_steps=20 * n * world, max_traj_len=10 - 3 * rank,
+                max_grad_norm=0.05, mirror=True, seed=0, allow_short_rollout=True)
+    algo = RecurrentPPO(args, "/tmp/apx_test_unused", env, rank=rank, world_size=world, group=dist.group.WORLD, hidden=64, layers=2)
+    algo.init_networks(0); algo.normalization_params(1000)
+    out = algo.iteration()
+    q.put((rank, len(algo.trajectories()), algo.learner.actor.params.cpu().numpy(), algo.learner.obs_mean.cpu().numpy(), np.asarray(out["losses"])))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_recurrent_ppo_two_ranks_agree_on_the_step_count():
+    """Recurrent PPO with N > 1 (SURVEY.md section 8e for row f1): the ranks hold different numbers of trajectories, the number of optimiser steps
+    per epoch is agreed by a MAX all-reduce and a rank that has run out contributes zero gradients: no hang, identical parameters and
+    observation statistics on both ranks."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_rec_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda r: r[0])
+    [p.join(timeout=120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    (_, n0, a0, m0, l0), (_, n1, a1, m1, l1) = res
+    assert n0 != n1                                                    # different episode limits -> different trajectory counts
+    assert -(-n0 // 48) != -(-n1 // 48)                               # ... and different minibatch counts: the zero-gradient path ran
+    np.testing.assert_array_equal(a0, a1); np.testing.assert_array_equal(m0, m1)
+    assert np.isfinite(a0).all() and np.isfinite(l0).all() and np.isfinite(l1).all()
+
+
+def test_eight_ranks_bench_driver_on_a_shared_gpu(tmp_path):
+    """The driver's multi-GPU command line (python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8 ...) with all eight ranks on
+    cuda:0 over gloo (APX_BENCH_SHARE_GPU=1, small env shards): env shards with disjoint RNG streams, observation / advantage moments, one
+    gradient all-reduce per optimiser step, max-over-ranks timing, ONE JSON line from rank 0."""
+    import json, subprocess, sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env["APX_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(repo, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--n_envs", "256", "--rollout_len", "8", "--minibatch", "512", "--no_cpu_baseline"]
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["parallelism"].startswith("dp8")
+    assert abs(d["value"] - 8 * 256 * 8 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
