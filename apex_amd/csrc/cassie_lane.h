@@ -371,14 +371,15 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         const int dep = l < 13 ? (l == 12 ? 13 : nibble(TD_DEPTH, l)) : d + 1, madr = cm_dof_madr[d];
         S.W(WK_M + madr) = sdot(cd, f) + cm_dof_armature[d];
         int cur = l;                                                  // walk the ancestor chain: leg dofs first, then pelvis dofs 5..0
-        sfor<1, 14>([&](auto An) {
+        sfor<1, 14>([&](auto An) {      // branch-free: inactive levels read dof 0's axis and store to the env's dummy word
             constexpr int a = An;
-            if (a < dep) {
-                int ad;
-                if (a < dep - 6) { cur = cur == 12 ? 8 : nibble(TD_PDOF, cur); ad = 6 + 13 * sd + cur; } else ad = dep - 1 - a;
-                const float* ap = (const float*)&S.W(WK_CDOF + 6 * ad);
-                S.W(WK_M + madr + a) = sdot(SV{{ap[0], ap[1], ap[2]}, {ap[3], ap[4], ap[5]}}, f);
-            }
+            if constexpr (a % 5 == 1) __builtin_amdgcn_sched_barrier(0);
+            const bool on = a < dep, inleg = a < dep - 6;
+            const int nxt = cur == 12 ? 8 : nibble(TD_PDOF, cur < 13 ? cur : 0);
+            cur = (on && inleg) ? nxt : cur;
+            const int ad = !on ? 0 : inleg ? 6 + 13 * sd + cur : dep - 1 - a;
+            const float* ap = (const float*)&S.W(WK_CDOF + 6 * ad);
+            S.W(on ? WK_M + madr + a : WK_DUMMY) = sdot(SV{{ap[0], ap[1], ap[2]}, {ap[3], ap[4], ap[5]}}, f);
         });
         // qfrc_smooth = passive - bias + actuation
         const int k = l;       // leg-local dof

@@ -64,7 +64,9 @@ class PPO:
         self.rank, self.world, self.group = rank, world_size, group
         self.device = env.device
         self.N = env.n_envs
-        self.D = int(getattr(env, "obs_dim", 50))              # 50 (command_profile clock) or 55 (phase)
+        self.D = int(getattr(env, "obs_dim", 50))              # 50 (command_profile clock) or 55 (phase), x (history + 1)
+        if getattr(env, "history", 0) and args.get("mirror", True):
+            raise NotImplementedError("--history needs --not_mirror: the reference's mirror index lists cover a single frame (cassie.py:244,262-271)")
         # steps per env per iteration: the reference samples >= num_steps in total (ppo.py:205)
         self.T = adist.rollout_len(self.num_steps, self.N, self.world)
         self.learner = engine.PPOLearner(self.D, 10, hidden, self.device, self.fixed_std, lr=self.lr, eps=self.eps,
@@ -159,7 +161,7 @@ class PPO:
         self.b_obs[0].copy_(self.obs)
         if self.noise_fn is None:
             self.noise.normal_(generator=self.gen)                # the whole rollout's action noise in one launch
-        if self.noise_fn is None and hasattr(env, "_h"):          # the HIP env: the T-step loop is one C-ABI call (apx_rollout)
+        if self.noise_fn is None and hasattr(env, "_h") and not getattr(env, "history", 0):          # the HIP env: the T-step loop is one C-ABI call (apx_rollout)
             from ._lib import load, check
             from .engine import _p, _stream
             check(load().apx_rollout(env._h, _p(L.actor.params), L.actor.H, _p(L.obs_mean), _p(L.obs_std), float(self.fixed_std * self.curr_anneal),

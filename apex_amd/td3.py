@@ -40,7 +40,7 @@ class HbmReplay:
 
 class TD3:
     def __init__(self, env, save_path, hidden=256, a_lr=1e-3, c_lr=1e-3, discount=0.99, tau=0.005, policy_noise=0.2, noise_clip=0.5, policy_freq=2,
-                 act_noise=0.3, batch_size=256, updates_per_step=1, replay_size=1_000_000, seed=0):
+                 act_noise=0.3, batch_size=256, updates_per_step=1, replay_size=1_000_000, seed=0, param_noise=False, noise_scale=0.3):
         self.env, self.save_path, self.device, self.N = env, save_path, env.device, env.n_envs
         self.learner = engine.TD3Learner(50, 10, hidden, self.device, 1.0, a_lr, c_lr)
         self.replay = HbmReplay(replay_size, 50, 10, self.device)
@@ -48,6 +48,24 @@ class TD3:
         self.act_noise, self.batch_size, self.updates_per_step, self.hidden = act_noise, batch_size, updates_per_step, hidden
         self.gen = torch.Generator(device=self.device); self.gen.manual_seed(int(seed) * 1000003 + 17)
         self.it = 0; self.total_steps = 0; self.obs = None
+        # parameter-space exploration noise (rl/utils/param_noise.py AdaptiveParamNoiseSpec; TD3.perturb_actor_parameters, sync_td3.py:113-121).
+        # The reference's synchronous loop builds the spec (initial 0.05, desired action stddev = --noise_scale, coefficient 1.05,
+        # sync_td3.py:286) but never passes it to the collectors; here --param_noise wires it the way the asynchronous variant does: collect
+        # with a perturbed copy of the actor, re-perturb and adapt the stddev after every collection round.
+        self.param_noise = bool(param_noise)
+        self.pn_std, self.pn_desired, self.pn_coef = 0.05, float(noise_scale), 1.05
+        self.actor_perturbed = engine.Mlp(50, hidden, 10, self.device) if self.param_noise else None
+
+    def perturb_actor_parameters(self):
+        """actor_perturbed <- actor + N(0, current_stddev) on every parameter (sync_td3.py:113-121)"""
+        self.actor_perturbed.params.copy_(self.learner.actor.params + torch.randn(self.learner.actor.n, device=self.device, generator=self.gen) * self.pn_std)
+
+    def adapt_param_noise(self, states):
+        """AdaptiveParamNoiseSpec.adapt(distance_metric(perturbed actions, actions)) on a batch of visited states (rl/utils/param_noise.py:19-50)"""
+        a = self.learner.act(states); ap = torch.tanh(self.actor_perturbed.forward(states))
+        dist = float(torch.sqrt(((a - ap) ** 2).mean(0).mean()))
+        self.pn_std = self.pn_std / self.pn_coef if dist > self.pn_desired else self.pn_std * self.pn_coef
+        return dist
 
     def init_networks(self, seed):
         from rl.policies.actor import FF_Actor
@@ -77,8 +95,10 @@ class TD3:
             self.obs = env.reset().clone()
         stats = torch.zeros(3, dtype=torch.float64, device=self.device); n_upd = 0
         ep_done = 0
+        if self.param_noise:
+            self.perturb_actor_parameters()
         for _ in range(steps):
-            a = L.act(self.obs)
+            a = torch.tanh(self.actor_perturbed.forward(self.obs)) if self.param_noise else L.act(self.obs)
             if self.act_noise != 0:
                 a = (a + torch.randn(self.N, 1, device=self.device, generator=self.gen) * self.act_noise).clamp(-1, 1)      # one scalar per env step (:77)
             nxt, rew, done, fin = env.step(a)
@@ -94,6 +114,8 @@ class TD3:
                 st, _ = L.train_step(s, ac, sn, r, nd, noise, self.it, self.discount, self.tau, self.noise_clip, self.policy_freq)
                 stats += st; n_upd += 1; self.it += 1
         self.total_steps += steps * self.N
+        if self.param_noise:
+            self.adapt_param_noise(self.obs)
         s = (stats / max(n_upd, 1)).cpu().numpy()
         return dict(q_loss=float(s[0]), avg_q1=float(s[1] / self.batch_size), avg_q2=float(s[2] / self.batch_size), updates=n_upd)
 
@@ -117,7 +139,8 @@ def run_experiment(args):
     logger = create_logger(args)
     algo = TD3(env, logger.dir, hidden=args.hidden, a_lr=args.a_lr, c_lr=args.c_lr, discount=args.discount, tau=args.tau, policy_noise=args.policy_noise,
                noise_clip=args.noise_clip, policy_freq=args.policy_freq, act_noise=args.act_noise, batch_size=args.batch_size,
-               updates_per_step=args.updates_per_step, replay_size=args.replay_size, seed=args.seed)
+               updates_per_step=args.updates_per_step, replay_size=args.replay_size, seed=args.seed, param_noise=getattr(args, "param_noise", False),
+               noise_scale=getattr(args, "noise_scale", 0.3))
     algo.init_networks(args.seed)
     updates = 0
     ret, eplen = algo.evaluate()

@@ -61,8 +61,8 @@ class CassieVecEnv:
     def __init__(self, n_envs=4096, simrate=50, dynamics_randomization=True, reward="clock", max_traj_len=400, seed=0,
                  device=0, pgs_iters=50, env_id_base=0, command_profile="clock", input_profile="full", history=0, learn_gains=False,
                  env_name="Cassie-v0", traj="walking", no_delta=True, ik_baseline=False):
-        if command_profile not in ("clock", "phase") or input_profile != "full" or history != 0 or learn_gains:
-            raise NotImplementedError("command_profile clock / phase with input_profile=full, history=0 are built (traj / min / history are not)")
+        if command_profile not in ("clock", "phase") or input_profile != "full" or learn_gains or history < 0:
+            raise NotImplementedError("command_profile clock / phase with input_profile=full are built (traj / min / learn_gains are not)")
         if command_profile == "phase" and env_name != "Cassie-v0":
             raise NotImplementedError("command_profile=phase is built for Cassie-v0")
         # util/env.py:22-32: Cassie-v0 -> CassieEnv; CassieTraj-v0 -> CassieTrajEnv, which with the CLI defaults (traj=walking,
@@ -80,7 +80,11 @@ class CassieVecEnv:
         r = parse_reward(reward) if command_profile == "clock" else parse_phase_reward(reward)
         cfg.command_profile = 0 if command_profile == "clock" else (2 if r["library"] else 1)
         self.command_profile = command_profile
-        self.obs_dim = OBS_DIM if command_profile == "clock" else OBS_DIM_PHASE
+        self.frame_dim = OBS_DIM if command_profile == "clock" else OBS_DIM_PHASE
+        # --history h (cassie.py:51-55,565,856-859): the observation is the newest frame followed by the h previous ones of the episode (zeros
+        # before its start); the kernel writes frames, the stack is kept here.  The reference's mirror lists cover one frame only.
+        self.history = int(history)
+        self.obs_dim = self.frame_dim * (self.history + 1)
         if command_profile == "phase":
             self.mirrored_obs = MIRRORED_OBS_PHASE
         cfg.n_envs, cfg.simrate, cfg.dynamics_randomization = n_envs, simrate, int(dynamics_randomization)
@@ -98,6 +102,8 @@ class CassieVecEnv:
         f32 = dict(dtype=torch.float32, device=self.device)
         self.obs = torch.zeros(n_envs, self.obs_dim, **f32)
         self.final_obs = torch.zeros(n_envs, self.obs_dim, **f32)
+        if self.history:
+            self._frame = torch.zeros(n_envs, self.frame_dim, **f32); self._fin_frame = torch.zeros(n_envs, self.frame_dim, **f32)
         self.reward = torch.zeros(n_envs, **f32)
         self.done = torch.zeros(n_envs, dtype=torch.uint8, device=self.device)
 
@@ -114,8 +120,22 @@ class CassieVecEnv:
 
     def reset(self, mask=None):
         """CassieEnv.reset for every env (or those with mask != 0); returns the [N, 50] observation tensor."""
-        check(_lib.load().apx_env_reset(self._h, _p(mask), _p(self.obs), _stream()))
+        if not self.history:
+            check(_lib.load().apx_env_reset(self._h, _p(mask), _p(self.obs), _stream()))
+            return self.obs
+        check(_lib.load().apx_env_reset(self._h, _p(mask), _p(self._frame), _stream()))
+        sel = torch.ones(self.n_envs, dtype=torch.bool, device=self.device) if mask is None else mask != 0
+        self._push(self._frame, sel, self.obs)
         return self.obs
+
+    def _push(self, frame, restart, out):
+        """state_history.insert(0, state)[:history + 1] (cassie.py:856-859); envs in `restart` begin a new episode: zero history first (:565)"""
+        D = self.frame_dim
+        old = torch.where(restart.view(-1, 1), torch.zeros_like(self.obs[:, :-D]), self.obs[:, :-D].clone())
+        new = torch.cat([frame, old], 1)
+        out.copy_(new)
+        if out is not self.obs:
+            self.obs.copy_(new)
 
     def update_speed(self, new_speed, new_side_speed=None):
         """CassieEnv.update_speed (cassie.py:757-775) for every env; arguments are [N] tensors (or floats)."""
@@ -125,7 +145,11 @@ class CassieVecEnv:
 
     def reset_for_test(self, full_reset=False):
         """CassieEnv.reset_for_test(full_reset) (cassie.py:682-742) for every env; returns the [N, 50] observation."""
-        check(_lib.load().apx_env_reset_for_test(self._h, _p(self.obs), int(bool(full_reset)), _stream()))
+        if not self.history:
+            check(_lib.load().apx_env_reset_for_test(self._h, _p(self.obs), int(bool(full_reset)), _stream()))
+            return self.obs
+        check(_lib.load().apx_env_reset_for_test(self._h, _p(self._frame), int(bool(full_reset)), _stream()))
+        self._push(self._frame, torch.ones(self.n_envs, dtype=torch.bool, device=self.device), self.obs)      # cassie.py:689: history cleared
         return self.obs
 
     def apply_force(self, xfrc, body_name="cassie-pelvis"):
@@ -154,7 +178,11 @@ class CassieVecEnv:
         """CassieEnv.step_basic (cassie.py:498-521) for every env: no reward / termination / command resampling; returns obs."""
         action = action.contiguous()
         assert action.shape == (self.n_envs, ACT_DIM) and action.dtype == torch.float32 and action.is_cuda
-        check(_lib.load().apx_env_step_basic(self._h, _p(action), _p(self.obs), _stream()))
+        if not self.history:
+            check(_lib.load().apx_env_step_basic(self._h, _p(action), _p(self.obs), _stream()))
+            return self.obs
+        check(_lib.load().apx_env_step_basic(self._h, _p(action), _p(self._frame), _stream()))
+        self._push(self._frame, torch.zeros(self.n_envs, dtype=torch.bool, device=self.device), self.obs)
         return self.obs
 
     def step(self, action, auto_reset=True, f_term=0, out=None):
@@ -171,7 +199,17 @@ class CassieVecEnv:
         if out is not None:
             assert obs.is_contiguous() and rew.is_contiguous() and done.is_contiguous() and fin.is_contiguous()
             assert obs.shape == (self.n_envs, self.obs_dim) and fin.shape == (self.n_envs, self.obs_dim) and done.dtype == torch.uint8
-        check(_lib.load().apx_env_step(self._h, _p(action), _p(obs), _p(rew), _p(done), _p(fin), int(auto_reset), _stream()))
+        if not self.history:
+            check(_lib.load().apx_env_step(self._h, _p(action), _p(obs), _p(rew), _p(done), _p(fin), int(auto_reset), _stream()))
+            return obs, rew, done, fin
+        # history: the kernel writes frames; the stacks are composed here.  A finished env's final observation is the stack that ends with
+        # its last frame; with auto_reset its new observation starts a fresh stack.
+        check(_lib.load().apx_env_step(self._h, _p(action), _p(self._frame), _p(rew), _p(done), _p(self._fin_frame), int(auto_reset), _stream()))
+        D = self.frame_dim
+        ended = done != 0
+        prev = self.obs[:, :-D].clone()
+        fin.copy_(torch.where(ended.view(-1, 1), torch.cat([self._fin_frame, prev], 1), fin))
+        self._push(self._frame, ended & bool(auto_reset), obs)
         return obs, rew, done, fin
 
     # ---- raw state access (tests, tools) ----

@@ -722,3 +722,35 @@ def test_heightfield_terrain_vs_oracle(dev, kind):
     for _ in range(3):
         g.step_basic(torch.zeros(N, 10, device=dev))
     assert abs(float(g.get_field("qpos")[:, 2].mean()) - 0.95) < 0.08
+
+
+def test_observation_history_stack(dev):
+    """--history h (cassie.py:51-55,565,856-859): observation = newest frame followed by the h previous frames of the episode, zeros before
+    its start; a finished env's final observation ends the OLD stack, its auto-reset observation starts a new one.  Frames come from the same
+    kernel: a history-0 twin env on the same seed produces them."""
+    from apex_amd.vecenv import CassieVecEnv
+    h = 2
+    a = CassieVecEnv(n_envs=N, seed=8, max_traj_len=6, history=h)
+    b = CassieVecEnv(n_envs=N, seed=8, max_traj_len=6)
+    assert a.obs_dim == 150 and a.observation_space.shape == (150,)
+    oa, ob = a.reset().clone(), b.reset().clone()
+    assert torch.equal(oa[:, :50], ob) and float(oa[:, 50:].abs().max()) == 0
+    frames = [ob.clone()]
+    g = torch.Generator(device=dev).manual_seed(1)
+    for t in range(9):
+        act = torch.randn(N, 10, device=dev, generator=g) * 0.1
+        oa, ra, da, fa = a.step(act); ob, rb, db, fb = b.step(act)
+        oa, fa, ob, fb = oa.clone(), fa.clone(), ob.clone(), fb.clone()
+        assert torch.equal(da, db) and torch.equal(ra, rb) and torch.equal(oa[:, :50], ob)
+        ended = (da != 0)
+        prev1, prev2 = frames[-1], (frames[-2] if len(frames) > 1 else torch.zeros_like(ob))
+        if len(frames) > 1:
+            prev2 = torch.where(last_ended.view(-1, 1), torch.zeros_like(prev2), prev2)      # an episode that began one step ago has one old frame only
+        # running envs: [new, prev1, prev2]; finished + restarted envs: [new, 0, 0] and the final observation [final frame, prev1, prev2]
+        exp = torch.cat([ob, torch.where(ended.view(-1, 1), torch.zeros_like(prev1), prev1), torch.where(ended.view(-1, 1), torch.zeros_like(prev2), prev2)], 1)
+        assert torch.equal(oa, exp), t
+        if bool(ended.any()):
+            expf = torch.cat([fb, prev1, prev2], 1)
+            assert torch.equal(fa[ended], expf[ended])
+        frames.append(ob.clone()); last_ended = ended
+    assert int((torch.stack([f for f in frames]).abs().sum() > 0)) == 1

@@ -472,6 +472,17 @@ def test_td3_driver_hbm_replay_and_updates(dev, tmp_path):
     algo.save()
     pol = torch.load(str(tmp_path / "actor.pt"), weights_only=False)
     assert type(pol).__name__ == "FF_Actor" and pol(torch.zeros(50)).abs().max() <= 1
+    # parameter-space noise (sync_td3.py:113-128, rl/utils/param_noise.py): perturbed actor = actor + N(0, stddev); the stddev adapts towards the
+    # desired action-space distance
+    pn = TD3(env, str(tmp_path), hidden=64, batch_size=128, updates_per_step=1, replay_size=5000, seed=2, param_noise=True, noise_scale=0.3)
+    pn.init_networks(0)
+    s0 = pn.pn_std
+    pn.collect_and_train(4)
+    d = (pn.actor_perturbed.params - pn.learner.actor.params)
+    assert 0.5 * s0 < float(d.std()) < 2.5 * s0 and pn.pn_std in (s0 * 1.05, s0 / 1.05)
+    obs = pn.obs
+    dist = pn.adapt_param_noise(obs)
+    assert 0 < dist < 1
 
 
 def test_full_size_config3_recurrent_iteration(dev, tmp_path):
