@@ -722,6 +722,156 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
     if (e < n) y[e] += x[e];
 }
 
+// ------------------------------------------------------------------------------------------------ persistent LSTM layer (sequence)
+// One launch runs ALL time steps of one LSTM layer (rl/policies/actor.py:253-289: nn.LSTMCell stepped over the padded sequence).  A
+// workgroup of four waves owns 16 batch rows for the whole sequence; W_hh (4H x H fp32 = 256 KB at H = 128) never leaves the REGISTER
+// FILE: wave w keeps the recurrent weights of units [w H/4, (w + 1) H/4) for all four gates as v_mfma_f32_16x16x4_f32 B operands
+// (H/4 k-quads x 4 gates x H/64 unit tiles = 256 VGPRs at H = 128).  Per step: A operand = h_{t-1} from LDS, 256 MFMAs per wave on
+// top of the precomputed input projection, and the gate maths is lane-local because a lane's accumulators hold i, f, g, o of the same
+// (row, unit) pairs.  Replaces 2 launches per step (accumulate-GEMM + gate kernel); the save format (activated gates, c, h) is unchanged.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+template <int H>
+__global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float* __restrict__ G, const float* __restrict__ Whh, const float* __restrict__ bhh,
+                                                               float* __restrict__ hc_h, float* __restrict__ hc_c, float* __restrict__ Cc,
+                                                               float* __restrict__ Hh, int T, long B) {
+    constexpr int UW = H / 4, NT = H / 64, KQ = H / 4, HP = H + 4;
+    __shared__ float hs[16][HP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 15, kg = lane >> 4;
+    const long r0 = (long)blockIdx.x * 16;
+    float W[KQ][4][NT];
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) W[kq][g][nt] = Whh[(size_t)(g * H + wave * UW + nt * 16 + col) * H + 4 * kq + kg];
+    float bh[4][NT], c[NT][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bh[g][nt] = bhh[g * H + wave * UW + nt * 16 + col];
+    // initial state
+    for (int e = tid; e < 16 * H; e += 256) { const int r = e / H, u = e - r * H; hs[r][u] = (hc_h && r0 + r < B) ? hc_h[(r0 + r) * H + u] : 0.f; }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const long row = r0 + 4 * kg + r; c[nt][r] = (hc_c && row < B) ? hc_c[row * H + wave * UW + nt * 16 + col] : 0.f; }
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        float* Gt = G + (size_t)t * B * 4 * H;
+        floatx4 acc[4][NT];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long row = r0 + 4 * kg + r;
+                    acc[g][nt][r] = (row < B ? Gt[row * 4 * H + g * H + wave * UW + nt * 16 + col] : 0.f) + bh[g][nt];
+                }
+#pragma unroll
+        for (int kq = 0; kq < KQ; ++kq) {
+            const float a = hs[col][4 * kq + kg];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, W[kq][g][nt], acc[g][nt], 0, 0, 0);
+        }
+        __syncthreads();                                   // every wave has read h_{t-1}
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long row = r0 + 4 * kg + r;
+                const int u = wave * UW + nt * 16 + col;
+                const float i = sigmf(acc[0][nt][r]), f = sigmf(acc[1][nt][r]), gg = tanhf(acc[2][nt][r]), o = sigmf(acc[3][nt][r]);
+                const float cn = f * c[nt][r] + i * gg, hn = o * tanhf(cn);
+                c[nt][r] = cn;
+                hs[4 * kg + r][u] = hn;
+                if (row < B) {
+                    float* g4 = Gt + row * 4 * H + u;
+                    g4[0] = i; g4[H] = f; g4[2 * H] = gg; g4[3 * H] = o;
+                    Cc[(size_t)t * B * H + row * H + u] = cn; Hh[(size_t)t * B * H + row * H + u] = hn;
+                }
+            }
+        __syncthreads();
+    }
+    if (hc_h)      // carried state out (rollout: hidden state of the next call)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long row = r0 + 4 * kg + r; const int u = wave * UW + nt * 16 + col;
+                if (row < B) { hc_h[row * H + u] = hs[4 * kg + r][u]; hc_c[row * H + u] = c[nt][r]; }
+            }
+}
+
+// BPTT of one layer in one launch: per step (descending) the gate backward of the wave's own units, then dh_{t-1} = dG_t W_hh with W_hh again
+// register-resident (now as the [4H x H/4] slice that produces the wave's units); dG_t goes to global memory for the weight-gradient GEMMs.
+template <int H>
+__global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float* __restrict__ G, const float* __restrict__ Cc, const float* __restrict__ Whh,
+                                                               const float* __restrict__ dHa, float* __restrict__ dG, int T, long B) {
+    constexpr int UW = H / 4, NT = H / 64, KQ = H, GP = 4 * H + 4;
+    __shared__ float dgs[16][GP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 15, kg = lane >> 4;
+    const long r0 = (long)blockIdx.x * 16;
+    float W[KQ][NT];                                       // B operand of dh = dG W_hh: B[k = gate column][n = unit] = Whh[k][n]
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) W[kq][nt] = Whh[(size_t)(4 * kq + kg) * H + wave * UW + nt * 16 + col];
+    float dc[NT][4], dhr[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dc[nt][r] = dhr[nt][r] = 0.f;
+    for (int t = T - 1; t >= 0; --t) {
+        const float* Gt = G + (size_t)t * B * 4 * H;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long row = r0 + 4 * kg + r; const int u = wave * UW + nt * 16 + col;
+                float di = 0.f, df = 0.f, dgg = 0.f, dob = 0.f;
+                if (row < B) {
+                    const float* g4 = Gt + row * 4 * H + u;
+                    const float i = g4[0], f = g4[H], gg = g4[2 * H], o = g4[3 * H];
+                    const float ct = Cc[(size_t)t * B * H + row * H + u], cp = t ? Cc[(size_t)(t - 1) * B * H + row * H + u] : 0.f;
+                    const float dh = dHa[(size_t)t * B * H + row * H + u] + dhr[nt][r];
+                    const float tc = tanhf(ct);
+                    const float dcv = dh * o * (1.f - tc * tc) + dc[nt][r];
+                    di = dcv * gg * i * (1.f - i); df = dcv * cp * f * (1.f - f); dgg = dcv * i * (1.f - gg * gg); dob = dh * tc * o * (1.f - o);
+                    dc[nt][r] = dcv * f;
+                    float* d4 = dG + (size_t)t * B * 4 * H + row * 4 * H + u;
+                    d4[0] = di; d4[H] = df; d4[2 * H] = dgg; d4[3 * H] = dob;
+                }
+                float* ds = &dgs[4 * kg + r][u];
+                ds[0] = di; ds[H] = df; ds[2 * H] = dgg; ds[3 * H] = dob;
+            }
+        __syncthreads();
+        if (t) {
+            floatx4 acc[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq) {
+                const float a = dgs[col][4 * kq + kg];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, W[kq][nt], acc[nt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dhr[nt][r] = acc[nt][r];
+        }
+        __syncthreads();
+    }
+}
+static bool lstm_persistent_ok(int H) {
+    static const bool on = getenv("APX_LSTM_STEPWISE") == nullptr;      // A/B: the per-step launches of round 1
+    return on && (H == 128 || H == 64);
+}
+
 // x[T, B, D] prepared input; hc = [L][2][B][H] carried (h, c) in / out, or NULL (zero start, final state dropped);
 // save = apx_lstm_workspace_floats(T, B, H, L) floats; y[T, B, O]
 extern "C" int apx_lstm_forward(const float* params, int D, int H, int L, int O, const float* x, int T, int64_t B, float* hc,
@@ -734,6 +884,14 @@ extern "C" int apx_lstm_forward(const float* params, int D, int H, int L, int O,
     for (int l = 0; l < L; ++l) {
         float* G = save + (size_t)l * TB * 6 * H; float* Cc = G + TB * 4 * H; float* Hh = Cc + TB * H;
         APX_TRY(linear_fwd(in, P.Wih[l], P.bih[l], G, TB, P.in[l], 4 * H, false, s));            // all time steps at once
+        if (lstm_persistent_ok(H)) {      // the whole sequence of this layer in one launch, W_hh resident in registers
+            float* hh = hc ? hc + (size_t)(2 * l) * B * H : nullptr; float* hcc = hc ? hc + (size_t)(2 * l + 1) * B * H : nullptr;
+            if (H == 128) hipLaunchKernelGGL(lstm_seq_fwd_kernel<128>, dim3(apx_cdiv(B, 16)), dim3(256), 0, s, G, P.Whh[l], P.bhh[l], hh, hcc, Cc, Hh, T, (long)B);
+            else hipLaunchKernelGGL(lstm_seq_fwd_kernel<64>, dim3(apx_cdiv(B, 16)), dim3(256), 0, s, G, P.Whh[l], P.bhh[l], hh, hcc, Cc, Hh, T, (long)B);
+            APX_LAUNCH_CHECK();
+            in = Hh;
+            continue;
+        }
         for (int t = 0; t < T; ++t) {
             const float* hp = t ? Hh + (size_t)(t - 1) * B * H : (hc ? hc + (size_t)(2 * l) * B * H : nullptr);
             const float* cp = t ? Cc + (size_t)(t - 1) * B * H : (hc ? hc + (size_t)(2 * l + 1) * B * H : nullptr);
@@ -777,6 +935,11 @@ extern "C" int apx_lstm_backward(const float* params, float* grads, int D, int H
         const float* G = save + (size_t)l * TB * 6 * H; const float* Cc = G + TB * 4 * H; const float* Hh = Cc + TB * H;
         const float* in = l ? save + (size_t)(l - 1) * TB * 6 * H + TB * 5 * H : x;
         APX_HIP(hipMemsetAsync(dc, 0, sizeof(float) * B * H, s));
+        if (lstm_persistent_ok(H)) {
+            if (H == 128) hipLaunchKernelGGL(lstm_seq_bwd_kernel<128>, dim3(apx_cdiv(B, 16)), dim3(256), 0, s, G, Cc, P.Whh[l], dHa, dG, T, (long)B);
+            else hipLaunchKernelGGL(lstm_seq_bwd_kernel<64>, dim3(apx_cdiv(B, 16)), dim3(256), 0, s, G, Cc, P.Whh[l], dHa, dG, T, (long)B);
+            APX_LAUNCH_CHECK();
+        } else
         for (int t = T - 1; t >= 0; --t) {
             hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(apx_cdiv(B * H, 256)), dim3(256), 0, s, G + (size_t)t * B * 4 * H, Cc + (size_t)t * B * H,
                                t ? Cc + (size_t)(t - 1) * B * H : nullptr, dHa + (size_t)t * B * H, t < T - 1 ? dhr : nullptr, dc,
