@@ -690,6 +690,7 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     e->wk = nullptr;
     APX_HIP(hipMalloc(&e->wk, 256));      // generation 4 keeps the stage hand-off in LDS: no HBM workspace
     e->hf = nullptr; e->hf_nrow = e->hf_ncol = 0; e->hf_size[0] = e->hf_size[1] = e->hf_size[2] = 0.f;
+    e->timing = 0; e->ev = nullptr; e->ev_cap = e->ev_n = 0; e->t_ms = 0.0; e->t_launches = 0;
     const Cfg c = make_cfg(*e);
     hipLaunchKernelGGL(env_init_kernel, dim3(e->n / 64), dim3(64), 0, 0, e->st, e->ist, e->n, c);
     APX_LAUNCH_CHECK();
@@ -707,6 +708,8 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
 extern "C" int apx_env_destroy(apx_env_t* e) {
     if (!e) return APX_OK;
     (void)hipFree(e->st); (void)hipFree(e->ist); (void)hipFree(e->wk); (void)hipFree(e->hf);
+    for (int i = 0; i < e->ev_cap; ++i) (void)hipEventDestroy((hipEvent_t)e->ev[i]);
+    free(e->ev);
     delete e;
     return APX_OK;
 }
@@ -773,11 +776,14 @@ extern "C" int apx_env_apply_force(apx_env_t* e, const float* xfrc, void* stream
 extern "C" int apx_env_step(apx_env_t* e, const float* action, float* obs, float* reward, uint8_t* done, float* final_obs,
                             int auto_reset, void* stream) {
     APX_REQUIRE(e && action && obs && reward && done, "null pointer");
+    const bool timed = e->timing && e->ev_n + 2 <= e->ev_cap;
+    if (timed) APX_HIP(hipEventRecord((hipEvent_t)e->ev[e->ev_n], (hipStream_t)stream));
     if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_step_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
                        make_cfg(*e), action, obs, reward, done, final_obs);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_step_kernel<false>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
                        make_cfg(*e), action, obs, reward, done, final_obs);
     APX_LAUNCH_CHECK();
+    if (timed) { APX_HIP(hipEventRecord((hipEvent_t)e->ev[e->ev_n + 1], (hipStream_t)stream)); e->ev_n += 2; }
     if (auto_reset) {   // finished envs restart in a second launch on the same stream (mask = done flags)
         if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
                            make_cfg(*e), done, obs);
@@ -785,6 +791,40 @@ extern "C" int apx_env_step(apx_env_t* e, const float* action, float* obs, float
                            make_cfg(*e), done, obs);
         APX_LAUNCH_CHECK();
     }
+    return APX_OK;
+}
+
+// Kernel timing for the roofline line of bench.py: while enabled, every env_step_kernel launch (apx_env_step and the steps inside apx_rollout) is
+// bracketed by a hipEvent pair on the launch stream; apx_env_timing_read drains the pairs into (total ms, launches).  Up to 4096 launches
+// between two reads are recorded, later ones run untimed.
+#define APX_TRY(x) do { int rc__ = (x); if (rc__ != APX_OK) return rc__; } while (0)
+static int timing_drain(apx_env* e) {
+    for (int i = 0; i + 1 < e->ev_n; i += 2) {
+        APX_HIP(hipEventSynchronize((hipEvent_t)e->ev[i + 1]));
+        float ms = 0.f;
+        APX_HIP(hipEventElapsedTime(&ms, (hipEvent_t)e->ev[i], (hipEvent_t)e->ev[i + 1]));
+        e->t_ms += ms; e->t_launches += 1;
+    }
+    e->ev_n = 0;
+    return APX_OK;
+}
+extern "C" int apx_env_timing(apx_env_t* e, int enable) {
+    APX_REQUIRE(e, "env");
+    if (enable && !e->ev) {
+        const int cap = 8192;
+        e->ev = (void**)calloc(cap, sizeof(void*));
+        APX_REQUIRE(e->ev, "alloc");
+        for (int i = 0; i < cap; ++i) { hipEvent_t ev; APX_HIP(hipEventCreate(&ev)); e->ev[i] = ev; e->ev_cap = i + 1; }
+    }
+    if (!enable) APX_TRY(timing_drain(e));
+    e->timing = enable ? 1 : 0;
+    return APX_OK;
+}
+extern "C" int apx_env_timing_read(apx_env_t* e, double* total_ms, int64_t* launches, int reset) {
+    APX_REQUIRE(e && total_ms && launches, "null pointer");
+    APX_TRY(timing_drain(e));
+    *total_ms = e->t_ms; *launches = e->t_launches;
+    if (reset) { e->t_ms = 0.0; e->t_launches = 0; }
     return APX_OK;
 }
 

@@ -32,6 +32,8 @@ struct apx_env {
     float* wk;      // unused placeholder allocation (the stage hand-off lives in LDS)
     int n;
     float* hf; int hf_nrow, hf_ncol; float hf_size[3];      // device copy of the height field (apx_env_set_hfield), or nullptr
+    // apx_env_timing: hipEvent pairs around every env_step_kernel launch, on the launch stream (bench.py's roofline.achieved)
+    int timing; void** ev; int ev_cap, ev_n; double t_ms; long t_launches;
 };
 
 // global-address-space pointers: St is passed by value into a non-inlined device function, where the compiler could

@@ -239,6 +239,16 @@ class CassieVecEnv:
         sz = (C.c_float * 3)(*[float(x) for x in size])
         check(lib.apx_env_set_hfield(self._h, C.c_void_p(d.data_ptr()), int(d.shape[0]), int(d.shape[1]), C.cast(sz, C.c_void_p), _stream()))
 
+    def kernel_timing(self, enable=True):
+        """switch the hipEvent bracketing of env_step_kernel launches on / off (include/apx.h apx_env_timing)"""
+        check(lib.apx_env_timing(self._h, 1 if enable else 0))
+
+    def kernel_timing_read(self, reset=True):
+        """(total ms, launches) of the env_step_kernel launches recorded since the last reset"""
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        check(lib.apx_env_timing_read(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
+
     def saturation(self):
         """(flags [N] int64, passes [N] int64): SAT_* bits (1 = more than 2 penetrating capsule ends on a leg, 2 = more than 1 active joint
         limit on a leg, 4 = pelvis sphere / hip-pitch capsule on the floor, 8 = a left-right capsule pair in contact) a forward pass of the

@@ -209,9 +209,9 @@ def main():
 
     for _ in range(a.warmup):
         algo.iteration()
-    # per-launch duration of the dominant kernel (env step), HIP events on the stream the kernel is launched on
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    act = torch.zeros(a.n_envs, 10, device=env.device)
+    # per-launch duration of the dominant kernel (env step): hipEvent pairs recorded by the library around every env_step_kernel launch of
+    # the timed region, on the stream the kernel is launched on (include/apx.h apx_env_timing)
+    env.kernel_timing(True); env.kernel_timing_read(reset=True)
     barrier()
     t0 = time.time()
     samp = opt = 0.0
@@ -224,17 +224,9 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax)
-    # dominant-kernel timing, outside the timed region (same state distribution, same launch geometry)
-    # (events bracket env_step_kernel alone: the restart of finished envs is a second launch and is issued outside the pair)
-    n_launch = 8
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_launch)]
-    for e0, e1 in evs:
-        e0.record()
-        env.step(act, auto_reset=False)
-        e1.record()
-        env.reset(mask=env.done)
-    torch.cuda.synchronize()
-    k_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / n_launch
+    k_total_ms, k_launches = env.kernel_timing_read(reset=True)      # the env_step_kernel launches of the timed region
+    env.kernel_timing(False)
+    k_ms = k_total_ms / max(k_launches, 1)
 
     # MFMA side: the actor's 3-layer fp32 forward on one minibatch (50 -> 256 -> 256 -> 10), events on the launch stream
     mb_rows = min(a.minibatch, a.rollout_len * a.n_envs)
@@ -274,7 +266,7 @@ def main():
             # north_star asks for is reported beside it.
             "roofline": {"kernel": "env_step_kernel", "bound": "valu", "achieved": round(flop_step * a.n_envs / (k_ms * 1e-3) / 1e12, 4),
                          "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop_step * a.n_envs / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 6),
-                         "traffic": _pmc_traffic_bytes(), "ms_per_launch": round(k_ms, 3),
+                         "traffic": _pmc_traffic_bytes(), "ms_per_launch": round(k_ms, 4), "launches_timed": k_launches,
                          "flop_per_env_step": flop_step, "flop_source": "instrumented count of oracle/cassie_phys.cpp (oracle.sim.count_flops); hand count of the tree-sparse formulation: %d" % roofline.ENV_STEP_FLOP,
                          "hbm": {"bytes_per_env_step": bytes_per_env_step, "achieved_GBps": round(achieved, 3), "peak_GBps": HBM_PEAK_GBS, "frac": round(achieved / HBM_PEAK_GBS, 6)},
                          "mlp_forward_mfma": {"what": "actor forward, %d x (50-256-256-10), fp32 MFMA (v_mfma_f32_32x32x2_f32), one fused launch (input normalisation + 3 layers, activations in LDS)" % mb_rows,

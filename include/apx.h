@@ -237,6 +237,13 @@ int apx_rollout(apx_env_t* env, const float* actor, int H, const float* obs_mean
 int apx_env_step(apx_env_t* env, const float* action, float* obs, float* reward, uint8_t* done, float* final_obs,
                  int auto_reset, void* stream);
 
+/* Measurement hook (no counterpart in the reference; bench.py's roofline.achieved): while enabled, every env_step_kernel launch - from
+ * apx_env_step and from the steps inside apx_rollout - is bracketed by a hipEvent pair on the launch stream.  apx_env_timing_read waits
+ * for the recorded launches and returns their summed duration and count since the last reset (at most 4096 launches between two reads
+ * are recorded, later ones run untimed). */
+int apx_env_timing(apx_env_t* env, int enable);
+int apx_env_timing_read(apx_env_t* env, double* total_ms, int64_t* launches, int reset);
+
 /* Raw simulator state access (cassie_sim_qpos / cassie_sim_qvel, include/cassiemujoco.h:83-87): copies, SoA ->
  * [n_envs, 35] / [n_envs, 32] row-major f32.  Used by tests and by apx_env_set_state for parity replays. */
 int apx_env_get_state(apx_env_t* env, float* qpos, float* qvel, void* stream);

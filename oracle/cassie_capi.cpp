@@ -82,6 +82,12 @@ static int field(Env& e, const char* name, double* io, bool set) {
     if (!std::strcmp(name, "xpos")) { if (!set) std::memcpy(io, e.st.xpos, sizeof(double) * 3 * NB); return 3 * NB; }
     if (!std::strcmp(name, "xquat")) { if (!set) std::memcpy(io, e.st.xquat, sizeof(double) * 4 * NB); return 4 * NB; }
     if (!std::strcmp(name, "efc_type")) { if (!set) for (int i = 0; i < MAXEFC; ++i) io[i] = e.st.efc_type[i]; return MAXEFC; }
+    if (!std::strcmp(name, "solver_hist")) { if (!set) for (int i = 0; i < 51; ++i) io[i] = e.iter_hist[i]; return 51; }
+    if (!std::strcmp(name, "solver")) {     // solver_iter of the last forward pass, sum and count over the env's life, tolerance, meaninertia
+        if (set) { e.par.tolerance = io[3]; return 5; }
+        io[0] = e.st.solver_iter; io[1] = (double)e.iter_sum; io[2] = (double)e.iter_passes; io[3] = e.par.tolerance; io[4] = e.par.meaninertia;
+        return 5;
+    }
     if (!std::strcmp(name, "ints")) {   // time, phase, counter, ncon, nefc, rng ctr, has_prev_action, has_prev_torque, sat flags (accumulated), ncon1
         int* p[10] = {&e.time, &e.phase, &e.counter, &e.st.ncon, &e.st.nefc, (int*)&e.rng.ctr, &e.has_prev_action, &e.has_prev_torque, &e.sat_acc, &e.st.ncon1};
         if (set) { for (int i = 0; i < 8; ++i) *p[i] = (int)io[i]; return 8; }     // the first 8 are settable (tests); sat / ncon1 are read-only

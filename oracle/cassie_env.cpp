@@ -135,6 +135,7 @@ void core_safety(const double* q, const double* qd, const double* cmd, double ra
 
 static void forward_snapshot(Env& e, Work& w, const double* ctrl) {
     forward(e.par, e.st, w, ctrl);
+    e.iter_sum += e.st.solver_iter; ++e.iter_passes; ++e.iter_hist[std::min(std::max(e.st.solver_iter, 0), 50)];
     e.sat_acc |= e.st.sat;                        // constraint sets beyond the HIP kernel's per-leg caps, accumulated over the env's life
     const State& s = e.st;
     for (int u = 0; u < 10; ++u) { e.snap_mpos[u] = s.qpos[cm_act_qposadr[u]]; e.snap_mvel[u] = s.qvel[cm_act_dof[u]]; }

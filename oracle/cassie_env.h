@@ -72,6 +72,7 @@ struct Env {
     double l_foot_frc, r_foot_frc, l_foot_orient_cost, r_foot_orient_cost;
     double prev_action[10], prev_torque[10]; int has_prev_action, has_prev_torque;
     double last_reward_terms[8];
+    long iter_sum, iter_passes; int iter_hist[51];   // solver statistics over every forward pass since env_init: sum / count / histogram of State::solver_iter
     int sat_acc;               // OR of State::sat over every forward pass since env_init (SatFlag bits)
 };
 

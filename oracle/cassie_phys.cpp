@@ -197,7 +197,7 @@ void default_params(Params& p) {
     for (int d = 0; d < NV; ++d) p.damping[d] = cm_dof_damping[d];
     p.friction = 1.0;
     p.floor_quat = {1, 0, 0, 0};
-    p.pgs_iters = 50;
+    p.pgs_iters = 50; p.tolerance = 0;      // see Params::tolerance
     set_const(p);
 }
 
@@ -206,6 +206,11 @@ void set_const(Params& p) {
     static State s; static Work w;
     kinematics(cm_qpos0, s, w);
     inertias(p, s, w);
+    {   // set0: stat.meaninertia = mean of the diagonal of M at qpos0 (scale of the solver's termination test)
+        double tr = 0;
+        for (int d = 0; d < NV; ++d) tr += w.M[d][d];
+        p.meaninertia = tr / NV;
+    }
     if (!cholesky(w.M, w.L)) return;
     static double Minv[NV][NV];
     for (int c = 0; c < NV; ++c) {
@@ -458,15 +463,25 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
         cost += f[i] * (0.5 * a + b[i]);
     }
     if (cost > 0) for (int i = 0; i < n; ++i) f[i] = 0;
-    for (int it = 0; it < p.pgs_iters; ++it)
+    // mj_solPGS: scalar Gauss-Seidel sweeps; a sweep's cost decrease, made dimensionless by 1 / (meaninertia * max(1, nv)), is compared with
+    // opt.tolerance after the sweep and the solver stops early once it falls below (at most opt.iterations = 50 sweeps, cassie.xml:5)
+    const double scale = 1.0 / (p.meaninertia * NV);
+    s.solver_iter = 0;
+    for (int it = 0; it < p.pgs_iters; ++it) {
+        double improvement = 0;
         for (int i = 0; i < n; ++i) {
             double res = b[i];
             for (int j = 0; j < n; ++j) res += AR[i][j] * f[j];
             CNT(2 * n + 3);                                  // the residual of a row touches every multiplier (A is dense: every row reaches the pelvis)
             double fi = f[i] - res / AR[i][i];
             if (rows[i].type != 0 && fi < 0) fi = 0;
+            const double df = fi - f[i];
+            improvement -= df * (0.5 * df * AR[i][i] + res); // costChange: the dual cost 1/2 f'(A + R) f + f'b moved by df along row i
             f[i] = fi;
         }
+        ++s.solver_iter;
+        if (p.tolerance > 0 && improvement * scale < p.tolerance) break;
+    }
     for (int d = 0; d < NV; ++d) {
         double a = qacc_smooth[d];
         for (int i = 0; i < n; ++i) { CNT(NZ(MiJ[i][d], f[i])); a += MiJ[i][d] * f[i]; }

@@ -99,6 +99,13 @@ struct Params {                  // per-env model parameters touched by dynamics
     double body_invweight0[NB][2];
     double dof_invweight0[NV];
     int pgs_iters;
+    // mjOption.tolerance: MuJoCo's PGS stops once the scaled cost improvement of a sweep falls below it (default 1e-8, cassie.xml:5 leaves it).
+    // The HIP kernel always runs opt.iterations = 50 sweeps (four envs share a wave: a per-env exit saves nothing), so the oracle's default
+    // is 0 = never stop early.  With 1e-8 the solver stops after 35 sweeps on average on a walking gait (12 % of the passes use all 50) and
+    // the 150-step return of the trained policy moves by < 0.1 % (tests/test_oracle_env.py::test_solver_tolerance_knob): the extra sweeps
+    // only tighten the same fixed point.
+    double tolerance = 0;
+    double meaninertia = 1;      // mjModel.stat.meaninertia = trace(M(qpos0)) / nv, recomputed by set_const like body_invweight0
     // terrain (cassie_hfield.xml:69,74, util/eval.py:73-76): when hf_data != nullptr the floor is a height field instead of the plane:
     // hf_nrow x hf_ncol samples (row = y, column = x) over [-hf_size[0], hf_size[0]] x [-hf_size[1], hf_size[1]], elevation = data * hf_size[2]
     const float* hf_data = nullptr; int hf_nrow = 0, hf_ncol = 0; double hf_size[3] = {0, 0, 0};
@@ -122,6 +129,7 @@ struct State {
     double con_dist[MAXCON]; int con_geom[MAXCON];
     V3 con_frame[MAXCON][3];     // contact frames (normal, two tangents) of the floor contacts of the most recent forward pass
     int sat;                     // SatFlag bits of the most recent forward pass: the constraint set exceeded what the HIP kernel instantiates
+    int solver_iter;             // sweeps the PGS solver ran in the most recent forward pass (mjData.solver_iter)
     int ncon1;                   // leg-leg (frictionless) contacts of the most recent forward pass
     double xfrc[6] = {0, 0, 0, 0, 0, 0};   // mjData.xfrc_applied row of cassie-pelvis: world force xyz, torque xyz, applied at the body COM
 };

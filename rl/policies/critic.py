@@ -1,10 +1,13 @@
-"""FF_V with the reference's pickle surface (rl/policies/critic.py:37-77): critic_layers, network_out, obs_std,
-obs_mean, normc_init; normalises its input only when NOT in training mode (critic.py:66-67)."""
+"""Host-side mirrors of the reference's critic classes, kept ONLY as the pickle surface: module path, class and
+attribute names, state_dict keys and forward signatures are dictated by the reference's checkpoints (rl/policies/critic.py:37-77 FF_V,
+118-168 Dual_Q_Critic, 236-296 LSTM_V), so the constructor bodies follow the reference by necessity.  The value nets normalise their input
+only when NOT in training mode (critic.py:66-67).  On the GPU the weights live in apex_amd.engine; these classes carry them to and from disk."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from rl.policies.base import Net, normc_fn
+from rl.policies.actor import _stack
 
 
 class Critic(Net):
@@ -22,27 +25,15 @@ class FF_V(Critic):
     def __init__(self, state_dim, layers=(256, 256), env_name="NOT SET", nonlinearity=F.relu, normc_init=True,
                  obs_std=None, obs_mean=None):
         super().__init__()
-        self.critic_layers = nn.ModuleList()
-        self.critic_layers += [nn.Linear(state_dim, layers[0])]
-        for i in range(len(layers) - 1):
-            self.critic_layers += [nn.Linear(layers[i], layers[i + 1])]
+        self.critic_layers = _stack(nn.Linear, (state_dim,) + tuple(layers))
         self.network_out = nn.Linear(layers[-1], 1)
-        self.env_name = env_name
-        self.nonlinearity = nonlinearity
-        self.obs_std = obs_std
-        self.obs_mean = obs_mean
-        self.normc_init = normc_init
-        self.init_parameters()
+        self.env_name, self.nonlinearity, self.obs_std, self.obs_mean, self.normc_init = env_name, nonlinearity, obs_std, obs_mean, normc_init
+        if normc_init:
+            self.apply(normc_fn)
         self.train()
 
-    def init_parameters(self):
-        if self.normc_init:
-            self.apply(normc_fn)
-
     def forward(self, inputs):
-        if self.training is False:
-            inputs = (inputs - self.obs_mean) / self.obs_std
-        x = inputs
+        x = inputs if self.training else (inputs - self.obs_mean) / self.obs_std
         for layer in self.critic_layers:
             x = self.nonlinearity(layer(x))
         return self.network_out(x)
@@ -57,16 +48,10 @@ class LSTM_V(Critic):
 
     def __init__(self, input_dim, layers=(128, 128), env_name="NOT SET", normc_init=True):
         super().__init__()
-        self.critic_layers = nn.ModuleList()
-        self.critic_layers += [nn.LSTMCell(input_dim, layers[0])]
-        for i in range(len(layers) - 1):
-            self.critic_layers += [nn.LSTMCell(layers[i], layers[i + 1])]
+        self.critic_layers = _stack(nn.LSTMCell, (input_dim,) + tuple(layers))
         self.network_out = nn.Linear(layers[-1], 1)
         self.init_hidden_state()
-        self.is_recurrent = True
-        self.env_name = env_name
-        self.obs_std = 1.0
-        self.obs_mean = 0.0
+        self.is_recurrent, self.env_name, self.obs_std, self.obs_mean = True, env_name, 1.0, 0.0
         if normc_init:
             self.initialize_parameters()
 
@@ -78,20 +63,17 @@ class LSTM_V(Critic):
         self.cells = [torch.zeros(batch_size, l.hidden_size) for l in self.critic_layers]
 
     def _step(self, x):
-        for idx, layer in enumerate(self.critic_layers):
-            self.hidden[idx], self.cells[idx] = layer(x, (self.hidden[idx], self.cells[idx]))
-            x = self.hidden[idx]
+        for i, cell in enumerate(self.critic_layers):
+            self.hidden[i], self.cells[i] = cell(x, (self.hidden[i], self.cells[i]))
+            x = self.hidden[i]
         return self.network_out(x)
 
     def forward(self, state):
-        if self.training is False:
-            state = (state - self.obs_mean) / self.obs_std
-        if state.dim() == 3:
-            self.init_hidden_state(batch_size=state.size(1))
-            return torch.stack([self._step(s_t) for s_t in state])
-        flat = state.dim() == 1
-        x = self._step(state.view(1, -1) if flat else state)
-        return x.view(-1) if flat else x
+        x = state if self.training else (state - self.obs_mean) / self.obs_std
+        if x.dim() == 3:
+            self.init_hidden_state(batch_size=x.size(1))
+            return torch.stack([self._step(x_t) for x_t in x])
+        return self._step(x.view(1, -1)).view(-1) if x.dim() == 1 else self._step(x)
 
 
 class Dual_Q_Critic(Critic):
@@ -99,20 +81,20 @@ class Dual_Q_Critic(Critic):
 
     def __init__(self, state_dim, action_dim, hidden_size=256, hidden_layers=2, env_name="NOT SET"):
         super().__init__()
-        self.q1_layers = nn.ModuleList([nn.Linear(state_dim + action_dim, hidden_size)] + [nn.Linear(hidden_size, hidden_size) for _ in range(hidden_layers - 1)])
-        self.q1_out = nn.Linear(hidden_size, 1)
-        self.q2_layers = nn.ModuleList([nn.Linear(state_dim + action_dim, hidden_size)] + [nn.Linear(hidden_size, hidden_size) for _ in range(hidden_layers - 1)])
-        self.q2_out = nn.Linear(hidden_size, 1)
+        sizes = (state_dim + action_dim,) + (hidden_size,) * hidden_layers
+        self.q1_layers, self.q1_out = _stack(nn.Linear, sizes), nn.Linear(hidden_size, 1)
+        self.q2_layers, self.q2_out = _stack(nn.Linear, sizes), nn.Linear(hidden_size, 1)
         self.env_name = env_name
 
+    @staticmethod
+    def _q(layers, out, sa):
+        for layer in layers:
+            sa = F.relu(layer(sa))
+        return out(sa)
+
     def Q1(self, state, action):
-        x = torch.cat([state, action], state.dim() - 1)
-        for layer in self.q1_layers:
-            x = F.relu(layer(x))
-        return self.q1_out(x)
+        return self._q(self.q1_layers, self.q1_out, torch.cat([state, action], state.dim() - 1))
 
     def forward(self, state, action):
-        x2 = torch.cat([state, action], state.dim() - 1)
-        for layer in self.q2_layers:
-            x2 = F.relu(layer(x2))
-        return self.Q1(state, action), self.q2_out(x2)
+        sa = torch.cat([state, action], state.dim() - 1)
+        return self._q(self.q1_layers, self.q1_out, sa), self._q(self.q2_layers, self.q2_out, sa)

@@ -519,7 +519,7 @@ def test_saturation_flags_vs_oracle_crafted(dev):
 
 
 def test_trained_policy_never_saturates_the_constraint_caps(dev):
-    """The kept checkpoint (trained_models/r01_cassie_v0_clock) walking for 300 steps on 256 envs with dynamics randomisation, speeds 0-3 m/s:
+    """The kept checkpoint (trained_models/r02_cassie_v0_clock) walking for 300 steps on 256 envs with dynamics randomisation, speeds 0-3 m/s:
     no forward pass of an env that stays up needs a constraint row the kernel does not instantiate (I_SAT stays 0); envs that fall may
     saturate only in the steps right before termination.  The same counters stay 0 through a push-recovery trial that is survived."""
     import os
@@ -528,7 +528,7 @@ def test_trained_policy_never_saturates_the_constraint_caps(dev):
     import sys; sys.path.insert(0, sys_path)
     import apex
     env = CassieVecEnv(n_envs=256, seed=31, max_traj_len=300)
-    actor, mean, std = apex._load_actor(os.path.join(sys_path, "trained_models", "r01_cassie_v0_clock"), env.device)
+    actor, mean, std = apex._load_actor(os.path.join(sys_path, "trained_models", "r02_cassie_v0_clock"), env.device)
     obs = env.reset()
     alive = torch.ones(256, dtype=torch.bool, device=dev)
     sat_alive = torch.zeros(256, dtype=torch.int64, device=dev)
@@ -543,11 +543,11 @@ def test_trained_policy_never_saturates_the_constraint_caps(dev):
     assert int(walked.sum()) >= 200, int(walked.sum())                       # the policy walks (dynamics randomisation, random commands)
     assert int(cnt[walked].max()) == 0, (flags[walked].unique(), int(cnt[walked].max()))
     env.close()
-    # push recovery (tools/eval_perturb.py semantics): 150 N for 0.2 s on the pelvis, survived -> still no saturation
+    # push recovery (tools/eval_perturb.py semantics): 100 N for 0.2 s on the pelvis, survived -> still no saturation
     env = CassieVecEnv(n_envs=64, seed=32, max_traj_len=100000, dynamics_randomization=False)
     obs = env.reset_for_test(full_reset=True); env.set_command(speed=0.5)
     push = torch.zeros(64, 6, device=dev); ang = torch.linspace(0, 6.28, 65, device=dev)[:64]
-    push[:, 0] = 150 * torch.cos(ang); push[:, 1] = 150 * torch.sin(ang)
+    push[:, 0] = 100 * torch.cos(ang); push[:, 1] = 100 * torch.sin(ang)
     for t in range(200):
         if t == 60: env.apply_force(push)
         if t == 68: env.apply_force(torch.zeros(64, 6, device=dev))

@@ -321,7 +321,7 @@ def test_g16_step_basic_bookkeeping(golden_dir):
 
 def test_g11c_estimator_height_model(golden_dir):
     """G11c: the reference filter's height output (pelvis.position[2] - terrain.height, observation entry 0) on our sensor stream while
-    a 1000-iteration policy trained with this build (the predecessor of trained_models/r01_cassie_v0_clock) walks for 3 s (6000 substeps of 2 kHz), with the true pelvis z and the lowest sole
+    a 1000-iteration policy trained with this build (a predecessor of trained_models/r02_cassie_v0_clock) walks for 3 s (6000 substeps of 2 kHz), with the true pelvis z and the lowest sole
     height per substep (tools/refprobe/gen_golden_estheight.py).  The build's model, height = z - L with L a first-order low-pass
     (EST_TAU) of the lowest sole height started at EST_L0 by state_output_setup, stays within 1.2 cm of the reference over the whole
     stream (the former constant offset z - 0.0818 is off by up to 8.4 cm on it); the oracle env implements exactly this recursion."""
@@ -520,3 +520,22 @@ def test_g22_phase_command_profile(golden_dir):
         e.set("so_mvel", g[p + "mvel"]); e.set("so_jpos", g[p + "jpos"]); e.set("so_jvel", g[p + "jvel"])
         e.set("motor_noise", g[p + "mnoise"]); e.set("joint_noise", g[p + "jnoise"])
         np.testing.assert_allclose(e.obs(), g[p + "obs"], atol=1e-12)
+
+
+def test_solver_tolerance_knob():
+    """mjOption.tolerance (MuJoCo default 1e-8): with the early exit of mj_solPGS the solver uses fewer than the 50 sweeps the oracle and the
+    HIP kernel always run, and a standing-start trajectory under a fixed action sequence stays within 1e-3 of the 50-sweep one."""
+    rs = np.random.RandomState(5)
+    acts = rs.randn(12, 10) * 0.1
+    out = []
+    for tol in (0.0, 1e-8):
+        e = S.OracleEnv(dyn_rand=False, seed=3, env_id=0)
+        e.reset_for_test()
+        sv = e.get("solver"); sv[3] = tol; e.set("solver", sv)
+        assert e.get("solver")[3] == tol and 1.0 < e.get("solver")[4] < 10.0            # meaninertia = trace(M(qpos0)) / nv
+        n0 = e.get("solver")[1:3].copy()
+        obs = [e.step(a)[0] for a in acts]
+        s = e.get("solver")
+        out.append((np.asarray(obs), (s[1] - n0[0]) / (s[2] - n0[1])))
+    assert out[0][1] == 50.0 and 5.0 < out[1][1] < 50.0, (out[0][1], out[1][1])
+    assert np.abs(out[0][0] - out[1][0]).max() < 1e-3

@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $ROOT/bench.py --steps 5 --warmup 1 > $OUT/bench_under_rocprof.log 2>&1 || true
-tail -1 $OUT/bench_under_rocprof.log > $OUT/${TAG}_bench_line_under_rocprof.json
+grep '^{' $OUT/bench_under_rocprof.log | tail -1 > $OUT/${TAG}_bench_line_under_rocprof.json
 python $ROOT/tools/rocprof_summary.py $(ls $OUT/kt/*/*.db | head -1) $OUT/${TAG}_bench_kernel_stats.txt > /dev/null
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/sq -- python $ROOT/tools/t_pmc.py > $OUT/sq.log 2>&1 || true
 python $ROOT/tools/pmc_summary.py $OUT/sq $OUT/${TAG}_env_step_pmc_sq.txt "# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -- python tools/t_pmc.py (per-dispatch means)" > /dev/null
