@@ -241,12 +241,12 @@ class CassieVecEnv:
 
     def kernel_timing(self, enable=True):
         """switch the hipEvent bracketing of env_step_kernel launches on / off (include/apx.h apx_env_timing)"""
-        check(lib.apx_env_timing(self._h, 1 if enable else 0))
+        check(_lib.load().apx_env_timing(self._h, 1 if enable else 0))
 
     def kernel_timing_read(self, reset=True):
         """(total ms, launches) of the env_step_kernel launches recorded since the last reset"""
         ms, n = C.c_double(0.0), C.c_int64(0)
-        check(lib.apx_env_timing_read(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
+        check(_lib.load().apx_env_timing_read(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
         return ms.value, n.value
 
     def saturation(self):
