@@ -113,17 +113,24 @@ def main_recurrent(a):
     """BASELINE.json configs[3] (next row f1): CassieTraj-v0 recurrent PPO, 2048 envs/GPU, whole-trajectory minibatches.  Same contract:
     W warm-up iterations, K timed ones between barriers, one JSON line on rank 0."""
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == a.gpus == 1, "the recurrent workload is single-GPU in this round"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    share = os.environ.get("APX_BENCH_SHARE_GPU") == "1"      # test hook: all ranks on cuda:0 over gloo
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     group = None
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local)); group = torch.distributed.group.WORLD
+        if share:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        group = torch.distributed.group.WORLD
     from apex_amd.vecenv import CassieVecEnv
     from apex_amd.ppo_recurrent import RecurrentPPO
     from apex_amd import dist as adist
-    n_envs, T = 2048, 400          # whole episodes: T = max_traj_len (every trajectory starts at an episode start, zero hidden state)
+    n_envs, T = (a.n_envs if a.n_envs != 4096 else 2048), 400          # whole episodes: T = max_traj_len (every trajectory starts at an episode start, zero hidden state)
     env = CassieVecEnv(n_envs=n_envs, seed=0, device=local, env_id_base=adist.shard_env_base(rank, n_envs), env_name="CassieTraj-v0")
-    args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=1024, epochs=a.epochs,
+    args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=min(1024, n_envs // 2), epochs=a.epochs,
                 num_steps=T * n_envs * world, max_traj_len=400, max_grad_norm=0.05, mirror=True, seed=0)
     algo = RecurrentPPO(args, "/tmp/apx_bench_unused", env, rank=rank, world_size=world, group=group)
     algo.init_networks(0); algo.normalization_params(10000)
@@ -148,7 +155,8 @@ def main_recurrent(a):
                           "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "CassieTraj-v0 recurrent PPO (LSTM 2x128 actor/critic, whole-trajectory minibatches), 2048 envs/GPU (BASELINE.json configs[3])",
-                                     "envs_per_gpu": n_envs, "rollout_len": T, "minibatch_trajectories": 1024, "epochs": a.epochs, "mirror_loss": True},
+                                     "envs_per_gpu": n_envs, "rollout_len": T, "minibatch_trajectories": min(1024, n_envs // 2), "epochs": a.epochs, "mirror_loss": True,
+                                     "parallelism": f"dp{world} (env shards; optimiser steps per epoch agreed by a MAX all-reduce, 1 gradient all-reduce per step)"},
                           "sample_s": round(samp / a.steps, 3), "optimize_s": round(opt / a.steps, 3)}))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -22,5 +22,13 @@ HASH=$(cd $ROOT && python -c "import bench; print(bench.kernel_source_hash())")
 python $ROOT/tools/pmc_summary.py $OUT/hbm $OUT/${TAG}_env_step_pmc_hbm.txt "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KB per dispatch) -- python tools/t_pmc.py; kernel sources sha1: $HASH" > /dev/null
 cd $ROOT
 python bench.py --steps 20 --warmup 2 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line.json
+python bench.py --steps 20 --warmup 2 --precision bf16 --no_cpu_baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line_bf16.json
+python bench.py --workload cassietraj_recurrent --steps 3 --warmup 1 --no_cpu_baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line_recurrent.json
+#   4. per-kernel time of the recurrent workload (persistent LSTM layer kernels)          -> profiles/<tag>_recurrent_kernel_stats.txt
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/ktr -- python $ROOT/bench.py --workload cassietraj_recurrent --steps 2 --warmup 1 --no_cpu_baseline > $OUT/rec_under_rocprof.log 2>&1 || true)
+python $ROOT/tools/rocprof_summary.py $(ls $OUT/ktr/*/*.db | head -1) $OUT/${TAG}_recurrent_kernel_stats.txt > /dev/null || true
+rm -rf $OUT/ktr
+#   5. -ffast-math A/B of the env kernel (needs lib/libapx_nofm.so: make -C apex_amd/csrc VARIANT=nofm FASTMATH=)  -> profiles/<tag>_fastmath_ab.json
+if [ -f apex_amd/lib/libapx_nofm.so ]; then python tools/t_fastmath_ab.py > $OUT/${TAG}_fastmath_ab.json 2>$OUT/fastmath_ab.err || true; fi
 rm -rf $OUT/kt $OUT/sq $OUT/fetch $OUT/write $OUT/hbm
 ls -la $OUT
