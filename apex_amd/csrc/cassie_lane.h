@@ -1112,6 +1112,10 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
             GX[K] = f2g{aa, bb};
         });
     }
+    // The row vectors are needed again only for the z~ read-back after the sweeps: park them in the (now free) row store instead of
+    // keeping 38 registers live across the loop.  Column c of leg g of lane l at rows[(2 c + g) 16 + l]: conflict-free, own lane only.
+    sfor<0, 19>([&](auto C) { rows[(2 * C + 0) * 16 + l] = A.J[C]; rows[(2 * C + 1) * 16 + l] = B.J[C]; });
+    static_assert(38 * 16 <= R4_CON, "parked row vectors fit below the contact slot records");
     // leg-leg row scalars to every lane
     float xb[MAXX], xR[MAXX], xiA[MAXX], xf[MAXX]; bool xact[MAXX];
     sfor<0, MAXX>([&](auto K) {
@@ -1194,29 +1198,49 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
         Gp[0][s] = f2{GAA[s] + ((s < 7 && l == s) ? A.R : 0.f), GBA[s]};
         Gp[1][s] = f2{GAB[s], GBB[s] + ((s < 7 && l == s) ? B.R : 0.f)};
     });
-    float tsum[2][6];                                       // sum over the sweeps of a row's residual: f_s = f0_s - sum_it t_s / (A_ss + R_s)
-    sfor<0, 2>([&](auto Lg) { sfor<0, 6>([&](auto Sx) { tsum[Lg][Sx] = 0.f; }); });
-    // pyramid row k of slot s: f <- max(alpha f + beta - iA (r_n + sm r_t), 0) with alpha = 1 - iA R, beta = -iA b (one fma off the chain)
-    float calpha[NCS][4], cbeta[NCS][4];
-    f2 kk[NCS][4]; float ko[NCS][4];                        // row k moves (r_n, r_active) by kk df and the other tangent's residual by ko df
-    sfor<0, NCS>([&](auto Sl) { sfor<0, 4>([&](auto K) {
-        constexpr int k = K;
-        kk[Sl][k] = f2{kn[Sl][k], k < 2 ? k1[Sl][k] : k2[Sl][k]}; ko[Sl][k] = k < 2 ? k2[Sl][k] : k1[Sl][k];
-        calpha[Sl][k] = 1.f - ciA[Sl][k] * cR[Sl]; cbeta[Sl][k] = -ciA[Sl][k] * cb[Sl][k];
-    }); });
-    const f2 cplus = {1.f, mu}, cminus = {1.f, -mu};
+    // Equality rows (round 2): the constant b_s is folded into the carried residual of the row's own lane (r~ = rho' + b) and the scale
+    // -1/(A_ss + R_s) into the Gram columns, so a row is ONE broadcast and ONE packed fma; the sum of a row's residuals over the sweeps
+    // (f_s = f0_s - sum_it t_s / (A_ss + R_s)) is accumulated on the row's own lane through a 0/1 selector.
+    r.x += l < 7 ? A.b : 0.f; r.y += l < 7 ? B.b : 0.f;
+    f2 GpS[2][6];
+    float selq[6];
+    sfor<0, 6>([&](auto Sx) {
+        constexpr int s = Sx;
+        GpS[0][s] = Gp[0][s] * (-eiA[0][s]); GpS[1][s] = Gp[1][s] * (-eiA[1][s]);
+        asm volatile("" : "+v"(GpS[0][s].x), "+v"(GpS[0][s].y), "+v"(GpS[1][s].x), "+v"(GpS[1][s].y));      // fast-math would undo the folding (t * -iA, then Gp)
+        selq[s] = l == s ? 1.f : 0.f;
+    });
+    float tacc[2] = {0.f, 0.f};
+    // Pyramid (round 2): the four row residuals u_k = r_n +- mu r_t are carried directly.  Row k: df = max(wp - iA u_k, -f_k) with
+    // wp = (alpha - 1) f_k + beta off the chain (alpha = 1 - iA R, beta = -iA b), f_k += df, and the LATER rows' residuals move by
+    // K[j][k] df with K[j][k] = d_j' G3 d_k (d_k = n + s_k mu t_a(k)); rho' of every lane moves by GpRow[k] df.
+    float cam1[NCS][4], cbeta[NCS][4], K10[NCS], K32[NCS];
+    f2 K23a[NCS], K23b[NCS], GpRow[NCS][4];
+    sfor<0, NCS>([&](auto Sl) {
+        constexpr int s = Sl, leg = s / MAXC, ln = 7 + 3 * (s % MAXC);
+        sfor<0, 4>([&](auto K) {
+            constexpr int k = K;
+            cam1[s][k] = -ciA[s][k] * cR[s]; cbeta[s][k] = -ciA[s][k] * cb[s][k];
+            GpRow[s][k] = Gp[leg][ln] + Gp[leg][ln + (k < 2 ? 1 : 2)] * ((k & 1) ? -mu : mu);
+        });
+        // K[j][k] = kn[k] + s_j (a_j == 1 ? k1[k] : k2[k])
+        K10[s] = kn[s][0] - mu * k1[s][0];
+        K23a[s] = f2{kn[s][0] + mu * k2[s][0], kn[s][0] - mu * k2[s][0]};
+        K23b[s] = f2{kn[s][1] + mu * k2[s][1], kn[s][1] - mu * k2[s][1]};
+        K32[s] = kn[s][2] - mu * k2[s][2];
+    });
+    const f2 cpm = {mu, -mu};
     for (int it = 0; it < pgs_iters; ++it) {
         sfor<0, 2>([&](auto Lg) {
             constexpr int leg = Lg;
             sfor<0, 6>([&](auto Sx) {
                 constexpr int s = Sx;
-                const float t = (leg ? dpp<0x150 + s>(r.y) : dpp<0x150 + s>(r.x)) + ec[leg][s];      // ec = b here (never updated)
-                const float df = -t * eiA[leg][s];
-                r += Gp[leg][s] * df;
-                tsum[leg][s] += t;
+                const float t = leg ? dpp<0x150 + s>(r.y) : dpp<0x150 + s>(r.x);
+                r += GpS[leg][s] * t;
+                tacc[leg] += selq[s] * t;
             });
             if (nlim[leg]) {
-                const float t = (leg ? dpp<0x150 + 6>(r.y) : dpp<0x150 + 6>(r.x)) + ec[leg][6];
+                const float t = leg ? dpp<0x150 + 6>(r.y) : dpp<0x150 + 6>(r.x);
                 const float fn = fmaxf(ef[leg][6] - t * eiA[leg][6], 0.f);
                 const float df = fn - ef[leg][6];
                 ef[leg][6] = fn;
@@ -1225,26 +1249,22 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
             sfor<0, MAXC>([&](auto Sl) {
                 constexpr int j = Sl, s = leg * MAXC + j, ln = 7 + 3 * j;
                 if (con[s]) {
-                    const float rn0 = leg ? dpp<0x150 + ln>(r.y) : dpp<0x150 + ln>(r.x), r10 = leg ? dpp<0x150 + ln + 1>(r.y) : dpp<0x150 + ln + 1>(r.x),
-                                r20 = leg ? dpp<0x150 + ln + 2>(r.y) : dpp<0x150 + ln + 2>(r.x);
-                    f2 pr = {rn0, r10};          // (r_n, r_t1) while rows n +- mu t1 are swept
-                    float ro = r20;              // the other tangent's residual
-                    f2 q01 = {0.f, 0.f}, q23 = {0.f, 0.f};      // (sum df, sum +-mu df) of rows 0,1 / 2,3
+                    const float rn = leg ? dpp<0x150 + ln>(r.y) : dpp<0x150 + ln>(r.x), r1 = leg ? dpp<0x150 + ln + 1>(r.y) : dpp<0x150 + ln + 1>(r.x),
+                                r2 = leg ? dpp<0x150 + ln + 2>(r.y) : dpp<0x150 + ln + 2>(r.x);
+                    f2 U01 = f2{rn, rn} + cpm * r1, U23 = f2{rn, rn} + cpm * r2;
+                    float wp[4], df[4];
                     sfor<0, 4>([&](auto K) {
-                        constexpr int k = K;
-                        if constexpr (k == 2) { const float t1 = pr.y; pr.y = ro; ro = t1; }      // now (r_n, r_t2), other = r_t1
-                        const float sm = (k & 1) ? -mu : mu;
-                        float w = calpha[s][k] * cf[s][k] + cbeta[s][k];
-                        asm volatile("" : "+v"(w));                 // keep the off-chain fma: fast-math would re-associate it back into the chain
-                        const float u = pr.x + sm * pr.y;
-                        const float fn = fmaxf(w - ciA[s][k] * u, 0.f);
-                        const float df = fn - cf[s][k];
-                        cf[s][k] = fn;
-                        pr += kk[s][k] * df; ro += ko[s][k] * df;
-                        if constexpr (k < 2) q01 += ((k & 1) ? cminus : cplus) * df; else q23 += ((k & 1) ? cminus : cplus) * df;
+                        wp[K] = cam1[s][K] * cf[s][K] + cbeta[s][K];
+                        asm volatile("" : "+v"(wp[K]));             // keep the off-chain fma: fast-math would re-associate it into the chain
                     });
-                    const float sdn = q01.x + q23.x;
-                    r += Gp[leg][ln] * sdn + Gp[leg][ln + 1] * q01.y + Gp[leg][ln + 2] * q23.y;
+                    df[0] = fmaxf(wp[0] - ciA[s][0] * U01.x, -cf[s][0]);
+                    U01.y += K10[s] * df[0]; U23 += K23a[s] * df[0];
+                    df[1] = fmaxf(wp[1] - ciA[s][1] * U01.y, -cf[s][1]);
+                    U23 += K23b[s] * df[1];
+                    df[2] = fmaxf(wp[2] - ciA[s][2] * U23.x, -cf[s][2]);
+                    U23.y += K32[s] * df[2];
+                    df[3] = fmaxf(wp[3] - ciA[s][3] * U23.y, -cf[s][3]);
+                    sfor<0, 4>([&](auto K) { cf[s][K] += df[K]; r += GpRow[s][K] * df[K]; });
                 }
             });
         });
@@ -1263,7 +1283,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     PROF(7);
     // ---- z~ = sum_r y~_r F_r back to the dof layout of the finish stage
     float ownA = 0.f, ownB = 0.f;                           // lanes 0..5: f0 - iA sum t; the limit lane's f is uniform (ef[.][6])
-    sfor<0, 6>([&](auto Sx) { if (l == Sx) { ownA = f0A - eiA[0][Sx] * tsum[0][Sx]; ownB = f0B - eiA[1][Sx] * tsum[1][Sx]; } });
+    if (l < 6) { ownA = f0A - A.invA * tacc[0]; ownB = f0B - B.invA * tacc[1]; }
     if (l == 6) { ownA = ef[0][6]; ownB = ef[1][6]; }
     sfor<0, NCS>([&](auto Sl) {
         constexpr int s = Sl, leg = s / MAXC, ln = 7 + 3 * (s % MAXC);
@@ -1277,8 +1297,9 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     sfor<0, MAXX>([&](auto K) { if (l == 13 + K && xact[K]) ownA = ownB = xf[K]; });
     sfor<0, 19>([&](auto C) {
         constexpr int c = C;
-        if constexpr (c < 6) { const float z = red16(A.J[c] * ownA + B.J[c] * ownB); if (l == 0) S.W(WK_ZT + c) = z; }
-        else { const float za = red16(A.J[c] * ownA), zb = red16(B.J[c] * ownB); if (l == 0) { S.W(WK_ZT + c) = za; S.W(WK_ZT + c + 13) = zb; } }
+        const float ja = rows[(2 * c + 0) * 16 + l], jb = rows[(2 * c + 1) * 16 + l];
+        if constexpr (c < 6) { const float z = red16(ja * ownA + jb * ownB); if (l == 0) S.W(WK_ZT + c) = z; }
+        else { const float za = red16(ja * ownA), zb = red16(jb * ownB); if (l == 0) { S.W(WK_ZT + c) = za; S.W(WK_ZT + c + 13) = zb; } }
     });
     if (l == 0) {
         // contact forces to the row store (foot-force readout in the finish stage)
