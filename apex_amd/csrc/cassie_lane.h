@@ -1198,19 +1198,41 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
         Gp[0][s] = f2{GAA[s] + ((s < 7 && l == s) ? A.R : 0.f), GBA[s]};
         Gp[1][s] = f2{GAB[s], GBB[s] + ((s < 7 && l == s) ? B.R : 0.f)};
     });
-    // Equality rows (round 2): the constant b_s is folded into the carried residual of the row's own lane (r~ = rho' + b) and the scale
-    // -1/(A_ss + R_s) into the Gram columns, so a row is ONE broadcast and ONE packed fma; the sum of a row's residuals over the sweeps
-    // (f_s = f0_s - sum_it t_s / (A_ss + R_s)) is accumulated on the row's own lane through a 0/1 selector.
+    // Equality rows (round 2).  (1) The constant b_s is folded into the carried residual of the row's own lane (r~ = rho' + b) and the
+    // scale -1/(A_ss + R_s) into the Gram columns g_s, so row s is t_s = r~[s], r~ += g_s t_s.  (2) The six rows of a leg are linear, so
+    // their Gauss-Seidel pass is composed ONCE per substep: t = T x with x = the six own residuals at the start of the pass and
+    // T = (I - N)^-1, N[s][j] = g_j[s] (j < s), and r~ += sum_j W_j x_j with W_j = sum_{s >= j} g_s T[s][j].  Same arithmetic as the
+    // row-by-row pass up to rounding, but the six broadcasts of a pass no longer wait for each other.  (3) f_s = f0_s - sum_it t_s /
+    // (A_ss + R_s) needs sum_it t = T (sum_it x): the own residual is accumulated once per pass and T applied after the loop.
     r.x += l < 7 ? A.b : 0.f; r.y += l < 7 ? B.b : 0.f;
-    f2 GpS[2][6];
-    float selq[6];
-    sfor<0, 6>([&](auto Sx) {
-        constexpr int s = Sx;
-        GpS[0][s] = Gp[0][s] * (-eiA[0][s]); GpS[1][s] = Gp[1][s] * (-eiA[1][s]);
-        asm volatile("" : "+v"(GpS[0][s].x), "+v"(GpS[0][s].y), "+v"(GpS[1][s].x), "+v"(GpS[1][s].y));      // fast-math would undo the folding (t * -iA, then Gp)
-        selq[s] = l == s ? 1.f : 0.f;
+    f2 W[2][6];
+    float Trow[2][6];                                       // row l of T on lanes 0..5
+    sfor<0, 2>([&](auto Lg) {
+        constexpr int leg = Lg;
+        f2 g[6];
+        sfor<0, 6>([&](auto Sx) { g[Sx] = Gp[leg][Sx] * (-eiA[leg][Sx]); });
+        float N[6][6], T[6][6];                             // N[s][k] = component `leg` of g_k on lane s, to every lane (k < s)
+        sfor<1, 6>([&](auto Sr) { sfor<0, Sr>([&](auto Kk) { N[Sr][Kk] = leg ? dpp<0x150 + Sr>(g[Kk].y) : dpp<0x150 + Sr>(g[Kk].x); }); });
+        sfor<1, 6>([&](auto Sr) {
+            constexpr int sr = Sr;
+            sfor<0, sr>([&](auto Jc) {
+                constexpr int j = Jc;
+                float acc = N[sr][j];
+                sfor<j + 1, sr>([&](auto Kk) { acc += N[sr][Kk] * T[Kk][j]; });
+                T[sr][j] = acc;
+            });
+        });
+        sfor<0, 6>([&](auto Jc) {
+            constexpr int j = Jc;
+            f2 w = g[j];
+            sfor<j + 1, 6>([&](auto Sr) { w += g[Sr] * T[Sr][j]; });
+            float tr = l == j ? 1.f : 0.f;
+            sfor<j + 1, 6>([&](auto Sr) { tr = l == Sr ? T[Sr][j] : tr; });
+            asm volatile("" : "+v"(w.x), "+v"(w.y), "+v"(tr));          // materialise here: fast-math would otherwise re-expand the composition inside the loop
+            W[leg][j] = w; Trow[leg][j] = tr;
+        });
     });
-    float tacc[2] = {0.f, 0.f};
+    f2 racc = {0.f, 0.f};                                   // (left, right) sum over the sweeps of the own residual at the start of the leg's pass
     // Pyramid (round 2): the four row residuals u_k = r_n +- mu r_t are carried directly.  Row k: df = max(wp - iA u_k, -f_k) with
     // wp = (alpha - 1) f_k + beta off the chain (alpha = 1 - iA R, beta = -iA b), f_k += df, and the LATER rows' residuals move by
     // K[j][k] df with K[j][k] = d_j' G3 d_k (d_k = n + s_k mu t_a(k)); rho' of every lane moves by GpRow[k] df.
@@ -1230,15 +1252,20 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
         K32[s] = kn[s][2] - mu * k2[s][2];
     });
     const f2 cpm = {mu, -mu};
+    f2 cfp[NCS][2], cam1p[NCS][2], cbetap[NCS][2];          // pyramid rows (0, 1) / (2, 3) of a slot packed for v_pk_fma_f32 / v_pk_add_f32
+    sfor<0, NCS>([&](auto Sl) { sfor<0, 2>([&](auto H) {
+        cfp[Sl][H] = f2{cf[Sl][2 * H], cf[Sl][2 * H + 1]}; cam1p[Sl][H] = f2{cam1[Sl][2 * H], cam1[Sl][2 * H + 1]}; cbetap[Sl][H] = f2{cbeta[Sl][2 * H], cbeta[Sl][2 * H + 1]};
+    }); });
     for (int it = 0; it < pgs_iters; ++it) {
         sfor<0, 2>([&](auto Lg) {
             constexpr int leg = Lg;
-            sfor<0, 6>([&](auto Sx) {
-                constexpr int s = Sx;
-                const float t = leg ? dpp<0x150 + s>(r.y) : dpp<0x150 + s>(r.x);
-                r += GpS[leg][s] * t;
-                tacc[leg] += selq[s] * t;
-            });
+            {
+                float x[6];
+                sfor<0, 6>([&](auto Sx) { x[Sx] = leg ? dpp<0x150 + Sx>(r.y) : dpp<0x150 + Sx>(r.x); });
+                if constexpr (leg) racc.y += r.y; else racc.x += r.x;
+                const f2 u = W[leg][0] * x[0] + W[leg][1] * x[1] + W[leg][2] * x[2], v = W[leg][3] * x[3] + W[leg][4] * x[4] + W[leg][5] * x[5];
+                r += u + v;
+            }
             if (nlim[leg]) {
                 const float t = leg ? dpp<0x150 + 6>(r.y) : dpp<0x150 + 6>(r.x);
                 const float fn = fmaxf(ef[leg][6] - t * eiA[leg][6], 0.f);
@@ -1252,19 +1279,18 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
                     const float rn = leg ? dpp<0x150 + ln>(r.y) : dpp<0x150 + ln>(r.x), r1 = leg ? dpp<0x150 + ln + 1>(r.y) : dpp<0x150 + ln + 1>(r.x),
                                 r2 = leg ? dpp<0x150 + ln + 2>(r.y) : dpp<0x150 + ln + 2>(r.x);
                     f2 U01 = f2{rn, rn} + cpm * r1, U23 = f2{rn, rn} + cpm * r2;
-                    float wp[4], df[4];
-                    sfor<0, 4>([&](auto K) {
-                        wp[K] = cam1[s][K] * cf[s][K] + cbeta[s][K];
-                        asm volatile("" : "+v"(wp[K]));             // keep the off-chain fma: fast-math would re-associate it into the chain
-                    });
-                    df[0] = fmaxf(wp[0] - ciA[s][0] * U01.x, -cf[s][0]);
-                    U01.y += K10[s] * df[0]; U23 += K23a[s] * df[0];
-                    df[1] = fmaxf(wp[1] - ciA[s][1] * U01.y, -cf[s][1]);
-                    U23 += K23b[s] * df[1];
-                    df[2] = fmaxf(wp[2] - ciA[s][2] * U23.x, -cf[s][2]);
-                    U23.y += K32[s] * df[2];
-                    df[3] = fmaxf(wp[3] - ciA[s][3] * U23.y, -cf[s][3]);
-                    sfor<0, 4>([&](auto K) { cf[s][K] += df[K]; r += GpRow[s][K] * df[K]; });
+                    f2 wa = cam1p[s][0] * cfp[s][0] + cbetap[s][0], wb = cam1p[s][1] * cfp[s][1] + cbetap[s][1];      // packed, off the chain
+                    asm volatile("" : "+v"(wa.x), "+v"(wa.y), "+v"(wb.x), "+v"(wb.y));      // fast-math would re-associate them into the chain
+                    f2 da, db;
+                    da.x = fmaxf(wa.x - ciA[s][0] * U01.x, -cfp[s][0].x);
+                    U01.y += K10[s] * da.x; U23 += K23a[s] * da.x;
+                    da.y = fmaxf(wa.y - ciA[s][1] * U01.y, -cfp[s][0].y);
+                    U23 += K23b[s] * da.y;
+                    db.x = fmaxf(wb.x - ciA[s][2] * U23.x, -cfp[s][1].x);
+                    U23.y += K32[s] * db.x;
+                    db.y = fmaxf(wb.y - ciA[s][3] * U23.y, -cfp[s][1].y);
+                    cfp[s][0] += da; cfp[s][1] += db;
+                    r += GpRow[s][0] * da.x + GpRow[s][1] * da.y + GpRow[s][2] * db.x + GpRow[s][3] * db.y;
                 }
             });
         });
@@ -1279,11 +1305,16 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
             }
         });
     }
+    sfor<0, NCS>([&](auto Sl) { cf[Sl][0] = cfp[Sl][0].x; cf[Sl][1] = cfp[Sl][0].y; cf[Sl][2] = cfp[Sl][1].x; cf[Sl][3] = cfp[Sl][1].y; });
     rA = r.x; rB = r.y;
     PROF(7);
     // ---- z~ = sum_r y~_r F_r back to the dof layout of the finish stage
     float ownA = 0.f, ownB = 0.f;                           // lanes 0..5: f0 - iA sum t; the limit lane's f is uniform (ef[.][6])
-    if (l < 6) { ownA = f0A - A.invA * tacc[0]; ownB = f0B - B.invA * tacc[1]; }
+    {   // sum_it t_s = (T sum_it x)_s on the row's own lane
+        float ta = 0.f, tb = 0.f;
+        sfor<0, 6>([&](auto Jc) { ta += Trow[0][Jc] * dpp<0x150 + Jc>(racc.x); tb += Trow[1][Jc] * dpp<0x150 + Jc>(racc.y); });
+        if (l < 6) { ownA = f0A - A.invA * ta; ownB = f0B - B.invA * tb; }
+    }
     if (l == 6) { ownA = ef[0][6]; ownB = ef[1][6]; }
     sfor<0, NCS>([&](auto Sl) {
         constexpr int s = Sl, leg = s / MAXC, ln = 7 + 3 * (s % MAXC);
