@@ -125,10 +125,11 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         constexpr int sd = Sd;
         body[sd] = 2 + 12 * sd + lb; qadr[sd] = 7 + 14 * sd + qoff; dadr[sd] = 6 + 13 * sd + doff;
         const int b = body[sd];
-        bpos[sd] = {cm_body_pos[3 * b], cm_body_pos[3 * b + 1], cm_body_pos[3 * b + 2]};
-        ipos[sd] = {cm_body_ipos[3 * b], cm_body_ipos[3 * b + 1], cm_body_ipos[3 * b + 2]};
-        bquat[sd] = {cm_body_quat[4 * b], cm_body_quat[4 * b + 1], cm_body_quat[4 * b + 2], cm_body_quat[4 * b + 3]};
-        sfor<0, 9>([&](auto K) { Ib[sd][K] = cm_body_inertia[9 * b + K]; });
+        const int cb = CT_BODY + CT_BODYSZ * (b - 2);              // the body's record in the wave-constant table
+        bpos[sd] = {ctf(cb), ctf(cb + 1), ctf(cb + 2)};
+        ipos[sd] = {ctf(cb + 3), ctf(cb + 4), ctf(cb + 5)};
+        bquat[sd] = {ctf(cb + 6), ctf(cb + 7), ctf(cb + 8), ctf(cb + 9)};
+        sfor<0, 9>([&](auto K) { Ib[sd][K] = ctf(cb + 10 + K); });
         mass[sd] = S(F_MASS + b);
     });
     const float jref = lb == 4 ? ct_jnt_ref[8] : lb == 7 ? ct_jnt_ref[10] : 0.f;          // knee, tarsus
@@ -368,8 +369,8 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         const float* cp = (const float*)&S.W(WK_CDOF + 6 * d);
         const SV cd = {{cp[0], cp[1], cp[2]}, {cp[3], cp[4], cp[5]}};
         const SV f = imul(c, cd);
-        const int dep = l < 13 ? (l == 12 ? 13 : nibble(TD_DEPTH, l)) : d + 1, madr = cm_dof_madr[d];
-        S.W(WK_M + madr) = sdot(cd, f) + cm_dof_armature[d];
+        const int dep = l < 13 ? (l == 12 ? 13 : nibble(TD_DEPTH, l)) : d + 1, madr = cti(CT_MADR + d);
+        S.W(WK_M + madr) = sdot(cd, f) + ctf(CT_ARM + d);
         int cur = l;                                                  // walk the ancestor chain: leg dofs first, then pelvis dofs 5..0
         sfor<1, 14>([&](auto An) {      // branch-free: inactive levels read dof 0's axis and store to the env's dummy word
             constexpr int a = An;
@@ -390,8 +391,8 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         const int u = k == 0 ? 0 : k == 1 ? 1 : k == 2 ? 2 : k == 6 ? 3 : k == 12 ? 4 : -1;       // actuated dofs: hip roll, yaw, pitch, knee, foot
         if (u >= 0) {
             const int ua = u + 5 * sd;
-            const float cmax = cm_act_ctrlmax[ua];
-            fs += cm_act_gear[ua] * fminf(fmaxf(S.W(WK_CTRL + ua), -cmax), cmax);
+            const float cmax = ctf(CT_CMAX + ua);
+            fs += ctf(CT_GEAR + ua) * fminf(fmaxf(S.W(WK_CTRL + ua), -cmax), cmax);
         }
         if constexpr (!QPOS0) {
             if (l >= 13) {      // external wrench on the pelvis (mjData.xfrc_applied, applied at the body's COM): J^T (f, tau) on the 6 free-joint dofs
@@ -436,7 +437,31 @@ constexpr MIdx make_midx() {            // offset of M[k][j] inside a leg's bloc
         }
     return t;
 }
-__device__ const MIdx kMidx = make_midx();
+// The wave-constant table (env_state.h CT_*), built at compile time and copied HBM -> LDS once per launch.
+struct CTab { unsigned v[CT_TOTAL]; };
+constexpr CTab make_ct() {
+    CTab t{};
+    auto fb = [](float x) { return __builtin_bit_cast(unsigned, x); };
+    for (int b = 2; b < 26; ++b) {
+        const int o = CT_BODY + CT_BODYSZ * (b - 2);
+        for (int k = 0; k < 3; ++k) { t.v[o + k] = fb(ct_body_pos[3 * b + k]); t.v[o + 3 + k] = fb(ct_body_ipos[3 * b + k]); }
+        for (int k = 0; k < 4; ++k) t.v[o + 6 + k] = fb(ct_body_quat[4 * b + k]);
+        for (int k = 0; k < 9; ++k) t.v[o + 10 + k] = fb(ct_body_inertia[9 * b + k]);
+    }
+    for (int d = 0; d < 32; ++d) { t.v[CT_MADR + d] = (unsigned)ct_dof_madr[d]; t.v[CT_ARM + d] = fb(ct_dof_armature[d]); }
+    for (int u = 0; u < 10; ++u) { t.v[CT_GEAR + u] = fb(ct_act_gear[u]); t.v[CT_CMAX + u] = fb(ct_act_ctrlmax[u]); }
+    const MIdx m = make_midx();
+    for (int l = 0; l < 16; ++l)
+        for (int w = 0; w < 7; ++w)
+            t.v[CT_MIDX + 7 * l + w] = (unsigned)m.v[13 * l + 2 * w] | (2 * w + 1 < 13 ? (unsigned)m.v[13 * l + 2 * w + 1] << 16 : 0u);
+    return t;
+}
+__device__ const CTab kCT = make_ct();
+__device__ __forceinline__ void ct_fill() {                 // all 64 lanes of the workgroup's single wave
+    lint* dst = (lint*)apx_lds4 + L4_EPW * L4_ES;
+    for (int i = threadIdx.x; i < CT_TOTAL; i += 64) dst[i] = (int)kCT.v[i];
+    wsync();
+}
 constexpr int M_LEG0 = ct_dof_madr[6], M_LEGSZ = ct_dof_madr[19] - ct_dof_madr[6];
 static_assert(M_LEG0 == 21 && M_LEGSZ == 143 && CM_NM == M_LEG0 + 2 * M_LEGSZ, "mass-matrix layout");
 
@@ -450,9 +475,13 @@ __device__ __forceinline__ LaneIdx lane_idx() {
     LaneIdx x;
     x.l = threadIdx.x & 15;
     const int lc = x.l < 13 ? x.l : 12;
-    x.own = cm_dof_madr[6 + lc] - M_LEG0;
+    x.own = cti(CT_MADR + 6 + lc) - M_LEG0;
     x.dep = lc == 12 ? 13 : nibble(TD_DEPTH, lc);
-    sfor<0, 13>([&](auto J) { x.mi[J] = kMidx.v[13 * x.l + J]; });
+    sfor<0, 7>([&](auto Wd) {
+        const unsigned w = (unsigned)cti(CT_MIDX + 7 * x.l + Wd);
+        x.mi[2 * Wd] = (unsigned short)(w & 0xFFFFu);
+        if constexpr (2 * Wd + 1 < 13) x.mi[2 * Wd + 1] = (unsigned short)(w >> 16);
+    });
     return x;
 }
 

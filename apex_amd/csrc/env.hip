@@ -11,7 +11,6 @@
 #include "cassie_model_gen.h"
 #include "cassie_lane.h"
 
-extern __shared__ __attribute__((aligned(16))) float4 apx_lds4[];   // dynamic LDS: the constraint-row store
 #include <new>
 #include <cstring>
 
@@ -443,7 +442,8 @@ __device__ float clock_reward(const St& S, const Cfg& cfg, const float* action, 
     const int env = blk * L4_EPW + row;                                                              \
     if (row >= L4_EPW || env >= n) return;                                                                            \
     const bool lead = l == 0;                                                                        \
-    const St S{(lfloat*)apx_lds4 + row * L4_ES, env};
+    const St S{(lfloat*)apx_lds4 + row * L4_ES, env};                                              \
+    c4::ct_fill();
 __device__ __forceinline__ void load_state(const St& S, const float* st, const int* ist, int n) {
     const int l = threadIdx.x & 15;
     constexpr int NIT = (F_TOTAL + 15) / 16;
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_for_test_kerne
     if (lead) write_obs(S, cfg, obs + (size_t)env * cfg.obs_dim);
     store_state(S, st, ist, n);
 }
-static constexpr size_t LDS_BYTES = (size_t)L4_EPW * L4_ES * sizeof(float);   // 37,120 B per wave, 4 waves per CU
+static constexpr size_t LDS_BYTES = (size_t)(L4_EPW * L4_ES + CT_TOTAL) * sizeof(float);      // env regions + wave-constant table   // 37,120 B per wave, 4 waves per CU
 #define ENV_GRID(n) dim3((n) / L4_EPW)
 #define ENV_BLOCK dim3(64)
 #define SETCONST_GRID(n) dim3((n) / L4_EPW)
