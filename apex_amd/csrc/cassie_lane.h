@@ -49,6 +49,9 @@ template <int LEG> constexpr unsigned chain_mask(int body) {
     return m;
 }
 
+#ifndef APX_CRBA_SB
+#define APX_CRBA_SB 0      /* scheduling barrier every n levels of the CRBA chain walk: measured 0 / 3 / 5 / 7 within 0.4 % */
+#endif
 // ------------------------------------------------------------------------------------------------ tree stage
 // Kinematics, velocities, RNE bias forces, composite inertias and the mass matrix, lane-parallel over the 12 bodies of a
 // leg (lane b: left body 2+b in slot 0, right body 14+b in slot 1); the pelvis is computed by every lane.  Bodies are
@@ -374,7 +377,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         int cur = l;                                                  // walk the ancestor chain: leg dofs first, then pelvis dofs 5..0
         sfor<1, 14>([&](auto An) {      // branch-free: inactive levels read dof 0's axis and store to the env's dummy word
             constexpr int a = An;
-            if constexpr (a % 5 == 1) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (APX_CRBA_SB > 0 && a % (APX_CRBA_SB > 0 ? APX_CRBA_SB : 1) == 1) __builtin_amdgcn_sched_barrier(0);
             const bool on = a < dep, inleg = a < dep - 6;
             const int nxt = cur == 12 ? 8 : nibble(TD_PDOF, cur < 13 ? cur : 0);
             cur = (on && inleg) ? nxt : cur;

@@ -867,9 +867,11 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float* __res
         __syncthreads();
     }
 }
-static bool lstm_persistent_ok(int H) {
+static bool lstm_persistent_ok(int H, int T) {
     static const bool on = getenv("APX_LSTM_STEPWISE") == nullptr;      // A/B: the per-step launches of round 1
-    return on && (H == 128 || H == 64);
+    // a launch re-loads W_hh into every workgroup's registers (256 KB at H = 128): worth it from a few time steps on; the one-step calls
+    // of the rollout (169 us per layer call against ~50 us for accumulate-GEMM + gate kernel) stay on the per-step path
+    return on && T >= 4 && (H == 128 || H == 64);
 }
 
 // x[T, B, D] prepared input; hc = [L][2][B][H] carried (h, c) in / out, or NULL (zero start, final state dropped);
@@ -884,7 +886,7 @@ extern "C" int apx_lstm_forward(const float* params, int D, int H, int L, int O,
     for (int l = 0; l < L; ++l) {
         float* G = save + (size_t)l * TB * 6 * H; float* Cc = G + TB * 4 * H; float* Hh = Cc + TB * H;
         APX_TRY(linear_fwd(in, P.Wih[l], P.bih[l], G, TB, P.in[l], 4 * H, false, s));            // all time steps at once
-        if (lstm_persistent_ok(H)) {      // the whole sequence of this layer in one launch, W_hh resident in registers
+        if (lstm_persistent_ok(H, T)) {      // the whole sequence of this layer in one launch, W_hh resident in registers
             float* hh = hc ? hc + (size_t)(2 * l) * B * H : nullptr; float* hcc = hc ? hc + (size_t)(2 * l + 1) * B * H : nullptr;
             if (H == 128) hipLaunchKernelGGL(lstm_seq_fwd_kernel<128>, dim3(apx_cdiv(B, 16)), dim3(256), 0, s, G, P.Whh[l], P.bhh[l], hh, hcc, Cc, Hh, T, (long)B);
             else hipLaunchKernelGGL(lstm_seq_fwd_kernel<64>, dim3(apx_cdiv(B, 16)), dim3(256), 0, s, G, P.Whh[l], P.bhh[l], hh, hcc, Cc, Hh, T, (long)B);
@@ -935,7 +937,7 @@ extern "C" int apx_lstm_backward(const float* params, float* grads, int D, int H
         const float* G = save + (size_t)l * TB * 6 * H; const float* Cc = G + TB * 4 * H; const float* Hh = Cc + TB * H;
         const float* in = l ? save + (size_t)(l - 1) * TB * 6 * H + TB * 5 * H : x;
         APX_HIP(hipMemsetAsync(dc, 0, sizeof(float) * B * H, s));
-        if (lstm_persistent_ok(H)) {
+        if (lstm_persistent_ok(H, T)) {
             if (H == 128) hipLaunchKernelGGL(lstm_seq_bwd_kernel<128>, dim3(apx_cdiv(B, 16)), dim3(256), 0, s, G, Cc, P.Whh[l], dHa, dG, T, (long)B);
             else hipLaunchKernelGGL(lstm_seq_bwd_kernel<64>, dim3(apx_cdiv(B, 16)), dim3(256), 0, s, G, Cc, P.Whh[l], dHa, dG, T, (long)B);
             APX_LAUNCH_CHECK();
