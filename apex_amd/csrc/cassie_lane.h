@@ -1265,9 +1265,9 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
         });
     });
     f2 racc = {0.f, 0.f};                                   // (left, right) sum over the sweeps of the own residual at the start of the leg's pass
-    // Pyramid (round 2): the four row residuals u_k = r_n +- mu r_t are carried directly.  Row k: df = max(wp - iA u_k, -f_k) with
-    // wp = (alpha - 1) f_k + beta off the chain (alpha = 1 - iA R, beta = -iA b), f_k += df, and the LATER rows' residuals move by
-    // K[j][k] df with K[j][k] = d_j' G3 d_k (d_k = n + s_k mu t_a(k)); rho' of every lane moves by GpRow[k] df.
+    // Pyramid (round 2): the four SCALED row residuals X_k = wp_k - iA_k u_k (u_k = r_n +- mu r_t) are formed at once.  Row k:
+    // df = max(X_k, -f_k) with wp = (alpha - 1) f_k + beta off the chain (alpha = 1 - iA R, beta = -iA b), f_k += df, and the LATER rows'
+    // X_j move by -iA_j K[j][k] df with K[j][k] = d_j' G3 d_k (d_k = n + s_k mu t_a(k)); rho' of every lane moves by GpRow[k] df.
     float cam1[NCS][4], cbeta[NCS][4], K10[NCS], K32[NCS];
     f2 K23a[NCS], K23b[NCS], GpRow[NCS][4];
     sfor<0, NCS>([&](auto Sl) {
@@ -1277,12 +1277,15 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
             cam1[s][k] = -ciA[s][k] * cR[s]; cbeta[s][k] = -ciA[s][k] * cb[s][k];
             GpRow[s][k] = Gp[leg][ln] + Gp[leg][ln + (k < 2 ? 1 : 2)] * ((k & 1) ? -mu : mu);
         });
-        // K[j][k] = kn[k] + s_j (a_j == 1 ? k1[k] : k2[k])
-        K10[s] = kn[s][0] - mu * k1[s][0];
-        K23a[s] = f2{kn[s][0] + mu * k2[s][0], kn[s][0] - mu * k2[s][0]};
-        K23b[s] = f2{kn[s][1] + mu * k2[s][1], kn[s][1] - mu * k2[s][1]};
-        K32[s] = kn[s][2] - mu * k2[s][2];
+        // K[j][k] = kn[k] + s_j (a_j == 1 ? k1[k] : k2[k]); stored pre-multiplied by the LATER row's 1 / (A_jj + R): the scaled residual
+        // X_j = wp_j - iA_j u_j of a later row moves by -iA_j K[j][k] df_k, so a row's place on the dependency chain is one fma + one max
+        K10[s] = ciA[s][1] * (kn[s][0] - mu * k1[s][0]);
+        K23a[s] = f2{ciA[s][2] * (kn[s][0] + mu * k2[s][0]), ciA[s][3] * (kn[s][0] - mu * k2[s][0])};
+        K23b[s] = f2{ciA[s][2] * (kn[s][1] + mu * k2[s][1]), ciA[s][3] * (kn[s][1] - mu * k2[s][1])};
+        K32[s] = ciA[s][3] * (kn[s][2] - mu * k2[s][2]);
     });
+    f2 ciAp[NCS][2];
+    sfor<0, NCS>([&](auto Sl) { ciAp[Sl][0] = f2{ciA[Sl][0], ciA[Sl][1]}; ciAp[Sl][1] = f2{ciA[Sl][2], ciA[Sl][3]}; });
     const f2 cpm = {mu, -mu};
     f2 cfp[NCS][2], cam1p[NCS][2], cbetap[NCS][2];          // pyramid rows (0, 1) / (2, 3) of a slot packed for v_pk_fma_f32 / v_pk_add_f32
     sfor<0, NCS>([&](auto Sl) { sfor<0, 2>([&](auto H) {
@@ -1313,14 +1316,19 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
                     f2 U01 = f2{rn, rn} + cpm * r1, U23 = f2{rn, rn} + cpm * r2;
                     f2 wa = cam1p[s][0] * cfp[s][0] + cbetap[s][0], wb = cam1p[s][1] * cfp[s][1] + cbetap[s][1];      // packed, off the chain
                     asm volatile("" : "+v"(wa.x), "+v"(wa.y), "+v"(wb.x), "+v"(wb.y));      // fast-math would re-associate them into the chain
+                    f2 X01 = wa - ciAp[s][0] * U01, X23 = wb - ciAp[s][1] * U23;        // scaled residuals of the four rows before any of them moved
+#define APX_PIN2(v) asm volatile("" : "+v"(v))      /* fix the association: fast-math would gather the corrections into one late sum */
+                    APX_PIN2(X01); APX_PIN2(X23);
                     f2 da, db;
-                    da.x = fmaxf(wa.x - ciA[s][0] * U01.x, -cfp[s][0].x);
-                    U01.y += K10[s] * da.x; U23 += K23a[s] * da.x;
-                    da.y = fmaxf(wa.y - ciA[s][1] * U01.y, -cfp[s][0].y);
-                    U23 += K23b[s] * da.y;
-                    db.x = fmaxf(wb.x - ciA[s][2] * U23.x, -cfp[s][1].x);
-                    U23.y += K32[s] * db.x;
-                    db.y = fmaxf(wb.y - ciA[s][3] * U23.y, -cfp[s][1].y);
+                    da.x = fmaxf(X01.x, -cfp[s][0].x);
+                    X01.y -= K10[s] * da.x; X23 -= K23a[s] * da.x;
+                    APX_PIN2(X23);
+                    da.y = fmaxf(X01.y, -cfp[s][0].y);
+                    X23 -= K23b[s] * da.y;
+                    APX_PIN2(X23);
+                    db.x = fmaxf(X23.x, -cfp[s][1].x);
+                    X23.y -= K32[s] * db.x;
+                    db.y = fmaxf(X23.y, -cfp[s][1].y);
                     cfp[s][0] += da; cfp[s][1] += db;
                     r += GpRow[s][0] * da.x + GpRow[s][1] * da.y + GpRow[s][2] * db.x + GpRow[s][3] * db.y;
                 }
