@@ -1175,12 +1175,18 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
             constexpr int k = K;
             cb[s][k] = Lr.cb[j][k]; cf[s][k] = Lr.cf[j][k];
             const float sm = ((k & 1) ? -mu : mu), gnj = k < 2 ? cG[s][1] : cG[s][2], gjj = k < 2 ? cG[s][3] : cG[s][5];
-            ciA[s][k] = rcpf(cG[s][0] + 2.f * sm * gnj + mu * mu * gjj + cR[s]);      // A_kk + R of row n + s mu t_j
+            ciA[s][k] = con[s] ? rcpf(cG[s][0] + 2.f * sm * gnj + mu * mu * gjj + cR[s]) : 0.f;      // 1 / (A_kk + R) of row n + s mu t_j; 0 = the slot is a no-op in the sweeps
             // row k = n + sm t_j moves the basis residuals (rn, r1, r2) by df * (G n-col + sm G j-col)
             kn[s][k] = cG[s][0] + sm * gnj; k1[s][k] = cG[s][1] + sm * (k < 2 ? cG[s][3] : cG[s][4]); k2[s][k] = cG[s][2] + sm * (k < 2 ? cG[s][4] : cG[s][5]);
         });
     });
     const int nlim[2] = {A.nlim, B.nlim};
+    // Wave-uniform activity of the conditional row groups: inside the sweeps only SCALAR branches are taken (skip a group when no env of
+    // the wave has it); an env without the row runs it with zero coefficients (iA = 0, f = 0: the update is exactly 0), so there is no
+    // exec-mask region in the loop at all.
+    bool anyc[NCS], anyl[2];
+    sfor<0, NCS>([&](auto Sl) { anyc[Sl] = __builtin_amdgcn_ballot_w64(con[Sl]) != 0ull; });
+    sfor<0, 2>([&](auto Lg) { anyl[Lg] = __builtin_amdgcn_ballot_w64(nlim[Lg] != 0) != 0ull; });
     // ---- warm start (mj_fwdConstraint): coefficient F_s of every basis vector, rho = G F, dual cost 1/2 F.rho + sum f (R f / 2 + b)
     float FA[13], FB[13];
     sfor<0, 7>([&](auto Sx) { FA[Sx] = ef[0][Sx]; FB[Sx] = ef[1][Sx]; });
@@ -1301,7 +1307,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
                 const f2 u = W[leg][0] * x[0] + W[leg][1] * x[1] + W[leg][2] * x[2], v = W[leg][3] * x[3] + W[leg][4] * x[4] + W[leg][5] * x[5];
                 r += u + v;
             }
-            if (nlim[leg]) {
+            if (anyl[leg]) {
                 const float t = leg ? dpp<0x150 + 6>(r.y) : dpp<0x150 + 6>(r.x);
                 const float fn = fmaxf(ef[leg][6] - t * eiA[leg][6], 0.f);
                 const float df = fn - ef[leg][6];
@@ -1310,7 +1316,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
             }
             sfor<0, MAXC>([&](auto Sl) {
                 constexpr int j = Sl, s = leg * MAXC + j, ln = 7 + 3 * j;
-                if (con[s]) {
+                if (anyc[s]) {
                     const float rn = leg ? dpp<0x150 + ln>(r.y) : dpp<0x150 + ln>(r.x), r1 = leg ? dpp<0x150 + ln + 1>(r.y) : dpp<0x150 + ln + 1>(r.x),
                                 r2 = leg ? dpp<0x150 + ln + 2>(r.y) : dpp<0x150 + ln + 2>(r.x);
                     f2 U01 = f2{rn, rn} + cpm * r1, U23 = f2{rn, rn} + cpm * r2;
@@ -1336,7 +1342,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
         });
         if (anyx) sfor<0, MAXX>([&](auto K) {               // leg-leg rows last, in pair order (frictionless: one unilateral row each)
             constexpr int k = K, s = 13 + k;
-            if (xact[k]) {
+            {       // an env without pair k has xiA = xf = 0: df = 0
                 const float t = dpp<0x150 + s>(r.x) + dpp<0x150 + s>(r.y) + xb[k];
                 const float fn = fmaxf(xf[k] - t * xiA[k], 0.f);
                 const float df = fn - xf[k];
