@@ -42,7 +42,12 @@ __device__ __forceinline__ float* rows4() { return (float*)(apx_lds4 + ((threadI
 // in mj_forward)
 // per-drive model constants as selects on the drive index inside a leg (u5 = 0 roll, 1 yaw, 2 pitch, 3 knee, 4 foot) instead of table
 // loads: a lane-indexed table needs a 64-bit address per lane that the compiler keeps alive across all 50 substeps (2 VGPRs each)
-template <class T> __device__ __forceinline__ T sel5(int u5, T a0, T a1, T a2, T a3, T a4) { return u5 == 0 ? a0 : u5 == 1 ? a1 : u5 == 2 ? a2 : u5 == 3 ? a3 : a4; }
+// (one plain select per step: a nested ?: chain of constants is turned into divergent branches, i.e. exec-mask regions, by the compiler)
+template <class T> __device__ __forceinline__ T sel5(int u5, T a0, T a1, T a2, T a3, T a4) {
+    T r = a4;
+    r = u5 == 3 ? a3 : r; r = u5 == 2 ? a2 : r; r = u5 == 1 ? a1 : r; r = u5 == 0 ? a0 : r;
+    return r;
+}
 static_assert(cmt::ct_act_gear[5] == cmt::ct_act_gear[0] && cmt::ct_act_gear[9] == cmt::ct_act_gear[4] && cmt::ct_act_bits[7] == cmt::ct_act_bits[2] &&
               cmt::ct_act_rpm[8] == cmt::ct_act_rpm[3] && cmt::ct_act_ctrlmax[6] == cmt::ct_act_ctrlmax[1] && cmt::ct_act_dof[5] == cmt::ct_act_dof[0] + 13 &&
               cmt::ct_act_dof[9] == cmt::ct_act_dof[4] + 13, "the two legs carry the same drives");
@@ -75,8 +80,8 @@ __device__ __forceinline__ void stage1_io_lane(St S, int mode) {   // (as a call
         tau_cmd = (flags & 16) ? kp * (S(F_PDT + u) - mpos) + kd * (0.f - mvel) : 0.f;
         // cassie_core_sim_step (G10): soft joint-limit zones 0.15 rad inside the drive limits
         constexpr float DEG = PI_F / 180.f;
-        const float lo_deg = u5 == 0 ? -15.f : u5 == 1 ? -22.f : u5 == 2 ? -50.f : u5 == 3 ? -156.f : -140.f;
-        const float hi_deg = u5 == 0 ? 20.f : u5 == 1 ? 22.f : u5 == 2 ? 80.f : u5 == 3 ? -42.f : -35.f;
+        const float lo_deg = sel5(u5, -15.f, -22.f, -50.f, -156.f, -140.f);
+        const float hi_deg = sel5(u5, 20.f, 22.f, 80.f, -42.f, -35.f);
         float lo = lo_deg * DEG + 0.15f, hi = hi_deg * DEG - 0.15f;
         if (u >= 5 && u5 < 2) { const float t = lo; lo = -hi; hi = -t; }      // roll / yaw mirror on the right leg
         sdepth = fmaxf(0.f, fmaxf(mpos - hi, lo - mpos));
@@ -94,7 +99,7 @@ __device__ __forceinline__ void stage1_io_lane(St S, int mode) {   // (as a call
     float sscale = fmaxf(0.f, 1.f - sdepth * (1.f / 0.15f)) * ((mot && u5 == 2) ? fmaxf(0.f, 1.f - cdepth * (1.f / 0.15f)) : 1.f);
     sscale *= c4::dpp<0xB1>(sscale); sscale *= c4::dpp<0x4E>(sscale); sscale *= c4::dpp<0x141>(sscale); sscale *= c4::dpp<0x140>(sscale);
     if (mot) {
-        const float sKp = u5 == 0 ? 1000.f : u5 == 1 ? 800.f : u5 == 4 ? 100.f : 1200.f, sKd = u5 < 2 ? 12.f : u5 == 4 ? 7.f : 36.f;
+        const float sKp = sel5(u5, 1000.f, 800.f, 1200.f, 1200.f, 100.f), sKd = sel5(u5, 12.f, 12.f, 36.f, 36.f, 7.f);
         const float d = sdepth;
         float tau = sscale * tau_cmd + ssign * sKp * d * (1.f + d * (1.f / 0.15f)) - fminf(1.f, d * (1.f / 0.15f)) * sKd * mvel;
         tau += sKp * cdepth * (1.f + cdepth * (1.f / 0.15f)) - fminf(1.f, cdepth * (1.f / 0.15f)) * sKd * mvel;      // coupled zone (0 off the pitch / knee lanes)
