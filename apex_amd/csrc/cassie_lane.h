@@ -135,7 +135,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         sfor<0, 9>([&](auto K) { Ib[sd][K] = ctf(cb + 10 + K); });
         mass[sd] = S(F_MASS + b);
     });
-    const float jref = lb == 4 ? ct_jnt_ref[8] : lb == 7 ? ct_jnt_ref[10] : 0.f;          // knee, tarsus
+    float jref = 0.f; jref = lb == 7 ? ct_jnt_ref[10] : jref; jref = lb == 4 ? ct_jnt_ref[8] : jref;      // knee, tarsus (plain selects: a nested ?: becomes branches)
     static_assert(ct_jnt_ref[19] == ct_jnt_ref[8] && ct_jnt_ref[21] == ct_jnt_ref[10] && ct_jnt_ref[9] == 0.f, "joint refs");
     // ---- pelvis (every lane)
     const V3 o = {qp(0), qp(1), qp(2)};
@@ -388,14 +388,16 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         // qfrc_smooth = passive - bias + actuation
         const int k = l;       // leg-local dof
         float fs = -S(F_DAMP + d) * S(F_QVEL + d) - sdot(cd, fsub);
-        if (l == 7) fs -= ct_jnt_stiffness[9] * qp(ct_jnt_qposadr[9] + 14 * sd);            // shin spring
-        if (l == 9) fs -= ct_jnt_stiffness[11] * qp(ct_jnt_qposadr[11] + 14 * sd);          // heel spring
+        // (branch-free: every lane reads, the coefficient selects)
+        fs -= (l == 7 ? ct_jnt_stiffness[9] : 0.f) * qp(ct_jnt_qposadr[9] + 14 * sd);            // shin spring
+        fs -= (l == 9 ? ct_jnt_stiffness[11] : 0.f) * qp(ct_jnt_qposadr[11] + 14 * sd);          // heel spring
         static_assert(ct_jnt_stiffness[20] == ct_jnt_stiffness[9] && ct_jnt_stiffness[22] == ct_jnt_stiffness[11] && ct_jnt_qposadr[20] == ct_jnt_qposadr[9] + 14, "springs");
-        const int u = k == 0 ? 0 : k == 1 ? 1 : k == 2 ? 2 : k == 6 ? 3 : k == 12 ? 4 : -1;       // actuated dofs: hip roll, yaw, pitch, knee, foot
-        if (u >= 0) {
+        {   // actuated dofs: hip roll, yaw, pitch (k = 0, 1, 2), knee (6), foot (12); the other lanes read drive 0 with gear 0
+            int u = 0; u = k == 1 ? 1 : u; u = k == 2 ? 2 : u; u = k == 6 ? 3 : u; u = k == 12 ? 4 : u;
+            const bool act = ((0x1047u >> k) & 1u) != 0u;
             const int ua = u + 5 * sd;
-            const float cmax = ctf(CT_CMAX + ua);
-            fs += ctf(CT_GEAR + ua) * fminf(fmaxf(S.W(WK_CTRL + ua), -cmax), cmax);
+            const float cmax = ctf(CT_CMAX + ua), g = act ? ctf(CT_GEAR + ua) : 0.f;
+            fs += g * fminf(fmaxf(S.W(WK_CTRL + ua), -cmax), cmax);
         }
         if constexpr (!QPOS0) {
             if (l >= 13) {      // external wrench on the pelvis (mjData.xfrc_applied, applied at the body's COM): J^T (f, tau) on the 6 free-joint dofs
@@ -941,12 +943,14 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out, int nxp, bo
     const bool isX = l >= 13 && (l - 13) < nxp && (l - 13) < MAXX;
     const int G = isX ? (LEG == 0 ? xp.gi : xp.gj) : (cs ? cgeo[1] : cgeo[0]);
     const unsigned mcon = mFT & ~(G >= 1 ? (1u << 18) : 0u) & ~(G >= 2 ? (1u << 14) : 0u);   // tarsus / shin contact: dofs below do not move the point
-    const unsigned m1 = isEq ? (E ? mAC1 : mPL1) : isCon ? mcon : isX ? (mcon & ~0x3Fu) : 0u, m2 = isEq ? (E ? mAC2 : mPL2) : 0u;
+    unsigned m1 = 0u; m1 = isX ? (mcon & ~0x3Fu) : m1; m1 = isCon ? mcon : m1; m1 = isEq ? (E ? mAC1 : mPL1) : m1;
+    const unsigned m2 = isEq ? (E ? mAC2 : mPL2) : 0u;
     V3 p1, p2;
     {
         const V3 e1 = {S.W(base + 6 * E), S.W(base + 6 * E + 1), S.W(base + 6 * E + 2)};
         const V3 e2 = {S.W(base + 6 * E + 3), S.W(base + 6 * E + 4), S.W(base + 6 * E + 5)};
-        const V3 cp = {isX ? xp.cp.x : cs ? cpt1.x : cpt0.x, isX ? xp.cp.y : cs ? cpt1.y : cpt0.y, isX ? xp.cp.z : cs ? cpt1.z : cpt0.z};
+        V3 cp = {cs ? cpt1.x : cpt0.x, cs ? cpt1.y : cpt0.y, cs ? cpt1.z : cpt0.z};
+        cp = {isX ? xp.cp.x : cp.x, isX ? xp.cp.y : cp.y, isX ? xp.cp.z : cp.z};
         p1 = isEq ? e1 : cp; p2 = e2;
     }
     V3 dir;
@@ -961,8 +965,9 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out, int nxp, bo
             V3 t = {0.f, uy ? 1.f : 0.f, uy ? 0.f : 1.f};
             t = t - cn * dot(cn, t); c1 = t * rsqrtf(dot(t, t)); c2 = cross(cn, c1);
         }
-        const float dcx = ax == 0 ? cn.x : ax == 1 ? c1.x : c2.x, dcy = ax == 0 ? cn.y : ax == 1 ? c1.y : c2.y,
-                    dcz = ax == 0 ? cn.z : ax == 1 ? c1.z : c2.z;
+        float dcx = c2.x, dcy = c2.y, dcz = c2.z;
+        dcx = ax == 1 ? c1.x : dcx; dcy = ax == 1 ? c1.y : dcy; dcz = ax == 1 ? c1.z : dcz;
+        dcx = ax == 0 ? cn.x : dcx; dcy = ax == 0 ? cn.y : dcy; dcz = ax == 0 ? cn.z : dcz;
         dir = {isEq ? (ax == 0 ? 1.f : 0.f) : dcx, isEq ? (ax == 1 ? 1.f : 0.f) : dcy, isEq ? (ax == 2 ? 1.f : 0.f) : dcz};
         constexpr float sx = LEG == 0 ? -1.f : 1.f;
         if (isX) dir = {sx * xp.n.x, sx * xp.n.y, sx * xp.n.z};
@@ -993,7 +998,7 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out, int nxp, bo
     // ---- equality / limit scalars (mj_makeImpedance, mj_referenceConstraint, warm start from qacc_warmstart)
     {
         const V3 cv = p1 - p2;
-        const float cpos = ax == 0 ? cv.x : ax == 1 ? cv.y : cv.z;
+        float cpos = cv.z; cpos = ax == 1 ? cv.y : cpos; cpos = ax == 0 ? cv.x : cpos;
         const float tranPL = S(F_BIW + ct_eq_body1[2 * LEG]) + S(F_BIW + ct_eq_body2[2 * LEG]);
         const float tranAC = S(F_BIW + ct_eq_body1[2 * LEG + 1]) + S(F_BIW + ct_eq_body2[2 * LEG + 1]);
         const float pos = isEq ? cpos : ldist, imp_pos = isEq ? sqrtf(dot(cv, cv)) : ldist;
@@ -1021,7 +1026,8 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out, int nxp, bo
         const float wn = dpp<0x150 + ln>(jw), w1 = dpp<0x150 + ln + 1>(jw), w2 = dpp<0x150 + ln + 2>(jw);
         const int Gs = cgeo[s];
         const float dist = cdist[s];
-        const float tran = Gs == 0 ? S(F_BIW + 13 + 12 * LEG) : Gs == 1 ? S(F_BIW + 9 + 12 * LEG) : S(F_BIW + 8 + 12 * LEG);
+        float tran = S(F_BIW + 8 + 12 * LEG);                 // all three are read, plain selects (loads in the arms of a nested ?: become branches)
+        { const float t9 = S(F_BIW + 9 + 12 * LEG), t13 = S(F_BIW + 13 + 12 * LEG); tran = Gs == 1 ? t9 : tran; tran = Gs == 0 ? t13 : tran; }
         const RowK kb = solref(0.005f);
         const float imp = impedance(dist);
         const float R1 = fmaxf(MINVAL, (1.f - imp) * rcpf(imp) * (tran + mu * mu * tran));
