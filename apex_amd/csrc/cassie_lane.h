@@ -284,17 +284,19 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
     wsync();
     PROF2(16);
     // ---- subtree sums (composite inertia, subtree force): descendants are the next ndesc bodies
-    sfor<0, 2>([&](auto Sd) {
-        constexpr int sd = Sd;
-        for (int i = 1; i <= 11; ++i) {
-            if (i <= ndesc) {
-                const float* p = xb + XB_SZ * (body[sd] + i);
-                crb[sd].m += p[0]; crb[sd].h = crb[sd].h + V3{p[1], p[2], p[3]};
-                sfor<0, 6>([&](auto K) { crb[sd].I[K] += p[4 + K]; });
-                frc[sd].a = frc[sd].a + V3{p[10], p[11], p[12]}; frc[sd].l = frc[sd].l + V3{p[13], p[14], p[15]};
-            }
-        }
-    });
+    // (a rolled, branch-free loop: a lane past its last descendant re-reads its own record with weight 0; both legs in one iteration)
+    _Pragma("unroll 1") for (int i = 1; i <= 11; ++i) {
+        const bool on = i <= ndesc;
+        const float w = on ? 1.f : 0.f;
+        const int di = on ? i : 0;
+        sfor<0, 2>([&](auto Sd) {
+            constexpr int sd = Sd;
+            const float* p = xb + XB_SZ * (body[sd] + di);
+            crb[sd].m += w * p[0]; crb[sd].h = crb[sd].h + V3{p[1], p[2], p[3]} * w;
+            sfor<0, 6>([&](auto K) { crb[sd].I[K] += w * p[4 + K]; });
+            frc[sd].a = frc[sd].a + V3{p[10], p[11], p[12]} * w; frc[sd].l = frc[sd].l + V3{p[13], p[14], p[15]} * w;
+        });
+    }
     wsync();
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
