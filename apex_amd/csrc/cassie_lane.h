@@ -135,6 +135,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         sfor<0, 9>([&](auto K) { Ib[sd][K] = ctf(cb + 10 + K); });
         mass[sd] = S(F_MASS + b);
     });
+    const int xbody[2] = {bl ? body[0] : 26, bl ? body[1] : 27};      // where this lane's exchange record goes (26, 27: spare records for the shadow lanes)
     float jref = 0.f; jref = lb == 7 ? ct_jnt_ref[10] : jref; jref = lb == 4 ? ct_jnt_ref[8] : jref;      // knee, tarsus (plain selects: a nested ?: becomes branches)
     static_assert(ct_jnt_ref[19] == ct_jnt_ref[8] && ct_jnt_ref[21] == ct_jnt_ref[10] && ct_jnt_ref[9] == 0.f, "joint refs");
     // ---- pelvis (every lane)
@@ -191,8 +192,8 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
     sfor<0, 3>([&](auto Rn) {
         constexpr int r = Rn;
         wsync();
-        if (bl) sfor<0, 2>([&](auto Sd) {
-            float* p = xb + XB_SZ * body[Sd];
+        sfor<0, 2>([&](auto Sd) {      // branch-free: the shadow lanes 12..15 write a spare record
+            float* p = xb + XB_SZ * xbody[Sd];
             p[0] = tp[Sd].x; p[1] = tp[Sd].y; p[2] = tp[Sd].z; p[3] = tq[Sd].w; p[4] = tq[Sd].x; p[5] = tq[Sd].y; p[6] = tq[Sd].z;
         });
         wsync();
@@ -222,8 +223,8 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         sfor<0, 3>([&](auto Rn) {
             constexpr int r = Rn;
             wsync();
-            if (bl) sfor<0, 2>([&](auto Sd) {
-                float* p = xb + XB_SZ * body[Sd];
+            sfor<0, 2>([&](auto Sd) {
+                float* p = xb + XB_SZ * xbody[Sd];
                 p[0] = val[Sd].a.x; p[1] = val[Sd].a.y; p[2] = val[Sd].a.z; p[3] = val[Sd].l.x; p[4] = val[Sd].l.y; p[5] = val[Sd].l.z;
             });
             wsync();
@@ -268,8 +269,8 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
         body_inertia_force(mat[sd], pos[sd], o, Ib[sd], ipos[sd], mass[sd], vel[sd], acc[sd], crb[sd], frc[sd]);
-        if (bl) {
-            float* p = xb + XB_SZ * body[sd];
+        {
+            float* p = xb + XB_SZ * xbody[sd];
             p[0] = crb[sd].m; p[1] = crb[sd].h.x; p[2] = crb[sd].h.y; p[3] = crb[sd].h.z;
             sfor<0, 6>([&](auto K) { p[4 + K] = crb[sd].I[K]; });
             p[10] = frc[sd].a.x; p[11] = frc[sd].a.y; p[12] = frc[sd].a.z; p[13] = frc[sd].l.x; p[14] = frc[sd].l.y; p[15] = frc[sd].l.z;
@@ -300,8 +301,8 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
     wsync();
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
-        if (bl) {
-            float* p = xb + XB_SZ * body[sd];
+        {
+            float* p = xb + XB_SZ * xbody[sd];
             p[0] = crb[sd].m; p[1] = crb[sd].h.x; p[2] = crb[sd].h.y; p[3] = crb[sd].h.z;
             sfor<0, 6>([&](auto K) { p[4 + K] = crb[sd].I[K]; });
             p[10] = frc[sd].a.x; p[11] = frc[sd].a.y; p[12] = frc[sd].a.z; p[13] = frc[sd].l.x; p[14] = frc[sd].l.y; p[15] = frc[sd].l.z;
