@@ -899,6 +899,16 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out, int nxp, bo
     // ---- uniform over the env's lanes: first active joint limit of this leg
     int nlim = 0, clim = -1, over = 0;
     float lsign = 0.f, ldist = 0.f, ldiw = 0.f;
+    // wave-uniform early out: in almost every substep no limited joint of any of the wave's four envs is outside its range
+    float lmin = 1.f;
+    sfor<0, NJ>([&](auto Jn) {
+        constexpr int j = Jn;
+        if constexpr (ct_jnt_limited[j] && ((ct_jnt_body[j] >= 14) == (LEG == 1)) && ct_jnt_body[j] >= 2) {
+            const float q = S(F_QPOS + ct_jnt_qposadr[j]);
+            lmin = fminf(lmin, fminf(q - ct_jnt_range[2 * j], ct_jnt_range[2 * j + 1] - q));
+        }
+    });
+    if (__builtin_amdgcn_ballot_w64(lmin < 0.f) != 0ull)
     sfor<0, NJ>([&](auto Jn) {
         constexpr int j = Jn;
         if constexpr (ct_jnt_limited[j] && ((ct_jnt_body[j] >= 14) == (LEG == 1)) && ct_jnt_body[j] >= 2) {
