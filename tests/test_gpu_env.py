@@ -257,6 +257,10 @@ def test_random_policy_statistics_match_oracle(dev):
             lens.append(ep_len[d].cpu().numpy()); ep_len[d] = 0
     lens = np.concatenate(lens)
     assert bad == 0 and lens.size > 10000
+    # the kernel's constraint caps (2 floor contacts + 1 limit per leg, 2 leg-leg rows): even on random-policy
+    # rollouts, where robots fall all the time, fewer than 1 in 10^4 forward passes would have needed more (measured: 6.5e-7)
+    flags, cnt = g.saturation()
+    assert float(cnt.sum()) / (T * n * 50) < 1e-4, (float(cnt.sum()), flags.unique())
     rng = np.random.RandomState(7); olens = []; orsum = 0.0; osteps = 0
     for i in range(no):
         e = S.OracleEnv(dyn_rand=True, seed=21, env_id=i); e.reset(); L = 0
