@@ -141,8 +141,12 @@ __device__ __forceinline__ void stage1_io_lane(St S, int mode) {   // (as a call
         // state_output_step: translationalAcceleration = accelerometer - R^T (0, 0, 9.806) in the sensor frame, unfiltered (step-response
         // probe of the reference binary, DESIGN.md section 5: the filter's gravity constant is 9.806, not the model's 9.81)
         constexpr float EST_G = 9.806f;
-        S(F_SO + SO_TACC) = S(F_SNAP + SN_ACC) - R.m[6] * EST_G; S(F_SO + SO_TACC + 1) = S(F_SNAP + SN_ACC + 1) - R.m[7] * EST_G;
-        S(F_SO + SO_TACC + 2) = S(F_SNAP + SN_ACC + 2) - R.m[8] * EST_G;
+        // ... minus the centripetal term of the IMU's offset from the pelvis origin, w x (w x r_imu); no angular-acceleration term (same probe):
+        // with both, golden G11 is reproduced to 5e-4 m/s^2
+        const V3 wg = {S(F_SNAP + SN_GYRO), S(F_SNAP + SN_GYRO + 1), S(F_SNAP + SN_GYRO + 2)};
+        const V3 cen = cross(wg, cross(wg, V3{cmt::ct_imu_pos[0], cmt::ct_imu_pos[1], cmt::ct_imu_pos[2]}));
+        S(F_SO + SO_TACC) = S(F_SNAP + SN_ACC) - R.m[6] * EST_G - cen.x; S(F_SO + SO_TACC + 1) = S(F_SNAP + SN_ACC + 1) - R.m[7] * EST_G - cen.y;
+        S(F_SO + SO_TACC + 2) = S(F_SNAP + SN_ACC + 2) - R.m[8] * EST_G - cen.z;
         const V3 vw = {S(F_SNAP + SN_VEL), S(F_SNAP + SN_VEL + 1), S(F_SNAP + SN_VEL + 2)};
         S(F_SO + SO_TVEL) = dot(col(R, 0), vw); S(F_SO + SO_TVEL + 1) = dot(col(R, 1), vw); S(F_SO + SO_TVEL + 2) = dot(col(R, 2), vw);
         { const float L = S(F_EST) + EST_ALPHA * (S(F_EST + 1) - S(F_EST)); S(F_EST) = L; S(F_SO + SO_HEIGHT) = S(F_SNAP + SN_PZ) - L; }      // golden G11c

@@ -196,7 +196,12 @@ void sim_step_pd(Env& e) {
         // static and tilted inputs); the filter's gravity constant is 9.806, not the model's 9.81
         const double EST_G = 9.806;
         const V3 gb = {R.m[6] * EST_G, R.m[7] * EST_G, R.m[8] * EST_G};                    // R^T (0,0,g)
-        e.so_tacc[0] = e.snap_acc[0] - gb.x; e.so_tacc[1] = e.snap_acc[1] - gb.y; e.so_tacc[2] = e.snap_acc[2] - gb.z;
+        // ... minus the centripetal term of the IMU's offset from the pelvis origin, w x (w x r_imu) (cassie.xml:265 site position); no
+        // angular-acceleration term (gyro steps and ramps through the binary: tools/refprobe/probe_estimator_acc.py).  With both, golden
+        // G11 (the binary on this simulator's sensor stream) is reproduced to 5e-4 m/s^2 (before: 0.09 .. 0.24 mean)
+        const V3 wg = {e.snap_gyro[0], e.snap_gyro[1], e.snap_gyro[2]}, ri = v3(cm_imu_pos);
+        const V3 cen = cross(wg, cross(wg, ri));
+        e.so_tacc[0] = e.snap_acc[0] - gb.x - cen.x; e.so_tacc[1] = e.snap_acc[1] - gb.y - cen.y; e.so_tacc[2] = e.snap_acc[2] - gb.z - cen.z;
         const V3 vw = {e.snap_vel[0], e.snap_vel[1], e.snap_vel[2]};
         e.so_tvel[0] = dot(col(R, 0), vw); e.so_tvel[1] = dot(col(R, 1), vw); e.so_tvel[2] = dot(col(R, 2), vw);
         // height = pelvis.position[2] - terrain.height of the reference filter, reproduced to < 1 cm on a 3 s walking stream by
