@@ -496,7 +496,7 @@ __device__ __forceinline__ LaneIdx lane_idx() {
 // factorise WK_M (+ hdamp * joint damping on the diagonal: mj_Euler's implicit damping)
 __device__ __forceinline__ void factor_lane(const St& S, const LaneIdx& X, float hdamp, LaneFac& F) {
     const int l = X.l;
-    float R[2][13], P[2][6];
+    float R[2][13], P[2][6], dg[2];
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd, blk = WK_M + M_LEG0 + M_LEGSZ * sd;
         sfor<0, 13>([&](auto J) {
@@ -507,6 +507,9 @@ __device__ __forceinline__ void factor_lane(const St& S, const LaneIdx& X, float
             R[sd][J] = v;
         });
         sfor<0, 6>([&](auto Pp) { const float v = S.W(blk + X.own + X.dep - 1 - Pp); P[sd][Pp] = l < 13 ? v : 0.f; });
+        // the lane's own diagonal entry is carried separately (dg -= (R_l[k] / D_k) R_l[k] at every step): reading R[sd][l] back at the end
+        // is a 13-way select on the lane index, which the compiler turns into a tree of divergent branches
+        dg[sd] = S.W(blk + X.own) + hdamp * S(F_DAMP + 6 + 13 * sd + (l < 13 ? l : 12));
     });
     // ---- legs: eliminate dof 12 .. 0 of both legs at once
     srfor<0, 13>([&](auto K) {
@@ -515,6 +518,7 @@ __device__ __forceinline__ void factor_lane(const St& S, const LaneIdx& X, float
             constexpr int sd = Sd;
             const float inv = rcpf(dpp<0x150 + k>(R[sd][k]));
             const float tmp = l < k ? R[sd][k] * inv : 0.f;
+            dg[sd] -= tmp * R[sd][k];
             sfor<0, k>([&](auto J) { constexpr int j = J; if constexpr (leg_anc(k, j)) R[sd][j] -= tmp * dpp<0x150 + k>(R[sd][j]); });
             sfor<0, 6>([&](auto Pp) { P[sd][Pp] -= tmp * dpp<0x150 + k>(P[sd][Pp]); });
             R[sd][k] = l < k ? tmp : R[sd][k];
@@ -522,8 +526,7 @@ __device__ __forceinline__ void factor_lane(const St& S, const LaneIdx& X, float
     });
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
-        float D = 1.f;
-        sfor<0, 13>([&](auto J) { if (l == J) D = R[sd][J]; });
+        const float D = l < 13 ? dg[sd] : 1.f;
         F.D[sd] = D; F.invD[sd] = rcpf(D);
         sfor<0, 13>([&](auto J) { F.Lr[sd][J] = (J < l && l < 13) ? R[sd][J] * F.invD[sd] : 0.f; F.Lc[sd][J] = J > l ? R[sd][J] : 0.f; });
         sfor<0, 6>([&](auto Pp) { F.w[sd][Pp] = P[sd][Pp] * F.invD[sd]; });
