@@ -1223,9 +1223,12 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     // a coefficient of leg-leg row k moves z~ by (XL | XR): rho_A by XL . A_r + XR_pel . A_r,pel, rho_B likewise
     sfor<0, MAXX>([&](auto K) { rA += GX[K].x * xf[K]; rB += GX[K].y * xf[K]; });
     {
-        float own = 0.f;       // F of this lane's own rows times rho
-        sfor<0, 13>([&](auto Sx) { if (l == Sx) own = FA[Sx] * rA + FB[Sx] * rB; });
-        sfor<0, MAXX>([&](auto K) { if (l == 13 + K) own = xf[K] * (rA + rB); });
+        // F of this lane's own rows times rho: the own coefficients by plain select chains (a 13-way `if (l == s)` over computed values
+        // becomes a tree of divergent branches); lanes 0..6 hold their own row's f in A.f / B.f
+        float fa = l < 7 ? A.f : 0.f, fb = l < 7 ? B.f : 0.f;
+        sfor<7, 13>([&](auto Sx) { fa = l == Sx ? FA[Sx] : fa; fb = l == Sx ? FB[Sx] : fb; });
+        float own = fa * rA + fb * rB;
+        sfor<0, MAXX>([&](auto K) { own = l == 13 + K ? xf[K] * (rA + rB) : own; });
         cost = 0.5f * red16(own);
     }
     sfor<0, MAXX>([&](auto K) { cost += xf[K] * (0.5f * xR[K] * xf[K] + xb[K]); });
@@ -1388,17 +1391,16 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
         constexpr int s = Sl, leg = s / MAXC, ln = 7 + 3 * (s % MAXC);
         const float dn = cf[s][0] + cf[s][1] + cf[s][2] + cf[s][3], d1 = mu * (cf[s][0] - cf[s][1]), d2 = mu * (cf[s][2] - cf[s][3]);
         float& own = leg ? ownB : ownA;
-        if (l == ln) own = dn;
-        if (l == ln + 1) own = d1;
-        if (l == ln + 2) own = d2;
+        own = l == ln ? dn : own; own = l == ln + 1 ? d1 : own; own = l == ln + 2 ? d2 : own;
     });
     if (l >= 13) ownA = ownB = 0.f;
     sfor<0, MAXX>([&](auto K) { if (l == 13 + K && xact[K]) ownA = ownB = xf[K]; });
     sfor<0, 19>([&](auto C) {
         constexpr int c = C;
         const float ja = rows[(2 * c + 0) * 16 + l], jb = rows[(2 * c + 1) * 16 + l];
-        if constexpr (c < 6) { const float z = red16(ja * ownA + jb * ownB); if (l == 0) S.W(WK_ZT + c) = z; }
-        else { const float za = red16(ja * ownA), zb = red16(jb * ownB); if (l == 0) { S.W(WK_ZT + c) = za; S.W(WK_ZT + c + 13) = zb; } }
+        // (red16 leaves the bit-identical total on every lane: all 16 lanes store it to the same word, no exec-mask region per column)
+        if constexpr (c < 6) { const float z = red16(ja * ownA + jb * ownB); S.W(WK_ZT + c) = z; }
+        else { const float za = red16(ja * ownA), zb = red16(jb * ownB); S.W(WK_ZT + c) = za; S.W(WK_ZT + c + 13) = zb; }
     });
     if (l == 0) {
         // contact forces to the row store (foot-force readout in the finish stage)
