@@ -368,9 +368,10 @@ def test_g11b_estimator_lite_on_a_walking_stream(golden_dir):
                          [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
                          [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
     Rm = np.stack([q2m(q) for q in g["quat"]])
-    tacc = g["acc"] - np.einsum("nji,j->ni", Rm, np.array([0, 0, 9.81]))
+    # acceleration: the exact restatement (see G11) holds on this stream too: 5e-5 m/s^2 max (the round-1 form: 0.03 mean, 0.12 max)
+    tacc = g["acc"] - np.einsum("nji,j->ni", Rm, np.array([0, 0, 9.806])) - np.cross(g["gyro"], np.cross(g["gyro"], np.array([0.03155, 0.0, -0.07996])))
     tvel = np.einsum("nji,nj->ni", Rm, g["v_world"])
-    assert np.abs(tacc - g["ref_tacc"]).mean(0).max() < 0.2            # m/s^2, signal std 0.6 .. 1.7
+    assert np.abs(tacc - g["ref_tacc"]).max() < 1e-3                   # m/s^2, signal std 1.0 .. 2.5
     assert np.abs(tvel[:, :2] - g["ref_tvel"][:, :2]).mean(0).max() < 0.08
     d = g["z"] - g["ref_height"]
     assert abs(d[120:].mean()) < 0.02 and d[0] > 0.08                  # reference: offset decays to ~0 on the ground

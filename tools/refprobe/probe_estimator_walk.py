@@ -38,7 +38,7 @@ for step in range(200):
         for k in range(3): out.pelvis.vectorNav.angularVelocity[k] = gy[k]; out.pelvis.vectorNav.linearAcceleration[k] = ac[k]
         so = cm.state_out_t(); cm.state_output_step(est, out, so)
     qpos, qvel = e.get("qpos"), e.get("qvel"); R = q2m(q)
-    rows.append(dict(z=qpos[2], quat=q.copy(), acc=ac.copy(), v_world=qvel[:3].copy(),
+    rows.append(dict(z=qpos[2], quat=q.copy(), acc=ac.copy(), gyro=gy.copy(), v_world=qvel[:3].copy(),
                      ref_height=so.pelvis.position[2] - so.terrain.height, ref_tvel=np.array(so.pelvis.translationalVelocity[:]),
                      ref_tacc=np.array(so.pelvis.translationalAcceleration[:]),
                      lite_height=e.get("so_height")[0], lite_tvel=e.get("so_tvel").copy(), lite_tacc=e.get("so_tacc").copy()))
@@ -54,7 +54,7 @@ print("env steps walked:", len(rows), " final pelvis z %.3f  mean forward speed 
 for nm, ref, lite in (("height", A("ref_height"), A("lite_height")), ("tvel", A("ref_tvel"), A("lite_tvel")), ("tacc", A("ref_tacc"), A("lite_tacc"))):
     err = np.abs(lite - ref); sig = np.std(ref, axis=0)
     print("%-6s mean |estimator-lite - reference filter| = %s   (std of the reference signal %s)" % (nm, np.round(err.mean(0), 4), np.round(sig, 4)))
-np.savez_compressed(os.path.join(GOLD, "g11b_estimator_walk.npz"), z=A("z"), quat=A("quat"), acc=A("acc"), v_world=A("v_world"),
+np.savez_compressed(os.path.join(GOLD, "g11b_estimator_walk.npz"), z=A("z"), quat=A("quat"), acc=A("acc"), gyro=A("gyro"), v_world=A("v_world"),
                     ref_height=A("ref_height"), ref_tvel=A("ref_tvel"), ref_tacc=A("ref_tacc"))
 print("wrote g11b", len(rows))
 
