@@ -730,11 +730,12 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
 // top of the precomputed input projection, and the gate maths is lane-local because a lane's accumulators hold i, f, g, o of the same
 // (row, unit) pairs.  Replaces 2 launches per step (accumulate-GEMM + gate kernel); the save format (activated gates, c, h) is unchanged.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
-template <int H>
-__global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float* __restrict__ G, const float* __restrict__ Whh, const float* __restrict__ bhh,
+template <int H, int NW>      // NW waves per workgroup: wave w owns units [w H/NW, (w + 1) H/NW) of all four gates
+__global__ __launch_bounds__(64 * NW, 1) void lstm_seq_fwd_kernel(float* __restrict__ G, const float* __restrict__ Whh, const float* __restrict__ bhh,
                                                                float* __restrict__ hc_h, float* __restrict__ hc_c, float* __restrict__ Cc,
                                                                float* __restrict__ Hh, int T, long B) {
-    constexpr int UW = H / 4, NT = H / 64, KQ = H / 4, HP = H + 4;
+    constexpr int UW = H / NW, NT = UW / 16, KQ = H / 4, HP = H + 4;
+    static_assert(UW % 16 == 0 && NT >= 1, "a wave owns whole 16-unit tiles");
     __shared__ float hs[16][HP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 15, kg = lane >> 4;
     const long r0 = (long)blockIdx.x * 16;
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float* __restrict_
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) bh[g][nt] = bhh[g * H + wave * UW + nt * 16 + col];
     // initial state
-    for (int e = tid; e < 16 * H; e += 256) { const int r = e / H, u = e - r * H; hs[r][u] = (hc_h && r0 + r < B) ? hc_h[(r0 + r) * H + u] : 0.f; }
+    for (int e = tid; e < 16 * H; e += 64 * NW) { const int r = e / H, u = e - r * H; hs[r][u] = (hc_h && r0 + r < B) ? hc_h[(r0 + r) * H + u] : 0.f; }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -808,10 +809,10 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_fwd_kernel(float* __restrict_
 
 // BPTT of one layer in one launch: per step (descending) the gate backward of the wave's own units, then dh_{t-1} = dG_t W_hh with W_hh again
 // register-resident (now as the [4H x H/4] slice that produces the wave's units); dG_t goes to global memory for the weight-gradient GEMMs.
-template <int H>
-__global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float* __restrict__ G, const float* __restrict__ Cc, const float* __restrict__ Whh,
+template <int H, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void lstm_seq_bwd_kernel(const float* __restrict__ G, const float* __restrict__ Cc, const float* __restrict__ Whh,
                                                                const float* __restrict__ dHa, float* __restrict__ dG, int T, long B) {
-    constexpr int UW = H / 4, NT = H / 64, KQ = H, GP = 4 * H + 4;
+    constexpr int UW = H / NW, NT = UW / 16, KQ = H, GP = 4 * H + 4;
     __shared__ float dgs[16][GP];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 15, kg = lane >> 4;
     const long r0 = (long)blockIdx.x * 16;
@@ -867,6 +868,9 @@ __global__ __launch_bounds__(256, 1) void lstm_seq_bwd_kernel(const float* __res
         __syncthreads();
     }
 }
+#ifndef LSTM_NW128
+#define LSTM_NW128 8      /* waves per workgroup at H = 128: 8 = one 16-unit tile per wave, two waves per SIMD (4: 0.56 ms per 400-step layer pass, 8: see DESIGN.md section 4.2) */
+#endif
 static bool lstm_persistent_ok(int H, int T) {
     static const bool on = getenv("APX_LSTM_STEPWISE") == nullptr;      // A/B: the per-step launches of round 1
     // a launch re-loads W_hh into every workgroup's registers (256 KB at H = 128): worth it from a few time steps on; the one-step calls
@@ -888,8 +892,8 @@ extern "C" int apx_lstm_forward(const float* params, int D, int H, int L, int O,
         APX_TRY(linear_fwd(in, P.Wih[l], P.bih[l], G, TB, P.in[l], 4 * H, false, s));            // all time steps at once
         if (lstm_persistent_ok(H, T)) {      // the whole sequence of this layer in one launch, W_hh resident in registers
             float* hh = hc ? hc + (size_t)(2 * l) * B * H : nullptr; float* hcc = hc ? hc + (size_t)(2 * l + 1) * B * H : nullptr;
-            if (H == 128) hipLaunchKernelGGL(lstm_seq_fwd_kernel<128>, dim3(apx_cdiv(B, 16)), dim3(256), 0, s, G, P.Whh[l], P.bhh[l], hh, hcc, Cc, Hh, T, (long)B);
-            else hipLaunchKernelGGL(lstm_seq_fwd_kernel<64>, dim3(apx_cdiv(B, 16)), dim3(256), 0, s, G, P.Whh[l], P.bhh[l], hh, hcc, Cc, Hh, T, (long)B);
+            if (H == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(lstm_seq_fwd_kernel<128, LSTM_NW128>), dim3(apx_cdiv(B, 16)), dim3(64 * LSTM_NW128), 0, s, G, P.Whh[l], P.bhh[l], hh, hcc, Cc, Hh, T, (long)B);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(lstm_seq_fwd_kernel<64, 4>), dim3(apx_cdiv(B, 16)), dim3(256), 0, s, G, P.Whh[l], P.bhh[l], hh, hcc, Cc, Hh, T, (long)B);
             APX_LAUNCH_CHECK();
             in = Hh;
             continue;
@@ -938,8 +942,8 @@ extern "C" int apx_lstm_backward(const float* params, float* grads, int D, int H
         const float* in = l ? save + (size_t)(l - 1) * TB * 6 * H + TB * 5 * H : x;
         APX_HIP(hipMemsetAsync(dc, 0, sizeof(float) * B * H, s));
         if (lstm_persistent_ok(H, T)) {
-            if (H == 128) hipLaunchKernelGGL(lstm_seq_bwd_kernel<128>, dim3(apx_cdiv(B, 16)), dim3(256), 0, s, G, Cc, P.Whh[l], dHa, dG, T, (long)B);
-            else hipLaunchKernelGGL(lstm_seq_bwd_kernel<64>, dim3(apx_cdiv(B, 16)), dim3(256), 0, s, G, Cc, P.Whh[l], dHa, dG, T, (long)B);
+            if (H == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(lstm_seq_bwd_kernel<128, LSTM_NW128>), dim3(apx_cdiv(B, 16)), dim3(64 * LSTM_NW128), 0, s, G, Cc, P.Whh[l], dHa, dG, T, (long)B);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(lstm_seq_bwd_kernel<64, 4>), dim3(apx_cdiv(B, 16)), dim3(256), 0, s, G, Cc, P.Whh[l], dHa, dG, T, (long)B);
             APX_LAUNCH_CHECK();
         } else
         for (int t = T - 1; t >= 0; --t) {
