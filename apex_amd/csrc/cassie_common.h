@@ -74,10 +74,9 @@ static_assert(ct_jnt_type[0] == 0 && ct_jnt_type[1] == 0 && ct_jnt_type[2] == 0 
 static_assert(ct_body_parent[1] == 0, "pelvis hangs off the world");
 
 __device__ __forceinline__ float impedance(float pos) {   // MuJoCo solimp defaults 0.9 0.95 0.001 0.5 2
-    const float x = fabsf(pos) * 1000.f;
-    if (x >= 1.f) return 0.95f;
-    if (x <= 0.f) return 0.9f;
-    const float y = x <= 0.5f ? 2.f * x * x : 1.f - 2.f * (1.f - x) * (1.f - x);
+    const float x = fminf(fabsf(pos) * 1000.f, 1.f);           // branch-free: y(0) = 0, y(1) = 1 are the two saturated values
+    const float lo = 2.f * x * x, hi = 1.f - 2.f * (1.f - x) * (1.f - x);
+    const float y = x <= 0.5f ? lo : hi;
     return 0.9f + y * 0.05f;
 }
 struct RowK { float K, B; };
