@@ -158,7 +158,12 @@ __device__ APX_STAGE void stage1b_tree_lane(St S) {
     c4::stage_tree_lane<false>(S, rows4());
     PROF(1);
 }
-__device__ APX_STAGE void stage2a_factor(St S) {
+// the factor stage is inlined: as a function it needs two callee-saved VGPRs more than it can park in AGPRs (8 B of scratch per call, the
+// only scratch user of the step kernel); inlined, every kernel of this file is scratch-free at the same speed
+#ifndef APX_STAGE_FACTOR
+#define APX_STAGE_FACTOR __forceinline__
+#endif
+__device__ APX_STAGE_FACTOR void stage2a_factor(St S) {
     PROF_START();
     c4::stage_factor_lane(S);
     PROF(2);
