@@ -842,8 +842,11 @@ __device__ __forceinline__ int legleg_pairs_lane(const St& S, float* rec) {
         const float a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r), c = dot(d1, r), b = dot(d1, d2), den = a * e - b * b;
         float sp = den > 1e-12f ? fminf(fmaxf((b * f - c * e) * rcpf(den), 0.f), 1.f) : 0.f;
         float tp = (b * sp + f) * rcpf(e);
-        if (tp < 0.f) { tp = 0.f; sp = fminf(fmaxf(-c * rcpf(a), 0.f), 1.f); }
-        else if (tp > 1.f) { tp = 1.f; sp = fminf(fmaxf((b - c) * rcpf(a), 0.f), 1.f); }
+        {   // the two clamped cases by plain selects (the if / else-if form is three exec-mask regions in every substep, ahead of the early out)
+            const float ia = rcpf(a), sp_lo = fminf(fmaxf(-c * ia, 0.f), 1.f), sp_hi = fminf(fmaxf((b - c) * ia, 0.f), 1.f);
+            sp = tp > 1.f ? sp_hi : sp; sp = tp < 0.f ? sp_lo : sp;
+            tp = fminf(fmaxf(tp, 0.f), 1.f);
+        }
         const V3 c1 = p1 + d1 * sp, dv = (p2 + d2 * tp) - c1;
         const float len = sqrtf(dot(dv, dv));
         const float rl = li == 0 ? ct_geom_radius[0] : ct_geom_radius[2], rr = rj == 0 ? ct_geom_radius[1] : ct_geom_radius[3];
