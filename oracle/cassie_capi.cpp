@@ -72,13 +72,15 @@ static int field(Env& e, const char* name, double* io, bool set) {
     FIELD("speed", &e.speed, 1) FIELD("side_speed", &e.side_speed, 1) FIELD("orient_add", &e.orient_add, 1)
     FIELD("so_mpos", e.so_mpos, 10) FIELD("so_mvel", e.so_mvel, 10) FIELD("so_torque", e.so_torque, 10)
     FIELD("so_jpos", e.so_jpos, 6) FIELD("so_jvel", e.so_jvel, 6) FIELD("so_quat", e.so_quat, 4)
-    FIELD("so_rotvel", e.so_rotvel, 3) FIELD("so_tvel", e.so_tvel, 3) FIELD("so_tacc", e.so_tacc, 3) FIELD("so_height", &e.so_height, 1) FIELD("est_L", &e.est_L, 1) FIELD("snap_sole", &e.snap_sole, 1) FIELD("snap_pz", &e.snap_pz, 1)
+    FIELD("so_rotvel", e.so_rotvel, 3) FIELD("so_tvel", e.so_tvel, 3) FIELD("so_tacc", e.so_tacc, 3) FIELD("so_height", &e.so_height, 1) FIELD("est_heel", e.est.heel, 2) FIELD("est_hx", e.est.hx, 12) FIELD("est_hP", e.est.hP, 72) FIELD("est_zx", e.est.zx, 5) FIELD("est_zP", e.est.zP, 25)
+    FIELD("est_terrain", &e.est.terrain, 1) FIELD("est_pos", e.est.pos, 3) FIELD("est_vel", e.est.vel, 3) FIELD("est_foot_rel", e.est.foot_rel, 6) FIELD("est_foot_force", e.est.foot_force, 6)
     FIELD("snap_acc", e.snap_acc, 3) FIELD("snap_gyro", e.snap_gyro, 3) FIELD("snap_quat", e.snap_quat, 4)
     FIELD("snap_mpos", e.snap_mpos, 10) FIELD("snap_jpos", e.snap_jpos, 6)
     FIELD("l_foot_vel", e.l_foot_vel, 3) FIELD("r_foot_vel", e.r_foot_vel, 3)
     FIELD("reward_terms", e.last_reward_terms, 8) FIELD("clock_x", e.clock.x, 8) FIELD("phaselen", &e.clock.phaselen, 1)
     FIELD("swing_stance", &e.swing_duration, 2) FIELD("prev_action", e.prev_action, 10) FIELD("prev_torque", e.prev_torque, 10)
     FIELD("tq_fifo", e.tq_fifo, 60)
+    if (!std::strcmp(name, "est_flags")) { if (set) e.est.inited = (int)io[0]; else { io[0] = e.est.inited; io[1] = e.est.lm_iters; } return 2; }
     if (!std::strcmp(name, "xpos")) { if (!set) std::memcpy(io, e.st.xpos, sizeof(double) * 3 * NB); return 3 * NB; }
     if (!std::strcmp(name, "xquat")) { if (!set) std::memcpy(io, e.st.xquat, sizeof(double) * 4 * NB); return 4 * NB; }
     if (!std::strcmp(name, "efc_type")) { if (!set) for (int i = 0; i < MAXEFC; ++i) io[i] = e.st.efc_type[i]; return MAXEFC; }
@@ -98,6 +100,23 @@ static int field(Env& e, const char* name, double* io, bool set) {
 }
 int orc_env_get(void* h, const char* name, double* out) { return field(*(Env*)h, name, out, false); }
 int orc_env_set(void* h, const char* name, const double* in) { return field(*(Env*)h, name, (double*)in, true); }
+// the restated state estimator on its own (golden G11: the reference binary's output on a recorded sensor stream)
+void* orc_est_create() { StateOutput* s = new StateOutput; state_output_setup(*s); return s; }
+void orc_est_destroy(void* h) { delete (StateOutput*)h; }
+void orc_est_setup(void* h) { state_output_setup(*(StateOutput*)h); }
+// in: mpos10 jpos6 quat4 gyro3 acc3 (26 doubles); out: pos3 vel3 tacc3 terrain foot_rel6 foot_force6 heel2 lm_iters (25 doubles)
+void orc_est_step(void* h, const double* in, double* out) {
+    StateOutput& s = *(StateOutput*)h;
+    EstSensors x;
+    std::memcpy(x.mpos, in, sizeof(double) * 10); std::memcpy(x.jpos, in + 10, sizeof(double) * 6); std::memcpy(x.quat, in + 16, sizeof(double) * 4);
+    std::memcpy(x.gyro, in + 20, sizeof(double) * 3); std::memcpy(x.acc, in + 23, sizeof(double) * 3);
+    state_output_step(s, x);
+    std::memcpy(out, s.pos, sizeof(double) * 3); std::memcpy(out + 3, s.vel, sizeof(double) * 3); std::memcpy(out + 6, s.tacc, sizeof(double) * 3);
+    out[9] = s.terrain; std::memcpy(out + 10, s.foot_rel, sizeof(double) * 6); std::memcpy(out + 16, s.foot_force, sizeof(double) * 6);
+    out[22] = s.heel[0]; out[23] = s.heel[1]; out[24] = s.lm_iters;
+}
+double orc_est_heel_residual(double knee, double shin, double tarsus, double heel, double* grad4) { return heel_residual(knee, shin, tarsus, heel, grad4); }
+void orc_est_mldivide23(const double* M6 /* row-major 2 x 3 */, const double* tau, double* x) { const double M[2][3] = {{M6[0], M6[1], M6[2]}, {M6[3], M6[4], M6[5]}}; mldivide23(M, tau, x); }
 unsigned long long orc_flops(int reset) { const unsigned long long v = g_flops; if (reset) g_flops = 0; return v; }      // instrumented op count of this thread
 void orc_env_set_const(void* h) { set_const(((Env*)h)->par); }
 void orc_env_set_kernel_caps(void* h, int on) { ((Env*)h)->par.kernel_caps = on; }

@@ -141,14 +141,7 @@ static void forward_snapshot(Env& e, Work& w, const double* ctrl) {
     for (int u = 0; u < 10; ++u) { e.snap_mpos[u] = s.qpos[cm_act_qposadr[u]]; e.snap_mvel[u] = s.qvel[cm_act_dof[u]]; }
     for (int k = 0; k < 6; ++k) { e.snap_jpos[k] = s.qpos[cm_jsens_qposadr[k]]; e.snap_jvel[k] = s.qvel[cm_jsens_dofadr[k]]; }
     for (int k = 0; k < 4; ++k) e.snap_quat[k] = s.qpos[3 + k];
-    for (int k = 0; k < 3; ++k) { e.snap_gyro[k] = s.sens_gyro[k]; e.snap_acc[k] = s.sens_acc[k]; e.snap_vel[k] = s.qvel[k]; }
-    e.snap_pz = s.qpos[2];
-    e.snap_sole = 1e9;
-    for (int g = 0; g < 2; ++g) {            // foot capsules (geoms 0, 1)
-        const int b = cm_geom_body[g];
-        const V3 c = s.xpos[b] + mul(s.xmat[b], v3(cm_geom_pos + 3 * g)), ax = mul(s.xmat[b], v3(cm_geom_axis + 3 * g));
-        e.snap_sole = std::min(e.snap_sole, std::min((c + ax * cm_geom_half[g]).z, (c - ax * cm_geom_half[g]).z) - cm_geom_radius[g]);
-    }
+    for (int k = 0; k < 3; ++k) { e.snap_gyro[k] = s.sens_gyro[k]; e.snap_acc[k] = s.sens_acc[k]; }
 }
 
 static void foot_positions(const State& s, double* fp) {   // cassie_sim_foot_positions
@@ -184,31 +177,18 @@ void sim_step_pd(Env& e) {
         e.so_jpos[k] = x; e.so_jvel[k] = y;
     }
     e.jenc_primed = 1;
-    // --- state estimator: 39 pass-through fields + 7 filtered ones (estimator-lite)
+    // --- state estimator (state_output_step): 39 pass-through fields + the 7 filtered ones from the restated filter bank (cassie_estimator.h)
     for (int k = 0; k < 4; ++k) e.so_quat[k] = e.snap_quat[k];
     for (int k = 0; k < 3; ++k) e.so_rotvel[k] = e.snap_gyro[k];
     {
-        // estimator-lite, chosen by pushing this simulator's sensor stream through the reference's state_output_step
-        // (tools/refprobe/probe_estimator.py, golden G11): acceleration = specific force minus gravity in the PELVIS frame,
-        // velocity in the pelvis frame
-        const M3 R = q2m(Q4{e.snap_quat[0], e.snap_quat[1], e.snap_quat[2], e.snap_quat[3]});
-        // step-response probe of the binary: translationalAcceleration = accelerometer - R^T (0, 0, 9.806), sensor frame, unfiltered (exact on
-        // static and tilted inputs); the filter's gravity constant is 9.806, not the model's 9.81
-        const double EST_G = 9.806;
-        const V3 gb = {R.m[6] * EST_G, R.m[7] * EST_G, R.m[8] * EST_G};                    // R^T (0,0,g)
-        // ... minus the centripetal term of the IMU's offset from the pelvis origin, w x (w x r_imu) (cassie.xml:265 site position); no
-        // angular-acceleration term (gyro steps and ramps through the binary: tools/refprobe/probe_estimator_acc.py).  With both, golden
-        // G11 (the binary on this simulator's sensor stream) is reproduced to 5e-4 m/s^2 (before: 0.09 .. 0.24 mean)
-        const V3 wg = {e.snap_gyro[0], e.snap_gyro[1], e.snap_gyro[2]}, ri = v3(cm_imu_pos);
-        const V3 cen = cross(wg, cross(wg, ri));
-        e.so_tacc[0] = e.snap_acc[0] - gb.x - cen.x; e.so_tacc[1] = e.snap_acc[1] - gb.y - cen.y; e.so_tacc[2] = e.snap_acc[2] - gb.z - cen.z;
-        const V3 vw = {e.snap_vel[0], e.snap_vel[1], e.snap_vel[2]};
-        e.so_tvel[0] = dot(col(R, 0), vw); e.so_tvel[1] = dot(col(R, 1), vw); e.so_tvel[2] = dot(col(R, 2), vw);
-        // height = pelvis.position[2] - terrain.height of the reference filter, reproduced to < 1 cm on a 3 s walking stream by
-        // z - L with L a first-order low-pass (0.86 s) of the lowest sole height, L = 0.126 right after state_output_setup (golden
-        // G11c); the filter state persists across episodes exactly like the reference's estimator object
-        e.est_L += 0.0005 / EST_TAU * (e.snap_sole - e.est_L);
-        e.so_height = e.snap_pz - e.est_L;
+        EstSensors in;
+        for (int u = 0; u < 10; ++u) in.mpos[u] = e.so_mpos[u];
+        for (int k = 0; k < 6; ++k) in.jpos[k] = e.so_jpos[k];
+        for (int k = 0; k < 4; ++k) in.quat[k] = e.snap_quat[k];
+        for (int k = 0; k < 3; ++k) { in.gyro[k] = e.snap_gyro[k]; in.acc[k] = e.snap_acc[k]; }
+        state_output_step(e.est, in);
+        for (int k = 0; k < 3; ++k) { e.so_tvel[k] = e.est.vel[k]; e.so_tacc[k] = e.est.tacc[k]; }
+        e.so_height = e.est.pos[2] - e.est.terrain;          // pelvis.position[2] - terrain.height, cassie.py:793
     }
     // --- pd_input_step: tau = P (pTarget - q) + D (dTarget - qd), no clamp (PdInput.h; SURVEY §2.2 bit-exact probe)
     double tau[10], ctrl[10];
@@ -271,7 +251,7 @@ void env_obs(const Env& e, double* o) {
 void env_init(Env& e, const EnvCfg& cfg, uint32_t env_id) {
     std::memset(&e, 0, sizeof(e));
     e.cfg = cfg;
-    e.est_L = EST_L0; e.snap_sole = EST_L0;            // state_output_setup
+    state_output_setup(e.est);
     default_params(e.par);
     e.par.pgs_iters = cfg.pgs_iters;
     e.rng = Philox{(uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), env_id, 0};
@@ -345,7 +325,7 @@ void env_reset_for_test(Env& e, double* obs, bool full_reset) {
         e.so_quat[0] = 1; e.so_quat[1] = e.so_quat[2] = e.so_quat[3] = 0;
         for (int k = 0; k < 3; ++k) e.so_rotvel[k] = e.so_tvel[k] = e.so_tacc[k] = 0;
         e.so_height = 1.01;
-        e.est_L = EST_L0;                                 // state_output_setup
+        state_output_setup(e.est);
     }
     if (e.cfg.dynamics_randomization) {
         const int iters = e.par.pgs_iters;

@@ -5,6 +5,7 @@
 #pragma once
 #include <cstdint>
 #include "cassie_phys.h"
+#include "cassie_estimator.h"
 
 namespace orc {
 
@@ -40,7 +41,6 @@ struct Clock {                // the four clock splines of create_phase_reward, 
 };
 void make_clock(Clock& c, double swing, double stance, double relax, int stance_mode, int have_incentive, int freq);
 
-constexpr double EST_TAU = 0.86, EST_L0 = 0.126;   // fitted on the reference's state_output_step (tools/refprobe/gen_golden_estheight.py)
 struct Env {
     EnvCfg cfg;
     Params par;
@@ -61,9 +61,7 @@ struct Env {
     double jenc_x[6][4], jenc_y[6][3]; int jenc_primed;
     // sensor snapshot consumed by the NEXT substep (sensordata is one mj_step1 old when step_ethercat reads it)
     double snap_mpos[10], snap_mvel[10], snap_jpos[6], snap_jvel[6], snap_quat[4], snap_gyro[3], snap_acc[3];
-    double snap_pz, snap_vel[3];
-    double snap_sole;          // lowest world z of the two foot soles (foot capsule end centre - radius) of the last forward pass
-    double est_L;              // height filter of the state estimator (golden G11c): height = z - L, L' = (snap_sole - L) / EST_TAU
+    StateOutput est;           // the reference's state estimator object (cassie_estimator.h): persists across episodes, cleared by the full reset
     // state_out_t fields get_full_state / the reward read (cassie.py:817-850, clock_rewards.py:48,77)
     double so_mpos[10], so_mvel[10], so_torque[10], so_jpos[6], so_jvel[6], so_quat[4], so_rotvel[3], so_tvel[3],
         so_tacc[3], so_height;

@@ -56,6 +56,13 @@ def lib():
         L.orc_core_safety.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
         L.orc_philox.restype = C.c_uint32
         L.orc_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+        L.orc_est_create.restype = C.c_void_p
+        L.orc_est_destroy.argtypes = [C.c_void_p]
+        L.orc_est_setup.argtypes = [C.c_void_p]
+        L.orc_est_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_est_heel_residual.restype = C.c_double
+        L.orc_est_heel_residual.argtypes = [C.c_double] * 4 + [C.c_void_p]
+        L.orc_est_mldivide23.argtypes = [C.c_void_p] * 3
         L.orc_rollout_bench.restype = C.c_double
         L.orc_rollout_bench.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_double]
         _lib = L
@@ -233,3 +240,38 @@ def count_flops(n_steps=40, act_std=0.2, seed=0):
     total = getattr(count_flops, "_acc", 0) + lib().orc_flops(1)
     count_flops._acc = 0
     return total / done_steps
+
+
+class StateEstimator:
+    """The restated reference estimator on its own (oracle/cassie_estimator.h): step(mpos10, jpos6, quat4, gyro3, acc3) ->
+    dict(pos, vel, tacc, terrain, foot_rel, foot_force, heel, lm_iters)."""
+    def __init__(self):
+        self.h = lib().orc_est_create()
+
+    def __del__(self):
+        try:
+            lib().orc_est_destroy(self.h)
+        except Exception:
+            pass
+
+    def setup(self):
+        lib().orc_est_setup(self.h)
+
+    def step(self, sensors26):
+        x = np.ascontiguousarray(sensors26, dtype=np.float64)
+        assert x.size == 26
+        o = np.zeros(25)
+        lib().orc_est_step(self.h, _ptr(x), _ptr(o))
+        return dict(pos=o[0:3], vel=o[3:6], tacc=o[6:9], terrain=o[9], foot_rel=o[10:16].reshape(2, 3), foot_force=o[16:22].reshape(2, 3), heel=o[22:24], lm_iters=int(o[24]))
+
+
+def heel_residual(knee, shin, tarsus, heel):
+    g = np.zeros(4)
+    r = lib().orc_est_heel_residual(float(knee), float(shin), float(tarsus), float(heel), _ptr(g))
+    return r, g
+
+
+def mldivide23(M, tau):
+    Mm = np.ascontiguousarray(M, dtype=np.float64).reshape(6); t = np.ascontiguousarray(tau, dtype=np.float64); x = np.zeros(3)
+    lib().orc_est_mldivide23(_ptr(Mm), _ptr(t), _ptr(x))
+    return x
