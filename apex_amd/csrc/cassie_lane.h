@@ -659,12 +659,7 @@ __device__ __forceinline__ void stage_finish_lane(const St& S, const float* rows
         sfor<0, 10>([&](auto U) { S(F_SNAP + SN_MPOS + U) = S(F_QPOS + ct_act_qposadr[U]); });
         sfor<0, 6>([&](auto K) { S(F_SNAP + SN_JPOS + K) = S(F_QPOS + ct_jsens_qposadr[K]); });
         sfor<0, 4>([&](auto K) { S(F_SNAP + SN_QUAT + K) = S(F_QPOS + 3 + K); });
-        sfor<0, 3>([&](auto K) { S(F_SNAP + SN_GYRO + K) = S(F_QVEL + 3 + K); S(F_SNAP + SN_VEL + K) = S(F_QVEL + K); });
-        S(F_SNAP + SN_PZ) = S(F_QPOS + 2);
-        {   // lowest world z of the two foot soles (foot capsule end centre - radius), same pre-integration kinematics as the rest
-            const float zl = fminf(S.W(WK_PTS + 14), S.W(WK_PTS + 17)) - ct_geom_radius[0], zr = fminf(S.W(WK_PTS + 44), S.W(WK_PTS + 47)) - ct_geom_radius[1];
-            S(F_EST + 1) = fminf(zl, zr);
-        }
+        sfor<0, 3>([&](auto K) { S(F_SNAP + SN_GYRO + K) = S(F_QVEL + 3 + K); });
         {   // world z of the contact force on the foot bodies (cassie_sim_foot_forces -> get_foot_forces()[2], [8])
             const int nc[2] = {(int)S.W(WK_MISC + 0), (int)S.W(WK_MISC + 1)};
             const float mu = S(F_FRIC);

@@ -10,6 +10,7 @@
 #include "apx_common.h"
 #include "cassie_model_gen.h"
 #include "cassie_lane.h"
+#include "estimator_lane.h"
 
 #include <new>
 #include <cstring>
@@ -51,12 +52,13 @@ template <class T> __device__ __forceinline__ T sel5(int u5, T a0, T a1, T a2, T
 static_assert(cmt::ct_act_gear[5] == cmt::ct_act_gear[0] && cmt::ct_act_gear[9] == cmt::ct_act_gear[4] && cmt::ct_act_bits[7] == cmt::ct_act_bits[2] &&
               cmt::ct_act_rpm[8] == cmt::ct_act_rpm[3] && cmt::ct_act_ctrlmax[6] == cmt::ct_act_ctrlmax[1] && cmt::ct_act_dof[5] == cmt::ct_act_dof[0] + 13 &&
               cmt::ct_act_dof[9] == cmt::ct_act_dof[4] + 13, "the two legs carry the same drives");
-__device__ __forceinline__ void stage1_io_lane(St S, int mode) {   // (as a called function the reset kernel faults: kept inline)
+__device__ __forceinline__ void stage1_io_lane(St S, int mode, float* estrec) {   // (as a called function the reset kernel faults: kept inline)
     PROF_START();
     int l = threadIdx.x & 15;
     asm volatile("" : "+v"(l));      // opaque: otherwise every per-lane constant below is hoisted out of the 50-substep loop and has to be
                                      // kept (= spilled to scratch) across the constraint stage, which needs the whole register file
     if (mode == 0) { if (l < 10) S.W(c4::WK_CTRL + l) = 0.f; PROF(0); return; }
+    est::Rec rec = est::rec_load(estrec, S.env, l);      // in flight while the encoder model runs
     const int flags = S.I(I_FLAGS);
     const bool mot = l < 10;
     const int u = mot ? l : 0, u5 = u >= 5 ? u - 5 : u, k = mot ? 0 : l - 10;
@@ -133,24 +135,13 @@ __device__ __forceinline__ void stage1_io_lane(St S, int mode) {   // (as a call
     }
     if (l == 0) {
         S.I(I_FLAGS) = flags | 3;
-        // estimator: pass-through fields + estimator-lite for the 7 filtered ones (golden G11)
-        const Q4 q = {S(F_SNAP + SN_QUAT), S(F_SNAP + SN_QUAT + 1), S(F_SNAP + SN_QUAT + 2), S(F_SNAP + SN_QUAT + 3)};
+        // state estimator, pass-through fields (pelvis.orientation / rotationalVelocity = vectorNav orientation / gyro)
         _Pragma("unroll") for (int i = 0; i < 4; ++i) S(F_SO + SO_QUAT + i) = S(F_SNAP + SN_QUAT + i);
         _Pragma("unroll") for (int i = 0; i < 3; ++i) S(F_SO + SO_ROTVEL + i) = S(F_SNAP + SN_GYRO + i);
-        const M3 R = q2m(q);
-        // state_output_step: translationalAcceleration = accelerometer - R^T (0, 0, 9.806) in the sensor frame, unfiltered (step-response
-        // probe of the reference binary, DESIGN.md section 5: the filter's gravity constant is 9.806, not the model's 9.81)
-        constexpr float EST_G = 9.806f;
-        // ... minus the centripetal term of the IMU's offset from the pelvis origin, w x (w x r_imu); no angular-acceleration term (same probe):
-        // with both, golden G11 is reproduced to 5e-4 m/s^2
-        const V3 wg = {S(F_SNAP + SN_GYRO), S(F_SNAP + SN_GYRO + 1), S(F_SNAP + SN_GYRO + 2)};
-        const V3 cen = cross(wg, cross(wg, V3{cmt::ct_imu_pos[0], cmt::ct_imu_pos[1], cmt::ct_imu_pos[2]}));
-        S(F_SO + SO_TACC) = S(F_SNAP + SN_ACC) - R.m[6] * EST_G - cen.x; S(F_SO + SO_TACC + 1) = S(F_SNAP + SN_ACC + 1) - R.m[7] * EST_G - cen.y;
-        S(F_SO + SO_TACC + 2) = S(F_SNAP + SN_ACC + 2) - R.m[8] * EST_G - cen.z;
-        const V3 vw = {S(F_SNAP + SN_VEL), S(F_SNAP + SN_VEL + 1), S(F_SNAP + SN_VEL + 2)};
-        S(F_SO + SO_TVEL) = dot(col(R, 0), vw); S(F_SO + SO_TVEL + 1) = dot(col(R, 1), vw); S(F_SO + SO_TVEL + 2) = dot(col(R, 2), vw);
-        { const float L = S(F_EST) + EST_ALPHA * (S(F_EST + 1) - S(F_EST)); S(F_EST) = L; S(F_SO + SO_HEIGHT) = S(F_SNAP + SN_PZ) - L; }      // golden G11c
     }
+    c4::wsync();                                          // the encoder lanes' outputs are the estimator's inputs
+    est::est_step_lane(S, rec);                           // the 7 filtered fields: translationalVelocity, translationalAcceleration, height
+    est::rec_store(estrec, S.env, l, rec);
     PROF(0);
 }
 __device__ APX_STAGE void stage1b_tree_lane(St S) {
@@ -197,7 +188,7 @@ __device__ __forceinline__ void sim_step_pd(const St& S, const Cfg& cfg, int mod
 #ifdef APX_PROF
     const unsigned long long t0__ = clock64();
 #endif
-    stage1_io_lane(S, mode);
+    stage1_io_lane(S, mode, cfg.est);
     c4::wsync();
     stage1b_tree_lane(S);
     c4::wsync();
@@ -482,7 +473,6 @@ __global__ __launch_bounds__(64) void env_init_kernel(float* st, int* ist, int n
     auto G = [&](int f) -> float& { return st[(size_t)f * n + env]; };
     for (int f = 0; f < F_TOTAL; ++f) G(f) = 0.f;
     for (int f = 0; f < I_TOTAL; ++f) ist[(size_t)f * n + env] = 0;
-    G(F_EST) = EST_L0; G(F_EST + 1) = EST_L0;                     // state_output_setup
     for (int i = 0; i < NQ; ++i) G(F_QPOS + i) = cm_init_qpos[i];
     for (int b = 0; b < NB; ++b) G(F_MASS + b) = cm_body_mass[b];
     for (int d = 0; d < NV; ++d) G(F_DAMP + d) = cm_dof_damping[d];
@@ -622,8 +612,8 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_for_test_kerne
             S(F_SO + SO_QUAT) = 1.f;
             for (int k = 0; k < 3; ++k) { S(F_SO + SO_QUAT + 1 + k) = 0.f; S(F_SO + SO_ROTVEL + k) = 0.f; S(F_SO + SO_TVEL + k) = 0.f; S(F_SO + SO_TACC + k) = 0.f; }
             S(F_SO + SO_HEIGHT) = 1.01f;                                         // pelvis.position[2] = 1.01, terrain.height = 0
-            S(F_EST) = EST_L0;                                                   // state_output_setup: the height filter restarts
         }
+        if (l < 7) { est::Rec z; c4::sfor<0, 6>([&](auto K) { z.v[K] = est::f4{0.f, 0.f, 0.f, 0.f}; }); est::rec_store(cfg.est, S.env, l, z); }      // state_output_setup: the estimator restarts
         c4::wsync();
     } else {
         sim_step_pd<HF>(S, cfg, 1);                                        // self.cassie_state = self.sim.step_pd(self.u), stale targets
@@ -677,7 +667,7 @@ static Cfg make_cfg(const apx_env& env) {
     const apx_env_cfg& c = env.cfg;
     return Cfg{Hf{env.hf, env.hf_nrow, env.hf_ncol, env.hf_size[0], env.hf_size[1], env.hf_size[2]}, c.simrate, c.dynamics_randomization, c.stance_mode, c.have_incentive, c.max_traj_len, c.pgs_iters,
                (unsigned)c.seed, (unsigned)(c.seed >> 32), (unsigned)c.env_id_base, c.reward_kind, c.env_kind, c.command_profile,
-               c.command_profile == 0 ? APX_OBS_DIM : APX_OBS_DIM_PHASE};
+               c.command_profile == 0 ? APX_OBS_DIM : APX_OBS_DIM_PHASE, env.wk};
 }
 
 extern "C" void apx_env_default_cfg(apx_env_cfg* c) {
@@ -702,7 +692,8 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     APX_HIP(hipMalloc(&e->st, sizeof(float) * (size_t)F_TOTAL * e->n));
     APX_HIP(hipMalloc(&e->ist, sizeof(int) * (size_t)I_TOTAL * e->n));
     e->wk = nullptr;
-    APX_HIP(hipMalloc(&e->wk, 256));      // generation 4 keeps the stage hand-off in LDS: no HBM workspace
+    APX_HIP(hipMalloc(&e->wk, sizeof(float) * (size_t)est::REC * e->n));      // state-estimator records (estimator_lane.h); the stage hand-off itself lives in LDS
+    APX_HIP(hipMemset(e->wk, 0, sizeof(float) * (size_t)est::REC * e->n));  // state_output_setup
     e->hf = nullptr; e->hf_nrow = e->hf_ncol = 0; e->hf_size[0] = e->hf_size[1] = e->hf_size[2] = 0.f;
     e->timing = 0; e->ev = nullptr; e->ev_cap = e->ev_n = 0; e->t_ms = 0.0; e->t_launches = 0;
     const Cfg c = make_cfg(*e);
@@ -900,7 +891,8 @@ static const FieldDesc kFields[] = {
     {"so_mpos", F_SO + SO_MPOS, 10}, {"so_mvel", F_SO + SO_MVEL, 10}, {"so_torque", F_SO + SO_TORQUE, 10},
     {"so_jpos", F_SO + SO_JPOS, 6}, {"so_jvel", F_SO + SO_JVEL, 6}, {"so_quat", F_SO + SO_QUAT, 4},
     {"so_rotvel", F_SO + SO_ROTVEL, 3}, {"so_tvel", F_SO + SO_TVEL, 3}, {"so_tacc", F_SO + SO_TACC, 3}, {"so_height", F_SO + SO_HEIGHT, 1},
-    {"foot_vel", F_FOOTVEL, 6}, {"prev_action", F_PREVACT, 10}, {"prev_torque", F_PREVTQ, 10}, {"cmd", F_CMD, 7}, {"fwd", F_FWD, 16}, {"xfrc", F_XFRC, 6}, {"est", F_EST, 2},
+    {"foot_vel", F_FOOTVEL, 6}, {"prev_action", F_PREVACT, 10}, {"prev_torque", F_PREVTQ, 10}, {"cmd", F_CMD, 7}, {"fwd", F_FWD, 16}, {"xfrc", F_XFRC, 6},
+    {"menc", F_MENC, 90}, {"jenc_x", F_JENCX, 24}, {"jenc_y", F_JENCY, 12}, {"snap", F_SNAP, 26}, {"foot_prev", F_FOOTPREV, 6},      // (teacher-forced parity tests copy the oracle's whole state in)
 };
 
 static const FieldDesc* find_field(const char* name) {
@@ -936,6 +928,10 @@ extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, voi
         APX_LAUNCH_CHECK();
         return 0;
     }
+    if (!strcmp(name, "est")) {       // the state-estimator records, [n][est::REC] as stored (estimator_lane.h)
+        APX_HIP(hipMemcpyAsync(out, e->wk, sizeof(float) * (size_t)est::REC * e->n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return est::REC;
+    }
     const FieldDesc* f = find_field(name);
     APX_REQUIRE(f, "unknown field");
     hipLaunchKernelGGL(gather_kernel, dim3(apx_cdiv((long)e->n * f->cnt, 256)), dim3(256), 0, (hipStream_t)stream, e->st, e->n, f->f0, f->cnt, out);
@@ -955,6 +951,10 @@ extern "C" int apx_env_set_field(apx_env_t* e, const char* name, const float* in
         hipLaunchKernelGGL(scatter_int_kernel, dim3(apx_cdiv((long)e->n * I_TOTAL, 256)), dim3(256), 0, (hipStream_t)stream, e->ist, e->n, (int)I_TOTAL, in);
         APX_LAUNCH_CHECK();
         return I_TOTAL;
+    }
+    if (!strcmp(name, "est")) {
+        APX_HIP(hipMemcpyAsync(e->wk, in, sizeof(float) * (size_t)est::REC * e->n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return est::REC;
     }
     const FieldDesc* f = find_field(name);
     APX_REQUIRE(f, "unknown field");

@@ -9,15 +9,14 @@ enum Field : int {
     F_QPOS = 0, F_QVEL = F_QPOS + ES_NQ, F_QACCW = F_QVEL + ES_NV, F_MASS = F_QACCW + ES_NV, F_DAMP = F_MASS + ES_NB,
     F_FRIC = F_DAMP + ES_NV, F_FLOOR = F_FRIC + 1 /* n, t1, t2: 9 */, F_BIW = F_FLOOR + 9, F_DIW = F_BIW + ES_NB,
     F_MNOISE = F_DIW + ES_NV, F_JNOISE = F_MNOISE + 10, F_PDT = F_JNOISE + 6, F_FIFO = F_PDT + 10, F_MENC = F_FIFO + 60,
-    F_JENCX = F_MENC + 90, F_JENCY = F_JENCX + 24, F_SNAP = F_JENCY + 12 /* mpos10 jpos6 quat4 gyro3 acc3 vel3 pz1 */,
-    F_SO = F_SNAP + 30 /* mpos10 mvel10 torque10 jpos6 jvel6 quat4 rotvel3 tvel3 tacc3 height1 */, F_FOOTPREV = F_SO + 56,
+    F_JENCX = F_MENC + 90, F_JENCY = F_JENCX + 24, F_SNAP = F_JENCY + 12 /* mpos10 jpos6 quat4 gyro3 acc3 */,
+    F_SO = F_SNAP + 26 /* mpos10 mvel10 torque10 jpos6 jvel6 quat4 rotvel3 tvel3 tacc3 height1 */, F_FOOTPREV = F_SO + 56,
     F_FOOTVEL = F_FOOTPREV + 6, F_PREVACT = F_FOOTVEL + 6, F_PREVTQ = F_PREVACT + 10,
     F_CMD = F_PREVTQ + 10 /* speed side orient swing stance phaselen stance_mode */, F_FWD = F_CMD + 7 /* foot force z L,R; foot quat L4 R4; foot pos 6 */,
     F_XFRC = F_FWD + 16 /* external wrench on the pelvis, world frame: force xyz, torque xyz (mjData.xfrc_applied row of cassie-pelvis) */,
-    F_EST = F_XFRC + 6 /* height filter of the state estimator: [0] L = low-passed lowest sole height, [1] lowest sole world z of the last forward pass */,
-    F_TOTAL = F_EST + 2
+    F_TOTAL = F_XFRC + 6      // (the state estimator's persistent state is not here: env-major records in apx_env::wk, estimator_lane.h)
 };
-enum SnapOff { SN_MPOS = 0, SN_JPOS = 10, SN_QUAT = 16, SN_GYRO = 20, SN_ACC = 23, SN_VEL = 26, SN_PZ = 29 };
+enum SnapOff { SN_MPOS = 0, SN_JPOS = 10, SN_QUAT = 16, SN_GYRO = 20, SN_ACC = 23 };
 enum SoOff { SO_MPOS = 0, SO_MVEL = 10, SO_TORQUE = 20, SO_JPOS = 30, SO_JVEL = 36, SO_QUAT = 42, SO_ROTVEL = 46, SO_TVEL = 49, SO_TACC = 52, SO_HEIGHT = 55 };
 enum IField : int { I_TIME = 0, I_PHASE, I_COUNTER, I_RNG, I_FLAGS /* bit0 menc primed, 1 jenc primed, 2 prev_action, 3 prev_torque */,
                     I_SAT /* constraint sets beyond what the kernel instantiates: bits 0-3 = SAT_* flags seen since env creation, bits 8.. = number of such forward passes */, I_TOTAL };
@@ -29,7 +28,7 @@ struct apx_env {
     apx_env_cfg cfg;
     float* st;      // [F_TOTAL, n]
     int* ist;       // [I_TOTAL, n]
-    float* wk;      // unused placeholder allocation (the stage hand-off lives in LDS)
+    float* wk;      // state-estimator records, [n][est::REC] env-major (estimator_lane.h); the stage hand-off itself lives in LDS
     int n;
     float* hf; int hf_nrow, hf_ncol; float hf_size[3];      // device copy of the height field (apx_env_set_hfield), or nullptr
     // apx_env_timing: hipEvent pairs around every env_step_kernel launch, on the launch stream (bench.py's roofline.achieved)
@@ -66,12 +65,10 @@ struct St {
     __device__ __forceinline__ lint& I(int f) const { return ((lint*)p)[L4_INT + f]; }
 };
 
-// state estimator height model (golden G11c): height = z - L, L' = (lowest sole z - L) / EST_TAU, L = EST_L0 after state_output_setup
-constexpr float EST_TAU = 0.86f, EST_L0 = 0.126f, EST_ALPHA = 0.0005f / EST_TAU;
 // terrain of cassie_hfield.xml (util/eval.py:73-76): nrow x ncol raw elevations (rows along y, columns along x) over [-sx, sx] x [-sy, sy],
 // elevation = data * sz; data == nullptr: the floor plane of cassie.xml:73
 struct Hf { const float* data; int nrow, ncol; float sx, sy, sz; };
-struct Cfg { Hf hf; int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; int reward_kind, env_kind, command_profile, obs_dim; };
+struct Cfg { Hf hf; int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; int reward_kind, env_kind, command_profile, obs_dim; float* est /* state-estimator records, [n][est::REC] (estimator_lane.h) */; };
 
 // ------------------------------------------------------------------------------------------------ Philox4x32-10
 __device__ __forceinline__ unsigned philox(unsigned k0, unsigned k1, unsigned env, unsigned ctr) {

@@ -215,7 +215,7 @@ class CassieVecEnv:
     # ---- raw state access (tests, tools) ----
     def get_field(self, name, count=None):
         lib = _lib.load()
-        buf = torch.zeros(self.n_envs, 128, dtype=torch.float32, device=self.device)
+        buf = torch.zeros(self.n_envs, 192, dtype=torch.float32, device=self.device)
         n = lib.apx_env_get_field(self._h, name.encode(), _p(buf), _stream())
         if n < 0:
             check(n)
