@@ -100,17 +100,41 @@ def eval_main(argv):
     from apex_amd.vecenv import CassieVecEnv
     from apex_amd.engine import Mlp
     from apex_amd.eval import evaluate
-    env = CassieVecEnv(n_envs=a.n_envs, reward=a.reward, max_traj_len=a.max_traj_len, dynamics_randomization=False)
+    env = CassieVecEnv(n_envs=a.n_envs, max_traj_len=a.max_traj_len, dynamics_randomization=False, **_run_env_kwargs(a.path, a.reward))
     if a.terrain is not None and ".npy" in a.terrain:            # env.sim = CassieSim("cassie_hfield.xml"); sim.set_hfield_data(np.load(terrain).flatten())
         import numpy as np
         path = a.terrain if os.path.exists(a.terrain) else os.path.join("./cassie/cassiemujoco/terrains/", a.terrain)
         env.set_hfield(np.load(path), size=(50.0, 50.0, 0.15))  # cassie_hfield.xml:69
     actor, mean, std = _load_actor(a.path, env.device)
+    _check_obs_dim(actor, env)
     out = evaluate(actor, env, mean, std, speed=a.speed, side_speed=a.side_speed, max_steps=a.max_traj_len, basic=a.basic)
     ln, rt = out["lengths"].cpu(), out["returns"].cpu()
     print("episodes %d  mean length %.1f (min %d, max %d)  mean return %.3f  fell %d  reached the time limit %d" % (
         a.n_envs, float(ln.mean()), int(ln.min()), int(ln.max()), float(rt.mean()), int(out["terminated"].sum()), int(out["truncated"].sum())))
     return 0
+
+
+def _run_env_kwargs(path, reward_flag):
+    """env-defining arguments of the run that produced the checkpoint (experiment.pkl, util/log.py:57-64 / parse_previous :74-91): a policy trained with
+    --command_profile phase or --history h expects that observation, not the 50-entry default"""
+    import os, pickle
+    kw = dict(reward=reward_flag)
+    pkl = os.path.join(path, "experiment.pkl")
+    if os.path.exists(pkl):
+        with open(pkl, "rb") as f:
+            run = pickle.load(f)
+        for key, arg in (("reward", "reward"), ("command_profile", "command_profile"), ("history", "history"), ("env_name", "env_name")):
+            if getattr(run, arg, None) is not None:
+                kw[key] = getattr(run, arg)
+        if reward_flag != "clock":
+            kw["reward"] = reward_flag                       # an explicit --reward wins
+    return kw
+
+
+def _check_obs_dim(actor, env):
+    D = getattr(actor, "D", None) or getattr(getattr(actor, "net", None), "D", None)
+    if D is not None and D != env.obs_dim:
+        raise ValueError("the checkpoint expects %d observation entries, the env built from its experiment.pkl produces %d (command_profile / history mismatch)" % (D, env.obs_dim))
 
 
 def _load_actor(path, device):
@@ -152,8 +176,10 @@ def eval_perturb_main(argv):
     a = p.parse_args(argv)
     from apex_amd.vecenv import CassieVecEnv
     from apex_amd.eval import compute_perturbs
-    mk = lambda n: CassieVecEnv(n_envs=n, reward=a.reward, max_traj_len=100000, dynamics_randomization=False)
+    kw = _run_env_kwargs(a.path, a.reward)
+    mk = lambda n: CassieVecEnv(n_envs=n, max_traj_len=100000, dynamics_randomization=False, **kw)
     actor, mean, std = _load_actor(a.path, torch.device("cuda", 0))
+    _check_obs_dim(actor, mk(64))
     t0 = time.time()
     mf, fell = compute_perturbs(actor, mk, mean, std, wait_time=a.wait_time, perturb_duration=a.perturb_duration,
                                 perturb_size=a.perturb_size, perturb_incr=a.perturb_incr, num_angles=a.num_angles, n_sizes=a.n_sizes)
@@ -183,8 +209,10 @@ def eval_commands_main(argv):
     a = p.parse_args(argv)
     from apex_amd.vecenv import CassieVecEnv
     from apex_amd.eval import eval_commands
-    mk = lambda n: CassieVecEnv(n_envs=n, reward=a.reward, max_traj_len=100000, dynamics_randomization=False)
+    kw = _run_env_kwargs(a.path, a.reward)
+    mk = lambda n: CassieVecEnv(n_envs=n, max_traj_len=100000, dynamics_randomization=False, **kw)
     actor, mean, std = _load_actor(a.path, torch.device("cuda", 0))
+    _check_obs_dim(actor, mk(64))
     t0 = time.time()
     d = eval_commands(actor, mk, mean, std, num_steps=a.n_steps, num_commands=a.n_commands, max_speed=a.max_speed,
                       min_speed=a.min_speed, num_iters=a.n_iter)

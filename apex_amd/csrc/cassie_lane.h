@@ -807,8 +807,8 @@ __device__ __forceinline__ float floor_dist_dev(const Hf& hf, V3 fn, V3 c, float
     if constexpr (!HF) { n = fn; return dot(c - V3{ct_floor_pos[0], ct_floor_pos[1], ct_floor_pos[2]}, fn) - rad; }
     else {
     const float dx = 2.f * hf.sx / (float)(hf.ncol - 1), dy = 2.f * hf.sy / (float)(hf.nrow - 1);
-    const float u = fminf(fmaxf((c.x + hf.sx) / dx, 0.f), (float)(hf.ncol - 1) - 1e-4f), v = fminf(fmaxf((c.y + hf.sy) / dy, 0.f), (float)(hf.nrow - 1) - 1e-4f);
-    const int ci = (int)u, ri = (int)v;
+    const float u = fminf(fmaxf((c.x + hf.sx) / dx, 0.f), (float)(hf.ncol - 1)), v = fminf(fmaxf((c.y + hf.sy) / dy, 0.f), (float)(hf.nrow - 1));
+    const int ci = min((int)u, hf.ncol - 2), ri = min((int)v, hf.nrow - 2);      // the cell index is clamped as an INTEGER: a float margin is below fp32 resolution on large fields
     const float fu = u - (float)ci, fv = v - (float)ri;
     const float* q = hf.data + (size_t)ri * hf.ncol + ci;
     const float h00 = hf.sz * q[0], h10 = hf.sz * q[1], h01 = hf.sz * q[hf.ncol], h11 = hf.sz * q[hf.ncol + 1];

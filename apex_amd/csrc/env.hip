@@ -908,6 +908,11 @@ extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, voi
         APX_LAUNCH_CHECK();
         return I_TOTAL;
     }
+    if (!strcmp(name, "ints_bits")) {      // the same words bit for bit (an int32 view of `out`): counters above 2^24 do not survive the float conversion
+        hipLaunchKernelGGL(gather_kernel, dim3(apx_cdiv((long)e->n * I_TOTAL, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)e->ist, e->n, 0, (int)I_TOTAL, out);
+        APX_LAUNCH_CHECK();
+        return I_TOTAL;
+    }
 #ifdef APX_PROF
     if (!strcmp(name, "prof")) {   // 48 cumulative phase cycle counters, then reset
         unsigned long long h[48];

@@ -19,10 +19,31 @@ def rollout_len(num_steps, n_envs, world):
     return max(1, -(-num_steps // (n_envs * world)))
 
 
+# optional timing of the gradient all-reduce (bench.py at N > 1): event pairs around every allreduce_mean_ on the current stream, drained by timing_read()
+_timing = {"on": False, "events": []}
+
+
+def timing(enable):
+    _timing["on"] = bool(enable); _timing["events"] = []
+
+
+def timing_read():
+    """(total ms, calls) of the all-reduces recorded since timing(True)"""
+    ev = _timing["events"]; _timing["events"] = []
+    if ev:
+        ev[-1][1].synchronize()
+    return sum(a.elapsed_time(b) for a, b in ev), len(ev)
+
+
 def allreduce_mean_(flat, group=None, world=None):
     world = world or dist.get_world_size(group)
+    rec = _timing["on"] and flat.is_cuda
+    if rec:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); e0.record()
     dist.all_reduce(flat, group=group)
     flat /= world
+    if rec:
+        e1.record(); _timing["events"].append((e0, e1))
     return flat
 
 

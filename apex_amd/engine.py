@@ -95,6 +95,8 @@ class Mlp:
     def forward(self, x, obs_mean=None, obs_std=None, idx=None, sign_perm=None, clock_mask=0, keep=False, out=None, precision=0):
         _need_gpu(x)
         x = x.contiguous()
+        assert x.shape[-1] == self.D, "input width %d, the network was built for %d" % (x.shape[-1], self.D)      # a wrong row stride reads out of bounds on the device
+        assert obs_mean is None or obs_mean.numel() == self.D, "observation statistics of %d entries for a %d-input network" % (obs_mean.numel(), self.D)
         B = x.shape[0] if idx is None else idx.numel()
         dev = x.device
         if keep or precision or not (self.H == 256 and self.D <= 64 and self.O <= 128):
@@ -146,6 +148,7 @@ class Lstm:
         step = x.dim() == 2
         x3 = (x.unsqueeze(0) if step else x).contiguous()
         T, B, _ = x3.shape
+        assert x3.shape[-1] == self.D, "input width %d, the network was built for %d" % (x3.shape[-1], self.D)
         lib = _lib.load()
         save = torch.empty(int(lib.apx_lstm_workspace_floats(T, B, self.H, self.L)), dtype=torch.float32, device=x.device)
         y = torch.empty(T, B, self.O, dtype=torch.float32, device=x.device)

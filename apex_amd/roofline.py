@@ -5,9 +5,10 @@ persistent per-env state (F_TOTAL fp32 fields + 5 int fields, env.hip `enum Fiel
 ENV_STEP_FLOP: fp32 operations of one env step of the tree-sparse formulation, counted analytically per substep
  x 50.
 """
-F_TOTAL = 586          # floats of persistent state per env (env_state.h: enum Field)
+F_TOTAL = 580          # floats of persistent state per env (env_state.h: enum Field)
 I_TOTAL = 6
-ENV_STEP_BYTES = 2 * 4 * (F_TOTAL + I_TOTAL) + 4 * 10 + 4 * 50 + 4 + 1
+EST_REC = 168          # state-estimator record per env (estimator_lane.h): read + written once per env step at least (it moves through L2 every substep)
+ENV_STEP_BYTES = 2 * 4 * (F_TOTAL + I_TOTAL + EST_REC) + 4 * 10 + 4 * 50 + 4 + 1
 
 # per-substep fp32 op count (multiply-add = 2), typical walking state: 12 equality rows + 2 contacts (8 rows) = 20 rows
 _FK = 25 * 95 + 32 * 12

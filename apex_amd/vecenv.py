@@ -253,7 +253,7 @@ class CassieVecEnv:
         """(flags [N] int64, passes [N] int64): SAT_* bits (1 = more than 2 penetrating capsule ends on a leg, 2 = more than 1 active joint
         limit on a leg, 4 = pelvis sphere / hip-pitch capsule on the floor, 8 = a left-right capsule pair in contact) a forward pass of the
         env has needed beyond the constraint rows the kernel instantiates since the env was created, and how many such passes there were."""
-        sat = self.get_field("ints")[:, 5].to(torch.int64)
+        sat = self.get_field("ints_bits").view(torch.int32)[:, 5].to(torch.int64)      # bit-exact integer words (the float view of "ints" rounds above 2^24)
         return sat & 0xFF, sat >> 8
 
     def substep(self):

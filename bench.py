@@ -220,6 +220,8 @@ def main():
     # per-launch duration of the dominant kernel (env step): hipEvent pairs recorded by the library around every env_step_kernel launch of
     # the timed region, on the stream the kernel is launched on (include/apx.h apx_env_timing)
     env.kernel_timing(True); env.kernel_timing_read(reset=True)
+    if world > 1:
+        adist.timing(True)
     barrier()
     t0 = time.time()
     samp = opt = 0.0
@@ -232,7 +234,13 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax)
+    ar_ms, ar_calls = adist.timing_read() if world > 1 else (0.0, 0)
+    adist.timing(False)
     k_total_ms, k_launches = env.kernel_timing_read(reset=True)      # the env_step_kernel launches of the timed region
+    if k_launches == 0:      # APX_ROLLOUT_GRAPH=1: the rollout was captured during warm-up, before the event pairs were switched on -> a few eager timed launches
+        for _ in range(8):
+            env.step(algo.b_act[0] if hasattr(algo, "b_act") else torch.zeros(a.n_envs, 10, device=env.device), auto_reset=True)
+        k_total_ms, k_launches = env.kernel_timing_read(reset=True)
     env.kernel_timing(False)
     k_ms = k_total_ms / max(k_launches, 1)
 
@@ -269,13 +277,19 @@ def main():
                        "parallelism": f"dp{world} (env shards, 1 RCCL grad all-reduce per optimiser step)"},
             "sampling_env_steps_per_s": round(a.steps * a.rollout_len * a.n_envs * world / max(samp, 1e-9), 1),
             "sample_s": round(samp / a.steps, 3), "optimize_s": round(opt / a.steps, 3),
+            # what the collective path actually was in this run (explains a scaling curve on its own): ranks the process group saw, backend, and the
+            # gradient / scalar all-reduces of the timed region (hipEvents on the launch stream of rank 0)
+            "collectives": {"rccl_ranks_seen": torch.distributed.get_world_size() if world > 1 else 1, "backend": torch.distributed.get_backend() if world > 1 else None,
+                            "allreduce_calls_per_step": round(ar_calls / a.steps, 1), "allreduce_ms_per_step": round(ar_ms / a.steps, 3), "gradient_floats": 160523},
             # the binding bound of the dominant kernel is the fp32 vector pipe (HBM traffic is 1.1 x the algorithmic bytes and
             # < 0.1 % of the peak): achieved = instrumented flops of the CPU restatement per env step x envs / launch time.  The HBM view
             # north_star asks for is reported beside it.
             "roofline": {"kernel": "env_step_kernel", "bound": "valu", "achieved": round(flop_step * a.n_envs / (k_ms * 1e-3) / 1e12, 4),
                          "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop_step * a.n_envs / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 6),
+                         # the same launch time against the KERNEL's own (tree-sparse) operation count: the dense oracle executes ~13 % more operations than the kernel needs
+                         "frac_sparse": round(roofline.ENV_STEP_FLOP * a.n_envs / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 6), "flop_per_env_step_sparse": roofline.ENV_STEP_FLOP,
                          "traffic": _pmc_traffic_bytes(), "ms_per_launch": round(k_ms, 4), "launches_timed": k_launches,
-                         "flop_per_env_step": flop_step, "flop_source": "instrumented count of oracle/cassie_phys.cpp (oracle.sim.count_flops); hand count of the tree-sparse formulation: %d" % roofline.ENV_STEP_FLOP,
+                         "flop_per_env_step": flop_step, "flop_source": "oracle-equivalent flops: instrumented count of the dense fp64 restatement oracle/cassie_phys.cpp (oracle.sim.count_flops); frac_sparse uses the hand count of the kernel's tree-sparse formulation",
                          "hbm": {"bytes_per_env_step": bytes_per_env_step, "achieved_GBps": round(achieved, 3), "peak_GBps": HBM_PEAK_GBS, "frac": round(achieved / HBM_PEAK_GBS, 6)},
                          "mlp_forward_mfma": {"what": "actor forward, %d x (50-256-256-10), fp32 MFMA (v_mfma_f32_32x32x2_f32), one fused launch (input normalisation + 3 layers, activations in LDS)" % mb_rows,
                                               "ms": round(mlp_ms, 4), "achieved_tflops": round(mlp_flop / (mlp_ms * 1e-3) / 1e12, 2),

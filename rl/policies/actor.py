@@ -31,6 +31,8 @@ class _FixedStdGaussian(Actor):
         return self.fixed_std
 
     def forward(self, state, deterministic=True, anneal=1.0):
+        if getattr(self, "bounded", False):      # a reference checkpoint with tanh-bounded means: refuse at the first forward, deterministic or not
+            raise NotImplementedError("checkpoints with tanh-bounded means are not supported by this engine")
         mu = self._mean(state)
         self.action = mu if deterministic else torch.distributions.Normal(mu, self._std() * anneal).sample()
         return self.action
