@@ -373,6 +373,12 @@ __device__ void env_reset_finish(const St& S, const Cfg& cfg) {
 template <bool HF>
 __device__ __forceinline__ void env_reset(const St& S, const Cfg& cfg) {
     const bool lead = (threadIdx.x & 15) == 0;
+    if (cfg.est_lifetime > 0 && S.I(I_AGE) >= cfg.est_lifetime) {      // this env instance has served a PPO.sample call's worth of steps: the next one starts with a new estimator
+        const int l = threadIdx.x & 15;
+        if (l < 7) { est::Rec z; c4::sfor<0, 6>([&](auto K) { z.v[K] = est::f4{0.f, 0.f, 0.f, 0.f}; }); est::rec_store(cfg.est, S.env, l, z); }
+        c4::wsync();
+        if (lead) S.I(I_AGE) = 0;
+    }
     if (lead) env_reset_draws(S, cfg);
     c4::wsync();
     if (cfg.dyn_rand) setconst_lane(S);               // sim.set_const -> mj_setConst
@@ -534,7 +540,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
         const float height = S(F_QPOS + 2);
         int time = S.I(I_TIME) + 1, phase = S.I(I_PHASE) + 1;
         if ((float)phase > S(F_CMD + 5)) { phase = 0; S.I(I_COUNTER) += 1; }
-        S.I(I_TIME) = time; S.I(I_PHASE) = phase;
+        S.I(I_TIME) = time; S.I(I_PHASE) = phase; S.I(I_AGE) += 1;
         // NaN test on the bit pattern: it must survive -ffast-math (finite-math-only would fold `h != h` away)
         const bool h_nan = (__float_as_uint(height) & 0x7fffffffu) > 0x7f800000u;
         int dn = (height < 0.4f || height > 3.0f || h_nan) ? 1 : 0;
@@ -614,6 +620,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_for_test_kerne
             S(F_SO + SO_HEIGHT) = 1.01f;                                         // pelvis.position[2] = 1.01, terrain.height = 0
         }
         if (l < 7) { est::Rec z; c4::sfor<0, 6>([&](auto K) { z.v[K] = est::f4{0.f, 0.f, 0.f, 0.f}; }); est::rec_store(cfg.est, S.env, l, z); }      // state_output_setup: the estimator restarts
+        if (lead) S.I(I_AGE) = 0;
         c4::wsync();
     } else {
         sim_step_pd<HF>(S, cfg, 1);                                        // self.cassie_state = self.sim.step_pd(self.u), stale targets
@@ -667,14 +674,14 @@ static Cfg make_cfg(const apx_env& env) {
     const apx_env_cfg& c = env.cfg;
     return Cfg{Hf{env.hf, env.hf_nrow, env.hf_ncol, env.hf_size[0], env.hf_size[1], env.hf_size[2]}, c.simrate, c.dynamics_randomization, c.stance_mode, c.have_incentive, c.max_traj_len, c.pgs_iters,
                (unsigned)c.seed, (unsigned)(c.seed >> 32), (unsigned)c.env_id_base, c.reward_kind, c.env_kind, c.command_profile,
-               c.command_profile == 0 ? APX_OBS_DIM : APX_OBS_DIM_PHASE, env.wk};
+               c.command_profile == 0 ? APX_OBS_DIM : APX_OBS_DIM_PHASE, c.est_lifetime, env.wk};
 }
 
 extern "C" void apx_env_default_cfg(apx_env_cfg* c) {
     if (!c) return;
     *c = apx_env_cfg{};
     c->n_envs = 4096; c->simrate = 50; c->dynamics_randomization = 1; c->reward_kind = 0; c->stance_mode = 0;
-    c->have_incentive = 1; c->max_traj_len = 400; c->seed = 0; c->device = 0; c->pgs_iters = 50;
+    c->have_incentive = 1; c->max_traj_len = 400; c->seed = 0; c->device = 0; c->pgs_iters = 50; c->est_lifetime = 169;      /* 5096 // 30, apex.py:244-246 */
 }
 
 extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {

@@ -19,6 +19,7 @@ enum Field : int {
 enum SnapOff { SN_MPOS = 0, SN_JPOS = 10, SN_QUAT = 16, SN_GYRO = 20, SN_ACC = 23 };
 enum SoOff { SO_MPOS = 0, SO_MVEL = 10, SO_TORQUE = 20, SO_JPOS = 30, SO_JVEL = 36, SO_QUAT = 42, SO_ROTVEL = 46, SO_TVEL = 49, SO_TACC = 52, SO_HEIGHT = 55 };
 enum IField : int { I_TIME = 0, I_PHASE, I_COUNTER, I_RNG, I_FLAGS /* bit0 menc primed, 1 jenc primed, 2 prev_action, 3 prev_torque */,
+                    I_AGE /* env steps since the state estimator of this env was set up (apx_env_cfg.est_lifetime) */,
                     I_SAT /* constraint sets beyond what the kernel instantiates: bits 0-3 = SAT_* flags seen since env creation, bits 8.. = number of such forward passes */, I_TOTAL };
 // what a forward pass needed beyond the kernel's per-leg caps (same bits as oracle/cassie_phys.h SatFlag): > 2 penetrating capsule ends on a
 // leg, > 1 active joint limit on a leg, pelvis sphere / hip-pitch capsule on the floor, a left-right capsule pair in contact
@@ -47,7 +48,7 @@ typedef __attribute__((address_space(3))) int lint;
 #ifndef APX_L4_EPW
 #define APX_L4_EPW 4
 #endif
-constexpr int L4_INT = 586 /* >= F_TOTAL */, L4_WK = 592, L4_ROWS = 1664, L4_ES = 2384, L4_EPW = APX_L4_EPW;      // envs per wave (16 lanes each)
+constexpr int L4_INT = 584 /* >= F_TOTAL */, L4_WK = 592, L4_ROWS = 1664, L4_ES = 2384, L4_EPW = APX_L4_EPW;      // envs per wave (16 lanes each)
 static_assert(F_TOTAL <= L4_INT && L4_INT + I_TOTAL <= L4_WK, "LDS state region");
 // Wave-constant table behind the four env regions (one copy per single-wave workgroup, filled from HBM once per launch by ct_fill):
 // model constants that the stages index by LANE (body records, dof / actuator tables, mass-matrix index map).  Without it every such
@@ -68,7 +69,7 @@ struct St {
 // terrain of cassie_hfield.xml (util/eval.py:73-76): nrow x ncol raw elevations (rows along y, columns along x) over [-sx, sx] x [-sy, sy],
 // elevation = data * sz; data == nullptr: the floor plane of cassie.xml:73
 struct Hf { const float* data; int nrow, ncol; float sx, sy, sz; };
-struct Cfg { Hf hf; int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; int reward_kind, env_kind, command_profile, obs_dim; float* est /* state-estimator records, [n][est::REC] (estimator_lane.h) */; };
+struct Cfg { Hf hf; int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; int reward_kind, env_kind, command_profile, obs_dim, est_lifetime; float* est /* state-estimator records, [n][est::REC] (estimator_lane.h) */; };
 
 // ------------------------------------------------------------------------------------------------ Philox4x32-10
 __device__ __forceinline__ unsigned philox(unsigned k0, unsigned k1, unsigned env, unsigned ctr) {

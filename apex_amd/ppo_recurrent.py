@@ -28,8 +28,8 @@ class RecurrentPPO:
         self.save_path, self.env = save_path, env
         self.rank, self.world, self.group = rank, world_size, group
         self.device, self.N = env.device, env.n_envs
-        if env.obs_dim != 50:
-            raise NotImplementedError("recurrent PPO is built for the 50-entry observation (command_profile=clock, history 0); this env produces %d entries" % env.obs_dim)
+        if getattr(env, "obs_dim", 50) != 50:
+            raise NotImplementedError("recurrent PPO is built for the 50-entry observation (command_profile=clock, history 0); this env produces %d entries" % getattr(env, "obs_dim", 50))
         self.T = adist.rollout_len(self.num_steps, self.N, self.world)
         # every iteration restarts all envs (each trajectory must begin at an episode start with zero hidden state, like the padded
         # training pass assumes), so a grid shorter than max_traj_len would never show the policy the later part of an episode

@@ -42,8 +42,8 @@ class TD3:
     def __init__(self, env, save_path, hidden=256, a_lr=1e-3, c_lr=1e-3, discount=0.99, tau=0.005, policy_noise=0.2, noise_clip=0.5, policy_freq=2,
                  act_noise=0.3, batch_size=256, updates_per_step=1, replay_size=1_000_000, seed=0, param_noise=False, noise_scale=0.3):
         self.env, self.save_path, self.device, self.N = env, save_path, env.device, env.n_envs
-        if env.obs_dim != 50:
-            raise NotImplementedError("TD3 is built for the 50-entry observation (command_profile=clock, history 0); this env produces %d entries" % env.obs_dim)
+        if getattr(env, "obs_dim", 50) != 50:
+            raise NotImplementedError("TD3 is built for the 50-entry observation (command_profile=clock, history 0); this env produces %d entries" % getattr(env, "obs_dim", 50))
         self.learner = engine.TD3Learner(50, 10, hidden, self.device, 1.0, a_lr, c_lr)
         self.replay = HbmReplay(replay_size, 50, 10, self.device)
         self.discount, self.tau, self.policy_noise, self.noise_clip, self.policy_freq = discount, tau, policy_noise, noise_clip, policy_freq

@@ -60,7 +60,7 @@ class CassieVecEnv:
 
     def __init__(self, n_envs=4096, simrate=50, dynamics_randomization=True, reward="clock", max_traj_len=400, seed=0,
                  device=0, pgs_iters=50, env_id_base=0, command_profile="clock", input_profile="full", history=0, learn_gains=False,
-                 env_name="Cassie-v0", traj="walking", no_delta=True, ik_baseline=False):
+                 env_name="Cassie-v0", traj="walking", no_delta=True, ik_baseline=False, est_lifetime=169):
         if command_profile not in ("clock", "phase") or input_profile != "full" or learn_gains or history < 0:
             raise NotImplementedError("command_profile clock / phase with input_profile=full are built (traj / min / learn_gains are not)")
         if command_profile == "phase" and env_name != "Cassie-v0":
@@ -91,6 +91,7 @@ class CassieVecEnv:
         cfg.reward_kind, cfg.stance_mode, cfg.have_incentive = r["reward_kind"], r["stance_mode"], r["have_incentive"]
         cfg.max_traj_len, cfg.seed, cfg.device, cfg.pgs_iters = max_traj_len, seed, device, pgs_iters
         cfg.env_id_base = env_id_base
+        cfg.est_lifetime = int(est_lifetime)      # env steps served by one estimator object (one PPO.sample call of the reference builds one CassieEnv); 0 = never restarted
         cfg.env_kind = 1 if env_name == "CassieTraj-v0" else 0
         self.device = torch.device("cuda", device)
         torch.cuda.set_device(self.device)
@@ -253,7 +254,7 @@ class CassieVecEnv:
         """(flags [N] int64, passes [N] int64): SAT_* bits (1 = more than 2 penetrating capsule ends on a leg, 2 = more than 1 active joint
         limit on a leg, 4 = pelvis sphere / hip-pitch capsule on the floor, 8 = a left-right capsule pair in contact) a forward pass of the
         env has needed beyond the constraint rows the kernel instantiates since the env was created, and how many such passes there were."""
-        sat = self.get_field("ints_bits").view(torch.int32)[:, 5].to(torch.int64)      # bit-exact integer words (the float view of "ints" rounds above 2^24)
+        sat = self.get_field("ints_bits").view(torch.int32)[:, 6].to(torch.int64)      # bit-exact integer words (the float view of "ints" rounds above 2^24)
         return sat & 0xFF, sat >> 8
 
     def substep(self):

@@ -184,7 +184,11 @@ typedef struct apx_env_cfg {
     int command_profile;        /* 0 clock (obs 50: ..., sin, cos, speed, side speed), 1 phase (cassie.py:266-271,529-545,805-808: swing / stance
                                  * duration and the stance mode are drawn per reset, obs 55: ..., sin, cos, swing, stance, one-hot stance mode,
                                  * speed, side speed), 2 phase with the "library" draws (:531-539) */
-    int reserved[4];
+    int est_lifetime;           /* env steps after which the next CassieEnv.reset also restarts the state estimator (state_output_setup), 0 = never.  The reference
+                                 * builds a NEW CassieEnv -> cassie_sim_init -> estimator per PPO.sample call (rl/algos/ppo.py:152), i.e. an estimator object serves
+                                 * num_steps // num_procs env steps (apex.py:244-246 defaults: 5096 // 30 = 169) and then the episodes of the next call start
+                                 * from a fresh one; a lock-step env lives for the whole training run, so the lifetime is carried per env instead */
+    int reserved[3];
 } apx_env_cfg;
 
 void apx_env_default_cfg(apx_env_cfg* cfg);

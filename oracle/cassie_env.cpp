@@ -325,7 +325,7 @@ void env_reset_for_test(Env& e, double* obs, bool full_reset) {
         e.so_quat[0] = 1; e.so_quat[1] = e.so_quat[2] = e.so_quat[3] = 0;
         for (int k = 0; k < 3; ++k) e.so_rotvel[k] = e.so_tvel[k] = e.so_tacc[k] = 0;
         e.so_height = 1.01;
-        state_output_setup(e.est);
+        state_output_setup(e.est); e.est_age = 0;
     }
     if (e.cfg.dynamics_randomization) {
         const int iters = e.par.pgs_iters;
@@ -360,6 +360,9 @@ void traj_ref_state(double phase, double phaselen, double speed, int counter, do
 // CassieEnv.reset, cassie.py:523-680 (env_kind 1: CassieTrajEnv.reset, cassie_traj.py:599-778)
 void env_reset(Env& e, double* obs) {
     static thread_local Work w;
+    // the reference builds a new CassieEnv (-> cassie_sim_init -> a new estimator) per PPO.sample call (rl/algos/ppo.py:152); a lock-step env outlives
+    // the call, so the estimator's lifetime is carried: after est_lifetime env steps the next reset starts from state_output_setup
+    if (e.cfg.est_lifetime > 0 && e.est_age >= e.cfg.est_lifetime) { state_output_setup(e.est); e.est_age = 0; }
     Philox& r = e.rng;
     e.speed = e.cfg.env_kind == 1 ? (double)r.randint(41) / 10 : r.uniform(-0.3, 4.0);      // cassie_traj.py:608: random.randint(0, 40) / 10
     e.side_speed = r.uniform(-0.3, 0.3);
@@ -520,7 +523,7 @@ int env_step(Env& e, const double* action, double* obs, double* reward) {
     const double inv = 1.0 / e.cfg.simrate;
     e.l_foot_frc *= inv; e.r_foot_frc *= inv; e.l_foot_orient_cost *= inv; e.r_foot_orient_cost *= inv;
     const double height = e.st.qpos[2];
-    e.time += 1; e.phase += 1;
+    e.time += 1; e.phase += 1; e.est_age += 1;
     if (e.phase > e.clock.phaselen) { e.phase = 0; e.counter += 1; }
     int done = (height < 0.4 || height > 3.0 || !(height == height)) ? 1 : 0;
     if (!e.has_prev_action) { for (int u = 0; u < 10; ++u) e.prev_action[u] = action[u]; e.has_prev_action = 1; }

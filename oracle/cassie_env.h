@@ -30,6 +30,7 @@ struct EnvCfg {
     int pgs_iters = 50;
     uint64_t seed = 0;
     int command_profile = 0;  // 0 clock (obs 50), 1 phase (cassie.py:266-271,529-545,805-808: obs 55), 2 phase with the "library" draws (:531-539)
+    int est_lifetime = 169;   // env steps after which the next reset also restarts the estimator (one PPO.sample call of the reference builds one CassieEnv: ppo.py:152; 5096 // 30, apex.py:244-246); 0 = never
     int env_kind = 0;         // 0 Cassie-v0 (cassie/cassie.py), 1 CassieTraj-v0 with the CLI defaults (cassie/cassie_traj.py: trajectory-pose reset)
 };
 
@@ -48,6 +49,7 @@ struct Env {
     Philox rng;
     // episode / command state (cassie.py:71-78,117-119)
     int time, phase, counter;
+    int est_age;               // env steps since the estimator object was set up
     double speed, side_speed, orient_add;
     Clock clock;
     double swing_duration, stance_duration;     // of the current clock (observed by the phase command profile)

@@ -75,7 +75,7 @@ def _ptr(a):
 
 class OracleEnv:
     def __init__(self, simrate=50, dyn_rand=True, reward_kind=0, stance_mode=0, incentive=True, max_traj_len=400,
-                 pgs_iters=50, seed=0, env_id=0, env_kind=0, command_profile=0):
+                 pgs_iters=50, seed=0, env_id=0, env_kind=0, command_profile=0, est_lifetime=169):
         self.h = lib().orc_env_new(simrate, int(dyn_rand), reward_kind, stance_mode, int(incentive), max_traj_len,
                                    pgs_iters, seed, env_id)
         self.obs_dim = 50 if command_profile == 0 else 55
@@ -83,6 +83,8 @@ class OracleEnv:
             lib().orc_env_set_kind(self.h, int(env_kind))
         if command_profile:      # 1 phase, 2 phase with the "library" draws
             lib().orc_env_set_command_profile(self.h, int(command_profile))
+        if est_lifetime != 169:
+            self.set("est_age", [0, est_lifetime])
 
     def __del__(self):
         try:

@@ -69,4 +69,5 @@ def oracle_to_kernel(genv, oenvs, model_params=True):
         oi = e.get("ints"); pr = e.get("enc_primed")
         ints[i, 0:3] = oi[0:3]; ints[i, 3] = oi[5]
         ints[i, 4] = int(pr[0]) | int(pr[1]) << 1 | int(oi[6]) << 2 | int(oi[7]) << 3 | 16
+        ints[i, 5] = int(e.get("est_age")[0])
     genv.set_field("ints", T(ints))
