@@ -932,6 +932,17 @@ extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, voi
         return 48;
     }
 #endif
+#ifdef APX_CHECK
+    if (!strcmp(name, "oob")) {       // first out-of-range S / S.W / S.I index of the checked build: kind (1 state, 2 workspace, 3 int), index, env, lane; then cleared
+        int h[4];
+        APX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_oob), sizeof(h)));
+        float hf[4] = {(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        APX_HIP(hipMemcpy(out, hf, sizeof(hf), hipMemcpyHostToDevice));
+        const int z[4] = {0, 0, 0, 0};
+        APX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_oob), z, sizeof(z)));
+        return 4;
+    }
+#endif
     if (!strcmp(name, "substep")) {   // debugging hook: out[0] (host-readable count is not needed) - run one raw substep
         if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_substep_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), 1,
                            (const float*)nullptr, (float*)nullptr);

@@ -59,11 +59,23 @@ static_assert(CT_TOTAL == 676 && (L4_EPW * L4_ES) % 4 == 0, "wave-constant table
 extern __shared__ __attribute__((aligned(16))) float4 apx_lds4[];   // dynamic LDS: [env regions | wave-constant table]
 __device__ __forceinline__ float ctf(int i) { return ((const lfloat*)apx_lds4)[L4_EPW * L4_ES + i]; }
 __device__ __forceinline__ int cti(int i) { return ((const lint*)apx_lds4)[L4_EPW * L4_ES + i]; }
+#ifdef APX_CHECK
+// `make VARIANT=check EXTRA=-DAPX_CHECK`: every S(f) / S.W(i) / S.I(f) index is range-checked; the first violation is recorded (kind, index, env, lane) in
+// g_oob and the access is redirected to word 0 of its region, so the run continues and apx_env_get_field("oob") reports it (tests/test_gpu_env.py)
+__device__ int g_oob[4] = {0, 0, 0, 0};
+__device__ __forceinline__ int apx_chk(int idx, int lo, int hi, int kind, int env) {
+    if (idx < lo || idx >= hi) { if (atomicCAS(&g_oob[0], 0, kind) == 0) { g_oob[1] = idx; g_oob[2] = env; g_oob[3] = (int)threadIdx.x; } return lo; }
+    return idx;
+}
+#define APX_CHK(idx, lo, hi, kind) apx_chk(idx, lo, hi, kind, env)
+#else
+#define APX_CHK(idx, lo, hi, kind) (idx)
+#endif
 struct St {
     lfloat* p; int env;
-    __device__ __forceinline__ lfloat& operator()(int f) const { return p[f]; }
-    __device__ __forceinline__ lfloat& W(int i) const { return p[L4_WK + i]; }
-    __device__ __forceinline__ lint& I(int f) const { return ((lint*)p)[L4_INT + f]; }
+    __device__ __forceinline__ lfloat& operator()(int f) const { return p[APX_CHK(f, 0, L4_INT, 1)]; }
+    __device__ __forceinline__ lfloat& W(int i) const { return p[L4_WK + APX_CHK(i, 0, L4_ROWS - L4_WK, 2)]; }
+    __device__ __forceinline__ lint& I(int f) const { return ((lint*)p)[L4_INT + APX_CHK(f, 0, L4_WK - L4_INT, 3)]; }
 };
 
 // terrain of cassie_hfield.xml (util/eval.py:73-76): nrow x ncol raw elevations (rows along y, columns along x) over [-sx, sx] x [-sy, sy],

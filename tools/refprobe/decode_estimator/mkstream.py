@@ -3,7 +3,7 @@ import numpy as np, torch
 sys.path.insert(0, "/root/repo/tools/refprobe"); sys.path.insert(0, "/root/repo")
 from native_blocks import cm, make_out, DRIVES, JOINTS
 from oracle.sim import OracleEnv
-policy = torch.load("/root/repo/trained_models/r02_cassie_v0_clock/actor.pt", weights_only=False); policy.eval()
+policy = torch.load("/root/repo/trained_models/r03_cassie_v0_clock/actor.pt", weights_only=False); policy.eval()
 est = cm.state_output_alloc(); cm.state_output_setup(est)
 def dump(est):
     p = ctypes.cast(est, ctypes.POINTER(ctypes.c_double))

@@ -13,7 +13,7 @@ from native_blocks import cm, make_out, DRIVES, JOINTS
 from oracle.sim import OracleEnv
 from common import GOLD
 
-run_dir = sys.argv[1] if len(sys.argv) > 1 else "/root/repo/trained_models/r02_cassie_v0_clock"
+run_dir = sys.argv[1] if len(sys.argv) > 1 else "/root/repo/trained_models/r03_cassie_v0_clock"
 policy = torch.load(os.path.join(run_dir, "actor.pt"), weights_only=False); policy.eval()
 lib = cm._libraries["./libcassiemujoco.so"]
 base = ctypes.cast(lib.state_output_step, ctypes.c_void_p).value - 0x296b0      # load address of the library (state_output_step sits at 0x296b0)
