@@ -33,7 +33,7 @@ class EnvCfg(C.Structure):
     _fields_ = [
         ("n_envs", C.c_int), ("simrate", C.c_int), ("dynamics_randomization", C.c_int), ("reward_kind", C.c_int),
         ("stance_mode", C.c_int), ("have_incentive", C.c_int), ("max_traj_len", C.c_int),
-        ("seed", C.c_uint64), ("device", C.c_int), ("pgs_iters", C.c_int), ("env_id_base", C.c_int), ("env_kind", C.c_int), ("command_profile", C.c_int), ("est_lifetime", C.c_int), ("reserved", C.c_int * 3),
+        ("seed", C.c_uint64), ("device", C.c_int), ("pgs_iters", C.c_int), ("env_id_base", C.c_int), ("env_kind", C.c_int), ("command_profile", C.c_int), ("est_lifetime", C.c_int), ("input_profile", C.c_int), ("reserved", C.c_int * 2),
     ]
 
 

@@ -258,34 +258,45 @@ __device__ __forceinline__ void yaw_inv_rotate3(float yaw, const float* v, float
 // get_full_state (cassie/cassie.py:787-859), written straight to obs[env*50 ..]
 __device__ void write_obs(const St& S, const Cfg& cfg, float* o) {
     const float yaw = S(F_CMD + 2);
-    o[0] = S(F_SO + SO_HEIGHT);
+    Q4 nq;
     {
         float sz, cz;
         sincosf(0.5f * yaw, &sz, &cz);
         Q4 q = {cz, 0.f, 0.f, sz};
         if (q.w < 0.f) q = {-q.w, 0.f, 0.f, -q.z};
-        Q4 r = qmul(Q4{q.w, 0.f, 0.f, -q.z}, Q4{S(F_SO + SO_QUAT), S(F_SO + SO_QUAT + 1), S(F_SO + SO_QUAT + 2), S(F_SO + SO_QUAT + 3)});
-        if (r.w < 0.f) r = {-r.w, -r.x, -r.y, -r.z};
-        o[1] = r.w; o[2] = r.x; o[3] = r.y; o[4] = r.z;
+        nq = qmul(Q4{q.w, 0.f, 0.f, -q.z}, Q4{S(F_SO + SO_QUAT), S(F_SO + SO_QUAT + 1), S(F_SO + SO_QUAT + 2), S(F_SO + SO_QUAT + 3)});
+        if (nq.w < 0.f) nq = {-nq.w, -nq.x, -nq.y, -nq.z};
     }
-    for (int u = 0; u < 10; ++u) o[5 + u] = S(F_SO + SO_MPOS + u) + S(F_MNOISE + u);
-    float v[3];
-    for (int k = 0; k < 3; ++k) v[k] = S(F_SO + SO_TVEL + k);
-    yaw_inv_rotate3(yaw, v, o + 15);
-    for (int k = 0; k < 3; ++k) o[18 + k] = S(F_SO + SO_ROTVEL + k);
-    for (int u = 0; u < 10; ++u) o[21 + u] = S(F_SO + SO_MVEL + u);
-    for (int k = 0; k < 3; ++k) v[k] = S(F_SO + SO_TACC + k);
-    yaw_inv_rotate3(yaw, v, o + 31);
-    for (int k = 0; k < 6; ++k) o[34 + k] = S(F_SO + SO_JPOS + k) + S(F_JNOISE + k);
-    for (int k = 0; k < 6; ++k) o[40 + k] = S(F_SO + SO_JVEL + k);
+    int n;
+    if (cfg.input_profile == 1) {      // input_profile "min" (cassie.py:829-837): the estimator's foot positions / orientations from its record (estimator_lane.h, lane 6)
+        const float* r = cfg.est + (size_t)S.env * est::REC + 24 * 6 + 4;
+        for (int k = 0; k < 3; ++k) { o[k] = r[k]; o[3 + k] = r[4 + k]; o[10 + k] = S(F_SO + SO_ROTVEL + k); }
+        o[6] = nq.w; o[7] = nq.x; o[8] = nq.y; o[9] = nq.z;
+        for (int k = 0; k < 4; ++k) { o[13 + k] = r[8 + k]; o[17 + k] = r[12 + k]; }
+        n = APX_OBS_MIN;
+    } else {
+        o[0] = S(F_SO + SO_HEIGHT);
+        o[1] = nq.w; o[2] = nq.x; o[3] = nq.y; o[4] = nq.z;
+        for (int u = 0; u < 10; ++u) o[5 + u] = S(F_SO + SO_MPOS + u) + S(F_MNOISE + u);
+        float v[3];
+        for (int k = 0; k < 3; ++k) v[k] = S(F_SO + SO_TVEL + k);
+        yaw_inv_rotate3(yaw, v, o + 15);
+        for (int k = 0; k < 3; ++k) o[18 + k] = S(F_SO + SO_ROTVEL + k);
+        for (int u = 0; u < 10; ++u) o[21 + u] = S(F_SO + SO_MVEL + u);
+        for (int k = 0; k < 3; ++k) v[k] = S(F_SO + SO_TACC + k);
+        yaw_inv_rotate3(yaw, v, o + 31);
+        for (int k = 0; k < 6; ++k) o[34 + k] = S(F_SO + SO_JPOS + k) + S(F_JNOISE + k);
+        for (int k = 0; k < 6; ++k) o[40 + k] = S(F_SO + SO_JVEL + k);
+        n = 46;
+    }
     const float ang = 2.f * PI_F * (float)S.I(I_PHASE) / S(F_CMD + 5);
-    o[46] = sinf(ang); o[47] = cosf(ang);
-    if (cfg.command_profile == 0) { o[48] = S(F_CMD + 0); o[49] = S(F_CMD + 1); return; }
+    o[n] = sinf(ang); o[n + 1] = cosf(ang);
+    if (cfg.command_profile == 0) { o[n + 2] = S(F_CMD + 0); o[n + 3] = S(F_CMD + 1); return; }
     // command_profile "phase" (cassie.py:805-808): clock, swing / stance duration, one-hot stance mode (grounded, aerial, zero), speed, side speed
     const int sm = (int)S(F_CMD + 6);
-    o[48] = S(F_CMD + 3); o[49] = S(F_CMD + 4);
-    o[50] = sm == 1 ? 1.f : 0.f; o[51] = sm == 2 ? 1.f : 0.f; o[52] = sm == 0 ? 1.f : 0.f;
-    o[53] = S(F_CMD + 0); o[54] = S(F_CMD + 1);
+    o[n + 2] = S(F_CMD + 3); o[n + 3] = S(F_CMD + 4);
+    o[n + 4] = sm == 1 ? 1.f : 0.f; o[n + 5] = sm == 2 ? 1.f : 0.f; o[n + 6] = sm == 0 ? 1.f : 0.f;
+    o[n + 7] = S(F_CMD + 0); o[n + 8] = S(F_CMD + 1);
 }
 
 __device__ __forceinline__ void clock_from_speed(const St& S, float speed, int freq) {   // cassie.py:556-559
@@ -674,7 +685,7 @@ static Cfg make_cfg(const apx_env& env) {
     const apx_env_cfg& c = env.cfg;
     return Cfg{Hf{env.hf, env.hf_nrow, env.hf_ncol, env.hf_size[0], env.hf_size[1], env.hf_size[2]}, c.simrate, c.dynamics_randomization, c.stance_mode, c.have_incentive, c.max_traj_len, c.pgs_iters,
                (unsigned)c.seed, (unsigned)(c.seed >> 32), (unsigned)c.env_id_base, c.reward_kind, c.env_kind, c.command_profile,
-               c.command_profile == 0 ? APX_OBS_DIM : APX_OBS_DIM_PHASE, c.est_lifetime, env.wk};
+               (c.input_profile ? APX_OBS_MIN : 46) + (c.command_profile == 0 ? 4 : 9), c.est_lifetime, c.input_profile, env.wk};
 }
 
 extern "C" void apx_env_default_cfg(apx_env_cfg* c) {
@@ -691,6 +702,7 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     APX_REQUIRE(cfg->env_kind == 0 || (cfg->env_kind == 1 && cfg->simrate == 50), "env_kind: 0 Cassie-v0, 1 CassieTraj-v0 (walking trajectory table is for simrate 50)");
     APX_REQUIRE(cfg->reward_kind >= 0 && cfg->reward_kind <= 2, "reward_kind: 0 clock_reward, 1 early_clock_reward, 2 max_vel_clock_reward");
     APX_REQUIRE(cfg->pgs_iters > 0 && cfg->max_traj_len > 0, "pgs_iters / max_traj_len");
+    APX_REQUIRE(cfg->input_profile == 0 || cfg->input_profile == 1, "input_profile: 0 full, 1 min");
     APX_REQUIRE(cfg->command_profile >= 0 && cfg->command_profile <= 2 && (cfg->command_profile == 0 || cfg->env_kind == 0), "command_profile: 0 clock, 1 phase, 2 phase (library draws); phase needs Cassie-v0");
     APX_HIP(hipSetDevice(cfg->device));
     apx_env* e = new (std::nothrow) apx_env;
@@ -849,7 +861,7 @@ __global__ void act_noise_kernel(const float* __restrict__ mu, const float* __re
 extern "C" int apx_rollout(apx_env_t* e, const float* actor, int H, const float* obs_mean, const float* obs_std, float sigma, const float* noise, int T,
                            float* obs_grid, float* act_grid, float* mu_grid, float* rew_grid, uint8_t* done_grid, float* fin_grid, float* obs_next, void* stream) {
     APX_REQUIRE(e && actor && obs_grid && act_grid && mu_grid && rew_grid && done_grid && fin_grid && obs_next && T > 0, "rollout arguments");
-    const int D = e->cfg.command_profile == 0 ? APX_OBS_DIM : APX_OBS_DIM_PHASE, A = APX_ACT_DIM;
+    const int D = make_cfg(*e).obs_dim, A = APX_ACT_DIM;
     const long N = e->n;
     for (int t = 0; t < T; ++t) {
         float* obs = obs_grid + (size_t)t * N * D; float* mu = mu_grid + (size_t)t * N * A; float* act = act_grid + (size_t)t * N * A;

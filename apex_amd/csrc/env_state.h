@@ -81,7 +81,7 @@ struct St {
 // terrain of cassie_hfield.xml (util/eval.py:73-76): nrow x ncol raw elevations (rows along y, columns along x) over [-sx, sx] x [-sy, sy],
 // elevation = data * sz; data == nullptr: the floor plane of cassie.xml:73
 struct Hf { const float* data; int nrow, ncol; float sx, sy, sz; };
-struct Cfg { Hf hf; int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; int reward_kind, env_kind, command_profile, obs_dim, est_lifetime; float* est /* state-estimator records, [n][est::REC] (estimator_lane.h) */; };
+struct Cfg { Hf hf; int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; int reward_kind, env_kind, command_profile, obs_dim, est_lifetime, input_profile; float* est /* state-estimator records, [n][est::REC] (estimator_lane.h) */; };
 
 // ------------------------------------------------------------------------------------------------ Philox4x32-10
 __device__ __forceinline__ unsigned philox(unsigned k0, unsigned k1, unsigned env, unsigned ctr) {

@@ -23,7 +23,7 @@ namespace est {
 using c4::V3; using c4::Q4; using c4::dpp; using c4::sfor; using c4::rcpf;
 
 constexpr int REC = 168;                       // floats per env: lane r < 7 owns [24 r, 24 r + 24)
-// lanes 0..5: Px[6] Py[6] Pz[6] xX xY xZ pad3;  lane 6: heelL heelR terrain inited pad20
+// lanes 0..5: Px[6] Py[6] Pz[6] xX xY xZ pad3;  lane 6: heelL heelR terrain inited | L foot pos3 pad | R foot pos3 pad | L foot quat4 | R foot quat4 | pad4
 constexpr float E_DT = 0.0005f, E_G = 9.806f, E_M = 31.f, E_W2 = 9.806f /* g / pendulum height 1.0 */;
 constexpr float K_SHIN = 1500.f, K_HEEL = 1250.f;
 constexpr float HEEL_LIM = 0.78539816f - 1e-6f;
@@ -246,7 +246,14 @@ __device__ __forceinline__ void est_step_lane(const St& S, Rec& rec) {
     }
     sfor<0, 6>([&](auto B) { constexpr int b = B; rec.v[b / 4][b % 4] = fx.P[b]; rec.v[(6 + b) / 4][(6 + b) % 4] = fy.P[b]; rec.v[(12 + b) / 4][(12 + b) % 4] = fz.P[b]; });
     rec.v[4][2] = fx.x; rec.v[4][3] = fy.x; rec.v[5][0] = fz.x;
-    if (l == 6) { rec.v[0][0] = heel[0]; rec.v[0][1] = heel[1]; rec.v[0][2] = terr; rec.v[0][3] = 1.f; }
+    // leftFoot / rightFoot .position and .orientation (input_profile "min", cassie.py:829-837): foot body frame times the routine's constant frame offset
+    Q4 fq = c4::qmul(q, Q4{0.24184476264797528f, -0.24184476264797528f, -0.66446302438867138f, 0.66446302438867138f});
+    if (fq.w < 0.f) fq = {-fq.w, -fq.x, -fq.y, -fq.z};
+    const float rpx = bc<14>(pf.x), rpy = bc<14>(pf.y), rpz = bc<14>(pf.z), rqw = bc<14>(fq.w), rqx = bc<14>(fq.x), rqy = bc<14>(fq.y), rqz = bc<14>(fq.z);
+    if (l == 6) {
+        rec.v[0][0] = heel[0]; rec.v[0][1] = heel[1]; rec.v[0][2] = terr; rec.v[0][3] = 1.f;
+        rec.v[1] = f4{pf.x, pf.y, pf.z, 0.f}; rec.v[2] = f4{rpx, rpy, rpz, 0.f}; rec.v[3] = f4{fq.w, fq.x, fq.y, fq.z}; rec.v[4] = f4{rqw, rqx, rqy, rqz};
+    }
 }
 
 }  // namespace est

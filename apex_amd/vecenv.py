@@ -25,6 +25,16 @@ OBS_DIM_PHASE = 55
 # command_profile "phase" (cassie/cassie.py:266-271): the 46 base entries, then clock (2), swing / stance duration + one-hot stance mode (5),
 # speed / side speed (2) mirror onto themselves
 MIRRORED_OBS_PHASE = MIRRORED_OBS[:46] + list(range(46, 55))
+# input_profile "min" (cassie/cassie.py:246-256): L / R foot position, pelvis quaternion, pelvis rotational velocity, L / R foot quaternion
+MIRRORED_OBS_MIN = [3, 4, 5, 0.1, 1, 2, 6, -7, 8, -9, -10, 11, -12, 17, -18, 19, -20, 13, -14, 15, -16]
+OBS_DIM_MIN = 21
+
+
+def mirrored_obs_for(command_profile, input_profile):
+    """CassieEnv.set_up_state_space (cassie/cassie.py:234-278): the mirror index list of one observation frame"""
+    base = MIRRORED_OBS[:46] if input_profile == "full" else MIRRORED_OBS_MIN
+    n_ext = 4 if command_profile == "clock" else 9
+    return list(base) + [len(base) + i for i in range(n_ext)]
 
 
 def parse_phase_reward(reward):
@@ -61,8 +71,8 @@ class CassieVecEnv:
     def __init__(self, n_envs=4096, simrate=50, dynamics_randomization=True, reward="clock", max_traj_len=400, seed=0,
                  device=0, pgs_iters=50, env_id_base=0, command_profile="clock", input_profile="full", history=0, learn_gains=False,
                  env_name="Cassie-v0", traj="walking", no_delta=True, ik_baseline=False, est_lifetime=169):
-        if command_profile not in ("clock", "phase") or input_profile != "full" or learn_gains or history < 0:
-            raise NotImplementedError("command_profile clock / phase with input_profile=full are built (traj / min / learn_gains are not)")
+        if command_profile not in ("clock", "phase") or input_profile not in ("full", "min") or learn_gains or history < 0:
+            raise NotImplementedError("command_profile clock / phase with input_profile full / min are built (the traj command profile and learn_gains are not)")
         if command_profile == "phase" and env_name != "Cassie-v0":
             raise NotImplementedError("command_profile=phase is built for Cassie-v0")
         # util/env.py:22-32: Cassie-v0 -> CassieEnv; CassieTraj-v0 -> CassieTrajEnv, which with the CLI defaults (traj=walking,
@@ -80,13 +90,15 @@ class CassieVecEnv:
         r = parse_reward(reward) if command_profile == "clock" else parse_phase_reward(reward)
         cfg.command_profile = 0 if command_profile == "clock" else (2 if r["library"] else 1)
         self.command_profile = command_profile
-        self.frame_dim = OBS_DIM if command_profile == "clock" else OBS_DIM_PHASE
+        cfg.input_profile = 0 if input_profile == "full" else 1
+        self.input_profile = input_profile
+        self.frame_dim = (46 if input_profile == "full" else OBS_DIM_MIN) + (4 if command_profile == "clock" else 9)
+        self.clock_inds = [self.frame_dim - (4 if command_profile == "clock" else 9) + i for i in range(2)]
         # --history h (cassie.py:51-55,565,856-859): the observation is the newest frame followed by the h previous ones of the episode (zeros
         # before its start); the kernel writes frames, the stack is kept here.  The reference's mirror lists cover one frame only.
         self.history = int(history)
         self.obs_dim = self.frame_dim * (self.history + 1)
-        if command_profile == "phase":
-            self.mirrored_obs = MIRRORED_OBS_PHASE
+        self.mirrored_obs = mirrored_obs_for(command_profile, input_profile)
         cfg.n_envs, cfg.simrate, cfg.dynamics_randomization = n_envs, simrate, int(dynamics_randomization)
         cfg.reward_kind, cfg.stance_mode, cfg.have_incentive = r["reward_kind"], r["stance_mode"], r["have_incentive"]
         cfg.max_traj_len, cfg.seed, cfg.device, cfg.pgs_iters = max_traj_len, seed, device, pgs_iters

@@ -26,6 +26,7 @@ extern "C" {
 
 #define APX_OBS_DIM 50   /* cassie/cassie.py:236-265  (46 estimator + 2 clock + 2 speed), command_profile clock */
 #define APX_OBS_DIM_PHASE 55   /* + swing, stance, one-hot stance mode (cassie.py:266-271) */
+#define APX_OBS_MIN 21         /* estimator entries of input_profile min (cassie.py:237,246-256): obs = 21 + 4 (clock) or 21 + 9 (phase) */
 #define APX_ACT_DIM 10   /* cassie/cassie.py:68 */
 #define APX_NQ 35        /* cassie/cassiemujoco/cassiemujoco.py:36-39 */
 #define APX_NV 32
@@ -188,7 +189,9 @@ typedef struct apx_env_cfg {
                                  * builds a NEW CassieEnv -> cassie_sim_init -> estimator per PPO.sample call (rl/algos/ppo.py:152), i.e. an estimator object serves
                                  * num_steps // num_procs env steps (apex.py:244-246 defaults: 5096 // 30 = 169) and then the episodes of the next call start
                                  * from a fresh one; a lock-step env lives for the whole training run, so the lifetime is carried per env instead */
-    int reserved[3];
+    int input_profile;          /* 0 full: the 46 joint-level estimator entries (cassie.py:244,839-850); 1 min: 21 entries = leftFoot / rightFoot .position, pelvis
+                                 * orientation, rotational velocity, leftFoot / rightFoot .orientation of state_out_t (cassie.py:246-256,829-837) */
+    int reserved[2];
 } apx_env_cfg;
 
 void apx_env_default_cfg(apx_env_cfg* cfg);

@@ -25,6 +25,7 @@ void orc_env_reset(void* h, double* obs) { env_reset(*(Env*)h, obs); }
 int orc_env_step(void* h, const double* action, double* obs, double* reward) { return env_step(*(Env*)h, action, obs, reward); }
 void orc_env_substep(void* h) { sim_step_pd(*(Env*)h); }
 void orc_env_step_basic(void* h, const double* action, double* obs) { env_step_basic(*(Env*)h, action, obs); }
+void orc_env_set_input_profile(void* h, int ip) { ((Env*)h)->cfg.input_profile = ip; }     // 1 = min (cassie.py:829-837)
 void orc_env_set_command_profile(void* h, int cp) { ((Env*)h)->cfg.command_profile = cp; }     // 1 / 2 = phase (obs 55)
 void orc_env_set_kind(void* h, int kind) { ((Env*)h)->cfg.env_kind = kind; }     // 1 = CassieTraj-v0 (trajectory-pose reset)
 void orc_traj_ref_state(double phase, double phaselen, double speed, int counter, double* qpos, double* qvel) { traj_ref_state(phase, phaselen, speed, counter, qpos, qvel); }
@@ -73,7 +74,7 @@ static int field(Env& e, const char* name, double* io, bool set) {
     FIELD("so_mpos", e.so_mpos, 10) FIELD("so_mvel", e.so_mvel, 10) FIELD("so_torque", e.so_torque, 10)
     FIELD("so_jpos", e.so_jpos, 6) FIELD("so_jvel", e.so_jvel, 6) FIELD("so_quat", e.so_quat, 4)
     FIELD("so_rotvel", e.so_rotvel, 3) FIELD("so_tvel", e.so_tvel, 3) FIELD("so_tacc", e.so_tacc, 3) FIELD("so_height", &e.so_height, 1) FIELD("est_heel", e.est.heel, 2) FIELD("est_hx", e.est.hx, 12) FIELD("est_hP", e.est.hP, 72) FIELD("est_zx", e.est.zx, 5) FIELD("est_zP", e.est.zP, 25)
-    FIELD("est_terrain", &e.est.terrain, 1) FIELD("est_pos", e.est.pos, 3) FIELD("est_vel", e.est.vel, 3) FIELD("est_foot_rel", e.est.foot_rel, 6) FIELD("est_foot_force", e.est.foot_force, 6)
+    FIELD("est_terrain", &e.est.terrain, 1) FIELD("est_pos", e.est.pos, 3) FIELD("est_vel", e.est.vel, 3) FIELD("est_foot_rel", e.est.foot_rel, 6) FIELD("est_foot_force", e.est.foot_force, 6) FIELD("est_foot_quat", e.est.foot_quat, 8)
     FIELD("snap_acc", e.snap_acc, 3) FIELD("snap_gyro", e.snap_gyro, 3) FIELD("snap_quat", e.snap_quat, 4)
     FIELD("snap_mpos", e.snap_mpos, 10) FIELD("snap_jpos", e.snap_jpos, 6)
     FIELD("l_foot_vel", e.l_foot_vel, 3) FIELD("r_foot_vel", e.r_foot_vel, 3)
@@ -106,7 +107,7 @@ int orc_env_set(void* h, const char* name, const double* in) { return field(*(En
 void* orc_est_create() { StateOutput* s = new StateOutput; state_output_setup(*s); return s; }
 void orc_est_destroy(void* h) { delete (StateOutput*)h; }
 void orc_est_setup(void* h) { state_output_setup(*(StateOutput*)h); }
-// in: mpos10 jpos6 quat4 gyro3 acc3 (26 doubles); out: pos3 vel3 tacc3 terrain foot_rel6 foot_force6 heel2 lm_iters (25 doubles)
+// in: mpos10 jpos6 quat4 gyro3 acc3 (26 doubles); out: pos3 vel3 tacc3 terrain foot_rel6 foot_force6 heel2 lm_iters foot_quat8 (33 doubles)
 void orc_est_step(void* h, const double* in, double* out) {
     StateOutput& s = *(StateOutput*)h;
     EstSensors x;
@@ -115,7 +116,7 @@ void orc_est_step(void* h, const double* in, double* out) {
     state_output_step(s, x);
     std::memcpy(out, s.pos, sizeof(double) * 3); std::memcpy(out + 3, s.vel, sizeof(double) * 3); std::memcpy(out + 6, s.tacc, sizeof(double) * 3);
     out[9] = s.terrain; std::memcpy(out + 10, s.foot_rel, sizeof(double) * 6); std::memcpy(out + 16, s.foot_force, sizeof(double) * 6);
-    out[22] = s.heel[0]; out[23] = s.heel[1]; out[24] = s.lm_iters;
+    out[22] = s.heel[0]; out[23] = s.heel[1]; out[24] = s.lm_iters; std::memcpy(out + 25, s.foot_quat, sizeof(double) * 8);
 }
 double orc_est_heel_residual(double knee, double shin, double tarsus, double heel, double* grad4) { return heel_residual(knee, shin, tarsus, heel, grad4); }
 void orc_est_mldivide23(const double* M6 /* row-major 2 x 3 */, const double* tau, double* x) { const double M[2][3] = {{M6[0], M6[1], M6[2]}, {M6[3], M6[4], M6[5]}}; mldivide23(M, tau, x); }

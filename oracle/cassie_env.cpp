@@ -230,22 +230,31 @@ static void quat_yaw_inverse_apply(double yaw, const double* v, int n, double* o
 
 // get_full_state, cassie.py:787-859 (input_profile full, command_profile clock)
 void env_obs(const Env& e, double* o) {
-    o[0] = e.so_height;
-    quat_yaw_inverse_apply(e.orient_add, e.so_quat, 4, o + 1);
-    for (int u = 0; u < 10; ++u) o[5 + u] = e.so_mpos[u] + e.motor_noise[u];
-    quat_yaw_inverse_apply(e.orient_add, e.so_tvel, 3, o + 15);
-    for (int k = 0; k < 3; ++k) o[18 + k] = e.so_rotvel[k];
-    for (int u = 0; u < 10; ++u) o[21 + u] = e.so_mvel[u];
-    quat_yaw_inverse_apply(e.orient_add, e.so_tacc, 3, o + 31);
-    for (int k = 0; k < 6; ++k) o[34 + k] = e.so_jpos[k] + e.joint_noise[k];
-    for (int k = 0; k < 6; ++k) o[40 + k] = e.so_jvel[k];
-    o[46] = std::sin(2 * PI * e.phase / e.clock.phaselen);
-    o[47] = std::cos(2 * PI * e.phase / e.clock.phaselen);
-    if (e.cfg.command_profile == 0) { o[48] = e.speed; o[49] = e.side_speed; return; }
+    int n;
+    if (e.cfg.input_profile == 1) {      // input_profile "min" (cassie.py:829-837): foot positions, pelvis orientation, rotational velocity, foot orientations
+        for (int k = 0; k < 3; ++k) { o[k] = e.est.foot_rel[0][k]; o[3 + k] = e.est.foot_rel[1][k]; o[10 + k] = e.so_rotvel[k]; }
+        quat_yaw_inverse_apply(e.orient_add, e.so_quat, 4, o + 6);
+        for (int k = 0; k < 4; ++k) { o[13 + k] = e.est.foot_quat[0][k]; o[17 + k] = e.est.foot_quat[1][k]; }
+        n = 21;
+    } else {
+        o[0] = e.so_height;
+        quat_yaw_inverse_apply(e.orient_add, e.so_quat, 4, o + 1);
+        for (int u = 0; u < 10; ++u) o[5 + u] = e.so_mpos[u] + e.motor_noise[u];
+        quat_yaw_inverse_apply(e.orient_add, e.so_tvel, 3, o + 15);
+        for (int k = 0; k < 3; ++k) o[18 + k] = e.so_rotvel[k];
+        for (int u = 0; u < 10; ++u) o[21 + u] = e.so_mvel[u];
+        quat_yaw_inverse_apply(e.orient_add, e.so_tacc, 3, o + 31);
+        for (int k = 0; k < 6; ++k) o[34 + k] = e.so_jpos[k] + e.joint_noise[k];
+        for (int k = 0; k < 6; ++k) o[40 + k] = e.so_jvel[k];
+        n = 46;
+    }
+    o[n] = std::sin(2 * PI * e.phase / e.clock.phaselen);
+    o[n + 1] = std::cos(2 * PI * e.phase / e.clock.phaselen);
+    if (e.cfg.command_profile == 0) { o[n + 2] = e.speed; o[n + 3] = e.side_speed; return; }
     // command_profile "phase" (cassie.py:805-808): clock, swing / stance duration, encode_stance_mode (grounded, aerial, zero), speed, side speed
-    o[48] = e.swing_duration; o[49] = e.stance_duration;
-    o[50] = e.cfg.stance_mode == 1; o[51] = e.cfg.stance_mode == 2; o[52] = e.cfg.stance_mode == 0;
-    o[53] = e.speed; o[54] = e.side_speed;
+    o[n + 2] = e.swing_duration; o[n + 3] = e.stance_duration;
+    o[n + 4] = e.cfg.stance_mode == 1; o[n + 5] = e.cfg.stance_mode == 2; o[n + 6] = e.cfg.stance_mode == 0;
+    o[n + 7] = e.speed; o[n + 8] = e.side_speed;
 }
 
 void env_init(Env& e, const EnvCfg& cfg, uint32_t env_id) {

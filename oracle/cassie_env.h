@@ -31,6 +31,7 @@ struct EnvCfg {
     uint64_t seed = 0;
     int command_profile = 0;  // 0 clock (obs 50), 1 phase (cassie.py:266-271,529-545,805-808: obs 55), 2 phase with the "library" draws (:531-539)
     int est_lifetime = 169;   // env steps after which the next reset also restarts the estimator (one PPO.sample call of the reference builds one CassieEnv: ppo.py:152; 5096 // 30, apex.py:244-246); 0 = never
+    int input_profile = 0;    // 0 full (46 estimator entries), 1 min (21: foot positions, pelvis orientation / rotational velocity, foot orientations; cassie.py:246-256,829-837)
     int env_kind = 0;         // 0 Cassie-v0 (cassie/cassie.py), 1 CassieTraj-v0 with the CLI defaults (cassie/cassie_traj.py: trajectory-pose reset)
 };
 

@@ -38,7 +38,7 @@ inline M3 matmul(const M3& a, const M3& b) {
 inline V3 mulT(const M3& R, V3 v) { return {R.m[0] * v.x + R.m[3] * v.y + R.m[6] * v.z, R.m[1] * v.x + R.m[4] * v.y + R.m[7] * v.z, R.m[2] * v.x + R.m[5] * v.y + R.m[8] * v.z}; }
 
 // foot-frame origin relative to the pelvis (pelvis axes) and its partial derivatives with respect to the shin and tarsus angles
-void foot_kinematics(int leg, const double q[7], V3& p, V3& dshin, V3& dtarsus) {
+void foot_kinematics(int leg, const double q[7], V3& p, V3& dshin, V3& dtarsus, M3& Rfoot) {
     M3 R = {{1, 0, 0, 0, 1, 0, 0, 0, 1}};
     V3 o = {0, 0, 0}, jo[7]; M3 jR[7];
     for (int k = 0; k < 7; ++k) {
@@ -50,7 +50,7 @@ void foot_kinematics(int leg, const double q[7], V3& p, V3& dshin, V3& dtarsus) 
         R = matmul(matmul(R, q2m(Q4{cm_body_quat[4 * b], cm_body_quat[4 * b + 1], cm_body_quat[4 * b + 2], cm_body_quat[4 * b + 3]})), Rz);
         jo[k] = o; jR[k] = R;
     }
-    p = o + mul(R, v3(FOOT_OFF));
+    p = o + mul(R, v3(FOOT_OFF)); Rfoot = R;
     dshin = cross(col(jR[4], 2), p - jo[4]);
     dtarsus = cross(col(jR[5], 2), p - jo[5]);
 }
@@ -194,8 +194,15 @@ void state_output_step(StateOutput& s, const EstSensors& in) {
     V3 fw[2]; double fz[2];
     for (int leg = 0; leg < 2; ++leg) {
         const double q[7] = {in.mpos[5 * leg], in.mpos[5 * leg + 1], in.mpos[5 * leg + 2], in.mpos[5 * leg + 3], in.jpos[3 * leg], in.jpos[3 * leg + 1], in.mpos[5 * leg + 4]};
-        V3 p, dS, dT; double gr[4];
-        foot_kinematics(leg, q, p, dS, dT);
+        V3 p, dS, dT; double gr[4]; M3 Rf;
+        foot_kinematics(leg, q, p, dS, dT, Rf);
+        {   // foot orientation output: foot body frame times the routine's constant frame offset C = [[-c, 0, -s], [s, 0, -c], [0, -1, 0]], c = cos 40 deg, s = sin 40 deg
+            const double c40 = 0.76604444311897803, s40 = 0.64278760968653933;
+            const M3 C = {{-c40, 0, -s40, s40, 0, -c40, 0, -1, 0}};
+            const M3 Re = matmul(Rf, C);
+            const double w = 0.5 * std::sqrt(std::max(0.0, 1 + Re.m[0] + Re.m[4] + Re.m[8]));      // the foot frame stays within a few degrees of the pelvis frame: w ~ 1
+            s.foot_quat[leg][0] = w; s.foot_quat[leg][1] = (Re.m[7] - Re.m[5]) / (4 * w); s.foot_quat[leg][2] = (Re.m[2] - Re.m[6]) / (4 * w); s.foot_quat[leg][3] = (Re.m[3] - Re.m[1]) / (4 * w);
+        }
         heel_residual(q[3], q[4], q[5], s.heel[leg], gr);
         const V3 a = dS - dT * (gr[1] / gr[2]), b = dT * (-gr[3] / gr[2]);       // d foot / d shin, d foot / d heel spring: the tarsus angle follows the closure
         const double M[2][3] = {{-a.x, -a.y, -a.z}, {-b.x, -b.y, -b.z}}, tau[2] = {K_SHIN * in.jpos[3 * leg], K_HEEL * s.heel[leg]};

@@ -35,6 +35,7 @@ struct StateOutput {
     // outputs of the most recent step (state_out_t fields)
     double pos[3], vel[3], tacc[3];          // pelvis.position, pelvis.translationalVelocity (world-aligned axes), pelvis.translationalAcceleration
     double foot_rel[2][3];                   // leftFoot / rightFoot .position (pelvis frame)
+    double foot_quat[2][4];                  // leftFoot / rightFoot .orientation (pelvis frame; the foot body's frame turned by the routine's constant offset)
     double foot_force[2][3];                 // estimated foot force, world z exact, x / y in the heading frame of the binary not reproduced (unused)
     int lm_iters;                            // Levenberg-Marquardt iterations of the most recent heel solve (diagnostics)
 };

@@ -29,6 +29,7 @@ def lib():
         L.orc_env_apply_force.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_env_set_kind.argtypes = [C.c_void_p, C.c_int]
         L.orc_env_set_command_profile.argtypes = [C.c_void_p, C.c_int]
+        L.orc_env_set_input_profile.argtypes = [C.c_void_p, C.c_int]
         L.orc_traj_ref_state.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_env_set_command.argtypes = [C.c_void_p, C.c_double, C.c_int]
         L.orc_env_obs.argtypes = [C.c_void_p, C.c_void_p]
@@ -75,10 +76,12 @@ def _ptr(a):
 
 class OracleEnv:
     def __init__(self, simrate=50, dyn_rand=True, reward_kind=0, stance_mode=0, incentive=True, max_traj_len=400,
-                 pgs_iters=50, seed=0, env_id=0, env_kind=0, command_profile=0, est_lifetime=169):
+                 pgs_iters=50, seed=0, env_id=0, env_kind=0, command_profile=0, est_lifetime=169, input_profile=0):
         self.h = lib().orc_env_new(simrate, int(dyn_rand), reward_kind, stance_mode, int(incentive), max_traj_len,
                                    pgs_iters, seed, env_id)
-        self.obs_dim = 50 if command_profile == 0 else 55
+        self.obs_dim = (46 if input_profile == 0 else 21) + (4 if command_profile == 0 else 9)
+        if input_profile:        # 1 = min
+            lib().orc_env_set_input_profile(self.h, int(input_profile))
         if env_kind:
             lib().orc_env_set_kind(self.h, int(env_kind))
         if command_profile:      # 1 phase, 2 phase with the "library" draws
@@ -262,9 +265,9 @@ class StateEstimator:
     def step(self, sensors26):
         x = np.ascontiguousarray(sensors26, dtype=np.float64)
         assert x.size == 26
-        o = np.zeros(25)
+        o = np.zeros(33)
         lib().orc_est_step(self.h, _ptr(x), _ptr(o))
-        return dict(pos=o[0:3], vel=o[3:6], tacc=o[6:9], terrain=o[9], foot_rel=o[10:16].reshape(2, 3), foot_force=o[16:22].reshape(2, 3), heel=o[22:24], lm_iters=int(o[24]))
+        return dict(pos=o[0:3], vel=o[3:6], tacc=o[6:9], terrain=o[9], foot_rel=o[10:16].reshape(2, 3), foot_force=o[16:22].reshape(2, 3), heel=o[22:24], lm_iters=int(o[24]), foot_quat=o[25:33].reshape(2, 4))
 
 
 def heel_residual(knee, shin, tarsus, heel):

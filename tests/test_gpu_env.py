@@ -862,3 +862,29 @@ def test_range_checked_build_sees_no_out_of_range_index(dev):
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "t_check.py"), "40"], env=dict(os.environ, APX_LIB=lib), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "RESULT clean" in out.stdout, out.stdout[-2000:]
+
+
+def test_min_input_profile_vs_oracle(dev):
+    """input_profile "min" (cassie.py:246-256,829-837): the observation is built from the state estimator's foot positions / orientations (leftFoot / rightFoot of
+    state_out_t: golden G11 pins them in the oracle, G8 the packing and the mirror list) instead of the 46 joint-level entries.  Kernel vs oracle over a
+    reset and 6 env steps, clock and phase command profiles; 25 / 30 entries."""
+    from apex_amd.vecenv import CassieVecEnv
+    for cp, cpi, dim in (("clock", 0, 25), ("phase", 1, 30)):
+        genv = CassieVecEnv(n_envs=64, dynamics_randomization=True, seed=12, input_profile="min", command_profile=cp)
+        assert genv.obs_dim == dim and len(genv.mirrored_obs) == dim
+        oenv = [S.OracleEnv(dyn_rand=True, seed=12, env_id=i, input_profile=1, command_profile=cpi) for i in range(8)]
+        obs = genv.reset().cpu().numpy()
+        ref = np.stack([e.reset() for e in oenv])
+        np.testing.assert_allclose(obs[:8], ref, atol=3e-4)
+        rng = np.random.RandomState(3)
+        for t in range(6):
+            act = (rng.randn(64, 10) * 0.1).astype(np.float32)
+            obs, rew, done, _ = genv.step(torch.tensor(act, device=dev), auto_reset=False)
+            obs = obs.cpu().numpy()
+            for i, e in enumerate(oenv):
+                o, r, d = e.step(act[i].astype(np.float64))
+                assert d == done[i]
+                np.testing.assert_allclose(obs[i, :6], o[:6], atol=2e-3 * (t + 1), err_msg="foot positions")
+                np.testing.assert_allclose(obs[i, 6:10], o[6:10], atol=2e-3 * (t + 1)); np.testing.assert_allclose(obs[i, 13:21], o[13:21], atol=5e-3 * (t + 1), err_msg="foot orientations")
+                np.testing.assert_allclose(obs[i, 21:], o[21:], atol=1e-5)
+        genv.close()

@@ -53,6 +53,18 @@ def test_g8_full_state(golden_dir):
         e.set("so_mvel", g[p + "mvel"]); e.set("so_jpos", g[p + "jpos"]); e.set("so_jvel", g[p + "jvel"])
         e.set("motor_noise", g[p + "mnoise"]); e.set("joint_noise", g[p + "jnoise"])
         np.testing.assert_allclose(e.obs(), g[p + "obs"], atol=1e-12)
+    # input_profile "min" (cassie.py:246-256,829-837) x command_profile clock / phase: the reference's get_full_state on synthetic state_out_t values
+    from apex_amd.vecenv import mirrored_obs_for
+    for cp, key in ((0, "min_clock"), (1, "min_phase")):
+        e = S.OracleEnv(input_profile=1, command_profile=cp, stance_mode=1)
+        assert list(g[key + "_mirror"]) == list(mirrored_obs_for("phase" if cp else "clock", "min")) and int(g[key + "_dim"]) == e.obs_dim
+        for c in range(int(g["n_min"])):
+            p = f"{key}{c}_"
+            phase, phaselen, speed, side, orient, swing, stance = g[p + "scal"]
+            ints = e.get("ints"); ints[1] = phase; e.set("ints", ints)
+            e.set("phaselen", [phaselen]); e.set("speed", [speed]); e.set("side_speed", [side]); e.set("orient_add", [orient]); e.set("swing_stance", [swing, stance])
+            e.set("so_quat", g[p + "quat"]); e.set("so_rotvel", g[p + "rotvel"]); e.set("est_foot_rel", g[p + "foot_pos"]); e.set("est_foot_quat", g[p + "foot_quat"])
+            np.testing.assert_allclose(e.obs(), g[p + "obs"], atol=1e-12)
 
 
 def test_g9_pd_law(golden_dir):
@@ -90,16 +102,16 @@ def test_g11_state_estimator_restated(golden_dir):
     g = np.load(os.path.join(golden_dir, "g11_state_estimator.npz"))
     sens, ref = np.insert(g["sens"].astype(np.float64), [16, 16, 16, 16], g["quat"], axis=1), g["ref"]      # mpos10 jpos6 quat4 gyro3 acc3
     est = S.StateEstimator()
-    err = np.zeros(5); iters = []
+    err = np.zeros(6); iters = []
     for t in range(len(sens)):
         r = est.step(sens[t]); iters.append(r["lm_iters"])
         if t % 5 == 0:
             o = ref[t // 5]
             err = np.maximum(err, [np.abs(r["pos"] - o[0:3]).max(), np.abs(r["vel"] - o[3:6]).max(), np.abs(r["tacc"] - o[6:9]).max(), abs(r["terrain"] - o[9]),
-                                   np.abs(r["foot_rel"].reshape(-1) - o[10:16]).max()])
+                                   np.abs(r["foot_rel"].reshape(-1) - o[10:16]).max(), np.abs(r["foot_quat"].reshape(-1) - o[16:24]).max()])
     o = g["ref_last"]
     assert np.abs(np.concatenate([r["pos"], r["vel"], r["tacc"], [r["terrain"]]]) - o[:10]).max() < 2e-7
-    assert err[0] < 2e-7 and err[1] < 2e-7 and err[2] < 1e-12 and err[3] < 2e-7 and err[4] < 2e-7, err
+    assert err[0] < 2e-7 and err[1] < 2e-7 and err[2] < 1e-12 and err[3] < 2e-7 and err[4] < 2e-7 and err[5] < 2e-7, err      # (the last: leftFoot / rightFoot .orientation)
     assert abs((r["pos"][2] - r["terrain"]) - (o[2] - o[9])) < 2e-7                      # observation entry 0
     assert 0 < max(iters) <= 6 and np.mean(iters) < 4                                     # Levenberg-Marquardt passes per 2 kHz sample (limit 5 + the closing pass)
     # the signal is not trivial on this stream: the robot walks (velocity up to ~2 m/s while it stands up, terrain estimate moves by centimetres)

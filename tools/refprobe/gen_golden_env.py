@@ -121,6 +121,34 @@ def g8():
         out[pre + "jpos"] = np.array(s.cassie_state.joint.position); out[pre + "jvel"] = np.array(s.cassie_state.joint.velocity)
         out[pre + "mnoise"] = s.motor_encoder_noise; out[pre + "jnoise"] = s.joint_encoder_noise
     out["n_cases"] = n
+    # input_profile "min": foot positions / orientations of the estimator instead of the 46 joint-level entries (cassie.py:246-256,829-837)
+    out["n_min"] = 6
+    for cp in ("clock", "phase"):
+        key = "min_" + cp
+        space, clock_inds, mirrored = CassieEnv.set_up_state_space(None, cp, "min")
+        out[key + "_mirror"] = np.array(mirrored, dtype=np.float64); out[key + "_dim"] = len(space)
+        for c in range(6):
+            s = types.SimpleNamespace()
+            s.command_profile = cp; s.input_profile = "min"; s.sim = _Sim(np.zeros(35), np.zeros(32))
+            s.phase = int(rng.randint(0, 30)); s.phaselen = rng.uniform(22.0, 36.0)
+            s.speed = rng.uniform(-0.3, 4); s.side_speed = rng.uniform(-0.3, 0.3); s.orient_add = rng.uniform(-1.5, 1.5)
+            s.swing_duration = rng.uniform(0.1, 0.5); s.stance_duration = rng.uniform(0.1, 0.3); s.stance_mode = "grounded"
+            q = rng.randn(4); q /= np.linalg.norm(q)
+            fq = rng.randn(2, 4); fq /= np.linalg.norm(fq, axis=1, keepdims=True)
+            foot = lambda k: types.SimpleNamespace(position=list(rng.randn(3)), orientation=list(fq[k]))
+            lf, rf = foot(0), foot(1)
+            s.cassie_state = types.SimpleNamespace(
+                pelvis=types.SimpleNamespace(position=[0, 0, 1.0], orientation=list(q), rotationalVelocity=list(rng.randn(3)), translationalVelocity=list(rng.randn(3)), translationalAcceleration=list(rng.randn(3))),
+                terrain=types.SimpleNamespace(height=0.0), leftFoot=lf, rightFoot=rf,
+                motor=types.SimpleNamespace(position=list(rng.randn(10)), velocity=list(rng.randn(10))), joint=types.SimpleNamespace(position=list(rng.randn(6)), velocity=list(rng.randn(6))))
+            s.joint_rand = False
+            s.history = 0; s.state_history = [np.zeros(len(space))]
+            s.rotate_to_orient = lambda v, s=s: CassieEnv.rotate_to_orient(s, v)
+            pre = f"{key}{c}_"
+            out[pre + "obs"] = CassieEnv.get_full_state(s)
+            out[pre + "scal"] = np.array([s.phase, s.phaselen, s.speed, s.side_speed, s.orient_add, s.swing_duration, s.stance_duration])
+            out[pre + "quat"] = q; out[pre + "rotvel"] = np.array(s.cassie_state.pelvis.rotationalVelocity)
+            out[pre + "foot_pos"] = np.array(lf.position + rf.position); out[pre + "foot_quat"] = fq.reshape(-1)
     np.savez_compressed(os.path.join(GOLD, "g8_full_state.npz"), **out)
 
 

@@ -30,7 +30,7 @@ def feed(est, s26):
     for k in range(3): out.pelvis.vectorNav.angularVelocity[k] = float(s26[20 + k]); out.pelvis.vectorNav.linearAcceleration[k] = float(s26[23 + k])
     so = cm.state_out_t(); cm.state_output_step(est, out, so)
     return np.concatenate([so.pelvis.position[:], so.pelvis.translationalVelocity[:], so.pelvis.translationalAcceleration[:], [so.terrain.height],
-                           so.leftFoot.position[:], so.rightFoot.position[:]])
+                           so.leftFoot.position[:], so.rightFoot.position[:], so.leftFoot.orientation[:], so.rightFoot.orientation[:]])
 
 
 # ---- 1. the whole routine on a walking stream
