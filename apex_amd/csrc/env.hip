@@ -255,6 +255,16 @@ __device__ __forceinline__ void yaw_inv_rotate3(float yaw, const float* v, float
     out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
 
+// self.phase of the reference as a float: I_PHASE + 0.5 x the half bit of I_FLAGS (bit 5); bit 6 = self.phase_add is 1.5 (tools/test_commands.py:86)
+__device__ __forceinline__ float fphase(const St& S) { return (float)S.I(I_PHASE) + 0.5f * (float)((S.I(I_FLAGS) >> 5) & 1); }
+// self.phase += self.phase_add; wrap (cassie.py:447-453, 511-515)
+__device__ __forceinline__ void advance_phase(const St& S) {
+    int flags = S.I(I_FLAGS), phase = S.I(I_PHASE);
+    const int half = (flags >> 5) & 1;
+    if (flags & 64) { phase += 1 + half; flags ^= 32; } else phase += 1;
+    if ((float)phase + 0.5f * (float)((flags >> 5) & 1) > S(F_CMD + 5)) { phase = 0; flags &= ~32; S.I(I_COUNTER) += 1; }
+    S.I(I_PHASE) = phase; S.I(I_FLAGS) = flags;
+}
 // get_full_state (cassie/cassie.py:787-859), written straight to obs[env*50 ..]
 __device__ void write_obs(const St& S, const Cfg& cfg, float* o) {
     const float yaw = S(F_CMD + 2);
@@ -289,7 +299,7 @@ __device__ void write_obs(const St& S, const Cfg& cfg, float* o) {
         for (int k = 0; k < 6; ++k) o[40 + k] = S(F_SO + SO_JVEL + k);
         n = 46;
     }
-    const float ang = 2.f * PI_F * (float)S.I(I_PHASE) / S(F_CMD + 5);
+    const float ang = 2.f * PI_F * fphase(S) / S(F_CMD + 5);
     o[n] = sinf(ang); o[n + 1] = cosf(ang);
     if (cfg.command_profile == 0) { o[n + 2] = S(F_CMD + 0); o[n + 3] = S(F_CMD + 1); return; }
     // command_profile "phase" (cassie.py:805-808): clock, swing / stance duration, one-hot stance mode (grounded, aerial, zero), speed, side speed
@@ -337,7 +347,7 @@ __device__ void env_reset_draws(const St& S, const Cfg& cfg) {
         S(F_CMD + 3) = swing; S(F_CMD + 4) = stance; S(F_CMD + 5) = (2.f * swing + 2.f * stance) * (float)(2000 / cfg.simrate);
         S(F_CMD + 6) = pick == 0u ? 1.f : pick == 1u ? 2.f : 0.f;
     }
-    S.I(I_PHASE) = (int)r.randint((unsigned)floorf(S(F_CMD + 5)) + 1u);
+    S.I(I_PHASE) = (int)r.randint((unsigned)floorf(S(F_CMD + 5)) + 1u); S.I(I_FLAGS) &= ~32;
     S.I(I_TIME) = 0; S.I(I_COUNTER) = 0;
     if (cfg.dyn_rand) {
         for (int d = 0; d < 6; ++d) { (void)r.u01(); S(F_DAMP + d) = cm_dof_damping[d]; }
@@ -423,7 +433,7 @@ __device__ float clock_reward(const St& S, const Cfg& cfg, const float* action, 
     const float pelvis_motion = straight + hdiff + 0.25f * pacc;
     ClockK ck;
     clock_knots(S(F_CMD + 3), S(F_CMD + 4), 2000 / cfg.simrate, ck);
-    const float ph = (float)S.I(I_PHASE);
+    const float ph = fphase(S);
     const int smode = (int)S(F_CMD + 6);                  // per env: the phase command profile draws it at every reset
     const float lfc = clock_eval(ck, 0, ph, smode, cfg.incentive), lvc = clock_eval(ck, 1, ph, smode, cfg.incentive);
     const float rfc = clock_eval(ck, 2, ph, smode, cfg.incentive), rvc = clock_eval(ck, 3, ph, smode, cfg.incentive);
@@ -549,9 +559,9 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
         const float inv = 1.f / (float)cfg.simrate;
         const float lfrc = S.W(ACC + 0) * inv, rfrc = S.W(ACC + 1) * inv, lor = S.W(ACC + 2) * inv, ror = S.W(ACC + 3) * inv;
         const float height = S(F_QPOS + 2);
-        int time = S.I(I_TIME) + 1, phase = S.I(I_PHASE) + 1;
-        if ((float)phase > S(F_CMD + 5)) { phase = 0; S.I(I_COUNTER) += 1; }
-        S.I(I_TIME) = time; S.I(I_PHASE) = phase; S.I(I_AGE) += 1;
+        const int time = S.I(I_TIME) + 1;
+        advance_phase(S);
+        S.I(I_TIME) = time; S.I(I_AGE) += 1;
         // NaN test on the bit pattern: it must survive -ffast-math (finite-math-only would fold `h != h` away)
         const bool h_nan = (__float_as_uint(height) & 0x7fffffffu) > 0x7f800000u;
         int dn = (height < 0.4f || height > 3.0f || h_nan) ? 1 : 0;
@@ -596,10 +606,8 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_substep_kernel(float
     c4::wsync();
     for (int i = 0; i < n_sub; ++i) sim_step_pd<HF>(S, cfg, 1);
     if (action && lead) {
-        int phase = S.I(I_PHASE) + 1;
         S.I(I_TIME) += 1;
-        if ((float)phase > S(F_CMD + 5)) { phase = 0; S.I(I_COUNTER) += 1; }
-        S.I(I_PHASE) = phase;
+        advance_phase(S);
         if (obs) write_obs(S, cfg, obs + (size_t)env * cfg.obs_dim);
     }
     store_state(S, st, ist, n);
@@ -610,7 +618,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_for_test_kerne
     ENV_SETUP
     load_state(S, st, ist, n);
     if (lead) {
-        S.I(I_PHASE) = 0; S.I(I_TIME) = 0; S.I(I_COUNTER) = 0;
+        S.I(I_PHASE) = 0; S.I(I_TIME) = 0; S.I(I_COUNTER) = 0; S.I(I_FLAGS) &= ~(32 | 64);      // phase_add = 1 (cassie.py:687)
         S(F_CMD + 0) = 0.f; S(F_CMD + 2) = 0.f;                                  // speed, orient_add (side speed is NOT reset)
         S(F_CMD + 3) = 0.15f; S(F_CMD + 4) = 0.25f; S(F_CMD + 5) = (2.f * 0.15f + 2.f * 0.25f) * (float)(2000 / cfg.simrate); S(F_CMD + 6) = 1.f;      // grounded (cassie.py:699-702)
     }
@@ -675,7 +683,8 @@ __global__ void env_update_speed_kernel(float* st, int* ist, int n, Cfg cfg, con
     const double freq = (double)(2000 / cfg.simrate);
     const double old_len = (2.0 * (double)F(F_CMD + 3) + 2.0 * (double)F(F_CMD + 4)) * freq, new_len = (2.0 * swing + 2.0 * stance) * freq;
     int& phase = ist[(size_t)I_PHASE * n + env];
-    phase = (int)(new_len * (double)phase / old_len);
+    int& flg = ist[(size_t)I_FLAGS * n + env];
+    phase = (int)(new_len * ((double)phase + 0.5 * (double)((flg >> 5) & 1)) / old_len); flg &= ~32;
     F(F_CMD + 0) = sp; F(F_CMD + 1) = sd; F(F_CMD + 3) = (float)swing; F(F_CMD + 4) = (float)stance; F(F_CMD + 5) = (float)new_len;
 }
 

@@ -133,8 +133,7 @@ def eval_commands(actor, make_env, obs_mean=None, obs_std=None, num_steps=200, n
     (previous +- U[0.4, 1.3], reflected into [min_speed, max_speed]) and, half a period later, a yaw command change of
     +- U[pi/6, pi/3] applied to the policy input; failed when qpos[2] < 0.4.  Returns save_data [num_iters, 6] float32 numpy with the
     reference's columns: passed, (-1 | 0 = failed in the half period after a speed change, 1 = after an orientation change), speed,
-    orient_add, last speed change, last orientation change.  Not reproduced: phase_add = 1.5 above 1.4 m/s (test_commands.py:87-90;
-    the phase counter of the kernel is an integer)."""
+    orient_add, last speed change, last orientation change.  phase_add = 1.5 above 1.4 m/s (test_commands.py:85-88) is carried per env."""
     import numpy as np
     n = ((num_iters + 63) // 64) * 64
     env = make_env(n)
@@ -151,7 +150,7 @@ def eval_commands(actor, make_env, obs_mean=None, obs_std=None, num_steps=200, n
     orients = U(np.pi / 6, np.pi / 3, n, num_commands) * sign(n, num_commands)
     fwd = (lambda o: actor.forward(o, obs_mean, obs_std)) if hasattr(actor, "forward") else actor
     obs = env.reset_for_test(full_reset=True)
-    env.set_command(speed=0.5, side_speed=0.0)
+    env.set_command(speed=0.5, side_speed=0.0, phase_add=1.0)
     orient_add = torch.zeros(n, device=dev); speed = torch.full((n,), 0.5, device=dev)
     passed = torch.ones(n, dtype=torch.bool, device=dev)
     data = torch.zeros(n, 6, device=dev)
@@ -163,7 +162,7 @@ def eval_commands(actor, make_env, obs_mean=None, obs_std=None, num_steps=200, n
             new = speeds[:, speed_ind].clamp(min_speed, max_speed)
             last_dspeed = new - speeds[:, max(0, speed_ind - 1)]
             speed = new
-            env.set_command(speed=speed)
+            env.set_command(speed=speed, phase_add=torch.where(speed > 1.4, 1.5, 1.0))      # test_commands.py:85-88
             speed_ind += 1
         elif count == num_steps // 2:
             last_dorient = orients[:, orient_ind]

@@ -173,7 +173,7 @@ class CassieVecEnv:
         x = torch.as_tensor(xfrc, dtype=torch.float32, device=self.device).expand(self.n_envs, 6).contiguous()
         check(_lib.load().apx_env_apply_force(self._h, _p(x), _stream()))
 
-    def set_command(self, speed=None, side_speed=None, orient_add=None, phase=None):
+    def set_command(self, speed=None, side_speed=None, orient_add=None, phase=None, phase_add=None):
         """Plain attribute writes `env.speed = ...`, `env.orient_add = ...`, `env.phase = ...` of the reference's test harnesses
         (tools/eval_perturb.py:32, tools/test_commands.py:66-120): no clipping, the clock is NOT rebuilt (unlike update_speed)."""
         if speed is not None or side_speed is not None or orient_add is not None:
@@ -182,9 +182,18 @@ class CassieVecEnv:
                 if v is not None:
                     cmd[:, col] = torch.as_tensor(v, dtype=torch.float32, device=self.device)
             self.set_field("cmd", cmd)
-        if phase is not None:
+        if phase is not None or phase_add is not None:      # the phase is an integer + a half bit, phase_add 1 or 1.5 a flag (I_FLAGS bits 5, 6; tools/test_commands.py:86)
             ints = self.get_field("ints")
-            ints[:, 1] = torch.as_tensor(phase, dtype=torch.float32, device=self.device)
+            flags = ints[:, 4].to(torch.int64)
+            if phase is not None:
+                ph = torch.as_tensor(phase, dtype=torch.float32, device=self.device).expand(self.n_envs)
+                ints[:, 1] = torch.floor(ph)
+                flags = (flags & ~32) | ((ph - torch.floor(ph) >= 0.5).to(torch.int64) << 5)
+            if phase_add is not None:
+                pa = torch.as_tensor(phase_add, dtype=torch.float32, device=self.device).expand(self.n_envs)
+                assert bool(((pa == 1.0) | (pa == 1.5)).all()), "phase_add: 1 or 1.5 (tools/test_commands.py:86-88)"
+                flags = (flags & ~64) | ((pa > 1.25).to(torch.int64) << 6)
+            ints[:, 4] = flags.to(torch.float32)
             self.set_field("ints", ints)
 
     def step_basic(self, action):

@@ -18,7 +18,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak
+VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak = fp32 MFMA peak (MI355X_MICROARCH.md)
+BF16_MFMA_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
 
 
 def cpu_baseline(seconds_hint=12.0, n_envs=4096, rollout_len=32, minibatch=16384, epochs=3):
@@ -34,7 +35,7 @@ def cpu_baseline(seconds_hint=12.0, n_envs=4096, rollout_len=32, minibatch=16384
     flop = sim.count_flops(20)
     # learner: one minibatch of the bench shape through the fp64 numpy oracle (BLAS threads as numpy is configured)
     rng = np.random.RandomState(0)
-    H, mb = 256, min(minibatch, 4096)
+    H, mb = 256, minibatch                 # one FULL minibatch of the bench shape is timed (about 1 s of numpy per 16 384 rows)
     shapes = [(H, 50), (H,), (H, H), (H,), (10, H), (10,)]
     Wa = [rng.randn(*s) * 0.05 for s in shapes]; Wc = [rng.randn(*s) * 0.05 for s in shapes[:4] + [(1, H), (1,)]]
     obs = rng.randn(mb, 50); ph = rng.rand(mb) * 6.28; obs[:, 46] = np.sin(ph); obs[:, 47] = np.cos(ph); act = rng.randn(mb, 10) * 0.3; ret = rng.randn(mb, 1); adv = rng.randn(mb, 1)
@@ -50,7 +51,7 @@ def cpu_baseline(seconds_hint=12.0, n_envs=4096, rollout_len=32, minibatch=16384
             "sample": f"{cores} envs x {n_steps} env steps (50 substeps each), sampling only, fp64 dense oracle, one env per thread",
             "end_to_end": {"value": round(e2e, 1), "unit": "env-steps/s",
                            "sample": f"one iteration of {steps_it} env steps at the sampling rate above + {epochs} epochs x {steps_it // minibatch} minibatches of {minibatch} "
-                                     f"through the fp64 numpy learner (timed on one {mb}-row minibatch: {t_mb:.2f} s per {minibatch} rows)"},
+                                     f"through the fp64 numpy learner (one full {mb}-row minibatch timed: {t_mb:.2f} s; the iteration's update = that x {epochs * (steps_it // minibatch)})"},
             "flop_per_env_step_counted": int(flop)}
 
 
@@ -59,17 +60,17 @@ def kernel_source_hash():
     """sha1 over the env kernel's sources: a PMC profile is only quoted while it was taken on THIS kernel"""
     import hashlib
     h = hashlib.sha1()
-    for f in ("env.hip", "cassie_lane.h", "cassie_common.h", "env_state.h"):
+    for f in ("env.hip", "cassie_lane.h", "estimator_lane.h", "cassie_common.h", "env_state.h"):
         h.update(open(os.path.join(REPO, "apex_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:12]
 
 
 def _pmc_traffic_bytes():
-    """HBM bytes per env_step_kernel launch from the committed rocprofv3 PMC passes (profiles/r02_env_step_pmc_hbm.txt, 4096 envs): 2 x
+    """HBM bytes per env_step_kernel launch from the committed rocprofv3 PMC passes (profiles/r03_env_step_pmc_hbm.txt, 4096 envs): 2 x
     FETCH_SIZE (gfx950 correction of the microarchitecture guide) + WRITE_SIZE, both in KB.  The profile records the hash of the kernel
     sources it was taken on (tools/profile_round.sh); a profile of another kernel is NOT quoted: None + a note on stderr."""
     import re
-    path = os.path.join(REPO, "profiles", "r02_env_step_pmc_hbm.txt")
+    path = os.path.join(REPO, "profiles", "r03_env_step_pmc_hbm.txt")
     try:
         txt = open(path).read()
         m = re.search(r"kernel sources sha1: (\w+)", txt)
@@ -256,6 +257,17 @@ def main():
     g1.record(); torch.cuda.synchronize()
     mlp_ms = g0.elapsed_time(g1) / 20
     mlp_flop = 2.0 * mb_rows * (50 * 256 + 256 * 256 + 256 * 10)
+    mlp_bf16 = None
+    if a.precision == "bf16":       # the bf16 GEMM path (three launches: bf16 MFMA inputs, fp32 accumulate) is priced against the DENSE bf16 MFMA peak, not the fp32 one
+        for _ in range(3):
+            algo.learner.actor.forward(xb, algo.learner.obs_mean, algo.learner.obs_std, precision=1)
+        g0.record()
+        for _ in range(20):
+            algo.learner.actor.forward(xb, algo.learner.obs_mean, algo.learner.obs_std, precision=1)
+        g1.record(); torch.cuda.synchronize()
+        bms = g0.elapsed_time(g1) / 20
+        mlp_bf16 = {"what": "the same forward through gemm_bf16_kernel (v_mfma_f32_32x32x8bf16_1k), three launches", "ms": round(bms, 4), "achieved_tflops": round(mlp_flop / (bms * 1e-3) / 1e12, 2),
+                    "peak_tflops": BF16_MFMA_PEAK_TFLOPS, "frac": round(mlp_flop / (bms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 5)}
 
     if rank == 0:
         steps_total = a.steps * a.rollout_len * a.n_envs * world
@@ -295,6 +307,8 @@ def main():
                                               "ms": round(mlp_ms, 4), "achieved_tflops": round(mlp_flop / (mlp_ms * 1e-3) / 1e12, 2),
                                               "peak_tflops": VALU_PEAK_TFLOPS, "frac": round(mlp_flop / (mlp_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)}},
         }
+        if mlp_bf16:
+            res["roofline"]["mlp_forward_mfma_bf16"] = mlp_bf16
         if cpu:
             res["cpu_baseline"] = cpu
         print(json.dumps(res))

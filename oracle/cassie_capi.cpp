@@ -82,6 +82,7 @@ static int field(Env& e, const char* name, double* io, bool set) {
     FIELD("swing_stance", &e.swing_duration, 2) FIELD("prev_action", e.prev_action, 10) FIELD("prev_torque", e.prev_torque, 10)
     FIELD("tq_fifo", e.tq_fifo, 60) FIELD("menc_hist", e.menc_hist, 90) FIELD("jenc_x", e.jenc_x, 24) FIELD("jenc_y", e.jenc_y, 18) FIELD("foot_pos_prev", e.foot_pos_prev, 6)
     if (!std::strcmp(name, "enc_primed")) { if (set) { e.menc_primed = (int)io[0]; e.jenc_primed = (int)io[1]; } else { io[0] = e.menc_primed; io[1] = e.jenc_primed; } return 2; }
+    if (!std::strcmp(name, "phase_add")) { if (set) { e.phase_add15 = io[0] > 1.25; e.phase_half = (int)io[1]; } else { io[0] = e.phase_add15 ? 1.5 : 1.0; io[1] = e.phase_half; } return 2; }
     if (!std::strcmp(name, "est_age")) { if (set) { e.est_age = (int)io[0]; e.cfg.est_lifetime = (int)io[1]; } else { io[0] = e.est_age; io[1] = e.cfg.est_lifetime; } return 2; }
     if (!std::strcmp(name, "est_flags")) { if (set) e.est.inited = (int)io[0]; else { io[0] = e.est.inited; io[1] = e.est.lm_iters; } return 2; }
     if (!std::strcmp(name, "xpos")) { if (!set) std::memcpy(io, e.st.xpos, sizeof(double) * 3 * NB); return 3 * NB; }

@@ -212,6 +212,12 @@ void sim_step_pd(Env& e) {
     euler(e.par, e.st, w);
 }
 
+static inline double fphase(const Env& e) { return e.phase + 0.5 * e.phase_half; }
+// self.phase += self.phase_add; wrap (cassie.py:447-453, 511-515) with phase_add 1 or 1.5
+static void advance_phase(Env& e) {
+    if (e.phase_add15) { e.phase += 1 + e.phase_half; e.phase_half ^= 1; } else e.phase += 1;
+    if (fphase(e) > e.clock.phaselen) { e.phase = 0; e.phase_half = 0; e.counter += 1; }
+}
 static void quat_yaw_inverse_apply(double yaw, const double* v, int n, double* out) {
     // rotate_to_orient (cassie.py:280-291): q = euler2quat(z=yaw); iq = inverse(q)
     const double cz = std::cos(yaw / 2), sz = std::sin(yaw / 2);
@@ -248,8 +254,8 @@ void env_obs(const Env& e, double* o) {
         for (int k = 0; k < 6; ++k) o[40 + k] = e.so_jvel[k];
         n = 46;
     }
-    o[n] = std::sin(2 * PI * e.phase / e.clock.phaselen);
-    o[n + 1] = std::cos(2 * PI * e.phase / e.clock.phaselen);
+    o[n] = std::sin(2 * PI * fphase(e) / e.clock.phaselen);
+    o[n + 1] = std::cos(2 * PI * fphase(e) / e.clock.phaselen);
     if (e.cfg.command_profile == 0) { o[n + 2] = e.speed; o[n + 3] = e.side_speed; return; }
     // command_profile "phase" (cassie.py:805-808): clock, swing / stance duration, encode_stance_mode (grounded, aerial, zero), speed, side speed
     o[n + 2] = e.swing_duration; o[n + 3] = e.stance_duration;
@@ -285,8 +291,7 @@ void env_step_basic(Env& e, const double* action, double* obs) {
         e.pd_P[u] = P[u % 5]; e.pd_D[u] = D[u % 5];
     }
     for (int i = 0; i < e.cfg.simrate; ++i) sim_step_pd(e);
-    e.time += 1; e.phase += 1;
-    if (e.phase > e.clock.phaselen) { e.phase = 0; e.counter += 1; }
+    e.time += 1; advance_phase(e);
     env_obs(e, obs);
 }
 
@@ -304,7 +309,7 @@ void env_update_speed(Env& e, double new_speed, double new_side_speed) {
     const double old_phaselen = e.clock.phaselen;
     e.swing_duration = swing; e.stance_duration = stance;
     make_clock(e.clock, swing, stance, 0.1, e.cfg.stance_mode, e.cfg.have_incentive, 2000 / e.cfg.simrate);
-    e.phase = (int)(e.clock.phaselen * e.phase / old_phaselen);
+    e.phase = (int)(e.clock.phaselen * fphase(e) / old_phaselen); e.phase_half = 0;
 }
 
 // CassieEnv.reset_for_test(full_reset=False) (cassie.py:682-742): evaluation start.  Counters and commands to zero, the fixed
@@ -313,7 +318,7 @@ void env_update_speed(Env& e, double new_speed, double new_side_speed) {
 // of that one step_pd (self.cassie_state), i.e. from before set_const.
 void env_reset_for_test(Env& e, double* obs, bool full_reset) {
     static thread_local Work w;
-    e.phase = 0; e.time = 0; e.counter = 0; e.orient_add = 0; e.speed = 0;
+    e.phase = 0; e.time = 0; e.counter = 0; e.orient_add = 0; e.speed = 0; e.phase_half = 0; e.phase_add15 = 0;      // cassie.py:687 phase_add = 1
     e.cfg.stance_mode = 1;
     e.swing_duration = 0.15; e.stance_duration = 0.25;
     make_clock(e.clock, 0.15, 0.25, 0.1, e.cfg.stance_mode, e.cfg.have_incentive, 2000 / e.cfg.simrate);
@@ -388,6 +393,7 @@ void env_reset(Env& e, double* obs) {
         e.swing_duration = swing; e.stance_duration = stance;
         make_clock(e.clock, swing, stance, 0.1, e.cfg.stance_mode, e.cfg.have_incentive, 2000 / e.cfg.simrate);
     }
+    e.phase_half = 0;
     e.phase = (int)r.randint((uint32_t)std::floor(e.clock.phaselen) + 1);   // random.randint(0, floor(phaselen)) inclusive
     e.time = 0; e.counter = 0;
     if (e.cfg.dynamics_randomization) {
@@ -450,7 +456,7 @@ static double clock_reward(Env& e, const double* action) {   // cassie/rewards/c
     double pacc = 0;
     for (int k = 0; k < 3; ++k) pacc += std::fabs(e.so_rotvel[k]) + std::fabs(e.so_tacc[k]);
     const double pelvis_motion = straight + hdiff + 0.25 * pacc;
-    const double lfc = e.clock.eval(0, e.phase), lvc = e.clock.eval(1, e.phase), rfc = e.clock.eval(2, e.phase), rvc = e.clock.eval(3, e.phase);
+    const double lfc = e.clock.eval(0, fphase(e)), lvc = e.clock.eval(1, fphase(e)), rfc = e.clock.eval(2, fphase(e)), rvc = e.clock.eval(3, fphase(e));
     const double frc_score = std::tan(PI / 4 * lfc * nlf) + std::tan(PI / 4 * rfc * nrf);
     const double vel_score = std::tan(PI / 4 * lvc * nlv) + std::tan(PI / 4 * rvc * nrv);
     const double hip_roll = std::fabs(s.qvel[6]) + std::fabs(s.qvel[13]);    // :74 indexes qvel[13] (left shin), sic
@@ -480,7 +486,7 @@ static double early_clock_reward(Env& e, const double* action) {
     if (straight < 0.05) straight = 0;
     double hdiff = std::fabs(s.qpos[2] - 0.9);
     if (hdiff < 0.05 + 0.05 * e.speed) hdiff = 0;
-    const double lfc = e.clock.eval(0, e.phase), lvc = e.clock.eval(1, e.phase), rfc = e.clock.eval(2, e.phase), rvc = e.clock.eval(3, e.phase);
+    const double lfc = e.clock.eval(0, fphase(e)), lvc = e.clock.eval(1, fphase(e)), rfc = e.clock.eval(2, fphase(e)), rvc = e.clock.eval(3, fphase(e));
     const double frc_score = std::tanh(lfc * nlf) + std::tanh(rfc * nrf), vel_score = std::tanh(lvc * nlv) + std::tanh(rvc * nrv);
     return 0.250 * frc_score + 0.350 * vel_score + 0.200 * std::exp(-com_vel_err) + 0.100 * std::exp(-(com_orient + foot_orient)) +
            0.100 * std::exp(-(straight + hdiff));
@@ -499,7 +505,7 @@ static double max_vel_clock_reward(Env& e, const double* action) {
     if (straight < 0.05) straight = 0;
     double hdiff = std::fabs(s.qpos[2] - 1.0);               // +- 0.2 m dead zone around 1.0 m (:452-455)
     if (hdiff < 0.2) hdiff = 0;
-    const double lfc = e.clock.eval(0, e.phase), lvc = e.clock.eval(1, e.phase), rfc = e.clock.eval(2, e.phase), rvc = e.clock.eval(3, e.phase);
+    const double lfc = e.clock.eval(0, fphase(e)), lvc = e.clock.eval(1, fphase(e)), rfc = e.clock.eval(2, fphase(e)), rvc = e.clock.eval(3, fphase(e));
     const double frc = std::tanh(lfc * nlf) + std::tanh(rfc * nrf), vel = std::tanh(lvc * nlv) + std::tanh(rvc * nrv);
     return 0.1 * std::exp(-com_orient) + 0.1 * std::exp(-foot_orient) + 0.1 * std::exp(-(straight + hdiff)) + 0.2 * frc + 0.2 * vel +
            0.3 * (s.qvel[0] / 3.0);
@@ -532,8 +538,7 @@ int env_step(Env& e, const double* action, double* obs, double* reward) {
     const double inv = 1.0 / e.cfg.simrate;
     e.l_foot_frc *= inv; e.r_foot_frc *= inv; e.l_foot_orient_cost *= inv; e.r_foot_orient_cost *= inv;
     const double height = e.st.qpos[2];
-    e.time += 1; e.phase += 1; e.est_age += 1;
-    if (e.phase > e.clock.phaselen) { e.phase = 0; e.counter += 1; }
+    e.time += 1; e.est_age += 1; advance_phase(e);
     int done = (height < 0.4 || height > 3.0 || !(height == height)) ? 1 : 0;
     if (!e.has_prev_action) { for (int u = 0; u < 10; ++u) e.prev_action[u] = action[u]; e.has_prev_action = 1; }
     if (!e.has_prev_torque) { for (int u = 0; u < 10; ++u) e.prev_torque[u] = e.so_torque[u]; e.has_prev_torque = 1; }

@@ -51,6 +51,7 @@ struct Env {
     // episode / command state (cassie.py:71-78,117-119)
     int time, phase, counter;
     int est_age;               // env steps since the estimator object was set up
+    int phase_half, phase_add15;   // self.phase_add = 1.5 of the command harness (tools/test_commands.py:86, cassie.py:448): the phase is phase + 0.5 phase_half
     double speed, side_speed, orient_add;
     Clock clock;
     double swing_duration, stance_duration;     // of the current clock (observed by the phase command profile)

@@ -888,3 +888,26 @@ def test_min_input_profile_vs_oracle(dev):
                 np.testing.assert_allclose(obs[i, 6:10], o[6:10], atol=2e-3 * (t + 1)); np.testing.assert_allclose(obs[i, 13:21], o[13:21], atol=5e-3 * (t + 1), err_msg="foot orientations")
                 np.testing.assert_allclose(obs[i, 21:], o[21:], atol=1e-5)
         genv.close()
+
+
+def test_fractional_phase_add_vs_oracle(dev):
+    """self.phase_add = 1.5 of the command harness (tools/test_commands.py:86, cassie.py:448,511): the phase advances by 1.5 per env step and wraps on the float
+    comparison; clock entries of the observation and the clock reward follow the float phase.  40 steps (two wraps) against the oracle, mixed 1 / 1.5 batch."""
+    genv, oenv = _mk(False, 41, 64)
+    genv.reset_for_test(); [e.reset_for_test() for e in oenv[:8]]
+    pa = torch.tensor([1.5 if i % 2 == 0 else 1.0 for i in range(64)])
+    genv.set_command(speed=1.6, phase_add=pa)
+    for i, e in enumerate(oenv[:8]):
+        e.set("speed", [1.6]); e.set("phase_add", [float(pa[i]), 0])
+    zero = torch.zeros(64, 10, device=dev)
+    halves = 0
+    for t in range(40):
+        obs, rew, done, _ = genv.step(zero, auto_reset=False)
+        obs, rew = obs.cpu().numpy(), rew.cpu().numpy(); ints = genv.get_field("ints").cpu().numpy()
+        for i, e in enumerate(oenv[:8]):
+            o, r, d = e.step(np.zeros(10))
+            oi = e.get("ints"); half = int(e.get("phase_add")[1]); halves += half
+            assert int(ints[i, 1]) == int(oi[1]) and (int(ints[i, 4]) >> 5) & 1 == half and int(ints[i, 2]) == int(oi[2]), (t, i)
+            np.testing.assert_allclose(obs[i, 46:50], o[46:50], atol=2e-6)
+            assert abs(rew[i] - r) < 0.02 * (t + 1)
+    assert halves > 50 and int(oenv[0].get("ints")[2]) >= 1 and int(oenv[0].get("ints")[2]) > int(oenv[1].get("ints")[2]) - 1      # half phases occurred, the 1.5 envs wrapped

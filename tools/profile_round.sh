@@ -5,7 +5,7 @@
 #   3. FETCH_SIZE / WRITE_SIZE, two separate --pmc passes (guide: HBM)     -> profiles/<tag>_env_step_pmc_hbm.txt (+ hash of the kernel sources)
 # Everything is written under gpurun_out/prof_<tag>/ (merged back by gpurun); copy the .txt / .json files into profiles/ afterwards.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
@@ -28,6 +28,15 @@ python bench.py --workload cassietraj_recurrent --steps 3 --warmup 1 --no_cpu_ba
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/ktr -- python $ROOT/bench.py --workload cassietraj_recurrent --steps 2 --warmup 1 --no_cpu_baseline > $OUT/rec_under_rocprof.log 2>&1 || true)
 python $ROOT/tools/rocprof_summary.py $(ls $OUT/ktr/*/*.db | head -1) $OUT/${TAG}_recurrent_kernel_stats.txt > /dev/null || true
 rm -rf $OUT/ktr
+#   4b. MFMA pipe counters of the learner kernels (fused fp32 forward, gemm_f32_kernel<*>, gemm_bf16_kernel<*>), own --pmc passes  -> profiles/<tag>_learner_pmc_mfma.txt
+(cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $OUT/mfma -- python $ROOT/tools/t_pmc_learner.py > $OUT/mfma.log 2>&1 || true)
+python $ROOT/tools/pmc_summary.py $OUT/mfma $OUT/${TAG}_learner_pmc_mfma.txt "# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 -- python tools/t_pmc_learner.py (per-dispatch means; MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES)" > /dev/null || true
+rm -rf $OUT/mfma
+#   4c. TD3 workload: bench line + per-kernel time  -> profiles/<tag>_bench_line_td3.json, <tag>_td3_kernel_stats.txt
+python bench.py --workload cassie_td3 --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line_td3.json || true
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/ktt -- python $ROOT/bench.py --workload cassie_td3 --steps 2 --warmup 1 > $OUT/td3_under_rocprof.log 2>&1 || true)
+python $ROOT/tools/rocprof_summary.py $(ls $OUT/ktt/*/*.db | head -1) $OUT/${TAG}_td3_kernel_stats.txt > /dev/null || true
+rm -rf $OUT/ktt
 #   5. -ffast-math A/B of the env kernel (needs lib/libapx_nofm.so: make -C apex_amd/csrc VARIANT=nofm FASTMATH=)  -> profiles/<tag>_fastmath_ab.json
 if [ -f apex_amd/lib/libapx_nofm.so ]; then python tools/t_fastmath_ab.py > $OUT/${TAG}_fastmath_ab.json 2>$OUT/fastmath_ab.err || true; fi
 rm -rf $OUT/kt $OUT/sq $OUT/fetch $OUT/write $OUT/hbm
