@@ -49,6 +49,9 @@ template <int LEG> constexpr unsigned chain_mask(int body) {
     return m;
 }
 
+#ifndef APX_SUBTREE_DPP
+#define APX_SUBTREE_DPP 1      /* subtree sums by DPP prefix scans (round 3) instead of the descendant loop over LDS records */
+#endif
 #ifndef APX_CRBA_SB
 #define APX_CRBA_SB 0      /* scheduling barrier every n levels of the CRBA chain walk: measured 0 / 3 / 5 / 7 within 0.4 % */
 #endif
@@ -218,22 +221,22 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         own[sd] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
         sfor<0, 3>([&](auto K) { const V3 ax = col(mat[sd], K); cdof[sd][K] = {ax, cross(ax, r)}; own[sd] = own[sd] + cdof[sd][K] * qd[sd][K]; });
     });
-    // chain sum of a spatial vector (6 floats per body record)
+    // chain sum of a spatial vector: val_b <- sum of val over b and its ancestors inside the leg.  Bodies are numbered depth-first, so "a is an
+    // ancestor of b" is the interval test a <= b <= a + ndesc_a: add val_a at lane a, take it away again at lane a + ndesc_a + 1, and the inclusive
+    // prefix sum over the lanes is the chain sum.  The take-away lanes are fixed offsets (achilles rod -> knee, knee spring -> shin, heel spring ->
+    // foot crank: one lane up; foot crank and plantar rod -> foot), so the whole thing is 6 DPP row shifts and 6 adds per float: no LDS round trip
+    // (the pointer-jumping form of round 2 cost three store / fence / load rounds per sum).
+    static_assert(TB_NDESC == nib(11, 10, 9, 0, 7, 0, 5, 4, 0, 1, 0, 0), "take-away lanes of the chain sum");
+    const float cm1 = (lb == 4 || lb == 6 || lb == 9 || lb == 11) ? 1.f : 0.f, cm2 = lb == 11 ? 1.f : 0.f;
+    auto chain_scan = [&](float own) {
+        float d = own - cm1 * dpp<0x111>(own) - cm2 * dpp<0x112>(own);
+        d += dpp<0x111>(d); d += dpp<0x112>(d); d += dpp<0x114>(d); d += dpp<0x118>(d);
+        return d;
+    };
     auto chain_sum = [&](SV (&val)[2]) {
-        sfor<0, 3>([&](auto Rn) {
-            constexpr int r = Rn;
-            wsync();
-            sfor<0, 2>([&](auto Sd) {
-                float* p = xb + XB_SZ * xbody[Sd];
-                p[0] = val[Sd].a.x; p[1] = val[Sd].a.y; p[2] = val[Sd].a.z; p[3] = val[Sd].l.x; p[4] = val[Sd].l.y; p[5] = val[Sd].l.z;
-            });
-            wsync();
-            sfor<0, 2>([&](auto Sd) {
-                constexpr int sd = Sd;
-                const float* p = xb + XB_SZ * (2 + 12 * sd + (jump[r] == 15 ? lb : jump[r]));
-                const SV av = {{p[0], p[1], p[2]}, {p[3], p[4], p[5]}};
-                if (jump[r] != 15) val[sd] = val[sd] + av;
-            });
+        sfor<0, 2>([&](auto Sd) {
+            val[Sd].a.x = chain_scan(val[Sd].a.x); val[Sd].a.y = chain_scan(val[Sd].a.y); val[Sd].a.z = chain_scan(val[Sd].a.z);
+            val[Sd].l.x = chain_scan(val[Sd].l.x); val[Sd].l.y = chain_scan(val[Sd].l.y); val[Sd].l.z = chain_scan(val[Sd].l.z);
         });
     };
     sfor<0, 2>([&](auto Sd) { vel[Sd] = own[Sd]; });
@@ -285,6 +288,29 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
     wsync();
     PROF2(16);
     // ---- subtree sums (composite inertia, subtree force): descendants are the next ndesc bodies
+#if APX_SUBTREE_DPP
+    // depth-first numbering again: the subtree of b is the lane interval [b, b + ndesc_b], so its sum is prefix(b + ndesc_b) - prefix(b - 1).  The
+    // inclusive prefix is 4 DPP shift-adds; the upper end is lane 11 for the bodies on the path to the foot, the own lane for the leaves, lane 10 for
+    // the foot crank: one row broadcast and two selects.  No LDS reads (the loop form below re-reads up to 11 descendant records per lane).
+    {
+        static_assert(TB_NDESC == nib(11, 10, 9, 0, 7, 0, 5, 4, 0, 1, 0, 0), "upper ends of the subtree intervals");
+        const bool leaf = lb == 3 || lb == 5 || lb == 8 || lb == 10, crank = lb == 9;
+        auto subtree = [&](float x) {
+            float pz = x;
+            pz += dpp<0x111>(pz); pz += dpp<0x112>(pz); pz += dpp<0x114>(pz); pz += dpp<0x118>(pz);
+            float hi = dpp<0x150 + 11>(pz);
+            hi = leaf ? pz : hi; hi = crank ? dpp<0x101>(pz) : hi;
+            return hi - dpp<0x111>(pz);
+        };
+        sfor<0, 2>([&](auto Sd) {
+            constexpr int sd = Sd;
+            crb[sd].m = subtree(crb[sd].m); crb[sd].h.x = subtree(crb[sd].h.x); crb[sd].h.y = subtree(crb[sd].h.y); crb[sd].h.z = subtree(crb[sd].h.z);
+            sfor<0, 6>([&](auto K) { crb[sd].I[K] = subtree(crb[sd].I[K]); });
+            frc[sd].a.x = subtree(frc[sd].a.x); frc[sd].a.y = subtree(frc[sd].a.y); frc[sd].a.z = subtree(frc[sd].a.z);
+            frc[sd].l.x = subtree(frc[sd].l.x); frc[sd].l.y = subtree(frc[sd].l.y); frc[sd].l.z = subtree(frc[sd].l.z);
+        });
+    }
+#else
     // (a rolled, branch-free loop: a lane past its last descendant re-reads its own record with weight 0; both legs in one iteration)
     _Pragma("unroll 1") for (int i = 1; i <= 11; ++i) {
         const bool on = i <= ndesc;
@@ -298,6 +324,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             frc[sd].a = frc[sd].a + V3{p[10], p[11], p[12]} * w; frc[sd].l = frc[sd].l + V3{p[13], p[14], p[15]} * w;
         });
     }
+#endif
     wsync();
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
@@ -820,7 +847,7 @@ __device__ __forceinline__ float floor_dist_dev(const Hf& hf, V3 fn, V3 c, float
     return (c.z - hh) * inv - rad;
     }
 }
-constexpr int MAXX = 2;
+constexpr int MAXX = 3;      // leg-leg rows on lanes 13, 14, 15 (round 3: a policy recovering from a push keeps three capsule pairs in contact)
 struct XPair { int gi, gj; V3 n, cp; float dist; };
 constexpr int XSEL = 80, XSEL_SZ = 12;                    // compacted records of the MAXX selected pairs behind the 9 pair records (floats in the row scratch)
 // the selected pair of lane 13 + k (k < nx), re-read where it is needed instead of being carried in registers through the row stage

@@ -140,8 +140,10 @@ __device__ __forceinline__ void stage1_io_lane(St S, int mode, float* estrec) { 
         _Pragma("unroll") for (int i = 0; i < 3; ++i) S(F_SO + SO_ROTVEL + i) = S(F_SNAP + SN_GYRO + i);
     }
     c4::wsync();                                          // the encoder lanes' outputs are the estimator's inputs
+    PROF2(37);
     est::est_step_lane(S, rec);                           // the 7 filtered fields: translationalVelocity, translationalAcceleration, height
     est::rec_store(estrec, S.env, l, rec);
+    PROF2(38);
     PROF(0);
 }
 __device__ APX_STAGE void stage1b_tree_lane(St S) {

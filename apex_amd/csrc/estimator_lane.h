@@ -157,6 +157,7 @@ __device__ __forceinline__ void est_step_lane(const St& S, Rec& rec) {
             heel[lg] = fminf(fmaxf(heel[lg] - r * rcpf(gX[lg]), -HEEL_LIM), HEEL_LIM);      // (the Jacobian below takes the gradient of the second evaluation point: O(step^2) off the root)
         });
     });
+    PROF2(33);
     // ---------------------------------------------------------------- leg kinematics: local transforms, prefix product over the chain
     const int k = l & 7, lg = l >> 3;
     constexpr unsigned long long KB = c4::nib(2, 3, 4, 6, 8, 9, 13, 2, 0, 0, 0, 0);
@@ -182,6 +183,7 @@ __device__ __forceinline__ void est_step_lane(const St& S, Rec& rec) {
         o = {ok ? on.x : o.x, ok ? on.y : o.y, ok ? on.z : o.z};
         q = {ok ? qn.w : q.w, ok ? qn.x : q.x, ok ? qn.y : q.y, ok ? qn.z : q.z};
     });
+    PROF2(34);
     // foot-frame origin on the foot lanes (k == 6), handed to the shin / tarsus lanes (row_shl 2 / 1) for d foot / d angle = z x (foot - joint origin)
     const V3 pf = o + qrot(q, V3{FOOT_OFF_X, FOOT_OFF_Y, 0.f});
     const V3 p1 = {dpp<0x101>(pf.x), dpp<0x101>(pf.y), dpp<0x101>(pf.z)}, p2 = {dpp<0x102>(pf.x), dpp<0x102>(pf.y), dpp<0x102>(pf.z)};
@@ -221,6 +223,7 @@ __device__ __forceinline__ void est_step_lane(const St& S, Rec& rec) {
     const c4::M3 Rp = c4::q2m(pq);
     const V3 ab = {S(F_SNAP + SN_ACC) - Rp.m[6] * E_G - cen.x, S(F_SNAP + SN_ACC + 1) - Rp.m[7] * E_G - cen.y, S(F_SNAP + SN_ACC + 2) - Rp.m[8] * E_G - cen.z};
     const V3 aw = c4::mul(Rp, ab);
+    PROF2(35);
     // ---------------------------------------------------------------- first call after state_output_setup: zero pelvis state, feet at MINUS the offset
     if (inited == 0.f) {
         sfor<0, 6>([&](auto B) { const float dg = (row && l == B) ? 1e-6f : 0.f; fx.P[B] = dg; fy.P[B] = dg; fz.P[B] = (B < 5) ? dg : 0.f; });
@@ -231,6 +234,7 @@ __device__ __forceinline__ void est_step_lane(const St& S, Rec& rec) {
     hfilter_step(fx, l, -lfx, -rfx, fl, fr, aw.x);
     hfilter_step(fy, l, -lfy, -rfy, fl, fr, aw.y);
     zfilter_step(fz, l, -lfz, -rfz, fl, fr);
+    PROF2(36);
     // ---------------------------------------------------------------- terrain height: low-pass of the load-weighted kinematic foot height while loaded
     const float pz = bc<0>(fz.x);
     if (fl + fr > 1.f) {

@@ -20,10 +20,11 @@ _SOLVES = 2 * 5 * 307               # u~, v~, w~, qacc, Euler rhs/solve
 _ROWS = 20 * (2 * 60 + 2 * 100 + 2 * 19 * 4)     # Jacobian + whitening + commit dots
 _PGS = 50 * 20 * (2 * 19 * 2 + 8)
 _MISC = 1500
-SUBSTEP_FLOP = _FK + _INERTIA + _VEL_RNE + _CRBA + _FACTOR + _SOLVES + _ROWS + _PGS + _MISC
+_EST = 2 * 2 * 13 * 8 + 14 * 60 + 475 + 170      # state estimator in its lane form (estimator_lane.h): two closure evaluations per leg, leg kinematics, three Kalman filters, force solve / IMU
+SUBSTEP_FLOP = _FK + _INERTIA + _VEL_RNE + _CRBA + _FACTOR + _SOLVES + _ROWS + _PGS + _MISC + _EST
 ENV_STEP_FLOP = 50 * SUBSTEP_FLOP
 # The figure the roofline uses: INSTRUMENTED count of the fp64 CPU restatement (oracle/cassie_phys.cpp counts every multiply / add where it
 # happens, skipping structural zeros of its dense loops), mean over 60 env steps of a random-action rollout with
-# resets: `python -c "from oracle import sim; print(sim.count_flops(60))"` -> 6.86e6.  bench.py re-measures it in its cpu_baseline leg and
+# resets: `python -c "from oracle import sim; print(sim.count_flops(60))"` -> 7.17e6.  bench.py re-measures it in its cpu_baseline leg and
 # reports both; this constant is what is used when that leg is skipped.
-ENV_STEP_FLOP_COUNTED = 6_860_000
+ENV_STEP_FLOP_COUNTED = 7_170_000      # round 3: + the restated state estimator (oracle/cassie_estimator.cpp is instrumented the same way), 6.86e6 before

@@ -3,6 +3,10 @@
 
 namespace orc {
 
+// instrumented operation count, same convention as cassie_phys.cpp (multiplies + adds where they happen, structural zeros skipped, one per transcendental)
+#define CNT(n) (g_flops += (unsigned long long)(n))
+#define NZ(a, b) (((a) != 0.0 && (b) != 0.0) ? 2 : 0)
+
 namespace {
 constexpr double EST_DT = 0.0005, EST_G = 9.806, EST_H = 1.0, EST_M = 31.0;      // filter constants of state_output_setup (object dump: dt, g, pendulum height, mass)
 constexpr double K_SHIN = 1500.0, K_HEEL = 1250.0;                               // leg-spring stiffnesses the routine uses (cassie.xml:117,127)
@@ -48,9 +52,9 @@ void foot_kinematics(int leg, const double q[7], V3& p, V3& dshin, V3& dtarsus, 
         const double c = std::cos(ang), s = std::sin(ang);
         const M3 Rz = {{c, -s, 0, s, c, 0, 0, 0, 1}};
         R = matmul(matmul(R, q2m(Q4{cm_body_quat[4 * b], cm_body_quat[4 * b + 1], cm_body_quat[4 * b + 2], cm_body_quat[4 * b + 3]})), Rz);
-        jo[k] = o; jR[k] = R;
+        jo[k] = o; jR[k] = R; CNT(15 + 3 + 2 + 45 + 36);      // origin, angle, sin / cos, two 3 x 3 products (the joint rotation has 4 non-trivial entries)
     }
-    p = o + mul(R, v3(FOOT_OFF)); Rfoot = R;
+    p = o + mul(R, v3(FOOT_OFF)); Rfoot = R; CNT(15 + 2 * (9 + 3));
     dshin = cross(col(jR[4], 2), p - jo[4]);
     dtarsus = cross(col(jR[5], 2), p - jo[5]);
 }
@@ -60,16 +64,17 @@ void kf_scalar_update(int n, double* x, double* P, int i, int j, double z, doubl
     double Ph[6], hP[6];
     for (int a = 0; a < n; ++a) { Ph[a] = P[a * n + i] - (j >= 0 ? P[a * n + j] : 0.0); hP[a] = P[i * n + a] - (j >= 0 ? P[j * n + a] : 0.0); }
     const double s = Ph[i] - (j >= 0 ? Ph[j] : 0.0) + r, innov = z - (x[i] - (j >= 0 ? x[j] : 0.0));
+    CNT((j >= 0 ? 2 * n : 0) + 4);
     for (int a = 0; a < n; ++a) {
         const double K = Ph[a] / s;
-        x[a] += K * innov;
-        for (int b = 0; b < n; ++b) P[a * n + b] -= K * hP[b];
+        x[a] += K * innov; CNT(Ph[a] != 0.0 ? 3 : 0);
+        for (int b = 0; b < n; ++b) { CNT(NZ(K, hP[b])); P[a * n + b] -= K * hP[b]; }
     }
 }
 void apa(int n, const double* A, double* P) {      // P <- A P A^T
     double T[36], R[36];
-    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double s = 0; for (int k = 0; k < n; ++k) s += A[i * n + k] * P[k * n + j]; T[i * n + j] = s; }
-    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double s = 0; for (int k = 0; k < n; ++k) s += T[i * n + k] * A[j * n + k]; R[i * n + j] = s; }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double s = 0; for (int k = 0; k < n; ++k) { CNT(i == k ? 0 : NZ(A[i * n + k], P[k * n + j])); s += A[i * n + k] * P[k * n + j]; } T[i * n + j] = s; }      // (the unit diagonal of A costs nothing)
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double s = 0; for (int k = 0; k < n; ++k) { CNT(j == k ? 0 : NZ(T[i * n + k], A[j * n + k])); s += T[i * n + k] * A[j * n + k]; } R[i * n + j] = s; }
     for (int i = 0; i < n * n; ++i) P[i] = R[i];
 }
 // horizontal filter step (0x1cd10): extended Kalman filter on the linear inverted pendulum
@@ -83,7 +88,7 @@ void hfilter_step(double* x, double* P, double zL, double zR, double fl, double 
     A[1] = EST_DT;
     x[0] = p + EST_DT * v;
     if (contact) {
-        x[1] = v + EST_DT * (w2 * (p - al * pL - (1 - al) * pR) + fd / EST_M);
+        x[1] = v + EST_DT * (w2 * (p - al * pL - (1 - al) * pR) + fd / EST_M); CNT(11 + 12);
         A[6] = EST_DT * w2; A[8] = -EST_DT * w2 * al; A[9] = -EST_DT * w2 * (1 - al); A[10] = -EST_DT * w2 * (pL - pR); A[11] = EST_DT / EST_M;
     }
     apa(6, A, P);
@@ -122,8 +127,8 @@ double heel_residual(double knee, double shin, double tarsus, double heel, doubl
     if (grad4) grad4[0] = grad4[1] = grad4[2] = grad4[3] = 0;
     for (const auto& t : kHeelTerm) {
         const double u = t[0] * knee + t[1] * shin + t[2] * tarsus + t[3] * heel + t[5];
-        r += t[4] * std::cos(u);
-        if (grad4) { const double ds = -t[4] * std::sin(u); for (int k = 0; k < 4; ++k) grad4[k] += ds * t[k]; }
+        r += t[4] * std::cos(u); CNT(2 * ((t[0] != 0) + (t[1] != 0) + (t[2] != 0) + (t[3] != 0)) + 1 + 3);
+        if (grad4) { const double ds = -t[4] * std::sin(u); for (int k = 0; k < 4; ++k) { CNT(t[k] != 0 ? 2 : 0); grad4[k] += ds * t[k]; } CNT(2); }
     }
     return r;
 }
@@ -151,7 +156,7 @@ void heel_solve(double heel[2], const double legL[3], const double legR[3], int*
             double xn[2] = {std::min(std::max(x[0] + h[0], HEEL_LB), HEEL_UB), std::min(std::max(x[1] + h[1], HEEL_LB), HEEL_UB)}, rn[2], Jn[2];
             eval(xn, rn, Jn);
             const double Fn = 0.5 * (rn[0] * rn[0] + rn[1] * rn[1]);
-            const double rho = (F - Fn) / (0.5 * (h[0] * (mu * h[0] - g[0]) + h[1] * (mu * h[1] - g[1])));
+            const double rho = (F - Fn) / (0.5 * (h[0] * (mu * h[0] - g[0]) + h[1] * (mu * h[1] - g[1]))); CNT(4 + 6 + 3 + 12 + 6);
             if (rho > 0) {
                 for (int i = 0; i < 2; ++i) { x[i] = xn[i]; r[i] = rn[i]; J[i] = Jn[i]; g[i] = J[i] * r[i]; A[i] = J[i] * J[i]; }
                 F = Fn;
@@ -177,6 +182,7 @@ void mldivide23(const double M[2][3], const double tau[2], double x[3]) {
         const double pr = e0 * M[0][j] + e1 * M[1][j], a = M[0][j] - e0 * pr, b = M[1][j] - e1 * pr, n = a * a + b * b;
         if (n > best) { best = n; j2 = j; }
     }
+    CNT(9 + 2 * 14 + 3 + 8);      // column norms, projections, 2 x 2 solve
     const double det = M[0][j1] * M[1][j2] - M[0][j2] * M[1][j1];
     x[0] = x[1] = x[2] = 0;
     x[j1] = (tau[0] * M[1][j2] - M[0][j2] * tau[1]) / det;
@@ -204,6 +210,7 @@ void state_output_step(StateOutput& s, const EstSensors& in) {
             s.foot_quat[leg][0] = w; s.foot_quat[leg][1] = (Re.m[7] - Re.m[5]) / (4 * w); s.foot_quat[leg][2] = (Re.m[2] - Re.m[6]) / (4 * w); s.foot_quat[leg][3] = (Re.m[3] - Re.m[1]) / (4 * w);
         }
         heel_residual(q[3], q[4], q[5], s.heel[leg], gr);
+        CNT(2 * 9 + 8 + 9 + 15);           // two cross products (foot_kinematics), closure Jacobian, rotation of the force
         const V3 a = dS - dT * (gr[1] / gr[2]), b = dT * (-gr[3] / gr[2]);       // d foot / d shin, d foot / d heel spring: the tarsus angle follows the closure
         const double M[2][3] = {{-a.x, -a.y, -a.z}, {-b.x, -b.y, -b.z}}, tau[2] = {K_SHIN * in.jpos[3 * leg], K_HEEL * s.heel[leg]};
         double f[3];
@@ -218,7 +225,7 @@ void state_output_step(StateOutput& s, const EstSensors& in) {
     const V3 w = v3(in.gyro), cen = cross(w, cross(w, v3(IMU_R))), gb = mulT(R, V3{0, 0, EST_G});
     const V3 ab = {in.acc[0] - gb.x - cen.x, in.acc[1] - gb.y - cen.y, in.acc[2] - gb.z - cen.z};
     s.tacc[0] = ab.x; s.tacc[1] = ab.y; s.tacc[2] = ab.z;
-    const V3 aw = mul(R, ab);
+    const V3 aw = mul(R, ab); CNT(12 + 15 + 18 + 15 + 2 * 15);      // quaternion to matrix, gravity, centripetal term, world acceleration, world foot offsets
     const double lf[3] = {fw[0].x, fw[0].y, fw[0].z}, rf[3] = {fw[1].x, fw[1].y, fw[1].z}, awv[3] = {aw.x, aw.y, aw.z};
     // --- first call after setup (0x2d9c0-0x2e26f): zero pelvis state, foot states at MINUS the kinematic foot offset, P = 1e-6 I
     if (!s.inited) {

@@ -24,7 +24,7 @@ constexpr int NB = CM_NBODY, NV = CM_NV, NQ = CM_NQ, NJ = CM_NJNT, NG = CM_NGEOM
 // pyramidal), and the 3 x 3 left-right capsule pairs (condim 1, frictionless).  The HIP kernel keeps the first KERNEL_MAXCON_LEG floor
 // contacts (order foot, tarsus, shin), the first KERNEL_MAXLIM_LEG limit per leg and the first KERNEL_MAXLEGLEG leg-leg pairs; `State::sat` reports when a
 // substep needed more, so that the cap is a checked property of a rollout, not an assumption.
-constexpr int KERNEL_MAXCON_LEG = 2, KERNEL_MAXLIM_LEG = 1, KERNEL_MAXLEGLEG = 2;
+constexpr int KERNEL_MAXCON_LEG = 2, KERNEL_MAXLIM_LEG = 1, KERNEL_MAXLEGLEG = 3;
 constexpr int MAXCON_LEG = 8, MAXLIM_LEG = 8;      // 4 capsules x 2 ends; 8 limited joints per leg
 constexpr int MAXCON = 2 * MAXCON_LEG + 1, MAXLIM = 2 * MAXLIM_LEG, MAXCON1 = 9;      // + pelvis sphere; 9 frictionless leg-leg contacts
 constexpr int MAXEFC = 3 * NEQ + MAXLIM + 4 * MAXCON + MAXCON1;

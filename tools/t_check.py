@@ -4,7 +4,8 @@ out-of-range S(f) / S.W(i) / S.I(f) index the kernels saw.  Prints `oob [kind, i
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-assert "check" in os.environ.get("APX_LIB", ""), "run with APX_LIB=<path to libapx_check.so>"
+LIB = os.environ.get("APX_LIB", "")
+assert "check" in LIB or "asan" in LIB, "run with APX_LIB=<path to libapx_check.so> (or libapx_asan.so under tools/t_asan.sh: the sanitizer reports by itself)"
 from apex_amd.vecenv import CassieVecEnv
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 torch.manual_seed(0)
@@ -22,7 +23,7 @@ for kw in (dict(), dict(command_profile="phase"), dict(env_name="CassieTraj-v0")
         env.set_hfield(None)
     env.reset_for_test(full_reset=True); env.step_basic(torch.zeros(256, 10, device="cuda")); env.reset_for_test(); env.update_speed(1.0)
     env.apply_force(torch.tensor([50.0, 0, 0, 0, 0, 0])); env.step(torch.zeros(256, 10, device="cuda"))
-    oob = env.get_field("oob")[0, :4].cpu().numpy()
+    oob = env.get_field("oob")[0, :4].cpu().numpy() if "check" in LIB else np.zeros(4)
     print("variant %s: oob %s" % (kw, oob.astype(int).tolist()))
     if oob[0] != 0 and worst is None: worst = oob
 print("RESULT", "clean" if worst is None else worst.astype(int).tolist())

@@ -26,6 +26,7 @@ fine = {12: "tree: constants, pelvis, joint quats", 13: "tree: pose pointer-jump
         20: "factor: elimination + pelvis block", 21: "factor: store", 23: "rows leg 0 (tail: scalars)", 24: "rows leg 1 (tail: scalars)",
         25: "rows: limit/contact detection + Jacobian (both legs)", 26: "rows: raw dots (both legs)", 27: "rows: whitening (both legs)",
         28: "finish: factor load + vectors", 29: "finish: qacc solve + sensors", 30: "finish: rhs = smooth + L^T D^1/2 z", 31: "finish: second factorisation",
-        32: "finish: solves"}
+        32: "finish: solves", 37: "io: encoders, PD, safety, delay line", 33: "estimator: record unpack + heel springs (2 Newton steps)", 34: "estimator: leg kinematics (DPP prefix product)",
+        35: "estimator: spring Jacobian, force solve, IMU", 36: "estimator: three Kalman filters", 38: "estimator: terrain, outputs, record store"}
 if p[12:].sum() > 0:
     for k in sorted(fine): print("  [%2d] %-52s %8.0f" % (k, fine[k], p[k]))
