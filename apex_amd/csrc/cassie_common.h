@@ -23,6 +23,12 @@ template <int B, int E, class F> __device__ __forceinline__ void srfor(F&& f) { 
     if constexpr (B < E) { f(std::integral_constant<int, E - 1>{}); srfor<B, E - 1>(f); }
 }
 
+// Bit pattern of a float, opaque to the optimiser.  The env kernels are built with -ffast-math; there LLVM recognises `(bits & 0x7f800000) == 0x7f800000` on
+// a plain bitcast as "is NaN or inf" and folds it to false (round 3: the disassembly held no trace of the round-2 divergence guards).  The empty asm
+// hides where the integer came from.
+__device__ __forceinline__ unsigned fbits(float v) { unsigned u = __float_as_uint(v); asm volatile("" : "+v"(u)); return u; }
+__device__ __forceinline__ bool nonfinite(float v) { return (fbits(v) & 0x7f800000u) == 0x7f800000u; }      // NaN or +-inf
+
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }

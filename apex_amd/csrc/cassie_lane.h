@@ -49,9 +49,6 @@ template <int LEG> constexpr unsigned chain_mask(int body) {
     return m;
 }
 
-#ifndef APX_SUBTREE_DPP
-#define APX_SUBTREE_DPP 1      /* subtree sums by DPP prefix scans (round 3) instead of the descendant loop over LDS records */
-#endif
 #ifndef APX_CRBA_SB
 #define APX_CRBA_SB 0      /* scheduling barrier every n levels of the CRBA chain walk: measured 0 / 3 / 5 / 7 within 0.4 % */
 #endif
@@ -288,29 +285,10 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
     wsync();
     PROF2(16);
     // ---- subtree sums (composite inertia, subtree force): descendants are the next ndesc bodies
-#if APX_SUBTREE_DPP
-    // depth-first numbering again: the subtree of b is the lane interval [b, b + ndesc_b], so its sum is prefix(b + ndesc_b) - prefix(b - 1).  The
-    // inclusive prefix is 4 DPP shift-adds; the upper end is lane 11 for the bodies on the path to the foot, the own lane for the leaves, lane 10 for
-    // the foot crank: one row broadcast and two selects.  No LDS reads (the loop form below re-reads up to 11 descendant records per lane).
-    {
-        static_assert(TB_NDESC == nib(11, 10, 9, 0, 7, 0, 5, 4, 0, 1, 0, 0), "upper ends of the subtree intervals");
-        const bool leaf = lb == 3 || lb == 5 || lb == 8 || lb == 10, crank = lb == 9;
-        auto subtree = [&](float x) {
-            float pz = x;
-            pz += dpp<0x111>(pz); pz += dpp<0x112>(pz); pz += dpp<0x114>(pz); pz += dpp<0x118>(pz);
-            float hi = dpp<0x150 + 11>(pz);
-            hi = leaf ? pz : hi; hi = crank ? dpp<0x101>(pz) : hi;
-            return hi - dpp<0x111>(pz);
-        };
-        sfor<0, 2>([&](auto Sd) {
-            constexpr int sd = Sd;
-            crb[sd].m = subtree(crb[sd].m); crb[sd].h.x = subtree(crb[sd].h.x); crb[sd].h.y = subtree(crb[sd].h.y); crb[sd].h.z = subtree(crb[sd].h.z);
-            sfor<0, 6>([&](auto K) { crb[sd].I[K] = subtree(crb[sd].I[K]); });
-            frc[sd].a.x = subtree(frc[sd].a.x); frc[sd].a.y = subtree(frc[sd].a.y); frc[sd].a.z = subtree(frc[sd].a.z);
-            frc[sd].l.x = subtree(frc[sd].l.x); frc[sd].l.y = subtree(frc[sd].l.y); frc[sd].l.z = subtree(frc[sd].l.z);
-        });
-    }
-#else
+    // (Two DPP forms were measured in round 3 and dropped.  Prefix differences, prefix(b + ndesc) - prefix(b - 1): the inertia of a 0.1 kg rod as the
+    // difference of two whole-leg prefixes loses its digits in fp32, the mass matrix stops being positive definite, every env is NaN within a step.
+    // A bottom-up sweep "s += [lane is the parent] * s(lane + k)", 11 child edges per float: correct, but 352 dependent v_mov_dpp + v_fmac pairs are
+    // slower than the loop's 88 ds_read_b128 + 352 v_fmac: 2.79 ms against 2.74 ms per launch.)
     // (a rolled, branch-free loop: a lane past its last descendant re-reads its own record with weight 0; both legs in one iteration)
     _Pragma("unroll 1") for (int i = 1; i <= 11; ++i) {
         const bool on = i <= ndesc;
@@ -324,7 +302,6 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             frc[sd].a = frc[sd].a + V3{p[10], p[11], p[12]} * w; frc[sd].l = frc[sd].l + V3{p[13], p[14], p[15]} * w;
         });
     }
-#endif
     wsync();
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
@@ -393,12 +370,13 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         const int d = l < 13 ? 6 + 13 * sd + l : (l - 13) + 3 * sd;
         const int db = l < 13 ? 2 + 12 * sd + (l == 12 ? 11 : nibble(TD_BODY, l)) : 1;
         SI c; SV fsub;
-        if (l < 13) {
+        {   // (selects, not a branch around a struct copy: the copy form kept the pelvis composite in a 40-byte stack object = scratch)
+            const bool leg = l < 13;
             const float* p = xb + XB_SZ * db;
-            c.m = p[0]; c.h = {p[1], p[2], p[3]};
-            sfor<0, 6>([&](auto K) { c.I[K] = p[4 + K]; });
-            fsub = {{p[10], p[11], p[12]}, {p[13], p[14], p[15]}};
-        } else { c = pcrb; fsub = pfrc; }
+            c.m = leg ? p[0] : pcrb.m; c.h = {leg ? p[1] : pcrb.h.x, leg ? p[2] : pcrb.h.y, leg ? p[3] : pcrb.h.z};
+            sfor<0, 6>([&](auto K) { c.I[K] = leg ? p[4 + K] : pcrb.I[K]; });
+            fsub = {{leg ? p[10] : pfrc.a.x, leg ? p[11] : pfrc.a.y, leg ? p[12] : pfrc.a.z}, {leg ? p[13] : pfrc.l.x, leg ? p[14] : pfrc.l.y, leg ? p[15] : pfrc.l.z}};
+        }
         const float* cp = (const float*)&S.W(WK_CDOF + 6 * d);
         const SV cd = {{cp[0], cp[1], cp[2]}, {cp[3], cp[4], cp[5]}};
         const SV f = imul(c, cd);
@@ -847,7 +825,10 @@ __device__ __forceinline__ float floor_dist_dev(const Hf& hf, V3 fn, V3 c, float
     return (c.z - hh) * inv - rad;
     }
 }
-constexpr int MAXX = 3;      // leg-leg rows on lanes 13, 14, 15 (round 3: a policy recovering from a push keeps three capsule pairs in contact)
+#ifndef APX_MAXX
+#define APX_MAXX 3
+#endif
+constexpr int MAXX = APX_MAXX;      // leg-leg rows on lanes 13, 14, 15 (round 3: a policy recovering from a push keeps three capsule pairs in contact)
 struct XPair { int gi, gj; V3 n, cp; float dist; };
 constexpr int XSEL = 80, XSEL_SZ = 12;                    // compacted records of the MAXX selected pairs behind the 9 pair records (floats in the row scratch)
 // the selected pair of lane 13 + k (k < nx), re-read where it is needed instead of being carried in registers through the row stage

@@ -564,8 +564,8 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
         const int time = S.I(I_TIME) + 1;
         advance_phase(S);
         S.I(I_TIME) = time; S.I(I_AGE) += 1;
-        // NaN test on the bit pattern: it must survive -ffast-math (finite-math-only would fold `h != h` away)
-        const bool h_nan = (__float_as_uint(height) & 0x7fffffffu) > 0x7f800000u;
+        // non-finite test on the bit pattern, through c4::fbits: it must survive -ffast-math (finite-math-only folds `h != h` AND the plain bit test away)
+        const bool h_nan = c4::nonfinite(height);
         int dn = (height < 0.4f || height > 3.0f || h_nan) ? 1 : 0;
         int flags = S.I(I_FLAGS);
         if (!(flags & 4)) for (int u = 0; u < 10; ++u) S(F_PREVACT + u) = act[u];
@@ -574,7 +574,10 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
         float rew = clock_reward(S, cfg, act, lfrc, rfrc, lor, ror);
         // a diverged env (non-finite height or reward) ends its episode with reward 0: one NaN in the rollout grid would poison the
         // return scan, the advantage moments and from there every parameter (bit-pattern tests: they must survive -ffast-math)
-        if ((__float_as_uint(rew) & 0x7f800000u) == 0x7f800000u || h_nan) { rew = 0.f; dn = 1; }
+        if (c4::nonfinite(rew) || h_nan) {
+            rew = 0.f; dn = 1;
+            S.I(I_FLAGS) &= ~3;      // the encoder filters restart from the first sample after the reset: the joint-velocity biquad is recursive and would carry a NaN for ever
+        }
         for (int u = 0; u < 10; ++u) { S(F_PREVACT + u) = act[u]; S(F_PREVTQ + u) = S(F_SO + SO_TORQUE + u); }
         {   // command resampling, cassie.py:483-491; fixed 6 draws per step
             Rng r{cfg.seed_lo, cfg.seed_hi, cfg.env_base + (unsigned)env, (unsigned)S.I(I_RNG)};

@@ -20,7 +20,7 @@
 #include "cassie_lane.h"
 
 namespace est {
-using c4::V3; using c4::Q4; using c4::dpp; using c4::sfor; using c4::rcpf;
+using c4::V3; using c4::Q4; using c4::dpp; using c4::sfor; using c4::rcpf; using c4::nonfinite;
 
 constexpr int REC = 168;                       // floats per env: lane r < 7 owns [24 r, 24 r + 24)
 // lanes 0..5: Px[6] Py[6] Pz[6] xX xY xZ pad3;  lane 6: heelL heelR terrain inited | L foot pos3 pad | R foot pos3 pad | L foot quat4 | R foot quat4 | pad4
@@ -133,9 +133,18 @@ __device__ __forceinline__ void est_step_lane(const St& S, Rec& rec) {
     const bool row = l < 6;
     sfor<0, 6>([&](auto B) { fx.P[B] = row ? fx.P[B] : 0.f; fy.P[B] = row ? fy.P[B] : 0.f; fz.P[B] = row ? fz.P[B] : 0.f; });
     fx.x = row ? fx.x : 0.f; fy.x = row ? fy.x : 0.f; fz.x = row ? fz.x : 0.f;
-    float heel[2] = {bc<6>(rec.v[0][0]), bc<6>(rec.v[0][1])};
-    float terr = bc<6>(rec.v[0][2]);
-    const float inited = bc<6>(rec.v[0][3]);
+    // a non-finite word anywhere in the stored record (fast-math min / max clamps would turn some of them into finite garbage instead of carrying them to
+    // the test after the update): this update starts from state_output_setup.  One hardware add chain per lane carries a NaN / inf to a single bit test.
+    float rsum = 0.f;
+    sfor<0, 6>([&](auto K) { rsum += (rec.v[K][0] + rec.v[K][1]) + (rec.v[K][2] + rec.v[K][3]); });
+    const bool stale = c4::red16(nonfinite(rsum) ? 1.f : 0.f) > 0.f;
+    if (stale) {
+        sfor<0, 6>([&](auto B) { fx.P[B] = fy.P[B] = fz.P[B] = 0.f; });
+        fx.x = fy.x = fz.x = 0.f;
+    }
+    float heel[2] = {stale ? 0.f : bc<6>(rec.v[0][0]), stale ? 0.f : bc<6>(rec.v[0][1])};
+    float terr = stale ? 0.f : bc<6>(rec.v[0][2]);
+    const float inited = stale ? 0.f : bc<6>(rec.v[0][3]);
     // ---------------------------------------------------------------- heel springs: two Newton steps on the closure series, one term per lane
     const int lt = l < 13 ? l : 12;
     const float hc = l < 13 ? selN<13>(lt, [](auto K) { return HT_C[K]; }) : 0.f, hp = selN<13>(lt, [](auto K) { return HT_P[K]; });
@@ -248,6 +257,15 @@ __device__ __forceinline__ void est_step_lane(const St& S, Rec& rec) {
         S(F_SO + SO_TACC) = ab.x; S(F_SO + SO_TACC + 1) = ab.y; S(F_SO + SO_TACC + 2) = ab.z;
         S(F_SO + SO_HEIGHT) = pz - terr;
     }
+    // a diverged env (non-finite sensors) must not poison the persistent record: restart the estimator (state_output_setup) on the next substep
+    // (c4::nonfinite: a bit-pattern test that survives -ffast-math).  One NaN anywhere in a filter reaches every row's state within the update.
+    const bool badl = nonfinite(fx.x) || nonfinite(fy.x) || nonfinite(fz.x) || nonfinite(heel[0]) || nonfinite(heel[1]) || nonfinite(terr) || nonfinite(fx.P[0]) || nonfinite(fy.P[0]) || nonfinite(fz.P[0]);
+    const bool bad = c4::red16(badl ? 1.f : 0.f) > 0.f;
+    float keep = bad ? 0.f : 1.f;
+    if (bad) {
+        sfor<0, 6>([&](auto B) { fx.P[B] = fy.P[B] = fz.P[B] = 0.f; });
+        fx.x = fy.x = fz.x = 0.f; heel[0] = heel[1] = 0.f; terr = 0.f;
+    }
     sfor<0, 6>([&](auto B) { constexpr int b = B; rec.v[b / 4][b % 4] = fx.P[b]; rec.v[(6 + b) / 4][(6 + b) % 4] = fy.P[b]; rec.v[(12 + b) / 4][(12 + b) % 4] = fz.P[b]; });
     rec.v[4][2] = fx.x; rec.v[4][3] = fy.x; rec.v[5][0] = fz.x;
     // leftFoot / rightFoot .position and .orientation (input_profile "min", cassie.py:829-837): foot body frame times the routine's constant frame offset
@@ -255,8 +273,9 @@ __device__ __forceinline__ void est_step_lane(const St& S, Rec& rec) {
     if (fq.w < 0.f) fq = {-fq.w, -fq.x, -fq.y, -fq.z};
     const float rpx = bc<14>(pf.x), rpy = bc<14>(pf.y), rpz = bc<14>(pf.z), rqw = bc<14>(fq.w), rqx = bc<14>(fq.x), rqy = bc<14>(fq.y), rqz = bc<14>(fq.z);
     if (l == 6) {
-        rec.v[0][0] = heel[0]; rec.v[0][1] = heel[1]; rec.v[0][2] = terr; rec.v[0][3] = 1.f;
-        rec.v[1] = f4{pf.x, pf.y, pf.z, 0.f}; rec.v[2] = f4{rpx, rpy, rpz, 0.f}; rec.v[3] = f4{fq.w, fq.x, fq.y, fq.z}; rec.v[4] = f4{rqw, rqx, rqy, rqz};
+        rec.v[0][0] = heel[0]; rec.v[0][1] = heel[1]; rec.v[0][2] = terr; rec.v[0][3] = keep;
+        rec.v[1] = bad ? f4{0.f, 0.f, 0.f, 0.f} : f4{pf.x, pf.y, pf.z, 0.f}; rec.v[2] = bad ? f4{0.f, 0.f, 0.f, 0.f} : f4{rpx, rpy, rpz, 0.f};
+        rec.v[3] = bad ? f4{1.f, 0.f, 0.f, 0.f} : f4{fq.w, fq.x, fq.y, fq.z}; rec.v[4] = bad ? f4{1.f, 0.f, 0.f, 0.f} : f4{rqw, rqx, rqy, rqz};
     }
 }
 
