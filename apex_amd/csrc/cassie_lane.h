@@ -49,6 +49,20 @@ template <int LEG> constexpr unsigned chain_mask(int body) {
     return m;
 }
 
+#ifndef APX_SUBTREE_SFX
+#define APX_SUBTREE_SFX 1  /* subtree sums as DPP suffix sums (round 3) instead of the descendant loop over LDS records */
+#endif
+#ifndef APX_CRBA_DPP
+#define APX_CRBA_DPP 1     /* mass-matrix off-diagonals by row broadcasts over the ancestor dofs (round 3) instead of the per-lane chain walk through LDS */
+#endif
+// level of leg dof j in the ancestor chain of leg dof lane l (1 = parent dof, ...; 0 = j is not a proper ancestor of l), one nibble per lane
+constexpr unsigned long long crba_level_table(int j) {
+    unsigned long long t = 0;
+    for (int k = 0; k < 13; ++k)
+        for (int a = 1; a < ct_dof_depth[6 + k]; ++a)
+            if (ct_dof_anc[16 * (6 + k) + a] == 6 + j) t |= (unsigned long long)a << (4 * k);
+    return t;
+}
 #ifndef APX_CRBA_SB
 #define APX_CRBA_SB 0      /* scheduling barrier every n levels of the CRBA chain walk: measured 0 / 3 / 5 / 7 within 0.4 % */
 #endif
@@ -289,6 +303,33 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
     // difference of two whole-leg prefixes loses its digits in fp32, the mass matrix stops being positive definite, every env is NaN within a step.
     // A bottom-up sweep "s += [lane is the parent] * s(lane + k)", 11 child edges per float: correct, but 352 dependent v_mov_dpp + v_fmac pairs are
     // slower than the loop's 88 ds_read_b128 + 352 v_fmac: 2.79 ms against 2.74 ms per launch.)
+#if APX_SUBTREE_SFX
+    // Depth-first numbering: every subtree interval [b, b + ndesc] ends at the foot (lane 11) except the leaves (own value) and the foot crank (itself
+    // + the plantar rod).  So the subtree sum of a body on the path to the foot is the inclusive SUFFIX sum over lanes b..11 - four row_shl adds, sums
+    // only (the prefix-DIFFERENCE form above cancels) - and the others are one select each.  The shadow lanes 12..15 carry copies of the foot and are
+    // zeroed first.  No LDS reads.
+    {
+        static_assert(TB_NDESC == nib(11, 10, 9, 0, 7, 0, 5, 4, 0, 1, 0, 0), "subtree intervals end at the foot, except leaves and the foot crank");
+        const bool leafb = lb == 3 || lb == 5 || lb == 8 || lb == 10, crank = lb == 9;
+        auto subtree = [&](float x) {
+            const float x0 = bl ? x : 0.f;
+            float sfx = x0;
+            sfx += dpp<0x101>(sfx); sfx += dpp<0x102>(sfx); sfx += dpp<0x104>(sfx); sfx += dpp<0x108>(sfx);
+            const float two = x0 + dpp<0x101>(x0);
+            float r = leafb ? x0 : sfx;
+            r = crank ? two : r;
+            return r;
+        };
+        sfor<0, 2>([&](auto Sd) {
+            constexpr int sd = Sd;
+            const float c0 = subtree(crb[sd].m), c1 = subtree(crb[sd].h.x), c2 = subtree(crb[sd].h.y), c3 = subtree(crb[sd].h.z), c4 = subtree(crb[sd].I[0]),
+                        c5 = subtree(crb[sd].I[1]), c6 = subtree(crb[sd].I[2]), c7 = subtree(crb[sd].I[3]), c8 = subtree(crb[sd].I[4]), c9 = subtree(crb[sd].I[5]);
+            crb[sd] = SI{c0, {c1, c2, c3}, {c4, c5, c6, c7, c8, c9}};
+            frc[sd].a.x = subtree(frc[sd].a.x); frc[sd].a.y = subtree(frc[sd].a.y); frc[sd].a.z = subtree(frc[sd].a.z);
+            frc[sd].l.x = subtree(frc[sd].l.x); frc[sd].l.y = subtree(frc[sd].l.y); frc[sd].l.z = subtree(frc[sd].l.z);
+        });
+    }
+#else
     // (a rolled, branch-free loop: a lane past its last descendant re-reads its own record with weight 0; both legs in one iteration)
     _Pragma("unroll 1") for (int i = 1; i <= 11; ++i) {
         const bool on = i <= ndesc;
@@ -302,6 +343,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             frc[sd].a = frc[sd].a + V3{p[10], p[11], p[12]} * w; frc[sd].l = frc[sd].l + V3{p[13], p[14], p[15]} * w;
         });
     }
+#endif
     wsync();
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
@@ -327,16 +369,17 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
     if constexpr (!QPOS0) {
         const V3 fn = {S(F_FLOOR), S(F_FLOOR + 1), S(F_FLOOR + 2)}, p0 = {ct_floor_pos[0], ct_floor_pos[1], ct_floor_pos[2]};
         static_assert(ct_geom_body[8] == 1 && ct_geom_body[6] == 4 && ct_geom_body[7] == 16, "pelvis sphere, hip-pitch capsules");
-        float hitb = 0.f;
-        if (l == 0) hitb = dot(o + mul(pmat, cv3<8>(ct_geom_pos)) - p0, fn) - ct_geom_radius[8] < 0.f ? 1.f : 0.f;
-        if (l == 2) sfor<0, 2>([&](auto Sd) {
+        // (branch-free: every lane evaluates both tests on its own bodies, lane 0 keeps the sphere result and lane 2 = hip pitch the capsule result)
+        const float hitp = dot(o + mul(pmat, cv3<8>(ct_geom_pos)) - p0, fn) - ct_geom_radius[8] < 0.f ? 1.f : 0.f;
+        float hitc = 0.f;
+        sfor<0, 2>([&](auto Sd) {
             constexpr int sd = Sd;
             const V3 c = pos[sd] + mul(mat[sd], cv3<6 + sd>(ct_geom_pos)), ax = mul(mat[sd], cv3<6 + sd>(ct_geom_axis)) * ct_geom_half[6 + sd];
             const float d = fminf(dot(c + ax - p0, fn), dot(c - ax - p0, fn)) - ct_geom_radius[6 + sd];
-            hitb = d < 0.f ? 1.f : hitb;
+            hitc = d < 0.f ? 1.f : hitc;
         });
-        if (l == 0) S.W(WK_MISC + 4) = hitb;
-        if (l == 2) S.W(WK_MISC + 5) = hitb;
+        int ho = WK_DUMMY; ho = l == 0 ? WK_MISC + 4 : ho; ho = l == 2 ? WK_MISC + 5 : ho;
+        S.W(ho) = l == 0 ? hitp : hitc;
     }
     // ---- anchor points, capsule ends, foot pose (body lanes that own them)
     sfor<0, 2>([&](auto Sd) {
@@ -353,35 +396,67 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         }
         static_assert(ct_eq_body1[0] == 12 && ct_eq_body2[0] == 13 && ct_eq_body1[1] == 5 && ct_eq_body2[1] == 10, "connect bodies");
         static_assert(ct_geom_body[0] == 13 && ct_geom_body[2] == 9 && ct_geom_body[4] == 8, "capsule bodies");
-        if (l == 10) put(base + 0, pos[sd] + mul(mat[sd], cv3<2 * sd>(ct_eq_anchor1)));            // plantar-rod: connect 0, anchor 1
-        if (l == 11) {                                                                             // foot: connect 0 anchor 2, capsule, pose
-            put(base + 3, pos[sd] + mul(mat[sd], cv3<2 * sd>(ct_eq_anchor2)));
-            cap(base + 12, cv3<0 + sd>(ct_geom_pos), cv3<0 + sd>(ct_geom_axis), ct_geom_half[0 + sd]);
+        // Branch-free (round 3; the six `if (l == ..)` blocks per leg were six exec-mask regions each): every lane transforms ONE anchor and ONE capsule with
+        // constants picked by select chains and stores them to its slots, or to the dummy words when it owns none.
+        {   // connect anchors: plantar rod (10) eq 0 anchor 1, foot (11) eq 0 anchor 2, achilles rod (3) eq 1 anchor 1, heel spring (8) eq 1 anchor 2
+            constexpr V3 a10 = cv3<2 * sd>(ct_eq_anchor1), a11 = cv3<2 * sd>(ct_eq_anchor2), a3 = cv3<2 * sd + 1>(ct_eq_anchor1), a8 = cv3<2 * sd + 1>(ct_eq_anchor2);
+            V3 ap = a10; int ao = base + 0;
+            ap.x = l == 11 ? a11.x : ap.x; ap.y = l == 11 ? a11.y : ap.y; ap.z = l == 11 ? a11.z : ap.z; ao = l == 11 ? base + 3 : ao;
+            ap.x = l == 3 ? a3.x : ap.x; ap.y = l == 3 ? a3.y : ap.y; ap.z = l == 3 ? a3.z : ap.z; ao = l == 3 ? base + 6 : ao;
+            ap.x = l == 8 ? a8.x : ap.x; ap.y = l == 8 ? a8.y : ap.y; ap.z = l == 8 ? a8.z : ap.z; ao = l == 8 ? base + 9 : ao;
+            const bool has = l == 10 || l == 11 || l == 3 || l == 8;
+            put(has ? ao : WK_DUMMY, pos[sd] + mul(mat[sd], ap));
         }
-        if (l == 3) put(base + 6, pos[sd] + mul(mat[sd], cv3<2 * sd + 1>(ct_eq_anchor1)));         // achilles-rod: connect 1, anchor 1
-        if (l == 8) put(base + 9, pos[sd] + mul(mat[sd], cv3<2 * sd + 1>(ct_eq_anchor2)));         // heel-spring: connect 1, anchor 2
-        if (l == 7) cap(base + 18, cv3<2 + sd>(ct_geom_pos), cv3<2 + sd>(ct_geom_axis), ct_geom_half[2 + sd]);      // tarsus capsule
-        if (l == 6) cap(base + 24, cv3<4 + sd>(ct_geom_pos), cv3<4 + sd>(ct_geom_axis), ct_geom_half[4 + sd]);      // shin capsule
+        {   // capsules: foot (11), tarsus (7), shin (6)
+            constexpr V3 p11 = cv3<0 + sd>(ct_geom_pos), x11 = cv3<0 + sd>(ct_geom_axis), p7 = cv3<2 + sd>(ct_geom_pos), x7 = cv3<2 + sd>(ct_geom_axis),
+                         p6 = cv3<4 + sd>(ct_geom_pos), x6 = cv3<4 + sd>(ct_geom_axis);
+            V3 cp = p11, cx = x11; float ch = ct_geom_half[0 + sd]; int co = base + 12;
+            cp.x = l == 7 ? p7.x : cp.x; cp.y = l == 7 ? p7.y : cp.y; cp.z = l == 7 ? p7.z : cp.z;
+            cx.x = l == 7 ? x7.x : cx.x; cx.y = l == 7 ? x7.y : cx.y; cx.z = l == 7 ? x7.z : cx.z; ch = l == 7 ? ct_geom_half[2 + sd] : ch; co = l == 7 ? base + 18 : co;
+            cp.x = l == 6 ? p6.x : cp.x; cp.y = l == 6 ? p6.y : cp.y; cp.z = l == 6 ? p6.z : cp.z;
+            cx.x = l == 6 ? x6.x : cx.x; cx.y = l == 6 ? x6.y : cx.y; cx.z = l == 6 ? x6.z : cx.z; ch = l == 6 ? ct_geom_half[4 + sd] : ch; co = l == 6 ? base + 24 : co;
+            const bool has = l == 11 || l == 7 || l == 6;
+            const V3 c = pos[sd] + mul(mat[sd], cp), ax = mul(mat[sd], cx) * ch;
+            put(has ? co : WK_DUMMY, c + ax); put(has ? co + 3 : WK_DUMMY, c - ax);
+        }
     });
     PROF2(18);
     // ---- mass-matrix rows and bias forces, dof lanes: k = 0..12 -> leg dof k of both legs; 13..15 -> pelvis dofs (l-13, l-10)
+#if APX_CRBA_DPP
+    SV cdv[2], fv[2]; int madrv[2];
+#endif
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
         const int d = l < 13 ? 6 + 13 * sd + l : (l - 13) + 3 * sd;
         const int db = l < 13 ? 2 + 12 * sd + (l == 12 ? 11 : nibble(TD_BODY, l)) : 1;
         SI c; SV fsub;
-        {   // (selects, not a branch around a struct copy: the copy form kept the pelvis composite in a 40-byte stack object = scratch)
+        {   // (selects, not a branch around a struct copy: the copy form kept the pelvis composite in a 40-byte stack object = scratch.  The loads are
+            // pinned by an empty asm: clang otherwise predicates each of the 16 loads on `leg`, one exec-mask region per word)
             const bool leg = l < 13;
             const float* p = xb + XB_SZ * db;
-            c.m = leg ? p[0] : pcrb.m; c.h = {leg ? p[1] : pcrb.h.x, leg ? p[2] : pcrb.h.y, leg ? p[3] : pcrb.h.z};
-            sfor<0, 6>([&](auto K) { c.I[K] = leg ? p[4 + K] : pcrb.I[K]; });
-            fsub = {{leg ? p[10] : pfrc.a.x, leg ? p[11] : pfrc.a.y, leg ? p[12] : pfrc.a.z}, {leg ? p[13] : pfrc.l.x, leg ? p[14] : pfrc.l.y, leg ? p[15] : pfrc.l.z}};
+            float w[16];
+            sfor<0, 16>([&](auto K) { w[K] = p[K]; });
+            asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]), "+v"(w[10]),
+                         "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]));
+            c.m = leg ? w[0] : pcrb.m; c.h = {leg ? w[1] : pcrb.h.x, leg ? w[2] : pcrb.h.y, leg ? w[3] : pcrb.h.z};
+            sfor<0, 6>([&](auto K) { c.I[K] = leg ? w[4 + K] : pcrb.I[K]; });
+            fsub = {{leg ? w[10] : pfrc.a.x, leg ? w[11] : pfrc.a.y, leg ? w[12] : pfrc.a.z}, {leg ? w[13] : pfrc.l.x, leg ? w[14] : pfrc.l.y, leg ? w[15] : pfrc.l.z}};
         }
         const float* cp = (const float*)&S.W(WK_CDOF + 6 * d);
         const SV cd = {{cp[0], cp[1], cp[2]}, {cp[3], cp[4], cp[5]}};
         const SV f = imul(c, cd);
         const int dep = l < 13 ? (l == 12 ? 13 : nibble(TD_DEPTH, l)) : d + 1, madr = cti(CT_MADR + d);
         S.W(WK_M + madr) = sdot(cd, f) + ctf(CT_ARM + d);
+#if APX_CRBA_DPP
+        // off-diagonal entries M[d][anc] = cdof_anc . f_d.  The pelvis ancestors' axes are known to every lane (unit translations, the columns of the
+        // pelvis rotation about o itself), so their six entries need no operand fetch at all; the leg ancestors follow below, both legs together.
+        sfor<0, 6>([&](auto Pp) {
+            constexpr int p = Pp;
+            const float v = p < 3 ? (p == 0 ? f.l.x : p == 1 ? f.l.y : f.l.z) : dot(col(pmat, p < 3 ? 0 : p - 3), f.a);
+            S.W(p < dep - 1 ? WK_M + madr + dep - 1 - p : WK_DUMMY) = v;
+        });
+        cdv[sd] = cd; fv[sd] = f; madrv[sd] = madr;
+#else
         int cur = l;                                                  // walk the ancestor chain: leg dofs first, then pelvis dofs 5..0
         sfor<1, 14>([&](auto An) {      // branch-free: inactive levels read dof 0's axis and store to the env's dummy word
             constexpr int a = An;
@@ -393,6 +468,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             const float* ap = (const float*)&S.W(WK_CDOF + 6 * ad);
             S.W(on ? WK_M + madr + a : WK_DUMMY) = sdot(SV{{ap[0], ap[1], ap[2]}, {ap[3], ap[4], ap[5]}}, f);
         });
+#endif
         // qfrc_smooth = passive - bias + actuation
         const int k = l;       // leg-local dof
         float fs = -S(F_DAMP + d) * S(F_QVEL + d) - sdot(cd, fsub);
@@ -416,6 +492,27 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         }
         S.W(WK_SMOOTH + d) = fs;
     });
+#if APX_CRBA_DPP
+    // leg ancestors: a UNIFORM loop over the nine leg dofs that have descendants (hip roll / yaw / pitch, the first two achilles-rod axes, knee, shin,
+    // tarsus, foot crank).  Lane j's axis reaches the row by six row broadcasts, every lane forms cdof_j . f_own, and a per-lane level table says where
+    // (or whether: level 0 = not an ancestor, the store goes to the dummy word) the entry belongs in the ancestor-chain layout.  Round 2 walked the
+    // chain per lane instead: 13 levels x (parent lookup, 6 LDS reads at lane-dependent addresses, dot, store) per leg.
+    {
+        constexpr int ANC[9] = {0, 1, 2, 3, 4, 6, 7, 8, 10};
+        const int l4 = 4 * l;
+        sfor<0, 9>([&](auto Jn) {
+            constexpr int j = ANC[Jn];
+            constexpr unsigned long long T = crba_level_table(j);
+            const int a = (int)((T >> l4) & 15ull);
+            sfor<0, 2>([&](auto Sd) {
+                constexpr int sd = Sd;
+                const SV aj = {{dpp<0x150 + j>(cdv[sd].a.x), dpp<0x150 + j>(cdv[sd].a.y), dpp<0x150 + j>(cdv[sd].a.z)},
+                               {dpp<0x150 + j>(cdv[sd].l.x), dpp<0x150 + j>(cdv[sd].l.y), dpp<0x150 + j>(cdv[sd].l.z)}};
+                S.W(a ? WK_M + madrv[sd] + a : WK_DUMMY) = sdot(aj, fv[sd]);
+            });
+        });
+    }
+#endif
     PROF2(19);
     // ---- foot pose for the reward / foot velocity (cassie.py:328-331,426-427)
     if (!QPOS0 && l == 11) sfor<0, 2>([&](auto Sd) {
