@@ -937,7 +937,7 @@ def test_estimator_record_recovers_from_non_finite_state(dev):
     assert all(est_from_record(e2[i])["inited"] == 1.0 for i in (3, 7, 9)) and np.isfinite(e2).all()
     # and the other way round: non-finite SENSORS (a NaN joint position) leave a zeroed record, restarted on the next finite update
     qp = genv.get_field("qpos"); qp[12, 9] = float("nan"); genv.set_field("qpos", qp)
-    genv.substep()
+    genv.substep(); genv.substep()      # (the estimator reads the sensor snapshot taken at the end of the previous substep)
     e3 = genv.get_field("est").cpu().numpy()
     assert np.isfinite(e3).all() and est_from_record(e3[12])["inited"] == 0.0 and np.abs(e3[12][:144]).max() == 0.0
 
