@@ -172,6 +172,7 @@ def eval_perturb_main(argv):
     p.add_argument("--perturb_size", type=float, default=100.0)
     p.add_argument("--perturb_incr", type=float, default=10.0)
     p.add_argument("--n_sizes", type=int, default=40)
+    p.add_argument("--perturb_body", type=str, default="cassie-pelvis")      # tools/eval_perturb.py:104
     p.add_argument("--reward", type=str, default="clock")
     a = p.parse_args(argv)
     from apex_amd.vecenv import CassieVecEnv
@@ -182,7 +183,8 @@ def eval_perturb_main(argv):
     _check_obs_dim(actor, mk(64))
     t0 = time.time()
     mf, fell = compute_perturbs(actor, mk, mean, std, wait_time=a.wait_time, perturb_duration=a.perturb_duration,
-                                perturb_size=a.perturb_size, perturb_incr=a.perturb_incr, num_angles=a.num_angles, n_sizes=a.n_sizes)
+                                perturb_size=a.perturb_size, perturb_incr=a.perturb_incr, num_angles=a.num_angles, n_sizes=a.n_sizes,
+                                perturb_body=a.perturb_body)
     dt = time.time() - t0
     np.save(os.path.join(a.path, "eval_perturbs.npy"), mf)
     print("push-recovery sweep: %d trials in %.1f s" % (fell.size, dt))

@@ -72,6 +72,7 @@ SIGNATURES = {
     "apx_env_update_speed": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
     "apx_env_reset_for_test": (C.c_int, [c_ptr, c_ptr, C.c_int, c_ptr]),
     "apx_env_apply_force": (C.c_int, [c_ptr, c_ptr, c_ptr]),
+    "apx_env_apply_force_body": (C.c_int, [c_ptr, c_ptr, C.c_int, c_ptr]),
     "apx_env_step_basic": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
     "apx_env_timing": (C.c_int, [c_ptr, C.c_int]),
     "apx_env_timing_read": (C.c_int, [c_ptr, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),

@@ -352,6 +352,10 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             p[0] = crb[sd].m; p[1] = crb[sd].h.x; p[2] = crb[sd].h.y; p[3] = crb[sd].h.z;
             sfor<0, 6>([&](auto K) { p[4 + K] = crb[sd].I[K]; });
             p[10] = frc[sd].a.x; p[11] = frc[sd].a.y; p[12] = frc[sd].a.z; p[13] = frc[sd].l.x; p[14] = frc[sd].l.y; p[15] = frc[sd].l.z;
+            if constexpr (!QPOS0) {      // the body's COM relative to o: where an external wrench on this body acts (mjData.xfrc_applied, below)
+                const V3 cr = (pos[sd] - o) + mul(mat[sd], ipos[sd]);
+                p[16] = cr.x; p[17] = cr.y; p[18] = cr.z;
+            }
         }
     });
     wsync();
@@ -484,11 +488,19 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             fs += g * fminf(fmaxf(S.W(WK_CTRL + ua), -cmax), cmax);
         }
         if constexpr (!QPOS0) {
-            if (l >= 13) {      // external wrench on the pelvis (mjData.xfrc_applied, applied at the body's COM): J^T (f, tau) on the 6 free-joint dofs
-                const V3 xf = {S(F_XFRC), S(F_XFRC + 1), S(F_XFRC + 2)}, xt = {S(F_XFRC + 3), S(F_XFRC + 4), S(F_XFRC + 5)};
-                const V3 rp = mul(pmat, V3{cm_body_ipos[3], cm_body_ipos[4], cm_body_ipos[5]});      // xipos - o
-                fs += dot(cd.a, xt + cross(rp, xf)) + dot(cd.l, xf);
-            }
+            // external wrench (one row of mjData.xfrc_applied: body I_XBODY, applied at that body's COM): J^T (f, tau) on the dofs of the body's ancestor
+            // chain.  The six free-joint dofs always see it; a leg dof sees it when its body is an ancestor-or-self of the pushed body, which with the
+            // depth-first numbering is the interval test  body(dof) <= pushed <= body(dof) + ndesc.  Branch-free: a 0 / 1 weight.
+            const int xbd = S.I(I_XBODY);                       // 0 / 1: pelvis (the harnesses' default), 2..25: a leg body
+            const bool xleg = xbd >= 2;
+            const int xsd = xbd >= 14 ? 1 : 0, xlb = xbd - 2 - 12 * xsd;
+            const V3 xf = {S(F_XFRC), S(F_XFRC + 1), S(F_XFRC + 2)}, xt = {S(F_XFRC + 3), S(F_XFRC + 4), S(F_XFRC + 5)};
+            const float* xr = xb + XB_SZ * (xleg ? xbd : 2) + 16;
+            const V3 rpp = mul(pmat, V3{cm_body_ipos[3], cm_body_ipos[4], cm_body_ipos[5]});      // pelvis: xipos - o
+            const V3 rp = {xleg ? xr[0] : rpp.x, xleg ? xr[1] : rpp.y, xleg ? xr[2] : rpp.z};
+            const int dbl = l == 12 ? 11 : nibble(TD_BODY, l < 13 ? l : 0), dnd = nibble(TB_NDESC, dbl);
+            const bool hit = l >= 13 || (xleg && xsd == sd && dbl <= xlb && xlb <= dbl + dnd);
+            fs += (hit ? 1.f : 0.f) * (dot(cd.a, xt + cross(rp, xf)) + dot(cd.l, xf));
         }
         S.W(WK_SMOOTH + d) = fs;
     });

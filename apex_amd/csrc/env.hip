@@ -804,12 +804,16 @@ extern "C" int apx_env_reset_for_test(apx_env_t* e, float* obs_out, int full_res
 }
 
 __global__ void scatter_kernel(float* st, int n, int f0, int cnt, const float* in);
-extern "C" int apx_env_apply_force(apx_env_t* e, const float* xfrc, void* stream) {
+__global__ void fill_int_kernel(int* p, int n, int v) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+extern "C" int apx_env_apply_force_body(apx_env_t* e, const float* xfrc, int body, void* stream) {
     APX_REQUIRE(e && xfrc, "null pointer");
+    APX_REQUIRE(body >= 1 && body < ES_NB, "body id out of range (1 = cassie-pelvis ... 25 = right-foot)");
     hipLaunchKernelGGL(scatter_kernel, dim3(apx_cdiv((long)e->n * 6, 256)), dim3(256), 0, (hipStream_t)stream, e->st, e->n, (int)F_XFRC, 6, xfrc);
+    hipLaunchKernelGGL(fill_int_kernel, dim3(apx_cdiv((long)e->n, 256)), dim3(256), 0, (hipStream_t)stream, e->ist + (size_t)I_XBODY * e->n, e->n, body);
     APX_LAUNCH_CHECK();
     return APX_OK;
 }
+extern "C" int apx_env_apply_force(apx_env_t* e, const float* xfrc, void* stream) { return apx_env_apply_force_body(e, xfrc, 1, stream); }
 
 extern "C" int apx_env_step(apx_env_t* e, const float* action, float* obs, float* reward, uint8_t* done, float* final_obs,
                             int auto_reset, void* stream) {

@@ -13,14 +13,15 @@ enum Field : int {
     F_SO = F_SNAP + 26 /* mpos10 mvel10 torque10 jpos6 jvel6 quat4 rotvel3 tvel3 tacc3 height1 */, F_FOOTPREV = F_SO + 56,
     F_FOOTVEL = F_FOOTPREV + 6, F_PREVACT = F_FOOTVEL + 6, F_PREVTQ = F_PREVACT + 10,
     F_CMD = F_PREVTQ + 10 /* speed side orient swing stance phaselen stance_mode */, F_FWD = F_CMD + 7 /* foot force z L,R; foot quat L4 R4; foot pos 6 */,
-    F_XFRC = F_FWD + 16 /* external wrench on the pelvis, world frame: force xyz, torque xyz (mjData.xfrc_applied row of cassie-pelvis) */,
+    F_XFRC = F_FWD + 16 /* external wrench, world frame: force xyz, torque xyz (the mjData.xfrc_applied row of body I_XBODY) */,
     F_TOTAL = F_XFRC + 6      // (the state estimator's persistent state is not here: env-major records in apx_env::wk, estimator_lane.h)
 };
 enum SnapOff { SN_MPOS = 0, SN_JPOS = 10, SN_QUAT = 16, SN_GYRO = 20, SN_ACC = 23 };
 enum SoOff { SO_MPOS = 0, SO_MVEL = 10, SO_TORQUE = 20, SO_JPOS = 30, SO_JVEL = 36, SO_QUAT = 42, SO_ROTVEL = 46, SO_TVEL = 49, SO_TACC = 52, SO_HEIGHT = 55 };
 enum IField : int { I_TIME = 0, I_PHASE, I_COUNTER, I_RNG, I_FLAGS /* bit0 menc primed, 1 jenc primed, 2 prev_action, 3 prev_torque */,
                     I_AGE /* env steps since the state estimator of this env was set up (apx_env_cfg.est_lifetime) */,
-                    I_SAT /* constraint sets beyond what the kernel instantiates: bits 0-3 = SAT_* flags seen since env creation, bits 8.. = number of such forward passes */, I_TOTAL };
+                    I_SAT /* constraint sets beyond what the kernel instantiates: bits 0-3 = SAT_* flags seen since env creation, bits 8.. = number of such forward passes */,
+                    I_XBODY /* MuJoCo body id the F_XFRC wrench acts on (0 / 1 = cassie-pelvis) */, I_TOTAL };
 // what a forward pass needed beyond the kernel's per-leg caps (same bits as oracle/cassie_phys.h SatFlag): > 2 penetrating capsule ends on a
 // leg, > 1 active joint limit on a leg, pelvis sphere / hip-pitch capsule on the floor, a left-right capsule pair in contact
 enum SatFlag : int { SAT_CONTACTS = 1, SAT_LIMITS = 2, SAT_BODY_FLOOR = 4, SAT_LEG_LEG = 8 };

@@ -62,12 +62,12 @@ def evaluate(actor, env, obs_mean=None, obs_std=None, speed=None, side_speed=0.0
 
 @torch.no_grad()
 def compute_perturbs(actor, make_env, obs_mean=None, obs_std=None, wait_time=4.0, perturb_duration=0.2, perturb_size=100.0,
-                     perturb_incr=10.0, num_angles=4, n_sizes=40, num_phases=33, speed=0.5):
+                     perturb_incr=10.0, num_angles=4, n_sizes=40, num_phases=33, speed=0.5, perturb_body="cassie-pelvis"):
     """The reference's push-recovery sweep (tools/eval_perturb.py:99-160 `compute_perturbs`, :15-85 `perturb_worker`) as ONE batch.
 
     Reference, per (angle, phase): grow the push by `perturb_incr` from `perturb_size` until the robot falls; every trial is
     reset_for_test(full_reset=True), `env.speed = 0.5`, 2 (phaselen + 1) + phase policy steps, then the wrench
-    [F cos a, F sin a, 0, 0, 0, 0] on cassie-pelvis for `perturb_duration` s of sim time, then up to `wait_time` s without it, failed
+    [F cos a, F sin a, 0, 0, 0, 0] on `perturb_body` (default cassie-pelvis, eval_perturb.py:104) for `perturb_duration` s of sim time, then up to `wait_time` s without it, failed
     when qpos[2] < 0.4 during the wait; result max_force[phase, angle] = (first failing size) - incr.
     Here: one env per (angle, phase, size) trial, all trials in lock step; `n_sizes` bounds the sweep (a cell that never fails
     reports the largest size tried).  make_env(n) -> CassieVecEnv with n envs (dynamics_randomization off).
@@ -98,12 +98,12 @@ def compute_perturbs(actor, make_env, obs_mean=None, obs_std=None, wait_time=4.0
     zero = torch.zeros_like(wrench)
     for k in range(num_phases - 1 + n_push + n_wait):
         pushing = (k >= p_i) & (k < p_i + n_push)
-        env.apply_force(torch.where(pushing.view(n, 1), wrench, zero))
+        env.apply_force(torch.where(pushing.view(n, 1), wrench, zero), perturb_body)
         obs, _, _, _ = env.step(fwd(obs), auto_reset=False)
         waiting = (k >= p_i + n_push) & (k < p_i + n_push + n_wait)
         z = env.get_field("qpos")[:, 2]
         fell |= waiting & (z < 0.4)
-    env.apply_force(zero)
+    env.apply_force(zero, perturb_body)
     fell = (fell & valid)[:n_trials].view(num_angles, num_phases, n_sizes).permute(1, 0, 2).cpu().numpy()
     first = np.where(fell.any(-1), fell.argmax(-1), n_sizes)            # index of the first failing size (n_sizes = never)
     max_force = (perturb_size + perturb_incr * first - perturb_incr).astype(np.float32)

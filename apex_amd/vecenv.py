@@ -62,6 +62,11 @@ def parse_reward(reward):
     return dict(reward_kind=kind, stance_mode=stance, have_incentive=int(have_incentive))
 
 
+# MuJoCo body ids of cassie.xml (world = 0): the name argument of CassieSim.apply_force (cassiemujoco.py:99)
+BODY_NAMES = ["world", "cassie-pelvis"] + [side + "-" + n for side in ("left", "right") for n in (
+    "hip-roll", "hip-yaw", "hip-pitch", "achilles-rod", "knee", "knee-spring", "shin", "tarsus", "heel-spring", "foot-crank", "plantar-rod", "foot")]
+
+
 class CassieVecEnv:
     clock_based = True
     clock_inds = CLOCK_INDS
@@ -167,11 +172,12 @@ class CassieVecEnv:
 
     def apply_force(self, xfrc, body_name="cassie-pelvis"):
         """CassieSim.apply_force (cassiemujoco.py:99-103) for every env: xfrc [N, 6] (or [6]) = world-frame force xyz + torque xyz on
-        the pelvis; stays applied until overwritten (tools/eval_perturb.py:62,70)."""
-        if body_name != "cassie-pelvis":
-            raise NotImplementedError("external wrenches are supported on cassie-pelvis only")
+        body `body_name` (a cassie.xml body name, tools/eval_perturb.py's perturb_body), acting at that body's centre of mass; stays applied until
+        overwritten (tools/eval_perturb.py:62,70).  One pushed body at a time: a call replaces the previous wrench whatever body it was on."""
+        if body_name not in BODY_NAMES[1:]:
+            raise ValueError("unknown body %r (cassie.xml bodies: %s)" % (body_name, ", ".join(BODY_NAMES[1:])))
         x = torch.as_tensor(xfrc, dtype=torch.float32, device=self.device).expand(self.n_envs, 6).contiguous()
-        check(_lib.load().apx_env_apply_force(self._h, _p(x), _stream()))
+        check(_lib.load().apx_env_apply_force_body(self._h, _p(x), BODY_NAMES.index(body_name), _stream()))
 
     def set_command(self, speed=None, side_speed=None, orient_add=None, phase=None, phase_add=None):
         """Plain attribute writes `env.speed = ...`, `env.orient_add = ...`, `env.phase = ...` of the reference's test harnesses

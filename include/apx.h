@@ -221,8 +221,14 @@ int apx_env_update_speed(apx_env_t* env, const float* speed, const float* side_s
 int apx_env_reset_for_test(apx_env_t* env, float* obs_out, int full_reset, void* stream);
 /* CassieSim.apply_force(xfrc, "cassie-pelvis") (cassiemujoco.py:99-103, cassie_sim_apply_force include/cassiemujoco.h:184):
  * xfrc[n_envs*6] f32 [dev] = world-frame force xyz then torque xyz on the pelvis at its centre of mass; it stays applied
- * until overwritten (tools/eval_perturb.py:62,70) or a full reset.  Only the pelvis body is supported. */
+ * until overwritten (tools/eval_perturb.py:62,70) or a full reset. */
 int apx_env_apply_force(apx_env_t* env, const float* xfrc, void* stream);
+/* CassieSim.apply_force(xfrc, body_name) for any body (tools/eval_perturb.py's perturb_body): body = MuJoCo body id of cassie.xml,
+ * 1 = cassie-pelvis, 2..13 = left hip-roll, hip-yaw, hip-pitch, achilles-rod, knee, knee-spring, shin, tarsus, heel-spring, foot-crank,
+ * plantar-rod, foot, 14..25 = the same on the right.  The wrench acts at that body's centre of mass (one row of mjData.xfrc_applied).
+ * ONE pushed body at a time per handle: the call replaces the previous wrench whatever body that was on (the reference keeps a row per
+ * body; its harnesses only ever push one). */
+int apx_env_apply_force_body(apx_env_t* env, const float* xfrc, int body, void* stream);
 /* CassieEnv.step_basic (cassie/cassie.py:498-521, 355-387) for every env: the substeps and the time / phase bookkeeping of a
  * step, without reward, termination, trackers or command resampling (evaluation at a fixed command); obs[n_envs*50]. */
 int apx_env_step_basic(apx_env_t* env, const float* action, float* obs, void* stream);

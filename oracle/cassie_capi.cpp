@@ -31,7 +31,8 @@ void orc_env_set_kind(void* h, int kind) { ((Env*)h)->cfg.env_kind = kind; }    
 void orc_traj_ref_state(double phase, double phaselen, double speed, int counter, double* qpos, double* qvel) { traj_ref_state(phase, phaselen, speed, counter, qpos, qvel); }
 void orc_env_update_speed(void* h, double speed, double side_speed) { env_update_speed(*(Env*)h, speed, side_speed); }
 void orc_env_reset_for_test(void* h, double* obs, int full_reset) { env_reset_for_test(*(Env*)h, obs, full_reset != 0); }
-void orc_env_apply_force(void* h, const double* xfrc) { for (int k = 0; k < 6; ++k) ((Env*)h)->st.xfrc[k] = xfrc[k]; }   // CassieSim.apply_force on cassie-pelvis
+void orc_env_apply_force(void* h, const double* xfrc) { for (int k = 0; k < 6; ++k) ((Env*)h)->st.xfrc[k] = xfrc[k]; ((Env*)h)->st.xfrc_body = 1; }   // CassieSim.apply_force on cassie-pelvis
+void orc_env_apply_force_body(void* h, const double* xfrc, int body) { for (int k = 0; k < 6; ++k) ((Env*)h)->st.xfrc[k] = xfrc[k]; ((Env*)h)->st.xfrc_body = body; }   // ... on any body (mjData.xfrc_applied row `body`)
 // test helper: the command / clock / phase state a training reset with first speed draw `speed0` leaves behind (cassie.py:553-563)
 void orc_env_set_command(void* h, double speed0, int phase) { Env& e = *(Env*)h; e.speed = speed0; env_clock_from_speed(e); e.phase = phase; }
 void orc_env_obs(void* h, double* obs) { env_obs(*(Env*)h, obs); }

@@ -296,11 +296,14 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
         const double c = std::min(std::max(ctrl ? ctrl[u] : 0.0, -cm_act_ctrlmax[u]), cm_act_ctrlmax[u]);
         w.smooth[cm_act_dof[u]] += cm_act_gear[u] * c;
     }
-    {   // mj_xfrcAccumulate for the pelvis: J^T (f, tau) with the wrench acting at xipos; only the 6 free-joint dofs see it
+    {   // mj_xfrcAccumulate for the pushed body: J^T (f, tau) with the wrench acting at that body's xipos, over the dofs of its ancestor chain
+        const int b = s.xfrc_body;
         const V3 f = {s.xfrc[0], s.xfrc[1], s.xfrc[2]}, t = {s.xfrc[3], s.xfrc[4], s.xfrc[5]};
-        const V3 p = s.xpos[1] + mul(s.xmat[1], v3(cm_body_ipos + 3));
+        const V3 p = s.xpos[b] + mul(s.xmat[b], v3(cm_body_ipos + 3 * b));
         const V3 to = t + cross(p - w.o, f);
-        for (int d = 0; d < 6; ++d) w.smooth[d] += dot(w.cdof[d].a, to) + dot(w.cdof[d].l, f);
+        int last = -1;
+        for (int a = b; a >= 1 && last < 0; a = cm_body_parent[a]) if (cm_body_dofnum[a] > 0) last = cm_body_dofadr[a] + cm_body_dofnum[a] - 1;
+        for (int d = last; d >= 0; d = cm_dof_parent[d]) w.smooth[d] += dot(w.cdof[d].a, to) + dot(w.cdof[d].l, f);
     }
     cholesky(w.M, w.L);
     double qacc_smooth[NV];

@@ -131,7 +131,8 @@ struct State {
     int sat;                     // SatFlag bits of the most recent forward pass: the constraint set exceeded what the HIP kernel instantiates
     int solver_iter;             // sweeps the PGS solver ran in the most recent forward pass (mjData.solver_iter)
     int ncon1;                   // leg-leg (frictionless) contacts of the most recent forward pass
-    double xfrc[6] = {0, 0, 0, 0, 0, 0};   // mjData.xfrc_applied row of cassie-pelvis: world force xyz, torque xyz, applied at the body COM
+    double xfrc[6] = {0, 0, 0, 0, 0, 0};   // one row of mjData.xfrc_applied: world force xyz, torque xyz, applied at the COM of body xfrc_body
+    int xfrc_body = 1;                     // the body of that row (1 = cassie-pelvis, the harnesses' default; one pushed body at a time)
 };
 
 struct Work {

@@ -10,6 +10,10 @@ _SO = os.path.join(_HERE, "_build", "liboracle.so")
 _lib = None
 
 
+# MuJoCo body ids of cassie.xml (world = 0): the name argument of CassieSim.apply_force
+BODY_NAMES = ["world", "cassie-pelvis"] + [side + "-" + n for side in ("left", "right") for n in (
+    "hip-roll", "hip-yaw", "hip-pitch", "achilles-rod", "knee", "knee-spring", "shin", "tarsus", "heel-spring", "foot-crank", "plantar-rod", "foot")]
+
 def lib():
     global _lib
     if _lib is None:
@@ -27,6 +31,7 @@ def lib():
         L.orc_env_step_basic.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_env_reset_for_test.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_env_apply_force.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_env_apply_force_body.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_env_set_kind.argtypes = [C.c_void_p, C.c_int]
         L.orc_env_set_command_profile.argtypes = [C.c_void_p, C.c_int]
         L.orc_env_set_input_profile.argtypes = [C.c_void_p, C.c_int]
@@ -127,10 +132,11 @@ class OracleEnv:
         lib().orc_env_reset_for_test(self.h, _ptr(obs), int(bool(full_reset)))
         return obs
 
-    def apply_force(self, xfrc):
+    def apply_force(self, xfrc, body_name="cassie-pelvis"):
+        """CassieSim.apply_force (cassiemujoco.py:99-103): one row of mjData.xfrc_applied; one pushed body at a time."""
         x = np.ascontiguousarray(xfrc, dtype=np.float64)
         assert x.shape == (6,)
-        lib().orc_env_apply_force(self.h, _ptr(x))
+        lib().orc_env_apply_force_body(self.h, _ptr(x), BODY_NAMES.index(body_name))
 
     def obs(self):
         o = np.zeros(self.obs_dim)

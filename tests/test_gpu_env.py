@@ -962,3 +962,33 @@ def test_diverged_env_ends_its_episode(dev):
         obs, rew, done, _ = genv.step(zero, auto_reset=True)
     assert np.isfinite(obs.cpu().numpy()).all() and np.isfinite(rew.cpu().numpy()).all()
     assert np.isfinite(genv.get_field("est").cpu().numpy()).all() and np.isfinite(genv.get_field("qpos").cpu().numpy()).all()
+
+
+def test_apply_force_on_any_body_vs_oracle(dev):
+    """CassieSim.apply_force(xfrc, body_name) for bodies other than the pelvis (tools/eval_perturb.py's perturb_body; mjData.xfrc_applied row of that
+    body, J^T over its ancestor chain): single substeps from identical states, kernel vs oracle, for a foot, a tarsus, a hip-pitch and a plantar rod on
+    either side.  The pushed body must matter: the same substep without the wrench differs by much more than the parity tolerance."""
+    from tests.state_xfer import oracle_to_kernel
+    n = 64
+    genv, oenv = _mk(False, 61, n)
+    genv.reset(); [e.reset() for e in oenv]
+    zero = torch.zeros(n, 10, device=dev)
+    for _ in range(2):
+        genv.step(zero, auto_reset=False); [e.step(np.zeros(10)) for e in oenv]
+    rng = np.random.RandomState(3)
+    for body in ("left-foot", "right-tarsus", "left-hip-pitch", "right-plantar-rod", "right-foot", "cassie-pelvis"):
+        xfrc = np.concatenate([rng.uniform(-40, 40, (n, 3)), rng.uniform(-3, 3, (n, 3))], 1).astype(np.float32)
+        oracle_to_kernel(genv, oenv)
+        q0 = np.stack([e.get("qvel") for e in oenv])
+        genv.apply_force(torch.tensor(xfrc), body)
+        [e.apply_force(xfrc[i].astype(np.float64), body) for i, e in enumerate(oenv)]
+        for _ in range(4):
+            genv.substep(); [e.substep() for e in oenv]
+        qv = genv.get_field("qvel").cpu().numpy(); qo = np.stack([e.get("qvel") for e in oenv])
+        moved = np.abs(qo - q0).max()
+        err = np.abs(qv - qo).max()
+        assert err < 2e-2 and err < 0.05 * moved, (body, err, moved)
+        # without the wrench the same substeps end somewhere else (the wrench is not a no-op on this body)
+        genv.apply_force(torch.zeros(6), body); [e.apply_force(np.zeros(6), body) for e in oenv]
+    genv.apply_force(torch.zeros(6))
+    assert int(genv.get_field("ints")[0, 7]) == 1      # back on the pelvis row

@@ -377,6 +377,23 @@ def test_apply_force_on_the_pelvis():
         a = (com_vel(e) - v0) / (n * 0.0005)
         # semi-implicit Euler with a configuration-dependent M conserves momentum to O(h): 5e-5 relative here
         np.testing.assert_allclose(a, np.array([0, 0, -9.81]) + np.array(xfrc[:3]) / M, atol=5e-4)
+    # the same balance for a wrench on any other body (mjData.xfrc_applied row of that body: J^T over its ancestor chain), and the pushed
+    # body itself must feel it: a lateral force on the left foot accelerates the left foot sideways, not the right one
+    for body in ("left-foot", "right-tarsus", "left-hip-pitch", "right-plantar-rod"):
+        e = S.OracleEnv(dyn_rand=False, seed=0, env_id=0)
+        e.reset_for_test(full_reset=True)
+        xfrc = [12.0, 20.0, -5.0, 0.3, -0.2, 0.1]
+        e.apply_force(xfrc, body)
+        v0 = com_vel(e)
+        e.phys_step(np.zeros(10), 6)
+        a = (com_vel(e) - v0) / (6 * 0.0005)
+        np.testing.assert_allclose(a, np.array([0, 0, -9.81]) + np.array(xfrc[:3]) / M, atol=2e-3, err_msg=body)
+    ea, eb = S.OracleEnv(dyn_rand=False, seed=0, env_id=0), S.OracleEnv(dyn_rand=False, seed=0, env_id=0)
+    ea.reset_for_test(full_reset=True); eb.reset_for_test(full_reset=True)
+    ea.apply_force([0, 30.0, 0, 0, 0, 0], "left-foot")
+    ea.phys_step(np.zeros(10), 6); eb.phys_step(np.zeros(10), 6)
+    dq = ea.get("qvel") - eb.get("qvel")
+    assert np.abs(dq[6:19]).max() > 5 * np.abs(dq[19:32]).max() and np.abs(dq[6:19]).max() > 0.05
 
 
 def test_g16_step_basic_bookkeeping(golden_dir):
