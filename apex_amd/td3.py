@@ -32,8 +32,9 @@ class HbmReplay:
         self.r.index_copy_(0, idx, r); self.nd.index_copy_(0, idx, notdone)
         self.ptr = (self.ptr + n) % self.cap; self.size = min(self.size + n, self.cap)
 
-    def sample(self, batch_size, gen):
-        ind = torch.randint(0, self.size, (batch_size,), device=self.device, generator=gen)      # np.random.randint(0, len, size): with replacement
+    def sample(self, batch_size, gen, ind=None):
+        if ind is None:
+            ind = torch.randint(0, self.size, (batch_size,), device=self.device, generator=gen)      # np.random.randint(0, len, size): with replacement
         g = lambda x: x.index_select(0, ind)
         return g(self.s), g(self.s2), g(self.a), g(self.r), g(self.nd)
 
@@ -120,6 +121,58 @@ class TD3:
             self.adapt_param_noise(self.obs)
         s = (stats / max(n_upd, 1)).cpu().numpy()
         return dict(q_loss=float(s[0]), avg_q1=float(s[1] / self.batch_size), avg_q2=float(s[2] / self.batch_size), updates=n_upd)
+
+    @torch.no_grad()
+    def reference_round(self, max_traj_len, explore_fn=None, index_fn=None, smooth_fn=None):
+        """ONE pass of the reference's synchronous loop body with its own collection semantics (sync_td3.py:304-313), for parity runs and for users
+        who want the reference's schedule: every env is one of its workers and collects ONE whole episode from a fresh reset
+        (collect_experience, :59-98: action = clip(actor(s) + one N(0, act_noise) scalar, -1, 1); done_bool = 1 at the time limit too, :82);
+        the episodes are merged worker-major (np.concatenate of the workers' lists, :52) into the ring replay (remote_replay.py:66-74); then
+        TD3.train runs for as many iterations as transitions were collected (:313), its iteration counter restarting at 0 (:137), every batch
+        sampled uniformly with replacement from everything collected so far.  explore_fn(env, step) / index_fn(it) / smooth_fn(it) replace the
+        random draws (golden G20c replays the reference's streams through them).  Returns the reference's train() statistics: avg_q1 (mean over
+        iterations and batch), q_loss (mean over iterations), pi_loss (sum over the policy updates / ALL iterations, as :203 does)."""
+        env, L, N, dev = self.env, self.learner, self.N, self.device
+        obs = env.reset().clone()
+        alive = torch.ones(N, dtype=torch.bool, device=dev)
+        steps = []
+        t = 0
+        while bool(alive.any()) and t < max_traj_len:
+            a = L.act(obs)
+            if self.act_noise != 0:
+                eps = (torch.tensor([[explore_fn(e, t)] for e in range(N)], dtype=torch.float32, device=dev) if explore_fn is not None
+                       else torch.randn(N, 1, device=dev, generator=self.gen) * self.act_noise)
+                a = (a + eps).clamp(-1, 1)
+            nxt, rew, done, fin = env.step(a)
+            term = done != 0
+            ended = term | (t + 1 == max_traj_len)
+            s2 = torch.where(term.view(-1, 1), fin, nxt)
+            steps.append((obs.clone(), s2.clone(), a.clone(), rew.clone(), (~ended).float(), alive.clone()))
+            alive = alive & ~term
+            obs = nxt.clone(); t += 1
+        n_new = 0
+        for e in range(N):                                   # worker-major merge
+            rows = [k for k in range(len(steps)) if bool(steps[k][5][e])]
+            if not rows:
+                continue
+            g = lambda j: torch.stack([steps[k][j][e] for k in rows])
+            self.replay.add(g(0), g(1), g(2), g(3), g(4))
+            n_new += len(rows)
+        self.total_steps += n_new
+        q_loss = avg_q1 = pi_loss = 0.0
+        for it in range(n_new):
+            ind = None if index_fn is None else torch.as_tensor(index_fn(it), dtype=torch.long, device=dev)
+            s, sn, ac, r, nd = self.replay.sample(self.batch_size, self.gen, ind)
+            noise = (torch.as_tensor(smooth_fn(it), dtype=torch.float32, device=dev) if smooth_fn is not None
+                     else torch.randn(self.batch_size, 10, device=dev, generator=self.gen) * self.policy_noise)
+            st, pl = L.train_step(s, ac, sn, r, nd, noise, it, self.discount, self.tau, self.noise_clip, self.policy_freq)
+            stc = st.cpu().numpy()
+            q_loss += float(stc[0]); avg_q1 += float(stc[1]) / self.batch_size
+            if pl is not None:
+                pi_loss += float(pl)
+        self.it += n_new
+        k = max(n_new, 1)
+        return dict(transitions=n_new, avg_q1=avg_q1 / k, q_loss=q_loss / k, pi_loss=pi_loss / k)
 
     @torch.no_grad()
     def evaluate(self, n_envs=256, max_traj_len=400):

@@ -394,3 +394,80 @@ def test_bf16_throughput_mode_vs_fp32(dev, golden_dir):
     y0 = net.forward(obs[:4096], Ls[0].obs_mean, Ls[0].obs_std)
     y1, _, _, _ = net.forward(obs[:4096], Ls[0].obs_mean, Ls[0].obs_std, keep=True, precision=1)
     assert float((y0 - y1).abs().max()) < 2e-2 * float(y0.abs().max()) + 1e-3
+
+
+class _ToyTd3Env:
+    """The toy dynamics of tools/refprobe/gen_golden_td3_loop.py (G20c) as an N-column device env with the CassieVecEnv surface the TD3 driver uses:
+    reset() starts a new scripted episode in every column (episode counter in column order, like the reference's workers run one after the other),
+    step(act) -> (next_obs, reward, done, final_obs); a finished column keeps stepping on harmlessly (the driver ignores it)."""
+    def __init__(self, dev, n, lens):
+        self.device, self.n_envs, self.obs_dim, self.lens, self.k = dev, n, 50, [int(x) for x in lens], 0
+
+    def _obs(self):
+        o = self.x.clone()
+        o[:, 46] = torch.sin(0.2 * self.t); o[:, 47] = torch.cos(0.2 * self.t)
+        return o.float()
+
+    def reset(self):
+        ks = torch.arange(self.k + 1, self.k + 1 + self.n_envs, dtype=torch.float64, device=self.device); self.k += self.n_envs
+        self.L = torch.tensor([self.lens[(int(k) - 1) % len(self.lens)] for k in ks.tolist()], device=self.device)
+        self.t = torch.zeros(self.n_envs, dtype=torch.float64, device=self.device)
+        self.x = torch.cos(torch.arange(50, dtype=torch.float64, device=self.device).view(1, 50) * 0.1 * ks.view(-1, 1))
+        return self._obs()
+
+    def step(self, act):
+        self.t = self.t + 1
+        self.x = 0.9 * self.x + 0.1 * act.double().repeat(1, 5) + 0.01
+        rew = torch.exp(-self.x.abs().mean(1)).float()
+        obs = self._obs()
+        done = (self.t >= self.L).to(torch.uint8)
+        return obs, rew, done, obs.clone()
+
+
+def test_td3_whole_loop_golden_g20c(dev, golden_dir):
+    """G20c: three rounds of the reference's synchronous TD3 loop body (parallel_collect_experience -> add_parallel -> train, sync_td3.py:304-313)
+    on the toy env, replayed through apex_amd.td3.TD3.reference_round with the captured exploration / sampling / smoothing streams: the
+    transitions of every round (collection with the live actor: the rounds depend on each other through the updates), the returned statistics,
+    the live nets after every round and the target nets at the end."""
+    import os
+    from apex_amd.td3 import TD3
+    g = np.load(os.path.join(golden_dir, "g20c_td3_loop.npz"))
+    P, B, H, mtl = int(g["procs"]), int(g["batch"]), int(g["hidden"]), int(g["max_traj_len"])
+    env = _ToyTd3Env(dev, P, g["lens"])
+    algo = TD3(env, "/tmp/g20c", hidden=H, a_lr=float(g["lr"]), c_lr=float(g["lr"]), discount=float(g["discount"]), tau=float(g["tau"]),
+               policy_noise=float(g["policy_noise"]), noise_clip=float(g["noise_clip"]), policy_freq=int(g["policy_freq"]), act_noise=float(g["act_noise"]),
+               batch_size=B, replay_size=4096)
+    L = algo.learner
+    ak, ck = [str(k) for k in g["actor_keys"]], [str(k) for k in g["critic_keys"]]
+    L.actor.load_list([g["actor0." + k] for k in ak]); L.actor_t.load_list([g["actor0." + k] for k in ak])
+    for i in range(2):
+        L.q[i].load_list([g["critic0." + k] for k in ck[6 * i:6 * i + 6]]); L.q_t[i].load_list([g["critic0." + k] for k in ck[6 * i:6 * i + 6]])
+    lens = [int(x) for x in g["lens"]]
+    seen = 0
+    for r in range(int(g["rounds"])):
+        p = "r%d_" % r
+        T = int(g[p + "T"])
+        ep = [min(lens[(r * P + i) % len(lens)], mtl) for i in range(P)]          # worker i's episode length this round
+        assert sum(ep) == T
+        off = np.concatenate([[0], np.cumsum(ep)])
+        ex, idx, sm = g[p + "explore"], g[p + "idx"], g[p + "smooth"]
+        out = algo.reference_round(mtl, explore_fn=lambda e, t: ex[off[e] + t] if t < ep[e] else 0.0, index_fn=lambda it: idx[it], smooth_fn=lambda it: sm[it])
+        assert out["transitions"] == T
+        rp = algo.replay
+        sl = slice(seen, seen + T)
+        np.testing.assert_allclose(rp.s[sl].cpu().numpy(), g[p + "s"], atol=2e-5, err_msg="states round %d" % r)
+        np.testing.assert_allclose(rp.a[sl].cpu().numpy(), g[p + "a"], atol=2e-5, err_msg="actions round %d" % r)
+        np.testing.assert_allclose(rp.s2[sl].cpu().numpy(), g[p + "s2"], atol=2e-5)
+        np.testing.assert_allclose(rp.r[sl].cpu().numpy(), g[p + "rew"], atol=1e-5)
+        np.testing.assert_array_equal(rp.nd[sl].cpu().numpy(), 1.0 - g[p + "d"])          # done_bool, incl. the time limit
+        seen += T
+        np.testing.assert_allclose([out["avg_q1"], out["q_loss"], out["pi_loss"]], [float(g[p + "avg_q1"]), float(g[p + "q_loss"]), float(g[p + "pi_loss"])],
+                                   rtol=5e-4, atol=5e-6, err_msg="statistics round %d" % r)
+        for nm, nets, keys in (("actor", [L.actor], ak), ("critic", L.q, ck)):
+            for k, v in zip(keys, [v for net in nets for v in net.views()]):
+                d = np.abs(v.cpu().numpy() - g[p + nm + "." + k])
+                assert (d > 5e-5).mean() < 2e-2 and d.max() < 2.1e-3 * (r + 1), (r, nm, k, (d > 5e-5).mean(), d.max())      # Adam at lr 1e-3: a sign tie at g ~ 0 moves a weight by 2e-3
+    for nm, nets, keys in (("actor_target", [L.actor_t], ak), ("critic_target", L.q_t, ck)):
+        for k, v in zip(keys, [v for net in nets for v in net.views()]):
+            d = np.abs(v.cpu().numpy() - g[nm + "." + k])
+            assert d.max() < 2e-4, (nm, k, d.max())
