@@ -107,25 +107,42 @@ class RecurrentPPO:
         noise = torch.zeros(N, 10, device=self.device)
         norm = lambda o: ((o - L.obs_mean) / L.obs_std).contiguous()
         self.b_boot.zero_()
+        # No host round trip inside the loop (round 3): the Python loop runs ahead of the GPU, so launch latency hides behind the 3 ms env kernel.
+        # The critic's one-step chain does not feed the env step: it runs on a side stream, next to the env kernel (2048 envs fill half the SIMDs).
+        main = torch.cuda.current_stream(self.device)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side
+        side.wait_stream(main)
         for t in range(T):
             self.b_obs[t].copy_(obs)
+            ev_obs = main.record_event()
+            with torch.cuda.stream(side):
+                side.wait_event(ev_obs)
+                self.b_val[t].copy_(L.critic.forward(self.b_obs[t], hc=hc_c).view(-1))
             mu = L.actor.forward(norm(obs), hc=hc_a)
-            self.b_val[t].copy_(L.critic.forward(obs.contiguous(), hc=hc_c).view(-1))
             if self.noise_fn is None:
                 noise.normal_(generator=self.gen)
             else:
                 self.noise_fn(t, noise)
             torch.add(mu, noise, alpha=self.fixed_std, out=self.b_act[t])
             env.step(self.b_act[t], out=(obs, self.b_rew[t], self.b_done[t], self.b_fin[t]))      # writes the next observation into `obs`
-            tr = self.b_done[t] == 2
+            ev_step = main.record_event()
             last = t == T - 1
-            if bool(tr.any()) or last:                      # V(s') with the critic's carried state (ppo.py:183-184), without advancing it
-                rows = tr if not last else (tr | (self.b_done[t] == 0))
-                src = torch.where((self.b_done[t] != 0).view(N, 1), self.b_fin[t], obs)      # the episode's own next observation
-                v_next = L.critic.forward(src.contiguous(), hc=hc_c.clone()).view(-1)
-                self.b_boot[t] = torch.where(rows, v_next, torch.zeros_like(v_next))
-            ended = self.b_done[t] != 0
-            hc_a[:, :, ended] = 0; hc_c[:, :, ended] = 0    # init_hidden_state at every episode start (ppo.py:164-168)
+            with torch.cuda.stream(side):
+                side.wait_event(ev_step)
+                # a time-limit truncation needs max_traj_len steps since the env's last reset, and every env was reset at t = 0: before step
+                # max_traj_len - 1 there is nothing to bootstrap (and no reason to ask the device whether there is)
+                if last or t + 1 >= self.max_traj_len:      # V(s') with the critic's carried state (ppo.py:183-184), without advancing it
+                    tr = self.b_done[t] == 2
+                    rows = tr if not last else (tr | (self.b_done[t] == 0))
+                    src = torch.where((self.b_done[t] != 0).view(N, 1), self.b_fin[t], obs)      # the episode's own next observation
+                    v_next = L.critic.forward(src.contiguous(), hc=hc_c.clone()).view(-1)
+                    self.b_boot[t] = torch.where(rows, v_next, torch.zeros_like(v_next))
+                    main.wait_event(side.record_event())      # `obs` is overwritten by the next env step
+                hc_c.mul_((self.b_done[t] == 0).view(1, 1, N, 1))      # init_hidden_state at every episode start (ppo.py:164-168)
+            hc_a.mul_((self.b_done[t] == 0).view(1, 1, N, 1))
+        main.wait_stream(side)
         self.b_end.copy_((self.b_done != 0).to(torch.uint8)); self.b_end[T - 1] = 1      # the grid end cuts the last trajectory of every column
         ret = engine.returns_scan(self.b_rew, self.b_end, self.b_boot, torch.zeros(N, device=self.device), self.gamma)
         return ret
