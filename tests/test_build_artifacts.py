@@ -1,0 +1,55 @@
+"""Checks on the BUILT library that need no GPU: registers / scratch of the env kernels and the presence of the divergence guards in the ISA.
+Both were regressions that no parity test saw: 44 B of scratch from a struct copy under a branch (round 3), and the bit-pattern NaN tests of round 2
+folded to `false` by -ffast-math.  Reads apex_amd/lib/libapx.so with the ROCm binutils (llvm-objdump / llvm-readelf under /opt/rocm/lib/llvm/bin)."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(REPO, "apex_amd", "lib", "libapx.so")
+BIN = "/opt/rocm/lib/llvm/bin"
+
+
+@pytest.fixture(scope="module")
+def code_objects():
+    if not os.path.exists(LIB):
+        pytest.skip("libapx.so not built")
+    if not os.path.exists(os.path.join(BIN, "llvm-objdump")):
+        pytest.skip("ROCm binutils not present")
+    d = tempfile.mkdtemp()
+    shutil.copy(LIB, os.path.join(d, "lib.so"))
+    subprocess.run([os.path.join(BIN, "llvm-objdump"), "--offloading", "lib.so"], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    cos = [os.path.join(d, f) for f in os.listdir(d) if "gfx950" in f]
+    assert cos, "no gfx950 code object in libapx.so"
+    yield cos
+    shutil.rmtree(d, ignore_errors=True)
+
+
+def test_env_kernels_use_no_scratch(code_objects):
+    """private_segment_fixed_size of every env kernel (step / substep / reset, plane and height-field variants) is 0: scratch in the 2 kHz substep is HBM
+    traffic per wave and per substep, and every codegen scare so far came with it."""
+    seen = 0
+    for co in code_objects:
+        notes = subprocess.run([os.path.join(BIN, "llvm-readelf"), "--notes", co], capture_output=True, text=True).stdout
+        for m in re.finditer(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+)", notes, re.S):
+            name, scratch = m.group(1), int(m.group(2))
+            if "env_" in name and "kernel" in name:
+                seen += 1
+                assert scratch == 0, (name, scratch)
+    assert seen >= 9
+
+
+def test_divergence_guards_survive_fast_math(code_objects):
+    """The non-finite tests (c4::fbits) must be in the ISA of the step kernels: an exponent-mask compare with 0x7f800000.  A plain bitcast test is folded
+    away under -ffast-math, which is how round 2 shipped without them."""
+    big = max(code_objects, key=os.path.getsize)
+    asm = subprocess.run([os.path.join(BIN, "llvm-objdump"), "-d", "--mcpu=gfx950", big], capture_output=True, text=True).stdout
+    blocks = re.split(r"\n(?=[0-9a-f]+ <)", asm)
+    step = [b for b in blocks if re.match(r"[0-9a-f]+ <_Z15env_step_kernel", b)]
+    assert len(step) == 2
+    for b in step:
+        assert b.count("0x7f800000") >= 4, b[:80]
