@@ -49,6 +49,9 @@ template <int LEG> constexpr unsigned chain_mask(int body) {
     return m;
 }
 
+#ifndef APX_POSE_DPP
+#define APX_POSE_DPP 1     /* pose pointer jumping through ds_bpermute lane fetches (round 3) instead of the exchange records in LDS */
+#endif
 #ifndef APX_SUBTREE_SFX
 #define APX_SUBTREE_SFX 1  /* subtree sums as DPP suffix sums (round 3) instead of the descendant loop over LDS records */
 #endif
@@ -200,6 +203,33 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
     PROF2(12);
     // ---- pointer jumping over the ancestor chain (depth <= 8: 3 rounds).  Round r composes a body's transform with the
     // record of its 2^r-th ancestor, which by then spans 2^r levels itself; the same rounds give the chain sums below.
+#if APX_POSE_DPP
+    // Round r composes a body's transform with that of its 2^r-th ancestor, which by then spans 2^r levels itself.  The ancestor's transform is fetched
+    // straight from its lane with ds_bpermute (the LDS crossbar, no memory): seven words per leg and round, one wait per round.  Round 2 went through the
+    // exchange records (store, fence, load at a lane-dependent address, fence, per round).  A row_shr + select form is 7 VALU per word and is the trap of
+    // this kernel: clang predicates `c ? dpp(v) : r` as a DPP move under an exec mask, and a DPP read of a DISABLED source lane returns 0.
+    V3 tp[2]; Q4 tq[2];
+    sfor<0, 2>([&](auto Sd) { tp[Sd] = bpos[Sd]; tq[Sd] = lq[Sd]; });
+    {
+        const int jumpl[3] = {par, nibble(TB_PAR2, lb), nibble(TB_PAR4, lb)};
+        const int rowbase = (int)(threadIdx.x & 48u);
+        sfor<0, 3>([&](auto Rn) {
+            constexpr int r = Rn;
+            const bool on = jumpl[r] != 15;
+            const int src = 4 * (rowbase + (on ? jumpl[r] : l));
+            auto fetch = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v))); };
+            sfor<0, 2>([&](auto Sd) {
+                constexpr int sd = Sd;
+                const V3 ap = {fetch(tp[sd].x), fetch(tp[sd].y), fetch(tp[sd].z)};
+                const Q4 aq = {fetch(tq[sd].w), fetch(tq[sd].x), fetch(tq[sd].y), fetch(tq[sd].z)};
+                const V3 np = ap + mul(q2m(aq), tp[sd]);
+                const Q4 nq = qmul(aq, tq[sd]);
+                tp[sd] = {on ? np.x : tp[sd].x, on ? np.y : tp[sd].y, on ? np.z : tp[sd].z};
+                tq[sd] = {on ? nq.w : tq[sd].w, on ? nq.x : tq[sd].x, on ? nq.y : tq[sd].y, on ? nq.z : tq[sd].z};
+            });
+        });
+    }
+#else
     const int jump[3] = {par, nibble(TB_PAR2, lb), nibble(TB_PAR4, lb)};
     V3 tp[2]; Q4 tq[2];
     sfor<0, 2>([&](auto Sd) { tp[Sd] = bpos[Sd]; tq[Sd] = lq[Sd]; });
@@ -220,6 +250,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             if (jump[r] != 15) { tp[sd] = np; tq[sd] = nq; }
         });
     });
+#endif
     PROF2(13);
     M3 mat[2]; V3 pos[2]; Q4 quat[2]; SV vel[2], acc[2]; SV cdof[2][3];
     SV own[2];                                                        // this body's joint velocity contribution sum_K cdof_K qd_K
@@ -299,14 +330,14 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
     wsync();
     PROF2(16);
     // ---- subtree sums (composite inertia, subtree force): descendants are the next ndesc bodies
-    // (Two DPP forms were measured in round 3 and dropped.  Prefix differences, prefix(b + ndesc) - prefix(b - 1): the inertia of a 0.1 kg rod as the
-    // difference of two whole-leg prefixes loses its digits in fp32, the mass matrix stops being positive definite, every env is NaN within a step.
-    // A bottom-up sweep "s += [lane is the parent] * s(lane + k)", 11 child edges per float: correct, but 352 dependent v_mov_dpp + v_fmac pairs are
-    // slower than the loop's 88 ds_read_b128 + 352 v_fmac: 2.79 ms against 2.74 ms per launch.)
+    // (Two other DPP forms were measured in round 3 and dropped.  Prefix differences, prefix(b + ndesc) - prefix(b - 1): every env NaN within a step - the
+    // inertia of a 0.1 kg rod as the difference of two whole-leg prefixes loses its digits in fp32, and the form also held a `c ? dpp(v) : r` select,
+    // which clang executes as a DPP move under c's exec mask (a disabled source lane reads as 0; tools/dpp_audit.py).  A bottom-up sweep
+    // "s += [lane is the parent] * s(lane + k)", 11 child edges per float: correct, but 352 dependent v_mov_dpp + v_fmac pairs: 2.79 against 2.74 ms.)
 #if APX_SUBTREE_SFX
     // Depth-first numbering: every subtree interval [b, b + ndesc] ends at the foot (lane 11) except the leaves (own value) and the foot crank (itself
     // + the plantar rod).  So the subtree sum of a body on the path to the foot is the inclusive SUFFIX sum over lanes b..11 - four row_shl adds, sums
-    // only (the prefix-DIFFERENCE form above cancels) - and the others are one select each.  The shadow lanes 12..15 carry copies of the foot and are
+    // only (a prefix-DIFFERENCE form cancels in fp32) - and the others are one select each.  The shadow lanes 12..15 carry copies of the foot and are
     // zeroed first.  No LDS reads.
     {
         static_assert(TB_NDESC == nib(11, 10, 9, 0, 7, 0, 5, 4, 0, 1, 0, 0), "subtree intervals end at the foot, except leaves and the foot crank");

@@ -53,3 +53,16 @@ def test_divergence_guards_survive_fast_math(code_objects):
     assert len(step) == 2
     for b in step:
         assert b.count("0x7f800000") >= 4, b[:80]
+
+
+def test_no_cross_lane_read_under_a_select_mask():
+    """tools/dpp_audit.py on the product build: no DPP / bpermute instruction inside a short exec-mask region.  clang compiles `c ? dpp(v) : r` to a DPP
+    move under the mask of `c`, and a cross-lane read of a lane that the mask disabled returns 0 - silently (round 3: a pose fetch written that way produced
+    accelerations off by 1000 x; the most likely cause of the two unexplained faults of round 2)."""
+    import sys
+    if not os.path.exists(LIB) or not os.path.exists(os.path.join(BIN, "llvm-objdump")):
+        pytest.skip("library or ROCm binutils not present")
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import dpp_audit
+    hits = dpp_audit.audit(dpp_audit.disassemble(LIB), 16)
+    assert not hits, hits[:3]
