@@ -1,4 +1,4 @@
-# A/B of kernel variants: `bash tools/_ab.sh out_dir lib1 lib2 ...` (library base names under apex_amd/lib): quick parity tests + kernel ms for each
+# A/B of kernel variants: `bash tools/ab_variants.sh out_dir lib1 lib2 ...` (library base names under apex_amd/lib): quick parity tests + kernel ms for each
 out=gpurun_out/$1; shift; mkdir -p $out
 for L in "$@"; do
   echo "== $L"
