@@ -21,6 +21,7 @@ mkdir -p $OUT/hbm; cp -r $OUT/fetch $OUT/hbm/; cp -r $OUT/write $OUT/hbm/
 HASH=$(cd $ROOT && python -c "import bench; print(bench.kernel_source_hash())")
 python $ROOT/tools/pmc_summary.py $OUT/hbm $OUT/${TAG}_env_step_pmc_hbm.txt "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KB per dispatch) -- python tools/t_pmc.py; kernel sources sha1: $HASH" > /dev/null
 cd $ROOT
+cp $OUT/${TAG}_env_step_pmc_hbm.txt $ROOT/profiles/ 2>/dev/null || true      # bench.py reads roofline.traffic from profiles/<tag>_env_step_pmc_hbm.txt (same kernel-source hash): the lines below carry it
 python bench.py --steps 20 --warmup 2 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line.json
 python bench.py --steps 20 --warmup 2 --precision bf16 --no_cpu_baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line_bf16.json
 python bench.py --workload cassietraj_recurrent --steps 3 --warmup 1 --no_cpu_baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line_recurrent.json
