@@ -66,3 +66,28 @@ def test_no_cross_lane_read_under_a_select_mask():
     import dpp_audit
     hits = dpp_audit.audit(dpp_audit.disassemble(LIB), 16)
     assert not hits, hits[:3]
+
+
+def test_dpp_audit_flags_the_shape_it_is_meant_to_find():
+    """Positive control for tools/dpp_audit.py on a hand-written listing: a DPP move between s_and_saveexec and the matching s_or (the predicated select) is
+    reported, the same move outside a region or inside a long structured region is not."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import dpp_audit
+    bad = """
+0000000000001000 <kern_a>:
+	v_cmp_eq_u32_e32 vcc, 6, v1
+	s_and_saveexec_b64 s[4:5], vcc
+	v_mov_b32_dpp v21, v20 row_shr:6 row_mask:0xf bank_mask:0xf bound_ctrl:1
+	s_or_b64 exec, exec, s[4:5]
+	v_add_f32_e32 v2, v21, v3
+"""
+    good = """
+0000000000002000 <kern_b>:
+	v_mov_b32_dpp v21, v20 row_shr:6 row_mask:0xf bank_mask:0xf bound_ctrl:1
+	s_and_saveexec_b64 s[4:5], vcc
+""" + "\tv_add_f32_e32 v2, v2, v3\n" * 40 + """	v_mov_b32_dpp v22, v20 row_newbcast:3 row_mask:0xf bank_mask:0xf bound_ctrl:1
+	s_or_b64 exec, exec, s[4:5]
+"""
+    hits = dpp_audit.audit(bad + good, 16)
+    assert len(hits) == 1 and hits[0][0] == "kern_a" and "row_shr:6" in hits[0][2][0]
