@@ -52,6 +52,9 @@ template <int LEG> constexpr unsigned chain_mask(int body) {
 #ifndef APX_POSE_DPP
 #define APX_POSE_DPP 1     /* pose pointer jumping through ds_bpermute lane fetches (round 3) instead of the exchange records in LDS */
 #endif
+#ifndef APX_SUBTREE_PD
+#define APX_SUBTREE_PD 0
+#endif
 #ifndef APX_SUBTREE_SFX
 #define APX_SUBTREE_SFX 1  /* subtree sums as DPP suffix sums (round 3) instead of the descendant loop over LDS records */
 #endif
@@ -330,11 +333,32 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
     wsync();
     PROF2(16);
     // ---- subtree sums (composite inertia, subtree force): descendants are the next ndesc bodies
-    // (Two other DPP forms were measured in round 3 and dropped.  Prefix differences, prefix(b + ndesc) - prefix(b - 1): every env NaN within a step - the
-    // inertia of a 0.1 kg rod as the difference of two whole-leg prefixes loses its digits in fp32, and the form also held a `c ? dpp(v) : r` select,
-    // which clang executes as a DPP move under c's exec mask (a disabled source lane reads as 0; tools/dpp_audit.py).  A bottom-up sweep
-    // "s += [lane is the parent] * s(lane + k)", 11 child edges per float: correct, but 352 dependent v_mov_dpp + v_fmac pairs: 2.79 against 2.74 ms.)
-#if APX_SUBTREE_SFX
+    // (Two other DPP forms were measured in round 3 and dropped.  Prefix differences, prefix(b + ndesc) - prefix(b - 1), below as APX_SUBTREE_PD: as first
+    // written every env went NaN within a step - it held a `c ? dpp(v) : r` select, which clang executes as a DPP move under c's exec mask, where a disabled
+    // source lane reads as 0 (tools/dpp_audit.py).  With the cross-lane reads pinned it runs and passes the rollout parity tests, but fails the single-substep
+    // tolerance on the rod axes (the inertia of a 0.1 kg rod as the difference of two whole-leg prefixes loses digits in fp32) and is not faster: 2.61 ms.
+    // A bottom-up sweep "s += [lane is the parent] * s(lane + k)", 11 child edges per float: correct, but 352 dependent v_mov_dpp + v_fmac pairs: 2.79 against 2.74 ms.)
+#if APX_SUBTREE_PD      /* experiment only (tools/ab_variants.sh): the prefix-DIFFERENCE form with every cross-lane read taken unconditionally and pinned */
+    {
+        const bool leafb = lb == 3 || lb == 5 || lb == 8 || lb == 10, crank = lb == 9;
+        auto subtree = [&](float x) {
+            float pz = bl ? x : 0.f;
+            pz += dpp<0x111>(pz); pz += dpp<0x112>(pz); pz += dpp<0x114>(pz); pz += dpp<0x118>(pz);
+            float hi = dpp<0x150 + 11>(pz), nx = dpp<0x101>(pz), lo = dpp<0x111>(pz);
+            asm volatile("" : "+v"(hi), "+v"(nx), "+v"(lo));
+            float top = leafb ? pz : hi; top = crank ? nx : top;
+            return top - lo;
+        };
+        sfor<0, 2>([&](auto Sd) {
+            constexpr int sd = Sd;
+            const float c0 = subtree(crb[sd].m), c1 = subtree(crb[sd].h.x), c2 = subtree(crb[sd].h.y), c3 = subtree(crb[sd].h.z), c4 = subtree(crb[sd].I[0]),
+                        c5 = subtree(crb[sd].I[1]), c6 = subtree(crb[sd].I[2]), c7 = subtree(crb[sd].I[3]), c8 = subtree(crb[sd].I[4]), c9 = subtree(crb[sd].I[5]);
+            crb[sd] = SI{c0, {c1, c2, c3}, {c4, c5, c6, c7, c8, c9}};
+            frc[sd].a.x = subtree(frc[sd].a.x); frc[sd].a.y = subtree(frc[sd].a.y); frc[sd].a.z = subtree(frc[sd].a.z);
+            frc[sd].l.x = subtree(frc[sd].l.x); frc[sd].l.y = subtree(frc[sd].l.y); frc[sd].l.z = subtree(frc[sd].l.z);
+        });
+    }
+#elif APX_SUBTREE_SFX
     // Depth-first numbering: every subtree interval [b, b + ndesc] ends at the foot (lane 11) except the leaves (own value) and the foot crank (itself
     // + the plantar rod).  So the subtree sum of a body on the path to the foot is the inclusive SUFFIX sum over lanes b..11 - four row_shl adds, sums
     // only (a prefix-DIFFERENCE form cancels in fp32) - and the others are one select each.  The shadow lanes 12..15 carry copies of the foot and are
