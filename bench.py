@@ -85,6 +85,28 @@ def _pmc_traffic_bytes():
         return None
 
 
+def _pmc_issue():
+    """The instruction-issue view of the env kernel, from the SQ counter pass of the same profile round (profiles/r03_env_step_pmc_sq.txt, quoted only while
+    the HBM pass next to it carries this tree's kernel-source hash).  One single-wave workgroup sits on each SIMD, and a SIMD can start at most one VALU
+    instruction per quad-cycle, the unit SQ_WAVE_CYCLES counts in: valu_issue_frac = SQ_INSTS_VALU / SQ_WAVE_CYCLES is how much of that ceiling the
+    instruction stream uses, wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES how much of the time the wave sits in s_waitcnt.  flop_per_lane_instr relates it to the
+    flop roofline: a stream of packed FMAs (what the 157.3 TFLOP/s peak assumes) would be 4, plain FMAs 2."""
+    import re
+    from apex_amd import roofline
+    if _pmc_traffic_bytes() is None:
+        return None
+    try:
+        txt = open(os.path.join(REPO, "profiles", "r03_env_step_pmc_sq.txt")).read()
+        line = re.search(r"env_step_kernel[^:]*: (.*)", txt).group(1)
+        g = lambda k: float(re.search(k + r"=([0-9.e+]+)", line).group(1))
+        valu, wave, wait = g("SQ_INSTS_VALU"), g("SQ_WAVE_CYCLES"), g("SQ_WAIT_ANY")
+        return {"valu_issue_frac": round(valu / wave, 4), "wait_frac": round(wait / wave, 4), "valu_instr_per_launch": valu,
+                "flop_per_lane_instr": round(roofline.ENV_STEP_FLOP_COUNTED * 4096 / (valu * 64.0), 3),
+                "source": "profiles/r03_env_step_pmc_sq.txt (rocprofv3 --pmc, 4096 envs, per-dispatch means)"}
+    except Exception:
+        return None
+
+
 def main_td3(a):
     """BASELINE.json configs[4] (next row f2): Cassie-v0 TD3, 1 GPU, 10^6-transition replay in HBM; a "step" = 32 lock-step env steps of 4096
     envs, each followed by 4 twin-critic updates on 1024 samples."""
@@ -300,7 +322,7 @@ def main():
                          "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop_step * a.n_envs / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 6),
                          # the same launch time against the KERNEL's own (tree-sparse) operation count: the dense oracle executes ~13 % more operations than the kernel needs
                          "frac_sparse": round(roofline.ENV_STEP_FLOP * a.n_envs / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 6), "flop_per_env_step_sparse": roofline.ENV_STEP_FLOP,
-                         "traffic": _pmc_traffic_bytes(), "ms_per_launch": round(k_ms, 4), "launches_timed": k_launches,
+                         "traffic": _pmc_traffic_bytes(), "issue": _pmc_issue(), "ms_per_launch": round(k_ms, 4), "launches_timed": k_launches,
                          "flop_per_env_step": flop_step, "flop_source": "oracle-equivalent flops: instrumented count of the dense fp64 restatement oracle/cassie_phys.cpp (oracle.sim.count_flops); frac_sparse uses the hand count of the kernel's tree-sparse formulation",
                          "hbm": {"bytes_per_env_step": bytes_per_env_step, "achieved_GBps": round(achieved, 3), "peak_GBps": HBM_PEAK_GBS, "frac": round(achieved / HBM_PEAK_GBS, 6)},
                          "mlp_forward_mfma": {"what": "actor forward, %d x (50-256-256-10), fp32 MFMA (v_mfma_f32_32x32x2_f32), one fused launch (input normalisation + 3 layers, activations in LDS)" % mb_rows,
