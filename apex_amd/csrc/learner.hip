@@ -686,8 +686,8 @@ extern "C" size_t apx_lstm_workspace_floats(int T, int64_t B, int H, int L) { re
 
 __device__ __forceinline__ float sigmf(float x) { return 1.f / (1.f + expf(-x)); }
 // gates[B, 4H]: pre-activations (x W_ih^T + b_ih + h W_hh^T) in, activated (i, f, g, o) out
-__global__ void lstm_cell_fwd_kernel(float* __restrict__ gates, const float* __restrict__ bhh, const float* __restrict__ c_prev,
-                                     float* __restrict__ c_out, float* __restrict__ h_out, long B, int H) {
+__global__ void lstm_cell_fwd_kernel(float* __restrict__ gates, const float* __restrict__ bhh, const float* c_prev /* may alias c_out: the one-step call updates c in place */,
+                                     float* c_out, float* __restrict__ h_out, long B, int H) {
     const long e = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (e >= B * H) return;
     const long b = e / H; const int j = (int)(e - b * H);
@@ -896,6 +896,16 @@ extern "C" int apx_lstm_forward(const float* params, int D, int H, int L, int O,
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(lstm_seq_fwd_kernel<64, 4>), dim3(apx_cdiv(B, 16)), dim3(256), 0, s, G, P.Whh[l], P.bhh[l], hh, hcc, Cc, Hh, T, (long)B);
             APX_LAUNCH_CHECK();
             in = Hh;
+            continue;
+        }
+        if (T == 1 && hc) {      // the rollout's one-step call: the gate kernel updates the carried (h, c) in place (element-wise: a thread reads c[i] and
+            // writes c[i], and the recurrent GEMM that read h has finished on this stream), the next layer reads h from there: no copies
+            float* hslot = hc + (size_t)(2 * l) * B * H; float* cslot = hc + (size_t)(2 * l + 1) * B * H;
+            GemmArgs g{hslot, H, 1, P.Whh[l], 1, H, G, 4 * H, nullptr, 0, (int)B, 4 * H, H, 0, 0};
+            APX_TRY(launch_gemm(EPI_ACC, g, 1, s));
+            hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(apx_cdiv(B * H, 256)), dim3(256), 0, s, G, P.bhh[l], cslot, cslot, hslot, (long)B, H);
+            APX_LAUNCH_CHECK();
+            in = hslot;
             continue;
         }
         for (int t = 0; t < T; ++t) {
