@@ -53,7 +53,24 @@ def build_parser():
     p.add_argument("--bf16", dest="precision", action="store_const", const=1, default=0, help="learner GEMMs with bf16 MFMA inputs (fp32 accumulate / master weights); default fp32 MFMA")
     p.add_argument("--eval_every", type=int, default=10, help="deterministic evaluation pass (ppo.py:464) every k iterations; 1 = the reference's cadence, 0 = off")
     p.add_argument("--eval_envs", type=int, default=256, help="envs (= episodes) of the evaluation pass")
+    p.add_argument("--est_lifetime", type=int, default=None, help="env steps served by one state-estimator object: the reference builds a new CassieEnv (-> cassie_sim_init -> "
+                   "state_output_setup) per PPO.sample call (rl/algos/ppo.py:152), i.e. every num_steps // num_procs env steps.  Default: 5096 // --num_procs "
+                   "(5096 = the reference's --num_steps default, apex.py:244-246; this front-end's own --num_steps is rescaled to the lock-step batch and no longer "
+                   "describes one worker's share) = 169 with the reference's defaults; 0 = one estimator for the whole run")
     return p
+
+
+REFERENCE_NUM_STEPS = 5096      # the reference's --num_steps default (apex.py:244): what one PPO.sample fan-out collects in total
+
+
+def resolve_est_lifetime(args):
+    """est_lifetime of the run (DESIGN.md section 5, "Estimator lifetime"): explicit flag, else the reference's per-worker share num_steps // num_procs
+    (rl/algos/ppo.py:194: each of the n_proc workers samples min_steps // n_proc steps with ONE CassieEnv).  Stored in args, hence in experiment.pkl / .info."""
+    if getattr(args, "est_lifetime", None) is None:
+        args.est_lifetime = REFERENCE_NUM_STEPS // max(1, int(args.num_procs))
+    if args.est_lifetime < 0:
+        raise SystemExit("--est_lifetime must be >= 0")
+    return args
 
 
 def resolve_horizon(args, argv):
@@ -123,7 +140,8 @@ def _run_env_kwargs(path, reward_flag):
     if os.path.exists(pkl):
         with open(pkl, "rb") as f:
             run = pickle.load(f)
-        for key, arg in (("reward", "reward"), ("command_profile", "command_profile"), ("history", "history"), ("env_name", "env_name")):
+        for key, arg in (("reward", "reward"), ("command_profile", "command_profile"), ("input_profile", "input_profile"), ("history", "history"),
+                         ("env_name", "env_name"), ("est_lifetime", "est_lifetime"), ("simrate", "simrate")):
             if getattr(run, arg, None) is not None:
                 kw[key] = getattr(run, arg)
         if reward_flag != "clock":
@@ -270,6 +288,7 @@ def main(argv=None):
     from apex_amd.ppo import run_experiment
     args = parse_previous(args)
     args = resolve_horizon(args, argv[1:])
+    args = resolve_est_lifetime(args)
     run_experiment(args)
     return 0
 

@@ -146,6 +146,9 @@ class Lstm:
         """x [T, B, D] prepared input (or [B, D] for one step with the carried state hc [L, 2, B, H], updated in place)."""
         _need_gpu(x)
         step = x.dim() == 2
+        if keep and step and hc is not None:
+            raise ValueError("Lstm.forward(keep=True) with a carried one-step state: the in-place (h, c) path does not fill the backward workspace; "
+                             "run the sequence form [T, B, D] from a zero state for BPTT")
         x3 = (x.unsqueeze(0) if step else x).contiguous()
         T, B, _ = x3.shape
         assert x3.shape[-1] == self.D, "input width %d, the network was built for %d" % (x3.shape[-1], self.D)
@@ -191,6 +194,8 @@ class PPOLearner:
             self.obs_sp = torch.as_tensor(signed_perm_from_mirror(mirrored_obs), device=device)
             self.act_sp = torch.as_tensor(signed_perm_from_mirror(mirrored_acts), device=device)
             for c in clock_inds:
+                if not 0 <= int(c) < obs_dim:      # the reference takes them from env.clock_inds (rl/algos/ppo.py:307-310); a column beyond the observation would silently never be phase-shifted
+                    raise ValueError("clock index %d outside the %d-entry observation" % (int(c), obs_dim))
                 self.clock_mask |= 1 << int(c)
         self._ws = None
         self._scal = torch.zeros(6, dtype=torch.float64, device=device)
@@ -261,6 +266,8 @@ class RecurrentPPOLearner:
             self.obs_sgn = torch.as_tensor(np.where(sp >= 0, 1.0, -1.0), dtype=torch.float32, device=device)
             self.act_sp = torch.as_tensor(signed_perm_from_mirror(mirrored_acts), device=device)
             self.clock_cols = [int(c) for c in clock_inds]
+            if any(not 0 <= c < obs_dim for c in self.clock_cols):
+                raise ValueError("clock indices %r outside the %d-entry observation" % (self.clock_cols, obs_dim))
         self._scal = torch.zeros(6, dtype=torch.float64, device=device)
         self._acc = torch.zeros(8, dtype=torch.float64, device=device)
 

@@ -62,6 +62,8 @@ def parse_previous(args):
         run_args = pickle.load(open(os.path.join(args.previous, "experiment.pkl"), "rb"))
         for k in ("recurrent", "env_name", "command_profile", "input_profile", "learn_gains", "traj", "no_delta", "ik_baseline"):
             setattr(args, k, getattr(run_args, k))
+        if getattr(run_args, "est_lifetime", None) is not None and getattr(args, "est_lifetime", None) is None:
+            args.est_lifetime = run_args.est_lifetime      # (engine flag) the continued run keeps the estimator lifetime it was trained with
         if args.exchange_reward is not None:
             args.reward = args.exchange_reward
             args.run_name = run_args.run_name + "_NEW-" + args.reward

@@ -62,6 +62,7 @@ class PPO:
         self.save_path = save_path
         self.env = env
         self.rank, self.world, self.group = rank, world_size, group
+        self.dist_on = group is not None      # the collective path runs whenever a process group is given, world_size 1 included (APX_FORCE_DIST: the RCCL path on one GPU)
         self.device = env.device
         self.N = env.n_envs
         self.D = int(getattr(env, "obs_dim", 50))              # 50 (command_profile clock) or 55 (phase), x (history + 1)
@@ -72,7 +73,7 @@ class PPO:
         self.learner = engine.PPOLearner(self.D, 10, hidden, self.device, self.fixed_std, lr=self.lr, eps=self.eps,
                                          clip=self.clip, entropy_coeff=self.entropy_coeff, grad_clip=self.grad_clip, precision=int(args.get("precision", 0)),
                                          mirrored_obs=list(getattr(env, "mirrored_obs", MIRRORED_OBS)) if self.mirror else None,
-                                         mirrored_acts=MIRRORED_ACTS if self.mirror else None, clock_inds=CLOCK_INDS)
+                                         mirrored_acts=MIRRORED_ACTS if self.mirror else None, clock_inds=list(getattr(env, "clock_inds", CLOCK_INDS)))      # env.clock_inds like rl/algos/ppo.py:307-310 (21, 22 with input_profile=min)
         self.total_steps = 0
         self.highest_reward = -1
         self.gen = torch.Generator(device=self.device)
@@ -87,7 +88,7 @@ class PPO:
         self.b_endb = torch.zeros(T, N, dtype=torch.bool, device=self.device)
         self.b_fin = torch.zeros(T, N, self.D, **f32)
         self.noise = torch.zeros(T, N, 10, **f32)
-        self.use_graph = bool(args.get("graph", False)) and self.world == 1
+        self.use_graph = bool(args.get("graph", False)) and not self.dist_on
         self._graph = None
         self.ep_ret = torch.zeros(N, **f32); self.ep_len = torch.zeros(N, **f32)
         self.obs = None
@@ -235,7 +236,7 @@ class PPO:
             nb = B // mb                                                                     # drop_last=True, ppo.py:416
             for k in range(nb):
                 idx = perm[k * mb:(k + 1) * mb]
-                if self.world > 1:
+                if self.dist_on:
                     scal = L.minibatch(obs, act, ret, adv, mu, idx=idx, mirror=self.mirror, grad_only=True, sync=False)
                     adist.allreduce_mean_(L.grad_flat, group=self.group, world=self.world)   # one RCCL all-reduce / step
                     L.apply_grads(scale=1.0)
@@ -245,7 +246,7 @@ class PPO:
                 if self.trace is not None:
                     self.trace.append(scal.clone())
             both = torch.cat([acc / max(nb, 1), scal.to(acc.dtype)])                         # epoch means + the last minibatch (KL test)
-            if self.world > 1:
+            if self.dist_on:
                 adist.allreduce_mean_(both, group=self.group, world=self.world)              # ONE scalar all-reduce per epoch
             both = both.cpu().numpy()                                                        # the epoch's only host sync: the KL decision
             losses, kl_last = both[:6], float(both[10])
@@ -368,7 +369,7 @@ def run_experiment(args):
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     group = None
-    if world > 1:
+    if world > 1 or os.environ.get("APX_FORCE_DIST") == "1":      # (APX_FORCE_DIST: the RCCL path at world_size 1, launched through torch.distributed.run)
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
         group = torch.distributed.group.WORLD
     torch.manual_seed(args.seed); np.random.seed(args.seed)
@@ -376,7 +377,7 @@ def run_experiment(args):
     env_kwargs = dict(simrate=args.simrate, dynamics_randomization=args.dyn_random, reward=args.reward, seed=args.seed,
                       command_profile=args.command_profile, input_profile=args.input_profile, history=args.history,
                       learn_gains=args.learn_gains, env_name=args.env_name, traj=args.traj, no_delta=args.no_delta,
-                      ik_baseline=args.ik_baseline)
+                      ik_baseline=args.ik_baseline, est_lifetime=int(getattr(args, "est_lifetime", None) if getattr(args, "est_lifetime", None) is not None else 169))
     env = CassieVecEnv(n_envs=n_envs, max_traj_len=args.max_traj_len, device=local, env_id_base=adist.shard_env_base(rank, n_envs), **env_kwargs)
     logger = create_logger(args) if rank == 0 else None
     a = dict(vars(args)); a["mirror"] = args.mirror; a["env_kwargs"] = env_kwargs

@@ -27,9 +27,13 @@ class RecurrentPPO:
         self.env_name = args.get("env_name", "Cassie-v0")
         self.save_path, self.env = save_path, env
         self.rank, self.world, self.group = rank, world_size, group
+        self.dist_on = group is not None      # the collective path runs whenever a process group is given, world_size 1 included (APX_FORCE_DIST: the RCCL path on one GPU)
         self.device, self.N = env.device, env.n_envs
         if getattr(env, "obs_dim", 50) != 50:
             raise NotImplementedError("recurrent PPO is built for the 50-entry observation (command_profile=clock, history 0); this env produces %d entries" % getattr(env, "obs_dim", 50))
+        # the bootstrap of time-limit truncations is only looked for from step max_traj_len - 1 on (sample()): that threshold must be the one the ENV uses for done == 2
+        if getattr(env, "max_traj_len", self.max_traj_len) != self.max_traj_len:
+            raise ValueError("env.max_traj_len %d != args max_traj_len %d: time-limit truncations would be bootstrapped with 0" % (env.max_traj_len, self.max_traj_len))
         self.T = adist.rollout_len(self.num_steps, self.N, self.world)
         # every iteration restarts all envs (each trajectory must begin at an episode start with zero hidden state, like the padded
         # training pass assumes), so a grid shorter than max_traj_len would never show the policy the later part of an episode
@@ -39,7 +43,7 @@ class RecurrentPPO:
         self.H, self.L = hidden, layers
         self.learner = engine.RecurrentPPOLearner(50, 10, hidden, layers, self.device, self.fixed_std, lr=self.lr, eps=self.eps, clip=self.clip,
                                                   grad_clip=self.grad_clip, mirrored_obs=MIRRORED_OBS if self.mirror else None,
-                                                  mirrored_acts=MIRRORED_ACTS if self.mirror else None, clock_inds=CLOCK_INDS)
+                                                  mirrored_acts=MIRRORED_ACTS if self.mirror else None, clock_inds=list(getattr(env, "clock_inds", CLOCK_INDS)))      # env.clock_inds like rl/algos/ppo.py:307-310 (21, 22 with input_profile=min)
         self.gen = torch.Generator(device=self.device); self.gen.manual_seed(int(args.get("seed", 0)) * 1000003 + rank)
         T, N = self.T, self.N
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -140,8 +144,8 @@ class RecurrentPPO:
                     v_next = L.critic.forward(src.contiguous(), hc=hc_c.clone()).view(-1)
                     self.b_boot[t] = torch.where(rows, v_next, torch.zeros_like(v_next))
                     main.wait_event(side.record_event())      # `obs` is overwritten by the next env step
-                hc_c.mul_((self.b_done[t] == 0).view(1, 1, N, 1))      # init_hidden_state at every episode start (ppo.py:164-168)
-            hc_a.mul_((self.b_done[t] == 0).view(1, 1, N, 1))
+                hc_c.masked_fill_((self.b_done[t] != 0).view(1, 1, N, 1), 0.0)      # init_hidden_state at every episode start (ppo.py:164-168); an assignment, not a product: 0 * NaN stays NaN
+            hc_a.masked_fill_((self.b_done[t] != 0).view(1, 1, N, 1), 0.0)
         main.wait_stream(side)
         self.b_end.copy_((self.b_done != 0).to(torch.uint8)); self.b_end[T - 1] = 1      # the grid end cuts the last trajectory of every column
         ret = engine.returns_scan(self.b_rew, self.b_end, self.b_boot, torch.zeros(N, device=self.device), self.gamma)
@@ -178,7 +182,7 @@ class RecurrentPPO:
         # optimiser steps per epoch is agreed first (max over ranks); a rank that has run out of trajectories contributes a zero gradient to
         # the remaining all-reduces.  Every rank therefore issues the same sequence of collectives and ends with the same parameters.
         n_mb = -(-len(trajs) // mb)
-        if self.world > 1:
+        if self.dist_on:
             cnt = torch.tensor([n_mb], dtype=torch.int64, device=self.device)
             torch.distributed.all_reduce(cnt, op=torch.distributed.ReduceOp.MAX, group=self.group)
             n_mb = int(cnt)
@@ -202,15 +206,15 @@ class RecurrentPPO:
                 gi = idx.clamp(min=0).view(-1)
                 pick = lambda x, d: (flat(x, d).index_select(0, gi) * valid.view(-1, 1)).view(idx.shape[0], idx.shape[1], d)
                 scal = L.minibatch(pick(self.b_obs, 50), pick(self.b_act, 10), pick(retf, 1), pick(adv, 1), valid.float().unsqueeze(-1),
-                                   mirror=self.mirror, grad_only=self.world > 1)
-                if self.world > 1:
+                                   mirror=self.mirror, grad_only=self.dist_on)
+                if self.dist_on:
                     adist.allreduce_mean_(L.grad_flat, group=self.group, world=self.world)
                     L.apply_grads()
                 acc += scal; nb += 1
                 if self.trace is not None:
                     self.trace.append(scal.clone())
             both = torch.cat([acc / max(nb, 1), scal.to(acc.dtype)])
-            if self.world > 1:
+            if self.dist_on:
                 adist.allreduce_mean_(both, group=self.group, world=self.world)          # the KL decision must be the same on every rank
             both = both.cpu().numpy()
             losses, kl_last = both[:6], float(both[10]); epochs_run += 1

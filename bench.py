@@ -107,6 +107,19 @@ def _pmc_issue():
         return None
 
 
+def _init_group(world, local, share):
+    """The process group of the N > 1 path: RCCL ("nccl" IS RCCL on ROCm), one rank per GPU.  APX_FORCE_DIST=1 also builds it at world_size 1 (launched through
+    torch.distributed.run --nproc-per-node 1), so that init_process_group("nccl", device_id=...), the gradient / moment / scalar all-reduces on device tensors and
+    their event timing can be executed on a 1-GPU box; APX_BENCH_SHARE_GPU=1 (tests) puts every rank on cuda:0 over gloo."""
+    if world == 1 and os.environ.get("APX_FORCE_DIST") != "1":
+        return None
+    if share:
+        torch.distributed.init_process_group("gloo")
+    else:
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+    return torch.distributed.group.WORLD
+
+
 def main_td3(a):
     """BASELINE.json configs[4] (next row f2): Cassie-v0 TD3, 1 GPU, 10^6-transition replay in HBM; a "step" = 32 lock-step env steps of 4096
     envs, each followed by 4 twin-critic updates on 1024 samples."""
@@ -141,13 +154,8 @@ def main_recurrent(a):
     if share:
         local = 0
     torch.cuda.set_device(local)
-    group = None
-    if world > 1:
-        if share:
-            torch.distributed.init_process_group("gloo")
-        else:
-            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
-        group = torch.distributed.group.WORLD
+    group = _init_group(world, local, share)
+    dist_on = group is not None
     from apex_amd.vecenv import CassieVecEnv
     from apex_amd.ppo_recurrent import RecurrentPPO
     from apex_amd import dist as adist
@@ -160,18 +168,22 @@ def main_recurrent(a):
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier(); torch.cuda.synchronize()
     for _ in range(a.warmup):
         algo.iteration()
+    if dist_on:
+        adist.timing(True)
     barrier(); t0 = time.time(); samp = opt = 0.0
     for _ in range(a.steps):
         out = algo.iteration(); samp += out["sample_time"]; opt += out["optimize_time"]
     barrier(); dt = time.time() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=env.device)
-    if world > 1:
+    if dist_on:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax)
+    ar_ms, ar_calls = adist.timing_read() if dist_on else (0.0, 0)
+    adist.timing(False)
     if rank == 0:
         steps_total = a.steps * T * n_envs * world
         print(json.dumps({"metric": "env-steps/sec (whole node) CassieTraj-v0 recurrent PPO @2048 envs/GPU", "value": round(steps_total / dt, 1),
@@ -180,8 +192,11 @@ def main_recurrent(a):
                           "config": {"workload": "CassieTraj-v0 recurrent PPO (LSTM 2x128 actor/critic, whole-trajectory minibatches), 2048 envs/GPU (BASELINE.json configs[3])",
                                      "envs_per_gpu": n_envs, "rollout_len": T, "minibatch_trajectories": min(1024, n_envs // 2), "epochs": a.epochs, "mirror_loss": True,
                                      "parallelism": f"dp{world} (env shards; optimiser steps per epoch agreed by a MAX all-reduce, 1 gradient all-reduce per step)"},
-                          "sample_s": round(samp / a.steps, 3), "optimize_s": round(opt / a.steps, 3)}))
-    if world > 1:
+                          "sample_s": round(samp / a.steps, 3), "optimize_s": round(opt / a.steps, 3),
+                          "collectives": {"rccl_ranks_seen": torch.distributed.get_world_size() if dist_on else 1, "backend": torch.distributed.get_backend() if dist_on else None,
+                                          "allreduce_calls_per_step": round(ar_calls / a.steps, 1), "allreduce_ms_per_step": round(ar_ms / a.steps, 3),
+                                          "gradient_floats": int(algo.learner.grad_flat.numel())}}))
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 
@@ -215,12 +230,8 @@ def main():
     if share:
         local = 0
     torch.cuda.set_device(local)
-    if world > 1:
-        if share:
-            torch.distributed.init_process_group("gloo")
-        else:
-            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
-        group = torch.distributed.group.WORLD
+    group = _init_group(world, local, share)
+    dist_on = group is not None
     from apex_amd.vecenv import CassieVecEnv
     from apex_amd.ppo import PPO
     from apex_amd import dist as adist
@@ -234,7 +245,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
@@ -243,7 +254,7 @@ def main():
     # per-launch duration of the dominant kernel (env step): hipEvent pairs recorded by the library around every env_step_kernel launch of
     # the timed region, on the stream the kernel is launched on (include/apx.h apx_env_timing)
     env.kernel_timing(True); env.kernel_timing_read(reset=True)
-    if world > 1:
+    if dist_on:
         adist.timing(True)
     barrier()
     t0 = time.time()
@@ -254,10 +265,10 @@ def main():
     barrier()
     dt = time.time() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=env.device)
-    if world > 1:
+    if dist_on:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax)
-    ar_ms, ar_calls = adist.timing_read() if world > 1 else (0.0, 0)
+    ar_ms, ar_calls = adist.timing_read() if dist_on else (0.0, 0)
     adist.timing(False)
     k_total_ms, k_launches = env.kernel_timing_read(reset=True)      # the env_step_kernel launches of the timed region
     if k_launches == 0:      # APX_ROLLOUT_GRAPH=1: the rollout was captured during warm-up, before the event pairs were switched on -> a few eager timed launches
@@ -313,7 +324,7 @@ def main():
             "sample_s": round(samp / a.steps, 3), "optimize_s": round(opt / a.steps, 3),
             # what the collective path actually was in this run (explains a scaling curve on its own): ranks the process group saw, backend, and the
             # gradient / scalar all-reduces of the timed region (hipEvents on the launch stream of rank 0)
-            "collectives": {"rccl_ranks_seen": torch.distributed.get_world_size() if world > 1 else 1, "backend": torch.distributed.get_backend() if world > 1 else None,
+            "collectives": {"rccl_ranks_seen": torch.distributed.get_world_size() if dist_on else 1, "backend": torch.distributed.get_backend() if dist_on else None,
                             "allreduce_calls_per_step": round(ar_calls / a.steps, 1), "allreduce_ms_per_step": round(ar_ms / a.steps, 3), "gradient_floats": 160523},
             # the binding bound of the dominant kernel is the fp32 vector pipe (HBM traffic is 1.1 x the algorithmic bytes and
             # < 0.1 % of the peak): achieved = instrumented flops of the CPU restatement per env step x envs / launch time.  The HBM view
@@ -334,7 +345,7 @@ def main():
         if cpu:
             res["cpu_baseline"] = cpu
         print(json.dumps(res))
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

@@ -121,6 +121,8 @@ void orc_est_step(void* h, const double* in, double* out) {
     out[22] = s.heel[0]; out[23] = s.heel[1]; out[24] = s.lm_iters; std::memcpy(out + 25, s.foot_quat, sizeof(double) * 8);
 }
 double orc_est_heel_residual(double knee, double shin, double tarsus, double heel, double* grad4) { return heel_residual(knee, shin, tarsus, heel, grad4); }
+void orc_est_hfilter_step(double* x6, double* P36, double zL, double zR, double fl, double fr, double acc) { hfilter_step(x6, P36, zL, zR, fl, fr, acc); }
+void orc_est_zfilter_step(double* x5, double* P25, double zL, double zR, double fl, double fr) { zfilter_step(x5, P25, zL, zR, fl, fr); }
 void orc_est_mldivide23(const double* M6 /* row-major 2 x 3 */, const double* tau, double* x) { const double M[2][3] = {{M6[0], M6[1], M6[2]}, {M6[3], M6[4], M6[5]}}; mldivide23(M, tau, x); }
 unsigned long long orc_flops(int reset) { const unsigned long long v = g_flops; if (reset) g_flops = 0; return v; }      // instrumented op count of this thread
 void orc_env_set_const(void* h) { set_const(((Env*)h)->par); }

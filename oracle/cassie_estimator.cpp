@@ -77,6 +77,8 @@ void apa(int n, const double* A, double* P) {      // P <- A P A^T
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) { double s = 0; for (int k = 0; k < n; ++k) { CNT(j == k ? 0 : NZ(T[i * n + k], A[j * n + k])); s += T[i * n + k] * A[j * n + k]; } R[i * n + j] = s; }
     for (int i = 0; i < n * n; ++i) P[i] = R[i];
 }
+}  // namespace
+
 // horizontal filter step (0x1cd10): extended Kalman filter on the linear inverted pendulum
 void hfilter_step(double* x, double* P, double zL, double zR, double fl, double fr, double acc) {
     const double tot = fl + fr;
@@ -120,7 +122,6 @@ void zfilter_step(double* x, double* P, double zL, double zR, double fl, double 
     kf_scalar_update(5, x, P, 0, 2, zL, 1e-6);
     kf_scalar_update(5, x, P, 0, 3, zR, 1e-6);
 }
-}  // namespace
 
 double heel_residual(double knee, double shin, double tarsus, double heel, double* grad4) {
     double r = kHeelConst;

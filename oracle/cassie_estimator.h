@@ -46,5 +46,9 @@ void state_output_step(StateOutput& s, const EstSensors& in);
 double heel_residual(double knee, double shin, double tarsus, double heel, double* grad4 /* d/d(knee, shin, tarsus, heel) or nullptr */);
 void heel_solve(double heel[2], const double legL[3], const double legR[3], int* iters);
 void mldivide23(const double M[2][3], const double tau[2], double x[3]);
+// one step of a horizontal filter (0x1cd10; x[6], P[36] row-major, in place): measurements zL = p - foot L, zR = p - foot R, foot loads fl, fr >= 0, IMU acceleration
+void hfilter_step(double* x, double* P, double zL, double zR, double fl, double fr, double acc);
+// one step of the vertical filter (inline in the binary, 0x2a858-0x2c607; x[5], P[25])
+void zfilter_step(double* x, double* P, double zL, double zR, double fl, double fr);
 
 }  // namespace orc

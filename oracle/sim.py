@@ -69,6 +69,8 @@ def lib():
         L.orc_est_heel_residual.restype = C.c_double
         L.orc_est_heel_residual.argtypes = [C.c_double] * 4 + [C.c_void_p]
         L.orc_est_mldivide23.argtypes = [C.c_void_p] * 3
+        L.orc_est_hfilter_step.argtypes = [C.c_void_p, C.c_void_p] + [C.c_double] * 5
+        L.orc_est_zfilter_step.argtypes = [C.c_void_p, C.c_void_p] + [C.c_double] * 4
         L.orc_rollout_bench.restype = C.c_double
         L.orc_rollout_bench.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_double]
         _lib = L
@@ -280,6 +282,19 @@ def heel_residual(knee, shin, tarsus, heel):
     g = np.zeros(4)
     r = lib().orc_est_heel_residual(float(knee), float(shin), float(tarsus), float(heel), _ptr(g))
     return r, g
+
+
+def hfilter_step(x, P, zL, zR, fl, fr, acc):
+    """one step of the estimator's horizontal filter, oracle/cassie_estimator.cpp hfilter_step (the C++ the env runs) -> (x', P')"""
+    xx = np.array(x, dtype=np.float64).reshape(6).copy(); PP = np.array(P, dtype=np.float64).reshape(36).copy()
+    lib().orc_est_hfilter_step(_ptr(xx), _ptr(PP), float(zL), float(zR), float(fl), float(fr), float(acc))
+    return xx, PP.reshape(6, 6)
+
+
+def zfilter_step(x, P, zL, zR, fl, fr):
+    xx = np.array(x, dtype=np.float64).reshape(5).copy(); PP = np.array(P, dtype=np.float64).reshape(25).copy()
+    lib().orc_est_zfilter_step(_ptr(xx), _ptr(PP), float(zL), float(zR), float(fl), float(fr))
+    return xx, PP.reshape(5, 5)
 
 
 def mldivide23(M, tau):

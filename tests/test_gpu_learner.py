@@ -348,6 +348,42 @@ def test_full_size_properties_of_the_learner_kernels(dev):
     np.testing.assert_allclose(scal[5], 0.4 * float(((mu - mir) ** 2).mean()), rtol=2e-4)
 
 
+def test_mirror_loss_uses_the_env_clock_columns_min_profile(dev):
+    """with input_profile=min the clock pair sits in columns 21, 22 of the 25-entry observation (cassie.py:829-837), and the reference takes the
+    columns from env.clock_inds (rl/algos/ppo.py:307-310).  The mirror term of the fused minibatch must equal 0.4 * mean((f(s) - M_a f(M_s s))^2) with the
+    min-profile mirror list and THOSE columns phase-shifted; columns beyond the observation are refused."""
+    from apex_amd import engine
+    from apex_amd.vecenv import mirrored_obs_for, MIRRORED_ACTS, OBS_DIM_MIN
+    D = OBS_DIM_MIN + 4
+    clock = [D - 4, D - 3]
+    mo = mirrored_obs_for("clock", "min")
+    with pytest.raises(ValueError):
+        engine.PPOLearner(D, 10, 256, dev, float(np.exp(-1.5)), mirrored_obs=mo, mirrored_acts=MIRRORED_ACTS, clock_inds=[46, 47])
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
+    L = engine.PPOLearner(D, 10, 256, dev, float(np.exp(-1.5)), mirrored_obs=mo, mirrored_acts=MIRRORED_ACTS, clock_inds=clock)
+    L.actor.params.copy_(rnd(L.actor.n) * 0.05); L.critic.params.copy_(rnd(L.critic.n) * 0.05)
+    B = 4096
+    obs = rnd(B, D) * 0.5; ph = torch.rand(B, device=dev, generator=g) * 6.28; obs[:, clock[0]] = torch.sin(ph); obs[:, clock[1]] = torch.cos(ph)
+    act = rnd(B, 10) * 0.3; retb = rnd(B); advb = rnd(B)
+    mu = L.old_means(obs)
+    scal = L.minibatch(obs, act, retb, advb, mu, grad_only=True)
+    sp = engine.signed_perm_from_mirror(mo); ap = engine.signed_perm_from_mirror(MIRRORED_ACTS)
+    src = torch.as_tensor(np.where(sp >= 0, sp, -sp - 1), device=dev); sgn = torch.as_tensor(np.where(sp >= 0, 1.0, -1.0), dtype=torch.float32, device=dev)
+    mobs = obs.index_select(1, src) * sgn
+    for c in clock:
+        mobs[:, c] = torch.sin(torch.asin(mobs[:, c].clamp(-1, 1)) + np.pi)
+    f_m = L.actor.forward(mobs.contiguous(), L.obs_mean, L.obs_std)
+    asrc = torch.as_tensor(np.where(ap >= 0, ap, -ap - 1), device=dev); asgn = torch.as_tensor(np.where(ap >= 0, 1.0, -1.0), dtype=torch.float32, device=dev)
+    mir = f_m.index_select(1, asrc) * asgn
+    want = 0.4 * float(((mu - mir) ** 2).mean())
+    np.testing.assert_allclose(scal[5], want, rtol=2e-4)
+    # and it is NOT what the full-profile columns would give (no column phase-shifted at all): the test can tell the difference
+    mobs0 = obs.index_select(1, src) * sgn
+    mir0 = L.actor.forward(mobs0.contiguous(), L.obs_mean, L.obs_std).index_select(1, asrc) * asgn
+    assert abs(0.4 * float(((mu - mir0) ** 2).mean()) - want) > 1e-3 * want
+
+
 def test_bf16_throughput_mode_vs_fp32(dev, golden_dir):
     """precision = 1 (BASELINE configs[1] "bf16"; SURVEY section 8d cfg-2: bf16 MFMA inputs, fp32 accumulate, fp32 master weights / Adam): the six
     scalars of update_policy against golden G4 within bf16 round-off,

@@ -142,3 +142,25 @@ def test_eight_ranks_bench_driver_on_a_shared_gpu(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["parallelism"].startswith("dp8")
     assert abs(d["value"] - 8 * 256 * 8 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+
+
+def test_rccl_path_at_world_size_one(tmp_path):
+    """the RCCL branch itself, executed on one GPU.  APX_FORCE_DIST=1 + torch.distributed.run --nproc-per-node 1 sends bench.py through
+    init_process_group("nccl", device_id=...), the flat-gradient all-reduce on the 160 523-float device tensor (one per optimiser step), the advantage /
+    observation moment all-reduces and the merged per-epoch scalar all-reduce, with the event timing of apex_amd/dist.py around them."""
+    import json, subprocess, sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env["APX_FORCE_DIST"] = "1"; env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.pop("APX_BENCH_SHARE_GPU", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--n_envs", "1024", "--rollout_len", "16", "--minibatch", "2048", "--no_cpu_baseline"]
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    c = d["collectives"]
+    assert c["backend"] == "nccl" and c["rccl_ranks_seen"] == 1 and c["gradient_floats"] == 160523
+    # 3 epochs x 8 minibatches of 2048 gradient all-reduces + 3 per-epoch scalar all-reduces per iteration (fewer only if the KL test stops an epoch loop early)
+    assert 9 <= c["allreduce_calls_per_step"] <= 27
+    assert c["allreduce_ms_per_step"] > 0.0
+    assert d["n_gpus"] == 1 and d["value"] > 0

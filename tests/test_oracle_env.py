@@ -133,13 +133,22 @@ def test_g11_estimator_internal_routines(golden_dir):
     for x, o in zip(g["ml_in"], g["ml_out"]):
         sol = S.mldivide23(x[:6].reshape(2, 3), x[6:8])
         assert np.abs(sol - o).max() < 1e-11 * max(1.0, np.abs(o).max()) and np.sum(sol == 0.0) == 1          # the basic solution: one exact zero
-    e = S.OracleEnv(dyn_rand=False, seed=0)
     for x, o in zip(g["hf_in"], g["hf_out"]):
-        # drive the env's x filter: state, covariance, then one estimator step would need sensors; the filter step itself is exposed through the
-        # env fields (est_hx / est_hP) and the pure-python restatement below, which the C++ shares line by line
+        # the binary's vectors against the ORACLE's own C++ filter step (oracle/cassie_estimator.cpp hfilter_step through the C API: the code the env
+        # runs), and against the batch-update Python form below as a second opinion (the C++ processes the diagonal-R update as four scalar updates)
         x0, P0, a = x[:6], x[6:42].reshape(6, 6), x[42:48]
+        xc, Pc = S.hfilter_step(x0, P0, a[0] - a[1], a[0] - a[2], max(0.0, a[3]), max(0.0, a[4]), a[5])
+        assert np.abs(xc - o[:6]).max() < 1e-12 and np.abs(Pc.reshape(-1) - o[6:]).max() < 1e-14, (np.abs(xc - o[:6]).max(), np.abs(Pc.reshape(-1) - o[6:]).max())
         xn, Pn = _hfilter_py(x0, P0, a)
         assert np.abs(xn - o[:6]).max() < 1e-12 and np.abs(Pn.reshape(-1) - o[6:]).max() < 1e-15
+    # the vertical filter is inline in the binary (no callable entry point, hence no known-answer vector): the C++ step against its textbook form
+    rng = np.random.RandomState(3)
+    for _ in range(20):
+        x0 = rng.randn(5); Mh = rng.randn(5, 5) * 1e-3; P0 = Mh @ Mh.T + 1e-6 * np.eye(5)
+        zL, zR, fl, fr = rng.randn() * 0.1, rng.randn() * 0.1, abs(rng.randn()) * 100, abs(rng.randn()) * 100
+        xc, Pc = S.zfilter_step(x0, P0, zL, zR, fl, fr)
+        xn, Pn = _zfilter_py(x0, P0, zL, zR, fl, fr)
+        assert np.abs(xc - xn).max() < 1e-12 and np.abs(Pc - Pn).max() < 1e-15
 
 
 def _hfilter_py(x, P, a, dt=5e-4, g=9.806, hgt=1.0, m=31.0):
@@ -157,6 +166,16 @@ def _hfilter_py(x, P, a, dt=5e-4, g=9.806, hgt=1.0, m=31.0):
     H = np.zeros((4, 6)); H[0, 0] = 1; H[0, 2] = -1; H[1, 0] = 1; H[1, 3] = -1; H[2, 4] = 1; H[3, 1] = 1
     K = Pp @ H.T @ np.linalg.inv(H @ Pp @ H.T + np.diag([1e-6, 1e-6, 1e-6, 1.0]))
     return xp + K @ (np.array([a0 - a1, a0 - a2, alpha_m, v + dt * acc]) - H @ xp), Pp - K @ H @ Pp
+
+
+def _zfilter_py(x, P, zL, zR, fl, fr, dt=5e-4, g=9.806, m=31.0):
+    """the vertical Kalman filter of state_output_step as decoded (oracle/cassie_estimator.cpp zfilter_step), batch update"""
+    A = np.eye(5); A[0, 1] = dt; A[1, 4] = dt / m
+    xp = np.array(x, dtype=float); xp[0] = x[0] + dt * x[1]; xp[1] = x[1] + dt / m * x[4] + dt * ((fl + fr) / m - g)
+    Pp = A @ P @ A.T + np.diag([1e-8, 1e-8, 1e-6 if 50.0 > fl else 1e-10, 1e-6 if 50.0 > fr else 1e-10, 0.01])
+    H = np.zeros((2, 5)); H[0, 0] = 1; H[0, 2] = -1; H[1, 0] = 1; H[1, 3] = -1
+    K = Pp @ H.T @ np.linalg.inv(H @ Pp @ H.T + 1e-6 * np.eye(2))
+    return xp + K @ (np.array([zL, zR]) - H @ xp), Pp - K @ H @ Pp
 
 
 def test_estimator_in_the_env_persists_across_resets():

@@ -15,6 +15,15 @@ for N in 1 2 4 8; do
   fi
   echo "N=$N: $(cut -c1-160 $OUT/n$N.json)"
 done
+# the recurrent workload (BASELINE.json configs[3]) over the same N
+for N in 1 2 4 8; do
+  if [ "$N" = "1" ]; then
+    python bench.py --workload cassietraj_recurrent --gpus 1 --steps 2 --warmup 1 --no_cpu_baseline 2>$OUT/rec_n$N.err | tail -1 > $OUT/rec_n$N.json
+  else
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port $((PORT + 10 + N)) bench.py --workload cassietraj_recurrent --gpus $N --steps 2 --warmup 1 2>$OUT/rec_n$N.err | grep '^{' | tail -1 > $OUT/rec_n$N.json
+  fi
+  echo "recurrent N=$N: $(cut -c1-160 $OUT/rec_n$N.json)"
+done
 python - <<'PY'
 import json
 rows = {n: json.load(open("gpurun_out/scale/n%d.json" % n)) for n in (1, 2, 4, 8)}
