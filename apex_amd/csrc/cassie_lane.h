@@ -1000,7 +1000,8 @@ __device__ __forceinline__ XPair xpair_load(const float* rec, int l) {
     const float* q = rec + XSEL + XSEL_SZ * (l >= 13 && l < 13 + MAXX ? l - 13 : 0);
     return XPair{(int)q[8], (int)q[9], {q[2], q[3], q[4]}, {q[5], q[6], q[7]}, q[1]};
 }
-__device__ __forceinline__ int legleg_pairs_lane(const St& S, float* rec) {
+__device__ __forceinline__ int legleg_pairs_lane(const St& S, float* rec, int& xmask) {
+    xmask = 0;
     const int l = threadIdx.x & 15, li = l < 9 ? l / 3 : 0, rj = l < 9 ? l - 3 * (l / 3) : 0;
     {
         const lfloat* pl = &S.W(WK_PTS + 12 + 6 * li); const lfloat* pr = &S.W(WK_PTS + 30 + 12 + 6 * rj);
@@ -1038,7 +1039,7 @@ __device__ __forceinline__ int legleg_pairs_lane(const St& S, float* rec) {
         const float* q = rec + 8 * p;
         const bool h = q[0] != 0.f;
         if (h && nx == k) { x.gi = p / 3; x.gj = p % 3; x.dist = q[1]; x.n = {q[2], q[3], q[4]}; x.cp = {q[5], q[6], q[7]}; }
-        nx += h ? 1 : 0;
+        nx += h ? 1 : 0; xmask |= h ? (1 << p) : 0;
     });
     if (k >= 0 && k < MAXX) {
         float* q = rec + XSEL + XSEL_SZ * k;
@@ -1058,6 +1059,7 @@ struct LegRows {
     float vel, ju, jw, nn;       // this lane's raw dots J . qvel, J . qacc_smooth, J . qacc_warmstart and |y~|^2 (the leg-leg lanes combine the two legs)
     int nc, nlim;                // uniform over the env's lanes from here on
     int over;                    // SAT_LIMITS / SAT_CONTACTS: more active limits / penetrating capsule ends than the lane map has slots for
+    int lmask, cmask;            // which limited joints of the leg are outside their range / which capsule ends penetrate (row-set signature, I_ROWSET)
     float cG[MAXC][6], cR[MAXC], cb[MAXC][4], cf[MAXC][4], isfoot[MAXC];
     float cfz[MAXC][3];          // world z of the contact frame (n, t1, t2) of each slot: the foot-force readout (cassie_sim_foot_forces)
 };
@@ -1070,7 +1072,7 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out, int nxp, bo
     const float mu = S(F_FRIC);
     constexpr int base = WK_PTS + 30 * LEG;
     // ---- uniform over the env's lanes: first active joint limit of this leg
-    int nlim = 0, clim = -1, over = 0;
+    int nlim = 0, clim = -1, over = 0, lmask = 0, lbit = 0;
     float lsign = 0.f, ldist = 0.f, ldiw = 0.f;
     // wave-uniform early out: in almost every substep no limited joint of any of the wave's four envs is outside its range
     float lmin = 1.f;
@@ -1087,6 +1089,7 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out, int nxp, bo
         if constexpr (ct_jnt_limited[j] && ((ct_jnt_body[j] >= 14) == (LEG == 1)) && ct_jnt_body[j] >= 2) {
             const float q = S(F_QPOS + ct_jnt_qposadr[j]);
             const float dlo = q - ct_jnt_range[2 * j], dhi = ct_jnt_range[2 * j + 1] - q;
+            lmask |= (dlo < 0.f || dhi < 0.f) ? (1 << lbit) : 0; ++lbit;
             if (dlo < 0.f || dhi < 0.f) {
                 if (nlim == 0) {
                     constexpr int d = ct_jnt_dofadr[j];
@@ -1097,7 +1100,7 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out, int nxp, bo
     });
     // ---- uniform: first MAXC penetrating capsule ends in the order foot e0,e1, tarsus e0,e1, shin e0,e1
     const V3 p0 = {ct_floor_pos[0], ct_floor_pos[1], ct_floor_pos[2]};
-    int nc = 0;
+    int nc = 0, cmask = 0;
     static_assert(MAXC == 2, "two contact slots per leg");
     V3 cpt0 = {0.f, 0.f, 0.f}, cpt1 = {0.f, 0.f, 0.f}, cn0 = fn, cn1 = fn; float cdist[MAXC]; int cgeo[MAXC];
     sfor<0, MAXC>([&](auto Sl) { cdist[Sl] = 0.f; cgeo[Sl] = 0; });
@@ -1106,7 +1109,12 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out, int nxp, bo
         const V3 ctr = ldv3<base + 12 + 3 * I>(S);
         V3 sn;
         const float dist = floor_dist_dev<HF>(hf, fn, ctr, ct_geom_radius[2 * G + LEG], sn);
+#ifdef APX_NEG_MAXC1      /* NEGATIVE CONTROL of the parity suite (make VARIANT=maxc1 EXTRA=-DAPX_NEG_MAXC1): only ONE floor contact per leg is instantiated; the teacher-forced test must fail on it */
+        const bool hit = dist < 0.f && nc < 1;
+#else
         const bool hit = dist < 0.f && nc < MAXC;
+#endif
+        cmask |= dist < 0.f ? (1 << I) : 0;
         over |= (dist < 0.f && nc >= MAXC) ? SAT_CONTACTS : 0;
         const V3 cp = ctr - sn * (ct_geom_radius[2 * G + LEG] + 0.5f * dist);
         if (hit && nc == 0) { cpt0 = cp; cn0 = sn; }
@@ -1231,7 +1239,7 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out, int nxp, bo
             out.cf[s][k] = (s < nc && f > 0.f) ? f : 0.f;
         });
     });
-    out.nc = nc; out.nlim = nlim; out.over = over;
+    out.nc = nc; out.nlim = nlim; out.over = over; out.lmask = lmask; out.cmask = cmask;
     sfor<0, MAXC>([&](auto Sl) {
         V3 cn = fn, c1 = ft1, c2 = ft2;
         if constexpr (HF) {
@@ -1255,7 +1263,8 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     const int l = threadIdx.x & 15;
     const float mu = S(F_FRIC);
     LegRows A, B;
-    const int nxp = legleg_pairs_lane(S, rows);
+    int xmask;
+    const int nxp = legleg_pairs_lane(S, rows, xmask);
     const bool anyx = __builtin_amdgcn_ballot_w64(nxp > 0) != 0ull;          // wave-uniform: some env of the wave has a leg-leg contact
     rows_lane<0, HF>(S, A, nxp, anyx, rows, hf);
     PROF2(23);
@@ -1266,6 +1275,14 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     if (l == 0) {
         const int sat = A.over | B.over | ((S.W(WK_MISC + 4) + S.W(WK_MISC + 5) > 0.f) ? SAT_BODY_FLOOR : 0) | (nxp > MAXX ? SAT_LEG_LEG : 0);
         if (sat) S.I(I_SAT) = (S.I(I_SAT) | sat) + 256;
+        {   // row-set signature of this forward pass, folded into the env step's hash (multiplicative hash over two words; the oracle folds the same words): limited joints out of
+            // range (8 bits per leg), penetrating capsule ends (6 per leg), pelvis sphere / hip-pitch capsules on the floor, the 9 left x right capsule pairs
+            const unsigned bf = (S.W(WK_MISC + 4) > 0.f ? 1u : 0u) | (S.W(WK_MISC + 5) > 0.f ? 2u : 0u);
+            const unsigned s1 = (unsigned)A.lmask | (unsigned)B.lmask << 8 | (unsigned)A.cmask << 16 | (unsigned)B.cmask << 22 | bf << 28;
+            unsigned h = (unsigned)S.I(I_ROWSET);
+            h = (h ^ s1) * 0x9E3779B1u; h ^= h >> 15; h = (h ^ (unsigned)xmask) * 0x9E3779B1u; h ^= h >> 15;
+            S.I(I_ROWSET) = (int)h;
+        }
         S.W(WK_MISC + 0) = (float)A.nc; S.W(WK_MISC + 1) = (float)B.nc; S.W(WK_MISC + 2) = (float)A.nlim; S.W(WK_MISC + 3) = (float)B.nlim;
     }
     if (l == 0) sfor<0, 2 * MAXC>([&](auto Sl) {

@@ -538,7 +538,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
     if (lead) {
         for (int u = 0; u < 10; ++u)
             S(F_PDT + u) = action[(size_t)env * APX_ACT_DIM + u] + kOffset[u] - (cfg.dyn_rand ? S(F_MNOISE + u) : 0.f);     // cassie.py:295-298
-        S.I(I_FLAGS) |= 16;
+        S.I(I_FLAGS) |= 16; S.I(I_ROWSET) = 0;
         for (int k = 0; k < 4; ++k) S.W(ACC + k) = 0.f;
     }
     c4::wsync();

@@ -21,7 +21,9 @@ enum SoOff { SO_MPOS = 0, SO_MVEL = 10, SO_TORQUE = 20, SO_JPOS = 30, SO_JVEL = 
 enum IField : int { I_TIME = 0, I_PHASE, I_COUNTER, I_RNG, I_FLAGS /* bit0 menc primed, 1 jenc primed, 2 prev_action, 3 prev_torque */,
                     I_AGE /* env steps since the state estimator of this env was set up (apx_env_cfg.est_lifetime) */,
                     I_SAT /* constraint sets beyond what the kernel instantiates: bits 0-3 = SAT_* flags seen since env creation, bits 8.. = number of such forward passes */,
-                    I_XBODY /* MuJoCo body id the F_XFRC wrench acts on (0 / 1 = cassie-pelvis) */, I_TOTAL };
+                    I_XBODY /* MuJoCo body id the F_XFRC wrench acts on (0 / 1 = cassie-pelvis) */,
+                    I_ROWSET /* hash of the active constraint-row sets (limits, capsule ends, body-floor, leg-leg pairs) of the 50 forward passes of the most recent env step:
+                                the parity tests bin kernel-vs-oracle errors by "same row sets in every substep" (tests/test_gpu_env.py) */, I_TOTAL };
 // what a forward pass needed beyond the kernel's per-leg caps (same bits as oracle/cassie_phys.h SatFlag): > 2 penetrating capsule ends on a
 // leg, > 1 active joint limit on a leg, pelvis sphere / hip-pitch capsule on the floor, a left-right capsule pair in contact
 enum SatFlag : int { SAT_CONTACTS = 1, SAT_LIMITS = 2, SAT_BODY_FLOOR = 4, SAT_LEG_LEG = 8 };
@@ -49,7 +51,7 @@ typedef __attribute__((address_space(3))) int lint;
 #ifndef APX_L4_EPW
 #define APX_L4_EPW 4
 #endif
-constexpr int L4_INT = 584 /* >= F_TOTAL */, L4_WK = 592, L4_ROWS = 1664, L4_ES = 2384, L4_EPW = APX_L4_EPW;      // envs per wave (16 lanes each)
+constexpr int L4_INT = 580 /* >= F_TOTAL */, L4_WK = 592, L4_ROWS = 1664, L4_ES = 2384, L4_EPW = APX_L4_EPW;      // envs per wave (16 lanes each)
 static_assert(F_TOTAL <= L4_INT && L4_INT + I_TOTAL <= L4_WK, "LDS state region");
 // Wave-constant table behind the four env regions (one copy per single-wave workgroup, filled from HBM once per launch by ct_fill):
 // model constants that the stages index by LANE (body records, dof / actuator tables, mass-matrix index map).  Without it every such

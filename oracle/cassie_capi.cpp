@@ -82,6 +82,10 @@ static int field(Env& e, const char* name, double* io, bool set) {
     FIELD("reward_terms", e.last_reward_terms, 8) FIELD("clock_x", e.clock.x, 8) FIELD("phaselen", &e.clock.phaselen, 1)
     FIELD("swing_stance", &e.swing_duration, 2) FIELD("prev_action", e.prev_action, 10) FIELD("prev_torque", e.prev_torque, 10)
     FIELD("tq_fifo", e.tq_fifo, 60) FIELD("menc_hist", e.menc_hist, 90) FIELD("jenc_x", e.jenc_x, 24) FIELD("jenc_y", e.jenc_y, 18) FIELD("foot_pos_prev", e.foot_pos_prev, 6)
+    if (!std::strcmp(name, "clock_rebuild")) {      // (set) the clock tables from the env's swing / stance durations: a state copied field by field carries the durations, not the knot tables
+        if (set) make_clock(e.clock, e.swing_duration, e.stance_duration, 0.1, e.cfg.stance_mode, e.cfg.have_incentive, 2000 / e.cfg.simrate);
+        return 0;
+    }
     if (!std::strcmp(name, "enc_primed")) { if (set) { e.menc_primed = (int)io[0]; e.jenc_primed = (int)io[1]; } else { io[0] = e.menc_primed; io[1] = e.jenc_primed; } return 2; }
     if (!std::strcmp(name, "phase_add")) { if (set) { e.phase_add15 = io[0] > 1.25; e.phase_half = (int)io[1]; } else { io[0] = e.phase_add15 ? 1.5 : 1.0; io[1] = e.phase_half; } return 2; }
     if (!std::strcmp(name, "est_age")) { if (set) { e.est_age = (int)io[0]; e.cfg.est_lifetime = (int)io[1]; } else { io[0] = e.est_age; io[1] = e.cfg.est_lifetime; } return 2; }
@@ -99,7 +103,8 @@ static int field(Env& e, const char* name, double* io, bool set) {
         int* p[10] = {&e.time, &e.phase, &e.counter, &e.st.ncon, &e.st.nefc, (int*)&e.rng.ctr, &e.has_prev_action, &e.has_prev_torque, &e.sat_acc, &e.st.ncon1};
         if (set) { for (int i = 0; i < 8; ++i) *p[i] = (int)io[i]; return 8; }     // the first 8 are settable (tests); sat / ncon1 are read-only
         for (int i = 0; i < 10; ++i) io[i] = *p[i];
-        return 10;
+        io[10] = (double)(e.rowset_hash & 0xffffu); io[11] = (double)(e.rowset_hash >> 16);      // row-set hash of the most recent env step, two 16-bit halves
+        return 12;
     }
     return -1;
 }

@@ -523,8 +523,10 @@ int env_step(Env& e, const double* action, double* obs, double* reward) {
         e.pd_target[u] = action[u] + kOffset[u] - (e.cfg.dynamics_randomization ? e.motor_noise[u] : 0.0);
         e.pd_P[u] = kP[u % 5]; e.pd_D[u] = kD[u % 5];
     }
+    e.rowset_hash = 0;
     for (int i = 0; i < e.cfg.simrate; ++i) {
         sim_step_pd(e);
+        for (int k = 0; k < 2; ++k) { e.rowset_hash = (e.rowset_hash ^ e.st.rowsig[k]) * 0x9E3779B1u; e.rowset_hash ^= e.rowset_hash >> 15; }      // multiplicative hash over the row-set signatures, like the kernel's I_ROWSET
         double fp[6];
         foot_positions(e.st, fp);
         for (int k = 0; k < 3; ++k) { e.l_foot_vel[k] = (fp[k] - e.foot_pos_prev[k]) / 0.0005; e.r_foot_vel[k] = (fp[3 + k] - e.foot_pos_prev[3 + k]) / 0.0005; }

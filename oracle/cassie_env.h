@@ -75,6 +75,7 @@ struct Env {
     double prev_action[10], prev_torque[10]; int has_prev_action, has_prev_torque;
     double last_reward_terms[8];
     long iter_sum, iter_passes; int iter_hist[51];   // solver statistics over every forward pass since env_init: sum / count / histogram of State::solver_iter
+    uint32_t rowset_hash = 0;  // hash of State::rowsig over the forward passes of the most recent env_step (the kernel keeps the same in I_ROWSET)
     int sat_acc;               // OR of State::sat over every forward pass since env_init (SatFlag bits)
 };
 

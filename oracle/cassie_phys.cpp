@@ -315,7 +315,7 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
     // solution of the strictly convex dual for any sweep order, only the iterates differ.
     int n = 0;
     Row* rows = w.rows;
-    s.ncon = 0; s.sat = 0;
+    s.ncon = 0; s.sat = 0; s.rowsig[0] = s.rowsig[1] = 0;
     int con_row[MAXCON];
     // signed distance of a sphere (centre ctr, radius rad) to the floor under it: the plane (cassie.xml:73, tilted by dynamics randomisation)
     // or the height-field triangle (cassie_hfield.xml:74); nrm = that surface's unit normal
@@ -367,12 +367,15 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
             n += 3;
         }
         int nlim = 0;   // joint limits (mj_instantiateLimit), solreflimit default 0.02 1: every active one
+        int lbit = -1;
         for (int j = 0; j < NJ && nlim < MAXLIM_LEG; ++j) {
             if (!cm_jnt_limited[j] || cm_jnt_body[j] < body_lo || cm_jnt_body[j] > body_hi) continue;
+            ++lbit;
             const double q = s.qpos[cm_jnt_qposadr[j]];
             for (int side = 0; side < 2 && nlim < MAXLIM_LEG; ++side) {
                 const double dist = side == 0 ? q - cm_jnt_range[2 * j] : cm_jnt_range[2 * j + 1] - q;
                 if (dist >= 0) continue;
+                s.rowsig[0] |= 1u << (lbit + 8 * leg);
                 if (nlim >= KERNEL_MAXLIM_LEG) { s.sat |= SAT_LIMITS; if (p.kernel_caps) continue; }
                 Row& r = rows[n];
                 std::memset(r.J, 0, sizeof(r.J));
@@ -394,6 +397,7 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
                 V3 nrm;
                 const double dist = floor_dist(ctr, cm_geom_radius[g], nrm);
                 if (dist >= 0) continue;
+                s.rowsig[0] |= g >= 6 ? (2u << 28) : (1u << (16 + 6 * leg + (g / 2) * 2 + e));
                 if (g >= 6) { s.sat |= SAT_BODY_FLOOR; if (p.kernel_caps) continue; }
                 else if (ncl >= KERNEL_MAXCON_LEG) { s.sat |= SAT_CONTACTS; if (p.kernel_caps) continue; }
                 add_floor_contact(g, b, ctr, dist, nrm);
@@ -406,7 +410,7 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
         const V3 ctr = s.xpos[b] + mul(s.xmat[b], v3(cm_geom_pos + 3 * g));
         V3 nrm;
         const double dist = floor_dist(ctr, cm_geom_radius[g], nrm);
-        if (dist < 0) s.sat |= SAT_BODY_FLOOR;
+        if (dist < 0) { s.sat |= SAT_BODY_FLOOR; s.rowsig[0] |= 1u << 28; }
         if (dist < 0 && !p.kernel_caps) add_floor_contact(g, b, ctr, dist, nrm);
     }
     // left-leg vs right-leg capsules (contype 2 / conaffinity 4 against contype 4 / conaffinity 2, cassie.xml:23-35): foot, tarsus, shin
@@ -422,6 +426,7 @@ void forward(const Params& p, State& s, Work& w, const double* ctrl) {
             const V3 dv = c2 - c1;
             const double len = norm(dv), dist = len - cm_geom_radius[gl] - cm_geom_radius[gr];
             if (dist >= 0 || len < MINVAL) continue;
+            s.rowsig[1] |= 1u << (3 * (gl / 2) + gr / 2);
             if (s.ncon1 >= KERNEL_MAXLEGLEG) { s.sat |= SAT_LEG_LEG; if (p.kernel_caps) continue; }
             const V3 nn = dv * (1.0 / len);                                     // from the left geom to the right geom
             const V3 cp = c1 + nn * (cm_geom_radius[gl] + 0.5 * dist);

@@ -131,6 +131,8 @@ struct State {
     int sat;                     // SatFlag bits of the most recent forward pass: the constraint set exceeded what the HIP kernel instantiates
     int solver_iter;             // sweeps the PGS solver ran in the most recent forward pass (mjData.solver_iter)
     int ncon1;                   // leg-leg (frictionless) contacts of the most recent forward pass
+    unsigned rowsig[2];          // row-set signature of the most recent forward pass (what was DETECTED, before any cap): [0] = limited joints out of range (8 bits per leg) |
+                                 // penetrating foot / tarsus / shin capsule ends (6 per leg) << 16 | (pelvis sphere, any hip-pitch capsule) on the floor << 28; [1] = the 9 left x right pairs
     double xfrc[6] = {0, 0, 0, 0, 0, 0};   // one row of mjData.xfrc_applied: world force xyz, torque xyz, applied at the COM of body xfrc_body
     int xfrc_body = 1;                     // the body of that row (1 = cassie-pelvis, the harnesses' default; one pushed body at a time)
 };

@@ -6,7 +6,12 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "liboracle.so")
+# ORC_REAL=float selects the fp32 CONTROL build of the same sources (oracle/Makefile target `f32`: `double` -> `float`, single-precision literals): every array
+# that crosses the C API is then float32.  One variant per process; the parity tests run the control in a subprocess (tests/test_oracle_env.py).
+_F32 = os.environ.get("ORC_REAL") == "float"
+_REAL = np.float32 if _F32 else np.float64
+_CR = C.c_float if _F32 else C.c_double
+_SO = os.path.join(_HERE, "_build", "liboracle_f32.so" if _F32 else "liboracle.so")
 _lib = None
 
 
@@ -18,7 +23,7 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_SO):
-            subprocess.check_call(["make", "-C", _HERE])
+            subprocess.check_call(["make", "-C", _HERE] + (["f32"] if _F32 else []))
         L = C.CDLL(_SO)
         L.orc_env_new.restype = C.c_void_p
         L.orc_env_new.argtypes = [C.c_int] * 7 + [C.c_uint64, C.c_uint32]
@@ -27,7 +32,7 @@ def lib():
         L.orc_env_step.restype = C.c_int
         L.orc_env_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_env_substep.argtypes = [C.c_void_p]
-        L.orc_env_update_speed.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.orc_env_update_speed.argtypes = [C.c_void_p, _CR, _CR]
         L.orc_env_step_basic.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_env_reset_for_test.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_env_apply_force.argtypes = [C.c_void_p, C.c_void_p]
@@ -35,15 +40,15 @@ def lib():
         L.orc_env_set_kind.argtypes = [C.c_void_p, C.c_int]
         L.orc_env_set_command_profile.argtypes = [C.c_void_p, C.c_int]
         L.orc_env_set_input_profile.argtypes = [C.c_void_p, C.c_int]
-        L.orc_traj_ref_state.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
-        L.orc_env_set_command.argtypes = [C.c_void_p, C.c_double, C.c_int]
+        L.orc_traj_ref_state.argtypes = [_CR, _CR, _CR, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_env_set_command.argtypes = [C.c_void_p, _CR, C.c_int]
         L.orc_env_obs.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_phys_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_com_velocity.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_phys_forward.argtypes = [C.c_void_p, C.c_void_p]
-        L.orc_constraint_violation.restype = C.c_double
+        L.orc_constraint_violation.restype = _CR
         L.orc_constraint_violation.argtypes = [C.c_void_p]
-        L.orc_total_energy.restype = C.c_double
+        L.orc_total_energy.restype = _CR
         L.orc_total_energy.argtypes = [C.c_void_p]
         L.orc_env_get.restype = C.c_int
         L.orc_env_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
@@ -53,26 +58,26 @@ def lib():
         L.orc_flops.restype = C.c_uint64
         L.orc_flops.argtypes = [C.c_int]
         L.orc_env_set_kernel_caps.argtypes = [C.c_void_p, C.c_int]
-        L.orc_env_set_hfield.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
-        L.orc_floor_query.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_void_p]
-        L.orc_clock_eval.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+        L.orc_env_set_hfield.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, _CR, _CR, _CR]
+        L.orc_floor_query.argtypes = [C.c_void_p, _CR, _CR, C.c_void_p]
+        L.orc_clock_eval.argtypes = [_CR, _CR, _CR, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p]
-        L.orc_clock_reward_eval.restype = C.c_double
+        L.orc_clock_reward_eval.restype = _CR
         L.orc_clock_reward_eval.argtypes = [C.c_void_p] * 11
-        L.orc_core_safety.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        L.orc_core_safety.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _CR, C.c_void_p]
         L.orc_philox.restype = C.c_uint32
         L.orc_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
         L.orc_est_create.restype = C.c_void_p
         L.orc_est_destroy.argtypes = [C.c_void_p]
         L.orc_est_setup.argtypes = [C.c_void_p]
         L.orc_est_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        L.orc_est_heel_residual.restype = C.c_double
-        L.orc_est_heel_residual.argtypes = [C.c_double] * 4 + [C.c_void_p]
+        L.orc_est_heel_residual.restype = _CR
+        L.orc_est_heel_residual.argtypes = [_CR] * 4 + [C.c_void_p]
         L.orc_est_mldivide23.argtypes = [C.c_void_p] * 3
-        L.orc_est_hfilter_step.argtypes = [C.c_void_p, C.c_void_p] + [C.c_double] * 5
-        L.orc_est_zfilter_step.argtypes = [C.c_void_p, C.c_void_p] + [C.c_double] * 4
-        L.orc_rollout_bench.restype = C.c_double
-        L.orc_rollout_bench.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_double]
+        L.orc_est_hfilter_step.argtypes = [C.c_void_p, C.c_void_p] + [_CR] * 5
+        L.orc_est_zfilter_step.argtypes = [C.c_void_p, C.c_void_p] + [_CR] * 4
+        L.orc_rollout_bench.restype = _CR
+        L.orc_rollout_bench.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, _CR]
         _lib = L
     return _lib
 
@@ -105,13 +110,13 @@ class OracleEnv:
             pass
 
     def reset(self):
-        obs = np.zeros(self.obs_dim)
+        obs = np.zeros(self.obs_dim, dtype=_REAL)
         lib().orc_env_reset(self.h, _ptr(obs))
         return obs
 
     def step(self, action):
-        a = np.ascontiguousarray(action, dtype=np.float64)
-        obs = np.zeros(self.obs_dim); rew = np.zeros(1)
+        a = np.ascontiguousarray(action, dtype=_REAL)
+        obs = np.zeros(self.obs_dim, dtype=_REAL); rew = np.zeros(1, dtype=_REAL)
         done = lib().orc_env_step(self.h, _ptr(a), _ptr(obs), _ptr(rew))
         return obs, float(rew[0]), done
 
@@ -119,7 +124,7 @@ class OracleEnv:
         lib().orc_env_substep(self.h)
 
     def step_basic(self, action):
-        a = np.ascontiguousarray(action, dtype=np.float64); obs = np.zeros(self.obs_dim)
+        a = np.ascontiguousarray(action, dtype=_REAL); obs = np.zeros(self.obs_dim, dtype=_REAL)
         lib().orc_env_step_basic(self.h, _ptr(a), _ptr(obs))
         return obs
 
@@ -130,50 +135,50 @@ class OracleEnv:
         lib().orc_env_set_command(self.h, float(speed0), int(phase))
 
     def reset_for_test(self, full_reset=False):
-        obs = np.zeros(self.obs_dim)
+        obs = np.zeros(self.obs_dim, dtype=_REAL)
         lib().orc_env_reset_for_test(self.h, _ptr(obs), int(bool(full_reset)))
         return obs
 
     def apply_force(self, xfrc, body_name="cassie-pelvis"):
         """CassieSim.apply_force (cassiemujoco.py:99-103): one row of mjData.xfrc_applied; one pushed body at a time."""
-        x = np.ascontiguousarray(xfrc, dtype=np.float64)
+        x = np.ascontiguousarray(xfrc, dtype=_REAL)
         assert x.shape == (6,)
         lib().orc_env_apply_force_body(self.h, _ptr(x), BODY_NAMES.index(body_name))
 
     def obs(self):
-        o = np.zeros(self.obs_dim)
+        o = np.zeros(self.obs_dim, dtype=_REAL)
         lib().orc_env_obs(self.h, _ptr(o))
         return o
 
     def com_velocity(self):
-        v = np.zeros(3)
+        v = np.zeros(3, dtype=_REAL)
         lib().orc_com_velocity(self.h, _ptr(v))
         return v
 
     def phys_step(self, ctrl, n=1):
-        c = np.ascontiguousarray(ctrl, dtype=np.float64)
+        c = np.ascontiguousarray(ctrl, dtype=_REAL)
         lib().orc_phys_step(self.h, _ptr(c), n)
 
     def phys_forward(self, ctrl=None):
-        c = np.zeros(10) if ctrl is None else np.ascontiguousarray(ctrl, dtype=np.float64)
+        c = np.zeros(10, dtype=_REAL) if ctrl is None else np.ascontiguousarray(ctrl, dtype=_REAL)
         lib().orc_phys_forward(self.h, _ptr(c))
 
     def get(self, name):
-        buf = np.zeros(128)
+        buf = np.zeros(128, dtype=_REAL)
         n = lib().orc_env_get(self.h, name.encode(), _ptr(buf))
         if n < 0:
             raise KeyError(name)
         return buf[:n].copy()
 
     def set(self, name, val):
-        v = np.ascontiguousarray(np.asarray(val, dtype=np.float64).reshape(-1))
-        buf = np.zeros(128); buf[:v.size] = v
+        v = np.ascontiguousarray(np.asarray(val, dtype=_REAL).reshape(-1))
+        buf = np.zeros(128, dtype=_REAL); buf[:v.size] = v
         n = lib().orc_env_set(self.h, name.encode(), _ptr(buf))
         if n < 0:
             raise KeyError(name)
 
     def clock_reward_eval(self, qpos, qvel, scal, foot_vel, rotvel, tacc, torque, prev_torque, prev_action, action):
-        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in
+        arrs = [np.ascontiguousarray(a, dtype=_REAL) for a in
                 (qpos, qvel, scal, foot_vel, rotvel, tacc, torque, prev_torque, prev_action, action)]
         return lib().orc_clock_reward_eval(self.h, *[_ptr(a) for a in arrs])
 
@@ -192,7 +197,7 @@ class OracleEnv:
         return self
 
     def floor_query(self, x, y):
-        out = np.zeros(4)
+        out = np.zeros(4, dtype=_REAL)
         lib().orc_floor_query(self.h, float(x), float(y), _ptr(out))
         return out[0], out[1:]
 
@@ -207,15 +212,15 @@ class OracleEnv:
 
 
 def clock_eval(swing, stance, relax, mode, inc, freq, phases):
-    ph = np.ascontiguousarray(phases, dtype=np.float64)
-    out = np.zeros((len(ph), 4)); pl = np.zeros(1)
+    ph = np.ascontiguousarray(phases, dtype=_REAL)
+    out = np.zeros((len(ph), 4), dtype=_REAL); pl = np.zeros(1, dtype=_REAL)
     lib().orc_clock_eval(swing, stance, relax, mode, int(inc), freq, len(ph), _ptr(ph), _ptr(out), _ptr(pl))
     return out, float(pl[0])
 
 
 def core_safety(q, qd, cmd, radio=1.0):
-    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (q, qd, cmd)]
-    out = np.zeros(10)
+    a = [np.ascontiguousarray(x, dtype=_REAL) for x in (q, qd, cmd)]
+    out = np.zeros(10, dtype=_REAL)
     lib().orc_core_safety(_ptr(a[0]), _ptr(a[1]), _ptr(a[2]), float(radio), _ptr(out))
     return out
 
@@ -230,7 +235,7 @@ def rollout_bench(n_envs, n_steps, threads, seed=0, act_std=0.2):
 
 def traj_ref_state(phase, phaselen, speed, counter=0):
     """CassieTrajEnv.get_ref_state of the oracle (walking trajectory, simrate 50) -> (qpos[35], qvel[32])."""
-    q, v = np.zeros(35), np.zeros(32)
+    q, v = np.zeros(35, dtype=_REAL), np.zeros(32, dtype=_REAL)
     lib().orc_traj_ref_state(float(phase), float(phaselen), float(speed), int(counter), _ptr(q), _ptr(v))
     return q, v
 
@@ -271,33 +276,33 @@ class StateEstimator:
         lib().orc_est_setup(self.h)
 
     def step(self, sensors26):
-        x = np.ascontiguousarray(sensors26, dtype=np.float64)
+        x = np.ascontiguousarray(sensors26, dtype=_REAL)
         assert x.size == 26
-        o = np.zeros(33)
+        o = np.zeros(33, dtype=_REAL)
         lib().orc_est_step(self.h, _ptr(x), _ptr(o))
         return dict(pos=o[0:3], vel=o[3:6], tacc=o[6:9], terrain=o[9], foot_rel=o[10:16].reshape(2, 3), foot_force=o[16:22].reshape(2, 3), heel=o[22:24], lm_iters=int(o[24]), foot_quat=o[25:33].reshape(2, 4))
 
 
 def heel_residual(knee, shin, tarsus, heel):
-    g = np.zeros(4)
+    g = np.zeros(4, dtype=_REAL)
     r = lib().orc_est_heel_residual(float(knee), float(shin), float(tarsus), float(heel), _ptr(g))
     return r, g
 
 
 def hfilter_step(x, P, zL, zR, fl, fr, acc):
     """one step of the estimator's horizontal filter, oracle/cassie_estimator.cpp hfilter_step (the C++ the env runs) -> (x', P')"""
-    xx = np.array(x, dtype=np.float64).reshape(6).copy(); PP = np.array(P, dtype=np.float64).reshape(36).copy()
+    xx = np.array(x, dtype=_REAL).reshape(6).copy(); PP = np.array(P, dtype=_REAL).reshape(36).copy()
     lib().orc_est_hfilter_step(_ptr(xx), _ptr(PP), float(zL), float(zR), float(fl), float(fr), float(acc))
     return xx, PP.reshape(6, 6)
 
 
 def zfilter_step(x, P, zL, zR, fl, fr):
-    xx = np.array(x, dtype=np.float64).reshape(5).copy(); PP = np.array(P, dtype=np.float64).reshape(25).copy()
+    xx = np.array(x, dtype=_REAL).reshape(5).copy(); PP = np.array(P, dtype=_REAL).reshape(25).copy()
     lib().orc_est_zfilter_step(_ptr(xx), _ptr(PP), float(zL), float(zR), float(fl), float(fr))
     return xx, PP.reshape(5, 5)
 
 
 def mldivide23(M, tau):
-    Mm = np.ascontiguousarray(M, dtype=np.float64).reshape(6); t = np.ascontiguousarray(tau, dtype=np.float64); x = np.zeros(3)
+    Mm = np.ascontiguousarray(M, dtype=_REAL).reshape(6); t = np.ascontiguousarray(tau, dtype=_REAL); x = np.zeros(3, dtype=_REAL)
     lib().orc_est_mldivide23(_ptr(Mm), _ptr(t), _ptr(x))
     return x

@@ -71,3 +71,39 @@ def oracle_to_kernel(genv, oenvs, model_params=True):
         ints[i, 4] = int(pr[0]) | int(pr[1]) << 1 | int(oi[6]) << 2 | int(oi[7]) << 3 | 16
         ints[i, 5] = int(e.get("est_age")[0])
     genv.set_field("ints", T(ints))
+
+
+# every field of the oracle's Env that persists from one env step to the next (oracle/cassie_capi.cpp `field`), in an order that can be replayed with set()
+ORACLE_STATE_FIELDS = ("mass", "damping", "friction", "floor_quat", "motor_noise", "joint_noise", "qpos", "qvel", "qacc_warm", "pd_target", "pd_P", "pd_D", "tq_fifo",
+                       "menc_hist", "jenc_x", "jenc_y", "enc_primed", "snap_mpos", "snap_jpos", "snap_quat", "snap_gyro", "snap_acc", "so_mpos", "so_mvel", "so_torque", "so_jpos",
+                       "so_jvel", "so_quat", "so_rotvel", "so_tvel", "so_tacc", "so_height", "est_heel", "est_hx", "est_hP", "est_zx", "est_zP", "est_terrain", "est_flags",
+                       "l_foot_vel", "r_foot_vel", "foot_pos_prev", "prev_action", "prev_torque", "speed", "side_speed", "orient_add", "swing_stance", "phase_add", "est_age")
+
+
+def oracle_state(e):
+    """the persistent state of one oracle env as {field: float64 array} (+ the integer words)"""
+    d = {k: np.asarray(e.get(k), dtype=np.float64).copy() for k in ORACLE_STATE_FIELDS}
+    d["ints"] = np.asarray(e.get("ints"), dtype=np.float64)[:8].copy()
+    return d
+
+
+def oracle_load_state(e, d, set_const=True):
+    """teacher forcing oracle -> oracle (the fp32 control build takes the fp64 oracle's state): model parameters, set_const in the target's own arithmetic
+    (like the kernel, which recomputes its invweights in fp32), then every persistent field, the integer words and the clock tables"""
+    for k in ORACLE_STATE_FIELDS:
+        e.set(k, d[k])
+    if set_const:
+        e.set_const()
+    e.set("ints", d["ints"])
+    e.set("clock_rebuild", [0.0])
+
+
+# ---- fixed tolerances of ONE env step from an identical state, on the (env, step) pairs whose active constraint-row sets were the same in all 50 substeps of
+# both sides (row-set hash: I_ROWSET in the kernel, Env::rowset_hash in the oracle).  Set from the fp32 CONTROL (the oracle's own sources compiled in fp32
+# against the fp64 oracle, identical states: tests/test_oracle_env.py::test_fp32_control_of_the_parity_tolerances), whose maxima on 960 walking (env, step)
+# pairs are: acceleration 7.2e-2 m/s^2, motor velocity 5.3e-2 rad/s (the 9-tap FIR on truncated encoder counts: one count is 0.03 rad/s on the foot drive),
+# reward 1.6e-3.  max tolerance = 2 x the control's maximum for those stiff groups; the kernel measured 8.6e-2 / 5.4e-2 / 1.9e-3 (round 4).
+TF_NAMES = ["height+quat", "motor pos", "tvel", "gyro", "motor vel", "tacc", "joint pos", "joint vel", "clock+cmd", "reward", "qpos", "qvel"]
+TF_TOL_SAME = np.array([1e-4, 2e-4, 1e-3, 2e-3, 1e-1, 1.5e-1, 2e-3, 6e-2, 1e-5, 3e-3, 5e-5, 1e-2])
+TF_TOL_SAME_P99 = np.array([5e-6, 1e-4, 2e-4, 1e-3, 5e-2, 8e-2, 1e-4, 2e-2, 1e-5, 1.2e-3, 2e-5, 6e-3])
+TF_MAX_DIFFERING_FRACTION = 0.025      # kernel: 1.56 % of 3200 pairs, fp32 control: 0.94 % of 960

@@ -69,29 +69,42 @@ def test_substeps_track_oracle(dev):
 
 
 def test_env_steps_vs_oracle(dev):
-    """Full env steps (50 substeps each, contacts, reward, termination, command resampling, auto-reset)."""
+    """Free-running env steps (50 substeps each, contacts, reward, termination, command resampling) from the same reset with the same random actions: the integer
+    bookkeeping (time, phase, cycle counter, RNG counter) and the done flags stay bit-exact, the SLOW observation groups (height, orientation, motor / joint
+    positions, clock, commands) stay together with a drift bound per step.  The stiff groups (velocities, accelerations, reward) are NOT compared here: two free
+    trajectories separate, and a tolerance that grows with t proves little - they are held to FIXED tolerances from identical states in
+    test_teacher_forced_env_steps_random_actions / ..._on_walking_states."""
     genv, oenv = _mk(True, 3)
     genv.reset(); [e.reset() for e in oenv]
     rng = np.random.RandomState(0)
-    n_chk = N          # every env of the batch
-    # per-group tolerance growth per env step (fp32 lanes vs fp64 host through 50 contact-rich substeps each): slow variables (height,
-    # orientation, motor / joint positions), filtered velocities, accelerations (the stiffest signal: a contact switching one substep
-    # earlier moves it by m/s^2); motor velocities come from a 9-tap FIR on TRUNCATED encoder counts (one count = 0.03 rad/s on the foot drive)
-    grp = [(slice(0, 15), 3e-3), (slice(15, 21), 3e-2), (slice(21, 31), 0.15), (slice(31, 34), 1.5), (slice(34, 40), 3e-3), (slice(40, 46), 8e-2), (slice(46, 50), 1e-5)]
+    grp = [(slice(0, 15), 3e-3), (slice(34, 40), 3e-3), (slice(46, 50), 1e-5)]
     for t in range(12):
         act = (rng.randn(N, 10) * 0.15).astype(np.float32)
         obs, rew, done, fin = genv.step(torch.tensor(act, device=dev), auto_reset=False)
         obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
-        for i in range(n_chk):
+        for i in range(N):
             o, r, d = oenv[i].step(act[i].astype(np.float64))
             assert d == done[i], (t, i)
-            # height / orientation / motor positions: slow variables
             for sl, tol in grp:
                 np.testing.assert_allclose(obs[i, sl], o[sl], atol=tol * (t + 1), err_msg=f"t={t} env={i} obs{sl}")
-            assert abs(rew[i] - r) < 0.02 * (t + 1), (t, i, rew[i], r)
         ints = genv.get_field("ints").cpu().numpy()
-        oints = np.stack([e.get("ints") for e in oenv[:n_chk]])
-        np.testing.assert_array_equal(ints[:n_chk, [0, 1, 2, 3]], oints[:, [0, 1, 2, 5]])
+        oints = np.stack([e.get("ints") for e in oenv])
+        np.testing.assert_array_equal(ints[:, [0, 1, 2, 3]], oints[:, [0, 1, 2, 5]])
+
+
+def test_teacher_forced_env_steps_random_actions(dev):
+    """The teacher-forced comparison (kernel state overwritten with the oracle's before every env step) on RANDOM-action rollouts from reset: robots that stumble and
+    fall - joint limits, shin / tarsus contacts, safety zones - instead of the trained gait.  Same binning by identical constraint-row sets and the same FIXED
+    tolerances as test_teacher_forced_env_steps_on_walking_states."""
+    E, same = _teacher_forced_rows(dev, n_steps=30, active=48, actions="random")
+    Es, Ed = E[same], E[~same]
+    for k, nm in enumerate(TF_NAMES):
+        print("teacher-forced/random %-12s same sets (n=%d): median %.2e p99 %.2e max %.2e | differing sets (n=%d): max %.2e" % (
+            nm, len(Es), np.median(Es[:, k]), np.percentile(Es[:, k], 99), Es[:, k].max(), len(Ed), Ed[:, k].max() if len(Ed) else 0))
+    frac = 1.0 - same.mean()
+    print("teacher-forced/random: differing row sets in %.4f of the (env, step) pairs" % frac)
+    assert frac < 0.08, frac      # falling robots switch contacts more often than a gait does (measured 4.8 % of 1440 pairs)
+    assert np.all(Es.max(0) <= TF_TOL_SAME), (Es.max(0), TF_TOL_SAME)
 
 
 def test_safety_zones_vs_oracle(dev):
@@ -801,10 +814,20 @@ def test_estimator_twin_from_identical_state(dev):
     assert worst[0] < 6e-4 and worst[1] < 2e-3 and worst[2] < 2e-2 and worst[3] < 2e-2 and worst[4] < 2e-3 and worst[5] < 1e-4 and worst[6] < 2e-2 and worst[7] < 2e-2, worst
 
 
-def test_teacher_forced_env_steps_on_walking_states(dev):
-    """One env step of the kernel against one env step of the oracle FROM THE SAME STATE, on the states a trained policy visits (walking, contact
-    switches every step), 100 steps x 32 envs: the kernel's state is overwritten with the oracle's before every step (tests/state_xfer.py), so every
-    tolerance is fixed: pose entries 1e-4-level, velocities 5e-3-level, accelerations, reward 1e-3.  Integer bookkeeping bit-exact."""
+def _kernel_hash(genv):
+    """I_ROWSET of every env: hash of the active constraint-row sets over the 50 forward passes of the most recent env step (bit-exact integer view)"""
+    return genv.get_field("ints_bits").view(torch.int32)[:, 8].cpu().numpy().astype(np.int64) & 0xffffffff
+
+
+def _oracle_hash(e):
+    ii = e.get("ints")
+    return int(ii[10]) | int(ii[11]) << 16
+
+
+from tests.state_xfer import TF_NAMES, TF_TOL_SAME, TF_TOL_SAME_P99, TF_MAX_DIFFERING_FRACTION      # fixed tolerances, shared with the fp32 control test (CPU suite)
+
+
+def _teacher_forced_rows(dev, n_steps=100, active=32, actions="policy"):
     from tests.state_xfer import oracle_to_kernel
     import os
     n = 64
@@ -812,42 +835,71 @@ def test_teacher_forced_env_steps_on_walking_states(dev):
     genv.reset(); [e.reset() for e in oenv]
     policy = torch.load(os.path.join(os.path.dirname(__file__), "..", "trained_models", "r03_cassie_v0_clock", "actor.pt"), weights_only=False).eval()
     obs_o = np.stack([e.obs() for e in oenv])
-    #          height+quat  motor pos   tvel        gyro        motor vel   tacc        joint pos   joint vel   clock+cmd
-    grp = [(slice(0, 5), 2e-4), (slice(5, 15), 2e-4), (slice(15, 18), 5e-3), (slice(18, 21), 2e-2), (slice(21, 31), 0.25), (slice(31, 34), 0.5), (slice(34, 40), 2e-4), (slice(40, 46), 0.1), (slice(46, 50), 1e-5)]
-    rows = []
-    active = 32
-    for t in range(100):
-        with torch.no_grad():
-            act = policy(torch.tensor(obs_o, dtype=torch.float32), deterministic=True).numpy().astype(np.float32)
+    grp = [slice(0, 5), slice(5, 15), slice(15, 18), slice(18, 21), slice(21, 31), slice(31, 34), slice(34, 40), slice(40, 46), slice(46, 50)]
+    rows, same = [], []
+    rng = np.random.RandomState(5)
+    for t in range(n_steps):
+        if actions == "policy":
+            with torch.no_grad():
+                act = policy(torch.tensor(obs_o, dtype=torch.float32), deterministic=True).numpy().astype(np.float32)
+        else:
+            act = (rng.randn(n, 10) * 0.15).astype(np.float32)
         oracle_to_kernel(genv, oenv)
         obs, rew, done, _ = genv.step(torch.tensor(act, device=dev), auto_reset=False)
         obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
         qp, qv = genv.get_field("qpos").cpu().numpy(), genv.get_field("qvel").cpu().numpy()
         ints = genv.get_field("ints").cpu().numpy()
+        kh = _kernel_hash(genv)
         for i, e in enumerate(oenv[:active]):
             o, r, d = e.step(act[i].astype(np.float64)); obs_o[i] = o
             assert d == done[i], (t, i, d, done[i])
             np.testing.assert_array_equal(ints[i, [0, 1, 2, 3]], e.get("ints")[[0, 1, 2, 5]])
-            errs = [np.abs(obs[i, sl] - o[sl]).max() for sl, _ in grp] + [abs(rew[i] - r), np.abs(qp[i] - e.get("qpos")).max(), np.abs(qv[i] - e.get("qvel")).max()]
-            rows.append(errs)
+            rows.append([np.abs(obs[i, sl] - o[sl]).max() for sl in grp] + [abs(rew[i] - r), np.abs(qp[i] - e.get("qpos")).max(), np.abs(qv[i] - e.get("qvel")).max()])
+            same.append(int(kh[i]) == _oracle_hash(e))
             if d:
                 e.reset(); obs_o[i] = e.obs()
         for i in range(active, n):                         # keep the rest of the batch defined (they mirror env 0's action stream)
             o, r, d = oenv[i].step(act[i].astype(np.float64)); obs_o[i] = o
             if d:
                 oenv[i].reset(); obs_o[i] = oenv[i].obs()
-    E = np.array(rows)
-    p50, p99, mx = np.percentile(E, 50, axis=0), np.percentile(E, 99, axis=0), E.max(0)
-    names = ["height+quat", "motor pos", "tvel", "gyro", "motor vel", "tacc", "joint pos", "joint vel", "clock+cmd", "reward", "qpos", "qvel"]
-    for k, nm in enumerate(names):
-        print("teacher-forced %-12s median %.2e  p99 %.2e  max %.2e" % (nm, p50[k], p99[k], mx[k]))
-    # fixed tolerances on one env step from an identical state (fp32 lanes vs fp64 host through 50 contact-rich substeps): 99 % of the (env, step) pairs, and a
-    # ceiling for the rest (a contact that switches one substep apart moves the stiff signals of that step: accelerations, motor velocities through the
-    # FIR on truncated encoder counts)
-    tol99 = np.array([2e-4, 1e-3, 5e-3, 2e-2, 0.25, 0.8, 2e-3, 0.2, 1e-5, 5e-3, 2e-3, 0.3])
-    tolmx = np.array([1e-3, 5e-3, 2e-2, 0.1, 1.0, 5.0, 1e-2, 1.0, 1e-5, 5e-2, 1e-2, 2.0])
-    assert np.all(p99 <= tol99), (p99, tol99)
-    assert np.all(mx <= tolmx), (mx, tolmx)
+    return np.array(rows), np.array(same)
+
+
+def test_teacher_forced_env_steps_on_walking_states(dev):
+    """One env step of the kernel against one env step of the oracle FROM THE SAME STATE, on the states a trained policy visits (walking, contact switches
+    every step), 100 steps x 32 envs: the kernel's whole state is overwritten with the oracle's before every step (tests/state_xfer.py).  Every (env, step)
+    pair is binned by whether kernel and oracle had the SAME active constraint-row sets (limits, capsule ends, body-floor, leg-leg pairs) in all 50 substeps
+    (I_ROWSET against the oracle's hash of the same signature words).  On the identical-set population every tolerance is FIXED and is the fp32 level that the
+    fp32 control build of the oracle itself shows against the fp64 oracle; the differing-set population (a contact that switches a substep earlier or later) is
+    bounded in SIZE.  Integer bookkeeping bit-exact.  Negative control: test_teacher_forced_test_fails_on_a_one_contact_kernel."""
+    E, same = _teacher_forced_rows(dev)
+    Es, Ed = E[same], E[~same]
+    for k, nm in enumerate(TF_NAMES):
+        print("teacher-forced %-12s same sets (n=%d): median %.2e p99 %.2e max %.2e | differing sets (n=%d): median %.2e max %.2e" % (
+            nm, len(Es), np.median(Es[:, k]), np.percentile(Es[:, k], 99), Es[:, k].max(), len(Ed), np.median(Ed[:, k]) if len(Ed) else 0, Ed[:, k].max() if len(Ed) else 0))
+    frac = 1.0 - same.mean()
+    print("teacher-forced: differing row sets in %.4f of the (env, step) pairs" % frac)
+    assert frac < TF_MAX_DIFFERING_FRACTION, frac
+    assert np.all(Es.max(0) <= TF_TOL_SAME), (Es.max(0), TF_TOL_SAME)
+    assert np.all(np.percentile(Es, 99, axis=0) <= TF_TOL_SAME_P99), (np.percentile(Es, 99, axis=0), TF_TOL_SAME_P99)
+    # the differing-set pairs: one contact / limit row more or less for a substep or two moves the stiff signals of that step (accelerations, FIR motor velocities);
+    # a ceiling only, far above the identical-set level and far below a wrong model (the one-contact kernel breaks it)
+    if len(Ed):
+        assert np.all(Ed.max(0) <= np.array([1e-3, 5e-3, 2e-2, 0.1, 1.0, 5.0, 1e-2, 1.0, 1e-5, 5e-2, 1e-2, 2.0])), Ed.max(0)
+
+
+def test_teacher_forced_test_fails_on_a_one_contact_kernel(dev):
+    """NEGATIVE CONTROL: the same test against a kernel that instantiates only ONE floor contact per leg (libapx_maxc1.so: make VARIANT=maxc1
+    EXTRA=-DAPX_NEG_MAXC1, built by __graft_entry__.build()) must FAIL - the tolerances above can tell a wrong constraint set from round-off."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "apex_amd", "lib", "libapx_maxc1.so")
+    if not os.path.exists(lib):
+        pytest.skip("build it with: make -C apex_amd/csrc VARIANT=maxc1 EXTRA=-DAPX_NEG_MAXC1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_env.py"), "-x", "-q", "-m", "gpu", "-k", "test_teacher_forced_env_steps_on_walking_states"],
+                       env=dict(os.environ, APX_LIB=lib), capture_output=True, text=True, timeout=1200, cwd=root)
+    assert r.returncode != 0 and "1 failed" in r.stdout, r.stdout[-1500:]
+    assert "AssertionError" in r.stdout or "assert" in r.stdout
 
 
 def test_range_checked_build_sees_no_out_of_range_index(dev):

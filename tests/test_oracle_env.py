@@ -596,3 +596,52 @@ def test_solver_tolerance_knob():
         out.append((np.asarray(obs), (s[1] - n0[0]) / (s[2] - n0[1])))
     assert out[0][1] == 50.0 and 5.0 < out[1][1] < 50.0, (out[0][1], out[1][1])
     assert np.abs(out[0][0] - out[1][0]).max() < 1e-3
+
+
+def test_fp32_control_of_the_parity_tolerances(tmp_path):
+    """The CONTROL of the GPU parity tolerances: the oracle's own sources compiled in fp32 (`make -C oracle f32`: double -> float, single-precision
+    literals) against the fp64 oracle, one env step from IDENTICAL states on the walking states of the trained policy, binned by "same active constraint-row sets in
+    all 50 substeps" exactly like tests/test_gpu_env.py::test_teacher_forced_env_steps_on_walking_states.  It shows (1) that the fixed tolerances the kernel is held
+    to are what a plain fp32 implementation of the same algorithm needs (the control passes them, and its maxima are within 10 x of them on the stiff groups, so the
+    tolerances are not slack), and (2) that a small fraction of (env, step) pairs sees a contact switch a substep apart in ANY fp32 implementation."""
+    import subprocess, sys, torch
+    from concurrent.futures import ThreadPoolExecutor
+    from tests.state_xfer import ORACLE_STATE_FIELDS, oracle_state, TF_TOL_SAME, TF_TOL_SAME_P99, TF_MAX_DIFFERING_FRACTION
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n_env, n_step, seed = 12, 40, 22
+    policy = torch.load(os.path.join(root, "trained_models", "r03_cassie_v0_clock", "actor.pt"), weights_only=False).eval()
+    envs = [S.OracleEnv(dyn_rand=True, seed=seed, env_id=i) for i in range(n_env)]
+    obs = np.stack([e.reset() for e in envs])
+    rec = {k: np.zeros((n_env, n_step) + envs[0].get(k).shape) for k in ORACLE_STATE_FIELDS}; rec["ints"] = np.zeros((n_env, n_step, 8))
+    A = np.zeros((n_env, n_step, 10)); O = np.zeros((n_env, n_step, 50)); R = np.zeros((n_env, n_step)); D = np.zeros((n_env, n_step), dtype=np.int64); H = np.zeros((n_env, n_step), dtype=np.int64)
+    with ThreadPoolExecutor(os.cpu_count() or 1) as ex:
+        for t in range(n_step):
+            with torch.no_grad():
+                act = policy(torch.tensor(obs, dtype=torch.float32), deterministic=True).numpy().astype(np.float64)
+
+            def one(i):
+                e = envs[i]; st = oracle_state(e)
+                for k in ORACLE_STATE_FIELDS:
+                    rec[k][i, t] = st[k]
+                rec["ints"][i, t] = st["ints"]
+                o, r, d = e.step(act[i]); ii = e.get("ints")
+                A[i, t] = act[i]; O[i, t] = o; R[i, t] = r; D[i, t] = d; H[i, t] = int(ii[10]) | int(ii[11]) << 16
+                obs[i] = e.reset() if d else o
+            list(ex.map(one, range(n_env)))
+    src, dst = str(tmp_path / "rec.npz"), str(tmp_path / "out.npz")
+    np.savez(src, seed=seed, action=A, obs=O, rew=R, done=D, hash=H, **{"st_" + k: v for k, v in rec.items()})
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fp32_control_worker.py"), src, dst], env=dict(os.environ, ORC_REAL="float"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    b = np.load(dst)
+    np.testing.assert_array_equal(b["done"], D)
+    same = b["hash"] == H
+    grp = [slice(0, 5), slice(5, 15), slice(15, 18), slice(18, 21), slice(21, 31), slice(31, 34), slice(34, 40), slice(40, 46), slice(46, 50)]
+    E = np.stack([np.abs(O[..., sl] - b["obs"][..., sl]).max(-1) for sl in grp] + [np.abs(R - b["rew"])], -1)      # [env, step, 10]
+    Es = E[same]
+    frac = 1.0 - same.mean()
+    print("fp32 control: differing row sets in %.4f of %d pairs; identical-set maxima %s" % (frac, same.size, np.array2string(Es.max(0), precision=2)))
+    assert frac < TF_MAX_DIFFERING_FRACTION
+    assert np.all(Es.max(0) <= TF_TOL_SAME[:10]), (Es.max(0), TF_TOL_SAME[:10])
+    assert np.all(np.percentile(Es, 99, axis=0) <= TF_TOL_SAME_P99[:10])
+    for k in (4, 5, 9):      # motor velocity, acceleration, reward: the tolerance is within 10 x of what fp32 itself does
+        assert Es[:, k].max() > TF_TOL_SAME[k] / 10, (k, Es[:, k].max())
