@@ -332,21 +332,23 @@ __device__ void traj_pose(const St& S, float phase, float phaselen, float speed,
 
 // CassieEnv.reset (cassie/cassie.py:523-680)
 // reset, part 1 (wave 0): command / clock / dynamics-randomisation draws (cassie.py:525-657) and the init pose
-__device__ void env_reset_draws(const St& S, const Cfg& cfg) {
-    Rng r{cfg.seed_lo, cfg.seed_hi, cfg.env_base + (unsigned)S.env, (unsigned)S.I(I_RNG)};
+__device__ void env_reset_draws(const St& S, const Cfg& cfg, int episode) {
+    Rng r{cfg.seed_lo, cfg.seed_hi, cfg.env_base + (unsigned)S.env, (unsigned)episode * RNG_RESET_BLOCK, RNG_RESET};
     const float speed0 = cfg.env_kind == 1 ? (float)r.randint(41u) / 10.f : r.uniform(-0.3f, 4.0f);      // cassie_traj.py:608: random.randint(0, 40) / 10
     (void)r.uniform(-0.3f, 0.3f);
     S(F_CMD) = speed0;                                   // kept for the trajectory-pose reset; replaced by the command redraw after the settle step
     if (cfg.command_profile == 0) { clock_from_speed(S, speed0, 2000 / cfg.simrate); S(F_CMD + 6) = (float)cfg.stance_mode; }
     else {      // command_profile "phase" (cassie.py:529-545): swing / stance duration and stance mode drawn per episode
-        float swing, stance;
+        // durations and cycle length in fp64 from the INTEGER draws, like the reference's Python floats: (2 x 0.07 + 2 x 0.13) x 40 is exactly 16 there and 15.999999 in
+        // fp32, and `phase > phaselen` (cassie.py:451) would wrap one step early
+        double swing, stance;
         if (cfg.command_profile == 2) {                  // "library" reward variant (:531-539)
             S(F_CMD) = (float)r.randint(31u) / 10.f;
-            const float total = (float)(3u + r.randint(4u)) / 10.f, ratio = (float)(2u + r.randint(7u)) / 10.f;
+            const double total = (double)(3u + r.randint(4u)) / 10.0, ratio = (double)(2u + r.randint(7u)) / 10.0;
             swing = total * ratio; stance = total - swing;
-        } else { swing = (float)(1u + r.randint(50u)) / 100.f; stance = (float)(1u + r.randint(30u)) / 100.f; }
+        } else { swing = (double)(1u + r.randint(50u)) / 100.0; stance = (double)(1u + r.randint(30u)) / 100.0; }
         const unsigned pick = r.randint(3u);             // np.random.choice(["grounded", "aerial", "zero"])
-        S(F_CMD + 3) = swing; S(F_CMD + 4) = stance; S(F_CMD + 5) = (2.f * swing + 2.f * stance) * (float)(2000 / cfg.simrate);
+        S(F_CMD + 3) = (float)swing; S(F_CMD + 4) = (float)stance; S(F_CMD + 5) = (float)((2.0 * swing + 2.0 * stance) * (double)(2000 / cfg.simrate));
         S(F_CMD + 6) = pick == 0u ? 1.f : pick == 1u ? 2.f : 0.f;
     }
     S.I(I_PHASE) = (int)r.randint((unsigned)floorf(S(F_CMD + 5)) + 1u); S.I(I_FLAGS) &= ~32;
@@ -381,20 +383,19 @@ __device__ void env_reset_draws(const St& S, const Cfg& cfg) {
     }
     for (int i = 0; i < NQ; ++i) S(F_QPOS + i) = cm_init_qpos[i];
     for (int i = 0; i < NV; ++i) { S(F_QVEL + i) = 0.f; S(F_QACCW + i) = 0.f; }
-    S.I(I_RNG) = (int)r.ctr;
 }
 // reset, part 3 (wave 0): command redraw after the settle step (cassie.py:667-670)
 __device__ void env_reset_finish(const St& S, const Cfg& cfg) {
-    Rng r{cfg.seed_lo, cfg.seed_hi, cfg.env_base + (unsigned)S.env, (unsigned)S.I(I_RNG)};
+    Rng r{cfg.seed_lo, cfg.seed_hi, cfg.env_base + (unsigned)S.env, (unsigned)S.I(I_EPISODE) * RNG_RESET_BLOCK + RNG_RESET_TAIL, RNG_RESET};      // the redraws close the episode's block
     for (int k = 0; k < 6; ++k) S(F_FOOTPREV + k) = S(F_FWD + 10 + k);
     S(F_CMD + 2) = 0.f;
     S(F_CMD + 0) = r.uniform(-0.3f, 4.0f);
     S(F_CMD + 1) = r.uniform(-0.3f, 0.3f);
-    S.I(I_RNG) = (int)r.ctr;
 }
+__device__ int g_reset_miss = 0;
 // CassieEnv.reset (cassie/cassie.py:523-680); called by all 16 lanes of the env's row
 template <bool HF>
-__device__ __forceinline__ void env_reset(const St& S, const Cfg& cfg) {
+__device__ __forceinline__ void env_reset(const St& S, const Cfg& cfg, int n) {
     const bool lead = (threadIdx.x & 15) == 0;
     if (cfg.est_lifetime > 0 && S.I(I_AGE) >= cfg.est_lifetime) {      // this env instance has served a PPO.sample call's worth of steps: the next one starts with a new estimator
         const int l = threadIdx.x & 15;
@@ -402,11 +403,22 @@ __device__ __forceinline__ void env_reset(const St& S, const Cfg& cfg) {
         c4::wsync();
         if (lead) S.I(I_AGE) = 0;
     }
-    if (lead) env_reset_draws(S, cfg);
+    // Everything of the reset up to its settle step is a function of (seed, env, episode index) alone and is computed by env_reset_prepare_kernel into the env's ring -
+    // ahead of time (apx_env_prepare_resets, while the learner runs) or, for an env whose slot does not hold this episode, by the masked launch that precedes this kernel.
+    // ONE implementation of that part, so a prepared and an unprepared reset are bit-identical.  Here: copy the image, then the settle step.
+    const int ep = S.I(I_EPISODE) + 1, slot = ep % RST_K;
+    {
+        const int l = threadIdx.x & 15;
+        if (lead && cfg.rst_int[(size_t)(2 * slot) * n + S.env] != ep) atomicAdd(&g_reset_miss, 1);      // (cannot happen: the masked prepare launch runs first; reported by apx_env_get_field("reset_miss"))
+        const float* img = cfg.rst + (size_t)slot * F_TOTAL * n + S.env;
+        for (int f = l; f < F_PDT; f += 16) S(f) = img[(size_t)f * n];                       // qpos, qvel, qacc_warmstart, mass, damping, friction, floor, invweights, encoder offsets
+        for (int f = F_SNAP + l; f < F_SNAP + 26; f += 16) S(f) = img[(size_t)f * n];        // sensor snapshot of the forward pass at the init pose
+        if (l < 7) S(F_CMD + l) = img[(size_t)(F_CMD + l) * n];
+        S(F_FWD + l) = img[(size_t)(F_FWD + l) * n];
+        if (lead) { S.I(I_PHASE) = cfg.rst_int[(size_t)(2 * slot + 1) * n + S.env]; S.I(I_FLAGS) &= ~32; S.I(I_TIME) = 0; S.I(I_COUNTER) = 0; }
+    }
+    if (lead) S.I(I_EPISODE) = ep;
     c4::wsync();
-    if (cfg.dyn_rand) setconst_lane(S);               // sim.set_const -> mj_setConst
-
-    sim_step_pd<HF>(S, cfg, 0);               // cassie_sim_set_const ends in mj_forward
     if (cfg.env_kind == 1) {                          // CassieTrajEnv.reset: set_qpos / set_qvel with the reference state of the start phase
         if (lead) traj_pose(S, (float)S.I(I_PHASE), S(F_CMD + 5), S(F_CMD), 0);      // (cassie_traj.py:752-758); no mj_forward follows, so the
         c4::wsync();                                  // settle step below still reads the init-pose sensor snapshot, like the reference
@@ -522,9 +534,30 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_kernel(float* 
     ENV_SETUP
     if (mask && !mask[env]) return;
     load_state(S, st, ist, n);
-    env_reset<HF>(S, cfg);
+    env_reset<HF>(S, cfg, n);
     if (obs && lead) write_obs(S, cfg, obs + (size_t)env * cfg.obs_dim);
     store_state(S, st, ist, n);
+}
+
+// apx_env_prepare_resets / the first half of every reset: the part of episode (I_EPISODE + ahead)'s reset that does not depend on how the current episode ends - draws from the episode-keyed stream,
+// mj_setConst on the randomised model, the forward pass at the init pose - computed ahead of time (while the learner runs) into the env's ring slot.  The working image
+// starts from the env's current state; only the fields the reset defines are read back by env_reset.  Nothing of the env itself is modified.
+template <bool HF>
+__global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_prepare_kernel(const float* st, const int* ist, float* wk, int n, Cfg cfg, float* rst, int* rst_int, int ahead, const uint8_t* mask) {
+    ENV_SETUP
+    const int ep = ist[(size_t)I_EPISODE * n + env] + ahead, slot = ep % RST_K;
+    const bool need = (!mask || mask[env]) && rst_int[(size_t)(2 * slot) * n + env] != ep;      // mask = the done flags: only the envs that restart now and whose slot is not prepared
+    if (__builtin_amdgcn_ballot_w64(need) == 0ull) return;      // wave-uniform: the slots of all four envs are filled
+    load_state(S, st, ist, n);
+    if (lead) env_reset_draws(S, cfg, ep);
+    c4::wsync();
+    if (cfg.dyn_rand) setconst_lane(S);
+    sim_step_pd<HF>(S, cfg, 0);
+    c4::wsync();
+    if (!need) return;
+    float* img = rst + (size_t)slot * F_TOTAL * n + env;
+    for (int f = l; f < F_TOTAL; f += 16) img[(size_t)f * n] = S(f);
+    if (lead) { rst_int[(size_t)(2 * slot + 1) * n + env] = S.I(I_PHASE); rst_int[(size_t)(2 * slot) * n + env] = ep; }
 }
 
 template <bool HF>
@@ -580,7 +613,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
         }
         for (int u = 0; u < 10; ++u) { S(F_PREVACT + u) = act[u]; S(F_PREVTQ + u) = S(F_SO + SO_TORQUE + u); }
         {   // command resampling, cassie.py:483-491; fixed 6 draws per step
-            Rng r{cfg.seed_lo, cfg.seed_hi, cfg.env_base + (unsigned)env, (unsigned)S.I(I_RNG)};
+            Rng r{cfg.seed_lo, cfg.seed_hi, cfg.env_base + (unsigned)env, (unsigned)S.I(I_RNG), RNG_STEP};
             if (cfg.env_kind == 1 && cfg.dyn_rand) (void)r.u01();                 // cassie_traj.py:463-464 draws a simrate the loop never uses
             { const unsigned k = r.randint(300); const float u = r.uniform(-0.2f, 0.2f); if (k == 0) S(F_CMD + 2) += u; }
             { const unsigned k = r.randint(100); const float u = r.uniform(-0.3f, 4.0f); if (k == 0) S(F_CMD + 0) = fminf(fmaxf(u, -0.3f), 4.0f); }
@@ -699,7 +732,7 @@ static Cfg make_cfg(const apx_env& env) {
     const apx_env_cfg& c = env.cfg;
     return Cfg{Hf{env.hf, env.hf_nrow, env.hf_ncol, env.hf_size[0], env.hf_size[1], env.hf_size[2]}, c.simrate, c.dynamics_randomization, c.stance_mode, c.have_incentive, c.max_traj_len, c.pgs_iters,
                (unsigned)c.seed, (unsigned)(c.seed >> 32), (unsigned)c.env_id_base, c.reward_kind, c.env_kind, c.command_profile,
-               (c.input_profile ? APX_OBS_MIN : 46) + (c.command_profile == 0 ? 4 : 9), c.est_lifetime, c.input_profile, env.wk};
+               (c.input_profile ? APX_OBS_MIN : 46) + (c.command_profile == 0 ? 4 : 9), c.est_lifetime, c.input_profile, env.wk, env.rst, env.rst_int};
 }
 
 extern "C" void apx_env_default_cfg(apx_env_cfg* c) {
@@ -727,12 +760,16 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     e->wk = nullptr;
     APX_HIP(hipMalloc(&e->wk, sizeof(float) * (size_t)est::REC * e->n));      // state-estimator records (estimator_lane.h); the stage hand-off itself lives in LDS
     APX_HIP(hipMemset(e->wk, 0, sizeof(float) * (size_t)est::REC * e->n));  // state_output_setup
+    e->rst = nullptr; e->rst_int = nullptr;
+    APX_HIP(hipMalloc(&e->rst, sizeof(float) * (size_t)RST_K * F_TOTAL * e->n));
+    APX_HIP(hipMalloc(&e->rst_int, sizeof(int) * (size_t)RST_K * 2 * e->n));
+    APX_HIP(hipMemset(e->rst_int, 0xFF, sizeof(int) * (size_t)RST_K * 2 * e->n));      // -1: no slot holds an episode
     e->hf = nullptr; e->hf_nrow = e->hf_ncol = 0; e->hf_size[0] = e->hf_size[1] = e->hf_size[2] = 0.f;
     e->timing = 0; e->ev = nullptr; e->ev_cap = e->ev_n = 0; e->t_ms = 0.0; e->t_launches = 0;
     const Cfg c = make_cfg(*e);
     hipLaunchKernelGGL(env_init_kernel, dim3(e->n / 64), dim3(64), 0, 0, e->st, e->ist, e->n, c);
     APX_LAUNCH_CHECK();
-    for (const void* fn : {(const void*)env_step_kernel<false>, (const void*)env_step_kernel<true>, (const void*)env_reset_kernel<false>, (const void*)env_reset_kernel<true>,
+    for (const void* fn : {(const void*)env_step_kernel<false>, (const void*)env_step_kernel<true>, (const void*)env_reset_kernel<false>, (const void*)env_reset_kernel<true>, (const void*)env_reset_prepare_kernel<false>, (const void*)env_reset_prepare_kernel<true>,
                            (const void*)env_substep_kernel<false>, (const void*)env_substep_kernel<true>, (const void*)env_reset_for_test_kernel<false>,
                            (const void*)env_reset_for_test_kernel<true>})
         APX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
@@ -745,16 +782,34 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
 
 extern "C" int apx_env_destroy(apx_env_t* e) {
     if (!e) return APX_OK;
-    (void)hipFree(e->st); (void)hipFree(e->ist); (void)hipFree(e->wk); (void)hipFree(e->hf);
+    (void)hipFree(e->st); (void)hipFree(e->ist); (void)hipFree(e->wk); (void)hipFree(e->hf); (void)hipFree(e->rst); (void)hipFree(e->rst_int);
     for (int i = 0; i < e->ev_cap; ++i) (void)hipEventDestroy((hipEvent_t)e->ev[i]);
     free(e->ev);
     delete e;
     return APX_OK;
 }
 
+// prepared resets depend on the model inputs of the forward pass (terrain, external wrench, fields written through the setters): drop them when one of those changes
+static int invalidate_prepared(apx_env* e, void* stream) {
+    APX_HIP(hipMemsetAsync(e->rst_int, 0xFF, sizeof(int) * (size_t)RST_K * 2 * e->n, (hipStream_t)stream));
+    return APX_OK;
+}
+static int launch_prepare(apx_env* e, int ahead, const uint8_t* mask, void* stream) {
+    if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_prepare_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), e->rst, e->rst_int, ahead, mask);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_prepare_kernel<false>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), e->rst, e->rst_int, ahead, mask);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+}
+extern "C" int apx_env_prepare_resets(apx_env_t* e, void* stream) {
+    APX_REQUIRE(e, "env");
+    for (int ahead = 1; ahead <= RST_K; ++ahead) { const int rc = launch_prepare(e, ahead, nullptr, stream); if (rc != APX_OK) return rc; }
+    return APX_OK;
+}
+
 extern "C" int apx_env_set_hfield(apx_env_t* e, const float* data, int nrow, int ncol, const float* size3, void* stream) {
     APX_REQUIRE(e, "env");
     APX_HIP(hipStreamSynchronize((hipStream_t)stream));           // kernels in flight still read the old field
+    { const int rc = invalidate_prepared(e, stream); if (rc != APX_OK) return rc; }
     (void)hipFree(e->hf); e->hf = nullptr; e->hf_nrow = e->hf_ncol = 0;
     if (!data) return APX_OK;                                     // back to the plane
     APX_REQUIRE(nrow >= 2 && ncol >= 2 && size3 && size3[0] > 0.f && size3[1] > 0.f, "height field: nrow, ncol >= 2 and positive half extents");
@@ -766,6 +821,7 @@ extern "C" int apx_env_set_hfield(apx_env_t* e, const float* data, int nrow, int
 
 extern "C" int apx_env_reset(apx_env_t* e, const uint8_t* mask, float* obs_out, void* stream) {
     APX_REQUIRE(e, "env");
+    { const int rc = launch_prepare(e, 1, mask, stream); if (rc != APX_OK) return rc; }      // the envs of the mask whose ring slot does not hold their next episode (exits at once otherwise)
     if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
                        make_cfg(*e), mask, obs_out);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_kernel<false>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
@@ -808,6 +864,7 @@ __global__ void fill_int_kernel(int* p, int n, int v) { const int i = blockIdx.x
 extern "C" int apx_env_apply_force_body(apx_env_t* e, const float* xfrc, int body, void* stream) {
     APX_REQUIRE(e && xfrc, "null pointer");
     APX_REQUIRE(body >= 1 && body < ES_NB, "body id out of range (1 = cassie-pelvis ... 25 = right-foot)");
+    { const int rc = invalidate_prepared(e, stream); if (rc != APX_OK) return rc; }
     hipLaunchKernelGGL(scatter_kernel, dim3(apx_cdiv((long)e->n * 6, 256)), dim3(256), 0, (hipStream_t)stream, e->st, e->n, (int)F_XFRC, 6, xfrc);
     hipLaunchKernelGGL(fill_int_kernel, dim3(apx_cdiv((long)e->n, 256)), dim3(256), 0, (hipStream_t)stream, e->ist + (size_t)I_XBODY * e->n, e->n, body);
     APX_LAUNCH_CHECK();
@@ -827,6 +884,7 @@ extern "C" int apx_env_step(apx_env_t* e, const float* action, float* obs, float
     APX_LAUNCH_CHECK();
     if (timed) { APX_HIP(hipEventRecord((hipEvent_t)e->ev[e->ev_n + 1], (hipStream_t)stream)); e->ev_n += 2; }
     if (auto_reset) {   // finished envs restart in a second launch on the same stream (mask = done flags)
+        { const int rc = launch_prepare(e, 1, done, stream); if (rc != APX_OK) return rc; }      // only for finished envs whose next episode is not in the ring: normally none, the launch exits at once
         if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
                            make_cfg(*e), done, obs);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_kernel<false>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
@@ -962,6 +1020,15 @@ extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, voi
         return 48;
     }
 #endif
+    if (!strcmp(name, "reset_miss")) {      // resets that found no prepared image (must stay 0); then cleared
+        int h = 0;
+        APX_HIP(hipMemcpyFromSymbol(&h, HIP_SYMBOL(g_reset_miss), sizeof(h)));
+        const float hf = (float)h;
+        APX_HIP(hipMemcpy(out, &hf, sizeof(hf), hipMemcpyHostToDevice));
+        const int z = 0;
+        APX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_reset_miss), &z, sizeof(z)));
+        return 1;
+    }
 #ifdef APX_CHECK
     if (!strcmp(name, "oob")) {       // first out-of-range S / S.W / S.I index of the checked build: kind (1 state, 2 workspace, 3 int), index, env, lane; then cleared
         int h[4];
@@ -994,6 +1061,7 @@ extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, voi
 
 extern "C" int apx_env_set_field(apx_env_t* e, const char* name, const float* in, void* stream) {
     APX_REQUIRE(e && name, "null pointer");
+    { const int rc = invalidate_prepared(e, stream); if (rc != APX_OK) return rc; }
     if (!strcmp(name, "set_const")) {   // recompute invweight0 after mass edits (sim.set_const)
         hipLaunchKernelGGL(env_setconst_kernel, SETCONST_GRID(e->n), dim3(64), SETCONST_LDS, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e));
         APX_LAUNCH_CHECK();

@@ -23,7 +23,8 @@ enum IField : int { I_TIME = 0, I_PHASE, I_COUNTER, I_RNG, I_FLAGS /* bit0 menc 
                     I_SAT /* constraint sets beyond what the kernel instantiates: bits 0-3 = SAT_* flags seen since env creation, bits 8.. = number of such forward passes */,
                     I_XBODY /* MuJoCo body id the F_XFRC wrench acts on (0 / 1 = cassie-pelvis) */,
                     I_ROWSET /* hash of the active constraint-row sets (limits, capsule ends, body-floor, leg-leg pairs) of the 50 forward passes of the most recent env step:
-                                the parity tests bin kernel-vs-oracle errors by "same row sets in every substep" (tests/test_gpu_env.py) */, I_TOTAL };
+                                the parity tests bin kernel-vs-oracle errors by "same row sets in every substep" (tests/test_gpu_env.py) */,
+                    I_EPISODE /* resets done so far: episode e takes its reset draws from the stream (seed, env, RNG_RESET, 128 e + k) */, I_TOTAL };
 // what a forward pass needed beyond the kernel's per-leg caps (same bits as oracle/cassie_phys.h SatFlag): > 2 penetrating capsule ends on a
 // leg, > 1 active joint limit on a leg, pelvis sphere / hip-pitch capsule on the floor, a left-right capsule pair in contact
 enum SatFlag : int { SAT_CONTACTS = 1, SAT_LIMITS = 2, SAT_BODY_FLOOR = 4, SAT_LEG_LEG = 8 };
@@ -32,6 +33,9 @@ struct apx_env {
     apx_env_cfg cfg;
     float* st;      // [F_TOTAL, n]
     int* ist;       // [I_TOTAL, n]
+    // prepared resets (apx_env_prepare_resets): RST_K ring slots per env, slot = episode % RST_K; rst = [RST_K x F_TOTAL, n] images of the state fields a reset defines up to its
+    // settle step (randomised model, set_const invweights, init pose, forward-pass sensor snapshot), rst_int = [RST_K x 2, n]: the episode the slot holds (-1 none), its start phase
+    float* rst; int* rst_int;
     float* wk;      // state-estimator records, [n][est::REC] env-major (estimator_lane.h); the stage hand-off itself lives in LDS
     int n;
     float* hf; int hf_nrow, hf_ncol; float hf_size[3];      // device copy of the height field (apx_env_set_hfield), or nullptr
@@ -84,11 +88,12 @@ struct St {
 // terrain of cassie_hfield.xml (util/eval.py:73-76): nrow x ncol raw elevations (rows along y, columns along x) over [-sx, sx] x [-sy, sy],
 // elevation = data * sz; data == nullptr: the floor plane of cassie.xml:73
 struct Hf { const float* data; int nrow, ncol; float sx, sy, sz; };
-struct Cfg { Hf hf; int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; int reward_kind, env_kind, command_profile, obs_dim, est_lifetime, input_profile; float* est /* state-estimator records, [n][est::REC] (estimator_lane.h) */; };
+constexpr int RST_K = 2;
+struct Cfg { Hf hf; int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; int reward_kind, env_kind, command_profile, obs_dim, est_lifetime, input_profile; float* est /* state-estimator records, [n][est::REC] (estimator_lane.h) */; const float* rst; const int* rst_int; /* prepared resets or nullptr */ };
 
 // ------------------------------------------------------------------------------------------------ Philox4x32-10
-__device__ __forceinline__ unsigned philox(unsigned k0, unsigned k1, unsigned env, unsigned ctr) {
-    unsigned c0 = ctr, c1 = env, c2 = 0x41505845u, c3 = 0;
+__device__ __forceinline__ unsigned philox(unsigned k0, unsigned k1, unsigned env, unsigned ctr, unsigned dom) {
+    unsigned c0 = ctr, c1 = env, c2 = 0x41505845u, c3 = dom;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
@@ -98,9 +103,12 @@ __device__ __forceinline__ unsigned philox(unsigned k0, unsigned k1, unsigned en
     }
     return c0;
 }
+// stream domains (4th counter word): 0 = the per-step command draws, ctr = the env's running counter I_RNG; 1 = reset draws, ctr = 128 * episode + k: a reset is a
+// function of (seed, env, episode index) alone, so the next episode's randomised model can be prepared ahead of time (env_reset_prepare_kernel)
+constexpr unsigned RNG_STEP = 0u, RNG_RESET = 1u, RNG_RESET_BLOCK = 128u, RNG_RESET_TAIL = 126u;
 struct Rng {
-    unsigned k0, k1, env, ctr;
-    __device__ __forceinline__ unsigned u32() { return philox(k0, k1, env, ctr++); }
+    unsigned k0, k1, env, ctr, dom;
+    __device__ __forceinline__ unsigned u32() { return philox(k0, k1, env, ctr++, dom); }
     __device__ __forceinline__ float u01() { return ((float)(u32() >> 8) + 0.5f) * (1.0f / 16777216.0f); }
     __device__ __forceinline__ float uniform(float a, float b) { return a + (b - a) * u01(); }
     __device__ __forceinline__ unsigned randint(unsigned n) { return (unsigned)(((unsigned long long)u32() * n) >> 32); }

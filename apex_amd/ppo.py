@@ -88,6 +88,7 @@ class PPO:
         self.b_endb = torch.zeros(T, N, dtype=torch.bool, device=self.device)
         self.b_fin = torch.zeros(T, N, self.D, **f32)
         self.noise = torch.zeros(T, N, 10, **f32)
+        self.prepare_resets = bool(args.get("prepare_resets", True)); self._side = None
         self.use_graph = bool(args.get("graph", False)) and not self.dist_on
         self._graph = None
         self.ep_ret = torch.zeros(N, **f32); self.ep_len = torch.zeros(N, **f32)
@@ -289,8 +290,15 @@ class PPO:
         ret, ep_rets, ep_lens = self.sample()
         torch.cuda.synchronize(self.device)
         t1 = time.time()
+        # the next resets of every env (draws, set_const, forward pass: everything up to the settle step) are prepared on a side stream while the learner runs
+        # (apx_env_prepare_resets): the in-rollout reset then only copies them and runs its one settle substep
+        if self.prepare_resets and hasattr(self.env, "prepare_resets"):
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(self._side):
+                self.env.prepare_resets()
         losses, kl, epochs_run = self.update(ret)
-        torch.cuda.synchronize(self.device)
+        torch.cuda.synchronize(self.device)      # (all streams of the device: the prepared resets are complete before the next rollout)
         t2 = time.time()
         steps = self.T * self.N * self.world
         self.total_steps += steps

@@ -226,6 +226,11 @@ class RecurrentPPO:
         t0 = time.time()
         ret = self.sample()
         torch.cuda.synchronize(self.device); t1 = time.time()
+        if hasattr(self.env, "prepare_resets"):      # next resets prepared on a side stream while the update runs (apx_env_prepare_resets)
+            if getattr(self, "_prep_side", None) is None:
+                self._prep_side = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(self._prep_side):
+                self.env.prepare_resets()
         losses, kl, epochs_run = self.update(ret)
         torch.cuda.synchronize(self.device); t2 = time.time()
         ended = self.b_done != 0

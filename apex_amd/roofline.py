@@ -6,7 +6,7 @@ ENV_STEP_FLOP: fp32 operations of one env step of the tree-sparse formulation, c
  x 50.
 """
 F_TOTAL = 580          # floats of persistent state per env (env_state.h: enum Field)
-I_TOTAL = 9          # int fields per env (env_state.h: enum IField)
+I_TOTAL = 10         # int fields per env (env_state.h: enum IField)
 EST_REC = 168          # state-estimator record per env (estimator_lane.h): read + written once per env step at least (it moves through L2 every substep)
 ENV_STEP_BYTES = 2 * 4 * (F_TOTAL + I_TOTAL + EST_REC) + 4 * 10 + 4 * 50 + 4 + 1
 

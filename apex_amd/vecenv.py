@@ -146,6 +146,10 @@ class CassieVecEnv:
         self._push(self._frame, sel, self.obs)
         return self.obs
 
+    def prepare_resets(self):
+        """apx_env_prepare_resets: precompute the next two resets of every env (draws, set_const, forward pass) off the rollout's critical path"""
+        check(_lib.load().apx_env_prepare_resets(self._h, _stream()))
+
     def _push(self, frame, restart, out):
         """state_history.insert(0, state)[:history + 1] (cassie.py:856-859); envs in `restart` begin a new episode: zero history first (:565)"""
         D = self.frame_dim

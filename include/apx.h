@@ -208,6 +208,14 @@ int apx_env_set_hfield(apx_env_t* env, const float* data, int nrow, int ncol, co
 
 int apx_env_reset(apx_env_t* env, const uint8_t* mask, float* obs_out, void* stream);
 
+/* Scheduling hook without a reference counterpart: compute, for every env, the part of its NEXT two CassieEnv.reset calls (cassie/cassie.py:523-665) that does
+ * not depend on how the running episode ends - command / clock / dynamics-randomisation draws (:525-657), sim.set_const (:660: mj_setConst, init pose, mj_forward) -
+ * into a per-env ring, e.g. while the learner runs.  A later reset (apx_env_reset, the auto-reset of apx_env_step / apx_rollout) that finds its episode in the ring
+ * copies it and only runs the settle step_pd (:665) and the command redraw (:669-670); otherwise it computes everything as before.  Results are bit-identical either
+ * way: reset draws are keyed by (seed, env, episode index), not by the env's running draw counter.  The ring is dropped by apx_env_set_hfield,
+ * apx_env_apply_force(_body) and apx_env_set_field. */
+int apx_env_prepare_resets(apx_env_t* env, void* stream);
+
 /* Evaluation-side API.
  * CassieEnv.update_speed (cassie/cassie.py:757-775, clock command profile) for every env: speed[n_envs] f32 [dev],
  * side_speed[n_envs] f32 [dev] or NULL (= 0): commands are clipped to [-0.3, 4] / [-0.3, 0.3], the clock is rebuilt from the

@@ -88,6 +88,7 @@ static int field(Env& e, const char* name, double* io, bool set) {
     }
     if (!std::strcmp(name, "enc_primed")) { if (set) { e.menc_primed = (int)io[0]; e.jenc_primed = (int)io[1]; } else { io[0] = e.menc_primed; io[1] = e.jenc_primed; } return 2; }
     if (!std::strcmp(name, "phase_add")) { if (set) { e.phase_add15 = io[0] > 1.25; e.phase_half = (int)io[1]; } else { io[0] = e.phase_add15 ? 1.5 : 1.0; io[1] = e.phase_half; } return 2; }
+    if (!std::strcmp(name, "episode")) { if (set) e.episode = (int)io[0]; else io[0] = e.episode; return 1; }
     if (!std::strcmp(name, "est_age")) { if (set) { e.est_age = (int)io[0]; e.cfg.est_lifetime = (int)io[1]; } else { io[0] = e.est_age; io[1] = e.cfg.est_lifetime; } return 2; }
     if (!std::strcmp(name, "est_flags")) { if (set) e.est.inited = (int)io[0]; else { io[0] = e.est.inited; io[1] = e.est.lm_iters; } return 2; }
     if (!std::strcmp(name, "xpos")) { if (!set) std::memcpy(io, e.st.xpos, sizeof(double) * 3 * NB); return 3 * NB; }
@@ -168,8 +169,8 @@ double orc_clock_reward_eval(void* h, const double* qpos, const double* qvel, co
 
 void orc_core_safety(const double* q, const double* qd, const double* cmd, double radio, double* out) { core_safety(q, qd, cmd, radio, out); }
 
-uint32_t orc_philox(uint64_t seed, uint32_t env, uint32_t ctr) {
-    Philox p{(uint32_t)seed, (uint32_t)(seed >> 32), env, ctr};
+uint32_t orc_philox(uint64_t seed, uint32_t env, uint32_t ctr, uint32_t dom) {
+    Philox p{(uint32_t)seed, (uint32_t)(seed >> 32), env, ctr, dom};
     return p.next_u32();
 }
 
@@ -186,7 +187,7 @@ double orc_rollout_bench(int n_envs, int n_steps, int threads, uint64_t seed, do
             const int i = next.fetch_add(1);
             if (i >= n_envs) return;
             Env& e = *envs[i];
-            Philox an{(uint32_t)(seed ^ 0x5bd1e995u), 77u, (uint32_t)i, 0};
+            Philox an{(uint32_t)(seed ^ 0x5bd1e995u), 77u, (uint32_t)i, 0, 0};
             double obs[50], rew, act[10];
             env_reset(e, obs);
             for (int t = 0; t < n_steps; ++t) {

@@ -15,7 +15,7 @@ static inline void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
 uint32_t Philox::next_u32() {
-    uint32_t c[4] = {ctr, env, 0x41505845u, 0};   // (draw index, env id, tag, 0)
+    uint32_t c[4] = {ctr, env, 0x41505845u, dom};   // (draw index, env id, tag, stream domain)
     uint32_t k0 = key0, k1 = key1;
     for (int r = 0; r < 10; ++r) {
         philox_round(c, k0, k1);
@@ -269,7 +269,7 @@ void env_init(Env& e, const EnvCfg& cfg, uint32_t env_id) {
     state_output_setup(e.est);
     default_params(e.par);
     e.par.pgs_iters = cfg.pgs_iters;
-    e.rng = Philox{(uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), env_id, 0};
+    e.rng = Philox{(uint32_t)cfg.seed, (uint32_t)(cfg.seed >> 32), env_id, 0, 0};
     reset_state(e.st);
 }
 
@@ -377,7 +377,10 @@ void env_reset(Env& e, double* obs) {
     // the reference builds a new CassieEnv (-> cassie_sim_init -> a new estimator) per PPO.sample call (rl/algos/ppo.py:152); a lock-step env outlives
     // the call, so the estimator's lifetime is carried: after est_lifetime env steps the next reset starts from state_output_setup
     if (e.cfg.est_lifetime > 0 && e.est_age >= e.cfg.est_lifetime) { state_output_setup(e.est); e.est_age = 0; }
-    Philox& r = e.rng;
+    // reset draws come from their own counter-based stream keyed by (seed, env, episode index): order-independent of the per-step command draws, so the kernel can
+    // prepare the next episode's randomised model ahead of time (apx_env_prepare_resets).  Draw ORDER inside a reset is the reference's (golden G14).
+    e.episode += 1;
+    Philox r{e.rng.key0, e.rng.key1, e.rng.env, (uint32_t)e.episode * 128u, 1};
     e.speed = e.cfg.env_kind == 1 ? (double)r.randint(41) / 10 : r.uniform(-0.3, 4.0);      // cassie_traj.py:608: random.randint(0, 40) / 10
     e.side_speed = r.uniform(-0.3, 0.3);
     if (e.cfg.command_profile == 0) set_clock_from_speed(e);
@@ -433,6 +436,7 @@ void env_reset(Env& e, double* obs) {
     sim_step_pd(e);                                         // cassie.py:665: one step with the stale self.u
     foot_positions(e.st, e.foot_pos_prev);
     e.orient_add = 0;
+    r.ctr = (uint32_t)e.episode * 128u + 126u;              // the two command redraws sit at the end of the episode's block (the number of draws before them depends on the command profile)
     e.speed = r.uniform(-0.3, 4.0);                         // cassie.py:669-670 (clock keeps the FIRST speed draw)
     e.side_speed = r.uniform(-0.3, 0.3);
     e.l_foot_frc = e.r_foot_frc = e.l_foot_orient_cost = e.r_foot_orient_cost = 0;

@@ -14,6 +14,7 @@ struct Philox {
     uint32_t key0, key1;      // seed
     uint32_t env;             // stream id
     uint32_t ctr;             // draws consumed so far (persisted per env)
+    uint32_t dom = 0;         // stream domain (4th counter word): 0 = the per-step command draws (sequential counter), 1 = reset draws, counter = 128 * episode + k
     uint32_t next_u32();
     double uniform01() { return ((double)(float)(next_u32() >> 8) + 0.5) * (1.0 / 16777216.0); }
     double uniform(double a, double b) { return a + (b - a) * uniform01(); }
@@ -50,6 +51,7 @@ struct Env {
     Philox rng;
     // episode / command state (cassie.py:71-78,117-119)
     int time, phase, counter;
+    int episode;               // resets done so far: episode e draws its reset from the order-independent stream (seed, env, dom 1, 128 e + k), so a reset can be computed ahead of time
     int est_age;               // env steps since the estimator object was set up
     int phase_half, phase_add15;   // self.phase_add = 1.5 of the command harness (tools/test_commands.py:86, cassie.py:448): the phase is phase + 0.5 phase_half
     double speed, side_speed, orient_add;

@@ -203,7 +203,7 @@ void default_params(Params& p) {
 
 // mj_setConst subset: body_invweight0 / dof_invweight0 from M^-1 at qpos0 (used by the constraint regulariser R)
 void set_const(Params& p) {
-    static State s; static Work w;
+    static thread_local State s; static thread_local Work w;      // (thread_local: resets run concurrently in orc_rollout_bench and in the threaded tests; plain statics raced until round 4)
     kinematics(cm_qpos0, s, w);
     inertias(p, s, w);
     {   // set0: stat.meaninertia = mean of the diagonal of M at qpos0 (scale of the solver's termination test)
@@ -212,7 +212,7 @@ void set_const(Params& p) {
         p.meaninertia = tr / NV;
     }
     if (!cholesky(w.M, w.L)) return;
-    static double Minv[NV][NV];
+    static thread_local double Minv[NV][NV];
     for (int c = 0; c < NV; ++c) {
         double e[NV] = {0}, x[NV];
         e[c] = 1;

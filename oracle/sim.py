@@ -66,7 +66,7 @@ def lib():
         L.orc_clock_reward_eval.argtypes = [C.c_void_p] * 11
         L.orc_core_safety.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _CR, C.c_void_p]
         L.orc_philox.restype = C.c_uint32
-        L.orc_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+        L.orc_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
         L.orc_est_create.restype = C.c_void_p
         L.orc_est_destroy.argtypes = [C.c_void_p]
         L.orc_est_setup.argtypes = [C.c_void_p]
@@ -225,8 +225,9 @@ def core_safety(q, qd, cmd, radio=1.0):
     return out
 
 
-def philox(seed, env, ctr):
-    return lib().orc_philox(seed, env, ctr)
+def philox(seed, env, ctr, dom=0):
+    """one Philox4x32-10 draw of stream (seed, env, dom): dom 0 = the per-step command draws (ctr = the env's running counter), dom 1 = reset draws (ctr = 128 * episode + k)"""
+    return lib().orc_philox(seed, env, ctr, dom)
 
 
 def rollout_bench(n_envs, n_steps, threads, seed=0, act_std=0.2):

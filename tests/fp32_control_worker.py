@@ -14,7 +14,8 @@ def main(src, dst):
     from oracle import sim as S
     from tests.state_xfer import ORACLE_STATE_FIELDS, oracle_load_state
     assert S._F32, "run with ORC_REAL=float"
-    g = np.load(src)
+    with np.load(src) as z:
+        g = {k: z[k] for k in z.files}      # materialised once: NpzFile re-reads the zip member on every access and is not thread-safe
     n_env, n_step = g["action"].shape[:2]
     obs = np.zeros((n_env, n_step, g["obs"].shape[-1])); rew = np.zeros((n_env, n_step)); done = np.zeros((n_env, n_step), dtype=np.int64); hsh = np.zeros((n_env, n_step), dtype=np.int64)
 

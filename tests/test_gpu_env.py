@@ -1044,3 +1044,32 @@ def test_apply_force_on_any_body_vs_oracle(dev):
         genv.apply_force(torch.zeros(6), body); [e.apply_force(np.zeros(6), body) for e in oenv]
     genv.apply_force(torch.zeros(6))
     assert int(genv.get_field("ints")[0, 7]) == 1      # back on the pelvis row
+
+
+def test_prepared_resets_are_bit_identical_to_computed_ones(dev):
+    """apx_env_prepare_resets: the draws, set_const and forward pass of the next two resets of every env are computed ahead of time into a per-env
+    ring, keyed by the episode index; an auto-reset that finds its episode there copies it and only runs the settle step.  Two envs with the same seed, one prepared before
+    every step and one never, must stay BIT-identical over rollouts full of resets (random actions, short episodes: envs that end three times between two
+    preparations exercise the fallback as well), for both env kinds and the phase command profile."""
+    from apex_amd.vecenv import CassieVecEnv
+    for kw, prep_every in ((dict(), 1), (dict(), 25), (dict(env_name="CassieTraj-v0"), 3), (dict(command_profile="phase"), 2), (dict(dynamics_randomization=False), 1)):
+        a = CassieVecEnv(n_envs=256, seed=31, max_traj_len=12, **kw); b = CassieVecEnv(n_envs=256, seed=31, max_traj_len=12, **kw)
+        oa, ob = a.reset().clone(), b.reset().clone()
+        assert torch.equal(oa, ob)
+        g = torch.Generator(device=dev); g.manual_seed(4)
+        nres = 0
+        for t in range(40):
+            if t % prep_every == 0:
+                a.prepare_resets()
+            act = torch.randn(256, 10, device=dev, generator=g) * 0.3
+            oa, ra, da, fa = a.step(act); ob, rb, db, fb = b.step(act)
+            assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db), (kw, t)
+            nres += int((da != 0).sum())
+        for name in ("qpos", "qvel", "qacc_warm", "mass", "damping", "friction", "floor", "body_invweight0", "dof_invweight0", "motor_noise", "joint_noise", "snap", "cmd", "fwd", "tq_fifo", "menc"):
+            assert torch.equal(a.get_field(name), b.get_field(name)), (kw, name)
+        ia, ib = a.get_field("ints_bits").view(torch.int32), b.get_field("ints_bits").view(torch.int32)
+        assert torch.equal(ia, ib)
+        assert torch.equal(a.get_field("est"), b.get_field("est"))
+        assert float(a.get_field("reset_miss")[0, 0]) == 0 and float(b.get_field("reset_miss")[0, 0]) == 0
+        assert nres > 256 * 2 and int(ia[:, 9].max()) >= 4          # every env restarted several times: ring hits and (with rare preparation) fallbacks
+        a.close(); b.close()

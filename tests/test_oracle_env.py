@@ -297,7 +297,7 @@ def test_g14_reset_draws_and_randomisation_tables(golden_dir):
         e = S.OracleEnv(dyn_rand=True, seed=seed, env_id=eid)
         d0, m0 = e.get("damping").copy(), e.get("mass").copy()
         e.reset()
-        u01 = lambda k: ((S.philox(seed, eid, k) >> 8) + 0.5) / 16777216.0
+        u01 = lambda k: ((S.philox(seed, eid, 128 + k, 1) >> 8) + 0.5) / 16777216.0      # reset stream of episode 1: (seed, env, dom 1, 128 * episode + k)
         uni = lambda k, a, b: a + (b - a) * u01(k)
         np.testing.assert_allclose(e.get("damping"), [d0[d] * (d_lo[d] + (d_hi[d] - d_lo[d]) * u01(3 + d)) for d in range(32)], rtol=1e-12)
         exp_m = [0.0] + [m0[b] * uni(35 + b, 0.5, 1.5) for b in range(1, 26)]
@@ -308,8 +308,8 @@ def test_g14_reset_draws_and_randomisation_tables(golden_dir):
         np.testing.assert_allclose(e.get("floor_quat"), [cx * cy, cy * sx, cx * sy, sx * sy], atol=1e-12)
         np.testing.assert_allclose(e.get("motor_noise"), [uni(66 + u, -0.01, 0.01) for u in range(10)], rtol=1e-12)
         np.testing.assert_allclose(e.get("joint_noise"), [uni(76 + k, -0.01, 0.01) for k in range(6)], rtol=1e-12)
-        np.testing.assert_allclose([e.get("speed")[0], e.get("side_speed")[0]], [uni(82, -0.3, 4.0), uni(83, -0.3, 0.3)], rtol=1e-12)
-        assert int(e.get("ints")[5]) == 84                                                           # draws consumed by one reset
+        np.testing.assert_allclose([e.get("speed")[0], e.get("side_speed")[0]], [uni(126, -0.3, 4.0), uni(127, -0.3, 0.3)], rtol=1e-12)      # the command redraws close the episode's block
+        assert int(e.get("ints")[5]) == 0 and int(e.get("episode")[0]) == 1                          # a reset consumes nothing of the per-step stream: it is keyed by the episode index
 
 
 def test_g16_update_speed_and_reset_for_test(golden_dir):
@@ -549,8 +549,8 @@ def test_g22_phase_command_profile(golden_dir):
         e = S.OracleEnv(dyn_rand=False, seed=seed, env_id=eid, command_profile=cp)
         obs = e.reset()
         assert obs.shape == (55,)
-        u01 = lambda k: ((S.philox(seed, eid, k) >> 8) + 0.5) / 16777216.0
-        ri = lambda k, n: (S.philox(seed, eid, k) * n) >> 32
+        u01 = lambda k: ((S.philox(seed, eid, 128 + k, 1) >> 8) + 0.5) / 16777216.0
+        ri = lambda k, n: (S.philox(seed, eid, 128 + k, 1) * n) >> 32
         if cp == 1:
             swing, stance, pick, k = (1 + ri(2, 50)) / 100, (1 + ri(3, 30)) / 100, ri(4, 3), 5
         else:
@@ -608,7 +608,8 @@ def test_fp32_control_of_the_parity_tolerances(tmp_path):
     from concurrent.futures import ThreadPoolExecutor
     from tests.state_xfer import ORACLE_STATE_FIELDS, oracle_state, TF_TOL_SAME, TF_TOL_SAME_P99, TF_MAX_DIFFERING_FRACTION
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    n_env, n_step, seed = 12, 40, 22
+    n_env, n_step, seed = 16, 60, 22
+    nthr = torch.get_num_threads(); torch.set_num_threads(1)      # the policy's matmul summation order must not depend on the host's thread count: the rollout is chaotic
     policy = torch.load(os.path.join(root, "trained_models", "r03_cassie_v0_clock", "actor.pt"), weights_only=False).eval()
     envs = [S.OracleEnv(dyn_rand=True, seed=seed, env_id=i) for i in range(n_env)]
     obs = np.stack([e.reset() for e in envs])
@@ -628,6 +629,7 @@ def test_fp32_control_of_the_parity_tolerances(tmp_path):
                 A[i, t] = act[i]; O[i, t] = o; R[i, t] = r; D[i, t] = d; H[i, t] = int(ii[10]) | int(ii[11]) << 16
                 obs[i] = e.reset() if d else o
             list(ex.map(one, range(n_env)))
+    torch.set_num_threads(nthr)
     src, dst = str(tmp_path / "rec.npz"), str(tmp_path / "out.npz")
     np.savez(src, seed=seed, action=A, obs=O, rew=R, done=D, hash=H, **{"st_" + k: v for k, v in rec.items()})
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "fp32_control_worker.py"), src, dst], env=dict(os.environ, ORC_REAL="float"), capture_output=True, text=True, timeout=600)
@@ -639,9 +641,13 @@ def test_fp32_control_of_the_parity_tolerances(tmp_path):
     E = np.stack([np.abs(O[..., sl] - b["obs"][..., sl]).max(-1) for sl in grp] + [np.abs(R - b["rew"])], -1)      # [env, step, 10]
     Es = E[same]
     frac = 1.0 - same.mean()
-    print("fp32 control: differing row sets in %.4f of %d pairs; identical-set maxima %s" % (frac, same.size, np.array2string(Es.max(0), precision=2)))
+    print("fp32 control: differing row sets in %.4f of %d pairs; identical-set maxima %s p99 %s" % (frac, same.size, np.array2string(Es.max(0), precision=2, max_line_width=400),
+                                                                                                     np.array2string(np.percentile(Es, 99, axis=0), precision=2, max_line_width=400)))
     assert frac < TF_MAX_DIFFERING_FRACTION
+    # the control meets the tolerances the kernel is held to (measured on these 960 pairs: acceleration max 9.2e-2 / p99 5.3e-2 m/s^2, motor velocity 4.2e-2 rad/s,
+    # reward 9.2e-4; the kernel: 8.6e-2 / 6.3e-2, 5.4e-2, 1.9e-3 on 3150 pairs) ...
     assert np.all(Es.max(0) <= TF_TOL_SAME[:10]), (Es.max(0), TF_TOL_SAME[:10])
-    assert np.all(np.percentile(Es, 99, axis=0) <= TF_TOL_SAME_P99[:10])
-    for k in (4, 5, 9):      # motor velocity, acceleration, reward: the tolerance is within 10 x of what fp32 itself does
+    assert np.all(np.percentile(Es, 99, axis=0) <= TF_TOL_SAME_P99[:10]), (np.percentile(Es, 99, axis=0), TF_TOL_SAME_P99[:10])
+    # ... and they are not slack: on the stiff groups (motor velocity, acceleration, reward) plain fp32 round-off reaches a good fraction of them
+    for k in (4, 5, 9):
         assert Es[:, k].max() > TF_TOL_SAME[k] / 10, (k, Es[:, k].max())
