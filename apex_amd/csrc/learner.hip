@@ -389,10 +389,13 @@ static int linear_bwd_input(const float* dY, const float* W, const float* mask, 
 // db[Dout] += column sums of dY, fused into the same launch (they ride on the dY tile already in LDS)
 static int linear_bwd_weight(const float* dY, const float* X, float* dW, float* db, long B, int Din, int Dout, hipStream_t s, int prec = 0) {
     GemmArgs g{dY, 1, Dout, X, Din, 1, dW, Din, db, 0, Dout, Din, (int)B, 0, prec};
-    int ksplit = (int)(B / 256);
+    // split-K so that the launch fills the chip whatever the size of dW: about 2048 workgroups (256 CUs x 2 per CU x 4 waves each), at least 64 batch rows per
+    // workgroup.  (Until round 4: B / 256 capped at 64, which left the 10 x 256 and 256 x 50 gradients with 256 workgroups walking 256 rows each.)
+    const long tiles = (long)apx_cdiv(Dout, GBM) * apx_cdiv(Din, GBN);
+    long ksplit = 2048 / tiles;
+    if (ksplit > B / 64) ksplit = B / 64;
     if (ksplit < 1) ksplit = 1;
-    if (ksplit > 64) ksplit = 64;
-    return launch_gemm(EPI_ATOMIC, g, ksplit, s);
+    return launch_gemm(EPI_ATOMIC, g, (int)ksplit, s);
 }
 
 extern "C" size_t apx_mlp_param_count(int D, int H, int O) {
@@ -1100,12 +1103,9 @@ __global__ void clip_adam_kernel(float* __restrict__ p, float* __restrict__ m, f
     }
 }
 
-extern "C" int apx_clip_adam(float* param, float* m, float* v, float* grad, int64_t n, float grad_scale,
-                             float grad_clip, float lr, float adam_eps, int adam_t, double* sumsq_scratch,
-                             void* stream) {
-    APX_REQUIRE(param && m && v && grad && sumsq_scratch && n > 0 && adam_t >= 1, "args");
-    hipStream_t s = (hipStream_t)stream;
-    APX_HIP(hipMemsetAsync(sumsq_scratch, 0, sizeof(double), s));
+static int clip_adam_impl(float* param, float* m, float* v, float* grad, int64_t n, float grad_scale, float grad_clip, float lr, float adam_eps, int adam_t,
+                          double* sumsq_scratch, hipStream_t s, bool clear) {
+    if (clear) APX_HIP(hipMemsetAsync(sumsq_scratch, 0, sizeof(double), s));
     const int grid = (int)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
     hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, grad, n, sumsq_scratch);
     APX_LAUNCH_CHECK();
@@ -1114,6 +1114,12 @@ extern "C" int apx_clip_adam(float* param, float* m, float* v, float* grad, int6
                        grad_clip, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), adam_eps);
     APX_LAUNCH_CHECK();
     return APX_OK;
+}
+extern "C" int apx_clip_adam(float* param, float* m, float* v, float* grad, int64_t n, float grad_scale,
+                             float grad_clip, float lr, float adam_eps, int adam_t, double* sumsq_scratch,
+                             void* stream) {
+    APX_REQUIRE(param && m && v && grad && sumsq_scratch && n > 0 && adam_t >= 1, "args");
+    return clip_adam_impl(param, m, v, grad, n, grad_scale, grad_clip, lr, adam_eps, adam_t, sumsq_scratch, (hipStream_t)stream, true);
 }
 
 // ------------------------------------------------------------------------------------------------ PPO minibatch
@@ -1127,11 +1133,13 @@ struct PpoWs {
         char* p = (char*)base;
         size_t off = 0;
         auto take = [&](size_t nfloat) { float* r = (float*)(p + off); off += align_up(nfloat * sizeof(float)); return r; };
-        xn = take(mb * D); xm = take(mb * D); xr = take(mb * D);
-        a1 = take(mb * H); a2 = take(mb * H); m1 = take(mb * H); m2 = take(mb * H); c1 = take(mb * H); c2 = take(mb * H);
-        mu = take(mb * A); mum = take(mb * A); v = take(mb);
-        dmu = take(mb * A); dmum = take(mb * A); dv = take(mb);
-        dh2 = take(mb * H); dh1 = take(mb * H);
+        // the actor's two grad-carrying instances pi(s) and pi(M_s s) share the weights: their rows are ADJACENT ([2 mb, .] blocks: first s, then M_s s), so that
+        // the forward is one 2 mb-row launch and the backward one chain of five GEMMs over 2 mb rows instead of two chains
+        xn = take(2 * mb * D); xm = xn + mb * D; xr = take(mb * D);
+        a1 = take(2 * mb * H); m1 = a1 + mb * H; a2 = take(2 * mb * H); m2 = a2 + mb * H; c1 = take(mb * H); c2 = take(mb * H);
+        mu = take(2 * mb * A); mum = mu + mb * A; v = take(mb);
+        dmu = take(2 * mb * A); dmum = dmu + mb * A; dv = take(mb);
+        dh2 = take(2 * mb * H); dh1 = take(2 * mb * H);
         acc = (double*)(p + off); off += align_up(16 * sizeof(double));
         bytes = off;
     }
@@ -1160,17 +1168,22 @@ extern "C" int apx_ppo_minibatch(const apx_ppo_args* a, void* stream) {
     PpoWs w(a->workspace, mb, D, H, A);
     const size_t na = apx_mlp_param_count(D, H, A), nc = apx_mlp_param_count(D, H, 1);
     APX_HIP(hipMemsetAsync(w.acc, 0, 16 * sizeof(double), s));
-    APX_HIP(hipMemsetAsync(a->actor_grad, 0, na * sizeof(float), s));
-    APX_HIP(hipMemsetAsync(a->critic_grad, 0, nc * sizeof(float), s));
-    // forwards
-    APX_TRY(prep_obs(a->obs, mb, D, a->idx, nullptr, 0, a->obs_mean, a->obs_std, w.xn, s));
-    APX_TRY(mlp_forward_impl(a->actor, D, H, A, w.xn, mb, w.a1, w.a2, w.mu, s, prec));
-    if (mirror) {
-        APX_TRY(prep_obs(a->obs, mb, D, a->idx, a->obs_sign_perm, a->clock_mask, a->obs_mean, a->obs_std, w.xm, s));
-        APX_TRY(mlp_forward_impl(a->actor, D, H, A, w.xm, mb, w.m1, w.m2, w.mum, s, prec));
+    if (a->critic_grad == a->actor_grad + na) APX_HIP(hipMemsetAsync(a->actor_grad, 0, (na + nc) * sizeof(float), s));      // one flat gradient buffer (engine.PPOLearner): one fill
+    else {
+        APX_HIP(hipMemsetAsync(a->actor_grad, 0, na * sizeof(float), s));
+        APX_HIP(hipMemsetAsync(a->critic_grad, 0, nc * sizeof(float), s));
     }
-    APX_TRY(prep_obs(a->obs, mb, D, a->idx, nullptr, 0, nullptr, nullptr, w.xr, s));   // critic: raw obs (critic.py:66)
-    APX_TRY(mlp_forward_impl(a->critic, D, H, 1, w.xr, mb, w.c1, w.c2, w.v, s, prec));
+    // forwards: pi(s) and pi(M_s s) as ONE pass over 2 mb rows
+    const long ma = mirror ? 2 * mb : mb;
+    APX_TRY(prep_obs(a->obs, mb, D, a->idx, nullptr, 0, a->obs_mean, a->obs_std, w.xn, s));
+    if (mirror) APX_TRY(prep_obs(a->obs, mb, D, a->idx, a->obs_sign_perm, a->clock_mask, a->obs_mean, a->obs_std, w.xm, s));
+    APX_TRY(mlp_forward_impl(a->actor, D, H, A, w.xn, ma, w.a1, w.a2, w.mu, s, prec));
+    if (prec == 0 && fused_ok(D, H, 1))      // critic: raw obs (critic.py:66); the row gather rides in the fused forward, which also leaves the gathered rows in w.xr for the backward
+        APX_TRY(mlp_fused_launch(a->critic, D, H, 1, FusedIn{a->obs, a->idx, nullptr, 0, nullptr, nullptr, w.xr}, mb, w.c1, w.c2, w.v, s));
+    else {
+        APX_TRY(prep_obs(a->obs, mb, D, a->idx, nullptr, 0, nullptr, nullptr, w.xr, s));
+        APX_TRY(mlp_forward_impl(a->critic, D, H, 1, w.xr, mb, w.c1, w.c2, w.v, s, prec));
+    }
     // losses
     LossArgs L{w.mu, mirror ? w.mum : nullptr, w.v, a->act, a->ret, a->adv, a->old_mu, a->idx, nullptr, a->act_sign_perm,
                w.dmu, w.dmum, w.dv, w.acc, mb, A, a->fixed_std, a->clip, a->mirror_coeff};
@@ -1179,14 +1192,12 @@ extern "C" int apx_ppo_minibatch(const apx_ppo_args* a, void* stream) {
     hipLaunchKernelGGL(finish_scalars_kernel, dim3(1), dim3(1), 0, s, w.acc, a->fixed_std, a->scalars_out);
     APX_LAUNCH_CHECK();
     // backwards
-    APX_TRY(mlp_backward_impl(a->actor, a->actor_grad, D, H, A, w.xn, w.a1, w.a2, w.dmu, mb, w.dh2, w.dh1, s, prec));
-    if (mirror)
-        APX_TRY(mlp_backward_impl(a->actor, a->actor_grad, D, H, A, w.xm, w.m1, w.m2, w.dmum, mb, w.dh2, w.dh1, s, prec));
+    APX_TRY(mlp_backward_impl(a->actor, a->actor_grad, D, H, A, w.xn, w.a1, w.a2, w.dmu, ma, w.dh2, w.dh1, s, prec));      // both instances: 2 mb rows
     APX_TRY(mlp_backward_impl(a->critic, a->critic_grad, D, H, 1, w.xr, w.c1, w.c2, w.dv, mb, w.dh2, w.dh1, s, prec));
     if (a->grad_only) return APX_OK;
-    APX_TRY(apx_clip_adam(a->actor, a->actor_m, a->actor_v, a->actor_grad, (int64_t)na, 1.f, a->grad_clip, a->lr,
-                          a->adam_eps, a->adam_t, w.acc + 8, s));
-    APX_TRY(apx_clip_adam(a->critic, a->critic_m, a->critic_v, a->critic_grad, (int64_t)nc, 1.f, a->grad_clip, a->lr,
-                          a->adam_eps, a->adam_t, w.acc + 9, s));
+    APX_TRY(clip_adam_impl(a->actor, a->actor_m, a->actor_v, a->actor_grad, (int64_t)na, 1.f, a->grad_clip, a->lr,
+                           a->adam_eps, a->adam_t, w.acc + 8, s, false));      // (w.acc was cleared above: no second fill)
+    APX_TRY(clip_adam_impl(a->critic, a->critic_m, a->critic_v, a->critic_grad, (int64_t)nc, 1.f, a->grad_clip, a->lr,
+                           a->adam_eps, a->adam_t, w.acc + 9, s, false));
     return APX_OK;
 }
