@@ -389,10 +389,12 @@ static int linear_bwd_input(const float* dY, const float* W, const float* mask, 
 // db[Dout] += column sums of dY, fused into the same launch (they ride on the dY tile already in LDS)
 static int linear_bwd_weight(const float* dY, const float* X, float* dW, float* db, long B, int Din, int Dout, hipStream_t s, int prec = 0) {
     GemmArgs g{dY, 1, Dout, X, Din, 1, dW, Din, db, 0, Dout, Din, (int)B, 0, prec};
-    // split-K so that the launch fills the chip whatever the size of dW: about 2048 workgroups (256 CUs x 2 per CU x 4 waves each), at least 64 batch rows per
-    // workgroup.  (Until round 4: B / 256 capped at 64, which left the 10 x 256 and 256 x 50 gradients with 256 workgroups walking 256 rows each.)
+    // split-K sized to the chip, not to the batch: about 1024 workgroups whatever the shape of dW, at least 64 batch rows per workgroup.  More splits only add
+    // atomics (the 256 x 256 gradient at 128 splits is 8.4 M atomic adds = 55 us, L2-atomic bound), fewer leave CUs idle on the 10 x 256 and 256 x 50 gradients
+    // (measured with APX_KSPLIT_WGS = 256 / 512 / 1024 / 2048 on the bench minibatch, tools/t_ksplit_sweep.sh: backward 10 GEMMs 391 / 327 / 324 / 358 us).
     const long tiles = (long)apx_cdiv(Dout, GBM) * apx_cdiv(Din, GBN);
-    long ksplit = 2048 / tiles;
+    static const long target_wgs = getenv("APX_KSPLIT_WGS") ? atol(getenv("APX_KSPLIT_WGS")) : 1024;
+    long ksplit = target_wgs / tiles;
     if (ksplit > B / 64) ksplit = B / 64;
     if (ksplit < 1) ksplit = 1;
     return launch_gemm(EPI_ATOMIC, g, (int)ksplit, s);
