@@ -66,11 +66,11 @@ def kernel_source_hash():
 
 
 def _pmc_traffic_bytes():
-    """HBM bytes per env_step_kernel launch from the committed rocprofv3 PMC passes (profiles/r03_env_step_pmc_hbm.txt, 4096 envs): 2 x
+    """HBM bytes per env_step_kernel launch from the committed rocprofv3 PMC passes (profiles/r04_env_step_pmc_hbm.txt, 4096 envs): 2 x
     FETCH_SIZE (gfx950 correction of the microarchitecture guide) + WRITE_SIZE, both in KB.  The profile records the hash of the kernel
     sources it was taken on (tools/profile_round.sh); a profile of another kernel is NOT quoted: None + a note on stderr."""
     import re
-    path = os.path.join(REPO, "profiles", "r03_env_step_pmc_hbm.txt")
+    path = os.path.join(REPO, "profiles", "r04_env_step_pmc_hbm.txt")
     try:
         txt = open(path).read()
         m = re.search(r"kernel sources sha1: (\w+)", txt)
@@ -86,7 +86,7 @@ def _pmc_traffic_bytes():
 
 
 def _pmc_issue():
-    """The instruction-issue view of the env kernel, from the SQ counter pass of the same profile round (profiles/r03_env_step_pmc_sq.txt, quoted only while
+    """The instruction-issue view of the env kernel, from the SQ counter pass of the same profile round (profiles/r04_env_step_pmc_sq.txt + r04_env_step_pmc_issue.txt, quoted only while
     the HBM pass next to it carries this tree's kernel-source hash).  One single-wave workgroup sits on each SIMD, and a SIMD can start at most one VALU
     instruction per quad-cycle, the unit SQ_WAVE_CYCLES counts in: valu_issue_frac = SQ_INSTS_VALU / SQ_WAVE_CYCLES is how much of that ceiling the
     instruction stream uses, wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES how much of the time the wave sits in s_waitcnt.  flop_per_lane_instr relates it to the
@@ -96,13 +96,31 @@ def _pmc_issue():
     if _pmc_traffic_bytes() is None:
         return None
     try:
-        txt = open(os.path.join(REPO, "profiles", "r03_env_step_pmc_sq.txt")).read()
+        txt = open(os.path.join(REPO, "profiles", "r04_env_step_pmc_sq.txt")).read()
         line = re.search(r"env_step_kernel[^:]*: (.*)", txt).group(1)
         g = lambda k: float(re.search(k + r"=([0-9.e+]+)", line).group(1))
         valu, wave, wait = g("SQ_INSTS_VALU"), g("SQ_WAVE_CYCLES"), g("SQ_WAIT_ANY")
-        return {"valu_issue_frac": round(valu / wave, 4), "wait_frac": round(wait / wave, 4), "valu_instr_per_launch": valu,
-                "flop_per_lane_instr": round(roofline.ENV_STEP_FLOP_COUNTED * 4096 / (valu * 64.0), 3),
-                "source": "profiles/r03_env_step_pmc_sq.txt (rocprofv3 --pmc, 4096 envs, per-dispatch means)"}
+        out = {"valu_issue_frac": round(valu / wave, 4), "wait_frac": round(wait / wave, 4), "valu_instr_per_launch": valu,
+               "flop_per_lane_instr": round(roofline.ENV_STEP_FLOP_COUNTED * 4096 / (valu * 64.0), 3),
+               "source": "profiles/r04_env_step_pmc_sq.txt + r04_env_step_pmc_issue.txt (rocprofv3 --pmc, 4096 envs, per-dispatch means)"}
+        try:      # the split of the wait (round 4, tools/profile_issue.sh): instruction-issue shares, LDS issue stalls, instruction-cache misses, dynamic arithmetic share
+            it = open(os.path.join(REPO, "profiles", "r04_env_step_pmc_issue.txt")).read()
+            if re.search(r"kernel sources sha1: (\w+)", it).group(1) == kernel_source_hash():
+                def gi(k):
+                    m = re.search(r"env_step_kernel[^\n]*?" + k + r"=([0-9.e+]+)", it)
+                    return float(m.group(1)) if m else None
+                wc = gi("SQ_WAVE_CYCLES")
+                out["split"] = {"active_any_frac": round(gi("SQ_ACTIVE_INST_ANY") / wc, 4), "active_valu_frac": round(gi("SQ_ACTIVE_INST_VALU") / wc, 4),
+                                "active_salu_frac": round(gi("SQ_ACTIVE_INST_SCA") / wc, 4), "active_lds_frac": round(gi("SQ_ACTIVE_INST_LDS") / wc, 4),
+                                "wait_any_frac": round(gi("SQ_WAIT_ANY") / wc, 4), "wait_inst_lds_frac": round(gi("SQ_WAIT_INST_LDS") / wc, 4),
+                                "idle_frac_not_waiting": round(1.0 - (gi("SQ_ACTIVE_INST_ANY") + gi("SQ_WAIT_ANY")) / wc, 4),
+                                "icache_hit_rate": round(gi("SQC_ICACHE_HITS") / gi("SQC_ICACHE_REQ"), 5), "icache_misses_per_launch": gi("SQC_ICACHE_MISSES") + gi("SQC_ICACHE_MISSES_DUPLICATE"),
+                                "valu_fp32_arith_share": round((gi("SQ_INSTS_VALU_ADD_F32") + gi("SQ_INSTS_VALU_MUL_F32") + gi("SQ_INSTS_VALU_FMA_F32") + gi("SQ_INSTS_VALU_TRANS_F32")) / gi("SQ_INSTS_VALU"), 4),
+                                "valu_int32_share": round(gi("SQ_INSTS_VALU_INT32") / gi("SQ_INSTS_VALU"), 4),
+                                "bound": "LDS latency with one wave per SIMD (s_waitcnt on ds_read results; LDS issue stalls and instruction fetch are each < 1 % / < 4 %)"}
+        except Exception:
+            pass
+        return out
     except Exception:
         return None
 

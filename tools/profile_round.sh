@@ -5,7 +5,7 @@
 #   3. FETCH_SIZE / WRITE_SIZE, two separate --pmc passes (guide: HBM)     -> profiles/<tag>_env_step_pmc_hbm.txt (+ hash of the kernel sources)
 # Everything is written under gpurun_out/prof_<tag>/ (merged back by gpurun); copy the .txt / .json files into profiles/ afterwards.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
@@ -21,7 +21,7 @@ mkdir -p $OUT/hbm; cp -r $OUT/fetch $OUT/hbm/; cp -r $OUT/write $OUT/hbm/
 HASH=$(cd $ROOT && python -c "import bench; print(bench.kernel_source_hash())")
 python $ROOT/tools/pmc_summary.py $OUT/hbm $OUT/${TAG}_env_step_pmc_hbm.txt "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, KB per dispatch) -- python tools/t_pmc.py; kernel sources sha1: $HASH" > /dev/null
 cd $ROOT
-cp $OUT/${TAG}_env_step_pmc_hbm.txt $ROOT/profiles/ 2>/dev/null || true      # bench.py reads roofline.traffic from profiles/<tag>_env_step_pmc_hbm.txt (same kernel-source hash): the lines below carry it
+cp $OUT/${TAG}_env_step_pmc_hbm.txt $OUT/${TAG}_env_step_pmc_sq.txt $ROOT/profiles/ 2>/dev/null || true      # bench.py reads roofline.traffic from profiles/<tag>_env_step_pmc_hbm.txt (same kernel-source hash): the lines below carry it
 python bench.py --steps 20 --warmup 2 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line.json
 python bench.py --steps 20 --warmup 2 --precision bf16 --no_cpu_baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line_bf16.json
 python bench.py --workload cassietraj_recurrent --steps 3 --warmup 1 --no_cpu_baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line_recurrent.json
@@ -38,6 +38,11 @@ python bench.py --workload cassie_td3 --steps 3 --warmup 1 2>/dev/null | tail -1
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/ktt -- python $ROOT/bench.py --workload cassie_td3 --steps 2 --warmup 1 > $OUT/td3_under_rocprof.log 2>&1 || true)
 python $ROOT/tools/rocprof_summary.py $(ls $OUT/ktt/*/*.db | head -1) $OUT/${TAG}_td3_kernel_stats.txt > /dev/null || true
 rm -rf $OUT/ktt
+#   4d. the RCCL path at world_size 1 (APX_FORCE_DIST=1 through torch.distributed.run): init_process_group("nccl"), gradient / moment / scalar all-reduces on device tensors  -> profiles/<tag>_bench_line_nccl_ws1.json
+APX_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29561 bench.py --gpus 1 --steps 5 --warmup 1 --no_cpu_baseline 2>$OUT/nccl_ws1.err | grep '^{' | tail -1 > $OUT/${TAG}_bench_line_nccl_ws1.json || true
+#   4e. issue-side counters of the env kernel + the I-cache probe (tools/profile_issue.sh)  -> profiles/<tag>_env_step_pmc_issue.txt, <tag>_icache_probe.txt
+bash tools/profile_issue.sh $TAG > $OUT/issue.log 2>&1 || true
+cp gpurun_out/prof_issue_$TAG/${TAG}_env_step_pmc_issue.txt gpurun_out/prof_issue_$TAG/${TAG}_icache_probe.txt $OUT/ 2>/dev/null || true
 #   5. -ffast-math A/B of the env kernel (needs lib/libapx_nofm.so: make -C apex_amd/csrc VARIANT=nofm FASTMATH=)  -> profiles/<tag>_fastmath_ab.json
 if [ -f apex_amd/lib/libapx_nofm.so ]; then python tools/t_fastmath_ab.py > $OUT/${TAG}_fastmath_ab.json 2>$OUT/fastmath_ab.err || true; fi
 rm -rf $OUT/kt $OUT/sq $OUT/fetch $OUT/write $OUT/hbm
