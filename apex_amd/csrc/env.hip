@@ -560,9 +560,15 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_prepare_kernel
     if (lead) { rst_int[(size_t)(2 * slot + 1) * n + env] = S.I(I_PHASE); rst_int[(size_t)(2 * slot) * n + env] = ep; }
 }
 
+#ifdef APX_WAVETIME      /* experiment build: shader-clock duration of every wave of the step kernel (the launch lasts as long as its slowest wave) */
+__device__ unsigned long long g_wavetime[4096];
+#endif
 template <bool HF>
 __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const float* action, float* obs,
                                                       float* reward, uint8_t* done, float* final_obs) {
+#ifdef APX_WAVETIME
+    const unsigned long long wt0__ = clock64();
+#endif
     ENV_SETUP
     load_state(S, st, ist, n);
     // nothing of the env-step bookkeeping stays in registers across the substeps (the constraint stage needs every one of the 512):
@@ -627,6 +633,9 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
         if (dn && final_obs) for (int k = 0; k < cfg.obs_dim; ++k) final_obs[(size_t)env * cfg.obs_dim + k] = obs[(size_t)env * cfg.obs_dim + k];
     }
     store_state(S, st, ist, n);
+#ifdef APX_WAVETIME
+    if (threadIdx.x == 0 && blk < 4096) g_wavetime[blk] = clock64() - wt0__;
+#endif
 }
 
 // action == NULL: raw substeps with the current pd targets (tests): n_sub x cassie_sim_step_pd.
@@ -1018,6 +1027,17 @@ extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, voi
         unsigned long long z[48] = {0};
         APX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c4::g_prof_acc), z, sizeof(z)));
         return 48;
+    }
+#endif
+#ifdef APX_WAVETIME
+    if (!strcmp(name, "wavetime")) {      // shader-clock cycles of each wave (= workgroup, 4 consecutive envs) of the most recent env_step_kernel launch, one value per env row
+        static unsigned long long h[4096];
+        APX_HIP(hipDeviceSynchronize());
+        APX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wavetime), sizeof(h)));
+        static float hf[4096 * 4];
+        for (int i = 0; i < e->n && i < 4096 * 4; ++i) hf[i] = (float)h[i / 4];
+        APX_HIP(hipMemcpy(out, hf, sizeof(float) * (size_t)(e->n < 16384 ? e->n : 16384), hipMemcpyHostToDevice));
+        return 1;
     }
 #endif
     if (!strcmp(name, "reset_miss")) {      // resets that found no prepared image (must stay 0); then cleared
