@@ -107,6 +107,9 @@ __device__ unsigned long long g_prof_last;
 #define PROF2(i) do {} while (0)
 #endif
 
+#ifdef APX_WAVETIME
+__device__ unsigned g_wavefeat[4096 * 4];      // experiment build (tools/t_wavetime.py): optional row groups each wave ran
+#endif
 // stage hand-off layout inside the per-env LDS region (floats, offsets from L4_WK)
 constexpr int WK_M = 0, WK_CDOF = WK_M + NM, WK_SMOOTH = WK_CDOF + 6 * NV, WK_QS = WK_SMOOTH + NV, WK_PTS = WK_QS + NV,
               WK_PEL = WK_PTS + 60, WK_LD = WK_PEL + 24, WK_DISQ = WK_LD + NM, WK_ZT = WK_DISQ + NV, WK_QACC = WK_ZT + NV,

@@ -24,6 +24,13 @@ __device__ __forceinline__ void wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CS
 template <int CTRL> __device__ __forceinline__ float dpp(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
 }
+// d = (a.y, a.y) * b + c as ONE v_pk_fma_f32: op_sel takes the high half of the pair `a` for both result lanes
+typedef float f2pk __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2pk pk_fma_hi(f2pk a, f2pk b, f2pk c) {
+    f2pk d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 // all-lanes sum over the 16-lane row (butterfly: every lane ends with the bit-identical total)
 __device__ __forceinline__ float red16(float t) {
     t += dpp<0xB1>(t);      // quad_perm [1,0,3,2]
@@ -1396,6 +1403,12 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     bool anyc[NCS], anyl[2];
     sfor<0, NCS>([&](auto Sl) { anyc[Sl] = __builtin_amdgcn_ballot_w64(con[Sl]) != 0ull; });
     sfor<0, 2>([&](auto Lg) { anyl[Lg] = __builtin_amdgcn_ballot_w64(nlim[Lg] != 0) != 0ull; });
+#ifdef APX_WAVETIME      /* experiment build: which optional row groups did this wave run (per launch: substeps with leg-leg rows, with a limit row, sum of active contact slots) */
+    if (threadIdx.x == 0) {
+        g_wavefeat[blockIdx.x * 4 + 0] += anyx ? 1u : 0u; g_wavefeat[blockIdx.x * 4 + 1] += (anyl[0] || anyl[1]) ? 1u : 0u;
+        g_wavefeat[blockIdx.x * 4 + 2] += (unsigned)anyc[0] + (unsigned)anyc[1] + (unsigned)anyc[2] + (unsigned)anyc[3];
+    }
+#endif
     // ---- warm start (mj_fwdConstraint): coefficient F_s of every basis vector, rho = G F, dual cost 1/2 F.rho + sum f (R f / 2 + b)
     float FA[13], FB[13];
     sfor<0, 7>([&](auto Sx) { FA[Sx] = ef[0][Sx]; FB[Sx] = ef[1][Sx]; });
@@ -1487,7 +1500,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     // df = max(X_k, -f_k) with wp = (alpha - 1) f_k + beta off the chain (alpha = 1 - iA R, beta = -iA b), f_k += df, and the LATER rows'
     // X_j move by -iA_j K[j][k] df with K[j][k] = d_j' G3 d_k (d_k = n + s_k mu t_a(k)); rho' of every lane moves by GpRow[k] df.
     float cam1[NCS][4], cbeta[NCS][4], K10[NCS], K32[NCS];
-    f2 K23a[NCS], K23b[NCS], GpRow[NCS][4];
+    f2 K23a[NCS], nK23b[NCS], GpRow[NCS][4];
     sfor<0, NCS>([&](auto Sl) {
         constexpr int s = Sl, leg = s / MAXC, ln = 7 + 3 * (s % MAXC);
         sfor<0, 4>([&](auto K) {
@@ -1499,7 +1512,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
         // X_j = wp_j - iA_j u_j of a later row moves by -iA_j K[j][k] df_k, so a row's place on the dependency chain is one fma + one max
         K10[s] = ciA[s][1] * (kn[s][0] - mu * k1[s][0]);
         K23a[s] = f2{ciA[s][2] * (kn[s][0] + mu * k2[s][0]), ciA[s][3] * (kn[s][0] - mu * k2[s][0])};
-        K23b[s] = f2{ciA[s][2] * (kn[s][1] + mu * k2[s][1]), ciA[s][3] * (kn[s][1] - mu * k2[s][1])};
+        nK23b[s] = f2{-ciA[s][2] * (kn[s][1] + mu * k2[s][1]), -ciA[s][3] * (kn[s][1] - mu * k2[s][1])};      // (negated: the update is one fma)
         K32[s] = ciA[s][3] * (kn[s][2] - mu * k2[s][2]);
     });
     f2 ciAp[NCS][2];
@@ -1533,22 +1546,24 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
                                 r2 = leg ? dpp<0x150 + ln + 2>(r.y) : dpp<0x150 + ln + 2>(r.x);
                     f2 U01 = f2{rn, rn} + cpm * r1, U23 = f2{rn, rn} + cpm * r2;
                     f2 wa = cam1p[s][0] * cfp[s][0] + cbetap[s][0], wb = cam1p[s][1] * cfp[s][1] + cbetap[s][1];      // packed, off the chain
-                    asm volatile("" : "+v"(wa.x), "+v"(wa.y), "+v"(wb.x), "+v"(wb.y));      // fast-math would re-associate them into the chain
-                    f2 X01 = wa - ciAp[s][0] * U01, X23 = wb - ciAp[s][1] * U23;        // scaled residuals of the four rows before any of them moved
 #define APX_PIN2(v) asm volatile("" : "+v"(v))      /* fix the association: fast-math would gather the corrections into one late sum */
+                    APX_PIN2(wa); APX_PIN2(wb);      // fast-math would re-associate them into the chain (pinned as PAIRS: pinning the halves one by one costs a v_mov pair + s_nop per slot and sweep)
+                    f2 X01 = wa - ciAp[s][0] * U01, X23 = wb - ciAp[s][1] * U23;        // scaled residuals of the four rows before any of them moved
                     APX_PIN2(X01); APX_PIN2(X23);
                     f2 da, db;
                     da.x = fmaxf(X01.x, -cfp[s][0].x);
                     X01.y -= K10[s] * da.x; X23 -= K23a[s] * da.x;
                     APX_PIN2(X23);
                     da.y = fmaxf(X01.y, -cfp[s][0].y);
-                    X23 -= K23b[s] * da.y;
+                    X23 = pk_fma_hi(da, nK23b[s], X23);                                  // X23 -= K23b da.y
                     APX_PIN2(X23);
                     db.x = fmaxf(X23.x, -cfp[s][1].x);
                     X23.y -= K32[s] * db.x;
                     db.y = fmaxf(X23.y, -cfp[s][1].y);
                     cfp[s][0] += da; cfp[s][1] += db;
-                    r += GpRow[s][0] * da.x + GpRow[s][1] * da.y + GpRow[s][2] * db.x + GpRow[s][3] * db.y;
+                    // the multipliers da.y / db.y are the HIGH halves of the (da.x, da.y) / (db.x, db.y) pairs: taken in place by op_sel (pk_fma_hi) instead of a v_mov into the low
+                    // half of a fresh pair (3 moves per slot and sweep, 50 sweeps per substep)
+                    r = pk_fma_hi(db, GpRow[s][3], GpRow[s][2] * db.x + pk_fma_hi(da, GpRow[s][1], GpRow[s][0] * da.x + r));
                 }
             });
         });

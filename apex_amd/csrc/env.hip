@@ -634,7 +634,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
     }
     store_state(S, st, ist, n);
 #ifdef APX_WAVETIME
-    if (threadIdx.x == 0 && blk < 4096) g_wavetime[blk] = clock64() - wt0__;
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_wavetime[blockIdx.x] = clock64() - wt0__;
 #endif
 }
 
@@ -1034,10 +1034,15 @@ extern "C" int apx_env_get_field(apx_env_t* e, const char* name, float* out, voi
         static unsigned long long h[4096];
         APX_HIP(hipDeviceSynchronize());
         APX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wavetime), sizeof(h)));
-        static float hf[4096 * 4];
-        for (int i = 0; i < e->n && i < 4096 * 4; ++i) hf[i] = (float)h[i / 4];
-        APX_HIP(hipMemcpy(out, hf, sizeof(float) * (size_t)(e->n < 16384 ? e->n : 16384), hipMemcpyHostToDevice));
-        return 1;
+        static unsigned f[4096 * 4];
+        APX_HIP(hipMemcpyFromSymbol(f, HIP_SYMBOL(c4::g_wavefeat), sizeof(f)));
+        static float hf[4096 * 4 * 4];
+        const int nw = e->n / 4 < 4096 ? e->n / 4 : 4096;      // out rows = waves: [cycles, substeps with leg-leg rows, with a limit row, sum of active contact slots]
+        for (int i = 0; i < nw; ++i) { hf[4 * i] = (float)h[i]; hf[4 * i + 1] = (float)f[4 * i]; hf[4 * i + 2] = (float)f[4 * i + 1]; hf[4 * i + 3] = (float)f[4 * i + 2]; }
+        APX_HIP(hipMemcpy(out, hf, sizeof(float) * (size_t)nw * 4, hipMemcpyHostToDevice));
+        static unsigned z[4096 * 4];
+        APX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c4::g_wavefeat), z, sizeof(z)));
+        return 4;
     }
 #endif
     if (!strcmp(name, "reset_miss")) {      // resets that found no prepared image (must stay 0); then cleared
