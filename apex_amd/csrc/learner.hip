@@ -434,37 +434,46 @@ struct FusedLds { float (*A1s)[FBM + 1]; float (*A2s)[FBM + 1]; float (*Ws)[FBN 
 template <int NKT>
 __device__ __forceinline__ void fused_layer(const FusedLds& L, float (*In)[FBM + 1], int K, const float* __restrict__ W, const float* __restrict__ bias,
                                             int N, bool relu, float (*OutS)[FBM + 1], float* __restrict__ outG, int ldo, long m0, long B) {
-    const int tid = threadIdx.x, lane = tid & 63, wn = (tid >> 6) * 32;
+    // Round 4: the weight operand no longer goes through LDS.  A lane of v_mfma_f32_32x32x2_f32 holds B[k][n] for n = lane & 31 and ONE k per instruction; with the k of a
+    // 16-deep tile dealt as k = 8 (lane >> 5) + j over the 8 instructions j of the tile (instead of 2 j + (lane >> 5)), a lane's eight operands are 32 contiguous bytes of
+    // its weight row W[n][.]: four dwordx2 loads straight from L2 into the registers the MFMAs read, FPF tiles ahead.  No weight tile in LDS, no barrier inside a layer
+    // (the old form: write tile, barrier, 8 MFMAs, barrier - 0.68 us per tile step against 0.24 us of MFMA work).  Rows k >= K of `In` are zero, so what a lane reads
+    // past the end of its weight row (the next row / the next parameter block: finite numbers) is multiplied by zero.
+    const int tid = threadIdx.x, lane = tid & 63, wn = (tid >> 6) * 32, h = lane >> 5;
+    typedef float f2w __attribute__((ext_vector_type(2)));
     for (int nb = 0; nb * FBN < N; ++nb) {
         floatx16 acc = {0};
-        float rw[FPF][8];
-        auto fetch = [&](int kt, float (&r)[8]) {
+        const int col = nb * FBN + wn + (lane & 31);
+        const bool wave_on = nb * FBN + wn < N;      // a wave whose 32-column slice lies beyond N (output layer) leaves the MFMA pipe to the co-resident workgroup
+        const float* wrow = W + (long)(col < N ? col : N - 1) * K + 8 * h;
+        f2w rw[FPF][4];
+        const bool k_even = (K & 1) == 0;      // an odd row length (D = 25 / 55: min / phase profiles) leaves the rows 4-byte aligned only: scalar loads there
+        auto fetch = [&](int kt, f2w (&r)[4]) {
+            if (k_even) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int kk = tid & 15, n = (tid >> 4) + 16 * i;      // k contiguous in memory: coalesced 64-B runs
-                const int gn = nb * FBN + n, gk = kt * GBK + kk;
-                r[i] = (gn < N && gk < K) ? W[(long)gn * K + gk] : 0.f;
+                for (int q = 0; q < 4; ++q) r[q] = *reinterpret_cast<const f2w*>(wrow + kt * GBK + 2 * q);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r[q] = f2w{wrow[kt * GBK + 2 * q], wrow[kt * GBK + 2 * q + 1]};
             }
         };
+        if (wave_on) {
 #pragma unroll
-        for (int p = 0; p < FPF; ++p) if (p < NKT) fetch(p, rw[p]);
+            for (int p = 0; p < FPF; ++p) if (p < NKT) fetch(p, rw[p]);
 #pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
+            for (int kt = 0; kt < NKT; ++kt) {
+                f2w cur[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) L.Ws[tid & 15][(tid >> 4) + 16 * i] = rw[kt % FPF][i];
-            __syncthreads();
-            if (kt + FPF < NKT) fetch(kt + FPF, rw[kt % FPF]);
-            if (nb * FBN + wn < N) {                 // a wave whose 32-column slice lies beyond N (output layer) leaves the MFMA pipe to the co-resident workgroup
+                for (int q = 0; q < 4; ++q) cur[q] = rw[kt % FPF][q];
+                if (kt + FPF < NKT) fetch(kt + FPF, rw[kt % FPF]);
 #pragma unroll
-                for (int kk = 0; kk < GBK; kk += 2) {
-                    const float av = In[kt * GBK + kk + (lane >> 5)][lane & 31];
-                    const float bv = L.Ws[kk + (lane >> 5)][wn + (lane & 31)];
+                for (int j = 0; j < 8; ++j) {
+                    const float av = In[kt * GBK + 8 * h + j][lane & 31];
+                    const float bv = (j & 1) ? cur[j >> 1].y : cur[j >> 1].x;
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
                 }
             }
-            __syncthreads();
         }
-        const int col = nb * FBN + wn + (lane & 31);
         const float bs = col < N ? bias[col] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -521,7 +530,7 @@ static bool fused_ok(int D, int H, int O) {
 }
 static int mlp_fused_launch(const float* params, int D, int H, int O, const FusedIn& in, long B, float* a1, float* a2, float* y, hipStream_t s) {
     MlpView p(params, D, H, O);
-    const size_t lds = sizeof(float) * (2 * FH * (FBM + 1) + GBK * (FBN + 1));
+    const size_t lds = sizeof(float) * (2 * FH * (FBM + 1));      // activations only: the weights go from L2 straight into the MFMA operand registers
     if (!g_fused_attr_set) {
         APX_HIP(hipFuncSetAttribute((const void*)mlp_fused_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         g_fused_attr_set = true;
