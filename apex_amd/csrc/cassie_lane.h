@@ -675,17 +675,20 @@ __device__ __forceinline__ void factor_lane(const St& S, const LaneIdx& X, float
     float R[2][13], P[2][6], dg[2];
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd, blk = WK_M + M_LEG0 + M_LEGSZ * sd;
+        // the lane's own h * damping, loaded ONCE and unconditionally: `l == J ? hdamp * S(F_DAMP + .. + J) : 0` inside the loop put each of the 13 loads into its own
+        // exec-mask region with a full LDS wait (26 serialised round trips in the second factorisation, 2.7 k cycles per substep)
+        const float hd = hdamp * S(F_DAMP + 6 + 13 * sd + (l < 13 ? l : 12));
         sfor<0, 13>([&](auto J) {
             const bool ok = X.mi[J] != 0xFFFF;
             float v = S.W(blk + (ok ? X.mi[J] : 0));            // unconditional load from a clamped address + select: no exec-mask region
             v = ok ? v : 0.f;
-            v += l == J ? hdamp * S(F_DAMP + 6 + 13 * sd + J) : 0.f;
+            v += l == J ? hd : 0.f;
             R[sd][J] = v;
         });
         sfor<0, 6>([&](auto Pp) { const float v = S.W(blk + X.own + X.dep - 1 - Pp); P[sd][Pp] = l < 13 ? v : 0.f; });
         // the lane's own diagonal entry is carried separately (dg -= (R_l[k] / D_k) R_l[k] at every step): reading R[sd][l] back at the end
         // is a 13-way select on the lane index, which the compiler turns into a tree of divergent branches
-        dg[sd] = S.W(blk + X.own) + hdamp * S(F_DAMP + 6 + 13 * sd + (l < 13 ? l : 12));
+        dg[sd] = S.W(blk + X.own) + hd;
     });
     // ---- legs: eliminate dof 12 .. 0 of both legs at once
     srfor<0, 13>([&](auto K) {
@@ -831,21 +834,36 @@ __device__ __forceinline__ void stage_finish_lane(const St& S, const float* rows
     sfor<0, 2>([&](auto Sd) { qacc.a[Sd] += qs.a[Sd]; });
     sfor<0, 6>([&](auto Pp) { qacc.p[Pp] += qs.p[Pp]; });
     if (l == 0) {
-        // sensor snapshot of the PRE-integration state (sensordata is one mj_step1 old when step_ethercat reads it)
-        sfor<0, 10>([&](auto U) { S(F_SNAP + SN_MPOS + U) = S(F_QPOS + ct_act_qposadr[U]); });
-        sfor<0, 6>([&](auto K) { S(F_SNAP + SN_JPOS + K) = S(F_QPOS + ct_jsens_qposadr[K]); });
-        sfor<0, 4>([&](auto K) { S(F_SNAP + SN_QUAT + K) = S(F_QPOS + 3 + K); });
-        sfor<0, 3>([&](auto K) { S(F_SNAP + SN_GYRO + K) = S(F_QVEL + 3 + K); });
-        {   // world z of the contact force on the foot bodies (cassie_sim_foot_forces -> get_foot_forces()[2], [8])
-            const int nc[2] = {(int)S.W(WK_MISC + 0), (int)S.W(WK_MISC + 1)};
+        // sensor snapshot of the PRE-integration state (sensordata is one mj_step1 old when step_ethercat reads it).  Every load before the first store: the compiler orders
+        // an LDS load behind any earlier LDS store it cannot prove disjoint, and the copy-by-copy form was a chain of load -> wait -> store round trips on lane 0
+        {
+            float mp[10], jp[6], qq[4], gy[3];
+            sfor<0, 10>([&](auto U) { mp[U] = S(F_QPOS + ct_act_qposadr[U]); });
+            sfor<0, 6>([&](auto K) { jp[K] = S(F_QPOS + ct_jsens_qposadr[K]); });
+            sfor<0, 4>([&](auto K) { qq[K] = S(F_QPOS + 3 + K); });
+            sfor<0, 3>([&](auto K) { gy[K] = S(F_QVEL + 3 + K); });
+            // world z of the contact force on the foot bodies (cassie_sim_foot_forces -> get_foot_forces()[2], [8]); branch-free: every slot record is read, the
+            // slots that do not count (beyond the leg's contact count, or not a foot capsule) get weight 0
+            const float nc0 = S.W(WK_MISC + 0), nc1 = S.W(WK_MISC + 1);
             const float mu = S(F_FRIC);
+            float crv[2 * MAXC][8];
+            sfor<0, 2 * MAXC>([&](auto Sl) {
+                const float* cr = rows + R4_CON + R4_CONSZ * Sl;
+                crv[Sl][0] = cr[7]; crv[Sl][1] = cr[8]; crv[Sl][2] = cr[9]; crv[Sl][3] = cr[10];
+                crv[Sl][4] = cr[12]; crv[Sl][5] = cr[13]; crv[Sl][6] = cr[14]; crv[Sl][7] = cr[15];
+            });
             float fz[2] = {0.f, 0.f};
             sfor<0, 2 * MAXC>([&](auto Sl) {
                 constexpr int sl = Sl, lg = sl / MAXC;
-                const float* cr = rows + R4_CON + R4_CONSZ * sl;
-                if ((sl % MAXC) < nc[lg] && cr[7] != 0.f)      // cr[8..10] = world z of the slot's contact frame (n, t1, t2)
-                    fz[lg] += cr[8] * (cr[12] + cr[13] + cr[14] + cr[15]) + mu * (cr[9] * (cr[12] - cr[13]) + cr[10] * (cr[14] - cr[15]));
+                const float* c = crv[sl];      // c[1..3] = world z of the slot's contact frame (n, t1, t2), c[4..7] = the four pyramid forces
+                const bool on = (float)(sl % MAXC) < (lg ? nc1 : nc0) && c[0] != 0.f;
+                const float v = c[1] * (c[4] + c[5] + c[6] + c[7]) + mu * (c[2] * (c[4] - c[5]) + c[3] * (c[6] - c[7]));
+                fz[lg] += on ? v : 0.f;
             });
+            sfor<0, 10>([&](auto U) { S(F_SNAP + SN_MPOS + U) = mp[U]; });
+            sfor<0, 6>([&](auto K) { S(F_SNAP + SN_JPOS + K) = jp[K]; });
+            sfor<0, 4>([&](auto K) { S(F_SNAP + SN_QUAT + K) = qq[K]; });
+            sfor<0, 3>([&](auto K) { S(F_SNAP + SN_GYRO + K) = gy[K]; });
             S(F_FWD + 0) = fz[0]; S(F_FWD + 1) = fz[1];
         }
         {   // accelerometer at the imu site (cassie.xml:267): classical acceleration of the site point, site frame
@@ -1597,13 +1615,23 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     });
     if (l >= 13) ownA = ownB = 0.f;
     sfor<0, MAXX>([&](auto K) { if (l == 13 + K && xact[K]) ownA = ownB = xf[K]; });
-    sfor<0, 19>([&](auto C) {
-        constexpr int c = C;
-        const float ja = rows[(2 * c + 0) * 16 + l], jb = rows[(2 * c + 1) * 16 + l];
-        // (red16 leaves the bit-identical total on every lane: all 16 lanes store it to the same word, no exec-mask region per column)
-        if constexpr (c < 6) { const float z = red16(ja * ownA + jb * ownB); S.W(WK_ZT + c) = z; }
-        else { const float za = red16(ja * ownA), zb = red16(jb * ownB); S.W(WK_ZT + c) = za; S.W(WK_ZT + c + 13) = zb; }
-    });
+    {   // All 38 parked values are loaded BEFORE the first store (the compiler cannot prove that a store to the hand-off words does not alias the row store, and orders
+        // every later load behind it: the column-by-column form compiled to load -> full LDS wait -> four dependent DPP adds with hazard nops -> store, 19 times = 4 k
+        // cycles), and the 32 butterflies advance stage by stage so that independent chains fill each other's DPP hazard slots.
+        float t[32];
+        sfor<0, 19>([&](auto C) {
+            constexpr int c = C;
+            const float ja = rows[(2 * c + 0) * 16 + l], jb = rows[(2 * c + 1) * 16 + l];
+            if constexpr (c < 6) t[c] = ja * ownA + jb * ownB;
+            else { t[c] = ja * ownA; t[c + 13] = jb * ownB; }
+        });
+        sfor<0, 32>([&](auto I) { t[I] += dpp<0xB1>(t[I]); });       // quad_perm [1,0,3,2]
+        sfor<0, 32>([&](auto I) { t[I] += dpp<0x4E>(t[I]); });       // quad_perm [2,3,0,1]
+        sfor<0, 32>([&](auto I) { t[I] += dpp<0x141>(t[I]); });      // row_half_mirror
+        sfor<0, 32>([&](auto I) { t[I] += dpp<0x140>(t[I]); });      // row_mirror
+        // (the butterfly leaves the bit-identical total on every lane: all 16 lanes store it to the same word, no exec-mask region per column)
+        sfor<0, 32>([&](auto I) { S.W(WK_ZT + I) = t[I]; });
+    }
     if (l == 0) {
         // contact forces to the row store (foot-force readout in the finish stage)
         sfor<0, NCS>([&](auto Sl) {
