@@ -898,41 +898,51 @@ __device__ __forceinline__ void stage_finish_lane(const St& S, const float* rows
     sfor<0, 6>([&](auto Pp) { rhs.p[Pp] *= F.invDp[Pp]; });
     solve_L_lane(F, rhs);
     PROF2(32);
-    // ---- integrate: qvel += h a; hinges / slides qpos += h qvel; ball joints rotate by h w
-    float qv[2], qvp[6];
+    // ---- integrate: qvel += h a; hinges / slides qpos += h qvel; ball joints rotate by h w.
+    // Three phases - every load, the arithmetic, every store: written as read-modify-write per item (`S(F_QPOS + qa) += ..`, rotate() reading and writing its
+    // quaternion) the compiler had to keep each load behind the previous store (it cannot prove two LDS words disjoint): a chain of ~ 20 LDS round trips.
+    static_assert(ct_jnt_qposadr[7] == 10 && ct_jnt_qposadr[8] == 14 && ct_jnt_qposadr[14] == 20 && ct_jnt_qposadr[18] == 24, "qpos layout");
+    const int hoff = lc < 3 ? lc : lc + 1;      // leg-local hinge dof k -> qpos offset inside the leg block: k 0,1,2 -> 0,1,2; k >= 6 -> k + 1 (the ball's quaternion takes 4)
+    float qv[2], qvp[6], hq[2], ppos[3];
+    Q4 bq[2], pq;
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
-        qv[sd] = S(F_QVEL + 6 + 13 * sd + lc) + DT * rhs.a[sd];
-        if (l < 13) { S(F_QVEL + 6 + 13 * sd + l) = qv[sd]; S(F_QACCW + 6 + 13 * sd + l) = qacc.a[sd]; }
+        qv[sd] = S(F_QVEL + 6 + 13 * sd + lc);
+        hq[sd] = S(F_QPOS + 7 + 14 * sd + hoff);
+        bq[sd] = {S(F_QPOS + 10 + 14 * sd), S(F_QPOS + 11 + 14 * sd), S(F_QPOS + 12 + 14 * sd), S(F_QPOS + 13 + 14 * sd)};
     });
-    sfor<0, 6>([&](auto Pp) { qvp[Pp] = S(F_QVEL + Pp) + DT * rhs.p[Pp]; });
-    auto rotate = [&](int qa, V3 wv) {
+    sfor<0, 6>([&](auto Pp) { qvp[Pp] = S(F_QVEL + Pp); });
+    sfor<0, 3>([&](auto K) { ppos[K] = S(F_QPOS + K); });
+    pq = {S(F_QPOS + 3), S(F_QPOS + 4), S(F_QPOS + 5), S(F_QPOS + 6)};
+    auto rotate = [&](Q4 q, V3 wv) {
         const float nw = sqrtf(dot(wv, wv));
-        Q4 q = {S(F_QPOS + qa), S(F_QPOS + qa + 1), S(F_QPOS + qa + 2), S(F_QPOS + qa + 3)};
-        if (nw > 0.f) {
-            float sn, cs;
-            __sincosf(0.5f * nw * DT, &sn, &cs);
-            const float sc = sn * rcpf(nw);
-            q = qmul(q, Q4{cs, wv.x * sc, wv.y * sc, wv.z * sc});
-        }
-        q = qnormalize(q);
-        S(F_QPOS + qa) = q.w; S(F_QPOS + qa + 1) = q.x; S(F_QPOS + qa + 2) = q.y; S(F_QPOS + qa + 3) = q.z;
+        float sn, cs;
+        __sincosf(0.5f * nw * DT, &sn, &cs);
+        const float sc = sn * rcpf(fmaxf(nw, 1e-30f));
+        const Q4 qr = qmul(q, Q4{cs, wv.x * sc, wv.y * sc, wv.z * sc});
+        const bool mv = nw > 0.f;
+        return qnormalize(Q4{mv ? qr.w : q.w, mv ? qr.x : q.x, mv ? qr.y : q.y, mv ? qr.z : q.z});
     };
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
+        qv[sd] += DT * rhs.a[sd];
         const float w1 = dpp<0x150 + 4>(qv[sd]), w2 = dpp<0x150 + 5>(qv[sd]);      // achilles ball joint: dofs k = 3, 4, 5 on lanes 3..5
-        if (l == 3) rotate(ct_jnt_qposadr[7] + 14 * sd, V3{qv[sd], w1, w2});
-        else if (l < 13 && l != 4 && l != 5) {
-            // leg-local hinge dof k -> qpos offset inside the leg block: k 0,1,2 -> 0,1,2; k >= 6 -> k + 1 (the ball's quaternion takes 4)
-            const int qa = 7 + 14 * sd + (l < 3 ? l : l + 1);
-            S(F_QPOS + qa) += DT * qv[sd];
-        }
+        bq[sd] = rotate(bq[sd], V3{qv[sd], w1, w2});                                 // (meaningful on lane 3 only)
+        hq[sd] += DT * qv[sd];
     });
-    static_assert(ct_jnt_qposadr[7] == 10 && ct_jnt_qposadr[8] == 14 && ct_jnt_qposadr[14] == 20 && ct_jnt_qposadr[18] == 24, "qpos layout");
+    sfor<0, 6>([&](auto Pp) { qvp[Pp] += DT * rhs.p[Pp]; });
+    sfor<0, 3>([&](auto K) { ppos[K] += DT * qvp[K]; });
+    pq = rotate(pq, V3{qvp[3], qvp[4], qvp[5]});
+    sfor<0, 2>([&](auto Sd) {
+        constexpr int sd = Sd;
+        if (l < 13) { S(F_QVEL + 6 + 13 * sd + l) = qv[sd]; S(F_QACCW + 6 + 13 * sd + l) = qacc.a[sd]; }
+        if (l == 3) { S(F_QPOS + 10 + 14 * sd) = bq[sd].w; S(F_QPOS + 11 + 14 * sd) = bq[sd].x; S(F_QPOS + 12 + 14 * sd) = bq[sd].y; S(F_QPOS + 13 + 14 * sd) = bq[sd].z; }
+        else if (l < 13 && l != 4 && l != 5) S(F_QPOS + 7 + 14 * sd + hoff) = hq[sd];
+    });
     if (l == 0) {
         sfor<0, 6>([&](auto Pp) { S(F_QVEL + Pp) = qvp[Pp]; S(F_QACCW + Pp) = qacc.p[Pp]; });
-        sfor<0, 3>([&](auto K) { S(F_QPOS + K) += DT * qvp[K]; });
-        rotate(3, V3{qvp[3], qvp[4], qvp[5]});
+        sfor<0, 3>([&](auto K) { S(F_QPOS + K) = ppos[K]; });
+        S(F_QPOS + 3) = pq.w; S(F_QPOS + 4) = pq.x; S(F_QPOS + 5) = pq.y; S(F_QPOS + 6) = pq.z;
     }
 }
 
@@ -1059,13 +1069,23 @@ __device__ __forceinline__ int legleg_pairs_lane(const St& S, float* rec, int& x
     XPair x; x.gi = 0; x.gj = 0; x.n = {0.f, 0.f, 0.f}; x.cp = {0.f, 0.f, 0.f}; x.dist = 0.f;
     int nx = 0;
     const int k = l - 13;
-    sfor<0, 9>([&](auto P) {
-        constexpr int p = P;
-        const float* q = rec + 8 * p;
-        const bool h = q[0] != 0.f;
-        if (h && nx == k) { x.gi = p / 3; x.gj = p % 3; x.dist = q[1]; x.n = {q[2], q[3], q[4]}; x.cp = {q[5], q[6], q[7]}; }
-        nx += h ? 1 : 0; xmask |= h ? (1 << p) : 0;
-    });
+    {   // the nine hit flags first, then ONE record read at the selected index (a load inside `if (h && nx == k)` per pair was nine serialised LDS round trips)
+        float hit[9];
+        sfor<0, 9>([&](auto P) { hit[P] = rec[8 * P]; });
+        int sel = -1;
+        sfor<0, 9>([&](auto P) {
+            constexpr int p = P;
+            const bool h = hit[p] != 0.f;
+            sel = (h && nx == k) ? p : sel;
+            nx += h ? 1 : 0; xmask |= h ? (1 << p) : 0;
+        });
+        const float* q = rec + 8 * (sel >= 0 ? sel : 0);
+        const float q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];
+        const bool on = sel >= 0;
+        const int sp = on ? sel : 0;
+        x.gi = sp / 3; x.gj = sp - 3 * (sp / 3);
+        x.dist = on ? q1 : 0.f; x.n = {on ? q2 : 0.f, on ? q3 : 0.f, on ? q4 : 0.f}; x.cp = {on ? q5 : 0.f, on ? q6 : 0.f, on ? q7 : 0.f};
+    }
     if (k >= 0 && k < MAXX) {
         float* q = rec + XSEL + XSEL_SZ * k;
         q[1] = x.dist; q[2] = x.n.x; q[3] = x.n.y; q[4] = x.n.z; q[5] = x.cp.x; q[6] = x.cp.y; q[7] = x.cp.z; q[8] = (float)x.gi; q[9] = (float)x.gj;

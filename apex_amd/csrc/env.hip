@@ -584,15 +584,22 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
     for (int i = 0; i < cfg.simrate; ++i) {
         sim_step_pd<HF>(S, cfg, 1);                                        // all lanes (barriers inside)
         if (!lead) continue;
-        for (int k = 0; k < 6; ++k) {                                            // cassie.py:328-331
-            const float fp = S(F_FWD + 10 + k);
-            S(F_FOOTVEL + k) = (fp - S(F_FOOTPREV + k)) / 0.0005f;
-            S(F_FOOTPREV + k) = fp;
+        {   // every load before the first store (a load behind a store to a word the compiler cannot prove different waits for it: these were ten LDS round trips)
+            float fw[16], pv[6], ac[4];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) fw[k] = S(F_FWD + k);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) pv[k] = S(F_FOOTPREV + k);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ac[k] = S.W(ACC + k);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { S(F_FOOTVEL + k) = (fw[10 + k] - pv[k]) / 0.0005f; S(F_FOOTPREV + k) = fw[10 + k]; }      // cassie.py:328-331
+            float il = 0.f, ir = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { il += kNeutralFoot[k] * fw[2 + k]; ir += kNeutralFoot[k] * fw[6 + k]; }
+            S.W(ACC + 0) = ac[0] + fw[0]; S.W(ACC + 1) = ac[1] + fw[1];                                                              // cassie.py:418-420
+            S.W(ACC + 2) = ac[2] + 1.f - il * il; S.W(ACC + 3) = ac[3] + 1.f - ir * ir;                                              // cassie.py:426-427
         }
-        S.W(ACC + 0) += S(F_FWD + 0); S.W(ACC + 1) += S(F_FWD + 1);               // cassie.py:418-420
-        float il = 0.f, ir = 0.f;
-        for (int k = 0; k < 4; ++k) { il += kNeutralFoot[k] * S(F_FWD + 2 + k); ir += kNeutralFoot[k] * S(F_FWD + 6 + k); }
-        S.W(ACC + 2) += 1.f - il * il; S.W(ACC + 3) += 1.f - ir * ir;             // cassie.py:426-427
     }
     if (lead) {
         float act[10];
