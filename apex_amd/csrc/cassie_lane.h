@@ -1213,17 +1213,37 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out, int nxp, bo
     }
     const V3 q1 = cross(p1 - o, dir), q2 = cross(p2 - o, dir);       // dir . (a x r) = a . (r x dir)
     float (&J)[19] = out.J;
-    sfor<0, 19>([&](auto C) {
-        constexpr int c = C, d = c2d<LEG>(c);
-        const V3 ca = {S.W(WK_CDOF + 6 * d), S.W(WK_CDOF + 6 * d + 1), S.W(WK_CDOF + 6 * d + 2)};
-        const V3 cl = {S.W(WK_CDOF + 6 * d + 3), S.W(WK_CDOF + 6 * d + 4), S.W(WK_CDOF + 6 * d + 5)};
-        const float dl = dot(dir, cl);
-        const float g1 = dl + dot(q1, ca), g2 = dl + dot(q2, ca);
-        float v = ((m1 >> c) & 1u) ? g1 : 0.f;
-        v -= ((m2 >> c) & 1u) ? g2 : 0.f;
-        if (isLim && nlim && c == clim) v = lsign;
-        J[c] = v;
-    });
+    {   // The 19 motion axes (6 words each) are fetched a chunk of JCH columns AHEAD of the arithmetic that uses them, with scheduling barriers that keep the compiler from
+        // sinking the loads back to their uses: left alone it issued the three ds_read2 of a column, waited the full LDS latency, did the column's dozen instructions, and
+        // only then issued the next column's loads (19 exposed round trips per leg).
+        constexpr int JCH = 4, NCH = (19 + JCH - 1) / JCH;
+        float buf[2][JCH][6];
+        auto fetch = [&](auto Ch, auto Bf) {
+            sfor<0, JCH>([&](auto K) {
+                constexpr int c = Ch * JCH + K;
+                if constexpr (c < 19) sfor<0, 6>([&](auto I) { buf[Bf][K][I] = S.W(WK_CDOF + 6 * c2d<LEG>(c) + I); });
+            });
+        };
+        fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        sfor<0, NCH>([&](auto Ch) {
+            constexpr int ch = Ch, bf = ch & 1;
+            if constexpr (ch + 1 < NCH) fetch(std::integral_constant<int, ch + 1>{}, std::integral_constant<int, (ch + 1) & 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            sfor<0, JCH>([&](auto K) {
+                constexpr int c = ch * JCH + K;
+                if constexpr (c < 19) {
+                    const V3 ca = {buf[bf][K][0], buf[bf][K][1], buf[bf][K][2]}, cl = {buf[bf][K][3], buf[bf][K][4], buf[bf][K][5]};
+                    const float dl = dot(dir, cl);
+                    const float g1 = dl + dot(q1, ca), g2 = dl + dot(q2, ca);
+                    float v = ((m1 >> c) & 1u) ? g1 : 0.f;
+                    v -= ((m2 >> c) & 1u) ? g2 : 0.f;
+                    if (isLim && nlim && c == clim) v = lsign;
+                    J[c] = v;
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
     PROF2(25);
     float vel = 0.f, ju = 0.f, jw = 0.f;
     sfor<0, 19>([&](auto C) {
