@@ -280,15 +280,22 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
     // (the pointer-jumping form of round 2 cost three store / fence / load rounds per sum).
     static_assert(TB_NDESC == nib(11, 10, 9, 0, 7, 0, 5, 4, 0, 1, 0, 0), "take-away lanes of the chain sum");
     const float cm1 = (lb == 4 || lb == 6 || lb == 9 || lb == 11) ? 1.f : 0.f, cm2 = lb == 11 ? 1.f : 0.f;
-    auto chain_scan = [&](float own) {
-        float d = own - cm1 * dpp<0x111>(own) - cm2 * dpp<0x112>(own);
-        d += dpp<0x111>(d); d += dpp<0x112>(d); d += dpp<0x114>(d); d += dpp<0x118>(d);
-        return d;
-    };
+    // (the twelve scans of a chain sum advance STAGE BY STAGE: one scan after the other is a chain of dependent DPP adds with a hazard nop between each pair)
     auto chain_sum = [&](SV (&val)[2]) {
+        float d[12];
         sfor<0, 2>([&](auto Sd) {
-            val[Sd].a.x = chain_scan(val[Sd].a.x); val[Sd].a.y = chain_scan(val[Sd].a.y); val[Sd].a.z = chain_scan(val[Sd].a.z);
-            val[Sd].l.x = chain_scan(val[Sd].l.x); val[Sd].l.y = chain_scan(val[Sd].l.y); val[Sd].l.z = chain_scan(val[Sd].l.z);
+            d[6 * Sd] = val[Sd].a.x; d[6 * Sd + 1] = val[Sd].a.y; d[6 * Sd + 2] = val[Sd].a.z; d[6 * Sd + 3] = val[Sd].l.x; d[6 * Sd + 4] = val[Sd].l.y; d[6 * Sd + 5] = val[Sd].l.z;
+        });
+        float s1[12], s2[12];
+        sfor<0, 12>([&](auto I) { s1[I] = dpp<0x111>(d[I]); });
+        sfor<0, 12>([&](auto I) { s2[I] = dpp<0x112>(d[I]); });
+        sfor<0, 12>([&](auto I) { d[I] = d[I] - cm1 * s1[I] - cm2 * s2[I]; });
+        sfor<0, 12>([&](auto I) { d[I] += dpp<0x111>(d[I]); });
+        sfor<0, 12>([&](auto I) { d[I] += dpp<0x112>(d[I]); });
+        sfor<0, 12>([&](auto I) { d[I] += dpp<0x114>(d[I]); });
+        sfor<0, 12>([&](auto I) { d[I] += dpp<0x118>(d[I]); });
+        sfor<0, 2>([&](auto Sd) {
+            val[Sd].a = {d[6 * Sd], d[6 * Sd + 1], d[6 * Sd + 2]}; val[Sd].l = {d[6 * Sd + 3], d[6 * Sd + 4], d[6 * Sd + 5]};
         });
     };
     sfor<0, 2>([&](auto Sd) { vel[Sd] = own[Sd]; });
@@ -373,22 +380,22 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
     {
         static_assert(TB_NDESC == nib(11, 10, 9, 0, 7, 0, 5, 4, 0, 1, 0, 0), "subtree intervals end at the foot, except leaves and the foot crank");
         const bool leafb = lb == 3 || lb == 5 || lb == 8 || lb == 10, crank = lb == 9;
-        auto subtree = [&](float x) {
-            const float x0 = bl ? x : 0.f;
-            float sfx = x0;
-            sfx += dpp<0x101>(sfx); sfx += dpp<0x102>(sfx); sfx += dpp<0x104>(sfx); sfx += dpp<0x108>(sfx);
-            const float two = x0 + dpp<0x101>(x0);
-            float r = leafb ? x0 : sfx;
-            r = crank ? two : r;
-            return r;
-        };
         sfor<0, 2>([&](auto Sd) {
             constexpr int sd = Sd;
-            const float c0 = subtree(crb[sd].m), c1 = subtree(crb[sd].h.x), c2 = subtree(crb[sd].h.y), c3 = subtree(crb[sd].h.z), c4 = subtree(crb[sd].I[0]),
-                        c5 = subtree(crb[sd].I[1]), c6 = subtree(crb[sd].I[2]), c7 = subtree(crb[sd].I[3]), c8 = subtree(crb[sd].I[4]), c9 = subtree(crb[sd].I[5]);
-            crb[sd] = SI{c0, {c1, c2, c3}, {c4, c5, c6, c7, c8, c9}};
-            frc[sd].a.x = subtree(frc[sd].a.x); frc[sd].a.y = subtree(frc[sd].a.y); frc[sd].a.z = subtree(frc[sd].a.z);
-            frc[sd].l.x = subtree(frc[sd].l.x); frc[sd].l.y = subtree(frc[sd].l.y); frc[sd].l.z = subtree(frc[sd].l.z);
+            // sixteen suffix sums per leg, stage by stage (one after the other they are chains of dependent DPP adds with hazard nops)
+            float x0[16], sfx[16], two[16];
+            x0[0] = crb[sd].m; x0[1] = crb[sd].h.x; x0[2] = crb[sd].h.y; x0[3] = crb[sd].h.z;
+            sfor<0, 6>([&](auto K) { x0[4 + K] = crb[sd].I[K]; });
+            x0[10] = frc[sd].a.x; x0[11] = frc[sd].a.y; x0[12] = frc[sd].a.z; x0[13] = frc[sd].l.x; x0[14] = frc[sd].l.y; x0[15] = frc[sd].l.z;
+            sfor<0, 16>([&](auto I) { x0[I] = bl ? x0[I] : 0.f; sfx[I] = x0[I]; });
+            sfor<0, 16>([&](auto I) { two[I] = x0[I] + dpp<0x101>(x0[I]); });
+            sfor<0, 16>([&](auto I) { sfx[I] += dpp<0x101>(sfx[I]); });
+            sfor<0, 16>([&](auto I) { sfx[I] += dpp<0x102>(sfx[I]); });
+            sfor<0, 16>([&](auto I) { sfx[I] += dpp<0x104>(sfx[I]); });
+            sfor<0, 16>([&](auto I) { sfx[I] += dpp<0x108>(sfx[I]); });
+            sfor<0, 16>([&](auto I) { float r = leafb ? x0[I] : sfx[I]; r = crank ? two[I] : r; x0[I] = r; });
+            crb[sd] = SI{x0[0], {x0[1], x0[2], x0[3]}, {x0[4], x0[5], x0[6], x0[7], x0[8], x0[9]}};
+            frc[sd].a = {x0[10], x0[11], x0[12]}; frc[sd].l = {x0[13], x0[14], x0[15]};
         });
     }
 #else
