@@ -732,7 +732,12 @@ def test_heightfield_terrain_vs_oracle(dev, kind):
         ncon += int(e.get("ints")[3])
         ref = e.get("qacc_warm"); scale = np.maximum(1.0, np.abs(ref))
         tol = np.full(32, 3e-2); tol[[9, 22]] = 0.25
-        assert np.all(np.abs(qa[i] - ref) / scale <= tol), (kind, i, np.abs(qa[i] - ref) / scale)
+        # a dof whose acceleration is a few rad/s^2 inside a vector of 2 000 - 10 000 rad/s^2 (the crafted penetration) carries the
+        # rounding of the large ones: the fp32 build of the ORACLE (make -C oracle f32) already moves such a dof by 1.3e-2 relative
+        # (slope, env 0) and the stiff ones by 2.4e-4 of max|qacc|; floor of 2e-5 * max|qacc| absolute under the relative bound
+        err = np.abs(qa[i] - ref)
+        ok = (err / scale <= tol) | (err <= 2e-5 * np.abs(ref).max())
+        assert np.all(ok), (kind, i, err / scale, err / np.abs(ref).max())
     assert ncon >= 6
     # env steps with the PD hold from those states
     for t in range(4):
