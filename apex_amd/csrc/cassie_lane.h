@@ -24,6 +24,32 @@ __device__ __forceinline__ void wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CS
 template <int CTRL> __device__ __forceinline__ float dpp(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
 }
+// acc -= bcast_K(acc) * m with the row broadcast as the DPP source of the fmac (see factor_lane for the hazard discipline these need)
+template <int K> __device__ __forceinline__ void fnmac_bcast(float& acc, float m) {
+    asm volatile("v_fmac_f32_dpp %0, %0, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "n"(K));
+}
+// one step of a triangular solve on the two leg slots at once: a_s -= bcast_K(a_s) * m_s.  Each slot's chain reads through DPP what it wrote one step
+// earlier: the other slot's instruction and the s_nop are the two wait states that needs (the FIRST step of a chain is preceded by solve_fence)
+template <int K> __device__ __forceinline__ void solve_step2(float& a0, float& a1, float m0, float m1) {
+    asm volatile("s_nop 0\n\tv_fmac_f32_dpp %0, %0, -%2 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\tv_fmac_f32_dpp %1, %1, -%3 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+                 : "+v"(a0), "+v"(a1) : "v"(m0), "v"(m1), "n"(K));
+}
+// acc += bcast_K(src) * m / bcast_K(src) * m (src is not written by these: the only hazard is a compiler-generated definition of src right in front of
+// its first DPP read, which the caller's fence excludes)
+template <int K> __device__ __forceinline__ void fmac_bcast(float& acc, float src, float m) {
+    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(K));
+}
+template <int K> __device__ __forceinline__ float mul_bcast(float src, float m) {
+    float r;
+    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "v"(m), "n"(K));
+    return r;
+}
+__device__ __forceinline__ void solve_fence(float& a0, float& a1) { asm volatile("s_nop 1" : "+v"(a0), "+v"(a1)); }
+template <int K> __device__ __forceinline__ float rcp_bcast(float x) {
+    float r;
+    asm volatile("v_rcp_f32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf\n\ts_nop 0" : "=v"(r) : "v"(x), "n"(K));
+    return r;
+}
 // d = (a.y, a.y) * b + c as ONE v_pk_fma_f32: op_sel takes the high half of the pair `a` for both result lanes
 typedef float f2pk __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2pk pk_fma_hi(f2pk a, f2pk b, f2pk c) {
@@ -697,19 +723,36 @@ __device__ __forceinline__ void factor_lane(const St& S, const LaneIdx& X, float
         // is a 13-way select on the lane index, which the compiler turns into a tree of divergent branches
         dg[sd] = S.W(blk + X.own) + hd;
     });
-    // ---- legs: eliminate dof 12 .. 0 of both legs at once
+    // ---- legs: eliminate dof 12 .. 0 of both legs at once.  An eliminated entry is x -= t * bcast_k(x): written as v_fmac_f32 with the broadcast as its
+    // DPP source operand and t negated by the source modifier (ONE instruction; the compiler's own selection is v_mov_b32_dpp + v_fma_f32 with a neg modifier, its DPP combiner does not take
+    // tied-accumulator instructions).  Inline asm is invisible to the hazard recogniser, so the distances are kept by construction: the statements are
+    // volatile (program order), a register written by one of them is read through DPP again no sooner than 6 statements later (order per step: next pivot's
+    // column, the other columns, pelvis couplings of leg 0, next pivot's reciprocal, pelvis couplings of leg 1), the fence below claims every register so
+    // that no compiler-generated definition can sit right in front of its first DPP read, and the reciprocal carries its own wait state for the
+    // transcendental-forwarding rule of gfx940+.
+#define APX_FENCE19(sd) asm volatile("s_nop 1" : "+v"(R[sd][0]), "+v"(R[sd][1]), "+v"(R[sd][2]), "+v"(R[sd][3]), "+v"(R[sd][4]), "+v"(R[sd][5]), "+v"(R[sd][6]), \
+        "+v"(R[sd][7]), "+v"(R[sd][8]), "+v"(R[sd][9]), "+v"(R[sd][10]), "+v"(R[sd][11]), "+v"(R[sd][12]),                                               \
+        "+v"(P[sd][0]), "+v"(P[sd][1]), "+v"(P[sd][2]), "+v"(P[sd][3]), "+v"(P[sd][4]), "+v"(P[sd][5]))
+    APX_FENCE19(0); APX_FENCE19(1);
+    float inv[2];
+    sfor<0, 2>([&](auto Sd) { inv[Sd] = rcp_bcast<12>(R[Sd][12]); });
     srfor<0, 13>([&](auto K) {
         constexpr int k = K;
+        float tmp[2];
         sfor<0, 2>([&](auto Sd) {
             constexpr int sd = Sd;
-            const float inv = rcpf(dpp<0x150 + k>(R[sd][k]));
-            const float tmp = l < k ? R[sd][k] * inv : 0.f;
-            dg[sd] -= tmp * R[sd][k];
-            sfor<0, k>([&](auto J) { constexpr int j = J; if constexpr (leg_anc(k, j)) R[sd][j] -= tmp * dpp<0x150 + k>(R[sd][j]); });
-            sfor<0, 6>([&](auto Pp) { P[sd][Pp] -= tmp * dpp<0x150 + k>(P[sd][Pp]); });
-            R[sd][k] = l < k ? tmp : R[sd][k];
+            tmp[sd] = l < k ? R[sd][k] * inv[sd] : 0.f;
+            dg[sd] -= tmp[sd] * R[sd][k];
         });
+        if constexpr (k >= 1) sfor<0, 2>([&](auto Sd) { if constexpr (leg_anc(k, k - 1)) fnmac_bcast<k>(R[Sd][k - 1], tmp[Sd]); });
+        srfor<0, (k >= 1 ? k - 1 : 0)>([&](auto J) { constexpr int j = J; sfor<0, 2>([&](auto Sd) { if constexpr (leg_anc(k, j)) fnmac_bcast<k>(R[Sd][j], tmp[Sd]); }); });
+        sfor<0, 6>([&](auto Pp) { fnmac_bcast<k>(P[0][Pp], tmp[0]); });
+        if constexpr (k >= 1) sfor<0, 2>([&](auto Sd) { inv[Sd] = rcp_bcast<k - 1>(R[Sd][k - 1]); });
+        sfor<0, 6>([&](auto Pp) { fnmac_bcast<k>(P[1][Pp], tmp[1]); });
+        sfor<0, 2>([&](auto Sd) { R[Sd][k] = l < k ? tmp[Sd] : R[Sd][k]; });
     });
+    APX_FENCE19(0); APX_FENCE19(1);      // ... and no compiler-generated DPP read right behind the last write
+#undef APX_FENCE19
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
         const float D = l < 13 ? dg[sd] : 1.f;
@@ -786,7 +829,9 @@ __device__ __forceinline__ LaneVec vec_load(const St& S, const LaneIdx& X, int o
 }
 // x <- L^-T x (leaves -> root)
 __device__ __forceinline__ void solve_LT_lane(const LaneFac& F, LaneVec& x) {
-    srfor<0, 13>([&](auto I) { constexpr int i = I; sfor<0, 2>([&](auto Sd) { x.a[Sd] -= F.Lc[Sd][i] * dpp<0x150 + i>(x.a[Sd]); }); });
+    solve_fence(x.a[0], x.a[1]);
+    srfor<0, 13>([&](auto I) { constexpr int i = I; solve_step2<i>(x.a[0], x.a[1], F.Lc[0][i], F.Lc[1][i]); });
+    solve_fence(x.a[0], x.a[1]);
     sfor<0, 6>([&](auto Pp) { x.p[Pp] -= red16(F.w[0][Pp] * x.a[0] + F.w[1][Pp] * x.a[1]); });
     srfor<1, 6>([&](auto I) { constexpr int i = I; sfor<0, i>([&](auto J) { x.p[J] -= F.Lp[i][J] * x.p[i]; }); });
 }
@@ -794,12 +839,15 @@ __device__ __forceinline__ void solve_LT_lane(const LaneFac& F, LaneVec& x) {
 __device__ __forceinline__ void solve_L_lane(const LaneFac& F, LaneVec& x) {
     sfor<1, 6>([&](auto I) { constexpr int i = I; sfor<0, i>([&](auto J) { x.p[i] -= F.Lp[i][J] * x.p[J]; }); });
     sfor<0, 2>([&](auto Sd) { sfor<0, 6>([&](auto Pp) { x.a[Sd] -= F.w[Sd][Pp] * x.p[Pp]; }); });
-    sfor<0, 13>([&](auto Jj) { constexpr int j = Jj; sfor<0, 2>([&](auto Sd) { x.a[Sd] -= F.Lr[Sd][j] * dpp<0x150 + j>(x.a[Sd]); }); });
+    solve_fence(x.a[0], x.a[1]);
+    sfor<0, 13>([&](auto Jj) { constexpr int j = Jj; solve_step2<j>(x.a[0], x.a[1], F.Lr[0][j], F.Lr[1][j]); });
+    solve_fence(x.a[0], x.a[1]);
 }
 // y = L^T x
 __device__ __forceinline__ LaneVec mul_LT_lane(const LaneFac& F, const LaneVec& x) {
     LaneVec y = x;
-    sfor<0, 13>([&](auto I) { constexpr int i = I; sfor<0, 2>([&](auto Sd) { y.a[Sd] += F.Lc[Sd][i] * dpp<0x150 + i>(x.a[Sd]); }); });
+    { float x0 = x.a[0], x1 = x.a[1]; solve_fence(x0, x1);
+      sfor<0, 13>([&](auto I) { constexpr int i = I; fmac_bcast<i>(y.a[0], x0, F.Lc[0][i]); fmac_bcast<i>(y.a[1], x1, F.Lc[1][i]); }); }
     sfor<0, 6>([&](auto Pp) { y.p[Pp] += red16(F.w[0][Pp] * x.a[0] + F.w[1][Pp] * x.a[1]); });
     sfor<1, 6>([&](auto I) { constexpr int i = I; sfor<0, i>([&](auto J) { y.p[J] += F.Lp[i][J] * x.p[i]; }); });
     return y;
@@ -1392,35 +1440,32 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, in
     typedef float f2g __attribute__((ext_vector_type(2)));
     f2g GX[MAXX];                                  // leg-leg row k = (XL | XR) on lane 13 + k: how its coefficient moves (rho_A, rho_B) of this lane
     {
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        f2 JP[19];                                 // (left, right) row of this lane, packed for v_pk_fma_f32
-        sfor<0, 19>([&](auto C) { JP[C] = f2{A.J[C], B.J[C]}; });
+        // every product takes its broadcast operand through DPP inside the multiply-add (v_fmac_f32_dpp): 2 instructions per leg column and source lane,
+        // 4 per pelvis column, where a separate v_mov_b32_dpp per broadcast + packed fmas took 3 and 4
+#define APX_FENCE19J(L) asm volatile("s_nop 1" : "+v"(L.J[0]), "+v"(L.J[1]), "+v"(L.J[2]), "+v"(L.J[3]), "+v"(L.J[4]), "+v"(L.J[5]), "+v"(L.J[6]), "+v"(L.J[7]), \
+        "+v"(L.J[8]), "+v"(L.J[9]), "+v"(L.J[10]), "+v"(L.J[11]), "+v"(L.J[12]), "+v"(L.J[13]), "+v"(L.J[14]), "+v"(L.J[15]), "+v"(L.J[16]), "+v"(L.J[17]), "+v"(L.J[18]))
+        APX_FENCE19J(A); APX_FENCE19J(B);
+#undef APX_FENCE19J
         sfor<0, 13>([&](auto Sx) {
             constexpr int s = Sx;
-            f2 d = {0.f, 0.f}, x = {0.f, 0.f};     // (aa, bb), (ab, ba)
-            sfor<0, 19>([&](auto C) {
+            float aa = mul_bcast<s>(A.J[0], A.J[0]), bb = mul_bcast<s>(B.J[0], B.J[0]);
+            float ab = mul_bcast<s>(B.J[0], A.J[0]), ba = mul_bcast<s>(A.J[0], B.J[0]);      // the legs only meet in the pelvis columns
+            sfor<1, 19>([&](auto C) {
                 constexpr int c = C;
-                const f2 sv = {dpp<0x150 + s>(A.J[c]), dpp<0x150 + s>(B.J[c])};
-                d += JP[c] * sv;
-                if constexpr (c < 6) x += JP[c] * f2{sv.y, sv.x};      // the legs only meet in the pelvis columns
+                fmac_bcast<s>(aa, A.J[c], A.J[c]); fmac_bcast<s>(bb, B.J[c], B.J[c]);
+                if constexpr (c < 6) { fmac_bcast<s>(ab, B.J[c], A.J[c]); fmac_bcast<s>(ba, A.J[c], B.J[c]); }
             });
-            // pin the sums here: LLVM otherwise sinks the fma chains into the conditional contact blocks that consume them while the
-            // (convergent) broadcasts stay put, and ~500 broadcast values get spilled to scratch in between
-            float aa = d.x, bb = d.y, ab = x.x, ba = x.y;
+            // pin the sums here: LLVM otherwise sinks the fma chains into the conditional contact blocks that consume them
             asm volatile("" : "+v"(aa), "+v"(bb), "+v"(ab), "+v"(ba));
             GAA[s] = aa; GBB[s] = bb; GAB[s] = ab; GBA[s] = ba;
         });
         sfor<0, MAXX>([&](auto K) { GX[K] = f2g{0.f, 0.f}; });
         if (anyx) sfor<0, MAXX>([&](auto K) {
             constexpr int s = 13 + K;
-            f2 d = {0.f, 0.f};                      // (A_r . XL + A_r,pel . XR_pel, B_r . XR + B_r,pel . XL_pel)
-            sfor<0, 19>([&](auto C) {
-                constexpr int c = C;
-                const f2 sv = {dpp<0x150 + s>(A.J[c]), dpp<0x150 + s>(B.J[c])};
-                d += JP[c] * sv;
-                if constexpr (c < 6) d += JP[c] * f2{sv.y, sv.x};
-            });
-            float aa = d.x, bb = d.y;
+            // (A_r . XL + A_r,pel . XR_pel, B_r . XR + B_r,pel . XL_pel)
+            float aa = mul_bcast<s>(A.J[0], A.J[0]), bb = mul_bcast<s>(B.J[0], B.J[0]);
+            sfor<1, 19>([&](auto C) { constexpr int c = C; fmac_bcast<s>(aa, A.J[c], A.J[c]); fmac_bcast<s>(bb, B.J[c], B.J[c]); });
+            sfor<0, 6>([&](auto C) { constexpr int c = C; fmac_bcast<s>(aa, B.J[c], A.J[c]); fmac_bcast<s>(bb, A.J[c], B.J[c]); });
             asm volatile("" : "+v"(aa), "+v"(bb));
             GX[K] = f2g{aa, bb};
         });
