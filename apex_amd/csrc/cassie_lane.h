@@ -44,6 +44,9 @@ template <int K> __device__ __forceinline__ float mul_bcast(float src, float m) 
     asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "v"(m), "n"(K));
     return r;
 }
+template <int K> __device__ __forceinline__ void fnmac_bcast3(float& acc, float src, float m) {
+    asm("v_fmac_f32_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(K));
+}
 __device__ __forceinline__ void solve_fence(float& a0, float& a1) { asm volatile("s_nop 1" : "+v"(a0), "+v"(a1)); }
 template <int K> __device__ __forceinline__ float rcp_bcast(float x) {
     float r;
@@ -687,6 +690,12 @@ struct LaneFac {
     float Lp[6][6], Dp[6], invDp[6];                          // pelvis block (uniform): L[i][j] for j < i
 };
 struct LaneVec { float a[2]; float p[6]; };                   // a[slot] = this lane's leg dof, p = pelvis dofs (uniform)
+// (see whiten_regs)
+struct FacRegs {
+    float Lr[2][13], w[2][6], disq[2];       // L[me][leg dof j], L[me][pelvis dof p], 1/sqrt(D_me)
+    float Lp[6][6], disqp[6];                // pelvis block L[i][j] (j < i), 1/sqrt(D_p): uniform
+    LaneVec qs, qv, qw;                      // qacc_smooth, qvel, qacc_warmstart: a[slot] = this lane's leg dof, p = pelvis dofs (uniform)
+};
 struct LaneIdx { int l, own, dep; unsigned short mi[13]; };   // own = offset of the lane's diagonal entry inside the leg block
 __device__ __forceinline__ LaneIdx lane_idx() {
     LaneIdx x;
@@ -853,8 +862,8 @@ __device__ __forceinline__ LaneVec mul_LT_lane(const LaneFac& F, const LaneVec& 
     return y;
 }
 
-// stage B: factorisation + qacc_smooth = M^-1 qfrc_smooth
-__device__ __forceinline__ void stage_factor_lane(const St& S) {
+// stage B: factorisation + qacc_smooth = M^-1 qfrc_smooth; the share of the factor that the row stage needs stays in registers (FR)
+__device__ __forceinline__ void stage_factor_lane(const St& S, FacRegs& FR) {
     const LaneIdx X = lane_idx();
     LaneFac F;
     factor_lane(S, X, 0.f, F);
@@ -862,13 +871,22 @@ __device__ __forceinline__ void stage_factor_lane(const St& S) {
     fac_store(S, X, F);
     PROF2(21);
     LaneVec x = vec_load(S, X, -1, WK_SMOOTH);
+    FR.qv = vec_load(S, X, F_QVEL, 0); FR.qw = vec_load(S, X, F_QACCW, 0);
     solve_LT_lane(F, x);
     sfor<0, 2>([&](auto Sd) { x.a[Sd] *= F.invD[Sd]; });
     sfor<0, 6>([&](auto Pp) { x.p[Pp] *= F.invDp[Pp]; });
     solve_L_lane(F, x);
     if (X.l < 13) sfor<0, 2>([&](auto Sd) { S.W(WK_QS + 6 + 13 * Sd + X.l) = x.a[Sd]; });
     if (X.l == 0) sfor<0, 6>([&](auto Pp) { S.W(WK_QS + Pp) = x.p[Pp]; });
+    FR.qs = x;
+    sfor<0, 2>([&](auto Sd) {
+        sfor<0, 13>([&](auto J) { FR.Lr[Sd][J] = F.Lr[Sd][J]; });
+        sfor<0, 6>([&](auto Pp) { FR.w[Sd][Pp] = F.w[Sd][Pp]; });
+        FR.disq[Sd] = rsqrtf(F.D[Sd]);
+    });
+    sfor<0, 6>([&](auto Pi) { FR.disqp[Pi] = rsqrtf(F.Dp[Pi]); sfor<0, Pi>([&](auto Qi) { FR.Lp[Pi][Qi] = F.Lp[Pi][Qi]; }); });
 }
+__device__ __forceinline__ void stage_factor_lane(const St& S) { FacRegs FR; stage_factor_lane(S, FR); }
 
 // stage E: qacc, foot force, IMU, then (do_euler) mj_Euler with implicit joint damping:
 // (M + h D) a = qfrc_smooth + J^T f = qfrc_smooth + L^T D^1/2 z~
@@ -1011,6 +1029,39 @@ __device__ __forceinline__ float whiten_lane(const St& S, float (&J)[19]) {
     float nn = 0.f;
     sfor<0, 19>([&](auto C) { constexpr int c = C; J[c] *= S.W(WK_DISQ + c2d<LEG>(c)); nn += J[c] * J[c]; });
     return nn;
+}
+
+// What the row stage needs of the factor stage, kept in REGISTERS across the stage boundary (lane l = leg dof l of both legs): the rows of L, 1/sqrt(D), the (uniform)
+// pelvis block, and the lane-distributed vectors of the three raw dots.  The whitening then takes every L entry as the DPP row-broadcast source of its
+// multiply-add (v_fmac_f32_dpp) instead of streaming the factor back from LDS: ~130 LDS reads + ~75 AGPR round trips per leg less.
+template <int LEG>
+__device__ __forceinline__ float whiten_regs(const FacRegs& F, float (&J)[19]) {
+    srfor<0, 19>([&](auto C) {
+        constexpr int c = C, i = c2d<LEG>(c);
+        sfor<1, ct_dof_depth[i]>([&](auto A) {
+            constexpr int a = A, g = ct_dof_anc[16 * i + a], t = d2c(g);
+            if constexpr (i >= 6) {
+                constexpr int li = i - 6 - 13 * LEG;
+                if constexpr (g >= 6) fnmac_bcast3<li>(J[t], F.Lr[LEG][g - 6 - 13 * LEG], J[c]);
+                else fnmac_bcast3<li>(J[t], F.w[LEG][g], J[c]);
+            } else J[t] -= F.Lp[i][g] * J[c];
+        });
+    });
+    float nn = 0.f;
+    sfor<0, 19>([&](auto C) {
+        constexpr int c = C, i = c2d<LEG>(c);
+        if constexpr (i >= 6) J[c] = mul_bcast<i - 6 - 13 * LEG>(F.disq[LEG], J[c]); else J[c] *= F.disqp[i];
+        nn += J[c] * J[c];
+    });
+    return nn;
+}
+// J . x for a lane-distributed vector x
+template <int LEG>
+__device__ __forceinline__ float dot_regs(const LaneVec& x, const float (&J)[19]) {
+    float r = 0.f;
+    sfor<0, 6>([&](auto C) { r += J[C] * x.p[C]; });
+    sfor<6, 19>([&](auto C) { constexpr int c = C; fmac_bcast<c - 6>(r, x.a[LEG], J[c]); });
+    return r;
 }
 
 // mj_setConst subset, lane-parallel (after stage_tree_lane<true> and stage_factor_lane): body_invweight0 (translational) of the
@@ -1164,7 +1215,7 @@ struct LegRows {
     float cfz[MAXC][3];          // world z of the contact frame (n, t1, t2) of each slot: the foot-force readout (cassie_sim_foot_forces)
 };
 template <int LEG, bool HF>
-__device__ __forceinline__ void rows_lane(const St& S, LegRows& out, int nxp, bool anyx, const float* rec, const Hf& hf) {
+__device__ __forceinline__ void rows_lane(const St& S, const FacRegs& FR, LegRows& out, int nxp, bool anyx, const float* rec, const Hf& hf) {
     const int l = threadIdx.x & 15;
     const V3 o = {S(F_QPOS), S(F_QPOS + 1), S(F_QPOS + 2)};
     const V3 fn = {S(F_FLOOR), S(F_FLOOR + 1), S(F_FLOOR + 2)}, ft1 = {S(F_FLOOR + 3), S(F_FLOOR + 4), S(F_FLOOR + 5)},
@@ -1300,13 +1351,12 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out, int nxp, bo
         });
     }
     PROF2(25);
-    float vel = 0.f, ju = 0.f, jw = 0.f;
-    sfor<0, 19>([&](auto C) {
-        constexpr int c = C, d = c2d<LEG>(c);
-        vel += J[c] * S(F_QVEL + d); ju += J[c] * S.W(WK_QS + d); jw += J[c] * S(F_QACCW + d);
-    });
+    const float vel = dot_regs<LEG>(FR.qv, J), ju = dot_regs<LEG>(FR.qs, J), jw = dot_regs<LEG>(FR.qw, J);
     PROF2(26);
-    const float nn = whiten_lane<LEG>(S, J);
+    const float nn = whiten_regs<LEG>(FR, J);
+    // the next reader takes J through DPP (row_shr) and cannot see the asm writes
+    asm volatile("s_nop 1" : "+v"(J[0]), "+v"(J[1]), "+v"(J[2]), "+v"(J[3]), "+v"(J[4]), "+v"(J[5]), "+v"(J[6]), "+v"(J[7]), "+v"(J[8]), "+v"(J[9]), "+v"(J[10]), "+v"(J[11]),
+                 "+v"(J[12]), "+v"(J[13]), "+v"(J[14]), "+v"(J[15]), "+v"(J[16]), "+v"(J[17]), "+v"(J[18]));
     out.vel = vel; out.ju = ju; out.jw = jw; out.nn = nn;
     PROF2(27);
     // ---- equality / limit scalars (mj_makeImpedance, mj_referenceConstraint, warm start from qacc_warmstart)
@@ -1379,16 +1429,24 @@ __device__ __forceinline__ void rows_lane(const St& S, LegRows& out, int nxp, bo
 // broadcast + scalar update + 2 fma: no cross-lane reduction inside the 50 sweeps.  Order is leg-major as before (left: 6
 // equality rows, limit, contacts; then right), a pyramidal contact sweeps its 4 rows through the 3x3 Gram block.
 template <bool HF>
-__device__ __forceinline__ void stage_rows_pgs_lane(const St& S, float* rows, int pgs_iters, const Hf& hf) {
+__device__ __forceinline__ void stage_rows_pgs_lane(const St& S, FacRegs& FR, float* rows, int pgs_iters, const Hf& hf) {
     const int l = threadIdx.x & 15;
     const float mu = S(F_FRIC);
     LegRows A, B;
     int xmask;
     const int nxp = legleg_pairs_lane(S, rows, xmask);
     const bool anyx = __builtin_amdgcn_ballot_w64(nxp > 0) != 0ull;          // wave-uniform: some env of the wave has a leg-leg contact
-    rows_lane<0, HF>(S, A, nxp, anyx, rows, hf);
+    {   // every register the row stage reads through DPP: fenced once against compiler-generated definitions right in front of the first read
+#define APX_F13(a) "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12])
+#define APX_F6(a) "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5])
+        asm volatile("s_nop 1" : APX_F13(FR.Lr[0]), APX_F6(FR.w[0]), "+v"(FR.disq[0]), "+v"(FR.qs.a[0]), "+v"(FR.qv.a[0]), "+v"(FR.qw.a[0]));
+        asm volatile("s_nop 1" : APX_F13(FR.Lr[1]), APX_F6(FR.w[1]), "+v"(FR.disq[1]), "+v"(FR.qs.a[1]), "+v"(FR.qv.a[1]), "+v"(FR.qw.a[1]));
+#undef APX_F13
+#undef APX_F6
+    }
+    rows_lane<0, HF>(S, FR, A, nxp, anyx, rows, hf);
     PROF2(23);
-    rows_lane<1, HF>(S, B, nxp, anyx, rows, hf);
+    rows_lane<1, HF>(S, FR, B, nxp, anyx, rows, hf);
     PROF2(24);
     // bookkeeping that must not stay live across the sweeps: saturation report, contact / limit counts, and the contact slot records for
     // the foot-force readout of the finish stage (foot flag, world z of the slot's frame)

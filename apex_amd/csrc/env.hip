@@ -156,15 +156,15 @@ __device__ APX_STAGE void stage1b_tree_lane(St S) {
 #ifndef APX_STAGE_FACTOR
 #define APX_STAGE_FACTOR __forceinline__
 #endif
-__device__ APX_STAGE_FACTOR void stage2a_factor(St S) {
+__device__ APX_STAGE_FACTOR void stage2a_factor(St S, c4::FacRegs& FR) {
     PROF_START();
-    c4::stage_factor_lane(S);
+    c4::stage_factor_lane(S, FR);
     PROF(2);
 }
 template <bool HF>
-__device__ __forceinline__ void stage3_rows_pgs_lane(St S, const Cfg& cfg) {
+__device__ __forceinline__ void stage3_rows_pgs_lane(St S, c4::FacRegs& FR, const Cfg& cfg) {
     PROF_START();
-    c4::stage_rows_pgs_lane<HF>(S, rows4(), cfg.pgs_iters, cfg.hf);
+    c4::stage_rows_pgs_lane<HF>(S, FR, rows4(), cfg.pgs_iters, cfg.hf);
     PROF(3);
 }
 // inlined like the rows / PGS stage: as a function it needs 36 callee-saved VGPRs, i.e. 36 scratch stores + 36 loads per lane per
@@ -194,9 +194,10 @@ __device__ __forceinline__ void sim_step_pd(const St& S, const Cfg& cfg, int mod
     c4::wsync();
     stage1b_tree_lane(S);
     c4::wsync();
-    stage2a_factor(S);
+    c4::FacRegs FR;                    // the share of the factor that the row stage reads, in registers across the stage boundary
+    stage2a_factor(S, FR);
     c4::wsync();
-    stage3_rows_pgs_lane<HF>(S, cfg);
+    stage3_rows_pgs_lane<HF>(S, FR, cfg);
     c4::wsync();
     stage4_finish(S, mode);
     c4::wsync();

@@ -4,6 +4,9 @@ cycles per instruction per stage (1 wave per SIMD: a full-rate VALU instruction 
 usage: python tools/stage_isa.py <disassembly.s of the code object> [prof2 log]"""
 import re, sys, collections
 
+COARSE = ["io_model", "tree_walk", "factor", "pgs_tail(z~)", "finish+euler", "rows(2 legs)", "gram+warm", "pgs_sweeps"]
+
+
 def main(path, log=None):
     lines = open(path).read().split("\n")
     segs = []; cur = collections.Counter(); in_k = False; getpc = []; fn = None
@@ -38,8 +41,10 @@ def main(path, log=None):
     cyc = {}
     if log:
         for ln in open(log):
-            m = re.match(r"\s+\[(\d+)\]\s+(.*?)\s+(\d+)$", ln)
+            m = re.match(r"\s+\[\s*(\d+)\]\s+(.*?)\s+(\d+)$", ln)
             if m: cyc[int(m.group(1))] = (m.group(2), int(m.group(3)))
+            m = re.match(r"(io_model|tree_walk|factor|pgs_tail\(z~\)|finish\+euler|rows\(2 legs\)|gram\+warm|pgs_sweeps)\s+(\d+) cycles", ln)
+            if m: cyc[COARSE.index(m.group(1))] = (m.group(1) + " (tail of the stage behind its last fine probe)", int(m.group(2)))
     allt = collections.Counter(g[1] for c, gp in segs if gp for g in gp if g[1])
     last = allt.most_common(1)[0][0]; base = min(t for t in allt if t != last and abs(t - last) < 4096) if allt else 0
     print("%-52s %6s %6s %5s %5s %5s %5s %5s %5s %5s %6s %7s %5s" % ("segment (code in front of the probe)", "instr", "valu", "dpp", "pk", "sel", "mov", "ldsR", "ldsW", "wait", "nopcy", "cycles", "c/i"))
