@@ -1319,35 +1319,26 @@ __device__ __forceinline__ void rows_lane(const St& S, const FacRegs& FR, LegRow
     }
     const V3 q1 = cross(p1 - o, dir), q2 = cross(p2 - o, dir);       // dir . (a x r) = a . (r x dir)
     float (&J)[19] = out.J;
-    {   // The 19 motion axes (6 words each) are fetched a chunk of JCH columns AHEAD of the arithmetic that uses them, with scheduling barriers that keep the compiler from
-        // sinking the loads back to their uses: left alone it issued the three ds_read2 of a column, waited the full LDS latency, did the column's dozen instructions, and
-        // only then issued the next column's loads (19 exposed round trips per leg).
-        constexpr int JCH = 4, NCH = (19 + JCH - 1) / JCH;
-        float buf[2][JCH][6];
-        auto fetch = [&](auto Ch, auto Bf) {
-            sfor<0, JCH>([&](auto K) {
-                constexpr int c = Ch * JCH + K;
-                if constexpr (c < 19) sfor<0, 6>([&](auto I) { buf[Bf][K][I] = S.W(WK_CDOF + 6 * c2d<LEG>(c) + I); });
-            });
-        };
-        fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-        sfor<0, NCH>([&](auto Ch) {
-            constexpr int ch = Ch, bf = ch & 1;
-            if constexpr (ch + 1 < NCH) fetch(std::integral_constant<int, ch + 1>{}, std::integral_constant<int, (ch + 1) & 1>{});
-            __builtin_amdgcn_sched_barrier(0);
-            sfor<0, JCH>([&](auto K) {
-                constexpr int c = ch * JCH + K;
-                if constexpr (c < 19) {
-                    const V3 ca = {buf[bf][K][0], buf[bf][K][1], buf[bf][K][2]}, cl = {buf[bf][K][3], buf[bf][K][4], buf[bf][K][5]};
-                    const float dl = dot(dir, cl);
-                    const float g1 = dl + dot(q1, ca), g2 = dl + dot(q2, ca);
-                    float v = ((m1 >> c) & 1u) ? g1 : 0.f;
-                    v -= ((m2 >> c) & 1u) ? g2 : 0.f;
-                    if (isLim && nlim && c == clim) v = lsign;
-                    J[c] = v;
-                }
-            });
-            __builtin_amdgcn_sched_barrier(0);
+    {   // The 19 motion axes come from REGISTERS: lane l holds the axis of leg dof l (and lanes 0..5 the pelvis axes), loaded once per leg, and a column's six words are the
+        // DPP row-broadcast sources of its nine multiply-adds (v_mul_f32_dpp / v_fmac_f32_dpp) - 18 LDS reads per leg where streaming the columns took 114 (and, before the
+        // loads were chunked, 19 exposed round trips)
+        float cdl[6], cdp[6];
+        {
+            const int ll = l < 13 ? l : 12, lp = l < 6 ? l : 5;
+            sfor<0, 6>([&](auto I) { cdl[I] = S.W(WK_CDOF + 6 * (6 + 13 * LEG) + 6 * ll + I); cdp[I] = S.W(WK_CDOF + 6 * lp + I); });
+        }
+        asm volatile("s_nop 1" : "+v"(cdl[0]), "+v"(cdl[1]), "+v"(cdl[2]), "+v"(cdl[3]), "+v"(cdl[4]), "+v"(cdl[5]),
+                                 "+v"(cdp[0]), "+v"(cdp[1]), "+v"(cdp[2]), "+v"(cdp[3]), "+v"(cdp[4]), "+v"(cdp[5]));
+        sfor<0, 19>([&](auto C) {
+            constexpr int c = C, src = c < 6 ? c : c - 6;
+            const float (&cd)[6] = c < 6 ? cdp : cdl;
+            float dl = mul_bcast<src>(cd[3], dir.x), g1 = mul_bcast<src>(cd[0], q1.x), g2 = mul_bcast<src>(cd[0], q2.x);
+            fmac_bcast<src>(dl, cd[4], dir.y); fmac_bcast<src>(g1, cd[1], q1.y); fmac_bcast<src>(g2, cd[1], q2.y);
+            fmac_bcast<src>(dl, cd[5], dir.z); fmac_bcast<src>(g1, cd[2], q1.z); fmac_bcast<src>(g2, cd[2], q2.z);
+            float v = ((m1 >> c) & 1u) ? g1 + dl : 0.f;
+            v -= ((m2 >> c) & 1u) ? g2 + dl : 0.f;
+            if (isLim && nlim && c == clim) v = lsign;
+            J[c] = v;
         });
     }
     PROF2(25);
