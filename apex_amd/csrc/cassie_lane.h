@@ -47,6 +47,10 @@ template <int K> __device__ __forceinline__ float mul_bcast(float src, float m) 
 template <int K> __device__ __forceinline__ void fnmac_bcast3(float& acc, float src, float m) {
     asm("v_fmac_f32_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(K));
 }
+// acc += row_shr:N(x) * x (lanes without a source N places down contribute 0)
+template <int N> __device__ __forceinline__ void fmac_shr(float& acc, float x) {
+    asm("v_fmac_f32_dpp %0, %1, %1 row_shr:%2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "n"(N));
+}
 __device__ __forceinline__ void solve_fence(float& a0, float& a1) { asm volatile("s_nop 1" : "+v"(a0), "+v"(a1)); }
 template <int K> __device__ __forceinline__ float rcp_bcast(float x) {
     float r;
@@ -1371,7 +1375,8 @@ __device__ __forceinline__ void rows_lane(const St& S, const FacRegs& FR, LegRow
     }
     // ---- contact scalars: Gram matrix of (n, t1, t2) across the three basis lanes, pyramid rows n +- mu t_j
     float a1 = 0.f, a2 = 0.f;
-    sfor<0, 19>([&](auto C) { a1 += J[C] * dpp<0x111>(J[C]); a2 += J[C] * dpp<0x112>(J[C]); });     // row_shr:1, row_shr:2
+    // a1 += J[C] * row_shr:1(J[C]), a2 likewise with row_shr:2: the shifted operand is the DPP source of the fmac (J is fenced right above)
+    sfor<0, 19>([&](auto C) { fmac_shr<1>(a1, J[C]); fmac_shr<2>(a2, J[C]); });
     sfor<0, MAXC>([&](auto Sl) {
         constexpr int s = Sl, ln = 7 + 3 * s;
         const float gnn = dpp<0x150 + ln>(nn), g11 = dpp<0x150 + ln + 1>(nn), g22 = dpp<0x150 + ln + 2>(nn);

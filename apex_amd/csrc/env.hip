@@ -394,9 +394,8 @@ __device__ void env_reset_finish(const St& S, const Cfg& cfg) {
     S(F_CMD + 1) = r.uniform(-0.3f, 0.3f);
 }
 __device__ int g_reset_miss = 0;
-// CassieEnv.reset (cassie/cassie.py:523-680); called by all 16 lanes of the env's row
-template <bool HF>
-__device__ __forceinline__ void env_reset(const St& S, const Cfg& cfg, int n) {
+// CassieEnv.reset (cassie/cassie.py:523-680) up to its settle step; called by all 16 lanes of the env's row
+__device__ __forceinline__ void env_restart_head(const St& S, const Cfg& cfg, int n) {
     const bool lead = (threadIdx.x & 15) == 0;
     if (cfg.est_lifetime > 0 && S.I(I_AGE) >= cfg.est_lifetime) {      // this env instance has served a PPO.sample call's worth of steps: the next one starts with a new estimator
         const int l = threadIdx.x & 15;
@@ -404,15 +403,22 @@ __device__ __forceinline__ void env_reset(const St& S, const Cfg& cfg, int n) {
         c4::wsync();
         if (lead) S.I(I_AGE) = 0;
     }
-    // Everything of the reset up to its settle step is a function of (seed, env, episode index) alone and is computed by env_reset_prepare_kernel into the env's ring -
-    // ahead of time (apx_env_prepare_resets, while the learner runs) or, for an env whose slot does not hold this episode, by the masked launch that precedes this kernel.
-    // ONE implementation of that part, so a prepared and an unprepared reset are bit-identical.  Here: copy the image, then the settle step.
+    // Everything of the reset up to its settle step is a function of (seed, env, episode index) alone and sits in the env's ring (env_reset_kernel, part 0: ahead of time
+    // while the learner runs, or on demand right before this).  Here: copy the image; the caller runs the settle step.
     const int ep = S.I(I_EPISODE) + 1, slot = ep % RST_K;
     {
         const int l = threadIdx.x & 15;
-        if (lead && cfg.rst_int[(size_t)(2 * slot) * n + S.env] != ep) atomicAdd(&g_reset_miss, 1);      // (cannot happen: the masked prepare launch runs first; reported by apx_env_get_field("reset_miss"))
+        if (lead && cfg.rst_int[(size_t)(2 * slot) * n + S.env] != ep) atomicAdd(&g_reset_miss, 1);      // (cannot happen: the first part of env_reset_kernel fills the slot; reported by apx_env_get_field("reset_miss"))
         const float* img = cfg.rst + (size_t)slot * F_TOTAL * n + S.env;
-        for (int f = l; f < F_PDT; f += 16) S(f) = img[(size_t)f * n];                       // qpos, qvel, qacc_warmstart, mass, damping, friction, floor, invweights, encoder offsets
+        {   // qpos, qvel, qacc_warmstart, mass, damping, friction, floor, invweights, encoder offsets: every load of the image in flight before the first LDS store (as a plain
+            // copy loop the compiler waited for each HBM load in turn: ~30 dependent round trips, a third of the kernel)
+            constexpr int NCP = (F_PDT + 15) / 16;
+            float v[NCP];
+#pragma unroll
+            for (int k = 0; k < NCP; ++k) { const int f = l + 16 * k; v[k] = img[(size_t)(f < F_PDT ? f : 0) * n]; }
+#pragma unroll
+            for (int k = 0; k < NCP; ++k) { const int f = l + 16 * k; if (f < F_PDT) S(f) = v[k]; }
+        }
         for (int f = F_SNAP + l; f < F_SNAP + 26; f += 16) S(f) = img[(size_t)f * n];        // sensor snapshot of the forward pass at the init pose
         if (l < 7) S(F_CMD + l) = img[(size_t)(F_CMD + l) * n];
         S(F_FWD + l) = img[(size_t)(F_FWD + l) * n];
@@ -424,9 +430,7 @@ __device__ __forceinline__ void env_reset(const St& S, const Cfg& cfg, int n) {
         if (lead) traj_pose(S, (float)S.I(I_PHASE), S(F_CMD + 5), S(F_CMD), 0);      // (cassie_traj.py:752-758); no mj_forward follows, so the
         c4::wsync();                                  // settle step below still reads the init-pose sensor snapshot, like the reference
     }
-    sim_step_pd<HF>(S, cfg, 1);               // cassie.py:665 (stale pd_in_t)
-    if (lead) env_reset_finish(S, cfg);
-    c4::wsync();
+    // the caller runs the settle step (cassie.py:665, stale pd_in_t: F_PDT is not part of the image) and env_reset_finish
 }
 
 // clock_reward (cassie/rewards/clock_rewards.py:6-110)
@@ -530,35 +534,46 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_setconst_kernel(floa
     store_state(S, st, ist, n);
 }
 
-template <bool HF>
-__global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const uint8_t* mask, float* obs) {
-    ENV_SETUP
-    if (mask && !mask[env]) return;
-    load_state(S, st, ist, n);
-    env_reset<HF>(S, cfg, n);
-    if (obs && lead) write_obs(S, cfg, obs + (size_t)env * cfg.obs_dim);
-    store_state(S, st, ist, n);
-}
 
-// apx_env_prepare_resets / the first half of every reset: the part of episode (I_EPISODE + ahead)'s reset that does not depend on how the current episode ends - draws from the episode-keyed stream,
-// mj_setConst on the randomised model, the forward pass at the init pose - computed ahead of time (while the learner runs) into the env's ring slot.  The working image
-// starts from the env's current state; only the fields the reset defines are read back by env_reset.  Nothing of the env itself is modified.
+// CassieEnv.reset in two parts of ONE kernel.  Part 0, the IMAGE: the part of episode ep's reset that does not depend on how the episode before it ends -
+// draws from the episode-keyed stream, mj_setConst on the randomised model, the forward pass at the init pose - written to the env's ring slot (ep % RST_K); the working copy
+// starts from the env's current state and nothing of the env itself is modified.  Part 1, the RESTART: copy the image's fields into the env, settle step, tail draws, observation.
+//   ahead > 0 (apx_env_prepare_resets, while the learner runs): part 0 only, for episode I_EPISODE + ahead of the envs of `mask` whose slot does not hold it yet;
+//   ahead = 0 (apx_env_reset, the auto-reset of apx_env_step with mask = the done flags): part 0 for the envs of `mask` whose slot does not hold episode I_EPISODE + 1 (normally
+//   none: one launch per env step instead of two), then part 1 for all envs of `mask`.
+// One kernel: an image is always computed by the same machine code (the forward-pass instance of the substep), a settle step by the other instance, so a restart is the
+// same bits whether its image was prepared ahead or computed on demand (two KERNELS with their own inlined copies differed by an ulp under -ffast-math).
 template <bool HF>
-__global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_prepare_kernel(const float* st, const int* ist, float* wk, int n, Cfg cfg, float* rst, int* rst_int, int ahead, const uint8_t* mask) {
+__global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, float* rst, int* rst_int, int ahead, const uint8_t* mask, float* obs) {
     ENV_SETUP
-    const int ep = ist[(size_t)I_EPISODE * n + env] + ahead, slot = ep % RST_K;
-    const bool need = (!mask || mask[env]) && rst_int[(size_t)(2 * slot) * n + env] != ep;      // mask = the done flags: only the envs that restart now and whose slot is not prepared
-    if (__builtin_amdgcn_ballot_w64(need) == 0ull) return;      // wave-uniform: the slots of all four envs are filled
+    const bool in_mask = !mask || mask[env] != 0;
+    const int ep = ist[(size_t)I_EPISODE * n + env] + (ahead > 0 ? ahead : 1), slot = ep % RST_K;
+    const bool need = in_mask && rst_int[(size_t)(2 * slot) * n + env] != ep, restart = ahead == 0 && in_mask;
+    if (__builtin_amdgcn_ballot_w64(need || restart) == 0ull) return;      // wave-uniform: nothing to do for the four envs
     load_state(S, st, ist, n);
-    if (lead) env_reset_draws(S, cfg, ep);
-    c4::wsync();
-    if (cfg.dyn_rand) setconst_lane(S);
-    sim_step_pd<HF>(S, cfg, 0);
-    c4::wsync();
-    if (!need) return;
-    float* img = rst + (size_t)slot * F_TOTAL * n + env;
-    for (int f = l; f < F_TOTAL; f += 16) img[(size_t)f * n] = S(f);
-    if (lead) { rst_int[(size_t)(2 * slot + 1) * n + env] = S.I(I_PHASE); rst_int[(size_t)(2 * slot) * n + env] = ep; }
+    if (__builtin_amdgcn_ballot_w64(need) != 0ull) {
+        if (need) {
+            if (lead) env_reset_draws(S, cfg, ep);
+            c4::wsync();
+            if (cfg.dyn_rand) setconst_lane(S);
+            sim_step_pd<HF>(S, cfg, 0);                    // forward pass only
+            c4::wsync();
+            float* img = rst + (size_t)slot * F_TOTAL * n + env;
+            for (int f = l; f < F_TOTAL; f += 16) img[(size_t)f * n] = S(f);
+            if (lead) { rst_int[(size_t)(2 * slot + 1) * n + env] = S.I(I_PHASE); rst_int[(size_t)(2 * slot) * n + env] = ep; }
+            if (restart) { __threadfence(); load_state(S, st, ist, n); }      // back to the env's own state: the restart copies the image's fields over it
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(restart) != 0ull) {
+        if (restart) {
+            env_restart_head(S, cfg, n);
+            sim_step_pd<HF>(S, cfg, 1);                    // cassie.py:665 (stale pd_in_t)
+            if (lead) env_reset_finish(S, cfg);
+            c4::wsync();
+            if (obs && lead) write_obs(S, cfg, obs + (size_t)env * cfg.obs_dim);
+        }
+    }
+    if (restart) store_state(S, st, ist, n);
 }
 
 #ifdef APX_WAVETIME      /* experiment build: shader-clock duration of every wave of the step kernel (the launch lasts as long as its slowest wave) */
@@ -786,7 +801,7 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     const Cfg c = make_cfg(*e);
     hipLaunchKernelGGL(env_init_kernel, dim3(e->n / 64), dim3(64), 0, 0, e->st, e->ist, e->n, c);
     APX_LAUNCH_CHECK();
-    for (const void* fn : {(const void*)env_step_kernel<false>, (const void*)env_step_kernel<true>, (const void*)env_reset_kernel<false>, (const void*)env_reset_kernel<true>, (const void*)env_reset_prepare_kernel<false>, (const void*)env_reset_prepare_kernel<true>,
+    for (const void* fn : {(const void*)env_step_kernel<false>, (const void*)env_step_kernel<true>, (const void*)env_reset_kernel<false>, (const void*)env_reset_kernel<true>, 
                            (const void*)env_substep_kernel<false>, (const void*)env_substep_kernel<true>, (const void*)env_reset_for_test_kernel<false>,
                            (const void*)env_reset_for_test_kernel<true>})
         APX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
@@ -811,15 +826,15 @@ static int invalidate_prepared(apx_env* e, void* stream) {
     APX_HIP(hipMemsetAsync(e->rst_int, 0xFF, sizeof(int) * (size_t)RST_K * 2 * e->n, (hipStream_t)stream));
     return APX_OK;
 }
-static int launch_prepare(apx_env* e, int ahead, const uint8_t* mask, void* stream) {
-    if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_prepare_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), e->rst, e->rst_int, ahead, mask);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_prepare_kernel<false>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), e->rst, e->rst_int, ahead, mask);
+static int launch_reset(apx_env* e, int ahead, const uint8_t* mask, float* obs, void* stream) {
+    if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), e->rst, e->rst_int, ahead, mask, obs);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_kernel<false>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), e->rst, e->rst_int, ahead, mask, obs);
     APX_LAUNCH_CHECK();
     return APX_OK;
 }
 extern "C" int apx_env_prepare_resets(apx_env_t* e, void* stream) {
     APX_REQUIRE(e, "env");
-    for (int ahead = 1; ahead <= RST_K; ++ahead) { const int rc = launch_prepare(e, ahead, nullptr, stream); if (rc != APX_OK) return rc; }
+    for (int ahead = 1; ahead <= RST_K; ++ahead) { const int rc = launch_reset(e, ahead, nullptr, nullptr, stream); if (rc != APX_OK) return rc; }
     return APX_OK;
 }
 
@@ -838,13 +853,7 @@ extern "C" int apx_env_set_hfield(apx_env_t* e, const float* data, int nrow, int
 
 extern "C" int apx_env_reset(apx_env_t* e, const uint8_t* mask, float* obs_out, void* stream) {
     APX_REQUIRE(e, "env");
-    { const int rc = launch_prepare(e, 1, mask, stream); if (rc != APX_OK) return rc; }      // the envs of the mask whose ring slot does not hold their next episode (exits at once otherwise)
-    if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
-                       make_cfg(*e), mask, obs_out);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_kernel<false>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
-                       make_cfg(*e), mask, obs_out);
-    APX_LAUNCH_CHECK();
-    return APX_OK;
+    return launch_reset(e, 0, mask, obs_out, stream);
 }
 
 extern "C" int apx_env_update_speed(apx_env_t* e, const float* speed, const float* side_speed, void* stream) {
@@ -900,14 +909,7 @@ extern "C" int apx_env_step(apx_env_t* e, const float* action, float* obs, float
                        make_cfg(*e), action, obs, reward, done, final_obs);
     APX_LAUNCH_CHECK();
     if (timed) { APX_HIP(hipEventRecord((hipEvent_t)e->ev[e->ev_n + 1], (hipStream_t)stream)); e->ev_n += 2; }
-    if (auto_reset) {   // finished envs restart in a second launch on the same stream (mask = done flags)
-        { const int rc = launch_prepare(e, 1, done, stream); if (rc != APX_OK) return rc; }      // only for finished envs whose next episode is not in the ring: normally none, the launch exits at once
-        if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
-                           make_cfg(*e), done, obs);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_kernel<false>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
-                           make_cfg(*e), done, obs);
-        APX_LAUNCH_CHECK();
-    }
+    if (auto_reset) { const int rc = launch_reset(e, 0, done, obs, stream); if (rc != APX_OK) return rc; }      // finished envs restart in a second launch on the same stream (mask = done flags)
     return APX_OK;
 }
 
