@@ -154,7 +154,8 @@ __global__ void prep_obs_kernel(const float* __restrict__ x, int64_t B, int D, c
 // Block tile 64x64x16, 4 waves, each wave one 32x32 v_mfma_f32_32x32x2_f32 accumulator.
 // LDS tiles are k-major ([k][m], [k][n]) so the MFMA operand fetch (lane l: k = l>>5, m|n = l&31) is a
 // conflict-free ds_read_b32 (two 32-lane halves, 32 consecutive dwords each).
-enum { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_MASK = 3, EPI_ATOMIC = 4, EPI_ACC = 5 /* C += AB, no split-K */ };
+enum { EPI_STORE = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2, EPI_MASK = 3, EPI_ATOMIC = 4, EPI_ACC = 5 /* C += AB, no split-K */,
+       EPI_PARTIAL = 6 /* split-K, every K chunk STORES its product to its own slab C + z * part_stride (summed by grad_reduce_kernel); the bias gradient stays atomic */ };
 
 struct GemmArgs {
     const float* A; long a_rs, a_cs;
@@ -162,6 +163,7 @@ struct GemmArgs {
     float* C; long ldc;
     const float* aux; long ld_aux;   // bias[N] or mask[M, ld_aux]
     int M, N, K, kchunk;
+    long part_stride;                // EPI_PARTIAL: floats between the slabs of consecutive K chunks
     int prec;                        // 0: fp32 MFMA (exact fp32 products); 1: operands rounded to bf16, fp32 accumulate (v_mfma_f32_32x32x8_bf16_1k)
 };
 
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     floatx16 acc = {0};
     const bool a_kmajor = (g.a_cs == 1);   // k contiguous in memory
     const bool b_kmajor = (g.b_rs == 1);
-    const bool bias_grad = EPI == EPI_ATOMIC && g.aux != nullptr && blockIdx.y == 0;
+    const bool bias_grad = (EPI == EPI_ATOMIC || EPI == EPI_PARTIAL) && g.aux != nullptr && blockIdx.y == 0;
     float bsum = 0.f;
     // software pipeline: the global loads of k-tile t+1 are in flight while the MFMAs of tile t run out of LDS
     float ra[4], rb[4];
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
         __syncthreads();
         if (k0 + GBK < kend) fetch(k0 + GBK);
-        if (EPI == EPI_ATOMIC && bias_grad && tid < GBM) {      // fused bias gradient: column sums of dY ride on the A tile
+        if ((EPI == EPI_ATOMIC || EPI == EPI_PARTIAL) && bias_grad && tid < GBM) {      // fused bias gradient: column sums of dY ride on the A tile
 #pragma unroll
             for (int kk = 0; kk < GBK; ++kk) bsum += As[kk][tid];
         }
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         }
         __syncthreads();
     }
-    if (EPI == EPI_ATOMIC && bias_grad && tid < GBM && m0 + tid < g.M) atomicAdd(const_cast<float*>(g.aux) + m0 + tid, bsum);
+    if ((EPI == EPI_ATOMIC || EPI == EPI_PARTIAL) && bias_grad && tid < GBM && m0 + tid < g.M) atomicAdd(const_cast<float*>(g.aux) + m0 + tid, bsum);
     const int col = n0 + wn + (lane & 31);
     if (col >= g.N) return;
     float bias = 0.f;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row >= g.M) continue;
         float v = acc[r];
-        float* c = g.C + (long)row * g.ldc + col;
+        float* c = g.C + (EPI == EPI_PARTIAL ? (long)blockIdx.z * g.part_stride : 0l) + (long)row * g.ldc + col;
         if (EPI == EPI_BIAS) v += bias;
         if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
         if (EPI == EPI_MASK) v = g.aux[(long)row * g.ld_aux + col] > 0.f ? v : 0.f;
@@ -245,6 +247,93 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
         else if (EPI == EPI_ACC) *c += v;
         else *c = v;
     }
+}
+
+// ------------------------------------------------------------------------------------------------ fp32 MFMA GEMM, 128 x 128 tiles
+// The two big shapes of the backward pass - dX = dY W (M = batch, N = K = 256) and dW = dY^T X (M = N = 256, K = batch) - run at half the operand traffic per flop of the
+// 64 x 64 kernel: block tile 128 x 128 x 16, 4 waves, each wave a 64 x 64 sub-tile = 2 x 2 accumulators of v_mfma_f32_32x32x2_f32 (four MFMAs per four ds_read_b32), operands
+// fetched from HBM / L2 as float4 one k-tile ahead of the MFMAs.  Shapes: M, N multiples of 128, K chunks multiples of 16, B(k, n) contiguous in n (both call sites), A(m, k)
+// contiguous in k (dX) or in m (dW); everything else stays on gemm_f32_kernel.  Epilogues: EPI_STORE, EPI_MASK, EPI_PARTIAL (+ the fused bias gradient).
+#define G2M 128
+#define G2N 128
+#define G2P 132      /* LDS row pitch in floats: 16-byte aligned rows for the float4 stores of the m- / n-contiguous operands */
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f32_128_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[GBK][G2P];
+    __shared__ __attribute__((aligned(16))) float Bs[GBK][G2P];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * G2M, n0 = blockIdx.y * G2N;
+    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = floatx16{0};
+    const bool a_kmajor = g.a_cs == 1;
+    const bool bias_grad = EPI == EPI_PARTIAL && g.aux != nullptr && blockIdx.y == 0;
+    float bsum = 0.f;
+    f4v ra[2], rb[2];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (a_kmajor) { const int row = (tid >> 2) + 64 * i, kq = (tid & 3) * 4; ra[i] = *(const f4v*)(g.A + (long)(m0 + row) * g.a_rs + k0 + kq); }
+            else          { const int k = (tid >> 5) + 8 * i, mq = (tid & 31) * 4;  ra[i] = *(const f4v*)(g.A + (long)(k0 + k) * g.a_cs + m0 + mq); }
+            { const int k = (tid >> 5) + 8 * i, nq = (tid & 31) * 4; rb[i] = *(const f4v*)(g.B + (long)(k0 + k) * g.b_rs + n0 + nq); }
+        }
+    };
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += GBK) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (a_kmajor) {
+                const int row = (tid >> 2) + 64 * i, kq = (tid & 3) * 4;
+                As[kq][row] = ra[i].x; As[kq + 1][row] = ra[i].y; As[kq + 2][row] = ra[i].z; As[kq + 3][row] = ra[i].w;
+            } else { const int k = (tid >> 5) + 8 * i, mq = (tid & 31) * 4; *(f4v*)&As[k][mq] = ra[i]; }
+            { const int k = (tid >> 5) + 8 * i, nq = (tid & 31) * 4; *(f4v*)&Bs[k][nq] = rb[i]; }
+        }
+        __syncthreads();
+        if (k0 + GBK < kend) fetch(k0 + GBK);
+        if (EPI == EPI_PARTIAL && bias_grad && tid < G2M) {      // fused bias gradient: column sums of dY ride on the A tile
+#pragma unroll
+            for (int kk = 0; kk < GBK; ++kk) bsum += As[kk][tid];
+        }
+#pragma unroll
+        for (int kk = 0; kk < GBK; kk += 2) {
+            const int kr = kk + (lane >> 5), c = lane & 31;
+            const float a0 = As[kr][wm + c], a1 = As[kr][wm + 32 + c], b0 = Bs[kr][wn + c], b1 = Bs[kr][wn + 32 + c];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (EPI == EPI_PARTIAL && bias_grad && tid < G2M) atomicAdd(const_cast<float*>(g.aux) + m0 + tid, bsum);
+    float* Cb = g.C + (EPI == EPI_PARTIAL ? (long)blockIdx.z * g.part_stride : 0l);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + 32 * j + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float v = acc[i][j][r];
+                if (EPI == EPI_MASK) v = g.aux[(long)row * g.ld_aux + col] > 0.f ? v : 0.f;
+                Cb[(long)row * g.ldc + col] = v;
+            }
+        }
+}
+static bool gemm128_ok(int epi, const GemmArgs& g, int kchunk) {
+    static const bool off = getenv("APX_GEMM128") && atoi(getenv("APX_GEMM128")) == 0;
+    if (off || g.prec != 0 || !(epi == EPI_STORE || epi == EPI_MASK || epi == EPI_PARTIAL)) return false;
+    if (g.M % G2M || g.N % G2N || g.K % GBK || kchunk % GBK || g.K < 64) return false;
+    if (epi != EPI_PARTIAL && (long)(g.M / G2M) * (g.N / G2N) < 384) return false;      // too few 128 x 128 tiles to fill the chip: the 64 x 64 kernel's 4x workgroups hide the latency better
+    if (g.b_cs != 1 || g.b_rs % 4 || ((uintptr_t)g.B & 15) || ((uintptr_t)g.A & 15)) return false;
+    if (g.a_cs == 1) return g.a_rs % 4 == 0;
+    return g.a_rs == 1 && g.a_cs % 4 == 0;
 }
 
 // ------------------------------------------------------------------------------------------------ bf16 MFMA GEMM (precision 1)
@@ -340,7 +429,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
 static int launch_gemm(int epi, const GemmArgs& g0, int ksplit, hipStream_t s) {
     GemmArgs g = g0;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return APX_OK;
-    if (epi != EPI_ATOMIC) ksplit = 1;
+    if (epi != EPI_ATOMIC && epi != EPI_PARTIAL) ksplit = 1;
     const int kt = g.prec == 1 ? HBK : GBK;
     int kchunk = (g.K + ksplit - 1) / ksplit;
     kchunk = ((kchunk + kt - 1) / kt) * kt;
@@ -360,6 +449,16 @@ static int launch_gemm(int epi, const GemmArgs& g0, int ksplit, hipStream_t s) {
         APX_LAUNCH_CHECK();
         return APX_OK;
     }
+    if (gemm128_ok(epi, g, kchunk)) {
+        dim3 grid2(g.M / G2M, g.N / G2N, nz);
+        switch (epi) {
+            case EPI_STORE: hipLaunchKernelGGL(gemm_f32_128_kernel<EPI_STORE>, grid2, block, 0, s, g); break;
+            case EPI_MASK: hipLaunchKernelGGL(gemm_f32_128_kernel<EPI_MASK>, grid2, block, 0, s, g); break;
+            default: hipLaunchKernelGGL(gemm_f32_128_kernel<EPI_PARTIAL>, grid2, block, 0, s, g); break;
+        }
+        APX_LAUNCH_CHECK();
+        return APX_OK;
+    }
     switch (epi) {
         case EPI_STORE: hipLaunchKernelGGL(gemm_f32_kernel<EPI_STORE>, grid, block, 0, s, g); break;
         case EPI_BIAS: hipLaunchKernelGGL(gemm_f32_kernel<EPI_BIAS>, grid, block, 0, s, g); break;
@@ -367,6 +466,7 @@ static int launch_gemm(int epi, const GemmArgs& g0, int ksplit, hipStream_t s) {
         case EPI_MASK: hipLaunchKernelGGL(gemm_f32_kernel<EPI_MASK>, grid, block, 0, s, g); break;
         case EPI_ATOMIC: hipLaunchKernelGGL(gemm_f32_kernel<EPI_ATOMIC>, grid, block, 0, s, g); break;
         case EPI_ACC: hipLaunchKernelGGL(gemm_f32_kernel<EPI_ACC>, grid, block, 0, s, g); break;
+        case EPI_PARTIAL: hipLaunchKernelGGL(gemm_f32_kernel<EPI_PARTIAL>, grid, block, 0, s, g); break;
         default: return APX_E_ARG;
     }
     APX_LAUNCH_CHECK();
@@ -376,28 +476,89 @@ static int launch_gemm(int epi, const GemmArgs& g0, int ksplit, hipStream_t s) {
 // Y[B,Dout] = act(X[B,Din] W^T + b), W torch layout [Dout, Din]
 static int linear_fwd(const float* X, const float* W, const float* b, float* Y, long B, int Din, int Dout, bool relu,
                       hipStream_t s, int prec = 0) {
-    GemmArgs g{X, Din, 1, W, 1, Din, Y, Dout, b, 0, (int)B, Dout, Din, 0, prec};
+    GemmArgs g{X, Din, 1, W, 1, Din, Y, Dout, b, 0, (int)B, Dout, Din, 0, 0, prec};
     return launch_gemm(relu ? EPI_BIAS_RELU : EPI_BIAS, g, 1, s);
 }
 // dX[B,Din] = (dY[B,Dout] W) * (mask > 0)   (mask = saved post-ReLU activation of the layer below, or NULL)
 static int linear_bwd_input(const float* dY, const float* W, const float* mask, float* dX, long B, int Din, int Dout,
                             hipStream_t s, int prec = 0) {
-    GemmArgs g{dY, Dout, 1, W, Din, 1, dX, Din, mask, Din, (int)B, Din, Dout, 0, prec};
+    GemmArgs g{dY, Dout, 1, W, Din, 1, dX, Din, mask, Din, (int)B, Din, Dout, 0, 0, prec};
     return launch_gemm(mask ? EPI_MASK : EPI_STORE, g, 1, s);
 }
-// dW[Dout,Din] += dY^T X  (split-K over the batch, fp32 atomics)
+// dW[Dout,Din] += dY^T X  (split-K over the batch)
 // db[Dout] += column sums of dY, fused into the same launch (they ride on the dY tile already in LDS)
-static int linear_bwd_weight(const float* dY, const float* X, float* dW, float* db, long B, int Din, int Dout, hipStream_t s, int prec = 0) {
-    GemmArgs g{dY, 1, Dout, X, Din, 1, dW, Din, db, 0, Dout, Din, (int)B, 0, prec};
-    // split-K sized to the chip, not to the batch: about 1024 workgroups whatever the shape of dW, at least 64 batch rows per workgroup.  More splits only add
-    // atomics (the 256 x 256 gradient at 128 splits is 8.4 M atomic adds = 55 us, L2-atomic bound), fewer leave CUs idle on the 10 x 256 and 256 x 50 gradients
-    // (measured with APX_KSPLIT_WGS = 256 / 512 / 1024 / 2048 on the bench minibatch, tools/t_ksplit_sweep.sh: backward 10 GEMMs 391 / 327 / 324 / 358 us).
+// Two ways to add the K chunks up.  fp32 atomics straight into dW: simple, but the L2 atomic units bound the launch (the 256 x 256 gradient at 64 chunks is 4.2 M atomic adds,
+// the 256 x 50 one at 256 chunks 3.3 M: 20 - 30 us each, more than their MFMA time).  Or, when the caller lends scratch (GradParts): every chunk STORES its product to its own
+// slab and ONE grad_reduce_kernel per minibatch adds the slabs of all six weight gradients into the flat gradient - coalesced streams instead of atomics.
+struct GradSeg { float* dst; const float* src; int count, nz; };
+struct GradParts {
+    float* scratch; size_t cap, used;      // floats
+    GradSeg seg[8]; int nseg;
+};
+constexpr size_t GRAD_PART_FLOATS = (size_t)1024 * GBM * GBN;      // upper bound of one weight gradient's slabs: about 1024 workgroups x one 64 x 64 tile each
+static int linear_bwd_weight(const float* dY, const float* X, float* dW, float* db, long B, int Din, int Dout, hipStream_t s, int prec = 0, GradParts* parts = nullptr) {
+    GemmArgs g{dY, 1, Dout, X, Din, 1, dW, Din, db, 0, Dout, Din, (int)B, 0, 0, prec};
+    // split-K sized to the chip, not to the batch: about 1024 workgroups whatever the shape of dW, at least 64 batch rows per workgroup (fewer leave CUs idle on the
+    // 10 x 256 and 256 x 50 gradients; measured with APX_KSPLIT_WGS = 256 / 512 / 1024 / 2048 on the bench minibatch, tools/t_ksplit_sweep.sh)
     const long tiles = (long)apx_cdiv(Dout, GBM) * apx_cdiv(Din, GBN);
     static const long target_wgs = getenv("APX_KSPLIT_WGS") ? atol(getenv("APX_KSPLIT_WGS")) : 1024;
     long ksplit = target_wgs / tiles;
+    static const long ks128 = getenv("APX_KSPLIT128") ? atol(getenv("APX_KSPLIT128")) : 64;
+    if (parts && prec == 0 && Dout % G2M == 0 && Din % G2N == 0) ksplit = ks128;      // 128 x 128 tiles (gemm_f32_128_kernel): 4 tiles x 64 chunks = one workgroup per CU
     if (ksplit > B / 64) ksplit = B / 64;
     if (ksplit < 1) ksplit = 1;
+    if (parts && prec == 0 && ksplit > 1 && parts->nseg < 8) {
+        int kchunk = (int)((B + ksplit - 1) / ksplit); kchunk = ((kchunk + GBK - 1) / GBK) * GBK;
+        const int nz = (int)((B + kchunk - 1) / kchunk);
+        const size_t need = (size_t)nz * Dout * Din;
+        if (parts->used + need <= parts->cap) {
+            float* slab = parts->scratch + parts->used; parts->used += need;
+            g.C = slab; g.part_stride = (long)Dout * Din;
+            parts->seg[parts->nseg++] = GradSeg{dW, slab, Dout * Din, nz};
+            return launch_gemm(EPI_PARTIAL, g, (int)ksplit, s);
+        }
+    }
     return launch_gemm(EPI_ATOMIC, g, (int)ksplit, s);
+}
+struct GradSegs { GradSeg seg[8]; int nseg; };
+// 64 elements x 4 groups of slabs per workgroup: the slab loop is a chain of dependent-latency loads, so the parallelism comes from threads, not from the loop
+__global__ __launch_bounds__(256) void grad_reduce_kernel(GradSegs G) {
+    __shared__ float part[4][64];
+    const int el = threadIdx.x & 63, zg = threadIdx.x >> 6;
+    long e = blockIdx.x * 64l + el;
+    float sum = 0.f; float* dst = nullptr;
+#pragma unroll 1
+    for (int k = 0; k < G.nseg; ++k) {
+        const GradSeg& q = G.seg[k];
+        const long padded = ((long)q.count + 63) / 64 * 64;      // a workgroup never straddles two segments
+        if (e < padded) {
+            if (e < q.count) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                const int z0 = (int)((long)q.nz * zg / 4), z1 = (int)((long)q.nz * (zg + 1) / 4);
+                int z = z0;
+                for (; z + 3 < z1; z += 4) {
+                    a0 += q.src[(long)z * q.count + e]; a1 += q.src[(long)(z + 1) * q.count + e]; a2 += q.src[(long)(z + 2) * q.count + e]; a3 += q.src[(long)(z + 3) * q.count + e];
+                }
+                for (; z < z1; ++z) a0 += q.src[(long)z * q.count + e];
+                sum = (a0 + a1) + (a2 + a3); dst = q.dst + e;
+            }
+            break;
+        }
+        e -= padded;
+    }
+    part[zg][el] = sum;
+    __syncthreads();
+    if (zg == 0 && dst) *dst += (part[0][el] + part[1][el]) + (part[2][el] + part[3][el]);
+}
+static int grad_reduce(GradParts& parts, hipStream_t s) {
+    if (parts.nseg == 0) return APX_OK;
+    GradSegs G; long total = 0;
+    for (int k = 0; k < parts.nseg; ++k) { G.seg[k] = parts.seg[k]; total += ((long)parts.seg[k].count + 63) / 64; }
+    G.nseg = parts.nseg;
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3(total), dim3(256), 0, s, G);
+    APX_LAUNCH_CHECK();
+    parts.nseg = 0; parts.used = 0;
+    return APX_OK;
 }
 
 extern "C" size_t apx_mlp_param_count(int D, int H, int O) {
@@ -552,14 +713,14 @@ static int mlp_forward_impl(const float* params, int D, int H, int O, const floa
 
 // grads += d(loss)/d(params) given dy = d(loss)/d(y); dh1/dh2 are [B,H] scratch
 static int mlp_backward_impl(const float* params, float* grads, int D, int H, int O, const float* xn, const float* a1,
-                             const float* a2, const float* dy, long B, float* dh2, float* dh1, hipStream_t s, int prec = 0) {
+                             const float* a2, const float* dy, long B, float* dh2, float* dh1, hipStream_t s, int prec = 0, GradParts* parts = nullptr) {
     MlpView p(params, D, H, O);
     MlpGrad g(grads, D, H, O);
-    APX_TRY(linear_bwd_weight(dy, a2, g.W2, g.b2, B, H, O, s, prec));
+    APX_TRY(linear_bwd_weight(dy, a2, g.W2, g.b2, B, H, O, s, prec, parts));
     APX_TRY(linear_bwd_input(dy, p.W2, a2, dh2, B, H, O, s, prec));
-    APX_TRY(linear_bwd_weight(dh2, a1, g.W1, g.b1, B, H, H, s, prec));
+    APX_TRY(linear_bwd_weight(dh2, a1, g.W1, g.b1, B, H, H, s, prec, parts));
     APX_TRY(linear_bwd_input(dh2, p.W1, a1, dh1, B, H, H, s, prec));
-    APX_TRY(linear_bwd_weight(dh1, xn, g.W0, g.b0, B, D, H, s, prec));
+    APX_TRY(linear_bwd_weight(dh1, xn, g.W0, g.b0, B, D, H, s, prec, parts));
     return APX_OK;
 }
 
@@ -1137,7 +1298,7 @@ extern "C" int apx_clip_adam(float* param, float* m, float* v, float* grad, int6
 static size_t align_up(size_t x) { return (x + 63) & ~(size_t)63; }
 
 struct PpoWs {
-    float *xn, *xm, *xr, *a1, *a2, *m1, *m2, *c1, *c2, *mu, *mum, *v, *dmu, *dmum, *dv, *dh2, *dh1;
+    float *xn, *xm, *xr, *a1, *a2, *m1, *m2, *c1, *c2, *mu, *mum, *v, *dmu, *dmum, *dv, *dh2, *dh1, *parts;
     double* acc;
     size_t bytes;
     PpoWs(void* base, long mb, int D, int H, int A) {
@@ -1151,6 +1312,7 @@ struct PpoWs {
         mu = take(2 * mb * A); mum = mu + mb * A; v = take(mb);
         dmu = take(2 * mb * A); dmum = dmu + mb * A; dv = take(mb);
         dh2 = take(2 * mb * H); dh1 = take(2 * mb * H);
+        parts = take(6 * GRAD_PART_FLOATS);      // K-chunk slabs of the six weight gradients of a minibatch (linear_bwd_weight)
         acc = (double*)(p + off); off += align_up(16 * sizeof(double));
         bytes = off;
     }
@@ -1203,8 +1365,10 @@ extern "C" int apx_ppo_minibatch(const apx_ppo_args* a, void* stream) {
     hipLaunchKernelGGL(finish_scalars_kernel, dim3(1), dim3(1), 0, s, w.acc, a->fixed_std, a->scalars_out);
     APX_LAUNCH_CHECK();
     // backwards
-    APX_TRY(mlp_backward_impl(a->actor, a->actor_grad, D, H, A, w.xn, w.a1, w.a2, w.dmu, ma, w.dh2, w.dh1, s, prec));      // both instances: 2 mb rows
-    APX_TRY(mlp_backward_impl(a->critic, a->critic_grad, D, H, 1, w.xr, w.c1, w.c2, w.dv, mb, w.dh2, w.dh1, s, prec));
+    GradParts parts{w.parts, 6 * GRAD_PART_FLOATS, 0, {}, 0};
+    APX_TRY(mlp_backward_impl(a->actor, a->actor_grad, D, H, A, w.xn, w.a1, w.a2, w.dmu, ma, w.dh2, w.dh1, s, prec, &parts));      // both instances: 2 mb rows
+    APX_TRY(mlp_backward_impl(a->critic, a->critic_grad, D, H, 1, w.xr, w.c1, w.c2, w.dv, mb, w.dh2, w.dh1, s, prec, &parts));
+    APX_TRY(grad_reduce(parts, s));                     // the K-chunk slabs of the six weight gradients -> the flat gradient, one launch
     if (a->grad_only) return APX_OK;
     APX_TRY(clip_adam_impl(a->actor, a->actor_m, a->actor_v, a->actor_grad, (int64_t)na, 1.f, a->grad_clip, a->lr,
                            a->adam_eps, a->adam_t, w.acc + 8, s, false));      // (w.acc was cleared above: no second fill)
