@@ -520,6 +520,56 @@ static int linear_bwd_weight(const float* dY, const float* X, float* dW, float* 
     }
     return launch_gemm(EPI_ATOMIC, g, (int)ksplit, s);
 }
+// Output layer of the backward pass, one launch instead of two GEMMs: dW2 = dY^T A2 (K chunk slab), db2 += column sums of dY, and dH2 = (dY W2) * (A2 > 0).  With O = 10 (or 1)
+// outputs both products are 10 multiply-adds per element of A2 and the launch is the stream A2 in, dH2 out; as 64 x 64 MFMA tiles they were two launches that each read A2
+// (and wasted 54 of the 64 tile rows).  One thread per hidden column: W2's column and the O running sums stay in registers, the chunk's rows of dY are broadcast from LDS.
+#define BH_ROWS 64
+template <int O>
+__global__ __launch_bounds__(256) void bwd_head_kernel(const float* __restrict__ dY, const float* __restrict__ W2, const float* __restrict__ A2, float* __restrict__ dH2,
+                                                       float* __restrict__ slab, float* __restrict__ db, long B, int H) {
+    __shared__ float dys[BH_ROWS][O];
+    const int tid = threadIdx.x;
+    const long r0 = (long)blockIdx.x * BH_ROWS;
+    const int nr = (int)min((long)BH_ROWS, B - r0);
+    for (int e = tid; e < BH_ROWS * O; e += 256) { const int r = e / O, o = e - r * O; dys[r][o] = r < nr ? dY[(r0 + r) * O + o] : 0.f; }
+    __syncthreads();
+    for (int c = tid; c < H; c += 256) {
+        float w[O], acc[O];
+#pragma unroll
+        for (int o = 0; o < O; ++o) { w[o] = W2[(long)o * H + c]; acc[o] = 0.f; }
+        auto row = [&](int r, float a) {
+            float d = 0.f;
+#pragma unroll
+            for (int o = 0; o < O; ++o) { d += dys[r][o] * w[o]; acc[o] += dys[r][o] * a; }
+            dH2[(r0 + r) * H + c] = a > 0.f ? d : 0.f;
+        };
+        if (nr == BH_ROWS) {      // whole chunk: 16 rows of A2 in flight per thread (the launch is a stream, its speed is the number of loads in flight)
+#pragma unroll 1
+            for (int rb = 0; rb < BH_ROWS; rb += 16) {
+                float av[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) av[k] = A2[(r0 + rb + k) * H + c];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) row(rb + k, av[k]);
+            }
+        } else for (int r = 0; r < nr; ++r) row(r, A2[(r0 + r) * H + c]);
+#pragma unroll
+        for (int o = 0; o < O; ++o) slab[(long)blockIdx.x * O * H + (long)o * H + c] = acc[o];
+    }
+    if (tid < O) { float b = 0.f; for (int r = 0; r < BH_ROWS; ++r) b += dys[r][tid]; atomicAdd(db + tid, b); }
+}
+// returns false when the shape / scratch does not fit (the caller falls back to the two GEMMs)
+static bool bwd_head(const float* dY, const float* W2, const float* A2, float* dH2, float* dW2, float* db2, long B, int H, int O, GradParts* parts, hipStream_t s) {
+    if (!parts || parts->nseg >= 8 || (O != 1 && O != 10)) return false;
+    const int nz = (int)apx_cdiv(B, BH_ROWS);
+    const size_t need = (size_t)nz * O * H;
+    if (parts->used + need > parts->cap) return false;
+    float* slab = parts->scratch + parts->used; parts->used += need;
+    parts->seg[parts->nseg++] = GradSeg{dW2, slab, O * H, nz};
+    if (O == 10) hipLaunchKernelGGL(bwd_head_kernel<10>, dim3(nz), dim3(256), 0, s, dY, W2, A2, dH2, slab, db2, B, H);
+    else hipLaunchKernelGGL(bwd_head_kernel<1>, dim3(nz), dim3(256), 0, s, dY, W2, A2, dH2, slab, db2, B, H);
+    return hipGetLastError() == hipSuccess;
+}
 struct GradSegs { GradSeg seg[8]; int nseg; };
 // 64 elements x 4 groups of slabs per workgroup: the slab loop is a chain of dependent-latency loads, so the parallelism comes from threads, not from the loop
 __global__ __launch_bounds__(256) void grad_reduce_kernel(GradSegs G) {
@@ -716,8 +766,10 @@ static int mlp_backward_impl(const float* params, float* grads, int D, int H, in
                              const float* a2, const float* dy, long B, float* dh2, float* dh1, hipStream_t s, int prec = 0, GradParts* parts = nullptr) {
     MlpView p(params, D, H, O);
     MlpGrad g(grads, D, H, O);
-    APX_TRY(linear_bwd_weight(dy, a2, g.W2, g.b2, B, H, O, s, prec, parts));
-    APX_TRY(linear_bwd_input(dy, p.W2, a2, dh2, B, H, O, s, prec));
+    if (!(prec == 0 && bwd_head(dy, p.W2, a2, dh2, g.W2, g.b2, B, H, O, parts, s))) {
+        APX_TRY(linear_bwd_weight(dy, a2, g.W2, g.b2, B, H, O, s, prec, parts));
+        APX_TRY(linear_bwd_input(dy, p.W2, a2, dh2, B, H, O, s, prec));
+    }
     APX_TRY(linear_bwd_weight(dh2, a1, g.W1, g.b1, B, H, H, s, prec, parts));
     APX_TRY(linear_bwd_input(dh2, p.W1, a1, dh1, B, H, H, s, prec));
     APX_TRY(linear_bwd_weight(dh1, xn, g.W0, g.b0, B, D, H, s, prec, parts));
