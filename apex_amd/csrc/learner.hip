@@ -1346,6 +1346,61 @@ extern "C" int apx_clip_adam(float* param, float* m, float* v, float* grad, int6
     return clip_adam_impl(param, m, v, grad, n, grad_scale, grad_clip, lr, adam_eps, adam_t, sumsq_scratch, (hipStream_t)stream, true);
 }
 
+// ---- the small launches of a minibatch, merged (each launch is ~5 us of stream time whatever it does: 13 of them were a tenth of the minibatch)
+// head: clears the loss accumulators and the flat gradient, gathers + normalises the minibatch rows (xn) and their mirrored copy (xm = xn + rows * D)
+__global__ __launch_bounds__(256) void ppo_head_kernel(const float* __restrict__ x, int64_t rows, int D, const int64_t* __restrict__ idx, const int32_t* __restrict__ sign_perm,
+                                                       uint64_t clock_mask, const float* __restrict__ mean, const float* __restrict__ stdv, float* __restrict__ xn,
+                                                       float* __restrict__ grad, int64_t ngrad, float* __restrict__ acc32) {
+    const int64_t e0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = e0; e < ngrad; e += stride) grad[e] = 0.f;
+    if (e0 < 32) acc32[e0] = 0.f;
+    const int64_t total = (sign_perm ? 2 : 1) * rows * D;
+    for (int64_t e = e0; e < total; e += stride) {
+        const bool mir = e >= rows * D;
+        const int64_t f = mir ? e - rows * D : e, b = f / D;
+        const int c = (int)(f - b * D);
+        const int64_t row = idx ? idx[b] : b;
+        float v;
+        if (mir) {
+            const int32_t sp = sign_perm[c];
+            v = sp >= 0 ? x[row * D + sp] : -x[row * D + (-sp - 1)];
+            if (c < 64 && ((clock_mask >> c) & 1ull)) v = sinf(asinf(v) + 3.14159265358979323846f);  // wrappers.py:65-66
+        } else v = x[row * D + c];
+        xn[e] = (v - mean[c]) / stdv[c];
+    }
+}
+// tail: squared gradient norms of both networks in one launch (+ the loss scalars), then both clipped Adam steps in one launch
+struct AdamSeg { float *p, *m, *v; const float* g; int64_t n; const double* sumsq; };
+__global__ __launch_bounds__(256) void sumsq2_kernel(const float* __restrict__ ga, int64_t na, double* __restrict__ outa, const float* __restrict__ gc, int64_t nc,
+                                                     double* __restrict__ outc, int blocks_a, const double* acc, float sd, double* scal) {
+    const bool first = (int)blockIdx.x < blocks_a;
+    const float* g = first ? ga : gc; const int64_t n = first ? na : nc;
+    const int b = first ? blockIdx.x : blockIdx.x - blocks_a, nb = first ? blocks_a : gridDim.x - blocks_a;
+    double a[1] = {0};
+    for (int64_t i = b * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)nb * blockDim.x) a[0] += (double)g[i] * (double)g[i];
+    block_atomic_add<1>(a, first ? outa : outc);
+    if (scal && blockIdx.x == 0 && threadIdx.x == 0) {      // (finish_scalars_kernel)
+        scal[0] = acc[0]; scal[1] = 0.5 + 0.5 * log(2.0 * 3.14159265358979323846) + log((double)sd); scal[2] = acc[4]; scal[3] = acc[1]; scal[4] = acc[2]; scal[5] = acc[3];
+    }
+}
+__global__ __launch_bounds__(256) void clip_adam2_kernel(AdamSeg A, AdamSeg C, int blocks_a, float grad_clip, float step_size, float inv_bc2_sqrt, float eps) {
+    const bool first = (int)blockIdx.x < blocks_a;
+    const AdamSeg& S = first ? A : C;
+    const int b = first ? blockIdx.x : blockIdx.x - blocks_a, nb = first ? blocks_a : gridDim.x - blocks_a;
+    // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), applied when < 1
+    const float total = (float)sqrt(*S.sumsq);
+    float coef = grad_clip / (total + 1e-6f);
+    coef = coef < 1.f ? coef : 1.f;
+    for (int64_t i = b * (int64_t)blockDim.x + threadIdx.x; i < S.n; i += (int64_t)nb * blockDim.x) {
+        const float gi = S.g[i] * coef;
+        const float mi = 0.9f * S.m[i] + 0.1f * gi;
+        const float vi = 0.999f * S.v[i] + 0.001f * gi * gi;
+        S.m[i] = mi; S.v[i] = vi;
+        const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+        S.p[i] -= step_size * (mi / denom);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ PPO minibatch
 static size_t align_up(size_t x) { return (x + 63) & ~(size_t)63; }
 
@@ -1392,16 +1447,19 @@ extern "C" int apx_ppo_minibatch(const apx_ppo_args* a, void* stream) {
     const bool mirror = a->obs_sign_perm != nullptr;
     PpoWs w(a->workspace, mb, D, H, A);
     const size_t na = apx_mlp_param_count(D, H, A), nc = apx_mlp_param_count(D, H, 1);
-    APX_HIP(hipMemsetAsync(w.acc, 0, 16 * sizeof(double), s));
-    if (a->critic_grad == a->actor_grad + na) APX_HIP(hipMemsetAsync(a->actor_grad, 0, (na + nc) * sizeof(float), s));      // one flat gradient buffer (engine.PPOLearner): one fill
-    else {
-        APX_HIP(hipMemsetAsync(a->actor_grad, 0, na * sizeof(float), s));
-        APX_HIP(hipMemsetAsync(a->critic_grad, 0, nc * sizeof(float), s));
-    }
     // forwards: pi(s) and pi(M_s s) as ONE pass over 2 mb rows
     const long ma = mirror ? 2 * mb : mb;
-    APX_TRY(prep_obs(a->obs, mb, D, a->idx, nullptr, 0, a->obs_mean, a->obs_std, w.xn, s));
-    if (mirror) APX_TRY(prep_obs(a->obs, mb, D, a->idx, a->obs_sign_perm, a->clock_mask, a->obs_mean, a->obs_std, w.xm, s));
+    if (a->critic_grad == a->actor_grad + na) {      // one flat gradient buffer (engine.PPOLearner): clears, gather and mirror in one launch
+        hipLaunchKernelGGL(ppo_head_kernel, dim3(apx_cdiv(ma * D, 256)), dim3(256), 0, s, a->obs, (int64_t)mb, D, a->idx, a->obs_sign_perm, a->clock_mask, a->obs_mean, a->obs_std,
+                           w.xn, a->actor_grad, (int64_t)(na + nc), (float*)w.acc);
+        APX_LAUNCH_CHECK();
+    } else {
+        APX_HIP(hipMemsetAsync(w.acc, 0, 16 * sizeof(double), s));
+        APX_HIP(hipMemsetAsync(a->actor_grad, 0, na * sizeof(float), s));
+        APX_HIP(hipMemsetAsync(a->critic_grad, 0, nc * sizeof(float), s));
+        APX_TRY(prep_obs(a->obs, mb, D, a->idx, nullptr, 0, a->obs_mean, a->obs_std, w.xn, s));
+        if (mirror) APX_TRY(prep_obs(a->obs, mb, D, a->idx, a->obs_sign_perm, a->clock_mask, a->obs_mean, a->obs_std, w.xm, s));
+    }
     APX_TRY(mlp_forward_impl(a->actor, D, H, A, w.xn, ma, w.a1, w.a2, w.mu, s, prec));
     if (prec == 0 && fused_ok(D, H, 1))      // critic: raw obs (critic.py:66); the row gather rides in the fused forward, which also leaves the gathered rows in w.xr for the backward
         APX_TRY(mlp_fused_launch(a->critic, D, H, 1, FusedIn{a->obs, a->idx, nullptr, 0, nullptr, nullptr, w.xr}, mb, w.c1, w.c2, w.v, s));
@@ -1414,17 +1472,21 @@ extern "C" int apx_ppo_minibatch(const apx_ppo_args* a, void* stream) {
                w.dmu, w.dmum, w.dv, w.acc, mb, A, a->fixed_std, a->clip, a->mirror_coeff};
     hipLaunchKernelGGL(ppo_loss_kernel, dim3(apx_cdiv(mb, 256)), dim3(256), 0, s, L);
     APX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(finish_scalars_kernel, dim3(1), dim3(1), 0, s, w.acc, a->fixed_std, a->scalars_out);
-    APX_LAUNCH_CHECK();
+    if (a->grad_only) { hipLaunchKernelGGL(finish_scalars_kernel, dim3(1), dim3(1), 0, s, w.acc, a->fixed_std, a->scalars_out); APX_LAUNCH_CHECK(); }      // (otherwise: in the tail)
     // backwards
     GradParts parts{w.parts, 6 * GRAD_PART_FLOATS, 0, {}, 0};
     APX_TRY(mlp_backward_impl(a->actor, a->actor_grad, D, H, A, w.xn, w.a1, w.a2, w.dmu, ma, w.dh2, w.dh1, s, prec, &parts));      // both instances: 2 mb rows
     APX_TRY(mlp_backward_impl(a->critic, a->critic_grad, D, H, 1, w.xr, w.c1, w.c2, w.dv, mb, w.dh2, w.dh1, s, prec, &parts));
     APX_TRY(grad_reduce(parts, s));                     // the K-chunk slabs of the six weight gradients -> the flat gradient, one launch
     if (a->grad_only) return APX_OK;
-    APX_TRY(clip_adam_impl(a->actor, a->actor_m, a->actor_v, a->actor_grad, (int64_t)na, 1.f, a->grad_clip, a->lr,
-                           a->adam_eps, a->adam_t, w.acc + 8, s, false));      // (w.acc was cleared above: no second fill)
-    APX_TRY(clip_adam_impl(a->critic, a->critic_m, a->critic_v, a->critic_grad, (int64_t)nc, 1.f, a->grad_clip, a->lr,
-                           a->adam_eps, a->adam_t, w.acc + 9, s, false));
+    {   // (w.acc was cleared by the head: no second fill)
+        const int ba = (int)((na + 255) / 256 < 384 ? (na + 255) / 256 : 384), bc = (int)((nc + 255) / 256 < 384 ? (nc + 255) / 256 : 384);
+        hipLaunchKernelGGL(sumsq2_kernel, dim3(ba + bc), dim3(256), 0, s, a->actor_grad, (int64_t)na, w.acc + 8, a->critic_grad, (int64_t)nc, w.acc + 9, ba, w.acc, a->fixed_std, a->scalars_out);
+        APX_LAUNCH_CHECK();
+        const double bc1 = 1.0 - pow(0.9, a->adam_t), bc2 = 1.0 - pow(0.999, a->adam_t);
+        hipLaunchKernelGGL(clip_adam2_kernel, dim3(ba + bc), dim3(256), 0, s, AdamSeg{a->actor, a->actor_m, a->actor_v, a->actor_grad, (int64_t)na, w.acc + 8},
+                           AdamSeg{a->critic, a->critic_m, a->critic_v, a->critic_grad, (int64_t)nc, w.acc + 9}, ba, a->grad_clip, (float)(a->lr / bc1), (float)(1.0 / sqrt(bc2)), a->adam_eps);
+        APX_LAUNCH_CHECK();
+    }
     return APX_OK;
 }
