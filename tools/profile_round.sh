@@ -13,6 +13,7 @@ cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/kt -- python $ROOT/bench.py --steps 5 --warmup 1 > $OUT/bench_under_rocprof.log 2>&1 || true
 grep '^{' $OUT/bench_under_rocprof.log | tail -1 > $OUT/${TAG}_bench_line_under_rocprof.json
 python $ROOT/tools/rocprof_summary.py $(ls $OUT/kt/*/*.db | head -1) $OUT/${TAG}_bench_kernel_stats.txt > /dev/null
+python $ROOT/tools/rocprof_timeline.py $(ls $OUT/kt/*/*.db | head -1) $OUT/${TAG}_timeline.txt > /dev/null || true      # what runs between two env steps / inside one learner minibatch
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/sq -- python $ROOT/tools/t_pmc.py > $OUT/sq.log 2>&1 || true
 python $ROOT/tools/pmc_summary.py $OUT/sq $OUT/${TAG}_env_step_pmc_sq.txt "# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -- python tools/t_pmc.py (per-dispatch means)" > /dev/null
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python $ROOT/tools/t_pmc.py > $OUT/fetch.log 2>&1 || true
@@ -45,5 +46,10 @@ bash tools/profile_issue.sh $TAG > $OUT/issue.log 2>&1 || true
 cp gpurun_out/prof_issue_$TAG/${TAG}_env_step_pmc_issue.txt gpurun_out/prof_issue_$TAG/${TAG}_icache_probe.txt $OUT/ 2>/dev/null || true
 #   5. -ffast-math A/B of the env kernel (needs lib/libapx_nofm.so: make -C apex_amd/csrc VARIANT=nofm FASTMATH=)  -> profiles/<tag>_fastmath_ab.json
 if [ -f apex_amd/lib/libapx_nofm.so ]; then python tools/t_fastmath_ab.py > $OUT/${TAG}_fastmath_ab.json 2>$OUT/fastmath_ab.err || true; fi
+#   6. stage profile of the env kernel (shader-clock probes; needs lib/libapx_prof.so and libapx_prof2.so)  -> profiles/<tag>_stage_profile.txt
+if [ -f apex_amd/lib/libapx_prof.so ]; then
+  { echo "# stage profile (APX_LIB=apex_amd/lib/libapx_prof.so / libapx_prof2.so python tools/t_prof.py), kernel sources sha1 $HASH"; APX_LIB=$ROOT/apex_amd/lib/libapx_prof.so python tools/t_prof.py 2>/dev/null;
+    echo "# fine probes (-DAPX_PROF=2)"; APX_LIB=$ROOT/apex_amd/lib/libapx_prof2.so python tools/t_prof.py 2>/dev/null; } > $OUT/${TAG}_stage_profile.txt || true
+fi
 rm -rf $OUT/kt $OUT/sq $OUT/fetch $OUT/write $OUT/hbm
 ls -la $OUT
