@@ -27,6 +27,9 @@ def main():
     out.append("# one step in detail (kernel, duration us, idle gap in front us)")
     for i in range(steps[-3], steps[-2] + 1):
         n, s0, e0 = rows[i]; out.append("  %-50s %8.2f %8.2f" % (n, (e0 - s0) / 1e3, (s0 - rows[i - 1][2]) / 1e3))
+    gaps = sorted(((rows[i + 1][1] - max(r[2] for r in rows[max(a, i - 3):i + 1]), i) for i in range(a, b)), reverse=True)[:14]
+    out.append("# largest idle gaps inside the span (us, after kernel -> before kernel)")
+    for gp, i in gaps: out.append("  %8.1f  %s -> %s" % (gp / 1e3, rows[i][0][-40:], rows[i + 1][0][-40:]))
     pre = [i for i, r in enumerate(rows) if "ppo_loss_kernel" in r[0]]
     if len(pre) > 3:
         out.append("# one minibatch of the learner in detail (kernel, duration us, idle gap in front us)")
