@@ -19,7 +19,6 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak = fp32 MFMA peak (MI355X_MICROARCH.md)
-BF16_MFMA_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
 
 
 def cpu_baseline(seconds_hint=12.0, n_envs=4096, rollout_len=32, minibatch=16384, epochs=3):
@@ -228,8 +227,6 @@ def main():
     ap.add_argument("--minibatch", type=int, default=16384)
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
-                    help="learner GEMMs: f32 = fp32 MFMA (parity mode, the default headline line); bf16 = bf16 MFMA inputs, fp32 accumulate, fp32 master weights (BASELINE configs[1] throughput variant)")
     ap.add_argument("--workload", default="cassie_ppo", choices=["cassie_ppo", "cassietraj_recurrent", "cassie_td3"],
                     help="cassie_ppo = BASELINE.json configs[1] (the headline, default); cassietraj_recurrent = configs[3]: CassieTraj-v0, LSTM 2x128, 2048 envs/GPU; cassie_td3 = configs[4]: TD3, 1M-transition replay in HBM")
     a = ap.parse_args()
@@ -256,7 +253,7 @@ def main():
     env = CassieVecEnv(n_envs=a.n_envs, seed=0, device=local, env_id_base=adist.shard_env_base(rank, a.n_envs))
     args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=a.minibatch,
                 epochs=a.epochs, num_steps=a.rollout_len * a.n_envs * world, max_traj_len=400, max_grad_norm=0.05,
-                mirror=True, std_dev=-1.5, seed=0, graph=os.environ.get("APX_ROLLOUT_GRAPH", "0") == "1", precision=1 if a.precision == "bf16" else 0)
+                mirror=True, std_dev=-1.5, seed=0, graph=os.environ.get("APX_ROLLOUT_GRAPH", "0") == "1", precision=0)      # fp32 MFMA, the parity mode, is the only mode of the bench (the bf16 GEMM option of the library was worth +0.6 % end to end: DESIGN.md section 4.3)
     algo = PPO(args, "/tmp/apx_bench_unused", env, rank=rank, world_size=world, group=group)
     algo.init_networks(0)
     algo.normalization_params(10000)
@@ -308,17 +305,6 @@ def main():
     g1.record(); torch.cuda.synchronize()
     mlp_ms = g0.elapsed_time(g1) / 20
     mlp_flop = 2.0 * mb_rows * (50 * 256 + 256 * 256 + 256 * 10)
-    mlp_bf16 = None
-    if a.precision == "bf16":       # the bf16 GEMM path (three launches: bf16 MFMA inputs, fp32 accumulate) is priced against the DENSE bf16 MFMA peak, not the fp32 one
-        for _ in range(3):
-            algo.learner.actor.forward(xb, algo.learner.obs_mean, algo.learner.obs_std, precision=1)
-        g0.record()
-        for _ in range(20):
-            algo.learner.actor.forward(xb, algo.learner.obs_mean, algo.learner.obs_std, precision=1)
-        g1.record(); torch.cuda.synchronize()
-        bms = g0.elapsed_time(g1) / 20
-        mlp_bf16 = {"what": "the same forward through gemm_bf16_kernel (v_mfma_f32_32x32x8bf16_1k), three launches", "ms": round(bms, 4), "achieved_tflops": round(mlp_flop / (bms * 1e-3) / 1e12, 2),
-                    "peak_tflops": BF16_MFMA_PEAK_TFLOPS, "frac": round(mlp_flop / (bms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 5)}
 
     if rank == 0:
         steps_total = a.steps * a.rollout_len * a.n_envs * world
@@ -333,7 +319,7 @@ def main():
             "metric": "env-steps/sec (whole node) Cassie-v0 PPO @4096 envs/GPU", "value": round(steps_total / dt, 1),
             "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.precision == "f32" else "bf16 (learner GEMM inputs; fp32 accumulate, master weights, physics and rollout policy)", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Cassie-v0 PPO, 4096 batched envs/GPU, 2x256 MLP actor/critic (BASELINE.json configs[1])",
                        "envs_per_gpu": a.n_envs, "rollout_len": a.rollout_len, "simrate": 50, "minibatch": a.minibatch,
                        "epochs": a.epochs, "mirror_loss": True, "dynamics_randomization": True, "eval_rollouts": False,
@@ -358,8 +344,6 @@ def main():
                                               "ms": round(mlp_ms, 4), "achieved_tflops": round(mlp_flop / (mlp_ms * 1e-3) / 1e12, 2),
                                               "peak_tflops": VALU_PEAK_TFLOPS, "frac": round(mlp_flop / (mlp_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)}},
         }
-        if mlp_bf16:
-            res["roofline"]["mlp_forward_mfma_bf16"] = mlp_bf16
         if cpu:
             res["cpu_baseline"] = cpu
         print(json.dumps(res))

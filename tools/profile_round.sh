@@ -24,7 +24,6 @@ python $ROOT/tools/pmc_summary.py $OUT/hbm $OUT/${TAG}_env_step_pmc_hbm.txt "# r
 cd $ROOT
 cp $OUT/${TAG}_env_step_pmc_hbm.txt $OUT/${TAG}_env_step_pmc_sq.txt $ROOT/profiles/ 2>/dev/null || true      # bench.py reads roofline.traffic from profiles/<tag>_env_step_pmc_hbm.txt (same kernel-source hash): the lines below carry it
 python bench.py --steps 20 --warmup 2 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line.json
-python bench.py --steps 20 --warmup 2 --precision bf16 --no_cpu_baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line_bf16.json
 python bench.py --workload cassietraj_recurrent --steps 3 --warmup 1 --no_cpu_baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line_recurrent.json
 #   4. per-kernel time of the recurrent workload (persistent LSTM layer kernels)          -> profiles/<tag>_recurrent_kernel_stats.txt
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/ktr -- python $ROOT/bench.py --workload cassietraj_recurrent --steps 2 --warmup 1 --no_cpu_baseline > $OUT/rec_under_rocprof.log 2>&1 || true)
