@@ -1470,7 +1470,7 @@ extern "C" int apx_ppo_minibatch(const apx_ppo_args* a, void* stream) {
     // losses
     LossArgs L{w.mu, mirror ? w.mum : nullptr, w.v, a->act, a->ret, a->adv, a->old_mu, a->idx, nullptr, a->act_sign_perm,
                w.dmu, w.dmum, w.dv, w.acc, mb, A, a->fixed_std, a->clip, a->mirror_coeff};
-    hipLaunchKernelGGL(ppo_loss_kernel, dim3(apx_cdiv(mb, 256)), dim3(256), 0, s, L);
+    hipLaunchKernelGGL(ppo_loss_kernel, dim3(apx_cdiv(mb, 64)), dim3(64), 0, s, L);
     APX_LAUNCH_CHECK();
     if (a->grad_only) { hipLaunchKernelGGL(finish_scalars_kernel, dim3(1), dim3(1), 0, s, w.acc, a->fixed_std, a->scalars_out); APX_LAUNCH_CHECK(); }      // (otherwise: in the tail)
     // backwards
