@@ -34,3 +34,6 @@ void apx_set_error(const char* fmt, ...);
     } while (0)
 
 static inline int apx_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+// learner.hip, used by env.hip's apx_rollout (internal, not exported through include/apx.h)
+int apx_mlp_forward_act(const float* params, int D, int H, int O, const float* x, int64_t B, const float* obs_mean, const float* obs_std, float* y, float* act,
+                        const float* noise, float sigma, void* stream);

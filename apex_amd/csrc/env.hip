@@ -960,10 +960,15 @@ extern "C" int apx_rollout(apx_env_t* e, const float* actor, int H, const float*
     const long N = e->n;
     for (int t = 0; t < T; ++t) {
         float* obs = obs_grid + (size_t)t * N * D; float* mu = mu_grid + (size_t)t * N * A; float* act = act_grid + (size_t)t * N * A;
-        int rc = apx_mlp_forward(actor, D, H, A, obs, N, nullptr, nullptr, 0, obs_mean, obs_std, nullptr, nullptr, nullptr, mu, 0, stream);
-        if (rc != APX_OK) return rc;
-        hipLaunchKernelGGL(act_noise_kernel, dim3(apx_cdiv(N * A, 256)), dim3(256), 0, (hipStream_t)stream, mu, noise ? noise + (size_t)t * N * A : nullptr, sigma, N * A, act);
-        APX_LAUNCH_CHECK();
+        const float* nz = noise ? noise + (size_t)t * N * A : nullptr;
+        int rc = apx_mlp_forward_act(actor, D, H, A, obs, N, obs_mean, obs_std, mu, act, nz, sigma, stream);      // forward + noise in one launch (the reference's 2 x 256 shape)
+        if (rc < 0) return APX_E_HIP;
+        if (rc == 0) {
+            rc = apx_mlp_forward(actor, D, H, A, obs, N, nullptr, nullptr, 0, obs_mean, obs_std, nullptr, nullptr, nullptr, mu, 0, stream);
+            if (rc != APX_OK) return rc;
+            hipLaunchKernelGGL(act_noise_kernel, dim3(apx_cdiv(N * A, 256)), dim3(256), 0, (hipStream_t)stream, mu, nz, sigma, N * A, act);
+            APX_LAUNCH_CHECK();
+        }
         rc = apx_env_step(e, act, t + 1 < T ? obs_grid + (size_t)(t + 1) * N * D : obs_next, rew_grid + (size_t)t * N, done_grid + (size_t)t * N,
                           fin_grid + (size_t)t * N * D, 1, stream);
         if (rc != APX_OK) return rc;

@@ -644,7 +644,8 @@ struct FusedLds { float (*A1s)[FBM + 1]; float (*A2s)[FBM + 1]; float (*Ws)[FBN 
 // one layer: out[32, N] = act(In[32, K] W^T + b), In = k-major LDS, W torch layout [N, K]; NKT = ceil(K / 16) k-tiles
 template <int NKT>
 __device__ __forceinline__ void fused_layer(const FusedLds& L, float (*In)[FBM + 1], int K, const float* __restrict__ W, const float* __restrict__ bias,
-                                            int N, bool relu, float (*OutS)[FBM + 1], float* __restrict__ outG, int ldo, long m0, long B) {
+                                            int N, bool relu, float (*OutS)[FBM + 1], float* __restrict__ outG, int ldo, long m0, long B,
+                                            float* __restrict__ actG = nullptr, const float* __restrict__ noise = nullptr, float sigma = 0.f) {
     // Round 4: the weight operand no longer goes through LDS.  A lane of v_mfma_f32_32x32x2_f32 holds B[k][n] for n = lane & 31 and ONE k per instruction; with the k of a
     // 16-deep tile dealt as k = 8 (lane >> 5) + j over the 8 instructions j of the tile (instead of 2 j + (lane >> 5)), a lane's eight operands are 32 contiguous bytes of
     // its weight row W[n][.]: four dwordx2 loads straight from L2 into the registers the MFMAs read, FPF tiles ahead.  No weight tile in LDS, no barrier inside a layer
@@ -693,12 +694,15 @@ __device__ __forceinline__ void fused_layer(const FusedLds& L, float (*In)[FBM +
             if (relu) v = fmaxf(v, 0.f);
             if (OutS && col < N) OutS[col][row] = v;
             if (outG && col < N && m0 + row < B) outG[(m0 + row) * ldo + col] = v;
+            if (actG && col < N && m0 + row < B) actG[(m0 + row) * ldo + col] = v + (noise ? sigma * noise[(m0 + row) * ldo + col] : 0.f);
         }
     }
     __syncthreads();
 }
 struct FusedIn {           // where the 32 x D input tile comes from: prepared rows (everything else NULL) or raw observations + the prep of prep_obs_kernel
     const float* x; const int64_t* idx; const int32_t* sign_perm; uint64_t clock_mask; const float *mean, *stdv; float* xn_out;
+    // optional epilogue of the output layer (the rollout, apx_rollout): act = y + sigma * noise (noise may be NULL: act = y), saving the act_noise launch of every env step
+    float* act_out; const float* noise; float sigma;
 };
 __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(const float* __restrict__ W0, const float* __restrict__ b0, const float* __restrict__ W1,
                                                             const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
@@ -731,7 +735,7 @@ __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(const float* __restr
     __syncthreads();
     fused_layer<4>(L, L.A2s, D, W0, b0, FH, true, L.A1s, a1, FH, m0, B);      // k-tiles beyond D: zero-padded X rows, zero-guarded weights
     fused_layer<FH / GBK>(L, L.A1s, FH, W1, b1, FH, true, L.A2s, a2, FH, m0, B);
-    fused_layer<FH / GBK>(L, L.A2s, FH, W2, b2, O, false, nullptr, y, O, m0, B);
+    fused_layer<FH / GBK>(L, L.A2s, FH, W2, b2, O, false, nullptr, y, O, m0, B, I.act_out, I.noise, I.sigma);
 }
 
 static bool g_fused_attr_set = false;
@@ -754,7 +758,7 @@ static int mlp_forward_impl(const float* params, int D, int H, int O, const floa
                             float* y, hipStream_t s, int prec = 0) {
     MlpView p(params, D, H, O);
     if (prec == 0 && fused_ok(D, H, O))       // one launch, activations stay in LDS (fp32 MFMA)
-        return mlp_fused_launch(params, D, H, O, FusedIn{xn, nullptr, nullptr, 0, nullptr, nullptr, nullptr}, B, a1, a2, y, s);
+        return mlp_fused_launch(params, D, H, O, FusedIn{xn, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f}, B, a1, a2, y, s);
     APX_TRY(linear_fwd(xn, p.W0, p.b0, a1, B, D, H, true, s, prec));
     APX_TRY(linear_fwd(a1, p.W1, p.b1, a2, B, H, H, true, s, prec));
     APX_TRY(linear_fwd(a2, p.W2, p.b2, y, B, H, O, false, s, prec));
@@ -795,10 +799,19 @@ extern "C" int apx_mlp_forward(const float* params, int D, int H, int O, const f
     APX_REQUIRE((obs_mean == nullptr) == (obs_std == nullptr), "obs_mean/obs_std");
     hipStream_t s = (hipStream_t)stream;
     if (precision == 0 && fused_ok(D, H, O))      // input prep inside the fused kernel; NULL outputs are simply not written
-        return mlp_fused_launch(params, D, H, O, FusedIn{x, idx, sign_perm, clock_mask, obs_mean, obs_std, xn_out}, B, act1, act2, y, s);
+        return mlp_fused_launch(params, D, H, O, FusedIn{x, idx, sign_perm, clock_mask, obs_mean, obs_std, xn_out, nullptr, nullptr, 0.f}, B, act1, act2, y, s);
     APX_REQUIRE(xn_out && act1 && act2, "xn_out / act1 / act2 may only be NULL for the fused fp32 shapes (H = 256, D <= 64, O <= 128)");
     APX_TRY(prep_obs(x, B, D, idx, sign_perm, clock_mask, obs_mean, obs_std, xn_out, s));
     return mlp_forward_impl(params, D, H, O, xn_out, B, act1, act2, y, s, precision);
+}
+
+// apx_rollout's policy step: mu = pi(normalise(obs)) and act = mu + sigma * noise in ONE launch when the fused shape applies (returns 1 if it did, 0 if the caller has to
+// run apx_mlp_forward + the noise kernel, < 0 on error); internal (apx_common.h), not part of the C ABI
+int apx_mlp_forward_act(const float* params, int D, int H, int O, const float* x, int64_t B, const float* obs_mean, const float* obs_std, float* y, float* act,
+                        const float* noise, float sigma, void* stream) {
+    if (!fused_ok(D, H, O) || B <= 0) return 0;
+    const int rc = mlp_fused_launch(params, D, H, O, FusedIn{x, nullptr, nullptr, 0, obs_mean, obs_std, nullptr, act, noise, sigma}, B, nullptr, nullptr, y, (hipStream_t)stream);
+    return rc == APX_OK ? 1 : -1;
 }
 
 // ------------------------------------------------------------------------------------------------ TD3 primitives (next row f2)
@@ -1462,7 +1475,7 @@ extern "C" int apx_ppo_minibatch(const apx_ppo_args* a, void* stream) {
     }
     APX_TRY(mlp_forward_impl(a->actor, D, H, A, w.xn, ma, w.a1, w.a2, w.mu, s, prec));
     if (prec == 0 && fused_ok(D, H, 1))      // critic: raw obs (critic.py:66); the row gather rides in the fused forward, which also leaves the gathered rows in w.xr for the backward
-        APX_TRY(mlp_fused_launch(a->critic, D, H, 1, FusedIn{a->obs, a->idx, nullptr, 0, nullptr, nullptr, w.xr}, mb, w.c1, w.c2, w.v, s));
+        APX_TRY(mlp_fused_launch(a->critic, D, H, 1, FusedIn{a->obs, a->idx, nullptr, 0, nullptr, nullptr, w.xr, nullptr, nullptr, 0.f}, mb, w.c1, w.c2, w.v, s));
     else {
         APX_TRY(prep_obs(a->obs, mb, D, a->idx, nullptr, 0, nullptr, nullptr, w.xr, s));
         APX_TRY(mlp_forward_impl(a->critic, D, H, 1, w.xr, mb, w.c1, w.c2, w.v, s, prec));
