@@ -104,7 +104,7 @@ __device__ __forceinline__ unsigned philox(unsigned k0, unsigned k1, unsigned en
     return c0;
 }
 // stream domains (4th counter word): 0 = the per-step command draws, ctr = the env's running counter I_RNG; 1 = reset draws, ctr = 128 * episode + k: a reset is a
-// function of (seed, env, episode index) alone, so the next episode's randomised model can be prepared ahead of time (env_reset_prepare_kernel)
+// function of (seed, env, episode index) alone, so the next episode's randomised model can be prepared ahead of time (env_reset_kernel, part 0)
 constexpr unsigned RNG_STEP = 0u, RNG_RESET = 1u, RNG_RESET_BLOCK = 128u, RNG_RESET_TAIL = 126u;
 struct Rng {
     unsigned k0, k1, env, ctr, dom;
