@@ -699,6 +699,47 @@ __device__ __forceinline__ void fused_layer(const FusedLds& L, float (*In)[FBM +
     }
     __syncthreads();
 }
+// The OUTPUT layer (N <= 32: one 32-column slice): as a column-sliced layer it is 16 k-tiles on wave 0 alone while the other three waves - and, with two workgroups per
+// CU, three of the four MFMA pipes - idle: SIMD 0 then carries 28.7 k MFMA cycles per workgroup against 20.5 k on the others and bounds the launch.  Here the K range is
+// dealt over the four waves (4 k-tiles each, all prefetched at once), the four partial accumulators meet in the (free) A1 tile and wave 0 runs the epilogue.
+template <int NKT>
+__device__ __forceinline__ void fused_out_layer(const FusedLds& L, float (*In)[FBM + 1], int K, const float* __restrict__ W, const float* __restrict__ bias, int N,
+                                                float* __restrict__ outG, int ldo, long m0, long B, float* __restrict__ actG, const float* __restrict__ noise, float sigma) {
+    static_assert(NKT % 4 == 0, "k-tiles dealt over four waves");
+    constexpr int KW = NKT / 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, col = lane & 31;
+    typedef float f2w __attribute__((ext_vector_type(2)));
+    const float* wrow = W + (long)(col < N ? col : N - 1) * K + 8 * h;
+    f2w rw[KW][4];
+#pragma unroll
+    for (int p = 0; p < KW; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rw[p][q] = *reinterpret_cast<const f2w*>(wrow + (w * KW + p) * GBK + 2 * q);      // (K = 256: even, 8-byte aligned rows)
+    floatx16 acc = {0};
+#pragma unroll
+    for (int p = 0; p < KW; ++p)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float av = In[(w * KW + p) * GBK + 8 * h + j][col];
+            const float bv = (j & 1) ? rw[p][j >> 1].y : rw[p][j >> 1].x;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+    float* red = reinterpret_cast<float*>(L.A1s);      // [4 waves][16][64] floats = 16 KB of the 33 KB tile
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(w * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (w == 0) {
+        const float bs = col < N ? bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const float v = ((red[r * 64 + lane] + red[(16 + r) * 64 + lane]) + (red[(32 + r) * 64 + lane] + red[(48 + r) * 64 + lane])) + bs;
+            if (outG && col < N && m0 + row < B) outG[(m0 + row) * ldo + col] = v;
+            if (actG && col < N && m0 + row < B) actG[(m0 + row) * ldo + col] = v + (noise ? sigma * noise[(m0 + row) * ldo + col] : 0.f);
+        }
+    }
+    __syncthreads();
+}
 struct FusedIn {           // where the 32 x D input tile comes from: prepared rows (everything else NULL) or raw observations + the prep of prep_obs_kernel
     const float* x; const int64_t* idx; const int32_t* sign_perm; uint64_t clock_mask; const float *mean, *stdv; float* xn_out;
     // optional epilogue of the output layer (the rollout, apx_rollout): act = y + sigma * noise (noise may be NULL: act = y), saving the act_noise launch of every env step
@@ -735,7 +776,8 @@ __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(const float* __restr
     __syncthreads();
     fused_layer<4>(L, L.A2s, D, W0, b0, FH, true, L.A1s, a1, FH, m0, B);      // k-tiles beyond D: zero-padded X rows, zero-guarded weights
     fused_layer<FH / GBK>(L, L.A1s, FH, W1, b1, FH, true, L.A2s, a2, FH, m0, B);
-    fused_layer<FH / GBK>(L, L.A2s, FH, W2, b2, O, false, nullptr, y, O, m0, B, I.act_out, I.noise, I.sigma);
+    if (O <= 32) fused_out_layer<FH / GBK>(L, L.A2s, FH, W2, b2, O, y, O, m0, B, I.act_out, I.noise, I.sigma);
+    else fused_layer<FH / GBK>(L, L.A2s, FH, W2, b2, O, false, nullptr, y, O, m0, B, I.act_out, I.noise, I.sigma);
 }
 
 static bool g_fused_attr_set = false;
