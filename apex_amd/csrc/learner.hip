@@ -1211,6 +1211,151 @@ extern "C" int apx_lstm_forward(const float* params, int D, int H, int L, int O,
     return linear_fwd(in, P.Wo, P.bo, y, TB, H, O, false, s);
 }
 
+// ------------------------------------------------------------------------------------------------ fused one-step recurrent pass (the rollout)
+// PPO.sample's policy step for a recurrent actor / critic (rl/policies/actor.py:253-289 stepped once, rl/algos/ppo.py:160-184): input normalisation, two stacked
+// LSTMCell(128) and the linear head in ONE launch.  As separate launches a step was 7 kernels (input GEMM, accumulate GEMM, gate kernel per layer, head GEMM) behind 4
+// element-wise torch kernels (normalise, hidden-state reset, noise, add): ~0.2 ms of the 2.6 ms env step at 2048 envs.  A workgroup of four waves carries 16 rows:
+// the layer input [x | h_prev] (then [h1 | h2_prev]) sits in LDS, wave w owns units [32 w, 32 w + 32) of all four gates as v_mfma_f32_16x16x4_f32 accumulators (a lane
+// holds i, f, g, o of the same (row, unit) pairs, so the gate arithmetic is lane-local), and the weights stream from L2 as float4: the k of a 16-deep tile is dealt
+// k = 4 (lane >> 4) + q over the tile's four MFMAs q, so a lane's four B operands are 16 contiguous bytes of its row of the PACKED weight [W_ih | W_hh].
+// apx_lstm_step_pack builds that packed block (W_ih padded to 64 columns, the two bias vectors summed) once per rollout.  Restrictions: L = 2, H = 128, D <= 64, O <= 16.
+#define LS_H 128
+#define LS_DP 64
+struct LstmStepView {      // the packed block
+    const float *W1, *b1, *W2, *b2, *Wo, *bo;
+    __host__ __device__ LstmStepView(const float* p, int O) {
+        W1 = p; p += (size_t)4 * LS_H * (LS_DP + LS_H); b1 = p; p += 4 * LS_H; W2 = p; p += (size_t)4 * LS_H * 2 * LS_H; b2 = p; p += 4 * LS_H; Wo = p; p += (size_t)O * LS_H; bo = p;
+    }
+};
+extern "C" size_t apx_lstm_step_pack_floats(int D, int H, int L, int O) {
+    if (H != LS_H || L != 2 || D > LS_DP || O > 16) return 0;
+    return (size_t)4 * LS_H * (LS_DP + LS_H) + 4 * LS_H + (size_t)4 * LS_H * 2 * LS_H + 4 * LS_H + (size_t)O * LS_H + O;
+}
+__global__ void lstm_step_pack_kernel(const float* __restrict__ Wih0, const float* __restrict__ Whh0, const float* __restrict__ bih0, const float* __restrict__ bhh0,
+                                      const float* __restrict__ Wih1, const float* __restrict__ Whh1, const float* __restrict__ bih1, const float* __restrict__ bhh1,
+                                      const float* __restrict__ Wo, const float* __restrict__ bo, int D, int O, float* __restrict__ out) {
+    constexpr int H = LS_H, K1 = LS_DP + LS_H, K2 = 2 * LS_H;
+    const long n1 = (long)4 * H * K1, n2 = (long)4 * H * K2, total = n1 + 4 * H + n2 + 4 * H + (long)O * H + O;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        float v;
+        if (e < n1) { const int n = (int)(e / K1), k = (int)(e - (long)n * K1); v = k < LS_DP ? (k < D ? Wih0[(long)n * D + k] : 0.f) : Whh0[(long)n * H + (k - LS_DP)]; }
+        else if (e < n1 + 4 * H) { const int n = (int)(e - n1); v = bih0[n] + bhh0[n]; }
+        else if (e < n1 + 4 * H + n2) { const long f = e - n1 - 4 * H; const int n = (int)(f / K2), k = (int)(f - (long)n * K2); v = k < H ? Wih1[(long)n * H + k] : Whh1[(long)n * H + (k - H)]; }
+        else if (e < n1 + 4 * H + n2 + 4 * H) { const int n = (int)(e - n1 - 4 * H - n2); v = bih1[n] + bhh1[n]; }
+        else if (e < n1 + 4 * H + n2 + 4 * H + (long)O * H) v = Wo[e - (n1 + 4 * H + n2 + 4 * H)];
+        else v = bo[e - (n1 + 4 * H + n2 + 4 * H + (long)O * H)];
+        out[e] = v;
+    }
+}
+extern "C" int apx_lstm_step_pack(const float* params, int D, int H, int L, int O, float* packed, void* stream) {
+    APX_REQUIRE(params && packed && apx_lstm_step_pack_floats(D, H, L, O) > 0, "lstm step pack: L = 2, H = 128, D <= 64, O <= 16");
+    const LstmView P(params, D, H, L, O);
+    hipLaunchKernelGGL(lstm_step_pack_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, P.Wih[0], P.Whh[0], P.bih[0], P.bhh[0], P.Wih[1], P.Whh[1], P.bih[1], P.bhh[1], P.Wo, P.bo, D, O, packed);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+}
+// one LSTM layer of the step for the workgroup's 16 rows: pre-activations over the K-wide LDS tile, gates, state update; h_new -> hn (LDS, row-major) and the carried state
+template <int K>
+__device__ __forceinline__ void lstm_step_layer(const float (*tile)[K + 4], const float* __restrict__ Wc, const float* __restrict__ bs, float* __restrict__ hslot, float* __restrict__ cslot,
+                                                const bool (&live)[4], long r0, long B, float* hn, int hn_pitch) {
+    constexpr int H = LS_H, NT = 2, NTILE = K / 16;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 15, kg = lane >> 4;
+    typedef float f4w __attribute__((ext_vector_type(4)));
+    floatx4 acc[4][NT];
+    const float* wrow[4][NT];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = g * H + wave * 32 + nt * 16 + col;
+            const float b = bs[n];
+            acc[g][nt] = floatx4{b, b, b, b};
+            wrow[g][nt] = Wc + (long)n * K + 4 * kg;
+        }
+    f4w wq[2][4][NT];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wq[0][g][nt] = *reinterpret_cast<const f4w*>(wrow[g][nt]);
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+        if (t + 1 < NTILE) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) wq[(t + 1) & 1][g][nt] = *reinterpret_cast<const f4w*>(wrow[g][nt] + 16 * (t + 1));
+        }
+        const f4w a = *reinterpret_cast<const f4w*>(&tile[col][16 * t + 4 * kg]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], wq[t & 1][g][nt][q], acc[g][nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kg + r, unit = wave * 32 + nt * 16 + col;
+            const long grow = r0 + row;
+            const float i = sigmf(acc[0][nt][r]), f = sigmf(acc[1][nt][r]), gg = tanhf(acc[2][nt][r]), o = sigmf(acc[3][nt][r]);
+            const float cp = (grow < B && live[r]) ? cslot[grow * H + unit] : 0.f;
+            const float c = f * cp + i * gg, h = o * tanhf(c);
+            if (grow < B) { cslot[grow * H + unit] = c; hslot[grow * H + unit] = h; }
+            hn[row * hn_pitch + unit] = h;
+        }
+}
+__global__ __launch_bounds__(256) void lstm_step_fused_kernel(const float* __restrict__ packed, int D, int O, const float* __restrict__ x, const float* __restrict__ mean,
+                                                              const float* __restrict__ stdv, const uint8_t* __restrict__ reset, float* __restrict__ hc, long B,
+                                                              float* __restrict__ y, float* __restrict__ act, const float* __restrict__ noise, float sigma) {
+    constexpr int H = LS_H, K1 = LS_DP + LS_H, K2 = 2 * LS_H;
+    __shared__ __attribute__((aligned(16))) float t1[16][K1 + 4];      // [x (64, zero padded) | h1_prev]; later rows 0..15 x [0, 128) = h2 for the head
+    __shared__ __attribute__((aligned(16))) float t2[16][K2 + 4];      // [h1 | h2_prev]
+    const LstmStepView P(packed, O);
+    const int tid = threadIdx.x, kg = (tid & 63) >> 4;
+    const long r0 = (long)blockIdx.x * 16;
+    float* h0 = hc; float* c0 = hc + (size_t)B * H; float* h1 = hc + (size_t)2 * B * H; float* c1 = hc + (size_t)3 * B * H;
+    for (int e = tid; e < 16 * LS_DP; e += 256) {
+        const int r = e / LS_DP, k = e - r * LS_DP; const long row = r0 + r;
+        float v = 0.f;
+        if (row < B && k < D) { v = x[row * D + k]; if (mean) v = (v - mean[k]) / stdv[k]; }
+        t1[r][k] = v;
+    }
+    for (int e = tid; e < 16 * H; e += 256) {
+        const int r = e / H, u = e - r * H; const long row = r0 + r;
+        const bool z = row < B && !(reset && reset[row] != 0);      // init_hidden_state at an episode start (ppo.py:164-168): the carried state reads as zero
+        t1[r][LS_DP + u] = z ? h0[row * H + u] : 0.f;
+        t2[r][H + u] = z ? h1[row * H + u] : 0.f;
+    }
+    bool live[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const long row = r0 + 4 * kg + r; live[r] = row < B && !(reset && reset[row] != 0); }
+    __syncthreads();
+    lstm_step_layer<K1>(t1, P.W1, P.b1, h0, c0, live, r0, B, &t2[0][0], K2 + 4);
+    __syncthreads();
+    lstm_step_layer<K2>(t2, P.W2, P.b2, h1, c1, live, r0, B, &t1[0][0], K1 + 4);
+    __syncthreads();
+    if (tid < 16 * O) {
+        const int r = tid / O, o = tid - r * O; const long row = r0 + r;
+        float sacc = P.bo[o];
+#pragma unroll 8
+        for (int k = 0; k < H; ++k) sacc += t1[r][k] * P.Wo[o * H + k];
+        if (row < B) {
+            y[row * O + o] = sacc;
+            if (act) act[row * O + o] = sacc + (noise ? sigma * noise[row * O + o] : 0.f);
+        }
+    }
+}
+extern "C" int apx_lstm_step(const float* packed, int D, int H, int L, int O, const float* x, const float* obs_mean, const float* obs_std, const uint8_t* reset, float* hc,
+                             int64_t B, float* y, float* act, const float* noise, float sigma, void* stream) {
+    APX_REQUIRE(packed && x && hc && y && B > 0 && apx_lstm_step_pack_floats(D, H, L, O) > 0, "lstm step: L = 2, H = 128, D <= 64, O <= 16, carried state required");
+    APX_REQUIRE((obs_mean == nullptr) == (obs_std == nullptr), "obs_mean/obs_std");
+    hipLaunchKernelGGL(lstm_step_fused_kernel, dim3(apx_cdiv(B, 16)), dim3(256), 0, (hipStream_t)stream, packed, D, O, x, obs_mean, obs_std, reset, hc, (long)B, y, act, noise, sigma);
+    APX_LAUNCH_CHECK();
+    return APX_OK;
+}
+
 // grads += d(loss)/d(params) for dy[T, B, O] (zero start state).  scratch: (8H + max(D, H)) * T * B ... see apx_lstm_bwd_scratch_floats
 extern "C" size_t apx_lstm_bwd_scratch_floats(int T, int64_t B, int D, int H) { return (size_t)T * B * (4 * H + 2 * H) + (size_t)B * 2 * H + 4 * H; }
 extern "C" int apx_lstm_backward(const float* params, float* grads, int D, int H, int L, int O, const float* x, int T, int64_t B,

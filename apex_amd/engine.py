@@ -159,6 +159,32 @@ class Lstm:
         y = y[0] if step else y
         return (y, x3, save) if keep else y
 
+    # ---- the rollout's one-step pass as one launch (apx_lstm_step): normalisation, hidden-state reset, both cells, head and the action noise
+    def step_supported(self):
+        return int(_lib.load().apx_lstm_step_pack_floats(self.D, self.H, self.L, self.O)) > 0
+
+    def pack_step(self):
+        """Re-lay the parameters for apx_lstm_step ([W_ih | W_hh] per cell, summed biases); call again whenever the parameters changed."""
+        lib = _lib.load()
+        n = int(lib.apx_lstm_step_pack_floats(self.D, self.H, self.L, self.O))
+        if n == 0:
+            raise ValueError("apx_lstm_step needs L = 2, H = 128, D <= 64, O <= 16")
+        if getattr(self, "_packed", None) is None or self._packed.numel() != n:
+            self._packed = torch.empty(n, dtype=torch.float32, device=self.params.device)
+        check(lib.apx_lstm_step_pack(_p(self.params), self.D, self.H, self.L, self.O, _p(self._packed), _stream()))
+        return self._packed
+
+    def step(self, x, hc, obs_mean=None, obs_std=None, reset=None, noise=None, sigma=0.0, act_out=None, y_out=None):
+        """One rollout step on raw observations x [B, D]: y = head(LSTM(normalise(x))), hc [L, 2, B, H] updated in place; the rows whose `reset` byte (uint8 [B]) is
+        non-zero start from a zero state; act_out (if given) = y + sigma * noise.  pack_step() must have been called after the last parameter change."""
+        _need_gpu(x)
+        B = x.shape[0]
+        assert x.is_contiguous() and hc.is_contiguous() and x.shape[1] == self.D and self._packed is not None
+        y = y_out if y_out is not None else torch.empty(B, self.O, dtype=torch.float32, device=x.device)
+        check(_lib.load().apx_lstm_step(_p(self._packed), self.D, self.H, self.L, self.O, _p(x), _p(obs_mean), _p(obs_std), _p(reset), _p(hc), B, _p(y),
+                                        _p(act_out), _p(noise), float(sigma), _stream()))
+        return y
+
     def backward(self, grads, x3, save, dy):
         """grads (flat, same layout) += d(loss)/d(params) for dy [T, B, O]; x3 / save from forward(keep=True) with a zero start state."""
         T, B, _ = x3.shape

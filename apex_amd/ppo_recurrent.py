@@ -118,18 +118,32 @@ class RecurrentPPO:
             self._side = torch.cuda.Stream(device=self.device)
         side = self._side
         side.wait_stream(main)
+        # the policy step as ONE launch per network (apx_lstm_step: normalisation, init_hidden_state of the restarted rows, both cells, head, action noise) where the
+        # shape allows it (2 x LSTMCell(128)); otherwise the per-launch chain
+        import os
+        fused = os.environ.get("APX_LSTM_STEP", "1") != "0" and L.actor.step_supported() and L.critic.step_supported()
+        if fused:
+            L.actor.pack_step(); L.critic.pack_step()
+            side.wait_stream(main)
         for t in range(T):
             self.b_obs[t].copy_(obs)
             ev_obs = main.record_event()
+            prev_done = self.b_done[t - 1] if (fused and t > 0) else None      # uint8 0 / 1 / 2: non-zero rows start from a zero state
             with torch.cuda.stream(side):
                 side.wait_event(ev_obs)
-                self.b_val[t].copy_(L.critic.forward(self.b_obs[t], hc=hc_c).view(-1))
-            mu = L.actor.forward(norm(obs), hc=hc_a)
+                if fused:
+                    L.critic.step(self.b_obs[t], hc_c, reset=prev_done, y_out=self.b_val[t].view(N, 1))
+                else:
+                    self.b_val[t].copy_(L.critic.forward(self.b_obs[t], hc=hc_c).view(-1))
             if self.noise_fn is None:
                 noise.normal_(generator=self.gen)
             else:
                 self.noise_fn(t, noise)
-            torch.add(mu, noise, alpha=self.fixed_std, out=self.b_act[t])
+            if fused:
+                L.actor.step(self.b_obs[t], hc_a, L.obs_mean, L.obs_std, reset=prev_done, noise=noise, sigma=self.fixed_std, act_out=self.b_act[t])
+            else:
+                mu = L.actor.forward(norm(obs), hc=hc_a)
+                torch.add(mu, noise, alpha=self.fixed_std, out=self.b_act[t])
             env.step(self.b_act[t], out=(obs, self.b_rew[t], self.b_done[t], self.b_fin[t]))      # writes the next observation into `obs`
             ev_step = main.record_event()
             last = t == T - 1
@@ -144,8 +158,10 @@ class RecurrentPPO:
                     v_next = L.critic.forward(src.contiguous(), hc=hc_c.clone()).view(-1)
                     self.b_boot[t] = torch.where(rows, v_next, torch.zeros_like(v_next))
                     main.wait_event(side.record_event())      # `obs` is overwritten by the next env step
-                hc_c.masked_fill_((self.b_done[t] != 0).view(1, 1, N, 1), 0.0)      # init_hidden_state at every episode start (ppo.py:164-168); an assignment, not a product: 0 * NaN stays NaN
-            hc_a.masked_fill_((self.b_done[t] != 0).view(1, 1, N, 1), 0.0)
+                if not fused:
+                    hc_c.masked_fill_((self.b_done[t] != 0).view(1, 1, N, 1), 0.0)      # init_hidden_state at every episode start (ppo.py:164-168); an assignment, not a product: 0 * NaN stays NaN
+            if not fused:
+                hc_a.masked_fill_((self.b_done[t] != 0).view(1, 1, N, 1), 0.0)
         main.wait_stream(side)
         self.b_end.copy_((self.b_done != 0).to(torch.uint8)); self.b_end[T - 1] = 1      # the grid end cuts the last trajectory of every column
         ret = engine.returns_scan(self.b_rew, self.b_end, self.b_boot, torch.zeros(N, device=self.device), self.gamma)

@@ -111,6 +111,15 @@ size_t apx_lstm_workspace_floats(int T, int64_t B, int H, int L);
 size_t apx_lstm_bwd_scratch_floats(int T, int64_t B, int D, int H);
 int apx_lstm_forward(const float* params, int D, int H, int L, int O, const float* x, int T, int64_t B, float* hc, float* save,
                      float* y, void* stream);
+/* The rollout's one-step recurrent pass as ONE launch (PPO.sample's policy step, rl/algos/ppo.py:160-184 over rl/policies/actor.py:253-289): input normalisation
+ * (obs_mean / obs_std, or NULL for a prepared input), init_hidden_state for the rows whose `reset` byte is non-zero (NULL: none), two LSTMCell(128), the linear head and,
+ * optionally, act = y + sigma * noise.  `packed` = the network's parameters re-laid by apx_lstm_step_pack ([W_ih | W_hh] per cell with W_ih padded to 64 columns, summed
+ * biases, head; apx_lstm_step_pack_floats floats, 0 = shape not supported: L = 2, H = 128, D <= 64, O <= 16) - pack again whenever the parameters change.
+ * hc = [2][2][B][128] carried (h, c), updated in place; x[B,D], y[B,O], act[B,O] or NULL, noise[B,O] or NULL; all f32 [dev]. */
+size_t apx_lstm_step_pack_floats(int D, int H, int L, int O);
+int apx_lstm_step_pack(const float* params, int D, int H, int L, int O, float* packed, void* stream);
+int apx_lstm_step(const float* packed, int D, int H, int L, int O, const float* x, const float* obs_mean, const float* obs_std, const uint8_t* reset, float* hc,
+                  int64_t B, float* y, float* act, const float* noise, float sigma, void* stream);
 int apx_lstm_backward(const float* params, float* grads, int D, int H, int L, int O, const float* x, int T, int64_t B,
                       const float* save, const float* dy, float* scratch, void* stream);
 

@@ -507,3 +507,38 @@ def test_td3_whole_loop_golden_g20c(dev, golden_dir):
         for k, v in zip(keys, [v for net in nets for v in net.views()]):
             d = np.abs(v.cpu().numpy() - g[nm + "." + k])
             assert d.max() < 2e-4, (nm, k, d.max())
+
+
+def test_fused_recurrent_step_equals_the_per_launch_chain(dev):
+    """apx_lstm_step (the rollout's policy step as one launch: normalisation, init_hidden_state of restarted rows, two LSTMCell(128), head, action noise) against the
+    chain it replaces - normalise, masked state reset, apx_lstm_forward(T = 1), mu + sigma * noise - over several steps with a carried state, for the actor (O = 10) and
+    the critic (O = 1) shapes, ragged batch sizes included.  Same arithmetic up to the order of the K sum (one accumulation over [x | h] instead of two GEMMs): 2e-5."""
+    from apex_amd import engine
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    for D, O, B in ((49, 10, 2048), (49, 1, 300), (40, 10, 17), (64, 10, 33)):
+        net = engine.Lstm(D, 128, 2, O, dev)
+        assert net.step_supported()
+        net.params.copy_(torch.randn(net.n, device=dev, generator=g) * 0.08)
+        net.pack_step()
+        mean = torch.randn(D, device=dev, generator=g); std = torch.rand(D, device=dev, generator=g) + 0.5
+        hc_a = torch.randn(2, 2, B, 128, device=dev, generator=g) * 0.3; hc_b = hc_a.clone()
+        reset = None
+        for t in range(4):
+            x = torch.randn(B, D, device=dev, generator=g)
+            noise = torch.randn(B, O, device=dev, generator=g)
+            # reference chain
+            if reset is not None:
+                hc_a.masked_fill_((reset != 0).view(1, 1, B, 1), 0.0)
+            mu_a = net.forward(((x - mean) / std).contiguous(), hc=hc_a)
+            act_a = mu_a + 0.2 * noise
+            # fused
+            act_b = torch.empty(B, O, device=dev)
+            mu_b = net.step(x, hc_b, mean, std, reset=reset, noise=noise, sigma=0.2, act_out=act_b)
+            np.testing.assert_allclose(mu_b.cpu().numpy(), mu_a.cpu().numpy(), rtol=0, atol=2e-5, err_msg="mu D=%d O=%d B=%d t=%d" % (D, O, B, t))
+            np.testing.assert_allclose(act_b.cpu().numpy(), act_a.cpu().numpy(), rtol=0, atol=2e-5)
+            np.testing.assert_allclose(hc_b.cpu().numpy(), hc_a.cpu().numpy(), rtol=0, atol=2e-5, err_msg="state D=%d O=%d B=%d t=%d" % (D, O, B, t))
+            reset = (torch.rand(B, device=dev, generator=g) < 0.3).to(torch.uint8) * 2      # (the done flags are 0 / 1 / 2)
+        # a prepared input without normalisation, no noise, no reset
+        y_a = net.forward(x.contiguous(), hc=hc_a); y_b = net.step(x, hc_b)
+        np.testing.assert_allclose(y_b.cpu().numpy(), y_a.cpu().numpy(), rtol=0, atol=2e-5)
+    assert not engine.Lstm(50, 64, 2, 10, dev).step_supported() and not engine.Lstm(80, 128, 2, 10, dev).step_supported()
