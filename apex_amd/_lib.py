@@ -60,6 +60,7 @@ SIGNATURES = {
     "apx_lstm_step_pack_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "apx_lstm_step_pack": (C.c_int, [c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr]),
     "apx_lstm_step": (C.c_int, [c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int64, c_ptr, c_ptr, c_ptr, C.c_float, c_ptr]),
+    "apx_rec_gather": (C.c_int, [c_ptr, C.c_int, C.c_int64, C.c_int, C.c_int] + [c_ptr] * 5 + [C.c_uint64] + [c_ptr] * 10),
     "apx_lstm_backward": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, C.c_int, C.c_int64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "apx_mlp_forward": (C.c_int, [c_ptr, C.c_int, C.c_int, C.c_int, c_ptr, C.c_int64, c_ptr, c_ptr, C.c_uint64, c_ptr,
                                   c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, c_ptr]),
@@ -73,6 +74,7 @@ SIGNATURES = {
     "apx_env_set_hfield": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, c_ptr]),
     "apx_env_reset": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
     "apx_env_prepare_resets": (C.c_int, [c_ptr, c_ptr]),
+    "apx_env_set_refill": (C.c_int, [c_ptr, C.c_int]),
     "apx_env_update_speed": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
     "apx_env_reset_for_test": (C.c_int, [c_ptr, c_ptr, C.c_int, c_ptr]),
     "apx_env_apply_force": (C.c_int, [c_ptr, c_ptr, c_ptr]),

@@ -798,6 +798,9 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     APX_HIP(hipMemset(e->rst_int, 0xFF, sizeof(int) * (size_t)RST_K * 2 * e->n));      // -1: no slot holds an episode
     e->hf = nullptr; e->hf_nrow = e->hf_ncol = 0; e->hf_size[0] = e->hf_size[1] = e->hf_size[2] = 0.f;
     e->timing = 0; e->ev = nullptr; e->ev_cap = e->ev_n = 0; e->t_ms = 0.0; e->t_launches = 0;
+    // up to 2048 envs leave half of the SIMDs idle during an env step: the images of the restarted envs' next episodes are computed there (apx_env_set_refill overrides)
+    e->refill = getenv("APX_REFILL") ? atoi(getenv("APX_REFILL")) != 0 : e->n <= 2048;
+    e->refill_pending = 0; e->side = nullptr; e->ev_reset = nullptr; e->ev_refill = nullptr;
     const Cfg c = make_cfg(*e);
     hipLaunchKernelGGL(env_init_kernel, dim3(e->n / 64), dim3(64), 0, 0, e->st, e->ist, e->n, c);
     APX_LAUNCH_CHECK();
@@ -817,16 +820,51 @@ extern "C" int apx_env_destroy(apx_env_t* e) {
     (void)hipFree(e->st); (void)hipFree(e->ist); (void)hipFree(e->wk); (void)hipFree(e->hf); (void)hipFree(e->rst); (void)hipFree(e->rst_int);
     for (int i = 0; i < e->ev_cap; ++i) (void)hipEventDestroy((hipEvent_t)e->ev[i]);
     free(e->ev);
+    if (e->side) { (void)hipStreamSynchronize((hipStream_t)e->side); (void)hipStreamDestroy((hipStream_t)e->side); }
+    if (e->ev_reset) (void)hipEventDestroy((hipEvent_t)e->ev_reset);
+    if (e->ev_refill) (void)hipEventDestroy((hipEvent_t)e->ev_refill);
     delete e;
     return APX_OK;
 }
 
 // prepared resets depend on the model inputs of the forward pass (terrain, external wrench, fields written through the setters): drop them when one of those changes
+// a refill launched by the previous step writes the ring on the side stream: whatever touches the ring next on `stream` waits for it
+static int refill_join(apx_env* e, void* stream) {
+    if (e->refill_pending) { APX_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)e->ev_refill, 0)); e->refill_pending = 0; }
+    return APX_OK;
+}
 static int invalidate_prepared(apx_env* e, void* stream) {
+    { const int rc = refill_join(e, stream); if (rc != APX_OK) return rc; }
     APX_HIP(hipMemsetAsync(e->rst_int, 0xFF, sizeof(int) * (size_t)RST_K * 2 * e->n, (hipStream_t)stream));
     return APX_OK;
 }
+static int launch_reset_raw(apx_env* e, int ahead, const uint8_t* mask, float* obs, void* stream);
 static int launch_reset(apx_env* e, int ahead, const uint8_t* mask, float* obs, void* stream) {
+    { const int rc = refill_join(e, stream); if (rc != APX_OK) return rc; }
+    return launch_reset_raw(e, ahead, mask, obs, stream);
+}
+// In-rollout refill: the envs that restarted in the reset just launched on `stream` have consumed a ring slot; part 0 of env_reset_kernel for their next RST_K episodes
+// runs on the side stream (no mask: a wave whose four envs hold their next episodes leaves at once), next to whatever `stream` does until its next reset launch.  Part 0
+// reads I_EPISODE (stable between resets) and writes only the ring; its result is a function of (seed, env, episode) alone, not of the env state it starts from.
+static int launch_refill(apx_env* e, void* stream) {
+    if (!e->side) {
+        APX_HIP(hipStreamCreateWithFlags((hipStream_t*)&e->side, hipStreamNonBlocking));
+        APX_HIP(hipEventCreateWithFlags((hipEvent_t*)&e->ev_reset, hipEventDisableTiming));
+        APX_HIP(hipEventCreateWithFlags((hipEvent_t*)&e->ev_refill, hipEventDisableTiming));
+    }
+    APX_HIP(hipEventRecord((hipEvent_t)e->ev_reset, (hipStream_t)stream));
+    APX_HIP(hipStreamWaitEvent((hipStream_t)e->side, (hipEvent_t)e->ev_reset, 0));
+    for (int ahead = 1; ahead <= RST_K; ++ahead) { const int rc = launch_reset_raw(e, ahead, nullptr, nullptr, e->side); if (rc != APX_OK) return rc; }
+    APX_HIP(hipEventRecord((hipEvent_t)e->ev_refill, (hipStream_t)e->side));
+    e->refill_pending = 1;
+    return APX_OK;
+}
+extern "C" int apx_env_set_refill(apx_env_t* e, int on) {
+    APX_REQUIRE(e, "env");
+    e->refill = on != 0;
+    return APX_OK;
+}
+static int launch_reset_raw(apx_env* e, int ahead, const uint8_t* mask, float* obs, void* stream) {
     if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), e->rst, e->rst_int, ahead, mask, obs);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_reset_kernel<false>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), e->rst, e->rst_int, ahead, mask, obs);
     APX_LAUNCH_CHECK();
@@ -909,7 +947,10 @@ extern "C" int apx_env_step(apx_env_t* e, const float* action, float* obs, float
                        make_cfg(*e), action, obs, reward, done, final_obs);
     APX_LAUNCH_CHECK();
     if (timed) { APX_HIP(hipEventRecord((hipEvent_t)e->ev[e->ev_n + 1], (hipStream_t)stream)); e->ev_n += 2; }
-    if (auto_reset) { const int rc = launch_reset(e, 0, done, obs, stream); if (rc != APX_OK) return rc; }      // finished envs restart in a second launch on the same stream (mask = done flags)
+    if (auto_reset) {      // finished envs restart in a second launch on the same stream (mask = done flags)
+        { const int rc = launch_reset(e, 0, done, obs, stream); if (rc != APX_OK) return rc; }
+        if (e->refill) { const int rc = launch_refill(e, stream); if (rc != APX_OK) return rc; }
+    }
     return APX_OK;
 }
 

@@ -1040,6 +1040,22 @@ __global__ __launch_bounds__(64 * NW, 1) void lstm_seq_fwd_kernel(float* __restr
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const long row = r0 + 4 * kg + r; c[nt][r] = (hc_c && row < B) ? hc_c[row * H + wave * UW + nt * 16 + col] : 0.f; }
     __syncthreads();
+    // the input projection of step t + 1 is fetched while the MFMAs of step t run (as the first thing of its own step the 16 loads were an exposed HBM round trip per
+    // step: 6.9 us per step against 3.4 us of MFMA issue)
+    float gn[4][NT][4];
+    auto fetch_g = [&](int t) {
+        const float* Gt = G + (size_t)t * B * 4 * H;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long row = r0 + 4 * kg + r;
+                    gn[g][nt][r] = row < B ? Gt[row * 4 * H + g * H + wave * UW + nt * 16 + col] : 0.f;
+                }
+    };
+    fetch_g(0);
     for (int t = 0; t < T; ++t) {
         float* Gt = G + (size_t)t * B * 4 * H;
         floatx4 acc[4][NT];
@@ -1048,10 +1064,8 @@ __global__ __launch_bounds__(64 * NW, 1) void lstm_seq_fwd_kernel(float* __restr
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const long row = r0 + 4 * kg + r;
-                    acc[g][nt][r] = (row < B ? Gt[row * 4 * H + g * H + wave * UW + nt * 16 + col] : 0.f) + bh[g][nt];
-                }
+                for (int r = 0; r < 4; ++r) acc[g][nt][r] = gn[g][nt][r] + bh[g][nt];
+        if (t + 1 < T) fetch_g(t + 1);
 #pragma unroll
         for (int kq = 0; kq < KQ; ++kq) {
             const float a = hs[col][4 * kq + kg];
@@ -1108,8 +1122,26 @@ __global__ __launch_bounds__(64 * NW, 1) void lstm_seq_bwd_kernel(const float* _
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dc[nt][r] = dhr[nt][r] = 0.f;
-    for (int t = T - 1; t >= 0; --t) {
+    // what step t - 1 reads (activated gates, c_{t-2}, dh from above) is fetched while the MFMAs of step t run; c_{t-1} is carried over from step t
+    float pg[NT][4][4], pct[NT][4], pcp[NT][4], pdh[NT][4];
+    auto fetch = [&](int t, bool first) {
         const float* Gt = G + (size_t)t * B * 4 * H;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long row = r0 + 4 * kg + r; const int u = wave * UW + nt * 16 + col;
+                if (row < B) {
+                    const float* g4 = Gt + row * 4 * H + u;
+                    pg[nt][r][0] = g4[0]; pg[nt][r][1] = g4[H]; pg[nt][r][2] = g4[2 * H]; pg[nt][r][3] = g4[3 * H];
+                    pct[nt][r] = first ? Cc[(size_t)t * B * H + row * H + u] : pcp[nt][r];
+                    pcp[nt][r] = t ? Cc[(size_t)(t - 1) * B * H + row * H + u] : 0.f;
+                    pdh[nt][r] = dHa[(size_t)t * B * H + row * H + u];
+                }
+            }
+    };
+    fetch(T - 1, true);
+    for (int t = T - 1; t >= 0; --t) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -1117,10 +1149,9 @@ __global__ __launch_bounds__(64 * NW, 1) void lstm_seq_bwd_kernel(const float* _
                 const long row = r0 + 4 * kg + r; const int u = wave * UW + nt * 16 + col;
                 float di = 0.f, df = 0.f, dgg = 0.f, dob = 0.f;
                 if (row < B) {
-                    const float* g4 = Gt + row * 4 * H + u;
-                    const float i = g4[0], f = g4[H], gg = g4[2 * H], o = g4[3 * H];
-                    const float ct = Cc[(size_t)t * B * H + row * H + u], cp = t ? Cc[(size_t)(t - 1) * B * H + row * H + u] : 0.f;
-                    const float dh = dHa[(size_t)t * B * H + row * H + u] + dhr[nt][r];
+                    const float i = pg[nt][r][0], f = pg[nt][r][1], gg = pg[nt][r][2], o = pg[nt][r][3];
+                    const float ct = pct[nt][r], cp = pcp[nt][r];
+                    const float dh = pdh[nt][r] + dhr[nt][r];
                     const float tc = tanhf(ct);
                     const float dcv = dh * o * (1.f - tc * tc) + dc[nt][r];
                     di = dcv * gg * i * (1.f - i); df = dcv * cp * f * (1.f - f); dgg = dcv * i * (1.f - gg * gg); dob = dh * tc * o * (1.f - o);
@@ -1133,6 +1164,7 @@ __global__ __launch_bounds__(64 * NW, 1) void lstm_seq_bwd_kernel(const float* _
             }
         __syncthreads();
         if (t) {
+            fetch(t - 1, false);
             floatx4 acc[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -1214,8 +1246,8 @@ extern "C" int apx_lstm_forward(const float* params, int D, int H, int L, int O,
 // ------------------------------------------------------------------------------------------------ fused one-step recurrent pass (the rollout)
 // PPO.sample's policy step for a recurrent actor / critic (rl/policies/actor.py:253-289 stepped once, rl/algos/ppo.py:160-184): input normalisation, two stacked
 // LSTMCell(128) and the linear head in ONE launch.  As separate launches a step was 7 kernels (input GEMM, accumulate GEMM, gate kernel per layer, head GEMM) behind 4
-// element-wise torch kernels (normalise, hidden-state reset, noise, add): ~0.2 ms of the 2.6 ms env step at 2048 envs.  A workgroup of four waves carries 16 rows:
-// the layer input [x | h_prev] (then [h1 | h2_prev]) sits in LDS, wave w owns units [32 w, 32 w + 32) of all four gates as v_mfma_f32_16x16x4_f32 accumulators (a lane
+// element-wise torch kernels (normalise, hidden-state reset, noise, add): ~0.2 ms of the 2.6 ms env step at 2048 envs.  A workgroup of eight waves carries 16 rows:
+// the layer input [x | h_prev] (then [h1 | h2_prev]) sits in LDS, wave w owns units [16 w, 16 w + 16) of all four gates as v_mfma_f32_16x16x4_f32 accumulators (a lane
 // holds i, f, g, o of the same (row, unit) pairs, so the gate arithmetic is lane-local), and the weights stream from L2 as float4: the k of a 16-deep tile is dealt
 // k = 4 (lane >> 4) + q over the tile's four MFMAs q, so a lane's four B operands are 16 contiguous bytes of its row of the PACKED weight [W_ih | W_hh].
 // apx_lstm_step_pack builds that packed block (W_ih padded to 64 columns, the two bias vectors summed) once per rollout.  Restrictions: L = 2, H = 128, D <= 64, O <= 16.
@@ -1254,75 +1286,72 @@ extern "C" int apx_lstm_step_pack(const float* params, int D, int H, int L, int 
     APX_LAUNCH_CHECK();
     return APX_OK;
 }
-// one LSTM layer of the step for the workgroup's 16 rows: pre-activations over the K-wide LDS tile, gates, state update; h_new -> hn (LDS, row-major) and the carried state
+// one LSTM layer of the step for the workgroup's 16 rows: pre-activations over the K-wide LDS tile, gates, state update; h_new -> hn (LDS, row-major) and the carried state.
+// The launch is a latency chain (128 workgroups, every one streams the whole packed weight out of L2): eight waves per workgroup (wave w owns units [16 w, 16 w + 16) of
+// all four gates, two waves per SIMD) and the weight tiles fetched LS_PF k-tiles ahead of their MFMAs (four waves, one tile ahead: 67 us per 2048-row call).
+#define LS_NW 8
+#define LS_PF 3
 template <int K>
 __device__ __forceinline__ void lstm_step_layer(const float (*tile)[K + 4], const float* __restrict__ Wc, const float* __restrict__ bs, float* __restrict__ hslot, float* __restrict__ cslot,
                                                 const bool (&live)[4], long r0, long B, float* hn, int hn_pitch) {
-    constexpr int H = LS_H, NT = 2, NTILE = K / 16;
+    constexpr int H = LS_H, NTILE = K / 16, UW = LS_H / LS_NW;
+    static_assert(UW == 16, "a wave owns one 16-unit tile of every gate");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col = lane & 15, kg = lane >> 4;
     typedef float f4w __attribute__((ext_vector_type(4)));
-    floatx4 acc[4][NT];
-    const float* wrow[4][NT];
+    floatx4 acc[4];
+    const float* wrow[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 4; ++g) {
+        const int n = g * H + wave * UW + col;
+        const float b = bs[n];
+        acc[g] = floatx4{b, b, b, b};
+        wrow[g] = Wc + (long)n * K + 4 * kg;
+    }
+    f4w wq[LS_PF + 1][4];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int n = g * H + wave * 32 + nt * 16 + col;
-            const float b = bs[n];
-            acc[g][nt] = floatx4{b, b, b, b};
-            wrow[g][nt] = Wc + (long)n * K + 4 * kg;
-        }
-    f4w wq[2][4][NT];
+    for (int p = 0; p < LS_PF; ++p)
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wq[0][g][nt] = *reinterpret_cast<const f4w*>(wrow[g][nt]);
+        for (int g = 0; g < 4; ++g) wq[p][g] = *reinterpret_cast<const f4w*>(wrow[g] + 16 * p);
 #pragma unroll
     for (int t = 0; t < NTILE; ++t) {
-        if (t + 1 < NTILE) {
+        if (t + LS_PF < NTILE) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) wq[(t + 1) & 1][g][nt] = *reinterpret_cast<const f4w*>(wrow[g][nt] + 16 * (t + 1));
+            for (int g = 0; g < 4; ++g) wq[(t + LS_PF) % (LS_PF + 1)][g] = *reinterpret_cast<const f4w*>(wrow[g] + 16 * (t + LS_PF));
         }
         const f4w a = *reinterpret_cast<const f4w*>(&tile[col][16 * t + 4 * kg]);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], wq[t & 1][g][nt][q], acc[g][nt], 0, 0, 0);
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], wq[t % (LS_PF + 1)][g][q], acc[g], 0, 0, 0);
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * kg + r, unit = wave * 32 + nt * 16 + col;
-            const long grow = r0 + row;
-            const float i = sigmf(acc[0][nt][r]), f = sigmf(acc[1][nt][r]), gg = tanhf(acc[2][nt][r]), o = sigmf(acc[3][nt][r]);
-            const float cp = (grow < B && live[r]) ? cslot[grow * H + unit] : 0.f;
-            const float c = f * cp + i * gg, h = o * tanhf(c);
-            if (grow < B) { cslot[grow * H + unit] = c; hslot[grow * H + unit] = h; }
-            hn[row * hn_pitch + unit] = h;
-        }
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * kg + r, unit = wave * UW + col;
+        const long grow = r0 + row;
+        const float i = sigmf(acc[0][r]), f = sigmf(acc[1][r]), gg = tanhf(acc[2][r]), o = sigmf(acc[3][r]);
+        const float cp = (grow < B && live[r]) ? cslot[grow * H + unit] : 0.f;
+        const float c = f * cp + i * gg, h = o * tanhf(c);
+        if (grow < B) { cslot[grow * H + unit] = c; hslot[grow * H + unit] = h; }
+        hn[row * hn_pitch + unit] = h;
+    }
 }
-__global__ __launch_bounds__(256) void lstm_step_fused_kernel(const float* __restrict__ packed, int D, int O, const float* __restrict__ x, const float* __restrict__ mean,
+__global__ __launch_bounds__(64 * LS_NW) void lstm_step_fused_kernel(const float* __restrict__ packed, int D, int O, const float* __restrict__ x, const float* __restrict__ mean,
                                                               const float* __restrict__ stdv, const uint8_t* __restrict__ reset, float* __restrict__ hc, long B,
                                                               float* __restrict__ y, float* __restrict__ act, const float* __restrict__ noise, float sigma) {
-    constexpr int H = LS_H, K1 = LS_DP + LS_H, K2 = 2 * LS_H;
+    constexpr int H = LS_H, K1 = LS_DP + LS_H, K2 = 2 * LS_H, NTH = 64 * LS_NW;
     __shared__ __attribute__((aligned(16))) float t1[16][K1 + 4];      // [x (64, zero padded) | h1_prev]; later rows 0..15 x [0, 128) = h2 for the head
     __shared__ __attribute__((aligned(16))) float t2[16][K2 + 4];      // [h1 | h2_prev]
     const LstmStepView P(packed, O);
     const int tid = threadIdx.x, kg = (tid & 63) >> 4;
     const long r0 = (long)blockIdx.x * 16;
     float* h0 = hc; float* c0 = hc + (size_t)B * H; float* h1 = hc + (size_t)2 * B * H; float* c1 = hc + (size_t)3 * B * H;
-    for (int e = tid; e < 16 * LS_DP; e += 256) {
+    for (int e = tid; e < 16 * LS_DP; e += NTH) {
         const int r = e / LS_DP, k = e - r * LS_DP; const long row = r0 + r;
         float v = 0.f;
         if (row < B && k < D) { v = x[row * D + k]; if (mean) v = (v - mean[k]) / stdv[k]; }
         t1[r][k] = v;
     }
-    for (int e = tid; e < 16 * H; e += 256) {
+    for (int e = tid; e < 16 * H; e += NTH) {
         const int r = e / H, u = e - r * H; const long row = r0 + r;
         const bool z = row < B && !(reset && reset[row] != 0);      // init_hidden_state at an episode start (ppo.py:164-168): the carried state reads as zero
         t1[r][LS_DP + u] = z ? h0[row * H + u] : 0.f;
@@ -1351,13 +1380,15 @@ extern "C" int apx_lstm_step(const float* packed, int D, int H, int L, int O, co
                              int64_t B, float* y, float* act, const float* noise, float sigma, void* stream) {
     APX_REQUIRE(packed && x && hc && y && B > 0 && apx_lstm_step_pack_floats(D, H, L, O) > 0, "lstm step: L = 2, H = 128, D <= 64, O <= 16, carried state required");
     APX_REQUIRE((obs_mean == nullptr) == (obs_std == nullptr), "obs_mean/obs_std");
-    hipLaunchKernelGGL(lstm_step_fused_kernel, dim3(apx_cdiv(B, 16)), dim3(256), 0, (hipStream_t)stream, packed, D, O, x, obs_mean, obs_std, reset, hc, (long)B, y, act, noise, sigma);
+    hipLaunchKernelGGL(lstm_step_fused_kernel, dim3(apx_cdiv(B, 16)), dim3(64 * LS_NW), 0, (hipStream_t)stream, packed, D, O, x, obs_mean, obs_std, reset, hc, (long)B, y, act, noise, sigma);
     APX_LAUNCH_CHECK();
     return APX_OK;
 }
 
 // grads += d(loss)/d(params) for dy[T, B, O] (zero start state).  scratch: (8H + max(D, H)) * T * B ... see apx_lstm_bwd_scratch_floats
-extern "C" size_t apx_lstm_bwd_scratch_floats(int T, int64_t B, int D, int H) { return (size_t)T * B * (4 * H + 2 * H) + (size_t)B * 2 * H + 4 * H; }
+// (+ the K-chunk slabs of four weight gradients: two-stage split-K like the MLP path, one grad_reduce_kernel at the end instead of fp32 atomics into dW)
+constexpr int LSTM_PART_GRADS = 4;
+extern "C" size_t apx_lstm_bwd_scratch_floats(int T, int64_t B, int D, int H) { return (size_t)T * B * (4 * H + 2 * H) + (size_t)B * 2 * H + 4 * H + LSTM_PART_GRADS * GRAD_PART_FLOATS; }
 extern "C" int apx_lstm_backward(const float* params, float* grads, int D, int H, int L, int O, const float* x, int T, int64_t B,
                                  const float* save, const float* dy, float* scratch, void* stream) {
     APX_REQUIRE(params && grads && x && save && dy && scratch && T > 0 && B > 0 && L >= 1 && L <= 4, "lstm backward arguments");
@@ -1371,6 +1402,12 @@ extern "C" int apx_lstm_backward(const float* params, float* grads, int D, int H
     float* dhr = dHx + TB * H;                   // [B, H]     recurrent d(loss)/d(h_{t-1})
     float* dc = dhr + B * H;                     // [B, H]
     float* dbt = dc + B * H;                     // [4H]
+    // W_ih / W_hh gradients: K = T B reductions.  As fp32 atomics into dW they were the longest launches of the recurrent minibatch (220 - 270 us each on the 2 B-column
+    // actor pass, bound by the L2 atomic units); every K chunk stores its product to its own slab instead and one grad_reduce_kernel adds them up (128 x 128 tiles where
+    // the shape allows: W_hh and the upper layers' W_ih are 512 x 128)
+    static const bool use_parts = !(getenv("APX_LSTM_PARTS") && atoi(getenv("APX_LSTM_PARTS")) == 0);
+    GradParts parts{dbt + 4 * H, LSTM_PART_GRADS * GRAD_PART_FLOATS, 0, {}, 0};
+    GradParts* pp = use_parts ? &parts : nullptr;
     const float* Htop = save + (size_t)(L - 1) * TB * 6 * H + TB * 5 * H;
     APX_TRY(linear_bwd_weight(dy, Htop, const_cast<float*>(Gd.Wo), const_cast<float*>(Gd.bo), TB, H, O, s));
     APX_TRY(linear_bwd_input(dy, P.Wo, nullptr, dHa, TB, H, O, s));
@@ -1390,18 +1427,61 @@ extern "C" int apx_lstm_backward(const float* params, float* grads, int D, int H
             APX_LAUNCH_CHECK();
             if (t) APX_TRY(linear_bwd_input(dG + (size_t)t * B * 4 * H, P.Whh[l], nullptr, dhr, B, H, 4 * H, s));      // dh_{t-1} = dG_t W_hh
         }
+        if (l) {      // the input gradient first: the layer below waits for it, the weight gradients of this layer do not
+            APX_TRY(linear_bwd_input(dG, P.Wih[l], nullptr, dHx, TB, P.in[l], 4 * H, s));
+            float* tmp = dHa; dHa = dHx; dHx = tmp;
+        }
         APX_HIP(hipMemsetAsync(dbt, 0, sizeof(float) * 4 * H, s));
-        APX_TRY(linear_bwd_weight(dG, in, const_cast<float*>(Gd.Wih[l]), dbt, TB, P.in[l], 4 * H, s));
+        APX_TRY(linear_bwd_weight(dG, in, const_cast<float*>(Gd.Wih[l]), dbt, TB, P.in[l], 4 * H, s, 0, pp));
         hipLaunchKernelGGL(axpy_kernel, dim3(apx_cdiv(4 * H, 256)), dim3(256), 0, s, const_cast<float*>(Gd.bih[l]), dbt, (long)4 * H);
         hipLaunchKernelGGL(axpy_kernel, dim3(apx_cdiv(4 * H, 256)), dim3(256), 0, s, const_cast<float*>(Gd.bhh[l]), dbt, (long)4 * H);
         APX_LAUNCH_CHECK();
         if (T > 1)      // dW_hh += sum_{t >= 1} dG_t^T h_{t-1}
-            APX_TRY(linear_bwd_weight(dG + (size_t)B * 4 * H, Hh, const_cast<float*>(Gd.Whh[l]), nullptr, (long)(T - 1) * B, H, 4 * H, s));
-        if (l) {
-            APX_TRY(linear_bwd_input(dG, P.Wih[l], nullptr, dHx, TB, P.in[l], 4 * H, s));
-            float* tmp = dHa; dHa = dHx; dHx = tmp;
+            APX_TRY(linear_bwd_weight(dG + (size_t)B * 4 * H, Hh, const_cast<float*>(Gd.Whh[l]), nullptr, (long)(T - 1) * B, H, 4 * H, s, 0, pp));
+    }
+    return grad_reduce(parts, s);
+}
+
+// ------------------------------------------------------------------------------------------------ recurrent minibatch assembly
+// The padded [T_max, B] batch of rl/algos/ppo.py:411-430 (pad_sequence over the sampled trajectories: zero rows behind a trajectory's end) gathered out of the rollout
+// grid in ONE launch: raw observations (LSTM_V's input), normalised observations (old policy), [normalised | mirrored + normalised] side by side along the batch axis
+// (pi(s) and pi(M s) as one 2 B-column pass), actions, returns, advantages and the 0 / 1 mask.  As torch ops this was 26 launches per minibatch (4 gathers, the masks,
+// normalise, mirror with its asin / sin columns, cat): 0.45 ms of a 5.9 ms minibatch.  One wave per padded row, lane = column.
+__global__ __launch_bounds__(256) void rec_gather_kernel(const int64_t* __restrict__ idx, long rows, long B, int D, int A, const float* __restrict__ obs, const float* __restrict__ act,
+                                                         const float* __restrict__ ret, const float* __restrict__ adv, const int32_t* __restrict__ sign_perm, uint64_t clock_mask,
+                                                         const float* __restrict__ mean, const float* __restrict__ stdv, float* __restrict__ obs_raw, float* __restrict__ xn,
+                                                         float* __restrict__ xa, float* __restrict__ act_p, float* __restrict__ ret_p, float* __restrict__ adv_p, float* __restrict__ mask) {
+    const long r = blockIdx.x * 4l + (threadIdx.x >> 6);
+    const int c = threadIdx.x & 63;
+    if (r >= rows) return;
+    const long src = idx[r];
+    const bool valid = src >= 0;
+    const long t = r / B, b = r - t * B;
+    for (int k = c; k < D; k += 64) {
+        const float v = valid ? obs[src * D + k] : 0.f;
+        obs_raw[r * D + k] = v;
+        const float n = (v - mean[k]) / stdv[k];
+        xn[r * D + k] = n;
+        if (xa) {
+            xa[(t * 2 * B + b) * D + k] = n;
+            const int32_t sp = sign_perm[k];
+            float m = valid ? (sp >= 0 ? obs[src * D + sp] : -obs[src * D + (-sp - 1)]) : (sp >= 0 ? 0.f : -0.f);
+            if (k < 64 && ((clock_mask >> k) & 1ull)) m = sinf(asinf(m) + 3.14159265358979323846f);      // wrappers.py:65-66 (a padded row: sin(pi), like the reference's mirrored zeros)
+            xa[(t * 2 * B + B + b) * D + k] = (m - mean[k]) / stdv[k];
         }
     }
+    for (int k = c; k < A; k += 64) act_p[r * A + k] = valid ? act[src * A + k] : 0.f;
+    if (c == 0) { ret_p[r] = valid ? ret[src] : 0.f; adv_p[r] = valid ? adv[src] : 0.f; mask[r] = valid ? 1.f : 0.f; }
+}
+extern "C" int apx_rec_gather(const int64_t* idx, int T, int64_t B, int D, int A, const float* obs, const float* act, const float* ret, const float* adv,
+                              const int32_t* obs_sign_perm, uint64_t clock_mask, const float* obs_mean, const float* obs_std, float* obs_raw, float* xn, float* xa,
+                              float* act_p, float* ret_p, float* adv_p, float* mask, void* stream) {
+    APX_REQUIRE(idx && obs && act && ret && adv && obs_mean && obs_std && obs_raw && xn && act_p && ret_p && adv_p && mask && T > 0 && B > 0 && D > 0 && A > 0, "rec gather arguments");
+    APX_REQUIRE((xa == nullptr) == (obs_sign_perm == nullptr), "xa (the [x | mirror(x)] batch) goes with obs_sign_perm");
+    const long rows = (long)T * B;
+    hipLaunchKernelGGL(rec_gather_kernel, dim3(apx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, idx, rows, (long)B, D, A, obs, act, ret, adv, obs_sign_perm, clock_mask,
+                       obs_mean, obs_std, obs_raw, xn, xa, act_p, ret_p, adv_p, mask);
+    APX_LAUNCH_CHECK();
     return APX_OK;
 }
 

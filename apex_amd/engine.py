@@ -291,9 +291,11 @@ class RecurrentPPOLearner:
             self.obs_src = torch.as_tensor(np.where(sp >= 0, sp, -sp - 1), dtype=torch.long, device=device)
             self.obs_sgn = torch.as_tensor(np.where(sp >= 0, 1.0, -1.0), dtype=torch.float32, device=device)
             self.act_sp = torch.as_tensor(signed_perm_from_mirror(mirrored_acts), device=device)
+            self.obs_sp = torch.as_tensor(np.asarray(sp, dtype=np.int32), device=device)
             self.clock_cols = [int(c) for c in clock_inds]
             if any(not 0 <= c < obs_dim for c in self.clock_cols):
                 raise ValueError("clock indices %r outside the %d-entry observation" % (self.clock_cols, obs_dim))
+            self.clock_mask = sum(1 << c for c in self.clock_cols)
         self._scal = torch.zeros(6, dtype=torch.float64, device=device)
         self._acc = torch.zeros(8, dtype=torch.float64, device=device)
 
@@ -307,18 +309,39 @@ class RecurrentPPOLearner:
             m[..., c] = torch.sin(torch.asin(m[..., c]) + np.pi)
         return m
 
-    def minibatch(self, obs, act, ret, adv, mask, mirror=True, grad_only=False):
+    def gather(self, idx, obs, act, ret, adv, mirror=True):
+        """The padded minibatch of ppo.py:411-430 out of the rollout grid in one launch (apx_rec_gather).  idx [T, B] int64 flat grid rows, -1 = padded; obs [rows, D],
+        act [rows, A], ret / adv [rows].  Returns (obs [T, B, D], act, ret, adv, mask [T, B, 1], prepared) for minibatch(..., prepared=prepared)."""
+        _need_gpu(idx, obs)
+        T, B = idx.shape
+        D, A = self.actor.D, self.actor.O
+        dev = obs.device
+        use_mirror = mirror and self.act_sp is not None
+        e = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+        obs_raw, xn, act_p, ret_p, adv_p, mask = e(T, B, D), e(T, B, D), e(T, B, A), e(T, B, 1), e(T, B, 1), e(T, B, 1)
+        xa = e(T, 2 * B, D) if use_mirror else None
+        assert idx.is_contiguous() and obs.is_contiguous() and act.is_contiguous() and ret.is_contiguous() and adv.is_contiguous()
+        check(_lib.load().apx_rec_gather(_p(idx), T, B, D, A, _p(obs), _p(act), _p(ret), _p(adv), _p(self.obs_sp) if use_mirror else None,
+                                         self.clock_mask if use_mirror else 0, _p(self.obs_mean), _p(self.obs_std), _p(obs_raw), _p(xn), _p(xa), _p(act_p), _p(ret_p),
+                                         _p(adv_p), _p(mask), _stream()))
+        return obs_raw, act_p, ret_p, adv_p, mask, (xn, xa if use_mirror else xn)
+
+    def minibatch(self, obs, act, ret, adv, mask, mirror=True, grad_only=False, prepared=None):
         """obs [T, B, D], act [T, B, A], ret / adv / mask [T, B, 1] padded like torch's pad_sequence.  Returns the six scalars (device f64).
         The three sequence passes that do not depend on each other (old policy, new policy, critic) are latency-bound chains of small
-        launches; they run on three HIP streams side by side, and so do the actor's and the critic's backward passes."""
+        launches; they run on three HIP streams side by side, and so do the actor's and the critic's backward passes.
+        prepared = the (xn, xa) pair of gather(): the normalised / mirrored inputs are not rebuilt."""
         lib = _lib.load()
         T, B, _ = obs.shape
         A = self.actor.O
         norm = lambda o: ((o - self.obs_mean) / self.obs_std).contiguous()
-        xn = norm(obs)
         obs_c = obs.contiguous()
         use_mirror = mirror and self.act_sp is not None
-        xa = torch.cat([xn, norm(self.mirror_obs(obs))], dim=1) if use_mirror else xn      # pi(s) and pi(M s) share the weights: one pass over 2B columns
+        if prepared is not None:
+            xn, xa = prepared
+        else:
+            xn = norm(obs)
+            xa = torch.cat([xn, norm(self.mirror_obs(obs))], dim=1) if use_mirror else xn      # pi(s) and pi(M s) share the weights: one pass over 2B columns
         main = torch.cuda.current_stream()
         if getattr(self, "_side", None) is None:
             self._side = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))

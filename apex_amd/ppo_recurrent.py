@@ -170,21 +170,21 @@ class RecurrentPPO:
     def trajectories(self):
         """(column, t0, t1) of every trajectory in the grid, in (column, time) order -> int64 [n_traj, 3] on the host."""
         end = self.b_end.t().contiguous().cpu().numpy()                              # [N, T]
-        out = []
-        for n in range(self.N):
-            t0 = 0
-            for t1 in np.nonzero(end[n])[0]:
-                out.append((n, t0, int(t1) + 1)); t0 = int(t1) + 1
-        return np.array(out, dtype=np.int64)
+        col, tend = np.nonzero(end)                                                  # row-major: sorted by column, then time
+        t1 = tend.astype(np.int64) + 1
+        t0 = np.zeros_like(t1)
+        if len(t1) > 1:
+            t0[1:] = np.where(col[1:] == col[:-1], t1[:-1], 0)                       # a trajectory starts where the previous one of its column ended
+        return np.stack([col.astype(np.int64), t0, t1], axis=1)
 
     def padded_index(self, trajs):
-        """Flat grid indices t * N + n of a set of trajectories as a [T_max, B] tensor, -1 where padded (torch's pad_sequence layout)."""
+        """Flat grid indices t * N + n of a set of trajectories as a [T_max, B] tensor, -1 where padded (torch's pad_sequence layout).
+        (Vectorised: as a Python loop over the 1024 trajectories of a minibatch it was 1.7 ms of host time in front of every 4 ms of learner kernels.)"""
         lens = trajs[:, 2] - trajs[:, 1]
-        Tm, B = int(lens.max()), len(trajs)
-        idx = np.full((Tm, B), -1, dtype=np.int64)
-        for b, (n, t0, t1) in enumerate(trajs):
-            idx[: t1 - t0, b] = np.arange(t0, t1) * self.N + n
-        return torch.as_tensor(idx, device=self.device)
+        Tm = int(lens.max())
+        tr = torch.as_tensor(np.ascontiguousarray(trajs), device=self.device)       # [B, 3]: 24 KB
+        tt = torch.arange(Tm, device=self.device, dtype=torch.int64).view(Tm, 1)
+        return torch.where(tt < (tr[:, 2] - tr[:, 1]).view(1, -1), (tr[:, 1].view(1, -1) + tt) * self.N + tr[:, 0].view(1, -1), -1)
 
     # ------------------------------------------------------------------------------------------ optimisation
     def update(self, ret):
@@ -218,11 +218,8 @@ class RecurrentPPO:
                     L.apply_grads()
                     continue
                 idx = self.padded_index(trajs[order[k:k + mb]])
-                valid = idx >= 0
-                gi = idx.clamp(min=0).view(-1)
-                pick = lambda x, d: (flat(x, d).index_select(0, gi) * valid.view(-1, 1)).view(idx.shape[0], idx.shape[1], d)
-                scal = L.minibatch(pick(self.b_obs, 50), pick(self.b_act, 10), pick(retf, 1), pick(adv, 1), valid.float().unsqueeze(-1),
-                                   mirror=self.mirror, grad_only=self.dist_on)
+                o_p, a_p, r_p, d_p, m_p, prep = L.gather(idx, flat(self.b_obs, 50), flat(self.b_act, 10), retf, adv, mirror=self.mirror)      # one launch (apx_rec_gather)
+                scal = L.minibatch(o_p, a_p, r_p, d_p, m_p, mirror=self.mirror, grad_only=self.dist_on, prepared=prep)
                 if self.dist_on:
                     adist.allreduce_mean_(L.grad_flat, group=self.group, world=self.world)
                     L.apply_grads()

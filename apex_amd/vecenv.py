@@ -150,6 +150,10 @@ class CassieVecEnv:
         """apx_env_prepare_resets: precompute the next two resets of every env (draws, set_const, forward pass) off the rollout's critical path"""
         check(_lib.load().apx_env_prepare_resets(self._h, _stream()))
 
+    def set_refill(self, on):
+        """apx_env_set_refill: refill the reset ring of the envs that just restarted next to the following env step (default: on up to 2048 envs)"""
+        check(_lib.load().apx_env_set_refill(self._h, int(bool(on))))
+
     def _push(self, frame, restart, out):
         """state_history.insert(0, state)[:history + 1] (cassie.py:856-859); envs in `restart` begin a new episode: zero history first (:565)"""
         D = self.frame_dim

@@ -123,6 +123,15 @@ int apx_lstm_step(const float* packed, int D, int H, int L, int O, const float* 
 int apx_lstm_backward(const float* params, float* grads, int D, int H, int L, int O, const float* x, int T, int64_t B,
                       const float* save, const float* dy, float* scratch, void* stream);
 
+/* The padded minibatch of the recurrent update (rl/algos/ppo.py:411-430: pad_sequence over the sampled trajectories, zero rows behind a trajectory's end) gathered out of
+ * the rollout grid in one launch.  idx [T, B] int64: flat grid row of (t, b), -1 = padded.  obs [rows_total, D], act [rows_total, A], ret / adv [rows_total].
+ * Outputs (all [T, B, .] f32): obs_raw (LSTM_V's input, critic.py:262-263), xn = (obs - obs_mean) / obs_std, act_p, ret_p, adv_p, mask (1 = real row), and - when
+ * obs_sign_perm is given (SymmetricEnv.mirror_clock_observation, rl/envs/wrappers.py:59-67; clock_mask as in apx_mlp_forward) - xa [T, 2 B, D] = [xn | normalised
+ * mirrored observation] along the batch axis (pi(s) and pi(M s) share the weights: one 2 B-column pass).  xa and obs_sign_perm are both NULL or both given. [dev] */
+int apx_rec_gather(const int64_t* idx, int T, int64_t B, int D, int A, const float* obs, const float* act, const float* ret, const float* adv,
+                   const int32_t* obs_sign_perm, uint64_t clock_mask, const float* obs_mean, const float* obs_std, float* obs_raw, float* xn, float* xa,
+                   float* act_p, float* ret_p, float* adv_p, float* mask, void* stream);
+
 /* The loss stage of PPO.update_policy alone (rl/algos/ppo.py:284-318,338-345) for callers that run their own forward / backward (the
  * recurrent path): rows = T*B entries of a padded batch, mu / mum (mirrored branch, NULL = no mirror loss) [rows,A], v [rows], act
  * [rows,A], ret / adv / mask [rows] (mask NULL = all ones; it weights the actor and critic terms only, every mean is over ALL rows like
@@ -224,6 +233,10 @@ int apx_env_reset(apx_env_t* env, const uint8_t* mask, float* obs_out, void* str
  * way: reset draws are keyed by (seed, env, episode index), not by the env's running draw counter.  The ring is dropped by apx_env_set_hfield,
  * apx_env_apply_force(_body) and apx_env_set_field. */
 int apx_env_prepare_resets(apx_env_t* env, void* stream);
+/* The same hook inside a rollout: when on, every auto-reset of apx_env_step / apx_rollout is followed by the ring refill of the envs that just restarted (their next two
+ * episodes), launched on a stream the env owns, next to the following env step; the next reset launch waits for it.  Default: on for n_envs <= 2048 (an env step of up
+ * to 2048 envs leaves half of the SIMDs idle), off above.  Results do not depend on it (same bits, see apx_env_prepare_resets). */
+int apx_env_set_refill(apx_env_t* env, int on);
 
 /* Evaluation-side API.
  * CassieEnv.update_speed (cassie/cassie.py:757-775, clock command profile) for every env: speed[n_envs] f32 [dev],

@@ -1057,14 +1057,18 @@ def test_prepared_resets_are_bit_identical_to_computed_ones(dev):
     every step and one never, must stay BIT-identical over rollouts full of resets (random actions, short episodes: envs that end three times between two
     preparations exercise the fallback as well), for both env kinds and the phase command profile."""
     from apex_amd.vecenv import CassieVecEnv
-    for kw, prep_every in ((dict(), 1), (dict(), 25), (dict(env_name="CassieTraj-v0"), 3), (dict(command_profile="phase"), 2), (dict(dynamics_randomization=False), 1)):
+    # (+ apx_env_set_refill: env a also refills the ring of the envs that just restarted on its own side stream, next to the following env step; env b never does)
+    for kw, prep_every, refill in ((dict(), 1, False), (dict(), 25, False), (dict(env_name="CassieTraj-v0"), 3, False), (dict(command_profile="phase"), 2, False),
+                                   (dict(dynamics_randomization=False), 1, False), (dict(), 1000, True), (dict(env_name="CassieTraj-v0"), 7, True),
+                                   (dict(command_profile="phase"), 1000, True), (dict(dynamics_randomization=False), 1000, True)):
         a = CassieVecEnv(n_envs=256, seed=31, max_traj_len=12, **kw); b = CassieVecEnv(n_envs=256, seed=31, max_traj_len=12, **kw)
+        a.set_refill(refill); b.set_refill(False)
         oa, ob = a.reset().clone(), b.reset().clone()
         assert torch.equal(oa, ob)
         g = torch.Generator(device=dev); g.manual_seed(4)
         nres = 0
         for t in range(40):
-            if t % prep_every == 0:
+            if t % prep_every == 0 and (t > 0 or not refill):
                 a.prepare_resets()
             act = torch.randn(256, 10, device=dev, generator=g) * 0.3
             oa, ra, da, fa = a.step(act); ob, rb, db, fb = b.step(act)

@@ -542,3 +542,37 @@ def test_fused_recurrent_step_equals_the_per_launch_chain(dev):
         y_a = net.forward(x.contiguous(), hc=hc_a); y_b = net.step(x, hc_b)
         np.testing.assert_allclose(y_b.cpu().numpy(), y_a.cpu().numpy(), rtol=0, atol=2e-5)
     assert not engine.Lstm(50, 64, 2, 10, dev).step_supported() and not engine.Lstm(80, 128, 2, 10, dev).step_supported()
+
+
+def test_rec_gather_equals_the_torch_assembly(dev):
+    """apx_rec_gather (the padded recurrent minibatch in one launch) against the torch ops it replaces: index_select of the grid rows times the 0 / 1 mask,
+    (x - mean) / std, SymmetricEnv.mirror_clock_observation on the PADDED observations (zero rows included: the reference's mirror term is not masked), cat along
+    the batch axis.  Bit-exact: same formulas, same libm routines."""
+    from apex_amd import engine
+    from apex_amd.ppo import MIRRORED_OBS, MIRRORED_ACTS, CLOCK_INDS
+    g = torch.Generator(device=dev); g.manual_seed(9)
+    L = engine.RecurrentPPOLearner(50, 10, 128, 2, dev, 0.13, mirrored_obs=MIRRORED_OBS, mirrored_acts=MIRRORED_ACTS, clock_inds=CLOCK_INDS)
+    L.obs_mean.copy_(torch.randn(50, device=dev, generator=g)); L.obs_std.copy_(torch.rand(50, device=dev, generator=g) + 0.5)
+    rows = 5000
+    obs = torch.randn(rows, 50, device=dev, generator=g) * 0.7
+    obs[:, list(CLOCK_INDS)] = torch.sin(torch.rand(rows, 2, device=dev, generator=g) * 6.28)      # the clock columns live in [-1, 1]
+    act = torch.randn(rows, 10, device=dev, generator=g); ret = torch.randn(rows, device=dev, generator=g); adv = torch.randn(rows, device=dev, generator=g)
+    for T, B in ((37, 21), (1, 3), (64, 256)):
+        idx = torch.randint(0, rows, (T, B), device=dev, generator=g)
+        lens = torch.randint(1, T + 1, (B,), device=dev, generator=g)
+        idx = torch.where(torch.arange(T, device=dev).view(T, 1) < lens.view(1, B), idx, -1).contiguous()
+        for mirror in (True, False):
+            o, a, r, d, m, (xn, xa) = L.gather(idx, obs, act, ret, adv, mirror=mirror)
+            valid = idx >= 0; gi = idx.clamp(min=0).view(-1)
+            pick = lambda x, dd: (x.view(rows, dd).index_select(0, gi) * valid.view(-1, 1)).view(T, B, dd)
+            o_ref = pick(obs, 50)
+            norm = lambda z: (z - L.obs_mean) / L.obs_std
+            assert torch.equal(o, o_ref) and torch.equal(a, pick(act, 10)) and torch.equal(r, pick(ret, 1)) and torch.equal(d, pick(adv, 1))
+            assert torch.equal(m, valid.float().unsqueeze(-1))
+            assert torch.equal(xn, norm(o_ref))
+            if mirror:
+                ref = torch.cat([norm(o_ref), norm(L.mirror_obs(o_ref))], dim=1)
+                assert xa.shape == ref.shape
+                np.testing.assert_allclose(xa.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-6)
+            else:
+                assert xa is xn
