@@ -253,7 +253,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 // The two big shapes of the backward pass - dX = dY W (M = batch, N = K = 256) and dW = dY^T X (M = N = 256, K = batch) - run at half the operand traffic per flop of the
 // 64 x 64 kernel: block tile 128 x 128 x 16, 4 waves, each wave a 64 x 64 sub-tile = 2 x 2 accumulators of v_mfma_f32_32x32x2_f32 (four MFMAs per four ds_read_b32), operands
 // fetched from HBM / L2 as float4 one k-tile ahead of the MFMAs.  Shapes: M, N multiples of 128, K chunks multiples of 16, B(k, n) contiguous in n (both call sites), A(m, k)
-// contiguous in k (dX) or in m (dW); everything else stays on gemm_f32_kernel.  Epilogues: EPI_STORE, EPI_MASK, EPI_PARTIAL (+ the fused bias gradient).
+// contiguous in k (dX) or in m (dW); B(k, n) contiguous in n, or in k (Y = X W^T + b: the LSTM's input projection of the upper layers, EPI_BIAS); everything else stays on
+// gemm_f32_kernel.  Epilogues: EPI_STORE, EPI_BIAS, EPI_MASK, EPI_PARTIAL (+ the fused bias gradient).
 #define G2M 128
 #define G2N 128
 #define G2P 132      /* LDS row pitch in floats: 16-byte aligned rows for the float4 stores of the m- / n-contiguous operands */
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_128_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = floatx16{0};
     const bool a_kmajor = g.a_cs == 1;
+    const bool b_kmajor = g.b_cs != 1;      // B(k, n) contiguous in k (Y = X W^T with W in torch layout: the forward pass); gemm128_ok admits b_cs == 1 or b_rs == 1
     const bool bias_grad = EPI == EPI_PARTIAL && g.aux != nullptr && blockIdx.y == 0;
     float bsum = 0.f;
     f4v ra[2], rb[2];
@@ -280,7 +282,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_128_kernel(GemmArgs g) {
         for (int i = 0; i < 2; ++i) {
             if (a_kmajor) { const int row = (tid >> 2) + 64 * i, kq = (tid & 3) * 4; ra[i] = *(const f4v*)(g.A + (long)(m0 + row) * g.a_rs + k0 + kq); }
             else          { const int k = (tid >> 5) + 8 * i, mq = (tid & 31) * 4;  ra[i] = *(const f4v*)(g.A + (long)(k0 + k) * g.a_cs + m0 + mq); }
-            { const int k = (tid >> 5) + 8 * i, nq = (tid & 31) * 4; rb[i] = *(const f4v*)(g.B + (long)(k0 + k) * g.b_rs + n0 + nq); }
+            if (b_kmajor) { const int row = (tid >> 2) + 64 * i, kq = (tid & 3) * 4; rb[i] = *(const f4v*)(g.B + (long)(n0 + row) * g.b_cs + k0 + kq); }
+            else          { const int k = (tid >> 5) + 8 * i, nq = (tid & 31) * 4; rb[i] = *(const f4v*)(g.B + (long)(k0 + k) * g.b_rs + n0 + nq); }
         }
     };
     fetch(kbeg);
@@ -291,7 +294,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_128_kernel(GemmArgs g) {
                 const int row = (tid >> 2) + 64 * i, kq = (tid & 3) * 4;
                 As[kq][row] = ra[i].x; As[kq + 1][row] = ra[i].y; As[kq + 2][row] = ra[i].z; As[kq + 3][row] = ra[i].w;
             } else { const int k = (tid >> 5) + 8 * i, mq = (tid & 31) * 4; *(f4v*)&As[k][mq] = ra[i]; }
-            { const int k = (tid >> 5) + 8 * i, nq = (tid & 31) * 4; *(f4v*)&Bs[k][nq] = rb[i]; }
+            if (b_kmajor) {
+                const int row = (tid >> 2) + 64 * i, kq = (tid & 3) * 4;
+                Bs[kq][row] = rb[i].x; Bs[kq + 1][row] = rb[i].y; Bs[kq + 2][row] = rb[i].z; Bs[kq + 3][row] = rb[i].w;
+            } else { const int k = (tid >> 5) + 8 * i, nq = (tid & 31) * 4; *(f4v*)&Bs[k][nq] = rb[i]; }
         }
         __syncthreads();
         if (k0 + GBK < kend) fetch(k0 + GBK);
@@ -321,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_128_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 float v = acc[i][j][r];
+                if (EPI == EPI_BIAS) v += g.aux[col];
                 if (EPI == EPI_MASK) v = g.aux[(long)row * g.ld_aux + col] > 0.f ? v : 0.f;
                 Cb[(long)row * g.ldc + col] = v;
             }
@@ -328,10 +335,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_128_kernel(GemmArgs g) {
 }
 static bool gemm128_ok(int epi, const GemmArgs& g, int kchunk) {
     static const bool off = getenv("APX_GEMM128") && atoi(getenv("APX_GEMM128")) == 0;
-    if (off || g.prec != 0 || !(epi == EPI_STORE || epi == EPI_MASK || epi == EPI_PARTIAL)) return false;
+    if (off || g.prec != 0 || !(epi == EPI_STORE || epi == EPI_MASK || epi == EPI_PARTIAL || epi == EPI_BIAS)) return false;
     if (g.M % G2M || g.N % G2N || g.K % GBK || kchunk % GBK || g.K < 64) return false;
     if (epi != EPI_PARTIAL && (long)(g.M / G2M) * (g.N / G2N) < 384) return false;      // too few 128 x 128 tiles to fill the chip: the 64 x 64 kernel's 4x workgroups hide the latency better
-    if (g.b_cs != 1 || g.b_rs % 4 || ((uintptr_t)g.B & 15) || ((uintptr_t)g.A & 15)) return false;
+    if (((uintptr_t)g.B & 15) || ((uintptr_t)g.A & 15)) return false;
+    if (!((g.b_cs == 1 && g.b_rs % 4 == 0) || (g.b_rs == 1 && g.b_cs % 4 == 0 && g.b_cs != 1))) return false;
     if (g.a_cs == 1) return g.a_rs % 4 == 0;
     return g.a_rs == 1 && g.a_cs % 4 == 0;
 }
@@ -454,6 +462,7 @@ static int launch_gemm(int epi, const GemmArgs& g0, int ksplit, hipStream_t s) {
         switch (epi) {
             case EPI_STORE: hipLaunchKernelGGL(gemm_f32_128_kernel<EPI_STORE>, grid2, block, 0, s, g); break;
             case EPI_MASK: hipLaunchKernelGGL(gemm_f32_128_kernel<EPI_MASK>, grid2, block, 0, s, g); break;
+            case EPI_BIAS: hipLaunchKernelGGL(gemm_f32_128_kernel<EPI_BIAS>, grid2, block, 0, s, g); break;
             default: hipLaunchKernelGGL(gemm_f32_128_kernel<EPI_PARTIAL>, grid2, block, 0, s, g); break;
         }
         APX_LAUNCH_CHECK();
@@ -1307,6 +1316,9 @@ __device__ __forceinline__ void lstm_step_layer(const float (*tile)[K + 4], cons
         acc[g] = floatx4{b, b, b, b};
         wrow[g] = Wc + (long)n * K + 4 * kg;
     }
+    float cprev[4];                                     // the carried cell state of the lane's (row, unit) pairs: in flight across the MFMAs
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const long grow = r0 + 4 * kg + r; cprev[r] = (grow < B && live[r]) ? cslot[grow * H + wave * UW + col] : 0.f; }
     f4w wq[LS_PF + 1][4];
 #pragma unroll
     for (int p = 0; p < LS_PF; ++p)
@@ -1329,8 +1341,7 @@ __device__ __forceinline__ void lstm_step_layer(const float (*tile)[K + 4], cons
         const int row = 4 * kg + r, unit = wave * UW + col;
         const long grow = r0 + row;
         const float i = sigmf(acc[0][r]), f = sigmf(acc[1][r]), gg = tanhf(acc[2][r]), o = sigmf(acc[3][r]);
-        const float cp = (grow < B && live[r]) ? cslot[grow * H + unit] : 0.f;
-        const float c = f * cp + i * gg, h = o * tanhf(c);
+        const float c = f * cprev[r] + i * gg, h = o * tanhf(c);
         if (grow < B) { cslot[grow * H + unit] = c; hslot[grow * H + unit] = h; }
         hn[row * hn_pitch + unit] = h;
     }
@@ -1365,12 +1376,25 @@ __global__ __launch_bounds__(64 * LS_NW) void lstm_step_fused_kernel(const float
     __syncthreads();
     lstm_step_layer<K2>(t2, P.W2, P.b2, h1, c1, live, r0, B, &t1[0][0], K1 + 4);
     __syncthreads();
-    if (tid < 16 * O) {
-        const int r = tid / O, o = tid - r * O; const long row = r0 + r;
-        float sacc = P.bo[o];
-#pragma unroll 8
-        for (int k = 0; k < H; ++k) sacc += t1[r][k] * P.Wo[o * H + k];
-        if (row < B) {
+    // head: two lanes per (row, output), 64 k each as 16 float4 of W_o (all in flight at once) against the row of h2 in LDS, pair sum over DPP.  (One thread per output with
+    // a 128-long loop was a chain of sixteen L2 round trips at the end of the launch.)
+    {
+        typedef float f4w __attribute__((ext_vector_type(4)));
+        const int pair = tid >> 1, half = tid & 1;
+        const bool on = pair < 16 * O;
+        const int r = on ? pair / O : 0, o = on ? pair - r * O : 0; const long row = r0 + r;
+        f4w w[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) w[q] = *reinterpret_cast<const f4w*>(P.Wo + (size_t)o * H + 64 * half + 4 * q);
+        float sacc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const f4w h = *reinterpret_cast<const f4w*>(&t1[r][64 * half + 4 * q]);
+            sacc += h[0] * w[q][0] + h[1] * w[q][1] + h[2] * w[q][2] + h[3] * w[q][3];
+        }
+        sacc += __shfl_xor(sacc, 1);
+        if (on && half == 0 && row < B) {
+            sacc += P.bo[o];
             y[row * O + o] = sacc;
             if (act) act[row * O + o] = sacc + (noise ? sigma * noise[row * O + o] : 0.f);
         }

@@ -125,8 +125,14 @@ class RecurrentPPO:
         if fused:
             L.actor.pack_step(); L.critic.pack_step()
             side.wait_stream(main)
+        # the env writes the next observation straight into the grid row of the next step (no per-step copy); the last one goes to a scratch row
+        self.b_obs[0].copy_(obs)
+        nxt_last = torch.empty_like(obs)
+        noise_all = None
+        if self.noise_fn is None:      # every step's action noise in one launch instead of one small launch per step in front of the policy step
+            noise_all = torch.empty(T, N, 10, device=self.device).normal_(generator=self.gen)
         for t in range(T):
-            self.b_obs[t].copy_(obs)
+            nxt = self.b_obs[t + 1] if t + 1 < T else nxt_last
             ev_obs = main.record_event()
             prev_done = self.b_done[t - 1] if (fused and t > 0) else None      # uint8 0 / 1 / 2: non-zero rows start from a zero state
             with torch.cuda.stream(side):
@@ -135,16 +141,16 @@ class RecurrentPPO:
                     L.critic.step(self.b_obs[t], hc_c, reset=prev_done, y_out=self.b_val[t].view(N, 1))
                 else:
                     self.b_val[t].copy_(L.critic.forward(self.b_obs[t], hc=hc_c).view(-1))
-            if self.noise_fn is None:
-                noise.normal_(generator=self.gen)
+            if noise_all is not None:
+                noise = noise_all[t]
             else:
                 self.noise_fn(t, noise)
             if fused:
                 L.actor.step(self.b_obs[t], hc_a, L.obs_mean, L.obs_std, reset=prev_done, noise=noise, sigma=self.fixed_std, act_out=self.b_act[t])
             else:
-                mu = L.actor.forward(norm(obs), hc=hc_a)
+                mu = L.actor.forward(norm(self.b_obs[t]), hc=hc_a)
                 torch.add(mu, noise, alpha=self.fixed_std, out=self.b_act[t])
-            env.step(self.b_act[t], out=(obs, self.b_rew[t], self.b_done[t], self.b_fin[t]))      # writes the next observation into `obs`
+            env.step(self.b_act[t], out=(nxt, self.b_rew[t], self.b_done[t], self.b_fin[t]))      # writes the next observation into the next grid row
             ev_step = main.record_event()
             last = t == T - 1
             with torch.cuda.stream(side):
@@ -154,10 +160,9 @@ class RecurrentPPO:
                 if last or t + 1 >= self.max_traj_len:      # V(s') with the critic's carried state (ppo.py:183-184), without advancing it
                     tr = self.b_done[t] == 2
                     rows = tr if not last else (tr | (self.b_done[t] == 0))
-                    src = torch.where((self.b_done[t] != 0).view(N, 1), self.b_fin[t], obs)      # the episode's own next observation
+                    src = torch.where((self.b_done[t] != 0).view(N, 1), self.b_fin[t], nxt)      # the episode's own next observation
                     v_next = L.critic.forward(src.contiguous(), hc=hc_c.clone()).view(-1)
                     self.b_boot[t] = torch.where(rows, v_next, torch.zeros_like(v_next))
-                    main.wait_event(side.record_event())      # `obs` is overwritten by the next env step
                 if not fused:
                     hc_c.masked_fill_((self.b_done[t] != 0).view(1, 1, N, 1), 0.0)      # init_hidden_state at every episode start (ppo.py:164-168); an assignment, not a product: 0 * NaN stays NaN
             if not fused:

@@ -576,3 +576,26 @@ def test_rec_gather_equals_the_torch_assembly(dev):
                 np.testing.assert_allclose(xa.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-6)
             else:
                 assert xa is xn
+
+
+def test_lstm_forward_backward_large_batch_equals_small_batches(dev):
+    """The large-shape paths of the recurrent learner - the 128 x 128 GEMM with a k-contiguous B operand and bias epilogue (upper layers' input projection), the K-chunk
+    slabs + grad_reduce of the weight gradients, the prefetching sequence kernels - against the same network run over 64-column slices of the batch, which stay on the
+    64 x 64 kernels and the atomic split-K: outputs 1e-5, gradients 2e-4 relative to their scale (sums over 16 384 rows in a different order)."""
+    from apex_amd import engine
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    T, B, D, O = 8, 2048, 49, 10
+    net = engine.Lstm(D, 128, 2, O, dev)
+    net.params.copy_(torch.randn(net.n, device=dev, generator=g) * 0.08)
+    x = torch.randn(T, B, D, device=dev, generator=g); dy = torch.randn(T, B, O, device=dev, generator=g) * 0.1
+    y, x3, save = net.forward(x, keep=True)
+    gr = torch.zeros(net.n, device=dev); net.backward(gr, x3, save, dy)
+    gr_s = torch.zeros(net.n, device=dev); ys = []
+    for b0 in range(0, B, 64):
+        xs = x[:, b0:b0 + 64].contiguous()
+        y1, x31, save1 = net.forward(xs, keep=True); ys.append(y1)
+        net.backward(gr_s, x31, save1, dy[:, b0:b0 + 64].contiguous())
+    np.testing.assert_allclose(y.cpu().numpy(), torch.cat(ys, 1).cpu().numpy(), rtol=0, atol=1e-5)
+    for name, a, b in zip(("Wih0", "Whh0", "bih0", "bhh0", "Wih1", "Whh1", "bih1", "bhh1", "Wo", "bo"), net.views(gr), net.views(gr_s)):
+        scale = float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) < 2e-4 * scale, (name, float((a - b).abs().max()), scale)
