@@ -60,7 +60,7 @@ SIGNATURES = {
     "apx_lstm_step_pack_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "apx_lstm_step_pack": (C.c_int, [c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr]),
     "apx_lstm_step": (C.c_int, [c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int64, c_ptr, c_ptr, c_ptr, C.c_float, c_ptr]),
-    "apx_rec_gather": (C.c_int, [c_ptr, C.c_int, C.c_int64, C.c_int, C.c_int] + [c_ptr] * 5 + [C.c_uint64] + [c_ptr] * 10),
+    "apx_rec_gather": (C.c_int, [c_ptr, c_ptr, c_ptr, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int] + [c_ptr] * 5 + [C.c_uint64] + [c_ptr] * 10),
     "apx_lstm_backward": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, C.c_int, C.c_int64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "apx_mlp_forward": (C.c_int, [c_ptr, C.c_int, C.c_int, C.c_int, c_ptr, C.c_int64, c_ptr, c_ptr, C.c_uint64, c_ptr,
                                   c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, c_ptr]),

@@ -1471,16 +1471,21 @@ extern "C" int apx_lstm_backward(const float* params, float* grads, int D, int H
 // grid in ONE launch: raw observations (LSTM_V's input), normalised observations (old policy), [normalised | mirrored + normalised] side by side along the batch axis
 // (pi(s) and pi(M s) as one 2 B-column pass), actions, returns, advantages and the 0 / 1 mask.  As torch ops this was 26 launches per minibatch (4 gathers, the masks,
 // normalise, mirror with its asin / sin columns, cat): 0.45 ms of a 5.9 ms minibatch.  One wave per padded row, lane = column.
-__global__ __launch_bounds__(256) void rec_gather_kernel(const int64_t* __restrict__ idx, long rows, long B, int D, int A, const float* __restrict__ obs, const float* __restrict__ act,
+__global__ __launch_bounds__(256) void rec_gather_kernel(const int64_t* __restrict__ idx, const int64_t* __restrict__ traj, const int64_t* __restrict__ sel, long N, long rows, long B, int D, int A, const float* __restrict__ obs, const float* __restrict__ act,
                                                          const float* __restrict__ ret, const float* __restrict__ adv, const int32_t* __restrict__ sign_perm, uint64_t clock_mask,
                                                          const float* __restrict__ mean, const float* __restrict__ stdv, float* __restrict__ obs_raw, float* __restrict__ xn,
                                                          float* __restrict__ xa, float* __restrict__ act_p, float* __restrict__ ret_p, float* __restrict__ adv_p, float* __restrict__ mask) {
     const long r = blockIdx.x * 4l + (threadIdx.x >> 6);
     const int c = threadIdx.x & 63;
     if (r >= rows) return;
-    const long src = idx[r];
-    const bool valid = src >= 0;
     const long t = r / B, b = r - t * B;
+    long src;
+    if (idx) src = idx[r];
+    else {      // column b = trajectory sel[b] = (grid column n, t0, t1): its step t sits in grid row (t0 + t) N + n
+        const int64_t* tr = traj + 3 * (sel ? sel[b] : b);
+        src = t < tr[2] - tr[1] ? (tr[1] + t) * N + tr[0] : -1;
+    }
+    const bool valid = src >= 0;
     for (int k = c; k < D; k += 64) {
         const float v = valid ? obs[src * D + k] : 0.f;
         obs_raw[r * D + k] = v;
@@ -1497,13 +1502,13 @@ __global__ __launch_bounds__(256) void rec_gather_kernel(const int64_t* __restri
     for (int k = c; k < A; k += 64) act_p[r * A + k] = valid ? act[src * A + k] : 0.f;
     if (c == 0) { ret_p[r] = valid ? ret[src] : 0.f; adv_p[r] = valid ? adv[src] : 0.f; mask[r] = valid ? 1.f : 0.f; }
 }
-extern "C" int apx_rec_gather(const int64_t* idx, int T, int64_t B, int D, int A, const float* obs, const float* act, const float* ret, const float* adv,
+extern "C" int apx_rec_gather(const int64_t* idx, const int64_t* traj, const int64_t* sel, int64_t N, int T, int64_t B, int D, int A, const float* obs, const float* act, const float* ret, const float* adv,
                               const int32_t* obs_sign_perm, uint64_t clock_mask, const float* obs_mean, const float* obs_std, float* obs_raw, float* xn, float* xa,
                               float* act_p, float* ret_p, float* adv_p, float* mask, void* stream) {
-    APX_REQUIRE(idx && obs && act && ret && adv && obs_mean && obs_std && obs_raw && xn && act_p && ret_p && adv_p && mask && T > 0 && B > 0 && D > 0 && A > 0, "rec gather arguments");
+    APX_REQUIRE((idx || (traj && N > 0)) && obs && act && ret && adv && obs_mean && obs_std && obs_raw && xn && act_p && ret_p && adv_p && mask && T > 0 && B > 0 && D > 0 && A > 0, "rec gather arguments");
     APX_REQUIRE((xa == nullptr) == (obs_sign_perm == nullptr), "xa (the [x | mirror(x)] batch) goes with obs_sign_perm");
     const long rows = (long)T * B;
-    hipLaunchKernelGGL(rec_gather_kernel, dim3(apx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, idx, rows, (long)B, D, A, obs, act, ret, adv, obs_sign_perm, clock_mask,
+    hipLaunchKernelGGL(rec_gather_kernel, dim3(apx_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, idx, traj, sel, (long)N, rows, (long)B, D, A, obs, act, ret, adv, obs_sign_perm, clock_mask,
                        obs_mean, obs_std, obs_raw, xn, xa, act_p, ret_p, adv_p, mask);
     APX_LAUNCH_CHECK();
     return APX_OK;

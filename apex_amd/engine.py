@@ -309,19 +309,26 @@ class RecurrentPPOLearner:
             m[..., c] = torch.sin(torch.asin(m[..., c]) + np.pi)
         return m
 
-    def gather(self, idx, obs, act, ret, adv, mirror=True):
-        """The padded minibatch of ppo.py:411-430 out of the rollout grid in one launch (apx_rec_gather).  idx [T, B] int64 flat grid rows, -1 = padded; obs [rows, D],
-        act [rows, A], ret / adv [rows].  Returns (obs [T, B, D], act, ret, adv, mask [T, B, 1], prepared) for minibatch(..., prepared=prepared)."""
-        _need_gpu(idx, obs)
-        T, B = idx.shape
+    def gather(self, idx, obs, act, ret, adv, mirror=True, traj=None, sel=None, grid_cols=0, t_max=0):
+        """The padded minibatch of ppo.py:411-430 out of the rollout grid in one launch (apx_rec_gather).  Either idx [T, B] int64 flat grid rows, -1 = padded, or
+        (idx None) traj [n_traj, 3] int64 (column, t0, t1) + sel [B] int64 trajectory numbers + grid_cols + t_max = the longest selected trajectory (the index is then
+        formed inside the kernel); obs [rows, D], act [rows, A], ret / adv [rows].  Returns (obs [T, B, D], act, ret, adv, mask [T, B, 1], prepared) for
+        minibatch(..., prepared=prepared)."""
+        _need_gpu(obs)
+        if idx is not None:
+            T, B = idx.shape
+            assert idx.is_contiguous()
+        else:
+            T, B = int(t_max), int(sel.shape[0])
+            assert traj.is_contiguous() and sel.is_contiguous() and traj.dtype == torch.int64 and sel.dtype == torch.int64 and grid_cols > 0 and T > 0
         D, A = self.actor.D, self.actor.O
         dev = obs.device
         use_mirror = mirror and self.act_sp is not None
         e = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
         obs_raw, xn, act_p, ret_p, adv_p, mask = e(T, B, D), e(T, B, D), e(T, B, A), e(T, B, 1), e(T, B, 1), e(T, B, 1)
         xa = e(T, 2 * B, D) if use_mirror else None
-        assert idx.is_contiguous() and obs.is_contiguous() and act.is_contiguous() and ret.is_contiguous() and adv.is_contiguous()
-        check(_lib.load().apx_rec_gather(_p(idx), T, B, D, A, _p(obs), _p(act), _p(ret), _p(adv), _p(self.obs_sp) if use_mirror else None,
+        assert obs.is_contiguous() and act.is_contiguous() and ret.is_contiguous() and adv.is_contiguous()
+        check(_lib.load().apx_rec_gather(_p(idx), _p(traj), _p(sel), int(grid_cols), T, B, D, A, _p(obs), _p(act), _p(ret), _p(adv), _p(self.obs_sp) if use_mirror else None,
                                          self.clock_mask if use_mirror else 0, _p(self.obs_mean), _p(self.obs_std), _p(obs_raw), _p(xn), _p(xa), _p(act_p), _p(ret_p),
                                          _p(adv_p), _p(mask), _stream()))
         return obs_raw, act_p, ret_p, adv_p, mask, (xn, xa if use_mirror else xn)

@@ -203,6 +203,8 @@ class RecurrentPPO:
         # optimiser steps per epoch is agreed first (max over ranks); a rank that has run out of trajectories contributes a zero gradient to
         # the remaining all-reduces.  Every rank therefore issues the same sequence of collectives and ends with the same parameters.
         n_mb = -(-len(trajs) // mb)
+        trajs_dev = torch.as_tensor(np.ascontiguousarray(trajs), device=self.device)      # [n_traj, 3] (column, t0, t1)
+        lens = trajs[:, 2] - trajs[:, 1]
         if self.dist_on:
             cnt = torch.tensor([n_mb], dtype=torch.int64, device=self.device)
             torch.distributed.all_reduce(cnt, op=torch.distributed.ReduceOp.MAX, group=self.group)
@@ -212,8 +214,10 @@ class RecurrentPPO:
         for epoch in range(self.epochs):
             if self.perm_fn is not None:
                 order = np.asarray(self.perm_fn(epoch))
+                order_dev = torch.as_tensor(order.astype(np.int64), device=self.device)
             else:
-                order = torch.randperm(len(trajs), device=self.device, generator=self.gen).cpu().numpy()      # SubsetRandomSampler over trajectories
+                order_dev = torch.randperm(len(trajs), device=self.device, generator=self.gen)      # SubsetRandomSampler over trajectories
+                order = order_dev.cpu().numpy()
             acc = torch.zeros(6, dtype=torch.float64, device=self.device); nb = 0
             for kk in range(n_mb):                                               # BatchSampler(..., drop_last=False), ppo.py:413
                 k = kk * mb
@@ -222,8 +226,10 @@ class RecurrentPPO:
                     adist.allreduce_mean_(L.grad_flat, group=self.group, world=self.world)
                     L.apply_grads()
                     continue
-                idx = self.padded_index(trajs[order[k:k + mb]])
-                o_p, a_p, r_p, d_p, m_p, prep = L.gather(idx, flat(self.b_obs, 50), flat(self.b_act, 10), retf, adv, mirror=self.mirror)      # one launch (apx_rec_gather)
+                # one launch (apx_rec_gather); the [T_max, B] index of padded_index() is formed inside it from the trajectory list
+                sel = order_dev[k:k + mb]
+                o_p, a_p, r_p, d_p, m_p, prep = L.gather(None, flat(self.b_obs, 50), flat(self.b_act, 10), retf, adv, mirror=self.mirror, traj=trajs_dev, sel=sel,
+                                                         grid_cols=self.N, t_max=int(lens[order[k:k + mb]].max()))
                 scal = L.minibatch(o_p, a_p, r_p, d_p, m_p, mirror=self.mirror, grad_only=self.dist_on, prepared=prep)
                 if self.dist_on:
                     adist.allreduce_mean_(L.grad_flat, group=self.group, world=self.world)

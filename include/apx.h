@@ -124,11 +124,13 @@ int apx_lstm_backward(const float* params, float* grads, int D, int H, int L, in
                       const float* save, const float* dy, float* scratch, void* stream);
 
 /* The padded minibatch of the recurrent update (rl/algos/ppo.py:411-430: pad_sequence over the sampled trajectories, zero rows behind a trajectory's end) gathered out of
- * the rollout grid in one launch.  idx [T, B] int64: flat grid row of (t, b), -1 = padded.  obs [rows_total, D], act [rows_total, A], ret / adv [rows_total].
+ * the rollout grid in one launch.  Which grid row column b holds at step t: either idx [T, B] int64 (flat grid row, -1 = padded), or - idx NULL - the trajectory list
+ * traj [n_traj, 3] int64 = (grid column n, t0, t1) with sel [B] int64 (NULL: 0..B-1) naming column b's trajectory and N = the grid's column count: step t of the
+ * trajectory is grid row (t0 + t) N + n, padded from t1 - t0 on (no index tensor is built at all).  obs [rows_total, D], act [rows_total, A], ret / adv [rows_total].
  * Outputs (all [T, B, .] f32): obs_raw (LSTM_V's input, critic.py:262-263), xn = (obs - obs_mean) / obs_std, act_p, ret_p, adv_p, mask (1 = real row), and - when
  * obs_sign_perm is given (SymmetricEnv.mirror_clock_observation, rl/envs/wrappers.py:59-67; clock_mask as in apx_mlp_forward) - xa [T, 2 B, D] = [xn | normalised
  * mirrored observation] along the batch axis (pi(s) and pi(M s) share the weights: one 2 B-column pass).  xa and obs_sign_perm are both NULL or both given. [dev] */
-int apx_rec_gather(const int64_t* idx, int T, int64_t B, int D, int A, const float* obs, const float* act, const float* ret, const float* adv,
+int apx_rec_gather(const int64_t* idx, const int64_t* traj, const int64_t* sel, int64_t N, int T, int64_t B, int D, int A, const float* obs, const float* act, const float* ret, const float* adv,
                    const int32_t* obs_sign_perm, uint64_t clock_mask, const float* obs_mean, const float* obs_std, float* obs_raw, float* xn, float* xa,
                    float* act_p, float* ret_p, float* adv_p, float* mask, void* stream);
 

@@ -576,6 +576,24 @@ def test_rec_gather_equals_the_torch_assembly(dev):
                 np.testing.assert_allclose(xa.cpu().numpy(), ref.cpu().numpy(), rtol=0, atol=2e-6)
             else:
                 assert xa is xn
+    # the index formed inside the kernel from the trajectory list (column, t0, t1) + a selection = the explicit [T_max, B] index of padded_index()
+    Ngrid, Tgrid = 25, 200                                                 # rows = 5000 = Tgrid * Ngrid
+    trajs = []
+    for n in range(Ngrid):
+        cuts = sorted(set(np.random.RandomState(n).randint(1, Tgrid, 6).tolist() + [Tgrid]))
+        t0 = 0
+        for t1 in cuts:
+            trajs.append((n, t0, t1)); t0 = t1
+    trajs = np.array(trajs, dtype=np.int64)
+    sel = np.random.RandomState(1).permutation(len(trajs))[:40].astype(np.int64)
+    lens = trajs[sel, 2] - trajs[sel, 1]; Tm = int(lens.max())
+    idx = np.full((Tm, len(sel)), -1, dtype=np.int64)
+    for b, (n, t0, t1) in enumerate(trajs[sel]):
+        idx[: t1 - t0, b] = np.arange(t0, t1) * Ngrid + n
+    ref = L.gather(torch.as_tensor(idx, device=dev), obs, act, ret, adv, mirror=True)
+    got = L.gather(None, obs, act, ret, adv, mirror=True, traj=torch.as_tensor(trajs, device=dev), sel=torch.as_tensor(sel, device=dev), grid_cols=Ngrid, t_max=Tm)
+    for a, b in zip(ref[:5] + ref[5], got[:5] + got[5]):
+        assert torch.equal(a, b)
 
 
 def test_lstm_forward_backward_large_batch_equals_small_batches(dev):
