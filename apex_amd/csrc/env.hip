@@ -847,6 +847,8 @@ static int launch_reset(apx_env* e, int ahead, const uint8_t* mask, float* obs, 
 // runs on the side stream (no mask: a wave whose four envs hold their next episodes leaves at once), next to whatever `stream` does until its next reset launch.  Part 0
 // reads I_EPISODE (stable between resets) and writes only the ring; its result is a function of (seed, env, episode) alone, not of the env state it starts from.
 static int launch_refill(apx_env* e, void* stream) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return APX_OK;      // a captured rollout keeps to its one stream
     if (!e->side) {
         APX_HIP(hipStreamCreateWithFlags((hipStream_t*)&e->side, hipStreamNonBlocking));
         APX_HIP(hipEventCreateWithFlags((hipEvent_t*)&e->ev_reset, hipEventDisableTiming));
@@ -862,6 +864,7 @@ static int launch_refill(apx_env* e, void* stream) {
 extern "C" int apx_env_set_refill(apx_env_t* e, int on) {
     APX_REQUIRE(e, "env");
     e->refill = on != 0;
+    if (!on && e->refill_pending) { APX_HIP(hipEventSynchronize((hipEvent_t)e->ev_refill)); e->refill_pending = 0; }      // switching off drains the refill in flight
     return APX_OK;
 }
 static int launch_reset_raw(apx_env* e, int ahead, const uint8_t* mask, float* obs, void* stream) {

@@ -91,6 +91,8 @@ class PPO:
         self.prepare_resets = bool(args.get("prepare_resets", True)); self._side = None
         self.use_graph = bool(args.get("graph", False)) and not self.dist_on
         self._graph = None
+        if self.use_graph and hasattr(env, "set_refill"):
+            env.set_refill(False)      # the captured rollout is a single-stream graph: no side-stream refill of the reset ring inside it (drains one in flight)
         self.ep_ret = torch.zeros(N, **f32); self.ep_len = torch.zeros(N, **f32)
         self.obs = None
         # parity mode: replay captured draw streams instead of the Philox generator.
