@@ -687,12 +687,16 @@ __device__ __forceinline__ void fused_layer(const FusedLds& L, float (*In)[FBM +
 #pragma unroll
                 for (int q = 0; q < 4; ++q) cur[q] = rw[kt % FPF][q];
                 if (kt + FPF < NKT) fetch(kt + FPF, rw[kt % FPF]);
+                // (without the fences the scheduler sinks every fetch to just above its MFMAs to save registers - one load, s_waitcnt vmcnt(0), four MFMAs, twice per
+                // tile: an exposed L2 round trip per half tile and an MFMA pipe that is busy half of the time)
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float av = In[kt * GBK + 8 * h + j][lane & 31];
                     const float bv = (j & 1) ? cur[j >> 1].y : cur[j >> 1].x;
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         const float bs = col < N ? bias[col] : 0.f;
@@ -1330,11 +1334,13 @@ __device__ __forceinline__ void lstm_step_layer(const float (*tile)[K + 4], cons
 #pragma unroll
             for (int g = 0; g < 4; ++g) wq[(t + LS_PF) % (LS_PF + 1)][g] = *reinterpret_cast<const f4w*>(wrow[g] + 16 * (t + LS_PF));
         }
+        __builtin_amdgcn_sched_barrier(0);      // keep the fetch LS_PF tiles ahead: left alone, the scheduler sinks every load to just above its MFMAs (vmcnt(1) waits) to save registers
         const f4w a = *reinterpret_cast<const f4w*>(&tile[col][16 * t + 4 * kg]);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], wq[t % (LS_PF + 1)][g][q], acc[g], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -1346,7 +1352,7 @@ __device__ __forceinline__ void lstm_step_layer(const float (*tile)[K + 4], cons
         hn[row * hn_pitch + unit] = h;
     }
 }
-__global__ __launch_bounds__(64 * LS_NW) void lstm_step_fused_kernel(const float* __restrict__ packed, int D, int O, const float* __restrict__ x, const float* __restrict__ mean,
+__global__ __launch_bounds__(64 * LS_NW) __attribute__((amdgpu_waves_per_eu(2, 2))) void lstm_step_fused_kernel(const float* __restrict__ packed, int D, int O, const float* __restrict__ x, const float* __restrict__ mean,
                                                               const float* __restrict__ stdv, const uint8_t* __restrict__ reset, float* __restrict__ hc, long B,
                                                               float* __restrict__ y, float* __restrict__ act, const float* __restrict__ noise, float sigma) {
     constexpr int H = LS_H, K1 = LS_DP + LS_H, K2 = 2 * LS_H, NTH = 64 * LS_NW;
