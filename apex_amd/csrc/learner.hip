@@ -1054,58 +1054,75 @@ __global__ __launch_bounds__(64 * NW, 1) void lstm_seq_fwd_kernel(float* __restr
         for (int r = 0; r < 4; ++r) { const long row = r0 + 4 * kg + r; c[nt][r] = (hc_c && row < B) ? hc_c[row * H + wave * UW + nt * 16 + col] : 0.f; }
     __syncthreads();
     // the input projection of step t + 1 is fetched while the MFMAs of step t run (as the first thing of its own step the 16 loads were an exposed HBM round trip per
-    // step: 6.9 us per step against 3.4 us of MFMA issue)
+    // step: 6.9 us per step against 3.4 us of MFMA issue).  A workgroup whose 16 rows all exist runs the loop WITHOUT row guards: a guarded load / store is an exec-mask
+    // region behind a branch, the compiler cannot count the stores in flight behind it and ends every step on s_waitcnt vmcnt(0) - the write latency of the step's 24
+    // stores, exposed 400 times.  The h_{t-1} operands of MFMA group kq + 2 are read from LDS before the MFMAs of group kq (fenced: the scheduler had put every
+    // ds_read + s_waitcnt lgkmcnt(0) directly in front of its eight MFMAs).
     float gn[4][NT][4];
-    auto fetch_g = [&](int t) {
-        const float* Gt = G + (size_t)t * B * 4 * H;
+    auto run = [&](auto FullTag) {
+        constexpr bool FULL = decltype(FullTag)::value;
+        auto fetch_g = [&](int t) {
+            const float* Gt = G + (size_t)t * B * 4 * H;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const long row = r0 + 4 * kg + r;
+                        gn[g][nt][r] = (FULL || row < B) ? Gt[row * 4 * H + g * H + wave * UW + nt * 16 + col] : 0.f;
+                    }
+        };
+        fetch_g(0);
+        for (int t = 0; t < T; ++t) {
+            float* Gt = G + (size_t)t * B * 4 * H;
+            floatx4 acc[4][NT];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[g][nt][r] = gn[g][nt][r] + bh[g][nt];
+            if (t + 1 < T) fetch_g(t + 1);
+            float a0 = hs[col][kg], a1 = hs[col][4 + kg];
+#pragma unroll
+            for (int kq = 0; kq < KQ; kq += 2) {
+                float n0 = 0.f, n1 = 0.f;
+                if (kq + 2 < KQ) { n0 = hs[col][4 * (kq + 2) + kg]; n1 = hs[col][4 * (kq + 3) + kg]; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, W[kq][g][nt], acc[g][nt], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, W[kq + 1][g][nt], acc[g][nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                a0 = n0; a1 = n1;
+            }
+            __syncthreads();                                   // every wave has read h_{t-1}
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const long row = r0 + 4 * kg + r;
-                    gn[g][nt][r] = row < B ? Gt[row * 4 * H + g * H + wave * UW + nt * 16 + col] : 0.f;
+                    const int u = wave * UW + nt * 16 + col;
+                    const float i = sigmf(acc[0][nt][r]), f = sigmf(acc[1][nt][r]), gg = tanhf(acc[2][nt][r]), o = sigmf(acc[3][nt][r]);
+                    const float cn = f * c[nt][r] + i * gg, hn = o * tanhf(cn);
+                    c[nt][r] = cn;
+                    hs[4 * kg + r][u] = hn;
+                    if (FULL || row < B) {
+                        float* g4 = Gt + row * 4 * H + u;
+                        g4[0] = i; g4[H] = f; g4[2 * H] = gg; g4[3 * H] = o;
+                        Cc[(size_t)t * B * H + row * H + u] = cn; Hh[(size_t)t * B * H + row * H + u] = hn;
+                    }
                 }
-    };
-    fetch_g(0);
-    for (int t = 0; t < T; ++t) {
-        float* Gt = G + (size_t)t * B * 4 * H;
-        floatx4 acc[4][NT];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[g][nt][r] = gn[g][nt][r] + bh[g][nt];
-        if (t + 1 < T) fetch_g(t + 1);
-#pragma unroll
-        for (int kq = 0; kq < KQ; ++kq) {
-            const float a = hs[col][4 * kq + kg];
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, W[kq][g][nt], acc[g][nt], 0, 0, 0);
+            __syncthreads();
         }
-        __syncthreads();                                   // every wave has read h_{t-1}
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long row = r0 + 4 * kg + r;
-                const int u = wave * UW + nt * 16 + col;
-                const float i = sigmf(acc[0][nt][r]), f = sigmf(acc[1][nt][r]), gg = tanhf(acc[2][nt][r]), o = sigmf(acc[3][nt][r]);
-                const float cn = f * c[nt][r] + i * gg, hn = o * tanhf(cn);
-                c[nt][r] = cn;
-                hs[4 * kg + r][u] = hn;
-                if (row < B) {
-                    float* g4 = Gt + row * 4 * H + u;
-                    g4[0] = i; g4[H] = f; g4[2 * H] = gg; g4[3 * H] = o;
-                    Cc[(size_t)t * B * H + row * H + u] = cn; Hh[(size_t)t * B * H + row * H + u] = hn;
-                }
-            }
-        __syncthreads();
-    }
+    };
+    static_assert(KQ % 2 == 0, "MFMA groups are taken in pairs");
+    if (r0 + 16 <= B) run(std::true_type{}); else run(std::false_type{});
     if (hc_h)      // carried state out (rollout: hidden state of the next call)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -1135,65 +1152,85 @@ __global__ __launch_bounds__(64 * NW, 1) void lstm_seq_bwd_kernel(const float* _
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dc[nt][r] = dhr[nt][r] = 0.f;
-    // what step t - 1 reads (activated gates, c_{t-2}, dh from above) is fetched while the MFMAs of step t run; c_{t-1} is carried over from step t
+    // what step t - 1 reads (activated gates, c_{t-2}, dh from above) is fetched while the MFMAs of step t run; c_{t-1} is carried over from step t.  Like the forward
+    // kernel: no row guards for a workgroup whose 16 rows all exist (exact vmcnt waits instead of vmcnt(0) behind exec-mask regions), LDS operands one block of four
+    // MFMAs ahead.
     float pg[NT][4][4], pct[NT][4], pcp[NT][4], pdh[NT][4];
-    auto fetch = [&](int t, bool first) {
-        const float* Gt = G + (size_t)t * B * 4 * H;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long row = r0 + 4 * kg + r; const int u = wave * UW + nt * 16 + col;
-                if (row < B) {
-                    const float* g4 = Gt + row * 4 * H + u;
-                    pg[nt][r][0] = g4[0]; pg[nt][r][1] = g4[H]; pg[nt][r][2] = g4[2 * H]; pg[nt][r][3] = g4[3 * H];
-                    pct[nt][r] = first ? Cc[(size_t)t * B * H + row * H + u] : pcp[nt][r];
-                    pcp[nt][r] = t ? Cc[(size_t)(t - 1) * B * H + row * H + u] : 0.f;
-                    pdh[nt][r] = dHa[(size_t)t * B * H + row * H + u];
-                }
-            }
-    };
-    fetch(T - 1, true);
-    for (int t = T - 1; t >= 0; --t) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long row = r0 + 4 * kg + r; const int u = wave * UW + nt * 16 + col;
-                float di = 0.f, df = 0.f, dgg = 0.f, dob = 0.f;
-                if (row < B) {
-                    const float i = pg[nt][r][0], f = pg[nt][r][1], gg = pg[nt][r][2], o = pg[nt][r][3];
-                    const float ct = pct[nt][r], cp = pcp[nt][r];
-                    const float dh = pdh[nt][r] + dhr[nt][r];
-                    const float tc = tanhf(ct);
-                    const float dcv = dh * o * (1.f - tc * tc) + dc[nt][r];
-                    di = dcv * gg * i * (1.f - i); df = dcv * cp * f * (1.f - f); dgg = dcv * i * (1.f - gg * gg); dob = dh * tc * o * (1.f - o);
-                    dc[nt][r] = dcv * f;
-                    float* d4 = dG + (size_t)t * B * 4 * H + row * 4 * H + u;
-                    d4[0] = di; d4[H] = df; d4[2 * H] = dgg; d4[3 * H] = dob;
-                }
-                float* ds = &dgs[4 * kg + r][u];
-                ds[0] = di; ds[H] = df; ds[2 * H] = dgg; ds[3 * H] = dob;
-            }
-        __syncthreads();
-        if (t) {
-            fetch(t - 1, false);
-            floatx4 acc[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kq = 0; kq < KQ; ++kq) {
-                const float a = dgs[col][4 * kq + kg];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, W[kq][nt], acc[nt], 0, 0, 0);
-            }
+    auto run = [&](auto FullTag) {
+        constexpr bool FULL = decltype(FullTag)::value;
+        auto fetch = [&](int t, bool first) {
+            const float* Gt = G + (size_t)t * B * 4 * H;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dhr[nt][r] = acc[nt][r];
+                for (int r = 0; r < 4; ++r) {
+                    const long row = r0 + 4 * kg + r; const int u = wave * UW + nt * 16 + col;
+                    if (FULL || row < B) {
+                        const float* g4 = Gt + row * 4 * H + u;
+                        pg[nt][r][0] = g4[0]; pg[nt][r][1] = g4[H]; pg[nt][r][2] = g4[2 * H]; pg[nt][r][3] = g4[3 * H];
+                        pct[nt][r] = first ? Cc[(size_t)t * B * H + row * H + u] : pcp[nt][r];
+                        pcp[nt][r] = t ? Cc[(size_t)(t - 1) * B * H + row * H + u] : 0.f;
+                        pdh[nt][r] = dHa[(size_t)t * B * H + row * H + u];
+                    }
+                }
+        };
+        fetch(T - 1, true);
+        for (int t = T - 1; t >= 0; --t) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long row = r0 + 4 * kg + r; const int u = wave * UW + nt * 16 + col;
+                    float di = 0.f, df = 0.f, dgg = 0.f, dob = 0.f;
+                    if (FULL || row < B) {
+                        const float i = pg[nt][r][0], f = pg[nt][r][1], gg = pg[nt][r][2], o = pg[nt][r][3];
+                        const float ct = pct[nt][r], cp = pcp[nt][r];
+                        const float dh = pdh[nt][r] + dhr[nt][r];
+                        const float tc = tanhf(ct);
+                        const float dcv = dh * o * (1.f - tc * tc) + dc[nt][r];
+                        di = dcv * gg * i * (1.f - i); df = dcv * cp * f * (1.f - f); dgg = dcv * i * (1.f - gg * gg); dob = dh * tc * o * (1.f - o);
+                        dc[nt][r] = dcv * f;
+                        float* d4 = dG + (size_t)t * B * 4 * H + row * 4 * H + u;
+                        d4[0] = di; d4[H] = df; d4[2 * H] = dgg; d4[3 * H] = dob;
+                    }
+                    float* ds = &dgs[4 * kg + r][u];
+                    ds[0] = di; ds[H] = df; ds[2 * H] = dgg; ds[3 * H] = dob;
+                }
+            __syncthreads();
+            if (t) {
+                fetch(t - 1, false);
+                floatx4 acc[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+                float av[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) av[j] = dgs[col][4 * j + kg];
+#pragma unroll
+                for (int kq = 0; kq < KQ; kq += 4) {
+                    float nv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (kq + 4 < KQ) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) nv[j] = dgs[col][4 * (kq + 4 + j) + kg];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], W[kq + j][nt], acc[nt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) av[j] = nv[j];
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dhr[nt][r] = acc[nt][r];
+            }
+            __syncthreads();
         }
-        __syncthreads();
-    }
+    };
+    static_assert(KQ % 4 == 0, "MFMA groups are taken in blocks of four");
+    if (r0 + 16 <= B) run(std::true_type{}); else run(std::false_type{});
 }
 #ifndef LSTM_NW128
 #define LSTM_NW128 8      /* waves per workgroup at H = 128: 8 = one 16-unit tile per wave, two waves per SIMD (4: 0.56 ms per 400-step layer pass, 8: see DESIGN.md section 4.2) */
