@@ -800,7 +800,7 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     e->timing = 0; e->ev = nullptr; e->ev_cap = e->ev_n = 0; e->t_ms = 0.0; e->t_launches = 0;
     // up to 2048 envs leave half of the SIMDs idle during an env step: the images of the restarted envs' next episodes are computed there (apx_env_set_refill overrides)
     e->refill = getenv("APX_REFILL") ? atoi(getenv("APX_REFILL")) != 0 : e->n <= 2048;
-    e->refill_pending = 0; e->side = nullptr; e->ev_reset = nullptr; e->ev_refill = nullptr;
+    e->refill_pending = 0; e->refill_due = 0; e->side = nullptr; e->ev_reset = nullptr; e->ev_refill = nullptr;
     const Cfg c = make_cfg(*e);
     hipLaunchKernelGGL(env_init_kernel, dim3(e->n / 64), dim3(64), 0, 0, e->st, e->ist, e->n, c);
     APX_LAUNCH_CHECK();
@@ -864,6 +864,7 @@ static int launch_refill(apx_env* e, void* stream) {
 extern "C" int apx_env_set_refill(apx_env_t* e, int on) {
     APX_REQUIRE(e, "env");
     e->refill = on != 0;
+    if (!on) e->refill_due = 0;
     if (!on && e->refill_pending) { APX_HIP(hipEventSynchronize((hipEvent_t)e->ev_refill)); e->refill_pending = 0; }      // switching off drains the refill in flight
     return APX_OK;
 }
@@ -942,6 +943,7 @@ extern "C" int apx_env_apply_force(apx_env_t* e, const float* xfrc, void* stream
 extern "C" int apx_env_step(apx_env_t* e, const float* action, float* obs, float* reward, uint8_t* done, float* final_obs,
                             int auto_reset, void* stream) {
     APX_REQUIRE(e && action && obs && reward && done, "null pointer");
+    if (e->refill && e->refill_due) { e->refill_due = 0; const int rc = launch_refill(e, stream); if (rc != APX_OK) return rc; }      // runs next to the env step launched below
     const bool timed = e->timing && e->ev_n + 2 <= e->ev_cap;
     if (timed) APX_HIP(hipEventRecord((hipEvent_t)e->ev[e->ev_n], (hipStream_t)stream));
     if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_step_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n,
@@ -952,7 +954,7 @@ extern "C" int apx_env_step(apx_env_t* e, const float* action, float* obs, float
     if (timed) { APX_HIP(hipEventRecord((hipEvent_t)e->ev[e->ev_n + 1], (hipStream_t)stream)); e->ev_n += 2; }
     if (auto_reset) {      // finished envs restart in a second launch on the same stream (mask = done flags)
         { const int rc = launch_reset(e, 0, done, obs, stream); if (rc != APX_OK) return rc; }
-        if (e->refill) { const int rc = launch_refill(e, stream); if (rc != APX_OK) return rc; }
+        e->refill_due = e->refill;      // launched in front of the NEXT env step (below): right behind the reset it would share the chip with the latency-bound policy step
     }
     return APX_OK;
 }

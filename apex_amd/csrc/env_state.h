@@ -43,7 +43,7 @@ struct apx_env {
     int timing; void** ev; int ev_cap, ev_n; double t_ms; long t_launches;
     // in-rollout refill of the reset ring (apx_env_set_refill): after the auto-reset of a step, part 0 of env_reset_kernel for the next two episodes of the envs that just
     // restarted runs on the env's own side stream, next to the following env step; the next reset launch waits for it
-    int refill, refill_pending; void* side; void* ev_reset; void* ev_refill;
+    int refill, refill_pending, refill_due; void* side; void* ev_reset; void* ev_refill;
 };
 
 // global-address-space pointers: St is passed by value into a non-inlined device function, where the compiler could

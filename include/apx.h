@@ -236,7 +236,8 @@ int apx_env_reset(apx_env_t* env, const uint8_t* mask, float* obs_out, void* str
  * apx_env_apply_force(_body) and apx_env_set_field. */
 int apx_env_prepare_resets(apx_env_t* env, void* stream);
 /* The same hook inside a rollout: when on, every auto-reset of apx_env_step / apx_rollout is followed by the ring refill of the envs that just restarted (their next two
- * episodes), launched on a stream the env owns, next to the following env step; the next reset launch waits for it.  Default: on for n_envs <= 2048 (an env step of up
+ * episodes), launched on a stream the env owns in front of the following env step (behind whatever the caller put on `stream` in between: the policy step), so that it
+ * runs next to that env step; the next reset launch waits for it.  Default: on for n_envs <= 2048 (an env step of up
  * to 2048 envs leaves half of the SIMDs idle), off above.  Results do not depend on it (same bits, see apx_env_prepare_resets).  Switching it off waits for a refill
  * in flight; a step issued on a stream under graph capture skips it (switch it off BEFORE capturing a rollout, so that no refill is pending inside the capture). */
 int apx_env_set_refill(apx_env_t* env, int on);
