@@ -243,13 +243,16 @@ def eval_commands_main(argv):
     return 0
 
 
-def td3_main(argv):
+def td3_main(argv, async_mode=False):
     """`apex.py td3 ...` (row f2): synchronous TD3 (reference apex.py:140-166 flags of syncTD3 where they still apply) on the batched env with
-    the replay buffer in HBM.  --n_envs / --collect_steps / --updates_per_step replace the Ray worker counts."""
+    the replay buffer in HBM.  --n_envs / --collect_steps / --updates_per_step replace the Ray worker counts.
+    `apex.py td3_async ...` (reference apex.py:160-211, rl/algos/async_td3.py): collection with a periodically re-loaded copy of the policy (--initial_load_freq lock
+    steps), per-dimension action noise, the updates on a second HIP stream next to the following env step (apex_amd/td3.py::collect_and_train_async)."""
     import argparse
     p = argparse.ArgumentParser()
     p.add_argument("--env_name", default="Cassie-v0"); p.add_argument("--reward", default="clock", type=str)
-    p.add_argument("--seed", type=int, default=0); p.add_argument("--logdir", type=str, default="./trained_models/syncTD3/")
+    p.add_argument("--seed", type=int, default=0); p.add_argument("--logdir", type=str, default="./trained_models/td3_async/" if async_mode else "./trained_models/syncTD3/")
+    p.add_argument("--initial_load_freq", type=int, default=10)      # (td3_async) lock steps between two re-loads of the behaviour copy (reference apex.py:188)
     p.add_argument("--run_name", type=str, default=None); p.add_argument("--previous", type=str, default=None)
     p.add_argument("--max_timesteps", type=float, default=1e8); p.add_argument("--max_traj_len", type=int, default=400)
     p.add_argument("--a_lr", type=float, default=1e-3); p.add_argument("--c_lr", type=float, default=1e-3)
@@ -263,6 +266,7 @@ def td3_main(argv):
     p.add_argument("--param_noise", type=bool, default=False); p.add_argument("--noise_scale", type=float, default=0.3)      # reference apex.py:143-144
     a = p.parse_args(argv)
     a.max_timesteps = int(a.max_timesteps)
+    a.async_mode = bool(async_mode)
     from apex_amd.td3 import run_experiment
     run_experiment(a)
     return 0
@@ -274,6 +278,8 @@ def main(argv=None):
         return eval_main(argv[1:])
     if argv and argv[0] == "td3":
         return td3_main(argv[1:])
+    if argv and argv[0] == "td3_async":
+        return td3_main(argv[1:], async_mode=True)
     if argv and argv[0] == "eval_commands":
         return eval_commands_main(argv[1:])
     if argv and argv[0] == "eval_perturb":

@@ -122,6 +122,68 @@ class TD3:
         s = (stats / max(n_upd, 1)).cpu().numpy()
         return dict(q_loss=float(s[0]), avg_q1=float(s[1] / self.batch_size), avg_q2=float(s[2] / self.batch_size), updates=n_upd)
 
+    # ------------------------------------------------------------------------------------------ asynchronous variant
+    @torch.no_grad()
+    def collect_and_train_async(self, steps, load_freq=10):
+        """The reference's ASYNCHRONOUS TD3 (rl/algos/async_td3.py) on the batched env: collection and learning are decoupled.
+        Reference: every Actor steps its env with a COPY of the global policy that it re-loads every `load_freq` of its own timesteps (:205-213), adds N(0, act_noise) PER
+        ACTION DIMENSION (:253-256; the synchronous loop draws one scalar), asks the Learner for one update per collected step without waiting for it (:285) and ships
+        its transitions to the replay; the Learner samples whatever the replay holds (:404-415).
+        Here: the collection (behaviour-policy forward, env step, replay write) runs on the caller's stream, the `updates_per_step` updates per lock-step env step run on
+        a second HIP stream NEXT TO THE FOLLOWING ENV STEP - the updates are latency chains of small launches (batch 1024: 32 workgroups), the env step is one long
+        launch that issues at 60 % of its SIMDs' rate; serialised they cost 2.5 + 1.5 ms per lock step.  The behaviour copy is re-loaded every `load_freq` lock steps from
+        the parameters as they were two steps earlier (so that the collector never waits for the learner).  Ordering that keeps the replay consistent: the updates of
+        step t wait for the replay write of step t and draw all their batches first; the replay write of step t + 1 waits for those draws (a ring slot is never
+        overwritten while a batch is being gathered from it)."""
+        L, env = self.learner, self.env
+        load_freq = max(3, int(load_freq))      # a snapshot is written two steps before it is used: with a period >= 3 the two buffers never hold two pending snapshots
+        if self.obs is None:
+            self.obs = env.reset().clone()
+        main = torch.cuda.current_stream(self.device)
+        if getattr(self, "_upd", None) is None:
+            self._upd = torch.cuda.Stream(device=self.device)
+            self.behav = [engine.Mlp(50, self.hidden, 10, self.device), engine.Mlp(50, self.hidden, 10, self.device)]
+            self.behav[0].params.copy_(L.actor.params); self._cur = 0; self._async_t = 0; self._snap = {}
+            self._stats = torch.zeros(3, dtype=torch.float64, device=self.device)
+        upd = self._upd
+        upd.wait_stream(main)
+        self._stats.zero_(); n_upd = 0
+        ev_sampled = None
+        for _ in range(steps):
+            t = self._async_t
+            if t in self._snap:                                   # re-load the behaviour copy (async_td3.py:205-213): written by the learner stream two steps ago
+                main.wait_event(self._snap.pop(t)); self._cur ^= 1
+            a = torch.tanh(self.behav[self._cur].forward(self.obs))
+            if self.act_noise != 0:
+                a = (a + torch.randn(self.N, 10, device=self.device, generator=self.gen) * self.act_noise).clamp(-1, 1)      # per dimension (:253-256)
+            nxt, rew, done, fin = env.step(a)
+            ended = done != 0
+            s2 = torch.where(ended.view(-1, 1), fin, nxt)
+            if ev_sampled is not None:
+                main.wait_event(ev_sampled)                       # the previous step's batches have been gathered
+            self.replay.add(self.obs, s2, a, rew, (~ended).float())
+            ev_added = main.record_event()
+            self.obs = nxt.clone()
+            if self.replay.size >= self.batch_size:
+                with torch.cuda.stream(upd):
+                    upd.wait_event(ev_added)
+                    batches = []
+                    for _k in range(self.updates_per_step):
+                        b = self.replay.sample(self.batch_size, self.gen)
+                        batches.append(b + (torch.randn(self.batch_size, 10, device=self.device, generator=self.gen) * self.policy_noise,))
+                    ev_sampled = upd.record_event()
+                    for s, sn, ac, r, nd, noise in batches:
+                        st, _ = L.train_step(s, ac, sn, r, nd, noise, self.it, self.discount, self.tau, self.noise_clip, self.policy_freq)
+                        self._stats += st; n_upd += 1; self.it += 1
+                    if (t + 2) % load_freq == 0:                  # the snapshot the collector switches to at step t + 2
+                        self.behav[self._cur ^ 1].params.copy_(L.actor.params)
+                        self._snap[t + 2] = upd.record_event()
+            self._async_t += 1
+        main.wait_stream(upd)                                     # the caller (evaluation, checkpoint) sees the learner's parameters
+        self.total_steps += steps * self.N
+        s = (self._stats / max(n_upd, 1)).cpu().numpy()
+        return dict(q_loss=float(s[0]), avg_q1=float(s[1] / self.batch_size), avg_q2=float(s[2] / self.batch_size), updates=n_upd)
+
     @torch.no_grad()
     def reference_round(self, max_traj_len, explore_fn=None, index_fn=None, smooth_fn=None):
         """ONE pass of the reference's synchronous loop body with its own collection semantics (sync_td3.py:304-313), for parity runs and for users
@@ -202,7 +264,10 @@ def run_experiment(args):
     logger.add_scalar("Test/Return", ret, updates); logger.add_scalar("Test/Eplen", eplen, updates)
     while algo.total_steps < args.max_timesteps:
         t0 = time.time()
-        out = algo.collect_and_train(args.collect_steps)
+        if getattr(args, "async_mode", False):
+            out = algo.collect_and_train_async(args.collect_steps, load_freq=getattr(args, "initial_load_freq", 10))
+        else:
+            out = algo.collect_and_train(args.collect_steps)
         torch.cuda.synchronize(); dt = time.time() - t0
         updates += out["updates"]
         for k in ("avg_q1", "avg_q2", "q_loss"):

@@ -148,17 +148,20 @@ def main_td3(a):
     env = CassieVecEnv(n_envs=n_envs, seed=0)
     algo = TD3(env, "/tmp/apx_bench_unused", batch_size=bs, updates_per_step=upd, replay_size=1_000_000, seed=0)
     algo.init_networks(0)
+    run = (lambda: algo.collect_and_train_async(T, load_freq=10)) if a.td3_async else (lambda: algo.collect_and_train(T))      # --td3_async: rl/algos/async_td3.py's decoupled form
     for _ in range(a.warmup):
-        algo.collect_and_train(T)
+        run()
     torch.cuda.synchronize(); t0 = time.time()
     for _ in range(a.steps):
-        out = algo.collect_and_train(T)
+        out = run()
     torch.cuda.synchronize(); dt = time.time() - t0
-    print(json.dumps({"metric": "env-steps/sec Cassie-v0 TD3 @4096 envs, replay in HBM", "value": round(a.steps * T * n_envs / dt, 1), "unit": "env-steps/s",
+    print(json.dumps({"metric": "env-steps/sec Cassie-v0 TD3 @4096 envs, replay in HBM" + (" (asynchronous: updates next to the following env step)" if a.td3_async else ""),
+                      "value": round(a.steps * T * n_envs / dt, 1), "unit": "env-steps/s",
                       "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
                       "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                       "config": {"workload": "Cassie-v0 TD3, 1M-transition replay buffer in HBM, twin-critic update in HIP (BASELINE.json configs[4])",
-                                 "envs_per_gpu": n_envs, "collect_steps": T, "updates_per_env_step": upd, "batch_size": bs, "replay_capacity": 1000000},
+                                 "envs_per_gpu": n_envs, "collect_steps": T, "updates_per_env_step": upd, "batch_size": bs, "replay_capacity": 1000000,
+                                 "mode": "async (behaviour copy re-loaded every 10 lock steps, rl/algos/async_td3.py)" if a.td3_async else "sync (rl/algos/sync_td3.py)"},
                       "updates_per_s": round(a.steps * T * upd / dt, 1), "replay_size": int(algo.replay.size)}))
 
 
@@ -227,6 +230,7 @@ def main():
     ap.add_argument("--minibatch", type=int, default=16384)
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--td3_async", action="store_true", help="cassie_td3 workload only: the asynchronous variant (collection and updates on two streams)")
     ap.add_argument("--workload", default="cassie_ppo", choices=["cassie_ppo", "cassietraj_recurrent", "cassie_td3"],
                     help="cassie_ppo = BASELINE.json configs[1] (the headline, default); cassietraj_recurrent = configs[3]: CassieTraj-v0, LSTM 2x128, 2048 envs/GPU; cassie_td3 = configs[4]: TD3, 1M-transition replay in HBM")
     a = ap.parse_args()

@@ -616,3 +616,39 @@ def test_apx_rollout_equals_the_stepwise_loop(dev):
     na, nb = int((a.b_done != 0).sum()), int((b.b_done != 0).sum())
     assert na > 256 and abs(na - nb) <= 0.05 * na                                # episodes ended and restarted inside the call, at the same rate
     assert torch.isfinite(a.b_obs).all() and torch.isfinite(a.b_val).all()
+
+
+def test_td3_async_collection_and_updates_on_two_streams(dev, tmp_path):
+    """rl/algos/async_td3.py on the batched env (TD3.collect_and_train_async): collection with a periodically re-loaded behaviour copy and per-dimension action noise on
+    one stream, the updates on a second one next to the following env step.  Same bookkeeping as the synchronous loop (one transition per env and step in the ring, as
+    many updates as asked, moving weights, trailing targets), the behaviour copy equals the learner's actor as of its last re-load and lags the live actor, and - the
+    race check - two runs from the same seed end with bit-identical parameters and replay contents although every update overlapped an env step and a replay write."""
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd.td3 import TD3
+
+    def run():
+        env = CassieVecEnv(n_envs=256, seed=3, max_traj_len=15)
+        algo = TD3(env, str(tmp_path), hidden=64, batch_size=128, updates_per_step=3, replay_size=3000, seed=1)      # 3000 < 24 x 256: the ring wraps twice
+        algo.init_networks(0)
+        a0 = algo.learner.actor.params.clone()
+        snaps = []
+        out = None
+        for _ in range(3):
+            out = algo.collect_and_train_async(8, load_freq=4)
+            snaps.append(algo.behav[algo._cur].params.clone())
+        torch.cuda.synchronize()
+        res = (algo.learner.actor.params.clone(), algo.learner.critic_flat.clone(), algo.replay.s.clone(), algo.replay.a.clone(), algo.replay.r.clone(), snaps, out, a0, algo)
+        return res
+    actor, critic, rs, ra, rr, snaps, out, a0, algo = run()
+    assert out["updates"] == 8 * 3 and np.isfinite([out["q_loss"], out["avg_q1"], out["avg_q2"]]).all()
+    assert algo.replay.size == 3000 and algo.total_steps == 24 * 256 and algo.it == 24 * 3
+    assert (ra.abs() <= 1).all() and (actor - a0).abs().max() > 1e-4
+    # per-dimension exploration noise (async_td3.py:253-256): the stored actions of one step are not a common shift of tanh(behaviour(s))
+    pre = torch.tanh(algo.behav[algo._cur].forward(rs[:256]))
+    d = ra[:256] - pre
+    assert d.std(dim=1).mean() > 0.05
+    # the behaviour copy is a past state of the actor: it moved between re-loads and differs from the live actor
+    assert (snaps[0] - a0).abs().max() > 0 and (snaps[2] - snaps[0]).abs().max() > 0 and (snaps[2] - actor).abs().max() > 0
+    actor2, critic2, rs2, ra2, rr2, _, _, _, algo2 = run()
+    assert torch.equal(actor, actor2) and torch.equal(critic, critic2) and torch.equal(rs, rs2) and torch.equal(ra, ra2) and torch.equal(rr, rr2)
+    algo.env.close(); algo2.env.close()
