@@ -28,6 +28,7 @@ python bench.py --workload cassietraj_recurrent --steps 3 --warmup 1 --no_cpu_ba
 #   4. per-kernel time of the recurrent workload (persistent LSTM layer kernels)          -> profiles/<tag>_recurrent_kernel_stats.txt
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/ktr -- python $ROOT/bench.py --workload cassietraj_recurrent --steps 2 --warmup 1 --no_cpu_baseline > $OUT/rec_under_rocprof.log 2>&1 || true)
 python $ROOT/tools/rocprof_summary.py $(ls $OUT/ktr/*/*.db | head -1) $OUT/${TAG}_recurrent_kernel_stats.txt > /dev/null || true
+python $ROOT/tools/rocprof_timeline.py $(ls $OUT/ktr/*/*.db | head -1) $OUT/${TAG}_recurrent_timeline.txt > /dev/null || true      # one rollout step / one recurrent minibatch, kernel by kernel
 rm -rf $OUT/ktr
 #   4b. MFMA pipe counters of the learner kernels (fused fp32 forward, gemm_f32_kernel<*>, gemm_bf16_kernel<*>), own --pmc passes  -> profiles/<tag>_learner_pmc_mfma.txt
 (cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $OUT/mfma -- python $ROOT/tools/t_pmc_learner.py > $OUT/mfma.log 2>&1 || true)
@@ -35,6 +36,7 @@ python $ROOT/tools/pmc_summary.py $OUT/mfma $OUT/${TAG}_learner_pmc_mfma.txt "# 
 rm -rf $OUT/mfma
 #   4c. TD3 workload: bench line + per-kernel time  -> profiles/<tag>_bench_line_td3.json, <tag>_td3_kernel_stats.txt
 python bench.py --workload cassie_td3 --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line_td3.json || true
+python bench.py --workload cassie_td3 --td3_async --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line_td3_async.json || true
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/ktt -- python $ROOT/bench.py --workload cassie_td3 --steps 2 --warmup 1 > $OUT/td3_under_rocprof.log 2>&1 || true)
 python $ROOT/tools/rocprof_summary.py $(ls $OUT/ktt/*/*.db | head -1) $OUT/${TAG}_td3_kernel_stats.txt > /dev/null || true
 rm -rf $OUT/ktt
