@@ -42,6 +42,19 @@ def test_cli_horizon_defaults_scale_with_the_env_batch():
         apex.resolve_horizon(apex.build_parser().parse_args(argv), argv)
 
 
+def test_cli_td3_and_td3_async_route_to_the_same_driver(monkeypatch):
+    """`apex.py td3` / `apex.py td3_async` (reference apex.py:118-158 / :160-211): both reach apex_amd.td3.run_experiment, the asynchronous one with async_mode set, its
+    own default log directory and --initial_load_freq (reference default 10)."""
+    import apex
+    import apex_amd.td3 as td3
+    seen = []
+    monkeypatch.setattr(td3, "run_experiment", lambda a: seen.append(a))
+    assert apex.main(["td3", "--n_envs", "64"]) == 0 and apex.main(["td3_async", "--n_envs", "64", "--act_noise", "0.2"]) == 0
+    s, a = seen
+    assert (s.async_mode, s.logdir, s.n_envs) == (False, "./trained_models/syncTD3/", 64)
+    assert (a.async_mode, a.logdir, a.initial_load_freq, a.act_noise) == (True, "./trained_models/td3_async/", 10, 0.2)
+
+
 def test_g13_run_directory_layout(golden_dir, tmp_path):
     from apex_amd.log import create_logger
     cases = json.load(open(os.path.join(golden_dir, "g13_logdir.json")))
