@@ -120,7 +120,6 @@ class RecurrentPPO:
         side.wait_stream(main)
         # the policy step as ONE launch per network (apx_lstm_step: normalisation, init_hidden_state of the restarted rows, both cells, head, action noise) where the
         # shape allows it (2 x LSTMCell(128)); otherwise the per-launch chain
-        import os
         fused = os.environ.get("APX_LSTM_STEP", "1") != "0" and L.actor.step_supported() and L.critic.step_supported()
         if fused:
             L.actor.pack_step(); L.critic.pack_step()
