@@ -150,8 +150,10 @@ class RecurrentPPO:
                 mu = L.actor.forward(norm(self.b_obs[t]), hc=hc_a)
                 torch.add(mu, noise, alpha=self.fixed_std, out=self.b_act[t])
             env.step(self.b_act[t], out=(nxt, self.b_rew[t], self.b_done[t], self.b_fin[t]))      # writes the next observation into the next grid row
-            ev_step = main.record_event()
             last = t == T - 1
+            if fused and not (last or t + 1 >= self.max_traj_len):
+                continue      # nothing for the side stream behind this step: the critic's next step is ordered by the next ev_obs (an event record is a barrier packet on the main stream)
+            ev_step = main.record_event()
             with torch.cuda.stream(side):
                 side.wait_event(ev_step)
                 # a time-limit truncation needs max_traj_len steps since the env's last reset, and every env was reset at t = 0: before step
