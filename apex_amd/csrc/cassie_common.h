@@ -71,6 +71,65 @@ __device__ __forceinline__ V3 symmul(const float* I, V3 v) {
 __device__ __forceinline__ SV imul(const SI& s, SV v) { return {symmul(s.I, v.a) + cross(s.h, v.l), v.l * s.m - cross(s.h, v.a)}; }
 template <int K> constexpr V3 cv3(const float* p) { return V3{p[3 * K], p[3 * K + 1], p[3 * K + 2]}; }
 
+// ---- the same algebra on PAIRS (round 5): component .x = leg slot 0 (left), .y = slot 1 (right).  A lane of the tree stage carries body b of BOTH legs; written on
+// 2-vectors, the arithmetic of the two slots is one v_pk_{mul,add,fma}_f32 per pair (VOP3P has no DPP / no select: cross-lane moves and v_cndmask stay per component, and
+// a uniform operand is a splat the compiler folds into op_sel_hi).  Same expressions, same order of operations as the scalar forms above.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 splat(float s) { return f2{s, s}; }
+__device__ __forceinline__ f2 sel2(bool c, f2 a, f2 b) { return f2{c ? a.x : b.x, c ? a.y : b.y}; }
+struct V3p { f2 x, y, z; };
+__device__ __forceinline__ V3p lift(V3 v) { return {splat(v.x), splat(v.y), splat(v.z)}; }
+__device__ __forceinline__ V3p operator+(V3p a, V3p b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3p operator-(V3p a, V3p b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3p operator*(V3p a, f2 s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ V3p operator*(V3p a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f2 dot(V3p a, V3p b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f2 dot(V3 a, V3p b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3p cross(V3p a, V3p b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ V3p sel2(bool c, V3p a, V3p b) { return {sel2(c, a.x, b.x), sel2(c, a.y, b.y), sel2(c, a.z, b.z)}; }
+struct Q4p { f2 w, x, y, z; };
+__device__ __forceinline__ Q4p lift(Q4 q) { return {splat(q.w), splat(q.x), splat(q.y), splat(q.z)}; }
+__device__ __forceinline__ Q4p qmul(Q4p a, Q4p b) {
+    return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+            a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+__device__ __forceinline__ Q4p sel2(bool c, Q4p a, Q4p b) { return {sel2(c, a.w, b.w), sel2(c, a.x, b.x), sel2(c, a.y, b.y), sel2(c, a.z, b.z)}; }
+__device__ __forceinline__ Q4p qnormalize(Q4p q) {
+    const f2 n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+    const bool ok0 = n2.x > 1e-30f, ok1 = n2.y > 1e-30f;
+    const f2 s = {rsqrtf(n2.x), rsqrtf(n2.y)};
+    const Q4p r = {q.w * s, q.x * s, q.y * s, q.z * s};
+    return {f2{ok0 ? r.w.x : 1.f, ok1 ? r.w.y : 1.f}, f2{ok0 ? r.x.x : 0.f, ok1 ? r.x.y : 0.f}, f2{ok0 ? r.y.x : 0.f, ok1 ? r.y.y : 0.f}, f2{ok0 ? r.z.x : 0.f, ok1 ? r.z.y : 0.f}};
+}
+struct M3p { f2 m[9]; };
+__device__ __forceinline__ M3p q2m(Q4p q) {
+    const f2 w = q.w, x = q.x, y = q.y, z = q.z;
+    return {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z),
+             1 - 2 * (x * x + z * z), 2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x),
+             1 - 2 * (x * x + y * y)}};
+}
+__device__ __forceinline__ V3p mul(const M3p& R, V3p v) {
+    return {R.m[0] * v.x + R.m[1] * v.y + R.m[2] * v.z, R.m[3] * v.x + R.m[4] * v.y + R.m[5] * v.z,
+            R.m[6] * v.x + R.m[7] * v.y + R.m[8] * v.z};
+}
+__device__ __forceinline__ V3p mul(const M3& R, V3p v) {      // uniform rotation, pair vector
+    return {R.m[0] * v.x + R.m[1] * v.y + R.m[2] * v.z, R.m[3] * v.x + R.m[4] * v.y + R.m[5] * v.z,
+            R.m[6] * v.x + R.m[7] * v.y + R.m[8] * v.z};
+}
+__device__ __forceinline__ V3p col(const M3p& R, int k) { return {R.m[k], R.m[3 + k], R.m[6 + k]}; }
+struct SVp { V3p a, l; };
+__device__ __forceinline__ SVp lift(SV v) { return {lift(v.a), lift(v.l)}; }
+__device__ __forceinline__ SVp operator+(SVp p, SVp q) { return {p.a + q.a, p.l + q.l}; }
+__device__ __forceinline__ SVp operator*(SVp p, f2 s) { return {p.a * s, p.l * s}; }
+__device__ __forceinline__ SVp crossMotion(SVp v, SVp s) { return {cross(v.a, s.a), cross(v.a, s.l) + cross(v.l, s.a)}; }
+__device__ __forceinline__ SVp crossForce(SVp v, SVp f) { return {cross(v.a, f.a) + cross(v.l, f.l), cross(v.a, f.l)}; }
+__device__ __forceinline__ f2 sdot(SVp m, SVp f) { return dot(m.a, f.a) + dot(m.l, f.l); }
+struct SIp { f2 m; V3p h; f2 I[6]; };
+__device__ __forceinline__ V3p symmul(const f2* I, V3p v) {
+    return {I[0] * v.x + I[3] * v.y + I[4] * v.z, I[3] * v.x + I[1] * v.y + I[5] * v.z, I[4] * v.x + I[5] * v.y + I[2] * v.z};
+}
+__device__ __forceinline__ SVp imul(const SIp& s, SVp v) { return {symmul(s.I, v.a) + cross(s.h, v.l), v.l * s.m - cross(s.h, v.a)}; }
+
 // local column (0..18) of a row of leg LEG -> global dof
 template <int LEG> constexpr int c2d(int c) { return c < 6 ? c : c + 13 * LEG; }
 constexpr int d2c(int d) { return d < 6 ? d : (d < 19 ? d : d - 13); }

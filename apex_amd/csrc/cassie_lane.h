@@ -89,18 +89,6 @@ template <int LEG> constexpr unsigned chain_mask(int body) {
     return m;
 }
 
-#ifndef APX_POSE_DPP
-#define APX_POSE_DPP 1     /* pose pointer jumping through ds_bpermute lane fetches (round 3) instead of the exchange records in LDS */
-#endif
-#ifndef APX_SUBTREE_PD
-#define APX_SUBTREE_PD 0
-#endif
-#ifndef APX_SUBTREE_SFX
-#define APX_SUBTREE_SFX 1  /* subtree sums as DPP suffix sums (round 3) instead of the descendant loop over LDS records */
-#endif
-#ifndef APX_CRBA_DPP
-#define APX_CRBA_DPP 1     /* mass-matrix off-diagonals by row broadcasts over the ancestor dofs (round 3) instead of the per-lane chain walk through LDS */
-#endif
 // level of leg dof j in the ancestor chain of leg dof lane l (1 = parent dof, ...; 0 = j is not a proper ancestor of l), one nibble per lane
 constexpr unsigned long long crba_level_table(int j) {
     unsigned long long t = 0;
@@ -109,9 +97,6 @@ constexpr unsigned long long crba_level_table(int j) {
             if (ct_dof_anc[16 * (6 + k) + a] == 6 + j) t |= (unsigned long long)a << (4 * k);
     return t;
 }
-#ifndef APX_CRBA_SB
-#define APX_CRBA_SB 0      /* scheduling barrier every n levels of the CRBA chain walk: measured 0 / 3 / 5 / 7 within 0.4 % */
-#endif
 // ------------------------------------------------------------------------------------------------ tree stage
 // Kinematics, velocities, RNE bias forces, composite inertias and the mass matrix, lane-parallel over the 12 bodies of a
 // leg (lane b: left body 2+b in slot 0, right body 14+b in slot 1); the pelvis is computed by every lane.  Bodies are
@@ -120,7 +105,8 @@ constexpr unsigned long long crba_level_table(int j) {
 // ancestor-chain layout, WK_CDOF, WK_SMOOTH, WK_PTS, WK_PEL, F_FWD foot pose).
 constexpr int WK_CTRL = WK_QACC;                        // actuator-side torques from the io stage (10)
 constexpr int WK_DUMMY = WK_QACC + 16;                  // sink for predicated-off stores (keeps them branch-free)
-constexpr int XB_SZ = 20;                               // exchange record per body: pos3 quat4 vel6 acc6 | crb10 frc6
+// a pair store `S.W(off) .. S.W(off + 32)` (leg slot 1 of a WK_PTS point sits 30 words behind slot 0) aimed at the sink lands in the unused tail of WK_ZP2
+static_assert(WK_DUMMY + 30 >= WK_ZP2 + 4 && WK_DUMMY + 33 <= WK_TOTAL, "sink of the pair stores");
 constexpr unsigned long long nib(int a0, int a1, int a2, int a3, int a4, int a5, int a6, int a7, int a8, int a9, int a10, int a11) {
     return (unsigned long long)a0 | (unsigned long long)a1 << 4 | (unsigned long long)a2 << 8 | (unsigned long long)a3 << 12 |
            (unsigned long long)a4 << 16 | (unsigned long long)a5 << 20 | (unsigned long long)a6 << 24 | (unsigned long long)a7 << 28 |
@@ -143,17 +129,6 @@ __device__ __forceinline__ int nibble(unsigned long long t, int i) { return (int
 static_assert(ct_body_parent[8] == 6 && ct_body_parent[13] == 9 && ct_body_parent[12] == 11 && ct_body_dofadr[8] == 13 && ct_jnt_qposadr[9] == 15 &&
               ct_body_dofadr[13] == 18 && ct_jnt_qposadr[14] == 20 && ct_body_dofnum[5] == 3 && ct_body_dofnum[7] == 0, "leg topology tables");
 
-struct XRec { V3 pos; Q4 quat; SV vel, acc; };
-__device__ __forceinline__ XRec xb_read(const float* xb, int body) {
-    const float* p = xb + XB_SZ * body;
-    return {{p[0], p[1], p[2]}, {p[3], p[4], p[5], p[6]}, {{p[7], p[8], p[9]}, {p[10], p[11], p[12]}}, {{p[13], p[14], p[15]}, {p[16], p[17], p[18]}}};
-}
-__device__ __forceinline__ void xb_write(float* xb, int body, const XRec& r) {
-    float* p = xb + XB_SZ * body;
-    p[0] = r.pos.x; p[1] = r.pos.y; p[2] = r.pos.z; p[3] = r.quat.w; p[4] = r.quat.x; p[5] = r.quat.y; p[6] = r.quat.z;
-    p[7] = r.vel.a.x; p[8] = r.vel.a.y; p[9] = r.vel.a.z; p[10] = r.vel.l.x; p[11] = r.vel.l.y; p[12] = r.vel.l.z;
-    p[13] = r.acc.a.x; p[14] = r.acc.a.y; p[15] = r.acc.a.z; p[16] = r.acc.l.x; p[17] = r.acc.l.y; p[18] = r.acc.l.z;
-}
 // spatial inertia of a body about o in world axes + its RNE force (c3::visit)
 __device__ __forceinline__ void body_inertia_force(const M3& R, V3 pos, V3 o, const float (&Ib)[9], V3 ipos, float m, const SV& vel, const SV& acc, SI& c, SV& frc) {
     float RI[9], Iw[9];
@@ -166,93 +141,109 @@ __device__ __forceinline__ void body_inertia_force(const M3& R, V3 pos, V3 o, co
     c.I[3] = Iw[1] - m * r.x * r.y; c.I[4] = Iw[2] - m * r.x * r.z; c.I[5] = Iw[5] - m * r.y * r.z;
     frc = imul(c, acc) + crossForce(vel, imul(c, vel));
 }
+// ... of the lane's body in BOTH leg slots (pair form, cassie_common.h)
+__device__ __forceinline__ void body_inertia_force(const M3p& R, V3p pos, V3 o, const f2 (&Ib)[9], V3p ipos, f2 m, const SVp& vel, const SVp& acc, SIp& c, SVp& frc) {
+    f2 RI[9], Iw[9];
+    sfor<0, 3>([&](auto I) { sfor<0, 3>([&](auto K) { RI[3 * I + K] = R.m[3 * I] * Ib[K] + R.m[3 * I + 1] * Ib[3 + K] + R.m[3 * I + 2] * Ib[6 + K]; }); });
+    sfor<0, 3>([&](auto I) { sfor<0, 3>([&](auto K) { if constexpr (K >= I) Iw[3 * I + K] = RI[3 * I] * R.m[3 * K] + RI[3 * I + 1] * R.m[3 * K + 1] + RI[3 * I + 2] * R.m[3 * K + 2]; }); });
+    const V3p r = pos + mul(R, ipos) - lift(o);
+    const f2 rr = dot(r, r);
+    c.m = m; c.h = r * m;
+    c.I[0] = Iw[0] + m * (rr - r.x * r.x); c.I[1] = Iw[4] + m * (rr - r.y * r.y); c.I[2] = Iw[8] + m * (rr - r.z * r.z);
+    c.I[3] = Iw[1] - m * r.x * r.y; c.I[4] = Iw[2] - m * r.x * r.z; c.I[5] = Iw[5] - m * r.y * r.z;
+    frc = imul(c, acc) + crossForce(vel, imul(c, vel));
+}
 
 struct Qpos0 { float v[CM_NQ]; };
 constexpr Qpos0 make_qpos0() { Qpos0 q{}; for (int i = 0; i < CM_NQ; ++i) q.v[i] = ct_qpos0[i]; return q; }
 __device__ const Qpos0 kQpos0 = make_qpos0();
 
+template <int CTRL> __device__ __forceinline__ f2 dpp2(f2 v) { return f2{dpp<CTRL>(v.x), dpp<CTRL>(v.y)}; }
+// Exchange records of the tree stage (row-store region): one per leg-local body, PAIR layout like the constant table: word k of leg slot sd at XB_SZ lb + 2 k + sd.
+// [0..9] composite inertia (m, h3, I6), [10..15] subtree force, [16..18] the body's COM relative to the pelvis origin; record 12 = sink of the shadow lanes.
+constexpr int XB_SZ = 40, XB_SPARE = 12;
+static_assert(13 * XB_SZ <= 704, "exchange records fit the row-store region");
+
 // QPOS0 = true: the configuration-only pass of mj_setConst (qpos0, zero velocities; emits the COM of the bodies that carry
 // constraints instead of anchors / capsule ends)
+//
+// Round 5: the stage is written on (left, right) PAIRS.  A lane carries leg-local body b of both legs; every quantity of the two slots is an f2 and the arithmetic is
+// v_pk_{mul,add,fma}_f32 - one instruction where rounds 1-4 issued two (the stage had 0 packed of 1 816 fp32 arithmetic instructions).  What cannot pack stays per
+// component: DPP row shifts / broadcasts and ds_bpermute (VOP3P has no DPP form), selects, the transcendental pairs, LDS traffic at per-slot addresses.
 template <bool QPOS0>
 __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
     auto qp = [&](int i) -> float { if constexpr (QPOS0) return kQpos0.v[i]; else return S(F_QPOS + i); };
+    auto qp2 = [&](int i) -> f2 { return f2{qp(i), qp(i + 14)}; };                 // the same joint of the two legs (qpos blocks 7.., 21..)
+    auto qv2 = [&](int i) -> f2 { return f2{S(F_QVEL + i), S(F_QVEL + i + 13)}; };   // dof blocks 6.., 19..
     const int l = threadIdx.x & 15;
-    const int lb = l < 12 ? l : 11;                                     // lanes 12..15 shadow the foot lane (their body results are not stored)
+    const int lb = l < 12 ? l : 11;                                     // lanes 12..15 shadow the foot lane (their body results go to the spare record)
     const bool bl = l < 12;
-    // ---- per-lane model constants of the two bodies (left, right)
-    int body[2], qadr[2], dadr[2];
-    const int depth = nibble(TB_DEPTH, lb), par = nibble(TB_PARENT, lb), ndesc = nibble(TB_NDESC, lb), qoff = nibble(TB_QOFF, lb), doff = nibble(TB_DOFF, lb);
+    // ---- per-lane model constants of the two bodies (left, right): one 64-bit LDS operand per pair
+    const int par = nibble(TB_PARENT, lb), qoff = nibble(TB_QOFF, lb), doff = nibble(TB_DOFF, lb);
     const bool hasj = qoff != 15, ball = lb == 3;
-    V3 bpos[2], ipos[2]; Q4 bquat[2]; float Ib[2][9], mass[2];
-    sfor<0, 2>([&](auto Sd) {
-        constexpr int sd = Sd;
-        body[sd] = 2 + 12 * sd + lb; qadr[sd] = 7 + 14 * sd + qoff; dadr[sd] = 6 + 13 * sd + doff;
-        const int b = body[sd];
-        const int cb = CT_BODY + CT_BODYSZ * (b - 2);              // the body's record in the wave-constant table
-        bpos[sd] = {ctf(cb), ctf(cb + 1), ctf(cb + 2)};
-        ipos[sd] = {ctf(cb + 3), ctf(cb + 4), ctf(cb + 5)};
-        bquat[sd] = {ctf(cb + 6), ctf(cb + 7), ctf(cb + 8), ctf(cb + 9)};
-        sfor<0, 9>([&](auto K) { Ib[sd][K] = ctf(cb + 10 + K); });
-        mass[sd] = S(F_MASS + b);
-    });
-    const int xbody[2] = {bl ? body[0] : 26, bl ? body[1] : 27};      // where this lane's exchange record goes (26, 27: spare records for the shadow lanes)
+    const int qadr = 7 + qoff, dadr = 6 + doff;                         // left leg; the right leg's are + 14 / + 13
+    const int cb = CT_BODY + CT_BODYSZ * lb;
+    auto ct2 = [&](int k) -> f2 { return f2{ctf(cb + 2 * k), ctf(cb + 2 * k + 1)}; };
+    const V3p bpos = {ct2(0), ct2(1), ct2(2)}, ipos = {ct2(3), ct2(4), ct2(5)};
+    const Q4p bquat = {ct2(6), ct2(7), ct2(8), ct2(9)};
+    f2 Ib[9];
+    sfor<0, 9>([&](auto K) { Ib[K] = ct2(10 + K); });
+    // the shadow lanes carry a massless copy of the foot: their composite inertia and force are exactly 0, so the suffix sums below need no masking
+    const float blf = bl ? 1.f : 0.f;
+    const f2 mass = f2{S(F_MASS + 2 + lb), S(F_MASS + 14 + lb)} * blf;
+    sfor<0, 9>([&](auto K) { Ib[K] = Ib[K] * blf; });
+    const int xrec = XB_SZ * (bl ? lb : XB_SPARE);                      // where this lane's exchange record goes
     float jref = 0.f; jref = lb == 7 ? ct_jnt_ref[10] : jref; jref = lb == 4 ? ct_jnt_ref[8] : jref;      // knee, tarsus (plain selects: a nested ?: becomes branches)
     static_assert(ct_jnt_ref[19] == ct_jnt_ref[8] && ct_jnt_ref[21] == ct_jnt_ref[10] && ct_jnt_ref[9] == 0.f, "joint refs");
-    // ---- pelvis (every lane)
+    // ---- pelvis (every lane, uniform)
     const V3 o = {qp(0), qp(1), qp(2)};
-    XRec pel;
-    pel.pos = o;
-    pel.quat = qnormalize(Q4{qp(3), qp(4), qp(5), qp(6)});
-    const M3 pmat = q2m(pel.quat);
+    const Q4 pquat = qnormalize(Q4{qp(3), qp(4), qp(5), qp(6)});
+    const M3 pmat = q2m(pquat);
     SV pc[6] = {{{0, 0, 0}, {1, 0, 0}}, {{0, 0, 0}, {0, 1, 0}}, {{0, 0, 0}, {0, 0, 1}}, {col(pmat, 0), {0, 0, 0}}, {col(pmat, 1), {0, 0, 0}}, {col(pmat, 2), {0, 0, 0}}};
+    SV pvel, pacc;
     {
         SV v = {{0, 0, 0}, {S(F_QVEL), S(F_QVEL + 1), S(F_QVEL + 2)}};
         SV a = {{0, 0, 0}, {0, 0, GRAV}};
         const SV vp = v;
         sfor<3, 6>([&](auto D) { const float qd = S(F_QVEL + D); a = a + crossMotion(vp, pc[D]) * qd; v = v + pc[D] * qd; });
-        pel.vel = v; pel.acc = a;
+        pvel = v; pacc = a;
     }
     if (l == 0) {
-        xb_write(xb, 1, pel);
         sfor<0, 6>([&](auto D) {
             S.W(WK_CDOF + 6 * D) = pc[D].a.x; S.W(WK_CDOF + 6 * D + 1) = pc[D].a.y; S.W(WK_CDOF + 6 * D + 2) = pc[D].a.z;
             S.W(WK_CDOF + 6 * D + 3) = pc[D].l.x; S.W(WK_CDOF + 6 * D + 4) = pc[D].l.y; S.W(WK_CDOF + 6 * D + 5) = pc[D].l.z;
         });
-        S.W(WK_PEL + 0) = pel.acc.a.x; S.W(WK_PEL + 1) = pel.acc.a.y; S.W(WK_PEL + 2) = pel.acc.a.z;
-        S.W(WK_PEL + 3) = pel.acc.l.x; S.W(WK_PEL + 4) = pel.acc.l.y; S.W(WK_PEL + 5) = pel.acc.l.z;
-        S.W(WK_PEL + 6) = pel.vel.a.x; S.W(WK_PEL + 7) = pel.vel.a.y; S.W(WK_PEL + 8) = pel.vel.a.z;
-        S.W(WK_PEL + 9) = pel.vel.l.x; S.W(WK_PEL + 10) = pel.vel.l.y; S.W(WK_PEL + 11) = pel.vel.l.z;
+        S.W(WK_PEL + 0) = pacc.a.x; S.W(WK_PEL + 1) = pacc.a.y; S.W(WK_PEL + 2) = pacc.a.z;
+        S.W(WK_PEL + 3) = pacc.l.x; S.W(WK_PEL + 4) = pacc.l.y; S.W(WK_PEL + 5) = pacc.l.z;
+        S.W(WK_PEL + 6) = pvel.a.x; S.W(WK_PEL + 7) = pvel.a.y; S.W(WK_PEL + 8) = pvel.a.z;
+        S.W(WK_PEL + 9) = pvel.l.x; S.W(WK_PEL + 10) = pvel.l.y; S.W(WK_PEL + 11) = pvel.l.z;
         sfor<0, 9>([&](auto K) { S.W(WK_PEL + 12 + K) = pmat.m[K]; });
     }
     // ---- local joint rotation and joint velocities of this lane's bodies (hinge axis = local z, ball = x, y, z)
-    Q4 lq[2]; float qd[2][3];
-    sfor<0, 2>([&](auto Sd) {
-        constexpr int sd = Sd;
-        Q4 jq = {1.f, 0.f, 0.f, 0.f};
-        qd[sd][0] = qd[sd][1] = qd[sd][2] = 0.f;
+    Q4p lq; f2 qd[3];
+    {
+        Q4p jq = {splat(1.f), splat(0.f), splat(0.f), splat(0.f)};
+        qd[0] = qd[1] = qd[2] = splat(0.f);
         if (hasj) {
             if (ball) {
-                jq = qnormalize(Q4{qp(qadr[sd]), qp(qadr[sd] + 1), qp(qadr[sd] + 2), qp(qadr[sd] + 3)});
-                sfor<0, 3>([&](auto K) { qd[sd][K] = S(F_QVEL + dadr[sd] + K); });
+                jq = qnormalize(Q4p{qp2(qadr), qp2(qadr + 1), qp2(qadr + 2), qp2(qadr + 3)});
+                sfor<0, 3>([&](auto K) { qd[K] = qv2(dadr + K); });
             } else {
-                float sn, cs;
-                __sincosf(0.5f * (qp(qadr[sd]) - jref), &sn, &cs);
-                jq = {cs, 0.f, 0.f, sn};
-                qd[sd][2] = S(F_QVEL + dadr[sd]);
+                const f2 h = (qp2(qadr) - jref) * 0.5f;
+                float s0, c0, s1, c1;
+                __sincosf(h.x, &s0, &c0); __sincosf(h.y, &s1, &c1);
+                jq = {f2{c0, c1}, splat(0.f), splat(0.f), f2{s0, s1}};
+                qd[2] = qv2(dadr);
             }
         }
-        lq[sd] = qmul(bquat[sd], jq);
-    });
+        lq = qmul(bquat, jq);
+    }
     PROF2(12);
-    // ---- pointer jumping over the ancestor chain (depth <= 8: 3 rounds).  Round r composes a body's transform with the
-    // record of its 2^r-th ancestor, which by then spans 2^r levels itself; the same rounds give the chain sums below.
-#if APX_POSE_DPP
-    // Round r composes a body's transform with that of its 2^r-th ancestor, which by then spans 2^r levels itself.  The ancestor's transform is fetched
-    // straight from its lane with ds_bpermute (the LDS crossbar, no memory): seven words per leg and round, one wait per round.  Round 2 went through the
-    // exchange records (store, fence, load at a lane-dependent address, fence, per round).  A row_shr + select form is 7 VALU per word and is the trap of
-    // this kernel: clang predicates `c ? dpp(v) : r` as a DPP move under an exec mask, and a DPP read of a DISABLED source lane returns 0.
-    V3 tp[2]; Q4 tq[2];
-    sfor<0, 2>([&](auto Sd) { tp[Sd] = bpos[Sd]; tq[Sd] = lq[Sd]; });
+    // ---- pointer jumping over the ancestor chain (depth <= 8: 3 rounds).  Round r composes a body's transform with that of its 2^r-th ancestor, which by then spans
+    // 2^r levels itself.  The ancestor's transform is fetched straight from its lane with ds_bpermute (the LDS crossbar, no memory): seven words per leg and round, one
+    // wait per round.  A row_shr + select form is 7 VALU per word and is the trap of this kernel: clang predicates `c ? dpp(v) : r` as a DPP move under an exec mask,
+    // and a DPP read of a DISABLED source lane returns 0.
+    V3p tp = bpos; Q4p tq = lq;
     {
         const int jumpl[3] = {par, nibble(TB_PAR2, lb), nibble(TB_PAR4, lb)};
         const int rowbase = (int)(threadIdx.x & 48u);
@@ -260,214 +251,116 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             constexpr int r = Rn;
             const bool on = jumpl[r] != 15;
             const int src = 4 * (rowbase + (on ? jumpl[r] : l));
-            auto fetch = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v))); };
-            sfor<0, 2>([&](auto Sd) {
-                constexpr int sd = Sd;
-                const V3 ap = {fetch(tp[sd].x), fetch(tp[sd].y), fetch(tp[sd].z)};
-                const Q4 aq = {fetch(tq[sd].w), fetch(tq[sd].x), fetch(tq[sd].y), fetch(tq[sd].z)};
-                const V3 np = ap + mul(q2m(aq), tp[sd]);
-                const Q4 nq = qmul(aq, tq[sd]);
-                tp[sd] = {on ? np.x : tp[sd].x, on ? np.y : tp[sd].y, on ? np.z : tp[sd].z};
-                tq[sd] = {on ? nq.w : tq[sd].w, on ? nq.x : tq[sd].x, on ? nq.y : tq[sd].y, on ? nq.z : tq[sd].z};
-            });
+            auto fetch = [&](f2 v) { return f2{__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v.y)))}; };
+            const V3p ap = {fetch(tp.x), fetch(tp.y), fetch(tp.z)};
+            const Q4p aq = {fetch(tq.w), fetch(tq.x), fetch(tq.y), fetch(tq.z)};
+            const V3p np = ap + mul(q2m(aq), tp);
+            const Q4p nq = qmul(aq, tq);
+            tp = sel2(on, np, tp); tq = sel2(on, nq, tq);
         });
     }
-#else
-    const int jump[3] = {par, nibble(TB_PAR2, lb), nibble(TB_PAR4, lb)};
-    V3 tp[2]; Q4 tq[2];
-    sfor<0, 2>([&](auto Sd) { tp[Sd] = bpos[Sd]; tq[Sd] = lq[Sd]; });
-    sfor<0, 3>([&](auto Rn) {
-        constexpr int r = Rn;
-        wsync();
-        sfor<0, 2>([&](auto Sd) {      // branch-free: the shadow lanes 12..15 write a spare record
-            float* p = xb + XB_SZ * xbody[Sd];
-            p[0] = tp[Sd].x; p[1] = tp[Sd].y; p[2] = tp[Sd].z; p[3] = tq[Sd].w; p[4] = tq[Sd].x; p[5] = tq[Sd].y; p[6] = tq[Sd].z;
-        });
-        wsync();
-        sfor<0, 2>([&](auto Sd) {
-            constexpr int sd = Sd;
-            const float* p = xb + XB_SZ * (2 + 12 * sd + (jump[r] == 15 ? lb : jump[r]));
-            const V3 ap = {p[0], p[1], p[2]}; const Q4 aq = {p[3], p[4], p[5], p[6]};
-            const V3 np = ap + mul(q2m(aq), tp[sd]);
-            const Q4 nq = qmul(aq, tq[sd]);
-            if (jump[r] != 15) { tp[sd] = np; tq[sd] = nq; }
-        });
-    });
-#endif
     PROF2(13);
-    M3 mat[2]; V3 pos[2]; Q4 quat[2]; SV vel[2], acc[2]; SV cdof[2][3];
-    SV own[2];                                                        // this body's joint velocity contribution sum_K cdof_K qd_K
-    sfor<0, 2>([&](auto Sd) {
-        constexpr int sd = Sd;
-        pos[sd] = o + mul(pmat, tp[sd]);
-        quat[sd] = qnormalize(qmul(pel.quat, tq[sd]));
-        mat[sd] = q2m(quat[sd]);
-        const V3 r = o - pos[sd];
-        own[sd] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-        sfor<0, 3>([&](auto K) { const V3 ax = col(mat[sd], K); cdof[sd][K] = {ax, cross(ax, r)}; own[sd] = own[sd] + cdof[sd][K] * qd[sd][K]; });
-    });
+    const V3p pos = lift(o) + mul(pmat, tp);
+    const Q4p quat = qnormalize(qmul(lift(pquat), tq));
+    const M3p mat = q2m(quat);
+    SVp cdof[3], own;                                                   // own = this body's joint velocity contribution sum_K cdof_K qd_K
+    {
+        const V3p r = lift(o) - pos;
+        own = {{splat(0.f), splat(0.f), splat(0.f)}, {splat(0.f), splat(0.f), splat(0.f)}};
+        sfor<0, 3>([&](auto K) { const V3p ax = col(mat, K); cdof[K] = {ax, cross(ax, r)}; own = own + cdof[K] * qd[K]; });
+    }
     // chain sum of a spatial vector: val_b <- sum of val over b and its ancestors inside the leg.  Bodies are numbered depth-first, so "a is an
     // ancestor of b" is the interval test a <= b <= a + ndesc_a: add val_a at lane a, take it away again at lane a + ndesc_a + 1, and the inclusive
     // prefix sum over the lanes is the chain sum.  The take-away lanes are fixed offsets (achilles rod -> knee, knee spring -> shin, heel spring ->
-    // foot crank: one lane up; foot crank and plantar rod -> foot), so the whole thing is 6 DPP row shifts and 6 adds per float: no LDS round trip
-    // (the pointer-jumping form of round 2 cost three store / fence / load rounds per sum).
+    // foot crank: one lane up; foot crank and plantar rod -> foot), so the whole thing is 6 DPP row shifts and 6 adds per float: no LDS round trip.
     static_assert(TB_NDESC == nib(11, 10, 9, 0, 7, 0, 5, 4, 0, 1, 0, 0), "take-away lanes of the chain sum");
     const float cm1 = (lb == 4 || lb == 6 || lb == 9 || lb == 11) ? 1.f : 0.f, cm2 = lb == 11 ? 1.f : 0.f;
     // (the twelve scans of a chain sum advance STAGE BY STAGE: one scan after the other is a chain of dependent DPP adds with a hazard nop between each pair)
-    auto chain_sum = [&](SV (&val)[2]) {
-        float d[12];
-        sfor<0, 2>([&](auto Sd) {
-            d[6 * Sd] = val[Sd].a.x; d[6 * Sd + 1] = val[Sd].a.y; d[6 * Sd + 2] = val[Sd].a.z; d[6 * Sd + 3] = val[Sd].l.x; d[6 * Sd + 4] = val[Sd].l.y; d[6 * Sd + 5] = val[Sd].l.z;
-        });
-        float s1[12], s2[12];
-        sfor<0, 12>([&](auto I) { s1[I] = dpp<0x111>(d[I]); });
-        sfor<0, 12>([&](auto I) { s2[I] = dpp<0x112>(d[I]); });
-        sfor<0, 12>([&](auto I) { d[I] = d[I] - cm1 * s1[I] - cm2 * s2[I]; });
-        sfor<0, 12>([&](auto I) { d[I] += dpp<0x111>(d[I]); });
-        sfor<0, 12>([&](auto I) { d[I] += dpp<0x112>(d[I]); });
-        sfor<0, 12>([&](auto I) { d[I] += dpp<0x114>(d[I]); });
-        sfor<0, 12>([&](auto I) { d[I] += dpp<0x118>(d[I]); });
-        sfor<0, 2>([&](auto Sd) {
-            val[Sd].a = {d[6 * Sd], d[6 * Sd + 1], d[6 * Sd + 2]}; val[Sd].l = {d[6 * Sd + 3], d[6 * Sd + 4], d[6 * Sd + 5]};
-        });
+    auto chain_sum = [&](SVp& val) {
+        f2 d[6] = {val.a.x, val.a.y, val.a.z, val.l.x, val.l.y, val.l.z};
+        f2 s1[6], s2[6];
+        sfor<0, 6>([&](auto I) { s1[I] = dpp2<0x111>(d[I]); });
+        sfor<0, 6>([&](auto I) { s2[I] = dpp2<0x112>(d[I]); });
+        sfor<0, 6>([&](auto I) { d[I] = d[I] - s1[I] * cm1 - s2[I] * cm2; });
+        sfor<0, 6>([&](auto I) { d[I].x += dpp<0x111>(d[I].x); d[I].y += dpp<0x111>(d[I].y); });
+        sfor<0, 6>([&](auto I) { d[I].x += dpp<0x112>(d[I].x); d[I].y += dpp<0x112>(d[I].y); });
+        sfor<0, 6>([&](auto I) { d[I].x += dpp<0x114>(d[I].x); d[I].y += dpp<0x114>(d[I].y); });
+        sfor<0, 6>([&](auto I) { d[I].x += dpp<0x118>(d[I].x); d[I].y += dpp<0x118>(d[I].y); });
+        val.a = {d[0], d[1], d[2]}; val.l = {d[3], d[4], d[5]};
     };
-    sfor<0, 2>([&](auto Sd) { vel[Sd] = own[Sd]; });
+    SVp vel = own, acc;
     chain_sum(vel);
-    sfor<0, 2>([&](auto Sd) {
-        constexpr int sd = Sd;
-        vel[sd] = vel[sd] + pel.vel;
-        const SV vp = {vel[sd].a - own[sd].a, vel[sd].l - own[sd].l};        // parent body's velocity
-        SV t = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-        sfor<0, 3>([&](auto K) { t = t + crossMotion(vp, cdof[sd][K]) * qd[sd][K]; });
-        acc[sd] = t;
-    });
+    {
+        vel = vel + lift(pvel);
+        const SVp vp = {vel.a - own.a, vel.l - own.l};                  // parent body's velocity
+        SVp t = {{splat(0.f), splat(0.f), splat(0.f)}, {splat(0.f), splat(0.f), splat(0.f)}};
+        sfor<0, 3>([&](auto K) { t = t + crossMotion(vp, cdof[K]) * qd[K]; });
+        acc = t;
+    }
     chain_sum(acc);
     PROF2(14);
-    sfor<0, 2>([&](auto Sd) {
+    acc = acc + lift(pacc);
+    if (bl && hasj) sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
-        acc[sd] = acc[sd] + pel.acc;
-        if (bl && hasj) {
-            if (ball) sfor<0, 3>([&](auto K) {
-                float* c = (float*)&S.W(WK_CDOF + 6 * (dadr[sd] + K));
-                c[0] = cdof[sd][K].a.x; c[1] = cdof[sd][K].a.y; c[2] = cdof[sd][K].a.z; c[3] = cdof[sd][K].l.x; c[4] = cdof[sd][K].l.y; c[5] = cdof[sd][K].l.z;
-            });
-            else {
-                float* c = (float*)&S.W(WK_CDOF + 6 * dadr[sd]);
-                c[0] = cdof[sd][2].a.x; c[1] = cdof[sd][2].a.y; c[2] = cdof[sd][2].a.z; c[3] = cdof[sd][2].l.x; c[4] = cdof[sd][2].l.y; c[5] = cdof[sd][2].l.z;
-            }
+        if (ball) sfor<0, 3>([&](auto K) {
+            float* c = (float*)&S.W(WK_CDOF + 6 * (dadr + 13 * sd + K));
+            c[0] = cdof[K].a.x[sd]; c[1] = cdof[K].a.y[sd]; c[2] = cdof[K].a.z[sd]; c[3] = cdof[K].l.x[sd]; c[4] = cdof[K].l.y[sd]; c[5] = cdof[K].l.z[sd];
+        });
+        else {
+            float* c = (float*)&S.W(WK_CDOF + 6 * (dadr + 13 * sd));
+            c[0] = cdof[2].a.x[sd]; c[1] = cdof[2].a.y[sd]; c[2] = cdof[2].a.z[sd]; c[3] = cdof[2].l.x[sd]; c[4] = cdof[2].l.y[sd]; c[5] = cdof[2].l.z[sd];
         }
     });
-    wsync();                                                  // every lane is done reading poses: the records become (crb, frc)
     PROF2(15);
     // ---- inertia + RNE force of the own bodies and of the pelvis
-    SI crb[2]; SV frc[2];
-    sfor<0, 2>([&](auto Sd) {
-        constexpr int sd = Sd;
-        body_inertia_force(mat[sd], pos[sd], o, Ib[sd], ipos[sd], mass[sd], vel[sd], acc[sd], crb[sd], frc[sd]);
-        {
-            float* p = xb + XB_SZ * xbody[sd];
-            p[0] = crb[sd].m; p[1] = crb[sd].h.x; p[2] = crb[sd].h.y; p[3] = crb[sd].h.z;
-            sfor<0, 6>([&](auto K) { p[4 + K] = crb[sd].I[K]; });
-            p[10] = frc[sd].a.x; p[11] = frc[sd].a.y; p[12] = frc[sd].a.z; p[13] = frc[sd].l.x; p[14] = frc[sd].l.y; p[15] = frc[sd].l.z;
-        }
-    });
+    SIp crb; SVp frc;
+    body_inertia_force(mat, pos, o, Ib, ipos, mass, vel, acc, crb, frc);
     SI pcrb; SV pfrc;
     {
         float Ipel[9];
         sfor<0, 9>([&](auto K) { Ipel[K] = ct_body_inertia[9 + K]; });
-        body_inertia_force(pmat, o, o, Ipel, cv3<1>(ct_body_ipos), S(F_MASS + 1), pel.vel, pel.acc, pcrb, pfrc);
+        body_inertia_force(pmat, o, o, Ipel, cv3<1>(ct_body_ipos), S(F_MASS + 1), pvel, pacc, pcrb, pfrc);
     }
-    wsync();
     PROF2(16);
-    // ---- subtree sums (composite inertia, subtree force): descendants are the next ndesc bodies
-    // (Two other DPP forms were measured in round 3 and dropped.  Prefix differences, prefix(b + ndesc) - prefix(b - 1), below as APX_SUBTREE_PD: as first
-    // written every env went NaN within a step - it held a `c ? dpp(v) : r` select, which clang executes as a DPP move under c's exec mask, where a disabled
-    // source lane reads as 0 (tools/dpp_audit.py).  With the cross-lane reads pinned it runs and passes the rollout parity tests, but fails the single-substep
-    // tolerance on the rod axes (the inertia of a 0.1 kg rod as the difference of two whole-leg prefixes loses digits in fp32) and is not faster: 2.61 ms.
-    // A bottom-up sweep "s += [lane is the parent] * s(lane + k)", 11 child edges per float: correct, but 352 dependent v_mov_dpp + v_fmac pairs: 2.79 against 2.74 ms.)
-#if APX_SUBTREE_PD      /* experiment only (tools/ab_variants.sh): the prefix-DIFFERENCE form with every cross-lane read taken unconditionally and pinned */
-    {
-        const bool leafb = lb == 3 || lb == 5 || lb == 8 || lb == 10, crank = lb == 9;
-        auto subtree = [&](float x) {
-            float pz = bl ? x : 0.f;
-            pz += dpp<0x111>(pz); pz += dpp<0x112>(pz); pz += dpp<0x114>(pz); pz += dpp<0x118>(pz);
-            float hi = dpp<0x150 + 11>(pz), nx = dpp<0x101>(pz), lo = dpp<0x111>(pz);
-            asm volatile("" : "+v"(hi), "+v"(nx), "+v"(lo));
-            float top = leafb ? pz : hi; top = crank ? nx : top;
-            return top - lo;
-        };
-        sfor<0, 2>([&](auto Sd) {
-            constexpr int sd = Sd;
-            const float c0 = subtree(crb[sd].m), c1 = subtree(crb[sd].h.x), c2 = subtree(crb[sd].h.y), c3 = subtree(crb[sd].h.z), c4 = subtree(crb[sd].I[0]),
-                        c5 = subtree(crb[sd].I[1]), c6 = subtree(crb[sd].I[2]), c7 = subtree(crb[sd].I[3]), c8 = subtree(crb[sd].I[4]), c9 = subtree(crb[sd].I[5]);
-            crb[sd] = SI{c0, {c1, c2, c3}, {c4, c5, c6, c7, c8, c9}};
-            frc[sd].a.x = subtree(frc[sd].a.x); frc[sd].a.y = subtree(frc[sd].a.y); frc[sd].a.z = subtree(frc[sd].a.z);
-            frc[sd].l.x = subtree(frc[sd].l.x); frc[sd].l.y = subtree(frc[sd].l.y); frc[sd].l.z = subtree(frc[sd].l.z);
-        });
-    }
-#elif APX_SUBTREE_SFX
-    // Depth-first numbering: every subtree interval [b, b + ndesc] ends at the foot (lane 11) except the leaves (own value) and the foot crank (itself
-    // + the plantar rod).  So the subtree sum of a body on the path to the foot is the inclusive SUFFIX sum over lanes b..11 - four row_shl adds, sums
-    // only (a prefix-DIFFERENCE form cancels in fp32) - and the others are one select each.  The shadow lanes 12..15 carry copies of the foot and are
-    // zeroed first.  No LDS reads.
+    // ---- subtree sums (composite inertia, subtree force).  Depth-first numbering: every subtree interval [b, b + ndesc] ends at the foot (lane 11) except the leaves
+    // (own value) and the foot crank (itself + the plantar rod).  So the subtree sum of a body on the path to the foot is the inclusive SUFFIX sum over lanes b..11 -
+    // four row_shl adds, sums only (a prefix-DIFFERENCE form cancels in fp32: round 3) - and the others are one select each.  The shadow lanes 12..15 are massless
+    // (above) and add exact zeros.  No LDS reads.
     {
         static_assert(TB_NDESC == nib(11, 10, 9, 0, 7, 0, 5, 4, 0, 1, 0, 0), "subtree intervals end at the foot, except leaves and the foot crank");
         const bool leafb = lb == 3 || lb == 5 || lb == 8 || lb == 10, crank = lb == 9;
-        sfor<0, 2>([&](auto Sd) {
-            constexpr int sd = Sd;
-            // sixteen suffix sums per leg, stage by stage (one after the other they are chains of dependent DPP adds with hazard nops)
-            float x0[16], sfx[16], two[16];
-            x0[0] = crb[sd].m; x0[1] = crb[sd].h.x; x0[2] = crb[sd].h.y; x0[3] = crb[sd].h.z;
-            sfor<0, 6>([&](auto K) { x0[4 + K] = crb[sd].I[K]; });
-            x0[10] = frc[sd].a.x; x0[11] = frc[sd].a.y; x0[12] = frc[sd].a.z; x0[13] = frc[sd].l.x; x0[14] = frc[sd].l.y; x0[15] = frc[sd].l.z;
-            sfor<0, 16>([&](auto I) { x0[I] = bl ? x0[I] : 0.f; sfx[I] = x0[I]; });
-            sfor<0, 16>([&](auto I) { two[I] = x0[I] + dpp<0x101>(x0[I]); });
-            sfor<0, 16>([&](auto I) { sfx[I] += dpp<0x101>(sfx[I]); });
-            sfor<0, 16>([&](auto I) { sfx[I] += dpp<0x102>(sfx[I]); });
-            sfor<0, 16>([&](auto I) { sfx[I] += dpp<0x104>(sfx[I]); });
-            sfor<0, 16>([&](auto I) { sfx[I] += dpp<0x108>(sfx[I]); });
-            sfor<0, 16>([&](auto I) { float r = leafb ? x0[I] : sfx[I]; r = crank ? two[I] : r; x0[I] = r; });
-            crb[sd] = SI{x0[0], {x0[1], x0[2], x0[3]}, {x0[4], x0[5], x0[6], x0[7], x0[8], x0[9]}};
-            frc[sd].a = {x0[10], x0[11], x0[12]}; frc[sd].l = {x0[13], x0[14], x0[15]};
+        // sixteen pairs of suffix sums in two batches of eight, each stage by stage (one sum after the other is a chain of dependent DPP adds with hazard nops; all
+        // sixteen at once keep 96 registers live and push the non-inlined stage past the callee-saved VGPRs it can park in AGPRs)
+        f2 x0[16];
+        x0[0] = crb.m; x0[1] = crb.h.x; x0[2] = crb.h.y; x0[3] = crb.h.z;
+        sfor<0, 6>([&](auto K) { x0[4 + K] = crb.I[K]; });
+        x0[10] = frc.a.x; x0[11] = frc.a.y; x0[12] = frc.a.z; x0[13] = frc.l.x; x0[14] = frc.l.y; x0[15] = frc.l.z;
+        sfor<0, 2>([&](auto Bt) {
+            constexpr int b0 = 8 * Bt;
+            f2 sfx[8], two[8];
+            sfor<0, 8>([&](auto I) { sfx[I].x = x0[b0 + I].x + dpp<0x101>(x0[b0 + I].x); sfx[I].y = x0[b0 + I].y + dpp<0x101>(x0[b0 + I].y); two[I] = sfx[I]; });
+            sfor<0, 8>([&](auto I) { sfx[I].x += dpp<0x102>(sfx[I].x); sfx[I].y += dpp<0x102>(sfx[I].y); });
+            sfor<0, 8>([&](auto I) { sfx[I].x += dpp<0x104>(sfx[I].x); sfx[I].y += dpp<0x104>(sfx[I].y); });
+            sfor<0, 8>([&](auto I) { sfx[I].x += dpp<0x108>(sfx[I].x); sfx[I].y += dpp<0x108>(sfx[I].y); });
+            sfor<0, 8>([&](auto I) { x0[b0 + I] = sel2(crank, two[I], sel2(leafb, x0[b0 + I], sfx[I])); });
+            if constexpr (Bt == 0) __builtin_amdgcn_sched_barrier(0);
         });
-    }
-#else
-    // (a rolled, branch-free loop: a lane past its last descendant re-reads its own record with weight 0; both legs in one iteration)
-    _Pragma("unroll 1") for (int i = 1; i <= 11; ++i) {
-        const bool on = i <= ndesc;
-        const float w = on ? 1.f : 0.f;
-        const int di = on ? i : 0;
-        sfor<0, 2>([&](auto Sd) {
-            constexpr int sd = Sd;
-            const float* p = xb + XB_SZ * (body[sd] + di);
-            crb[sd].m += w * p[0]; crb[sd].h = crb[sd].h + V3{p[1], p[2], p[3]} * w;
-            sfor<0, 6>([&](auto K) { crb[sd].I[K] += w * p[4 + K]; });
-            frc[sd].a = frc[sd].a + V3{p[10], p[11], p[12]} * w; frc[sd].l = frc[sd].l + V3{p[13], p[14], p[15]} * w;
-        });
-    }
-#endif
-    wsync();
-    sfor<0, 2>([&](auto Sd) {
-        constexpr int sd = Sd;
-        {
-            float* p = xb + XB_SZ * xbody[sd];
-            p[0] = crb[sd].m; p[1] = crb[sd].h.x; p[2] = crb[sd].h.y; p[3] = crb[sd].h.z;
-            sfor<0, 6>([&](auto K) { p[4 + K] = crb[sd].I[K]; });
-            p[10] = frc[sd].a.x; p[11] = frc[sd].a.y; p[12] = frc[sd].a.z; p[13] = frc[sd].l.x; p[14] = frc[sd].l.y; p[15] = frc[sd].l.z;
-            if constexpr (!QPOS0) {      // the body's COM relative to o: where an external wrench on this body acts (mjData.xfrc_applied, below)
-                const V3 cr = (pos[sd] - o) + mul(mat[sd], ipos[sd]);
-                p[16] = cr.x; p[17] = cr.y; p[18] = cr.z;
-            }
+        // the composite record: pairs are adjacent words, 128-bit stores
+        float* p = xb + xrec;
+        sfor<0, 16>([&](auto I) { p[2 * I] = x0[I].x; p[2 * I + 1] = x0[I].y; });
+        if constexpr (!QPOS0) {      // the body's COM relative to o: where an external wrench on this body acts (mjData.xfrc_applied, below)
+            const V3p cr = (pos - lift(o)) + mul(mat, ipos);
+            p[32] = cr.x.x; p[33] = cr.x.y; p[34] = cr.y.x; p[35] = cr.y.y; p[36] = cr.z.x; p[37] = cr.z.y;
         }
-    });
+    }
     wsync();
     PROF2(17);
-    {   // pelvis composite = own + the two hip-roll subtrees
+    {   // pelvis composite = own + the two hip-roll subtrees (record 0, both slots)
         sfor<0, 2>([&](auto Sd) {
-            const float* p = xb + XB_SZ * (2 + 12 * Sd);
-            pcrb.m += p[0]; pcrb.h = pcrb.h + V3{p[1], p[2], p[3]};
-            sfor<0, 6>([&](auto K) { pcrb.I[K] += p[4 + K]; });
-            pfrc.a = pfrc.a + V3{p[10], p[11], p[12]}; pfrc.l = pfrc.l + V3{p[13], p[14], p[15]};
+            const float* p = xb + Sd;
+            pcrb.m += p[0]; pcrb.h = pcrb.h + V3{p[2], p[4], p[6]};
+            sfor<0, 6>([&](auto K) { pcrb.I[K] += p[8 + 2 * K]; });
+            pfrc.a = pfrc.a + V3{p[20], p[22], p[24]}; pfrc.l = pfrc.l + V3{p[26], p[28], p[30]};
         });
     }
     // ---- collision geoms the constraint stage does not instantiate (pelvis sphere cassie.xml:87, hip-pitch capsules :101,164): only
@@ -477,117 +370,106 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         static_assert(ct_geom_body[8] == 1 && ct_geom_body[6] == 4 && ct_geom_body[7] == 16, "pelvis sphere, hip-pitch capsules");
         // (branch-free: every lane evaluates both tests on its own bodies, lane 0 keeps the sphere result and lane 2 = hip pitch the capsule result)
         const float hitp = dot(o + mul(pmat, cv3<8>(ct_geom_pos)) - p0, fn) - ct_geom_radius[8] < 0.f ? 1.f : 0.f;
-        float hitc = 0.f;
-        sfor<0, 2>([&](auto Sd) {
-            constexpr int sd = Sd;
-            const V3 c = pos[sd] + mul(mat[sd], cv3<6 + sd>(ct_geom_pos)), ax = mul(mat[sd], cv3<6 + sd>(ct_geom_axis)) * ct_geom_half[6 + sd];
-            const float d = fminf(dot(c + ax - p0, fn), dot(c - ax - p0, fn)) - ct_geom_radius[6 + sd];
-            hitc = d < 0.f ? 1.f : hitc;
-        });
+        constexpr V3 gp0 = cv3<6>(ct_geom_pos), gp1 = cv3<7>(ct_geom_pos), ga0 = cv3<6>(ct_geom_axis), ga1 = cv3<7>(ct_geom_axis);
+        const V3p c = pos + mul(mat, V3p{f2{gp0.x, gp1.x}, f2{gp0.y, gp1.y}, f2{gp0.z, gp1.z}});
+        const V3p ax = mul(mat, V3p{f2{ga0.x, ga1.x}, f2{ga0.y, ga1.y}, f2{ga0.z, ga1.z}}) * f2{ct_geom_half[6], ct_geom_half[7]};
+        const f2 da = dot(fn, c + ax - lift(p0)), db = dot(fn, c - ax - lift(p0));
+        const float d0 = fminf(da.x, db.x) - ct_geom_radius[6], d1 = fminf(da.y, db.y) - ct_geom_radius[7];
+        const float hitc = (d0 < 0.f || d1 < 0.f) ? 1.f : 0.f;
         int ho = WK_DUMMY; ho = l == 0 ? WK_MISC + 4 : ho; ho = l == 2 ? WK_MISC + 5 : ho;
         S.W(ho) = l == 0 ? hitp : hitc;
     }
     // ---- anchor points, capsule ends, foot pose (body lanes that own them)
-    sfor<0, 2>([&](auto Sd) {
-        constexpr int sd = Sd, base = WK_PTS + 30 * sd;
-        auto put = [&](int off, V3 p) { S.W(off) = p.x; S.W(off + 1) = p.y; S.W(off + 2) = p.z; };
-        auto cap = [&](int off, V3 cpos, V3 cax, float half) {
-            const V3 c = pos[sd] + mul(mat[sd], cpos), ax = mul(mat[sd], cax) * half;
-            put(off, c + ax); put(off + 3, c - ax);
+    {
+        auto put2 = [&](int off, V3p p) {      // leg slot sd's point at off + 30 sd
+            S.W(off) = p.x.x; S.W(off + 1) = p.y.x; S.W(off + 2) = p.z.x; S.W(off + 30) = p.x.y; S.W(off + 31) = p.y.y; S.W(off + 32) = p.z.y;
         };
+        constexpr int base = WK_PTS;
         if constexpr (QPOS0) {      // world COM of the constraint bodies, slot order of c2::cslot: achilles, heel-spring, plantar-rod, foot, tarsus, shin
             const int cs = l == 3 ? 0 : l == 8 ? 1 : l == 10 ? 2 : l == 11 ? 3 : l == 7 ? 4 : l == 6 ? 5 : -1;
-            if (cs >= 0) put(base + 3 * cs, pos[sd] + mul(mat[sd], ipos[sd]));
-            return;
-        }
+            if (cs >= 0) put2(base + 3 * cs, pos + mul(mat, ipos));
+        } else {
         static_assert(ct_eq_body1[0] == 12 && ct_eq_body2[0] == 13 && ct_eq_body1[1] == 5 && ct_eq_body2[1] == 10, "connect bodies");
         static_assert(ct_geom_body[0] == 13 && ct_geom_body[2] == 9 && ct_geom_body[4] == 8, "capsule bodies");
+        auto pairc = [](V3 a, V3 b) { return V3p{f2{a.x, b.x}, f2{a.y, b.y}, f2{a.z, b.z}}; };
         // Branch-free (round 3; the six `if (l == ..)` blocks per leg were six exec-mask regions each): every lane transforms ONE anchor and ONE capsule with
         // constants picked by select chains and stores them to its slots, or to the dummy words when it owns none.
         {   // connect anchors: plantar rod (10) eq 0 anchor 1, foot (11) eq 0 anchor 2, achilles rod (3) eq 1 anchor 1, heel spring (8) eq 1 anchor 2
-            constexpr V3 a10 = cv3<2 * sd>(ct_eq_anchor1), a11 = cv3<2 * sd>(ct_eq_anchor2), a3 = cv3<2 * sd + 1>(ct_eq_anchor1), a8 = cv3<2 * sd + 1>(ct_eq_anchor2);
-            V3 ap = a10; int ao = base + 0;
-            ap.x = l == 11 ? a11.x : ap.x; ap.y = l == 11 ? a11.y : ap.y; ap.z = l == 11 ? a11.z : ap.z; ao = l == 11 ? base + 3 : ao;
-            ap.x = l == 3 ? a3.x : ap.x; ap.y = l == 3 ? a3.y : ap.y; ap.z = l == 3 ? a3.z : ap.z; ao = l == 3 ? base + 6 : ao;
-            ap.x = l == 8 ? a8.x : ap.x; ap.y = l == 8 ? a8.y : ap.y; ap.z = l == 8 ? a8.z : ap.z; ao = l == 8 ? base + 9 : ao;
+            const V3p a10 = pairc(cv3<0>(ct_eq_anchor1), cv3<2>(ct_eq_anchor1)), a11 = pairc(cv3<0>(ct_eq_anchor2), cv3<2>(ct_eq_anchor2)),
+                      a3 = pairc(cv3<1>(ct_eq_anchor1), cv3<3>(ct_eq_anchor1)), a8 = pairc(cv3<1>(ct_eq_anchor2), cv3<3>(ct_eq_anchor2));
+            V3p ap = a10; int ao = base + 0;
+            ap = sel2(l == 11, a11, ap); ao = l == 11 ? base + 3 : ao;
+            ap = sel2(l == 3, a3, ap); ao = l == 3 ? base + 6 : ao;
+            ap = sel2(l == 8, a8, ap); ao = l == 8 ? base + 9 : ao;
             const bool has = l == 10 || l == 11 || l == 3 || l == 8;
-            put(has ? ao : WK_DUMMY, pos[sd] + mul(mat[sd], ap));
+            put2(has ? ao : WK_DUMMY, pos + mul(mat, ap));
         }
         {   // capsules: foot (11), tarsus (7), shin (6)
-            constexpr V3 p11 = cv3<0 + sd>(ct_geom_pos), x11 = cv3<0 + sd>(ct_geom_axis), p7 = cv3<2 + sd>(ct_geom_pos), x7 = cv3<2 + sd>(ct_geom_axis),
-                         p6 = cv3<4 + sd>(ct_geom_pos), x6 = cv3<4 + sd>(ct_geom_axis);
-            V3 cp = p11, cx = x11; float ch = ct_geom_half[0 + sd]; int co = base + 12;
-            cp.x = l == 7 ? p7.x : cp.x; cp.y = l == 7 ? p7.y : cp.y; cp.z = l == 7 ? p7.z : cp.z;
-            cx.x = l == 7 ? x7.x : cx.x; cx.y = l == 7 ? x7.y : cx.y; cx.z = l == 7 ? x7.z : cx.z; ch = l == 7 ? ct_geom_half[2 + sd] : ch; co = l == 7 ? base + 18 : co;
-            cp.x = l == 6 ? p6.x : cp.x; cp.y = l == 6 ? p6.y : cp.y; cp.z = l == 6 ? p6.z : cp.z;
-            cx.x = l == 6 ? x6.x : cx.x; cx.y = l == 6 ? x6.y : cx.y; cx.z = l == 6 ? x6.z : cx.z; ch = l == 6 ? ct_geom_half[4 + sd] : ch; co = l == 6 ? base + 24 : co;
+            const V3p p11 = pairc(cv3<0>(ct_geom_pos), cv3<1>(ct_geom_pos)), x11 = pairc(cv3<0>(ct_geom_axis), cv3<1>(ct_geom_axis)),
+                      p7 = pairc(cv3<2>(ct_geom_pos), cv3<3>(ct_geom_pos)), x7 = pairc(cv3<2>(ct_geom_axis), cv3<3>(ct_geom_axis)),
+                      p6 = pairc(cv3<4>(ct_geom_pos), cv3<5>(ct_geom_pos)), x6 = pairc(cv3<4>(ct_geom_axis), cv3<5>(ct_geom_axis));
+            V3p cp = p11, cx = x11; f2 ch = {ct_geom_half[0], ct_geom_half[1]}; int co = base + 12;
+            cp = sel2(l == 7, p7, cp); cx = sel2(l == 7, x7, cx); ch = sel2(l == 7, f2{ct_geom_half[2], ct_geom_half[3]}, ch); co = l == 7 ? base + 18 : co;
+            cp = sel2(l == 6, p6, cp); cx = sel2(l == 6, x6, cx); ch = sel2(l == 6, f2{ct_geom_half[4], ct_geom_half[5]}, ch); co = l == 6 ? base + 24 : co;
             const bool has = l == 11 || l == 7 || l == 6;
-            const V3 c = pos[sd] + mul(mat[sd], cp), ax = mul(mat[sd], cx) * ch;
-            put(has ? co : WK_DUMMY, c + ax); put(has ? co + 3 : WK_DUMMY, c - ax);
+            const V3p c = pos + mul(mat, cp), ax = mul(mat, cx) * ch;
+            put2(has ? co : WK_DUMMY, c + ax); put2(has ? co + 3 : WK_DUMMY, c - ax);
         }
-    });
+        }
+    }
     PROF2(18);
     // ---- mass-matrix rows and bias forces, dof lanes: k = 0..12 -> leg dof k of both legs; 13..15 -> pelvis dofs (l-13, l-10)
-#if APX_CRBA_DPP
-    SV cdv[2], fv[2]; int madrv[2];
-#endif
-    sfor<0, 2>([&](auto Sd) {
-        constexpr int sd = Sd;
-        const int d = l < 13 ? 6 + 13 * sd + l : (l - 13) + 3 * sd;
-        const int db = l < 13 ? 2 + 12 * sd + (l == 12 ? 11 : nibble(TD_BODY, l)) : 1;
-        SI c; SV fsub;
+    SVp cdv, fv; int madrv[2];
+    {
+        const bool leg = l < 13;
+        const int d0 = leg ? 6 + l : l - 13, d1 = leg ? 19 + l : l - 10;
+        const int dbl = l == 12 ? 11 : nibble(TD_BODY, leg ? l : 0);      // leg-local body of the lane's dof
+        SIp c; SVp fsub;
         {   // (selects, not a branch around a struct copy: the copy form kept the pelvis composite in a 40-byte stack object = scratch.  The loads are
-            // pinned by an empty asm: clang otherwise predicates each of the 16 loads on `leg`, one exec-mask region per word)
-            const bool leg = l < 13;
-            const float* p = xb + XB_SZ * db;
-            float w[16];
-            sfor<0, 16>([&](auto K) { w[K] = p[K]; });
+            // pinned by an empty asm: clang otherwise predicates each of the loads on `leg`, one exec-mask region per word)
+            const float* p = xb + XB_SZ * dbl;
+            f2 w[16];
+            sfor<0, 16>([&](auto K) { w[K] = f2{p[2 * K], p[2 * K + 1]}; });
             asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]), "+v"(w[10]),
                          "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]));
-            c.m = leg ? w[0] : pcrb.m; c.h = {leg ? w[1] : pcrb.h.x, leg ? w[2] : pcrb.h.y, leg ? w[3] : pcrb.h.z};
-            sfor<0, 6>([&](auto K) { c.I[K] = leg ? w[4 + K] : pcrb.I[K]; });
-            fsub = {{leg ? w[10] : pfrc.a.x, leg ? w[11] : pfrc.a.y, leg ? w[12] : pfrc.a.z}, {leg ? w[13] : pfrc.l.x, leg ? w[14] : pfrc.l.y, leg ? w[15] : pfrc.l.z}};
+            c.m = sel2(leg, w[0], splat(pcrb.m)); c.h = {sel2(leg, w[1], splat(pcrb.h.x)), sel2(leg, w[2], splat(pcrb.h.y)), sel2(leg, w[3], splat(pcrb.h.z))};
+            sfor<0, 6>([&](auto K) { c.I[K] = sel2(leg, w[4 + K], splat(pcrb.I[K])); });
+            fsub = {{sel2(leg, w[10], splat(pfrc.a.x)), sel2(leg, w[11], splat(pfrc.a.y)), sel2(leg, w[12], splat(pfrc.a.z))},
+                    {sel2(leg, w[13], splat(pfrc.l.x)), sel2(leg, w[14], splat(pfrc.l.y)), sel2(leg, w[15], splat(pfrc.l.z))}};
         }
-        const float* cp = (const float*)&S.W(WK_CDOF + 6 * d);
-        const SV cd = {{cp[0], cp[1], cp[2]}, {cp[3], cp[4], cp[5]}};
-        const SV f = imul(c, cd);
-        const int dep = l < 13 ? (l == 12 ? 13 : nibble(TD_DEPTH, l)) : d + 1, madr = cti(CT_MADR + d);
-        S.W(WK_M + madr) = sdot(cd, f) + ctf(CT_ARM + d);
-#if APX_CRBA_DPP
+        const float* cp0 = (const float*)&S.W(WK_CDOF + 6 * d0);
+        const float* cp1 = (const float*)&S.W(WK_CDOF + 6 * d1);
+        const SVp cd = {{f2{cp0[0], cp1[0]}, f2{cp0[1], cp1[1]}, f2{cp0[2], cp1[2]}}, {f2{cp0[3], cp1[3]}, f2{cp0[4], cp1[4]}, f2{cp0[5], cp1[5]}}};
+        const SVp f = imul(c, cd);
+        const int dep0 = leg ? (l == 12 ? 13 : nibble(TD_DEPTH, l)) : d0 + 1, dep1 = leg ? dep0 : d1 + 1;
+        const int madr0 = cti(CT_MADR + d0), madr1 = cti(CT_MADR + d1);
+        {
+            const f2 dg = sdot(cd, f) + f2{ctf(CT_ARM + d0), ctf(CT_ARM + d1)};
+            S.W(WK_M + madr0) = dg.x; S.W(WK_M + madr1) = dg.y;
+        }
         // off-diagonal entries M[d][anc] = cdof_anc . f_d.  The pelvis ancestors' axes are known to every lane (unit translations, the columns of the
         // pelvis rotation about o itself), so their six entries need no operand fetch at all; the leg ancestors follow below, both legs together.
         sfor<0, 6>([&](auto Pp) {
             constexpr int p = Pp;
-            const float v = p < 3 ? (p == 0 ? f.l.x : p == 1 ? f.l.y : f.l.z) : dot(col(pmat, p < 3 ? 0 : p - 3), f.a);
-            S.W(p < dep - 1 ? WK_M + madr + dep - 1 - p : WK_DUMMY) = v;
+            f2 v;
+            if constexpr (p < 3) v = p == 0 ? f.l.x : p == 1 ? f.l.y : f.l.z; else v = dot(col(pmat, p - 3), f.a);
+            S.W(p < dep0 - 1 ? WK_M + madr0 + dep0 - 1 - p : WK_DUMMY) = v.x;
+            S.W(p < dep1 - 1 ? WK_M + madr1 + dep1 - 1 - p : WK_DUMMY) = v.y;
         });
-        cdv[sd] = cd; fv[sd] = f; madrv[sd] = madr;
-#else
-        int cur = l;                                                  // walk the ancestor chain: leg dofs first, then pelvis dofs 5..0
-        sfor<1, 14>([&](auto An) {      // branch-free: inactive levels read dof 0's axis and store to the env's dummy word
-            constexpr int a = An;
-            if constexpr (APX_CRBA_SB > 0 && a % (APX_CRBA_SB > 0 ? APX_CRBA_SB : 1) == 1) __builtin_amdgcn_sched_barrier(0);
-            const bool on = a < dep, inleg = a < dep - 6;
-            const int nxt = cur == 12 ? 8 : nibble(TD_PDOF, cur < 13 ? cur : 0);
-            cur = (on && inleg) ? nxt : cur;
-            const int ad = !on ? 0 : inleg ? 6 + 13 * sd + cur : dep - 1 - a;
-            const float* ap = (const float*)&S.W(WK_CDOF + 6 * ad);
-            S.W(on ? WK_M + madr + a : WK_DUMMY) = sdot(SV{{ap[0], ap[1], ap[2]}, {ap[3], ap[4], ap[5]}}, f);
-        });
-#endif
+        cdv = cd; fv = f; madrv[0] = madr0; madrv[1] = madr1;
         // qfrc_smooth = passive - bias + actuation
         const int k = l;       // leg-local dof
-        float fs = -S(F_DAMP + d) * S(F_QVEL + d) - sdot(cd, fsub);
+        f2 fs = -(f2{S(F_DAMP + d0), S(F_DAMP + d1)} * f2{S(F_QVEL + d0), S(F_QVEL + d1)}) - sdot(cd, fsub);
         // (branch-free: every lane reads, the coefficient selects)
-        fs -= (l == 7 ? ct_jnt_stiffness[9] : 0.f) * qp(ct_jnt_qposadr[9] + 14 * sd);            // shin spring
-        fs -= (l == 9 ? ct_jnt_stiffness[11] : 0.f) * qp(ct_jnt_qposadr[11] + 14 * sd);          // heel spring
+        fs -= qp2(ct_jnt_qposadr[9]) * (l == 7 ? ct_jnt_stiffness[9] : 0.f);            // shin spring
+        fs -= qp2(ct_jnt_qposadr[11]) * (l == 9 ? ct_jnt_stiffness[11] : 0.f);          // heel spring
         static_assert(ct_jnt_stiffness[20] == ct_jnt_stiffness[9] && ct_jnt_stiffness[22] == ct_jnt_stiffness[11] && ct_jnt_qposadr[20] == ct_jnt_qposadr[9] + 14, "springs");
         {   // actuated dofs: hip roll, yaw, pitch (k = 0, 1, 2), knee (6), foot (12); the other lanes read drive 0 with gear 0
             int u = 0; u = k == 1 ? 1 : u; u = k == 2 ? 2 : u; u = k == 6 ? 3 : u; u = k == 12 ? 4 : u;
             const bool act = ((0x1047u >> k) & 1u) != 0u;
-            const int ua = u + 5 * sd;
-            const float cmax = ctf(CT_CMAX + ua), g = act ? ctf(CT_GEAR + ua) : 0.f;
-            fs += g * fminf(fmaxf(S.W(WK_CTRL + ua), -cmax), cmax);
+            const f2 cmax = {ctf(CT_CMAX + u), ctf(CT_CMAX + u + 5)}, g = f2{ctf(CT_GEAR + u), ctf(CT_GEAR + u + 5)} * (act ? 1.f : 0.f);
+            const f2 ct = {S.W(WK_CTRL + u), S.W(WK_CTRL + u + 5)};
+            fs += g * f2{fminf(fmaxf(ct.x, -cmax.x), cmax.x), fminf(fmaxf(ct.y, -cmax.y), cmax.y)};
         }
         if constexpr (!QPOS0) {
             // external wrench (one row of mjData.xfrc_applied: body I_XBODY, applied at that body's COM): J^T (f, tau) on the dofs of the body's ancestor
@@ -597,42 +479,50 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             const bool xleg = xbd >= 2;
             const int xsd = xbd >= 14 ? 1 : 0, xlb = xbd - 2 - 12 * xsd;
             const V3 xf = {S(F_XFRC), S(F_XFRC + 1), S(F_XFRC + 2)}, xt = {S(F_XFRC + 3), S(F_XFRC + 4), S(F_XFRC + 5)};
-            const float* xr = xb + XB_SZ * (xleg ? xbd : 2) + 16;
+            const float* xr = xb + XB_SZ * (xleg ? xlb : 0) + 32 + xsd;
             const V3 rpp = mul(pmat, V3{cm_body_ipos[3], cm_body_ipos[4], cm_body_ipos[5]});      // pelvis: xipos - o
-            const V3 rp = {xleg ? xr[0] : rpp.x, xleg ? xr[1] : rpp.y, xleg ? xr[2] : rpp.z};
-            const int dbl = l == 12 ? 11 : nibble(TD_BODY, l < 13 ? l : 0), dnd = nibble(TB_NDESC, dbl);
-            const bool hit = l >= 13 || (xleg && xsd == sd && dbl <= xlb && xlb <= dbl + dnd);
-            fs += (hit ? 1.f : 0.f) * (dot(cd.a, xt + cross(rp, xf)) + dot(cd.l, xf));
+            const V3 rp = {xleg ? xr[0] : rpp.x, xleg ? xr[2] : rpp.y, xleg ? xr[4] : rpp.z};
+            const int dnd = nibble(TB_NDESC, dbl);
+            const bool inchain = xleg && dbl <= xlb && xlb <= dbl + dnd;
+            const f2 hit = {(l >= 13 || (inchain && xsd == 0)) ? 1.f : 0.f, (l >= 13 || (inchain && xsd == 1)) ? 1.f : 0.f};
+            fs += hit * (dot(xt + cross(rp, xf), cd.a) + dot(xf, cd.l));
         }
-        S.W(WK_SMOOTH + d) = fs;
-    });
-#if APX_CRBA_DPP
+        S.W(WK_SMOOTH + d0) = fs.x; S.W(WK_SMOOTH + d1) = fs.y;
+    }
     // leg ancestors: a UNIFORM loop over the nine leg dofs that have descendants (hip roll / yaw / pitch, the first two achilles-rod axes, knee, shin,
-    // tarsus, foot crank).  Lane j's axis reaches the row by six row broadcasts, every lane forms cdof_j . f_own, and a per-lane level table says where
-    // (or whether: level 0 = not an ancestor, the store goes to the dummy word) the entry belongs in the ancestor-chain layout.  Round 2 walked the
-    // chain per lane instead: 13 levels x (parent lookup, 6 LDS reads at lane-dependent addresses, dot, store) per leg.
+    // tarsus, foot crank).  Lane j's axis reaches the row as the DPP row-broadcast SOURCE of the multiply-adds of cdof_j . f_own (v_mul_f32_dpp + 5 v_fmac_f32_dpp per
+    // slot: rounds 3-4 issued six v_mov_b32_dpp and six v_fma per slot), and a per-lane level table says where (or whether: level 0 = not an ancestor, the store goes
+    // to the dummy word) the entry belongs in the ancestor-chain layout.
     {
         constexpr int ANC[9] = {0, 1, 2, 3, 4, 6, 7, 8, 10};
         const int l4 = 4 * l;
+        float ca[2][6], fa[2][6];
+        sfor<0, 2>([&](auto Sd) {
+            constexpr int sd = Sd;
+            ca[sd][0] = cdv.a.x[sd]; ca[sd][1] = cdv.a.y[sd]; ca[sd][2] = cdv.a.z[sd]; ca[sd][3] = cdv.l.x[sd]; ca[sd][4] = cdv.l.y[sd]; ca[sd][5] = cdv.l.z[sd];
+            fa[sd][0] = fv.a.x[sd]; fa[sd][1] = fv.a.y[sd]; fa[sd][2] = fv.a.z[sd]; fa[sd][3] = fv.l.x[sd]; fa[sd][4] = fv.l.y[sd]; fa[sd][5] = fv.l.z[sd];
+        });
+        // the axes are read through DPP by inline asm the hazard recogniser cannot see: no compiler-generated definition right in front of the first read
+        asm volatile("s_nop 1" : "+v"(ca[0][0]), "+v"(ca[0][1]), "+v"(ca[0][2]), "+v"(ca[0][3]), "+v"(ca[0][4]), "+v"(ca[0][5]),
+                                 "+v"(ca[1][0]), "+v"(ca[1][1]), "+v"(ca[1][2]), "+v"(ca[1][3]), "+v"(ca[1][4]), "+v"(ca[1][5]));
         sfor<0, 9>([&](auto Jn) {
             constexpr int j = ANC[Jn];
             constexpr unsigned long long T = crba_level_table(j);
             const int a = (int)((T >> l4) & 15ull);
             sfor<0, 2>([&](auto Sd) {
                 constexpr int sd = Sd;
-                const SV aj = {{dpp<0x150 + j>(cdv[sd].a.x), dpp<0x150 + j>(cdv[sd].a.y), dpp<0x150 + j>(cdv[sd].a.z)},
-                               {dpp<0x150 + j>(cdv[sd].l.x), dpp<0x150 + j>(cdv[sd].l.y), dpp<0x150 + j>(cdv[sd].l.z)}};
-                S.W(a ? WK_M + madrv[sd] + a : WK_DUMMY) = sdot(aj, fv[sd]);
+                float v = mul_bcast<j>(ca[sd][0], fa[sd][0]);
+                sfor<1, 6>([&](auto K) { fmac_bcast<j>(v, ca[sd][K], fa[sd][K]); });
+                S.W(a ? WK_M + madrv[sd] + a : WK_DUMMY) = v;
             });
         });
     }
-#endif
     PROF2(19);
     // ---- foot pose for the reward / foot velocity (cassie.py:328-331,426-427)
     if (!QPOS0 && l == 11) sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd;
-        S(F_FWD + 2 + 4 * sd) = quat[sd].w; S(F_FWD + 3 + 4 * sd) = quat[sd].x; S(F_FWD + 4 + 4 * sd) = quat[sd].y; S(F_FWD + 5 + 4 * sd) = quat[sd].z;
-        S(F_FWD + 10 + 3 * sd) = pos[sd].x; S(F_FWD + 11 + 3 * sd) = pos[sd].y; S(F_FWD + 12 + 3 * sd) = pos[sd].z - 0.0550841220316708f;
+        S(F_FWD + 2 + 4 * sd) = quat.w[sd]; S(F_FWD + 3 + 4 * sd) = quat.x[sd]; S(F_FWD + 4 + 4 * sd) = quat.y[sd]; S(F_FWD + 5 + 4 * sd) = quat.z[sd];
+        S(F_FWD + 10 + 3 * sd) = pos.x[sd]; S(F_FWD + 11 + 3 * sd) = pos.y[sd]; S(F_FWD + 12 + 3 * sd) = pos.z[sd] - 0.0550841220316708f;
     });
 }
 
@@ -666,11 +556,11 @@ struct CTab { unsigned v[CT_TOTAL]; };
 constexpr CTab make_ct() {
     CTab t{};
     auto fb = [](float x) { return __builtin_bit_cast(unsigned, x); };
-    for (int b = 2; b < 26; ++b) {
-        const int o = CT_BODY + CT_BODYSZ * (b - 2);
-        for (int k = 0; k < 3; ++k) { t.v[o + k] = fb(ct_body_pos[3 * b + k]); t.v[o + 3 + k] = fb(ct_body_ipos[3 * b + k]); }
-        for (int k = 0; k < 4; ++k) t.v[o + 6 + k] = fb(ct_body_quat[4 * b + k]);
-        for (int k = 0; k < 9; ++k) t.v[o + 10 + k] = fb(ct_body_inertia[9 * b + k]);
+    for (int b = 2; b < 26; ++b) {      // (left, right) pair layout: env_state.h ct_body_word
+        const int sd = b >= 14 ? 1 : 0, lb = b - 2 - 12 * sd;
+        for (int k = 0; k < 3; ++k) { t.v[ct_body_word(lb, sd, k)] = fb(ct_body_pos[3 * b + k]); t.v[ct_body_word(lb, sd, 3 + k)] = fb(ct_body_ipos[3 * b + k]); }
+        for (int k = 0; k < 4; ++k) t.v[ct_body_word(lb, sd, 6 + k)] = fb(ct_body_quat[4 * b + k]);
+        for (int k = 0; k < 9; ++k) t.v[ct_body_word(lb, sd, 10 + k)] = fb(ct_body_inertia[9 * b + k]);
     }
     for (int d = 0; d < 32; ++d) { t.v[CT_MADR + d] = (unsigned)ct_dof_madr[d]; t.v[CT_ARM + d] = fb(ct_dof_armature[d]); }
     for (int u = 0; u < 10; ++u) { t.v[CT_GEAR + u] = fb(ct_act_gear[u]); t.v[CT_CMAX + u] = fb(ct_act_ctrlmax[u]); }

@@ -63,11 +63,14 @@ static_assert(F_TOTAL <= L4_INT && L4_INT + I_TOTAL <= L4_WK, "LDS state region"
 // Wave-constant table behind the four env regions (one copy per single-wave workgroup, filled from HBM once per launch by ct_fill):
 // model constants that the stages index by LANE (body records, dof / actuator tables, mass-matrix index map).  Without it every such
 // read was a global load from a __device__ table inside the 2 kHz substep.  38 144 + 2 704 = 40 848 B per workgroup: four still fit a CU.
-constexpr int CT_BODY = 0 /* bodies 2..25: pos3 ipos3 quat4 inertia9 pad1 */, CT_BODYSZ = 20, CT_MADR = CT_BODY + 24 * CT_BODYSZ, CT_ARM = CT_MADR + 32,
+constexpr int CT_BODY = 0 /* leg-local bodies 0..11 as (left, right) PAIRS: pos3 ipos3 quat4 inertia9 pad1, word k of leg slot sd at 40 lb + 2 k + sd (the tree stage loads a pair as one 64-bit operand of its packed arithmetic) */,
+              CT_BODYSZ = 40, CT_MADR = CT_BODY + 12 * CT_BODYSZ, CT_ARM = CT_MADR + 32,
               CT_GEAR = CT_ARM + 32, CT_CMAX = CT_GEAR + 10, CT_MIDX = CT_CMAX + 10 /* 16 lanes x 7 words: 13 ushort offsets */, CT_TOTAL = CT_MIDX + 16 * 7;
 static_assert(CT_TOTAL == 676 && (L4_EPW * L4_ES) % 4 == 0, "wave-constant table");
 extern __shared__ __attribute__((aligned(16))) float4 apx_lds4[];   // dynamic LDS: [env regions | wave-constant table]
 __device__ __forceinline__ float ctf(int i) { return ((const lfloat*)apx_lds4)[L4_EPW * L4_ES + i]; }
+// word k of the record of leg-local body lb (body id 2 + 12 sd + lb), leg slot sd
+constexpr int ct_body_word(int lb, int sd, int k) { return CT_BODY + CT_BODYSZ * lb + 2 * k + sd; }
 __device__ __forceinline__ int cti(int i) { return ((const lint*)apx_lds4)[L4_EPW * L4_ES + i]; }
 #ifdef APX_CHECK
 // `make VARIANT=check EXTRA=-DAPX_CHECK`: every S(f) / S.W(i) / S.I(f) index is range-checked; the first violation is recorded (kind, index, env, lane) in

@@ -174,7 +174,7 @@ __device__ __forceinline__ void est_step_lane(const St& S, Rec& rec) {
     // ---------------------------------------------------------------- leg kinematics: local transforms, prefix product over the chain
     const int k = l & 7, lg = l >> 3;
     constexpr unsigned long long KB = c4::nib(2, 3, 4, 6, 8, 9, 13, 2, 0, 0, 0, 0);
-    const int b = c4::nibble(KB, k) + 12 * lg, cb = CT_BODY + CT_BODYSZ * (b - 2);
+    const int cb = ct_body_word(c4::nibble(KB, k) - 2, lg, 0);      // body id nibble + 12 lg; consecutive words of a slot are 2 apart (pair layout)
     const int aidx = k < 4 ? SO_MPOS + 5 * lg + k : (k == 4 ? SO_JPOS + 3 * lg : (k == 5 ? SO_JPOS + 3 * lg + 1 : SO_MPOS + 5 * lg + 4));
     float jref = 0.f; jref = k == 3 ? cmt::ct_jnt_ref[8] : jref; jref = k == 5 ? cmt::ct_jnt_ref[10] : jref;      // knee, tarsus
     static_assert(cmt::ct_jnt_ref[19] == cmt::ct_jnt_ref[8] && cmt::ct_jnt_ref[21] == cmt::ct_jnt_ref[10], "joint refs mirror");
@@ -182,8 +182,8 @@ __device__ __forceinline__ void est_step_lane(const St& S, Rec& rec) {
     {
         float sn, cs;
         __sincosf(0.5f * (S(F_SO + aidx) - jref), &sn, &cs);
-        q = c4::qmul(Q4{ctf(cb + 6), ctf(cb + 7), ctf(cb + 8), ctf(cb + 9)}, Q4{cs, 0.f, 0.f, sn});
-        o = {ctf(cb), ctf(cb + 1), ctf(cb + 2)};
+        q = c4::qmul(Q4{ctf(cb + 12), ctf(cb + 14), ctf(cb + 16), ctf(cb + 18)}, Q4{cs, 0.f, 0.f, sn});
+        o = {ctf(cb), ctf(cb + 2), ctf(cb + 4)};
         if (k == 7) { q = {1.f, 0.f, 0.f, 0.f}; o = {0.f, 0.f, 0.f}; }
     }
     sfor<0, 3>([&](auto Rn) {

@@ -240,6 +240,11 @@ def test_single_substep_crafted_states(dev):
         scale = np.maximum(1.0, np.abs(ref_a))
         assert np.all(np.isfinite(qa[i]))
         tol = np.full(32, 3e-2); tol[[9, 22]] = 0.25      # spin of the achilles rods about their own axis: inertia 3.8e-6, fp32 solver noise
+        # ... whose ABSOLUTE level follows the largest acceleration of the env: the rod's coupling entries M[spin][ancestor] are O(1e-9) remainders of O(1e-2) terms (inertia
+        # about the pelvis origin), times ancestor accelerations of 2.5e5 rad/s^2 in the limit cases, over 3.8e-6.  The fp32 build of the ORACLE shows 4e-5 * max|qacc| on
+        # these two dofs from the same states (tests/test_oracle_env.py::test_fp32_control_of_the_crafted_substep_tolerance, CPU suite); the round-4 kernel sat at 0.237 of
+        # the per-dof 0.25 in case 10 by luck of its rounding order.
+        scale[[9, 22]] = np.maximum(scale[[9, 22]], 4e-4 * np.abs(ref_a).max())
         assert np.all(np.abs(qa[i] - ref_a) / scale <= tol), ("case %d" % i, np.abs(qa[i] - ref_a) / scale)
         np.testing.assert_allclose(qv[i], ref_v, atol=2e-3 + 5e-4 * np.abs(ref_a).max(), rtol=2e-3, err_msg="case %d" % i)
     assert ncon_seen >= 3          # more than the two foot ends: tarsus / shin geometry took part
