@@ -756,13 +756,18 @@ __device__ __forceinline__ LaneVec mul_LT_lane(const LaneFac& F, const LaneVec& 
     return y;
 }
 
-// stage B: factorisation + qacc_smooth = M^-1 qfrc_smooth; the share of the factor that the row stage needs stays in registers (FR)
-__device__ __forceinline__ void stage_factor_lane(const St& S, FacRegs& FR) {
+// stage B: factorisation + qacc_smooth = M^-1 qfrc_smooth.  STORE = false (the substep): nothing goes back to LDS - the share of the factor that the row stage needs (FR) and
+// the whole factor for the finish stage (F) stay in registers; the compiler parks what it cannot keep across the sweeps in AGPRs (one v_accvgpr_write / _read per word,
+// where rounds 1-4 stored the factor to the ancestor-chain layout with a select + address per word and the finish stage loaded it back: 2.9 k + 1.4 k cycles per substep).
+// STORE = true (mj_setConst, setconst_rows_lane reads WK_LD / WK_DISQ through whiten_lane).
+struct FacTail { float Lc[2][13], D[2], Dp[6]; };      // what the finish stage needs of the factor beyond FacRegs: the column view, the diagonal
+template <bool STORE>
+__device__ __forceinline__ void stage_factor_lane(const St& S, FacRegs& FR, FacTail& FT) {
     const LaneIdx X = lane_idx();
     LaneFac F;
     factor_lane(S, X, 0.f, F);
     PROF2(20);
-    fac_store(S, X, F);
+    if constexpr (STORE) fac_store(S, X, F);
     PROF2(21);
     LaneVec x = vec_load(S, X, -1, WK_SMOOTH);
     FR.qv = vec_load(S, X, F_QVEL, 0); FR.qw = vec_load(S, X, F_QACCW, 0);
@@ -770,29 +775,36 @@ __device__ __forceinline__ void stage_factor_lane(const St& S, FacRegs& FR) {
     sfor<0, 2>([&](auto Sd) { x.a[Sd] *= F.invD[Sd]; });
     sfor<0, 6>([&](auto Pp) { x.p[Pp] *= F.invDp[Pp]; });
     solve_L_lane(F, x);
-    if (X.l < 13) sfor<0, 2>([&](auto Sd) { S.W(WK_QS + 6 + 13 * Sd + X.l) = x.a[Sd]; });
-    if (X.l == 0) sfor<0, 6>([&](auto Pp) { S.W(WK_QS + Pp) = x.p[Pp]; });
+    if constexpr (STORE) {
+        if (X.l < 13) sfor<0, 2>([&](auto Sd) { S.W(WK_QS + 6 + 13 * Sd + X.l) = x.a[Sd]; });
+        if (X.l == 0) sfor<0, 6>([&](auto Pp) { S.W(WK_QS + Pp) = x.p[Pp]; });
+    }
     FR.qs = x;
     sfor<0, 2>([&](auto Sd) {
         sfor<0, 13>([&](auto J) { FR.Lr[Sd][J] = F.Lr[Sd][J]; });
         sfor<0, 6>([&](auto Pp) { FR.w[Sd][Pp] = F.w[Sd][Pp]; });
         FR.disq[Sd] = rsqrtf(F.D[Sd]);
     });
-    sfor<0, 6>([&](auto Pi) { FR.disqp[Pi] = rsqrtf(F.Dp[Pi]); sfor<0, Pi>([&](auto Qi) { FR.Lp[Pi][Qi] = F.Lp[Pi][Qi]; }); });
+    sfor<0, 6>([&](auto Pi) { FR.disqp[Pi] = rsqrtf(F.Dp[Pi]); FT.Dp[Pi] = F.Dp[Pi]; sfor<0, Pi>([&](auto Qi) { FR.Lp[Pi][Qi] = F.Lp[Pi][Qi]; }); });
+    sfor<0, 2>([&](auto Sd) { FT.D[Sd] = F.D[Sd]; sfor<0, 13>([&](auto J) { FT.Lc[Sd][J] = F.Lc[Sd][J]; }); });
 }
-__device__ __forceinline__ void stage_factor_lane(const St& S) { FacRegs FR; stage_factor_lane(S, FR); }
+__device__ __forceinline__ void stage_factor_lane(const St& S) { FacRegs FR; FacTail FT; stage_factor_lane<true>(S, FR, FT); }
 
 // stage E: qacc, foot force, IMU, then (do_euler) mj_Euler with implicit joint damping:
 // (M + h D) a = qfrc_smooth + J^T f = qfrc_smooth + L^T D^1/2 z~
-__device__ __forceinline__ void stage_finish_lane(const St& S, const float* rows, bool do_euler) {
+__device__ __forceinline__ void stage_finish_lane(const St& S, const float* rows, bool do_euler, const FacTail& FT, const FacRegs& FR) {
     const LaneIdx X = lane_idx();
     const int l = X.l, lc = l < 13 ? l : 12;
-    LaneFac F;
-    fac_load(S, X, F);
-    const LaneVec z = vec_load(S, X, -1, WK_ZT), qs = vec_load(S, X, -1, WK_QS);
-    float disq[2], disqp[6];
-    sfor<0, 2>([&](auto Sd) { disq[Sd] = S.W(WK_DISQ + 6 + 13 * Sd + lc); });
-    sfor<0, 6>([&](auto Pp) { disqp[Pp] = S.W(WK_DISQ + Pp); });
+    LaneFac F;      // the first factorisation, reassembled from the registers of the factor stage (the row stage fenced FR: its copies are the live ones)
+    sfor<0, 2>([&](auto Sd) {
+        sfor<0, 13>([&](auto J) { F.Lr[Sd][J] = FR.Lr[Sd][J]; F.Lc[Sd][J] = FT.Lc[Sd][J]; });
+        sfor<0, 6>([&](auto Pp) { F.w[Sd][Pp] = FR.w[Sd][Pp]; });
+        F.D[Sd] = FT.D[Sd];
+    });
+    sfor<0, 6>([&](auto Pi) { F.Dp[Pi] = FT.Dp[Pi]; sfor<0, Pi>([&](auto Qi) { F.Lp[Pi][Qi] = FR.Lp[Pi][Qi]; }); });
+    const LaneVec z = vec_load(S, X, -1, WK_ZT);
+    const LaneVec& qs = FR.qs;
+    const float (&disq)[2] = FR.disq; const float (&disqp)[6] = FR.disqp;
     LaneVec qacc;
     sfor<0, 2>([&](auto Sd) { qacc.a[Sd] = z.a[Sd] * disq[Sd]; });
     sfor<0, 6>([&](auto Pp) { qacc.p[Pp] = z.p[Pp] * disqp[Pp]; });

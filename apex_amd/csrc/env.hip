@@ -156,9 +156,9 @@ __device__ APX_STAGE void stage1b_tree_lane(St S) {
 #ifndef APX_STAGE_FACTOR
 #define APX_STAGE_FACTOR __forceinline__
 #endif
-__device__ APX_STAGE_FACTOR void stage2a_factor(St S, c4::FacRegs& FR) {
+__device__ APX_STAGE_FACTOR void stage2a_factor(St S, c4::FacRegs& FR, c4::FacTail& F) {
     PROF_START();
-    c4::stage_factor_lane(S, FR);
+    c4::stage_factor_lane<false>(S, FR, F);
     PROF(2);
 }
 template <bool HF>
@@ -169,9 +169,9 @@ __device__ __forceinline__ void stage3_rows_pgs_lane(St S, c4::FacRegs& FR, cons
 }
 // inlined like the rows / PGS stage: as a function it needs 36 callee-saved VGPRs, i.e. 36 scratch stores + 36 loads per lane per
 // substep (9 KB per wave-substep), several times the algorithmic HBM traffic of the whole kernel
-__device__ __forceinline__ void stage4_finish(St S, int mode) {
+__device__ __forceinline__ void stage4_finish(St S, int mode, const c4::FacTail& F, const c4::FacRegs& FR) {
     PROF_START();
-    c4::stage_finish_lane(S, rows4(), mode != 0);
+    c4::stage_finish_lane(S, rows4(), mode != 0, F, FR);
     PROF(4);
 }
 // mj_setConst (sim.set_const after dynamics randomisation), lane-parallel: tree at qpos0 -> factor -> |y~|^2 of unit rows
@@ -195,11 +195,12 @@ __device__ __forceinline__ void sim_step_pd(const St& S, const Cfg& cfg, int mod
     stage1b_tree_lane(S);
     c4::wsync();
     c4::FacRegs FR;                    // the share of the factor that the row stage reads, in registers across the stage boundary
-    stage2a_factor(S, FR);
+    c4::FacTail F;                     // ... and the rest of the factor for the finish stage (parked in AGPRs across the sweeps by the register allocator)
+    stage2a_factor(S, FR, F);
     c4::wsync();
     stage3_rows_pgs_lane<HF>(S, FR, cfg);
     c4::wsync();
-    stage4_finish(S, mode);
+    stage4_finish(S, mode, F, FR);
     c4::wsync();
 #ifdef APX_PROF
     if (threadIdx.x == 0 && blockIdx.x == 0) c4::g_prof_acc[8] += clock64() - t0__;
