@@ -537,11 +537,16 @@ constexpr bool leg_anc(int k, int j) {       // is leg dof j a proper ancestor o
     return false;
 }
 struct MIdx { unsigned short v[16 * 13]; };
-constexpr MIdx make_midx() {            // offset of M[k][j] inside a leg's block of the ancestor-chain layout, 0xFFFF = structural zero
+// A structural zero of the mass matrix is the offset of a word that HOLDS zero (round 5; it was the marker 0xFFFF, a clamped address and a select per entry and slot):
+// WK_FZERO for the left leg's block and WK_FZERO + M_LEGSZ for the right one's, i.e. the same block-relative offset MI_ZERO for both.  The two words sit in the factor
+// hand-off WK_LD (only mj_setConst stores a factor there: fac_store) and in the unused tail of WK_ZP2; factor_lane clears them before it loads.
+constexpr int WK_FZERO = WK_ZP2 + 10 - (ct_dof_madr[19] - ct_dof_madr[6]), MI_ZERO = WK_FZERO - (WK_M + ct_dof_madr[6]);
+static_assert(WK_FZERO >= WK_LD && WK_FZERO < WK_LD + NM && WK_ZP2 + 10 < WK_TOTAL && MI_ZERO > 0 && MI_ZERO < 0xFFFF, "zero words of the factor loads");
+constexpr MIdx make_midx() {            // offset of M[k][j] inside a leg's block of the ancestor-chain layout, MI_ZERO = structural zero
     MIdx t{};
     for (int k = 0; k < 16; ++k)
         for (int j = 0; j < 13; ++j) {
-            int off = 0xFFFF;
+            int off = MI_ZERO;
             if (k < 13) {
                 const int lo = k > j ? k : j, hi = k > j ? j : k;      // the entry is stored in the row of the deeper dof
                 for (int a = 0; a < ct_dof_depth[6 + lo]; ++a)
@@ -605,26 +610,26 @@ __device__ __forceinline__ LaneIdx lane_idx() {
     return x;
 }
 
-// factorise WK_M (+ hdamp * joint damping on the diagonal: mj_Euler's implicit damping)
+// factorise WK_M (DAMP: + hdamp * joint damping on the diagonal: mj_Euler's implicit damping; the lane adds it to ITS diagonal word of WK_M in place - the tree stage
+// rewrites the whole matrix every substep - so that the row loads below bring it along: a `l == J ? hd : 0` per entry was 26 selects + 26 adds per factorisation)
+template <bool DAMP>
 __device__ __forceinline__ void factor_lane(const St& S, const LaneIdx& X, float hdamp, LaneFac& F) {
     const int l = X.l;
     float R[2][13], P[2][6], dg[2];
+    S.W(WK_FZERO) = 0.f; S.W(WK_FZERO + M_LEGSZ) = 0.f;      // (every lane, same words: no exec-mask region)
+    if constexpr (DAMP) {
+        float d[2];
+        sfor<0, 2>([&](auto Sd) { d[Sd] = S.W(WK_M + M_LEG0 + M_LEGSZ * Sd + X.own) + hdamp * S(F_DAMP + 6 + 13 * Sd + (l < 13 ? l : 12)); });
+        sfor<0, 2>([&](auto Sd) { S.W(l < 13 ? WK_M + M_LEG0 + M_LEGSZ * Sd + X.own : WK_DUMMY) = d[Sd]; });
+        wsync();
+    }
     sfor<0, 2>([&](auto Sd) {
         constexpr int sd = Sd, blk = WK_M + M_LEG0 + M_LEGSZ * sd;
-        // the lane's own h * damping, loaded ONCE and unconditionally: `l == J ? hdamp * S(F_DAMP + .. + J) : 0` inside the loop put each of the 13 loads into its own
-        // exec-mask region with a full LDS wait (26 serialised round trips in the second factorisation, 2.7 k cycles per substep)
-        const float hd = hdamp * S(F_DAMP + 6 + 13 * sd + (l < 13 ? l : 12));
-        sfor<0, 13>([&](auto J) {
-            const bool ok = X.mi[J] != 0xFFFF;
-            float v = S.W(blk + (ok ? X.mi[J] : 0));            // unconditional load from a clamped address + select: no exec-mask region
-            v = ok ? v : 0.f;
-            v += l == J ? hd : 0.f;
-            R[sd][J] = v;
-        });
+        sfor<0, 13>([&](auto J) { R[sd][J] = S.W(blk + X.mi[J]); });      // a structural zero loads the zero word
         sfor<0, 6>([&](auto Pp) { const float v = S.W(blk + X.own + X.dep - 1 - Pp); P[sd][Pp] = l < 13 ? v : 0.f; });
         // the lane's own diagonal entry is carried separately (dg -= (R_l[k] / D_k) R_l[k] at every step): reading R[sd][l] back at the end
         // is a 13-way select on the lane index, which the compiler turns into a tree of divergent branches
-        dg[sd] = S.W(blk + X.own) + hd;
+        dg[sd] = S.W(blk + X.own);
     });
     // ---- legs: eliminate dof 12 .. 0 of both legs at once.  An eliminated entry is x -= t * bcast_k(x): written as v_fmac_f32 with the broadcast as its
     // DPP source operand and t negated by the source modifier (ONE instruction; the compiler's own selection is v_mov_b32_dpp + v_fma_f32 with a neg modifier, its DPP combiner does not take
@@ -669,7 +674,7 @@ __device__ __forceinline__ void factor_lane(const St& S, const LaneIdx& X, float
         sfor<0, Pi + 1>([&](auto Qi) {
             constexpr int p = Pi, q = Qi;
             float m = S.W(WK_M + ct_dof_madr[p] + (p - q));
-            if constexpr (p == q) m += hdamp * S(F_DAMP + p);
+            if constexpr (DAMP && p == q) m += hdamp * S(F_DAMP + p);
             Pm[p][q] = m - red16(F.w[0][q] * P[0][p] + F.w[1][q] * P[1][p]);
         });
     });
@@ -691,7 +696,7 @@ __device__ __forceinline__ void fac_store(const St& S, const LaneIdx& X, const L
         constexpr int sd = Sd, blk = WK_LD + M_LEG0 + M_LEGSZ * sd;
         const bool leg = l < 13;
         S.W(leg ? blk + X.own : WK_DUMMY) = F.D[sd];
-        sfor<0, 12>([&](auto J) { S.W((J < l && leg && X.mi[J] != 0xFFFF) ? blk + X.mi[J] : WK_DUMMY) = F.Lr[sd][J]; });
+        sfor<0, 12>([&](auto J) { S.W((J < l && leg && X.mi[J] != MI_ZERO) ? blk + X.mi[J] : WK_DUMMY) = F.Lr[sd][J]; });
         sfor<0, 6>([&](auto Pp) { S.W(leg ? blk + X.own + X.dep - 1 - Pp : WK_DUMMY) = F.w[sd][Pp]; });
         S.W(leg ? WK_DISQ + 6 + 13 * sd + l : WK_DUMMY) = rsqrtf(F.D[sd]);
     });
@@ -699,27 +704,6 @@ __device__ __forceinline__ void fac_store(const St& S, const LaneIdx& X, const L
         constexpr int p = Pi;
         S.W(WK_LD + ct_dof_madr[p]) = F.Dp[p]; S.W(WK_DISQ + p) = rsqrtf(F.Dp[p]);
         sfor<0, p>([&](auto Qi) { S.W(WK_LD + ct_dof_madr[p] + (p - Qi)) = F.Lp[p][Qi]; });
-    });
-}
-// ... and back (finish stage)
-__device__ __forceinline__ void fac_load(const St& S, const LaneIdx& X, LaneFac& F) {
-    const int l = X.l;
-    sfor<0, 2>([&](auto Sd) {
-        constexpr int sd = Sd, blk = WK_LD + M_LEG0 + M_LEGSZ * sd;
-        const float dv = S.W(blk + X.own);
-        F.D[sd] = l < 13 ? dv : 1.f; F.invD[sd] = rcpf(F.D[sd]);
-        sfor<0, 13>([&](auto J) {
-            const bool ok = X.mi[J] != 0xFFFF && l != J;
-            float v = S.W(blk + (ok ? X.mi[J] : 0));
-            v = ok ? v : 0.f;
-            F.Lr[sd][J] = J < l ? v : 0.f; F.Lc[sd][J] = J > l ? v : 0.f;
-        });
-        sfor<0, 6>([&](auto Pp) { const float v = S.W(blk + X.own + X.dep - 1 - Pp); F.w[sd][Pp] = l < 13 ? v : 0.f; });
-    });
-    sfor<0, 6>([&](auto Pi) {
-        constexpr int p = Pi;
-        F.Dp[p] = S.W(WK_LD + ct_dof_madr[p]); F.invDp[p] = rcpf(F.Dp[p]);
-        sfor<0, p>([&](auto Qi) { F.Lp[p][Qi] = S.W(WK_LD + ct_dof_madr[p] + (p - Qi)); });
     });
 }
 __device__ __forceinline__ LaneVec vec_load(const St& S, const LaneIdx& X, int off_state /* -1 = workspace */, int off) {
@@ -765,7 +749,7 @@ template <bool STORE>
 __device__ __forceinline__ void stage_factor_lane(const St& S, FacRegs& FR, FacTail& FT) {
     const LaneIdx X = lane_idx();
     LaneFac F;
-    factor_lane(S, X, 0.f, F);
+    factor_lane<false>(S, X, 0.f, F);
     PROF2(20);
     if constexpr (STORE) fac_store(S, X, F);
     PROF2(21);
@@ -870,7 +854,7 @@ __device__ __forceinline__ void stage_finish_lane(const St& S, const float* rows
     sfor<0, 6>([&](auto Pp) { rhs.p[Pp] += sm.p[Pp]; });
     __builtin_amdgcn_sched_barrier(0);
     PROF2(30);
-    factor_lane(S, X, DT, F);
+    factor_lane<true>(S, X, DT, F);
     PROF2(31);
     solve_LT_lane(F, rhs);
     sfor<0, 2>([&](auto Sd) { rhs.a[Sd] *= F.invD[Sd]; });
@@ -1155,30 +1139,43 @@ __device__ __forceinline__ void rows_lane(const St& S, const FacRegs& FR, LegRow
             }
         }
     });
-    // ---- uniform: first MAXC penetrating capsule ends in the order foot e0,e1, tarsus e0,e1, shin e0,e1
+    // ---- first MAXC penetrating capsule ends in the order foot e0,e1, tarsus e0,e1, shin e0,e1.  Lane-parallel (round 5): lane i < 6 tests end i, the row's six hit bits
+    // come back through a ballot, and the two selected ends are fetched from their lanes with ds_bpermute - ~30 instructions per leg where the uniform loop over the six
+    // ends (every lane computing all of them, eight selects per end to keep "the first two") took ~170.
     const V3 p0 = {ct_floor_pos[0], ct_floor_pos[1], ct_floor_pos[2]};
     int nc = 0, cmask = 0;
     static_assert(MAXC == 2, "two contact slots per leg");
-    V3 cpt0 = {0.f, 0.f, 0.f}, cpt1 = {0.f, 0.f, 0.f}, cn0 = fn, cn1 = fn; float cdist[MAXC]; int cgeo[MAXC];
-    sfor<0, MAXC>([&](auto Sl) { cdist[Sl] = 0.f; cgeo[Sl] = 0; });
-    sfor<0, 6>([&](auto I) {
-        constexpr int G = I / 2;
-        const V3 ctr = ldv3<base + 12 + 3 * I>(S);
+    V3 cpt0, cpt1, cn0 = fn, cn1 = fn; float cdist[MAXC]; int cgeo[MAXC];
+    {
+        const int ce = l < 6 ? l : 5;
+        const V3 ctr = {S.W(base + 12 + 3 * ce), S.W(base + 12 + 3 * ce + 1), S.W(base + 12 + 3 * ce + 2)};
+        float rad = ct_geom_radius[4 + LEG]; rad = ce < 4 ? ct_geom_radius[2 + LEG] : rad; rad = ce < 2 ? ct_geom_radius[0 + LEG] : rad;
         V3 sn;
-        const float dist = floor_dist_dev<HF>(hf, fn, ctr, ct_geom_radius[2 * G + LEG], sn);
+        const float dist = floor_dist_dev<HF>(hf, fn, ctr, rad, sn);
+        const V3 cp = ctr - sn * (rad + 0.5f * dist);
+        const unsigned rowsh = threadIdx.x & 48u;
+        cmask = (int)((__builtin_amdgcn_ballot_w64(l < 6 && dist < 0.f) >> rowsh) & 0x3Full);
+        const int rest = cmask & (cmask - 1), npen = __builtin_popcount(cmask);
+        const int i0 = cmask ? __builtin_ctz(cmask) : 0, i1 = rest ? __builtin_ctz(rest) : 0;
 #ifdef APX_NEG_MAXC1      /* NEGATIVE CONTROL of the parity suite (make VARIANT=maxc1 EXTRA=-DAPX_NEG_MAXC1): only ONE floor contact per leg is instantiated; the teacher-forced test must fail on it */
-        const bool hit = dist < 0.f && nc < 1;
+        nc = npen < 1 ? npen : 1;
 #else
-        const bool hit = dist < 0.f && nc < MAXC;
+        nc = npen < MAXC ? npen : MAXC;
+        over |= npen > MAXC ? SAT_CONTACTS : 0;
 #endif
-        cmask |= dist < 0.f ? (1 << I) : 0;
-        over |= (dist < 0.f && nc >= MAXC) ? SAT_CONTACTS : 0;
-        const V3 cp = ctr - sn * (ct_geom_radius[2 * G + LEG] + 0.5f * dist);
-        if (hit && nc == 0) { cpt0 = cp; cn0 = sn; }
-        if (hit && nc == 1) { cpt1 = cp; cn1 = sn; }
-        sfor<0, MAXC>([&](auto Sl) { if (hit && nc == Sl) { cdist[Sl] = dist; cgeo[Sl] = G; } });
-        nc += hit ? 1 : 0;
-    });
+        const int s0 = 4 * (int)(rowsh + i0), s1 = 4 * (int)(rowsh + i1);
+        auto f0 = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(s0, __float_as_int(v))); };
+        auto f1 = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(s1, __float_as_int(v))); };
+        const V3 a0 = {f0(cp.x), f0(cp.y), f0(cp.z)}, a1 = {f1(cp.x), f1(cp.y), f1(cp.z)};
+        const float d0 = f0(dist), d1 = f1(dist);
+        const bool h0 = nc > 0, h1 = nc > 1;
+        cpt0 = {h0 ? a0.x : 0.f, h0 ? a0.y : 0.f, h0 ? a0.z : 0.f}; cpt1 = {h1 ? a1.x : 0.f, h1 ? a1.y : 0.f, h1 ? a1.z : 0.f};
+        cdist[0] = h0 ? d0 : 0.f; cdist[1] = h1 ? d1 : 0.f; cgeo[0] = h0 ? i0 >> 1 : 0; cgeo[1] = h1 ? i1 >> 1 : 0;
+        if constexpr (HF) {
+            const V3 n0 = {f0(sn.x), f0(sn.y), f0(sn.z)}, n1 = {f1(sn.x), f1(sn.y), f1(sn.z)};
+            cn0 = {h0 ? n0.x : fn.x, h0 ? n0.y : fn.y, h0 ? n0.z : fn.z}; cn1 = {h1 ? n1.x : fn.x, h1 ? n1.y : fn.y, h1 ? n1.z : fn.z};
+        }
+    }
     // ---- this lane's row
     const bool isEq = l < 6, isLim = l == 6;
     const int E = l >= 3 ? 1 : 0, cs = l >= 10 ? 1 : 0;

@@ -818,10 +818,11 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
 
 extern "C" int apx_env_destroy(apx_env_t* e) {
     if (!e) return APX_OK;
+    if (e->side) (void)hipStreamSynchronize((hipStream_t)e->side);      // a ring refill in flight on the env's own stream still reads the state and writes the ring
     (void)hipFree(e->st); (void)hipFree(e->ist); (void)hipFree(e->wk); (void)hipFree(e->hf); (void)hipFree(e->rst); (void)hipFree(e->rst_int);
     for (int i = 0; i < e->ev_cap; ++i) (void)hipEventDestroy((hipEvent_t)e->ev[i]);
     free(e->ev);
-    if (e->side) { (void)hipStreamSynchronize((hipStream_t)e->side); (void)hipStreamDestroy((hipStream_t)e->side); }
+    if (e->side) (void)hipStreamDestroy((hipStream_t)e->side);
     if (e->ev_reset) (void)hipEventDestroy((hipEvent_t)e->ev_reset);
     if (e->ev_refill) (void)hipEventDestroy((hipEvent_t)e->ev_refill);
     delete e;
@@ -831,7 +832,14 @@ extern "C" int apx_env_destroy(apx_env_t* e) {
 // prepared resets depend on the model inputs of the forward pass (terrain, external wrench, fields written through the setters): drop them when one of those changes
 // a refill launched by the previous step writes the ring on the side stream: whatever touches the ring next on `stream` waits for it
 static int refill_join(apx_env* e, void* stream) {
-    if (e->refill_pending) { APX_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)e->ev_refill, 0)); e->refill_pending = 0; }
+    if (e->refill_pending) {
+        // a stream under graph capture cannot wait for an event recorded outside the capture: drain the refill on the host instead (it was launched by an earlier,
+        // uncaptured step; the capture then starts from a ring nobody writes)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) APX_HIP(hipEventSynchronize((hipEvent_t)e->ev_refill));
+        else APX_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)e->ev_refill, 0));
+        e->refill_pending = 0;
+    }
     return APX_OK;
 }
 static int invalidate_prepared(apx_env* e, void* stream) {
@@ -884,6 +892,7 @@ extern "C" int apx_env_prepare_resets(apx_env_t* e, void* stream) {
 extern "C" int apx_env_set_hfield(apx_env_t* e, const float* data, int nrow, int ncol, const float* size3, void* stream) {
     APX_REQUIRE(e, "env");
     APX_HIP(hipStreamSynchronize((hipStream_t)stream));           // kernels in flight still read the old field
+    if (e->refill_pending) { APX_HIP(hipEventSynchronize((hipEvent_t)e->ev_refill)); e->refill_pending = 0; }      // ... and so does a ring refill on the env's own stream
     { const int rc = invalidate_prepared(e, stream); if (rc != APX_OK) return rc; }
     (void)hipFree(e->hf); e->hf = nullptr; e->hf_nrow = e->hf_ncol = 0;
     if (!data) return APX_OK;                                     // back to the plane

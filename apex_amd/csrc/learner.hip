@@ -668,7 +668,7 @@ __device__ __forceinline__ void fused_layer(const FusedLds& L, float (*In)[FBM +
         const bool wave_on = nb * FBN + wn < N;      // a wave whose 32-column slice lies beyond N (output layer) leaves the MFMA pipe to the co-resident workgroup
         const float* wrow = W + (long)(col < N ? col : N - 1) * K + 8 * h;
         f2w rw[FPF][4];
-        const bool k_even = (K & 1) == 0;      // an odd row length (D = 25 / 55: min / phase profiles) leaves the rows 4-byte aligned only: scalar loads there
+        const bool k_even = (K & 1) == 0 && (reinterpret_cast<uintptr_t>(W) & 7) == 0;      // an odd row length (D = 25 / 55: min / phase profiles) or a block at an odd float offset (TD3's second critic inside critic_flat) leaves the rows 4-byte aligned only: scalar loads there
         auto fetch = [&](int kt, f2w (&r)[4]) {
             if (k_even) {
 #pragma unroll
@@ -723,11 +723,15 @@ __device__ __forceinline__ void fused_out_layer(const FusedLds& L, float (*In)[F
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, col = lane & 31;
     typedef float f2w __attribute__((ext_vector_type(2)));
     const float* wrow = W + (long)(col < N ? col : N - 1) * K + 8 * h;
+    const bool w_al8 = (reinterpret_cast<uintptr_t>(W) & 7) == 0 && (K & 1) == 0;
     f2w rw[KW][4];
 #pragma unroll
     for (int p = 0; p < KW; ++p)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rw[p][q] = *reinterpret_cast<const f2w*>(wrow + (w * KW + p) * GBK + 2 * q);      // (K = 256: even, 8-byte aligned rows)
+        for (int q = 0; q < 4; ++q) {      // (K = 256: even; 8-byte loads when the block itself is 8-byte aligned - TD3's second critic sits at an odd float offset of critic_flat)
+            const float* wp = wrow + (w * KW + p) * GBK + 2 * q;
+            rw[p][q] = w_al8 ? *reinterpret_cast<const f2w*>(wp) : f2w{wp[0], wp[1]};
+        }
     floatx16 acc = {0};
 #pragma unroll
     for (int p = 0; p < KW; ++p)

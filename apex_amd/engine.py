@@ -125,6 +125,8 @@ class Lstm:
         self.n = int(_lib.load().apx_lstm_param_count(D, H, L, O))
         self.params = torch.zeros(self.n, dtype=torch.float32, device=device)
         self.device = device
+        self._packed = None          # apx_lstm_step's layout of the parameters ...
+        self._packed_version = -1    # ... and the torch version counter of `params` it was made from (every in-place write bumps it)
 
     def views(self, flat=None):
         flat = self.params if flat is None else flat
@@ -169,17 +171,22 @@ class Lstm:
         n = int(lib.apx_lstm_step_pack_floats(self.D, self.H, self.L, self.O))
         if n == 0:
             raise ValueError("apx_lstm_step needs L = 2, H = 128, D <= 64, O <= 16")
-        if getattr(self, "_packed", None) is None or self._packed.numel() != n:
+        if self._packed is None or self._packed.numel() != n:
             self._packed = torch.empty(n, dtype=torch.float32, device=self.params.device)
         check(lib.apx_lstm_step_pack(_p(self.params), self.D, self.H, self.L, self.O, _p(self._packed), _stream()))
+        self._packed_version = self.params._version
         return self._packed
 
     def step(self, x, hc, obs_mean=None, obs_std=None, reset=None, noise=None, sigma=0.0, act_out=None, y_out=None):
         """One rollout step on raw observations x [B, D]: y = head(LSTM(normalise(x))), hc [L, 2, B, H] updated in place; the rows whose `reset` byte (uint8 [B]) is
-        non-zero start from a zero state; act_out (if given) = y + sigma * noise.  pack_step() must have been called after the last parameter change."""
+        non-zero start from a zero state; act_out (if given) = y + sigma * noise.  The packed copy of the parameters is refreshed here when a torch-side write changed
+        `params` since pack_step() (its version counter moved); a writer torch cannot see - the C-ABI optimiser step, a collective on the raw pointer - must call
+        pack_step() itself, as RecurrentPPO.sample does once per rollout."""
         _need_gpu(x)
         B = x.shape[0]
-        assert x.is_contiguous() and hc.is_contiguous() and x.shape[1] == self.D and self._packed is not None
+        assert x.is_contiguous() and hc.is_contiguous() and x.shape[1] == self.D
+        if self._packed is None or self._packed_version != self.params._version:
+            self.pack_step()
         y = y_out if y_out is not None else torch.empty(B, self.O, dtype=torch.float32, device=x.device)
         check(_lib.load().apx_lstm_step(_p(self._packed), self.D, self.H, self.L, self.O, _p(x), _p(obs_mean), _p(obs_std), _p(reset), _p(hc), B, _p(y),
                                         _p(act_out), _p(noise), float(sigma), _stream()))

@@ -136,7 +136,12 @@ class TD3:
         step t wait for the replay write of step t and draw all their batches first; the replay write of step t + 1 waits for those draws (a ring slot is never
         overwritten while a batch is being gathered from it)."""
         L, env = self.learner, self.env
-        load_freq = max(3, int(load_freq))      # a snapshot is written two steps before it is used: with a period >= 3 the two buffers never hold two pending snapshots
+        if int(load_freq) < 3:      # a snapshot is written two steps before it is used: with a period >= 3 the two buffers never hold two pending snapshots
+            import warnings
+            warnings.warn("td3_async: --initial_load_freq %d raised to 3 (the behaviour copy is double-buffered two lock steps ahead of its use)" % int(load_freq))
+        if getattr(self, "param_noise", False):
+            raise ValueError("td3_async: --param_noise is not supported by the asynchronous collector (the behaviour copy is a plain snapshot of the actor)")
+        load_freq = max(3, int(load_freq))
         if self.obs is None:
             self.obs = env.reset().clone()
         main = torch.cuda.current_stream(self.device)
