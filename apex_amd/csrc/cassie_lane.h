@@ -1353,7 +1353,8 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, FacRegs& FR, fl
             const unsigned bf = (S.W(WK_MISC + 4) > 0.f ? 1u : 0u) | (S.W(WK_MISC + 5) > 0.f ? 2u : 0u);
             const unsigned s1 = (unsigned)A.lmask | (unsigned)B.lmask << 8 | (unsigned)A.cmask << 16 | (unsigned)B.cmask << 22 | bf << 28;
             unsigned h = (unsigned)S.I(I_ROWSET);
-            h = (h ^ s1) * 0x9E3779B1u; h ^= h >> 15; h = (h ^ (unsigned)xmask) * 0x9E3779B1u; h ^= h >> 15;
+            const unsigned s2 = (unsigned)xmask | (unsigned)(int)S.W(WK_MISC + 6) << 16;      // leg-leg pairs | the state estimator's load switches of this substep (estimator_lane.h)
+            h = (h ^ s1) * 0x9E3779B1u; h ^= h >> 15; h = (h ^ s2) * 0x9E3779B1u; h ^= h >> 15;
             S.I(I_ROWSET) = (int)h;
         }
         S.W(WK_MISC + 0) = (float)A.nc; S.W(WK_MISC + 1) = (float)B.nc; S.W(WK_MISC + 2) = (float)A.nlim; S.W(WK_MISC + 3) = (float)B.nlim;

@@ -57,7 +57,7 @@ __device__ __forceinline__ void stage1_io_lane(St S, int mode, float* estrec) { 
     int l = threadIdx.x & 15;
     asm volatile("" : "+v"(l));      // opaque: otherwise every per-lane constant below is hoisted out of the 50-substep loop and has to be
                                      // kept (= spilled to scratch) across the constraint stage, which needs the whole register file
-    if (mode == 0) { if (l < 10) S.W(c4::WK_CTRL + l) = 0.f; PROF(0); return; }
+    if (mode == 0) { if (l < 10) S.W(c4::WK_CTRL + l) = 0.f; if (l == 0) S.W(c4::WK_MISC + 6) = 0.f; PROF(0); return; }
     est::Rec rec = est::rec_load(estrec, S.env, l);      // in flight while the encoder model runs
     const int flags = S.I(I_FLAGS);
     const bool mot = l < 10;
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_substep_kernel(float
     load_state(S, st, ist, n);
     if (action && lead) {
         for (int u = 0; u < 10; ++u) S(F_PDT + u) = action[(size_t)env * APX_ACT_DIM + u] + kOffset[u] - (cfg.dyn_rand ? S(F_MNOISE + u) : 0.f);
-        S.I(I_FLAGS) |= 16;
+        S.I(I_FLAGS) |= 16; S.I(I_ROWSET) = 0;      // (the row-set hash covers the substeps of this step_basic, like env_step's)
     }
     c4::wsync();
     for (int i = 0; i < n_sub; ++i) sim_step_pd<HF>(S, cfg, 1);

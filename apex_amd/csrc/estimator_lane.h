@@ -244,6 +244,9 @@ __device__ __forceinline__ void est_step_lane(const St& S, Rec& rec) {
         fy.x = l == 2 ? -lfy : (l == 3 ? -rfy : (l == 4 ? 0.5f : 0.f));
         fz.x = l == 2 ? -lfz : (l == 3 ? -rfz : (l == 4 ? E_M * E_G : 0.f));
     }
+    // the estimator's own discrete switches (process noise of a foot state below / above 50 N of estimated load, terrain update above 1 N): part of the row-set signature
+    // of this substep (I_ROWSET, folded by the constraint stage) - a load within fp32 round-off of 50 N flips a filter gain, which is a set difference, not round-off
+    if (l == 0) S.W(c4::WK_MISC + 6) = (float)((50.f > fl ? 1 : 0) | (50.f > fr ? 2 : 0) | (fl + fr > 1.f ? 4 : 0));
     hfilter_step(fx, l, -lfx, -rfx, fl, fr, aw.x);
     hfilter_step(fy, l, -lfy, -rfy, fl, fr, aw.y);
     zfilter_step(fz, l, -lfz, -rfz, fl, fr);

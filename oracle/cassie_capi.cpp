@@ -88,6 +88,7 @@ static int field(Env& e, const char* name, double* io, bool set) {
     }
     if (!std::strcmp(name, "enc_primed")) { if (set) { e.menc_primed = (int)io[0]; e.jenc_primed = (int)io[1]; } else { io[0] = e.menc_primed; io[1] = e.jenc_primed; } return 2; }
     if (!std::strcmp(name, "phase_add")) { if (set) { e.phase_add15 = io[0] > 1.25; e.phase_half = (int)io[1]; } else { io[0] = e.phase_add15 ? 1.5 : 1.0; io[1] = e.phase_half; } return 2; }
+    if (!std::strcmp(name, "stance_mode")) { if (set) e.cfg.stance_mode = (int)io[0]; else io[0] = e.cfg.stance_mode; return 1; }      // per-env under the phase command profile
     if (!std::strcmp(name, "episode")) { if (set) e.episode = (int)io[0]; else io[0] = e.episode; return 1; }
     if (!std::strcmp(name, "est_age")) { if (set) { e.est_age = (int)io[0]; e.cfg.est_lifetime = (int)io[1]; } else { io[0] = e.est_age; io[1] = e.cfg.est_lifetime; } return 2; }
     if (!std::strcmp(name, "est_flags")) { if (set) e.est.inited = (int)io[0]; else { io[0] = e.est.inited; io[1] = e.est.lm_iters; } return 2; }

@@ -283,6 +283,11 @@ static void set_clock_from_speed(Env& e) {   // cassie.py:556-559
 
 // CassieEnv.step_basic (cassie.py:498-521): simrate x step_sim_basic (PD targets = action + offset - encoder offsets, cassie.py:355-387),
 // time / phase bookkeeping, NO reward, termination, trackers or command resampling
+// multiplicative hash over the row-set signatures of one forward pass, like the kernel's I_ROWSET: constraint rows (rowsig[0]), leg-leg pairs | the state estimator's load switches
+static void fold_rowset(Env& e) {
+    const unsigned w[2] = {e.st.rowsig[0], e.st.rowsig[1] | (unsigned)e.est.sw << 16};
+    for (int k = 0; k < 2; ++k) { e.rowset_hash = (e.rowset_hash ^ w[k]) * 0x9E3779B1u; e.rowset_hash ^= e.rowset_hash >> 15; }
+}
 void env_step_basic(Env& e, const double* action, double* obs) {
     static const double offset[10] = {0.0045, 0.0, 0.4973, -1.1997, -1.5968, 0.0045, 0.0, 0.4973, -1.1997, -1.5968};
     static const double P[5] = {100, 100, 88, 96, 50}, D[5] = {10.0, 10.0, 8.0, 9.6, 5.0};
@@ -290,7 +295,11 @@ void env_step_basic(Env& e, const double* action, double* obs) {
         e.pd_target[u] = action[u] + offset[u] - (e.cfg.dynamics_randomization ? e.motor_noise[u] : 0.0);
         e.pd_P[u] = P[u % 5]; e.pd_D[u] = D[u % 5];
     }
-    for (int i = 0; i < e.cfg.simrate; ++i) sim_step_pd(e);
+    e.rowset_hash = 0;
+    for (int i = 0; i < e.cfg.simrate; ++i) {
+        sim_step_pd(e);
+        fold_rowset(e);      // like env_step: the parity tests bin step_basic steps by row set too
+    }
     e.time += 1; advance_phase(e);
     env_obs(e, obs);
 }
@@ -530,7 +539,7 @@ int env_step(Env& e, const double* action, double* obs, double* reward) {
     e.rowset_hash = 0;
     for (int i = 0; i < e.cfg.simrate; ++i) {
         sim_step_pd(e);
-        for (int k = 0; k < 2; ++k) { e.rowset_hash = (e.rowset_hash ^ e.st.rowsig[k]) * 0x9E3779B1u; e.rowset_hash ^= e.rowset_hash >> 15; }      // multiplicative hash over the row-set signatures, like the kernel's I_ROWSET
+        fold_rowset(e);
         double fp[6];
         foot_positions(e.st, fp);
         for (int k = 0; k < 3; ++k) { e.l_foot_vel[k] = (fp[k] - e.foot_pos_prev[k]) / 0.0005; e.r_foot_vel[k] = (fp[3 + k] - e.foot_pos_prev[3 + k]) / 0.0005; }

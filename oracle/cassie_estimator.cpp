@@ -239,6 +239,7 @@ void state_output_step(StateOutput& s, const EstSensors& in) {
         for (int i = 0; i < 25; ++i) s.zP[i] = (i % 6 == 0) ? 1e-6 : 0.0;
         s.inited = 1;
     }
+    s.sw = (50.0 > fz[0] ? 1 : 0) | (50.0 > fz[1] ? 2 : 0) | (fz[0] + fz[1] > 1.0 ? 4 : 0);
     for (int ax = 0; ax < 2; ++ax) hfilter_step(s.hx[ax], s.hP[ax], -lf[ax], -rf[ax], fz[0], fz[1], awv[ax]);
     zfilter_step(s.zx, s.zP, -lf[2], -rf[2], fz[0], fz[1]);
     // --- terrain height (0x2c70d-0x2cad7): only while the legs carry more than 1 N

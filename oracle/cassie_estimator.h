@@ -38,6 +38,7 @@ struct StateOutput {
     double foot_quat[2][4];                  // leftFoot / rightFoot .orientation (pelvis frame; the foot body's frame turned by the routine's constant offset)
     double foot_force[2][3];                 // estimated foot force, world z exact, x / y in the heading frame of the binary not reproduced (unused)
     int lm_iters;                            // Levenberg-Marquardt iterations of the most recent heel solve (diagnostics)
+    int sw;                                  // discrete switches of the most recent step: bit 0 / 1 = left / right foot load below 50 N (process noise of the foot states), bit 2 = terrain update (load > 1 N); part of the row-set signature
 };
 
 void state_output_setup(StateOutput& s);

@@ -44,14 +44,16 @@ def _floor_frame(fq):
 
 
 def oracle_to_kernel(genv, oenvs, model_params=True):
-    """set every persistent field of the HIP env (all envs) from the list of oracle envs (len == genv.n_envs)"""
-    assert len(oenvs) == genv.n_envs
-    G = lambda name: np.stack([e.get(name) for e in oenvs])
+    """set every persistent field of the HIP env (all envs) from the list of oracle envs; fewer oracle envs than kernel envs are tiled over the batch (kernel env i
+    takes oracle env i % len(oenvs): the tail of the batch stays a defined state that nobody compares)"""
+    assert 0 < len(oenvs) <= genv.n_envs
+    tile = np.arange(genv.n_envs) % len(oenvs)
+    G = lambda name: np.stack([e.get(name) for e in oenvs])[tile]
     T = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32)
     if model_params:
         for name in ("mass", "damping", "friction", "motor_noise", "joint_noise"):
             genv.set_field(name, T(G(name)))
-        genv.set_field("floor", T(np.stack([_floor_frame(e.get("floor_quat")) for e in oenvs])))
+        genv.set_field("floor", T(np.stack([_floor_frame(e.get("floor_quat")) for e in oenvs])[tile]))
         genv.set_field("set_const")                                     # invweights in fp32 from the copied masses (mj_setConst)
     for name in ("qpos", "qvel", "qacc_warm", "pd_target", "tq_fifo", "so_mpos", "so_mvel", "so_torque", "so_jpos", "so_jvel", "so_quat", "so_rotvel", "so_tvel", "so_tacc",
                  "so_height", "prev_action", "prev_torque", "jenc_x"):
@@ -61,14 +63,15 @@ def oracle_to_kernel(genv, oenvs, model_params=True):
     genv.set_field("snap", T(np.concatenate([G("snap_mpos"), G("snap_jpos"), G("snap_quat"), G("snap_gyro"), G("snap_acc")], 1)))
     genv.set_field("foot_prev", T(G("foot_pos_prev")))
     genv.set_field("foot_vel", T(np.concatenate([G("l_foot_vel"), G("r_foot_vel")], 1)))
-    cmd = np.stack([np.concatenate([e.get("speed"), e.get("side_speed"), e.get("orient_add"), e.get("swing_stance"), e.get("phaselen"), [genv.get_field("cmd")[0, 6].item()]]) for e in oenvs])
+    cmd = np.stack([np.concatenate([e.get("speed"), e.get("side_speed"), e.get("orient_add"), e.get("swing_stance"), e.get("phaselen"), e.get("stance_mode")]) for e in oenvs])[tile]
     genv.set_field("cmd", T(cmd))
-    genv.set_field("est", T(np.stack([est_record_from_oracle(e) for e in oenvs])))
+    genv.set_field("est", T(np.stack([est_record_from_oracle(e) for e in oenvs])[tile]))
     ints = genv.get_field("ints").cpu().numpy()
-    for i, e in enumerate(oenvs):
-        oi = e.get("ints"); pr = e.get("enc_primed")
+    for i in range(genv.n_envs):
+        e = oenvs[tile[i]]
+        oi = e.get("ints"); pr = e.get("enc_primed"); pa = e.get("phase_add")
         ints[i, 0:3] = oi[0:3]; ints[i, 3] = oi[5]
-        ints[i, 4] = int(pr[0]) | int(pr[1]) << 1 | int(oi[6]) << 2 | int(oi[7]) << 3 | 16
+        ints[i, 4] = int(pr[0]) | int(pr[1]) << 1 | int(oi[6]) << 2 | int(oi[7]) << 3 | 16 | int(pa[1]) << 5 | int(pa[0] > 1.25) << 6      # (half phase, phase_add = 1.5: tools/test_commands.py:86)
         ints[i, 5] = int(e.get("est_age")[0])
         ints[i, 9] = int(e.get("episode")[0])
     genv.set_field("ints", T(ints))
@@ -78,7 +81,7 @@ def oracle_to_kernel(genv, oenvs, model_params=True):
 ORACLE_STATE_FIELDS = ("mass", "damping", "friction", "floor_quat", "motor_noise", "joint_noise", "qpos", "qvel", "qacc_warm", "pd_target", "pd_P", "pd_D", "tq_fifo",
                        "menc_hist", "jenc_x", "jenc_y", "enc_primed", "snap_mpos", "snap_jpos", "snap_quat", "snap_gyro", "snap_acc", "so_mpos", "so_mvel", "so_torque", "so_jpos",
                        "so_jvel", "so_quat", "so_rotvel", "so_tvel", "so_tacc", "so_height", "est_heel", "est_hx", "est_hP", "est_zx", "est_zP", "est_terrain", "est_flags",
-                       "l_foot_vel", "r_foot_vel", "foot_pos_prev", "prev_action", "prev_torque", "speed", "side_speed", "orient_add", "swing_stance", "phase_add", "est_age", "episode")
+                       "l_foot_vel", "r_foot_vel", "foot_pos_prev", "prev_action", "prev_torque", "speed", "side_speed", "orient_add", "swing_stance", "stance_mode", "phase_add", "est_age", "episode")
 
 
 def oracle_state(e):

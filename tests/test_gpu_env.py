@@ -107,64 +107,8 @@ def test_teacher_forced_env_steps_random_actions(dev):
     assert np.all(Es.max(0) <= TF_TOL_SAME), (Es.max(0), TF_TOL_SAME)
 
 
-def test_safety_zones_vs_oracle(dev):
-    """Large hip-roll / hip-yaw / foot targets drive the joints into cassie_core_sim_step's soft zones (G10 model):
-    the delayed drive torques and the joint positions must track the oracle."""
-    genv, oenv = _mk(False, 4)
-    genv.reset(); [e.reset() for e in oenv[:8]]
-    rng = np.random.RandomState(1)
-    hit = 0
-    for t in range(3):
-        act = (rng.randn(N, 10) * 0.05).astype(np.float32)
-        act[:, [0, 1, 5, 6]] += rng.choice([-0.5, 0.5], size=(N, 4)).astype(np.float32)      # roll / yaw far past +-0.2
-        act[:, [4, 9]] += 0.9                                                                # foot past its -35 deg limit
-        obs, rew, done, _ = genv.step(torch.tensor(act, device=dev), auto_reset=False)
-        tq = genv.get_field("so_torque").cpu().numpy(); mp = genv.get_field("so_mpos").cpu().numpy()
-        for i, e in enumerate(oenv[:8]):
-            e.step(act[i].astype(np.float64))
-            np.testing.assert_allclose(mp[i], e.get("so_mpos"), atol=2e-3 * (t + 1))
-            np.testing.assert_allclose(tq[i], e.get("so_torque"), atol=1.5 * (t + 1), rtol=0.05)
-            q = e.get("so_mpos")
-            hit += int(q[0] > 0.2 or q[0] < -0.112 or abs(q[1]) > 0.234 or q[5] < -0.2 or q[5] > 0.112 or abs(q[6]) > 0.234 or q[4] > -0.761)
-    assert hit > 0            # the zones were actually reached
-
-
-def test_coupled_pitch_knee_zone_vs_oracle(dev):
-    """Deep-crouch targets drive hip pitch + knee below -135 deg: the coupled zone of cassie_core_sim_step (golden G10b)."""
-    genv, oenv = _mk(False, 9)
-    genv.reset(); [e.reset() for e in oenv[:8]]
-    rng = np.random.RandomState(3)
-    hit = 0
-    for t in range(8):
-        act = (rng.randn(N, 10) * 0.03).astype(np.float32)
-        act[:, [2, 7]] -= 1.1; act[:, [3, 8]] -= 1.3                     # pitch target -0.6, knee target -2.5
-        genv.step(torch.tensor(act, device=dev), auto_reset=False)
-        tq = genv.get_field("so_torque").cpu().numpy(); mp = genv.get_field("so_mpos").cpu().numpy()
-        for i, e in enumerate(oenv[:8]):
-            e.step(act[i].astype(np.float64))
-            np.testing.assert_allclose(mp[i], e.get("so_mpos"), atol=3e-3 * (t + 1))
-            np.testing.assert_allclose(tq[i], e.get("so_torque"), atol=2.5 * (t + 1), rtol=0.05)
-            q = e.get("so_mpos")
-            hit += int(q[2] + q[3] < -0.75 * np.pi or q[7] + q[8] < -0.75 * np.pi)
-    assert hit > 0            # the coupled zone was actually reached
-
-
-@pytest.mark.parametrize("reward,kind", [("early_clock", 1), ("max_vel_clock", 2)])
-def test_early_and_max_vel_clock_reward_vs_oracle(dev, reward, kind):
-    """--reward early_clock selects early_clock_reward (cassie.py:202-204, clock_rewards.py:119-223), --reward max_vel_clock
-    selects max_vel_clock_reward (cassie.py:223-224, clock_rewards.py:416-480)."""
-    from apex_amd.vecenv import CassieVecEnv
-    genv = CassieVecEnv(n_envs=N, dynamics_randomization=True, seed=6, reward=reward)
-    oenv = [S.OracleEnv(dyn_rand=True, seed=6, env_id=i, reward_kind=kind) for i in range(8)]
-    genv.reset(); [e.reset() for e in oenv]
-    rng = np.random.RandomState(2)
-    for t in range(4):
-        act = (rng.randn(N, 10) * 0.1).astype(np.float32)
-        _, rew, done, _ = genv.step(torch.tensor(act, device=dev), auto_reset=False)
-        rew = rew.cpu().numpy()
-        for i, e in enumerate(oenv):
-            _, r, d = e.step(act[i].astype(np.float64))
-            assert abs(rew[i] - r) < 0.02 * (t + 1), (t, i, rew[i], r)
+# (the safety-zone, coupled pitch-knee zone and early / max_vel reward comparisons of rounds 1-4 ran free with tolerances growing like (t + 1); they are scenarios of
+# test_teacher_forced_scenario now: same action generators, fixed tolerances from identical states, "the zones were actually reached" asserted there)
 
 
 def test_step_invariants_full_size(dev):
@@ -241,10 +185,10 @@ def test_single_substep_crafted_states(dev):
         assert np.all(np.isfinite(qa[i]))
         tol = np.full(32, 3e-2); tol[[9, 22]] = 0.25      # spin of the achilles rods about their own axis: inertia 3.8e-6, fp32 solver noise
         # ... whose ABSOLUTE level follows the largest acceleration of the env: the rod's coupling entries M[spin][ancestor] are O(1e-9) remainders of O(1e-2) terms (inertia
-        # about the pelvis origin), times ancestor accelerations of 2.5e5 rad/s^2 in the limit cases, over 3.8e-6.  The fp32 build of the ORACLE shows 4e-5 * max|qacc| on
-        # these two dofs from the same states (tests/test_oracle_env.py::test_fp32_control_of_the_crafted_substep_tolerance, CPU suite); the round-4 kernel sat at 0.237 of
-        # the per-dof 0.25 in case 10 by luck of its rounding order.
-        scale[[9, 22]] = np.maximum(scale[[9, 22]], 4e-4 * np.abs(ref_a).max())
+        # about the pelvis origin), times ancestor accelerations of 2.5e5 rad/s^2 in the limit cases, over 3.8e-6.  The fp32 build of the ORACLE shows 9.1e-5 * max|qacc| on
+        # these two dofs from the same states (tests/test_oracle_env.py::test_fp32_control_of_the_crafted_substep_tolerance, CPU suite): the floor below is 2.2 x that.  The
+        # round-4 kernel sat at 0.237 of the per-dof 0.25 in case 10 by luck of its rounding order; the round-5 kernel (packed tree stage) at 3e-5 * max|qacc|.
+        scale[[9, 22]] = np.maximum(scale[[9, 22]], 8e-4 * np.abs(ref_a).max())
         assert np.all(np.abs(qa[i] - ref_a) / scale <= tol), ("case %d" % i, np.abs(qa[i] - ref_a) / scale)
         np.testing.assert_allclose(qv[i], ref_v, atol=2e-3 + 5e-4 * np.abs(ref_a).max(), rtol=2e-3, err_msg="case %d" % i)
     assert ncon_seen >= 3          # more than the two foot ends: tarsus / shin geometry took part
@@ -294,35 +238,42 @@ def test_random_policy_statistics_match_oracle(dev):
 
 def test_update_speed_and_reset_for_test_vs_oracle(dev):
     """Evaluation-side API (next row f3): CassieEnv.update_speed and reset_for_test through the C ABI vs the oracle (which is
-    pinned to the reference by golden G16)."""
+    pinned to the reference by golden G16).  Both calls start from the ORACLE's state (teacher forcing, tests/state_xfer.py): what is compared is the call, not the
+    fp32-vs-fp64 drift of the steps in front of it; the steps behind reset_for_test are the scenarios eval_step / eval_step_basic of test_teacher_forced_scenario."""
+    from tests.state_xfer import oracle_to_kernel
     genv, oenv = _mk(True, 13)
-    genv.reset(); [e.reset() for e in oenv[:16]]
+    K = 16
+    genv.reset(); [e.reset() for e in oenv[:K]]
     rng = np.random.RandomState(4)
     act = (rng.randn(N, 10) * 0.1).astype(np.float32)
     for t in range(2):
-        genv.step(torch.tensor(act, device=dev), auto_reset=False)
-        [e.step(act[i].astype(np.float64)) for i, e in enumerate(oenv[:16])]
+        [e.step(act[i].astype(np.float64)) for i, e in enumerate(oenv[:K])]
+    oracle_to_kernel(genv, oenv[:K])
     # ---- update_speed: commands beyond the clip range included; phase rescale is integer work
     ns = rng.uniform(-0.8, 4.6, N).astype(np.float32); nd = rng.uniform(-0.5, 0.5, N).astype(np.float32)
+    ns[K:] = ns[np.arange(K, N) % K]; nd[K:] = nd[np.arange(K, N) % K]
     genv.update_speed(torch.tensor(ns), torch.tensor(nd))
     ints = genv.get_field("ints").cpu().numpy()
     mism = 0
-    for i, e in enumerate(oenv[:16]):
+    for i, e in enumerate(oenv[:K]):
         e.update_speed(float(ns[i]), float(nd[i]))
         mism += int(ints[i, 1] != int(e.get("ints")[1]))
     assert mism <= 1                                           # the old cycle length is fp32 state: a tie within fp32 rounding may flip
-    obs, rew, done, _ = genv.step(torch.tensor(act, device=dev), auto_reset=False)
+    acts = act[np.arange(N) % K]
+    obs, rew, done, _ = genv.step(torch.tensor(acts, device=dev), auto_reset=False)
     obs = obs.cpu().numpy()
-    for i, e in enumerate(oenv[:16]):
-        o, r, d = e.step(act[i].astype(np.float64))
+    for i, e in enumerate(oenv[:K]):
+        o, r, d = e.step(acts[i].astype(np.float64))
         np.testing.assert_allclose(obs[i, 48:50], o[48:50], atol=1e-6)                    # clipped commands
         np.testing.assert_allclose(obs[i, 46:48], o[46:48], atol=0.3 if mism else 1e-4)   # clock input sin / cos(2 pi phase / phaselen)
-    # ---- reset_for_test
+    # ---- reset_for_test, from the oracle's state again: the observation behind it is ONE settle substep away from identical states
+    oracle_to_kernel(genv, oenv[:K])
     gobs = genv.reset_for_test().cpu().numpy()
-    for i, e in enumerate(oenv[:16]):
+    grp = [slice(0, 5), slice(5, 15), slice(15, 18), slice(18, 21), slice(21, 31), slice(31, 34), slice(34, 40), slice(40, 46), slice(46, 50)]
+    for i, e in enumerate(oenv[:K]):
         o = e.reset_for_test()
-        tol = np.full(50, 2e-2 * 4); tol[21:31] = 0.3; tol[31:34] = 0.6; tol[40:46] = 0.3       # 4 env steps of fp32 vs fp64 dynamics behind it; velocities / accelerations are the noisy entries
-        assert np.all(np.abs(gobs[i] - o) <= tol + 5e-3 * np.abs(o)), ("env %d" % i, np.abs(gobs[i] - o).max())
+        err = np.array([np.abs(gobs[i, sl] - o[sl]).max() for sl in grp])
+        assert np.all(err <= TF_TOL_SAME[:9]), ("env %d" % i, err)
     gi = genv.get_field("ints").cpu().numpy()
     assert np.all(gi[:, :3] == 0)
     d0 = S.OracleEnv(dyn_rand=False, seed=0, env_id=0)
@@ -330,14 +281,6 @@ def test_update_speed_and_reset_for_test_vs_oracle(dev):
     np.testing.assert_allclose(genv.get_field("damping").cpu().numpy()[:4], np.tile(d0.get("damping"), (4, 1)), rtol=1e-6)
     assert np.all(genv.get_field("motor_noise").cpu().numpy() == 0) and np.all(genv.get_field("joint_noise").cpu().numpy() == 0)
     np.testing.assert_allclose(genv.get_field("friction").cpu().numpy()[:4, 0], 1.0)
-    # after reset_for_test the envs run the fixed grounded clock from the init pose
-    for t in range(2):
-        obs, rew, done, _ = genv.step(torch.tensor(act, device=dev), auto_reset=False)
-        obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
-        for i, e in enumerate(oenv[:8]):
-            o, r, d = e.step(act[i].astype(np.float64))
-            assert np.all(np.abs(obs[i] - o) <= tol * (t + 1) / 2 + 5e-3 * np.abs(o)), ("env %d step %d" % (i, t), np.abs(obs[i] - o).max())
-            assert abs(rew[i] - r) < 0.02 * (t + 1)
 
 
 def test_step_basic_vs_oracle(dev):
@@ -353,9 +296,7 @@ def test_step_basic_vs_oracle(dev):
         obs = genv.step_basic(torch.tensor(act, device=dev)).cpu().numpy()
         gi = genv.get_field("ints").cpu().numpy()
         for i, e in enumerate(oenv[:8]):
-            o = e.step_basic(act[i].astype(np.float64))
-            tol = np.full(50, 2e-2 * (t + 1)); tol[21:31] = 0.3 * (t + 1); tol[31:34] = 0.6 * (t + 1); tol[40:46] = 0.3 * (t + 1)
-            assert np.all(np.abs(obs[i] - o) <= tol + 5e-3 * np.abs(o)), (t, i, np.abs(obs[i] - o).max())
+            o = e.step_basic(act[i].astype(np.float64))      # (the observation itself: scenario eval_step_basic of test_teacher_forced_scenario, from identical states)
             oi = e.get("ints")
             assert (gi[i, 0], gi[i, 1], gi[i, 2]) == (oi[0], oi[1], oi[2])
             assert obs[i, 48] == 1.0 and obs[i, 49] == 0.0                       # the commanded speed stays put
@@ -443,16 +384,7 @@ def test_cassie_traj_v0_reset_and_steps_vs_oracle(dev):
         np.testing.assert_allclose(gq[i], e.get("qpos"), atol=2e-4); np.testing.assert_allclose(gv[i], e.get("qvel"), atol=3e-2)
         np.testing.assert_allclose(gobs[i, 46:50], oobs[i, 46:50], atol=1e-5)
     assert np.abs(gq[:, 2] - 1.01).max() > 5e-3 and len(np.unique(np.round(gq[:, 7], 3))) > 8        # poses differ from env to env: not the init pose
-    rng = np.random.RandomState(3)
-    tol = np.full(50, 1e-2); tol[21:31] = 0.3; tol[31:34] = 0.6; tol[40:46] = 0.3
-    for t in range(3):
-        act = (rng.randn(N, 10) * 0.1).astype(np.float32)
-        obs, rew, done, _ = genv.step(torch.tensor(act, device=dev), auto_reset=False)
-        obs, rew = obs.cpu().numpy(), rew.cpu().numpy()
-        for i, e in enumerate(oenv):
-            o, r, d = e.step(act[i].astype(np.float64))
-            assert np.all(np.abs(obs[i] - o) <= tol * (t + 1) + 5e-3 * np.abs(o)), ("env %d step %d" % (i, t), np.abs(obs[i] - o).max())
-            assert abs(rew[i] - r) < 0.02 * (t + 1)
+    # (the env steps behind the reset: scenario cassie_traj of test_teacher_forced_scenario, from identical states with fixed tolerances)
     # the masked restart inside apx_env_step uses the same trajectory-pose reset
     genv2 = CassieVecEnv(n_envs=N, dynamics_randomization=False, seed=4, env_name="CassieTraj-v0", max_traj_len=2)
     genv2.reset()
@@ -548,7 +480,7 @@ def test_saturation_flags_vs_oracle_crafted(dev):
 
 
 def test_trained_policy_never_saturates_the_constraint_caps(dev):
-    """The kept checkpoint (trained_models/r03_cassie_v0_clock) walking for 300 steps on 256 envs with dynamics randomisation, speeds 0-3 m/s:
+    """The kept checkpoint (trained_models/r04_cassie_v0_clock) walking for 300 steps on 256 envs with dynamics randomisation, speeds 0-3 m/s:
     no forward pass of an env that stays up needs a constraint row the kernel does not instantiate (I_SAT stays 0); envs that fall may
     saturate only in the steps right before termination.  The same counters stay 0 through a push-recovery trial that is survived."""
     import os
@@ -557,7 +489,7 @@ def test_trained_policy_never_saturates_the_constraint_caps(dev):
     import sys; sys.path.insert(0, sys_path)
     import apex
     env = CassieVecEnv(n_envs=256, seed=31, max_traj_len=300)
-    actor, mean, std = apex._load_actor(os.path.join(sys_path, "trained_models", "r03_cassie_v0_clock"), env.device)
+    actor, mean, std = apex._load_actor(os.path.join(sys_path, "trained_models", "r04_cassie_v0_clock"), env.device)
     obs = env.reset()
     alive = torch.ones(256, dtype=torch.bool, device=dev)
     sat_alive = torch.zeros(256, dtype=torch.int64, device=dev)
@@ -666,9 +598,8 @@ def test_phase_command_profile_vs_oracle(dev, reward, cp):
         for i, e in enumerate(o):
             oo, rr, dd = e.step(act[i].astype(np.float64))
             assert dd == done[i]
-            np.testing.assert_allclose(ob[i, 46:], oo[46:], atol=2e-6)
-            np.testing.assert_allclose(ob[i, :15], oo[:15], atol=3e-3 * (t + 1))
-            assert abs(rew[i] - rr) < 0.02 * (t + 1), (t, i, rew[i], rr)
+            np.testing.assert_allclose(ob[i, 46:], oo[46:], atol=2e-6)      # integer phase, durations, mode, commands: exact whatever the dynamics do
+            # (the 46 dynamics entries and the reward: scenarios phase_clock / phase_library of test_teacher_forced_scenario)
     g.update_speed(1.5, 0.1)
     c2 = g.get_field("cmd").cpu().numpy()
     np.testing.assert_allclose(c2[:, :2], [[1.5, 0.1]] * N); np.testing.assert_allclose(c2[:, 3:7], cmd[:, 3:7])      # durations / mode kept
@@ -744,12 +675,9 @@ def test_heightfield_terrain_vs_oracle(dev, kind):
         ok = (err / scale <= tol) | (err <= 2e-5 * np.abs(ref).max())
         assert np.all(ok), (kind, i, err / scale, err / np.abs(ref).max())
     assert ncon >= 6
-    # env steps with the PD hold from those states
+    # env steps with the PD hold from those states (kernel vs oracle: scenarios hfield_* of test_teacher_forced_scenario)
     for t in range(4):
-        ob = g.step_basic(torch.zeros(N, 10, device=dev)).cpu().numpy()
-        for i, e in enumerate(o):
-            oo = e.step_basic(np.zeros(10))
-            np.testing.assert_allclose(ob[i, :15], oo[:15], atol=4e-3 * (t + 1), err_msg="%s t=%d env=%d" % (kind, t, i))
+        g.step_basic(torch.zeros(N, 10, device=dev))
     assert np.isfinite(g.get_field("qpos").cpu().numpy()).all()
     g.set_hfield(None)                                                   # back to the plane: a robot at the origin stands at the usual height
     g.reset_for_test()
@@ -792,7 +720,9 @@ def test_observation_history_stack(dev):
 
 def test_estimator_twin_from_identical_state(dev):
     """The restated reference estimator (state_output_step; golden G11 pins the fp64 oracle to the binary) in its lane form: both sides start ONE env
-    step from the same state (teacher forcing, tests/state_xfer.py), so the 50 filter updates see the same sensors up to the fp32 physics of one step.
+    step from the same state (teacher forcing, tests/state_xfer.py), so the 50 filter updates see the same sensors up to the fp32 physics of one step
+    (pairs whose signature of constraint rows and estimator load switches differs in some substep - a foot load within round-off of the filters' 50 N threshold flips a
+    gain - are counted, bounded and left out, like in every teacher-forced test).
     Checked on the estimator's own state: heel springs (two Newton steps vs the reference's Levenberg-Marquardt), all three filters' states and
     covariances, terrain; and on the three observation groups it produces.  Tolerances are fixed (no growth with the rollout length)."""
     from tests.state_xfer import oracle_to_kernel, est_from_record
@@ -800,18 +730,24 @@ def test_estimator_twin_from_identical_state(dev):
     n = 64
     genv, oenv = _mk(True, 21, n)
     genv.reset(); [e.reset() for e in oenv]
-    policy = torch.load(os.path.join(os.path.dirname(__file__), "..", "trained_models", "r03_cassie_v0_clock", "actor.pt"), weights_only=False).eval()
+    policy = torch.load(os.path.join(os.path.dirname(__file__), "..", "trained_models", "r04_cassie_v0_clock", "actor.pt"), weights_only=False).eval()
     obs_o = np.stack([e.obs() for e in oenv])
-    worst = np.zeros(8)
+    worst = np.zeros(8); n_pairs = n_diff = 0
     for t in range(30):
         with torch.no_grad():
             act = policy(torch.tensor(obs_o, dtype=torch.float32), deterministic=True).numpy()
         act = (act + np.random.RandomState(t).randn(n, 10) * 0.05).astype(np.float32)
         oracle_to_kernel(genv, oenv)
         obs, rew, done, _ = genv.step(torch.tensor(act, device=dev), auto_reset=False)
-        obs = obs.cpu().numpy(); est = genv.get_field("est").cpu().numpy()
+        obs = obs.cpu().numpy(); est = genv.get_field("est").cpu().numpy(); kh = _kernel_hash(genv)
         for i, e in enumerate(oenv):
             o, r, d = e.step(act[i].astype(np.float64)); obs_o[i] = o
+            n_pairs += 1
+            if int(kh[i]) != _oracle_hash(e):      # a constraint row or one of the estimator's load switches (50 N: process noise of a foot state) differed in some substep: not round-off
+                n_diff += 1
+                if d:
+                    e.reset(); obs_o[i] = e.obs()
+                continue
             k = est_from_record(est[i])
             ohx, ohP, ozx, ozP = e.get("est_hx").reshape(2, 6), e.get("est_hP").reshape(2, 6, 6), e.get("est_zx"), e.get("est_zP").reshape(5, 5)
             errs = np.array([np.abs(k["heel"] - e.get("est_heel")).max(), np.abs(k["hx"][:, [0, 2, 3]] - ohx[:, [0, 2, 3]]).max(), np.abs(k["hx"][:, 1] - ohx[:, 1]).max(),
@@ -820,7 +756,8 @@ def test_estimator_twin_from_identical_state(dev):
             worst = np.maximum(worst, errs)
             if d:
                 e.reset(); obs_o[i] = e.obs()
-    print("estimator twin, worst over 30 steps x %d envs [heel, positions, velocity, load share, vertical, terrain, rel P(h), rel P(z)]:" % n, worst)
+    print("estimator twin, worst over the %d of %d pairs with identical row-set / estimator-switch signatures [heel, positions, velocity, load share, vertical, terrain, rel P(h), rel P(z)]:" % (n_pairs - n_diff, n_pairs), worst)
+    assert n_diff < TF_MAX_DIFFERING_FRACTION * n_pairs, (n_diff, n_pairs)
     assert worst[0] < 6e-4 and worst[1] < 2e-3 and worst[2] < 2e-2 and worst[3] < 2e-2 and worst[4] < 2e-3 and worst[5] < 1e-4 and worst[6] < 2e-2 and worst[7] < 2e-2, worst
 
 
@@ -843,7 +780,7 @@ def _teacher_forced_rows(dev, n_steps=100, active=32, actions="policy"):
     n = 64
     genv, oenv = _mk(True, 22, n)
     genv.reset(); [e.reset() for e in oenv]
-    policy = torch.load(os.path.join(os.path.dirname(__file__), "..", "trained_models", "r03_cassie_v0_clock", "actor.pt"), weights_only=False).eval()
+    policy = torch.load(os.path.join(os.path.dirname(__file__), "..", "trained_models", "r04_cassie_v0_clock", "actor.pt"), weights_only=False).eval()
     obs_o = np.stack([e.obs() for e in oenv])
     grp = [slice(0, 5), slice(5, 15), slice(15, 18), slice(18, 21), slice(21, 31), slice(31, 34), slice(34, 40), slice(40, 46), slice(46, 50)]
     rows, same = [], []
@@ -946,9 +883,7 @@ def test_min_input_profile_vs_oracle(dev):
             for i, e in enumerate(oenv):
                 o, r, d = e.step(act[i].astype(np.float64))
                 assert d == done[i]
-                np.testing.assert_allclose(obs[i, :6], o[:6], atol=2e-3 * (t + 1), err_msg="foot positions")
-                np.testing.assert_allclose(obs[i, 6:10], o[6:10], atol=2e-3 * (t + 1)); np.testing.assert_allclose(obs[i, 13:21], o[13:21], atol=5e-3 * (t + 1), err_msg="foot orientations")
-                np.testing.assert_allclose(obs[i, 21:], o[21:], atol=1e-5)
+                np.testing.assert_allclose(obs[i, 21:], o[21:], atol=1e-5)      # clock + commands; the foot entries: scenarios min_clock / min_phase of test_teacher_forced_scenario
         genv.close()
 
 
@@ -970,8 +905,7 @@ def test_fractional_phase_add_vs_oracle(dev):
             o, r, d = e.step(np.zeros(10))
             oi = e.get("ints"); half = int(e.get("phase_add")[1]); halves += half
             assert int(ints[i, 1]) == int(oi[1]) and (int(ints[i, 4]) >> 5) & 1 == half and int(ints[i, 2]) == int(oi[2]), (t, i)
-            np.testing.assert_allclose(obs[i, 46:50], o[46:50], atol=2e-6)
-            assert abs(rew[i] - r) < 0.02 * (t + 1)
+            np.testing.assert_allclose(obs[i, 46:50], o[46:50], atol=2e-6)      # (the reward along the float phase: scenario phase_add of test_teacher_forced_scenario)
     assert halves > 50 and int(oenv[0].get("ints")[2]) >= 1 and int(oenv[0].get("ints")[2]) > int(oenv[1].get("ints")[2]) - 1      # half phases occurred, the 1.5 envs wrapped
 
 
@@ -1087,3 +1021,69 @@ def test_prepared_resets_are_bit_identical_to_computed_ones(dev):
         assert float(a.get_field("reset_miss")[0, 0]) == 0 and float(b.get_field("reset_miss")[0, 0]) == 0
         assert nres > 256 * 2 and int(ia[:, 9].max()) >= 4          # every env restarted several times: ring hits and (with rare preparation) fallbacks
         a.close(); b.close()
+
+
+from tests.tf_scenarios import SCENARIOS as _SCENARIOS, G50 as _G50, TOL_TORQUE, TOL_MIN_FOOT_POS, TOL_MIN_FOOT_ORI
+
+
+@pytest.mark.parametrize("name", [s.name for s in _SCENARIOS])
+def test_teacher_forced_scenario(dev, name):
+    """Every env configuration / action regime that round 4 still compared free-running with tolerances growing like (t + 1): safety zones, coupled pitch-knee zone, early /
+    max_vel rewards, evaluation API (reset_for_test + update_speed, step and step_basic), CassieTraj-v0, the phase command profile, height fields, the min input profile,
+    fractional phase_add (tests/tf_scenarios.py).  TEACHER-FORCED like test_teacher_forced_env_steps_on_walking_states: the kernel's whole state is overwritten with the
+    fp64 oracle's before EVERY step, every (env, step) pair is binned by identical constraint-row sets in all 50 substeps, and the identical-set population is held to the
+    FIXED tolerances of tests/state_xfer.py (observation groups, reward, qpos, qvel) plus a fixed drive-torque tolerance and, for the min profile, fixed foot-entry
+    tolerances - all shown to be the fp32 level by the CPU-side control of the SAME scenarios (tests/test_oracle_env.py::test_fp32_control_of_the_scenarios).  Done flags
+    and the integer bookkeeping (time, phase, cycle counter, RNG counter) bit-exact on every pair."""
+    from apex_amd.vecenv import CassieVecEnv
+    from tests.state_xfer import oracle_to_kernel
+    from tests.tf_scenarios import BY_NAME
+    sc = BY_NAME[name]
+    genv = sc.make_kernel(CassieVecEnv)
+    oenv = sc.make_oracle(S)
+    n, K = genv.n_envs, len(oenv)
+    rng = np.random.RandomState(sc.rng_seed)
+    grp = sc.obs_groups or _G50
+    rows, same, reached = [], [], 0
+    for t in range(sc.n_steps):
+        act = sc.act(t, rng, K).astype(np.float32)
+        oracle_to_kernel(genv, oenv)
+        ak = torch.tensor(act[np.arange(n) % K], device=dev)
+        if sc.stepper == "step":
+            obs, rew, done, _ = genv.step(ak, auto_reset=False)
+            rew, done = rew.cpu().numpy(), done.cpu().numpy()
+        else:
+            obs = genv.step_basic(ak); rew = np.zeros(n, dtype=np.float32); done = np.zeros(n, dtype=np.int64)
+        obs = obs.cpu().numpy()
+        qp, qv = genv.get_field("qpos").cpu().numpy(), genv.get_field("qvel").cpu().numpy()
+        tq, mp = genv.get_field("so_torque").cpu().numpy(), genv.get_field("so_mpos").cpu().numpy()
+        ints = genv.get_field("ints").cpu().numpy(); kh = _kernel_hash(genv)
+        for i, e in enumerate(oenv):
+            o, r, d = sc.step_oracle(e, act[i].astype(np.float64))
+            assert d == done[i], (name, t, i, d, done[i])
+            np.testing.assert_array_equal(ints[i, [0, 1, 2, 3]], e.get("ints")[[0, 1, 2, 5]], err_msg="%s t=%d env=%d" % (name, t, i))
+            pa = e.get("phase_add")
+            assert (int(ints[i, 4]) >> 5) & 1 == int(pa[1]), (name, t, i)                                            # the half phase of phase_add = 1.5
+            rows.append([np.abs(obs[i, sl] - o[sl]).max() for sl in grp] + [abs(rew[i] - r), np.abs(qp[i] - e.get("qpos")).max(), np.abs(qv[i] - e.get("qvel")).max(),
+                                                                             np.abs(tq[i] - e.get("so_torque")).max(), np.abs(mp[i] - e.get("so_mpos")).max()])
+            same.append(int(kh[i]) == _oracle_hash(e))
+        if sc.reaches is not None:
+            reached += sc.reaches(oenv)
+        for e in oenv:
+            if sc.stepper == "step" and (e.get("qpos")[2] < 0.4 or int(e.get("ints")[0]) >= sc.okw.get("max_traj_len", 400)):
+                e.reset()
+    E, same = np.array(rows), np.array(same)
+    G = len(grp)
+    Es, frac = E[same], 1.0 - same.mean()
+    print("teacher-forced %-16s pairs %d differing sets %.3f | same sets: obs groups max %s | reward %.1e qpos %.1e qvel %.1e torque %.2e mpos %.1e" % (
+        name, len(E), frac, np.array2string(Es[:, :G].max(0), precision=1, max_line_width=300), Es[:, G].max(), Es[:, G + 1].max(), Es[:, G + 2].max(), Es[:, G + 3].max(), Es[:, G + 4].max()))
+    assert frac <= sc.differing_max, (name, frac)
+    if sc.reaches is not None:
+        assert reached > 0, name                                     # the zones were actually reached
+    if sc.min_profile:
+        assert Es[:, 0].max() <= TOL_MIN_FOOT_POS and Es[:, 3].max() <= TOL_MIN_FOOT_ORI and Es[:, 1].max() <= TF_TOL_SAME[0] and Es[:, 2].max() <= TF_TOL_SAME[3] and Es[:, 4].max() <= 1e-5, (name, Es[:, :G].max(0))
+    else:
+        assert np.all(Es[:, :G].max(0) <= TF_TOL_SAME[:G]), (name, Es[:, :G].max(0), TF_TOL_SAME[:G])
+    assert Es[:, G].max() <= TF_TOL_SAME[9] and Es[:, G + 1].max() <= TF_TOL_SAME[10] and Es[:, G + 2].max() <= TF_TOL_SAME[11], (name, Es[:, G:].max(0))
+    assert Es[:, G + 3].max() <= TOL_TORQUE and Es[:, G + 4].max() <= TF_TOL_SAME[1], (name, Es[:, G + 3].max(), Es[:, G + 4].max())
+    genv.close()

@@ -610,7 +610,7 @@ def test_fp32_control_of_the_parity_tolerances(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     n_env, n_step, seed = 16, 60, 22
     nthr = torch.get_num_threads(); torch.set_num_threads(1)      # the policy's matmul summation order must not depend on the host's thread count: the rollout is chaotic
-    policy = torch.load(os.path.join(root, "trained_models", "r03_cassie_v0_clock", "actor.pt"), weights_only=False).eval()
+    policy = torch.load(os.path.join(root, "trained_models", "r04_cassie_v0_clock", "actor.pt"), weights_only=False).eval()
     envs = [S.OracleEnv(dyn_rand=True, seed=seed, env_id=i) for i in range(n_env)]
     obs = np.stack([e.reset() for e in envs])
     rec = {k: np.zeros((n_env, n_step) + envs[0].get(k).shape) for k in ORACLE_STATE_FIELDS}; rec["ints"] = np.zeros((n_env, n_step, 8))
@@ -651,3 +651,126 @@ def test_fp32_control_of_the_parity_tolerances(tmp_path):
     # ... and they are not slack: on the stiff groups (motor velocity, acceleration, reward) plain fp32 round-off reaches a good fraction of them
     for k in (4, 5, 9):
         assert Es[:, k].max() > TF_TOL_SAME[k] / 10, (k, Es[:, k].max())
+
+
+def _scenario_records(sc, tmp_path):
+    """fp64 oracle rollout of a tests/tf_scenarios.py scenario with the state in front of every step recorded, and the fp32 build's replay of every step from that state"""
+    import subprocess, sys
+    from tests.state_xfer import ORACLE_STATE_FIELDS, oracle_state
+    from tests.tf_scenarios import N_ORACLE
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    envs = sc.make_oracle(S, N_ORACLE)
+    n_env, n_step = len(envs), sc.n_steps
+    rng = np.random.RandomState(sc.rng_seed)
+    dim = envs[0].obs_dim
+    rec = {k: np.zeros((n_env, n_step) + envs[0].get(k).shape) for k in ORACLE_STATE_FIELDS}; rec["ints"] = np.zeros((n_env, n_step, 8))
+    A = np.zeros((n_env, n_step, 10)); O = np.zeros((n_env, n_step, dim)); R = np.zeros((n_env, n_step)); D = np.zeros((n_env, n_step), dtype=np.int64); H = np.zeros((n_env, n_step), dtype=np.int64)
+    TQ = np.zeros((n_env, n_step, 10)); MP = np.zeros((n_env, n_step, 10)); QP = np.zeros((n_env, n_step, 35)); QV = np.zeros((n_env, n_step, 32))
+    reached = 0
+    for t in range(n_step):
+        act = sc.act(t, rng, n_env).astype(np.float32).astype(np.float64)
+        for i, e in enumerate(envs):
+            st = oracle_state(e)
+            for k in ORACLE_STATE_FIELDS:
+                rec[k][i, t] = st[k]
+            rec["ints"][i, t] = st["ints"]
+            o, r, d = sc.step_oracle(e, act[i]); ii = e.get("ints")
+            A[i, t] = act[i]; O[i, t] = o; R[i, t] = r; D[i, t] = d; H[i, t] = int(ii[10]) | int(ii[11]) << 16
+            TQ[i, t] = e.get("so_torque"); MP[i, t] = e.get("so_mpos"); QP[i, t] = e.get("qpos"); QV[i, t] = e.get("qvel")
+        if sc.reaches is not None:
+            reached += sc.reaches(envs)
+        for e, d in zip(envs, D[:, t]):
+            if d: e.reset()
+    src, dst = str(tmp_path / ("rec_%s.npz" % sc.name)), str(tmp_path / ("out_%s.npz" % sc.name))
+    np.savez(src, seed=0, action=A, obs=O, rew=R, done=D, hash=H, **{"st_" + k: v for k, v in rec.items()})
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fp32_control_worker.py"), src, dst, sc.name], env=dict(os.environ, ORC_REAL="float"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    b = np.load(dst)
+    return dict(obs=O, rew=R, done=D, hash=H, torque=TQ, mpos=MP, qpos=QP, qvel=QV), {k: b[k] for k in b.files}, reached
+
+
+def test_fp32_control_of_the_scenarios(tmp_path):
+    """The fp32 CONTROL of tests/test_gpu_env.py::test_teacher_forced_scenario (VERDICT r4 item 3): every scenario that round 4 compared free-running with (t + 1)
+    tolerances - safety zones, coupled zone, early / max_vel rewards, evaluation API, CassieTraj-v0, phase profile, height fields, min profile, fractional phase_add - in
+    the oracle's own sources compiled in fp32 against the fp64 oracle, one step from IDENTICAL states, binned by identical constraint-row sets.  The fixed tolerances the
+    kernel is held to (tests/state_xfer.py TF_TOL_SAME, tests/tf_scenarios.py TOL_*) are what plain fp32 needs: the control passes them in every scenario, and the
+    stiff ones are reached to within 10 x somewhere."""
+    from tests.state_xfer import TF_TOL_SAME
+    from tests.tf_scenarios import SCENARIOS, G50, TOL_TORQUE, TOL_MIN_FOOT_POS, TOL_MIN_FOOT_ORI
+    worst = {"torque": 0.0, "acc": 0.0, "mvel": 0.0, "foot_pos": 0.0, "foot_ori": 0.0}
+    for sc in SCENARIOS:
+        a, b, reached = _scenario_records(sc, tmp_path)
+        np.testing.assert_array_equal(a["done"], b["done"])
+        same = a["hash"] == b["hash"]
+        frac = 1.0 - same.mean()
+        grp = sc.obs_groups or G50
+        E = np.stack([np.abs(a["obs"][..., sl] - b["obs"][..., sl]).max(-1) for sl in grp], -1)[same]
+        er = np.abs(a["rew"] - b["rew"])[same]; eq = np.abs(a["qpos"] - b["qpos"]).max(-1)[same]; ev = np.abs(a["qvel"] - b["qvel"]).max(-1)[same]
+        et = np.abs(a["torque"] - b["torque"]).max(-1)[same]; em = np.abs(a["mpos"] - b["mpos"]).max(-1)[same]
+        print("fp32 control %-16s pairs %4d differing sets %.3f | obs groups max %s | reward %.1e qpos %.1e qvel %.1e torque %.2e mpos %.1e%s" % (
+            sc.name, same.size, frac, np.array2string(E.max(0), precision=1, max_line_width=300), er.max(), eq.max(), ev.max(), et.max(), em.max(),
+            " | zone visits %d" % reached if sc.reaches else ""))
+        assert frac <= sc.differing_max, (sc.name, frac)
+        if sc.reaches is not None:
+            assert reached > 0, sc.name
+        if sc.min_profile:
+            assert E[:, 0].max() <= TOL_MIN_FOOT_POS and E[:, 3].max() <= TOL_MIN_FOOT_ORI and E[:, 1].max() <= TF_TOL_SAME[0] and E[:, 2].max() <= TF_TOL_SAME[3], (sc.name, E.max(0))
+            worst["foot_pos"] = max(worst["foot_pos"], E[:, 0].max()); worst["foot_ori"] = max(worst["foot_ori"], E[:, 3].max())
+        else:
+            assert np.all(E.max(0) <= TF_TOL_SAME[:len(grp)]), (sc.name, E.max(0), TF_TOL_SAME[:len(grp)])
+            worst["acc"] = max(worst["acc"], E[:, 5].max()); worst["mvel"] = max(worst["mvel"], E[:, 4].max())
+        assert er.max() <= TF_TOL_SAME[9] and eq.max() <= TF_TOL_SAME[10] and ev.max() <= TF_TOL_SAME[11], (sc.name, er.max(), eq.max(), ev.max())
+        assert et.max() <= TOL_TORQUE and em.max() <= TF_TOL_SAME[1], (sc.name, et.max(), em.max())
+        worst["torque"] = max(worst["torque"], et.max())
+    print("fp32 control, worst over the scenarios:", worst)
+    # not slack: plain fp32 round-off reaches a tenth of the stiff tolerances somewhere
+    assert worst["torque"] > TOL_TORQUE / 10 and worst["acc"] > TF_TOL_SAME[5] / 10 and worst["mvel"] > TF_TOL_SAME[4] / 10, worst
+    assert worst["foot_pos"] > TOL_MIN_FOOT_POS / 20 and worst["foot_ori"] > TOL_MIN_FOOT_ORI / 20, worst
+
+
+def test_fp32_control_of_the_crafted_substep_tolerance(tmp_path):
+    """Control of tests/test_gpu_env.py::test_single_substep_crafted_states: the same twelve crafted states (feet pressed into the floor, pitched / rolled low poses, joints
+    beyond their limits) through ONE substep of the fp64 oracle and of its fp32 build.  Every dof but the two achilles-rod spins (dofs 9, 22: inertia 3.8e-6 kg m^2 about the
+    rod's own axis) agrees to 3e-2 of max(1, |qacc|); the spin dofs carry an ABSOLUTE error that follows the largest acceleration of the env (their coupling entries of the
+    mass matrix are 1e-9 remainders of 1e-2 terms, multiplied by ancestor accelerations of 1e5 rad/s^2 in the limit cases): 9e-5 max|qacc| in plain fp32; the GPU test's
+    floor on these two dofs is 0.25 x 8e-4 max|qacc| = 2.2 x that."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from oracle import sim as S
+rng = np.random.RandomState(5)
+envs = [S.OracleEnv(dyn_rand=False, seed=11, env_id=i) for i in range(12)]
+[e.reset() for e in envs]; [e.kernel_caps(True) for e in envs]
+out = []
+for i, e in enumerate(envs):
+    q = e.get("qpos").copy(); v = 0.05 * rng.randn(32); kind = i %% 4
+    if kind == 0: q[2] = 0.80 + 0.02 * rng.rand()
+    elif kind == 1:
+        q[2] = 0.45 + 0.05 * rng.rand(); ang = 0.9 + 0.3 * rng.rand(); q[3:7] = [np.cos(ang / 2), 0.0, np.sin(ang / 2), 0.0]
+    elif kind == 2:
+        q[2] = 1.2; q[7] = 0.45; q[14] = -0.60; q[20] = -0.45; q[21] = -0.45; q[28] = -2.95; q[34] = -2.50
+    else:
+        q[2] = 0.50 + 0.05 * rng.rand(); ang = 0.7; q[3:7] = [np.cos(ang / 2), np.sin(ang / 2), 0.0, 0.0]
+    e.set("qpos", q.astype(np.float32).astype(np.float64)); e.set("qvel", v.astype(np.float32).astype(np.float64)); e.set("qacc_warm", np.zeros(32))
+    e.substep()
+    out.append(np.asarray(e.get("qacc_warm"), dtype=np.float64))
+np.save(sys.argv[1], np.array(out))
+''' % root
+    res = {}
+    for real in ("double", "float"):
+        dst = str(tmp_path / ("qacc_%s.npy" % real))
+        r = subprocess.run([sys.executable, "-c", code, dst], env=dict(os.environ, ORC_REAL=real), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[real] = np.load(dst)
+    a, b = res["double"], res["float"]
+    spin = np.zeros(32, dtype=bool); spin[[9, 22]] = True
+    worst_rel, worst_spin = 0.0, 0.0
+    for i in range(12):
+        scale = np.maximum(1.0, np.abs(a[i])); err = np.abs(a[i] - b[i])
+        worst_rel = max(worst_rel, (err / scale)[~spin].max())
+        worst_spin = max(worst_spin, (err[spin] / np.abs(a[i]).max()).max())
+    print("fp32 control of the crafted substep: other dofs %.2e of max(1, |qacc|), spin dofs %.2e of max |qacc| of the env" % (worst_rel, worst_spin))
+    assert worst_rel < 3e-2
+    assert 2e-5 < worst_spin < 2e-4      # the GPU test allows 0.25 * 8e-4 = 2e-4 of max |qacc| on these two dofs
