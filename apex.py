@@ -50,7 +50,6 @@ def build_parser():
     p.add_argument("--bounded", type=bool, default=False)
     # engine flags (additions)
     p.add_argument("--n_envs", type=int, default=4096, help="lock-step envs per GPU (replaces Ray's num_procs)")
-    p.add_argument("--bf16", dest="precision", action="store_const", const=1, default=0, help="learner GEMMs with bf16 MFMA inputs (fp32 accumulate / master weights); default fp32 MFMA")
     p.add_argument("--eval_every", type=int, default=10, help="deterministic evaluation pass (ppo.py:464) every k iterations; 1 = the reference's cadence, 0 = off")
     p.add_argument("--eval_envs", type=int, default=256, help="envs (= episodes) of the evaluation pass")
     p.add_argument("--est_lifetime", type=int, default=None, help="env steps served by one state-estimator object: the reference builds a new CassieEnv (-> cassie_sim_init -> "

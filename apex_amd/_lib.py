@@ -22,7 +22,7 @@ class PpoArgs(C.Structure):
         ("obs_sign_perm", c_ptr), ("clock_mask", C.c_uint64), ("act_sign_perm", c_ptr),
         ("fixed_std", C.c_float), ("clip", C.c_float), ("entropy_coeff", C.c_float), ("grad_clip", C.c_float),
         ("lr", C.c_float), ("adam_eps", C.c_float), ("mirror_coeff", C.c_float),
-        ("adam_t", C.c_int), ("precision", C.c_int), ("grad_only", C.c_int),
+        ("adam_t", C.c_int), ("grad_only", C.c_int),
         ("workspace", c_ptr), ("workspace_bytes", C.c_size_t),
         ("scalars_out", c_ptr),
     ]
@@ -63,7 +63,7 @@ SIGNATURES = {
     "apx_rec_gather": (C.c_int, [c_ptr, c_ptr, c_ptr, C.c_int64, C.c_int, C.c_int64, C.c_int, C.c_int] + [c_ptr] * 5 + [C.c_uint64] + [c_ptr] * 10),
     "apx_lstm_backward": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, C.c_int, C.c_int64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "apx_mlp_forward": (C.c_int, [c_ptr, C.c_int, C.c_int, C.c_int, c_ptr, C.c_int64, c_ptr, c_ptr, C.c_uint64, c_ptr,
-                                  c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, c_ptr]),
+                                  c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "apx_ppo_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int, C.c_int]),
     "apx_ppo_minibatch": (C.c_int, [C.POINTER(PpoArgs), c_ptr]),
     "apx_clip_adam": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
@@ -105,6 +105,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ApxError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        f"(there is no CPU fallback)")
+    import torch  # noqa: F401  (first: libapx.so must bind to the HIP runtime torch ships - loaded the other way round, the process holds two runtimes and the library's sees no device)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol

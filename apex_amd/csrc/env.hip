@@ -1020,7 +1020,7 @@ extern "C" int apx_rollout(apx_env_t* e, const float* actor, int H, const float*
         int rc = apx_mlp_forward_act(actor, D, H, A, obs, N, obs_mean, obs_std, mu, act, nz, sigma, stream);      // forward + noise in one launch (the reference's 2 x 256 shape)
         if (rc < 0) return APX_E_HIP;
         if (rc == 0) {
-            rc = apx_mlp_forward(actor, D, H, A, obs, N, nullptr, nullptr, 0, obs_mean, obs_std, nullptr, nullptr, nullptr, mu, 0, stream);
+            rc = apx_mlp_forward(actor, D, H, A, obs, N, nullptr, nullptr, 0, obs_mean, obs_std, nullptr, nullptr, nullptr, mu, stream);
             if (rc != APX_OK) return rc;
             hipLaunchKernelGGL(act_noise_kernel, dim3(apx_cdiv(N * A, 256)), dim3(256), 0, (hipStream_t)stream, mu, nz, sigma, N * A, act);
             APX_LAUNCH_CHECK();

@@ -164,7 +164,6 @@ struct GemmArgs {
     const float* aux; long ld_aux;   // bias[N] or mask[M, ld_aux]
     int M, N, K, kchunk;
     long part_stride;                // EPI_PARTIAL: floats between the slabs of consecutive K chunks
-    int prec;                        // 0: fp32 MFMA (exact fp32 products); 1: operands rounded to bf16, fp32 accumulate (v_mfma_f32_32x32x8_bf16_1k)
 };
 
 #define GBM 64
@@ -335,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_128_kernel(GemmArgs g) {
 }
 static bool gemm128_ok(int epi, const GemmArgs& g, int kchunk) {
     static const bool off = getenv("APX_GEMM128") && atoi(getenv("APX_GEMM128")) == 0;
-    if (off || g.prec != 0 || !(epi == EPI_STORE || epi == EPI_MASK || epi == EPI_PARTIAL || epi == EPI_BIAS)) return false;
+    if (off || !(epi == EPI_STORE || epi == EPI_MASK || epi == EPI_PARTIAL || epi == EPI_BIAS)) return false;
     if (g.M % G2M || g.N % G2N || g.K % GBK || kchunk % GBK || g.K < 64) return false;
     if (epi != EPI_PARTIAL && (long)(g.M / G2M) * (g.N / G2N) < 384) return false;      // too few 128 x 128 tiles to fill the chip: the 64 x 64 kernel's 4x workgroups hide the latency better
     if (((uintptr_t)g.B & 15) || ((uintptr_t)g.A & 15)) return false;
@@ -344,119 +343,16 @@ static bool gemm128_ok(int epi, const GemmArgs& g, int kchunk) {
     return g.a_rs == 1 && g.a_cs % 4 == 0;
 }
 
-// ------------------------------------------------------------------------------------------------ bf16 MFMA GEMM (precision 1)
-// Same contract as gemm_f32_kernel; operands are rounded to bf16 (round-to-nearest-even) on their way into LDS, products accumulate in
-// fp32 (v_mfma_f32_32x32x8_bf16_1k: 4x the rate of the fp32 instruction per pass).  Block tile 64 x 64 x 32; LDS tiles are [m][k] /
-// [n][k] with k contiguous so that a lane's four consecutive-k operands are one ds_read_b64 (row pitch 36 halves: 8-byte aligned).
-typedef short bf16x4 __attribute__((ext_vector_type(4)));
-#define HBK 32
-#define HPITCH 36
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);                 // round to nearest even (inputs are finite)
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) unsigned short As[GBM][HPITCH];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[GBN][HPITCH];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * GBM, n0 = blockIdx.y * GBN;
-    const int kbeg = blockIdx.z * g.kchunk;
-    const int kend = min(g.K, kbeg + g.kchunk);
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    floatx16 acc = {0};
-    const bool a_kmajor = (g.a_cs == 1), b_kmajor = (g.b_rs == 1);
-    const bool bias_grad = EPI == EPI_ATOMIC && g.aux != nullptr && blockIdx.y == 0;
-    float bsum = 0.f;
-    float ra[8], rb[8];
-    auto coord = [&](bool kmaj, int i, int& mn, int& k) {
-        if (kmaj) { k = tid & 31; mn = (tid >> 5) + 8 * i; }
-        else      { mn = tid & 63; k = (tid >> 6) + 4 * i; }
-    };
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int m, k; coord(a_kmajor, i, m, k);
-            const int gm = m0 + m, gk = k0 + k;
-            ra[i] = (gm < g.M && gk < kend) ? g.A[gm * g.a_rs + gk * g.a_cs] : 0.f;
-            int n, kk; coord(b_kmajor, i, n, kk);
-            const int gn = n0 + n, gkk = k0 + kk;
-            rb[i] = (gn < g.N && gkk < kend) ? g.B[gkk * g.b_rs + gn * g.b_cs] : 0.f;
-        }
-    };
-    fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += HBK) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int m, k; coord(a_kmajor, i, m, k);
-            As[m][k] = f2bf(ra[i]);
-            int n, kk; coord(b_kmajor, i, n, kk);
-            Bs[n][kk] = f2bf(rb[i]);
-        }
-        __syncthreads();
-        if (k0 + HBK < kend) fetch(k0 + HBK);
-        if (EPI == EPI_ATOMIC && bias_grad && tid < GBM) {      // fused bias gradient: column sums of dY ride on the A tile (row tid of As = column m0 + tid of dY)
-            const uint2* rowp = (const uint2*)&As[tid][0];
-#pragma unroll
-            for (int q = 0; q < HBK / 4; ++q) {
-                const uint2 w = rowp[q];
-                bsum += bf2f((unsigned short)(w.x & 0xffffu)) + bf2f((unsigned short)(w.x >> 16)) + bf2f((unsigned short)(w.y & 0xffffu)) + bf2f((unsigned short)(w.y >> 16));
-            }
-        }
-#pragma unroll
-        for (int kk = 0; kk < HBK; kk += 8) {
-            const bf16x4 a = *(const bf16x4*)&As[wm + (lane & 31)][kk + 4 * (lane >> 5)];
-            const bf16x4 b = *(const bf16x4*)&Bs[wn + (lane & 31)][kk + 4 * (lane >> 5)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(a, b, acc, 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    if (EPI == EPI_ATOMIC && bias_grad && tid < GBM && m0 + tid < g.M) atomicAdd(const_cast<float*>(g.aux) + m0 + tid, bsum);
-    const int col = n0 + wn + (lane & 31);
-    if (col >= g.N) return;
-    float bias = 0.f;
-    if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) bias = g.aux[col];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= g.M) continue;
-        float v = acc[r];
-        float* c = g.C + (long)row * g.ldc + col;
-        if (EPI == EPI_BIAS) v += bias;
-        if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
-        if (EPI == EPI_MASK) v = g.aux[(long)row * g.ld_aux + col] > 0.f ? v : 0.f;
-        if (EPI == EPI_ATOMIC) atomicAdd(c, v);
-        else if (EPI == EPI_ACC) *c += v;
-        else *c = v;
-    }
-}
-
 static int launch_gemm(int epi, const GemmArgs& g0, int ksplit, hipStream_t s) {
     GemmArgs g = g0;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return APX_OK;
     if (epi != EPI_ATOMIC && epi != EPI_PARTIAL) ksplit = 1;
-    const int kt = g.prec == 1 ? HBK : GBK;
+    const int kt = GBK;
     int kchunk = (g.K + ksplit - 1) / ksplit;
     kchunk = ((kchunk + kt - 1) / kt) * kt;
     g.kchunk = kchunk;
     const int nz = (g.K + kchunk - 1) / kchunk;
     dim3 grid(apx_cdiv(g.M, GBM), apx_cdiv(g.N, GBN), nz), block(256);
-    if (g.prec == 1) {
-        switch (epi) {
-            case EPI_STORE: hipLaunchKernelGGL(gemm_bf16_kernel<EPI_STORE>, grid, block, 0, s, g); break;
-            case EPI_BIAS: hipLaunchKernelGGL(gemm_bf16_kernel<EPI_BIAS>, grid, block, 0, s, g); break;
-            case EPI_BIAS_RELU: hipLaunchKernelGGL(gemm_bf16_kernel<EPI_BIAS_RELU>, grid, block, 0, s, g); break;
-            case EPI_MASK: hipLaunchKernelGGL(gemm_bf16_kernel<EPI_MASK>, grid, block, 0, s, g); break;
-            case EPI_ATOMIC: hipLaunchKernelGGL(gemm_bf16_kernel<EPI_ATOMIC>, grid, block, 0, s, g); break;
-            case EPI_ACC: hipLaunchKernelGGL(gemm_bf16_kernel<EPI_ACC>, grid, block, 0, s, g); break;
-            default: return APX_E_ARG;
-        }
-        APX_LAUNCH_CHECK();
-        return APX_OK;
-    }
     if (gemm128_ok(epi, g, kchunk)) {
         dim3 grid2(g.M / G2M, g.N / G2N, nz);
         switch (epi) {
@@ -484,14 +380,14 @@ static int launch_gemm(int epi, const GemmArgs& g0, int ksplit, hipStream_t s) {
 
 // Y[B,Dout] = act(X[B,Din] W^T + b), W torch layout [Dout, Din]
 static int linear_fwd(const float* X, const float* W, const float* b, float* Y, long B, int Din, int Dout, bool relu,
-                      hipStream_t s, int prec = 0) {
-    GemmArgs g{X, Din, 1, W, 1, Din, Y, Dout, b, 0, (int)B, Dout, Din, 0, 0, prec};
+                      hipStream_t s) {
+    GemmArgs g{X, Din, 1, W, 1, Din, Y, Dout, b, 0, (int)B, Dout, Din, 0, 0};
     return launch_gemm(relu ? EPI_BIAS_RELU : EPI_BIAS, g, 1, s);
 }
 // dX[B,Din] = (dY[B,Dout] W) * (mask > 0)   (mask = saved post-ReLU activation of the layer below, or NULL)
 static int linear_bwd_input(const float* dY, const float* W, const float* mask, float* dX, long B, int Din, int Dout,
-                            hipStream_t s, int prec = 0) {
-    GemmArgs g{dY, Dout, 1, W, Din, 1, dX, Din, mask, Din, (int)B, Din, Dout, 0, 0, prec};
+                            hipStream_t s) {
+    GemmArgs g{dY, Dout, 1, W, Din, 1, dX, Din, mask, Din, (int)B, Din, Dout, 0, 0};
     return launch_gemm(mask ? EPI_MASK : EPI_STORE, g, 1, s);
 }
 // dW[Dout,Din] += dY^T X  (split-K over the batch)
@@ -505,18 +401,18 @@ struct GradParts {
     GradSeg seg[8]; int nseg;
 };
 constexpr size_t GRAD_PART_FLOATS = (size_t)1024 * GBM * GBN;      // upper bound of one weight gradient's slabs: about 1024 workgroups x one 64 x 64 tile each
-static int linear_bwd_weight(const float* dY, const float* X, float* dW, float* db, long B, int Din, int Dout, hipStream_t s, int prec = 0, GradParts* parts = nullptr) {
-    GemmArgs g{dY, 1, Dout, X, Din, 1, dW, Din, db, 0, Dout, Din, (int)B, 0, 0, prec};
+static int linear_bwd_weight(const float* dY, const float* X, float* dW, float* db, long B, int Din, int Dout, hipStream_t s, GradParts* parts = nullptr) {
+    GemmArgs g{dY, 1, Dout, X, Din, 1, dW, Din, db, 0, Dout, Din, (int)B, 0, 0};
     // split-K sized to the chip, not to the batch: about 1024 workgroups whatever the shape of dW, at least 64 batch rows per workgroup (fewer leave CUs idle on the
     // 10 x 256 and 256 x 50 gradients; measured with APX_KSPLIT_WGS = 256 / 512 / 1024 / 2048 on the bench minibatch, tools/t_ksplit_sweep.sh)
     const long tiles = (long)apx_cdiv(Dout, GBM) * apx_cdiv(Din, GBN);
     static const long target_wgs = getenv("APX_KSPLIT_WGS") ? atol(getenv("APX_KSPLIT_WGS")) : 1024;
     long ksplit = target_wgs / tiles;
     static const long ks128 = getenv("APX_KSPLIT128") ? atol(getenv("APX_KSPLIT128")) : 64;
-    if (parts && prec == 0 && Dout % G2M == 0 && Din % G2N == 0) ksplit = ks128;      // 128 x 128 tiles (gemm_f32_128_kernel): 4 tiles x 64 chunks = one workgroup per CU
+    if (parts && Dout % G2M == 0 && Din % G2N == 0) ksplit = ks128;      // 128 x 128 tiles (gemm_f32_128_kernel): 4 tiles x 64 chunks = one workgroup per CU
     if (ksplit > B / 64) ksplit = B / 64;
     if (ksplit < 1) ksplit = 1;
-    if (parts && prec == 0 && ksplit > 1 && parts->nseg < 8) {
+    if (parts && ksplit > 1 && parts->nseg < 8) {
         int kchunk = (int)((B + ksplit - 1) / ksplit); kchunk = ((kchunk + GBK - 1) / GBK) * GBK;
         const int nz = (int)((B + kchunk - 1) / kchunk);
         const size_t need = (size_t)nz * Dout * Din;
@@ -814,28 +710,28 @@ static int mlp_fused_launch(const float* params, int D, int H, int O, const Fuse
     return APX_OK;
 }
 static int mlp_forward_impl(const float* params, int D, int H, int O, const float* xn, long B, float* a1, float* a2,
-                            float* y, hipStream_t s, int prec = 0) {
+                            float* y, hipStream_t s) {
     MlpView p(params, D, H, O);
-    if (prec == 0 && fused_ok(D, H, O))       // one launch, activations stay in LDS (fp32 MFMA)
+    if (fused_ok(D, H, O))       // one launch, activations stay in LDS (fp32 MFMA)
         return mlp_fused_launch(params, D, H, O, FusedIn{xn, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f}, B, a1, a2, y, s);
-    APX_TRY(linear_fwd(xn, p.W0, p.b0, a1, B, D, H, true, s, prec));
-    APX_TRY(linear_fwd(a1, p.W1, p.b1, a2, B, H, H, true, s, prec));
-    APX_TRY(linear_fwd(a2, p.W2, p.b2, y, B, H, O, false, s, prec));
+    APX_TRY(linear_fwd(xn, p.W0, p.b0, a1, B, D, H, true, s));
+    APX_TRY(linear_fwd(a1, p.W1, p.b1, a2, B, H, H, true, s));
+    APX_TRY(linear_fwd(a2, p.W2, p.b2, y, B, H, O, false, s));
     return APX_OK;
 }
 
 // grads += d(loss)/d(params) given dy = d(loss)/d(y); dh1/dh2 are [B,H] scratch
 static int mlp_backward_impl(const float* params, float* grads, int D, int H, int O, const float* xn, const float* a1,
-                             const float* a2, const float* dy, long B, float* dh2, float* dh1, hipStream_t s, int prec = 0, GradParts* parts = nullptr) {
+                             const float* a2, const float* dy, long B, float* dh2, float* dh1, hipStream_t s, GradParts* parts = nullptr) {
     MlpView p(params, D, H, O);
     MlpGrad g(grads, D, H, O);
-    if (!(prec == 0 && bwd_head(dy, p.W2, a2, dh2, g.W2, g.b2, B, H, O, parts, s))) {
-        APX_TRY(linear_bwd_weight(dy, a2, g.W2, g.b2, B, H, O, s, prec, parts));
-        APX_TRY(linear_bwd_input(dy, p.W2, a2, dh2, B, H, O, s, prec));
+    if (!(bwd_head(dy, p.W2, a2, dh2, g.W2, g.b2, B, H, O, parts, s))) {
+        APX_TRY(linear_bwd_weight(dy, a2, g.W2, g.b2, B, H, O, s, parts));
+        APX_TRY(linear_bwd_input(dy, p.W2, a2, dh2, B, H, O, s));
     }
-    APX_TRY(linear_bwd_weight(dh2, a1, g.W1, g.b1, B, H, H, s, prec, parts));
-    APX_TRY(linear_bwd_input(dh2, p.W1, a1, dh1, B, H, H, s, prec));
-    APX_TRY(linear_bwd_weight(dh1, xn, g.W0, g.b0, B, D, H, s, prec, parts));
+    APX_TRY(linear_bwd_weight(dh2, a1, g.W1, g.b1, B, H, H, s, parts));
+    APX_TRY(linear_bwd_input(dh2, p.W1, a1, dh1, B, H, H, s));
+    APX_TRY(linear_bwd_weight(dh1, xn, g.W0, g.b0, B, D, H, s, parts));
     return APX_OK;
 }
 
@@ -849,19 +745,18 @@ static int prep_obs(const float* x, long B, int D, const int64_t* idx, const int
 
 extern "C" int apx_mlp_forward(const float* params, int D, int H, int O, const float* x, int64_t B, const int64_t* idx,
                                const int32_t* sign_perm, uint64_t clock_mask, const float* obs_mean,
-                               const float* obs_std, float* xn_out, float* act1, float* act2, float* y, int precision,
+                               const float* obs_std, float* xn_out, float* act1, float* act2, float* y,
                                void* stream) {
     APX_REQUIRE(D > 0 && H > 0 && O > 0 && B >= 0, "dims");
     if (B == 0) return APX_OK;   // empty batch: nothing to do (empty tensors have NULL data pointers)
     APX_REQUIRE(params && x && y, "null pointer");
-    APX_REQUIRE(precision == 0 || precision == 1, "precision: 0 fp32 MFMA, 1 bf16 MFMA inputs with fp32 accumulate");
     APX_REQUIRE((obs_mean == nullptr) == (obs_std == nullptr), "obs_mean/obs_std");
     hipStream_t s = (hipStream_t)stream;
-    if (precision == 0 && fused_ok(D, H, O))      // input prep inside the fused kernel; NULL outputs are simply not written
+    if (fused_ok(D, H, O))      // input prep inside the fused kernel; NULL outputs are simply not written
         return mlp_fused_launch(params, D, H, O, FusedIn{x, idx, sign_perm, clock_mask, obs_mean, obs_std, xn_out, nullptr, nullptr, 0.f}, B, act1, act2, y, s);
     APX_REQUIRE(xn_out && act1 && act2, "xn_out / act1 / act2 may only be NULL for the fused fp32 shapes (H = 256, D <= 64, O <= 128)");
     APX_TRY(prep_obs(x, B, D, idx, sign_perm, clock_mask, obs_mean, obs_std, xn_out, s));
-    return mlp_forward_impl(params, D, H, O, xn_out, B, act1, act2, y, s, precision);
+    return mlp_forward_impl(params, D, H, O, xn_out, B, act1, act2, y, s);
 }
 
 // apx_rollout's policy step: mu = pi(normalise(obs)) and act = mu + sigma * noise in ONE launch when the fused shape applies (returns 1 if it did, 0 if the caller has to
@@ -1503,12 +1398,12 @@ extern "C" int apx_lstm_backward(const float* params, float* grads, int D, int H
             float* tmp = dHa; dHa = dHx; dHx = tmp;
         }
         APX_HIP(hipMemsetAsync(dbt, 0, sizeof(float) * 4 * H, s));
-        APX_TRY(linear_bwd_weight(dG, in, const_cast<float*>(Gd.Wih[l]), dbt, TB, P.in[l], 4 * H, s, 0, pp));
+        APX_TRY(linear_bwd_weight(dG, in, const_cast<float*>(Gd.Wih[l]), dbt, TB, P.in[l], 4 * H, s, pp));
         hipLaunchKernelGGL(axpy_kernel, dim3(apx_cdiv(4 * H, 256)), dim3(256), 0, s, const_cast<float*>(Gd.bih[l]), dbt, (long)4 * H);
         hipLaunchKernelGGL(axpy_kernel, dim3(apx_cdiv(4 * H, 256)), dim3(256), 0, s, const_cast<float*>(Gd.bhh[l]), dbt, (long)4 * H);
         APX_LAUNCH_CHECK();
         if (T > 1)      // dW_hh += sum_{t >= 1} dG_t^T h_{t-1}
-            APX_TRY(linear_bwd_weight(dG + (size_t)B * 4 * H, Hh, const_cast<float*>(Gd.Whh[l]), nullptr, (long)(T - 1) * B, H, 4 * H, s, 0, pp));
+            APX_TRY(linear_bwd_weight(dG + (size_t)B * 4 * H, Hh, const_cast<float*>(Gd.Whh[l]), nullptr, (long)(T - 1) * B, H, 4 * H, s, pp));
     }
     return grad_reduce(parts, s);
 }
@@ -1792,8 +1687,6 @@ extern "C" int apx_ppo_minibatch(const apx_ppo_args* a, void* stream) {
     APX_REQUIRE(a->grad_only || (a->actor_m && a->actor_v && a->critic_m && a->critic_v), "Adam state");
     APX_REQUIRE(a->obs && a->act && a->ret && a->adv && a->old_mu && a->obs_mean && a->obs_std, "batch pointers");
     APX_REQUIRE(a->mb > 0 && a->D > 0 && a->H > 0 && a->A > 0 && a->A <= 64, "dims");
-    APX_REQUIRE(a->precision == 0 || a->precision == 1, "precision: 0 fp32 MFMA (parity mode), 1 bf16 MFMA inputs / fp32 accumulate / fp32 master weights (throughput mode)");
-    const int prec = a->precision;
     APX_REQUIRE(a->workspace && a->workspace_bytes >= apx_ppo_workspace_bytes(a->mb, a->D, a->H, a->A), "workspace");
     APX_REQUIRE(a->scalars_out, "scalars_out");
     APX_REQUIRE((a->obs_sign_perm == nullptr) == (a->act_sign_perm == nullptr), "mirror tables");
@@ -1816,12 +1709,12 @@ extern "C" int apx_ppo_minibatch(const apx_ppo_args* a, void* stream) {
         APX_TRY(prep_obs(a->obs, mb, D, a->idx, nullptr, 0, a->obs_mean, a->obs_std, w.xn, s));
         if (mirror) APX_TRY(prep_obs(a->obs, mb, D, a->idx, a->obs_sign_perm, a->clock_mask, a->obs_mean, a->obs_std, w.xm, s));
     }
-    APX_TRY(mlp_forward_impl(a->actor, D, H, A, w.xn, ma, w.a1, w.a2, w.mu, s, prec));
-    if (prec == 0 && fused_ok(D, H, 1))      // critic: raw obs (critic.py:66); the row gather rides in the fused forward, which also leaves the gathered rows in w.xr for the backward
+    APX_TRY(mlp_forward_impl(a->actor, D, H, A, w.xn, ma, w.a1, w.a2, w.mu, s));
+    if (fused_ok(D, H, 1))      // critic: raw obs (critic.py:66); the row gather rides in the fused forward, which also leaves the gathered rows in w.xr for the backward
         APX_TRY(mlp_fused_launch(a->critic, D, H, 1, FusedIn{a->obs, a->idx, nullptr, 0, nullptr, nullptr, w.xr, nullptr, nullptr, 0.f}, mb, w.c1, w.c2, w.v, s));
     else {
         APX_TRY(prep_obs(a->obs, mb, D, a->idx, nullptr, 0, nullptr, nullptr, w.xr, s));
-        APX_TRY(mlp_forward_impl(a->critic, D, H, 1, w.xr, mb, w.c1, w.c2, w.v, s, prec));
+        APX_TRY(mlp_forward_impl(a->critic, D, H, 1, w.xr, mb, w.c1, w.c2, w.v, s));
     }
     // losses
     LossArgs L{w.mu, mirror ? w.mum : nullptr, w.v, a->act, a->ret, a->adv, a->old_mu, a->idx, nullptr, a->act_sign_perm,
@@ -1831,8 +1724,8 @@ extern "C" int apx_ppo_minibatch(const apx_ppo_args* a, void* stream) {
     if (a->grad_only) { hipLaunchKernelGGL(finish_scalars_kernel, dim3(1), dim3(1), 0, s, w.acc, a->fixed_std, a->scalars_out); APX_LAUNCH_CHECK(); }      // (otherwise: in the tail)
     // backwards
     GradParts parts{w.parts, 6 * GRAD_PART_FLOATS, 0, {}, 0};
-    APX_TRY(mlp_backward_impl(a->actor, a->actor_grad, D, H, A, w.xn, w.a1, w.a2, w.dmu, ma, w.dh2, w.dh1, s, prec, &parts));      // both instances: 2 mb rows
-    APX_TRY(mlp_backward_impl(a->critic, a->critic_grad, D, H, 1, w.xr, w.c1, w.c2, w.dv, mb, w.dh2, w.dh1, s, prec, &parts));
+    APX_TRY(mlp_backward_impl(a->actor, a->actor_grad, D, H, A, w.xn, w.a1, w.a2, w.dmu, ma, w.dh2, w.dh1, s, &parts));      // both instances: 2 mb rows
+    APX_TRY(mlp_backward_impl(a->critic, a->critic_grad, D, H, 1, w.xr, w.c1, w.c2, w.dv, mb, w.dh2, w.dh1, s, &parts));
     APX_TRY(grad_reduce(parts, s));                     // the K-chunk slabs of the six weight gradients -> the flat gradient, one launch
     if (a->grad_only) return APX_OK;
     {   // (w.acc was cleared by the head: no second fill)

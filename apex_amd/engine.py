@@ -92,14 +92,14 @@ class Mlp:
         for v, t in zip(self.views(), tensors):
             v.copy_(torch.as_tensor(np.asarray(t), dtype=torch.float32))
 
-    def forward(self, x, obs_mean=None, obs_std=None, idx=None, sign_perm=None, clock_mask=0, keep=False, out=None, precision=0):
+    def forward(self, x, obs_mean=None, obs_std=None, idx=None, sign_perm=None, clock_mask=0, keep=False, out=None):
         _need_gpu(x)
         x = x.contiguous()
         assert x.shape[-1] == self.D, "input width %d, the network was built for %d" % (x.shape[-1], self.D)      # a wrong row stride reads out of bounds on the device
         assert obs_mean is None or obs_mean.numel() == self.D, "observation statistics of %d entries for a %d-input network" % (obs_mean.numel(), self.D)
         B = x.shape[0] if idx is None else idx.numel()
         dev = x.device
-        if keep or precision or not (self.H == 256 and self.D <= 64 and self.O <= 128):
+        if keep or not (self.H == 256 and self.D <= 64 and self.O <= 128):
             xn = torch.empty(B, self.D, dtype=torch.float32, device=dev)
             a1 = torch.empty(B, self.H, dtype=torch.float32, device=dev)
             a2 = torch.empty(B, self.H, dtype=torch.float32, device=dev)
@@ -111,8 +111,7 @@ class Mlp:
         else:
             y = torch.empty(B, self.O, dtype=torch.float32, device=dev)
         check(_lib.load().apx_mlp_forward(_p(self.params), self.D, self.H, self.O, _p(x), B, _p(idx), _p(sign_perm),
-                                          int(clock_mask), _p(obs_mean), _p(obs_std), _p(xn), _p(a1), _p(a2), _p(y), int(precision),
-                                          _stream()))
+                                          int(clock_mask), _p(obs_mean), _p(obs_std), _p(xn), _p(a1), _p(a2), _p(y), _stream()))
         return (y, xn, a1, a2) if keep else y
 
 
@@ -205,9 +204,8 @@ class PPOLearner:
     """Device-resident actor/critic + Adam state; one call = one PPO.update_policy (rl/algos/ppo.py:276-345)."""
 
     def __init__(self, obs_dim, act_dim, hidden, device, fixed_std, lr=1e-4, eps=1e-5, clip=0.2, entropy_coeff=0.0,
-                 grad_clip=0.05, mirrored_obs=None, mirrored_acts=None, clock_inds=(46, 47), mirror_coeff=0.4, precision=0):
+                 grad_clip=0.05, mirrored_obs=None, mirrored_acts=None, clock_inds=(46, 47), mirror_coeff=0.4):
         self.device = device
-        self.precision = int(precision)      # 0 fp32 MFMA (parity), 1 bf16 MFMA inputs / fp32 accumulate / fp32 master weights (throughput)
         self.actor = Mlp(obs_dim, hidden, act_dim, device)
         self.critic = Mlp(obs_dim, hidden, 1, device)
         z = lambda m: torch.zeros(m.n, dtype=torch.float32, device=device)
@@ -258,7 +256,7 @@ class PPOLearner:
             obs_sign_perm=_p(self.obs_sp) if use_mirror else None, clock_mask=self.clock_mask,
             act_sign_perm=_p(self.act_sp) if use_mirror else None, fixed_std=self.fixed_std, clip=self.clip,
             entropy_coeff=self.entropy_coeff, grad_clip=self.grad_clip, lr=self.lr, adam_eps=self.eps,
-            mirror_coeff=self.mirror_coeff, adam_t=max(self.t, 1), precision=self.precision, grad_only=int(grad_only),
+            mirror_coeff=self.mirror_coeff, adam_t=max(self.t, 1), grad_only=int(grad_only),
             workspace=_p(self._ws), workspace_bytes=self._ws.numel(), scalars_out=_p(self._scal))
         check(lib.apx_ppo_minibatch(C.byref(a), _stream()))
         return self._scal.cpu().numpy().copy() if sync else self._scal

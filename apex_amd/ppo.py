@@ -71,7 +71,7 @@ class PPO:
         # steps per env per iteration: the reference samples >= num_steps in total (ppo.py:205)
         self.T = adist.rollout_len(self.num_steps, self.N, self.world)
         self.learner = engine.PPOLearner(self.D, 10, hidden, self.device, self.fixed_std, lr=self.lr, eps=self.eps,
-                                         clip=self.clip, entropy_coeff=self.entropy_coeff, grad_clip=self.grad_clip, precision=int(args.get("precision", 0)),
+                                         clip=self.clip, entropy_coeff=self.entropy_coeff, grad_clip=self.grad_clip,
                                          mirrored_obs=list(getattr(env, "mirrored_obs", MIRRORED_OBS)) if self.mirror else None,
                                          mirrored_acts=MIRRORED_ACTS if self.mirror else None, clock_inds=list(getattr(env, "clock_inds", CLOCK_INDS)))      # env.clock_inds like rl/algos/ppo.py:307-310 (21, 22 with input_profile=min)
         self.total_steps = 0

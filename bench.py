@@ -65,11 +65,11 @@ def kernel_source_hash():
 
 
 def _pmc_traffic_bytes():
-    """HBM bytes per env_step_kernel launch from the committed rocprofv3 PMC passes (profiles/r04_env_step_pmc_hbm.txt, 4096 envs): 2 x
+    """HBM bytes per env_step_kernel launch from the committed rocprofv3 PMC passes (profiles/r05_env_step_pmc_hbm.txt, 4096 envs): 2 x
     FETCH_SIZE (gfx950 correction of the microarchitecture guide) + WRITE_SIZE, both in KB.  The profile records the hash of the kernel
     sources it was taken on (tools/profile_round.sh); a profile of another kernel is NOT quoted: None + a note on stderr."""
     import re
-    path = os.path.join(REPO, "profiles", "r04_env_step_pmc_hbm.txt")
+    path = os.path.join(REPO, "profiles", "r05_env_step_pmc_hbm.txt")
     try:
         txt = open(path).read()
         m = re.search(r"kernel sources sha1: (\w+)", txt)
@@ -84,8 +84,8 @@ def _pmc_traffic_bytes():
         return None
 
 
-def _pmc_issue():
-    """The instruction-issue view of the env kernel, from the SQ counter pass of the same profile round (profiles/r04_env_step_pmc_sq.txt + r04_env_step_pmc_issue.txt, quoted only while
+def _pmc_issue(flop_step):
+    """The instruction-issue view of the env kernel, from the SQ counter pass of the same profile round (profiles/r05_env_step_pmc_sq.txt + r05_env_step_pmc_issue.txt, quoted only while
     the HBM pass next to it carries this tree's kernel-source hash).  One single-wave workgroup sits on each SIMD, and a SIMD can start at most one VALU
     instruction per quad-cycle, the unit SQ_WAVE_CYCLES counts in: valu_issue_frac = SQ_INSTS_VALU / SQ_WAVE_CYCLES is how much of that ceiling the
     instruction stream uses, wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES how much of the time the wave sits in s_waitcnt.  flop_per_lane_instr relates it to the
@@ -95,15 +95,15 @@ def _pmc_issue():
     if _pmc_traffic_bytes() is None:
         return None
     try:
-        txt = open(os.path.join(REPO, "profiles", "r04_env_step_pmc_sq.txt")).read()
+        txt = open(os.path.join(REPO, "profiles", "r05_env_step_pmc_sq.txt")).read()
         line = re.search(r"env_step_kernel[^:]*: (.*)", txt).group(1)
         g = lambda k: float(re.search(k + r"=([0-9.e+]+)", line).group(1))
         valu, wave, wait = g("SQ_INSTS_VALU"), g("SQ_WAVE_CYCLES"), g("SQ_WAIT_ANY")
         out = {"valu_issue_frac": round(valu / wave, 4), "wait_frac": round(wait / wave, 4), "valu_instr_per_launch": valu,
-               "flop_per_lane_instr": round(roofline.ENV_STEP_FLOP_COUNTED * 4096 / (valu * 64.0), 3),
-               "source": "profiles/r04_env_step_pmc_sq.txt + r04_env_step_pmc_issue.txt (rocprofv3 --pmc, 4096 envs, per-dispatch means)"}
+               "flop_per_lane_instr": round(flop_step * 4096 / (valu * 64.0), 3),      # the SAME flop figure as roofline.frac
+               "source": "profiles/r05_env_step_pmc_sq.txt + r05_env_step_pmc_issue.txt (rocprofv3 --pmc, 4096 envs, per-dispatch means)"}
         try:      # the split of the wait (round 4, tools/profile_issue.sh): instruction-issue shares, LDS issue stalls, instruction-cache misses, dynamic arithmetic share
-            it = open(os.path.join(REPO, "profiles", "r04_env_step_pmc_issue.txt")).read()
+            it = open(os.path.join(REPO, "profiles", "r05_env_step_pmc_issue.txt")).read()
             if re.search(r"kernel sources sha1: (\w+)", it).group(1) == kernel_source_hash():
                 def gi(k):
                     m = re.search(r"env_step_kernel[^\n]*?" + k + r"=([0-9.e+]+)", it)
@@ -257,7 +257,7 @@ def main():
     env = CassieVecEnv(n_envs=a.n_envs, seed=0, device=local, env_id_base=adist.shard_env_base(rank, a.n_envs))
     args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=a.minibatch,
                 epochs=a.epochs, num_steps=a.rollout_len * a.n_envs * world, max_traj_len=400, max_grad_norm=0.05,
-                mirror=True, std_dev=-1.5, seed=0, graph=os.environ.get("APX_ROLLOUT_GRAPH", "0") == "1", precision=0)      # fp32 MFMA, the parity mode, is the only mode of the bench (the bf16 GEMM option of the library was worth +0.6 % end to end: DESIGN.md section 4.3)
+                mirror=True, std_dev=-1.5, seed=0, graph=os.environ.get("APX_ROLLOUT_GRAPH", "0") == "1")      # fp32 MFMA: the reference's own network precision and the library's only mode
     algo = PPO(args, "/tmp/apx_bench_unused", env, rank=rank, world_size=world, group=group)
     algo.init_networks(0)
     algo.normalization_params(10000)
@@ -341,7 +341,7 @@ def main():
                          "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop_step * a.n_envs / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 6),
                          # the same launch time against the KERNEL's own (tree-sparse) operation count: the dense oracle executes ~13 % more operations than the kernel needs
                          "frac_sparse": round(roofline.ENV_STEP_FLOP * a.n_envs / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 6), "flop_per_env_step_sparse": roofline.ENV_STEP_FLOP,
-                         "traffic": _pmc_traffic_bytes(), "issue": _pmc_issue(), "ms_per_launch": round(k_ms, 4), "launches_timed": k_launches,
+                         "traffic": _pmc_traffic_bytes(), "issue": _pmc_issue(flop_step), "ms_per_launch": round(k_ms, 4), "launches_timed": k_launches,
                          "flop_per_env_step": flop_step, "flop_source": "oracle-equivalent flops: instrumented count of the dense fp64 restatement oracle/cassie_phys.cpp (oracle.sim.count_flops); frac_sparse uses the hand count of the kernel's tree-sparse formulation",
                          "hbm": {"bytes_per_env_step": bytes_per_env_step, "achieved_GBps": round(achieved, 3), "peak_GBps": HBM_PEAK_GBS, "frac": round(achieved / HBM_PEAK_GBS, 6)},
                          "mlp_forward_mfma": {"what": "actor forward, %d x (50-256-256-10), fp32 MFMA (v_mfma_f32_32x32x2_f32), one fused launch (input normalisation + 3 layers, activations in LDS)" % mb_rows,

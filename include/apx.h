@@ -71,11 +71,11 @@ size_t apx_mlp_param_count(int D, int H, int O);
  * idx (may be NULL) gathers rows: x_row = x[idx[b]].  sign_perm (may be NULL) = int32[D] signed permutation
  * applied BEFORE normalisation (SymmetricEnv.mirror_clock_observation, rl/envs/wrappers.py:59-67): entry j>=0 takes
  * +x[j], entry -(j+1) takes -x[j]; clock_mask bit c set => column c additionally gets sin(asin(.)+pi).
- * precision: 0 = fp32 MFMA (exact fp32 products, the parity mode); 1 = operands rounded to bf16, fp32 accumulate (three GEMM launches,
- * xn_out / act1 / act2 required).                                                             all pointers [dev] */
+ * Arithmetic: fp32 MFMA (exact fp32 products) - the reference's own network precision and the only mode (round 5 removed the bf16 GEMM
+ * option: an MI200-era 32x32x8_1k kernel worth +0.6 % end to end, not the parity mode).  all pointers [dev] */
 int apx_mlp_forward(const float* params, int D, int H, int O, const float* x, int64_t B, const int64_t* idx,
                     const int32_t* sign_perm, uint64_t clock_mask, const float* obs_mean, const float* obs_std,
-                    float* xn_out, float* act1, float* act2, float* y, int precision, void* stream);
+                    float* xn_out, float* act1, float* act2, float* y, void* stream);
 
 /* TD3 primitives (next row f2; rl/algos/sync_td3.py:133-209 TD3.train with FF_Actor, rl/policies/actor.py:43-72, and Dual_Q_Critic,
  * rl/policies/critic.py:118-168, each Q a 3-layer ReLU MLP on cat(state, action)).  The networks run through apx_mlp_forward (no
@@ -165,8 +165,6 @@ typedef struct apx_ppo_args {
     /* hyper-parameters */
     float fixed_std, clip, entropy_coeff, grad_clip, lr, adam_eps, mirror_coeff;
     int adam_t;            /* 1-based optimiser step count (bias correction) */
-    int precision;         /* 0 fp32 MFMA (parity mode); 1 = bf16 MFMA inputs, fp32 accumulate, fp32 master weights and Adam (throughput mode,
-                            * BASELINE configs[1] / SURVEY section 8d cfg-2) */
     int grad_only;         /* 1 = stop after gradients (no clip/Adam): lets N>1 ranks all-reduce actor_grad/critic_grad */
     /* scratch: apx_ppo_workspace_bytes(mb, D, H, A) bytes [dev] */
     void* workspace; size_t workspace_bytes;

@@ -384,82 +384,6 @@ def test_mirror_loss_uses_the_env_clock_columns_min_profile(dev):
     assert abs(0.4 * float(((mu - mir0) ** 2).mean()) - want) > 1e-3 * want
 
 
-def test_bf16_throughput_mode_vs_fp32(dev, golden_dir):
-    """precision = 1 (BASELINE configs[1] "bf16"; SURVEY section 8d cfg-2: bf16 MFMA inputs, fp32 accumulate, fp32 master weights / Adam): the six
-    scalars of update_policy against golden G4 within bf16 round-off,
-    the gradients against the fp32 MFMA path (cosine > 0.999 at the 16 384-row minibatch, the critic's O = 1 bias gradient included), and a
-    standalone forward at precision 1 against the fp32 forward."""
-    from apex_amd import engine
-    from apex_amd.vecenv import MIRRORED_OBS, MIRRORED_ACTS, CLOCK_INDS
-    from tools.refprobe.common import MIRRORED_OBS_FULL_CLOCK, MIRRORED_ACTS as MA
-    g = np.load(os.path.join(golden_dir, "g4_update_policy.npz"))
-    for c in range(int(g["n_cases"])):
-        p = f"c{c}_"
-        H = int(g[p + "hidden"]); mirror = bool(g[p + "mirror"])
-        lr = engine.PPOLearner(50, 10, H, dev, fixed_std=np.exp(-1.5), entropy_coeff=float(g[p + "entropy_coeff"]), mirrored_obs=MIRRORED_OBS_FULL_CLOCK, mirrored_acts=MA, precision=1)
-        lr.actor.load_list([g[p + "actor0." + k] for k in ACTOR_KEYS]); lr.critic.load_list([g[p + "critic0." + k] for k in CRITIC_KEYS])
-        old = engine.Mlp(50, H, 10, dev); old.load_list([g[p + "old." + k] for k in ACTOR_KEYS])
-        lr.obs_mean.copy_(torch.tensor(g[p + "obs_mean"])); lr.obs_std.copy_(torch.tensor(g[p + "obs_std"]))
-        obs, act, ret, adv = (torch.tensor(g[p + f"s0_{k}"], device=dev) for k in ("obs", "act", "ret", "adv"))
-        scal = lr.minibatch(obs, act, ret.view(-1), adv.view(-1), old.forward(obs, lr.obs_mean, lr.obs_std), mirror=mirror)
-        ref = g[f"c{c}_scalars"][0]
-        np.testing.assert_allclose(scal[[0, 2, 3]], ref[[0, 2, 3]], rtol=2e-2, atol=2e-3, err_msg="case %d" % c)      # actor loss, critic loss, ratio
-        assert abs(scal[1] - ref[1]) < 1e-6 and abs(scal[4] - ref[4]) < 5e-3 * max(1.0, abs(ref[4]) / 1e-2) and abs(scal[5] - ref[5]) < 2e-2 * max(ref[5], 1e-3)
-    # gradients at the throughput minibatch vs the fp32 path
-    rng = np.random.RandomState(3)
-    B = 16384
-    Ls = [engine.PPOLearner(50, 10, 256, dev, float(np.exp(-1.5)), mirrored_obs=MIRRORED_OBS, mirrored_acts=MIRRORED_ACTS, clock_inds=CLOCK_INDS, precision=pr) for pr in (0, 1)]
-    sc = [0.1, 0.1, 0.05, 0.1, 0.02, 0.1]
-    Wa = [rng.randn(*v.shape).astype(np.float32) * k for v, k in zip(Ls[0].actor.views(), sc)]; Wc = [rng.randn(*v.shape).astype(np.float32) * k for v, k in zip(Ls[0].critic.views(), sc)]
-    obs = torch.tensor(rng.randn(B, 50).astype(np.float32), device=dev); ph = torch.rand(B, device=dev) * 6.28; obs[:, 46] = torch.sin(ph); obs[:, 47] = torch.cos(ph)
-    act = torch.tensor((rng.randn(B, 10) * 0.3).astype(np.float32), device=dev); ret = torch.tensor(rng.randn(B).astype(np.float32), device=dev); adv = torch.tensor(rng.randn(B).astype(np.float32), device=dev)
-    out = []
-    for L_ in Ls:
-        L_.actor.load_list(Wa); L_.critic.load_list(Wc)
-        mu = L_.old_means(obs) + 0.01
-        s_ = L_.minibatch(obs, act, ret, adv, mu, grad_only=True)
-        out.append((s_.copy() if hasattr(s_, "copy") else np.array(s_), L_.actor_g.clone(), L_.critic_g.clone()))
-    np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-2, atol=1e-3)
-    for k in (1, 2):
-        a, b = out[0][k].double(), out[1][k].double()
-        cos = float((a * b).sum() / (a.norm() * b.norm()))
-        assert cos > 0.999, (k, cos)          # measured: actor 0.9997, critic 0.9995
-    nb = Ls[0].critic.n
-    np.testing.assert_allclose(float(out[1][2][nb - 1]), float(out[0][2][nb - 1]), rtol=0.1, atol=1e-3)        # d/d(bias of the critic's output layer) = mean(v - ret): the O = 1 path (a small difference of O(1) terms)
-    net = engine.Mlp(50, 256, 10, dev); net.load_list(Wa)
-    y0 = net.forward(obs[:4096], Ls[0].obs_mean, Ls[0].obs_std)
-    y1, _, _, _ = net.forward(obs[:4096], Ls[0].obs_mean, Ls[0].obs_std, keep=True, precision=1)
-    assert float((y0 - y1).abs().max()) < 2e-2 * float(y0.abs().max()) + 1e-3
-
-
-class _ToyTd3Env:
-    """The toy dynamics of tools/refprobe/gen_golden_td3_loop.py (G20c) as an N-column device env with the CassieVecEnv surface the TD3 driver uses:
-    reset() starts a new scripted episode in every column (episode counter in column order, like the reference's workers run one after the other),
-    step(act) -> (next_obs, reward, done, final_obs); a finished column keeps stepping on harmlessly (the driver ignores it)."""
-    def __init__(self, dev, n, lens):
-        self.device, self.n_envs, self.obs_dim, self.lens, self.k = dev, n, 50, [int(x) for x in lens], 0
-
-    def _obs(self):
-        o = self.x.clone()
-        o[:, 46] = torch.sin(0.2 * self.t); o[:, 47] = torch.cos(0.2 * self.t)
-        return o.float()
-
-    def reset(self):
-        ks = torch.arange(self.k + 1, self.k + 1 + self.n_envs, dtype=torch.float64, device=self.device); self.k += self.n_envs
-        self.L = torch.tensor([self.lens[(int(k) - 1) % len(self.lens)] for k in ks.tolist()], device=self.device)
-        self.t = torch.zeros(self.n_envs, dtype=torch.float64, device=self.device)
-        self.x = torch.cos(torch.arange(50, dtype=torch.float64, device=self.device).view(1, 50) * 0.1 * ks.view(-1, 1))
-        return self._obs()
-
-    def step(self, act):
-        self.t = self.t + 1
-        self.x = 0.9 * self.x + 0.1 * act.double().repeat(1, 5) + 0.01
-        rew = torch.exp(-self.x.abs().mean(1)).float()
-        obs = self._obs()
-        done = (self.t >= self.L).to(torch.uint8)
-        return obs, rew, done, obs.clone()
-
-
 def test_td3_whole_loop_golden_g20c(dev, golden_dir):
     """G20c: three rounds of the reference's synchronous TD3 loop body (parallel_collect_experience -> add_parallel -> train, sync_td3.py:304-313)
     on the toy env, replayed through apex_amd.td3.TD3.reference_round with the captured exploration / sampling / smoothing streams: the

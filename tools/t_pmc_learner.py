@@ -1,4 +1,4 @@
-"""Learner kernels for a PMC pass: 20 actor forwards at 16 384 rows (fused 3-layer kernel), 4 PPO minibatch steps (all fp32 GEMM flavours), then the same in the bf16 mode."""
+"""Learner kernels for a PMC pass: 20 actor forwards at 16 384 rows (fused 3-layer kernel), 4 PPO minibatch steps (all fp32 GEMM flavours)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from apex_amd import engine
@@ -13,12 +13,6 @@ act = (torch.randn(B, 10, generator=g) * 0.3).to(dev); ret = torch.randn(B, gene
 for _ in range(20):
     L.actor.forward(obs, L.obs_mean, L.obs_std)
 mu = L.old_means(obs)
-for _ in range(4):
-    L.minibatch(obs, act, ret, adv, mu, sync=False)
-# the bf16 throughput mode: gemm_bf16_kernel (bf16 MFMA inputs, fp32 accumulate) in the forward and in the minibatch step
-L.precision = 1
-for _ in range(10):
-    L.actor.forward(obs, L.obs_mean, L.obs_std, precision=1)
 for _ in range(4):
     L.minibatch(obs, act, ret, adv, mu, sync=False)
 torch.cuda.synchronize()
