@@ -580,20 +580,17 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_kernel(float* 
 #ifdef APX_WAVETIME      /* experiment build: shader-clock duration of every wave of the step kernel (the launch lasts as long as its slowest wave) */
 __device__ unsigned long long g_wavetime[4096];
 #endif
+// CassieEnv.step (cassie/cassie.py:389-496) of one env on its 16-lane row, state resident in LDS: PD targets from the action, simrate substeps with the per-substep
+// accumulators, phase / time, termination, reward, command resampling.  act10 = the env's ten action entries (HBM row of the action batch for env_step_kernel, LDS words
+// for env_rollout_kernel); returns reward and done flag on the lead lane.  Outputs (observation, reward, done) are the caller's.
 template <bool HF>
-__global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const float* action, float* obs,
-                                                      float* reward, uint8_t* done, float* final_obs) {
-#ifdef APX_WAVETIME
-    const unsigned long long wt0__ = clock64();
-#endif
-    ENV_SETUP
-    load_state(S, st, ist, n);
+__device__ __forceinline__ void env_step_core(const St& S, const Cfg& cfg, int env, bool lead, const float* act10, float& rew_out, int& dn_out) {
     // nothing of the env-step bookkeeping stays in registers across the substeps (the constraint stage needs every one of the 512):
     // the action is re-read at the end, the four per-substep accumulators live in spare hand-off words of the env's LDS region
     constexpr int ACC = c4::WK_ZP2;                     // lfrc, rfrc, lor, ror
     if (lead) {
         for (int u = 0; u < 10; ++u)
-            S(F_PDT + u) = action[(size_t)env * APX_ACT_DIM + u] + kOffset[u] - (cfg.dyn_rand ? S(F_MNOISE + u) : 0.f);     // cassie.py:295-298
+            S(F_PDT + u) = act10[u] + kOffset[u] - (cfg.dyn_rand ? S(F_MNOISE + u) : 0.f);     // cassie.py:295-298
         S.I(I_FLAGS) |= 16; S.I(I_ROWSET) = 0;
         for (int k = 0; k < 4; ++k) S.W(ACC + k) = 0.f;
     }
@@ -620,7 +617,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
     }
     if (lead) {
         float act[10];
-        for (int u = 0; u < 10; ++u) act[u] = action[(size_t)env * APX_ACT_DIM + u];
+        for (int u = 0; u < 10; ++u) act[u] = act10[u];
         const float inv = 1.f / (float)cfg.simrate;
         const float lfrc = S.W(ACC + 0) * inv, rfrc = S.W(ACC + 1) * inv, lor = S.W(ACC + 2) * inv, ror = S.W(ACC + 3) * inv;
         const float height = S(F_QPOS + 2);
@@ -651,6 +648,20 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
             S.I(I_RNG) = (int)r.ctr;
         }
         if (!dn && time >= cfg.max_traj_len) dn = 2;
+        rew_out = rew; dn_out = dn;
+    }
+}
+template <bool HF>
+__global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const float* action, float* obs,
+                                                      float* reward, uint8_t* done, float* final_obs) {
+#ifdef APX_WAVETIME
+    const unsigned long long wt0__ = clock64();
+#endif
+    ENV_SETUP
+    load_state(S, st, ist, n);
+    float rew = 0.f; int dn = 0;
+    env_step_core<HF>(S, cfg, env, lead, action + (size_t)env * APX_ACT_DIM, rew, dn);
+    if (lead) {
         reward[env] = rew;
         done[env] = (uint8_t)dn;
         write_obs(S, cfg, obs + (size_t)env * cfg.obs_dim);
@@ -660,6 +671,143 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_step_kernel(float* s
 #ifdef APX_WAVETIME
     if (threadIdx.x == 0 && blockIdx.x < 4096) g_wavetime[blockIdx.x] = clock64() - wt0__;
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------ the T-step rollout as ONE launch (round 5)
+// PPO.sample's inner loop (rl/algos/ppo.py:160-184) - actor forward, action = mean + sigma * noise, env step, auto-reset - for T steps inside one kernel.  Envs never
+// interact and the policy is fixed during a rollout, so nothing orders one wave against another: a wave steps ITS four envs through all T steps at its own pace.  What the
+// per-step launches of rounds 1-4 paid between two env steps - the masked reset launch (73 us, of which 45 are the latency of the settle substep of ~14 envs), the actor
+// forward launch (27 us) and the launch gaps, 113 us of every 2 180 - is gone: a restart costs its settle substep to the ONE wave that holds the finished env, the forward
+// is 4 rows of fp32 VALU work per wave (~ 15 us), and there is no grid-wide join until the rollout ends.
+//
+// Policy forward of the wave's four envs (Gaussian_FF_Actor, rl/policies/actor.py:142-215): lane n carries unit 64 g + n of ALL FOUR envs, an input h[e][k] reaches the
+// lanes as a scalar operand (v_readlane), the weights stream from L2 in k-major order (Wt[k][n]: one coalesced 256-B row segment per load; re-laid once per rollout by
+// transpose_kernel).  Plain sequential-k fp32 fma per unit: not the MFMA forward's summation order - the rollout's means differ from mlp_fused_fwd_kernel's by round-off
+// (1e-7), which is why PPO recomputes the old-policy means of the batch with the learner's own forward after the rollout (apex_amd/ppo.py).
+constexpr int WK_ACT = c4::WK_QACC + 20;      // the env's current action (10 words): env_step_core reads it at both ends of the step
+static_assert(WK_ACT >= c4::WK_DUMMY + 3 && WK_ACT + 10 <= c4::WK_QACC + NV, "action words inside the spare tail of WK_QACC");
+struct RolloutArgs {
+    const float *Wt0, *b0, *Wt1, *b1, *Wt2, *b2;      // k-major weights [K][N], biases
+    const float *mean, *stdv;                          // observation normaliser (may be NULL)
+    float sigma; const float* noise;                   // [T, n, A] or NULL
+    int H, T;
+    float *obs_grid, *act_grid, *mu_grid, *rew_grid; uint8_t* done_grid; float *fin_grid, *obs_next;
+    float* rst; int* rst_int;                          // the reset ring, writable (an image missing from it is computed in place)
+    Cfg cfg;                                           // a copy of the launch's Cfg for the out-of-line restart (rollout_restart)
+};
+template <int KG, int NG>
+__device__ __forceinline__ void ff_layer4(const float* __restrict__ Wt, const float* __restrict__ bias, int K, int N, const float (&hin)[KG][4], float (&hout)[NG][4], bool relu) {
+    const int lane = threadIdx.x;
+    float acc[NG][4];
+    c4::sfor<0, NG>([&](auto G) {
+        const int nn = 64 * G + lane;
+        const float b = nn < N ? bias[nn] : 0.f;
+        c4::sfor<0, 4>([&](auto E) { acc[G][E] = b; });
+    });
+    c4::sfor<0, KG>([&](auto Kg) {
+        constexpr int kg = Kg;
+        const int kend = K - 64 * kg < 64 ? K - 64 * kg : 64;
+#pragma unroll 4
+        for (int kk = 0; kk < kend; ++kk) {
+            const float* wr = Wt + (size_t)(64 * kg + kk) * N;
+            float w[NG];
+            c4::sfor<0, NG>([&](auto G) { const int nn = 64 * G + lane; w[G] = nn < N ? wr[nn] : 0.f; });
+            c4::sfor<0, 4>([&](auto E) {
+                const float hk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hin[kg][E]), kk));
+                c4::sfor<0, NG>([&](auto G) { acc[G][E] = fmaf(hk, w[G], acc[G][E]); });
+            });
+        }
+    });
+    c4::sfor<0, NG>([&](auto G) { c4::sfor<0, 4>([&](auto E) { hout[G][E] = relu ? fmaxf(acc[G][E], 0.f) : acc[G][E]; }); });
+}
+__device__ __forceinline__ const RolloutArgs* ra_ptr(const RolloutArgs* p) { asm volatile("" : "+s"(p)); return p; }
+__device__ __forceinline__ lfloat* env_region(int e) { return (lfloat*)apx_lds4 + e * L4_ES; }
+// the restart of the finished envs of a wave inside env_rollout_kernel (all 64 lanes call; `fin` = this lane's env restarts)
+template <bool HF>
+__device__ __noinline__ void rollout_restart(St S, const RolloutArgs* rap, float* st, int* ist, int n, bool fin) {
+    const Cfg cfg = rap->cfg;
+    const int l = threadIdx.x & 15, env = S.env;
+    const bool lead = l == 0;
+    lfloat* stage = S.p + L4_ROWS;
+    const int ep = S.I(I_EPISODE) + 1, slot = ep % RST_K;
+    const bool miss = fin && rap->rst_int[(size_t)(2 * slot) * n + env] != ep;
+    if (__builtin_amdgcn_ballot_w64(miss) != 0ull) {      // the ring does not hold the episode (more resets of one env than prepared images): compute the image in place, like part 0 of env_reset_kernel
+        if (miss) {
+            store_state(S, st, ist, n);                    // the env's own state waits in HBM while its LDS region is the working copy
+            if (lead) env_reset_draws(S, cfg, ep);
+            c4::wsync();
+            if (cfg.dyn_rand) setconst_lane(S);
+            sim_step_pd<HF>(S, cfg, 0);                    // forward pass only
+            c4::wsync();
+            float* img = rap->rst + (size_t)slot * F_TOTAL * n + env;
+            for (int f = l; f < F_TOTAL; f += 16) img[(size_t)f * n] = S(f);
+            if (lead) { rap->rst_int[(size_t)(2 * slot + 1) * n + env] = S.I(I_PHASE); rap->rst_int[(size_t)(2 * slot) * n + env] = ep; }
+            __threadfence();
+            load_state(S, st, ist, n);
+        }
+    }
+    if (fin) {
+        env_restart_head(S, cfg, n);
+        sim_step_pd<HF>(S, cfg, 1);                        // cassie.py:665 (stale pd_in_t)
+        if (lead) env_reset_finish(S, cfg);
+        c4::wsync();
+        if (lead) write_obs(S, cfg, (float*)stage);
+    }
+    c4::wsync();
+}
+template <bool HF>
+__global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_rollout_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const RolloutArgs* rap) {
+    // The rollout's pointers are read from the argument block where they are used (through a pointer the optimiser cannot see through: not hoisted), not carried through the substeps: the constraint stage needs every
+    // register, and two dozen loop-invariant pointers in SGPRs spilled into it (v_writelane / scratch inside the 2 kHz loop)
+#define RA(f) (ra_ptr(rap)->f)
+    ENV_SETUP
+    load_state(S, st, ist, n);
+    const int D = cfg.obs_dim, A = APX_ACT_DIM, lane = threadIdx.x;
+    lfloat* stage = S.p + L4_ROWS;      // the env's observation (<= 64 words) between two steps: the row store is free at a step boundary
+    for (int k = l; k < D; k += 16) stage[k] = RA(obs_grid)[(size_t)env * D + k];      // t = 0: the caller's current observation
+    c4::wsync();
+    for (int t = 0; t < RA(T); ++t) {
+        {   // ---- actor forward of the wave's four envs
+            float hin[1][4], h1[4][4], h2[4][4], mu[1][4];
+            const float mn = (RA(mean) && lane < D) ? RA(mean)[lane] : 0.f, sd = (RA(stdv) && lane < D) ? RA(stdv)[lane] : 1.f;
+            c4::sfor<0, 4>([&](auto E) { const float v = lane < D ? (env_region(E) + L4_ROWS)[lane] : 0.f; hin[0][E] = lane < D ? (v - mn) / sd : 0.f; });
+            ff_layer4<1, 4>(RA(Wt0), RA(b0), D, RA(H), hin, h1, true);
+            ff_layer4<4, 4>(RA(Wt1), RA(b1), RA(H), RA(H), h1, h2, true);
+            ff_layer4<4, 1>(RA(Wt2), RA(b2), RA(H), A, h2, mu, false);
+            if (lane < A) c4::sfor<0, 4>([&](auto E) {
+                const int ee = blk * L4_EPW + E;
+                const size_t o = ((size_t)t * n + ee) * A + lane;
+                const float a = mu[0][E] + (RA(noise) ? RA(sigma) * RA(noise)[o] : 0.f);
+                RA(mu_grid)[o] = mu[0][E]; RA(act_grid)[o] = a;
+                (env_region(E) + L4_WK + WK_ACT)[lane] = a;
+            });
+            c4::wsync();
+        }
+        // ---- env step
+        float rew = 0.f; int dn = 0;
+        env_step_core<HF>(S, cfg, env, lead, (const float*)&S.W(WK_ACT), rew, dn);
+        if (lead) {
+            RA(rew_grid)[(size_t)t * n + env] = rew; RA(done_grid)[(size_t)t * n + env] = (uint8_t)dn;
+            write_obs(S, cfg, (float*)stage);
+            S.W(c4::WK_MISC + 7) = (float)dn;
+        }
+        c4::wsync();
+        const bool fin = S.W(c4::WK_MISC + 7) != 0.f;
+        if (fin) for (int k = l; k < D; k += 16) RA(fin_grid)[((size_t)t * n + env) * D + k] = stage[k];
+        // ---- auto-reset of the finished envs (CassieEnv.reset, cassie.py:523-680): the restart part of env_reset_kernel, on this wave alone, OUT OF LINE - inlined, the
+        // scalars it needs (ring pointers, seeds, the estimator's lifetime ...) stayed live through the 2 kHz loop above and spilled into it
+        if (__builtin_amdgcn_ballot_w64(fin) != 0ull) rollout_restart<HF>(S, rap, st, ist, n, fin);
+        float* on = (t + 1 < RA(T) ? RA(obs_grid) + (size_t)(t + 1) * n * D : RA(obs_next)) + (size_t)env * D;
+        for (int k = l; k < D; k += 16) on[k] = stage[k];
+    }
+    store_state(S, st, ist, n);
+#undef RA
+}
+__global__ void transpose_kernel(const float* __restrict__ W /* [N][K] */, float* __restrict__ Wt /* [K][N] */, int N, int K) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * K) return;
+    const int k = i / N, nn = i - k * N;
+    Wt[i] = W[(size_t)nn * K + k];
 }
 
 // action == NULL: raw substeps with the current pd targets (tests): n_sub x cassie_sim_step_pd.
@@ -802,10 +950,11 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     // up to 2048 envs leave half of the SIMDs idle during an env step: the images of the restarted envs' next episodes are computed there (apx_env_set_refill overrides)
     e->refill = getenv("APX_REFILL") ? atoi(getenv("APX_REFILL")) != 0 : e->n <= 2048;
     e->refill_pending = 0; e->refill_due = 0; e->side = nullptr; e->ev_reset = nullptr; e->ev_refill = nullptr;
+    e->pol_wt = nullptr; e->pol_wt_n = 0; e->roll_launches = 0; e->roll_ms = 0.0;
     const Cfg c = make_cfg(*e);
     hipLaunchKernelGGL(env_init_kernel, dim3(e->n / 64), dim3(64), 0, 0, e->st, e->ist, e->n, c);
     APX_LAUNCH_CHECK();
-    for (const void* fn : {(const void*)env_step_kernel<false>, (const void*)env_step_kernel<true>, (const void*)env_reset_kernel<false>, (const void*)env_reset_kernel<true>, 
+    for (const void* fn : {(const void*)env_rollout_kernel<false>, (const void*)env_rollout_kernel<true>, (const void*)env_step_kernel<false>, (const void*)env_step_kernel<true>, (const void*)env_reset_kernel<false>, (const void*)env_reset_kernel<true>, 
                            (const void*)env_substep_kernel<false>, (const void*)env_substep_kernel<true>, (const void*)env_reset_for_test_kernel<false>,
                            (const void*)env_reset_for_test_kernel<true>})
         APX_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
@@ -819,7 +968,7 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
 extern "C" int apx_env_destroy(apx_env_t* e) {
     if (!e) return APX_OK;
     if (e->side) (void)hipStreamSynchronize((hipStream_t)e->side);      // a ring refill in flight on the env's own stream still reads the state and writes the ring
-    (void)hipFree(e->st); (void)hipFree(e->ist); (void)hipFree(e->wk); (void)hipFree(e->hf); (void)hipFree(e->rst); (void)hipFree(e->rst_int);
+    (void)hipFree(e->pol_wt); (void)hipFree(e->st); (void)hipFree(e->ist); (void)hipFree(e->wk); (void)hipFree(e->hf); (void)hipFree(e->rst); (void)hipFree(e->rst_int);
     for (int i = 0; i < e->ev_cap; ++i) (void)hipEventDestroy((hipEvent_t)e->ev[i]);
     free(e->ev);
     if (e->side) (void)hipStreamDestroy((hipStream_t)e->side);
@@ -1014,6 +1163,34 @@ extern "C" int apx_rollout(apx_env_t* e, const float* actor, int H, const float*
     APX_REQUIRE(e && actor && obs_grid && act_grid && mu_grid && rew_grid && done_grid && fin_grid && obs_next && T > 0, "rollout arguments");
     const int D = make_cfg(*e).obs_dim, A = APX_ACT_DIM;
     const long N = e->n;
+    {   // ONE launch for the whole rollout (env_rollout_kernel) for the reference's 2 x 256 actor; APX_ROLLOUT_STEPWISE=1 or a stream under graph capture keep the per-step launches
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+        static const bool stepwise = getenv("APX_ROLLOUT_STEPWISE") && atoi(getenv("APX_ROLLOUT_STEPWISE")) != 0;
+        if (H == 256 && D <= 64 && !stepwise && !capturing) {
+            const long nw = (long)D * H + (long)H * H + (long)H * A;
+            if (e->pol_wt_n != nw) { (void)hipFree(e->pol_wt); e->pol_wt = nullptr; APX_HIP(hipMalloc(&e->pol_wt, sizeof(float) * nw + sizeof(RolloutArgs) + 16)); e->pol_wt_n = nw; }
+            { const int rc = refill_join(e, stream); if (rc != APX_OK) return rc; }      // a ring refill of an earlier stepwise call
+            e->refill_due = 0;
+            const float* W0 = actor; const float* b0 = W0 + (long)H * D; const float* W1 = b0 + H; const float* b1 = W1 + (long)H * H; const float* W2 = b1 + H; const float* b2 = W2 + (long)A * H;
+            float* Wt0 = e->pol_wt; float* Wt1 = Wt0 + (long)D * H; float* Wt2 = Wt1 + (long)H * H;
+            hipLaunchKernelGGL(transpose_kernel, dim3(apx_cdiv((long)H * D, 256)), dim3(256), 0, (hipStream_t)stream, W0, Wt0, H, D);
+            hipLaunchKernelGGL(transpose_kernel, dim3(apx_cdiv((long)H * H, 256)), dim3(256), 0, (hipStream_t)stream, W1, Wt1, H, H);
+            hipLaunchKernelGGL(transpose_kernel, dim3(apx_cdiv((long)A * H, 256)), dim3(256), 0, (hipStream_t)stream, W2, Wt2, A, H);
+            APX_LAUNCH_CHECK();
+            const RolloutArgs ra{Wt0, b0, Wt1, b1, Wt2, b2, obs_mean, obs_std, sigma, noise, H, T, obs_grid, act_grid, mu_grid, rew_grid, done_grid, fin_grid, obs_next, e->rst, e->rst_int, make_cfg(*e)};
+            RolloutArgs* rap = (RolloutArgs*)(e->pol_wt + nw);      // the argument block lives behind the weights (the kernel reads it field by field where it needs one)
+            APX_HIP(hipMemcpyAsync(rap, &ra, sizeof(ra), hipMemcpyHostToDevice, (hipStream_t)stream));
+            const bool timed = e->timing && e->ev_n + 2 <= e->ev_cap;
+            if (timed) APX_HIP(hipEventRecord((hipEvent_t)e->ev[e->ev_n], (hipStream_t)stream));
+            if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_rollout_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), (const RolloutArgs*)rap);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_rollout_kernel<false>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), (const RolloutArgs*)rap);
+            APX_LAUNCH_CHECK();
+            if (timed) { APX_HIP(hipEventRecord((hipEvent_t)e->ev[e->ev_n + 1], (hipStream_t)stream)); e->ev_n += 2; }
+            e->roll_launches += 1;
+            return APX_OK;
+        }
+    }
     for (int t = 0; t < T; ++t) {
         float* obs = obs_grid + (size_t)t * N * D; float* mu = mu_grid + (size_t)t * N * A; float* act = act_grid + (size_t)t * N * A;
         const float* nz = noise ? noise + (size_t)t * N * A : nullptr;

@@ -44,6 +44,8 @@ struct apx_env {
     // in-rollout refill of the reset ring (apx_env_set_refill): after the auto-reset of a step, part 0 of env_reset_kernel for the next two episodes of the envs that just
     // restarted runs on the env's own side stream, next to the following env step; the next reset launch waits for it
     int refill, refill_pending, refill_due; void* side; void* ev_reset; void* ev_refill;
+    // apx_rollout as one launch (env_rollout_kernel): the actor's weights in k-major order, re-laid at the start of every rollout; rollouts run that way, launches timed
+    float* pol_wt; long pol_wt_n; long roll_launches; double roll_ms;
 };
 
 // global-address-space pointers: St is passed by value into a non-inlined device function, where the compiler could

@@ -171,6 +171,10 @@ class PPO:
             check(load().apx_rollout(env._h, _p(L.actor.params), L.actor.H, _p(L.obs_mean), _p(L.obs_std), float(self.fixed_std * self.curr_anneal),
                                      _p(self.noise), T, _p(self.b_obs), _p(self.b_act), _p(self.b_mu), _p(self.b_rew), _p(self.b_done), _p(self.b_fin),
                                      _p(self.obs), _stream()))
+            # The one-launch rollout (env_rollout_kernel) computes the policy means with a per-wave fp32 forward whose summation order is not the learner's MFMA forward:
+            # the old-policy means the update compares against (ppo.py:287-291: the ratio is 1 at the first optimiser step) are recomputed with the learner's own forward
+            # over the whole grid - one launch, 0.3 % of an iteration - so that old and new log-probabilities come from the same arithmetic
+            L.actor.forward(self.b_obs.view(T * self.N, self.D), L.obs_mean, L.obs_std, out=self.b_mu.view(T * self.N, 10))
             L.critic.forward(self.b_obs.view(T * self.N, self.D), out=self.b_val.view(T * self.N, 1))
             return
         for t in range(T):      # every kernel writes straight into the rollout grids: no staging copies

@@ -10,6 +10,12 @@ I_TOTAL = 10         # int fields per env (env_state.h: enum IField)
 EST_REC = 168          # state-estimator record per env (estimator_lane.h): read + written once per env step at least (it moves through L2 every substep)
 ENV_STEP_BYTES = 2 * 4 * (F_TOTAL + I_TOTAL + EST_REC) + 4 * 10 + 4 * 50 + 4 + 1
 
+
+def rollout_bytes_per_env(T, D=50, A=10):
+    """Algorithmic HBM bytes per env of ONE env_rollout_kernel launch (round 5: T env steps per launch): the persistent state and the estimator record cross HBM once per
+    launch instead of once per step; per step: observation out (the next step reads it from LDS), mean + action out, noise in, reward + done out."""
+    return 2 * 4 * (F_TOTAL + I_TOTAL + EST_REC) + 4 * D + T * (4 * D + 2 * 4 * A + 4 * A + 4 + 1)
+
 # per-substep fp32 op count (multiply-add = 2), typical walking state: 12 equality rows + 2 contacts (8 rows) = 20 rows
 _FK = 25 * 95 + 32 * 12
 _INERTIA = 25 * 110

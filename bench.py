@@ -64,8 +64,8 @@ def kernel_source_hash():
     return h.hexdigest()[:12]
 
 
-def _pmc_traffic_bytes():
-    """HBM bytes per env_step_kernel launch from the committed rocprofv3 PMC passes (profiles/r05_env_step_pmc_hbm.txt, 4096 envs): 2 x
+def _pmc_traffic_bytes(kernel="env_step_kernel"):
+    """HBM bytes per launch of `kernel` (env_step_kernel: one env step; env_rollout_kernel: a T-step rollout) from the committed rocprofv3 PMC passes (profiles/r05_env_step_pmc_hbm.txt, 4096 envs): 2 x
     FETCH_SIZE (gfx950 correction of the microarchitecture guide) + WRITE_SIZE, both in KB.  The profile records the hash of the kernel
     sources it was taken on (tools/profile_round.sh); a profile of another kernel is NOT quoted: None + a note on stderr."""
     import re
@@ -77,8 +77,8 @@ def _pmc_traffic_bytes():
             print("bench.py: %s was taken on another build of the env kernel (%s vs %s): roofline.traffic = null; re-run tools/profile_round.sh" % (
                 path, m.group(1) if m else "no hash", kernel_source_hash()), file=sys.stderr)
             return None
-        f = float(re.search(r"env_step_kernel[^:]*: .*?FETCH_SIZE=([0-9.e+]+)", txt).group(1))
-        w = float(re.search(r"env_step_kernel[^:]*: .*?WRITE_SIZE=([0-9.e+]+)", txt).group(1))
+        f = float(re.search(kernel + r"[^:]*: .*?FETCH_SIZE=([0-9.e+]+)", txt).group(1))
+        w = float(re.search(kernel + r"[^:]*: .*?WRITE_SIZE=([0-9.e+]+)", txt).group(1))
         return int((2.0 * f + w) * 1024)
     except Exception:
         return None
@@ -296,6 +296,11 @@ def main():
         k_total_ms, k_launches = env.kernel_timing_read(reset=True)
     env.kernel_timing(False)
     k_ms = k_total_ms / max(k_launches, 1)
+    # round 5: apx_rollout is ONE launch per T-step rollout (env_rollout_kernel: policy forward, env step and restart of every step inside); the per-step launches
+    # (env_step_kernel) remain behind APX_ROLLOUT_STEPWISE=1, graph capture and the non-2x256 shapes
+    one_launch = k_launches <= a.steps
+    spl = a.rollout_len if one_launch else 1                       # env steps per launch
+    k_name = "env_rollout_kernel" if one_launch else "env_step_kernel"
 
     # MFMA side: the actor's 3-layer fp32 forward on one minibatch (50 -> 256 -> 256 -> 10), events on the launch stream
     mb_rows = min(a.minibatch, a.rollout_len * a.n_envs)
@@ -313,8 +318,8 @@ def main():
     if rank == 0:
         steps_total = a.steps * a.rollout_len * a.n_envs * world
         from apex_amd import roofline
-        bytes_per_env_step = roofline.ENV_STEP_BYTES
-        achieved = bytes_per_env_step * a.n_envs / (k_ms * 1e-3) / 1e9
+        bytes_per_env_launch = roofline.rollout_bytes_per_env(a.rollout_len) if one_launch else roofline.ENV_STEP_BYTES
+        achieved = bytes_per_env_launch * a.n_envs / (k_ms * 1e-3) / 1e9
         cpu = None
         if not a.no_cpu_baseline and world == 1:      # the CPU baseline is timed on rank 0 at N = 1 only; it also re-measures the flop count
             cpu = cpu_baseline(n_envs=a.n_envs, rollout_len=a.rollout_len, minibatch=a.minibatch, epochs=a.epochs)
@@ -337,13 +342,14 @@ def main():
             # the binding bound of the dominant kernel is the fp32 vector pipe (HBM traffic is 1.1 x the algorithmic bytes and
             # < 0.1 % of the peak): achieved = instrumented flops of the CPU restatement per env step x envs / launch time.  The HBM view
             # north_star asks for is reported beside it.
-            "roofline": {"kernel": "env_step_kernel", "bound": "valu", "achieved": round(flop_step * a.n_envs / (k_ms * 1e-3) / 1e12, 4),
-                         "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop_step * a.n_envs / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 6),
+            "roofline": {"kernel": k_name, "env_steps_per_launch_per_env": spl, "bound": "valu", "achieved": round(flop_step * a.n_envs * spl / (k_ms * 1e-3) / 1e12, 4),
+                         "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flop_step * a.n_envs * spl / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 6),
                          # the same launch time against the KERNEL's own (tree-sparse) operation count: the dense oracle executes ~13 % more operations than the kernel needs
-                         "frac_sparse": round(roofline.ENV_STEP_FLOP * a.n_envs / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 6), "flop_per_env_step_sparse": roofline.ENV_STEP_FLOP,
-                         "traffic": _pmc_traffic_bytes(), "issue": _pmc_issue(flop_step), "ms_per_launch": round(k_ms, 4), "launches_timed": k_launches,
+                         "frac_sparse": round(roofline.ENV_STEP_FLOP * a.n_envs * spl / (k_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 6), "flop_per_env_step_sparse": roofline.ENV_STEP_FLOP,
+                         # traffic: PMC bytes per launch of THIS kernel; issue: the SQ counters of env_step_kernel (the same substep code, one env step per launch: tools/t_pmc.py)
+                         "traffic": _pmc_traffic_bytes(k_name), "issue": _pmc_issue(flop_step), "ms_per_launch": round(k_ms, 4), "ms_per_env_step": round(k_ms / spl, 4), "launches_timed": k_launches,
                          "flop_per_env_step": flop_step, "flop_source": "oracle-equivalent flops: instrumented count of the dense fp64 restatement oracle/cassie_phys.cpp (oracle.sim.count_flops); frac_sparse uses the hand count of the kernel's tree-sparse formulation",
-                         "hbm": {"bytes_per_env_step": bytes_per_env_step, "achieved_GBps": round(achieved, 3), "peak_GBps": HBM_PEAK_GBS, "frac": round(achieved / HBM_PEAK_GBS, 6)},
+                         "hbm": {"bytes_per_env_per_launch": bytes_per_env_launch, "achieved_GBps": round(achieved, 3), "peak_GBps": HBM_PEAK_GBS, "frac": round(achieved / HBM_PEAK_GBS, 6)},
                          "mlp_forward_mfma": {"what": "actor forward, %d x (50-256-256-10), fp32 MFMA (v_mfma_f32_32x32x2_f32), one fused launch (input normalisation + 3 layers, activations in LDS)" % mb_rows,
                                               "ms": round(mlp_ms, 4), "achieved_tflops": round(mlp_flop / (mlp_ms * 1e-3) / 1e12, 2),
                                               "peak_tflops": VALU_PEAK_TFLOPS, "frac": round(mlp_flop / (mlp_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)}},

@@ -384,6 +384,34 @@ def test_mirror_loss_uses_the_env_clock_columns_min_profile(dev):
     assert abs(0.4 * float(((mu - mir0) ** 2).mean()) - want) > 1e-3 * want
 
 
+class _ToyTd3Env:
+    """The toy dynamics of tools/refprobe/gen_golden_td3_loop.py (G20c) as an N-column device env with the CassieVecEnv surface the TD3 driver uses:
+    reset() starts a new scripted episode in every column (episode counter in column order, like the reference's workers run one after the other),
+    step(act) -> (next_obs, reward, done, final_obs); a finished column keeps stepping on harmlessly (the driver ignores it)."""
+    def __init__(self, dev, n, lens):
+        self.device, self.n_envs, self.obs_dim, self.lens, self.k = dev, n, 50, [int(x) for x in lens], 0
+
+    def _obs(self):
+        o = self.x.clone()
+        o[:, 46] = torch.sin(0.2 * self.t); o[:, 47] = torch.cos(0.2 * self.t)
+        return o.float()
+
+    def reset(self):
+        ks = torch.arange(self.k + 1, self.k + 1 + self.n_envs, dtype=torch.float64, device=self.device); self.k += self.n_envs
+        self.L = torch.tensor([self.lens[(int(k) - 1) % len(self.lens)] for k in ks.tolist()], device=self.device)
+        self.t = torch.zeros(self.n_envs, dtype=torch.float64, device=self.device)
+        self.x = torch.cos(torch.arange(50, dtype=torch.float64, device=self.device).view(1, 50) * 0.1 * ks.view(-1, 1))
+        return self._obs()
+
+    def step(self, act):
+        self.t = self.t + 1
+        self.x = 0.9 * self.x + 0.1 * act.double().repeat(1, 5) + 0.01
+        rew = torch.exp(-self.x.abs().mean(1)).float()
+        obs = self._obs()
+        done = (self.t >= self.L).to(torch.uint8)
+        return obs, rew, done, obs.clone()
+
+
 def test_td3_whole_loop_golden_g20c(dev, golden_dir):
     """G20c: three rounds of the reference's synchronous TD3 loop body (parallel_collect_experience -> add_parallel -> train, sync_td3.py:304-313)
     on the toy env, replayed through apex_amd.td3.TD3.reference_round with the captured exploration / sampling / smoothing streams: the

@@ -603,8 +603,9 @@ def test_apx_rollout_equals_the_stepwise_loop(dev):
     b = mk()
     b.noise_fn = lambda t, out: out.copy_(noise[t])          # the Python loop, replaying the same draws
     b.sample()
-    assert torch.equal(a.b_obs[0], b.b_obs[0]) and torch.equal(a.b_mu[0], b.b_mu[0])
-    np.testing.assert_allclose(a.b_act.cpu().numpy(), (a.b_mu + a.fixed_std * noise).cpu().numpy(), rtol=0, atol=2e-7)
+    assert torch.equal(a.b_obs[0], b.b_obs[0]) and torch.equal(a.b_mu[0], b.b_mu[0])      # (b_mu: the learner's forward over the recorded observations on both sides)
+    # the action inside the one-launch rollout comes from the per-wave forward (sequential-k fp32, not the MFMA summation order): mean + sigma * noise to round-off
+    np.testing.assert_allclose(a.b_act.cpu().numpy(), (a.b_mu + a.fixed_std * noise).cpu().numpy(), rtol=0, atol=3e-6)
     for t in range(1, 3):      # (a flipped encoder count moves a FIR-filtered motor velocity by a few 1e-2: allow a handful of such entries)
         close = np.isclose(a.b_obs[t].cpu().numpy(), b.b_obs[t].cpu().numpy(), rtol=0, atol=5e-4 * t)
         # (the largest single entry is an acceleration or a FIR velocity of a robot whose contact switched one substep earlier: m/s^2 scale - the differing-row-set
@@ -616,6 +617,55 @@ def test_apx_rollout_equals_the_stepwise_loop(dev):
     na, nb = int((a.b_done != 0).sum()), int((b.b_done != 0).sum())
     assert na > 256 and abs(na - nb) <= 0.05 * na                                # episodes ended and restarted inside the call, at the same rate
     assert torch.isfinite(a.b_obs).all() and torch.isfinite(a.b_val).all()
+
+
+def test_one_launch_rollout_restarts_match_the_stepwise_resets(dev):
+    """The auto-reset INSIDE env_rollout_kernel (round 5: the whole T-step rollout is one launch; a finished env restarts on its own wave - ring image or, when the ring does
+    not hold the episode, the image computed in place - instead of in a masked env_reset_kernel launch) against the per-step launches (APX_ROLLOUT_STEPWISE=1) on a
+    horizon of ONE step: every env restarts after every step, so every step of both runs starts one settle substep behind a reset of the same (seed, env, episode) and the
+    two runs cannot drift apart.  No image is prepared: from the third restart of an env on, both ring slots are stale and the in-kernel image path runs.  Done flags
+    bit-equal, observations and rewards equal up to the round-off of two inlined copies of the substep (population rule for the FIR velocities: one encoder count)."""
+    import os, subprocess, sys
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd.ppo import PPO
+    def run():
+        env = CassieVecEnv(n_envs=256, seed=9, max_traj_len=1)
+        args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=1024, epochs=1, num_steps=256 * 8, max_traj_len=1,
+                    max_grad_norm=0.05, mirror=True, std_dev=-1.5, seed=0)
+        a = PPO(args, "/tmp/apx_test_unused", env); a.init_networks(0); a.normalization_params(256 * 20)
+        a.prepare_resets = False
+        a.sample()
+        return a
+    a = run()
+    assert (a.b_done == 2).all() and int(a.env.get_field("reset_miss")[0, 0]) == 0
+    ep = a.env.get_field("ints")[:, 9]
+    assert int(ep.min()) >= 8                                   # eight restarts per env: the ring (2 slots) was outrun
+    # the stepwise twin in a fresh process (the switch is read once per process)
+    code = ("import sys, torch; sys.path.insert(0, %r); import tests.test_gpu_ppo as T; a = T._stepwise_twin(); torch.save(dict(obs=a.b_obs.cpu(), rew=a.b_rew.cpu(), done=a.b_done.cpu(), act=a.b_act.cpu()), sys.argv[1])"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = "/tmp/apx_stepwise_twin.pt"
+    r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, APX_ROLLOUT_STEPWISE="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    b = torch.load(out)
+    assert torch.equal(a.b_done.cpu(), b["done"])
+    for t in range(a.T):
+        d = (a.b_obs[t].cpu() - b["obs"][t]).abs().numpy()
+        close = d <= 3e-4
+        assert close.mean() > 0.99 and d.max() < 0.2, (t, close.mean(), d.max())      # (a flipped encoder count moves the FIR velocities of that env: 0.5 % of the entries at t = 3)
+        dr = (a.b_rew[t].cpu() - b["rew"][t]).abs().numpy()
+        assert (dr <= 2e-3).mean() > 0.99 and dr.max() < 0.05, (t, dr.max())
+
+
+def _stepwise_twin():
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd.ppo import PPO
+    env = CassieVecEnv(n_envs=256, seed=9, max_traj_len=1)
+    args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=1024, epochs=1, num_steps=256 * 8, max_traj_len=1,
+                max_grad_norm=0.05, mirror=True, std_dev=-1.5, seed=0)
+    a = PPO(args, "/tmp/apx_test_unused", env); a.init_networks(0); a.normalization_params(256 * 20)
+    a.prepare_resets = False
+    a.sample()
+    return a
 
 
 def test_td3_async_collection_and_updates_on_two_streams(dev, tmp_path):
