@@ -1690,12 +1690,18 @@ extern "C" int apx_ppo_minibatch(const apx_ppo_args* a, void* stream) {
     APX_REQUIRE(a->workspace && a->workspace_bytes >= apx_ppo_workspace_bytes(a->mb, a->D, a->H, a->A), "workspace");
     APX_REQUIRE(a->scalars_out, "scalars_out");
     APX_REQUIRE((a->obs_sign_perm == nullptr) == (a->act_sign_perm == nullptr), "mirror tables");
+    APX_REQUIRE(a->grad_only >= 0 && a->grad_only <= 3, "grad_only: 0 full step, 1 gradients only, 2 / 3 gradients in two calls (actor half first)");
     hipStream_t s = (hipStream_t)stream;
     const long mb = a->mb;
     const int D = a->D, H = a->H, A = a->A;
     const bool mirror = a->obs_sign_perm != nullptr;
     PpoWs w(a->workspace, mb, D, H, A);
     const size_t na = apx_mlp_param_count(D, H, A), nc = apx_mlp_param_count(D, H, 1);
+    if (a->grad_only == 3) {      // second call of the two-call gradient form: the critic's backward on the activations the first call left in the workspace
+        GradParts parts{w.parts, 6 * GRAD_PART_FLOATS, 0, {}, 0};
+        APX_TRY(mlp_backward_impl(a->critic, a->critic_grad, D, H, 1, w.xr, w.c1, w.c2, w.dv, mb, w.dh2, w.dh1, s, &parts));
+        return grad_reduce(parts, s);
+    }
     // forwards: pi(s) and pi(M_s s) as ONE pass over 2 mb rows
     const long ma = mirror ? 2 * mb : mb;
     if (a->critic_grad == a->actor_grad + na) {      // one flat gradient buffer (engine.PPOLearner): clears, gather and mirror in one launch
@@ -1725,6 +1731,7 @@ extern "C" int apx_ppo_minibatch(const apx_ppo_args* a, void* stream) {
     // backwards
     GradParts parts{w.parts, 6 * GRAD_PART_FLOATS, 0, {}, 0};
     APX_TRY(mlp_backward_impl(a->actor, a->actor_grad, D, H, A, w.xn, w.a1, w.a2, w.dmu, ma, w.dh2, w.dh1, s, &parts));      // both instances: 2 mb rows
+    if (a->grad_only == 2) return grad_reduce(parts, s);      // the actor's gradient is final: the caller starts its all-reduce and comes back with grad_only = 3 for the critic's half
     APX_TRY(mlp_backward_impl(a->critic, a->critic_grad, D, H, 1, w.xr, w.c1, w.c2, w.dv, mb, w.dh2, w.dh1, s, &parts));
     APX_TRY(grad_reduce(parts, s));                     // the K-chunk slabs of the six weight gradients -> the flat gradient, one launch
     if (a->grad_only) return APX_OK;

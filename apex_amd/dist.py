@@ -47,6 +47,26 @@ def allreduce_mean_(flat, group=None, world=None):
     return flat
 
 
+def allreduce_begin(flat, group=None):
+    """Start the sum all-reduce of `flat` (async handle): the collective waits for the work already enqueued on the current stream and runs on the backend's own
+    stream while the caller keeps enqueueing (PPO.update: the actor's gradient travels while the critic's backward runs)."""
+    rec = _timing["on"] and flat.is_cuda
+    e0 = None
+    if rec:
+        e0 = torch.cuda.Event(enable_timing=True); e0.record()
+    return dist.all_reduce(flat, group=group, async_op=True), e0
+
+
+def allreduce_end(handles, flat, world):
+    """Join the handles of allreduce_begin (the current stream waits for the collectives) and turn the sums in `flat` into means."""
+    for h, _ in handles:
+        h.wait()
+    flat /= world
+    if handles and handles[0][1] is not None:
+        e1 = torch.cuda.Event(enable_timing=True); e1.record(); _timing["events"].append((handles[0][1], e1))
+    return flat
+
+
 def adv_stats_from_moments(mom):
     """(mean, unbiased std) from (sum a, sum a^2, n) — torch's .std() is unbiased (ppo.py:396)."""
     s, ss, n = (float(x) for x in mom)

@@ -244,8 +244,13 @@ class PPO:
             for k in range(nb):
                 idx = perm[k * mb:(k + 1) * mb]
                 if self.dist_on:
-                    scal = L.minibatch(obs, act, ret, adv, mu, idx=idx, mirror=self.mirror, grad_only=True, sync=False)
-                    adist.allreduce_mean_(L.grad_flat, group=self.group, world=self.world)   # one RCCL all-reduce / step
+                    # the flat gradient travels in its two halves: the actor's (81 418 floats) is final before the critic's backward starts, so its all-reduce runs on
+                    # the backend's stream NEXT TO that backward; the critic's (79 105) follows.  Same sums as one all-reduce of the whole buffer
+                    scal = L.minibatch(obs, act, ret, adv, mu, idx=idx, mirror=self.mirror, grad_only=2, sync=False)
+                    h = [adist.allreduce_begin(L.actor_g, group=self.group)]
+                    L.minibatch(obs, act, ret, adv, mu, idx=idx, mirror=self.mirror, grad_only=3, sync=False)
+                    h.append(adist.allreduce_begin(L.critic_g, group=self.group))
+                    adist.allreduce_end(h, L.grad_flat, self.world)
                     L.apply_grads(scale=1.0)
                 else:
                     scal = L.minibatch(obs, act, ret, adv, mu, idx=idx, mirror=self.mirror, sync=False)

@@ -137,6 +137,18 @@ def _init_group(world, local, share):
     return torch.distributed.group.WORLD
 
 
+def _gather_per_rank(sample_s, optimize_s, allreduce_ms, device, dist_on, world):
+    """{"sample_s": [...], "optimize_s": [...], "allreduce_ms_per_step": [...]} over the ranks (rank order): what a scaling record needs beyond rank 0's view"""
+    v = torch.tensor([sample_s, optimize_s, allreduce_ms], dtype=torch.float64, device=device)
+    if dist_on and world > 1:
+        out = [torch.zeros_like(v) for _ in range(world)]
+        torch.distributed.all_gather(out, v)
+    else:
+        out = [v]
+    m = torch.stack(out).cpu().numpy()
+    return {"sample_s": [round(float(x), 4) for x in m[:, 0]], "optimize_s": [round(float(x), 4) for x in m[:, 1]], "allreduce_ms_per_step": [round(float(x), 3) for x in m[:, 2]]}
+
+
 def main_td3(a):
     """BASELINE.json configs[4] (next row f2): Cassie-v0 TD3, 1 GPU, 10^6-transition replay in HBM; a "step" = 32 lock-step env steps of 4096
     envs, each followed by 4 twin-critic updates on 1024 samples."""
@@ -204,6 +216,7 @@ def main_recurrent(a):
     dt = float(tmax)
     ar_ms, ar_calls = adist.timing_read() if dist_on else (0.0, 0)
     adist.timing(False)
+    per_rank = _gather_per_rank(samp / a.steps, opt / a.steps, ar_ms / a.steps, env.device, dist_on, world)
     if rank == 0:
         steps_total = a.steps * T * n_envs * world
         print(json.dumps({"metric": "env-steps/sec (whole node) CassieTraj-v0 recurrent PPO @2048 envs/GPU", "value": round(steps_total / dt, 1),
@@ -215,7 +228,7 @@ def main_recurrent(a):
                           "sample_s": round(samp / a.steps, 3), "optimize_s": round(opt / a.steps, 3),
                           "collectives": {"rccl_ranks_seen": torch.distributed.get_world_size() if dist_on else 1, "backend": torch.distributed.get_backend() if dist_on else None,
                                           "allreduce_calls_per_step": round(ar_calls / a.steps, 1), "allreduce_ms_per_step": round(ar_ms / a.steps, 3),
-                                          "gradient_floats": int(algo.learner.grad_flat.numel())}}))
+                                          "gradient_floats": int(algo.learner.grad_flat.numel()), "per_rank": per_rank}}))
     if dist_on:
         torch.distributed.destroy_process_group()
 
@@ -289,6 +302,7 @@ def main():
     dt = float(tmax)
     ar_ms, ar_calls = adist.timing_read() if dist_on else (0.0, 0)
     adist.timing(False)
+    per_rank = _gather_per_rank(samp / a.steps, opt / a.steps, ar_ms / a.steps, env.device, dist_on, world)
     k_total_ms, k_launches = env.kernel_timing_read(reset=True)      # the env_step_kernel launches of the timed region
     if k_launches == 0:      # APX_ROLLOUT_GRAPH=1: the rollout was captured during warm-up, before the event pairs were switched on -> a few eager timed launches
         for _ in range(8):
@@ -338,7 +352,10 @@ def main():
             # what the collective path actually was in this run (explains a scaling curve on its own): ranks the process group saw, backend, and the
             # gradient / scalar all-reduces of the timed region (hipEvents on the launch stream of rank 0)
             "collectives": {"rccl_ranks_seen": torch.distributed.get_world_size() if dist_on else 1, "backend": torch.distributed.get_backend() if dist_on else None,
-                            "allreduce_calls_per_step": round(ar_calls / a.steps, 1), "allreduce_ms_per_step": round(ar_ms / a.steps, 3), "gradient_floats": 160523},
+                            "allreduce_calls_per_step": round(ar_calls / a.steps, 1), "allreduce_ms_per_step": round(ar_ms / a.steps, 3), "gradient_floats": 160523,
+                            # the gradient travels in two halves (actor, critic): the window measured per optimiser step runs from the start of the actor half to the join of
+                            # both and CONTAINS the critic's backward it overlaps; per_rank = what each rank saw (sampling, update, that window), for the scaling record
+                            "per_rank": per_rank},
             # the binding bound of the dominant kernel is the fp32 vector pipe (HBM traffic is 1.1 x the algorithmic bytes and
             # < 0.1 % of the peak): achieved = instrumented flops of the CPU restatement per env step x envs / launch time.  The HBM view
             # north_star asks for is reported beside it.

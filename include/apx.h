@@ -165,7 +165,9 @@ typedef struct apx_ppo_args {
     /* hyper-parameters */
     float fixed_std, clip, entropy_coeff, grad_clip, lr, adam_eps, mirror_coeff;
     int adam_t;            /* 1-based optimiser step count (bias correction) */
-    int grad_only;         /* 1 = stop after gradients (no clip/Adam): lets N>1 ranks all-reduce actor_grad/critic_grad */
+    int grad_only;         /* 1 = stop after gradients (no clip/Adam): lets N>1 ranks all-reduce actor_grad/critic_grad.
+                            * 2 then 3 = the same in two calls: 2 ends when the ACTOR's gradient is final (forwards, losses, scalars, actor backward), 3 runs the critic's
+                            * backward on the activations call 2 left in the workspace - so that the actor half of the all-reduce travels while the critic's backward runs */
     /* scratch: apx_ppo_workspace_bytes(mb, D, H, A) bytes [dev] */
     void* workspace; size_t workspace_bytes;
     double* scalars_out;

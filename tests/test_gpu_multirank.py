@@ -164,3 +164,24 @@ def test_rccl_path_at_world_size_one(tmp_path):
     assert 9 <= c["allreduce_calls_per_step"] <= 27
     assert c["allreduce_ms_per_step"] > 0.0
     assert d["n_gpus"] == 1 and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_rccl_path_at_world_size_one_recurrent(tmp_path):
+    """the RCCL branch of the RECURRENT workload (BASELINE configs[3]) on one GPU - APX_FORCE_DIST=1 + torch.distributed.run --nproc-per-node 1:
+    init_process_group("nccl"), the MAX all-reduce that agrees on the number of optimiser steps of an epoch, the flat LSTM-gradient all-reduce per step, the advantage /
+    observation moments and the per-epoch scalar all-reduce, on device tensors."""
+    import json, subprocess, sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env["APX_FORCE_DIST"] = "1"; env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.pop("APX_BENCH_SHARE_GPU", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(repo, "bench.py"), "--workload", "cassietraj_recurrent", "--gpus", "1", "--steps", "1", "--warmup", "1", "--n_envs", "256", "--epochs", "1", "--no_cpu_baseline"]
+    r = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    c = d["collectives"]
+    assert c["backend"] == "nccl" and c["rccl_ranks_seen"] == 1 and c["gradient_floats"] > 400000      # two LSTM(2 x 128) networks
+    assert c["allreduce_calls_per_step"] >= 2 and c["allreduce_ms_per_step"] > 0.0
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "recurrent" in d["metric"]

@@ -6,7 +6,7 @@
 #   - per-dispatch means of every group in ONE file  -> gpurun_out/prof_issue_<tag>/<tag>_env_step_pmc_issue.txt (stamped with the kernel-source hash)
 #   - the I-cache micro-benchmark (tools/proto/icache_probe*)  -> <tag>_icache_probe.txt
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_issue_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp

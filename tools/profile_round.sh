@@ -5,7 +5,7 @@
 #   3. FETCH_SIZE / WRITE_SIZE, two separate --pmc passes (guide: HBM)     -> profiles/<tag>_env_step_pmc_hbm.txt (+ hash of the kernel sources)
 # Everything is written under gpurun_out/prof_<tag>/ (merged back by gpurun); copy the .txt / .json files into profiles/ afterwards.
 set -e
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
@@ -25,12 +25,16 @@ cd $ROOT
 cp $OUT/${TAG}_env_step_pmc_hbm.txt $OUT/${TAG}_env_step_pmc_sq.txt $ROOT/profiles/ 2>/dev/null || true      # bench.py reads roofline.traffic from profiles/<tag>_env_step_pmc_hbm.txt (same kernel-source hash): the lines below carry it
 python bench.py --steps 20 --warmup 2 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line.json
 python bench.py --workload cassietraj_recurrent --steps 3 --warmup 1 --no_cpu_baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line_recurrent.json
+#   3b. the parity-run minibatch sizes (64 = the reference's CLI default apex.py:242, 2048 = the shipped run's) and the per-step-launch rollout for comparison
+python bench.py --steps 3 --warmup 1 --no_cpu_baseline --minibatch 2048 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line_mb2048.json || true
+timeout 900 python bench.py --steps 2 --warmup 1 --no_cpu_baseline --minibatch 64 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line_mb64.json || true
+APX_ROLLOUT_STEPWISE=1 python bench.py --steps 10 --warmup 2 --no_cpu_baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_line_stepwise_rollout.json || true
 #   4. per-kernel time of the recurrent workload (persistent LSTM layer kernels)          -> profiles/<tag>_recurrent_kernel_stats.txt
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/ktr -- python $ROOT/bench.py --workload cassietraj_recurrent --steps 2 --warmup 1 --no_cpu_baseline > $OUT/rec_under_rocprof.log 2>&1 || true)
 python $ROOT/tools/rocprof_summary.py $(ls $OUT/ktr/*/*.db | head -1) $OUT/${TAG}_recurrent_kernel_stats.txt > /dev/null || true
 python $ROOT/tools/rocprof_timeline.py $(ls $OUT/ktr/*/*.db | head -1) $OUT/${TAG}_recurrent_timeline.txt > /dev/null || true      # one rollout step / one recurrent minibatch, kernel by kernel
 rm -rf $OUT/ktr
-#   4b. MFMA pipe counters of the learner kernels (fused fp32 forward, gemm_f32_kernel<*>, gemm_bf16_kernel<*>), own --pmc passes  -> profiles/<tag>_learner_pmc_mfma.txt
+#   4b. MFMA pipe counters of the learner kernels (fused fp32 forward, gemm_f32_kernel<*>, gemm_f32_128_kernel<*>), own --pmc passes  -> profiles/<tag>_learner_pmc_mfma.txt
 (cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d $OUT/mfma -- python $ROOT/tools/t_pmc_learner.py > $OUT/mfma.log 2>&1 || true)
 python $ROOT/tools/pmc_summary.py $OUT/mfma $OUT/${TAG}_learner_pmc_mfma.txt "# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 -- python tools/t_pmc_learner.py (per-dispatch means; MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES)" > /dev/null || true
 rm -rf $OUT/mfma

@@ -32,6 +32,9 @@ print("%4s %16s %12s %12s %22s" % ("N", "env-steps/s", "ms/step", "efficiency", 
 for n, r in rows.items():
     c = r.get("collectives", {})
     print("%4d %16.0f %12.2f %12.3f %22s" % (n, r["value"], r["ms_per_step"], r["value"] / (n * base), c.get("allreduce_ms_per_step")))
+    pr = c.get("per_rank") or {}
+    for k in ("sample_s", "optimize_s", "allreduce_ms_per_step"):      # what every rank saw: a straggler rank or an exposed collective shows here, not in rank 0's line
+        if k in pr: print("       per-rank %-22s %s" % (k, " ".join("%.4g" % x for x in pr[k])))
 json.dump({"per_n": {n: {"value": r["value"], "ms_per_step": r["ms_per_step"], "efficiency": r["value"] / (n * base), "collectives": r.get("collectives")} for n, r in rows.items()}},
           open("gpurun_out/scale/summary.json", "w"), indent=1)
 PY
