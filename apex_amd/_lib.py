@@ -75,6 +75,7 @@ SIGNATURES = {
     "apx_env_reset": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
     "apx_env_prepare_resets": (C.c_int, [c_ptr, c_ptr]),
     "apx_env_set_refill": (C.c_int, [c_ptr, C.c_int]),
+    "apx_env_set_complete_rows": (C.c_int, [c_ptr, C.c_int]),
     "apx_env_update_speed": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
     "apx_env_reset_for_test": (C.c_int, [c_ptr, c_ptr, C.c_int, c_ptr]),
     "apx_env_apply_force": (C.c_int, [c_ptr, c_ptr, c_ptr]),

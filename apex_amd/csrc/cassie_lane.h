@@ -378,6 +378,16 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         const float hitc = (d0 < 0.f || d1 < 0.f) ? 1.f : 0.f;
         int ho = WK_DUMMY; ho = l == 0 ? WK_MISC + 4 : ho; ho = l == 2 ? WK_MISC + 5 : ho;
         S.W(ho) = l == 0 ? hitp : hitc;
+        // the points themselves for the complete-row path (cassie_complete.h): hip-pitch capsule ends (left e0, e1, right e0, e1) from the hip-pitch lane, the pelvis
+        // sphere centre from lane 0, 15 words of the row store that neither the exchange records nor the row stage's parked vectors touch
+        constexpr int XE = 38 * 16;
+        if (l == 2) {
+            const V3p e0 = c + ax, e1 = c - ax;
+            float* q = xb + XE;
+            q[0] = e0.x.x; q[1] = e0.y.x; q[2] = e0.z.x; q[3] = e1.x.x; q[4] = e1.y.x; q[5] = e1.z.x;
+            q[6] = e0.x.y; q[7] = e0.y.y; q[8] = e0.z.y; q[9] = e1.x.y; q[10] = e1.y.y; q[11] = e1.z.y;
+        }
+        if (l == 0) { const V3 pc = o + mul(pmat, cv3<8>(ct_geom_pos)); float* q = xb + XE + 12; q[0] = pc.x; q[1] = pc.y; q[2] = pc.z; }
     }
     // ---- anchor points, capsule ends, foot pose (body lanes that own them)
     {
@@ -385,8 +395,8 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             S.W(off) = p.x.x; S.W(off + 1) = p.y.x; S.W(off + 2) = p.z.x; S.W(off + 30) = p.x.y; S.W(off + 31) = p.y.y; S.W(off + 32) = p.z.y;
         };
         constexpr int base = WK_PTS;
-        if constexpr (QPOS0) {      // world COM of the constraint bodies, slot order of c2::cslot: achilles, heel-spring, plantar-rod, foot, tarsus, shin
-            const int cs = l == 3 ? 0 : l == 8 ? 1 : l == 10 ? 2 : l == 11 ? 3 : l == 7 ? 4 : l == 6 ? 5 : -1;
+        if constexpr (QPOS0) {      // world COM of the constraint bodies, slot order of c2::cslot: achilles, heel-spring, plantar-rod, foot, tarsus, shin; then hip pitch
+            const int cs = l == 3 ? 0 : l == 8 ? 1 : l == 10 ? 2 : l == 11 ? 3 : l == 7 ? 4 : l == 6 ? 5 : l == 2 ? 6 : -1;      // (6: hip pitch, for its invweight)
             if (cs >= 0) put2(base + 3 * cs, pos + mul(mat, ipos));
         } else {
         static_assert(ct_eq_body1[0] == 12 && ct_eq_body2[0] == 13 && ct_eq_body1[1] == 5 && ct_eq_body2[1] == 10, "connect bodies");
@@ -993,6 +1003,29 @@ __device__ __forceinline__ void setconst_rows_lane(const St& S) {
         if (isBody && ax == 2) S(F_BIW + bsel) = tr * (1.f / 3.f);
         if (isLim) S(F_DIW + 6 + 13 * LEG + kl) = nn;
     });
+    {   // third pass (round 5, for the complete-row path: cassie_complete.h): the bodies of the collision geoms the lane map does not instantiate - the hip-pitch body of
+        // this leg (capsule cassie.xml:101 / :163) on lanes 0..2 and, once (LEG 0), the pelvis (sphere :87) on lanes 3..5
+        static_assert(ct_qpos0[3] == 1.f && ct_qpos0[4] == 0.f && ct_qpos0[5] == 0.f && ct_qpos0[6] == 0.f && ct_geom_body[6] == 4 && ct_geom_body[7] == 16 && ct_geom_body[8] == 1, "pelvis upright at qpos0; hip-pitch / pelvis geoms");
+        const bool hip = l < 3, pel = LEG == 0 && l >= 3 && l < 6;
+        const int ax = l % 3;
+        const unsigned m = hip ? chain_mask<LEG>(4 + 12 * LEG) : (pel ? 0x3Fu : 0u);
+        V3 com = {S.W(WK_PTS + 30 * LEG + 18), S.W(WK_PTS + 30 * LEG + 19), S.W(WK_PTS + 30 * LEG + 20)};
+        const V3 pc = o + cv3<1>(ct_body_ipos);
+        com = {pel ? pc.x : com.x, pel ? pc.y : com.y, pel ? pc.z : com.z};
+        const V3 dir = {ax == 0 ? 1.f : 0.f, ax == 1 ? 1.f : 0.f, ax == 2 ? 1.f : 0.f};
+        const V3 q = cross(com - o, dir);
+        float J[19];
+        sfor<0, 19>([&](auto C) {
+            constexpr int c = C, d = c2d<LEG>(c);
+            const V3 ca = {S.W(WK_CDOF + 6 * d), S.W(WK_CDOF + 6 * d + 1), S.W(WK_CDOF + 6 * d + 2)};
+            const V3 cl = {S.W(WK_CDOF + 6 * d + 3), S.W(WK_CDOF + 6 * d + 4), S.W(WK_CDOF + 6 * d + 5)};
+            J[c] = ((m >> c) & 1u) ? dot(dir, cl) + dot(q, ca) : 0.f;
+        });
+        const float nn = whiten_lane<LEG>(S, J);
+        const float tr = nn + dpp<0x111>(nn) + dpp<0x112>(nn);
+        if (l == 2) S(F_BIW + 4 + 12 * LEG) = tr * (1.f / 3.f);
+        if (LEG == 0 && l == 5) S(F_BIW + 1) = tr * (1.f / 3.f);
+    }
     if (l == 0) S(F_BIW) = 0.f;
 }
 
@@ -1348,6 +1381,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, FacRegs& FR, fl
     if (l == 0) {
         const int sat = A.over | B.over | ((S.W(WK_MISC + 4) + S.W(WK_MISC + 5) > 0.f) ? SAT_BODY_FLOOR : 0) | (nxp > MAXX ? SAT_LEG_LEG : 0);
         if (sat) S.I(I_SAT) = (S.I(I_SAT) | sat) + 256;
+        S.W(WK_MISC + 7) = sat ? 1.f : 0.f;      // this pass needs rows beyond the lane map: sim_step_pd hands the env to the complete-row path (cassie_complete.h) instead of the finish stage
         {   // row-set signature of this forward pass, folded into the env step's hash (multiplicative hash over two words; the oracle folds the same words): limited joints out of
             // range (8 bits per leg), penetrating capsule ends (6 per leg), pelvis sphere / hip-pitch capsules on the floor, the 9 left x right capsule pairs
             const unsigned bf = (S.W(WK_MISC + 4) > 0.f ? 1u : 0u) | (S.W(WK_MISC + 5) > 0.f ? 2u : 0u);

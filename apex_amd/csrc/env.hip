@@ -10,6 +10,7 @@
 #include "apx_common.h"
 #include "cassie_model_gen.h"
 #include "cassie_lane.h"
+#include "cassie_complete.h"
 #include "estimator_lane.h"
 
 #include <new>
@@ -200,8 +201,20 @@ __device__ __forceinline__ void sim_step_pd(const St& S, const Cfg& cfg, int mod
     c4::wsync();
     stage3_rows_pgs_lane<HF>(S, FR, cfg);
     c4::wsync();
+    // a pass that needs more rows than the lane map carries (third capsule end of a leg on the floor, second limit of a leg, hip-pitch capsule / pelvis sphere on the floor,
+    // more than three capsule pairs) leaves the fast path here: its env skips the finish stage and gets its COMPLETE row set, solve and finish out of line (cassie_complete.h)
+#ifdef APX_NO_COMPLETE      /* A/B build: the capped fast path alone (rounds 1-4) */
     stage4_finish(S, mode, F, FR);
     c4::wsync();
+#else
+    const bool satp = cfg.complete_pool != nullptr && S.W(c4::WK_MISC + 7) != 0.f;
+    if (!satp) stage4_finish(S, mode, F, FR);
+    c4::wsync();
+    if (__builtin_amdgcn_ballot_w64(satp) != 0ull) {
+        if (satp) c4::substep_complete<HF>(S, rows4(), cfg.pgs_iters, cfg.hf, cfg.complete_pool, mode);
+        c4::wsync();
+    }
+#endif
 #ifdef APX_PROF
     if (threadIdx.x == 0 && blockIdx.x == 0) c4::g_prof_acc[8] += clock64() - t0__;
 #endif
@@ -913,7 +926,7 @@ static Cfg make_cfg(const apx_env& env) {
     const apx_env_cfg& c = env.cfg;
     return Cfg{Hf{env.hf, env.hf_nrow, env.hf_ncol, env.hf_size[0], env.hf_size[1], env.hf_size[2]}, c.simrate, c.dynamics_randomization, c.stance_mode, c.have_incentive, c.max_traj_len, c.pgs_iters,
                (unsigned)c.seed, (unsigned)(c.seed >> 32), (unsigned)c.env_id_base, c.reward_kind, c.env_kind, c.command_profile,
-               (c.input_profile ? APX_OBS_MIN : 46) + (c.command_profile == 0 ? 4 : 9), c.est_lifetime, c.input_profile, env.wk, env.rst, env.rst_int};
+               (c.input_profile ? APX_OBS_MIN : 46) + (c.command_profile == 0 ? 4 : 9), c.est_lifetime, c.input_profile, env.wk, env.rst, env.rst_int, env.complete_rows ? env.cp_pool : nullptr};
 }
 
 extern "C" void apx_env_default_cfg(apx_env_cfg* c) {
@@ -951,6 +964,9 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     e->refill = getenv("APX_REFILL") ? atoi(getenv("APX_REFILL")) != 0 : e->n <= 2048;
     e->refill_pending = 0; e->refill_due = 0; e->side = nullptr; e->ev_reset = nullptr; e->ev_refill = nullptr;
     e->pol_wt = nullptr; e->pol_wt_n = 0; e->roll_launches = 0; e->roll_ms = 0.0;
+    e->complete_rows = getenv("APX_COMPLETE_ROWS") ? atoi(getenv("APX_COMPLETE_ROWS")) != 0 : 1;
+    e->cp_pool = nullptr;
+    APX_HIP(hipMalloc(&e->cp_pool, sizeof(float) * (size_t)e->n * c4::CP_HBM_CAP * c4::CP_STRIDE));
     const Cfg c = make_cfg(*e);
     hipLaunchKernelGGL(env_init_kernel, dim3(e->n / 64), dim3(64), 0, 0, e->st, e->ist, e->n, c);
     APX_LAUNCH_CHECK();
@@ -968,7 +984,7 @@ extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
 extern "C" int apx_env_destroy(apx_env_t* e) {
     if (!e) return APX_OK;
     if (e->side) (void)hipStreamSynchronize((hipStream_t)e->side);      // a ring refill in flight on the env's own stream still reads the state and writes the ring
-    (void)hipFree(e->pol_wt); (void)hipFree(e->st); (void)hipFree(e->ist); (void)hipFree(e->wk); (void)hipFree(e->hf); (void)hipFree(e->rst); (void)hipFree(e->rst_int);
+    (void)hipFree(e->pol_wt); (void)hipFree(e->cp_pool); (void)hipFree(e->st); (void)hipFree(e->ist); (void)hipFree(e->wk); (void)hipFree(e->hf); (void)hipFree(e->rst); (void)hipFree(e->rst_int);
     for (int i = 0; i < e->ev_cap; ++i) (void)hipEventDestroy((hipEvent_t)e->ev[i]);
     free(e->ev);
     if (e->side) (void)hipStreamDestroy((hipStream_t)e->side);
@@ -1018,6 +1034,11 @@ static int launch_refill(apx_env* e, void* stream) {
     APX_HIP(hipEventRecord((hipEvent_t)e->ev_refill, (hipStream_t)e->side));
     e->refill_pending = 1;
     return APX_OK;
+}
+extern "C" int apx_env_set_complete_rows(apx_env_t* e, int on) {
+    APX_REQUIRE(e, "env");
+    e->complete_rows = on != 0;
+    return invalidate_prepared(e, nullptr);      // a prepared image holds a forward pass of the other kind
 }
 extern "C" int apx_env_set_refill(apx_env_t* e, int on) {
     APX_REQUIRE(e, "env");

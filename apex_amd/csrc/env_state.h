@@ -46,6 +46,7 @@ struct apx_env {
     int refill, refill_pending, refill_due; void* side; void* ev_reset; void* ev_refill;
     // apx_rollout as one launch (env_rollout_kernel): the actor's weights in k-major order, re-laid at the start of every rollout; rollouts run that way, launches timed
     float* pol_wt; long pol_wt_n; long roll_launches; double roll_ms;
+    int complete_rows; float* cp_pool;      // apx_env_set_complete_rows (default 1); the HBM tier of the complete-row path's basis pool
 };
 
 // global-address-space pointers: St is passed by value into a non-inlined device function, where the compiler could
@@ -97,7 +98,7 @@ struct St {
 // elevation = data * sz; data == nullptr: the floor plane of cassie.xml:73
 struct Hf { const float* data; int nrow, ncol; float sx, sy, sz; };
 constexpr int RST_K = 2;
-struct Cfg { Hf hf; int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; int reward_kind, env_kind, command_profile, obs_dim, est_lifetime, input_profile; float* est /* state-estimator records, [n][est::REC] (estimator_lane.h) */; const float* rst; const int* rst_int; /* prepared resets or nullptr */ };
+struct Cfg { Hf hf; int simrate, dyn_rand, stance_mode, incentive, max_traj_len, pgs_iters; unsigned seed_lo, seed_hi, env_base; int reward_kind, env_kind, command_profile, obs_dim, est_lifetime, input_profile; float* est /* state-estimator records, [n][est::REC] (estimator_lane.h) */; const float* rst; const int* rst_int; /* prepared resets or nullptr */ float* complete_pool; /* non-NULL: a pass beyond the lane map's row caps is solved with its complete row set (cassie_complete.h; the pointer = the HBM tier of its basis pool, [n][96 x 24]); NULL: capped, counted in I_SAT (rounds 1-4) */ };
 
 // ------------------------------------------------------------------------------------------------ Philox4x32-10
 __device__ __forceinline__ unsigned philox(unsigned k0, unsigned k1, unsigned env, unsigned ctr, unsigned dom) {

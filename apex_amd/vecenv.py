@@ -150,6 +150,10 @@ class CassieVecEnv:
         """apx_env_prepare_resets: precompute the next two resets of every env (draws, set_const, forward pass) off the rollout's critical path"""
         check(_lib.load().apx_env_prepare_resets(self._h, _stream()))
 
+    def set_complete_rows(self, on=True):
+        """apx_env_set_complete_rows: solve a forward pass beyond the lane map's row caps with its complete row set (default on) or cap it as in rounds 1-4"""
+        check(_lib.load().apx_env_set_complete_rows(self._h, int(bool(on))))
+
     def set_refill(self, on):
         """apx_env_set_refill: refill the reset ring of the envs that just restarted next to the following env step (default: on up to 2048 envs)"""
         check(_lib.load().apx_env_set_refill(self._h, int(bool(on))))

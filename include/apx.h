@@ -241,6 +241,11 @@ int apx_env_prepare_resets(apx_env_t* env, void* stream);
  * to 2048 envs leaves half of the SIMDs idle), off above.  Results do not depend on it (same bits, see apx_env_prepare_resets).  Switching it off waits for a refill
  * in flight; a step issued on a stream under graph capture skips it (switch it off BEFORE capturing a rollout, so that no refill is pending inside the capture). */
 int apx_env_set_refill(apx_env_t* env, int on);
+/* Rows beyond the lane map of the fast constraint stage (a third penetrating capsule end of a leg, a second active joint limit of a leg, the hip-pitch capsules
+ * cassie.xml:101,163 or the pelvis sphere :87 on the floor, more than three left-right capsule pairs): on (default), such a forward pass is solved with its COMPLETE
+ * row set in the order of mj_makeConstraint's per-leg restatement (oracle/cassie_phys.cpp) by an out-of-line z~-space Gauss-Seidel; off, the rows are capped as in
+ * rounds 1-4.  Either way I_SAT (apx_env_get_field "ints") counts the passes.  Replaces nothing of the reference: MuJoCo always instantiates every row. */
+int apx_env_set_complete_rows(apx_env_t* env, int on);
 
 /* Evaluation-side API.
  * CassieEnv.update_speed (cassie/cassie.py:757-775, clock command profile) for every env: speed[n_envs] f32 [dev],

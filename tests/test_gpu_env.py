@@ -143,7 +143,8 @@ def test_single_substep_crafted_states(dev):
     fp32 solver accuracy."""
     genv, oenv = _mk(False, 11)
     genv.reset(); [e.reset() for e in oenv[:12]]
-    [e.kernel_caps(True) for e in oenv[:12]]          # these states need more rows than the kernel keeps per leg: compare the kept ones
+    # (these states need more rows than the lane map of the fast constraint stage keeps per leg - 3 to 4 capsule ends of a leg on the floor, 3 limits per leg: rounds 1-4
+    # switched the oracle to the kernel's caps here; round 5 compares with the COMPLETE oracle, the kernel solves such a pass with its complete row set, cassie_complete.h)
     sat0 = genv.saturation()[0].cpu().numpy()
     rng = np.random.RandomState(5)
     qpos = genv.get_field("qpos").cpu().numpy().astype(np.float64)
@@ -471,10 +472,18 @@ def test_saturation_flags_vs_oracle_crafted(dev):
             assert cur & want == want and (want != 0 or cur == 0), (name, cur, want)
         if oflag is not None:
             assert cur == oflag, (name, cur, oflag)
-        if cur == 0:
-            ref = e.get("qacc_warm"); scale = np.maximum(1.0, np.abs(ref))
-            tol = np.full(32, 3e-2); tol[[9, 22]] = 0.25
-            assert np.all(np.abs(qa[i] - ref) / scale <= tol), (name, np.abs(qa[i] - ref) / scale)
+        # saturated or not: the accelerations are those of the COMPLETE row set (round 5: a saturated pass is solved out of line with every row, cassie_complete.h).
+        # Left out: the legs pushed THROUGH each other - seven redundant capsule-pair rows, an ill-conditioned dual on which 50 Gauss-Seidel sweeps end at a different
+        # vertex for every rounding: the fp32 build of the ORACLE differs from the fp64 oracle by 13.8 (relative) / 2 750 rad/s^2 there, with other pairs active
+        if name.startswith("legs pushed through"):
+            continue
+        ref = e.get("qacc_warm"); scale = np.maximum(1.0, np.abs(ref))
+        tol = np.full(32, 3e-2); tol[[9, 22]] = 0.25
+        scale[[9, 22]] = np.maximum(scale[[9, 22]], 8e-4 * np.abs(ref).max())      # (the rod-spin dofs: see test_single_substep_crafted_states)
+        # a dof of a few rad/s^2 inside a vector of 1e5 - 7e5 rad/s^2 (17 contacts: the folded robot on the floor) carries the rounding of the large ones:
+        # floor of 2e-5 * max|qacc| absolute under the relative bound, as in test_heightfield_terrain_vs_oracle (fp32 control there)
+        err = np.abs(qa[i] - ref)
+        assert np.all((err / scale <= tol) | (err <= 2e-5 * np.abs(ref).max())), (name, cur, err / scale)
     assert cnt[2] >= 1 and cnt[3] == 0 and cnt[0] == cnt[1] == 0
     assert int(oenv[3].get("ints")[9]) >= 1          # the crossed-legs case really had a leg-leg row in the oracle
 
@@ -663,8 +672,7 @@ def test_heightfield_terrain_vs_oracle(dev, kind):
     ncon = 0
     for i, e in enumerate(o):
         e.set("qpos", q[i].astype(np.float32).astype(np.float64)); e.set("qvel", np.zeros(32)); e.set("qacc_warm", np.zeros(32))
-        e.kernel_caps(True)
-        e.substep()
+        e.substep()                       # (the COMPLETE oracle: a third capsule end of a leg on a bump is solved by the kernel's complete-row path, cassie_complete.h)
         ncon += int(e.get("ints")[3])
         ref = e.get("qacc_warm"); scale = np.maximum(1.0, np.abs(ref))
         tol = np.full(32, 3e-2); tol[[9, 22]] = 0.25

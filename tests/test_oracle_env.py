@@ -742,7 +742,7 @@ sys.path.insert(0, %r)
 from oracle import sim as S
 rng = np.random.RandomState(5)
 envs = [S.OracleEnv(dyn_rand=False, seed=11, env_id=i) for i in range(12)]
-[e.reset() for e in envs]; [e.kernel_caps(True) for e in envs]
+[e.reset() for e in envs]
 out = []
 for i, e in enumerate(envs):
     q = e.get("qpos").copy(); v = 0.05 * rng.randn(32); kind = i %% 4

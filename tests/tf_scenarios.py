@@ -26,9 +26,9 @@ HF_SIZE = (4.0, 4.0, 0.15)
 
 
 class Scenario:
-    def __init__(self, name, okw, gkw, act, n_steps, rng_seed, stepper="step", prep=None, hfield=None, obs_groups=None, min_profile=False, differing_max=0.10, reaches=None):
+    def __init__(self, name, okw, gkw, act, n_steps, rng_seed, stepper="step", prep=None, hfield=None, obs_groups=None, min_profile=False, differing_max=0.10, reaches=None, prep_kernel=None):
         self.name, self.okw, self.gkw, self.act, self.n_steps, self.rng_seed, self.stepper = name, okw, gkw, act, n_steps, rng_seed, stepper
-        self.prep, self.hfield, self.obs_groups, self.min_profile, self.differing_max, self.reaches = prep, hfield, obs_groups, min_profile, differing_max, reaches
+        self.prep, self.hfield, self.obs_groups, self.min_profile, self.differing_max, self.reaches, self.prep_kernel = prep, hfield, obs_groups, min_profile, differing_max, reaches, prep_kernel
 
     def make_oracle(self, S, n=N_ORACLE):
         envs = [S.OracleEnv(env_id=i, **self.okw) for i in range(n)]
@@ -44,6 +44,8 @@ class Scenario:
         if self.hfield is not None:
             g.set_hfield(_terrain(self.hfield), HF_SIZE)
         g.reset()
+        if self.prep_kernel is not None:
+            self.prep_kernel(g)
         return g
 
     def step_oracle(self, e, a):
@@ -88,12 +90,35 @@ def _prep_phase_add(envs):       # tools/test_commands.py:86: phase_add 1.5 on e
 def _prep_hfield(envs):          # the robot starts at the origin: shift / lift it so that the feet meet the terrain at different places, 1-6 cm into the surface
     rng = np.random.RandomState(3)
     for e in envs:
-        e.reset_for_test(); e.kernel_caps(True)
+        e.reset_for_test()
         q = e.get("qpos").copy()
         q[0] = rng.uniform(-2.5, 2.5); q[1] = rng.uniform(-2.5, 2.5)
         hh, _ = e.floor_query(q[0], q[1])
         q[2] = 1.0 + hh + rng.uniform(-0.06, 0.0)
         e.set("qpos", q.astype(np.float32).astype(np.float64)); e.set("qvel", np.zeros(32)); e.set("qacc_warm", np.zeros(32))
+
+
+def _push_forces(n):            # a pelvis push per env, 150 - 300 N in a random horizontal direction (tools/eval_perturb.py:62 pushes up to a few hundred N)
+    rng = np.random.RandomState(17)
+    ang = rng.uniform(0, 2 * np.pi, n); mag = rng.uniform(150.0, 300.0, n)
+    f = np.zeros((n, 6)); f[:, 0] = mag * np.cos(ang); f[:, 1] = mag * np.sin(ang)
+    return f
+
+
+def _prep_push(envs):            # falling robots: wild actions (the scenario's generator) + a standing pelvis push; the external wrench is not part of a reset on either side
+    f = _push_forces(len(envs))
+    for e, x in zip(envs, f):
+        e.apply_force(x)
+
+
+def _prep_push_kernel(g):
+    import torch
+    f = _push_forces(N_ORACLE)
+    g.apply_force(torch.tensor(f[np.arange(g.n_envs) % N_ORACLE], dtype=torch.float32))
+
+
+def _saturated(envs):            # forward passes beyond the lane map's row caps seen so far (oracle/cassie_phys.h SatFlag, accumulated): the complete-row path ran
+    return int(sum(int(e.get("ints")[8]) != 0 for e in envs))
 
 
 def _zones_hit(envs):
@@ -129,6 +154,10 @@ SCENARIOS = [
     Scenario("min_phase", dict(dyn_rand=True, seed=12, input_profile=1, command_profile=1), dict(dynamics_randomization=True, seed=12, input_profile="min", command_profile="phase"), _gauss(0.1), 8, 3,
              obs_groups=GMIN(30), min_profile=True),
     Scenario("phase_add", dict(dyn_rand=False, seed=41), dict(dynamics_randomization=False, seed=41), _zeros, 40, 0, prep=_prep_phase_add),
+    # falling robots against the COMPLETE oracle: wild actions and a pelvis push - several limits of a leg at once, third / fourth capsule ends on the
+    # floor, hip-pitch capsules: passes beyond the lane map's caps, which the kernel solves with the complete row set (cassie_complete.h)
+    Scenario("falling_pushed", dict(dyn_rand=True, seed=31), dict(dynamics_randomization=True, seed=31), _gauss(1.0), 30, 9, prep=_prep_push, prep_kernel=_prep_push_kernel,
+             reaches=_saturated, differing_max=0.35),
 ]
 BY_NAME = {s.name: s for s in SCENARIOS}
 
