@@ -299,7 +299,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_128_kernel(GemmArgs g) {
             } else { const int k = (tid >> 5) + 8 * i, nq = (tid & 31) * 4; *(f4v*)&Bs[k][nq] = rb[i]; }
         }
         __syncthreads();
+#if !defined(APX_GEMM_ABL) || APX_GEMM_ABL < 2
         if (k0 + GBK < kend) fetch(k0 + GBK);
+#endif
         if (EPI == EPI_PARTIAL && bias_grad && tid < G2M) {      // fused bias gradient: column sums of dY ride on the A tile
 #pragma unroll
             for (int kk = 0; kk < GBK; ++kk) bsum += As[kk][tid];
@@ -327,8 +329,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_128_kernel(GemmArgs g) {
                 const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 float v = acc[i][j][r];
                 if (EPI == EPI_BIAS) v += g.aux[col];
+#if defined(APX_GEMM_ABL) && APX_GEMM_ABL >= 1
+                if (v == 123.456f) Cb[(long)row * g.ldc + col] = v;
+#else
                 if (EPI == EPI_MASK) v = g.aux[(long)row * g.ld_aux + col] > 0.f ? v : 0.f;
                 Cb[(long)row * g.ldc + col] = v;
+#endif
             }
         }
 }
