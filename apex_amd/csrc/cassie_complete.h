@@ -6,20 +6,22 @@
 // Here it is solved: when a pass saturates (SAT_* of that pass), the env's rows are rebuilt WITHOUT caps in the order of the fp64 oracle (oracle/cassie_phys.cpp:
 // per leg the connects, every active limit in joint order, every penetrating capsule end foot / tarsus / shin / hip-pitch; then the pelvis sphere; then the capsule
 // pairs) and swept by projected Gauss-Seidel in the whitened space z~ itself - row vector y~ = D^-1/2 L^-T J^T distributed over the env's 16 lanes (lane l: leg dof l of
-// the row's leg; the 6 pelvis entries on every lane), residual = y~ . z~ + b + R f by one DPP reduction, z~ += y~ df.  No Gram matrix: the row count is open.  That is
-// ~ 30 instructions per scalar row and ~ 95 per pyramidal contact and sweep against 4 / 25 in Gram space, i.e. 2 - 3 substeps of time for ONE saturated substep of ONE
-// wave - nothing on a rollout in which a wave steps its envs at its own pace (env_rollout_kernel), and never on a walking policy (no saturation at all).
+// the row's leg; the 6 pelvis entries on every lane), residual = y~ . z~ + b + R f by one DPP reduction, z~ += y~ df.  No Gram matrix: the row count is open.  Measured
+// (tools/t_complete_ms.py, every env of the launch in the same pose): a pass costs 0.25 - 0.9 ms against 0.08 ms of the fast path (4 - 12 x: ~ 50 us to build and whiten the
+// rows, 4 - 18 us per sweep) - nothing on a rollout in which a wave steps its envs at its own pace (env_rollout_kernel), and never on a walking policy (no saturation).
 // The result replaces what the capped fast path left in WK_ZT and in the contact-slot records; tree, factor and finish stages are the same code for both.
 #pragma once
 #include "cassie_lane.h"
 
 namespace c4 {
 
-// ---- pool of whitened basis vectors in LDS: record i = 24 words: [0..12] the 13 leg columns (lane l writes its own), [13..18] the pelvis columns, [19] leg of the row,
-// [20..23] row scalars (single rows: b, R, 1 / (A + R), f; the normal basis of a contact keeps more, below).  Records 0 .. CP_ROWS_CAP - 1 live in the row store below
-// the contact-slot records, the rest in the factor hand-off WK_LD (free in a substep: the factor is in registers; factor_lane clears its zero words before it loads).
+// ---- pool of whitened basis vectors in LDS: record i = 24 words: [0..12] the 13 leg columns (lane l writes its own), [13] leg of the row (or one extra word of the
+// record's kind), [14..15] / [16..19] the pelvis columns 4, 5 / 0..3, [20..23] row scalars (single rows: b, R, 1 / (A + R), f; the normal basis of a contact keeps more,
+// below): words [12..23] are three aligned 128-bit loads.  Records 0 .. CP_ROWS_CAP - 1 live in the row store below the contact-slot records, the rest in the factor
+// hand-off WK_LD (free in a substep: the factor is in registers; factor_lane clears its zero words before it loads).
 // Records beyond those 38 (a robot lying on the floor: 17 contacts = 51 basis vectors) go to a per-env overflow area in HBM (apx_env::cp_pool, CP_HBM_CAP records): their
 // vectors are read-only after the construction (one __threadfence), their scalars - rewritten every sweep - are accessed with agent-scope atomics (no stale L1 line).
+// The solve is compiled twice: cp_solve<true> when every record of the wave's envs is in LDS (ds_* instructions only, no tier branch), cp_solve<false> otherwise.
 constexpr int CP_STRIDE = 24, CP_ROWS_CAP = R4_CON / CP_STRIDE, CP_LD_CAP = NM / CP_STRIDE, CP_LDS_CAP = CP_ROWS_CAP + CP_LD_CAP, CP_HBM_CAP = 96, CP_CAP = CP_LDS_CAP + CP_HBM_CAP;
 static_assert(CP_ROWS_CAP == 26 && CP_LD_CAP == 12, "basis pool");
 static_assert(CP_CAP >= 12 + 16 + 3 * 17 + 2 * 9 && CP_CAP < 256, "every row cassie.xml can produce fits the pool");
@@ -54,28 +56,39 @@ struct ChainTab { unsigned m[12]; };
 constexpr ChainTab make_chaintab() { ChainTab t{}; for (int lb = 0; lb < 12; ++lb) t.m[lb] = chain_mask<0>(2 + lb) >> 6; return t; }
 __device__ const ChainTab kChain = make_chaintab();
 
+// record words: [0..12] leg columns, [13] leg of the row / one extra word per record kind, [14..15] pelvis columns 4, 5, [16..19] pelvis columns 0..3, [20..23] scalars:
+// words [12..23] of a record are three aligned 128-bit LDS loads
+constexpr int CPW_MISC = 13;
+constexpr int cpw_p(int P) { return P < 4 ? 16 + P : 10 + P; }
+constexpr int CP_LD0 = WK_LD + 1;      // first word of the WK_LD tier: 16-byte aligned inside the env's LDS region
+static_assert((L4_WK + CP_LD0) % 4 == 0 && L4_ROWS % 4 == 0 && L4_ES % 4 == 0 && CP_STRIDE % 4 == 0 && CP_LD0 + CP_LD_CAP * CP_STRIDE <= WK_LD + NM, "aligned records");
+// Gram blocks of the pyramidal contacts: 8-word entries (6 used) in the motion-axis table, first entry 16-byte aligned
+constexpr int CP_GRAM0 = WK_CDOF + 1, CP_GRAM_CAP = (6 * NV - 1) / 8;
+static_assert((L4_WK + CP_GRAM0) % 4 == 0 && CP_GRAM_CAP >= 17, "contact Gram table");
+typedef float f4r __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f4r lf4r;
+
 struct CompleteCtx {
-    const St& S; float* rows; float* hbm; int l; V3 o;
+    const St& S; lfloat* rows; lfloat* ld; float* hbm; int l, lc; bool act; V3 o;
     float cdl[2][6];      // motion axis of this lane's leg dof, both legs
     float cdp[6][6];      // the six pelvis axes (uniform)
     LaneFac F; float disq[2], disqp[6];
     LaneVec qs, qv, qw;
 };
-__device__ __forceinline__ float* cp_rec(const CompleteCtx& C, int i) {
-    if (i < CP_ROWS_CAP) return C.rows + CP_STRIDE * i;
-    if (i < CP_LDS_CAP) return (float*)&C.S.W(WK_LD) + CP_STRIDE * (i - CP_ROWS_CAP);
-    return C.hbm + (size_t)CP_STRIDE * (i - CP_LDS_CAP);
-}
-// scalar words of a record (rewritten during the sweeps): plain LDS words, or agent-scope atomics on the HBM tier
+// LDS tier: records 0 .. 25 in the row store, 26 .. 37 in WK_LD (a select between two LDS addresses, no branch); HBM tier behind
+__device__ __forceinline__ lfloat* cp_lds(const CompleteCtx& C, int i) { return (i < CP_ROWS_CAP ? C.rows : C.ld - CP_STRIDE * CP_ROWS_CAP) + CP_STRIDE * i; }
+__device__ __forceinline__ float* cp_hbm(const CompleteCtx& C, int i) { return C.hbm + (size_t)CP_STRIDE * (i - CP_LDS_CAP); }
+// scalar words of a record (rewritten during the sweeps): plain LDS words, or agent-scope atomics on the HBM tier.  LDS = true: the caller knows that every record of
+// the wave's envs is in LDS (the case outside a robot lying flat on the floor) - no tier branch, LDS instructions only
+template <bool LDS>
 __device__ __forceinline__ float sc_get(const CompleteCtx& C, int i, int k) {
-    float* r = cp_rec(C, i);
-    if (i < CP_LDS_CAP) return r[k];
-    return __int_as_float(__hip_atomic_load((int*)(r + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (LDS || i < CP_LDS_CAP) return cp_lds(C, i)[k];
+    return __int_as_float(__hip_atomic_load((int*)(cp_hbm(C, i) + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+template <bool LDS>
 __device__ __forceinline__ void sc_set(const CompleteCtx& C, int i, int k, float v) {
-    float* r = cp_rec(C, i);
-    if (i < CP_LDS_CAP) r[k] = v;
-    else __hip_atomic_store((int*)(r + k), __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (LDS || i < CP_LDS_CAP) cp_lds(C, i)[k] = v;
+    else __hip_atomic_store((int*)(cp_hbm(C, i) + k), __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float lv_dot(const CompleteCtx& C, const LaneVec& x, const LaneVec& y) {
     float r = red16(C.l < 13 ? x.a[0] * y.a[0] + x.a[1] * y.a[1] : 0.f);
@@ -105,30 +118,178 @@ __device__ __forceinline__ void whiten(const CompleteCtx& C, LaneVec& J, float& 
 }
 // store a whitened vector as pool record(s): a row of ONE leg takes one record, a left-right pair row two (left columns + pelvis, right columns)
 __device__ __forceinline__ void cp_store(const CompleteCtx& C, int i, const LaneVec& y, int leg) {
-    float* r = cp_rec(C, i);
-    if (C.l < 13) r[C.l] = leg ? y.a[1] : y.a[0];
-    if (C.l == 0) { sfor<0, 6>([&](auto P) { r[13 + P] = y.p[P]; }); sc_set(C, i, 19, (float)leg); }
+    const float col = leg ? y.a[1] : y.a[0];
+    if (i < CP_LDS_CAP) {
+        lfloat* r = cp_lds(C, i);
+        if (C.act) r[C.l] = col;
+        if (C.l == 0) { sfor<0, 6>([&](auto P) { r[cpw_p(P)] = y.p[P]; }); r[CPW_MISC] = (float)leg; }
+    } else {
+        float* r = cp_hbm(C, i);
+        if (C.act) r[C.l] = col;
+        if (C.l == 0) { sfor<0, 6>([&](auto P) { r[cpw_p(P)] = y.p[P]; }); sc_set<false>(C, i, CPW_MISC, (float)leg); }
+    }
+}
+// a record's vector part in registers: this lane's leg column (0 on lanes 13..15), the pelvis columns, the extra word
+struct RecVec { float ya, p[6], misc; };
+template <bool LDS>
+__device__ __forceinline__ RecVec rec_vec(const CompleteCtx& C, int i) {
+    RecVec v;
+    if (LDS || i < CP_LDS_CAP) {
+        lfloat* r = cp_lds(C, i);
+        const float col = r[C.lc];
+        const f4r q0 = *(lf4r*)(r + 12), q1 = *(lf4r*)(r + 16);
+        v.ya = C.act ? col : 0.f; v.misc = q0.y; v.p[0] = q1.x; v.p[1] = q1.y; v.p[2] = q1.z; v.p[3] = q1.w; v.p[4] = q0.z; v.p[5] = q0.w;
+    } else {
+        const float* r = cp_hbm(C, i);
+        v.ya = C.act ? r[C.lc] : 0.f;
+        sfor<0, 6>([&](auto P) { v.p[P] = r[cpw_p(P)]; });
+        v.misc = sc_get<false>(C, i, CPW_MISC);
+    }
+    return v;
+}
+template <bool LDS>
+__device__ __forceinline__ f4r rec_sc(const CompleteCtx& C, int i) {
+    if (LDS || i < CP_LDS_CAP) return *(lf4r*)(cp_lds(C, i) + 20);
+    return f4r{sc_get<false>(C, i, 20), sc_get<false>(C, i, 21), sc_get<false>(C, i, 22), sc_get<false>(C, i, 23)};
 }
 // rho = y~ . z~ and z~ += y~ df for a record of leg `leg` (lane-uniform over the env)
-__device__ __forceinline__ float cp_dot(const CompleteCtx& C, const float* r, int leg, const LaneVec& z) {
-    const float ya = C.l < 13 ? r[C.l] : 0.f;
-    float s = red16(ya * (leg ? z.a[1] : z.a[0]));
-    sfor<0, 6>([&](auto P) { s += r[13 + P] * z.p[P]; });
+__device__ __forceinline__ float rv_dot(const RecVec& v, bool leg, const LaneVec& z) {
+    float s = red16(v.ya * (leg ? z.a[1] : z.a[0]));
+    sfor<0, 6>([&](auto P) { s += v.p[P] * z.p[P]; });
     return s;
 }
-__device__ __forceinline__ void cp_axpy(const CompleteCtx& C, const float* r, int leg, float df, LaneVec& z) {
-    const float ya = C.l < 13 ? r[C.l] : 0.f;
-    z.a[0] += leg ? 0.f : ya * df; z.a[1] += leg ? ya * df : 0.f;
-    sfor<0, 6>([&](auto P) { z.p[P] += r[13 + P] * df; });
+__device__ __forceinline__ void rv_axpy(const RecVec& v, bool leg, float df, LaneVec& z) {
+    const float t = v.ya * df;
+    z.a[0] += leg ? 0.f : t; z.a[1] += leg ? t : 0.f;
+    sfor<0, 6>([&](auto P) { z.p[P] += v.p[P] * df; });
 }
 
 // row kinds of the sweep list (one word per row in LDS, oracle order): kind | first record << 4
 enum { CK_EQ = 0, CK_LIMIT = 1, CK_CONTACT = 2, CK_PAIR = 3 };
 
-template <bool HF>
-__device__ __forceinline__ void rows_pgs_complete(const St& S, const FacRegs& FR, const FacTail& FT, float* rows, int pgs_iters, const Hf& hf, float* pool) {
-    CompleteCtx C{S, rows, pool + (size_t)S.env * CP_HBM_CAP * CP_STRIDE, (int)(threadIdx.x & 15), {S(F_QPOS), S(F_QPOS + 1), S(F_QPOS + 2)}};
+// Warm start, projected Gauss-Seidel over the sweep list in oracle order, hand-off to the finish stage.
+template <bool LDS>
+__device__ __forceinline__ void cp_solve(const CompleteCtx& C, int nlist, int pgs_iters, float mu, int over, int nfoot0, int nfoot1) {
+    const St& S = C.S;
     const int l = C.l;
+    auto list_at = [&](int i) -> lfloat& { return *(i < 32 ? &S.W(WK_ZT) + i : &S.W(WK_DISQ) + (i - 32)); };
+    // ---------------------------------------------------------------- warm start: z~0 = sum y~ f0; kept only if its dual cost beats f = 0 (mj_fwdConstraint)
+    LaneVec z{{0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+    float cost = 0.f;
+    for (int i = 0; i < nlist; ++i) {
+        const int w = __float_as_int(list_at(i)), kind = w & 15, rec = (w >> 4) & 255;
+        const RecVec v0 = rec_vec<LDS>(C, rec);
+        const f4r s0 = rec_sc<LDS>(C, rec);
+        if (kind == CK_CONTACT) {
+            const RecVec v1 = rec_vec<LDS>(C, rec + 1), v2 = rec_vec<LDS>(C, rec + 2);
+            const f4r f = rec_sc<LDS>(C, rec + 1);
+            const float Rpy = sc_get<LDS>(C, rec + 2, 20);
+            const bool leg = v0.misc != 0.f;
+            rv_axpy(v0, leg, f.x + f.y + f.z + f.w, z); rv_axpy(v1, leg, mu * (f.x - f.y), z); rv_axpy(v2, leg, mu * (f.z - f.w), z);
+            cost += f.x * (0.5f * Rpy * f.x + s0.x) + f.y * (0.5f * Rpy * f.y + s0.y) + f.z * (0.5f * Rpy * f.z + s0.z) + f.w * (0.5f * Rpy * f.w + s0.w);
+        } else {
+            const float f = s0.w;
+            rv_axpy(v0, kind == CK_PAIR ? false : v0.misc != 0.f, f, z);
+            if (kind == CK_PAIR) rv_axpy(rec_vec<LDS>(C, rec + 1), true, f, z);
+            cost += f * (0.5f * s0.y * f + s0.x);
+        }
+    }
+    cost += 0.5f * lv_dot(C, z, z);
+    const bool cold = cost > 0.f;
+    if (cold) { z.a[0] = z.a[1] = 0.f; sfor<0, 6>([&](auto P) { z.p[P] = 0.f; }); }
+    wsync();
+    if (cold && l == 0)
+        for (int i = 0; i < nlist; ++i) {
+            const int w = __float_as_int(list_at(i)), kind = w & 15, rec = (w >> 4) & 255;
+            if (kind == CK_CONTACT) { sfor<0, 4>([&](auto K) { sc_set<LDS>(C, rec + 1, 20 + K, 0.f); }); }
+            else sc_set<LDS>(C, rec, 23, 0.f);
+        }
+    wsync();
+    // ---------------------------------------------------------------- projected Gauss-Seidel over the list, oracle order.  The list word of entry i + 1 is fetched while
+    // entry i is worked on; the loads of an entry (vectors, scalars, Gram block) issue together in front of its arithmetic.
+    for (int it = 0; it < pgs_iters; ++it) {
+        int w = __float_as_int(list_at(0));
+        for (int i = 0; i < nlist; ++i) {
+            const int kind = w & 15, rec = (w >> 4) & 255, ci = w >> 12;
+            const RecVec v0 = rec_vec<LDS>(C, rec);
+            const f4r s0 = rec_sc<LDS>(C, rec);
+            const int wn = __float_as_int(list_at(i + 1 < nlist ? i + 1 : i));
+            if (kind == CK_CONTACT) {
+                const RecVec v1 = rec_vec<LDS>(C, rec + 1), v2 = rec_vec<LDS>(C, rec + 2);
+                const f4r fv = rec_sc<LDS>(C, rec + 1);
+                const float Rpy = sc_get<LDS>(C, rec + 2, 20);
+                const lfloat* g = &S.W(CP_GRAM0 + 8 * ci);
+                const f4r g0 = *(const lf4r*)g;
+                const float gnn = g0.x, gn1 = g0.y, gn2 = g0.z, g11 = g0.w, g12 = g[4], g22 = g[5];
+                const bool leg = v0.misc != 0.f;
+                float rn = rv_dot(v0, leg, z), ra = rv_dot(v1, leg, z), rb = rv_dot(v2, leg, z);
+                float f[4] = {fv.x, fv.y, fv.z, fv.w};
+                const float bk[4] = {s0.x, s0.y, s0.z, s0.w};
+                float dn = 0.f, d1 = 0.f, d2 = 0.f;
+                sfor<0, 4>([&](auto K) {
+                    constexpr int k = K;
+                    const float sg = (k & 1) ? -mu : mu;
+                    const float gj = k < 2 ? gn1 : gn2, gjj = k < 2 ? g11 : g22;
+                    const float res = rn + sg * (k < 2 ? ra : rb) + bk[k] + Rpy * f[k];
+                    const float A = gnn + 2.f * sg * gj + mu * mu * gjj + Rpy;
+                    const float fnew = fmaxf(f[k] - res * rcpf(A), 0.f), df = fnew - f[k];
+                    f[k] = fnew;
+                    // the row n + sg t_j moves the three basis residuals
+                    rn += df * (gnn + sg * gj); ra += df * (gn1 + sg * (k < 2 ? g11 : g12)); rb += df * (gn2 + sg * (k < 2 ? g12 : g22));
+                    dn += df; if constexpr (k < 2) d1 += sg * df; else d2 += sg * df;
+                });
+                rv_axpy(v0, leg, dn, z); rv_axpy(v1, leg, d1, z); rv_axpy(v2, leg, d2, z);
+                if (l == 0) {
+                    if constexpr (LDS) *(lf4r*)(cp_lds(C, rec + 1) + 20) = f4r{f[0], f[1], f[2], f[3]};
+                    else sfor<0, 4>([&](auto K) { sc_set<false>(C, rec + 1, 20 + K, f[K]); });
+                }
+            } else {
+                const bool pair = kind == CK_PAIR;
+                const bool leg = pair ? false : v0.misc != 0.f;
+                RecVec v1 = rec_vec<LDS>(C, rec + (pair ? 1 : 0));      // the right-leg half of a pair row; a copy of the record otherwise (not used)
+                float rho = rv_dot(v0, leg, z);
+                const float rho1 = rv_dot(v1, true, z);
+                rho += pair ? rho1 : 0.f;
+                const float f = s0.w, res = rho + s0.x + s0.y * f;
+                float fnew = f - res * s0.z;
+                if (kind != CK_EQ) fnew = fmaxf(fnew, 0.f);
+                const float df = fnew - f;
+                rv_axpy(v0, leg, df, z);
+                rv_axpy(v1, true, pair ? df : 0.f, z);
+                if (l == 0) sc_set<LDS>(C, rec, 23, fnew);
+            }
+            w = wn;
+            wsync();
+        }
+    }
+    // ---------------------------------------------------------------- hand-off to the finish stage: contact-slot records of the FOOT capsules (foot-force readout), z~
+    if (l == 0) {
+        lfloat* const rows = C.rows;
+        sfor<0, 2 * MAXC>([&](auto Sl) { lfloat* cr = rows + R4_CON + R4_CONSZ * Sl; cr[7] = 0.f; sfor<0, 4>([&](auto K) { cr[12 + K] = 0.f; }); });
+        for (int i = 0; i < nlist; ++i) {
+            const int w = __float_as_int(list_at(i)), kind = w & 15, rec = (w >> 4) & 255;
+            if (kind != CK_CONTACT) continue;
+            const int slot = (int)sc_get<LDS>(C, rec + 2, CPW_MISC);
+            if (slot <= 0 || slot > MAXC) continue;
+            const int leg = (int)sc_get<LDS>(C, rec, CPW_MISC);
+            lfloat* cr = rows + R4_CON + R4_CONSZ * (MAXC * leg + slot - 1);
+            cr[7] = 1.f; cr[8] = sc_get<LDS>(C, rec + 2, 21); cr[9] = sc_get<LDS>(C, rec + 2, 22); cr[10] = sc_get<LDS>(C, rec + 1, CPW_MISC);      // world z of the contact frame (n, t1, t2)
+            sfor<0, 4>([&](auto K) { cr[12 + K] = sc_get<LDS>(C, rec + 1, 20 + K); });
+        }
+        S.W(WK_MISC + 0) = (float)(nfoot0 < MAXC ? nfoot0 : MAXC); S.W(WK_MISC + 1) = (float)(nfoot1 < MAXC ? nfoot1 : MAXC);
+        if (over) S.I(I_SAT) |= 16;      // more rows than the pool holds (never seen): reported
+    }
+    wsync();
+    if (l < 13) { S.W(WK_ZT + 6 + l) = z.a[0]; S.W(WK_ZT + 19 + l) = z.a[1]; }
+    if (l == 0) sfor<0, 6>([&](auto P) { S.W(WK_ZT + P) = z.p[P]; });
+    wsync();
+}
+
+template <bool HF>
+__device__ __forceinline__ void rows_pgs_complete(const St& S, const FacRegs& FR, const FacTail& FT, float* rows_generic, int pgs_iters, const Hf& hf, float* pool) {
+    lfloat* const rows = S.p + L4_ROWS;      // the env's row store (= rows_generic, as an LDS pointer: everything below compiles to ds_* instructions)
+    const int l = (int)(threadIdx.x & 15);
+    CompleteCtx C{S, rows, &S.W(CP_LD0), pool + (size_t)S.env * CP_HBM_CAP * CP_STRIDE, l, l < 13 ? l : 12, l < 13, {S(F_QPOS), S(F_QPOS + 1), S(F_QPOS + 2)}};
     {
         const int ll = l < 13 ? l : 12;
         sfor<0, 2>([&](auto Lg) { sfor<0, 6>([&](auto I) { C.cdl[Lg][I] = S.W(WK_CDOF + 6 * (6 + 13 * Lg + ll) + I); }); });
@@ -166,7 +327,7 @@ __device__ __forceinline__ void rows_pgs_complete(const St& S, const FacRegs& FR
         float f = -(jw - aref) * rcpf(R);
         if (kind != CK_EQ && f < 0.f) f = 0.f;
         cp_store(C, nrec, J, leg);
-        if (l == 0) { sc_set(C, nrec, 20, ju - aref); sc_set(C, nrec, 21, R); sc_set(C, nrec, 22, rcpf(nn + R)); sc_set(C, nrec, 23, f); }
+        if (l == 0) { sc_set<false>(C, nrec, 20, ju - aref); sc_set<false>(C, nrec, 21, R); sc_set<false>(C, nrec, 22, rcpf(nn + R)); sc_set<false>(C, nrec, 23, f); }
         push(kind, nrec); ++nrec;
     };
     // ---------------------------------------------------------------- pyramidal floor contact: three records (n, t1, t2).  Scalars: n-record [20..23] = b of the four pyramid
@@ -174,7 +335,7 @@ __device__ __forceinline__ void rows_pgs_complete(const St& S, const FacRegs& FR
     // of n, t1.  The 3 x 3 Gram block of the basis (6 words) goes to the contact's entry of a table in WK_CDOF (the motion axes are in registers by now).
     int ncont = 0;
     auto add_contact = [&](int leg, int lb, V3 ctr, float rad, float dist, V3 nrm, float tran, bool isfoot) {
-        if (nrec + 3 > CP_CAP || ncont >= 32) { over = 1; return; }
+        if (nrec + 3 > CP_CAP || ncont >= CP_GRAM_CAP) { over = 1; return; }
         V3 t1 = ft1, t2 = ft2;
         if constexpr (HF) {
             const bool uy = fabsf(nrm.y) < 0.5f;
@@ -203,11 +364,12 @@ __device__ __forceinline__ void rows_pgs_complete(const St& S, const FacRegs& FR
                 const float sg = (k & 1) ? -mu : mu;
                 const float vk = vel[0] + sg * (k < 2 ? vel[1] : vel[2]), uk = ju[0] + sg * (k < 2 ? ju[1] : ju[2]), wk = jw[0] + sg * (k < 2 ? jw[1] : jw[2]);
                 const float aref = -kb.B * vk - kb.K * imp * dist;
-                sc_set(C, nrec, 20 + k, uk - aref);
-                sc_set(C, nrec + 1, 20 + k, fmaxf(-(wk - aref) * iRpy, 0.f));
+                sc_set<false>(C, nrec, 20 + k, uk - aref);
+                sc_set<false>(C, nrec + 1, 20 + k, fmaxf(-(wk - aref) * iRpy, 0.f));
             });
-            sc_set(C, nrec + 1, 19, t2.z); sc_set(C, nrec + 2, 19, isfoot ? (float)(1 + nfoot[leg]) : 0.f); sc_set(C, nrec + 2, 20, Rpy); sc_set(C, nrec + 2, 21, nrm.z); sc_set(C, nrec + 2, 22, t1.z);
-            lfloat* g = &S.W(WK_CDOF + 6 * ncont);
+            // (cp_store wrote the leg into the extra word of all three records; the t1 and t2 records keep something else there)
+            sc_set<false>(C, nrec + 1, CPW_MISC, t2.z); sc_set<false>(C, nrec + 2, CPW_MISC, isfoot ? (float)(1 + nfoot[leg]) : 0.f); sc_set<false>(C, nrec + 2, 20, Rpy); sc_set<false>(C, nrec + 2, 21, nrm.z); sc_set<false>(C, nrec + 2, 22, t1.z);
+            lfloat* g = &S.W(CP_GRAM0 + 8 * ncont);
             g[0] = gnn; g[1] = gn1; g[2] = gn2; g[3] = g11; g[4] = g12; g[5] = g22;
         }
         if (isfoot) ++nfoot[leg];
@@ -302,112 +464,22 @@ __device__ __forceinline__ void rows_pgs_complete(const St& S, const FacRegs& FR
             const float aref = -kb.B * vel - kb.K * imp * dist;
             cp_store(C, nrec, J, 0);
             { LaneVec Jr = J; sfor<0, 6>([&](auto P) { Jr.p[P] = 0.f; }); cp_store(C, nrec + 1, Jr, 1); }
-            if (l == 0) { sc_set(C, nrec, 20, ju - aref); sc_set(C, nrec, 21, R); sc_set(C, nrec, 22, rcpf(n2 + R)); sc_set(C, nrec, 23, fmaxf(-(jw - aref) * rcpf(R), 0.f)); }
+            if (l == 0) { sc_set<false>(C, nrec, 20, ju - aref); sc_set<false>(C, nrec, 21, R); sc_set<false>(C, nrec, 22, rcpf(n2 + R)); sc_set<false>(C, nrec, 23, fmaxf(-(jw - aref) * rcpf(R), 0.f)); }
             push(CK_PAIR, nrec); nrec += 2;
         }
     if (nrec > CP_LDS_CAP) __threadfence();      // vectors on the HBM tier: visible to every lane's plain loads from here on
     wsync();
-    // ---------------------------------------------------------------- warm start: z~0 = sum y~ f0; kept only if its dual cost beats f = 0 (mj_fwdConstraint)
-    LaneVec z{{0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
-    float cost = 0.f;
-    for (int i = 0; i < nlist; ++i) {
-        const int w = __float_as_int(list_at(i)), kind = w & 15, rec = (w >> 4) & 255;
-        float* r = cp_rec(C, rec);
-        if (kind == CK_CONTACT) {
-            float* r1 = cp_rec(C, rec + 1); float* r2 = cp_rec(C, rec + 2);
-            const int leg = (int)sc_get(C, rec, 19);
-            const float f0 = sc_get(C, rec + 1, 20), f1 = sc_get(C, rec + 1, 21), f2 = sc_get(C, rec + 1, 22), f3 = sc_get(C, rec + 1, 23), Rpy = sc_get(C, rec + 2, 20);
-            cp_axpy(C, r, leg, f0 + f1 + f2 + f3, z); cp_axpy(C, r1, leg, mu * (f0 - f1), z); cp_axpy(C, r2, leg, mu * (f2 - f3), z);
-            cost += f0 * (0.5f * Rpy * f0 + sc_get(C, rec, 20)) + f1 * (0.5f * Rpy * f1 + sc_get(C, rec, 21)) + f2 * (0.5f * Rpy * f2 + sc_get(C, rec, 22)) + f3 * (0.5f * Rpy * f3 + sc_get(C, rec, 23));
-        } else {
-            const float f = sc_get(C, rec, 23);
-            cp_axpy(C, r, kind == CK_PAIR ? 0 : (int)sc_get(C, rec, 19), f, z);
-            if (kind == CK_PAIR) cp_axpy(C, cp_rec(C, rec + 1), 1, f, z);
-            cost += f * (0.5f * sc_get(C, rec, 21) * f + sc_get(C, rec, 20));
-        }
-    }
-    cost += 0.5f * lv_dot(C, z, z);
-    const bool cold = cost > 0.f;
-    if (cold) { z.a[0] = z.a[1] = 0.f; sfor<0, 6>([&](auto P) { z.p[P] = 0.f; }); }
-    wsync();
-    if (cold && l == 0)
-        for (int i = 0; i < nlist; ++i) {
-            const int w = __float_as_int(list_at(i)), kind = w & 15, rec = (w >> 4) & 255;
-            if (kind == CK_CONTACT) { sfor<0, 4>([&](auto K) { sc_set(C, rec + 1, 20 + K, 0.f); }); }
-            else sc_set(C, rec, 23, 0.f);
-        }
-    wsync();
-    // ---------------------------------------------------------------- projected Gauss-Seidel over the list, oracle order
-    for (int it = 0; it < pgs_iters; ++it) {
-        for (int i = 0; i < nlist; ++i) {
-            const int w = __float_as_int(list_at(i)), kind = w & 15, rec = (w >> 4) & 255, ci = w >> 12;
-            float* r = cp_rec(C, rec);
-            if (kind == CK_CONTACT) {
-                float* r1 = cp_rec(C, rec + 1); float* r2 = cp_rec(C, rec + 2);
-                const int leg = (int)sc_get(C, rec, 19);
-                float rn = cp_dot(C, r, leg, z), ra = cp_dot(C, r1, leg, z), rb = cp_dot(C, r2, leg, z);
-                const lfloat* g = &S.W(WK_CDOF + 6 * ci);
-                const float gnn = g[0], gn1 = g[1], gn2 = g[2], g11 = g[3], g12 = g[4], g22 = g[5];
-                const float Rpy = sc_get(C, rec + 2, 20);
-                float f[4] = {sc_get(C, rec + 1, 20), sc_get(C, rec + 1, 21), sc_get(C, rec + 1, 22), sc_get(C, rec + 1, 23)};
-                const float bk[4] = {sc_get(C, rec, 20), sc_get(C, rec, 21), sc_get(C, rec, 22), sc_get(C, rec, 23)};
-                float dn = 0.f, d1 = 0.f, d2 = 0.f;
-                sfor<0, 4>([&](auto K) {
-                    constexpr int k = K;
-                    const float sg = (k & 1) ? -mu : mu;
-                    const float gj = k < 2 ? gn1 : gn2, gjj = k < 2 ? g11 : g22;
-                    const float res = rn + sg * (k < 2 ? ra : rb) + bk[k] + Rpy * f[k];
-                    const float A = gnn + 2.f * sg * gj + mu * mu * gjj + Rpy;
-                    const float fnew = fmaxf(f[k] - res * rcpf(A), 0.f), df = fnew - f[k];
-                    f[k] = fnew;
-                    // the row n + sg t_j moves the three basis residuals
-                    rn += df * (gnn + sg * gj); ra += df * (gn1 + sg * (k < 2 ? g11 : g12)); rb += df * (gn2 + sg * (k < 2 ? g12 : g22));
-                    dn += df; if constexpr (k < 2) d1 += sg * df; else d2 += sg * df;
-                });
-                cp_axpy(C, r, leg, dn, z); cp_axpy(C, r1, leg, d1, z); cp_axpy(C, r2, leg, d2, z);
-                if (l == 0) sfor<0, 4>([&](auto K) { sc_set(C, rec + 1, 20 + K, f[K]); });
-            } else {
-                const int leg = kind == CK_PAIR ? 0 : (int)sc_get(C, rec, 19);
-                float rho = cp_dot(C, r, leg, z);
-                if (kind == CK_PAIR) rho += cp_dot(C, cp_rec(C, rec + 1), 1, z);
-                const float f = sc_get(C, rec, 23), res = rho + sc_get(C, rec, 20) + sc_get(C, rec, 21) * f;
-                float fnew = f - res * sc_get(C, rec, 22);
-                if (kind != CK_EQ) fnew = fmaxf(fnew, 0.f);
-                const float df = fnew - f;
-                cp_axpy(C, r, leg, df, z);
-                if (kind == CK_PAIR) cp_axpy(C, cp_rec(C, rec + 1), 1, df, z);
-                if (l == 0) sc_set(C, rec, 23, fnew);
-            }
-            wsync();
-        }
-    }
-    // ---------------------------------------------------------------- hand-off to the finish stage: contact-slot records of the FOOT capsules (foot-force readout), z~
-    if (l == 0) {
-        sfor<0, 2 * MAXC>([&](auto Sl) { float* cr = rows + R4_CON + R4_CONSZ * Sl; cr[7] = 0.f; sfor<0, 4>([&](auto K) { cr[12 + K] = 0.f; }); });
-        for (int i = 0; i < nlist; ++i) {
-            const int w = __float_as_int(list_at(i)), kind = w & 15, rec = (w >> 4) & 255;
-            if (kind != CK_CONTACT) continue;
-            const int slot = (int)sc_get(C, rec + 2, 19);
-            if (slot <= 0 || slot > MAXC) continue;
-            const int leg = (int)sc_get(C, rec, 19);
-            float* cr = rows + R4_CON + R4_CONSZ * (MAXC * leg + slot - 1);
-            cr[7] = 1.f; cr[8] = sc_get(C, rec + 2, 21); cr[9] = sc_get(C, rec + 2, 22); cr[10] = sc_get(C, rec + 1, 19);      // world z of the contact frame (n, t1, t2)
-            sfor<0, 4>([&](auto K) { cr[12 + K] = sc_get(C, rec + 1, 20 + K); });
-        }
-        S.W(WK_MISC + 0) = (float)(nfoot[0] < MAXC ? nfoot[0] : MAXC); S.W(WK_MISC + 1) = (float)(nfoot[1] < MAXC ? nfoot[1] : MAXC);
-        if (over) S.I(I_SAT) |= 16;      // more rows than the pool holds (never seen): reported
-    }
-    wsync();
-    if (l < 13) { S.W(WK_ZT + 6 + l) = z.a[0]; S.W(WK_ZT + 19 + l) = z.a[1]; }
-    if (l == 0) sfor<0, 6>([&](auto P) { S.W(WK_ZT + P) = z.p[P]; });
-    wsync();
+    // every record of the wave's envs in LDS (always, short of a robot lying flat on the floor): the solve compiles without the tier branches and without a global access
+    if (__builtin_amdgcn_ballot_w64(nrec > CP_LDS_CAP) == 0ull) cp_solve<true>(C, nlist, pgs_iters, mu, over, nfoot[0], nfoot[1]);
+    else cp_solve<false>(C, nlist, pgs_iters, mu, over, nfoot[0], nfoot[1]);
 }
 
 // The rest of a substep for the envs of a wave whose pass saturated, OUT OF LINE and called where nothing of the fast path is live any more (after the finish stage of the
 // other envs): the factor again from WK_M (the fast path's copy lives in registers that a call could only keep in callee-saved ones - carried through the sweeps, they
 // pushed reloads into the inline-asm DPP sequences, which the hazard recogniser cannot see), the complete rows and their solve, then the env's own finish stage.
 template <bool HF>
-__device__ __noinline__ void substep_complete(St S, float* rows, int pgs_iters, Hf hf, float* pool, int do_euler) {
+__device__ __noinline__ void substep_complete(St S, float* rows_arg, int pgs_iters, Hf hf, float* pool, int do_euler) {
+    float* const rows = (float*)(S.p + L4_ROWS);      // = rows_arg, spelled as a cast of the LDS pointer: behind the call boundary the compiler would otherwise have to treat it as a flat address
     FacRegs FR; FacTail FT;
     stage_factor_lane<false>(S, FR, FT);
     wsync();
