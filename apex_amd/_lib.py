@@ -84,6 +84,7 @@ SIGNATURES = {
     "apx_env_timing": (C.c_int, [c_ptr, C.c_int]),
     "apx_env_timing_read": (C.c_int, [c_ptr, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
     "apx_rollout": (C.c_int, [c_ptr, c_ptr, C.c_int, c_ptr, c_ptr, C.c_float, c_ptr, C.c_int] + [c_ptr] * 8),
+    "apx_rollout_lstm": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, c_ptr, C.c_float, c_ptr, C.c_int] + [c_ptr] * 8),
     "apx_env_step": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, c_ptr]),
     "apx_env_get_state": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
     "apx_env_set_state": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),
@@ -109,6 +110,8 @@ def load():
     import torch  # noqa: F401  (first: libapx.so must bind to the HIP runtime torch ships - loaded the other way round, the process holds two runtimes and the library's sees no device)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("APX_LIB_OLD_ABI") == "1" and not hasattr(lib, name):      # tools only: A/B timing against a library built from an older commit (APX_LIB=...), which lacks the newer entry points
+            continue
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args

@@ -381,6 +381,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
         // the points themselves for the complete-row path (cassie_complete.h): hip-pitch capsule ends (left e0, e1, right e0, e1) from the hip-pitch lane, the pelvis
         // sphere centre from lane 0, 15 words of the row store that neither the exchange records nor the row stage's parked vectors touch
         constexpr int XE = 38 * 16;
+#ifndef APX_NO_TREE_EXTRA      /* A/B build */
         if (l == 2) {
             const V3p e0 = c + ax, e1 = c - ax;
             float* q = xb + XE;
@@ -388,6 +389,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             q[6] = e0.x.y; q[7] = e0.y.y; q[8] = e0.z.y; q[9] = e1.x.y; q[10] = e1.y.y; q[11] = e1.z.y;
         }
         if (l == 0) { const V3 pc = o + mul(pmat, cv3<8>(ct_geom_pos)); float* q = xb + XE + 12; q[0] = pc.x; q[1] = pc.y; q[2] = pc.z; }
+#endif
     }
     // ---- anchor points, capsule ends, foot pose (body lanes that own them)
     {

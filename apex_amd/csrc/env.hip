@@ -707,6 +707,11 @@ struct RolloutArgs {
     float *obs_grid, *act_grid, *mu_grid, *rew_grid; uint8_t* done_grid; float *fin_grid, *obs_next;
     float* rst; int* rst_int;                          // the reset ring, writable (an image missing from it is computed in place)
     Cfg cfg;                                           // a copy of the launch's Cfg for the out-of-line restart (rollout_restart)
+    // recurrent actor (apx_rollout_lstm; Gaussian_LSTM_Actor, rl/policies/actor.py:218-311): two LSTMCell(128) + the head (Wt2 / b2 above, H = 128).  Gate matrices k-major
+    // [in][4 H] (gate order i, f, g, o), the two bias vectors of a cell as they are in the parameter block, the carried (h, c) of every env [n][2 cells][h | c][128]
+    int lstm = 0;
+    const float *Gx0 = nullptr, *Gh0 = nullptr, *bi0 = nullptr, *bh0 = nullptr, *Gx1 = nullptr, *Gh1 = nullptr, *bi1 = nullptr, *bh1 = nullptr;
+    float* hc = nullptr;
 };
 template <int KG, int NG>
 __device__ __forceinline__ void ff_layer4(const float* __restrict__ Wt, const float* __restrict__ bias, int K, int N, const float (&hin)[KG][4], float (&hout)[NG][4], bool relu) {
@@ -733,8 +738,61 @@ __device__ __forceinline__ void ff_layer4(const float* __restrict__ Wt, const fl
     });
     c4::sfor<0, NG>([&](auto G) { c4::sfor<0, 4>([&](auto E) { hout[G][E] = relu ? fmaxf(acc[G][E], 0.f) : acc[G][E]; }); });
 }
+// acc[G][E] += sum_k hin_E[k] Wt[k][64 G + lane]  (all N = 64 NG columns exist)
+template <int KG, int NG>
+__device__ __forceinline__ void ff_accum4(const float* __restrict__ Wt, int K, const float (&hin)[KG][4], float (&acc)[NG][4]) {
+    const int lane = threadIdx.x;
+    constexpr int N = 64 * NG;
+    c4::sfor<0, KG>([&](auto Kg) {
+        constexpr int kg = Kg;
+        const int kend = K - 64 * kg < 64 ? K - 64 * kg : 64;
+#pragma unroll 4
+        for (int kk = 0; kk < kend; ++kk) {
+            const float* wr = Wt + (size_t)(64 * kg + kk) * N + lane;
+            float w[NG];
+            c4::sfor<0, NG>([&](auto G) { w[G] = wr[64 * G]; });
+            c4::sfor<0, 4>([&](auto E) {
+                const float hk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hin[kg][E]), kk));
+                c4::sfor<0, NG>([&](auto G) { acc[G][E] = fmaf(hk, w[G], acc[G][E]); });
+            });
+        }
+    });
+}
+__device__ __forceinline__ float sigm_dev(float x) { return 1.f / (1.f + expf(-x)); }
+// One LSTMCell(128) for the wave's four envs (torch.nn.LSTMCell: gates = W_ih x + b_ih + W_hh h + b_hh, c' = f c + i g, h' = o tanh c').  Lane j owns the hidden units
+// j and 64 + j: gate column 64 G + lane = gate G >> 1 of unit 64 (G & 1) + lane.  hcw = the wave's carried states, cell `cell`.
+template <int KG>
+__device__ __forceinline__ void lstm_cell4(const float* Gx, int Kx, const float* Gh, const float* bi, const float* bh, float* hcw, int cell, const float (&xin)[KG][4], float (&hout)[2][4]) {
+    const int lane = threadIdx.x;
+    float g[8][4], h[2][4], c[2][4];
+    c4::sfor<0, 8>([&](auto G) { const float b = bi[64 * G + lane] + bh[64 * G + lane]; c4::sfor<0, 4>([&](auto E) { g[G][E] = b; }); });
+    c4::sfor<0, 4>([&](auto E) { c4::sfor<0, 2>([&](auto U) {
+        const float* q = hcw + 512 * E + 256 * cell + 64 * U + lane;
+        h[U][E] = q[0]; c[U][E] = q[128];
+    }); });
+    ff_accum4<KG, 8>(Gx, Kx, xin, g);
+    ff_accum4<2, 8>(Gh, 128, h, g);
+    c4::sfor<0, 4>([&](auto E) { c4::sfor<0, 2>([&](auto U) {
+        const float i = sigm_dev(g[U][E]), f = sigm_dev(g[2 + U][E]), gg = tanhf(g[4 + U][E]), o = sigm_dev(g[6 + U][E]);
+        const float cn = f * c[U][E] + i * gg, hn = o * tanhf(cn);
+        float* q = hcw + 512 * E + 256 * cell + 64 * U + lane;
+        q[0] = hn; q[128] = cn; hout[U][E] = hn;
+    }); });
+}
 __device__ __forceinline__ const RolloutArgs* ra_ptr(const RolloutArgs* p) { asm volatile("" : "+s"(p)); return p; }
 __device__ __forceinline__ lfloat* env_region(int e) { return (lfloat*)apx_lds4 + e * L4_ES; }
+// the recurrent actor's step for the wave's four envs: x = this lane's normalised observation entry of env 0..3; returns the action means (lane < 10).  The carried (h, c)
+// wait in HBM / L2 between two steps (the 2 kHz loop needs every register).
+struct Mu4 { float v[4]; };
+__device__ __noinline__ Mu4 rollout_lstm_actor(const RolloutArgs* rap, int D, int blk, float x0, float x1, float x2, float x3) {
+    float* hcw = rap->hc + (size_t)(blk * L4_EPW) * 512;
+    const float xin[1][4] = {{x0, x1, x2, x3}};
+    float ha[2][4], hb[2][4], mu[1][4];
+    lstm_cell4<1>(rap->Gx0, D, rap->Gh0, rap->bi0, rap->bh0, hcw, 0, xin, ha);
+    lstm_cell4<2>(rap->Gx1, 128, rap->Gh1, rap->bi1, rap->bh1, hcw, 1, ha, hb);
+    ff_layer4<2, 1>(rap->Wt2, rap->b2, 128, APX_ACT_DIM, hb, mu, false);
+    return Mu4{{mu[0][0], mu[0][1], mu[0][2], mu[0][3]}};
+}
 // the restart of the finished envs of a wave inside env_rollout_kernel (all 64 lanes call; `fin` = this lane's env restarts)
 template <bool HF>
 __device__ __noinline__ void rollout_restart(St S, const RolloutArgs* rap, float* st, int* ist, int n, bool fin) {
@@ -768,7 +826,7 @@ __device__ __noinline__ void rollout_restart(St S, const RolloutArgs* rap, float
     }
     c4::wsync();
 }
-template <bool HF>
+template <bool HF, bool LSTM = false>
 __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_rollout_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const RolloutArgs* rap) {
     // The rollout's pointers are read from the argument block where they are used (through a pointer the optimiser cannot see through: not hoisted), not carried through the substeps: the constraint stage needs every
     // register, and two dozen loop-invariant pointers in SGPRs spilled into it (v_writelane / scratch inside the 2 kHz loop)
@@ -778,15 +836,22 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_rollout_kernel(float
     const int D = cfg.obs_dim, A = APX_ACT_DIM, lane = threadIdx.x;
     lfloat* stage = S.p + L4_ROWS;      // the env's observation (<= 64 words) between two steps: the row store is free at a step boundary
     for (int k = l; k < D; k += 16) stage[k] = RA(obs_grid)[(size_t)env * D + k];      // t = 0: the caller's current observation
+    if constexpr (LSTM) { float* q = RA(hc) + (size_t)(blk * L4_EPW) * 512 + lane; for (int k = 0; k < 4 * 512; k += 64) q[k] = 0.f; }      // every rollout starts at an episode start: init_hidden_state (actor.py:291-293)
     c4::wsync();
     for (int t = 0; t < RA(T); ++t) {
         {   // ---- actor forward of the wave's four envs
-            float hin[1][4], h1[4][4], h2[4][4], mu[1][4];
+            float hin[1][4], mu[1][4];
             const float mn = (RA(mean) && lane < D) ? RA(mean)[lane] : 0.f, sd = (RA(stdv) && lane < D) ? RA(stdv)[lane] : 1.f;
             c4::sfor<0, 4>([&](auto E) { const float v = lane < D ? (env_region(E) + L4_ROWS)[lane] : 0.f; hin[0][E] = lane < D ? (v - mn) / sd : 0.f; });
-            ff_layer4<1, 4>(RA(Wt0), RA(b0), D, RA(H), hin, h1, true);
-            ff_layer4<4, 4>(RA(Wt1), RA(b1), RA(H), RA(H), h1, h2, true);
-            ff_layer4<4, 1>(RA(Wt2), RA(b2), RA(H), A, h2, mu, false);
+            if constexpr (LSTM) {      // recurrent actor (its own instantiation of the kernel: the feed-forward rollout carries none of this), out of line (cold for the feed-forward rollout; 24 KB of unrolled gate products that the kernel body does not have to carry)
+                const Mu4 m = rollout_lstm_actor(rap, D, blk, hin[0][0], hin[0][1], hin[0][2], hin[0][3]);
+                c4::sfor<0, 4>([&](auto E) { mu[0][E] = m.v[E]; });
+            } else {
+                float h1[4][4], h2[4][4];
+                ff_layer4<1, 4>(RA(Wt0), RA(b0), D, RA(H), hin, h1, true);
+                ff_layer4<4, 4>(RA(Wt1), RA(b1), RA(H), RA(H), h1, h2, true);
+                ff_layer4<4, 1>(RA(Wt2), RA(b2), RA(H), A, h2, mu, false);
+            }
             if (lane < A) c4::sfor<0, 4>([&](auto E) {
                 const int ee = blk * L4_EPW + E;
                 const size_t o = ((size_t)t * n + ee) * A + lane;
@@ -809,7 +874,10 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_rollout_kernel(float
         if (fin) for (int k = l; k < D; k += 16) RA(fin_grid)[((size_t)t * n + env) * D + k] = stage[k];
         // ---- auto-reset of the finished envs (CassieEnv.reset, cassie.py:523-680): the restart part of env_reset_kernel, on this wave alone, OUT OF LINE - inlined, the
         // scalars it needs (ring pointers, seeds, the estimator's lifetime ...) stayed live through the 2 kHz loop above and spilled into it
-        if (__builtin_amdgcn_ballot_w64(fin) != 0ull) rollout_restart<HF>(S, rap, st, ist, n, fin);
+        if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {
+            rollout_restart<HF>(S, rap, st, ist, n, fin);
+            if (LSTM && fin) { float* q = RA(hc) + (size_t)env * 512 + l; for (int k = 0; k < 512; k += 16) q[k] = 0.f; }      // a new episode starts from the zero state (ppo.py:164-168)
+        }
         float* on = (t + 1 < RA(T) ? RA(obs_grid) + (size_t)(t + 1) * n * D : RA(obs_next)) + (size_t)env * D;
         for (int k = l; k < D; k += 16) on[k] = stage[k];
     }
@@ -1227,6 +1295,44 @@ extern "C" int apx_rollout(apx_env_t* e, const float* actor, int H, const float*
                           fin_grid + (size_t)t * N * D, 1, stream);
         if (rc != APX_OK) return rc;
     }
+    return APX_OK;
+}
+
+// apx_rollout with the recurrent actor: the whole T-step rollout as ONE env_rollout_kernel launch, the two LSTM cells and the head evaluated per wave inside it
+extern "C" int apx_rollout_lstm(apx_env_t* e, const float* actor, int H, int L, const float* obs_mean, const float* obs_std, float sigma, const float* noise, int T,
+                                float* obs_grid, float* act_grid, float* mu_grid, float* rew_grid, uint8_t* done_grid, float* fin_grid, float* obs_next, void* stream) {
+    APX_REQUIRE(e && actor && obs_grid && act_grid && mu_grid && rew_grid && done_grid && fin_grid && obs_next && T > 0, "rollout arguments");
+    const int D = make_cfg(*e).obs_dim, A = APX_ACT_DIM;
+    APX_REQUIRE(H == 128 && L == 2 && D <= 64, "apx_rollout_lstm: 2 x LSTMCell(128), observation width <= 64");
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    APX_REQUIRE(!(hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone), "apx_rollout_lstm under graph capture");
+    const long G = 4 * H, n4 = (e->n + 3) / 4 * 4;
+    const long nw = (long)D * G + 3 * (long)H * G + (long)H * A + n4 * 512 + 1;      // (+ 1: never the size of the feed-forward actor's block)
+    if (e->pol_wt_n != nw) { (void)hipFree(e->pol_wt); e->pol_wt = nullptr; APX_HIP(hipMalloc(&e->pol_wt, sizeof(float) * nw + sizeof(RolloutArgs) + 16)); e->pol_wt_n = nw; }
+    { const int rc = refill_join(e, stream); if (rc != APX_OK) return rc; }
+    e->refill_due = 0;
+    // parameter block (include/apx.h apx_lstm_forward): per cell weight_ih [4H, in], weight_hh [4H, H], bias_ih, bias_hh; then the head
+    const float* Wi0 = actor; const float* Wh0 = Wi0 + G * D; const float* bi0 = Wh0 + G * H; const float* bh0 = bi0 + G;
+    const float* Wi1 = bh0 + G; const float* Wh1 = Wi1 + G * H; const float* bi1 = Wh1 + G * H; const float* bh1 = bi1 + G;
+    const float* W2 = bh1 + G; const float* b2 = W2 + (long)A * H;
+    float* Gx0 = e->pol_wt; float* Gh0 = Gx0 + (long)D * G; float* Gx1 = Gh0 + (long)H * G; float* Gh1 = Gx1 + (long)H * G; float* Wt2 = Gh1 + (long)H * G; float* hc = Wt2 + (long)H * A;
+    hipLaunchKernelGGL(transpose_kernel, dim3(apx_cdiv(G * D, 256)), dim3(256), 0, (hipStream_t)stream, Wi0, Gx0, (int)G, D);
+    hipLaunchKernelGGL(transpose_kernel, dim3(apx_cdiv(G * H, 256)), dim3(256), 0, (hipStream_t)stream, Wh0, Gh0, (int)G, H);
+    hipLaunchKernelGGL(transpose_kernel, dim3(apx_cdiv(G * H, 256)), dim3(256), 0, (hipStream_t)stream, Wi1, Gx1, (int)G, H);
+    hipLaunchKernelGGL(transpose_kernel, dim3(apx_cdiv(G * H, 256)), dim3(256), 0, (hipStream_t)stream, Wh1, Gh1, (int)G, H);
+    hipLaunchKernelGGL(transpose_kernel, dim3(apx_cdiv((long)A * H, 256)), dim3(256), 0, (hipStream_t)stream, W2, Wt2, A, H);
+    APX_LAUNCH_CHECK();
+    RolloutArgs ra{nullptr, nullptr, nullptr, nullptr, Wt2, b2, obs_mean, obs_std, sigma, noise, H, T, obs_grid, act_grid, mu_grid, rew_grid, done_grid, fin_grid, obs_next, e->rst, e->rst_int, make_cfg(*e)};
+    ra.lstm = 1; ra.Gx0 = Gx0; ra.Gh0 = Gh0; ra.bi0 = bi0; ra.bh0 = bh0; ra.Gx1 = Gx1; ra.Gh1 = Gh1; ra.bi1 = bi1; ra.bh1 = bh1; ra.hc = hc;
+    RolloutArgs* rap = (RolloutArgs*)(((uintptr_t)(e->pol_wt + nw) + 15) & ~(uintptr_t)15);
+    APX_HIP(hipMemcpyAsync(rap, &ra, sizeof(ra), hipMemcpyHostToDevice, (hipStream_t)stream));
+    const bool timed = e->timing && e->ev_n + 2 <= e->ev_cap;
+    if (timed) APX_HIP(hipEventRecord((hipEvent_t)e->ev[e->ev_n], (hipStream_t)stream));
+    if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_rollout_kernel<true, true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), (const RolloutArgs*)rap);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_rollout_kernel<false, true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), (const RolloutArgs*)rap);
+    APX_LAUNCH_CHECK();
+    if (timed) { APX_HIP(hipEventRecord((hipEvent_t)e->ev[e->ev_n + 1], (hipStream_t)stream)); e->ev_n += 2; }
+    e->roll_launches += 1;
     return APX_OK;
 }
 

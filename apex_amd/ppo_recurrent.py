@@ -130,7 +130,30 @@ class RecurrentPPO:
         noise_all = None
         if self.noise_fn is None:      # every step's action noise in one launch instead of one small launch per step in front of the policy step
             noise_all = torch.empty(T, N, 10, device=self.device).normal_(generator=self.gen)
-        for t in range(T):
+            self._noise_all = noise_all      # (kept for the tests: act - fixed_std * noise = the rollout's means)
+        # One launch for the whole rollout where the shape allows it (apx_rollout_lstm: 2 x LSTMCell(128) evaluated per wave inside env_rollout_kernel): no per-step launch, and a
+        # forward pass on the complete-row path stalls its own wave instead of the launch of all envs.  The critic's values follow over the stored grid, step by step with its
+        # carried state and the same bootstrap rule as below (it never fed the env step).
+        one_launch = (fused and noise_all is not None and hasattr(env, "_h") and not getattr(env, "history", 0) and self.H == 128 and self.L == 2
+                      and os.environ.get("APX_ROLLOUT_STEPWISE", "0") == "0")
+        if one_launch:
+            from ._lib import load, check
+            from .engine import _p, _stream
+            if getattr(self, "_b_mu", None) is None:
+                self._b_mu = torch.empty(T, N, 10, device=self.device)
+            check(load().apx_rollout_lstm(env._h, _p(L.actor.params), self.H, self.L, _p(L.obs_mean), _p(L.obs_std), float(self.fixed_std), _p(noise_all), T,
+                                          _p(self.b_obs), _p(self.b_act), _p(self._b_mu), _p(self.b_rew), _p(self.b_done), _p(self.b_fin), _p(nxt_last), _stream()))
+            for t in range(T):
+                L.critic.step(self.b_obs[t], hc_c, reset=self.b_done[t - 1] if t > 0 else None, y_out=self.b_val[t].view(N, 1))
+                last = t == T - 1
+                if last or t + 1 >= self.max_traj_len:
+                    nxt = self.b_obs[t + 1] if t + 1 < T else nxt_last
+                    tr = self.b_done[t] == 2
+                    rows = tr if not last else (tr | (self.b_done[t] == 0))
+                    src = torch.where((self.b_done[t] != 0).view(N, 1), self.b_fin[t], nxt)
+                    v_next = L.critic.forward(src.contiguous(), hc=hc_c.clone()).view(-1)
+                    self.b_boot[t] = torch.where(rows, v_next, torch.zeros_like(v_next))
+        for t in range(0 if not one_launch else T, T):
             nxt = self.b_obs[t + 1] if t + 1 < T else nxt_last
             ev_obs = main.record_event()
             prev_done = self.b_done[t - 1] if (fused and t > 0) else None      # uint8 0 / 1 / 2: non-zero rows start from a zero state

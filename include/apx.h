@@ -286,6 +286,15 @@ int apx_rollout(apx_env_t* env, const float* actor, int H, const float* obs_mean
                 float* obs_grid, float* act_grid, float* mu_grid, float* rew_grid, uint8_t* done_grid, float* fin_grid, float* obs_next,
                 void* stream);
 
+/* The same rollout with the recurrent actor (PPO.sample over Gaussian_LSTM_Actor, rl/algos/ppo.py:160-184 / rl/policies/actor.py:253-293): actor = the parameter block of
+ * apx_lstm_forward (L = 2 cells of H = 128, head of 10; other shapes: APX_E_ARG, the caller keeps its per-step loop of apx_lstm_step + apx_env_step).  Every env starts
+ * the rollout from the zero hidden state and returns to it when its episode ends (init_hidden_state); the carried states live in the handle.  One launch: a wave steps
+ * its four envs at its own pace, so a forward pass that needs the complete row set (apx_env_set_complete_rows) delays that wave alone, not the launch of every env.
+ * Grids as in apx_rollout. */
+int apx_rollout_lstm(apx_env_t* env, const float* actor, int H, int L, const float* obs_mean, const float* obs_std, float sigma, const float* noise, int T,
+                     float* obs_grid, float* act_grid, float* mu_grid, float* rew_grid, uint8_t* done_grid, float* fin_grid, float* obs_next,
+                     void* stream);
+
 int apx_env_step(apx_env_t* env, const float* action, float* obs, float* reward, uint8_t* done, float* final_obs,
                  int auto_reset, void* stream);
 

@@ -30,8 +30,8 @@ def code_objects():
 
 
 # the out-of-line COLD functions of the env kernels (round 5): the complete-row path of a saturated forward pass, the restart of finished envs inside the one-launch
-# rollout.  They are called where nothing of the hot loop is live, keep their callee-saved registers in scratch and are the only reason a kernel has a private segment.
-COLD_FUNCTIONS = ("substep_complete", "rollout_restart")
+# rollout, the recurrent actor's step inside it.  They are called where nothing of the hot loop is live, keep their callee-saved registers in scratch and are the only reason a kernel has a private segment.
+COLD_FUNCTIONS = ("substep_complete", "rollout_restart", "rollout_lstm_actor")
 CODE_BYTES_CEILING = {"env_step_kernel": 100 * 1024, "env_substep_kernel": 100 * 1024, "env_rollout_kernel": 110 * 1024, "stage1b_tree_lane": 20 * 1024}      # shipped: 94.8 / 77.0 / 101.7 / 17.8 KB (plane variants)
 
 

@@ -485,6 +485,51 @@ def test_td3_driver_hbm_replay_and_updates(dev, tmp_path):
     assert 0 < dist < 1
 
 
+def test_one_launch_recurrent_rollout_means_match_the_sequence_pass(dev, tmp_path):
+    """apx_rollout_lstm (round 5: the recurrent rollout as ONE env_rollout_kernel launch, the two LSTM cells and the head evaluated per wave inside it, hidden state zeroed
+    where an episode ends) against the learner's own sequence pass: on whole trajectories cut out of the recorded grid, the padded pass from the zero state reproduces the
+    means the in-kernel actor produced step by step with its carried (h, c) - the identity the padded update relies on - and the recorded actions are those means plus the
+    drawn noise.  Episodes end inside the call (max_traj_len 16 < T = 40, and falls), so the in-kernel hidden-state reset is on the path.  The critic's values over the
+    stored grid equal a step-by-step replay with a fresh carried state."""
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd.ppo_recurrent import RecurrentPPO
+    N, T, mtl = 512, 40, 16
+    env = CassieVecEnv(n_envs=N, seed=9, max_traj_len=mtl, env_name="CassieTraj-v0")
+    args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=512, epochs=1, num_steps=T * N, max_traj_len=mtl,
+                max_grad_norm=0.05, mirror=True, seed=3, env_name="CassieTraj-v0")
+    algo = RecurrentPPO(args, str(tmp_path), env, hidden=128, layers=2)
+    algo.init_networks(0)
+    algo.normalization_params(N * 50)
+    L = algo.learner
+    env.kernel_timing(True); env.kernel_timing_read(reset=True)
+    ret = algo.sample()
+    _, launches = env.kernel_timing_read(reset=True); env.kernel_timing(False)
+    assert launches == 1                                     # the one-launch path ran (the per-step path times T env_step_kernel launches)
+    noise = algo._noise_all
+    done = algo.b_done.cpu().numpy()
+    assert np.isfinite(algo.b_obs.cpu().numpy()).all() and np.isfinite(algo.b_rew.cpu().numpy()).all() and np.isfinite(ret.cpu().numpy()).all()
+    assert (done == 2).sum() > 0 and (done != 0).sum() >= N * (T // mtl)
+    np.testing.assert_allclose(algo.b_act.cpu().numpy(), (algo._b_mu + algo.fixed_std * noise).cpu().numpy(), rtol=0, atol=1e-6)
+    trajs = algo.trajectories()
+    sel = trajs[np.random.RandomState(0).permutation(len(trajs))[:128]]
+    idx = algo.padded_index(sel)
+    valid = idx >= 0
+    gi = idx.clamp(min=0).view(-1)
+    obs_p = (algo.b_obs.view(T * N, 50).index_select(0, gi) * valid.view(-1, 1)).view(idx.shape[0], 128, 50)
+    mu_seq = L.actor.forward(((obs_p - L.obs_mean) / L.obs_std).contiguous())
+    mu_roll = algo._b_mu.view(T * N, 10).index_select(0, gi).view(idx.shape[0], 128, 10)
+    d = ((mu_seq - mu_roll) * valid.unsqueeze(-1)).abs().max()
+    assert float(d) < 2e-5, float(d)
+    # a trajectory that does NOT start at t = 0 is in the sample (its first step follows an in-kernel hidden-state reset)
+    assert (sel[:, 1] > 0).any()
+    # the critic's values: step-by-step replay over the grid
+    hc = torch.zeros(2, 2, N, 128, device=dev)
+    for t in range(T):
+        v = torch.empty(N, 1, device=dev)
+        L.critic.step(algo.b_obs[t], hc, reset=algo.b_done[t - 1] if t > 0 else None, y_out=v)
+        assert torch.equal(v.view(-1), algo.b_val[t])
+
+
 def test_full_size_config3_recurrent_iteration(dev, tmp_path):
     """BASELINE configs[3] at full size: CassieTraj-v0, 2048 envs, LSTM 2 x 128 actor / critic, one whole iteration (rollout -> returns ->
     padded whole-trajectory minibatches -> update).  Size-independent properties: the returns equal the oracle's scan on the recorded
