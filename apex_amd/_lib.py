@@ -84,6 +84,7 @@ SIGNATURES = {
     "apx_env_timing": (C.c_int, [c_ptr, C.c_int]),
     "apx_env_timing_read": (C.c_int, [c_ptr, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
     "apx_rollout": (C.c_int, [c_ptr, c_ptr, C.c_int, c_ptr, c_ptr, C.c_float, c_ptr, C.c_int] + [c_ptr] * 8),
+    "apx_rollout_td3": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_float, C.c_float, c_ptr, C.c_int, C.c_int] + [c_ptr] * 8),
     "apx_rollout_lstm": (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, c_ptr, C.c_float, c_ptr, C.c_int] + [c_ptr] * 8),
     "apx_env_step": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, c_ptr]),
     "apx_env_get_state": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr]),

@@ -712,6 +712,8 @@ struct RolloutArgs {
     int lstm = 0;
     const float *Gx0 = nullptr, *Gh0 = nullptr, *bi0 = nullptr, *bh0 = nullptr, *Gx1 = nullptr, *Gh1 = nullptr, *bi1 = nullptr, *bh1 = nullptr;
     float* hc = nullptr;
+    // deterministic actor (apx_rollout_td3)
+    float max_action = 1.f; int noise_scalar = 0;
 };
 template <int KG, int NG>
 __device__ __forceinline__ void ff_layer4(const float* __restrict__ Wt, const float* __restrict__ bias, int K, int N, const float (&hin)[KG][4], float (&hout)[NG][4], bool relu) {
@@ -826,7 +828,8 @@ __device__ __noinline__ void rollout_restart(St S, const RolloutArgs* rap, float
     }
     c4::wsync();
 }
-template <bool HF, bool LSTM = false>
+// MODE 0: feed-forward Gaussian actor (PPO), 1: recurrent actor (apx_rollout_lstm), 2: feed-forward deterministic actor with tanh head and clipped exploration noise (TD3)
+template <bool HF, int MODE = 0>
 __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_rollout_kernel(float* st, int* ist, float* wk, int n, Cfg cfg, const RolloutArgs* rap) {
     // The rollout's pointers are read from the argument block where they are used (through a pointer the optimiser cannot see through: not hoisted), not carried through the substeps: the constraint stage needs every
     // register, and two dozen loop-invariant pointers in SGPRs spilled into it (v_writelane / scratch inside the 2 kHz loop)
@@ -836,14 +839,14 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_rollout_kernel(float
     const int D = cfg.obs_dim, A = APX_ACT_DIM, lane = threadIdx.x;
     lfloat* stage = S.p + L4_ROWS;      // the env's observation (<= 64 words) between two steps: the row store is free at a step boundary
     for (int k = l; k < D; k += 16) stage[k] = RA(obs_grid)[(size_t)env * D + k];      // t = 0: the caller's current observation
-    if constexpr (LSTM) { float* q = RA(hc) + (size_t)(blk * L4_EPW) * 512 + lane; for (int k = 0; k < 4 * 512; k += 64) q[k] = 0.f; }      // every rollout starts at an episode start: init_hidden_state (actor.py:291-293)
+    if constexpr (MODE == 1) { float* q = RA(hc) + (size_t)(blk * L4_EPW) * 512 + lane; for (int k = 0; k < 4 * 512; k += 64) q[k] = 0.f; }      // every rollout starts at an episode start: init_hidden_state (actor.py:291-293)
     c4::wsync();
     for (int t = 0; t < RA(T); ++t) {
         {   // ---- actor forward of the wave's four envs
             float hin[1][4], mu[1][4];
             const float mn = (RA(mean) && lane < D) ? RA(mean)[lane] : 0.f, sd = (RA(stdv) && lane < D) ? RA(stdv)[lane] : 1.f;
             c4::sfor<0, 4>([&](auto E) { const float v = lane < D ? (env_region(E) + L4_ROWS)[lane] : 0.f; hin[0][E] = lane < D ? (v - mn) / sd : 0.f; });
-            if constexpr (LSTM) {      // recurrent actor (its own instantiation of the kernel: the feed-forward rollout carries none of this), out of line (cold for the feed-forward rollout; 24 KB of unrolled gate products that the kernel body does not have to carry)
+            if constexpr (MODE == 1) {      // recurrent actor (its own instantiation of the kernel: the feed-forward rollout carries none of this), out of line (cold for the feed-forward rollout; 24 KB of unrolled gate products that the kernel body does not have to carry)
                 const Mu4 m = rollout_lstm_actor(rap, D, blk, hin[0][0], hin[0][1], hin[0][2], hin[0][3]);
                 c4::sfor<0, 4>([&](auto E) { mu[0][E] = m.v[E]; });
             } else {
@@ -855,8 +858,13 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_rollout_kernel(float
             if (lane < A) c4::sfor<0, 4>([&](auto E) {
                 const int ee = blk * L4_EPW + E;
                 const size_t o = ((size_t)t * n + ee) * A + lane;
-                const float a = mu[0][E] + (RA(noise) ? RA(sigma) * RA(noise)[o] : 0.f);
-                RA(mu_grid)[o] = mu[0][E]; RA(act_grid)[o] = a;
+                float m = mu[0][E], a;
+                if constexpr (MODE == 2) {      // FF_Actor.forward (rl/policies/actor.py: max_action * tanh) + the collector's exploration noise, clipped (sync_td3.py:77-78: one scalar per env step; async_td3.py:253-256: per dimension)
+                    m = RA(max_action) * tanhf(m);
+                    const float nz = RA(noise) ? RA(noise)[RA(noise_scalar) ? (size_t)t * n + ee : o] : 0.f;
+                    a = fminf(fmaxf(m + RA(sigma) * nz, -1.f), 1.f);
+                } else a = m + (RA(noise) ? RA(sigma) * RA(noise)[o] : 0.f);
+                RA(mu_grid)[o] = m; RA(act_grid)[o] = a;
                 (env_region(E) + L4_WK + WK_ACT)[lane] = a;
             });
             c4::wsync();
@@ -876,7 +884,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_rollout_kernel(float
         // scalars it needs (ring pointers, seeds, the estimator's lifetime ...) stayed live through the 2 kHz loop above and spilled into it
         if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {
             rollout_restart<HF>(S, rap, st, ist, n, fin);
-            if (LSTM && fin) { float* q = RA(hc) + (size_t)env * 512 + l; for (int k = 0; k < 512; k += 16) q[k] = 0.f; }      // a new episode starts from the zero state (ppo.py:164-168)
+            if (MODE == 1 && fin) { float* q = RA(hc) + (size_t)env * 512 + l; for (int k = 0; k < 512; k += 16) q[k] = 0.f; }      // a new episode starts from the zero state (ppo.py:164-168)
         }
         float* on = (t + 1 < RA(T) ? RA(obs_grid) + (size_t)(t + 1) * n * D : RA(obs_next)) + (size_t)env * D;
         for (int k = l; k < D; k += 16) on[k] = stage[k];
@@ -1247,8 +1255,8 @@ __global__ void act_noise_kernel(const float* __restrict__ mu, const float* __re
     const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
     if (i < n) act[i] = mu[i] + (noise ? sigma * noise[i] : 0.f);
 }
-extern "C" int apx_rollout(apx_env_t* e, const float* actor, int H, const float* obs_mean, const float* obs_std, float sigma, const float* noise, int T,
-                           float* obs_grid, float* act_grid, float* mu_grid, float* rew_grid, uint8_t* done_grid, float* fin_grid, float* obs_next, void* stream) {
+static int rollout_ff(apx_env_t* e, int td3, float max_action, int noise_scalar, const float* actor, int H, const float* obs_mean, const float* obs_std, float sigma, const float* noise, int T,
+                      float* obs_grid, float* act_grid, float* mu_grid, float* rew_grid, uint8_t* done_grid, float* fin_grid, float* obs_next, void* stream) {
     APX_REQUIRE(e && actor && obs_grid && act_grid && mu_grid && rew_grid && done_grid && fin_grid && obs_next && T > 0, "rollout arguments");
     const int D = make_cfg(*e).obs_dim, A = APX_ACT_DIM;
     const long N = e->n;
@@ -1267,12 +1275,16 @@ extern "C" int apx_rollout(apx_env_t* e, const float* actor, int H, const float*
             hipLaunchKernelGGL(transpose_kernel, dim3(apx_cdiv((long)H * H, 256)), dim3(256), 0, (hipStream_t)stream, W1, Wt1, H, H);
             hipLaunchKernelGGL(transpose_kernel, dim3(apx_cdiv((long)A * H, 256)), dim3(256), 0, (hipStream_t)stream, W2, Wt2, A, H);
             APX_LAUNCH_CHECK();
-            const RolloutArgs ra{Wt0, b0, Wt1, b1, Wt2, b2, obs_mean, obs_std, sigma, noise, H, T, obs_grid, act_grid, mu_grid, rew_grid, done_grid, fin_grid, obs_next, e->rst, e->rst_int, make_cfg(*e)};
+            RolloutArgs ra{Wt0, b0, Wt1, b1, Wt2, b2, obs_mean, obs_std, sigma, noise, H, T, obs_grid, act_grid, mu_grid, rew_grid, done_grid, fin_grid, obs_next, e->rst, e->rst_int, make_cfg(*e)};
+            ra.max_action = max_action; ra.noise_scalar = noise_scalar;
             RolloutArgs* rap = (RolloutArgs*)(e->pol_wt + nw);      // the argument block lives behind the weights (the kernel reads it field by field where it needs one)
             APX_HIP(hipMemcpyAsync(rap, &ra, sizeof(ra), hipMemcpyHostToDevice, (hipStream_t)stream));
             const bool timed = e->timing && e->ev_n + 2 <= e->ev_cap;
             if (timed) APX_HIP(hipEventRecord((hipEvent_t)e->ev[e->ev_n], (hipStream_t)stream));
-            if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_rollout_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), (const RolloutArgs*)rap);
+            if (td3) {
+                if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_rollout_kernel<true, 2>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), (const RolloutArgs*)rap);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_rollout_kernel<false, 2>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), (const RolloutArgs*)rap);
+            } else if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_rollout_kernel<true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), (const RolloutArgs*)rap);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_rollout_kernel<false>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), (const RolloutArgs*)rap);
             APX_LAUNCH_CHECK();
             if (timed) { APX_HIP(hipEventRecord((hipEvent_t)e->ev[e->ev_n + 1], (hipStream_t)stream)); e->ev_n += 2; }
@@ -1280,6 +1292,7 @@ extern "C" int apx_rollout(apx_env_t* e, const float* actor, int H, const float*
             return APX_OK;
         }
     }
+    APX_REQUIRE(!td3, "apx_rollout_td3: the one-launch path only (hidden width 256, observation width <= 64, no graph capture, APX_ROLLOUT_STEPWISE unset)");
     for (int t = 0; t < T; ++t) {
         float* obs = obs_grid + (size_t)t * N * D; float* mu = mu_grid + (size_t)t * N * A; float* act = act_grid + (size_t)t * N * A;
         const float* nz = noise ? noise + (size_t)t * N * A : nullptr;
@@ -1298,6 +1311,14 @@ extern "C" int apx_rollout(apx_env_t* e, const float* actor, int H, const float*
     return APX_OK;
 }
 
+extern "C" int apx_rollout(apx_env_t* e, const float* actor, int H, const float* obs_mean, const float* obs_std, float sigma, const float* noise, int T,
+                           float* obs_grid, float* act_grid, float* mu_grid, float* rew_grid, uint8_t* done_grid, float* fin_grid, float* obs_next, void* stream) {
+    return rollout_ff(e, 0, 1.f, 0, actor, H, obs_mean, obs_std, sigma, noise, T, obs_grid, act_grid, mu_grid, rew_grid, done_grid, fin_grid, obs_next, stream);
+}
+extern "C" int apx_rollout_td3(apx_env_t* e, const float* actor, int H, float max_action, float act_noise, const float* noise, int noise_per_dim, int T,
+                               float* obs_grid, float* act_grid, float* mu_grid, float* rew_grid, uint8_t* done_grid, float* fin_grid, float* obs_next, void* stream) {
+    return rollout_ff(e, 1, max_action, noise_per_dim ? 0 : 1, actor, H, nullptr, nullptr, act_noise, noise, T, obs_grid, act_grid, mu_grid, rew_grid, done_grid, fin_grid, obs_next, stream);
+}
 // apx_rollout with the recurrent actor: the whole T-step rollout as ONE env_rollout_kernel launch, the two LSTM cells and the head evaluated per wave inside it
 extern "C" int apx_rollout_lstm(apx_env_t* e, const float* actor, int H, int L, const float* obs_mean, const float* obs_std, float sigma, const float* noise, int T,
                                 float* obs_grid, float* act_grid, float* mu_grid, float* rew_grid, uint8_t* done_grid, float* fin_grid, float* obs_next, void* stream) {
@@ -1328,8 +1349,8 @@ extern "C" int apx_rollout_lstm(apx_env_t* e, const float* actor, int H, int L, 
     APX_HIP(hipMemcpyAsync(rap, &ra, sizeof(ra), hipMemcpyHostToDevice, (hipStream_t)stream));
     const bool timed = e->timing && e->ev_n + 2 <= e->ev_cap;
     if (timed) APX_HIP(hipEventRecord((hipEvent_t)e->ev[e->ev_n], (hipStream_t)stream));
-    if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_rollout_kernel<true, true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), (const RolloutArgs*)rap);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_rollout_kernel<false, true>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), (const RolloutArgs*)rap);
+    if (e->hf) hipLaunchKernelGGL(HIP_KERNEL_NAME(env_rollout_kernel<true, 1>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), (const RolloutArgs*)rap);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(env_rollout_kernel<false, 1>), ENV_GRID(e->n), ENV_BLOCK, LDS_BYTES, (hipStream_t)stream, e->st, e->ist, e->wk, e->n, make_cfg(*e), (const RolloutArgs*)rap);
     APX_LAUNCH_CHECK();
     if (timed) { APX_HIP(hipEventRecord((hipEvent_t)e->ev[e->ev_n + 1], (hipStream_t)stream)); e->ev_n += 2; }
     e->roll_launches += 1;

@@ -100,6 +100,38 @@ class TD3:
         ep_done = 0
         if self.param_noise:
             self.perturb_actor_parameters()
+        # The HIP env: the `steps` collection steps as ONE launch with the policy fixed (apx_rollout_td3 - what sync_td3.py does: collect_experience runs the current
+        # policy to the step budget, :300-313, THEN policy.train runs one iteration per collected timestep), all transitions into the replay, then steps x updates_per_step
+        # updates.  (The per-step loop below interleaves an update block behind every env step; it stays for envs without the C handle, parameter noise and non-256 widths.)
+        if (hasattr(env, "_h") and not self.param_noise and self.hidden == 256 and not getattr(env, "history", 0) and os.environ.get("APX_ROLLOUT_STEPWISE", "0") == "0"
+                and os.environ.get("APX_TD3_ROLLOUT", "1") != "0"):
+            from ._lib import load, check
+            from .engine import _p, _stream
+            T, N = steps, self.N
+            if getattr(self, "_g", None) is None or self._g["obs"].shape[0] != T:
+                f32 = dict(dtype=torch.float32, device=self.device)
+                self._g = dict(obs=torch.empty(T, N, 50, **f32), act=torch.empty(T, N, 10, **f32), mu=torch.empty(T, N, 10, **f32), rew=torch.empty(T, N, **f32),
+                               done=torch.empty(T, N, dtype=torch.uint8, device=self.device), fin=torch.zeros(T, N, 50, **f32), nxt=torch.empty(N, 50, **f32))
+            g = self._g
+            g["obs"][0].copy_(self.obs)
+            noise = torch.randn(T, N, device=self.device, generator=self.gen) if self.act_noise != 0 else None      # one scalar per env step (:77)
+            self._noise_last = noise      # (kept for the tests)
+            check(load().apx_rollout_td3(env._h, _p(L.actor.params), self.hidden, float(L.max_action), float(self.act_noise), _p(noise), 0, T, _p(g["obs"]), _p(g["act"]),
+                                         _p(g["mu"]), _p(g["rew"]), _p(g["done"]), _p(g["fin"]), _p(g["nxt"]), _stream()))
+            for t in range(T):
+                nxt = g["obs"][t + 1] if t + 1 < T else g["nxt"]
+                ended = g["done"][t] != 0
+                self.replay.add(g["obs"][t], torch.where(ended.view(-1, 1), g["fin"][t], nxt), g["act"][t], g["rew"][t], (~ended).float())
+            self.obs = g["nxt"].clone()
+            for _ in range(T * self.updates_per_step):
+                if self.replay.size < self.batch_size:
+                    break
+                s_, sn, ac, r, nd = self.replay.sample(self.batch_size, self.gen)
+                pn = torch.randn(self.batch_size, 10, device=self.device, generator=self.gen) * self.policy_noise
+                st, _ = L.train_step(s_, ac, sn, r, nd, pn, self.it, self.discount, self.tau, self.noise_clip, self.policy_freq)
+                stats += st; n_upd += 1; self.it += 1
+            steps = 0
+            self.total_steps += T * N
         for _ in range(steps):
             a = torch.tanh(self.actor_perturbed.forward(self.obs)) if self.param_noise else L.act(self.obs)
             if self.act_noise != 0:

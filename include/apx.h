@@ -295,6 +295,14 @@ int apx_rollout_lstm(apx_env_t* env, const float* actor, int H, int L, const flo
                      float* obs_grid, float* act_grid, float* mu_grid, float* rew_grid, uint8_t* done_grid, float* fin_grid, float* obs_next,
                      void* stream);
 
+/* The collection phase of TD3 as the same one-launch rollout (rl/algos/sync_td3.py:59-101 collect_experience: the policy is fixed while transitions are collected):
+ * actor = FF_Actor's parameter block (50-256-256-10, apx_mlp_forward layout), action = clip(max_action * tanh(net(obs)) + act_noise * noise, -1, 1) with noise
+ * [T, n_envs] (one scalar per env step, sync_td3.py:77-78; noise_per_dim = 0) or [T, n_envs, 10] (async_td3.py:253-256; noise_per_dim = 1), NULL = none.
+ * mu_grid receives the squashed means.  Other hidden widths, a stream under capture or APX_ROLLOUT_STEPWISE=1: APX_E_ARG (the caller steps the env itself). */
+int apx_rollout_td3(apx_env_t* env, const float* actor, int H, float max_action, float act_noise, const float* noise, int noise_per_dim, int T,
+                    float* obs_grid, float* act_grid, float* mu_grid, float* rew_grid, uint8_t* done_grid, float* fin_grid, float* obs_next,
+                    void* stream);
+
 int apx_env_step(apx_env_t* env, const float* action, float* obs, float* reward, uint8_t* done, float* final_obs,
                  int auto_reset, void* stream);
 

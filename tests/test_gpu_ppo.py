@@ -485,6 +485,42 @@ def test_td3_driver_hbm_replay_and_updates(dev, tmp_path):
     assert 0 < dist < 1
 
 
+def test_td3_one_launch_collection(dev, tmp_path):
+    """apx_rollout_td3 (round 5: TD3's collection phase as one env_rollout_kernel launch, policy fixed as in sync_td3.py's collect_experience) on the recorded grid: the
+    actions are clip(max_action tanh(actor(obs)) + act_noise * scalar noise, -1, 1) of the learner's own forward on the recorded observations, the replay holds exactly the
+    grid's transitions (terminal rows carry the episode's own final observation and not-done 0), and the update block ran steps x updates_per_step times."""
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd.td3 import TD3
+    N, T = 256, 12
+    env = CassieVecEnv(n_envs=N, seed=4, max_traj_len=8)
+    from apex_amd import engine
+    algo = TD3(env, str(tmp_path), hidden=256, act_noise=0.3, batch_size=256, updates_per_step=2, replay_size=N * T, seed=1)
+    algo.init_networks(0)
+    p0 = algo.learner.actor.params.clone()
+    env.kernel_timing(True); env.kernel_timing_read(reset=True)
+    out = algo.collect_and_train(T)
+    _, launches = env.kernel_timing_read(reset=True); env.kernel_timing(False)
+    assert launches == 1 and out["updates"] == T * 2 and algo.replay.size == N * T
+    g, noise = algo._g, algo._noise_last
+    L = algo.learner
+    pre = engine.Mlp(50, 256, 10, dev); pre.params.copy_(p0)
+    m = torch.tanh(pre.forward(g["obs"].view(T * N, 50))).view(T, N, 10)
+    # (TD3 feeds the RAW observation - no normalisation, sync_td3.py - so the first layer sums entries of O(10): the per-wave sequential-k fp32 sum and the MFMA sum of the
+    # learner differ by round-off in proportion to the row's largest entry, where the normalised PPO input stays within 3e-6)
+    d = (g["mu"] - m).abs()
+    big = g["obs"].abs().amax(-1, keepdim=True)                                  # the row's largest observation entry (a falling robot's velocities: 10 - 50)
+    assert float((d / (1.0 + big)).max()) < 2e-6 and float((d <= 5e-6).float().mean()) > 0.99, (float(d.max()), float((d / (1.0 + big)).max()))
+    np.testing.assert_allclose(g["act"].cpu().numpy(), (g["mu"] + 0.3 * noise.view(T, N, 1)).clamp(-1, 1).cpu().numpy(), rtol=0, atol=1e-6)
+    assert float(g["act"].abs().max()) <= 1.0 and int((g["done"] != 0).sum()) >= N      # max_traj_len 8 < T: every env restarted inside the launch
+    R = algo.replay
+    assert torch.equal(R.s[:N * T].view(T, N, 50), g["obs"]) and torch.equal(R.a[:N * T].view(T, N, 10), g["act"]) and torch.equal(R.r[:N * T].view(T, N), g["rew"])
+    ended = g["done"] != 0
+    assert torch.equal(R.nd[:N * T].view(T, N), (~ended).float())
+    nxt = torch.cat([g["obs"][1:], g["nxt"].unsqueeze(0)])
+    assert torch.equal(R.s2[:N * T].view(T, N, 50), torch.where(ended.unsqueeze(-1), g["fin"], nxt))
+    assert not torch.equal(L.actor.params, p0) and torch.isfinite(L.actor.params).all()
+
+
 def test_one_launch_recurrent_rollout_means_match_the_sequence_pass(dev, tmp_path):
     """apx_rollout_lstm (round 5: the recurrent rollout as ONE env_rollout_kernel launch, the two LSTM cells and the head evaluated per wave inside it, hidden state zeroed
     where an episode ends) against the learner's own sequence pass: on whole trajectories cut out of the recorded grid, the padded pass from the zero state reproduces the
