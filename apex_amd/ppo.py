@@ -141,21 +141,6 @@ class PPO:
         D = self.D
         s = torch.zeros(D, dtype=torch.float64, device=self.device); ss = torch.zeros_like(s); n = 0
         nz = torch.zeros(self.N, 10, dtype=torch.float32, device=self.device)
-        if self.noise_fn is None and hasattr(self.env, "_h") and not getattr(self.env, "history", 0) and self.learner.actor.H == 256:
-            # the HIP env: the whole pass as one rollout launch (apx_rollout with sigma = noise_std).  With N(0, 1) action noise most robots fall, and a forward pass that needs
-            # the complete row set stalls its own wave here instead of a launch of all envs
-            from ._lib import load, check
-            from .engine import _p, _stream
-            f32 = dict(dtype=torch.float32, device=self.device)
-            g_obs = torch.empty(steps, self.N, D, **f32); g_obs[0].copy_(obs)
-            g_act = torch.empty(steps, self.N, 10, **f32); g_mu = torch.empty_like(g_act); g_rew = torch.empty(steps, self.N, **f32)
-            g_done = torch.empty(steps, self.N, dtype=torch.uint8, device=self.device); g_fin = torch.empty(steps, self.N, D, **f32); nxt = torch.empty(self.N, D, **f32)
-            noise = torch.empty(steps, self.N, 10, **f32).normal_(generator=self.gen)
-            check(load().apx_rollout(self.env._h, _p(self.learner.actor.params), self.learner.actor.H, _p(self.learner.obs_mean), _p(self.learner.obs_std), float(noise_std),
-                                     _p(noise), steps, _p(g_obs), _p(g_act), _p(g_mu), _p(g_rew), _p(g_done), _p(g_fin), _p(nxt), _stream()))
-            flat = g_obs.view(steps * self.N, D).double()
-            s += flat.sum(0); ss += (flat * flat).sum(0); n += steps * self.N
-            steps = 0
         for t in range(steps):
             s += obs.double().sum(0); ss += (obs.double() ** 2).sum(0); n += obs.shape[0]
             mu = self.learner.actor.forward(obs, self.learner.obs_mean, self.learner.obs_std)

@@ -90,20 +90,6 @@ class RecurrentPPO:
         obs = self.env.reset()
         hc = torch.zeros(self.L, 2, self.N, self.H, device=self.device)
         s = torch.zeros(50, dtype=torch.float64, device=self.device); ss = torch.zeros_like(s); n = 0
-        if (hasattr(self.env, "_h") and not getattr(self.env, "history", 0) and self.H == 128 and self.L == 2 and self.noise_fn is None
-                and os.environ.get("APX_ROLLOUT_STEPWISE", "0") == "0"):      # the whole pass as one rollout launch (apx_rollout_lstm with sigma = noise_std), as in PPO.normalization_params
-            from ._lib import load, check
-            from .engine import _p, _stream
-            f32 = dict(dtype=torch.float32, device=self.device)
-            g_obs = torch.empty(steps, self.N, 50, **f32); g_obs[0].copy_(obs)
-            g_act = torch.empty(steps, self.N, 10, **f32); g_mu = torch.empty_like(g_act); g_rew = torch.empty(steps, self.N, **f32)
-            g_done = torch.empty(steps, self.N, dtype=torch.uint8, device=self.device); g_fin = torch.empty(steps, self.N, 50, **f32); nxt = torch.empty(self.N, 50, **f32)
-            noise = torch.empty(steps, self.N, 10, **f32).normal_(generator=self.gen)
-            check(load().apx_rollout_lstm(self.env._h, _p(L.actor.params), self.H, self.L, _p(L.obs_mean), _p(L.obs_std), float(noise_std), _p(noise), steps, _p(g_obs), _p(g_act),
-                                          _p(g_mu), _p(g_rew), _p(g_done), _p(g_fin), _p(nxt), _stream()))
-            flat = g_obs.view(steps * self.N, 50).double()
-            s += flat.sum(0); ss += (flat * flat).sum(0); n += steps * self.N
-            steps = 0
         for _ in range(steps):
             s += obs.double().sum(0); ss += (obs.double() ** 2).sum(0); n += obs.shape[0]
             mu = L.actor.forward(((obs - L.obs_mean) / L.obs_std).contiguous(), hc=hc)

@@ -713,7 +713,8 @@ def test_one_launch_rollout_restarts_match_the_stepwise_resets(dev):
         env = CassieVecEnv(n_envs=256, seed=9, max_traj_len=1)
         args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=1024, epochs=1, num_steps=256 * 8, max_traj_len=1,
                     max_grad_norm=0.05, mirror=True, std_dev=-1.5, seed=0)
-        a = PPO(args, "/tmp/apx_test_unused", env); a.init_networks(0); a.normalization_params(256 * 20)
+        a = PPO(args, "/tmp/apx_test_unused", env); a.init_networks(0)
+        _normalise_by_the_step_loop(a, 256 * 20)
         a.prepare_resets = False
         a.sample()
         return a
@@ -745,10 +746,20 @@ def _stepwise_twin():
     env = CassieVecEnv(n_envs=256, seed=9, max_traj_len=1)
     args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=1024, epochs=1, num_steps=256 * 8, max_traj_len=1,
                 max_grad_norm=0.05, mirror=True, std_dev=-1.5, seed=0)
-    a = PPO(args, "/tmp/apx_test_unused", env); a.init_networks(0); a.normalization_params(256 * 20)
+    a = PPO(args, "/tmp/apx_test_unused", env); a.init_networks(0)
+    _normalise_by_the_step_loop(a, 256 * 20)
     a.prepare_resets = False
     a.sample()
     return a
+
+
+def _normalise_by_the_step_loop(a, iters):
+    """Observation statistics through the per-step Python loop (the replayed-noise path of PPO.normalization_params) in BOTH twins: the default path is itself a rollout
+    launch as soon as normalization_params is routed through apx_rollout: its one-launch and per-step forms agree to round-off only, the twins would then start
+    from slightly different normalisation constants."""
+    a.noise_fn = lambda t, out: out.normal_(generator=a.gen)
+    a.normalization_params(iters)
+    a.noise_fn = None
 
 
 def test_td3_async_collection_and_updates_on_two_streams(dev, tmp_path):
