@@ -53,13 +53,12 @@ template <class T> __device__ __forceinline__ T sel5(int u5, T a0, T a1, T a2, T
 static_assert(cmt::ct_act_gear[5] == cmt::ct_act_gear[0] && cmt::ct_act_gear[9] == cmt::ct_act_gear[4] && cmt::ct_act_bits[7] == cmt::ct_act_bits[2] &&
               cmt::ct_act_rpm[8] == cmt::ct_act_rpm[3] && cmt::ct_act_ctrlmax[6] == cmt::ct_act_ctrlmax[1] && cmt::ct_act_dof[5] == cmt::ct_act_dof[0] + 13 &&
               cmt::ct_act_dof[9] == cmt::ct_act_dof[4] + 13, "the two legs carry the same drives");
-__device__ __forceinline__ void stage1_io_lane(St S, int mode, float* estrec) {   // (as a called function the reset kernel faults: kept inline)
+__device__ __forceinline__ void stage1_io_lane(St S, int mode, est::Rec& rec) {   // (as a called function the reset kernel faults: kept inline)
     PROF_START();
     int l = threadIdx.x & 15;
     asm volatile("" : "+v"(l));      // opaque: otherwise every per-lane constant below is hoisted out of the 50-substep loop and has to be
                                      // kept (= spilled to scratch) across the constraint stage, which needs the whole register file
     if (mode == 0) { if (l < 10) S.W(c4::WK_CTRL + l) = 0.f; if (l == 0) S.W(c4::WK_MISC + 6) = 0.f; PROF(0); return; }
-    est::Rec rec = est::rec_load(estrec, S.env, l);      // in flight while the encoder model runs
     const int flags = S.I(I_FLAGS);
     const bool mot = l < 10;
     const int u = mot ? l : 0, u5 = u >= 5 ? u - 5 : u, k = mot ? 0 : l - 10;
@@ -142,8 +141,7 @@ __device__ __forceinline__ void stage1_io_lane(St S, int mode, float* estrec) { 
     }
     c4::wsync();                                          // the encoder lanes' outputs are the estimator's inputs
     PROF2(37);
-    est::est_step_lane(S, rec);                           // the 7 filtered fields: translationalVelocity, translationalAcceleration, height
-    est::rec_store(estrec, S.env, l, rec);
+    est::est_step_lane(S, rec);                           // the 7 filtered fields: translationalVelocity, translationalAcceleration, height (the record itself stays in registers: loaded / stored once per env step by the caller)
     PROF2(38);
     PROF(0);
 }
@@ -186,12 +184,14 @@ __device__ __forceinline__ void setconst_lane(const St& S) {
     c4::wsync();
 }
 // one 2 kHz substep (cassie_sim_step_pd): the wave holds 4 envs, one per 16-lane row; every call site is reached by all lanes
+// `rec` = this lane's share of the env's state-estimator record (estimator_lane.h), carried in registers over the substeps of an env step (round 5: it went through L2 twice per
+// substep; in the one-launch rollout the hot lines were written back to HBM ~190 times per launch - 515 MB against 68 MB of algorithmic traffic)
 template <bool HF>
-__device__ __forceinline__ void sim_step_pd(const St& S, const Cfg& cfg, int mode) {
+__device__ __forceinline__ void sim_step_pd(const St& S, const Cfg& cfg, int mode, est::Rec& rec) {
 #ifdef APX_PROF
     const unsigned long long t0__ = clock64();
 #endif
-    stage1_io_lane(S, mode, cfg.est);
+    stage1_io_lane(S, mode, rec);
     c4::wsync();
     stage1b_tree_lane(S);
     c4::wsync();
@@ -218,6 +218,16 @@ __device__ __forceinline__ void sim_step_pd(const St& S, const Cfg& cfg, int mod
 #ifdef APX_PROF
     if (threadIdx.x == 0 && blockIdx.x == 0) c4::g_prof_acc[8] += clock64() - t0__;
 #endif
+}
+
+// the same with the record loaded from / stored to its HBM home around ONE substep (reset paths, forward-only passes: mode 0 does not touch it)
+template <bool HF>
+__device__ __forceinline__ void sim_step_pd(const St& S, const Cfg& cfg, int mode) {
+    const int l = threadIdx.x & 15;
+    est::Rec rec;
+    if (mode != 0) rec = est::rec_load(cfg.est, S.env, l);
+    sim_step_pd<HF>(S, cfg, mode, rec);
+    if (mode != 0) est::rec_store(cfg.est, S.env, l, rec);
 }
 
 // ------------------------------------------------------------------------------------------------ env logic
@@ -608,8 +618,10 @@ __device__ __forceinline__ void env_step_core(const St& S, const Cfg& cfg, int e
         for (int k = 0; k < 4; ++k) S.W(ACC + k) = 0.f;
     }
     c4::wsync();
+    const int el = threadIdx.x & 15;
+    est::Rec erec = est::rec_load(cfg.est, S.env, el);
     for (int i = 0; i < cfg.simrate; ++i) {
-        sim_step_pd<HF>(S, cfg, 1);                                        // all lanes (barriers inside)
+        sim_step_pd<HF>(S, cfg, 1, erec);                                  // all lanes (barriers inside)
         if (!lead) continue;
         {   // every load before the first store (a load behind a store to a word the compiler cannot prove different waits for it: these were ten LDS round trips)
             float fw[16], pv[6], ac[4];
@@ -628,6 +640,8 @@ __device__ __forceinline__ void env_step_core(const St& S, const Cfg& cfg, int e
             S.W(ACC + 2) = ac[2] + 1.f - il * il; S.W(ACC + 3) = ac[3] + 1.f - ir * ir;                                              // cassie.py:426-427
         }
     }
+    est::rec_store(cfg.est, S.env, el, erec);      // (before write_obs: the min input profile reads the estimator's foot poses from the record)
+    c4::wsync();
     if (lead) {
         float act[10];
         for (int u = 0; u < 10; ++u) act[u] = act10[u];
