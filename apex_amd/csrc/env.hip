@@ -53,12 +53,16 @@ template <class T> __device__ __forceinline__ T sel5(int u5, T a0, T a1, T a2, T
 static_assert(cmt::ct_act_gear[5] == cmt::ct_act_gear[0] && cmt::ct_act_gear[9] == cmt::ct_act_gear[4] && cmt::ct_act_bits[7] == cmt::ct_act_bits[2] &&
               cmt::ct_act_rpm[8] == cmt::ct_act_rpm[3] && cmt::ct_act_ctrlmax[6] == cmt::ct_act_ctrlmax[1] && cmt::ct_act_dof[5] == cmt::ct_act_dof[0] + 13 &&
               cmt::ct_act_dof[9] == cmt::ct_act_dof[4] + 13, "the two legs carry the same drives");
-__device__ __forceinline__ void stage1_io_lane(St S, int mode, est::Rec& rec) {   // (as a called function the reset kernel faults: kept inline)
+template <bool CARRY>
+__device__ __forceinline__ void stage1_io_lane(St S, int mode, est::Rec& carried, float* estrec) {   // (as a called function the reset kernel faults: kept inline)
     PROF_START();
     int l = threadIdx.x & 15;
     asm volatile("" : "+v"(l));      // opaque: otherwise every per-lane constant below is hoisted out of the 50-substep loop and has to be
                                      // kept (= spilled to scratch) across the constraint stage, which needs the whole register file
     if (mode == 0) { if (l < 10) S.W(c4::WK_CTRL + l) = 0.f; if (l == 0) S.W(c4::WK_MISC + 6) = 0.f; PROF(0); return; }
+    est::Rec local;
+    if constexpr (!CARRY) local = est::rec_load(estrec, S.env, l);      // in flight while the encoder model runs
+    est::Rec& rec = CARRY ? carried : local;
     const int flags = S.I(I_FLAGS);
     const bool mot = l < 10;
     const int u = mot ? l : 0, u5 = u >= 5 ? u - 5 : u, k = mot ? 0 : l - 10;
@@ -141,7 +145,8 @@ __device__ __forceinline__ void stage1_io_lane(St S, int mode, est::Rec& rec) { 
     }
     c4::wsync();                                          // the encoder lanes' outputs are the estimator's inputs
     PROF2(37);
-    est::est_step_lane(S, rec);                           // the 7 filtered fields: translationalVelocity, translationalAcceleration, height (the record itself stays in registers: loaded / stored once per env step by the caller)
+    est::est_step_lane(S, rec);                           // the 7 filtered fields: translationalVelocity, translationalAcceleration, height
+    if constexpr (!CARRY) est::rec_store(estrec, S.env, l, rec);      // (CARRY: the record stays in registers, loaded / stored once per env step by the caller)
     PROF2(38);
     PROF(0);
 }
@@ -186,12 +191,12 @@ __device__ __forceinline__ void setconst_lane(const St& S) {
 // one 2 kHz substep (cassie_sim_step_pd): the wave holds 4 envs, one per 16-lane row; every call site is reached by all lanes
 // `rec` = this lane's share of the env's state-estimator record (estimator_lane.h), carried in registers over the substeps of an env step (round 5: it went through L2 twice per
 // substep; in the one-launch rollout the hot lines were written back to HBM ~190 times per launch - 515 MB against 68 MB of algorithmic traffic)
-template <bool HF>
+template <bool HF, bool CARRY = true>
 __device__ __forceinline__ void sim_step_pd(const St& S, const Cfg& cfg, int mode, est::Rec& rec) {
 #ifdef APX_PROF
     const unsigned long long t0__ = clock64();
 #endif
-    stage1_io_lane(S, mode, rec);
+    stage1_io_lane<CARRY>(S, mode, rec, cfg.est);
     c4::wsync();
     stage1b_tree_lane(S);
     c4::wsync();
@@ -220,14 +225,11 @@ __device__ __forceinline__ void sim_step_pd(const St& S, const Cfg& cfg, int mod
 #endif
 }
 
-// the same with the record loaded from / stored to its HBM home around ONE substep (reset paths, forward-only passes: mode 0 does not touch it)
+// the same with the record loaded from / stored to its HBM home inside the io stage of the substep (per-step launch kernel, reset paths; mode 0 does not touch it)
 template <bool HF>
 __device__ __forceinline__ void sim_step_pd(const St& S, const Cfg& cfg, int mode) {
-    const int l = threadIdx.x & 15;
-    est::Rec rec;
-    if (mode != 0) rec = est::rec_load(cfg.est, S.env, l);
-    sim_step_pd<HF>(S, cfg, mode, rec);
-    if (mode != 0) est::rec_store(cfg.est, S.env, l, rec);
+    est::Rec none;      // (not touched: the io stage loads and stores the record itself)
+    sim_step_pd<HF, false>(S, cfg, mode, none);
 }
 
 // ------------------------------------------------------------------------------------------------ env logic
@@ -606,7 +608,9 @@ __device__ unsigned long long g_wavetime[4096];
 // CassieEnv.step (cassie/cassie.py:389-496) of one env on its 16-lane row, state resident in LDS: PD targets from the action, simrate substeps with the per-substep
 // accumulators, phase / time, termination, reward, command resampling.  act10 = the env's ten action entries (HBM row of the action batch for env_step_kernel, LDS words
 // for env_rollout_kernel); returns reward and done flag on the lead lane.  Outputs (observation, reward, done) are the caller's.
-template <bool HF>
+// CARRY: the estimator record stays in registers over the substeps of the step (the one-launch rollout: one load / store per step); the per-step launch kernel keeps the
+// per-substep memory form - carried, its 24 more live registers cost it 1.5 % (2.19 vs 2.15 ms, same box), where in the rollout kernel the launch time does not move
+template <bool HF, bool CARRY = false>
 __device__ __forceinline__ void env_step_core(const St& S, const Cfg& cfg, int env, bool lead, const float* act10, float& rew_out, int& dn_out) {
     // nothing of the env-step bookkeeping stays in registers across the substeps (the constraint stage needs every one of the 512):
     // the action is re-read at the end, the four per-substep accumulators live in spare hand-off words of the env's LDS region
@@ -619,9 +623,11 @@ __device__ __forceinline__ void env_step_core(const St& S, const Cfg& cfg, int e
     }
     c4::wsync();
     const int el = threadIdx.x & 15;
-    est::Rec erec = est::rec_load(cfg.est, S.env, el);
+    est::Rec erec;
+    if constexpr (CARRY) erec = est::rec_load(cfg.est, S.env, el);
     for (int i = 0; i < cfg.simrate; ++i) {
-        sim_step_pd<HF>(S, cfg, 1, erec);                                  // all lanes (barriers inside)
+        if constexpr (CARRY) sim_step_pd<HF>(S, cfg, 1, erec);             // all lanes (barriers inside)
+        else sim_step_pd<HF>(S, cfg, 1);
         if (!lead) continue;
         {   // every load before the first store (a load behind a store to a word the compiler cannot prove different waits for it: these were ten LDS round trips)
             float fw[16], pv[6], ac[4];
@@ -640,8 +646,7 @@ __device__ __forceinline__ void env_step_core(const St& S, const Cfg& cfg, int e
             S.W(ACC + 2) = ac[2] + 1.f - il * il; S.W(ACC + 3) = ac[3] + 1.f - ir * ir;                                              // cassie.py:426-427
         }
     }
-    est::rec_store(cfg.est, S.env, el, erec);      // (before write_obs: the min input profile reads the estimator's foot poses from the record)
-    c4::wsync();
+    if constexpr (CARRY) { est::rec_store(cfg.est, S.env, el, erec); c4::wsync(); }      // (before write_obs: the min input profile reads the estimator's foot poses from the record)
     if (lead) {
         float act[10];
         for (int u = 0; u < 10; ++u) act[u] = act10[u];
@@ -885,7 +890,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_rollout_kernel(float
         }
         // ---- env step
         float rew = 0.f; int dn = 0;
-        env_step_core<HF>(S, cfg, env, lead, (const float*)&S.W(WK_ACT), rew, dn);
+        env_step_core<HF, true>(S, cfg, env, lead, (const float*)&S.W(WK_ACT), rew, dn);
         if (lead) {
             RA(rew_grid)[(size_t)t * n + env] = rew; RA(done_grid)[(size_t)t * n + env] = (uint8_t)dn;
             write_obs(S, cfg, (float*)stage);
