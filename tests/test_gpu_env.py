@@ -429,10 +429,11 @@ def test_edge_cases_simrate_empty_mask_and_bad_arguments(dev):
 
 
 def test_saturation_flags_vs_oracle_crafted(dev):
-    """Row 'contact / limit set of cassie.xml': the kernel instantiates 2 floor contacts + 1 limit per leg; everything else cassie.xml can
-    produce (pelvis sphere :87, hip-pitch capsules :101,164, left-right capsule pairs :119-144, further capsule ends / limits) is DETECTED and
-    counted in I_SAT.  Crafted single-forward-pass states, one per geom pair class: the kernel's flags equal the flags of the oracle's
-    complete collision pass; in the unsaturated states kernel and (complete) oracle accelerations agree."""
+    """Row 'contact / limit set of cassie.xml': the fast path of the kernel instantiates 2 floor contacts + 1 limit per leg and three capsule pairs; everything else
+    cassie.xml can produce (pelvis sphere :87, hip-pitch capsules :101,164, left-right capsule pairs :119-144, further capsule ends / limits) is detected, counted in
+    I_SAT and - since round 5 - solved out of line with the complete row set (cassie_complete.h; the folded robot on the floor has 17 contacts = 63 basis records, i.e. the
+    HBM tier of the record pool is on the path).  Crafted single-forward-pass states, one per geom pair class: the kernel's flags equal the flags of the oracle's complete
+    collision pass, and kernel and (complete) oracle accelerations agree, saturated or not."""
     genv, oenv = _mk(False, 12)
     genv.reset()
     q0 = genv.get_field("qpos").cpu().numpy().astype(np.float64)[0]
