@@ -48,7 +48,15 @@ def _worker(rank, world, port, out):
     sl = slice(rank * 32, (rank + 1) * 32)                       # this rank's half of the union minibatch
     scal, g = _grads(Wa, Wo, Wc, obs[sl], act[sl], ret[sl], adv[sl])
     flat = torch.tensor(g)
+    two = flat.clone()
     adist.allreduce_mean_(flat)                                   # THE gradient collective
+    # ... and in the two-half asynchronous form of PPO.update (round 5: the actor's half travels while the critic's backward runs): two async all-reduces on views
+    # of the flat buffer, joined and averaged once
+    na = two.numel() // 2
+    h = [adist.allreduce_begin(two[:na])]
+    h.append(adist.allreduce_begin(two[na:]))
+    adist.allreduce_end(h, two, world)
+    assert torch.equal(two, flat)
     sc = torch.tensor(scal); adist.allreduce_mean_(sc)
     a = (ret[sl] - adv[sl]).reshape(-1)
     mom = torch.tensor([a.sum(), (a * a).sum(), float(a.size)], dtype=torch.float64)
