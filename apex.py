@@ -41,6 +41,7 @@ def build_parser():
     p.add_argument("--clip", type=float, default=0.2)
     p.add_argument("--minibatch_size", type=int, default=64)
     p.add_argument("--epochs", type=int, default=3)
+    p.add_argument("--epoch_kernel", action="store_true", help="minibatches of at most 256 rows on one GPU: every epoch's optimiser steps as ONE launch (apx_ppo_epoch)")
     p.add_argument("--num_steps", type=int, default=5096)
     p.add_argument("--use_gae", type=bool, default=True)
     p.add_argument("--num_procs", type=int, default=30)

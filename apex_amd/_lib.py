@@ -66,6 +66,9 @@ SIGNATURES = {
                                   c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "apx_ppo_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int, C.c_int, C.c_int]),
     "apx_ppo_minibatch": (C.c_int, [C.POINTER(PpoArgs), c_ptr]),
+    "apx_ppo_epoch_supported": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "apx_ppo_epoch_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "apx_ppo_epoch": (C.c_int, [C.POINTER(PpoArgs), c_ptr, C.c_int64, c_ptr]),
     "apx_clip_adam": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int, c_ptr, c_ptr]),
     "apx_env_default_cfg": (None, [C.POINTER(EnvCfg)]),

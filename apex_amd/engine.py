@@ -229,6 +229,7 @@ class PPOLearner:
                     raise ValueError("clock index %d outside the %d-entry observation" % (int(c), obs_dim))
                 self.clock_mask |= 1 << int(c)
         self._ws = None
+        self._ews = None
         self._scal = torch.zeros(6, dtype=torch.float64, device=device)
 
     def old_means(self, obs):
@@ -260,6 +261,38 @@ class PPOLearner:
             workspace=_p(self._ws), workspace_bytes=self._ws.numel(), scalars_out=_p(self._scal))
         check(lib.apx_ppo_minibatch(C.byref(a), _stream()))
         return self._scal.cpu().numpy().copy() if sync else self._scal
+
+    def epoch_supported(self, mb):
+        """Whether epoch() serves this minibatch size (the 2 x 256 networks, mb a multiple of 16 up to 1024)."""
+        return bool(_lib.load().apx_ppo_epoch_supported(int(mb), self.actor.D, self.actor.H, self.actor.O))
+
+    def epoch(self, obs, act, ret, adv, old_mu, perm, mb, mirror=True):
+        """nb = len(perm) // mb optimiser steps (the minibatch loop of rl/algos/ppo.py:417-438) as ONE launch: step k = minibatch(idx=perm[k mb:(k + 1) mb]).
+        Returns the [nb, 6] f64 device tensor of the steps' scalars (no host sync)."""
+        lib = _lib.load()
+        nb = int(perm.numel()) // int(mb)
+        assert nb >= 1 and perm.dtype == torch.int64 and perm.is_contiguous()
+        D, H, A = self.actor.D, self.actor.H, self.actor.O
+        need = int(lib.apx_ppo_epoch_workspace_bytes(int(mb), nb, D, H, A))
+        if need == 0:
+            raise _lib.ApxError("apx_ppo_epoch does not serve minibatch %d of a %d-%d-%d network" % (mb, D, H, A))
+        if self._ews is None or self._ews.numel() < need:
+            self._ews = torch.empty(need, dtype=torch.uint8, device=self.device)
+        scal = torch.empty(nb, 6, dtype=torch.float64, device=self.device)
+        use_mirror = mirror and self.obs_sp is not None
+        a = _lib.PpoArgs(
+            actor=_p(self.actor.params), actor_m=_p(self.actor_m), actor_v=_p(self.actor_v), actor_grad=_p(self.actor_g),
+            critic=_p(self.critic.params), critic_m=_p(self.critic_m), critic_v=_p(self.critic_v),
+            critic_grad=_p(self.critic_g), D=D, H=H, A=A, obs=_p(obs), act=_p(act), ret=_p(ret), adv=_p(adv),
+            old_mu=_p(old_mu), idx=None, mb=int(mb), obs_mean=_p(self.obs_mean), obs_std=_p(self.obs_std),
+            obs_sign_perm=_p(self.obs_sp) if use_mirror else None, clock_mask=self.clock_mask,
+            act_sign_perm=_p(self.act_sp) if use_mirror else None, fixed_std=self.fixed_std, clip=self.clip,
+            entropy_coeff=self.entropy_coeff, grad_clip=self.grad_clip, lr=self.lr, adam_eps=self.eps,
+            mirror_coeff=self.mirror_coeff, adam_t=self.t + 1, grad_only=0,
+            workspace=_p(self._ews), workspace_bytes=self._ews.numel(), scalars_out=_p(scal))
+        check(lib.apx_ppo_epoch(C.byref(a), _p(perm), nb, _stream()))
+        self.t += nb
+        return scal
 
     def apply_grads(self, scale=1.0):
         """clip + Adam on (all-reduced) gradients after minibatch(grad_only=True)."""

@@ -90,6 +90,11 @@ class PPO:
         self.noise = torch.zeros(T, N, 10, **f32)
         self.prepare_resets = bool(args.get("prepare_resets", True)); self._side = None
         self.use_graph = bool(args.get("graph", False)) and not self.dist_on
+        # small minibatches (the reference's CLI default 64, apex.py:242): the epoch's optimiser steps as ONE launch (apx_ppo_epoch) instead of 16 launches per step.
+        # "auto" = whenever the minibatch is at most epoch_kernel_max_mb rows and this is a single-GPU run (a gradient all-reduce per step needs the per-step launches)
+        ek = args.get("epoch_kernel") or os.environ.get("APX_PPO_EPOCH", "0")
+        self.epoch_kernel = ek in (True, 1, "1", "auto", "on", "true")
+        self.epoch_kernel_max_mb = int(args.get("epoch_kernel_max_mb", 256))
         self._graph = None
         if self.use_graph and hasattr(env, "set_refill"):
             env.set_refill(False)      # the captured rollout is a single-stream graph: no side-stream refill of the reset ring inside it (drains one in flight)
@@ -241,7 +246,15 @@ class PPO:
                 perm = self.perm_fn(epoch)
             acc = torch.zeros(6, dtype=torch.float64, device=self.device)
             nb = B // mb                                                                     # drop_last=True, ppo.py:416
-            for k in range(nb):
+            if self.epoch_kernel and not self.dist_on and mb <= self.epoch_kernel_max_mb and L.epoch_supported(mb):
+                scal_all = L.epoch(obs, act, ret, adv, mu, perm[:nb * mb].contiguous(), mb, mirror=self.mirror)      # [nb, 6]: every step's scalars, one launch
+                acc, scal = scal_all.sum(0), scal_all[-1]
+                if self.trace is not None:
+                    self.trace.extend(scal_all[i].clone() for i in range(nb))
+                nb_loop = 0
+            else:
+                nb_loop = nb
+            for k in range(nb_loop):
                 idx = perm[k * mb:(k + 1) * mb]
                 if self.dist_on:
                     # the flat gradient travels in its two halves: the actor's (81 418 floats) is final before the critic's backward starts, so its all-reduce runs on

@@ -243,6 +243,7 @@ def main():
     ap.add_argument("--minibatch", type=int, default=16384)
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--epoch_kernel", action="store_true", help="cassie_ppo, one GPU, --minibatch <= 256: an epoch's optimiser steps as ONE launch (apx_ppo_epoch) instead of 16 launches per step")
     ap.add_argument("--td3_async", action="store_true", help="cassie_td3 workload only: the asynchronous variant (collection and updates on two streams)")
     ap.add_argument("--workload", default="cassie_ppo", choices=["cassie_ppo", "cassietraj_recurrent", "cassie_td3"],
                     help="cassie_ppo = BASELINE.json configs[1] (the headline, default); cassietraj_recurrent = configs[3]: CassieTraj-v0, LSTM 2x128, 2048 envs/GPU; cassie_td3 = configs[4]: TD3, 1M-transition replay in HBM")
@@ -270,7 +271,7 @@ def main():
     env = CassieVecEnv(n_envs=a.n_envs, seed=0, device=local, env_id_base=adist.shard_env_base(rank, a.n_envs))
     args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=a.minibatch,
                 epochs=a.epochs, num_steps=a.rollout_len * a.n_envs * world, max_traj_len=400, max_grad_norm=0.05,
-                mirror=True, std_dev=-1.5, seed=0, graph=os.environ.get("APX_ROLLOUT_GRAPH", "0") == "1")      # fp32 MFMA: the reference's own network precision and the library's only mode
+                mirror=True, std_dev=-1.5, seed=0, graph=os.environ.get("APX_ROLLOUT_GRAPH", "0") == "1", epoch_kernel=a.epoch_kernel)      # fp32 MFMA: the reference's own network precision and the library's only mode
     algo = PPO(args, "/tmp/apx_bench_unused", env, rank=rank, world_size=world, group=group)
     algo.init_networks(0)
     algo.normalization_params(10000)
@@ -344,7 +345,7 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Cassie-v0 PPO, 4096 batched envs/GPU, 2x256 MLP actor/critic (BASELINE.json configs[1])",
-                       "envs_per_gpu": a.n_envs, "rollout_len": a.rollout_len, "simrate": 50, "minibatch": a.minibatch,
+                       "envs_per_gpu": a.n_envs, "rollout_len": a.rollout_len, "simrate": 50, "minibatch": a.minibatch, "optimiser_steps_as_one_launch_per_epoch": bool(algo.epoch_kernel and not dist_on and a.minibatch <= algo.epoch_kernel_max_mb),
                        "epochs": a.epochs, "mirror_loss": True, "dynamics_randomization": True, "eval_rollouts": False,
                        "parallelism": f"dp{world} (env shards, 1 RCCL grad all-reduce per optimiser step)"},
             "sampling_env_steps_per_s": round(a.steps * a.rollout_len * a.n_envs * world / max(samp, 1e-9), 1),

@@ -175,6 +175,17 @@ typedef struct apx_ppo_args {
 
 size_t apx_ppo_workspace_bytes(int64_t mb, int D, int H, int A);
 int apx_ppo_minibatch(const apx_ppo_args* args, void* stream);
+
+/* One EPOCH of optimiser steps in one launch, for the small minibatches of the reference's parity run (apex.py:242: minibatch_size 64): the loop
+ * `for indices in sampler: self.update_policy(...)` of rl/algos/ppo.py:417-438 with sampler = BatchSampler(SubsetRandomSampler(range(B)), mb, drop_last=True)
+ * (:414-415).  perm [nb * mb] int64 [dev] = the epoch's sample order; step k = apx_ppo_minibatch on idx = perm[k mb : (k + 1) mb] with adam_t = args->adam_t + k
+ * (forwards, losses, backwards, clip_grad_norm_, Adam - same arithmetic, fp32 MFMA; only the summation order of the GEMMs differs).  args as for apx_ppo_minibatch
+ * except: idx NULL, grad_only 0, adam_t = step count of the FIRST minibatch, workspace >= apx_ppo_epoch_workspace_bytes, scalars_out [nb, 6] f64 [dev] = the six
+ * scalars of every step.  actor_grad / critic_grad hold the last step's gradients afterwards.  Single-GPU only (a gradient all-reduce per step needs the per-step
+ * entry point).  apx_ppo_epoch_supported: H = 256, D <= 64, A <= 16, mb a multiple of 16 in 16..1024; the parameter blocks and the workspace 16-byte aligned. */
+int apx_ppo_epoch_supported(int64_t mb, int D, int H, int A);
+size_t apx_ppo_epoch_workspace_bytes(int64_t mb, int64_t nb, int D, int H, int A);
+int apx_ppo_epoch(const apx_ppo_args* args, const int64_t* perm, int64_t nb, void* stream);
 /* second half when grad_only=1 was used: global-norm clip (clip_grad_norm_, ppo.py:326,335) + Adam (ppo.py:355-356)
  * on an (all-reduced) gradient; scale multiplies the gradient first (1/world_size for an averaged sum). */
 int apx_clip_adam(float* param, float* m, float* v, float* grad, int64_t n, float grad_scale, float grad_clip,

@@ -44,3 +44,28 @@ def check_slim(got, ref_slim, atol, frac_tol=None, frac=0.0, err_msg=""):
     n = got.size
     assert abs(got.sum() - ref_slim[0]) <= atol * n * 0.05 + 1e-6 * max(1.0, abs(ref_slim[0])), (err_msg, "sum", got.sum(), ref_slim[0])
     assert abs(np.sqrt((got * got).sum()) - ref_slim[1]) <= atol * np.sqrt(n) + 1e-6 * max(1.0, ref_slim[1]), (err_msg, "l2")
+
+
+# ---- G4b (tools/refprobe/gen_golden_epoch.py): an epoch of small-minibatch PPO steps on the 2 x 256 networks; (mirror, minibatch, steps, Adam step count of the first)
+EPOCH_CASES = [(True, 64, 8, 1), (False, 64, 6, 1), (True, 32, 4, 7), (True, 128, 3, 1), (False, 16, 5, 2049)]
+_ACTOR_SHAPES = [(256, 50), (256,), (256, 256), (256,), (10, 256), (10,)]
+_CRITIC_SHAPES = [(256, 50), (256,), (256, 256), (256,), (1, 256), (1,)]
+
+
+def epoch_case_inputs(c):
+    """Inputs of G4b case c, regenerated from its seed: parameter lists (state_dict order) of the policy, the old policy (policy - noise) and the critic,
+    the normaliser, a batch of 1.25 x the epoch's rows (so that the sample order is a proper gather) and the epoch's sample order."""
+    mirror, mb, nb, adam_t0 = EPOCH_CASES[c]
+    rs = np.random.RandomState(4100 + c)
+    B = (nb * mb * 5) // 4
+    actor = seeded_params(_ACTOR_SHAPES, 4200 + c)
+    critic = seeded_params(_CRITIC_SHAPES, 4300 + c)
+    actor[4] = actor[4] * 0.5; critic[4] = critic[4] * 0.5
+    old = [w - nz for w, nz in zip(actor, seeded_noise(_ACTOR_SHAPES, 4400 + c, 0.004))]
+    obs = rs.randn(B, 50).astype(np.float32)
+    ph = rs.rand(B) * 2 * np.pi
+    obs[:, 46] = np.sin(ph); obs[:, 47] = np.cos(ph)      # clock columns are valid sines (arcsin in mirror_clock_observation)
+    return dict(actor=actor, old=old, critic=critic, obs=obs, act=(rs.randn(B, 10) * 0.3).astype(np.float32),
+                ret=rs.randn(B).astype(np.float32), adv=rs.randn(B).astype(np.float32),
+                obs_mean=(rs.randn(50) * 0.3).astype(np.float32), obs_std=(rs.rand(50) + 0.5).astype(np.float32),
+                perm=rs.permutation(B)[:nb * mb].astype(np.int64))

@@ -141,6 +141,40 @@ def test_ppo_update_golden_g4(dev, golden_dir):
             assert bad.mean() < 2e-3, (c, k, bad.mean())
 
 
+def test_ppo_steps_golden_g4b(dev, golden_dir):
+    """An epoch of small-minibatch steps (64 / 32 / 128 / 16 rows, the 2 x 256 networks, Adam step counts 1.. / 7.. / 2049..) through the per-step launches
+    against the reference's own per-step 6-tuples and post-epoch parameters (G4b; inputs regenerated from the fixture's seeds)."""
+    from golden_util import EPOCH_CASES, epoch_case_inputs, check_slim
+    from tests import epoch_worker as W
+    g = np.load(os.path.join(golden_dir, "g4b_epoch_h256.npz"))
+    for c, (mirror, mb, nb, adam_t0) in enumerate(EPOCH_CASES):
+        inp = epoch_case_inputs(c)
+        lr, data = W.make_learner(dev, inp, mirror, adam_t0)
+        scal = W.run_steps(lr, data, torch.tensor(inp["perm"], device=dev), mb, mirror)
+        np.testing.assert_allclose(scal, g[f"c{c}_scalars"], rtol=1e-5, atol=2e-7)      # (the actor loss is a cancelling mean: the reference's own fp32 rounding is ~2e-7 absolute there)
+        for i, w in enumerate(lr.actor.views()):
+            check_slim(w.cpu().numpy(), g[f"c{c}_actor1.{i}"], atol=2.5e-4, frac_tol=2e-6, frac=2e-3, err_msg=(c, "actor", i))
+        for i, w in enumerate(lr.critic.views()):
+            check_slim(w.cpu().numpy(), g[f"c{c}_critic1.{i}"], atol=2.5e-4, frac_tol=2e-6, frac=2e-3, err_msg=(c, "critic", i))
+
+
+# apx_ppo_epoch (ppo_small.hip: one persistent launch per epoch, grid-wide barriers) was written while GPU access was closed for the rest of round 5: it has compiled
+# for gfx950 and has NOT run on hardware yet, so the three checks are expected-to-fail-until-seen-passing (non-strict: an XPASS in the GPU log is the validation) and
+# run in a child process (tests/epoch_worker.py) so that a fault in that kernel cannot take the suite's GPU session with it.  PPO only uses the kernel on request
+# (PPO(epoch_kernel=True) / APX_PPO_EPOCH=1 / bench.py --epoch_kernel).
+@pytest.mark.xfail(strict=False, reason="apx_ppo_epoch has not run on hardware yet (GPU access closed while it was written)")
+@pytest.mark.parametrize("mode", ["golden", "twin", "ppo"])
+def test_ppo_epoch_one_launch(dev, mode):
+    """apx_ppo_epoch: golden = the reference's per-step outputs of G4b; twin = 48 steps of minibatch 64 against the per-step launches + bit-identical reruns;
+    ppo = PPO.update with the epoch kernel on / off on the same rollout."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "epoch_worker.py"), mode],
+                       capture_output=True, text=True, timeout=900)
+    print(r.stdout[-6000:]); print(r.stderr[-3000:])
+    assert r.returncode == 0, "apx_ppo_epoch %s check failed (see the worker's JSON lines above)" % mode
+
+
 def test_ppo_update_large_minibatch_vs_oracle(dev):
     """Throughput-sized minibatch (16 384) with index gather: gradients via grad_only vs the fp64 oracle."""
     from apex_amd import engine

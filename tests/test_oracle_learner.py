@@ -97,6 +97,32 @@ def test_g4_update_policy(golden_dir):
             assert bad.mean() < 1e-3, (c, k, bad.mean())
 
 
+def test_g4b_epoch_of_small_minibatches(golden_dir):
+    """G4b: an epoch of minibatch-64 / 32 / 128 / 16 optimiser steps on the 2 x 256 networks (the reference's CLI default minibatch, apex.py:242): the oracle's
+    per-step update against the reference's per-step 6-tuples and the post-epoch parameters (inputs regenerated from the fixture's seeds)."""
+    from golden_util import EPOCH_CASES, epoch_case_inputs, check_slim
+    g = np.load(os.path.join(golden_dir, "g4b_epoch_h256.npz"))
+    g5 = np.load(os.path.join(golden_dir, "g5_mirror.npz"))
+    assert int(g["n_cases"]) == len(EPOCH_CASES)
+    for c, (mirror, mb, nb, adam_t0) in enumerate(EPOCH_CASES):
+        inp = epoch_case_inputs(c)
+        actor, old, critic = inp["actor"], inp["old"], inp["critic"]
+        oa, oc = L.Adam(actor), L.Adam(critic)
+        oa.t = oc.t = adam_t0 - 1
+        scal_all = []
+        for k in range(nb):
+            idx = inp["perm"][k * mb:(k + 1) * mb]
+            scal, actor, critic = L.ppo_update(actor, old, critic, oa, oc, inp["obs"][idx], inp["act"][idx], inp["ret"][idx, None], inp["adv"][idx, None],
+                                               inp["obs_mean"], inp["obs_std"], np.exp(-1.5),
+                                               M_obs=g5["obs_mirror_matrix"] if mirror else None, M_act=g5["act_mirror_matrix"] if mirror else None)
+            scal_all.append(scal)
+        np.testing.assert_allclose(np.array(scal_all), g[f"c{c}_scalars"], rtol=3e-5, atol=2e-7)
+        for i, w in enumerate(actor):
+            check_slim(w, g[f"c{c}_actor1.{i}"], atol=2e-4, frac_tol=3e-6, frac=5e-3, err_msg=(c, "actor", i))
+        for i, w in enumerate(critic):
+            check_slim(w, g[f"c{c}_critic1.{i}"], atol=2e-4, frac_tol=3e-6, frac=5e-3, err_msg=(c, "critic", i))
+
+
 def _g15a_grid(g):
     idx = g["traj_idx"]; T = int(idx[-1])
     rew = g["rewards"].reshape(T, 1); end = np.zeros((T, 1), np.uint8); boot = np.zeros((T, 1))
