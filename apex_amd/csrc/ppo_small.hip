@@ -34,7 +34,7 @@ constexpr int SMAXG = 128;    // upper bound of the grid
 struct SmallNet {
     float *p, *m, *v, *g;     // parameters, Adam moments, flat gradient (layout of MlpView in learner.hip: W0 b0 W1 b1 W2 b2)
     float *X, *H1, *H2, *dZ2, *dZ1, *dY;      // [R, 64] padded input, [R, 256] activations / pre-activation gradients, [R, 16] padded output gradient
-    int O, R;                 // outputs, rows of a step
+    int O, R, Rp;             // outputs, rows of a step, rows rounded up to a multiple of 64 (the rows R..Rp of every row buffer stay zero)
     long n;                   // parameter count
 };
 
@@ -113,6 +113,24 @@ __device__ __forceinline__ floatx4 wave_tile(int kc0, int kc1, FA fa, FB fb, flo
     return acc;
 }
 
+// C = A^T B over the ROWS of two row-major matrices (weight / bias gradients: the contraction index is the sample row): Ac = &A[4 g][i], Bc = &B[4 g][n] of the lane.
+// No guards: every row buffer of the workspace is padded to a multiple of 64 rows that stay zero (the launch clears the workspace), chunks = padded rows / 16.
+template <int NB>
+__device__ __forceinline__ floatx4 rows_tile_nb(const float* Ac, int lda, const float* Bc, int ldb, int chunks, float* asum) {
+    return wave_tile<NB, true>(0, chunks,
+        [&](int kc, float (&a)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = Ac[(size_t)(16 * kc + j) * lda];
+        },
+        [&](int kc, float (&b)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bc[(size_t)(16 * kc + j) * ldb];
+        }, asum);
+}
+__device__ __forceinline__ floatx4 rows_tile(const float* Ac, int lda, const float* Bc, int ldb, int chunks, float* asum) {
+    return (chunks & 7) == 0 ? rows_tile_nb<8>(Ac, lda, Bc, ldb, chunks, asum) : rows_tile_nb<4>(Ac, lda, Bc, ldb, chunks, asum);
+}
+
 // the normalised (actor) / raw (critic) input rows of step k, zero-padded to 64 columns: ppo_head_kernel's arithmetic (learner.hip), wrappers.py:59-67 for the mirror
 __device__ __forceinline__ void gather_inputs(const SmallArgs& S, int k, int gtid, int gthreads) {
     const int Ra = S.net[0].R, Rc = S.net[1].R, D = S.D, mb = S.mb;
@@ -186,9 +204,9 @@ __global__ __launch_bounds__(256) void ppo_small_epoch_kernel(SmallArgs S) {
             const float* Wr = W0(n) + (size_t)(n0 + c) * D;
             const floatx4 acc = wave_tile<4, false>(0, 4,
                 [&](int kc, float (&a)[4]) { ld4(Xr + 16 * kc, a); },
-                [&](int kc, float (&b)[4]) {
+                [&](int kc, float (&b)[4]) {      // (columns D..63 of X are zero: what the loads beyond a W0 row fetch - the next row, b0, W1: all inside the block - is multiplied by 0)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { const int kk = 16 * kc + 4 * g + j; b[j] = kk < D ? Wr[kk] : 0.f; }
+                    for (int j = 0; j < 4; ++j) b[j] = Wr[16 * kc + 4 * g + j];
                 }, nullptr);
             const float bias = B0(n)[n0 + c];
 #pragma unroll
@@ -343,19 +361,9 @@ __global__ __launch_bounds__(256) void ppo_small_epoch_kernel(SmallArgs S) {
                     }
                 } else {
                     const int u = t - nd, ni = u >= (SH >> 4); const SmallNet& n = S.net[ni];
-                    const int c0 = (ni ? u - (SH >> 4) : u) << 4, R = n.R;
-                    const float* Ac = n.dY + (size_t)(4 * g) * SYP + c;
-                    const float* Bc = n.H2 + (size_t)(4 * g) * SH + c0 + c;
+                    const int c0 = (ni ? u - (SH >> 4) : u) << 4;
                     float as;
-                    const floatx4 acc = wave_tile<8, true>(0, R >> 4,
-                        [&](int kc, float (&a)[4]) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) a[j] = 16 * kc + 4 * g + j < R ? Ac[(size_t)(16 * kc + j) * SYP] : 0.f;
-                        },
-                        [&](int kc, float (&b)[4]) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) b[j] = 16 * kc + 4 * g + j < R ? Bc[(size_t)(16 * kc + j) * SH] : 0.f;
-                        }, &as);
+                    const floatx4 acc = rows_tile(n.dY + (size_t)(4 * g) * SYP + c, SYP, n.H2 + (size_t)(4 * g) * SH + c0 + c, SH, n.Rp >> 4, &as);
                     float* gW2 = n.g + oW2;
                     double s2 = 0.0;
 #pragma unroll
@@ -379,21 +387,11 @@ __global__ __launch_bounds__(256) void ppo_small_epoch_kernel(SmallArgs S) {
                 const bool six = t < 2 * n6;
                 const int u = six ? t : t - 2 * n6, per = six ? n6 : n8;
                 const int ni = u >= per; const SmallNet& n = S.net[ni];
-                const int tt = ni ? u - per : u, R = n.R;
+                const int tt = ni ? u - per : u;
                 const int n0 = (six ? tt >> 4 : tt >> 2) << 4, k0 = (six ? tt & 15 : tt & 3) << 4;
-                const float* Ac = (six ? n.dZ2 : n.dZ1) + (size_t)(4 * g) * SH + n0 + c;
                 const int ldb = six ? SH : SXP;
-                const float* Bc = (six ? n.H1 : n.X) + (size_t)(4 * g) * ldb + k0 + c;
                 float as;
-                const floatx4 acc = wave_tile<8, true>(0, R >> 4,
-                    [&](int kc, float (&a)[4]) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) a[j] = 16 * kc + 4 * g + j < R ? Ac[(size_t)(16 * kc + j) * SH] : 0.f;
-                    },
-                    [&](int kc, float (&b)[4]) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) b[j] = 16 * kc + 4 * g + j < R ? Bc[(size_t)(16 * kc + j) * ldb] : 0.f;
-                    }, &as);
+                const floatx4 acc = rows_tile((six ? n.dZ2 : n.dZ1) + (size_t)(4 * g) * SH + n0 + c, SH, (six ? n.H1 : n.X) + (size_t)(4 * g) * ldb + k0 + c, ldb, n.Rp >> 4, &as);
                 double s2 = 0.0;
                 if (six) {
                     float* gW = n.g + oW1;
@@ -463,6 +461,7 @@ __global__ __launch_bounds__(256) void ppo_small_epoch_kernel(SmallArgs S) {
 // ---------------------------------------------------------------------------------------------------------------------- host side
 namespace {
 size_t up64(size_t x) { return (x + 63) & ~(size_t)63; }
+long rpad(long r) { return (r + 63) / 64 * 64; }
 struct EpochWs {
     float *X[2], *H1[2], *H2[2], *dZ2[2], *dZ1[2], *dY[2], *tab;
     double *part, *lossp; unsigned* bar;
@@ -470,7 +469,7 @@ struct EpochWs {
     EpochWs(void* base, long mb, long nb, bool mirror) {
         char* p = (char*)base; size_t off = 0;
         auto take = [&](size_t nbytes) { char* r = p + off; off += up64(nbytes); return r; };
-        const long R[2] = {mirror ? 2 * mb : mb, mb};
+        const long R[2] = {rpad(mirror ? 2 * mb : mb), rpad(mb)};
         for (int i = 0; i < 2; ++i) {
             X[i] = (float*)take(R[i] * SXP * 4);
             H1[i] = (float*)take(R[i] * SH * 4); H2[i] = (float*)take(R[i] * SH * 4);
@@ -516,7 +515,7 @@ extern "C" int apx_ppo_epoch(const apx_ppo_args* a, const int64_t* perm, int64_t
         SmallNet& n = S.net[i];
         n.p = P[i]; n.m = M[i]; n.v = V[i]; n.g = Gr[i];
         n.X = w.X[i]; n.H1 = w.H1[i]; n.H2 = w.H2[i]; n.dZ2 = w.dZ2[i]; n.dZ1 = w.dZ1[i]; n.dY = w.dY[i];
-        n.O = i ? 1 : a->A; n.R = (int)(i == 0 && mirror ? 2 * a->mb : a->mb);
+        n.O = i ? 1 : a->A; n.R = (int)(i == 0 && mirror ? 2 * a->mb : a->mb); n.Rp = (int)rpad(n.R);
         n.n = (long)SH * a->D + SH + (long)SH * SH + SH + (long)n.O * SH + n.O;
     }
     S.D = a->D; S.A = a->A; S.mb = (int)a->mb; S.nb = (int)nb; S.mirror = mirror ? 1 : 0;
@@ -530,7 +529,7 @@ extern "C" int apx_ppo_epoch(const apx_ppo_args* a, const int64_t* perm, int64_t
     static const int forced = getenv("APX_PPO_EPOCH_WGS") ? atoi(getenv("APX_PPO_EPOCH_WGS")) : 0;
     int G = tiles <= 256 ? 64 : SMAXG;
     if (forced >= 1 && forced <= SMAXG) G = forced;
-    APX_HIP(hipMemsetAsync(w.bar, 0, 64, s));
+    APX_HIP(hipMemsetAsync(a->workspace, 0, w.bytes, s));      // the barrier counter and the padding rows of the row buffers
     hipLaunchKernelGGL(ppo_small_epoch_kernel, dim3(G), dim3(256), 0, s, S);
     APX_LAUNCH_CHECK();
     return APX_OK;

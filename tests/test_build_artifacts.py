@@ -126,3 +126,34 @@ def test_dpp_audit_flags_the_shape_it_is_meant_to_find():
 """
     hits = dpp_audit.audit(bad + good, 16)
     assert len(hits) == 1 and hits[0][0] == "kern_a" and "row_shr:6" in hits[0][2][0]
+
+
+def test_epoch_kernel_fences_and_operand_batches(code_objects):
+    """ppo_small_epoch_kernel (apx_ppo_epoch): (a) its grid barrier must carry the agent-scope release / acquire cache maintenance that makes one XCD's stores visible
+    to the others (buffer_wbl2 sc1 before the arrival, buffer_inv sc1 after the wait) - a barrier without them passes every single-XCD check and reads stale L2
+    lines on the real chip; (b) the operands of a K = 256 tile are fetched as ONE batch of 32 16-byte loads in front of its 64 MFMAs - left alone the scheduler sinks
+    each load to just before its MFMAs and a tile costs 16 L2 round trips instead of one; (c) no scratch instruction."""
+    for co in code_objects:
+        asm = subprocess.run([os.path.join(BIN, "llvm-objdump"), "-d", "--mcpu=gfx950", co], capture_output=True, text=True).stdout
+        if "ppo_small_epoch_kernel" in asm:
+            break
+    else:
+        pytest.fail("ppo_small_epoch_kernel not in libapx.so")
+    body = [b for b in re.split(r"\n(?=[0-9a-f]+ <)", asm) if re.match(r"[0-9a-f]+ <\S*ppo_small_epoch_kernel", b)][0]
+    ins = [ln.split()[0] + " " + " ".join(ln.split("//")[0].split()[1:]) for ln in body.split("\n")[1:] if "//" in ln]
+    assert sum(1 for i in ins if i.startswith("buffer_wbl2") and "sc1" in i) >= 7
+    assert sum(1 for i in ins if i.startswith("buffer_inv") and "sc1" in i) >= 7
+    assert not any(i.startswith("scratch_") for i in ins)
+    ops = [i.split()[0] for i in ins if i.split()[0] in ("global_load_dwordx4", "global_load_dword") or i.startswith("v_mfma")]
+    runs, prev, n = [], None, 0
+    for o in ops + [None]:
+        k = "mfma" if o and o.startswith("v_mfma") else o
+        if k == prev:
+            n += 1
+        else:
+            if prev:
+                runs.append((prev, n))
+            prev, n = k, 1
+    batched = [i for i in range(len(runs) - 1) if runs[i] == ("global_load_dwordx4", 32) and runs[i + 1][0] == "mfma"]
+    assert len(batched) >= 1, runs      # phase B: both operands contiguous in K
+    assert sum(n for k, n in runs if k == "mfma") >= 200
