@@ -37,6 +37,7 @@ try:
 except Exception as e:
     print('wgs $wgs failed', e)" | tee -a "$OUT/summary.txt"
 done
-( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o epoch -- python "$OLDPWD/bench.py" --steps 2 --warmup 1 --minibatch 64 --no_cpu_baseline --epoch_kernel > "$OLDPWD/$OUT/prof.log" 2>&1 )
-python tools/rocprof_summary.py "$OUT/prof" > "$OUT/kernel_stats_mb64_epoch.txt" 2>> "$OUT/summary.txt" || true
+ROOT=$(pwd)
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/prof" -- python "$ROOT/bench.py" --steps 2 --warmup 1 --minibatch 64 --no_cpu_baseline --epoch_kernel > "$ROOT/$OUT/prof.log" 2>&1 )
+python tools/rocprof_summary.py "$(ls $OUT/prof/*/*.db | head -1)" "$OUT/kernel_stats_mb64_epoch.txt" > /dev/null 2>> "$OUT/summary.txt" || true
 cat "$OUT/summary.txt"
