@@ -44,15 +44,24 @@ def _flat(params):
 
 
 _KEEP = []
+_PAGE = mmap.PAGESIZE
+_libc = C.CDLL(None, use_errno=True)
+_libc.mprotect.argtypes = [C.c_void_p, C.c_size_t, C.c_int]
 
 
 def _aligned(n, dtype):
-    """zeroed, page-aligned, MAP_SHARED (the emulation's workgroups are forked processes)"""
-    nbytes = max(n * np.dtype(dtype).itemsize, 1)
-    m = mmap.mmap(-1, nbytes, flags=mmap.MAP_SHARED | mmap.MAP_ANONYMOUS)
+    """zeroed MAP_SHARED buffer (the emulation's workgroups are forked processes) that ENDS at an inaccessible guard page (its size rounded up to 16 bytes: the kernel
+    wants 16-byte aligned blocks): a read or write of the kernel beyond any buffer it is handed is a SIGSEGV here, as it would be a memory fault on the GPU"""
+    nbytes = n * np.dtype(dtype).itemsize
+    span = (max(nbytes, 1) + 15) // 16 * 16
+    pages = (span + _PAGE - 1) // _PAGE
+    m = mmap.mmap(-1, (pages + 1) * _PAGE, flags=mmap.MAP_SHARED | mmap.MAP_ANONYMOUS)
     _KEEP.append(m)
-    return np.frombuffer(m, dtype=np.uint8, count=n * np.dtype(dtype).itemsize).view(dtype)
-
+    whole = np.frombuffer(m, dtype=np.uint8)
+    base = whole.ctypes.data
+    assert _libc.mprotect(base + pages * _PAGE, _PAGE, 0) == 0, "mprotect"
+    off = pages * _PAGE - span
+    return whole[off:off + nbytes].view(dtype)
 
 def _shared(a):
     out = _aligned(a.size, a.dtype).reshape(a.shape)
@@ -114,3 +123,13 @@ def test_epoch_kernel_source_reproduces_the_reference_g4b(emu, golden_dir, c, wg
     for name, ref_list in (("actor", inp["actor"]), ("critic", inp["critic"])):
         for i, w in enumerate(_split(bufs[name], [np.shape(x) for x in ref_list])):
             check_slim(w, g[f"c{c}_{name}1.{i}"], atol=2.5e-4, frac_tol=2e-6, frac=2e-3, err_msg=(c, name, i))
+
+
+def test_guard_pages_fault_on_an_overrun():
+    """positive control of the guard pages: one float beyond a buffer of this module's allocator kills the reading process"""
+    import sys
+    code = ("import sys, ctypes as C; sys.path[:0] = [%r, %r]; import numpy as np; import test_kernel_emulation as T; a = T._aligned(81418, np.float32); "
+            "print(C.c_float.from_address(a.ctypes.data + 4 * 81417).value); sys.stdout.flush(); print(C.c_float.from_address(a.ctypes.data + 4 * 81420).value)"
+            % (REPO, os.path.join(REPO, "tests")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert r.stdout.strip() == "0.0" and r.returncode == -11, (r.returncode, r.stdout, r.stderr[-300:])
