@@ -226,7 +226,7 @@ def main_recurrent(a):
                                      "envs_per_gpu": n_envs, "rollout_len": T, "minibatch_trajectories": min(1024, n_envs // 2), "epochs": a.epochs, "mirror_loss": True,
                                      "parallelism": f"dp{world} (env shards; optimiser steps per epoch agreed by a MAX all-reduce, 1 gradient all-reduce per step)"},
                           "sample_s": round(samp / a.steps, 3), "optimize_s": round(opt / a.steps, 3),
-            "optimiser_step_us": round(opt / a.steps / max(1, a.epochs * ((a.rollout_len * a.n_envs) // min(a.minibatch, a.rollout_len * a.n_envs))) * 1e6, 2),      # update time per optimiser step (no KL early stop in the bench: all epochs run)
+            "optimiser_step_us": round(opt / max(1, epochs_run * ((a.rollout_len * a.n_envs) // min(a.minibatch, a.rollout_len * a.n_envs))) * 1e6, 2), "epochs_run_per_step": round(epochs_run / a.steps, 2),      # update time per optimiser step over the epochs that ran (the KL test of ppo.py:449 may end an iteration's update early)
                           "collectives": {"rccl_ranks_seen": torch.distributed.get_world_size() if dist_on else 1, "backend": torch.distributed.get_backend() if dist_on else None,
                                           "allreduce_calls_per_step": round(ar_calls / a.steps, 1), "allreduce_ms_per_step": round(ar_ms / a.steps, 3),
                                           "gradient_floats": int(algo.learner.grad_flat.numel()), "per_rank": per_rank}}))
@@ -293,9 +293,10 @@ def main():
     barrier()
     t0 = time.time()
     samp = opt = 0.0
+    epochs_run = 0
     for _ in range(a.steps):
         out = algo.iteration()
-        samp += out["sample_time"]; opt += out["optimize_time"]
+        samp += out["sample_time"]; opt += out["optimize_time"]; epochs_run += out["epochs"]
     barrier()
     dt = time.time() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=env.device)
@@ -351,7 +352,7 @@ def main():
                        "parallelism": f"dp{world} (env shards, 1 RCCL grad all-reduce per optimiser step)"},
             "sampling_env_steps_per_s": round(a.steps * a.rollout_len * a.n_envs * world / max(samp, 1e-9), 1),
             "sample_s": round(samp / a.steps, 3), "optimize_s": round(opt / a.steps, 3),
-            "optimiser_step_us": round(opt / a.steps / max(1, a.epochs * ((a.rollout_len * a.n_envs) // min(a.minibatch, a.rollout_len * a.n_envs))) * 1e6, 2),      # update time per optimiser step (no KL early stop in the bench: all epochs run)
+            "optimiser_step_us": round(opt / max(1, epochs_run * ((a.rollout_len * a.n_envs) // min(a.minibatch, a.rollout_len * a.n_envs))) * 1e6, 2), "epochs_run_per_step": round(epochs_run / a.steps, 2),      # update time per optimiser step over the epochs that ran (the KL test of ppo.py:449 may end an iteration's update early)
             # what the collective path actually was in this run (explains a scaling curve on its own): ranks the process group saw, backend, and the
             # gradient / scalar all-reduces of the timed region (hipEvents on the launch stream of rank 0)
             "collectives": {"rccl_ranks_seen": torch.distributed.get_world_size() if dist_on else 1, "backend": torch.distributed.get_backend() if dist_on else None,
