@@ -25,7 +25,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 def emu():
     if not os.path.exists(CLANG):
         pytest.skip("no host clang++")
-    so = os.path.join(EMU, "_build", "libppo_small_emul.so")
+    so = os.path.join(EMU, "_build", "libapx_emul.so")
     srcs = [os.path.join(EMU, "emul_ppo_small.cpp"), os.path.join(EMU, "hip", "hip_runtime.h"), os.path.join(REPO, "apex_amd", "csrc", "ppo_small.hip")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["bash", os.path.join(EMU, "build.sh")])

@@ -1,0 +1,119 @@
+"""CPU: the learner half's kernel SOURCES (apex_amd/csrc/learner.hip, ppo_small.hip) compiled for the host under the lane-exact wave emulation of tools/hipemu and driven
+through the SAME host code (apex_amd/engine.py) and the SAME test bodies as the GPU parity tests of tests/test_gpu_learner.py - against the reference's goldens (G1-G4,
+G4b, G18-G20) and the fp64 oracle.  The redirection lives in this file only (a fixture swaps the loaded library handle and the three device hooks of engine.py for the
+duration of a test); the product has no CPU path and tests/test_abi_loads.py::test_compute_fails_loudly_without_gpu keeps saying so.
+
+What this adds while no GPU can be reached: every index, tile map, LDS layout, MFMA operand / accumulator assignment, reduction and epilogue of the learner kernels is
+executed as written and held to the reference's numbers in the CPU suite.  What it cannot see: gfx950 code generation, memory-model effects, speed."""
+import contextlib
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(REPO, "tools", "hipemu")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def emulated_library():
+    """build (when stale) and load tools/hipemu/_build/libapx_emul.so with the signatures of apex_amd/_lib.py for the symbols it has (the learner half)"""
+    from apex_amd import _lib
+    so = os.path.join(EMU, "_build", "libapx_emul.so")
+    srcs = [os.path.join(EMU, f) for f in ("emul_ppo_small.cpp", "emul_learner.cpp", "build.sh", os.path.join("hip", "hip_runtime.h"))] + \
+           [os.path.join(REPO, "apex_amd", "csrc", f) for f in ("ppo_small.hip", "learner.hip", "apx_common.h")] + [os.path.join(REPO, "include", "apx.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["bash", os.path.join(EMU, "build.sh")])
+    lib = C.CDLL(so)
+    for name, (res, args) in _lib.SIGNATURES.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name); fn.restype = res; fn.argtypes = args
+    lib.apx_emul_last_error.restype = C.c_char_p
+    lib.apx_last_error = lib.apx_emul_last_error
+    return lib
+
+
+class _NoStream:
+    cuda_stream = 0
+
+    def wait_stream(self, other):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+@pytest.fixture()
+def dev(monkeypatch):
+    """torch.device('cpu') with apex_amd.engine talking to the emulated kernel sources for this test only"""
+    if not os.path.exists(CLANG):
+        pytest.skip("no host clang++")
+    from apex_amd import _lib, engine
+    lib = emulated_library()
+    lib.apx_emul_set_workgroups(0)      # workgroups of a launch one after the other (only apx_ppo_epoch needs concurrent ones)
+    monkeypatch.setattr(_lib, "_lib", lib)
+    monkeypatch.setattr(engine, "_need_gpu", lambda *ts: None)
+    monkeypatch.setattr(engine, "_stream", lambda: None)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _NoStream())
+    monkeypatch.setattr(torch.cuda, "Stream", lambda *a, **k: _NoStream())
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    return torch.device("cpu")
+
+
+def _gpu_tests():
+    from tests import test_gpu_learner as G
+    return G
+
+
+def test_emulated_returns_scan_g1_g15a(dev, golden_dir):
+    G = _gpu_tests()
+    G.test_returns_scan_vs_oracle(dev)
+    G.test_returns_scan_golden_g1(dev, golden_dir)
+    G.test_returns_scan_golden_g15a(dev, golden_dir)
+
+
+def test_emulated_advantage_normalisation_g2(dev, golden_dir):
+    _gpu_tests().test_adv_norm_golden_g2(dev, golden_dir)
+
+
+def test_emulated_fused_forward_g3_and_ragged_shapes(dev, golden_dir):
+    G = _gpu_tests()
+    G.test_mlp_forward_golden_g3(dev, golden_dir)
+    G.test_mlp_forward_ragged_shapes(dev)
+
+
+def test_emulated_ppo_update_g4(dev, golden_dir):
+    _gpu_tests().test_ppo_update_golden_g4(dev, golden_dir)
+
+
+def test_emulated_ppo_steps_g4b(dev, golden_dir):
+    _gpu_tests().test_ppo_steps_golden_g4b(dev, golden_dir)
+
+
+@pytest.mark.parametrize("fname", ["g18_lstm.npz", "g18b_lstm_h128.npz"])
+def test_emulated_lstm_forward_backward_g18(dev, golden_dir, fname):
+    _gpu_tests().test_lstm_forward_backward_golden_g18(dev, golden_dir, fname)
+
+
+@pytest.mark.parametrize("fname", ["g19_lstm_update.npz", "g19b_lstm_update_h128.npz"])
+def test_emulated_recurrent_update_policy_g19(dev, golden_dir, fname):
+    _gpu_tests().test_recurrent_update_policy_golden_g19(dev, golden_dir, fname)
+
+
+@pytest.mark.parametrize("fname", ["g20_td3.npz", "g20b_td3_h256.npz"])
+def test_emulated_td3_train_g20(dev, golden_dir, fname):
+    _gpu_tests().test_td3_train_golden_g20(dev, golden_dir, fname)
+
+
+def test_emulated_mirror_loss_min_profile(dev):
+    _gpu_tests().test_mirror_loss_uses_the_env_clock_columns_min_profile(dev)
+
+
+def test_emulated_fused_recurrent_step_and_gather(dev):
+    G = _gpu_tests()
+    G.test_fused_recurrent_step_equals_the_per_launch_chain(dev)
+    G.test_rec_gather_equals_the_torch_assembly(dev)

@@ -1,8 +1,14 @@
 #!/bin/bash
-# host build of the epoch kernel's source under the HIP emulation header -> tools/hipemu/_build/libppo_small_emul.so (git-ignored)
+# host build of the learner-side kernel sources under the HIP emulation header -> tools/hipemu/_build/libapx_emul.so (git-ignored)
 set -e
 cd "$(dirname "$0")"
 mkdir -p _build
 CXX=${CXX:-/opt/rocm/lib/llvm/bin/clang++}
-$CXX -x c++ -std=c++17 -O2 -fPIC -shared -pthread -I. -I../../include -Wno-unused-function -Wno-unused-variable emul_ppo_small.cpp -o _build/libppo_small_emul.so
-echo built tools/hipemu/_build/libppo_small_emul.so
+sed 's|extern __shared__ float fls\[\];|float* fls = (float*)hipemu::g_dynsmem;|' ../../apex_amd/csrc/learner.hip > _build/learner_emul.hip
+grep -q 'hipemu::g_dynsmem' _build/learner_emul.hip
+FLAGS="-x c++ -std=c++17 -O2 -fPIC -pthread -I. -I../../apex_amd/csrc -I../../include -Wno-unused-function -Wno-unused-variable -Wno-unknown-attributes -Wno-ignored-attributes"
+$CXX $FLAGS -c emul_ppo_small.cpp -o _build/emul_ppo_small.o &
+$CXX $FLAGS -c emul_learner.cpp -o _build/emul_learner.o &
+wait
+$CXX -shared -pthread _build/emul_ppo_small.o _build/emul_learner.o -o _build/libapx_emul.so
+echo built tools/hipemu/_build/libapx_emul.so

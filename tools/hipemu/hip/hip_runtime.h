@@ -18,9 +18,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <functional>
+#include <sys/mman.h>
 #include <thread>
+#include <type_traits>
 #include <vector>
+using std::min;
+using std::max;
 
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 typedef void* hipStream_t;
@@ -29,6 +34,11 @@ constexpr hipError_t hipSuccess = 0;
 inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
 
 #define __global__
 #define __device__
@@ -36,20 +46,26 @@ inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static
 #define __launch_bounds__(...)
+#define amdgpu_waves_per_eu(...) unused      /* __attribute__((amdgpu_waves_per_eu(a, b))): an occupancy hint, meaningless on the host */
 #define __restrict__
 
 namespace hipemu {
 struct Wave;
-struct Lane { ucontext_t ctx; dim3 tid; int lane; unsigned ncoll; bool done; Wave* wave; std::vector<char> stack; };
+struct Lane { ucontext_t ctx; dim3 tid; int lane; unsigned ncoll; bool done; Wave* wave; char* stack; };
+constexpr size_t STACK_BYTES = 256 * 1024;
+constexpr int MAX_WAVES = 16;
 struct Wave {
     Lane lanes[64]; ucontext_t sched; int index;
     float A[2][64], B[2][64]; double Dv[2][64];
+    int nlanes;
     bool want_barrier;
     pthread_barrier_t* block_barrier;
     const std::function<void()>* body;
 };
 inline thread_local Lane* g_cur = nullptr;
 inline dim3 g_grid, g_block, g_bidx;
+inline char g_dynsmem[160 * 1024] __attribute__((aligned(64)));      // the dynamic LDS segment of the running workgroup (`extern __shared__`, see build.sh)
+inline char* g_stacks = nullptr;                                      // MAX_WAVES x 64 fiber stacks, mapped once (untouched pages cost nothing)
 inline int g_force_grid = 0;      // > 0: every launch runs with this many workgroups whatever the host code asked for
 inline void yield() { Lane* l = g_cur; swapcontext(&l->ctx, &l->wave->sched); }
 inline void fiber_entry(unsigned lo, unsigned hi) {
@@ -59,17 +75,16 @@ inline void fiber_entry(unsigned lo, unsigned hi) {
     swapcontext(&l->ctx, &l->wave->sched);
 }
 inline void run_wave(Wave* W) {
-    for (int i = 0; i < 64; ++i) {
+    for (int i = 0; i < W->nlanes; ++i) {
         Lane& l = W->lanes[i];
-        l.stack.resize(256 * 1024);
         getcontext(&l.ctx);
-        l.ctx.uc_stack.ss_sp = l.stack.data(); l.ctx.uc_stack.ss_size = l.stack.size(); l.ctx.uc_link = nullptr;
+        l.ctx.uc_stack.ss_sp = l.stack; l.ctx.uc_stack.ss_size = STACK_BYTES; l.ctx.uc_link = nullptr;
         const uintptr_t p = (uintptr_t)&l;
         makecontext(&l.ctx, (void (*)())fiber_entry, 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));
     }
     for (;;) {
         int live = 0;
-        for (int i = 0; i < 64; ++i) {
+        for (int i = 0; i < W->nlanes; ++i) {
             Lane& l = W->lanes[i];
             if (l.done) continue;
             g_cur = &l;
@@ -81,25 +96,43 @@ inline void run_wave(Wave* W) {
     }
 }
 inline void run_block(dim3 block, const std::function<void()>& body) {
-    const int nw = block.x / 64;
+    const int nthreads = (int)(block.x * block.y * block.z), nw = (nthreads + 63) / 64;
+    if (nw > MAX_WAVES) { fprintf(stderr, "hipemu: workgroup of %d threads\n", nthreads); abort(); }
+    if (!g_stacks) g_stacks = (char*)mmap(nullptr, (size_t)MAX_WAVES * 64 * STACK_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     pthread_barrier_t bar; pthread_barrier_init(&bar, nullptr, nw);
-    std::vector<Wave*> waves;
+    static Wave* waves[MAX_WAVES];
     for (int w = 0; w < nw; ++w) {
-        Wave* W = new Wave(); W->index = w; W->want_barrier = false; W->block_barrier = &bar; W->body = &body;
-        for (int i = 0; i < 64; ++i) { Lane& l = W->lanes[i]; l.tid = dim3(w * 64 + i); l.lane = i; l.ncoll = 0; l.done = false; l.wave = W; }
-        waves.push_back(W);
+        if (!waves[w]) waves[w] = new Wave();
+        Wave* W = waves[w]; W->index = w; W->want_barrier = false; W->block_barrier = &bar; W->body = &body;
+        W->nlanes = std::min(64, nthreads - 64 * w);
+        for (int i = 0; i < W->nlanes; ++i) {
+            Lane& l = W->lanes[i]; const unsigned t = w * 64 + i;
+            l.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y)); l.lane = i; l.ncoll = 0; l.done = false; l.wave = W;
+            l.stack = g_stacks + (size_t)(w * 64 + i) * STACK_BYTES;
+        }
     }
-    std::vector<std::thread> th;
-    for (Wave* W : waves) th.emplace_back(run_wave, W);
-    for (auto& t : th) t.join();
-    for (Wave* W : waves) delete W;
+    if (nw == 1) run_wave(waves[0]);
+    else {
+        std::vector<std::thread> th;
+        for (int w = 0; w < nw; ++w) th.emplace_back(run_wave, waves[w]);
+        for (auto& t : th) t.join();
+    }
     pthread_barrier_destroy(&bar);
 }
+// Default: the workgroups of a launch run one after the other in this process (kernels whose workgroups do not wait for each other).  With g_force_grid > 0 a launch
+// becomes that many CONCURRENT workgroups, one forked process each (a kernel with a grid barrier; its buffers must be MAP_SHARED).
 inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
-    if (g_force_grid > 0) grid = dim3(g_force_grid);
-    if (grid.x < 1 || grid.x > 16 || block.x % 64 != 0) { fprintf(stderr, "hipemu: 1..16 workgroups of whole waves (grid %u, block %u)\n", grid.x, block.x); abort(); }
-    if (g_force_grid > 0) grid = dim3(g_force_grid);
-    g_grid = grid; g_block = block; g_bidx = dim3(0);
+    g_block = block;
+    if (g_force_grid <= 0) {
+        g_grid = grid;
+        for (unsigned z = 0; z < grid.z; ++z)
+            for (unsigned y = 0; y < grid.y; ++y)
+                for (unsigned x = 0; x < grid.x; ++x) { g_bidx = dim3(x, y, z); run_block(block, body); }
+        return;
+    }
+    grid = dim3(g_force_grid);
+    if (grid.x > 16) { fprintf(stderr, "hipemu: at most 16 concurrent workgroups (%u)\n", grid.x); abort(); }
+    g_grid = grid; g_bidx = dim3(0);
     std::vector<pid_t> kids;
     for (unsigned b = 1; b < grid.x; ++b) {
         const pid_t pid = fork();
@@ -120,6 +153,17 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
 #define gridDim (hipemu::g_grid)
 #define blockDim (hipemu::g_block)
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) hipemu::launch(grid, block, [=]() { kern(__VA_ARGS__); })
+
+template <class T> inline T hipemu_atomic_add(T* p, T v) {
+    T old, nw;
+    __atomic_load(p, &old, __ATOMIC_SEQ_CST);
+    do { nw = old + v; } while (!__atomic_compare_exchange(p, &old, &nw, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST));
+    return old;
+}
+inline float atomicAdd(float* p, float v) { return hipemu_atomic_add(p, v); }
+inline double atomicAdd(double* p, double v) { return hipemu_atomic_add(p, v); }
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 
 inline void __syncthreads() { hipemu::g_cur->wave->want_barrier = true; hipemu::yield(); }
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
@@ -145,6 +189,22 @@ inline hipemu_f4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, hipemu_f
         float s = c[v];
         for (int k = 0; k < 4; ++k) s = fmaf(W->A[buf][16 * k + i], W->B[buf][16 * k + n], s);
         c[v] = s;
+    }
+    return c;
+}
+typedef float hipemu_f16v __attribute__((ext_vector_type(16)));
+// D = A B + C with A 32 x 2 (lane 32 k + i holds A[i][k]), B 2 x 32 (lane 32 k + n holds B[k][n]), C / D 32 x 32 (lane 32 h + n, component r: row (r & 3) + 8 (r >> 2) + 4 h)
+inline hipemu_f16v __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, hipemu_f16v c, int, int, int) {
+    hipemu::Lane* l = hipemu::g_cur; hipemu::Wave* W = l->wave;
+    const int buf = l->ncoll++ & 1, ln = l->lane;
+    W->A[buf][ln] = a; W->B[buf][ln] = b;
+    hipemu::yield();
+    const int n = ln & 31, h = ln >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        float s = c[r];
+        for (int k = 0; k < 2; ++k) s = fmaf(W->A[buf][32 * k + i], W->B[buf][32 * k + n], s);
+        c[r] = s;
     }
     return c;
 }
