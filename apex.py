@@ -262,6 +262,7 @@ def td3_main(argv, async_mode=False):
     p.add_argument("--batch_size", type=int, default=256); p.add_argument("--hidden", type=int, default=256)
     p.add_argument("--n_envs", type=int, default=4096); p.add_argument("--collect_steps", type=int, default=32)
     p.add_argument("--updates_per_step", type=int, default=1); p.add_argument("--replay_size", type=int, default=1000000)
+    p.add_argument("--td3_one_launch", action="store_true", default=None, help="(td3) the update block behind a collection as ONE launch (apx_td3_updates)")
     p.add_argument("--eval_every", type=int, default=10)
     p.add_argument("--param_noise", type=bool, default=False); p.add_argument("--noise_scale", type=float, default=0.3)      # reference apex.py:143-144
     a = p.parse_args(argv)

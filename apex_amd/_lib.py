@@ -28,6 +28,24 @@ class PpoArgs(C.Structure):
     ]
 
 
+class Td3Args(C.Structure):
+    """struct apx_td3_args (include/apx.h)."""
+    _fields_ = [
+        ("actor", c_ptr), ("actor_t", c_ptr), ("actor_m", c_ptr), ("actor_v", c_ptr),
+        ("critic", c_ptr), ("critic_t", c_ptr), ("critic_m", c_ptr), ("critic_v", c_ptr),
+        ("D", C.c_int), ("H", C.c_int), ("A", C.c_int),
+        ("state", c_ptr), ("next_state", c_ptr), ("action", c_ptr), ("reward", c_ptr), ("notdone", c_ptr),
+        ("ind", c_ptr), ("noise", c_ptr),
+        ("B", C.c_int64), ("U", C.c_int64),
+        ("it0", C.c_int), ("policy_freq", C.c_int),
+        ("max_action", C.c_float), ("noise_clip", C.c_float), ("discount", C.c_float), ("tau", C.c_float),
+        ("a_lr", C.c_float), ("c_lr", C.c_float), ("adam_eps", C.c_float),
+        ("t_a", C.c_int), ("t_c", C.c_int),
+        ("workspace", c_ptr), ("workspace_bytes", C.c_size_t),
+        ("stats_out", c_ptr),
+    ]
+
+
 class EnvCfg(C.Structure):
     """struct apx_env_cfg (include/apx.h)."""
     _fields_ = [
@@ -69,6 +87,9 @@ SIGNATURES = {
     "apx_ppo_epoch_supported": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int]),
     "apx_ppo_epoch_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "apx_ppo_epoch": (C.c_int, [C.POINTER(PpoArgs), c_ptr, C.c_int64, c_ptr]),
+    "apx_td3_updates_supported": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "apx_td3_updates_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "apx_td3_updates": (C.c_int, [C.POINTER(Td3Args), c_ptr]),
     "apx_clip_adam": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int, c_ptr, c_ptr]),
     "apx_env_default_cfg": (None, [C.POINTER(EnvCfg)]),

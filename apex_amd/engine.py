@@ -462,6 +462,35 @@ class TD3Learner:
         """FF_Actor.forward: max_action * tanh(network_out(...))."""
         return self.max_action * torch.tanh(self.actor.forward(state))
 
+    def updates_supported(self, batch):
+        return bool(_lib.load().apx_td3_updates_supported(int(batch), self.D, self.H, self.A))
+
+    def updates(self, state, next_state, action, reward, notdone, ind, noise, it0, discount=0.99, tau=0.005, noise_clip=0.5, policy_freq=2):
+        """U = ind.shape[0] iterations of TD3.train's loop body (sync_td3.py:133-209) as ONE launch (apx_td3_updates): update u works on the replay rows ind[u] [B] of
+        (state, next_state, action, reward, notdone) with the smoothing noise noise[u] [B, A] ~ N(0, policy_noise) (clamped inside) and iteration counter it0 + u.
+        Returns the [U, 4] f64 device tensor (critic loss, sum q1, sum q2, actor loss or 0) - no host sync."""
+        lib = _lib.load()
+        U, B = ind.shape
+        assert ind.dtype == torch.int64 and ind.is_contiguous() and noise.is_contiguous() and tuple(noise.shape) == (U, B, self.A)
+        for t in (state, next_state, action, reward, notdone):
+            assert t.is_contiguous() and t.dtype == torch.float32
+        need = int(lib.apx_td3_updates_workspace_bytes(B, U, self.D, self.H, self.A))
+        if need == 0:
+            raise _lib.ApxError("apx_td3_updates does not serve batch %d of a %d+%d-%d network" % (B, self.D, self.A, self.H))
+        if getattr(self, "_uws", None) is None or self._uws.numel() < need:
+            self._uws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        stats = torch.empty(U, 4, dtype=torch.float64, device=self.device)
+        a = _lib.Td3Args(actor=_p(self.actor.params), actor_t=_p(self.actor_t.params), actor_m=_p(self.a_m), actor_v=_p(self.a_v),
+                         critic=_p(self.critic_flat), critic_t=_p(self.critic_t_flat), critic_m=_p(self.c_m), critic_v=_p(self.c_v),
+                         D=self.D, H=self.H, A=self.A, state=_p(state), next_state=_p(next_state), action=_p(action), reward=_p(reward), notdone=_p(notdone),
+                         ind=_p(ind), noise=_p(noise), B=B, U=U, it0=int(it0), policy_freq=int(policy_freq), max_action=self.max_action, noise_clip=float(noise_clip),
+                         discount=float(discount), tau=float(tau), a_lr=self.a_lr, c_lr=self.c_lr, adam_eps=1e-8, t_a=self.t_a, t_c=self.t_c,
+                         workspace=_p(self._uws), workspace_bytes=self._uws.numel(), stats_out=_p(stats))
+        check(lib.apx_td3_updates(C.byref(a), _stream()))
+        self.t_c += U
+        self.t_a += sum(1 for u in range(U) if (int(it0) + u) % int(policy_freq) == 0)
+        return stats
+
     def train_step(self, state, action, next_state, reward, notdone, noise, it, discount=0.99, tau=0.005, noise_clip=0.5, policy_freq=2):
         """One iteration of TD3.train's loop on a sampled batch; noise [B, A] ~ N(0, policy_noise) (clamped inside).  Returns
         (critic loss, mean q1, mean q2, actor loss or None) as host floats only when asked via .item() by the caller: device tensors."""

@@ -41,7 +41,7 @@ class HbmReplay:
 
 class TD3:
     def __init__(self, env, save_path, hidden=256, a_lr=1e-3, c_lr=1e-3, discount=0.99, tau=0.005, policy_noise=0.2, noise_clip=0.5, policy_freq=2,
-                 act_noise=0.3, batch_size=256, updates_per_step=1, replay_size=1_000_000, seed=0, param_noise=False, noise_scale=0.3):
+                 act_noise=0.3, batch_size=256, updates_per_step=1, replay_size=1_000_000, seed=0, param_noise=False, noise_scale=0.3, one_launch_updates=None):
         self.env, self.save_path, self.device, self.N = env, save_path, env.device, env.n_envs
         if getattr(env, "obs_dim", 50) != 50:
             raise NotImplementedError("TD3 is built for the 50-entry observation (command_profile=clock, history 0); this env produces %d entries" % getattr(env, "obs_dim", 50))
@@ -51,6 +51,8 @@ class TD3:
         self.act_noise, self.batch_size, self.updates_per_step, self.hidden = act_noise, batch_size, updates_per_step, hidden
         self.gen = torch.Generator(device=self.device); self.gen.manual_seed(int(seed) * 1000003 + 17)
         self.it = 0; self.total_steps = 0; self.obs = None
+        # the update block behind a one-launch collection as ONE launch as well (apx_td3_updates, td3_small.hip); on request until it has run on hardware
+        self.one_launch_updates = bool(one_launch_updates) if one_launch_updates is not None else os.environ.get("APX_TD3_UPDATES", "0") == "1"
         # parameter-space exploration noise (rl/utils/param_noise.py AdaptiveParamNoiseSpec; TD3.perturb_actor_parameters, sync_td3.py:113-121).
         # The reference's synchronous loop builds the spec (initial 0.05, desired action stddev = --noise_scale, coefficient 1.05,
         # sync_td3.py:286) but never passes it to the collectors; here --param_noise wires it the way the asynchronous variant does: collect
@@ -123,9 +125,18 @@ class TD3:
                 ended = g["done"][t] != 0
                 self.replay.add(g["obs"][t], torch.where(ended.view(-1, 1), g["fin"][t], nxt), g["act"][t], g["rew"][t], (~ended).float())
             self.obs = g["nxt"].clone()
-            for _ in range(T * self.updates_per_step):
-                if self.replay.size < self.batch_size:
-                    break
+            n_todo = T * self.updates_per_step if self.replay.size >= self.batch_size else 0
+            if n_todo and self.one_launch_updates and L.updates_supported(self.batch_size):
+                # the whole update block as ONE launch (apx_td3_updates): the replay rows and the smoothing noise of every update are drawn up front (same distributions,
+                # one draw each for the block instead of one per update), the kernel gathers the rows out of the replay tensors itself
+                U, Bz = n_todo, self.batch_size
+                ind = torch.randint(0, self.replay.size, (U, Bz), device=self.device, generator=self.gen)
+                pn = torch.randn(U, Bz, 10, device=self.device, generator=self.gen) * self.policy_noise
+                R = self.replay
+                st = L.updates(R.s, R.s2, R.a, R.r, R.nd, ind, pn, self.it, self.discount, self.tau, self.noise_clip, self.policy_freq)
+                stats += st[:, :3].sum(0); n_upd += U; self.it += U
+                n_todo = 0
+            for _ in range(n_todo):
                 s_, sn, ac, r, nd = self.replay.sample(self.batch_size, self.gen)
                 pn = torch.randn(self.batch_size, 10, device=self.device, generator=self.gen) * self.policy_noise
                 st, _ = L.train_step(s_, ac, sn, r, nd, pn, self.it, self.discount, self.tau, self.noise_clip, self.policy_freq)
@@ -294,7 +305,7 @@ def run_experiment(args):
     algo = TD3(env, logger.dir, hidden=args.hidden, a_lr=args.a_lr, c_lr=args.c_lr, discount=args.discount, tau=args.tau, policy_noise=args.policy_noise,
                noise_clip=args.noise_clip, policy_freq=args.policy_freq, act_noise=args.act_noise, batch_size=args.batch_size,
                updates_per_step=args.updates_per_step, replay_size=args.replay_size, seed=args.seed, param_noise=getattr(args, "param_noise", False),
-               noise_scale=getattr(args, "noise_scale", 0.3))
+               noise_scale=getattr(args, "noise_scale", 0.3), one_launch_updates=getattr(args, "td3_one_launch", None))
     algo.init_networks(args.seed)
     updates = 0
     ret, eplen = algo.evaluate()

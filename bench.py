@@ -158,7 +158,7 @@ def main_td3(a):
     from apex_amd.td3 import TD3
     n_envs, T, upd, bs = 4096, 32, 4, 1024
     env = CassieVecEnv(n_envs=n_envs, seed=0)
-    algo = TD3(env, "/tmp/apx_bench_unused", batch_size=bs, updates_per_step=upd, replay_size=1_000_000, seed=0)
+    algo = TD3(env, "/tmp/apx_bench_unused", batch_size=bs, updates_per_step=upd, replay_size=1_000_000, seed=0, one_launch_updates=a.td3_one_launch)
     algo.init_networks(0)
     run = (lambda: algo.collect_and_train_async(T, load_freq=10)) if a.td3_async else (lambda: algo.collect_and_train(T))      # --td3_async: rl/algos/async_td3.py's decoupled form
     for _ in range(a.warmup):
@@ -173,7 +173,8 @@ def main_td3(a):
                       "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                       "config": {"workload": "Cassie-v0 TD3, 1M-transition replay buffer in HBM, twin-critic update in HIP (BASELINE.json configs[4])",
                                  "envs_per_gpu": n_envs, "collect_steps": T, "updates_per_env_step": upd, "batch_size": bs, "replay_capacity": 1000000,
-                                 "mode": "async (behaviour copy re-loaded every 10 lock steps, rl/algos/async_td3.py)" if a.td3_async else "sync (rl/algos/sync_td3.py)"},
+                                 "mode": "async (behaviour copy re-loaded every 10 lock steps, rl/algos/async_td3.py)" if a.td3_async else "sync (rl/algos/sync_td3.py)",
+                                 "update_block_as_one_launch": bool(a.td3_one_launch and not a.td3_async)},
                       "updates_per_s": round(a.steps * T * upd / dt, 1), "replay_size": int(algo.replay.size)}))
 
 
@@ -245,6 +246,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--epoch_kernel", action="store_true", help="cassie_ppo, one GPU, --minibatch <= 256: an epoch's optimiser steps as ONE launch (apx_ppo_epoch) instead of 16 launches per step")
+    ap.add_argument("--td3_one_launch", action="store_true", help="cassie_td3 workload only (synchronous form): the update block behind a collection as ONE launch (apx_td3_updates) instead of ~60 launches per update")
     ap.add_argument("--td3_async", action="store_true", help="cassie_td3 workload only: the asynchronous variant (collection and updates on two streams)")
     ap.add_argument("--workload", default="cassie_ppo", choices=["cassie_ppo", "cassietraj_recurrent", "cassie_td3"],
                     help="cassie_ppo = BASELINE.json configs[1] (the headline, default); cassietraj_recurrent = configs[3]: CassieTraj-v0, LSTM 2x128, 2048 envs/GPU; cassie_td3 = configs[4]: TD3, 1M-transition replay in HBM")

@@ -186,6 +186,31 @@ int apx_ppo_minibatch(const apx_ppo_args* args, void* stream);
 int apx_ppo_epoch_supported(int64_t mb, int D, int H, int A);
 size_t apx_ppo_epoch_workspace_bytes(int64_t mb, int64_t nb, int D, int H, int A);
 int apx_ppo_epoch(const apx_ppo_args* args, const int64_t* perm, int64_t nb, void* stream);
+/* A block of TD3 updates in one launch: `iterations` passes of the loop body of TD3.train (rl/algos/sync_td3.py:133-209, the same body in async_td3.py) - sample a batch,
+ * target-policy smoothing (:148-154), clipped double-Q target (:156-159), both critic regressions + Adam (:161-172), every policy_freq-th iteration the actor step on
+ * -Q1(s, pi(s)) (:175-186) and the Polyak averaging of both targets (:188-202).  The batches are rows `ind` [U, B] int64 [dev] of the replay tensors (the reference
+ * draws them with np.random.randint inside the loop, rl/utils/remote_replay.py:78-90), the smoothing noise `noise` [U, B, A] ~ N(0, policy_noise) [dev] is clamped to
+ * +-noise_clip here.  critic / critic_t / critic_m / critic_v: Dual_Q_Critic's two networks as one flat block (q1 then q2, apx_mlp_param_count(D + A, 256, 1) floats
+ * each).  it0 = the iteration counter of the first update (the actor step runs when it % policy_freq == 0), t_a / t_c = Adam steps already taken by the two
+ * optimisers.  stats_out [U, 4] f64 [dev]: critic loss, sum q1, sum q2, actor loss (0 without the actor step) of every update.  Adam as torch.optim.Adam (no clipping).
+ * apx_td3_updates_supported: H = 256, 48 <= D, D + A <= 64, A <= 12, B a multiple of 16 in 16..4096; parameter blocks and workspace 16-byte aligned. */
+typedef struct apx_td3_args {
+    float* actor; float* actor_t; float* actor_m; float* actor_v;
+    float* critic; float* critic_t; float* critic_m; float* critic_v;
+    int D, H, A;
+    const float* state; const float* next_state; const float* action; const float* reward; const float* notdone;   /* replay buffer [cap, .] */
+    const int64_t* ind; const float* noise;
+    int64_t B, U;
+    int it0, policy_freq;
+    float max_action, noise_clip, discount, tau, a_lr, c_lr, adam_eps;
+    int t_a, t_c;
+    void* workspace; size_t workspace_bytes;
+    double* stats_out;
+} apx_td3_args;
+int apx_td3_updates_supported(int64_t B, int D, int H, int A);
+size_t apx_td3_updates_workspace_bytes(int64_t B, int64_t U, int D, int H, int A);
+int apx_td3_updates(const apx_td3_args* args, void* stream);
+
 /* second half when grad_only=1 was used: global-norm clip (clip_grad_norm_, ppo.py:326,335) + Adam (ppo.py:355-356)
  * on an (all-reduced) gradient; scale multiplies the gradient first (1/world_size for an averaged sum). */
 int apx_clip_adam(float* param, float* m, float* v, float* grad, int64_t n, float grad_scale, float grad_clip,

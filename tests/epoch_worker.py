@@ -5,6 +5,8 @@ every check passed.
     python tests/epoch_worker.py golden      apx_ppo_epoch against the reference's own per-step outputs (tests/golden/g4b_epoch_h256.npz, inputs from seeds)
     python tests/epoch_worker.py twin        apx_ppo_epoch against the per-step apx_ppo_minibatch loop: 48 steps of minibatch 64 with mirror loss, reruns bit-identical
     python tests/epoch_worker.py ppo         PPO.update with epoch_kernel on / off on the same rollout of the HIP env (the wiring of apex_amd/ppo.py)
+    python tests/epoch_worker.py td3_golden  apx_td3_updates (td3_small.hip, the same kind of kernel for TD3's update block) against the reference's TD3.train outputs (G20b)
+    python tests/epoch_worker.py td3_twin    apx_td3_updates against the per-launch TD3Learner.train_step loop: batch 128 and batch 1024, random replay rows
 """
 import json
 import os
@@ -132,8 +134,27 @@ def ppo(dev):
         report("ppo actor parameters", float(d.max()) <= 5e-4 and float((d > 5e-6).float().mean()) <= 5e-3, max=float(d.max()))
 
 
+def td3_golden(dev):
+    from tests import test_gpu_learner as G
+    try:
+        G._run_g20(dev, os.path.join(REPO, "tests", "golden"), "g20b_td3_h256.npz", one_launch=True)
+        report("td3 one-launch updates vs G20b", True)
+    except AssertionError as e:
+        report("td3 one-launch updates vs G20b", False, detail=str(e)[:2000])
+
+
+def td3_twin(dev):
+    from tests import test_gpu_learner as G
+    for B, U in ((128, 6), (1024, 8)):
+        try:
+            G._td3_twin(dev, B=B, U=U, cap=5000)
+            report("td3 one launch == per-launch loop, batch %d" % B, True)
+        except AssertionError as e:
+            report("td3 one launch == per-launch loop, batch %d" % B, False, detail=str(e)[:2000])
+
+
 if __name__ == "__main__":
     assert torch.cuda.is_available(), "needs a GPU"
     dev = torch.device("cuda:0")
-    {"golden": golden, "twin": twin, "ppo": ppo}[sys.argv[1]](dev)
+    {"golden": golden, "twin": twin, "ppo": ppo, "td3_golden": td3_golden, "td3_twin": td3_twin}[sys.argv[1]](dev)
     sys.exit(1 if FAILED else 0)

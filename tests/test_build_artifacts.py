@@ -157,3 +157,21 @@ def test_epoch_kernel_fences_and_operand_batches(code_objects):
     batched = [i for i in range(len(runs) - 1) if runs[i] == ("global_load_dwordx4", 32) and runs[i + 1][0] == "mfma"]
     assert len(batched) >= 1, runs      # phase B: both operands contiguous in K
     assert sum(n for k, n in runs if k == "mfma") >= 200
+
+
+def test_td3_updates_kernel_fences_and_no_scratch(code_objects):
+    """td3_small_kernel (apx_td3_updates): the same grid barrier as the epoch kernel - agent-scope write-back before the arrival, invalidate after the wait - on each of
+    its 19 barrier sites, MFMA tiles present, no scratch instruction."""
+    for co in code_objects:
+        asm = subprocess.run([os.path.join(BIN, "llvm-objdump"), "-d", "--mcpu=gfx950", co], capture_output=True, text=True).stdout
+        if "td3_small_kernel" in asm:
+            break
+    else:
+        pytest.fail("td3_small_kernel not in libapx.so")
+    body = [b for b in re.split(r"\n(?=[0-9a-f]+ <)", asm) if re.match(r"[0-9a-f]+ <\S*td3_small_kernel", b)][0]
+    ins = [ln.split()[0] + " " + " ".join(ln.split("//")[0].split()[1:]) for ln in body.split("\n")[1:] if "//" in ln]
+    assert sum(1 for i in ins if i.startswith("buffer_wbl2") and "sc1" in i) >= 15
+    assert sum(1 for i in ins if i.startswith("buffer_inv") and "sc1" in i) >= 15
+    assert sum(1 for i in ins if i.startswith("global_atomic_add")) >= 15
+    assert sum(1 for i in ins if i.startswith("v_mfma_f32_16x16x4")) >= 300
+    assert not any(i.startswith("scratch_") for i in ins)

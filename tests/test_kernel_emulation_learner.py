@@ -23,8 +23,8 @@ def emulated_library():
     """build (when stale) and load tools/hipemu/_build/libapx_emul.so with the signatures of apex_amd/_lib.py for the symbols it has (the learner half)"""
     from apex_amd import _lib
     so = os.path.join(EMU, "_build", "libapx_emul.so")
-    srcs = [os.path.join(EMU, f) for f in ("emul_ppo_small.cpp", "emul_learner.cpp", "build.sh", os.path.join("hip", "hip_runtime.h"))] + \
-           [os.path.join(REPO, "apex_amd", "csrc", f) for f in ("ppo_small.hip", "learner.hip", "apx_common.h")] + [os.path.join(REPO, "include", "apx.h")]
+    srcs = [os.path.join(EMU, f) for f in ("emul_ppo_small.cpp", "emul_learner.cpp", "emul_td3_small.cpp", "build.sh", os.path.join("hip", "hip_runtime.h"))] + \
+           [os.path.join(REPO, "apex_amd", "csrc", f) for f in ("ppo_small.hip", "td3_small.hip", "mlp_tiles.h", "learner.hip", "apx_common.h")] + [os.path.join(REPO, "include", "apx.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["bash", os.path.join(EMU, "build.sh")])
     lib = C.CDLL(so)
@@ -117,3 +117,34 @@ def test_emulated_fused_recurrent_step_and_gather(dev):
     G = _gpu_tests()
     G.test_fused_recurrent_step_equals_the_per_launch_chain(dev)
     G.test_rec_gather_equals_the_torch_assembly(dev)
+
+
+@pytest.mark.parametrize("wgs", [1, 3])
+def test_emulated_td3_updates_one_launch_g20b(dev, golden_dir, wgs):
+    """apx_td3_updates (td3_small.hip: the block of updates as one persistent launch) against the reference's TD3.train outputs of G20b: four iterations at batch 64
+    on the 256-unit networks, two of them with the actor step and the Polyak averages.  With 1 and with 3 workgroups (forked processes: everything a workgroup
+    writes - parameters, Adam moments, workspace - is moved to shared memory first; the statistics are written by workgroup 0 = this process)."""
+    from apex_amd import _lib
+
+    def share(L):
+        for x in (L.actor.params, L.actor_t.params, L.critic_flat, L.critic_t_flat, L.a_m, L.a_v, L.c_m, L.c_v):
+            x.share_memory_()
+        L._uws = torch.zeros(int(_lib.load().apx_td3_updates_workspace_bytes(64, 4, 50, 256, 10)), dtype=torch.uint8).share_memory_()
+    _lib.load().apx_emul_set_workgroups(wgs)
+    try:
+        _gpu_tests()._run_g20(dev, golden_dir, "g20b_td3_h256.npz", one_launch=True, prepare=share)
+    finally:
+        _lib.load().apx_emul_set_workgroups(0)
+
+
+def test_emulated_td3_updates_twin_of_the_per_launch_path(dev):
+    """batch 128, six updates from iteration 3 (three with the actor step), random replay rows: one launch against the per-launch loop, both on the emulated sources"""
+    from apex_amd import _lib
+    lib = _lib.load()
+
+    def one_wg(L, B, U):
+        lib.apx_emul_set_workgroups(1)
+    try:
+        _gpu_tests()._td3_twin(dev, prepare=one_wg)
+    finally:
+        lib.apx_emul_set_workgroups(0)

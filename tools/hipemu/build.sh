@@ -9,6 +9,7 @@ grep -q 'hipemu::g_dynsmem' _build/learner_emul.hip
 FLAGS="-x c++ -std=c++17 -O2 -fPIC -pthread -I. -I../../apex_amd/csrc -I../../include -Wno-unused-function -Wno-unused-variable -Wno-unknown-attributes -Wno-ignored-attributes"
 $CXX $FLAGS -c emul_ppo_small.cpp -o _build/emul_ppo_small.o &
 $CXX $FLAGS -c emul_learner.cpp -o _build/emul_learner.o &
+$CXX $FLAGS -c emul_td3_small.cpp -o _build/emul_td3_small.o &
 wait
-$CXX -shared -pthread _build/emul_ppo_small.o _build/emul_learner.o -o _build/libapx_emul.so
+$CXX -shared -pthread _build/emul_ppo_small.o _build/emul_learner.o _build/emul_td3_small.o -o _build/libapx_emul.so
 echo built tools/hipemu/_build/libapx_emul.so
