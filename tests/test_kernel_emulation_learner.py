@@ -148,3 +148,58 @@ def test_emulated_td3_updates_twin_of_the_per_launch_path(dev):
         _gpu_tests()._td3_twin(dev, prepare=one_wg)
     finally:
         lib.apx_emul_set_workgroups(0)
+
+
+class _GridOnlyEnv:
+    """what PPO's constructor and update() read from an env (no stepping here: the rollout grids are filled by hand)"""
+    n_envs, obs_dim, history = 64, 50, 0
+
+    def __init__(self, device):
+        self.device = device
+
+
+def test_emulated_ppo_update_with_and_without_the_epoch_kernel(dev):
+    """apex_amd/ppo.py::PPO.update (advantage normalisation, sample order, epoch means, last-minibatch KL, trace) on hand-filled rollout grids of 64 envs x 8 steps,
+    minibatch 64, 2 epochs: the per-step launches against apx_ppo_epoch - the wiring the GPU worker's `ppo` mode checks on the real env."""
+    from apex_amd import _lib
+    from apex_amd.ppo import PPO
+    from golden_util import epoch_case_inputs
+    inp = epoch_case_inputs(0)
+    rs = np.random.RandomState(3)
+    res = []
+    for ek in (False, True):
+        args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=64, epochs=2, num_steps=8 * 64, max_traj_len=400,
+                    max_grad_norm=0.05, mirror=True, std_dev=-1.5, seed=0, epoch_kernel=ek, prepare_resets=False)
+        algo = PPO(args, "/tmp/apx_test_unused", _GridOnlyEnv(dev), rank=0, world_size=1, group=None)
+        L = algo.learner
+        L.actor.load_list(inp["actor"]); L.critic.load_list(inp["critic"])
+        L.obs_mean.copy_(torch.tensor(inp["obs_mean"])); L.obs_std.copy_(torch.tensor(inp["obs_std"]))
+        T, N = algo.T, algo.N
+        assert (T, N) == (8, 64)
+        r2 = np.random.RandomState(4)
+        obs = r2.randn(T, N, 50).astype(np.float32); ph = r2.rand(T, N) * 2 * np.pi
+        obs[..., 46] = np.sin(ph); obs[..., 47] = np.cos(ph)
+        algo.b_obs.copy_(torch.tensor(obs))
+        old = __import__("apex_amd.engine", fromlist=["Mlp"]).Mlp(50, 256, 10, dev); old.load_list(inp["old"])
+        algo.b_mu.copy_(old.forward(algo.b_obs.view(T * N, 50), L.obs_mean, L.obs_std).view(T, N, 10))
+        algo.b_act.copy_(algo.b_mu + torch.tensor(r2.randn(T, N, 10).astype(np.float32)) * algo.fixed_std)
+        algo.b_val.copy_(torch.tensor(r2.randn(T, N).astype(np.float32)))
+        ret = torch.tensor(r2.randn(T, N).astype(np.float32))
+        perms = [torch.tensor(rs.permutation(T * N).astype(np.int64)) for _ in range(2)] if not res else res[0][4]
+        algo.perm_fn = lambda epoch, perms=perms: perms[epoch]
+        algo.trace = []
+        if ek:
+            _lib.load().apx_emul_set_workgroups(1)
+        try:
+            losses, kl, epochs_run = algo.update(ret)
+        finally:
+            _lib.load().apx_emul_set_workgroups(0)
+        res.append((losses, kl, epochs_run, torch.stack(algo.trace).numpy(), perms, L.actor.params.clone(), L.critic.params.clone(), L.t))
+    (l0, k0, e0, t0, _, a0, c0, n0), (l1, k1, e1, t1, _, a1, c1, n1) = res
+    assert e0 == e1 == 2 and n0 == n1 == 16 and t0.shape == t1.shape == (16, 6)
+    np.testing.assert_allclose(t1, t0, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(l1, l0, rtol=1e-4, atol=1e-6)
+    assert abs(k1 - k0) <= 1e-4 * abs(k0) + 1e-7
+    for x, y in ((a0, a1), (c0, c1)):
+        d = (x - y).abs()
+        assert float(d.max()) <= 5e-4 and float((d > 5e-6).float().mean()) <= 5e-3, (float(d.max()), float((d > 5e-6).float().mean()))
