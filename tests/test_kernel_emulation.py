@@ -133,3 +133,17 @@ def test_guard_pages_fault_on_an_overrun():
             % (REPO, os.path.join(REPO, "tests")))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.stdout.strip() == "0.0" and r.returncode == -11, (r.returncode, r.stdout, r.stderr[-300:])
+
+
+def test_epoch_kernel_reruns_with_three_workgroups_are_bit_identical(emu):
+    """Three concurrent workgroups (processes the OS schedules as it likes), the same epoch three times: parameters, Adam moments and scalars must be bit-identical -
+    a phase that reads what another workgroup is still writing (a missing barrier) shows up here as run-to-run noise; the fixed-order partial sums make the exact
+    comparison legitimate."""
+    outs = []
+    for rep in range(3):
+        inp, scal, bufs = _run_case(emu, 2, 3)
+        outs.append((scal.copy(), {k: v.copy() for k, v in bufs.items()}))
+    for scal, bufs in outs[1:]:
+        assert np.array_equal(scal, outs[0][0])
+        for k in bufs:
+            assert np.array_equal(bufs[k], outs[0][1][k]), k

@@ -22,6 +22,15 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 def emulated_library():
     """build (when stale) and load tools/hipemu/_build/libapx_emul.so with the signatures of apex_amd/_lib.py for the symbols it has (the learner half)"""
     from apex_amd import _lib
+    if os.environ.get("APX_EMUL_LIB"):      # tools/hipemu/asan.sh: the AddressSanitizer build of the same sources
+        so = os.environ["APX_EMUL_LIB"]
+        lib = C.CDLL(so)
+        for name, (res, args) in _lib.SIGNATURES.items():
+            if hasattr(lib, name):
+                fn = getattr(lib, name); fn.restype = res; fn.argtypes = args
+        lib.apx_emul_last_error.restype = C.c_char_p
+        lib.apx_last_error = lib.apx_emul_last_error
+        return lib
     so = os.path.join(EMU, "_build", "libapx_emul.so")
     srcs = [os.path.join(EMU, f) for f in ("emul_ppo_small.cpp", "emul_learner.cpp", "emul_td3_small.cpp", "build.sh", os.path.join("hip", "hip_runtime.h"))] + \
            [os.path.join(REPO, "apex_amd", "csrc", f) for f in ("ppo_small.hip", "td3_small.hip", "mlp_tiles.h", "learner.hip", "apx_common.h")] + [os.path.join(REPO, "include", "apx.h")]
