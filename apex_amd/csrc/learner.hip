@@ -1668,16 +1668,17 @@ struct PpoWs {
     PpoWs(void* base, long mb, int D, int H, int A) {
         char* p = (char*)base;
         size_t off = 0;
-        auto take = [&](size_t nfloat) { float* r = (float*)(p + off); off += align_up(nfloat * sizeof(float)); return r; };
+        auto take = [&](size_t nfloat) { float* r = (float*)((uintptr_t)p + off);      /* (integer arithmetic: the size query runs this with a NULL base) */ off += align_up(nfloat * sizeof(float)); return r; };
         // the actor's two grad-carrying instances pi(s) and pi(M_s s) share the weights: their rows are ADJACENT ([2 mb, .] blocks: first s, then M_s s), so that
         // the forward is one 2 mb-row launch and the backward one chain of five GEMMs over 2 mb rows instead of two chains
-        xn = take(2 * mb * D); xm = xn + mb * D; xr = take(mb * D);
-        a1 = take(2 * mb * H); m1 = a1 + mb * H; a2 = take(2 * mb * H); m2 = a2 + mb * H; c1 = take(mb * H); c2 = take(mb * H);
-        mu = take(2 * mb * A); mum = mu + mb * A; v = take(mb);
-        dmu = take(2 * mb * A); dmum = dmu + mb * A; dv = take(mb);
+        auto second = [](float* q, size_t nfloat) { return (float*)((uintptr_t)q + nfloat * sizeof(float)); };      // the M_s s half of a [2 mb, .] block
+        xn = take(2 * mb * D); xm = second(xn, mb * D); xr = take(mb * D);
+        a1 = take(2 * mb * H); m1 = second(a1, mb * H); a2 = take(2 * mb * H); m2 = second(a2, mb * H); c1 = take(mb * H); c2 = take(mb * H);
+        mu = take(2 * mb * A); mum = second(mu, mb * A); v = take(mb);
+        dmu = take(2 * mb * A); dmum = second(dmu, mb * A); dv = take(mb);
         dh2 = take(2 * mb * H); dh1 = take(2 * mb * H);
         parts = take(6 * GRAD_PART_FLOATS);      // K-chunk slabs of the six weight gradients of a minibatch (linear_bwd_weight)
-        acc = (double*)(p + off); off += align_up(16 * sizeof(double));
+        acc = (double*)((uintptr_t)p + off); off += align_up(16 * sizeof(double));
         bytes = off;
     }
 };

@@ -389,7 +389,7 @@ struct EpochWs {
     size_t bytes;
     EpochWs(void* base, long mb, long nb, bool mirror) {
         char* p = (char*)base; size_t off = 0;
-        auto take = [&](size_t nbytes) { char* r = p + off; off += up64(nbytes); return r; };
+        auto take = [&](size_t nbytes) { char* r = (char*)((uintptr_t)p + off); off += up64(nbytes); return r;      /* (integer arithmetic: the size query runs this with a NULL base) */ };
         const long R[2] = {rpad(mirror ? 2 * mb : mb), rpad(mb)};
         for (int i = 0; i < 2; ++i) {
             X[i] = (float*)take(R[i] * SXP * 4);

@@ -385,7 +385,7 @@ struct Td3Ws {
     size_t bytes;
     Td3Ws(void* base, long B, long U) {
         char* p = (char*)base; size_t off = 0;
-        auto take = [&](size_t nbytes) { char* r = p + off; off += tup64(nbytes); return (float*)r; };
+        auto take = [&](size_t nbytes) { char* r = (char*)((uintptr_t)p + off); off += tup64(nbytes); return (float*)r;      /* (integer arithmetic: the size query runs this with a NULL base) */ };
         const long R = trpad(B);
         for (int i = 0; i < 5; ++i) X[i] = take(R * TXP * 4);      // inputs of AT, (Q1T, Q2T), (Q1, Q2), PA, QA
         for (int i = 0; i < NPASS; ++i) {

@@ -2,16 +2,24 @@
 # Memory-safety pass over the learner-side kernel sources: the host emulation (build.sh) compiled with AddressSanitizer, the emulated test suites run with the ASan runtime
 # preloaded, so that every read / write of a kernel beyond a tensor it was handed (torch's CPU allocations carry redzones then) aborts the run.  Fibers (ucontext) and ASan
 # coexist with detect_stack_use_after_return=0.   usage: bash tools/hipemu/asan.sh [pytest -k expression]   -> exit code of pytest
+# SAN=ubsan bash tools/hipemu/asan.sh: the same with UndefinedBehaviorSanitizer (misaligned vector loads, indices beyond a static = LDS array, shifts, overflow, NULL arithmetic).
 set -e
 cd "$(dirname "$0")"
 CXX=${CXX:-/opt/rocm/lib/llvm/bin/clang++}
-RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
-mkdir -p _build/asan
+SAN=${SAN:-asan}
+if [ "$SAN" = ubsan ]; then
+    RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.ubsan_standalone-x86_64.so | head -1)
+    SANFLAGS="-fsanitize=undefined -fno-sanitize=vptr,function -fno-sanitize-recover=undefined"; LINKFLAGS="-fsanitize=undefined"
+else
+    RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+    SANFLAGS="-fsanitize=address -shared-libsan -fno-omit-frame-pointer"; LINKFLAGS="-fsanitize=address -shared-libsan"
+fi
+mkdir -p _build/$SAN
 sed 's|extern __shared__ float fls\[\];|float* fls = (float*)hipemu::g_dynsmem;|' ../../apex_amd/csrc/learner.hip > _build/learner_emul.hip
-FLAGS="-x c++ -std=c++17 -O1 -g -fPIC -pthread -fsanitize=address -shared-libsan -fno-omit-frame-pointer -I. -I../../apex_amd/csrc -I../../include -Wno-unused-function -Wno-unused-variable -Wno-unknown-attributes -Wno-ignored-attributes"
-for f in emul_ppo_small emul_learner emul_td3_small; do $CXX $FLAGS -c $f.cpp -o _build/asan/$f.o 2> /dev/null & done
+FLAGS="-x c++ -std=c++17 -O1 -g -fPIC -pthread $SANFLAGS -I. -I../../apex_amd/csrc -I../../include -Wno-unused-function -Wno-unused-variable -Wno-unknown-attributes -Wno-ignored-attributes"
+for f in emul_ppo_small emul_learner emul_td3_small; do $CXX $FLAGS -c $f.cpp -o _build/$SAN/$f.o 2> /dev/null & done
 wait
-$CXX -shared -pthread -fsanitize=address -shared-libsan _build/asan/*.o -o _build/libapx_emul_asan.so
+$CXX -shared -pthread $LINKFLAGS _build/$SAN/*.o -o _build/libapx_emul_$SAN.so
 cd ../..
-LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 APX_EMUL_LIB=$PWD/tools/hipemu/_build/libapx_emul_asan.so \
+LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 APX_EMUL_LIB=$PWD/tools/hipemu/_build/libapx_emul_$SAN.so \
     python -m pytest tests/test_kernel_emulation_learner.py -q ${1:+-k "$1"}
