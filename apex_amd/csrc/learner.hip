@@ -339,10 +339,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_128_kernel(GemmArgs g) {
         }
 }
 static bool gemm128_ok(int epi, const GemmArgs& g, int kchunk) {
-    static const bool off = getenv("APX_GEMM128") && atoi(getenv("APX_GEMM128")) == 0;
+    static const int knob = getenv("APX_GEMM128") ? atoi(getenv("APX_GEMM128")) : 1;      // 0: never; 2: whenever the shape allows it (tests: the 128-tile kernel on small problems)
+    const bool off = knob == 0;
     if (off || !(epi == EPI_STORE || epi == EPI_MASK || epi == EPI_PARTIAL || epi == EPI_BIAS)) return false;
     if (g.M % G2M || g.N % G2N || g.K % GBK || kchunk % GBK || g.K < 64) return false;
-    if (epi != EPI_PARTIAL && (long)(g.M / G2M) * (g.N / G2N) < 384) return false;      // too few 128 x 128 tiles to fill the chip: the 64 x 64 kernel's 4x workgroups hide the latency better
+    if (knob != 2 && epi != EPI_PARTIAL && (long)(g.M / G2M) * (g.N / G2N) < 384) return false;      // too few 128 x 128 tiles to fill the chip: the 64 x 64 kernel's 4x workgroups hide the latency better
     if (((uintptr_t)g.B & 15) || ((uintptr_t)g.A & 15)) return false;
     if (!((g.b_cs == 1 && g.b_rs % 4 == 0) || (g.b_rs == 1 && g.b_cs % 4 == 0 && g.b_cs != 1))) return false;
     if (g.a_cs == 1) return g.a_rs % 4 == 0;

@@ -10,3 +10,9 @@ extern "C" const char* apx_emul_last_error() { return g_err; }
 // the grid of the next launches (the kernel's host code reads APX_PPO_EPOCH_WGS once; the emulation overrides the launch instead)
 extern "C" void apx_emul_set_workgroups(int g) { hipemu::g_force_grid = g; }
 extern "C" int apx_emul_last_grid() { return (int)hipemu::g_grid.x; }
+// launches so far of the kernels whose launch-site expression contains `part` (e.g. "gemm_f32_128_kernel<EPI_MASK>")
+extern "C" long apx_emul_launches(const char* part) {
+    long n = 0;
+    for (const auto& kv : hipemu::g_launches) if (kv.first.find(part) != std::string::npos) n += kv.second;
+    return n;
+}

@@ -20,6 +20,8 @@
 #include <cstring>
 #include <algorithm>
 #include <functional>
+#include <map>
+#include <string>
 #include <sys/mman.h>
 #include <thread>
 #include <type_traits>
@@ -66,6 +68,7 @@ inline thread_local Lane* g_cur = nullptr;
 inline dim3 g_grid, g_block, g_bidx;
 inline char g_dynsmem[160 * 1024] __attribute__((aligned(64)));      // the dynamic LDS segment of the running workgroup (`extern __shared__`, see build.sh)
 inline char* g_stacks = nullptr;                                      // MAX_WAVES x 64 fiber stacks, mapped once (untouched pages cost nothing)
+inline std::map<std::string, long> g_launches;      // launches per kernel expression as written at the launch site (tests ask which kernels a path really took)
 inline int g_force_grid = 0;      // > 0: every launch runs with this many workgroups whatever the host code asked for
 inline void yield() { Lane* l = g_cur; swapcontext(&l->ctx, &l->wave->sched); }
 inline void fiber_entry(unsigned lo, unsigned hi) {
@@ -152,7 +155,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
 #define blockIdx (hipemu::g_bidx)
 #define gridDim (hipemu::g_grid)
 #define blockDim (hipemu::g_block)
-#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) hipemu::launch(grid, block, [=]() { kern(__VA_ARGS__); })
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) (hipemu::g_launches[#kern] += 1, hipemu::launch(grid, block, [=]() { kern(__VA_ARGS__); }))
 
 template <class T> inline T hipemu_atomic_add(T* p, T v) {
     T old, nw;
