@@ -106,7 +106,7 @@ class Mlp:
         else:
             xn = a1 = a2 = None              # inference on the fused shapes: nothing but y leaves the kernel
         if out is not None:
-            assert out.is_contiguous() and out.numel() == B * self.O and out.dtype == torch.float32 and out.is_cuda
+            assert out.is_contiguous() and out.numel() == B * self.O and out.dtype == torch.float32 and out.device == dev
             y = out
         else:
             y = torch.empty(B, self.O, dtype=torch.float32, device=dev)

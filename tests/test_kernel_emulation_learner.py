@@ -53,9 +53,22 @@ def launches(part):
 
 
 class _NoStream:
+    """stands for a HIP stream and for an event on it: the emulation runs every launch to completion inside the call"""
     cuda_stream = 0
 
     def wait_stream(self, other):
+        pass
+
+    def wait_event(self, ev):
+        pass
+
+    def record_event(self, *a):
+        return self
+
+    def record(self, *a):
+        pass
+
+    def wait(self, *a):
         pass
 
     def synchronize(self):
@@ -75,6 +88,7 @@ def dev(monkeypatch):
     monkeypatch.setattr(engine, "_stream", lambda: None)
     monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _NoStream())
     monkeypatch.setattr(torch.cuda, "Stream", lambda *a, **k: _NoStream())
+    monkeypatch.setattr(torch.cuda, "Event", lambda *a, **k: _NoStream())
     monkeypatch.setattr(torch.cuda, "stream", lambda s: contextlib.nullcontext())
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
     return torch.device("cpu")
@@ -243,3 +257,35 @@ def test_emulated_128_tile_gemm_on_the_golden_shapes():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", "ppo_update_g4 or ppo_steps_g4b or td3_train_g20"],
                        capture_output=True, text=True, env=env, cwd=REPO)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def _ppo_tests():
+    from tests import test_gpu_ppo as P
+    return P
+
+
+# the whole-training-loop goldens take 1.5 - 5 minutes each under the emulation: part of `APX_EMUL_FULL=1 python -m pytest tests/test_kernel_emulation_learner.py`
+# (results of the last run: profiles/r05_emulation_checks.txt), not of the default CPU suite
+full = pytest.mark.skipif(os.environ.get("APX_EMUL_FULL") != "1", reason="minutes of emulation: APX_EMUL_FULL=1")
+
+
+@full
+def test_emulated_whole_train_loops_g15b_g15c(dev, golden_dir):
+    """the reference's PPO.train iterations on the toy env (sample with replayed noise -> returns -> epochs of minibatches -> KL early stop), G15b / G15c"""
+    P = _ppo_tests()
+    P.test_whole_train_loop_golden_g15b(dev, golden_dir)
+    P.test_kl_early_stop_golden_g15c(dev, golden_dir)
+
+
+def test_emulated_normalization_params_g21(dev, golden_dir):
+    _ppo_tests().test_normalization_params_golden_g21(dev, golden_dir)
+
+
+@full
+@pytest.mark.parametrize("fname", ["g15d_ppo_train_recurrent.npz", "g15e_ppo_train_recurrent_h128.npz"])
+def test_emulated_whole_train_loop_recurrent_g15d(dev, golden_dir, fname):
+    _ppo_tests().test_whole_train_loop_recurrent_golden_g15d(dev, golden_dir, fname)
+
+
+def test_emulated_td3_whole_loop_g20c(dev, golden_dir):
+    _gpu_tests().test_td3_whole_loop_golden_g20c(dev, golden_dir)
