@@ -289,3 +289,32 @@ def test_emulated_whole_train_loop_recurrent_g15d(dev, golden_dir, fname):
 
 def test_emulated_td3_whole_loop_g20c(dev, golden_dir):
     _gpu_tests().test_td3_whole_loop_golden_g20c(dev, golden_dir)
+
+
+@full
+@pytest.mark.parametrize("mb,nb,mirror", [(256, 2, True), (512, 2, False), (1024, 1, True)])
+def test_emulated_epoch_kernel_twin_at_larger_minibatches(dev, mb, nb, mirror):
+    """apx_ppo_epoch against the per-step launches at minibatch 256 / 512 / 1024 (several batches of 8 row chunks per weight-gradient tile, more 16-sample items than
+    workgroups): per-step scalars and post-epoch parameters"""
+    from apex_amd import _lib
+    from tests import epoch_worker as W
+    from golden_util import epoch_case_inputs
+    rs = np.random.RandomState(mb)
+    inp = epoch_case_inputs(0)
+    B = mb * nb + 64
+    obs = rs.randn(B, 50).astype(np.float32); ph = rs.rand(B) * 2 * np.pi
+    obs[:, 46] = np.sin(ph); obs[:, 47] = np.cos(ph)
+    inp.update(obs=obs, act=(rs.randn(B, 10) * 0.3).astype(np.float32), ret=rs.randn(B).astype(np.float32), adv=rs.randn(B).astype(np.float32))
+    perm = torch.tensor(rs.permutation(B)[:nb * mb].astype(np.int64))
+    la, da = W.make_learner(dev, inp, mirror)
+    sa = W.run_steps(la, da, perm, mb, mirror)
+    lb, db = W.make_learner(dev, inp, mirror)
+    _lib.load().apx_emul_set_workgroups(1)
+    try:
+        sb = lb.epoch(*db, perm, mb, mirror=mirror).numpy()
+    finally:
+        _lib.load().apx_emul_set_workgroups(0)
+    np.testing.assert_allclose(sb, sa, rtol=1e-4, atol=1e-6)
+    for x, y in ((la.actor.params, lb.actor.params), (la.critic.params, lb.critic.params)):
+        d = (x - y).abs()
+        assert float(d.max()) <= 5e-4 and float((d > 5e-6).float().mean()) <= 5e-3, (float(d.max()), float((d > 5e-6).float().mean()))
