@@ -774,3 +774,35 @@ np.save(sys.argv[1], np.array(out))
     print("fp32 control of the crafted substep: other dofs %.2e of max(1, |qacc|), spin dofs %.2e of max |qacc| of the env" % (worst_rel, worst_spin))
     assert worst_rel < 3e-2
     assert 2e-5 < worst_spin < 2e-4      # the GPU test allows 0.25 * 8e-4 = 2e-4 of max |qacc| on these two dofs
+
+
+def test_g23_kinematic_chain_on_the_agility_gait(golden_dir):
+    """The one physics-side fixture the reference holds that did NOT come out of this build: cassie/trajectory/stepdata.bin, a gait cycle of Agility's own Cassie
+    simulator at 2 kHz (every 4th sample here, G23).  Through the oracle's kinematic chain (joint axes, link offsets, foot capsules of cassie.xml as restated in
+    oracle/cassie_model_gen.h) every pose must be a walking robot on the floor z = 0: the lower foot's lowest point within [-1.5 mm, +1 mm] of the floor at EVERY
+    sample (the two simulators' contact penetration is a fraction of a millimetre), a foot on the floor does not slide (its body origin moves at centimetres per
+    second while the pelvis travels at 0.73 m/s and the swing foot at ~ 2 m/s), the swing foot clears the floor by ~ 10 cm.  A link 1 % too long or a joint axis
+    off by a degree breaks this by centimetres.  What it does not pin: inertias, springs, the constraint solver (a forward-dynamics comparison with the recorded
+    velocities is dominated by the 5 mm the recorded rod orientations miss the oracle's loop closures by)."""
+    g = np.load(os.path.join(golden_dir, "g23_agility_gait.npz"))
+    qpos, qvel, t = g["qpos"].astype(np.float64), g["qvel"].astype(np.float64), g["time"]
+    e = S.OracleEnv(seed=0, env_id=0, dyn_rand=False)
+    e.reset()
+    bl, br = S.BODY_NAMES.index("left-foot"), S.BODY_NAMES.index("right-foot")
+    low, pos = [], []
+    for i in range(len(t)):
+        e.set("qpos", qpos[i].copy()); e.set("qvel", qvel[i].copy()); e.phys_forward(None)
+        f = e.get("foot_low"); x = e.get("xpos").reshape(-1, 3)
+        low.append([f[1], f[3]]); pos.append([x[bl], x[br]])
+    low, pos = np.array(low), np.array(pos)
+    lower = low.min(1)
+    assert lower.min() > -1.5e-3 and lower.max() < 1.0e-3, (lower.min(), lower.max())
+    assert abs(lower.mean()) < 0.8e-3 and lower.std() < 0.5e-3
+    assert 0.08 < low.max() < 0.13                                        # swing clearance of the gait
+    dt = float(t[1] - t[0])
+    for k in range(2):
+        speed = np.linalg.norm(np.diff(pos[:, k], axis=0), axis=1) / dt
+        stance = low[:-1, k] < 2e-3
+        assert 0.4 < stance.mean() < 0.7                                  # a walking gait: each foot on the floor about half of the cycle
+        assert np.median(speed[stance]) < 0.06 and np.median(speed[~stance]) > 1.0, (np.median(speed[stance]), np.median(speed[~stance]))
+    assert 0.6 < qvel[:, 0].mean() < 0.9                                   # the recorded gait walks forward at ~ 0.73 m/s
