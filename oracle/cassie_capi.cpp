@@ -43,14 +43,22 @@ void orc_phys_step(void* h, const double* ctrl, int n) {
     Env& e = *(Env*)h;
     for (int i = 0; i < n; ++i) { step(e.par, e.st, w, ctrl); e.sat_acc |= e.st.sat; }
 }
+static thread_local Work g_fwd_work;      // (kept after the call: orc_efc_rows reads the constraint rows of the pass)
 void orc_phys_forward(void* h, const double* ctrl) {
-    static thread_local Work w;
     Env& e = *(Env*)h;
-    forward(e.par, e.st, w, ctrl);
+    forward(e.par, e.st, g_fwd_work, ctrl);
     e.sat_acc |= e.st.sat;
 }
 double orc_constraint_violation(void* h) { return constraint_violation(((Env*)h)->st); }
 void orc_com_velocity(void* h, double* out) { static thread_local Work w; Env& e = *(Env*)h; com_velocity(e.par, e.st, w, out); }
+void orc_momentum(void* h, double* out) { static thread_local Work w; Env& e = *(Env*)h; momentum(e.par, e.st, w, out); }
+void orc_inverse_dynamics(void* h, const double* qacc, double* out) { static thread_local Work w; Env& e = *(Env*)h; inverse_dynamics(e.par, e.st, w, qacc, out); }
+// constraint rows of the most recent orc_phys_forward of THIS thread: J [nefc, NV] and the row types (0 equality, 1 limit, 2 contact); returns nefc
+int orc_efc_rows(void* h, double* J, int* type) {
+    Env& e = *(Env*)h;
+    for (int i = 0; i < e.st.nefc; ++i) { for (int d = 0; d < NV; ++d) J[i * NV + d] = g_fwd_work.rows[i].J[d]; type[i] = g_fwd_work.rows[i].type; }
+    return e.st.nefc;
+}
 double orc_total_energy(void* h) { static thread_local Work w; Env& e = *(Env*)h; return total_energy(e.par, e.st, w); }
 
 #define FIELD(nm, ptr, cnt) if (!std::strcmp(name, nm)) { if (set) std::memcpy((void*)(ptr), io, sizeof(double) * (cnt)); else std::memcpy(io, (ptr), sizeof(double) * (cnt)); return cnt; }

@@ -576,6 +576,41 @@ void com_velocity(const Params& p, const State& s0, Work& w, double out[3]) {
     }
 }
 
+void momentum(const Params& p, const State& s0, Work& w, double out[25]) {
+    State s = s0;
+    kinematics(s.qpos, s, w);
+    inertias(p, s, w);
+    double row[6];
+    for (int k = 0; k < 6; ++k) {
+        double a = 0;
+        for (int j = 0; j < NV; ++j) a += w.M[k][j] * s.qvel[j];
+        row[k] = a;
+    }
+    V3 L = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) L = L + col(s.xmat[1], k) * row[3 + k];      // the ball joint's dofs are rotations about the pelvis body axes, taken about the pelvis origin (w.o)
+    out[0] = row[0]; out[1] = row[1]; out[2] = row[2]; out[3] = L.x; out[4] = L.y; out[5] = L.z;
+    out[6] = w.o.x; out[7] = w.o.y; out[8] = w.o.z;
+    const SI& c = w.crb[1];
+    out[9] = c.m; out[10] = w.o.x + c.h.x / c.m; out[11] = w.o.y + c.h.y / c.m; out[12] = w.o.z + c.h.z / c.m;
+    for (int leg = 0; leg < 2; ++leg) {
+        const int g = leg, b = cm_geom_body[g];
+        const V3 ctr = s.xpos[b] + mul(s.xmat[b], v3(cm_geom_pos + 3 * g)), ax = mul(s.xmat[b], v3(cm_geom_axis + 3 * g));
+        double* o = out + 13 + 6 * leg;
+        o[0] = ctr.x; o[1] = ctr.y; o[2] = ctr.z; o[3] = ax.x; o[4] = ax.y; o[5] = ax.z;
+    }
+}
+
+void inverse_dynamics(const Params& p, const State& s0, Work& w, const double* qacc, double* out) {
+    State s = s0;
+    s.xfrc_body = 0;
+    forward(p, s, w, nullptr);      // kinematics, M, bias, passive (the constraint part of the pass is not used)
+    for (int d = 0; d < NV; ++d) {
+        double a = w.bias[d] - w.passive[d];
+        for (int j = 0; j < NV; ++j) a += w.M[d][j] * qacc[j];
+        out[d] = a;
+    }
+}
+
 double total_energy(const Params& p, const State& s0, Work& w) {
     State s = s0;
     kinematics(s.qpos, s, w);

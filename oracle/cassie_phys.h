@@ -163,5 +163,10 @@ void floor_query(const Params& p, double x, double y, double& h, V3& n);
 double constraint_violation(const State& s);                      // max |p1-p2| over the 4 connect constraints
 void com_velocity(const Params& p, const State& s, Work& w, double out[3]);   // total linear momentum / total mass
 double total_energy(const Params& p, const State& s, Work& w);    // kinetic + gravity + spring potential
+// total momentum of the tree from the free joint's rows of M qvel: out = linear momentum [3], angular momentum about the pelvis origin in world axes [3], pelvis
+// origin [3], total mass, centre of mass [3], then per foot the capsule centre [3] and axis [3] (tests/test_oracle_env.py: the momentum balance of Agility's gait, G23)
+void momentum(const Params& p, const State& s, Work& w, double out[25]);
+// inverse dynamics of the unconstrained tree: out = M(q) qacc + bias(q, qvel) - passive(q, qvel) (the generalised force that actuators + constraints must supply)
+void inverse_dynamics(const Params& p, const State& s, Work& w, const double* qacc, double* out);
 
 }  // namespace orc

@@ -48,6 +48,10 @@ def lib():
         L.orc_phys_forward.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_constraint_violation.restype = _CR
         L.orc_constraint_violation.argtypes = [C.c_void_p]
+        L.orc_momentum.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_inverse_dynamics.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_efc_rows.restype = C.c_int
+        L.orc_efc_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_total_energy.restype = _CR
         L.orc_total_energy.argtypes = [C.c_void_p]
         L.orc_env_get.restype = C.c_int
@@ -206,6 +210,24 @@ class OracleEnv:
 
     def violation(self):
         return lib().orc_constraint_violation(self.h)
+
+    def momentum(self):
+        """dict of the tree's total momentum: p [3], L about the pelvis origin [3] (world axes), origin, mass, com, foot capsule (centre, axis) x 2"""
+        out = np.zeros(25, dtype=_REAL)
+        lib().orc_momentum(self.h, _ptr(out))
+        return dict(p=out[0:3], L=out[3:6], o=out[6:9], mass=float(out[9]), com=out[10:13], foot=[(out[13:16], out[16:19]), (out[19:22], out[22:25])])
+
+    def inverse_dynamics(self, qacc):
+        """M(q) qacc + bias - passive of the unconstrained tree at the current (qpos, qvel): what actuators and constraint forces must add up to"""
+        qa = np.ascontiguousarray(qacc, dtype=_REAL); out = np.zeros(32, dtype=_REAL)
+        lib().orc_inverse_dynamics(self.h, _ptr(qa), _ptr(out))
+        return out
+
+    def efc_rows(self):
+        """(J [nefc, 32], type [nefc]) of the constraint rows of the most recent phys_forward (0 equality, 1 limit, 2 contact)"""
+        J = np.zeros((200, 32), dtype=_REAL); ty = np.zeros(200, dtype=np.int32)
+        n = lib().orc_efc_rows(self.h, _ptr(J), ty.ctypes.data_as(C.c_void_p))
+        return J[:n].copy(), ty[:n].copy()
 
     def energy(self):
         return lib().orc_total_energy(self.h)

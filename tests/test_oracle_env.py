@@ -779,7 +779,7 @@ np.save(sys.argv[1], np.array(out))
 def test_g23_kinematic_chain_on_the_agility_gait(golden_dir):
     """The one physics-side fixture the reference holds that did NOT come out of this build: cassie/trajectory/stepdata.bin, a gait cycle of Agility's own Cassie
     simulator at 2 kHz (every 4th sample here, G23).  Through the oracle's kinematic chain (joint axes, link offsets, foot capsules of cassie.xml as restated in
-    oracle/cassie_model_gen.h) every pose must be a walking robot on the floor z = 0: the lower foot's lowest point within [-1.5 mm, +1 mm] of the floor at EVERY
+    oracle/cassie_model_gen.h) every pose must be a walking robot on Agility's floor z = 0 (cassie.xml's own plane lies 1 cm lower; irrelevant here): the lower foot's lowest point within [-1.5 mm, +1 mm] of the floor at EVERY
     sample (the two simulators' contact penetration is a fraction of a millimetre), a foot on the floor does not slide (its body origin moves at centimetres per
     second while the pelvis travels at 0.73 m/s and the swing foot at ~ 2 m/s), the swing foot clears the floor by ~ 10 cm.  A link 1 % too long or a joint axis
     off by a degree breaks this by centimetres.  What it does not pin: inertias, springs, the constraint solver (a forward-dynamics comparison with the recorded
@@ -806,3 +806,117 @@ def test_g23_kinematic_chain_on_the_agility_gait(golden_dir):
         assert 0.4 < stance.mean() < 0.7                                  # a walking gait: each foot on the floor about half of the cycle
         assert np.median(speed[stance]) < 0.06 and np.median(speed[~stance]) > 1.0, (np.median(speed[stance]), np.median(speed[~stance]))
     assert 0.6 < qvel[:, 0].mean() < 0.9                                   # the recorded gait walks forward at ~ 0.73 m/s
+
+
+def test_g23_momentum_balance_on_the_agility_gait(golden_dir):
+    """The dynamics side of the same external fixture, through the part of the model that needs no contact, closure or spring force: Newton - Euler for the whole tree.
+    In single support the ground reaction acts along the stance foot's capsule line, so about a point P of that line the contact has no moment along the line's axis a:
+        a . (d/dt L_P + v_P x p) = a . ((com - P) x m g)
+    with p, L_P the total linear / angular momentum from the free joint's rows of the oracle's M(q) qvel (masses, centres of mass, inertia tensors, kinematics of all 25
+    bodies) on the recorded (qpos, qvel), differentiated over the 2 ms between fixture samples.  Gravity's moment is 37 N m rms over the ~175 single-support samples of a
+    foot; the balance closes to 1.25 / 1.6 N m rms (3.4 / 4.4 %): the inertial model the oracle restates from cassie.xml reproduces the momentum budget of a gait simulated
+    elsewhere.  Sensitivity (measured): shin + tarsus masses x 1.5 -> residual 1.9 / 2.5, thigh x 1.3 -> 1.6 / 2.1.  Over the whole cycle the mean vertical ground
+    reaction is the robot's weight (33.3 kg) to 1e-4."""
+    g = np.load(os.path.join(golden_dir, "g23_agility_gait.npz"))
+    q, v, t = g["qpos"].astype(np.float64), g["qvel"].astype(np.float64), g["time"]
+    dt, N = float(t[1] - t[0]), len(t)
+    e = S.OracleEnv(seed=0, env_id=0, dyn_rand=False)
+    e.reset()
+    P, L, O, COM, F, low = np.zeros((N, 3)), np.zeros((N, 3)), np.zeros((N, 3)), np.zeros((N, 3)), np.zeros((N, 2, 2, 3)), np.zeros((N, 2))
+    for i in range(N):
+        e.set("qpos", q[i].copy()); e.set("qvel", v[i].copy()); e.phys_forward(None)
+        m = e.momentum()
+        P[i], L[i], O[i], COM[i], mass = m["p"], m["L"], m["o"], m["com"], m["mass"]
+        for k in range(2):
+            F[i, k, 0], F[i, k, 1] = m["foot"][k]
+        f = e.get("foot_low"); low[i] = [f[1], f[3]]
+    assert abs(mass - 33.312) < 1e-3                                         # cassie.xml's total mass
+    grav = np.array([0.0, 0.0, -9.81])
+    fz = mass * (np.gradient(P[:, 2] / mass, dt) + 9.81)
+    assert abs(fz.mean() / (mass * 9.81) - 1.0) < 2e-3 and fz.min() > 0.0    # a periodic gait carries its weight on average and never pulls on the floor
+    for k, lim in ((0, 1.5), (1, 1.9)):
+        idx = np.nonzero((low[:, k] < 2e-3) & (low[:, 1 - k] > 1e-2))[0]
+        idx = idx[(idx > 1) & (idx < N - 2)]
+        assert len(idx) > 150
+        Pk, ax = F[:, k, 0], F[:, k, 1]
+        LP = L + np.cross(O - Pk, P)
+        lhs = np.einsum("ij,ij->i", np.gradient(LP, dt, axis=0) + np.cross(np.gradient(Pk, dt, axis=0), P), ax)
+        rhs = np.einsum("ij,ij->i", np.cross(COM - Pk, mass * grav), ax)
+        rms = lambda x: float(np.sqrt((x[idx] ** 2).mean()))
+        assert 30.0 < rms(rhs) < 45.0 and rms(lhs - rhs) < lim and rms(lhs - rhs) < 0.05 * rms(rhs), (k, rms(rhs), rms(lhs - rhs))
+        assert np.corrcoef(lhs[idx], rhs[idx])[0, 1] > 0.97
+
+
+def test_g23_inverse_dynamics_of_the_swing_leg_reproduces_the_recorded_torques(golden_dir):
+    """The strongest statement the external fixture supports.  stepdata.bin also holds the ten joint-side motor torques Agility's simulator applied at each sample.  For a
+    leg in swing (no contact) the equations of motion of its 13 dofs read
+        M(q) qacc + bias(q, qvel) - passive(q, qvel) = S^T torque + J_closure^T f
+    with everything on the left from the oracle (mass matrix incl. the armatures, Coriolis / centrifugal / gravity terms by RNE, joint dampers and the knee / heel SPRINGS),
+    qacc the recorded velocities differentiated at 2 kHz, the torques recorded, and only the six components f of the leg's two loop-closure forces unknown (achilles rod,
+    plantar rod; directions J from the oracle's own connect rows).  (a) The hip roll / yaw / pitch rows see the closures only through the lever of that mismatch (both closure points hang on the thigh): the oracle's inverse dynamics equals
+    the recorded hip torques to 0.2 - 0.3 N m rms on 8 N m rms.  (b) Over the whole leg, after the least-squares fit of f, 7 of 13 equations per sample remain as checks:
+    the remainder is 0.3 / 0.5 N m rms on a left side of 12 N m rms (2.3 / 3.7 %), before the fit 4.5 - 4.8 N m.  So inertias, gear-reflected rotor inertias, bias forces,
+    spring rates and closure directions of the restated cassie.xml agree with an independent simulation of the same robot to a few per cent.  Still unpinned: contact,
+    the soft-constraint solver, integration - the MuJoCo-specific half."""
+    g = np.load(os.path.join(golden_dir, "g23_agility_gait.npz"))
+    q, v, a, tau = (g[k].astype(np.float64) for k in ("qpos", "qvel", "qacc", "torque"))
+    act = [6, 7, 8, 12, 18, 19, 20, 21, 25, 31]                              # dof of each motor (cassie.xml actuator order)
+    e = S.OracleEnv(seed=0, env_id=0, dyn_rand=False)
+    e.reset()
+    hip = {0: [], 1: []}; leg_res = {0: [], 1: []}
+    for i in range(2, len(q) - 2):
+        e.set("qpos", q[i].copy()); e.set("qvel", v[i].copy()); e.phys_forward(None)
+        idyn = e.inverse_dynamics(a[i]); f = e.get("foot_low"); J, ty = e.efc_rows()
+        r = idyn.copy()
+        for u, dof in enumerate(act):
+            r[dof] -= tau[i, u]
+        for leg, (d0, u0, lowz) in enumerate(((6, 0, f[1]), (19, 5, f[3]))):
+            if lowz < 0.02:
+                continue                                                      # only a foot clear of the floor
+            dofs = list(range(d0, d0 + 13))
+            hip[leg].append(np.concatenate([idyn[d0:d0 + 3], tau[i, u0:u0 + 3]]))
+            Jeq = J[ty == 0][:, dofs]
+            Jeq = Jeq[np.abs(Jeq).sum(1) > 0]
+            assert Jeq.shape[0] == 6 and np.abs(Jeq[:, :3]).max() < 0.02 * np.abs(Jeq).max()      # two connects per leg; the hip columns only see the 5 mm the recorded pose misses the closures by
+            fit = np.linalg.lstsq(Jeq.T, r[dofs], rcond=None)[0]
+            leg_res[leg].append([np.linalg.norm(idyn[dofs]), np.linalg.norm(r[dofs]), np.linalg.norm(r[dofs] - Jeq.T @ fit)])
+    rms = lambda x: float(np.sqrt(np.mean(np.square(x))))
+    for leg in (0, 1):
+        h = np.array(hip[leg]); lr = np.array(leg_res[leg])
+        assert len(h) > 120
+        for k, (lo, hi, lim) in enumerate(((6.0, 10.0, 0.30), (0.5, 1.0, 0.12), (6.0, 9.0, 0.40))):      # roll, yaw, pitch: torque rms window [N m], residual rms limit
+            assert lo < rms(h[:, 3 + k]) < hi and rms(h[:, k] - h[:, 3 + k]) < lim, (leg, k, rms(h[:, 3 + k]), rms(h[:, k] - h[:, 3 + k]))
+            assert np.corrcoef(h[:, k], h[:, 3 + k])[0, 1] > 0.995
+        assert 10.0 < rms(lr[:, 0]) < 15.0 and rms(lr[:, 1]) > 3.5 and rms(lr[:, 2]) < 0.6 and rms(lr[:, 2]) < 0.05 * rms(lr[:, 0]), (leg, rms(lr[:, 0]), rms(lr[:, 1]), rms(lr[:, 2]))
+
+
+def test_g23_whole_body_inverse_dynamics_with_fitted_contact_forces(golden_dir):
+    """All 32 equations of motion on the external gait: M(q) qacc + bias - passive - S^T torque must lie in the span of the constraint Jacobians - the twelve loop-closure
+    rows and the floor-contact rows of the stance foot's capsule ends (the robot is lowered by 12.5 mm for this: Agility's floor is z = 0, cassie.xml's plane lies at
+    z = -0.01, and the oracle builds contact rows only for a penetrating end; the dynamics do not depend on the height).  Single support: 2 contacts, rank 17, 15
+    equations per sample left as checks: remainder 6.6 N m rms on a left side of 372 (the 327 N weight included), i.e. 1.8 %, largest on the loaded knee / spring dofs
+    of the stance leg (2 - 4 N m on joint loads of 60 - 80).  Double support with both feet's contacts found (3 - 4 contacts): 1.1 - 1.3 N m."""
+    g = np.load(os.path.join(golden_dir, "g23_agility_gait.npz"))
+    q, v, a, tau = (g[k].astype(np.float64) for k in ("qpos", "qvel", "qacc", "torque"))
+    act = [6, 7, 8, 12, 18, 19, 20, 21, 25, 31]
+    e = S.OracleEnv(seed=0, env_id=0, dyn_rand=False)
+    e.reset()
+    rows = []
+    for i in range(2, len(q) - 2):
+        q2 = q[i].copy(); q2[2] -= 0.0125
+        e.set("qpos", q2); e.set("qvel", v[i].copy()); e.phys_forward(None)
+        idyn = e.inverse_dynamics(a[i]); J, ty = e.efc_rows()
+        r = idyn.copy()
+        for u, dof in enumerate(act):
+            r[dof] -= tau[i, u]
+        Jc = J[(ty == 0) | (ty == 2)]
+        rem = r - Jc.T @ np.linalg.lstsq(Jc.T, r, rcond=None)[0]
+        low = e.get("foot_low")[[1, 3]] + 0.01                                # above the oracle's floor
+        rows.append([int((ty == 2).sum()) // 4, float(low.max() > 0.01), np.linalg.norm(idyn), np.linalg.norm(r), np.linalg.norm(rem)])
+    rows = np.array(rows)
+    rms = lambda x: float(np.sqrt(np.mean(np.square(x))))
+    single = rows[(rows[:, 1] == 1) & (rows[:, 0] == 2)]
+    both = rows[rows[:, 0] >= 3]
+    assert len(single) > 300 and len(both) > 30
+    assert 330 < rms(single[:, 2]) < 420 and rms(single[:, 3]) > 300 and rms(single[:, 4]) < 8.5 and rms(single[:, 4]) < 0.025 * rms(single[:, 2]), (rms(single[:, 2]), rms(single[:, 4]))
+    assert rms(both[:, 4]) < 2.0, rms(both[:, 4])
