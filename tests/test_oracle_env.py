@@ -881,6 +881,21 @@ def test_g23_inverse_dynamics_of_the_swing_leg_reproduces_the_recorded_torques(g
             fit = np.linalg.lstsq(Jeq.T, r[dofs], rcond=None)[0]
             leg_res[leg].append([np.linalg.norm(idyn[dofs]), np.linalg.norm(r[dofs]), np.linalg.norm(r[dofs] - Jeq.T @ fit)])
     rms = lambda x: float(np.sqrt(np.mean(np.square(x))))
+    # negative control, same data: the recorded torques shifted by 16 ms against the motion must NOT fit (measured 2.4 N m; further sensitivities measured once:
+    # torques x 1.2 -> 2.3, shin + tarsus masses x 1.3 -> 0.95, foot mass x 2 -> 1.2, left / right torques swapped -> 78; a kinematically edited, non-simulated
+    # trajectory of the same format - cassie/trajectory/more-poses-trial.bin - leaves 4.5 N m of 7)
+    late = []
+    tau_late = np.roll(tau, 8, axis=0)
+    for i in range(2, len(q) - 2, 2):
+        e.set("qpos", q[i].copy()); e.set("qvel", v[i].copy()); e.phys_forward(None)
+        r = e.inverse_dynamics(a[i]); f = e.get("foot_low"); J, ty = e.efc_rows()
+        for u, dof in enumerate(act):
+            r[dof] -= tau_late[i, u]
+        for d0, lowz in ((6, f[1]), (19, f[3])):
+            if lowz >= 0.02:
+                dofs = list(range(d0, d0 + 13)); Jeq = J[ty == 0][:, dofs]; Jeq = Jeq[np.abs(Jeq).sum(1) > 0]
+                late.append(np.linalg.norm(r[dofs] - Jeq.T @ np.linalg.lstsq(Jeq.T, r[dofs], rcond=None)[0]))
+    assert rms(late) > 1.5, rms(late)
     for leg in (0, 1):
         h = np.array(hip[leg]); lr = np.array(leg_res[leg])
         assert len(h) > 120
