@@ -277,3 +277,39 @@ def test_product_code_never_touches_the_oracle_or_the_reference():
         assert "/root/reference" not in txt, f
     bench = open(os.path.join(root, "bench.py")).read()
     assert bench.count("from oracle") == 1 and "def cpu_baseline" in bench            # the one allowed use
+
+
+def _c_arrays(path):
+    """{name: float64 array} of every `cm_*[N] = {...}` table of a generated model header"""
+    import re
+    txt = open(path).read()
+    out = {}
+    for m in re.finditer(r"(c[mt]_[a-z0-9_]+)\[(\d+)\]\s*=\s*\{([^}]*)\}", txt):
+        vals = [float(x.strip().rstrip("f")) for x in m.group(3).replace("\n", " ").split(",") if x.strip()]
+        assert len(vals) == int(m.group(2)), (path, m.group(1))
+        out[m.group(1).replace("ct_", "cm_")] = np.array(vals)
+    return out
+
+
+def test_model_tables_of_kernel_and_oracle_are_the_same_model():
+    """The oracle's fp64 tables (oracle/cassie_model_gen.h: what the external gait of G23 pins from outside), the kernel's device tables and their constexpr twins
+    (apex_amd/csrc/cassie_model_gen.h, cassie_tables.h) must be ONE model: the same arrays, the float ones the fp32 rounding of the double ones.  And - where the
+    reference is present - exactly what tools/gen_model.py emits from the reference's cassie.xml today."""
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    o = _c_arrays(os.path.join(repo, "oracle", "cassie_model_gen.h"))
+    k = _c_arrays(os.path.join(repo, "apex_amd", "csrc", "cassie_model_gen.h"))
+    t = _c_arrays(os.path.join(repo, "apex_amd", "csrc", "cassie_tables.h"))
+    assert len(o) >= 50 and sorted(o) == sorted(k) == sorted(t)
+    for name in o:
+        f32 = o[name].astype(np.float32).astype(np.float64)
+        assert np.array_equal(k[name].astype(np.float32).astype(np.float64), f32), name
+        assert np.array_equal(t[name].astype(np.float32).astype(np.float64), f32), name
+    assert abs(o["cm_body_mass"].sum() - 33.312) < 1e-3
+    if os.path.isdir("/root/reference"):
+        import sys
+        sys.path.insert(0, os.path.join(repo, "tools"))
+        import gen_model
+        model = gen_model.compile_model()
+        assert gen_model.emit_header(model, "double", "ORACLE_CASSIE_MODEL_GEN_H") == open(os.path.join(repo, "oracle", "cassie_model_gen.h")).read()
+        assert gen_model.emit_header(model, "float", "APX_CASSIE_MODEL_GEN_H", decl="static __device__ const") == open(os.path.join(repo, "apex_amd", "csrc", "cassie_model_gen.h")).read()
