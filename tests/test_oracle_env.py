@@ -935,3 +935,36 @@ def test_g23_whole_body_inverse_dynamics_with_fitted_contact_forces(golden_dir):
     assert len(single) > 300 and len(both) > 30
     assert 330 < rms(single[:, 2]) < 420 and rms(single[:, 3]) > 300 and rms(single[:, 4]) < 8.5 and rms(single[:, 4]) < 0.025 * rms(single[:, 2]), (rms(single[:, 2]), rms(single[:, 4]))
     assert rms(both[:, 4]) < 2.0, rms(both[:, 4])
+
+
+def test_g24_the_reference_policies_walk_on_the_oracle_physics():
+    """Sim-to-sim transfer.  The two policies the reference ships (trained_models/*/actor.pt: trained by its PPO IN MUJOCO, no dynamics randomisation) are run closed loop
+    on the oracle - its physics, its restated state estimator, PD loop and motor model - through the observation their revision of Cassie-v0 produced (tests/ref_policy_eval.py).
+    A biped policy trained without randomisation is tuned to its simulator's contact and constraint dynamics; here both walk 6 s (200 policy steps) without falling and track
+    the commanded speed: 0 -> 0.00, 0.5 -> 0.46, 1.0 -> 0.98 m/s for the first."""
+    import ref_policy_eval as R
+    for tag, lims in (("a", ((0.0, 0.06), (0.5, 0.08), (1.0, 0.08))), ("b", ((0.5, 0.12), (1.0, 0.15)))):
+        for speed, tol in lims:
+            n, z, v = R.walk(tag, speed)
+            assert n == 200 and 0.85 < z < 1.05 and abs(v - speed) < tol, (tag, speed, n, z, v)
+
+
+def test_g24_push_sweep_matches_the_references_mujoco_table(golden_dir):
+    """The one MuJoCo-GENERATED physics result the reference holds: eval_perturbs.npy next to each shipped policy = the output of its own push sweep under MuJoCo (100
+    directions x 28 gait phases, largest 0.2 s pelvis push survived for 3 s, 10 N steps from 50 N).  The same protocol with the same policy on the ORACLE's physics, cell by
+    cell.  Measured on the 40-cell lattice (every 10th direction x every 7th phase, APX_SLOW=1): mean 146.5 N against MuJoCo's 150.5 N, correlation 0.94 over the cells and
+    0.985 over the direction means, mean absolute difference 11.5 N at a sweep resolution of 10 N, 16 of 40 cells identical, largest difference 40 N.  The default suite
+    runs 8 of those cells.  (The second shipped policy, 5k_retrain, carries an older argument set: mean 123.5 vs 125.8 N but 0.57 cell correlation - not asserted.)"""
+    import multiprocessing as mp
+    import ref_policy_eval as R
+    g = np.load(os.path.join(golden_dir, "g24_ref_policy_push_sweep.npz"))
+    full = os.environ.get("APX_SLOW") == "1"
+    cells = [("a", a, p) for a in range(0, 100, 10) for p in range(0, 28, 7)] if full else [("a", a, p) for a, p in ((0, 7), (20, 0), (30, 14), (40, 21), (50, 7), (60, 14), (80, 0), (90, 21))]
+    with mp.get_context("fork").Pool(min(8, os.cpu_count() or 1)) as pool:
+        res = pool.map(R.push_cell, cells)
+    mine = np.array([r[3] for r in res], dtype=np.float64)
+    ref = np.array([g[f"{t}_eval_perturbs"][a, p] for t, a, p in cells], dtype=np.float64)
+    print("oracle", mine.astype(int).tolist()); print("mujoco", ref.astype(int).tolist())
+    assert abs(mine.mean() - ref.mean()) < 0.08 * ref.mean(), (mine.mean(), ref.mean())
+    assert np.abs(mine - ref).mean() < 18.0 and np.abs(mine - ref).max() <= 60.0, (np.abs(mine - ref).mean(), np.abs(mine - ref).max())
+    assert np.corrcoef(mine, ref)[0, 1] > 0.85

@@ -1,0 +1,36 @@
+"""Golden G24: what the reference ships of a TRAINED policy and of its evaluation UNDER MUJOCO.
+
+trained_models/nodelta_neutral_StateEst_symmetry_speed0-3_freq1-2/ and trained_models/5k_retrain/ hold actor.pt (Gaussian_FF_Actor 49-256-256-10, trained by the reference's
+PPO on Cassie-v0 in MuJoCo, no dynamics randomisation, simrate 60) and eval_perturbs.npy = the output of the reference's own push sweep (test_policy.py:30-35,78-89 ->
+tools/eval_perturb.py:97-160: for 100 push directions x 28 gait phases the largest 0.2 s pelvis push, in 10 N steps from 50 N, after which the robot is still up 3 s later),
+i.e. a 100 x 28 table of closed-loop results of (policy, MuJoCo physics, estimator, PD loop).  This script stores the policy's tensors (state_dict order), its input
+normaliser and that table; tests/test_oracle_env.py replays policy and protocol on the ORACLE's physics and compares with the table (sim-to-sim transfer)."""
+from common import setup_reference_path, REF, GOLD
+setup_reference_path()
+import os
+import numpy as np
+import torch
+
+out = {}
+for tag, name in (("a", "nodelta_neutral_StateEst_symmetry_speed0-3_freq1-2"), ("b", "5k_retrain")):
+    d = os.path.join(REF, "trained_models", name)
+    pol = torch.load(os.path.join(d, "actor.pt"), weights_only=False)
+    pol.eval()
+    W = [p.detach().numpy().astype(np.float32) for p in pol.parameters()]
+    assert [w.shape for w in W] == [(256, 49), (256,), (256, 256), (256,), (10, 256), (10,)]
+    mean, std = pol.obs_mean.numpy().astype(np.float32), pol.obs_std.numpy().astype(np.float32)
+    x = torch.randn(5, 49)
+    h = (x.numpy() - mean) / std
+    for k in (0, 2):
+        h = np.maximum(h @ W[k].T + W[k + 1], 0.0)
+    np.testing.assert_allclose(h @ W[4].T + W[5], pol(x, True).detach().numpy(), rtol=1e-4, atol=1e-5)      # deterministic action = the mean: Linear-ReLU-Linear-ReLU-Linear on the normalised input
+    for i, w in enumerate(W):
+        out[f"{tag}_w{i}"] = w
+    out[f"{tag}_obs_mean"], out[f"{tag}_obs_std"] = mean, std
+    ev = np.load(os.path.join(d, "eval_perturbs.npy"))
+    assert ev.shape == (100, 28) and np.all(ev == np.round(ev / 10) * 10)
+    out[f"{tag}_eval_perturbs"] = ev.astype(np.int16)
+    out[f"{tag}_name"] = name
+out["protocol"] = np.array([60, 0.5, 3.0, 0.2, 50.0, 10.0])      # simrate, commanded speed, wait [s], push duration [s], first push [N], increment [N] (test_policy.py:30-35, experiment.pkl)
+np.savez_compressed(os.path.join(GOLD, "g24_ref_policy_push_sweep.npz"), **out)
+print("wrote g24_ref_policy_push_sweep.npz")
