@@ -97,3 +97,46 @@ def push_cell(args):
                 done = True
                 break
     return tag, ai, ph, size - incr
+
+
+def _qmul(a, b):
+    w1, x1, y1, z1 = a; w2, x2, y2, z2 = b
+    return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2])
+
+
+def command_run(seed, tag="a", num_steps=200, num_commands=6, max_speed=3.0, min_speed=0.0):
+    """one iteration of the reference's command-following test (tools/test_commands.py:56-122 run_test, :131-140 the schedules): a new speed every 200 steps (previous
+    +- U[0.4, 1.3], reflected into [0, 3]), half a period later a yaw command of +- U[pi/6, pi/3] applied to the policy's input, phase_add 1.5 above 1.4 m/s; failed when
+    the pelvis drops below 0.4 m.  Returns the reference's row (passed, half-period kind, speed, yaw offset, last speed step, last yaw step)."""
+    rng = np.random.RandomState(seed)
+    speeds = np.zeros(num_commands); speeds[0] = 0.5
+    for i in range(num_commands - 1):
+        add = rng.choice([-1, 1]) * rng.uniform(0.4, 1.3)
+        if speeds[i] + add < min_speed or speeds[i] + add > max_speed:
+            add = -add
+        speeds[i + 1] = speeds[i] + add
+    orients = rng.uniform(np.pi / 6, np.pi / 3, num_commands) * rng.choice([-1, 1], num_commands)
+    act, env = policy(tag), OldCassieEnv()
+    o = env.reset_for_test(); env.speed = 0.5; o = env.obs()
+    phase, phase_add, count, orient_ind, speed_ind, orient_add, passed = 0.0, 1.0, 0, 0, 1, 0.0, 1
+    while not (speed_ind == num_commands and orient_ind == num_commands and count == num_steps) and passed:
+        if count == num_steps:
+            count = 0
+            env.speed = float(np.clip(speeds[speed_ind], min_speed, max_speed)); phase_add = 1.5 if env.speed > 1.4 else 1.0
+            speed_ind += 1
+        elif count == num_steps // 2:
+            orient_add += orients[orient_ind]; orient_ind += 1
+        iq = np.array([np.cos(orient_add / 2), 0.0, 0.0, -np.sin(orient_add / 2)])
+        st = o.copy()
+        no = _qmul(iq, st[1:5])
+        st[1:5] = -no if no[0] < 0 else no
+        st[15:18] = _qmul(_qmul(iq, np.array([0.0, *st[15:18]])), np.array([iq[0], -iq[1], -iq[2], -iq[3]]))[1:]
+        st[46], st[47], st[48] = np.sin(2 * np.pi * phase / PHASELEN), np.cos(2 * np.pi * phase / PHASELEN), env.speed
+        env.e.step_basic(np.asarray(act(st), dtype=np.float64))
+        phase = 0.0 if phase + phase_add > PHASELEN else phase + phase_add
+        o = env.obs()
+        passed = 0 if env.e.get("qpos")[2] < 0.4 else 1
+        count += 1
+    if passed:
+        return [1.0, -1.0, 0.0, 0.0, 0.0, 0.0]
+    return [0.0, float(count // (num_steps // 2)), env.speed, orient_add, env.speed - speeds[max(0, speed_ind - 2)], orients[orient_ind - 1]]

@@ -31,6 +31,9 @@ for tag, name in (("a", "nodelta_neutral_StateEst_symmetry_speed0-3_freq1-2"), (
     assert ev.shape == (100, 28) and np.all(ev == np.round(ev / 10) * 10)
     out[f"{tag}_eval_perturbs"] = ev.astype(np.int16)
     out[f"{tag}_name"] = name
+    ec = np.load(os.path.join(d, "eval_commands.npy"))      # tools/test_commands.py under MuJoCo: 10 000 random command schedules; rows (passed, half-period kind, speed, yaw offset, last speed step, last yaw step)
+    assert ec.shape == (10000, 6)
+    out[f"{tag}_eval_commands"] = ec.astype(np.float32)
 out["protocol"] = np.array([60, 0.5, 3.0, 0.2, 50.0, 10.0])      # simrate, commanded speed, wait [s], push duration [s], first push [N], increment [N] (test_policy.py:30-35, experiment.pkl)
 np.savez_compressed(os.path.join(GOLD, "g24_ref_policy_push_sweep.npz"), **out)
 print("wrote g24_ref_policy_push_sweep.npz")
