@@ -1139,3 +1139,28 @@ def test_g24_push_sweep_of_the_reference_policy_on_the_kernel(golden_dir):
     assert abs(mine.mean() - ref.mean()) < 0.08 * ref.mean()
     assert np.corrcoef(mine.ravel(), ref.ravel())[0, 1] > 0.85 and np.corrcoef(mine.mean(1), ref.mean(1))[0, 1] > 0.95
     assert np.abs(mine - ref).mean() < 18.0
+
+
+@pytest.mark.xfail(strict=False, reason="written while GPU access was closed: the oracle-side twin (tests/test_oracle_env.py::test_g24_the_reference_policies_walk_on_the_oracle_physics) passes, this one has not run on hardware yet")
+@pytest.mark.parametrize("speed,tol", [(0.0, 0.08), (0.5, 0.10), (1.0, 0.10)])
+def test_g24_the_reference_policy_walks_on_the_kernel(golden_dir, speed, tol):
+    """Sim-to-sim transfer onto the KERNEL: the policy the reference trained in MuJoCo (G24), closed loop on the batched env through step_basic at simrate 60 - 64 envs,
+    200 policy steps (6 s): nobody falls, the pelvis stays at walking height, the commanded speed is tracked (oracle: 0 -> 0.00, 0.5 -> 0.46, 1.0 -> 0.98 m/s)."""
+    import os
+    from apex_amd.vecenv import CassieVecEnv
+    g = np.load(os.path.join(golden_dir, "g24_ref_policy_push_sweep.npz"))
+    dev = torch.device("cuda:0")
+    env = CassieVecEnv(n_envs=64, simrate=60, dynamics_randomization=False, seed=0, max_traj_len=100000)
+    pol = _RefPolicy49(g, "a", dev, speed)
+    obs = env.reset_for_test(full_reset=True)
+    x_half = None
+    for t in range(200):
+        obs = env.step_basic(pol(obs))
+        if t == 99:
+            x_half = env.get_field("qpos")[:, 0].clone()
+    q = env.get_field("qpos")
+    v = ((q[:, 0] - x_half) / (100 * 60 * 0.0005)).cpu().numpy()
+    z = q[:, 2].cpu().numpy()
+    assert (z > 0.85).all() and (z < 1.05).all(), (z.min(), z.max())
+    assert abs(v.mean() - speed) < tol, (speed, v.mean())
+    env.close()
