@@ -104,11 +104,13 @@ def _qmul(a, b):
     return np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2])
 
 
-def command_run(seed, tag="a", num_steps=200, num_commands=6, max_speed=3.0, min_speed=0.0):
+def command_run(seed, tag="a", num_steps=200, num_commands=6, max_speed=3.0, min_speed=0.0, resample=0):
     """one iteration of the reference's command-following test (tools/test_commands.py:56-122 run_test, :131-140 the schedules): a new speed every 200 steps (previous
     +- U[0.4, 1.3], reflected into [0, 3]), half a period later a yaw command of +- U[pi/6, pi/3] applied to the policy's input, phase_add 1.5 above 1.4 m/s; failed when
-    the pelvis drops below 0.4 m.  Returns the reference's row (passed, half-period kind, speed, yaw offset, last speed step, last yaw step)."""
-    rng = np.random.RandomState(seed)
+    the pelvis drops below 0.4 m.  Returns the reference's row (passed, half-period kind, speed, yaw offset, last speed step, last yaw step).
+    resample = R > 0: CassieEnv.step's own random command change, which the harness does not switch off - with probability 1 / R per step the commanded speed becomes
+    U[min, max] (cassie.py:486-487: R = 100 today; the revision that produced the shipped tables is unknown)."""
+    rng = np.random.RandomState(seed); rs = np.random.RandomState(100000 + seed)
     speeds = np.zeros(num_commands); speeds[0] = 0.5
     for i in range(num_commands - 1):
         add = rng.choice([-1, 1]) * rng.uniform(0.4, 1.3)
@@ -134,9 +136,15 @@ def command_run(seed, tag="a", num_steps=200, num_commands=6, max_speed=3.0, min
         st[46], st[47], st[48] = np.sin(2 * np.pi * phase / PHASELEN), np.cos(2 * np.pi * phase / PHASELEN), env.speed
         env.e.step_basic(np.asarray(act(st), dtype=np.float64))
         phase = 0.0 if phase + phase_add > PHASELEN else phase + phase_add
+        if resample and rs.randint(resample) == 0:
+            env.speed = float(rs.uniform(min_speed, max_speed))
         o = env.obs()
         passed = 0 if env.e.get("qpos")[2] < 0.4 else 1
         count += 1
     if passed:
         return [1.0, -1.0, 0.0, 0.0, 0.0, 0.0]
     return [0.0, float(count // (num_steps // 2)), env.speed, orient_add, env.speed - speeds[max(0, speed_ind - 2)], orients[orient_ind - 1]]
+
+
+def command_run_300(seed):
+    return command_run(seed, resample=300)
