@@ -94,6 +94,11 @@ def dev(monkeypatch):
     return torch.device("cpu")
 
 
+# the whole-training-loop goldens (and the two self-consistency twins of the recurrent step / gather) take 0.5 - 5 minutes each under the emulation: part of `APX_EMUL_FULL=1 python -m pytest tests/test_kernel_emulation_learner.py`
+# (results of the last run: profiles/r05_emulation_checks.txt), not of the default CPU suite
+full = pytest.mark.skipif(os.environ.get("APX_EMUL_FULL") != "1", reason="minutes of emulation: APX_EMUL_FULL=1")
+
+
 def _gpu_tests():
     from tests import test_gpu_learner as G
     return G
@@ -156,6 +161,7 @@ def test_emulated_mirror_loss_min_profile(dev):
     _gpu_tests().test_mirror_loss_uses_the_env_clock_columns_min_profile(dev)
 
 
+@full
 def test_emulated_fused_recurrent_step_and_gather(dev):
     G = _gpu_tests()
     G.test_fused_recurrent_step_equals_the_per_launch_chain(dev)
@@ -264,9 +270,7 @@ def _ppo_tests():
     return P
 
 
-# the whole-training-loop goldens take 1.5 - 5 minutes each under the emulation: part of `APX_EMUL_FULL=1 python -m pytest tests/test_kernel_emulation_learner.py`
-# (results of the last run: profiles/r05_emulation_checks.txt), not of the default CPU suite
-full = pytest.mark.skipif(os.environ.get("APX_EMUL_FULL") != "1", reason="minutes of emulation: APX_EMUL_FULL=1")
+
 
 
 @full
