@@ -148,3 +148,34 @@ def command_run(seed, tag="a", num_steps=200, num_commands=6, max_speed=3.0, min
 
 def command_run_300(seed):
     return command_run(seed, resample=300)
+
+
+def mission_run(args):
+    """one trial of the reference's "5k" stress test on the flat terrain (5k_test.py:26-70): the mission's per-step speed / yaw commands (cassie/missions/<name>/
+    command_trajectory_<speed>.pkl, in the fixture) through step_basic with the shipped policy; optional floor friction and foot mass.  Returns (name, speed, passed)."""
+    name, sp, fric, foot_mass = args
+    from oracle import sim as S
+    g = fixture()
+    speeds, orients = g["mission_%s_%s_speed" % (name, sp)].astype(np.float64), g["mission_%s_%s_orient" % (name, sp)].astype(np.float64)
+    act, env = policy("a"), OldCassieEnv()
+    if fric is not None:
+        m = env.e.get("mass")
+        for b in ("left-foot", "right-foot"):
+            m[S.BODY_NAMES.index(b)] = foot_mass
+        env.e.set("mass", m); env.e.set("friction", [fric]); env.e.set_const()
+    env.reset_for_test()
+    phase = 0.0
+    for i in range(len(speeds)):
+        env.speed = float(np.clip(speeds[i], 0.0, 3.0))
+        phase_add = 1.5 if env.speed > 1.4 else 1.0
+        iq = np.array([np.cos(orients[i] / 2), 0.0, 0.0, -np.sin(orients[i] / 2)])
+        st = env.obs()
+        no = _qmul(iq, st[1:5])
+        st[1:5] = -no if no[0] < 0 else no
+        st[15:18] = _qmul(_qmul(iq, np.array([0.0, *st[15:18]])), np.array([iq[0], -iq[1], -iq[2], -iq[3]]))[1:]
+        st[46], st[47], st[48] = np.sin(2 * np.pi * phase / PHASELEN), np.cos(2 * np.pi * phase / PHASELEN), env.speed
+        env.e.step_basic(np.asarray(act(st), dtype=np.float64))
+        phase = 0.0 if phase + phase_add > PHASELEN else phase + phase_add
+        if env.e.get("qpos")[2] < 0.4:
+            return name, sp, False
+    return name, sp, True

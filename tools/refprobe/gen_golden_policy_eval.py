@@ -34,6 +34,22 @@ for tag, name in (("a", "nodelta_neutral_StateEst_symmetry_speed0-3_freq1-2"), (
     ec = np.load(os.path.join(d, "eval_commands.npy"))      # tools/test_commands.py under MuJoCo: 10 000 random command schedules; rows (passed, half-period kind, speed, yaw offset, last speed step, last yaw step)
     assert ec.shape == (10000, 6)
     out[f"{tag}_eval_commands"] = ec.astype(np.float32)
+# the "5k" stress test of policy a under MuJoCo (5k_test.py:19-74; 5k_test.pkl = five pickled lists: pass, terrain, mission, friction, foot mass of 17 328 trials = 2 terrains x
+# 4 missions x 6 mission speeds x 19 frictions x 19 foot masses; the speed of a trial was not stored): the pass fractions on the flat terrain, and the missions' command files
+import pickle
+with open(os.path.join(REF, "trained_models", "nodelta_neutral_StateEst_symmetry_speed0-3_freq1-2", "5k_test.pkl"), "rb") as fh:
+    p5, terr, mis, fric, mass = (pickle.load(fh) for _ in range(5))
+p5, flat = np.array(p5), np.array([t.endswith("cassie.xml") for t in terr])
+assert len(p5) == 17328 == 2 * 4 * 6 * 19 * 19
+MISSIONS, MSPEEDS = ("straight", "curvy", "90_left", "90_right"), (0.5, 0.9, 1.4, 1.9, 2.3, 2.8)
+out["k5_missions"] = np.array(MISSIONS)
+out["k5_flat_pass"] = np.array([p5[flat & (np.array(mis) == m)].mean() for m in MISSIONS])
+out["k5_mission_speeds"] = np.array(MSPEEDS)
+for m in MISSIONS:
+    for sp in MSPEEDS:
+        with open(os.path.join(REF, "cassie", "missions", m, "command_trajectory_%s.pkl" % sp), "rb") as fh:
+            d = pickle.load(fh)
+        out["mission_%s_%s_speed" % (m, sp)] = np.asarray(d["speed"], np.float32); out["mission_%s_%s_orient" % (m, sp)] = np.asarray(d["orient"], np.float32)
 out["protocol"] = np.array([60, 0.5, 3.0, 0.2, 50.0, 10.0])      # simrate, commanded speed, wait [s], push duration [s], first push [N], increment [N] (test_policy.py:30-35, experiment.pkl)
 np.savez_compressed(os.path.join(GOLD, "g24_ref_policy_push_sweep.npz"), **out)
 print("wrote g24_ref_policy_push_sweep.npz")
