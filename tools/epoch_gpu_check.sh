@@ -43,6 +43,7 @@ done
 # the kernel against the reference's MuJoCo-generated tables (golden G24)
 timeout 900 python tools/eval_ref_policy.py push 2>&1 | tail -4 | tee -a "$OUT/summary.txt"
 timeout 900 python tools/eval_ref_policy.py commands 10000 2>&1 | tail -4 | tee -a "$OUT/summary.txt"
+timeout 900 python tools/eval_ref_policy.py missions 2>&1 | tail -5 | tee -a "$OUT/summary.txt"
 for wgs in 32 48 96 128; do      # grid size sweep at minibatch 64
     APX_PPO_EPOCH_WGS=$wgs timeout 600 python bench.py --steps 2 --warmup 1 --minibatch 64 --no_cpu_baseline --epoch_kernel 2> /dev/null | python -c "
 import json, sys

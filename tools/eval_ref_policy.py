@@ -2,6 +2,7 @@
 
     python tools/eval_ref_policy.py push        all 100 directions x 28 phases x 30 push sizes as ONE batch (apex_amd.eval.compute_perturbs) vs eval_perturbs.npy
     python tools/eval_ref_policy.py commands N  N random command schedules of tools/test_commands.py as one batch vs eval_commands.npy (pass rate, where the failures sit)
+    python tools/eval_ref_policy.py missions    the 4 missions x 6 speeds of the "5k" stress test (5k_test.py) on the flat terrain, one env each, vs 5k_test.pkl's pass fractions
 
 The oracle-side twins are tests/test_oracle_env.py::test_g24_* (CPU).  Open question this tool is for (DESIGN.md section 5): at 2 - 3 m/s the oracle's robot passes 0.71 of
 the command schedules, MuJoCo's 0.535 - does the kernel follow the oracle, and which modelling knob (friction, torque-speed limits, ...) moves the number?
@@ -55,6 +56,27 @@ def main():
         print("kernel mean %.1f N | MuJoCo %.1f N | corr cells %.3f, direction means %.3f | mean |diff| %.1f N, max %.0f | identical %d of 2800" % (
             mine.mean(), ref.mean(), np.corrcoef(mine.ravel(), ref.ravel())[0, 1], np.corrcoef(mine.mean(1), ref.mean(1))[0, 1], np.abs(mine - ref).mean(), np.abs(mine - ref).max(), int((mine == ref).sum())))
         print("direction means kernel", np.round(mine.mean(1)[::10]), "\n                MuJoCo", np.round(ref.mean(1)[::10]))
+        return
+    if mode == "missions":
+        names, msp = [str(x) for x in g["k5_missions"]], [float(x) for x in g["k5_mission_speeds"]]
+        cells = [(m, sp) for m in names for sp in msp]
+        n = 64
+        L = max(len(g["mission_%s_%s_speed" % c]) for c in cells)
+        spd = torch.zeros(L, n, device=dev); ori = torch.zeros(L, n, device=dev); ln = torch.zeros(n, dtype=torch.long, device=dev)
+        for i, c in enumerate(cells):
+            a, b = g["mission_%s_%s_speed" % c], g["mission_%s_%s_orient" % c]
+            spd[:len(a), i] = torch.tensor(a, device=dev); ori[:len(b), i] = torch.tensor(b, device=dev); ln[i] = len(a)
+        env = make_env(n); pol = Policy49(g, "a", dev, n)
+        obs = env.reset_for_test(full_reset=True)
+        fell = torch.zeros(n, dtype=torch.bool, device=dev)
+        for t in range(L):
+            pol.speed = spd[t].clamp(0.0, 3.0); pol.phase_add = torch.where(pol.speed > 1.4, 1.5, 1.0)
+            obs = env.step_basic(pol(E._yaw_unrotate_obs(obs, ori[t])))
+            fell |= (t < ln) & (env.get_field("qpos")[:, 2] < 0.4)
+        ok = (~fell[:len(cells)]).cpu().numpy().reshape(len(names), len(msp))
+        for m, row, ref in zip(names, ok, g["k5_flat_pass"]):
+            print("%-9s kernel passes %d of 6 (%s) | MuJoCo pass fraction over 6 speeds x 19 x 19 friction x foot mass %.3f | oracle: straight 6, curvy 6, 90_left 5 (falls at 2.8), 90_right 6" % (
+                m, int(row.sum()), " ".join("ok" if x else "F" for x in row), float(ref)))
         return
     # command following: apex_amd.eval.eval_commands' schedule logic with the policy's own clock / speed inputs
     n_it = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
