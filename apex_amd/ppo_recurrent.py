@@ -235,6 +235,7 @@ class RecurrentPPO:
             n_mb = int(cnt)
         L.sync_old()
         losses, kl_last, epochs_run = None, 0.0, 0
+        self.optimiser_steps = 0      # of this update (bench.py: update time per optimiser step)
         for epoch in range(self.epochs):
             if self.perm_fn is not None:
                 order = np.asarray(self.perm_fn(epoch))
@@ -265,7 +266,7 @@ class RecurrentPPO:
             if self.dist_on:
                 adist.allreduce_mean_(both, group=self.group, world=self.world)          # the KL decision must be the same on every rank
             both = both.cpu().numpy()
-            losses, kl_last = both[:6], float(both[10]); epochs_run += 1
+            losses, kl_last = both[:6], float(both[10]); epochs_run += 1; self.optimiser_steps += n_mb
             if kl_last > 0.02:
                 break
         return losses, kl_last, epochs_run
@@ -287,7 +288,7 @@ class RecurrentPPO:
         ep_rets, ep_lens, _, _ = episode_stats(self.b_rew, ended, z, z)
         steps = self.T * self.N * self.world
         self.total_steps += steps
-        return dict(steps=steps, sample_time=t1 - t0, optimize_time=t2 - t1, losses=losses, kl=kl, epochs=epochs_run, ep_returns=ep_rets, ep_lens=ep_lens)
+        return dict(steps=steps, sample_time=t1 - t0, optimize_time=t2 - t1, losses=losses, kl=kl, epochs=epochs_run, optimiser_steps=self.optimiser_steps, ep_returns=ep_rets, ep_lens=ep_lens)
 
     def train(self, n_itr, logger=None):
         for itr in range(n_itr):

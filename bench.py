@@ -208,8 +208,10 @@ def main_recurrent(a):
     if dist_on:
         adist.timing(True)
     barrier(); t0 = time.time(); samp = opt = 0.0
+    epochs_run = opt_steps = 0
     for _ in range(a.steps):
         out = algo.iteration(); samp += out["sample_time"]; opt += out["optimize_time"]
+        epochs_run += out.get("epochs", a.epochs); opt_steps += out.get("optimiser_steps", 0)
     barrier(); dt = time.time() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=env.device)
     if dist_on:
@@ -227,7 +229,7 @@ def main_recurrent(a):
                                      "envs_per_gpu": n_envs, "rollout_len": T, "minibatch_trajectories": min(1024, n_envs // 2), "epochs": a.epochs, "mirror_loss": True,
                                      "parallelism": f"dp{world} (env shards; optimiser steps per epoch agreed by a MAX all-reduce, 1 gradient all-reduce per step)"},
                           "sample_s": round(samp / a.steps, 3), "optimize_s": round(opt / a.steps, 3),
-            "optimiser_step_us": round(opt / max(1, epochs_run * ((a.rollout_len * a.n_envs) // min(a.minibatch, a.rollout_len * a.n_envs))) * 1e6, 2), "epochs_run_per_step": round(epochs_run / a.steps, 2),      # update time per optimiser step over the epochs that ran (the KL test of ppo.py:449 may end an iteration's update early)
+                          "optimiser_step_us": round(opt / opt_steps * 1e6, 2) if opt_steps else None, "epochs_run_per_step": round(epochs_run / a.steps, 2),      # update time per optimiser step (whole-trajectory minibatches) over the epochs that ran
                           "collectives": {"rccl_ranks_seen": torch.distributed.get_world_size() if dist_on else 1, "backend": torch.distributed.get_backend() if dist_on else None,
                                           "allreduce_calls_per_step": round(ar_calls / a.steps, 1), "allreduce_ms_per_step": round(ar_ms / a.steps, 3),
                                           "gradient_floats": int(algo.learner.grad_flat.numel()), "per_rank": per_rank}}))
