@@ -90,6 +90,7 @@ SIGNATURES = {
     "apx_td3_updates_supported": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.c_int]),
     "apx_td3_updates_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int]),
     "apx_td3_updates": (C.c_int, [C.POINTER(Td3Args), c_ptr]),
+    "apx_grid_barrier_selftest": (C.c_int, [C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr]),
     "apx_clip_adam": (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_int, c_ptr, c_ptr]),
     "apx_env_default_cfg": (None, [C.POINTER(EnvCfg)]),

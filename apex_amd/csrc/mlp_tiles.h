@@ -3,6 +3,7 @@
 // straight into the MFMA registers.  gfx950 only.
 #pragma once
 #include "apx_common.h"
+#include <cstdlib>
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
@@ -84,6 +85,32 @@ __device__ __forceinline__ floatx4 rows_tile_nb(const float* Ac, int lda, const 
 }
 __device__ __forceinline__ floatx4 rows_tile(const float* Ac, int lda, const float* Bc, int ldb, int chunks, float* asum) {
     return (chunks & 7) == 0 ? rows_tile_nb<8>(Ac, lda, Bc, ldb, chunks, asum) : rows_tile_nb<4>(Ac, lda, Bc, ldb, chunks, asum);
+}
+
+// Host side: launch of a persistent kernel whose workgroups wait for each other at grid_barrier.  The grid must be resident as a whole: checked against the occupancy
+// the runtime reports for THIS kernel (registers, LDS) before anything is enqueued, and launched as a cooperative kernel (the runtime refuses a grid it cannot hold
+// resident and serialises it against other cooperative launches of the device).  APX_COOP_LAUNCH=0 keeps the occupancy check and uses a plain launch (A/B knob).
+// The barrier's watchdog stays as the second line behind both.
+template <class Args>
+inline int launch_resident(void (*kernel)(Args), int G, int block, hipStream_t s, Args& S, const char* what) {
+    int dev = 0, cus = 0, coop = 0, per_cu = 0;
+    APX_HIP(hipGetDevice(&dev));
+    APX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    APX_HIP(hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev));
+    APX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0));
+    if ((long)per_cu * cus < G) {
+        apx_set_error("%s: a grid of %d workgroups cannot be resident at once on this device (%d CUs x %d workgroups)", what, G, cus, per_cu);
+        return APX_E_ARG;
+    }
+    static const bool plain = getenv("APX_COOP_LAUNCH") && atoi(getenv("APX_COOP_LAUNCH")) == 0;
+    if (coop && !plain) {
+        void* params[1] = {(void*)&S};
+        APX_HIP(hipLaunchCooperativeKernel(kernel, dim3(G), dim3(block), params, 0u, s));
+    } else {
+        hipLaunchKernelGGL(kernel, dim3(G), dim3(block), 0, s, S);
+        APX_LAUNCH_CHECK();
+    }
+    return APX_OK;
 }
 
 }  // namespace tiles

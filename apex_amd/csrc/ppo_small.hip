@@ -123,11 +123,14 @@ __global__ __launch_bounds__(256) void ppo_small_epoch_kernel(SmallArgs S) {
             const int tt = ni ? t - nta : t, r0 = (tt >> 4) << 4, n0 = (tt & 15) << 4;
             const float* Xr = n.X + (size_t)(r0 + c) * SXP + 4 * g;
             const float* Wr = W0(n) + (size_t)(n0 + c) * D;
+            const int lim = D - 4 * g;
             const floatx4 acc = wave_tile<4, false>(0, 4,
                 [&](int kc, float (&a)[4]) { ld4(Xr + 16 * kc, a); },
-                [&](int kc, float (&b)[4]) {      // (columns D..63 of X are zero: what the loads beyond a W0 row fetch - the next row, b0, W1: all inside the block - is multiplied by 0)
+                // columns D..63 of the padded contraction: the load stays inside the parameter block (what lies behind a W0 row is the next row, b0, W1) and the operand
+                // is an exact zero by a select (no exec-mask region; 0 x a non-finite b0 / W1 entry would be NaN)
+                [&](int kc, float (&b)[4]) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) b[j] = Wr[16 * kc + 4 * g + j];
+                    for (int j = 0; j < 4; ++j) { const float w = Wr[16 * kc + 4 * g + j]; b[j] = 16 * kc + j < lim ? w : 0.f; }
                 }, nullptr);
             const float bias = B0(n)[n0 + c];
 #pragma unroll
@@ -451,7 +454,5 @@ extern "C" int apx_ppo_epoch(const apx_ppo_args* a, const int64_t* perm, int64_t
     int G = tiles <= 256 ? 64 : SMAXG;
     if (forced >= 1 && forced <= SMAXG) G = forced;
     APX_HIP(hipMemsetAsync(a->workspace, 0, w.bytes, s));      // the barrier counter and the padding rows of the row buffers
-    hipLaunchKernelGGL(ppo_small_epoch_kernel, dim3(G), dim3(256), 0, s, S);
-    APX_LAUNCH_CHECK();
-    return APX_OK;
+    return tiles::launch_resident(ppo_small_epoch_kernel, G, 256, s, S, "apx_ppo_epoch");
 }

@@ -88,12 +88,13 @@ __global__ __launch_bounds__(256) void td3_small_kernel(TArgs S) {
             floatx4 acc; float bias;
             if (layer == 0) {
                 const float* Xr = n.X + (size_t)(r0 + c) * TXP + 4 * g;
+                const int lim = n.D - 4 * g;
                 const float* Wr = n.p + (size_t)(n0 + c) * n.D;
                 acc = wave_tile<4, false>(0, 4,
                     [&](int kc, float (&a)[4]) { ld4(Xr + 16 * kc, a); },
-                    [&](int kc, float (&b)[4]) {      // (columns D.. of X are zero: what the loads beyond a W0 row fetch - the next row, b0, W1 - is multiplied by 0)
+                    [&](int kc, float (&b)[4]) {      // columns D.. of the padded contraction: the load stays inside the parameter block (next row, b0, W1), the operand is an exact zero (see ppo_small.hip)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) b[j] = Wr[16 * kc + 4 * g + j];
+                        for (int j = 0; j < 4; ++j) { const float w = Wr[16 * kc + 4 * g + j]; b[j] = 16 * kc + j < lim ? w : 0.f; }
                     }, nullptr);
                 bias = n.p[oB0(n) + n0 + c];
             } else {
@@ -446,7 +447,5 @@ extern "C" int apx_td3_updates(const apx_td3_args* a, void* stream) {
     int G = a->B <= 64 ? 64 : TMAXG;      // every workgroup resident at once (the barrier spins): far below the 256 CUs
     if (forced >= 1 && forced <= TMAXG) G = forced;
     APX_HIP(hipMemsetAsync(a->workspace, 0, w.bytes, s));      // the barrier counter, the padding rows / columns of the row buffers
-    hipLaunchKernelGGL(td3_small_kernel, dim3(G), dim3(256), 0, s, S);
-    APX_LAUNCH_CHECK();
-    return APX_OK;
+    return tiles::launch_resident(td3_small_kernel, G, 256, s, S, "apx_td3_updates");
 }

@@ -230,6 +230,12 @@ class PPO:
         return ret, ep_rets, ep_lens
 
     # ------------------------------------------------------------------------------------------ optimisation
+    def epoch_kernel_in_use(self, mb):
+        """whether update() runs an epoch's optimiser steps of `mb` rows as ONE launch (apx_ppo_epoch).  Never with a process group: the gradient all-reduce sits between
+        the backward and the Adam step of every optimiser step, so an N > 1 run always takes the per-step launches - whatever --epoch_kernel says (bench.py prints this
+        decision in config, tests/test_multirank_gloo.py holds the exclusion)."""
+        return bool(self.epoch_kernel and not self.dist_on and mb <= self.epoch_kernel_max_mb and self.learner.epoch_supported(mb))
+
     def update(self, ret):
         L = self.learner
         B = self.T * self.N
@@ -246,7 +252,7 @@ class PPO:
                 perm = self.perm_fn(epoch)
             acc = torch.zeros(6, dtype=torch.float64, device=self.device)
             nb = B // mb                                                                     # drop_last=True, ppo.py:416
-            if self.epoch_kernel and not self.dist_on and mb <= self.epoch_kernel_max_mb and L.epoch_supported(mb):
+            if self.epoch_kernel_in_use(mb):
                 scal_all = L.epoch(obs, act, ret, adv, mu, perm[:nb * mb].contiguous(), mb, mirror=self.mirror)      # [nb, 6]: every step's scalars, one launch
                 acc, scal = scal_all.sum(0), scal_all[-1]
                 if self.trace is not None:

@@ -94,12 +94,14 @@ class TD3:
 
     @torch.no_grad()
     def collect_and_train(self, steps):
-        """`steps` lock-step env steps; after each one the N new transitions enter the replay and `updates_per_step` updates run."""
+        """`steps` lock-step env steps and `steps x updates_per_step` updates.  Default (HIP env, hidden 256, no parameter noise): the schedule of sync_td3.py:300-313 -
+        the whole collection runs first with the policy FIXED (one launch, apx_rollout_td3), its transitions enter the replay, then all updates run.  The fallback loop
+        (parameter noise, other widths, envs without the C handle) interleaves `updates_per_step` updates behind every env step instead: same number of steps and
+        updates, a different schedule - results of the two paths are not interchangeable."""
         L, env = self.learner, self.env
         if self.obs is None:
             self.obs = env.reset().clone()
         stats = torch.zeros(3, dtype=torch.float64, device=self.device); n_upd = 0
-        ep_done = 0
         if self.param_noise:
             self.perturb_actor_parameters()
         # The HIP env: the `steps` collection steps as ONE launch with the policy fixed (apx_rollout_td3 - what sync_td3.py does: collect_experience runs the current
@@ -134,6 +136,9 @@ class TD3:
                 pn = torch.randn(U, Bz, 10, device=self.device, generator=self.gen) * self.policy_noise
                 R = self.replay
                 st = L.updates(R.s, R.s2, R.a, R.r, R.nd, ind, pn, self.it, self.discount, self.tau, self.noise_clip, self.policy_freq)
+                if not bool(torch.isfinite(st).all()):      # the grid barrier's watchdog ends a launch that could not finish with NaN statistics AFTER parameters were partly updated
+                    raise FloatingPointError("apx_td3_updates returned non-finite statistics (its workgroups were not resident together, or the update diverged): "
+                                             "the networks are not valid any more; re-run from a checkpoint without --td3_one_launch")
                 stats += st[:, :3].sum(0); n_upd += U; self.it += U
                 n_todo = 0
             for _ in range(n_todo):

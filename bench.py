@@ -351,7 +351,7 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Cassie-v0 PPO, 4096 batched envs/GPU, 2x256 MLP actor/critic (BASELINE.json configs[1])",
-                       "envs_per_gpu": a.n_envs, "rollout_len": a.rollout_len, "simrate": 50, "minibatch": a.minibatch, "optimiser_steps_as_one_launch_per_epoch": bool(algo.epoch_kernel and not dist_on and a.minibatch <= algo.epoch_kernel_max_mb),
+                       "envs_per_gpu": a.n_envs, "rollout_len": a.rollout_len, "simrate": 50, "minibatch": a.minibatch, "optimiser_steps_as_one_launch_per_epoch": algo.epoch_kernel_in_use(mb_rows), "epoch_kernel_requested": bool(a.epoch_kernel),
                        "epochs": a.epochs, "mirror_loss": True, "dynamics_randomization": True, "eval_rollouts": False,
                        "parallelism": f"dp{world} (env shards, 1 RCCL grad all-reduce per optimiser step)"},
             "sampling_env_steps_per_s": round(a.steps * a.rollout_len * a.n_envs * world / max(samp, 1e-9), 1),

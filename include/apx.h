@@ -210,6 +210,11 @@ typedef struct apx_td3_args {
 int apx_td3_updates_supported(int64_t B, int D, int H, int A);
 size_t apx_td3_updates_workspace_bytes(int64_t B, int64_t U, int D, int H, int A);
 int apx_td3_updates(const apx_td3_args* args, void* stream);
+/* Diagnostic of the grid-wide barrier the two persistent launches above rely on (no reference counterpart: the reference's optimiser steps are separate torch calls):
+ * `workgroups` (1..256) resident workgroups run `phases` phases; in each one workgroup overwrites n_words words with the phase's pattern by plain stores, all pass the
+ * barrier, every workgroup reads the words back by plain loads, second barrier.  workspace [2 + n_words] u32 [dev], result [4] u64 [dev]: words read stale (must be 0),
+ * watchdog flag (must be 0), phases completed by workgroup 0, sum over workgroups of phases completed (must be workgroups x phases). */
+int apx_grid_barrier_selftest(int workgroups, int phases, int n_words, unsigned* workspace, unsigned long long* result, void* stream);
 
 /* second half when grad_only=1 was used: global-norm clip (clip_grad_norm_, ppo.py:326,335) + Adam (ppo.py:355-356)
  * on an (all-reduced) gradient; scale multiplies the gradient first (1/world_size for an averaged sum). */

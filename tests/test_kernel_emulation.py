@@ -147,3 +147,40 @@ def test_epoch_kernel_reruns_with_three_workgroups_are_bit_identical(emu):
         assert np.array_equal(scal, outs[0][0])
         for k in bufs:
             assert np.array_equal(bufs[k], outs[0][1][k]), k
+
+
+def _barrier_selftest(lib, wgs, phases, words):
+    lib.apx_grid_barrier_selftest.restype = C.c_int
+    lib.apx_grid_barrier_selftest.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    ws = _aligned(2 + words, np.uint32); res = _aligned(4, np.uint64)
+    lib.apx_emul_set_workgroups(wgs)
+    rc = lib.apx_grid_barrier_selftest(wgs, phases, words, ws.ctypes.data_as(C.c_void_p), res.ctypes.data_as(C.c_void_p), None)
+    assert rc == 0, lib.apx_emul_last_error()
+    return [int(x) for x in res], ws
+
+
+def test_grid_barrier_selftest_with_eight_workgroups(emu):
+    """The barrier's stress kernel (apx_grid_barrier_selftest, the GPU twin is tests/test_gpu_learner.py::test_grid_barrier_under_stress) with eight concurrent workgroups =
+    eight processes of 256 fibers on one shared counter: 300 phases x 2 barriers, every word of every phase read back by every workgroup.  What it pins here: the arrival
+    arithmetic (targets as multiples of the grid size on a counter that is never reset), writer rotation, that no workgroup runs ahead of a phase."""
+    res, ws = _barrier_selftest(emu, 8, 300, 777)
+    assert res == [0, 0, 300, 8 * 300], res
+    assert int(ws[0]) == 8 * 2 * 300 and int(ws[1]) == 0      # arrivals counted, watchdog silent
+
+
+def test_grid_barrier_selftest_with_one_workgroup(emu):
+    """degenerate grid: one workgroup is its own writer in every phase; all 50 phases complete, nothing stale, the word block was written"""
+    res, ws = _barrier_selftest(emu, 1, 50, 64)
+    assert res == [0, 0, 50, 50]
+    assert np.count_nonzero(ws[2:]) >= 60
+
+
+def test_grid_barrier_under_thread_sanitizer():
+    """The barrier's source with workgroups as THREADS under ThreadSanitizer (tools/hipemu/tsan_barrier.sh): 8 workgroups x 3000 phases and 3 x 20000, the word block
+    written and read by plain accesses that only the barrier orders - no report; the same build with the arrival counted RELAXED instead of RELEASE is reported as a
+    data race (positive control).  The shim's header states what this does not model (stand-alone fences, cache scopes: the GPU stress test's job)."""
+    if not os.path.exists(CLANG):
+        pytest.skip("no host clang++")
+    r = subprocess.run(["bash", os.path.join(EMU, "tsan_barrier.sh")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert r.stdout.count("stale 0 watchdog 0") == 2 and "positive control: the barrier without its release is reported" in r.stdout, r.stdout

@@ -88,3 +88,71 @@ def test_sharding_arithmetic():
     assert adist.shard_env_base(3, 4096) == 12288
     assert adist.rollout_len(5096, 4096, 1) == 2 and adist.rollout_len(131072 * 8, 4096, 8) == 32
     assert adist.rollout_len(10, 4096, 8) == 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# apx_ppo_epoch (an epoch's optimiser steps as one launch) has no place for a gradient all-reduce: with a process group PPO.update must take the per-step launches even when
+# the epoch kernel was asked for.  Two gloo ranks run PPO.update on the EMULATED kernel sources (tests/test_kernel_emulation_learner.py's redirection, set by hand in the
+# worker) with epoch_kernel=True on different halves of a batch: no launch of ppo_small_epoch_kernel on either rank, the per-step kernels ran, both ranks end with
+# bit-identical parameters (every step's gradient was all-reduced), and the decision the bench line prints says "not in use".
+def _epoch_exclusion_worker(rank, world, port, out):
+    import contextlib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    from apex_amd import _lib, engine
+    from apex_amd.ppo import PPO
+    from tests import test_kernel_emulation_learner as E
+    from golden_util import epoch_case_inputs
+    lib = E.emulated_library(); lib.apx_emul_set_workgroups(0)
+    _lib._lib = lib
+    engine._need_gpu = lambda *ts: None; engine._stream = lambda: None
+    ns = E._NoStream
+    torch.cuda.current_stream = lambda *a, **k: ns(); torch.cuda.Stream = lambda *a, **k: ns(); torch.cuda.Event = lambda *a, **k: ns()
+    torch.cuda.stream = lambda s: contextlib.nullcontext(); torch.cuda.synchronize = lambda *a, **k: None
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    inp = epoch_case_inputs(0)
+    args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=64, epochs=1, num_steps=2 * 64 * world, max_traj_len=400,
+                max_grad_norm=0.05, mirror=True, std_dev=-1.5, seed=0, epoch_kernel=True, prepare_resets=False)
+    algo = PPO(args, "/tmp/apx_test_unused", E._GridOnlyEnv(dev), rank=rank, world_size=world, group=dist.group.WORLD)
+    L_ = algo.learner
+    L_.actor.load_list(inp["actor"]); L_.critic.load_list(inp["critic"])
+    T, N = algo.T, algo.N
+    assert (T, N) == (2, 64) and algo.epoch_kernel and algo.dist_on
+    r2 = np.random.RandomState(40 + rank)                                    # each rank its own shard
+    obs = r2.randn(T, N, 50).astype(np.float32); ph = r2.rand(T, N) * 2 * np.pi
+    obs[..., 46] = np.sin(ph); obs[..., 47] = np.cos(ph)
+    algo.b_obs.copy_(torch.tensor(obs))
+    algo.b_mu.copy_(L_.actor.forward(algo.b_obs.view(T * N, 50), L_.obs_mean, L_.obs_std).view(T, N, 10))
+    algo.b_act.copy_(algo.b_mu + torch.tensor(r2.randn(T, N, 10).astype(np.float32)) * algo.fixed_std)
+    algo.b_val.copy_(torch.tensor(r2.randn(T, N).astype(np.float32)))
+    ret = torch.tensor(r2.randn(T, N).astype(np.float32))
+    perm = torch.tensor(np.random.RandomState(5).permutation(T * N).astype(np.int64))
+    algo.perm_fn = lambda epoch: perm
+    before = {k: E.launches(k) for k in ("ppo_small_epoch_kernel", "cooperative", "mlp_fused_fwd_kernel", "bwd_head_kernel")}
+    in_use = algo.epoch_kernel_in_use(64)
+    losses, kl, epochs_run = algo.update(ret)
+    d = {k: E.launches(k) - v for k, v in before.items()}
+    flat = torch.cat([L_.actor.params, L_.critic.params]).clone()
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    if rank == 0:
+        out.put((in_use, d, bool(torch.equal(both[0], both[1])), float((flat - torch.tensor(np.concatenate([np.asarray(p, np.float32).ravel() for p in inp["actor"] + inp["critic"]]))).abs().max()), L_.t, epochs_run))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_epoch_kernel_is_excluded_when_a_process_group_is_given():
+    import pytest
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("no host clang++ (kernel emulation)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_epoch_exclusion_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    in_use, d, same, moved, adam_t, epochs_run = q.get(timeout=900)
+    [p.join(timeout=120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert in_use is False
+    assert d["ppo_small_epoch_kernel"] == 0 and d["cooperative"] == 0, d            # the one-launch path was NOT taken ...
+    assert d["mlp_fused_fwd_kernel"] > 0 and d["bwd_head_kernel"] >= 2, d             # ... the per-step launches were (2 optimiser steps of 64 rows)
+    assert same and moved > 0 and adam_t == 2 and epochs_run == 1

@@ -7,6 +7,7 @@ static char g_err[512];
 void apx_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap); }
 extern "C" const char* apx_emul_last_error() { return g_err; }
 #include "../../apex_amd/csrc/ppo_small.hip"
+#include "../../apex_amd/csrc/barrier_selftest.hip"      // the grid barrier under stress, same emulation (forked workgroups on MAP_SHARED buffers)
 // the grid of the next launches (the kernel's host code reads APX_PPO_EPOCH_WGS once; the emulation overrides the launch instead)
 extern "C" void apx_emul_set_workgroups(int g) { hipemu::g_force_grid = g; }
 extern "C" int apx_emul_last_grid() { return (int)hipemu::g_grid.x; }

@@ -157,6 +157,18 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
 #define blockDim (hipemu::g_block)
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) (hipemu::g_launches[#kern] += 1, hipemu::launch(grid, block, [=]() { kern(__VA_ARGS__); }))
 
+// the residency queries and the cooperative launch of tiles::launch_resident (mlp_tiles.h): the emulated device holds what the test asks for (g_force_grid workgroups)
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount, hipDeviceAttributeCooperativeLaunch };
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int) { *v = a == hipDeviceAttributeMultiprocessorCount ? 256 : 1; return hipSuccess; }
+template <class F> inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 1; return hipSuccess; }
+template <class A> inline hipError_t hipLaunchCooperativeKernel(void (*f)(A), dim3 grid, dim3 block, void** params, unsigned, hipStream_t) {
+    const A a = *(const A*)params[0];
+    hipemu::g_launches["cooperative"] += 1;
+    hipemu::launch(grid, block, [=]() { f(a); });
+    return hipSuccess;
+}
+
 template <class T> inline T hipemu_atomic_add(T* p, T v) {
     T old, nw;
     __atomic_load(p, &old, __ATOMIC_SEQ_CST);
@@ -167,6 +179,7 @@ inline float atomicAdd(float* p, float v) { return hipemu_atomic_add(p, v); }
 inline double atomicAdd(double* p, double v) { return hipemu_atomic_add(p, v); }
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 
 inline void __syncthreads() { hipemu::g_cur->wave->want_barrier = true; hipemu::yield(); }
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
