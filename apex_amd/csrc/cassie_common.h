@@ -26,7 +26,7 @@ template <int B, int E, class F> __device__ __forceinline__ void srfor(F&& f) { 
 // Bit pattern of a float, opaque to the optimiser.  The env kernels are built with -ffast-math; there LLVM recognises `(bits & 0x7f800000) == 0x7f800000` on
 // a plain bitcast as "is NaN or inf" and folds it to false (round 3: the disassembly held no trace of the round-2 divergence guards).  The empty asm
 // hides where the integer came from.
-__device__ __forceinline__ unsigned fbits(float v) { unsigned u = __float_as_uint(v); asm volatile("" : "+v"(u)); return u; }
+__device__ __forceinline__ unsigned fbits(float v) { unsigned u = __float_as_uint(v); APX_PIN("+v"(u)); return u; }
 __device__ __forceinline__ bool nonfinite(float v) { return (fbits(v) & 0x7f800000u) == 0x7f800000u; }      // NaN or +-inf
 
 struct V3 { float x, y, z; };

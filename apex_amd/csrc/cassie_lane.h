@@ -16,54 +16,6 @@
 namespace c4 {
 static_assert(L4_WK + WK_TOTAL <= L4_ROWS && L4_ROWS % 4 == 0 && L4_ROWS + 704 <= L4_ES && L4_ES % 64 == 16, "per-env LDS layout");
 
-// v_rcp_f32 (1 ulp): __frcp_rn and '/' expand to the ~10-instruction correctly rounded division sequence
-__device__ __forceinline__ float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
-// The workgroup is ONE wave: LDS operations of a wave are processed in issue order, so a write -> read hand-off between lanes needs
-// no s_barrier / s_waitcnt drain, only a fence that keeps the compiler from reordering across it.
-__device__ __forceinline__ void wsync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-template <int CTRL> __device__ __forceinline__ float dpp(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
-}
-// acc -= bcast_K(acc) * m with the row broadcast as the DPP source of the fmac (see factor_lane for the hazard discipline these need)
-template <int K> __device__ __forceinline__ void fnmac_bcast(float& acc, float m) {
-    asm volatile("v_fmac_f32_dpp %0, %0, -%1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(m), "n"(K));
-}
-// one step of a triangular solve on the two leg slots at once: a_s -= bcast_K(a_s) * m_s.  Each slot's chain reads through DPP what it wrote one step
-// earlier: the other slot's instruction and the s_nop are the two wait states that needs (the FIRST step of a chain is preceded by solve_fence)
-template <int K> __device__ __forceinline__ void solve_step2(float& a0, float& a1, float m0, float m1) {
-    asm volatile("s_nop 0\n\tv_fmac_f32_dpp %0, %0, -%2 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\tv_fmac_f32_dpp %1, %1, -%3 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
-                 : "+v"(a0), "+v"(a1) : "v"(m0), "v"(m1), "n"(K));
-}
-// acc += bcast_K(src) * m / bcast_K(src) * m (src is not written by these: the only hazard is a compiler-generated definition of src right in front of
-// its first DPP read, which the caller's fence excludes)
-template <int K> __device__ __forceinline__ void fmac_bcast(float& acc, float src, float m) {
-    asm("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(K));
-}
-template <int K> __device__ __forceinline__ float mul_bcast(float src, float m) {
-    float r;
-    asm("v_mul_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "v"(m), "n"(K));
-    return r;
-}
-template <int K> __device__ __forceinline__ void fnmac_bcast3(float& acc, float src, float m) {
-    asm("v_fmac_f32_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(m), "n"(K));
-}
-// acc += row_shr:N(x) * x (lanes without a source N places down contribute 0)
-template <int N> __device__ __forceinline__ void fmac_shr(float& acc, float x) {
-    asm("v_fmac_f32_dpp %0, %1, %1 row_shr:%2 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "n"(N));
-}
-__device__ __forceinline__ void solve_fence(float& a0, float& a1) { asm volatile("s_nop 1" : "+v"(a0), "+v"(a1)); }
-template <int K> __device__ __forceinline__ float rcp_bcast(float x) {
-    float r;
-    asm volatile("v_rcp_f32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf\n\ts_nop 0" : "=v"(r) : "v"(x), "n"(K));
-    return r;
-}
-// d = (a.y, a.y) * b + c as ONE v_pk_fma_f32: op_sel takes the high half of the pair `a` for both result lanes
-typedef float f2pk __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2pk pk_fma_hi(f2pk a, f2pk b, f2pk c) {
-    f2pk d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
 // all-lanes sum over the 16-lane row (butterfly: every lane ends with the bit-identical total)
 __device__ __forceinline__ float red16(float t) {
     t += dpp<0xB1>(t);      // quad_perm [1,0,3,2]
@@ -442,7 +394,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             const float* p = xb + XB_SZ * dbl;
             f2 w[16];
             sfor<0, 16>([&](auto K) { w[K] = f2{p[2 * K], p[2 * K + 1]}; });
-            asm volatile("" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]), "+v"(w[10]),
+            APX_PIN("+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]), "+v"(w[10]),
                          "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]));
             c.m = sel2(leg, w[0], splat(pcrb.m)); c.h = {sel2(leg, w[1], splat(pcrb.h.x)), sel2(leg, w[2], splat(pcrb.h.y)), sel2(leg, w[3], splat(pcrb.h.z))};
             sfor<0, 6>([&](auto K) { c.I[K] = sel2(leg, w[4 + K], splat(pcrb.I[K])); });
@@ -515,7 +467,7 @@ __device__ __forceinline__ void stage_tree_lane(const St& S, float* xb) {
             fa[sd][0] = fv.a.x[sd]; fa[sd][1] = fv.a.y[sd]; fa[sd][2] = fv.a.z[sd]; fa[sd][3] = fv.l.x[sd]; fa[sd][4] = fv.l.y[sd]; fa[sd][5] = fv.l.z[sd];
         });
         // the axes are read through DPP by inline asm the hazard recogniser cannot see: no compiler-generated definition right in front of the first read
-        asm volatile("s_nop 1" : "+v"(ca[0][0]), "+v"(ca[0][1]), "+v"(ca[0][2]), "+v"(ca[0][3]), "+v"(ca[0][4]), "+v"(ca[0][5]),
+        APX_HAZARD_FENCE("+v"(ca[0][0]), "+v"(ca[0][1]), "+v"(ca[0][2]), "+v"(ca[0][3]), "+v"(ca[0][4]), "+v"(ca[0][5]),
                                  "+v"(ca[1][0]), "+v"(ca[1][1]), "+v"(ca[1][2]), "+v"(ca[1][3]), "+v"(ca[1][4]), "+v"(ca[1][5]));
         sfor<0, 9>([&](auto Jn) {
             constexpr int j = ANC[Jn];
@@ -650,7 +602,7 @@ __device__ __forceinline__ void factor_lane(const St& S, const LaneIdx& X, float
     // column, the other columns, pelvis couplings of leg 0, next pivot's reciprocal, pelvis couplings of leg 1), the fence below claims every register so
     // that no compiler-generated definition can sit right in front of its first DPP read, and the reciprocal carries its own wait state for the
     // transcendental-forwarding rule of gfx940+.
-#define APX_FENCE19(sd) asm volatile("s_nop 1" : "+v"(R[sd][0]), "+v"(R[sd][1]), "+v"(R[sd][2]), "+v"(R[sd][3]), "+v"(R[sd][4]), "+v"(R[sd][5]), "+v"(R[sd][6]), \
+#define APX_FENCE19(sd) APX_HAZARD_FENCE("+v"(R[sd][0]), "+v"(R[sd][1]), "+v"(R[sd][2]), "+v"(R[sd][3]), "+v"(R[sd][4]), "+v"(R[sd][5]), "+v"(R[sd][6]), \
         "+v"(R[sd][7]), "+v"(R[sd][8]), "+v"(R[sd][9]), "+v"(R[sd][10]), "+v"(R[sd][11]), "+v"(R[sd][12]),                                               \
         "+v"(P[sd][0]), "+v"(P[sd][1]), "+v"(P[sd][2]), "+v"(P[sd][3]), "+v"(P[sd][4]), "+v"(P[sd][5]))
     APX_FENCE19(0); APX_FENCE19(1);
@@ -1265,7 +1217,7 @@ __device__ __forceinline__ void rows_lane(const St& S, const FacRegs& FR, LegRow
             const int ll = l < 13 ? l : 12, lp = l < 6 ? l : 5;
             sfor<0, 6>([&](auto I) { cdl[I] = S.W(WK_CDOF + 6 * (6 + 13 * LEG) + 6 * ll + I); cdp[I] = S.W(WK_CDOF + 6 * lp + I); });
         }
-        asm volatile("s_nop 1" : "+v"(cdl[0]), "+v"(cdl[1]), "+v"(cdl[2]), "+v"(cdl[3]), "+v"(cdl[4]), "+v"(cdl[5]),
+        APX_HAZARD_FENCE("+v"(cdl[0]), "+v"(cdl[1]), "+v"(cdl[2]), "+v"(cdl[3]), "+v"(cdl[4]), "+v"(cdl[5]),
                                  "+v"(cdp[0]), "+v"(cdp[1]), "+v"(cdp[2]), "+v"(cdp[3]), "+v"(cdp[4]), "+v"(cdp[5]));
         sfor<0, 19>([&](auto C) {
             constexpr int c = C, src = c < 6 ? c : c - 6;
@@ -1284,7 +1236,7 @@ __device__ __forceinline__ void rows_lane(const St& S, const FacRegs& FR, LegRow
     PROF2(26);
     const float nn = whiten_regs<LEG>(FR, J);
     // the next reader takes J through DPP (row_shr) and cannot see the asm writes
-    asm volatile("s_nop 1" : "+v"(J[0]), "+v"(J[1]), "+v"(J[2]), "+v"(J[3]), "+v"(J[4]), "+v"(J[5]), "+v"(J[6]), "+v"(J[7]), "+v"(J[8]), "+v"(J[9]), "+v"(J[10]), "+v"(J[11]),
+    APX_HAZARD_FENCE("+v"(J[0]), "+v"(J[1]), "+v"(J[2]), "+v"(J[3]), "+v"(J[4]), "+v"(J[5]), "+v"(J[6]), "+v"(J[7]), "+v"(J[8]), "+v"(J[9]), "+v"(J[10]), "+v"(J[11]),
                  "+v"(J[12]), "+v"(J[13]), "+v"(J[14]), "+v"(J[15]), "+v"(J[16]), "+v"(J[17]), "+v"(J[18]));
     out.vel = vel; out.ju = ju; out.jw = jw; out.nn = nn;
     PROF2(27);
@@ -1369,8 +1321,8 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, FacRegs& FR, fl
     {   // every register the row stage reads through DPP: fenced once against compiler-generated definitions right in front of the first read
 #define APX_F13(a) "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12])
 #define APX_F6(a) "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5])
-        asm volatile("s_nop 1" : APX_F13(FR.Lr[0]), APX_F6(FR.w[0]), "+v"(FR.disq[0]), "+v"(FR.qs.a[0]), "+v"(FR.qv.a[0]), "+v"(FR.qw.a[0]));
-        asm volatile("s_nop 1" : APX_F13(FR.Lr[1]), APX_F6(FR.w[1]), "+v"(FR.disq[1]), "+v"(FR.qs.a[1]), "+v"(FR.qv.a[1]), "+v"(FR.qw.a[1]));
+        APX_HAZARD_FENCE(APX_F13(FR.Lr[0]), APX_F6(FR.w[0]), "+v"(FR.disq[0]), "+v"(FR.qs.a[0]), "+v"(FR.qv.a[0]), "+v"(FR.qw.a[0]));
+        APX_HAZARD_FENCE(APX_F13(FR.Lr[1]), APX_F6(FR.w[1]), "+v"(FR.disq[1]), "+v"(FR.qs.a[1]), "+v"(FR.qv.a[1]), "+v"(FR.qw.a[1]));
 #undef APX_F13
 #undef APX_F6
     }
@@ -1432,7 +1384,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, FacRegs& FR, fl
     {
         // every product takes its broadcast operand through DPP inside the multiply-add (v_fmac_f32_dpp): 2 instructions per leg column and source lane,
         // 4 per pelvis column, where a separate v_mov_b32_dpp per broadcast + packed fmas took 3 and 4
-#define APX_FENCE19J(L) asm volatile("s_nop 1" : "+v"(L.J[0]), "+v"(L.J[1]), "+v"(L.J[2]), "+v"(L.J[3]), "+v"(L.J[4]), "+v"(L.J[5]), "+v"(L.J[6]), "+v"(L.J[7]), \
+#define APX_FENCE19J(L) APX_HAZARD_FENCE("+v"(L.J[0]), "+v"(L.J[1]), "+v"(L.J[2]), "+v"(L.J[3]), "+v"(L.J[4]), "+v"(L.J[5]), "+v"(L.J[6]), "+v"(L.J[7]), \
         "+v"(L.J[8]), "+v"(L.J[9]), "+v"(L.J[10]), "+v"(L.J[11]), "+v"(L.J[12]), "+v"(L.J[13]), "+v"(L.J[14]), "+v"(L.J[15]), "+v"(L.J[16]), "+v"(L.J[17]), "+v"(L.J[18]))
         APX_FENCE19J(A); APX_FENCE19J(B);
 #undef APX_FENCE19J
@@ -1446,7 +1398,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, FacRegs& FR, fl
                 if constexpr (c < 6) { fmac_bcast<s>(ab, B.J[c], A.J[c]); fmac_bcast<s>(ba, A.J[c], B.J[c]); }
             });
             // pin the sums here: LLVM otherwise sinks the fma chains into the conditional contact blocks that consume them
-            asm volatile("" : "+v"(aa), "+v"(bb), "+v"(ab), "+v"(ba));
+            APX_PIN("+v"(aa), "+v"(bb), "+v"(ab), "+v"(ba));
             GAA[s] = aa; GBB[s] = bb; GAB[s] = ab; GBA[s] = ba;
         });
         sfor<0, MAXX>([&](auto K) { GX[K] = f2g{0.f, 0.f}; });
@@ -1456,7 +1408,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, FacRegs& FR, fl
             float aa = mul_bcast<s>(A.J[0], A.J[0]), bb = mul_bcast<s>(B.J[0], B.J[0]);
             sfor<1, 19>([&](auto C) { constexpr int c = C; fmac_bcast<s>(aa, A.J[c], A.J[c]); fmac_bcast<s>(bb, B.J[c], B.J[c]); });
             sfor<0, 6>([&](auto C) { constexpr int c = C; fmac_bcast<s>(aa, B.J[c], A.J[c]); fmac_bcast<s>(bb, A.J[c], B.J[c]); });
-            asm volatile("" : "+v"(aa), "+v"(bb));
+            APX_PIN("+v"(aa), "+v"(bb));
             GX[K] = f2g{aa, bb};
         });
     }
@@ -1591,7 +1543,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, FacRegs& FR, fl
             sfor<j + 1, 6>([&](auto Sr) { w += g[Sr] * T[Sr][j]; });
             float tr = l == j ? 1.f : 0.f;
             sfor<j + 1, 6>([&](auto Sr) { tr = l == Sr ? T[Sr][j] : tr; });
-            asm volatile("" : "+v"(w.x), "+v"(w.y), "+v"(tr));          // materialise here: fast-math would otherwise re-expand the composition inside the loop
+            APX_PIN("+v"(w.x), "+v"(w.y), "+v"(tr));          // materialise here: fast-math would otherwise re-expand the composition inside the loop
             W[leg][j] = w; Trow[leg][j] = tr;
         });
     });
@@ -1646,7 +1598,7 @@ __device__ __forceinline__ void stage_rows_pgs_lane(const St& S, FacRegs& FR, fl
                                 r2 = leg ? dpp<0x150 + ln + 2>(r.y) : dpp<0x150 + ln + 2>(r.x);
                     f2 U01 = f2{rn, rn} + cpm * r1, U23 = f2{rn, rn} + cpm * r2;
                     f2 wa = cam1p[s][0] * cfp[s][0] + cbetap[s][0], wb = cam1p[s][1] * cfp[s][1] + cbetap[s][1];      // packed, off the chain
-#define APX_PIN2(v) asm volatile("" : "+v"(v))      /* fix the association: fast-math would gather the corrections into one late sum */
+#define APX_PIN2(v) APX_PIN("+v"(v))      /* fix the association: fast-math would gather the corrections into one late sum */
                     APX_PIN2(wa); APX_PIN2(wb);      // fast-math would re-associate them into the chain (pinned as PAIRS: pinning the halves one by one costs a v_mov pair + s_nop per slot and sweep)
                     f2 X01 = wa - ciAp[s][0] * U01, X23 = wb - ciAp[s][1] * U23;        // scaled residuals of the four rows before any of them moved
                     APX_PIN2(X01); APX_PIN2(X23);

@@ -57,7 +57,7 @@ template <bool CARRY>
 __device__ __forceinline__ void stage1_io_lane(St S, int mode, est::Rec& carried, float* estrec) {   // (as a called function the reset kernel faults: kept inline)
     PROF_START();
     int l = threadIdx.x & 15;
-    asm volatile("" : "+v"(l));      // opaque: otherwise every per-lane constant below is hoisted out of the 50-substep loop and has to be
+    APX_PIN("+v"(l));      // opaque: otherwise every per-lane constant below is hoisted out of the 50-substep loop and has to be
                                      // kept (= spilled to scratch) across the constraint stage, which needs the whole register file
     if (mode == 0) { if (l < 10) S.W(c4::WK_CTRL + l) = 0.f; if (l == 0) S.W(c4::WK_MISC + 6) = 0.f; PROF(0); return; }
     est::Rec local;
@@ -800,7 +800,7 @@ __device__ __forceinline__ void lstm_cell4(const float* Gx, int Kx, const float*
         q[0] = hn; q[128] = cn; hout[U][E] = hn;
     }); });
 }
-__device__ __forceinline__ const RolloutArgs* ra_ptr(const RolloutArgs* p) { asm volatile("" : "+s"(p)); return p; }
+__device__ __forceinline__ const RolloutArgs* ra_ptr(const RolloutArgs* p) { APX_PIN("+s"(p)); return p; }
 __device__ __forceinline__ lfloat* env_region(int e) { return (lfloat*)apx_lds4 + e * L4_ES; }
 // the recurrent actor's step for the wave's four envs: x = this lane's normalised observation entry of env 0..3; returns the action means (lane < 10).  The carried (h, c)
 // wait in HBM / L2 between two steps (the 2 kHz loop needs every register).

@@ -1,6 +1,6 @@
 // Per-env persistent state layout (SoA in HBM, field-major) + tiny helpers shared by the env kernels.
 #pragma once
-#include <hip/hip_runtime.h>
+#include <gfx950/lane_ops.h>      // (hip_runtime.h + the inline-assembly dialect of the env kernels)
 #include "../../include/apx.h"
 
 constexpr int ES_NQ = 35, ES_NV = 32, ES_NB = 26;
@@ -70,7 +70,7 @@ constexpr int CT_BODY = 0 /* leg-local bodies 0..11 as (left, right) PAIRS: pos3
               CT_BODYSZ = 40, CT_MADR = CT_BODY + 12 * CT_BODYSZ, CT_ARM = CT_MADR + 32,
               CT_GEAR = CT_ARM + 32, CT_CMAX = CT_GEAR + 10, CT_MIDX = CT_CMAX + 10 /* 16 lanes x 7 words: 13 ushort offsets */, CT_TOTAL = CT_MIDX + 16 * 7;
 static_assert(CT_TOTAL == 676 && (L4_EPW * L4_ES) % 4 == 0, "wave-constant table");
-extern __shared__ __attribute__((aligned(16))) float4 apx_lds4[];   // dynamic LDS: [env regions | wave-constant table]
+APX_DYNAMIC_LDS(float4, apx_lds4, 16);   // dynamic LDS: [env regions | wave-constant table]
 __device__ __forceinline__ float ctf(int i) { return ((const lfloat*)apx_lds4)[L4_EPW * L4_ES + i]; }
 // word k of the record of leg-local body lb (body id 2 + 12 sd + lb), leg slot sd
 constexpr int ct_body_word(int lb, int sd, int k) { return CT_BODY + CT_BODYSZ * lb + 2 * k + sd; }

@@ -145,7 +145,7 @@ __device__ __forceinline__ void est_step_lane(const St& S, Rec& rec) {
     // (the broadcasts are taken unconditionally and pinned: `c ? dpp(v) : 0` compiles to a DPP move under an exec mask, and a DPP read of a lane that the
     // mask disabled returns 0.  Harmless here, `stale` is uniform over the env's row, but tools/dpp_audit.py keeps the library free of the shape.)
     float b0 = bc<6>(rec.v[0][0]), b1 = bc<6>(rec.v[0][1]), b2 = bc<6>(rec.v[0][2]), b3 = bc<6>(rec.v[0][3]);
-    asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+    APX_PIN("+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
     float heel[2] = {stale ? 0.f : b0, stale ? 0.f : b1};
     float terr = stale ? 0.f : b2;
     const float inited = stale ? 0.f : b3;

@@ -59,7 +59,7 @@ def kernel_source_hash():
     """sha1 over the env kernel's sources: a PMC profile is only quoted while it was taken on THIS kernel"""
     import hashlib
     h = hashlib.sha1()
-    for f in ("env.hip", "cassie_lane.h", "estimator_lane.h", "cassie_common.h", "env_state.h"):
+    for f in ("env.hip", "cassie_lane.h", "cassie_complete.h", "estimator_lane.h", "cassie_common.h", "env_state.h", os.path.join("gfx950", "lane_ops.h")):
         h.update(open(os.path.join(REPO, "apex_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:12]
 
