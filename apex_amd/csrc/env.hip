@@ -450,6 +450,7 @@ __device__ __forceinline__ void env_restart_head(const St& S, const Cfg& cfg, in
         S(F_FWD + l) = img[(size_t)(F_FWD + l) * n];
         if (lead) { S.I(I_PHASE) = cfg.rst_int[(size_t)(2 * slot + 1) * n + S.env]; S.I(I_FLAGS) &= ~32; S.I(I_TIME) = 0; S.I(I_COUNTER) = 0; }
     }
+    APX_LOCKSTEP();                                   // every lane has read I_EPISODE (its ring slot) before the lead moves it on
     if (lead) S.I(I_EPISODE) = ep;
     c4::wsync();
     if (cfg.env_kind == 1) {                          // CassieTrajEnv.reset: set_qpos / set_qvel with the reference state of the start phase
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_kernel(float* 
             float* img = rst + (size_t)slot * F_TOTAL * n + env;
             for (int f = l; f < F_TOTAL; f += 16) img[(size_t)f * n] = S(f);
             if (lead) { rst_int[(size_t)(2 * slot + 1) * n + env] = S.I(I_PHASE); rst_int[(size_t)(2 * slot) * n + env] = ep; }
-            if (restart) { __threadfence(); load_state(S, st, ist, n); }      // back to the env's own state: the restart copies the image's fields over it
+            if (restart) { __threadfence(); APX_LOCKSTEP(); load_state(S, st, ist, n); }      // back to the env's own state: the restart copies the image's fields over it (the lead's read of I_PHASE above comes first)
         }
     }
     if (__builtin_amdgcn_ballot_w64(restart) != 0ull) {

@@ -10,6 +10,10 @@
 // assembly (which the hazard recogniser cannot see).
 #define APX_PIN(...) asm volatile("" : __VA_ARGS__)
 #define APX_HAZARD_FENCE(...) asm volatile("s_nop 1" : __VA_ARGS__)
+// APX_LOCKSTEP(): marks a place where the code relies on the wave being ONE instruction stream: every lane's loads above this line are performed before any lane's
+// stores below it (no instruction is needed for that, so this expands to nothing).  The host emulation of the kernels runs the lanes one after the other between
+// rendezvous points and makes this one; its lockstep checker (tools/hipemu) finds the places that need the mark.
+#define APX_LOCKSTEP() ((void)0)
 // dynamic LDS of a kernel (the launch's shared-memory bytes) as an array of T
 #define APX_DYNAMIC_LDS(T, name, alignment) extern __shared__ __attribute__((aligned(alignment))) T name[]
 

@@ -16,6 +16,20 @@ from .engine import _p, _stream
 
 OBS_DIM, ACT_DIM = 50, 10
 
+
+# The two places this module touches the device runtime.  (tests/test_kernel_emulation_env.py points them - and the library handle - at the kernel SOURCES compiled
+# for the host, for the duration of a test; the product has no CPU path and raises here.)
+def _device(index):
+    if not torch.cuda.is_available():
+        raise _lib.ApxError("CassieVecEnv needs a GPU (there is no CPU fallback)")
+    d = torch.device("cuda", index)
+    torch.cuda.set_device(d)
+    return d
+
+
+def _on_device(t):
+    return t.is_cuda
+
 # cassie/cassie.py:244 (input_profile "full") + :262-265 (command_profile "clock"); cassie/cassie.py:69
 MIRRORED_OBS = [0.1, 1, -2, 3, -4, -10, -11, 12, 13, 14, -5, -6, 7, 8, 9, 15, -16, 17, -18, 19, -20, -26, -27, 28, 29, 30,
                 -21, -22, 23, 24, 25, 31, -32, 33, 37, 38, 39, 34, 35, 36, 43, 44, 45, 40, 41, 42, 46, 47, 48, 49]
@@ -87,8 +101,7 @@ class CassieVecEnv:
         if env_name == "CassieTraj-v0" and (traj != "walking" or not no_delta or ik_baseline or simrate != 50):
             raise NotImplementedError("CassieTraj-v0 is built for traj=walking, no_delta, simrate 50 (the CLI defaults)")
         self.env_name = env_name
-        if not torch.cuda.is_available():
-            raise _lib.ApxError("CassieVecEnv needs a GPU (there is no CPU fallback)")
+        self.device = _device(device)
         lib = _lib.load()
         cfg = _lib.EnvCfg()
         lib.apx_env_default_cfg(C.byref(cfg))
@@ -110,8 +123,6 @@ class CassieVecEnv:
         cfg.env_id_base = env_id_base
         cfg.est_lifetime = int(est_lifetime)      # env steps served by one estimator object (one PPO.sample call of the reference builds one CassieEnv); 0 = never restarted
         cfg.env_kind = 1 if env_name == "CassieTraj-v0" else 0
-        self.device = torch.device("cuda", device)
-        torch.cuda.set_device(self.device)
         self._h = C.c_void_p()
         check(lib.apx_env_create(C.byref(cfg), C.byref(self._h)))
         self.n_envs, self.simrate, self.max_traj_len = n_envs, simrate, max_traj_len
@@ -217,7 +228,7 @@ class CassieVecEnv:
     def step_basic(self, action):
         """CassieEnv.step_basic (cassie.py:498-521) for every env: no reward / termination / command resampling; returns obs."""
         action = action.contiguous()
-        assert action.shape == (self.n_envs, ACT_DIM) and action.dtype == torch.float32 and action.is_cuda
+        assert action.shape == (self.n_envs, ACT_DIM) and action.dtype == torch.float32 and _on_device(action)
         if not self.history:
             check(_lib.load().apx_env_step_basic(self._h, _p(action), _p(self.obs), _stream()))
             return self.obs
@@ -231,7 +242,7 @@ class CassieVecEnv:
         finished envs restart inside the same launch and `final_obs` holds their last observation (rows of envs that did not
         finish are left untouched).  `out` = (obs, reward, done, final_obs) lets the kernels write straight into caller-owned
         contiguous device buffers (e.g. slices of a rollout grid) instead of the env's own."""
-        if not action.is_cuda:
+        if not _on_device(action):
             raise _lib.ApxError("CassieVecEnv.step needs a device tensor (there is no CPU path)")
         action = action.contiguous()
         assert action.shape == (self.n_envs, ACT_DIM) and action.dtype == torch.float32

@@ -32,8 +32,9 @@ def emulated_library():
         lib.apx_last_error = lib.apx_emul_last_error
         return lib
     so = os.path.join(EMU, "_build", "libapx_emul.so")
-    srcs = [os.path.join(EMU, f) for f in ("emul_ppo_small.cpp", "emul_learner.cpp", "emul_td3_small.cpp", "build.sh", os.path.join("hip", "hip_runtime.h"))] + \
-           [os.path.join(REPO, "apex_amd", "csrc", f) for f in ("ppo_small.hip", "td3_small.hip", "mlp_tiles.h", "learner.hip", "apx_common.h")] + [os.path.join(REPO, "include", "apx.h")]
+    import glob
+    srcs = glob.glob(os.path.join(EMU, "*.cpp")) + [os.path.join(EMU, "build.sh")] + glob.glob(os.path.join(EMU, "hip", "*.h")) + glob.glob(os.path.join(EMU, "gfx950", "*.h")) + \
+           glob.glob(os.path.join(REPO, "apex_amd", "csrc", "*.hip")) + glob.glob(os.path.join(REPO, "apex_amd", "csrc", "*.h")) + [os.path.join(REPO, "include", "apx.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["bash", os.path.join(EMU, "build.sh")])
     lib = C.CDLL(so)

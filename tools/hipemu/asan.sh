@@ -16,7 +16,7 @@ else
 fi
 mkdir -p _build/$SAN
 sed 's|extern __shared__ float fls\[\];|float* fls = (float*)hipemu::g_dynsmem;|' ../../apex_amd/csrc/learner.hip > _build/learner_emul.hip
-FLAGS="-x c++ -std=c++17 -O1 -g -fPIC -pthread $SANFLAGS -I. -I../../apex_amd/csrc -I../../include -Wno-unused-function -Wno-unused-variable -Wno-unknown-attributes -Wno-ignored-attributes"
+FLAGS="-x c++ -std=c++17 -O1 -g -fPIC -pthread $SANFLAGS -I. -I../../apex_amd/csrc -I../../include -Wno-unused-function -Wno-unused-variable -Wno-unknown-attributes -Wno-ignored-attributes -DHIPEMU_UCONTEXT"
 for f in emul_ppo_small emul_learner emul_td3_small; do $CXX $FLAGS -c $f.cpp -o _build/$SAN/$f.o 2> /dev/null & done
 wait
 $CXX -shared -pthread $LINKFLAGS _build/$SAN/*.o -o _build/libapx_emul_$SAN.so

@@ -39,8 +39,33 @@ inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
-inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+template <class F> inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
+// the host runtime as env.hip uses it: "device" memory is host memory (filled with a byte pattern: hipMalloc does not clear either), every launch completes inside the call,
+// so streams and events have nothing to order
+typedef void* hipEvent_t;
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone, hipStreamCaptureStatusActive };
+constexpr unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2;
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+template <class T> inline hipError_t hipMalloc(T** p, size_t n) { *p = (T*)malloc(n ? n : 1); if (*p) memset((void*)*p, 0xA5, n); return *p ? hipSuccess : 2; }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* st) { *st = hipStreamCaptureStatusNone; return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+#define HIP_SYMBOL(x) (&(x))
+template <class S> inline hipError_t hipMemcpyToSymbol(S* sym, const void* src, size_t n) { memcpy((void*)sym, src, n); return hipSuccess; }
+template <class S> inline hipError_t hipMemcpyFromSymbol(void* dst, S* sym, size_t n) { memcpy(dst, (const void*)sym, n); return hipSuccess; }
 
 #define __global__
 #define __device__
@@ -53,12 +78,25 @@ inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { retu
 
 namespace hipemu {
 struct Wave;
-struct Lane { ucontext_t ctx; dim3 tid; int lane; unsigned ncoll; bool done; Wave* wave; char* stack; };
-constexpr size_t STACK_BYTES = 256 * 1024;
+// Fiber switch: six callee-saved registers and the stack pointer (a glibc swapcontext is a sigprocmask system call per switch - 0.3 us against ~5 ns - and the env
+// kernels switch 64 lanes at every DPP operand).  HIPEMU_UCONTEXT (the sanitizer builds of asan.sh, which know ucontext) keeps the portable form.
+#ifndef HIPEMU_UCONTEXT
+struct Ctx { void* sp; };
+__attribute__((naked, noinline)) inline void ctx_switch(void** /*save_sp: rdi*/, void* /*load_sp: rsi*/) {
+    asm volatile("pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+                 "movq %rsp, (%rdi)\n\tmovq %rsi, %rsp\n\t"
+                 "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\tret");
+}
+#else
+struct Ctx { ucontext_t uc; };
+#endif
+struct Lane { Ctx ctx; dim3 tid; int lane; unsigned ncoll; bool done; Wave* wave; char* stack; };
+constexpr size_t STACK_BYTES = 1024 * 1024;
 constexpr int MAX_WAVES = 16;
 struct Wave {
-    Lane lanes[64]; ucontext_t sched; int index;
+    Lane lanes[64]; Ctx sched; int index;
     float A[2][64], B[2][64]; double Dv[2][64];
+    uint32_t X[2][64], Y[2][64]; const void* site[2][64];      // 32-bit lane exchanges (DPP, bpermute, readlane, ballot) and the call site each lane made its from
     int nlanes;
     bool want_barrier;
     pthread_barrier_t* block_barrier;
@@ -69,34 +107,59 @@ inline dim3 g_grid, g_block, g_bidx;
 inline char g_dynsmem[160 * 1024] __attribute__((aligned(64)));      // the dynamic LDS segment of the running workgroup (`extern __shared__`, see build.sh)
 inline char* g_stacks = nullptr;                                      // MAX_WAVES x 64 fiber stacks, mapped once (untouched pages cost nothing)
 inline std::map<std::string, long> g_launches;      // launches per kernel expression as written at the launch site (tests ask which kernels a path really took)
+inline uint64_t g_block_gen = 0;      // workgroups run so far (the lockstep checker's epochs)
 inline int g_force_grid = 0;      // > 0: every launch runs with this many workgroups whatever the host code asked for
-inline void yield() { Lane* l = g_cur; swapcontext(&l->ctx, &l->wave->sched); }
+#ifndef HIPEMU_UCONTEXT
+inline void lockstep_flush();
+inline void yield() { lockstep_flush(); Lane* l = g_cur; ctx_switch(&l->ctx.sp, l->wave->sched.sp); }
+inline void fiber_main() {
+    Lane* l = g_cur;
+    (*l->wave->body)();
+    lockstep_flush();
+    l->done = true;
+    ctx_switch(&l->ctx.sp, l->wave->sched.sp);
+    abort();
+}
+inline void fiber_init(Lane& l) {      // a stack on which ctx_switch's six pops and its ret land in fiber_main with the ABI's alignment (rsp = 8 mod 16 at entry)
+    uintptr_t top = ((uintptr_t)l.stack + STACK_BYTES) & ~(uintptr_t)15;
+    void** sp = (void**)(top - 8);
+    *--sp = (void*)&fiber_main;
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;
+    l.ctx.sp = sp;
+}
+inline void resume(Wave* W, Lane& l) { ctx_switch(&W->sched.sp, l.ctx.sp); }
+#else
+inline void lockstep_flush();
+inline void yield() { lockstep_flush(); Lane* l = g_cur; swapcontext(&l->ctx.uc, &l->wave->sched.uc); }
 inline void fiber_entry(unsigned lo, unsigned hi) {
     Lane* l = (Lane*)(((uintptr_t)hi << 32) | (uintptr_t)lo);
     (*l->wave->body)();
     l->done = true;
-    swapcontext(&l->ctx, &l->wave->sched);
+    swapcontext(&l->ctx.uc, &l->wave->sched.uc);
 }
+inline void fiber_init(Lane& l) {
+    getcontext(&l.ctx.uc);
+    l.ctx.uc.uc_stack.ss_sp = l.stack; l.ctx.uc.uc_stack.ss_size = STACK_BYTES; l.ctx.uc.uc_link = nullptr;
+    const uintptr_t p = (uintptr_t)&l;
+    makecontext(&l.ctx.uc, (void (*)())fiber_entry, 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));
+}
+inline void resume(Wave* W, Lane& l) { swapcontext(&W->sched.uc, &l.ctx.uc); }
+#endif
 inline void run_wave(Wave* W) {
-    for (int i = 0; i < W->nlanes; ++i) {
-        Lane& l = W->lanes[i];
-        getcontext(&l.ctx);
-        l.ctx.uc_stack.ss_sp = l.stack; l.ctx.uc_stack.ss_size = STACK_BYTES; l.ctx.uc_link = nullptr;
-        const uintptr_t p = (uintptr_t)&l;
-        makecontext(&l.ctx, (void (*)())fiber_entry, 2, (unsigned)(p & 0xffffffffu), (unsigned)(p >> 32));
-    }
+    for (int i = 0; i < W->nlanes; ++i) fiber_init(W->lanes[i]);
     for (;;) {
         int live = 0;
         for (int i = 0; i < W->nlanes; ++i) {
             Lane& l = W->lanes[i];
             if (l.done) continue;
             g_cur = &l;
-            swapcontext(&W->sched, &l.ctx);
+            resume(W, l);
             live += !l.done;
         }
         if (W->want_barrier) { W->want_barrier = false; pthread_barrier_wait(W->block_barrier); }
         if (!live) break;
     }
+    g_cur = nullptr;      // host code runs outside any lane
 }
 inline void run_block(dim3 block, const std::function<void()>& body) {
     const int nthreads = (int)(block.x * block.y * block.z), nw = (nthreads + 63) / 64;
@@ -114,6 +177,7 @@ inline void run_block(dim3 block, const std::function<void()>& body) {
             l.stack = g_stacks + (size_t)(w * 64 + i) * STACK_BYTES;
         }
     }
+    ++g_block_gen;
     if (nw == 1) run_wave(waves[0]);
     else {
         std::vector<std::thread> th;
@@ -191,6 +255,154 @@ template <class T> inline void hipemu_atomic_store(T* p, T v) { __atomic_store(p
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST)
 inline void __builtin_amdgcn_s_sleep(int) { sched_yield(); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
+
+
+// ------------------------------------------------------------------------------------------------ 32-bit lane exchanges (the env kernels: DPP, ds_bpermute, readlane, ballot)
+// Every lane deposits its word (and the address of the call site) and yields; resumed, it reads the word of its source lane.  A collective sits in wave-uniform control
+// flow: a source lane that deposited from ANOTHER call site means the lanes of the wave have diverged around a collective, and the run aborts saying so.  A lane that has
+// left the kernel is an inactive lane: its word reads as zero (DPP with bound_ctrl, the way the kernels use it) and it is absent from ballots.
+namespace hipemu {
+struct Xchg { Wave* W; int buf, lane; const void* site; };
+#define HIPEMU_NOCOV __attribute__((no_sanitize("coverage")))
+HIPEMU_NOCOV __attribute__((noinline)) inline Xchg exchange2(uint32_t x, uint32_t y) {
+    Lane* l = g_cur; Wave* W = l->wave;
+    const int buf = l->ncoll++ & 1, ln = l->lane;
+    const void* site = __builtin_return_address(0);
+    W->X[buf][ln] = x; W->Y[buf][ln] = y; W->site[buf][ln] = site;
+    yield();
+    return Xchg{W, buf, ln, site};
+}
+HIPEMU_NOCOV inline uint32_t peek(const Xchg& e, int src, bool second = false) {
+    if (src < 0 || src >= e.W->nlanes || e.W->lanes[src].done) return 0u;
+    if (e.W->site[e.buf][src] != e.site) {
+        fprintf(stderr, "hipemu: lane %d reads lane %d across DIVERGED control flow (collective call sites %p vs %p)\n", e.lane, src, e.site, e.W->site[e.buf][src]);
+        abort();
+    }
+    return second ? e.W->Y[e.buf][src] : e.W->X[e.buf][src];
+}
+inline float asf(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+inline uint32_t asu(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+// source lane of a DPP control word (gfx9 encoding), -1 = no source (a shift beyond the row end)
+inline int dpp_src(int ctrl, int ln) {
+    const int row = ln & ~15, r = ln & 15;
+    if (ctrl < 0x100) return (ln & ~3) | ((ctrl >> (2 * (ln & 3))) & 3);                       // quad_perm
+    if (ctrl >= 0x101 && ctrl <= 0x10F) { const int n = ctrl - 0x100; return r + n <= 15 ? ln + n : -1; }      // row_shl: lane i takes lane i + n
+    if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl - 0x110; return r >= n ? ln - n : -1; }           // row_shr: lane i takes lane i - n
+    if (ctrl >= 0x121 && ctrl <= 0x12F) { const int n = ctrl - 0x120; return row | ((r - n) & 15); }           // row_ror
+    if (ctrl == 0x140) return row | (15 - r);                                                   // row_mirror
+    if (ctrl == 0x141) return (ln & ~7) | (7 - (ln & 7));                                       // row_half_mirror
+    if (ctrl >= 0x150 && ctrl <= 0x15F) return row | (ctrl - 0x150);                            // row_newbcast
+    fprintf(stderr, "hipemu: DPP control 0x%x not emulated\n", ctrl); abort();
+}
+// the DPP operand of lane ln: value of its source lane, 0 without one (bound_ctrl:1 / old = 0)
+inline float dpp_get(const Xchg& e, int ctrl, bool second = false) { return asf(peek(e, dpp_src(ctrl, e.lane), second)); }
+}  // namespace hipemu
+
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    if (old != 0 || row_mask != 0xF || bank_mask != 0xF || !bound_ctrl) { fprintf(stderr, "hipemu: update_dpp form not emulated\n"); abort(); }
+    const hipemu::Xchg e = hipemu::exchange2((uint32_t)src, 0u);
+    return (int)hipemu::peek(e, hipemu::dpp_src(ctrl, e.lane));
+}
+inline int __builtin_amdgcn_ds_bpermute(int addr, int v) {
+    const hipemu::Xchg e = hipemu::exchange2((uint32_t)v, 0u);
+    return (int)hipemu::peek(e, (addr >> 2) & 63);
+}
+inline int __builtin_amdgcn_readlane(int v, int k) {
+    const hipemu::Xchg e = hipemu::exchange2((uint32_t)v, 0u);
+    return (int)hipemu::peek(e, k & 63);
+}
+HIPEMU_NOCOV inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) {
+    const hipemu::Xchg e = hipemu::exchange2(p ? 1u : 0u, 0u);
+    unsigned long long m = 0;
+    for (int i = 0; i < e.W->nlanes; ++i) m |= (unsigned long long)(hipemu::peek(e, i) & 1u) << i;
+    return m;
+}
+// a wave is one instruction stream: LDS / memory written by a lane in front of this point is visible to every lane behind it.  Under the emulation the lanes are fibers
+// that run from collective to collective, so the hand-off needs a rendezvous
+inline void __builtin_amdgcn_wave_barrier() { hipemu::exchange2(0u, 0u); }
+inline void __builtin_amdgcn_fence(int, const char*) {}
+inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+inline float __frcp_rn(float x) { return 1.0f / x; }
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+inline void __sincosf(float x, float* s, float* c) { *s = sinf(x); *c = cosf(x); }      // (the device intrinsic is the fast hardware form; the host's is libm's)
+inline int __float_as_int(float f) { return (int)hipemu::asu(f); }
+inline unsigned __float_as_uint(float f) { return hipemu::asu(f); }
+inline float __int_as_float(int i) { return hipemu::asf((uint32_t)i); }
+inline float __uint_as_float(unsigned u) { return hipemu::asf(u); }
+struct alignas(16) float4 { float x, y, z, w; };
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+#define __constant__ static
+#define __noinline__ __attribute__((noinline))
+
+// ------------------------------------------------------------------------------------------------ lockstep checker (build.sh lockstep -> libapx_emul_lockstep.so)
+// A wave is ONE instruction stream: a lane's load in front of another lane's store in program order sees the old value whether or not anything separates the two.  The
+// emulation's lanes run from rendezvous to rendezvous (collectives, wsync) one after the other, so two accesses of DIFFERENT lanes to the same word - at least one a
+// store - with no rendezvous between them come out in lane order instead of program order.  This build has every load and store of the translation unit call in here
+// (-fsanitize-coverage=trace-loads,trace-stores) and reports each such pair once per store / load site; the kernel source then states the dependence with
+// APX_LOCKSTEP() (gfx950/lane_ops.h: nothing on the hardware, a rendezvous here).  Single-wave workgroups only (the env kernels).
+#ifndef HIPEMU_LOCKSTEP_CHECK
+namespace hipemu { inline void lockstep_flush() {} }
+#else
+#include <dlfcn.h>
+#include <set>
+#include <unordered_map>
+namespace hipemu {
+struct Shadow { uint64_t wep = ~0ull, rep = ~0ull, rmask = 0; int wlane = -1; uint32_t wold = 0; const void* wsite = nullptr; const void* rsite = nullptr; };
+inline std::unordered_map<uintptr_t, Shadow> g_shadow;
+inline std::set<std::pair<const void*, const void*>> g_reported;
+inline long g_conflicts = 0;
+inline bool g_in_check = false;
+// a store is reported when it has happened (the callback runs in front of it): a store of the value the word already held orders nothing
+struct Pending { uintptr_t word; uint32_t old; int lane, other; const void* site; const void* osite; };
+inline std::vector<Pending> g_pending;
+inline uintptr_t rel(const void* p) { Dl_info i; return dladdr(p, &i) && i.dli_fbase ? (uintptr_t)p - (uintptr_t)i.dli_fbase : (uintptr_t)p; }
+inline void conflict(const char* kind, uintptr_t word, int lane, int other, const void* site, const void* osite) {
+    ++g_conflicts;
+    if (!g_reported.insert({site, osite}).second) return;
+    const bool lds = word * 4 >= (uintptr_t)g_dynsmem && word * 4 < (uintptr_t)g_dynsmem + sizeof g_dynsmem;
+    fprintf(stderr, "hipemu lockstep: %s on %s word %ld: lane %d at +0x%lx vs lane %d at +0x%lx, no rendezvous between them\n", kind, lds ? "LDS" : "memory",
+            lds ? (long)(word - (uintptr_t)g_dynsmem / 4) : (long)word, lane, (unsigned long)rel(site), other, (unsigned long)rel(osite));
+}
+inline void flush_pending() {
+    for (const Pending& q : g_pending)
+        if (*(const volatile uint32_t*)(q.word * 4) != q.old) conflict("store behind another lane's load (program order: the load comes first or the store - the emulation ran the load first)", q.word, q.lane, q.other, q.site, q.osite);
+    g_pending.clear();
+}
+inline void access(const void* addr, int bytes, bool store, const void* site) {
+    Lane* l = g_cur;
+    if (!l || g_in_check || g_block.x * g_block.y * g_block.z > 64) return;
+    const uintptr_t a = (uintptr_t)addr;
+    if (a >= (uintptr_t)l->stack && a < (uintptr_t)l->stack + STACK_BYTES) return;      // the lane's own stack = its registers
+    if (a >= (uintptr_t)l->wave && a < (uintptr_t)l->wave + sizeof(Wave)) return;           // the emulation's own exchange buffers
+    g_in_check = true;
+    flush_pending();
+    const uint64_t ep = (g_block_gen << 40) | l->ncoll;
+    for (uintptr_t w = a >> 2; w <= (a + bytes - 1) >> 2; ++w) {
+        Shadow& sh = g_shadow[w];
+        const uint32_t now = *(const volatile uint32_t*)(w * 4);
+        if (store) {
+            if (sh.rep == ep && (sh.rmask & ~(1ull << l->lane))) g_pending.push_back(Pending{w, now, l->lane, __builtin_ctzll(sh.rmask & ~(1ull << l->lane)), site, sh.rsite});
+            if (sh.wep != ep || sh.wlane != l->lane) sh.wold = now;      // (stores of different lanes to one word in one interval: the sinks of predicated-off stores - not reported)
+            sh.wep = ep; sh.wlane = l->lane; sh.wsite = site;
+        } else {
+            if (sh.wep == ep && sh.wlane != l->lane && now != sh.wold)
+                conflict("load behind another lane's store of a new value", w, l->lane, sh.wlane, site, sh.wsite);
+            if (sh.rep != ep) { sh.rep = ep; sh.rmask = 0; }
+            sh.rmask |= 1ull << l->lane; sh.rsite = site;
+        }
+    }
+    g_in_check = false;
+}
+inline void lockstep_flush() { if (!g_in_check) { g_in_check = true; flush_pending(); g_in_check = false; } }
+}  // namespace hipemu
+#define HIPEMU_COV(n) \
+    extern "C" __attribute__((weak, noinline)) void __sanitizer_cov_load##n(void* p) { hipemu::access(p, n, false, __builtin_return_address(0)); } \
+    extern "C" __attribute__((weak, noinline)) void __sanitizer_cov_store##n(void* p) { hipemu::access(p, n, true, __builtin_return_address(0)); }
+HIPEMU_COV(1) HIPEMU_COV(2) HIPEMU_COV(4) HIPEMU_COV(8) HIPEMU_COV(16)
+extern "C" __attribute__((weak)) void __sanitizer_cov_trace_pc_guard(uint32_t*) {}
+extern "C" __attribute__((weak)) void __sanitizer_cov_trace_pc_guard_init(uint32_t*, uint32_t*) {}
+extern "C" __attribute__((weak)) long apx_emul_lockstep_conflicts() { return hipemu::g_conflicts; }
+#endif
 
 typedef float hipemu_f4 __attribute__((ext_vector_type(4)));
 // D = A B + C with A 16 x 4 (lane 16 k + i holds A[i][k]), B 4 x 16 (lane 16 k + n holds B[k][n]), C / D 16 x 16 (lane 16 g + n, component v: row 4 g + v, column n)
