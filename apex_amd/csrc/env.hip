@@ -590,6 +590,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_kernel(float* 
             if (lead) { rst_int[(size_t)(2 * slot + 1) * n + env] = S.I(I_PHASE); rst_int[(size_t)(2 * slot) * n + env] = ep; }
             if (restart) { __threadfence(); APX_LOCKSTEP(); load_state(S, st, ist, n); }      // back to the env's own state: the restart copies the image's fields over it (the lead's read of I_PHASE above comes first)
         }
+        APX_CONVERGE();
     }
     if (__builtin_amdgcn_ballot_w64(restart) != 0ull) {
         if (restart) {
@@ -599,6 +600,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_reset_kernel(float* 
             c4::wsync();
             if (obs && lead) write_obs(S, cfg, obs + (size_t)env * cfg.obs_dim);
         }
+        APX_CONVERGE();
     }
     if (restart) store_state(S, st, ist, n);
 }

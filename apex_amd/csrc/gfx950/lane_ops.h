@@ -14,6 +14,9 @@
 // stores below it (no instruction is needed for that, so this expands to nothing).  The host emulation of the kernels runs the lanes one after the other between
 // rendezvous points and makes this one; its lockstep checker (tools/hipemu) finds the places that need the mark.
 #define APX_LOCKSTEP() ((void)0)
+// APX_CONVERGE(): behind a branch that only some of the wave's env ROWS take and that contains cross-lane operations: the point where the rows are together again (the
+// exec mask's business on the hardware: nothing to emit; the host emulation parks the rows that sat the branch out here until the others arrive).
+#define APX_CONVERGE() ((void)0)
 // dynamic LDS of a kernel (the launch's shared-memory bytes) as an array of T
 #define APX_DYNAMIC_LDS(T, name, alignment) extern __shared__ __attribute__((aligned(alignment))) T name[]
 

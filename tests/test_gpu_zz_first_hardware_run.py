@@ -81,10 +81,23 @@ def test_g24_push_sweep_of_the_reference_policy_on_the_kernel(golden_dir):
     mf, fell = compute_perturbs(pol, make_env, wait_time=wait, perturb_duration=dur, perturb_size=first, perturb_incr=incr, num_angles=100, n_sizes=30, num_phases=28, speed=speed)
     mine = mf.T.astype(np.float64)                        # [direction, phase] like eval_perturbs.npy
     ref = g["a_eval_perturbs"].astype(np.float64)
-    print("kernel mean %.1f N, MuJoCo %.1f N, correlation %.3f, mean |diff| %.1f N, identical cells %d of 2800" % (mine.mean(), ref.mean(), np.corrcoef(mine.ravel(), ref.ravel())[0, 1], np.abs(mine - ref).mean(), int((mine == ref).sum())))
-    assert abs(mine.mean() - ref.mean()) < 0.08 * ref.mean()
-    assert np.corrcoef(mine.ravel(), ref.ravel())[0, 1] > 0.85 and np.corrcoef(mine.mean(1), ref.mean(1))[0, 1] > 0.95
-    assert np.abs(mine - ref).mean() < 18.0
+    d = np.abs(mine - ref)
+    print("kernel mean %.1f N, MuJoCo %.1f N, correlation %.3f, mean |diff| %.1f N, identical cells %d, within one 10 N step %d of 2800" % (
+        mine.mean(), ref.mean(), np.corrcoef(mine.ravel(), ref.ravel())[0, 1], d.mean(), int((d == 0).sum()), int((d <= 10).sum())))
+    # kernel vs MuJoCo at what the fp64 oracle achieves on its 280-cell lattice (-1.7 %, r 0.946 / 0.997, 75 % of the cells within one step; tests/test_oracle_env.py)
+    assert abs(mine.mean() - ref.mean()) < 0.04 * ref.mean()
+    assert np.corrcoef(mine.ravel(), ref.ravel())[0, 1] >= 0.92 and np.corrcoef(mine.mean(1), ref.mean(1))[0, 1] >= 0.98
+    assert d.mean() < 12.5 and (d <= 10).mean() >= 0.70
+    # kernel vs the ORACLE, cell by cell, on the oracle's lattice (tests/golden/g24_oracle_lattice_280.npz): same physics in fp32 - the outcome at the survival boundary is
+    # chaotic (the policy's arithmetic in torch instead of numpy already moves single cells by one step), so: nearly all cells within one step, most identical
+    lat = np.load(os.path.join(golden_dir, "g24_oracle_lattice_280.npz"))
+    dirs, phases = lat["directions"].astype(int), lat["phases"].astype(int)
+    do = np.abs(mine[np.ix_(dirs, phases)] - lat["oracle"].astype(np.float64))
+    print("kernel vs oracle on the 280-cell lattice: identical %.3f, within one step %.3f, max %.0f N" % ((do == 0).mean(), (do <= 10).mean(), do.max()))
+    assert (do <= 10).mean() >= 0.90 and (do == 0).mean() >= 0.60 and do.max() <= 50.0
+    import json
+    os.makedirs(os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out"), exist_ok=True)
+    json.dump({"kernel": mine.astype(int).tolist(), "mujoco": ref.astype(int).tolist()}, open(os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out", "g24_kernel_cells.json"), "w"))
 
 
 @pytest.mark.parametrize("speed,tol", [(0.0, 0.08), (0.5, 0.10), (1.0, 0.10)])

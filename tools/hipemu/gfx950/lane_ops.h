@@ -9,6 +9,7 @@
 #define APX_HAZARD_FENCE(...) ((void)0)
 // a rendezvous of the wave's lanes (see the product header)
 #define APX_LOCKSTEP() ((void)hipemu::exchange2(0u, 0u))
+#define APX_CONVERGE() hipemu::converge()
 // the dynamic LDS segment of the running workgroup
 #define APX_DYNAMIC_LDS(T, name, alignment) static T* const name = (T*)hipemu::g_dynsmem
 

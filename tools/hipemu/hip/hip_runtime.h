@@ -90,12 +90,13 @@ __attribute__((naked, noinline)) inline void ctx_switch(void** /*save_sp: rdi*/,
 #else
 struct Ctx { ucontext_t uc; };
 #endif
-struct Lane { Ctx ctx; dim3 tid; int lane; unsigned ncoll; bool done; Wave* wave; char* stack; };
+struct Lane { Ctx ctx; dim3 tid; int lane; unsigned ncoll; bool done; Wave* wave; char* stack; const void* conv_site; };
 constexpr size_t STACK_BYTES = 1024 * 1024;
 constexpr int MAX_WAVES = 16;
 struct Wave {
     Lane lanes[64]; Ctx sched; int index;
     float A[2][64], B[2][64]; double Dv[2][64];
+    unsigned conv_gen, conv_ncoll;      // reconvergence points (hipemu::converge)
     uint32_t X[2][64], Y[2][64]; const void* site[2][64];      // 32-bit lane exchanges (DPP, bpermute, readlane, ballot) and the call site each lane made its from
     int nlanes;
     bool want_barrier;
@@ -169,11 +170,11 @@ inline void run_block(dim3 block, const std::function<void()>& body) {
     static Wave* waves[MAX_WAVES];
     for (int w = 0; w < nw; ++w) {
         if (!waves[w]) waves[w] = new Wave();
-        Wave* W = waves[w]; W->index = w; W->want_barrier = false; W->block_barrier = &bar; W->body = &body;
+        Wave* W = waves[w]; W->index = w; W->want_barrier = false; W->conv_gen = 0; W->conv_ncoll = 0; W->block_barrier = &bar; W->body = &body;
         W->nlanes = std::min(64, nthreads - 64 * w);
         for (int i = 0; i < W->nlanes; ++i) {
             Lane& l = W->lanes[i]; const unsigned t = w * 64 + i;
-            l.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y)); l.lane = i; l.ncoll = 0; l.done = false; l.wave = W;
+            l.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y)); l.lane = i; l.ncoll = 0; l.done = false; l.wave = W; l.conv_site = nullptr;
             l.stack = g_stacks + (size_t)(w * 64 + i) * STACK_BYTES;
         }
     }
@@ -273,12 +274,33 @@ HIPEMU_NOCOV __attribute__((noinline)) inline Xchg exchange2(uint32_t x, uint32_
     return Xchg{W, buf, ln, site};
 }
 HIPEMU_NOCOV inline uint32_t peek(const Xchg& e, int src, bool second = false) {
-    if (src < 0 || src >= e.W->nlanes || e.W->lanes[src].done) return 0u;
+    if (src < 0 || src >= e.W->nlanes || e.W->lanes[src].done || e.W->lanes[src].conv_site) return 0u;      // no such lane / it has left the kernel / it sits out this branch (parked at a reconvergence point): an inactive lane
     if (e.W->site[e.buf][src] != e.site) {
         fprintf(stderr, "hipemu: lane %d reads lane %d across DIVERGED control flow (collective call sites %p vs %p)\n", e.lane, src, e.site, e.W->site[e.buf][src]);
         abort();
     }
     return second ? e.W->Y[e.buf][src] : e.W->X[e.buf][src];
+}
+// Reconvergence point (APX_CONVERGE() in the kernel source, behind a branch that only some ROWS of the wave take and that holds collectives): a lane waits here until
+// every live lane of the wave has arrived; the lanes inside the branch meanwhile run their collectives among themselves (a parked lane reads as inactive).  On the
+// hardware the exec mask does this by itself.
+HIPEMU_NOCOV __attribute__((noinline)) inline void converge() {
+    Lane* l = g_cur; Wave* W = l->wave;
+    const void* site = __builtin_return_address(0);
+    const unsigned gen = W->conv_gen;
+    l->conv_site = site;
+    for (;;) {
+        if (W->conv_gen != gen) break;
+        int waiting = 0, live = 0; unsigned mx = 0;
+        for (int i = 0; i < W->nlanes; ++i) {
+            const Lane& o = W->lanes[i];
+            if (o.done) continue;
+            ++live; mx = std::max(mx, o.ncoll); waiting += o.conv_site == site;
+        }
+        if (waiting == live) { W->conv_gen = gen + 1; W->conv_ncoll = (mx + 2) & ~1u; break; }
+        yield();
+    }
+    l->conv_site = nullptr; l->ncoll = W->conv_ncoll;
 }
 inline float asf(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 inline uint32_t asu(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
