@@ -470,6 +470,7 @@ __device__ __forceinline__ void rows_pgs_complete(const St& S, const FacRegs& FR
     if (nrec > CP_LDS_CAP) __threadfence();      // vectors on the HBM tier: visible to every lane's plain loads from here on
     wsync();
     // every record of the wave's envs in LDS (always, short of a robot lying flat on the floor): the solve compiles without the tier branches and without a global access
+    APX_CONVERGE();      // (the rows of the wave that are in here got their records in loops of their own length)
     if (__builtin_amdgcn_ballot_w64(nrec > CP_LDS_CAP) == 0ull) cp_solve<true>(C, nlist, pgs_iters, mu, over, nfoot[0], nfoot[1]);
     else cp_solve<false>(C, nlist, pgs_iters, mu, over, nfoot[0], nfoot[1]);
 }

@@ -584,6 +584,7 @@ __device__ __forceinline__ void factor_lane(const St& S, const LaneIdx& X, float
     if constexpr (DAMP) {
         float d[2];
         sfor<0, 2>([&](auto Sd) { d[Sd] = S.W(WK_M + M_LEG0 + M_LEGSZ * Sd + X.own) + hdamp * S(F_DAMP + 6 + 13 * Sd + (l < 13 ? l : 12)); });
+        APX_LOCKSTEP();      // (pelvis lanes 13..15 read lane 12's diagonal word, for a result that goes to the sink)
         sfor<0, 2>([&](auto Sd) { S.W(l < 13 ? WK_M + M_LEG0 + M_LEGSZ * Sd + X.own : WK_DUMMY) = d[Sd]; });
         wsync();
     }

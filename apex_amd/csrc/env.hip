@@ -214,9 +214,11 @@ __device__ __forceinline__ void sim_step_pd(const St& S, const Cfg& cfg, int mod
 #else
     const bool satp = cfg.complete_pool != nullptr && S.W(c4::WK_MISC + 7) != 0.f;
     if (!satp) stage4_finish(S, mode, F, FR);
+    APX_CONVERGE();
     c4::wsync();
     if (__builtin_amdgcn_ballot_w64(satp) != 0ull) {
         if (satp) c4::substep_complete<HF>(S, rows4(), cfg.pgs_iters, cfg.hf, cfg.complete_pool, mode);
+        APX_CONVERGE();
         c4::wsync();
     }
 #endif
@@ -829,6 +831,7 @@ __device__ __noinline__ void rollout_restart(St S, const RolloutArgs* rap, float
     if (__builtin_amdgcn_ballot_w64(miss) != 0ull) {      // the ring does not hold the episode (more resets of one env than prepared images): compute the image in place, like part 0 of env_reset_kernel
         if (miss) {
             store_state(S, st, ist, n);                    // the env's own state waits in HBM while its LDS region is the working copy
+            APX_LOCKSTEP();                                // (every lane has copied its words out before the lead's draws overwrite them)
             if (lead) env_reset_draws(S, cfg, ep);
             c4::wsync();
             if (cfg.dyn_rand) setconst_lane(S);
@@ -838,8 +841,10 @@ __device__ __noinline__ void rollout_restart(St S, const RolloutArgs* rap, float
             for (int f = l; f < F_TOTAL; f += 16) img[(size_t)f * n] = S(f);
             if (lead) { rap->rst_int[(size_t)(2 * slot + 1) * n + env] = S.I(I_PHASE); rap->rst_int[(size_t)(2 * slot) * n + env] = ep; }
             __threadfence();
+            APX_LOCKSTEP();
             load_state(S, st, ist, n);
         }
+        APX_CONVERGE();
     }
     if (fin) {
         env_restart_head(S, cfg, n);
@@ -848,6 +853,7 @@ __device__ __noinline__ void rollout_restart(St S, const RolloutArgs* rap, float
         c4::wsync();
         if (lead) write_obs(S, cfg, (float*)stage);
     }
+    APX_CONVERGE();
     c4::wsync();
 }
 // MODE 0: feed-forward Gaussian actor (PPO), 1: recurrent actor (apx_rollout_lstm), 2: feed-forward deterministic actor with tanh head and clipped exploration noise (TD3)

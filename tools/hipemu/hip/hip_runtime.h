@@ -8,6 +8,7 @@
 // and the lane computes its own part of the result - lane-exact operand / accumulator layout of the 16 x 16 x 4 MFMA.  __syncthreads is a pthread barrier between the
 // wave threads, entered by the wave's scheduler once all of its lanes have asked for it.  The grid barrier of the kernel is its own code (atomics on shared memory).
 #pragma once
+#include <dlfcn.h>
 #include <ucontext.h>
 #include <pthread.h>
 #include <sys/wait.h>
@@ -90,13 +91,13 @@ __attribute__((naked, noinline)) inline void ctx_switch(void** /*save_sp: rdi*/,
 #else
 struct Ctx { ucontext_t uc; };
 #endif
-struct Lane { Ctx ctx; dim3 tid; int lane; unsigned ncoll; bool done; Wave* wave; char* stack; const void* conv_site; };
+struct Lane { Ctx ctx; dim3 tid; int lane; unsigned ncoll; bool done; Wave* wave; char* stack; const void* conv_site; unsigned conv_seq; };
 constexpr size_t STACK_BYTES = 1024 * 1024;
 constexpr int MAX_WAVES = 16;
 struct Wave {
     Lane lanes[64]; Ctx sched; int index;
     float A[2][64], B[2][64]; double Dv[2][64];
-    unsigned conv_gen, conv_ncoll;      // reconvergence points (hipemu::converge)
+    unsigned conv_counter;      // arrival order at reconvergence points (hipemu::converge)
     uint32_t X[2][64], Y[2][64]; const void* site[2][64];      // 32-bit lane exchanges (DPP, bpermute, readlane, ballot) and the call site each lane made its from
     int nlanes;
     bool want_barrier;
@@ -170,15 +171,19 @@ inline void run_block(dim3 block, const std::function<void()>& body) {
     static Wave* waves[MAX_WAVES];
     for (int w = 0; w < nw; ++w) {
         if (!waves[w]) waves[w] = new Wave();
-        Wave* W = waves[w]; W->index = w; W->want_barrier = false; W->conv_gen = 0; W->conv_ncoll = 0; W->block_barrier = &bar; W->body = &body;
+        Wave* W = waves[w]; W->index = w; W->want_barrier = false; W->conv_counter = 0; W->block_barrier = &bar; W->body = &body;
         W->nlanes = std::min(64, nthreads - 64 * w);
         for (int i = 0; i < W->nlanes; ++i) {
             Lane& l = W->lanes[i]; const unsigned t = w * 64 + i;
-            l.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y)); l.lane = i; l.ncoll = 0; l.done = false; l.wave = W; l.conv_site = nullptr;
+            l.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y)); l.lane = i; l.ncoll = 0; l.done = false; l.wave = W; l.conv_site = nullptr; l.conv_seq = 0;
             l.stack = g_stacks + (size_t)(w * 64 + i) * STACK_BYTES;
         }
     }
     ++g_block_gen;
+    static const int lds_fill = getenv("HIPEMU_LDS_FILL") ? (int)strtol(getenv("HIPEMU_LDS_FILL"), nullptr, 0) : -1;      // what a workgroup finds in its dynamic LDS: by default what the one before it left (as on the hardware: anything); 0x00 / 0xff ...: that byte
+    if (lds_fill >= 0) memset(g_dynsmem, lds_fill, sizeof g_dynsmem);
+    static const int stack_fill = getenv("HIPEMU_STACK_FILL") ? (int)strtol(getenv("HIPEMU_STACK_FILL"), nullptr, 0) : -1;      // the lanes' "registers" before the kernel body runs (top 96 KB of each fiber stack): a result that depends on this byte reads a variable it never set
+    if (stack_fill >= 0) for (int w = 0; w < nw; ++w) for (int i = 0; i < waves[w]->nlanes; ++i) memset(waves[w]->lanes[i].stack + STACK_BYTES - 96 * 1024, stack_fill, 96 * 1024);
     if (nw == 1) run_wave(waves[0]);
     else {
         std::vector<std::thread> th;
@@ -263,6 +268,7 @@ inline void __builtin_amdgcn_sched_barrier(int) {}
 // flow: a source lane that deposited from ANOTHER call site means the lanes of the wave have diverged around a collective, and the run aborts saying so.  A lane that has
 // left the kernel is an inactive lane: its word reads as zero (DPP with bound_ctrl, the way the kernels use it) and it is absent from ballots.
 namespace hipemu {
+inline uintptr_t rel(const void* p) { Dl_info i; return dladdr(p, &i) && i.dli_fbase ? (uintptr_t)p - (uintptr_t)i.dli_fbase : (uintptr_t)p; }      // offset inside the library: llvm-symbolizer -e lib --inlines +0x..
 struct Xchg { Wave* W; int buf, lane; const void* site; };
 #define HIPEMU_NOCOV __attribute__((no_sanitize("coverage")))
 HIPEMU_NOCOV __attribute__((noinline)) inline Xchg exchange2(uint32_t x, uint32_t y) {
@@ -276,31 +282,33 @@ HIPEMU_NOCOV __attribute__((noinline)) inline Xchg exchange2(uint32_t x, uint32_
 HIPEMU_NOCOV inline uint32_t peek(const Xchg& e, int src, bool second = false) {
     if (src < 0 || src >= e.W->nlanes || e.W->lanes[src].done || e.W->lanes[src].conv_site) return 0u;      // no such lane / it has left the kernel / it sits out this branch (parked at a reconvergence point): an inactive lane
     if (e.W->site[e.buf][src] != e.site) {
-        fprintf(stderr, "hipemu: lane %d reads lane %d across DIVERGED control flow (collective call sites %p vs %p)\n", e.lane, src, e.site, e.W->site[e.buf][src]);
+        fprintf(stderr, "hipemu: lane %d reads lane %d across DIVERGED control flow (collective call sites +0x%lx vs +0x%lx)\n", e.lane, src, (unsigned long)rel(e.site), (unsigned long)rel(e.W->site[e.buf][src]));
         abort();
     }
     return second ? e.W->Y[e.buf][src] : e.W->X[e.buf][src];
 }
-// Reconvergence point (APX_CONVERGE() in the kernel source, behind a branch that only some ROWS of the wave take and that holds collectives): a lane waits here until
-// every live lane of the wave has arrived; the lanes inside the branch meanwhile run their collectives among themselves (a parked lane reads as inactive).  On the
-// hardware the exec mask does this by itself.
+// Reconvergence point (APX_CONVERGE() in the kernel source: where the lanes that entered a branch taken by only some ROWS of the wave - a branch that holds
+// collectives - are together again; the exec mask's business on the hardware).  A lane parks here.  When every live lane of the wave is parked somewhere, the group that
+// parked LAST is released: rows that sat a branch out park behind it at once, the rows inside arrive later - at an inner point first, whose group is then the
+// latest, and in the end at the outer point.  A parked lane reads as an inactive lane (zero operand, absent from ballots).
 HIPEMU_NOCOV __attribute__((noinline)) inline void converge() {
     Lane* l = g_cur; Wave* W = l->wave;
-    const void* site = __builtin_return_address(0);
-    const unsigned gen = W->conv_gen;
-    l->conv_site = site;
-    for (;;) {
-        if (W->conv_gen != gen) break;
-        int waiting = 0, live = 0; unsigned mx = 0;
+    l->conv_site = __builtin_return_address(0); l->conv_seq = ++W->conv_counter;
+    while (l->conv_site) {                      // (cleared by whichever lane releases this lane's group)
+        int parked = 0, live = 0; unsigned mx = 0, last_seq = 0; const void* last_site = nullptr;
         for (int i = 0; i < W->nlanes; ++i) {
             const Lane& o = W->lanes[i];
             if (o.done) continue;
-            ++live; mx = std::max(mx, o.ncoll); waiting += o.conv_site == site;
+            ++live; mx = std::max(mx, o.ncoll);
+            if (o.conv_site) { ++parked; if (o.conv_seq > last_seq) { last_seq = o.conv_seq; last_site = o.conv_site; } }
         }
-        if (waiting == live) { W->conv_gen = gen + 1; W->conv_ncoll = (mx + 2) & ~1u; break; }
+        if (parked == live) {
+            const unsigned nc = (mx + 2) & ~1u;      // the released lanes count their collectives from a common (even) number again
+            for (int i = 0; i < W->nlanes; ++i) { Lane& o = W->lanes[i]; if (!o.done && o.conv_site == last_site) { o.conv_site = nullptr; o.ncoll = nc; } }
+            continue;
+        }
         yield();
     }
-    l->conv_site = nullptr; l->ncoll = W->conv_ncoll;
 }
 inline float asf(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 inline uint32_t asu(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -320,20 +328,20 @@ inline int dpp_src(int ctrl, int ln) {
 inline float dpp_get(const Xchg& e, int ctrl, bool second = false) { return asf(peek(e, dpp_src(ctrl, e.lane), second)); }
 }  // namespace hipemu
 
-inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+__attribute__((always_inline)) inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     if (old != 0 || row_mask != 0xF || bank_mask != 0xF || !bound_ctrl) { fprintf(stderr, "hipemu: update_dpp form not emulated\n"); abort(); }
     const hipemu::Xchg e = hipemu::exchange2((uint32_t)src, 0u);
     return (int)hipemu::peek(e, hipemu::dpp_src(ctrl, e.lane));
 }
-inline int __builtin_amdgcn_ds_bpermute(int addr, int v) {
+__attribute__((always_inline)) inline int __builtin_amdgcn_ds_bpermute(int addr, int v) {
     const hipemu::Xchg e = hipemu::exchange2((uint32_t)v, 0u);
     return (int)hipemu::peek(e, (addr >> 2) & 63);
 }
-inline int __builtin_amdgcn_readlane(int v, int k) {
+__attribute__((always_inline)) inline int __builtin_amdgcn_readlane(int v, int k) {
     const hipemu::Xchg e = hipemu::exchange2((uint32_t)v, 0u);
     return (int)hipemu::peek(e, k & 63);
 }
-HIPEMU_NOCOV inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) {
+__attribute__((always_inline)) HIPEMU_NOCOV inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) {
     const hipemu::Xchg e = hipemu::exchange2(p ? 1u : 0u, 0u);
     unsigned long long m = 0;
     for (int i = 0; i < e.W->nlanes; ++i) m |= (unsigned long long)(hipemu::peek(e, i) & 1u) << i;
@@ -341,7 +349,7 @@ HIPEMU_NOCOV inline unsigned long long __builtin_amdgcn_ballot_w64(bool p) {
 }
 // a wave is one instruction stream: LDS / memory written by a lane in front of this point is visible to every lane behind it.  Under the emulation the lanes are fibers
 // that run from collective to collective, so the hand-off needs a rendezvous
-inline void __builtin_amdgcn_wave_barrier() { hipemu::exchange2(0u, 0u); }
+__attribute__((always_inline)) inline void __builtin_amdgcn_wave_barrier() { hipemu::exchange2(0u, 0u); }
 inline void __builtin_amdgcn_fence(int, const char*) {}
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline float __frcp_rn(float x) { return 1.0f / x; }
@@ -375,9 +383,8 @@ inline std::set<std::pair<const void*, const void*>> g_reported;
 inline long g_conflicts = 0;
 inline bool g_in_check = false;
 // a store is reported when it has happened (the callback runs in front of it): a store of the value the word already held orders nothing
-struct Pending { uintptr_t word; uint32_t old; int lane, other; const void* site; const void* osite; };
+struct Pending { uintptr_t word; uint32_t old; int lane, other; const void* site; const void* osite; bool waw; };
 inline std::vector<Pending> g_pending;
-inline uintptr_t rel(const void* p) { Dl_info i; return dladdr(p, &i) && i.dli_fbase ? (uintptr_t)p - (uintptr_t)i.dli_fbase : (uintptr_t)p; }
 inline void conflict(const char* kind, uintptr_t word, int lane, int other, const void* site, const void* osite) {
     ++g_conflicts;
     if (!g_reported.insert({site, osite}).second) return;
@@ -387,7 +394,9 @@ inline void conflict(const char* kind, uintptr_t word, int lane, int other, cons
 }
 inline void flush_pending() {
     for (const Pending& q : g_pending)
-        if (*(const volatile uint32_t*)(q.word * 4) != q.old) conflict("store behind another lane's load (program order: the load comes first or the store - the emulation ran the load first)", q.word, q.lane, q.other, q.site, q.osite);
+        if (*(const volatile uint32_t*)(q.word * 4) != q.old)
+            conflict(q.waw ? "two lanes store DIFFERENT values to one word (the later lane's stays here; on the hardware: program order, or unspecified within one instruction)"
+                           : "store behind another lane's load (program order: the load comes first or the store - the emulation ran the load first)", q.word, q.lane, q.other, q.site, q.osite);
     g_pending.clear();
 }
 inline void access(const void* addr, int bytes, bool store, const void* site) {
@@ -403,7 +412,8 @@ inline void access(const void* addr, int bytes, bool store, const void* site) {
         Shadow& sh = g_shadow[w];
         const uint32_t now = *(const volatile uint32_t*)(w * 4);
         if (store) {
-            if (sh.rep == ep && (sh.rmask & ~(1ull << l->lane))) g_pending.push_back(Pending{w, now, l->lane, __builtin_ctzll(sh.rmask & ~(1ull << l->lane)), site, sh.rsite});
+            if (sh.rep == ep && (sh.rmask & ~(1ull << l->lane))) g_pending.push_back(Pending{w, now, l->lane, __builtin_ctzll(sh.rmask & ~(1ull << l->lane)), site, sh.rsite, false});
+            if (sh.wep == ep && sh.wlane != l->lane) g_pending.push_back(Pending{w, now, l->lane, sh.wlane, site, sh.wsite, true});
             if (sh.wep != ep || sh.wlane != l->lane) sh.wold = now;      // (stores of different lanes to one word in one interval: the sinks of predicated-off stores - not reported)
             sh.wep = ep; sh.wlane = l->lane; sh.wsite = site;
         } else {
