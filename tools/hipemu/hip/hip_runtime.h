@@ -98,7 +98,7 @@ struct Wave {
     Lane lanes[64]; Ctx sched; int index;
     float A[2][64], B[2][64]; double Dv[2][64];
     unsigned conv_counter;      // arrival order at reconvergence points (hipemu::converge)
-    uint32_t X[2][64], Y[2][64]; const void* site[2][64];      // 32-bit lane exchanges (DPP, bpermute, readlane, ballot) and the call site each lane made its from
+    uint32_t X[8][64], Y[8][64]; const void* site[8][64]; unsigned seq[8][64];      // 8 deposit slots per lane: a lane may run up to 7 exchanges ahead of a reader of its deposit      // 32-bit lane exchanges (DPP, bpermute, readlane, ballot) and the call site each lane made its from
     int nlanes;
     bool want_barrier;
     pthread_barrier_t* block_barrier;
@@ -171,7 +171,7 @@ inline void run_block(dim3 block, const std::function<void()>& body) {
     static Wave* waves[MAX_WAVES];
     for (int w = 0; w < nw; ++w) {
         if (!waves[w]) waves[w] = new Wave();
-        Wave* W = waves[w]; W->index = w; W->want_barrier = false; W->conv_counter = 0; W->block_barrier = &bar; W->body = &body;
+        Wave* W = waves[w]; W->index = w; W->want_barrier = false; W->conv_counter = 0; memset(W->seq, 0xff, sizeof W->seq); W->block_barrier = &bar; W->body = &body;
         W->nlanes = std::min(64, nthreads - 64 * w);
         for (int i = 0; i < W->nlanes; ++i) {
             Lane& l = W->lanes[i]; const unsigned t = w * 64 + i;
@@ -269,23 +269,36 @@ inline void __builtin_amdgcn_sched_barrier(int) {}
 // left the kernel is an inactive lane: its word reads as zero (DPP with bound_ctrl, the way the kernels use it) and it is absent from ballots.
 namespace hipemu {
 inline uintptr_t rel(const void* p) { Dl_info i; return dladdr(p, &i) && i.dli_fbase ? (uintptr_t)p - (uintptr_t)i.dli_fbase : (uintptr_t)p; }      // offset inside the library: llvm-symbolizer -e lib --inlines +0x..
-struct Xchg { Wave* W; int buf, lane; const void* site; };
+struct Xchg { Wave* W; int buf, lane; const void* site; unsigned seq; };
 #define HIPEMU_NOCOV __attribute__((no_sanitize("coverage")))
 HIPEMU_NOCOV __attribute__((noinline)) inline Xchg exchange2(uint32_t x, uint32_t y) {
     Lane* l = g_cur; Wave* W = l->wave;
-    const int buf = l->ncoll++ & 1, ln = l->lane;
+    const unsigned seq = l->ncoll++;
+    const int buf = seq & 7, ln = l->lane;
     const void* site = __builtin_return_address(0);
-    W->X[buf][ln] = x; W->Y[buf][ln] = y; W->site[buf][ln] = site;
+    W->X[buf][ln] = x; W->Y[buf][ln] = y; W->site[buf][ln] = site; W->seq[buf][ln] = seq;
     yield();
-    return Xchg{W, buf, ln, site};
+    return Xchg{W, buf, ln, site, seq};
 }
 HIPEMU_NOCOV inline uint32_t peek(const Xchg& e, int src, bool second = false) {
-    if (src < 0 || src >= e.W->nlanes || e.W->lanes[src].done || e.W->lanes[src].conv_site) return 0u;      // no such lane / it has left the kernel / it sits out this branch (parked at a reconvergence point): an inactive lane
-    if (e.W->site[e.buf][src] != e.site) {
-        fprintf(stderr, "hipemu: lane %d reads lane %d across DIVERGED control flow (collective call sites +0x%lx vs +0x%lx)\n", e.lane, src, (unsigned long)rel(e.site), (unsigned long)rel(e.W->site[e.buf][src]));
-        abort();
+    if (src < 0 || src >= e.W->nlanes) return 0u;      // no such lane
+    for (long spins = 0;; ++spins) {
+        if (e.W->seq[e.buf][src] == e.seq) {            // the source lane's deposit for THIS exchange (wherever that lane is by now)
+            if (e.W->site[e.buf][src] != e.site) {
+                fprintf(stderr, "hipemu: lane %d reads lane %d across DIVERGED control flow (collective call sites +0x%lx vs +0x%lx)\n", e.lane, src, (unsigned long)rel(e.site), (unsigned long)rel(e.W->site[e.buf][src]));
+                abort();
+            }
+            return second ? e.W->Y[e.buf][src] : e.W->X[e.buf][src];
+        }
+        const Lane& o = e.W->lanes[src];
+        if (o.done || o.conv_site) return 0u;           // it has left the kernel / sits this branch out at a reconvergence point: an inactive lane (zero operand, absent from ballots)
+        if (spins > 4000000) {
+            fprintf(stderr, "hipemu: lane %d waits for lane %d at site +0x%lx (its collective %u, the other lane's %u): rows that took different paths meet here without a reconvergence point\n",
+                    e.lane, src, (unsigned long)rel(e.site), e.seq, o.ncoll);
+            abort();
+        }
+        yield();                                        // the source lane has not reached this exchange yet (lanes fall out of step behind reconvergence points)
     }
-    return second ? e.W->Y[e.buf][src] : e.W->X[e.buf][src];
 }
 // Reconvergence point (APX_CONVERGE() in the kernel source: where the lanes that entered a branch taken by only some ROWS of the wave - a branch that holds
 // collectives - are together again; the exec mask's business on the hardware).  A lane parks here.  When every live lane of the wave is parked somewhere, the group that
