@@ -11,7 +11,7 @@
 #define APX_LOCKSTEP() ((void)hipemu::exchange2(0u, 0u))
 #define APX_CONVERGE() hipemu::converge()
 // the dynamic LDS segment of the running workgroup
-#define APX_DYNAMIC_LDS(T, name, alignment) static T* const name = (T*)hipemu::g_dynsmem
+#define APX_DYNAMIC_LDS(T, name, alignment) static thread_local T* const name = (T*)hipemu::g_dynsmem
 
 namespace c4 {
 

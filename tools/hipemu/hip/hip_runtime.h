@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <functional>
 #include <map>
 #include <string>
@@ -105,9 +106,21 @@ struct Wave {
     const std::function<void()>* body;
 };
 inline thread_local Lane* g_cur = nullptr;
-inline dim3 g_grid, g_block, g_bidx;
-inline char g_dynsmem[160 * 1024] __attribute__((aligned(64)));      // the dynamic LDS segment of the running workgroup (`extern __shared__`, see build.sh)
-inline char* g_stacks = nullptr;                                      // MAX_WAVES x 64 fiber stacks, mapped once (untouched pages cost nothing)
+inline dim3 g_grid, g_block;
+inline thread_local dim3 g_bidx;
+// the dynamic LDS segment of the running workgroup (`extern __shared__`, see build.sh) and its fiber stacks: per host thread, because the single-wave workgroups of a launch
+// that do not wait for each other (the env kernels) are dealt over host threads (HIPEMU_THREADS, default: the cores)
+constexpr size_t DYNSMEM_BYTES = 160 * 1024;
+inline thread_local char* g_dynsmem = nullptr;      // (allocated by the thread that runs the workgroup; the wave threads of a multi-wave workgroup are handed the same block)
+// fiber stacks of the workgroups a host thread runs: mapped on first use for as many waves as that workgroup has, unmapped when the thread ends (the threads of a
+// threaded launch live for one launch: left mapped, a test session piles up terabytes of address space and every later fork() of a workgroup process crawls)
+struct StackArena {
+    char* base = nullptr; size_t bytes = 0;
+    ~StackArena() { if (base) munmap(base, bytes); }
+};
+inline thread_local StackArena g_stack_arena;
+struct LdsArena { char* p = nullptr; ~LdsArena() { free(p); } };
+inline thread_local LdsArena g_lds_arena;
 inline std::map<std::string, long> g_launches;      // launches per kernel expression as written at the launch site (tests ask which kernels a path really took)
 inline uint64_t g_block_gen = 0;      // workgroups run so far (the lockstep checker's epochs)
 inline int g_force_grid = 0;      // > 0: every launch runs with this many workgroups whatever the host code asked for
@@ -166,9 +179,17 @@ inline void run_wave(Wave* W) {
 inline void run_block(dim3 block, const std::function<void()>& body) {
     const int nthreads = (int)(block.x * block.y * block.z), nw = (nthreads + 63) / 64;
     if (nw > MAX_WAVES) { fprintf(stderr, "hipemu: workgroup of %d threads\n", nthreads); abort(); }
-    if (!g_stacks) g_stacks = (char*)mmap(nullptr, (size_t)MAX_WAVES * 64 * STACK_BYTES, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (!g_lds_arena.p) g_lds_arena.p = (char*)aligned_alloc(64, DYNSMEM_BYTES);
+    g_dynsmem = g_lds_arena.p;
+    StackArena& sa = g_stack_arena;
+    const size_t want = (size_t)nw * 64 * STACK_BYTES;
+    if (sa.bytes < want) {
+        if (sa.base) munmap(sa.base, sa.bytes);
+        sa.base = (char*)mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0); sa.bytes = want;
+    }
+    char* const g_stacks = sa.base;
     pthread_barrier_t bar; pthread_barrier_init(&bar, nullptr, nw);
-    static Wave* waves[MAX_WAVES];
+    static thread_local Wave* waves[MAX_WAVES];
     for (int w = 0; w < nw; ++w) {
         if (!waves[w]) waves[w] = new Wave();
         Wave* W = waves[w]; W->index = w; W->want_barrier = false; W->conv_counter = 0; memset(W->seq, 0xff, sizeof W->seq); W->block_barrier = &bar; W->body = &body;
@@ -179,25 +200,43 @@ inline void run_block(dim3 block, const std::function<void()>& body) {
             l.stack = g_stacks + (size_t)(w * 64 + i) * STACK_BYTES;
         }
     }
+#ifdef HIPEMU_LOCKSTEP_CHECK
     ++g_block_gen;
+#endif
     static const int lds_fill = getenv("HIPEMU_LDS_FILL") ? (int)strtol(getenv("HIPEMU_LDS_FILL"), nullptr, 0) : -1;      // what a workgroup finds in its dynamic LDS: by default what the one before it left (as on the hardware: anything); 0x00 / 0xff ...: that byte
-    if (lds_fill >= 0) memset(g_dynsmem, lds_fill, sizeof g_dynsmem);
+    if (lds_fill >= 0) memset(g_dynsmem, lds_fill, DYNSMEM_BYTES);
     static const int stack_fill = getenv("HIPEMU_STACK_FILL") ? (int)strtol(getenv("HIPEMU_STACK_FILL"), nullptr, 0) : -1;      // the lanes' "registers" before the kernel body runs (top 96 KB of each fiber stack): a result that depends on this byte reads a variable it never set
     if (stack_fill >= 0) for (int w = 0; w < nw; ++w) for (int i = 0; i < waves[w]->nlanes; ++i) memset(waves[w]->lanes[i].stack + STACK_BYTES - 96 * 1024, stack_fill, 96 * 1024);
     if (nw == 1) run_wave(waves[0]);
     else {
         std::vector<std::thread> th;
-        for (int w = 0; w < nw; ++w) th.emplace_back(run_wave, waves[w]);
+        char* const lds = g_dynsmem; const dim3 bidx = g_bidx;      // (thread-local in the thread that runs the workgroup: handed to its wave threads)
+        for (int w = 0; w < nw; ++w) th.emplace_back([lds, bidx](Wave* W) { g_dynsmem = lds; g_bidx = bidx; run_wave(W); }, waves[w]);
         for (auto& t : th) t.join();
     }
     pthread_barrier_destroy(&bar);
 }
 // Default: the workgroups of a launch run one after the other in this process (kernels whose workgroups do not wait for each other).  With g_force_grid > 0 a launch
 // becomes that many CONCURRENT workgroups, one forked process each (a kernel with a grid barrier; its buffers must be MAP_SHARED).
-inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+inline void launch(dim3 grid, dim3 block, const std::function<void()>& body, size_t dyn_lds = 0) {
     g_block = block;
     if (g_force_grid <= 0) {
         g_grid = grid;
+#ifndef HIPEMU_LOCKSTEP_CHECK
+        static const int host_threads = getenv("HIPEMU_THREADS") ? atoi(getenv("HIPEMU_THREADS")) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        const unsigned total = grid.x * grid.y * grid.z;
+        // single-wave workgroups that ask for DYNAMIC LDS (the env kernels; `__shared__` arrays are process-wide statics here: a kernel that declares one keeps to one thread)
+        if (host_threads > 1 && total >= 4 && block.x * block.y * block.z <= 64 && dyn_lds > 0) {
+            std::atomic<unsigned> next{0};
+            std::vector<std::thread> th;
+            for (int t = 0; t < std::min<int>(host_threads, (int)total); ++t)
+                th.emplace_back([&]() {
+                    for (unsigned b = next++; b < total; b = next++) { g_bidx = dim3(b % grid.x, (b / grid.x) % grid.y, b / (grid.x * grid.y)); run_block(block, body); }
+                });
+            for (auto& t : th) t.join();
+            return;
+        }
+#endif
         for (unsigned z = 0; z < grid.z; ++z)
             for (unsigned y = 0; y < grid.y; ++y)
                 for (unsigned x = 0; x < grid.x; ++x) { g_bidx = dim3(x, y, z); run_block(block, body); }
@@ -225,7 +264,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
 #define blockIdx (hipemu::g_bidx)
 #define gridDim (hipemu::g_grid)
 #define blockDim (hipemu::g_block)
-#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) (hipemu::g_launches[#kern] += 1, hipemu::launch(grid, block, [=]() { kern(__VA_ARGS__); }))
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) (hipemu::g_launches[#kern] += 1, hipemu::launch(grid, block, [=]() { kern(__VA_ARGS__); }, (size_t)(shmem)))
 
 // the residency queries and the cooperative launch of tiles::launch_resident (mlp_tiles.h): the emulated device holds what the test asks for (g_force_grid workgroups)
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount, hipDeviceAttributeCooperativeLaunch };
@@ -401,7 +440,7 @@ inline std::vector<Pending> g_pending;
 inline void conflict(const char* kind, uintptr_t word, int lane, int other, const void* site, const void* osite) {
     ++g_conflicts;
     if (!g_reported.insert({site, osite}).second) return;
-    const bool lds = word * 4 >= (uintptr_t)g_dynsmem && word * 4 < (uintptr_t)g_dynsmem + sizeof g_dynsmem;
+    const bool lds = word * 4 >= (uintptr_t)g_dynsmem && word * 4 < (uintptr_t)g_dynsmem + DYNSMEM_BYTES;
     fprintf(stderr, "hipemu lockstep: %s on %s word %ld: lane %d at +0x%lx vs lane %d at +0x%lx, no rendezvous between them\n", kind, lds ? "LDS" : "memory",
             lds ? (long)(word - (uintptr_t)g_dynsmem / 4) : (long)word, lane, (unsigned long)rel(site), other, (unsigned long)rel(osite));
 }
