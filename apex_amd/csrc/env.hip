@@ -913,6 +913,7 @@ __global__ __launch_bounds__(64, APX_WAVES_PER_EU) void env_rollout_kernel(float
         if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {
             rollout_restart<HF>(S, rap, st, ist, n, fin);
             if (MODE == 1 && fin) { float* q = RA(hc) + (size_t)env * 512 + l; for (int k = 0; k < 512; k += 16) q[k] = 0.f; }      // a new episode starts from the zero state (ppo.py:164-168)
+            if (MODE == 1) APX_LOCKSTEP();      // (the next step's cell loads every env's (h, c) on all 64 lanes: behind these stores in the wave's memory order)
         }
         float* on = (t + 1 < RA(T) ? RA(obs_grid) + (size_t)(t + 1) * n * D : RA(obs_next)) + (size_t)env * D;
         for (int k = l; k < D; k += 16) on[k] = stage[k];

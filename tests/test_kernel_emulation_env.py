@@ -89,7 +89,7 @@ def test_emulated_prepared_resets_are_bit_identical_to_computed_ones(dev):
     step and one never (its restarts compute the image on demand: the `need` rows of env_reset_kernel next to rows that only restart), 64 envs, episodes of 2 steps, 5
     steps: observations, rewards, done flags and the state fields bit-identical; every env restarted twice"""
     from apex_amd.vecenv import CassieVecEnv
-    for kw in (dict(), dict(env_name="CassieTraj-v0")):
+    for kw in (dict(), dict(env_name="CassieTraj-v0")) if os.environ.get("APX_EMUL_FULL") == "1" else (dict(),):
         a = CassieVecEnv(n_envs=64, seed=31, max_traj_len=2, **kw); b = CassieVecEnv(n_envs=64, seed=31, max_traj_len=2, **kw)
         a.set_refill(False); b.set_refill(False)
         oa, ob = a.reset().clone(), b.reset().clone()
@@ -141,3 +141,128 @@ def test_emulated_one_launch_rollout_equals_the_stepwise_loop(dev):
     assert (dr <= 5e-3).mean() > 0.99 and dr.max() < 0.1, dr.max()
     assert int(a.env.get_field("reset_miss")[0, 0]) == 0 and int(a.env.get_field("ints")[:, 9].min()) >= 2
     assert torch.isfinite(a.b_obs).all() and torch.isfinite(a.b_val).all()
+
+
+# The bodies of the GPU parity tests of tests/test_gpu_env.py, unchanged, on the emulated sources.  Default suite: the ones that take seconds; APX_EMUL_FULL=1: all of them
+# (results of the last full run: profiles/r06_emulation_checks.txt).
+full = pytest.mark.skipif(os.environ.get("APX_EMUL_FULL") != "1", reason="a minute or more of emulation each: APX_EMUL_FULL=1")
+
+
+def test_emulated_crafted_states_and_saturation_flags(dev):
+    """single substeps from crafted states (joint limits, shin / tarsus / third capsule end on the floor, hip-pitch capsule, pelvis sphere, leg-leg pairs: the COMPLETE
+    row path of cassie_complete.h) against the oracle's complete row set; saturation flags"""
+    G = _gpu_env_tests()
+    G.test_single_substep_crafted_states(dev)
+    G.test_saturation_flags_vs_oracle_crafted(dev)
+
+
+def test_emulated_eval_entry_points(dev):
+    """update_speed / reset_for_test, step_basic, the wrench on any body, CassieTraj-v0's reset and steps, the estimator record's recovery"""
+    G = _gpu_env_tests()
+    G.test_update_speed_and_reset_for_test_vs_oracle(dev)
+    G.test_step_basic_vs_oracle(dev)
+    G.test_apply_force_on_any_body_vs_oracle(dev)
+    G.test_cassie_traj_v0_reset_and_steps_vs_oracle(dev)
+    G.test_estimator_record_recovers_from_non_finite_state(dev)
+
+
+def test_emulated_phase_command_profile(dev):
+    _gpu_env_tests().test_phase_command_profile_vs_oracle(dev, "clock", 1)
+
+
+@full
+@pytest.mark.parametrize("name", ["test_env_steps_vs_oracle", "test_min_input_profile_vs_oracle", "test_fractional_phase_add_vs_oracle", "test_observation_history_stack",
+                                  "test_diverged_env_ends_its_episode", "test_estimator_twin_from_identical_state", "test_teacher_forced_env_steps_random_actions",
+                                  "test_teacher_forced_env_steps_on_walking_states"])
+def test_emulated_gpu_env_test_body(dev, name):
+    getattr(_gpu_env_tests(), name)(dev)
+
+
+@full
+@pytest.mark.parametrize("kind", ["slope", "noise", "hills"])
+def test_emulated_heightfield_terrain(dev, kind):
+    _gpu_env_tests().test_heightfield_terrain_vs_oracle(dev, kind)
+
+
+@full
+def test_emulated_phase_command_profile_library(dev):
+    _gpu_env_tests().test_phase_command_profile_vs_oracle(dev, "library_clock", 2)
+
+
+@full
+def test_emulated_full_reset_and_apply_force(dev, golden_dir):
+    _gpu_env_tests().test_full_reset_and_apply_force_vs_oracle(dev, golden_dir)
+
+
+def _scenario_names():
+    from tests.tf_scenarios import SCENARIOS
+    return [s.name for s in SCENARIOS]
+
+
+@full
+@pytest.mark.parametrize("name", _scenario_names())
+def test_emulated_teacher_forced_scenario(dev, name):
+    """every teacher-forced scenario of the GPU suite (safety zones, coupled zone, early / max_vel rewards, pushes, height fields, phase profile, eval entry points ..):
+    kernel state overwritten with the oracle's before every env step, FIXED tolerances on the identical-row-set population"""
+    _gpu_env_tests().test_teacher_forced_scenario(dev, name)
+
+
+def test_emulated_td3_one_launch_collection(dev, tmp_path):
+    """env_rollout_kernel<MODE 2> (apx_rollout_td3: deterministic actor with tanh head, clipped scalar exploration noise, in-kernel restarts) - the assertions of
+    test_gpu_ppo.py::test_td3_one_launch_collection on 64 envs x 4 steps with episodes of 2 steps, update block 4 x 1 updates of 64 rows through the emulated learner"""
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd.td3 import TD3
+    from apex_amd import engine
+    N, T = 64, 4
+    env = CassieVecEnv(n_envs=N, seed=4, max_traj_len=2)
+    algo = TD3(env, str(tmp_path), hidden=256, act_noise=0.3, batch_size=64, updates_per_step=1, replay_size=N * T, seed=1)
+    algo.init_networks(0)
+    p0 = algo.learner.actor.params.clone()
+    out = algo.collect_and_train(T)
+    assert out["updates"] == T and algo.replay.size == N * T
+    g, noise = algo._g, algo._noise_last
+    pre = engine.Mlp(50, 256, 10, dev); pre.params.copy_(p0)
+    m = torch.tanh(pre.forward(g["obs"].view(T * N, 50))).view(T, N, 10)
+    d = (g["mu"] - m).abs()
+    big = g["obs"].abs().amax(-1, keepdim=True)
+    assert float((d / (1.0 + big)).max()) < 2e-6, float((d / (1.0 + big)).max())
+    np.testing.assert_allclose(g["act"].numpy(), (g["mu"] + 0.3 * noise.view(T, N, 1)).clamp(-1, 1).numpy(), rtol=0, atol=1e-6)
+    assert int((g["done"] != 0).sum()) >= 2 * N
+    R = algo.replay
+    assert torch.equal(R.s[:N * T].view(T, N, 50), g["obs"]) and torch.equal(R.a[:N * T].view(T, N, 10), g["act"]) and torch.equal(R.r[:N * T].view(T, N), g["rew"])
+    ended = g["done"] != 0
+    assert torch.equal(R.nd[:N * T].view(T, N), (~ended).float())
+    nxt = torch.cat([g["obs"][1:], g["nxt"].unsqueeze(0)])
+    assert torch.equal(R.s2[:N * T].view(T, N, 50), torch.where(ended.unsqueeze(-1), g["fin"], nxt))
+    assert not torch.equal(algo.learner.actor.params, p0) and torch.isfinite(algo.learner.actor.params).all()
+
+
+def test_emulated_one_launch_recurrent_rollout(dev, tmp_path):
+    """env_rollout_kernel<MODE 1> (apx_rollout_lstm: two LSTMCell(128) + head per wave inside the rollout, hidden state zeroed where an episode ends) - the identity of
+    test_gpu_ppo.py::test_one_launch_recurrent_rollout_means_match_the_sequence_pass on 64 CassieTraj-v0 envs x 6 steps with episodes of 3 steps: the learner's padded
+    sequence pass from the zero state over whole trajectories cut out of the grid reproduces the means the in-kernel actor produced step by step with its carried (h, c)"""
+    from apex_amd.vecenv import CassieVecEnv
+    from apex_amd.ppo_recurrent import RecurrentPPO
+    N, T, mtl = 64, 6, 3
+    env = CassieVecEnv(n_envs=N, seed=9, max_traj_len=mtl, env_name="CassieTraj-v0")
+    args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=64, epochs=1, num_steps=T * N, max_traj_len=mtl,
+                max_grad_norm=0.05, mirror=True, seed=3, env_name="CassieTraj-v0")
+    algo = RecurrentPPO(args, str(tmp_path), env, hidden=128, layers=2)
+    algo.init_networks(0)
+    L = algo.learner
+    ret = algo.sample()
+    noise = algo._noise_all
+    done = algo.b_done.numpy()
+    assert np.isfinite(algo.b_obs.numpy()).all() and np.isfinite(algo.b_rew.numpy()).all() and np.isfinite(ret.numpy()).all()
+    assert (done == 2).sum() == N * (T // mtl)
+    np.testing.assert_allclose(algo.b_act.numpy(), (algo._b_mu + algo.fixed_std * noise).numpy(), rtol=0, atol=1e-6)
+    trajs = algo.trajectories()
+    assert len(trajs) == 2 * N and (trajs[:, 1] > 0).any()
+    idx = algo.padded_index(trajs)
+    valid = idx >= 0
+    gi = idx.clamp(min=0).view(-1)
+    obs_p = (algo.b_obs.view(T * N, 50).index_select(0, gi) * valid.view(-1, 1)).view(idx.shape[0], len(trajs), 50)
+    mu_seq = L.actor.forward(((obs_p - L.obs_mean) / L.obs_std).contiguous())
+    mu_roll = algo._b_mu.view(T * N, 10).index_select(0, gi).view(idx.shape[0], len(trajs), 10)
+    d = ((mu_seq - mu_roll) * valid.unsqueeze(-1)).abs().max()
+    assert float(d) < 2e-5, float(d)
