@@ -64,6 +64,48 @@ def kernel_source_hash():
     return h.hexdigest()[:12]
 
 
+def kernel_isa_hash():
+    """sha1 over the INSTRUCTION STREAM of the env code object of the built library (the largest gfx950 object of libapx.so, disassembled, addresses stripped), or None
+    without the ROCm binutils.  profiles/kernel_identity.json maps the source hash a profile was taken on to this hash: a refactor that leaves every instruction in place
+    (round 6: the inline assembly moved into gfx950/lane_ops.h, emulation marks that expand to nothing) keeps the profile quotable."""
+    import hashlib, shutil, subprocess, tempfile
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    lib = os.path.join(REPO, "apex_amd", "lib", "libapx.so")
+    if not (os.path.exists(objdump) and os.path.exists(lib)):
+        return None
+    d = tempfile.mkdtemp()
+    try:
+        shutil.copy(lib, os.path.join(d, "lib.so"))
+        subprocess.run([objdump, "--offloading", "lib.so"], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        cos = [os.path.join(d, f) for f in os.listdir(d) if "gfx950" in f]
+        if not cos:
+            return None
+        asm = subprocess.run([objdump, "-d", "--mcpu=gfx950", max(cos, key=os.path.getsize)], capture_output=True, text=True).stdout
+        body = "\n".join(ln.split(":", 1)[1] if ":" in ln else ln for ln in asm.split("\n")[2:])
+        return hashlib.sha1(body.encode()).hexdigest()[:12]
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+_ISA = {}
+
+
+def _profile_is_of_this_kernel(profile_hash):
+    """the profile was taken on this tree's env kernel: same source hash, or (profiles/kernel_identity.json) the same instruction stream"""
+    if profile_hash == kernel_source_hash():
+        return True
+    try:
+        ident = json.load(open(os.path.join(REPO, "profiles", "kernel_identity.json")))
+        want = ident.get(profile_hash, {}).get("isa_sha1")
+        if not want:
+            return False
+        if "h" not in _ISA:
+            _ISA["h"] = kernel_isa_hash()
+        return _ISA["h"] == want
+    except Exception:
+        return False
+
+
 def _pmc_traffic_bytes(kernel="env_step_kernel"):
     """HBM bytes per launch of `kernel` (env_step_kernel: one env step; env_rollout_kernel: a T-step rollout) from the committed rocprofv3 PMC passes (profiles/r05_env_step_pmc_hbm.txt, 4096 envs): 2 x
     FETCH_SIZE (gfx950 correction of the microarchitecture guide) + WRITE_SIZE, both in KB.  The profile records the hash of the kernel
@@ -73,7 +115,7 @@ def _pmc_traffic_bytes(kernel="env_step_kernel"):
     try:
         txt = open(path).read()
         m = re.search(r"kernel sources sha1: (\w+)", txt)
-        if not m or m.group(1) != kernel_source_hash():
+        if not m or not _profile_is_of_this_kernel(m.group(1)):
             print("bench.py: %s was taken on another build of the env kernel (%s vs %s): roofline.traffic = null; re-run tools/profile_round.sh" % (
                 path, m.group(1) if m else "no hash", kernel_source_hash()), file=sys.stderr)
             return None
@@ -104,7 +146,7 @@ def _pmc_issue(flop_step):
                "source": "profiles/r05_env_step_pmc_sq.txt + r05_env_step_pmc_issue.txt (rocprofv3 --pmc, 4096 envs, per-dispatch means)"}
         try:      # the split of the wait (round 4, tools/profile_issue.sh): instruction-issue shares, LDS issue stalls, instruction-cache misses, dynamic arithmetic share
             it = open(os.path.join(REPO, "profiles", "r05_env_step_pmc_issue.txt")).read()
-            if re.search(r"kernel sources sha1: (\w+)", it).group(1) == kernel_source_hash():
+            if _profile_is_of_this_kernel(re.search(r"kernel sources sha1: (\w+)", it).group(1)):
                 def gi(k):
                     m = re.search(r"env_step_kernel[^\n]*?" + k + r"=([0-9.e+]+)", it)
                     return float(m.group(1)) if m else None
