@@ -266,3 +266,49 @@ def test_emulated_one_launch_recurrent_rollout(dev, tmp_path):
     mu_roll = algo._b_mu.view(T * N, 10).index_select(0, gi).view(idx.shape[0], len(trajs), 10)
     d = ((mu_seq - mu_roll) * valid.unsqueeze(-1)).abs().max()
     assert float(d) < 2e-5, float(d)
+
+
+@full
+def test_emulated_cli_ppo_run_directory_checkpoints_and_scalars(dev, tmp_path, golden_dir):
+    """BASELINE configs[0]'s analogue END TO END on the emulated kernels: `apex.py ppo --env_name Cassie-v0 --reward clock` for 2 iterations of 64 envs x 8 steps (observation
+    statistics, one-launch rollouts, returns, PPO epochs through the emulated learner): the run directory <logdir>/Cassie-v0/<md5[:6]>-seed0 with experiment.info /
+    experiment.pkl, whole-module actor.pt / critic.pt that load with this repo's rl.policies classes, the reference's 13 scalar names - the assertions of
+    test_gpu_ppo.py::test_cli_ppo_run_directory_checkpoints_and_scalars"""
+    import json
+    import apex
+    rc = apex.main(["ppo", "--env_name", "Cassie-v0", "--reward", "clock", "--n_envs", "64", "--num_steps", "512", "--minibatch_size", "256",
+                    "--n_itr", "2", "--input_norm_steps", "128", "--eval_every", "0", "--max_traj_len", "4", "--logdir", str(tmp_path), "--seed", "0"])
+    # (--eval_every 0: no 256-env evaluation episodes, Test/Return = the batch return; --max_traj_len 4: episodes end inside the 8-step rollout, so there IS a return to beat and a checkpoint)
+    assert rc in (0, None)
+    runs = os.listdir(os.path.join(str(tmp_path), "Cassie-v0"))
+    assert len(runs) == 1 and runs[0].endswith("-seed0") and len(runs[0].split("-")[0]) == 6
+    run = os.path.join(str(tmp_path), "Cassie-v0", runs[0])
+    for f in ("actor.pt", "critic.pt", "experiment.info", "experiment.pkl"):
+        assert os.path.exists(os.path.join(run, f)), f
+    actor = torch.load(os.path.join(run, "actor.pt"), weights_only=False)
+    assert type(actor).__module__ == "rl.policies.actor" and type(actor).__name__ == "Gaussian_FF_Actor"
+    assert torch.is_tensor(actor.obs_mean) and actor.obs_mean.shape == (50,) and abs(float(actor.fixed_std) - np.exp(-1.5)) < 1e-6
+    y = actor(torch.zeros(50), deterministic=True)
+    assert y.shape[-1] == 10 and torch.isfinite(y).all()
+    g = np.load(os.path.join(golden_dir, "g15b_ppo_train.npz"))
+    if os.path.exists(os.path.join(run, "scalars.jsonl")):
+        names = set(json.loads(line)["tag"] for line in open(os.path.join(run, "scalars.jsonl")))
+        assert names == set(str(x) for x in g["scalar_names"])
+    else:
+        assert any(f.startswith("events.out.tfevents") for f in os.listdir(run))
+
+
+@full
+def test_emulated_range_checked_build():
+    """the env kernels' sources with -DAPX_CHECK under the emulation (tools/hipemu/build.sh check), driven through entry points, env kinds, profiles, a height field, restarts,
+    the complete-row path and the one-launch rollout (tests/emul_check_worker.py): no S(f) / S.W(i) / S.I(f) index leaves its LDS region - the CPU twin of
+    test_gpu_env.py::test_range_checked_build_sees_no_out_of_range_index"""
+    import subprocess
+    import sys
+    if not os.path.exists(CLANG):
+        pytest.skip("no host clang++")
+    subprocess.check_call(["bash", os.path.join(REPO, "tools", "hipemu", "build.sh"), "check"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tests", "emul_check_worker.py")], capture_output=True, text=True, timeout=3000,
+                         env=dict(os.environ, APX_EMUL_LIB=os.path.join(REPO, "tools", "hipemu", "_build", "libapx_emul_check.so")))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "RESULT clean" in out.stdout, out.stdout[-2000:]

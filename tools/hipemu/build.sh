@@ -12,6 +12,10 @@ if [ "${1:-}" = lockstep ]; then      # the lockstep checker (hip/hip_runtime.h)
     OUT=libapx_emul_lockstep.so; OBJ=_build/lockstep; mkdir -p $OBJ
     FLAGS="$FLAGS -g -DHIPEMU_LOCKSTEP_CHECK"; ENVFLAGS="-fsanitize-coverage=trace-pc-guard,trace-loads,trace-stores"
 fi
+if [ "${1:-}" = check ]; then         # the env kernels' range-checked accessors (-DAPX_CHECK, env_state.h): every S(f) / S.W(i) / S.I(f) index of an emulated run is tested against its LDS region
+    OUT=libapx_emul_check.so; OBJ=_build/check; mkdir -p $OBJ
+    ENVFLAGS="-DAPX_CHECK"
+fi
 pids=()
 grep -q ' fma ' /proc/cpuinfo && FLAGS="$FLAGS -mfma"      # fmaf as one instruction where the host has it (the env kernels' lane operations are fused multiply-adds)
 for u in emul_ppo_small emul_learner emul_td3_small emul_env; do

@@ -289,6 +289,7 @@ inline double atomicAdd(double* p, double v) { return hipemu_atomic_add(p, v); }
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline int atomicCAS(int* p, int expect, int desired) { __atomic_compare_exchange_n(p, &expect, desired, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); return expect; }
 
 inline void __syncthreads() { hipemu::g_cur->wave->want_barrier = true; hipemu::yield(); }
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
