@@ -25,6 +25,7 @@ def test_grid_barrier_under_stress(dev, wgs, phases, words):
     watchdog, every workgroup completed every phase.  (CPU twin on the emulated sources: tests/test_kernel_emulation.py::test_grid_barrier_selftest_with_eight_workgroups.)"""
     from apex_amd._lib import load, check
     from apex_amd.engine import _p, _stream
+    wgs = min(wgs, torch.cuda.get_device_properties(0).multi_processor_count)      # (every workgroup resident at once: at most one per CU is what the library's check grants)
     ws = torch.empty(2 + words, dtype=torch.int32, device=dev); res = torch.empty(4, dtype=torch.int64, device=dev)
     check(load().apx_grid_barrier_selftest(wgs, phases, words, _p(ws), _p(res), _stream()))
     torch.cuda.synchronize()
