@@ -1,5 +1,5 @@
 #!/bin/bash
-# Memory-safety pass over the learner-side kernel sources: the host emulation (build.sh) compiled with AddressSanitizer, the emulated test suites run with the ASan runtime
+# Memory-safety pass over the kernel sources (learner side by default; TESTS=tests/test_kernel_emulation_env.py: the env kernels): the host emulation (build.sh) compiled with AddressSanitizer, the emulated test suites run with the ASan runtime
 # preloaded, so that every read / write of a kernel beyond a tensor it was handed (torch's CPU allocations carry redzones then) aborts the run.  Fibers (ucontext) and ASan
 # coexist with detect_stack_use_after_return=0.   usage: bash tools/hipemu/asan.sh [pytest -k expression]   -> exit code of pytest
 # SAN=ubsan bash tools/hipemu/asan.sh: the same with UndefinedBehaviorSanitizer (misaligned vector loads, indices beyond a static = LDS array, shifts, overflow, NULL arithmetic).
@@ -17,9 +17,9 @@ fi
 mkdir -p _build/$SAN
 sed 's|extern __shared__ float fls\[\];|float* fls = (float*)hipemu::g_dynsmem;|' ../../apex_amd/csrc/learner.hip > _build/learner_emul.hip
 FLAGS="-x c++ -std=c++17 -O1 -g -fPIC -pthread $SANFLAGS -I. -I../../apex_amd/csrc -I../../include -Wno-unused-function -Wno-unused-variable -Wno-unknown-attributes -Wno-ignored-attributes -DHIPEMU_UCONTEXT"
-for f in emul_ppo_small emul_learner emul_td3_small; do $CXX $FLAGS -c $f.cpp -o _build/$SAN/$f.o 2> /dev/null & done
+for f in emul_ppo_small emul_learner emul_td3_small emul_env; do $CXX $FLAGS -c $f.cpp -o _build/$SAN/$f.o 2> /dev/null & done
 wait
-$CXX -shared -pthread $LINKFLAGS _build/$SAN/*.o -o _build/libapx_emul_$SAN.so
+$CXX -shared -pthread $LINKFLAGS _build/$SAN/*.o -ldl -o _build/libapx_emul_$SAN.so
 cd ../..
 LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 APX_EMUL_LIB=$PWD/tools/hipemu/_build/libapx_emul_$SAN.so \
-    python -m pytest tests/test_kernel_emulation_learner.py -q ${1:+-k "$1"}
+    python -m pytest ${TESTS:-tests/test_kernel_emulation_learner.py} -q ${1:+-k "$1"}
