@@ -312,3 +312,33 @@ def test_emulated_range_checked_build():
                          env=dict(os.environ, APX_EMUL_LIB=os.path.join(REPO, "tools", "hipemu", "_build", "libapx_emul_check.so")))
     assert out.returncode == 0, out.stderr[-2000:]
     assert "RESULT clean" in out.stdout, out.stdout[-2000:]
+
+
+def test_emulated_iteration_grids_bootstrap_and_returns(dev):
+    """PPO.sample + PPO.update on the emulated env AND learner kernels (short form of test_gpu_ppo.py::test_iteration_grids_bootstrap_and_returns: 64 envs x 6 steps, episodes
+    of 3): time-limit truncations carry the critic's value of the recorded FINAL observation as bootstrap and nothing else does, the returns equal the oracle's scan over the
+    recorded grids, episode statistics respect the limit, one update epoch runs to finite losses"""
+    from oracle import learner as OL
+    a = _small_ppo(dev, 64, 6, 3, 2)
+    ret, ep_rets, ep_lens = a.sample()
+    T, N = 6, 64
+    done, end, boot = a.b_done.numpy(), a.b_end.numpy(), a.b_boot.numpy()
+    assert np.array_equal(end != 0, done != 0) and set(np.unique(done)) <= {0, 1, 2} and (done == 2).sum() >= 2 * N - 8
+    vfin = a.learner.critic.forward(a.b_fin.view(T * N, 50)).view(T, N).numpy()
+    np.testing.assert_allclose(boot[done == 2], vfin[done == 2], rtol=1e-5, atol=1e-6)
+    assert np.all(boot[done != 2] == 0)
+    last_val = a.learner.critic.forward(a.obs).view(-1).numpy()
+    np.testing.assert_allclose(ret.numpy(), OL.returns_scan_grid_boot(a.b_rew.numpy(), end, boot, last_val, 0.99), rtol=1e-6, atol=1e-6)
+    el = ep_lens.numpy()
+    assert el.size == int((done != 0).sum()) and el.max() <= 3 and el.min() >= 1
+    losses, kl, epochs_run = a.update(ret)
+    assert np.all(np.isfinite(losses)) and np.isfinite(kl) and epochs_run == 1
+
+
+@full
+@pytest.mark.parametrize("name", ["test_recurrent_ppo_iteration_on_the_hip_env", "test_td3_driver_hbm_replay_and_updates", "test_td3_one_launch_collection"])
+def test_emulated_gpu_ppo_test_body(dev, tmp_path, name):
+    """bodies of tests/test_gpu_ppo.py on the emulated env + learner kernels: recurrent PPO iteration (rollout grids -> padded whole-trajectory minibatches -> update -> checkpoint ->
+    `apex.py eval` of the recurrent checkpoint), the TD3 driver (HBM replay, twin-critic updates, Polyak), TD3's one-launch collection at the GPU test's size"""
+    from tests import test_gpu_ppo as P
+    getattr(P, name)(dev, tmp_path)

@@ -11,7 +11,8 @@
 #define APX_LOCKSTEP() ((void)hipemu::exchange2(0u, 0u))
 #define APX_CONVERGE() hipemu::converge()
 // the dynamic LDS segment of the running workgroup
-#define APX_DYNAMIC_LDS(T, name, alignment) static thread_local T* const name = (T*)hipemu::g_dynsmem
+namespace hipemu { template <class T> struct LdsRef { template <class U> operator U*() const { return (U*)g_dynsmem; } T* operator+(long i) const { return (T*)g_dynsmem + i; } T& operator[](long i) const { return ((T*)g_dynsmem)[i]; } }; }      // (no pointer is cached: the segment belongs to whichever host thread runs the workgroup)
+#define APX_DYNAMIC_LDS(T, name, alignment) static constexpr hipemu::LdsRef<T> name {}
 
 namespace c4 {
 
