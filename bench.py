@@ -18,6 +18,9 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# test hook (tests/test_kernel_emulation_env.py runs the three workloads' code paths, JSON assembly included, on the emulated kernels): the TD3 and recurrent workloads shrink to 64 envs and 2 - 3 steps
+# (their BASELINE shapes are fixed in the code), the observation statistics pass is skipped; the line's config carries "tiny_test_shape": true.  Never set for a measurement.
+TINY = os.environ.get("APX_BENCH_TINY") == "1"
 VALU_PEAK_TFLOPS = 157.3       # fp32 vector peak = fp32 MFMA peak (MI355X_MICROARCH.md)
 
 
@@ -198,9 +201,9 @@ def main_td3(a):
     torch.cuda.set_device(0)
     from apex_amd.vecenv import CassieVecEnv
     from apex_amd.td3 import TD3
-    n_envs, T, upd, bs = 4096, 32, 4, 1024
+    n_envs, T, upd, bs = (64, 2, 1, 64) if TINY else (4096, 32, 4, 1024)
     env = CassieVecEnv(n_envs=n_envs, seed=0)
-    algo = TD3(env, "/tmp/apx_bench_unused", batch_size=bs, updates_per_step=upd, replay_size=1_000_000, seed=0, one_launch_updates=a.td3_one_launch)
+    algo = TD3(env, "/tmp/apx_bench_unused", batch_size=bs, updates_per_step=upd, replay_size=4096 if TINY else 1_000_000, seed=0, one_launch_updates=a.td3_one_launch)
     algo.init_networks(0)
     run = (lambda: algo.collect_and_train_async(T, load_freq=10)) if a.td3_async else (lambda: algo.collect_and_train(T))      # --td3_async: rl/algos/async_td3.py's decoupled form
     for _ in range(a.warmup):
@@ -216,7 +219,7 @@ def main_td3(a):
                       "config": {"workload": "Cassie-v0 TD3, 1M-transition replay buffer in HBM, twin-critic update in HIP (BASELINE.json configs[4])",
                                  "envs_per_gpu": n_envs, "collect_steps": T, "updates_per_env_step": upd, "batch_size": bs, "replay_capacity": 1000000,
                                  "mode": "async (behaviour copy re-loaded every 10 lock steps, rl/algos/async_td3.py)" if a.td3_async else "sync (rl/algos/sync_td3.py)",
-                                 "update_block_as_one_launch": bool(a.td3_one_launch and not a.td3_async)},
+                                 "update_block_as_one_launch": bool(a.td3_one_launch and not a.td3_async), **({"tiny_test_shape": True} if TINY else {})},
                       "updates_per_s": round(a.steps * T * upd / dt, 1), "replay_size": int(algo.replay.size)}))
 
 
@@ -235,11 +238,15 @@ def main_recurrent(a):
     from apex_amd.ppo_recurrent import RecurrentPPO
     from apex_amd import dist as adist
     n_envs, T = (a.n_envs if a.n_envs != 4096 else 2048), 400          # whole episodes: T = max_traj_len (every trajectory starts at an episode start, zero hidden state)
-    env = CassieVecEnv(n_envs=n_envs, seed=0, device=local, env_id_base=adist.shard_env_base(rank, n_envs), env_name="CassieTraj-v0")
+    if TINY:
+        n_envs, T = 64, 3
+    env = CassieVecEnv(n_envs=n_envs, seed=0, device=local, env_id_base=adist.shard_env_base(rank, n_envs), env_name="CassieTraj-v0", **({"max_traj_len": T} if TINY else {}))
     args = dict(gamma=0.99, lam=0.95, lr=1e-4, eps=1e-5, entropy_coeff=0.0, clip=0.2, minibatch_size=min(1024, n_envs // 2), epochs=a.epochs,
-                num_steps=T * n_envs * world, max_traj_len=400, max_grad_norm=0.05, mirror=True, seed=0)
+                num_steps=T * n_envs * world, max_traj_len=T if TINY else 400, max_grad_norm=0.05, mirror=True, seed=0)
     algo = RecurrentPPO(args, "/tmp/apx_bench_unused", env, rank=rank, world_size=world, group=group)
-    algo.init_networks(0); algo.normalization_params(10000)
+    algo.init_networks(0)
+    if not TINY:      # (at least 50 env steps: setup, not part of what the tiny shape is there to exercise)
+        algo.normalization_params(10000)
 
     def barrier():
         torch.cuda.synchronize()
@@ -268,7 +275,7 @@ def main_recurrent(a):
                           "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "CassieTraj-v0 recurrent PPO (LSTM 2x128 actor/critic, whole-trajectory minibatches), 2048 envs/GPU (BASELINE.json configs[3])",
-                                     "envs_per_gpu": n_envs, "rollout_len": T, "minibatch_trajectories": min(1024, n_envs // 2), "epochs": a.epochs, "mirror_loss": True,
+                                     "envs_per_gpu": n_envs, "rollout_len": T, "minibatch_trajectories": min(1024, n_envs // 2), "epochs": a.epochs, "mirror_loss": True, **({"tiny_test_shape": True} if TINY else {}),
                                      "parallelism": f"dp{world} (env shards; optimiser steps per epoch agreed by a MAX all-reduce, 1 gradient all-reduce per step)"},
                           "sample_s": round(samp / a.steps, 3), "optimize_s": round(opt / a.steps, 3),
                           "optimiser_step_us": round(opt / opt_steps * 1e6, 2) if opt_steps else None, "epochs_run_per_step": round(epochs_run / a.steps, 2),      # update time per optimiser step (whole-trajectory minibatches) over the epochs that ran
@@ -321,7 +328,8 @@ def main():
                 mirror=True, std_dev=-1.5, seed=0, graph=os.environ.get("APX_ROLLOUT_GRAPH", "0") == "1", epoch_kernel=a.epoch_kernel)      # fp32 MFMA: the reference's own network precision and the library's only mode
     algo = PPO(args, "/tmp/apx_bench_unused", env, rank=rank, world_size=world, group=group)
     algo.init_networks(0)
-    algo.normalization_params(10000)
+    if not TINY:
+        algo.normalization_params(10000)
 
     def barrier():
         torch.cuda.synchronize()
@@ -394,7 +402,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Cassie-v0 PPO, 4096 batched envs/GPU, 2x256 MLP actor/critic (BASELINE.json configs[1])",
                        "envs_per_gpu": a.n_envs, "rollout_len": a.rollout_len, "simrate": 50, "minibatch": a.minibatch, "optimiser_steps_as_one_launch_per_epoch": algo.epoch_kernel_in_use(mb_rows), "epoch_kernel_requested": bool(a.epoch_kernel),
-                       "epochs": a.epochs, "mirror_loss": True, "dynamics_randomization": True, "eval_rollouts": False,
+                       "epochs": a.epochs, "mirror_loss": True, "dynamics_randomization": True, "eval_rollouts": False, **({"tiny_test_shape": True} if TINY else {}),
                        "parallelism": f"dp{world} (env shards, 1 RCCL grad all-reduce per optimiser step)"},
             "sampling_env_steps_per_s": round(a.steps * a.rollout_len * a.n_envs * world / max(samp, 1e-9), 1),
             "sample_s": round(samp / a.steps, 3), "optimize_s": round(opt / a.steps, 3),

@@ -342,3 +342,36 @@ def test_emulated_gpu_ppo_test_body(dev, tmp_path, name):
     `apex.py eval` of the recurrent checkpoint), the TD3 driver (HBM replay, twin-critic updates, Polyak), TD3's one-launch collection at the GPU test's size"""
     from tests import test_gpu_ppo as P
     getattr(P, name)(dev, tmp_path)
+
+
+@pytest.mark.parametrize("workload,extra", [("cassie_ppo", ["--n_envs", "64", "--rollout_len", "2", "--minibatch", "64", "--epochs", "1"]),
+                                            ("cassietraj_recurrent", ["--epochs", "1", "--no_cpu_baseline"]), ("cassie_td3", ["--no_cpu_baseline"])])
+def test_emulated_bench_lines(dev, monkeypatch, capsys, workload, extra):
+    """bench.py's three workloads executed END TO END on the emulated kernels at a tiny shape (APX_BENCH_TINY: 64 envs, 2 - 3 steps; one timed step, no warm-up): every code
+    path of the timed region and the whole JSON assembly run - round 5 shipped a NameError there that no CPU test could see.  Asserted: one JSON line with the contract's
+    keys, the roofline and cpu_baseline objects on the headline, value = steps / time, "tiny_test_shape" in its config (such a line is never a measurement)."""
+    import json
+    import sys
+    import bench
+    monkeypatch.setattr(bench, "TINY", True)
+    full_baseline = bench.cpu_baseline
+    monkeypatch.setattr(bench, "cpu_baseline", lambda **kw: full_baseline(seconds_hint=0.3, **kw))      # (the oracle's sampling leg: a fraction of a second instead of 12)
+    monkeypatch.setattr(torch.cuda, "set_device", lambda *a, **k: None)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1", "--steps", "1", "--warmup", "0", "--workload", workload] + extra)
+    monkeypatch.delenv("RANK", raising=False); monkeypatch.delenv("WORLD_SIZE", raising=False)
+    bench.main()
+    lines = [ln for ln in capsys.readouterr().out.strip().split("\n") if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["dtype"] == "f32" and d["vs_baseline"] is None and d["config"]["tiny_test_shape"] is True and "workload" in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - {"cassie_ppo": 64 * 2, "cassietraj_recurrent": 64 * 3, "cassie_td3": 64 * 2}[workload] / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
+    if workload == "cassie_ppo":
+        r = d["roofline"]
+        assert r["kernel"] == "env_rollout_kernel" and r["bound"] == "valu" and r["launches_timed"] == 1 and r["frac"] > 0 and "hbm" in r and "mlp_forward_mfma" in r
+        c = d["cpu_baseline"]
+        assert c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1 and "sample" in c and c["end_to_end"]["value"] > 0
+        assert d["optimiser_step_us"] > 0 and d["config"]["optimiser_steps_as_one_launch_per_epoch"] is False
+    if workload == "cassietraj_recurrent":
+        assert d["optimiser_step_us"] > 0 and d["epochs_run_per_step"] == 1.0

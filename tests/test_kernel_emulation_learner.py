@@ -75,6 +75,9 @@ class _NoStream:
     def synchronize(self):
         pass
 
+    def elapsed_time(self, other):
+        return 1.0
+
 
 @pytest.fixture()
 def dev(monkeypatch):

@@ -64,7 +64,7 @@ inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullpt
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 1.f; return hipSuccess; }      // (a fixed millisecond: callers divide by it)
 #define HIP_SYMBOL(x) (&(x))
 template <class S> inline hipError_t hipMemcpyToSymbol(S* sym, const void* src, size_t n) { memcpy((void*)sym, src, n); return hipSuccess; }
 template <class S> inline hipError_t hipMemcpyFromSymbol(void* dst, S* sym, size_t n) { memcpy(dst, (const void*)sym, n); return hipSuccess; }
