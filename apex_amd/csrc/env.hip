@@ -1044,7 +1044,7 @@ extern "C" void apx_env_default_cfg(apx_env_cfg* c) {
 extern "C" int apx_env_create(const apx_env_cfg* cfg, apx_env_t** out) {
     APX_REQUIRE(cfg && out, "null");
     APX_REQUIRE(cfg->n_envs > 0 && cfg->n_envs % 64 == 0, "n_envs must be a positive multiple of 64");
-    APX_REQUIRE(cfg->simrate > 0 && 2000 % cfg->simrate == 0, "simrate must divide 2000");
+    APX_REQUIRE(cfg->simrate > 0 && cfg->simrate <= 2000, "simrate: 1..2000 substeps per env step (cycle lengths follow 2000 // simrate like cassie.py:545)");      // (the shipped policies of the reference ran at 60)
     APX_REQUIRE(cfg->env_kind == 0 || (cfg->env_kind == 1 && cfg->simrate == 50), "env_kind: 0 Cassie-v0, 1 CassieTraj-v0 (walking trajectory table is for simrate 50)");
     APX_REQUIRE(cfg->reward_kind >= 0 && cfg->reward_kind <= 2, "reward_kind: 0 clock_reward, 1 early_clock_reward, 2 max_vel_clock_reward");
     APX_REQUIRE(cfg->pgs_iters > 0 && cfg->max_traj_len > 0, "pgs_iters / max_traj_len");

@@ -375,3 +375,52 @@ def test_emulated_bench_lines(dev, monkeypatch, capsys, workload, extra):
         assert d["optimiser_step_us"] > 0 and d["config"]["optimiser_steps_as_one_launch_per_epoch"] is False
     if workload == "cassietraj_recurrent":
         assert d["optimiser_step_us"] > 0 and d["epochs_run_per_step"] == 1.0
+
+
+@full
+def test_emulated_g24_push_cells_of_the_reference_policy_on_the_kernel_sources(dev, golden_dir):
+    """Golden G24 on the KERNEL SOURCES: the reference's shipped, MuJoCo-trained policy on the emulated env kernel (49-entry observation of its Cassie-v0 revision, simrate 60,
+    through apx_env_step / apply_force like apex_amd.eval.compute_perturbs), 8 (direction, phase) cells of the oracle's 280-cell lattice x 8 push sizes bracketing the
+    oracle's result = 64 trials in lock step, the reference's protocol (tools/eval_perturb.py:36-85: two gait cycles, push for 0.2 s, survive 3 s).  The largest push survived
+    per cell on the kernel sources against the fp64 oracle's (same physics, fp32, other arithmetic: the boundary is chaotic, one 10 N step either way is the resolution) and
+    against MuJoCo's table."""
+    import math
+    from apex_amd.vecenv import CassieVecEnv
+    from test_gpu_zz_first_hardware_run import _RefPolicy49
+    g = np.load(os.path.join(golden_dir, "g24_ref_policy_push_sweep.npz"))
+    lat = np.load(os.path.join(golden_dir, "g24_oracle_lattice_280.npz"))
+    simrate, speed, wait, dur, first, incr = (float(x) for x in g["protocol"])
+    dirs, phases, table = lat["directions"].astype(int), lat["phases"].astype(int), lat["oracle"].astype(np.float64)
+    cells = [(0, 7), (20, 0), (30, 14), (40, 21), (50, 7), (60, 14), (80, 0), (90, 21)]
+    orc = np.array([table[list(dirs).index(a), list(phases).index(p)] for a, p in cells])
+    muj = np.array([g["a_eval_perturbs"][a, p] for a, p in cells], dtype=np.float64)
+    offs = np.arange(-4, 4) * incr                                    # sizes oracle - 40 .. oracle + 30
+    n = 64
+    a_i = np.repeat(np.arange(8), 8); s_i = np.tile(np.arange(8), 8)
+    angle = -2.0 * math.pi * np.array([cells[i][0] for i in a_i]) / 100.0
+    p_i = torch.tensor([cells[i][1] for i in a_i])
+    size = np.maximum(orc[a_i] + offs[s_i], first)
+    wrench = torch.zeros(n, 6); wrench[:, 0] = torch.tensor(size * np.cos(angle), dtype=torch.float32); wrench[:, 1] = torch.tensor(size * np.sin(angle), dtype=torch.float32)
+    env = CassieVecEnv(n_envs=n, simrate=int(simrate), dynamics_randomization=False, seed=0, max_traj_len=100000)
+    pol = _RefPolicy49(g, "a", dev, speed)
+    dt = env.simrate * 0.0005
+    n_push = int(math.ceil(dur / dt - 1e-9)); n_wait = int(math.ceil(wait / dt - 1e-9))
+    obs = env.reset_for_test(full_reset=True)
+    env.set_command(speed=speed)
+    for _ in range(2 * 28):
+        obs, _, _, _ = env.step(pol(obs), auto_reset=False)
+    fell = torch.zeros(n, dtype=torch.bool); zero = torch.zeros_like(wrench)
+    for k in range(27 + n_push + n_wait):
+        pushing = (k >= p_i) & (k < p_i + n_push)
+        env.apply_force(torch.where(pushing.view(n, 1), wrench, zero), "cassie-pelvis")
+        obs, _, _, _ = env.step(pol(obs), auto_reset=False)
+        waiting = (k >= p_i + n_push) & (k < p_i + n_push + n_wait)
+        fell |= waiting & (env.get_field("qpos")[:, 2] < 0.4)
+    fell = fell.view(8, 8).numpy()
+    firstfail = np.where(fell.any(1), fell.argmax(1), 8)
+    mine = np.array([size.reshape(8, 8)[c, min(f, 7)] - (incr if f < 8 else 0.0) for c, f in enumerate(firstfail)])      # (a cell that survives every size of its bracket reports the largest tried)
+    print("cells      ", cells); print("kernel src ", mine.astype(int).tolist()); print("oracle     ", orc.astype(int).tolist()); print("MuJoCo     ", muj.astype(int).tolist())
+    d = np.abs(mine - orc)
+    assert (d <= incr).sum() >= 6 and d.max() <= 40.0, (mine, orc)
+    assert abs(mine.mean() - muj.mean()) < 0.10 * muj.mean() and np.corrcoef(mine, muj)[0, 1] > 0.85
+    env.close()

@@ -93,7 +93,9 @@ __attribute__((naked, noinline)) inline void ctx_switch(void** /*save_sp: rdi*/,
 struct Ctx { ucontext_t uc; };
 #endif
 struct Lane { Ctx ctx; dim3 tid; int lane; unsigned ncoll; bool done; Wave* wave; char* stack; const void* conv_site; unsigned conv_seq; };
-#ifdef HIPEMU_UCONTEXT
+#if defined(HIPEMU_STACK_MB)
+constexpr size_t STACK_BYTES = (size_t)HIPEMU_STACK_MB * 1024 * 1024;
+#elif defined(HIPEMU_UCONTEXT)
 constexpr size_t STACK_BYTES = 16 * 1024 * 1024;      // the sanitizer builds (-O1, redzones around every local of the env kernels' inlined stages)
 #else
 constexpr size_t STACK_BYTES = 1024 * 1024;
