@@ -66,7 +66,7 @@ class _RefPolicy49:
         return self.net.forward(x, self.mean, self.std)
 
 
-def test_g24_push_sweep_of_the_reference_policy_on_the_kernel(golden_dir):
+def test_g24_push_sweep_of_the_reference_policy_on_the_kernel(dev, golden_dir):
     """The KERNEL against the one MuJoCo-generated table the reference ships (G24: eval_perturbs.npy of its own push sweep, 100 directions x 28 phases): the reference's
     policy on the batched env, every (direction, phase, push size) trial one env of ONE batch (apex_amd.eval.compute_perturbs: 84 000 envs in lock step), the largest
     push survived per cell against MuJoCo's.  The fp64 oracle reproduces the table to mean -2 %, correlation 0.94, mean |difference| 11.5 N on a 40-cell lattice; the
@@ -76,7 +76,6 @@ def test_g24_push_sweep_of_the_reference_policy_on_the_kernel(golden_dir):
     from apex_amd.eval import compute_perturbs
     g = np.load(os.path.join(golden_dir, "g24_ref_policy_push_sweep.npz"))
     simrate, speed, wait, dur, first, incr = (float(x) for x in g["protocol"])
-    dev = torch.device("cuda:0")
     pol = _RefPolicy49(g, "a", dev, speed)
     make_env = lambda n: CassieVecEnv(n_envs=n, simrate=int(simrate), dynamics_randomization=False, seed=0, max_traj_len=100000)
     mf, fell = compute_perturbs(pol, make_env, wait_time=wait, perturb_duration=dur, perturb_size=first, perturb_incr=incr, num_angles=100, n_sizes=30, num_phases=28, speed=speed)
@@ -102,13 +101,12 @@ def test_g24_push_sweep_of_the_reference_policy_on_the_kernel(golden_dir):
 
 
 @pytest.mark.parametrize("speed,tol", [(0.0, 0.08), (0.5, 0.10), (1.0, 0.10)])
-def test_g24_the_reference_policy_walks_on_the_kernel(golden_dir, speed, tol):
+def test_g24_the_reference_policy_walks_on_the_kernel(dev, golden_dir, speed, tol):
     """Sim-to-sim transfer onto the KERNEL: the policy the reference trained in MuJoCo (G24), closed loop on the batched env through step_basic at simrate 60 - 64 envs,
     200 policy steps (6 s): nobody falls, the pelvis stays at walking height, the commanded speed is tracked (oracle: 0 -> 0.00, 0.5 -> 0.46, 1.0 -> 0.98 m/s)."""
     import os
     from apex_amd.vecenv import CassieVecEnv
     g = np.load(os.path.join(golden_dir, "g24_ref_policy_push_sweep.npz"))
-    dev = torch.device("cuda:0")
     env = CassieVecEnv(n_envs=64, simrate=60, dynamics_randomization=False, seed=0, max_traj_len=100000)
     pol = _RefPolicy49(g, "a", dev, speed)
     obs = env.reset_for_test(full_reset=True)

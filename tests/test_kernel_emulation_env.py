@@ -424,3 +424,22 @@ def test_emulated_g24_push_cells_of_the_reference_policy_on_the_kernel_sources(d
     assert (d <= incr).sum() >= 6 and d.max() <= 40.0, (mine, orc)
     assert abs(mine.mean() - muj.mean()) < 0.10 * muj.mean() and np.corrcoef(mine, muj)[0, 1] > 0.85
     env.close()
+
+
+@full
+def test_emulated_g24_the_reference_policy_walks_on_the_kernel_sources(dev, golden_dir):
+    """the body of tests/test_gpu_zz_first_hardware_run.py::test_g24_the_reference_policy_walks_on_the_kernel at 0.5 m/s on the emulated sources: sim-to-sim transfer of the
+    reference's MuJoCo-trained policy through step_basic at simrate 60, 64 envs, 200 policy steps - nobody falls, walking height, commanded speed tracked"""
+    import test_gpu_zz_first_hardware_run as Z
+    Z.test_g24_the_reference_policy_walks_on_the_kernel(dev, golden_dir, 0.5, 0.10)
+
+
+@full
+@pytest.mark.parametrize("mode", ["golden", "twin", "ppo"])
+def test_emulated_epoch_worker_modes(dev, monkeypatch, mode):
+    """tests/epoch_worker.py - the script the GPU suite runs in a child process for the persistent one-launch trainers - with its own `golden`, `twin` and `ppo` bodies on the
+    emulated kernels (one workgroup for the cooperative launch): `ppo` is PPO.update with the epoch kernel on / off on the same rollout of the (emulated) env"""
+    import epoch_worker as W
+    monkeypatch.setattr(W, "FAILED", [])
+    getattr(W, mode)(dev)
+    assert W.FAILED == [], W.FAILED

@@ -129,7 +129,7 @@ struct LdsArena { char* p = nullptr; ~LdsArena() { free(p); } };
 inline thread_local LdsArena g_lds_arena;
 inline std::map<std::string, long> g_launches;      // launches per kernel expression as written at the launch site (tests ask which kernels a path really took)
 inline uint64_t g_block_gen = 0;      // workgroups run so far (the lockstep checker's epochs)
-inline int g_force_grid = 0;      // > 0: every launch runs with this many workgroups whatever the host code asked for
+inline int g_force_grid = 0;      // > 0: a cooperative launch runs with this many concurrent workgroups (default 1) whatever the host code asked for
 #ifndef HIPEMU_UCONTEXT
 inline void lockstep_flush();
 inline void yield() { lockstep_flush(); Lane* l = g_cur; ctx_switch(&l->ctx.sp, l->wave->sched.sp); }
@@ -222,11 +222,11 @@ inline void run_block(dim3 block, const std::function<void()>& body) {
     }
     pthread_barrier_destroy(&bar);
 }
-// Default: the workgroups of a launch run one after the other in this process (kernels whose workgroups do not wait for each other).  With g_force_grid > 0 a launch
-// becomes that many CONCURRENT workgroups, one forked process each (a kernel with a grid barrier; its buffers must be MAP_SHARED).
-inline void launch(dim3 grid, dim3 block, const std::function<void()>& body, size_t dyn_lds = 0) {
+// A plain launch: its workgroups run one after the other in this process (or, single-wave workgroups with dynamic LDS, on host threads).  A COOPERATIVE launch (a kernel with
+// a grid barrier: hipLaunchCooperativeKernel) becomes g_force_grid CONCURRENT workgroups (default 1), one forked process each; with more than one its buffers must be MAP_SHARED.
+inline void launch(dim3 grid, dim3 block, const std::function<void()>& body, size_t dyn_lds = 0, bool cooperative = false) {
     g_block = block;
-    if (g_force_grid <= 0) {
+    if (!cooperative) {      // (a plain launch: its workgroups do not wait for each other)
         g_grid = grid;
 #ifndef HIPEMU_LOCKSTEP_CHECK
         static const int host_threads = getenv("HIPEMU_THREADS") ? atoi(getenv("HIPEMU_THREADS")) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
@@ -248,7 +248,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body, siz
                 for (unsigned x = 0; x < grid.x; ++x) { g_bidx = dim3(x, y, z); run_block(block, body); }
         return;
     }
-    grid = dim3(g_force_grid);
+    grid = dim3(g_force_grid > 0 ? g_force_grid : 1);      // a cooperative launch (grid barrier inside): apx_emul_set_workgroups concurrent workgroups, one by default
     if (grid.x > 16) { fprintf(stderr, "hipemu: at most 16 concurrent workgroups (%u)\n", grid.x); abort(); }
     g_grid = grid; g_bidx = dim3(0);
     std::vector<pid_t> kids;
@@ -280,7 +280,7 @@ template <class F> inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocesso
 template <class A> inline hipError_t hipLaunchCooperativeKernel(void (*f)(A), dim3 grid, dim3 block, void** params, unsigned, hipStream_t) {
     const A a = *(const A*)params[0];
     hipemu::g_launches["cooperative"] += 1;
-    hipemu::launch(grid, block, [=]() { f(a); });
+    hipemu::launch(grid, block, [=]() { f(a); }, 0, true);
     return hipSuccess;
 }
 
