@@ -35,8 +35,12 @@ def emulated_library():
     import glob
     srcs = glob.glob(os.path.join(EMU, "*.cpp")) + [os.path.join(EMU, "build.sh")] + glob.glob(os.path.join(EMU, "hip", "*.h")) + glob.glob(os.path.join(EMU, "gfx950", "*.h")) + \
            glob.glob(os.path.join(REPO, "apex_amd", "csrc", "*.hip")) + glob.glob(os.path.join(REPO, "apex_amd", "csrc", "*.h")) + [os.path.join(REPO, "include", "apx.h")]
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["bash", os.path.join(EMU, "build.sh")])
+    import fcntl
+    os.makedirs(os.path.join(EMU, "_build"), exist_ok=True)
+    with open(os.path.join(EMU, "_build", ".lock"), "w") as lk:      # (the two ranks of a gloo test must not rebuild a stale library at the same time)
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+            subprocess.check_call(["bash", os.path.join(EMU, "build.sh")])
     lib = C.CDLL(so)
     for name, (res, args) in _lib.SIGNATURES.items():
         if hasattr(lib, name):

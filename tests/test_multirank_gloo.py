@@ -156,3 +156,60 @@ def test_epoch_kernel_is_excluded_when_a_process_group_is_given():
     assert d["ppo_small_epoch_kernel"] == 0 and d["cooperative"] == 0, d            # the one-launch path was NOT taken ...
     assert d["mlp_fused_fwd_kernel"] > 0 and d["bwd_head_kernel"] >= 2, d             # ... the per-step launches were (2 optimiser steps of 64 rows)
     assert same and moved > 0 and adam_t == 2 and epochs_run == 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# bench.py at N = 2 on the CPU: two gloo ranks run bench.main() end to end on the EMULATED kernels at the tiny test shape (APX_BENCH_TINY; APX_BENCH_SHARE_GPU=1 = the gloo
+# form of the launch contract): env shards by rank, gradient all-reduce per optimiser step, moments, the MAX-over-ranks time, the per-rank table, ONE JSON line on rank 0.
+def _bench_worker(rank, world, port, workload, out):
+    import contextlib, io, json, sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), APX_BENCH_SHARE_GPU="1", APX_BENCH_TINY="1")
+    from apex_amd import _lib, engine, vecenv
+    from tests import test_kernel_emulation_learner as E
+    lib = E.emulated_library(); lib.apx_emul_set_workgroups(0)
+    _lib._lib = lib
+    engine._need_gpu = lambda *ts: None; engine._stream = lambda: None; vecenv._stream = lambda: None
+    vecenv._device = lambda index: torch.device("cpu"); vecenv._on_device = lambda t: True
+    ns = E._NoStream
+    torch.cuda.current_stream = lambda *a, **k: ns(); torch.cuda.Stream = lambda *a, **k: ns(); torch.cuda.Event = lambda *a, **k: ns()
+    torch.cuda.stream = lambda s: contextlib.nullcontext(); torch.cuda.synchronize = lambda *a, **k: None; torch.cuda.set_device = lambda *a, **k: None
+    import bench
+    extra = ["--n_envs", "64", "--rollout_len", "2", "--minibatch", "64", "--epochs", "1"] if workload == "cassie_ppo" else ["--epochs", "1"]
+    sys.argv = ["bench.py", "--gpus", str(world), "--steps", "1", "--warmup", "0", "--workload", workload, "--no_cpu_baseline"] + extra
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main()
+    lines = [ln for ln in buf.getvalue().split("\n") if ln.startswith("{")]
+    out.put((rank, lines))
+
+
+def _bench_two_ranks(workload):
+    import json
+    import pytest
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("no host clang++ (kernel emulation)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, workload, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = dict(q.get(timeout=900) for _ in range(2))
+    [p.join(timeout=120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert got[1] == [] and len(got[0]) == 1                      # rank 0 prints the one line
+    return json.loads(got[0][0])
+
+
+def test_bench_headline_line_at_two_ranks():
+    d = _bench_two_ranks("cassie_ppo")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"].startswith("dp2") and d["config"]["tiny_test_shape"] is True
+    assert abs(d["value"] - 2 * 64 * 2 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]              # whole-job aggregate: both ranks' env steps over the MAX time
+    c = d["collectives"]
+    assert c["rccl_ranks_seen"] == 2 and c["backend"] == "gloo" and c["gradient_floats"] == 160523 and len(c["per_rank"]["sample_s"]) == 2
+    assert d["config"]["optimiser_steps_as_one_launch_per_epoch"] is False
+
+
+def test_bench_recurrent_line_at_two_ranks():
+    d = _bench_two_ranks("cassietraj_recurrent")
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"].startswith("dp2") and abs(d["value"] - 2 * 64 * 3 / (d["ms_per_step"] * 1e-3)) < 0.02 * d["value"]
+    assert d["collectives"]["rccl_ranks_seen"] == 2 and len(d["collectives"]["per_rank"]["optimize_s"]) == 2 and d["optimiser_step_us"] > 0
