@@ -336,12 +336,17 @@ def test_emulated_iteration_grids_bootstrap_and_returns(dev):
 
 
 @full
-@pytest.mark.parametrize("name", ["test_recurrent_ppo_iteration_on_the_hip_env", "test_td3_driver_hbm_replay_and_updates", "test_td3_one_launch_collection"])
-def test_emulated_gpu_ppo_test_body(dev, tmp_path, name):
+@pytest.mark.parametrize("name", ["test_recurrent_ppo_iteration_on_the_hip_env", "test_td3_driver_hbm_replay_and_updates", "test_td3_one_launch_collection",
+                                  "test_compute_perturbs_batched", "test_eval_commands_batched", "test_batched_deterministic_evaluation", "test_normalization_params_golden_g21"])
+def test_emulated_gpu_ppo_test_body(dev, tmp_path, golden_dir, name):
     """bodies of tests/test_gpu_ppo.py on the emulated env + learner kernels: recurrent PPO iteration (rollout grids -> padded whole-trajectory minibatches -> update -> checkpoint ->
-    `apex.py eval` of the recurrent checkpoint), the TD3 driver (HBM replay, twin-critic updates, Polyak), TD3's one-launch collection at the GPU test's size"""
+    `apex.py eval` of the recurrent checkpoint), the TD3 driver (HBM replay, twin-critic updates, Polyak), TD3's one-launch collection at the GPU test's size, the batched push sweep and
+    command-schedule evaluation (apex_amd/eval.py), deterministic evaluation, the observation-statistics golden G21"""
+    import inspect
     from tests import test_gpu_ppo as P
-    getattr(P, name)(dev, tmp_path)
+    fn = getattr(P, name)
+    have = dict(dev=dev, tmp_path=tmp_path, golden_dir=golden_dir)
+    fn(**{k: have[k] for k in inspect.signature(fn).parameters})
 
 
 @pytest.mark.parametrize("workload,extra", [("cassie_ppo", ["--n_envs", "64", "--rollout_len", "2", "--minibatch", "64", "--epochs", "1"]),
