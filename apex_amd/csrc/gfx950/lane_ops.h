@@ -4,6 +4,7 @@
 // (tools/hipemu/gfx950/lane_ops.h is the lane-exact host restatement of these operations, under which the same kernel sources run on the CPU in the test suite.)
 #pragma once
 #include <hip/hip_runtime.h>
+#include <gfx950/dynamic_lds.h>
 
 // APX_PIN("+v"(a), "+v"(b), ..): an opaque definition point of the listed registers - the compiler may not move, fold or re-associate their values across it.
 // APX_HAZARD_FENCE(..): the same and two wait states: no compiler-generated definition of a listed register sits right in front of a DPP read of it by inline
@@ -17,9 +18,6 @@
 // APX_CONVERGE(): behind a branch that only some of the wave's env ROWS take and that contains cross-lane operations: the point where the rows are together again (the
 // exec mask's business on the hardware: nothing to emit; the host emulation parks the rows that sat the branch out here until the others arrive).
 #define APX_CONVERGE() ((void)0)
-// dynamic LDS of a kernel (the launch's shared-memory bytes) as an array of T
-#define APX_DYNAMIC_LDS(T, name, alignment) extern __shared__ __attribute__((aligned(alignment))) T name[]
-
 namespace c4 {
 
 // v_rcp_f32 (1 ulp): __frcp_rn and '/' expand to the ~10-instruction correctly rounded division sequence

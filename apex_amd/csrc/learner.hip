@@ -9,6 +9,7 @@
 // Wave = 64 lanes.  GEMMs use v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain) so that the parity mode
 // meets the 1e-5 bar; everything elementwise is fused into GEMM epilogues or the single loss kernel.
 #include "apx_common.h"
+#include <gfx950/dynamic_lds.h>
 #include <cmath>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -669,9 +670,9 @@ __global__ __launch_bounds__(256) void mlp_fused_fwd_kernel(const float* __restr
                                                             const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
                                                             FusedIn I, long B, int D, int O, float* __restrict__ a1,
                                                             float* __restrict__ a2, float* __restrict__ y) {
-    extern __shared__ float fls[];
+    APX_DYNAMIC_LDS(float, fls, 4);
     FusedLds L;
-    L.A1s = reinterpret_cast<float (*)[FBM + 1]>(fls);
+    L.A1s = reinterpret_cast<float (*)[FBM + 1]>(fls + 0);
     L.A2s = reinterpret_cast<float (*)[FBM + 1]>(fls + FH * (FBM + 1));
     L.Ws = reinterpret_cast<float (*)[FBN + 1]>(fls + 2 * FH * (FBM + 1));
     const int tid = threadIdx.x;

@@ -17,7 +17,6 @@ else
     SANFLAGS="-fsanitize=address -shared-libsan -fno-omit-frame-pointer"; LINKFLAGS="-fsanitize=address -shared-libsan"
 fi
 mkdir -p _build/$SAN
-sed 's|extern __shared__ float fls\[\];|float* fls = (float*)hipemu::g_dynsmem;|' ../../apex_amd/csrc/learner.hip > _build/learner_emul.hip
 FLAGS="-x c++ -std=c++17 -O1 -g -fPIC -pthread $SANFLAGS -I. -I../../apex_amd/csrc -I../../include -Wno-unused-function -Wno-unused-variable -Wno-unknown-attributes -Wno-ignored-attributes ${SWITCH:--DHIPEMU_UCONTEXT}"
 for f in emul_ppo_small emul_learner emul_td3_small emul_env; do $CXX $FLAGS -c $f.cpp -o _build/$SAN/$f.o 2> /dev/null & done
 wait

@@ -4,8 +4,6 @@ set -e
 cd "$(dirname "$0")"
 mkdir -p _build
 CXX=${CXX:-/opt/rocm/lib/llvm/bin/clang++}
-sed 's|extern __shared__ float fls\[\];|float* fls = (float*)hipemu::g_dynsmem;|' ../../apex_amd/csrc/learner.hip > _build/learner_emul.hip
-grep -q 'hipemu::g_dynsmem' _build/learner_emul.hip
 FLAGS="-x c++ -std=c++17 -O2 -g1 -fPIC -pthread -I. -I../../apex_amd/csrc -I../../include -Wno-unused-function -Wno-unused-variable -Wno-unknown-attributes -Wno-ignored-attributes -Wno-psabi"
 OUT=libapx_emul.so; OBJ=_build
 if [ "${1:-}" = lockstep ]; then      # the lockstep checker (hip/hip_runtime.h): every load / store of the env kernels' translation unit reports to it

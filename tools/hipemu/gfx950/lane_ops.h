@@ -4,16 +4,13 @@
 // are fmaf).  Test infrastructure only.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <gfx950/dynamic_lds.h>
 
 #define APX_PIN(...) ((void)0)
 #define APX_HAZARD_FENCE(...) ((void)0)
 // a rendezvous of the wave's lanes (see the product header)
 #define APX_LOCKSTEP() ((void)hipemu::exchange2(0u, 0u))
 #define APX_CONVERGE() hipemu::converge()
-// the dynamic LDS segment of the running workgroup
-namespace hipemu { template <class T> struct LdsRef { template <class U> operator U*() const { return (U*)g_dynsmem; } T* operator+(long i) const { return (T*)g_dynsmem + i; } T& operator[](long i) const { return ((T*)g_dynsmem)[i]; } }; }      // (no pointer is cached: the segment belongs to whichever host thread runs the workgroup)
-#define APX_DYNAMIC_LDS(T, name, alignment) static constexpr hipemu::LdsRef<T> name {}
-
 namespace c4 {
 
 __device__ __forceinline__ float rcpf(float x) { return 1.0f / x; }
