@@ -1,12 +1,20 @@
-// Host emulation of the small part of HIP that apex_amd/csrc/ppo_small.hip uses, so that the kernel SOURCE can be compiled with the host clang++ and run on the CPU
-// (tools/hipemu/emul_ppo_small.cpp, tests/test_kernel_emulation.py).  Test infrastructure only: nothing in the product includes this file.
+// Host emulation of the part of HIP that the kernels of apex_amd/csrc use, so that the kernel SOURCES can be compiled with the host clang++ and run on the CPU: the learner side
+// (learner.hip, ppo_small.hip, td3_small.hip: emul_learner.cpp, emul_ppo_small.cpp, emul_td3_small.cpp) and the env side (env.hip with cassie_lane.h, cassie_complete.h,
+// estimator_lane.h: emul_env.cpp; its inline-assembly dialect is restated in gfx950/lane_ops.h next to this directory).  Test infrastructure only: nothing in the product
+// includes this file.
 //
-// Execution model: a workgroup is a PROCESS (grid.x > 1: the launch forks grid.x - 1 children; every buffer the kernel touches must then live in MAP_SHARED memory,
-// atomics and fences on it work across processes, and `static` = __shared__ is per process = per workgroup).  Each wave is an OS thread
-// that runs its 64 lanes as ucontext fibers in round-robin order.  A wave collective (v_mfma_f32_16x16x4_f32, __shfl_*) deposits the lane's operands in one of two
-// per-wave buffers and yields; when the lane is resumed every lane of the wave has deposited (collectives sit in wave-uniform control flow, as the hardware requires),
-// and the lane computes its own part of the result - lane-exact operand / accumulator layout of the 16 x 16 x 4 MFMA.  __syncthreads is a pthread barrier between the
-// wave threads, entered by the wave's scheduler once all of its lanes have asked for it.  The grid barrier of the kernel is its own code (atomics on shared memory).
+// Execution model.  A wave = 64 fibers (a six-register switch; ucontext for the sanitizer builds) that run round-robin from collective to collective.
+//  * Workgroups of a PLAIN launch run one after the other in the calling process; single-wave workgroups with dynamic LDS (the env kernels) are dealt over host threads.  A
+//    COOPERATIVE launch (a kernel with a grid barrier) runs apx_emul_set_workgroups concurrent workgroups, one forked process each (buffers in MAP_SHARED memory; `static` =
+//    __shared__ is per process = per workgroup).  The waves of a multi-wave workgroup are OS threads; __syncthreads is a pthread barrier between them.
+//  * MFMA and __shfl deposit the lane's operands in one of two per-wave buffers and yield; resumed, every lane has deposited (these kernels keep their waves in step) and the
+//    lane computes its part: lane-exact operand / accumulator layouts.
+//  * The 32-bit lane exchanges of the env kernels (DPP operands, ds_bpermute, v_readlane, ballots, wsync) carry a sequence number and their call site: a lane reads its source
+//    lane's deposit of the SAME sequence number, waits for a lane that is late, reads zero from a lane that sits the branch out (parked at a reconvergence point) or has left,
+//    and aborts when the call sites differ.  hipemu::converge() = APX_CONVERGE(): reconvergence of rows that took different paths.
+//  * HIPEMU_LOCKSTEP_CHECK (build.sh lockstep): every load / store of the translation unit is traced; pairs of accesses of two lanes whose order the hardware fixes by
+//    executing in lockstep, with no rendezvous between them here, are reported (APX_LOCKSTEP() in the kernel source makes the rendezvous).
+//  * Knobs: HIPEMU_THREADS, HIPEMU_LDS_FILL / HIPEMU_STACK_FILL (what a workgroup finds in LDS / a lane in its "registers": results must not depend on it).
 #pragma once
 #include <dlfcn.h>
 #include <ucontext.h>
