@@ -4,7 +4,7 @@ outputs (golden G4b: an epoch of small-minibatch PPO steps on the 2 x 256 networ
 buffers, so the kernel's own grid barrier, its per-workgroup partial sums and the dealing of tiles over the grid run as written).  What this pins without a GPU: every
 index, tile map, guard, the loss arithmetic, the gradient layout, clip + Adam, the scalar bookkeeping and the barrier counting of the kernel.  What it cannot see:
 the cache coherence between XCDs behind the barrier's fences and the compiler's gfx950 code - those are the GPU test's
-(tests/test_gpu_learner.py::test_ppo_epoch_one_launch)."""
+(tests/test_gpu_zz_first_hardware_run.py::test_ppo_epoch_one_launch)."""
 import ctypes as C
 import mmap
 import os
