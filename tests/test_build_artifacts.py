@@ -213,3 +213,32 @@ def test_hazard_audit_flags_what_it_is_meant_to_find():
     hits = hazard_audit.audit(bad + "\n" + good)
     assert sorted(h[0] for h in hits) == ["dpp", "dppx", "lane", "trans"], hits
     assert all(h[1] == "kern" for h in hits)
+
+
+def test_instruction_mix_ceilings_of_the_hot_env_kernels():
+    """Ceilings on what the instruction diets of rounds 4 - 5 removed from the hot env kernels, so that a change cannot bring it back unnoticed (the kernels are VALU-issue bound:
+    a select or a move costs what an FMA costs).  Shipped object: env_rollout_kernel<false,0> 16 788 instructions with 1 133 v_cndmask, 1 321 v_mov_b32, 503 s_nop and no scratch
+    instruction; env_step_kernel<false> 15 275 / 1 135 / 1 205 / 442; the tree stage 2 565 with 642 packed (v_pk_*) instructions.  And a ceiling on the cold side's callee-saved
+    register traffic (354 scratch instructions in rollout_restart<true>, 254 in substep_complete<false>): it may shrink, not grow."""
+    import sys
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import isa_diff
+    if not os.path.exists(LIB):
+        pytest.skip("libapx.so not built")
+    F = isa_diff.functions(LIB)
+
+    def one(frag):
+        ks = [k for k in F if frag in k]
+        assert len(ks) == 1, (frag, ks)
+        return F[ks[0]]
+
+    def count(ins, pred):
+        return sum(1 for ln in ins if pred(ln.split()[0]))
+    for frag, total, sel, mov, nop in (("env_rollout_kernelILb0ELi0", 16900, 1140, 1330, 510), ("env_step_kernelILb0", 15400, 1142, 1215, 450)):
+        ins = one(frag)
+        got = (len(ins), count(ins, lambda o: o.startswith("v_cndmask")), count(ins, lambda o: o.startswith("v_mov_b32")), count(ins, lambda o: o == "s_nop"))
+        assert got[0] <= total and got[1] <= sel and got[2] <= mov and got[3] <= nop, (frag, got)
+        assert count(ins, lambda o: o.startswith("scratch_")) == 0
+    tree = one("stage1b_tree_lane")
+    assert len(tree) <= 2600 and count(tree, lambda o: o.startswith("v_pk_")) >= 600
+    assert count(one("rollout_restartILb1"), lambda o: o.startswith("scratch_")) <= 354 and count(one("substep_completeILb0"), lambda o: o.startswith("scratch_")) <= 254
